@@ -1,0 +1,485 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference).  Nothing from the reference
+is copied: the script imports its `models` package unmodified, feeds it seeded
+inputs, records every eps draw of MultiDGTS._sample_gauss (dgts.py:177-180), and
+stores inputs / state_dicts / eps / outputs / gradients as small .npz files.
+
+One harness-side shim is installed: the reference writes
+`1 - torch.isnan(x)` (dmm.py:165, dgts.py:45, losses.py:35 ...), which torch >= 1.2
+rejects for bool tensors; `Tensor.__rsub__` is patched so that `1 - bool_tensor`
+means logical not, i.e. the torch-1.1 semantics the reference was written for.
+
+While generating, every case is also run through oracle/mdmm_oracle.py with the
+recorded eps replayed and the script aborts if they disagree (first pin of the
+oracle; tests/test_oracle_golden.py is the committed, portable pin).
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import helpers  # noqa: E402
+from helpers import FeatEncoder, FlatGaussEnc, ShapedBernoulliDec, make_inputs, save_npz  # noqa: E402
+
+REF = '/root/reference'
+sys.path.insert(0, REF)
+
+_orig_rsub = torch.Tensor.__rsub__
+
+
+def _rsub(self, other):
+    if self.dtype is torch.bool and not torch.is_tensor(other) and other == 1:
+        return ~self
+    return _orig_rsub(self, other)
+
+
+torch.Tensor.__rsub__ = _rsub
+
+import models as ref_models  # noqa: E402  (the reference package)
+from datasets.multiseq import len_to_mask as ref_len_to_mask  # noqa: E402
+from datasets.multiseq import mask_to_extent as ref_mask_to_extent  # noqa: E402
+from models import losses as ref_losses  # noqa: E402
+from models.dgts import MultiDGTS  # noqa: E402
+
+from oracle import mdmm_oracle as orc  # noqa: E402
+
+CPU = torch.device('cpu')
+RECORD = []
+_orig_sample = MultiDGTS._sample_gauss
+
+
+def _recording_sample(self, mean, std):
+    eps = torch.FloatTensor(std.size()).normal_()
+    RECORD.append(eps.clone())
+    return eps.mul(std).add_(mean)
+
+
+MultiDGTS._sample_gauss = _recording_sample
+
+
+def grads_of(model):
+    return {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p))
+            for k, p in model.named_parameters()}
+
+
+def check(tag, a, b, tol=2e-5):
+    err = helpers.rel_err(a, b)
+    assert err < tol, 'oracle/reference mismatch in %s: %.3e' % (tag, err)
+    return err
+
+
+# ---------------------------------------------------------------------------- G1 --
+def g1_primitives():
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    base = MultiDGTS()
+    # anchors
+    anchors = {
+        'poe_plain': (torch.tensor([[[0.]], [[2.]]]), torch.tensor([[[1.]], [[1.]]]), None),
+        'poe_inverse': (torch.tensor([[[0.]], [[2.]], [[0.]]]),
+                        torch.tensor([[[1.]], [[.5]], [[-1.]]]), None),
+        'poe_masked': (torch.tensor([[[0.]], [[2.]]]), torch.tensor([[[1.]], [[1.]]]),
+                       torch.tensor([[1], [0]], dtype=torch.uint8)),
+    }
+    for k, (m, s, w) in anchors.items():
+        rm, rs = base.product_of_experts(m, s, w)
+        om, os_ = orc.poe(m, s, w)
+        check(k, om, rm); check(k, os_, rs)
+        out[k] = {'mean': m, 'std': s, 'out_mean': rm, 'out_std': rs}
+        if w is not None:
+            out[k]['mask'] = w
+    # random 3-D masked with an inverse expert, and 4-D
+    for k, shape in (('poe_3d', (4, 7, 5)), ('poe_4d', (3, 6, 4, 5))):
+        m = torch.randn(shape, generator=g)
+        s = torch.rand(shape, generator=g) + 0.1
+        s[-1] = -(s[-1] + 2.0)                      # inverse expert, weaker than the rest
+        w = (torch.rand(shape[:-1], generator=g) < 0.7)
+        w[0] = True
+        m.requires_grad_(True); s.requires_grad_(True)
+        rm, rs = base.product_of_experts(m, s, w.to(torch.uint8))
+        coef_m = torch.randn(rm.shape, generator=g); coef_s = torch.randn(rs.shape, generator=g)
+        ((rm * coef_m).sum() + (rs * coef_s).sum()).backward()
+        om, os_ = orc.poe(m.detach(), s.detach(), w)
+        check(k, om, rm); check(k, os_, rs)
+        out[k] = {'mean': m, 'std': s, 'mask': w, 'out_mean': rm, 'out_std': rs,
+                  'coef_mean': coef_m, 'coef_std': coef_s,
+                  'g_mean': m.grad, 'g_std': s.grad}
+    # all-masked column -> 0/0 -> mean 0, std inf
+    m = torch.randn(2, 3, 4, generator=g); s = torch.rand(2, 3, 4, generator=g) + 0.1
+    w = torch.tensor([[1, 0, 1], [1, 0, 0]], dtype=torch.uint8)
+    rm, rs = base.product_of_experts(m, s, w)
+    out['poe_allmasked'] = {'mean': m, 'std': s, 'mask': w, 'out_mean': rm, 'out_std': rs}
+    # mean of experts
+    m = torch.randn(25, 4, 5, generator=g, requires_grad=True)
+    s = (torch.rand(25, 4, 5, generator=g) + 0.1).requires_grad_(True)
+    rm, rs = base.mean_of_experts(m, s)
+    cm = torch.randn(rm.shape, generator=g); cs = torch.randn(rs.shape, generator=g)
+    ((rm * cm).sum() + (rs * cs).sum()).backward()
+    om, os_ = orc.moment_match(m.detach(), s.detach())
+    check('moe', om, rm); check('moe', os_, rs)
+    out['moe'] = {'mean': m, 'std': s, 'out_mean': rm, 'out_std': rs, 'coef_mean': cm,
+                  'coef_std': cs, 'g_mean': m.grad, 'g_std': s.grad}
+    a = base.mean_of_experts(torch.tensor([[[0.]], [[2.]]]), torch.tensor([[[1.]], [[1.]]]))
+    out['moe_anchor'] = {'out_mean': a[0], 'out_std': a[1]}
+    # GTF forward + grads
+    for k, (zd, hd) in (('gtf_z5', (5, 20)), ('gtf_z32', (32, 32))):
+        torch.manual_seed(3)
+        gtf = ref_models.common.GaussianGTF(zd, hd, min_std=1e-3)
+        z = torch.randn(9, zd, generator=g, requires_grad=True)
+        mu, sd = gtf(z)
+        cm = torch.randn(mu.shape, generator=g); cs = torch.randn(sd.shape, generator=g)
+        ((mu * cm).sum() + (sd * cs).sum()).backward()
+        ogtf = orc.GaussianGTF(zd, hd, min_std=1e-3)
+        ogtf.load_state_dict(gtf.state_dict())
+        omu, osd = ogtf(z.detach())
+        check(k, omu, mu); check(k, osd, sd)
+        out[k] = {'sd': gtf.state_dict(), 'z': z, 'mean': mu, 'std': sd, 'coef_mean': cm,
+                  'coef_std': cs, 'g_z': z.grad, 'g_params': grads_of(gtf)}
+    # losses
+    T, B, D = 6, 3, 5
+    mask = ref_len_to_mask([6, 5, 3])
+    m1 = torch.randn(T, B, D, generator=g, requires_grad=True)
+    s1 = (torch.rand(T, B, D, generator=g) + 0.2).requires_grad_(True)
+    m2 = torch.randn(T, B, D, generator=g, requires_grad=True)
+    s2 = (torch.rand(T, B, D, generator=g) + 0.2).requires_grad_(True)
+    kl = ref_losses.kld_gauss(m1, s1, m2, s2, mask)
+    kl.backward()
+    check('kld', orc.kld_gauss(m1.detach(), s1.detach(), m2.detach(), s2.detach(), mask), kl)
+    out['kld'] = {'m1': m1, 's1': s1, 'm2': m2, 's2': s2, 'mask': mask, 'out': kl,
+                  'g_m1': m1.grad, 'g_s1': s1.grad, 'g_m2': m2.grad, 'g_s2': s2.grad}
+    out['kld_anchor'] = {'out': ref_losses.kld_gauss(torch.zeros(1, 1, 2), torch.ones(1, 1, 2),
+                                                     torch.ones(1, 1, 2), 2 * torch.ones(1, 1, 2))}
+    x = torch.randn(T, B, 4, generator=g)
+    x[4:, 1] = float('nan'); x[2, 0, 1] = float('nan')
+    mu = torch.randn(T, B, 4, generator=g, requires_grad=True)
+    sd = (torch.rand(T, B, 4, generator=g) + 0.2).requires_grad_(True)
+    nl = ref_losses.nll_gauss(mu, sd, x, mask)
+    nl.backward()
+    check('nll_gauss', orc.nll_gauss(mu.detach(), sd.detach(), x, mask), nl)
+    out['nll_gauss'] = {'mean': mu, 'std': sd, 'x': x, 'mask': mask, 'out': nl,
+                        'g_mean': mu.grad, 'g_std': sd.grad}
+    xb = (torch.rand(T, B, 2, 3, generator=g) < 0.5).float()
+    xb[5, 0] = float('nan')
+    th = torch.rand(T, B, 2, 3, generator=g) * 0.98 + 0.01
+    th[0, 0, 0, 0] = 0.0; th[0, 0, 0, 1] = 1.0          # exercises the -100 log clamp
+    th.requires_grad_(True)
+    nb = ref_losses.nll_bernoulli(th, xb, mask)
+    nb.backward()
+    check('nll_bern', orc.nll_bernoulli(th.detach(), xb, mask), nb)
+    out['nll_bernoulli'] = {'theta': th, 'x': xb, 'mask': mask, 'out': nb, 'g_theta': th.grad}
+    xc = torch.randint(0, 4, (T, B, 1), generator=g).float()
+    xc[3, 2] = float('nan')
+    pr = torch.softmax(torch.randn(T, B, 4, generator=g), dim=-1).requires_grad_(True)
+    nc = ref_losses.nll_categorical(pr, xc, mask)
+    nc.backward()
+    check('nll_cat', orc.nll_categorical(pr.detach(), xc, mask), nc)
+    out['nll_categorical'] = {'probs': pr, 'x': xc, 'mask': mask, 'out': nc, 'g_probs': pr.grad}
+    out['nll_cat_anchor'] = {'out': ref_losses.nll_categorical(
+        torch.tensor([[[.7, .2, .1]]]), torch.tensor([[[0.]]]))}
+    # mask helpers
+    mk = torch.tensor([[1, 0, 0, 1], [1, 0, 1, 0], [0, 0, 1, 1], [1, 0, 0, 0]])
+    ts, te = ref_mask_to_extent(mk)
+    os_, oe = orc.mask_to_extent(mk)
+    assert torch.equal(ts, os_) and torch.equal(te, oe)
+    out['extent'] = {'mask': mk, 't_start': ts, 't_stop': te}
+    save_npz(os.path.join(HERE, 'g1_primitives.npz'), out)
+
+
+# ---------------------------------------------------------------------------- DMM --
+SPEC_AB = [('a', 1, 'Normal'), ('b', 1, 'Normal')]
+SPEC_MIX = [('g', 3, 'Normal'), ('c', 4, 'Categorical'), ('v', (2, 3), 'Bernoulli')]
+
+
+def build_dmm(spec, z_dim, h_dim, seed=0):
+    torch.manual_seed(seed)
+    names = [s[0] for s in spec]
+    dims = [s[1] for s in spec]
+    dists = [s[2] for s in spec]
+    kw = dict(dists=dists, h_dim=h_dim, z_dim=z_dim, device=CPU)
+    okw = dict(dists=dists, h_dim=h_dim, z_dim=z_dim)
+    if any(d == 'Bernoulli' for d in dists):
+        # stand-in MLP enc/dec for Bernoulli modalities (flattened input)
+        encs, decs = {}, {}
+        for n, d, dist in spec:
+            if dist == 'Bernoulli':
+                nd = int(np.prod(d))
+                encs[n] = FlatGaussEnc(nd, z_dim, h_dim)
+                decs[n] = ShapedBernoulliDec(z_dim, d, h_dim)
+        ref = ref_models.MultiDMM(names, dims, encoders=encs, decoders=decs, **kw)
+        import copy
+        o = orc.OracleDMM(names, dims, encoders=copy.deepcopy(encs),
+                          decoders=copy.deepcopy(decs), **okw)
+    else:
+        ref = ref_models.MultiDMM(names, dims, **kw)
+        o = orc.OracleDMM(names, dims, **okw)
+    o.load_state_dict(ref.state_dict())
+    return ref, o
+
+
+def g2_zfilter():
+    out = {}
+    lengths = [6, 5, 3]
+    ref, o = build_dmm(SPEC_AB, 5, 20)
+    x = make_inputs(SPEC_AB, 6, lengths, seed=1, nan_spans=[('a', 1, 3, 0)])
+    out['sd'] = ref.state_dict()
+    out['x'] = x
+    out['lengths'] = np.array(lengths)
+    with torch.no_grad():
+        e_mean, e_std, e_mask = ref.encode(x)
+    out['e_mean'], out['e_std'], out['e_mask'] = e_mean, e_std, e_mask
+    n = 0
+    for direction in ('fwd', 'bwd'):
+        for K in (1, 25):
+            for sample in (False, True):
+                for sample_init in (False, True):
+                    if K > 1 and (not sample or sample_init):
+                        continue
+                    RECORD.clear()
+                    torch.manual_seed(100 + n)
+                    with torch.no_grad():
+                        infer, prior, zs = ref.z_filter(e_mean, e_std, e_mask, direction,
+                                                        sample, K, sample_init)
+                    eps = list(RECORD)
+                    o.noise = orc.ReplayNoise(eps)
+                    with torch.no_grad():
+                        oi, op, oz = o.z_filter(e_mean, e_std, e_mask.bool(), direction,
+                                                sample, K, sample_init)
+                    for a, b in ((oi[0], infer[0]), (oi[1], infer[1]), (op[0], prior[0]),
+                                 (op[1], prior[1]), (oz, zs)):
+                        check('z_filter', a, b)
+                    out['case%02d' % n] = {
+                        'direction': np.array(direction == 'bwd'), 'K': np.array(K),
+                        'sample': np.array(sample), 'sample_init': np.array(sample_init),
+                        'eps': eps, 'infer_mean': infer[0], 'infer_std': infer[1],
+                        'prior_mean': prior[0], 'prior_std': prior[1], 'samples': zs}
+                    n += 1
+    save_npz(os.path.join(HERE, 'g2_zfilter.npz'), out)
+
+
+def g3_forward():
+    out = {}
+    lengths = [7, 6, 6, 4]
+    rec_mults = {'g': 1.0, 'c': 10.0, 'v': 0.5}
+    ref, o = build_dmm(SPEC_MIX, 6, 12)
+    ref.eval(); o.eval()
+    x = make_inputs(SPEC_MIX, 7, lengths, seed=2,
+                    nan_spans=[('g', 1, 3, 0), ('c', 2, 5, 1), ('v', 0, 2, 2), ('g', 3, 4, 2),
+                               ('c', 3, 4, 2), ('v', 3, 4, 2)])
+    mask = ref_len_to_mask(lengths)
+    out['sd'] = ref.state_dict()
+    out['x'] = x
+    out['lengths'] = np.array(lengths)
+    out['rec_mults'] = {k: np.array(v) for k, v in rec_mults.items()}
+    n = 0
+    subsets = [['g', 'c', 'v'], ['g'], ['c'], ['v'], ['g', 'v']]
+    for mode in ('fsmooth', 'bsmooth', 'ffilter', 'bfilter'):
+        for sub in subsets:
+            for sample, kf in ((False, 1), (True, 1), (True, 7)):
+                if sub not in (subsets[0], subsets[1]) and sample:
+                    continue
+                if mode == 'bsmooth' and sample:
+                    # the reference itself goes non-finite here: ragged batch -> the first
+                    # processed step (t = T-1) has flt masked and the global prior cancelled
+                    # by its inverse expert -> std = inf -> sampled z = +-inf
+                    continue
+                xin = {m: x[m] for m in sub}
+                RECORD.clear()
+                torch.manual_seed(200 + n)
+                kw = dict(lengths=lengths, mode=mode, sample=sample, flt_particles=kf)
+                with torch.no_grad():
+                    infer, prior, recon = ref(xin, **kw)
+                    kld = ref.kld_loss(infer, prior, mask)
+                    rec = ref.rec_loss(x, recon, mask, rec_mults)
+                eps = list(RECORD)
+                o.noise = orc.ReplayNoise(eps)
+                with torch.no_grad():
+                    oi, op, orec = o(xin, **kw)
+                    check('fwd kld', o.kld_loss(oi, op, mask), kld)
+                    check('fwd rec', o.rec_loss(x, orec, mask, rec_mults), rec)
+                out['case%02d' % n] = {
+                    'mode': np.array(['fsmooth', 'bsmooth', 'ffilter', 'bfilter'].index(mode)),
+                    'subset': np.array([['g', 'c', 'v'].index(m) for m in sub]),
+                    'sample': np.array(sample), 'flt_particles': np.array(kf), 'eps': eps,
+                    'infer_mean': infer[0], 'infer_std': infer[1], 'prior_mean': prior[0],
+                    'prior_std': prior[1], 'kld': kld, 'rec': rec,
+                    'recon': {m: list(recon[m]) for m in recon}}
+                n += 1
+    save_npz(os.path.join(HERE, 'g3_forward.npz'), out)
+
+
+def g4_step():
+    out = {}
+    cases = [
+        ('z5', SPEC_AB, 5, 20, [6, 5, 3], [('a', 1, 3, 0)], {'a': .5, 'b': .5}, {}, 1.0),
+        ('z5_args', SPEC_AB, 5, 20, [6, 5, 3], [('a', 1, 3, 0)], {'a': .5, 'b': .5},
+         dict(f_mode='ffilter', s_mode='fsmooth', f_mult=0.3, s_mult=0.7, match_mult=0.05,
+              train_particles=4, match_particles=8), 0.37),
+        # bsmooth only stays finite when every sequence is observed at t = T-1 (see g3)
+        ('z5_bsmooth', SPEC_AB, 5, 20, [6, 6, 6], [('a', 1, 3, 0)], {'a': .5, 'b': .5},
+         dict(f_mode='bfilter', s_mode='bsmooth', train_particles=3, uni_loss=False), 1.0),
+        ('z5_nouni', SPEC_AB, 5, 20, [6, 5, 3], [('a', 1, 3, 0)], {'a': .5, 'b': .5},
+         dict(uni_loss=False), 1.0),
+        ('z32', SPEC_AB, 32, 32, [12, 12, 9, 7, 2], [('a', 2, 6, 1), ('b', 0, 3, 2)],
+         {'a': .5, 'b': .5}, {}, 0.5),
+        ('mix', SPEC_MIX, 6, 12, [7, 6, 6, 4], [('g', 1, 3, 0), ('c', 2, 5, 1), ('v', 0, 2, 2)],
+         {'g': 1.0, 'c': 10.0, 'v': 0.5}, dict(train_particles=5), 1.0),
+    ]
+    for name, spec, zd, hd, lengths, spans, rec_mults, kw, kld_mult in cases:
+        ref, o = build_dmm(spec, zd, hd)
+        targets = make_inputs(spec, max(lengths), lengths, seed=4)
+        inputs = {k: v.clone() for k, v in targets.items()}
+        for nm, t0, t1, b in spans:
+            inputs[nm][t0:t1, b] = float('nan')
+        mask = ref_len_to_mask(lengths)
+        RECORD.clear()
+        torch.manual_seed(123)
+        loss = ref.step(inputs, mask, kld_mult, rec_mults, targets=targets, lengths=lengths, **kw)
+        ref.zero_grad()
+        (loss / sum(lengths)).backward()
+        eps = list(RECORD)
+        o.noise = orc.ReplayNoise(eps)
+        oloss = o.step(inputs, mask, kld_mult, rec_mults, targets=targets, lengths=lengths, **kw)
+        (oloss / sum(lengths)).backward()
+        check('step loss ' + name, oloss, loss, 1e-5)
+        rg, og = grads_of(ref), grads_of(o)
+        for k in rg:
+            assert helpers.rel_err(og[k], rg[k]) < 1e-3 or float(rg[k].abs().max()) < 1e-6, k
+        if name == 'z5':
+            # anchor from SURVEY 8c (same seeds): 104.659653
+            print('  z5 step loss', float(loss))
+        out[name] = {'sd': ref.state_dict(), 'inputs': inputs, 'targets': targets,
+                     'lengths': np.array(lengths), 'kld_mult': np.array(kld_mult),
+                     'rec_mults': {k: np.array(v) for k, v in rec_mults.items()},
+                     'kw': {k: np.array(v) if not isinstance(v, str) else np.array(
+                         ['fsmooth', 'bsmooth', 'ffilter', 'bfilter'].index(v))
+                         for k, v in kw.items()},
+                     'z_dim': np.array(zd), 'h_dim': np.array(hd),
+                     'eps': eps, 'loss': loss, 'grads': rg}
+    save_npz(os.path.join(HERE, 'g4_step.npz'), out)
+
+
+# ---------------------------------------------------------------------------- DKS --
+def g5_dks():
+    out = {}
+    spec = [('a', 2, 'Normal'), ('c', 3, 'Categorical'), ('b', 4, 'Normal')]
+    names = [s[0] for s in spec]; dims = [s[1] for s in spec]; dists = [s[2] for s in spec]
+    lengths = [7, 6, 4, 4]
+    rec_mults = {'a': 1.0, 'c': 5.0, 'b': 0.5}
+    n = 0
+    for method, (rnn_dir, rnn_skip) in (('b-skip', ('bwd', True)), ('f-skip', ('fwd', True)),
+                                        ('b-mask', ('bwd', False)), ('f-mask', ('fwd', False))):
+        for feat_to_z in (True, False):
+            for layers in (1, 2):
+                if layers == 2 and method not in ('b-skip', 'f-mask'):
+                    continue
+                custom = (n % 3 == 0)
+                torch.manual_seed(5)
+                encs = {'b': FeatEncoder(4, 9)} if custom else None
+                import copy
+                kw = dict(dists=dists, h_dim=10, z_dim=6, feat_to_z=feat_to_z,
+                          rnn_dir=rnn_dir, rnn_skip=rnn_skip, rnn_layers=layers)
+                ref = ref_models.MultiDKS(names, dims, encoders=copy.deepcopy(encs),
+                                          device=CPU, **kw)
+                o = orc.OracleDKS(names, dims, encoders=copy.deepcopy(encs), **kw)
+                o.load_state_dict(ref.state_dict())
+                targets = make_inputs(spec, 7, lengths, seed=6 + n)
+                inputs = {k: v.clone() for k, v in targets.items()}
+                inputs['a'][2:4, 0] = float('nan')
+                inputs['c'][1:3, 1] = float('nan')
+                inputs['b'][3:, 2] = float('nan')       # modality b missing from t=3 on
+                mask = ref_len_to_mask(lengths)
+                case = {'rnn_bwd': np.array(rnn_dir == 'bwd'), 'rnn_skip': np.array(rnn_skip),
+                        'feat_to_z': np.array(feat_to_z), 'rnn_layers': np.array(layers),
+                        'custom_enc': np.array(custom), 'sd': ref.state_dict(),
+                        'inputs': inputs, 'targets': targets, 'lengths': np.array(lengths),
+                        'rec_mults': {k: np.array(v) for k, v in rec_mults.items()}}
+                # forward: multimodal sampled, unimodal (t_stop = 0), MAP
+                for tag, sub, sample in (('all', names, True), ('only_a', ['a'], True),
+                                         ('map', names, False)):
+                    RECORD.clear()
+                    torch.manual_seed(300 + n)
+                    xin = {m: inputs[m] for m in sub}
+                    with torch.no_grad():
+                        infer, prior, recon = ref(xin, lengths=lengths, sample=sample)
+                    eps = list(RECORD)
+                    o.noise = orc.ReplayNoise(eps)
+                    with torch.no_grad():
+                        oi, op, orec = o(xin, lengths=lengths, sample=sample)
+                    check('dks fwd', oi[0], infer[0]); check('dks fwd', oi[1], infer[1])
+                    check('dks fwd', op[0], prior[0]); check('dks fwd', op[1], prior[1])
+                    case['fwd_' + tag] = {
+                        'eps': eps, 'infer_mean': infer[0], 'infer_std': infer[1],
+                        'prior_mean': prior[0], 'prior_std': prior[1],
+                        'recon': {m: list(recon[m]) for m in recon}}
+                # step + grads
+                for tag, uni in (('step_uni', True), ('step_nouni', False)):
+                    RECORD.clear()
+                    torch.manual_seed(400 + n)
+                    ref.zero_grad()
+                    loss = ref.step(inputs, mask, 0.8, rec_mults, targets=targets,
+                                    uni_loss=uni, lengths=lengths)
+                    (loss / sum(lengths)).backward()
+                    eps = list(RECORD)
+                    o.noise = orc.ReplayNoise(eps)
+                    o.zero_grad()
+                    ol = o.step(inputs, mask, 0.8, rec_mults, targets=targets, uni_loss=uni,
+                                lengths=lengths)
+                    (ol / sum(lengths)).backward()
+                    check('dks step', ol, loss, 1e-5)
+                    case[tag] = {'eps': eps, 'loss': loss, 'kld_mult': np.array(0.8),
+                                 'grads': grads_of(ref)}
+                out['case%02d' % n] = case
+                n += 1
+    save_npz(os.path.join(HERE, 'g5_dks.npz'), out)
+
+
+# ------------------------------------------------------------------------ state dict --
+def g7_state_dicts():
+    out = {}
+    C = ref_models.common
+
+    def shapes(model):
+        return {k: np.array(v.shape) for k, v in model.state_dict().items()}
+
+    torch.manual_seed(0)
+    out['spirals_dmm'] = shapes(ref_models.MultiDMM(['spiral-x', 'spiral-y'], [1, 1],
+                                                    h_dim=20, z_dim=5, device=CPU))
+    out['spirals_dks'] = shapes(ref_models.MultiDKS(['spiral-x', 'spiral-y'], [1, 1],
+                                                    h_dim=20, z_dim=5, device=CPU))
+    mods = ['video', 'mask', 'action']
+    dims = [(3, 64, 64), (1, 64, 64), 10]
+    dists = ['Bernoulli', 'Bernoulli', 'Categorical']
+    out['weizmann_dmm'] = shapes(ref_models.MultiDMM(
+        mods, dims, dists, encoders={'video': C.ImageEncoder(256, n_channels=3),
+                                     'mask': C.ImageEncoder(256, n_channels=1)},
+        decoders={'video': C.ImageDecoder(256, n_channels=3),
+                  'mask': C.ImageDecoder(256, n_channels=1)},
+        h_dim=256, z_dim=256, device=CPU))
+    out['weizmann_dks'] = shapes(ref_models.MultiDKS(
+        mods, dims, dists, encoders={'video': C.ImageEncoder(256, gauss_out=False, n_channels=3),
+                                     'mask': C.ImageEncoder(256, gauss_out=False, n_channels=1)},
+        decoders={'video': C.ImageDecoder(256, n_channels=3),
+                  'mask': C.ImageDecoder(256, n_channels=1)},
+        h_dim=256, z_dim=256, device=CPU))
+    out['vidtimit_dmm'] = shapes(ref_models.MultiDMM(
+        ['video', 'audio'], [(3, 64, 64), (10, 1281)], ['Bernoulli', 'Bernoulli'],
+        encoders={'video': C.ImageEncoder(256), 'audio': C.AudioEncoder(256)},
+        decoders={'video': C.ImageDecoder(256), 'audio': C.AudioDecoder(256)},
+        h_dim=256, z_dim=256, device=CPU))
+    save_npz(os.path.join(HERE, 'g7_state_dicts.npz'), out)
+
+
+if __name__ == '__main__':
+    for fn in (g1_primitives, g2_zfilter, g3_forward, g4_step, g5_dks, g7_state_dicts):
+        print(fn.__name__)
+        fn()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print('%-24s %8.1f KB' % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

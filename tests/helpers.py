@@ -1,0 +1,162 @@
+"""Shared helpers for the test-suite (and for tests/golden/make_golden.py).
+
+Nothing in here is product code: it builds seeded inputs, flattens / restores nested
+tensors for the .npz fixtures and defines the tiny stand-in plug-in modules the
+fixtures were recorded with.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(REPO, 'multimodal-dmm_amd')
+GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
+for p in (REPO, PKG_DIR):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+class BernoulliMLP(nn.Module):
+    """Stand-in Bernoulli decoder (the reference only ships conv ones): returns (probs,)."""
+
+    def __init__(self, z_dim, out_dim, h_dim):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(z_dim, h_dim), nn.ReLU(),
+                                 nn.Linear(h_dim, out_dim), nn.Sigmoid())
+
+    def forward(self, z):
+        return (self.net(z),)
+
+
+class FlatGaussEnc(nn.Module):
+    """Stand-in Gaussian encoder for image-like (flattened) Bernoulli inputs: (mean, std)."""
+
+    def __init__(self, in_dim, z_dim, h_dim):
+        super().__init__()
+        self.trunk = nn.Sequential(nn.Linear(in_dim, h_dim), nn.ReLU())
+        self.to_mean = nn.Linear(h_dim, z_dim)
+        self.to_std = nn.Sequential(nn.Linear(h_dim, z_dim), nn.Softplus())
+
+    def forward(self, x):
+        h = self.trunk(x.flatten(1))
+        return self.to_mean(h), self.to_std(h) + 1e-3
+
+
+class ShapedBernoulliDec(nn.Module):
+    """Stand-in Bernoulli decoder reshaping to the modality's dims: returns (probs,)."""
+
+    def __init__(self, z_dim, dims, h_dim):
+        super().__init__()
+        self.dims = tuple(dims)
+        self.mlp = BernoulliMLP(z_dim, int(np.prod(dims)), h_dim)
+
+    def forward(self, z):
+        return (self.mlp(z)[0].reshape(-1, *self.dims),)
+
+
+class FeatEncoder(nn.Module):
+    """Stand-in DKS feature encoder with a custom feat_dim (read at dks.py:102-106)."""
+
+    def __init__(self, in_dim, feat_dim):
+        super().__init__()
+        self.feat_dim = feat_dim
+        self.net = nn.Sequential(nn.Linear(in_dim, feat_dim), nn.Tanh())
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def make_inputs(spec, t_max, lengths, seed=1, nan_spans=()):
+    """Seeded ragged NaN-padded (T,B,*dims) inputs.
+
+    spec: list of (name, dims, dist).  nan_spans: list of (name, t0, t1, b) set to NaN.
+    """
+    g = torch.Generator().manual_seed(seed)
+    b_dim = len(lengths)
+    out = {}
+    for name, dims, dist in spec:
+        shape = (t_max, b_dim) + (tuple(dims) if isinstance(dims, (tuple, list)) else (dims,))
+        if dist == 'Normal':
+            x = torch.randn(shape, generator=g)
+        elif dist == 'Bernoulli':
+            x = (torch.rand(shape, generator=g) < 0.5).float()
+        else:  # Categorical: one label column
+            n = int(np.prod(dims))
+            x = torch.randint(0, n, (t_max, b_dim, 1), generator=g).float()
+        for b, l in enumerate(lengths):
+            x[l:, b] = float('nan')
+        out[name] = x
+    for name, t0, t1, b in nan_spans:
+        out[name][t0:t1, b] = float('nan')
+    return out
+
+
+def save_npz(path, tree):
+    flat = {}
+
+    def rec(prefix, v):
+        if isinstance(v, dict):
+            for k, x in v.items():
+                rec(prefix + '/' + str(k) if prefix else str(k), x)
+        elif isinstance(v, (list, tuple)):
+            flat[prefix + '/#len'] = np.array(len(v))
+            for i, x in enumerate(v):
+                rec(prefix + '/' + str(i), x)
+        elif torch.is_tensor(v):
+            flat[prefix] = v.detach().cpu().numpy()
+        else:
+            flat[prefix] = np.asarray(v)
+    rec('', tree)
+    np.savez_compressed(path, **flat)
+
+
+class Golden:
+    """Read-side view of one fixture file."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
+        self.keys = list(self.z.keys())
+
+    def has(self, key):
+        return key in self.z
+
+    def t(self, key):
+        a = self.z[key]
+        return torch.from_numpy(np.array(a))
+
+    def scalar(self, key):
+        return self.z[key].item()
+
+    def sub(self, prefix):
+        """dict of tensors under prefix/ (one level of the remaining path kept as key)."""
+        pre = prefix + '/'
+        return {k[len(pre):]: self.t(k) for k in self.keys
+                if k.startswith(pre) and not k.endswith('#len')}
+
+    def seq(self, prefix):
+        n = int(self.z[prefix + '/#len'])
+        return [self.t('%s/%d' % (prefix, i)) for i in range(n)]
+
+    def cases(self):
+        return sorted({k.split('/')[0] for k in self.keys})
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b| over the finite entries; inf when the non-finite patterns
+    (positions of +-inf / NaN, which are legal outputs of the path) differ."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    fa, fb = torch.isfinite(a), torch.isfinite(b)
+    if not torch.equal(fa, fb):
+        return float('inf')
+    if not bool(fb.all()):
+        na, nb = a[~fa], b[~fb]
+        same = (torch.isnan(na) & torch.isnan(nb)) | (na == nb)
+        if not bool(same.all()):
+            return float('inf')
+        a, b = a[fa], b[fb]
+    if a.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))

@@ -1,0 +1,262 @@
+"""Pins oracle/mdmm_oracle.py against the golden vectors recorded from the reference
+(tests/golden/make_golden.py).  CPU only; runs anywhere."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import (FeatEncoder, FlatGaussEnc, Golden, ShapedBernoulliDec, rel_err)
+from oracle import mdmm_oracle as orc
+
+MODES = ['fsmooth', 'bsmooth', 'ffilter', 'bfilter']
+TOL = 2e-5
+
+
+def close(a, b, tol=TOL):
+    assert rel_err(a, b) < tol, rel_err(a, b)
+
+
+# --------------------------------------------------------------------------- G1 --
+def test_anchor_known_answers():
+    """SURVEY 8c anchors, obtained from the reference."""
+    g = Golden('g1_primitives.npz')
+    assert g.t('poe_plain/out_mean').item() == pytest.approx(1.0)
+    assert g.t('poe_plain/out_std').item() == pytest.approx(0.70710677)
+    assert g.t('poe_inverse/out_mean').item() == pytest.approx(2.0, abs=1e-6)
+    assert g.t('poe_inverse/out_std').item() == pytest.approx(0.5, abs=1e-6)
+    assert g.t('poe_masked/out_mean').item() == pytest.approx(0.0)
+    assert g.t('poe_masked/out_std').item() == pytest.approx(1.0)
+    assert g.t('moe_anchor/out_std').item() == pytest.approx(1.41421354)
+    assert g.t('kld_anchor/out').item() == pytest.approx(0.88629436)
+    assert g.t('nll_cat_anchor/out').item() == pytest.approx(-0.7)
+
+
+@pytest.mark.parametrize('case', ['poe_plain', 'poe_inverse', 'poe_masked', 'poe_3d', 'poe_4d',
+                                  'poe_allmasked'])
+def test_poe(case):
+    g = Golden('g1_primitives.npz')
+    mask = g.t(case + '/mask').bool() if g.has(case + '/mask') else None
+    m = g.t(case + '/mean').requires_grad_(True)
+    s = g.t(case + '/std').requires_grad_(True)
+    om, os_ = orc.poe(m, s, mask)
+    ref_m, ref_s = g.t(case + '/out_mean'), g.t(case + '/out_std')
+    fin = torch.isfinite(ref_s)
+    assert torch.equal(torch.isfinite(os_), fin)
+    close(om[fin], ref_m[fin]); close(os_[fin], ref_s[fin])
+    if g.has(case + '/g_mean'):
+        ((om * g.t(case + '/coef_mean')).sum() + (os_ * g.t(case + '/coef_std')).sum()).backward()
+        close(m.grad, g.t(case + '/g_mean')); close(s.grad, g.t(case + '/g_std'))
+
+
+def test_moment_match():
+    g = Golden('g1_primitives.npz')
+    m = g.t('moe/mean').requires_grad_(True)
+    s = g.t('moe/std').requires_grad_(True)
+    om, os_ = orc.moment_match(m, s)
+    close(om, g.t('moe/out_mean')); close(os_, g.t('moe/out_std'))
+    ((om * g.t('moe/coef_mean')).sum() + (os_ * g.t('moe/coef_std')).sum()).backward()
+    close(m.grad, g.t('moe/g_mean')); close(s.grad, g.t('moe/g_std'))
+
+
+@pytest.mark.parametrize('case,zd,hd', [('gtf_z5', 5, 20), ('gtf_z32', 32, 32)])
+def test_gtf(case, zd, hd):
+    g = Golden('g1_primitives.npz')
+    gtf = orc.GaussianGTF(zd, hd, min_std=1e-3)
+    gtf.load_state_dict(g.sub(case + '/sd'))
+    z = g.t(case + '/z').requires_grad_(True)
+    mu, sd = gtf(z)
+    close(mu, g.t(case + '/mean')); close(sd, g.t(case + '/std'))
+    ((mu * g.t(case + '/coef_mean')).sum() + (sd * g.t(case + '/coef_std')).sum()).backward()
+    close(z.grad, g.t(case + '/g_z'))
+    for k, p in gtf.named_parameters():
+        close(p.grad, g.t(case + '/g_params/' + k))
+
+
+def test_losses():
+    g = Golden('g1_primitives.npz')
+    t = {k: g.t('kld/' + k) for k in ('m1', 's1', 'm2', 's2', 'mask')}
+    for k in ('m1', 's1', 'm2', 's2'):
+        t[k].requires_grad_(True)
+    out = orc.kld_gauss(t['m1'], t['s1'], t['m2'], t['s2'], t['mask'])
+    close(out, g.t('kld/out'))
+    out.backward()
+    for k in ('m1', 's1', 'm2', 's2'):
+        close(t[k].grad, g.t('kld/g_' + k))
+    mu = g.t('nll_gauss/mean').requires_grad_(True)
+    sd = g.t('nll_gauss/std').requires_grad_(True)
+    out = orc.nll_gauss(mu, sd, g.t('nll_gauss/x'), g.t('nll_gauss/mask'))
+    close(out, g.t('nll_gauss/out'))
+    out.backward()
+    close(mu.grad, g.t('nll_gauss/g_mean')); close(sd.grad, g.t('nll_gauss/g_std'))
+    th = g.t('nll_bernoulli/theta').requires_grad_(True)
+    out = orc.nll_bernoulli(th, g.t('nll_bernoulli/x'), g.t('nll_bernoulli/mask'))
+    close(out, g.t('nll_bernoulli/out'))
+    out.backward()
+    close(th.grad, g.t('nll_bernoulli/g_theta'))
+    pr = g.t('nll_categorical/probs').requires_grad_(True)
+    out = orc.nll_categorical(pr, g.t('nll_categorical/x'), g.t('nll_categorical/mask'))
+    close(out, g.t('nll_categorical/out'))
+    out.backward()
+    close(pr.grad, g.t('nll_categorical/g_probs'))
+
+
+def test_mask_helpers():
+    g = Golden('g1_primitives.npz')
+    ts, te = orc.mask_to_extent(g.t('extent/mask'))
+    assert torch.equal(ts, g.t('extent/t_start')) and torch.equal(te, g.t('extent/t_stop'))
+    m = orc.len_to_mask([6, 5, 3])
+    assert m.shape == (6, 3, 1) and m.sum().item() == 14 and m.dtype == torch.bool
+
+
+# ---------------------------------------------------------------------- DMM models --
+SPEC_AB = [('a', 1, 'Normal'), ('b', 1, 'Normal')]
+SPEC_MIX = [('g', 3, 'Normal'), ('c', 4, 'Categorical'), ('v', (2, 3), 'Bernoulli')]
+
+
+def oracle_dmm(spec, z_dim, h_dim, sd):
+    names = [s[0] for s in spec]; dims = [s[1] for s in spec]; dists = [s[2] for s in spec]
+    encs, decs = {}, {}
+    for n, d, dist in spec:
+        if dist == 'Bernoulli':
+            encs[n] = FlatGaussEnc(int(np.prod(d)), z_dim, h_dim)
+            decs[n] = ShapedBernoulliDec(z_dim, d, h_dim)
+    o = orc.OracleDMM(names, dims, dists, encoders=encs or None, decoders=decs or None,
+                      h_dim=h_dim, z_dim=z_dim)
+    o.load_state_dict(sd)
+    return o
+
+
+def test_zfilter_cases():
+    g = Golden('g2_zfilter.npz')
+    o = oracle_dmm(SPEC_AB, 5, 20, g.sub('sd'))
+    e_mean, e_std, e_mask = g.t('e_mean'), g.t('e_std'), g.t('e_mask').bool()
+    x = g.sub('x')
+    with torch.no_grad():
+        om, os_, ok = o.encode(x)
+    close(om, e_mean); close(os_, e_std); assert torch.equal(ok, e_mask)
+    cases = [c for c in g.cases() if c.startswith('case')]
+    assert len(cases) == 10
+    for c in cases:
+        o.noise = orc.ReplayNoise(g.seq(c + '/eps')) if g.has(c + '/eps/#len') else None
+        with torch.no_grad():
+            infer, prior, z = o.z_filter(e_mean, e_std, e_mask,
+                                         'bwd' if g.scalar(c + '/direction') else 'fwd',
+                                         bool(g.scalar(c + '/sample')), int(g.scalar(c + '/K')),
+                                         bool(g.scalar(c + '/sample_init')))
+        close(infer[0], g.t(c + '/infer_mean')); close(infer[1], g.t(c + '/infer_std'))
+        close(prior[0], g.t(c + '/prior_mean')); close(prior[1], g.t(c + '/prior_std'))
+        close(z, g.t(c + '/samples'))
+
+
+def test_forward_modes():
+    g = Golden('g3_forward.npz')
+    o = oracle_dmm(SPEC_MIX, 6, 12, g.sub('sd')).eval()
+    x = g.sub('x')
+    lengths = g.t('lengths').tolist()
+    mask = orc.len_to_mask(lengths)
+    rec_mults = {k: float(v) for k, v in g.sub('rec_mults').items()}
+    names = ['g', 'c', 'v']
+    cases = [c for c in g.cases() if c.startswith('case')]
+    assert len(cases) >= 20
+    for c in cases:
+        sub = [names[i] for i in g.t(c + '/subset').tolist()]
+        o.noise = orc.ReplayNoise(g.seq(c + '/eps'))
+        with torch.no_grad():
+            infer, prior, recon = o({m: x[m] for m in sub}, lengths=lengths,
+                                    mode=MODES[int(g.scalar(c + '/mode'))],
+                                    sample=bool(g.scalar(c + '/sample')),
+                                    flt_particles=int(g.scalar(c + '/flt_particles')))
+            close(infer[0], g.t(c + '/infer_mean')); close(infer[1], g.t(c + '/infer_std'))
+            close(prior[0], g.t(c + '/prior_mean')); close(prior[1], g.t(c + '/prior_std'))
+            close(o.kld_loss(infer, prior, mask), g.t(c + '/kld'))
+            close(o.rec_loss(x, recon, mask, rec_mults), g.t(c + '/rec'))
+        for m in names:
+            for i, r in enumerate(g.seq(c + '/recon/' + m)):
+                close(recon[m][i], r)
+
+
+def _kw(g, c):
+    kw = {}
+    for k, v in g.sub(c + '/kw').items():
+        v = v.item()
+        kw[k] = MODES[int(v)] if k in ('f_mode', 's_mode') else v
+    return kw
+
+
+@pytest.mark.parametrize('case', ['z5', 'z5_args', 'z5_nouni', 'z5_bsmooth', 'z32', 'mix'])
+def test_step_loss_and_grads(case):
+    g = Golden('g4_step.npz')
+    spec = SPEC_MIX if case == 'mix' else SPEC_AB
+    o = oracle_dmm(spec, int(g.scalar(case + '/z_dim')), int(g.scalar(case + '/h_dim')),
+                   g.sub(case + '/sd'))
+    lengths = g.t(case + '/lengths').tolist()
+    mask = orc.len_to_mask(lengths)
+    rec_mults = {k: float(v) for k, v in g.sub(case + '/rec_mults').items()}
+    o.noise = orc.ReplayNoise(g.seq(case + '/eps'))
+    loss = o.step(g.sub(case + '/inputs'), mask, float(g.scalar(case + '/kld_mult')), rec_mults,
+                  targets=g.sub(case + '/targets'), lengths=lengths, **_kw(g, case))
+    assert o.noise.pos == len(o.noise.tensors)
+    close(loss, g.t(case + '/loss'), 1e-5)
+    (loss / sum(lengths)).backward()
+    for k, p in o.named_parameters():
+        ref = g.t(case + '/grads/' + k)
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert rel_err(got, ref) < 1e-3 or float(ref.abs().max()) < 1e-6, k
+
+
+# ---------------------------------------------------------------------- DKS models --
+def oracle_dks(g, c):
+    spec = [('a', 2, 'Normal'), ('c', 3, 'Categorical'), ('b', 4, 'Normal')]
+    encs = {'b': FeatEncoder(4, 9)} if bool(g.scalar(c + '/custom_enc')) else None
+    o = orc.OracleDKS([s[0] for s in spec], [s[1] for s in spec], [s[2] for s in spec],
+                      encoders=encs, h_dim=10, z_dim=6,
+                      feat_to_z=bool(g.scalar(c + '/feat_to_z')),
+                      rnn_dir='bwd' if g.scalar(c + '/rnn_bwd') else 'fwd',
+                      rnn_skip=bool(g.scalar(c + '/rnn_skip')),
+                      rnn_layers=int(g.scalar(c + '/rnn_layers')))
+    o.load_state_dict(g.sub(c + '/sd'))
+    return o
+
+
+def test_dks_forward_and_step():
+    g = Golden('g5_dks.npz')
+    cases = [c for c in g.cases() if c.startswith('case')]
+    assert len(cases) == 12
+    for c in cases:
+        o = oracle_dks(g, c)
+        inputs, targets = g.sub(c + '/inputs'), g.sub(c + '/targets')
+        lengths = g.t(c + '/lengths').tolist()
+        mask = orc.len_to_mask(lengths)
+        rec_mults = {k: float(v) for k, v in g.sub(c + '/rec_mults').items()}
+        for tag, sub, sample in (('all', ['a', 'c', 'b'], True), ('only_a', ['a'], True),
+                                 ('map', ['a', 'c', 'b'], False)):
+            p = c + '/fwd_' + tag
+            o.noise = orc.ReplayNoise(g.seq(p + '/eps')) if g.has(p + '/eps/#len') else None
+            with torch.no_grad():
+                infer, prior, recon = o({m: inputs[m] for m in sub}, lengths=lengths,
+                                        sample=sample)
+            close(infer[0], g.t(p + '/infer_mean')); close(infer[1], g.t(p + '/infer_std'))
+            close(prior[0], g.t(p + '/prior_mean')); close(prior[1], g.t(p + '/prior_std'))
+            for m in ('a', 'c', 'b'):
+                for i, r in enumerate(g.seq(p + '/recon/' + m)):
+                    close(recon[m][i], r)
+            if tag == 'only_a':     # unimodal pass: t_stop = 0 -> infer == prior for t > 0
+                assert torch.equal(infer[0][1:], prior[0][1:])
+        for tag, uni in (('step_uni', True), ('step_nouni', False)):
+            p = c + '/' + tag
+            o.noise = orc.ReplayNoise(g.seq(p + '/eps'))
+            o.zero_grad()
+            loss = o.step(inputs, mask, float(g.scalar(p + '/kld_mult')), rec_mults,
+                          targets=targets, uni_loss=uni, lengths=lengths)
+            close(loss, g.t(p + '/loss'), 1e-5)
+            (loss / sum(lengths)).backward()
+            for k, prm in o.named_parameters():
+                ref = g.t(p + '/grads/' + k)
+                got = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+                assert rel_err(got, ref) < 1e-3 or float(ref.abs().max()) < 1e-6, (c, k)
+
+
+def test_anneal():
+    assert orc.anneal(0.0, 1.0, 24, 2400) == pytest.approx(0.01)
+    assert orc.anneal(0.0, 0.5, 5000, 2400) == 0.5
