@@ -1,0 +1,197 @@
+/*
+ * mdmm_hip.h -- C ABI of libmdmm_hip.so: the MI355X (gfx950) kernels behind the MDMM
+ * ELBO-step hot path of ztangent/multimodal-dmm.
+ *
+ * The reference has no FFI: the path lives behind the Python nn.Module API of its
+ * `models` package.  These entry points are what a binding for that path would bind;
+ * each one names the reference op sequence (file:line under /root/reference) it
+ * replaces.  Conventions:
+ *   - extern "C", plain device pointers + explicit sizes, no torch types;
+ *   - every call is asynchronous on the hipStream_t passed as `void* stream`;
+ *   - no allocation, no global state, re-entrant; callers own all memory;
+ *   - return value: 0 = ok, >0 = hipError_t of the failed launch, <0 = MDMM_E_* argument
+ *     error (mdmm_strerror() gives text).  Nothing falls back to the CPU.
+ *   - all tensors fp32, time-first (T, B, ...) contiguous exactly as the reference's
+ *     collate produces them (datasets/multiseq.py:341-353): a tile of sequences at a
+ *     fixed t is contiguous, so wave loads coalesce.
+ */
+#ifndef MDMM_HIP_H
+#define MDMM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDMM_ABI_VERSION 1
+#define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
+#define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
+
+#define MDMM_E_ARG (-1)    /* bad size / NULL pointer                          */
+#define MDMM_E_LIMIT (-2)  /* exceeds MDMM_MAX_* or the LDS budget of one CU    */
+#define MDMM_E_ALIGN (-3)  /* packed weight buffers must be 16-byte aligned    */
+
+int mdmm_version(void);
+const char* mdmm_strerror(int code);
+/* round n up to the padded width the packed weights use (multiple of 4) */
+int mdmm_pad(int n);
+
+/* ---------------------------------------------------------------------------------
+ * Gated transition function, common.py:43-68 (GaussianGTF), packed for the kernels.
+ * Dp = mdmm_pad(D), Hp = mdmm_pad(H), F1 = 2*Hp + Dp.  Padding entries are zero.
+ *   row blocks of w_in (PyTorch [out][in] layout):
+ *     [0,Hp)      z_to_gate.0   (common.py:48)
+ *     [Hp,2Hp)    z_nonlin.0    (common.py:54)
+ *     [2Hp,F1)    z_lin         (common.py:53)
+ *   w_gate = z_to_gate.2 (common.py:50), w_nl = z_nonlin.2 (56), w_std = z_to_std.0 (58).
+ * wt_* are the transposes ([in][out]); the forward sweep reads wt_*, the backward
+ * sweep reads both.  */
+typedef struct mdmm_gtf {
+  const float* w_in;    /* [F1][Dp] */
+  const float* wt_in;   /* [Dp][F1] */
+  const float* b_in;    /* [F1]     */
+  const float* w_gate;  /* [Dp][Hp] */
+  const float* wt_gate; /* [Hp][Dp] */
+  const float* b_gate;  /* [Dp]     */
+  const float* w_nl;    /* [Dp][Hp] */
+  const float* wt_nl;   /* [Hp][Dp] */
+  const float* b_nl;    /* [Dp]     */
+  const float* w_std;   /* [Dp][Dp] */
+  const float* wt_std;  /* [Dp][Dp] */
+  const float* b_std;   /* [Dp]     */
+} mdmm_gtf_t;
+
+/* One Gaussian expert entering the per-step product of experts (dgts.py:15-51).
+ * mean/std are (T,B,D) (pass_stride == 0: shared by all passes, e.g. an encoder
+ * output) or (P,T,B,D) (pass_stride == T*B*D: one slab per pass, e.g. the filter-pass
+ * prior fed to the smoother, dmm.py:479).  mask is (T,B) float 0/1 or NULL (= ones).
+ * pass_bits: bit p set <=> the expert takes part in pass p (a unimodal pass simply
+ * leaves the other modalities out, dgts.py:126-129 / dmm.py:162-163).
+ * g_mean/g_std (backward only, may be NULL): same layout as mean/std, overwritten. */
+typedef struct mdmm_expert {
+  const float* mean;
+  const float* std;
+  const float* mask;
+  float* g_mean;
+  float* g_std;
+  int64_t pass_stride;
+  uint32_t pass_bits;
+  uint32_t reserved;
+} mdmm_expert_t;
+
+/* The BFVI filtering / smoothing sweep, MultiDMM.z_filter (dmm.py:319-412) with
+ * z_next (214-258), product_of_experts (dgts.py:15-51), mean_of_experts (53-83) and
+ * _sample_gauss (177-180) fused into one persistent kernel: the whole time loop of a
+ * tile of sequences runs inside one workgroup, P passes at once.
+ * trans_only = 1 runs a single z_next (dmm.py:214-258) on given particles z_rows.  */
+typedef struct mdmm_sweep {
+  int32_t T, B, D, H;
+  int32_t P, K, E;
+  int32_t reverse;       /* 1 = direction 'bwd' (t = T-1 .. 0), dmm.py:367-373          */
+  int32_t sample;        /* dmm.py:398: sample || K > 1 || (first step && sample_init)  */
+  int32_t sample_init;
+  int32_t use_inv_prior; /* add the inverse global prior expert (mu0, -sigma0), dmm.py:476-477 */
+  int32_t trans_only;
+  float min_std;         /* dmm.py:111-112, common.py:66 */
+  float reserved0;
+  uint64_t seed, offset; /* Philox4x32-10 stream, used when eps == NULL */
+  const float* eps;      /* (P,T,K,B,D) recorded N(0,1) draws, or NULL */
+  const float* z_rows;   /* trans_only: (K,B,D) */
+  const float* z0_mean;    /* (D) dmm.py:115 */
+  const float* z0_log_std; /* (D) dmm.py:116 */
+  mdmm_gtf_t gtf;
+  mdmm_expert_t experts[MDMM_MAX_EXPERTS];
+  /* outputs of the forward sweep, (P,T,B,D) each ((B,D) for trans_only prior_*);
+   * the backward sweep reads infer_* / prior_* back instead of storing activations */
+  float* infer_mean;
+  float* infer_std;
+  float* prior_mean;
+  float* prior_std;
+  float* samples;        /* may be NULL */
+  /* backward sweep: upstream gradients (any may be NULL = zero) */
+  const float* g_infer_mean;
+  const float* g_infer_std;
+  const float* g_prior_mean;
+  const float* g_prior_std;
+  const float* g_samples;
+  float* g_z0_mean;      /* (D)  += d/d z0_mean            (atomic; zero before the call) */
+  float* g_z0_sigma;     /* (D)  += d/d (exp(z0_log_std)+min_std)                         */
+  float* g_z_rows;       /* trans_only: (K,B,D) */
+  /* weight-gradient operands, one row per transition row (p,t,b,k):
+   *   spill_g [rows][2Hp+Dp | Dp | Dp | Dp] = d/d pre-activations of (in | gate | nl | std)
+   *   spill_x [rows][Dp | Hp | Hp | Dp]     = (z | relu gate-hidden | relu nl-hidden | nl)
+   * dW = G^T X is then one plain GEMM per layer (contraction over rows).  */
+  float* spill_g;
+  float* spill_x;
+  int64_t spill_rows;    /* capacity; needs P*B*K*(T-1) (K*B for trans_only) */
+} mdmm_sweep_t;
+
+int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream);
+int mdmm_bfvi_sweep_bwd(const mdmm_sweep_t* args, void* stream);
+/* widths of one spill_g / spill_x row for (D,H) */
+int mdmm_sweep_spill_width_g(int D, int H);
+int mdmm_sweep_spill_width_x(int D, int H);
+
+/* ---------------------------------------------------------------------------------
+ * Stand-alone product / mixture of experts: MultiDGTS.product_of_experts
+ * (dgts.py:15-51) and mean_of_experts (dgts.py:53-83) on (E,N,D) with mask (E,N) or NULL
+ * (NULL = derived from NaNs in std, dgts.py:44-45 / 75-76).  */
+int mdmm_poe_fwd(const float* mean, const float* std, const float* mask, int E, int64_t N,
+                 int D, float* out_mean, float* out_std, void* stream);
+int mdmm_poe_bwd(const float* mean, const float* std, const float* mask, int E, int64_t N,
+                 int D, const float* g_out_mean, const float* g_out_std, float* g_mean,
+                 float* g_std, void* stream);
+int mdmm_moe_fwd(const float* mean, const float* std, const float* mask, int E, int64_t N,
+                 int D, float* out_mean, float* out_std, void* stream);
+int mdmm_moe_bwd(const float* mean, const float* std, const float* mask, int E, int64_t N,
+                 int D, const float* out_mean, const float* out_std, const float* g_out_mean,
+                 const float* g_out_std, float* g_mean, float* g_std, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Masked loss reductions, losses.py.  `rows` = T*B (times P when passes are stacked),
+ * `inner` = product of the trailing dims, seq_mask is (rows) float 0/1 or NULL.
+ * Forward kernels ADD the sum into *out (fp64 accumulator, zero it first); backward
+ * kernels write scale * d(sum)/d(input) (or add it, when `accumulate` != 0).  */
+/* losses.py:14-21 kld_gauss(infer || prior) */
+int mdmm_kld_gauss_fwd(const float* m1, const float* s1, const float* m2, const float* s2,
+                       const float* seq_mask, int64_t rows, int inner, double* out,
+                       void* stream);
+int mdmm_kld_gauss_bwd(const float* m1, const float* s1, const float* m2, const float* s2,
+                       const float* seq_mask, int64_t rows, int inner, float scale,
+                       float* g_m1, float* g_s1, float* g_m2, float* g_s2, int accumulate,
+                       void* stream);
+/* losses.py:68-89 nll_gauss; x may hold NaN (= missing, excluded) */
+int mdmm_nll_gauss_fwd(const float* mean, const float* std, const float* x,
+                       const float* seq_mask, int64_t rows, int inner, double* out,
+                       void* stream);
+int mdmm_nll_gauss_bwd(const float* mean, const float* std, const float* x,
+                       const float* seq_mask, int64_t rows, int inner, float scale,
+                       float* g_mean, float* g_std, void* stream);
+/* losses.py:23-42 nll_bernoulli = F.binary_cross_entropy(sum), log clamped at -100 */
+int mdmm_nll_bernoulli_fwd(const float* theta, const float* x, const float* seq_mask,
+                           int64_t rows, int inner, double* out, void* stream);
+int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const float* seq_mask,
+                           int64_t rows, int inner, float scale, float* g_theta,
+                           void* stream);
+/* losses.py:44-66 nll_categorical: reference behaviour = minus the summed PROBABILITY of
+ * the observed class (F.nll_loss on probs).  probs (rows, n_cat), x (rows) labels as
+ * float (NaN = missing).  */
+int mdmm_nll_categorical_fwd(const float* probs, const float* x, const float* seq_mask,
+                             int64_t rows, int n_cat, double* out, void* stream);
+int mdmm_nll_categorical_bwd(const float* probs, const float* x, const float* seq_mask,
+                             int64_t rows, int n_cat, float scale, float* g_probs,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * The noise the sweeps draw when eps == NULL: out[i] = N(0,1) sample number i of the
+ * Philox4x32-10 stream (seed, offset), i in [0, n).  Element i is the eps of the
+ * (p,t,k,b,d) entry with flat index i of a (P,T,K,B,D) tensor, so a caller can
+ * materialise exactly what a sweep used (replaces dgts.py:179 `normal_()`).  */
+int mdmm_philox_normal(uint64_t seed, uint64_t offset, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDMM_HIP_H */

@@ -1,0 +1,123 @@
+// Device-side helpers shared by the MDMM kernels (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MDMM_POE_EPS 1e-8f  // dgts.py:15
+
+namespace mdmm {
+
+// ---------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG + Box-Muller.  One counter per 4 consecutive elements of
+// the (P,T,K,B,D) noise tensor, so forward and backward sweeps regenerate identical
+// eps from (seed, offset, element index) without storing it.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2,
+                                              uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t h0 = __umulhi(M0, c0), l0 = M0 * c0;
+  uint32_t h1 = __umulhi(M1, c2), l1 = M1 * c2;
+  uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint64_t stream,
+                                        uint32_t out[4]) {
+  uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32);
+  uint32_t c2 = (uint32_t)stream, c3 = (uint32_t)(stream >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// standard normal for element `idx` of the stream (seed, offset)
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, uint64_t idx) {
+  uint32_t r[4];
+  philox4(seed, idx >> 2, offset, r);
+  const int pair = (int)((idx >> 1) & 1);
+  const uint32_t a = r[2 * pair], b = r[2 * pair + 1];
+  // u1 in (0,1], u2 in [0,1)
+  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+  const float rad = sqrtf(-2.0f * logf(u1));
+  float s, c;
+  sincosf(6.28318530717958647692f * u2, &s, &c);
+  return (idx & 1) ? rad * s : rad * c;
+}
+
+// ---------------------------------------------------------------------------------
+// scalar math in the reference's form
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// nn.Softplus(beta=1, threshold=20), common.py:36,60
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+// d softplus / dx (torch: z/(z+1) with z = exp(x), 1 above the threshold)
+__device__ __forceinline__ float softplus_grad_(float x) {
+  if (x > 20.0f) return 1.0f;
+  const float z = expf(x);
+  return z / (z + 1.0f);
+}
+__device__ __forceinline__ float signf_(float x) {
+  return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : x);  // sign(0) = 0, sign(NaN) = NaN
+}
+
+// Product of experts accumulator, dgts.py:39-51.
+struct Poe {
+  float num, prec;
+  __device__ __forceinline__ void init() { num = 0.0f; prec = 0.0f; }
+  // c = mask value (0/1) of the expert for this (t,b)
+  __device__ __forceinline__ void add(float mu, float sd, float c) {
+    const float var = sd * sd + MDMM_POE_EPS;
+    const float t = (1.0f / var) * signf_(sd) * c;   // dgts.py:42,46
+    const float m = mu * c;                          // dgts.py:47
+    num += m * t;
+    prec += t;
+  }
+  __device__ __forceinline__ void finish(float& mean, float& std) const {
+    float m = num / prec;
+    mean = (m != m) ? 0.0f : m;                      // dgts.py:49
+    std = sqrtf(1.0f / prec);                        // dgts.py:50
+  }
+};
+
+// Adjoint of one expert of a PoE.  (g_num, g_prec) are d/d(num), d/d(prec) of the
+// product; returns d/d mu_e, d/d sd_e.
+__device__ __forceinline__ void poe_expert_bwd(float mu, float sd, float c, float g_num,
+                                               float g_prec, float& g_mu, float& g_sd) {
+  const float var = sd * sd + MDMM_POE_EPS;
+  const float inv = 1.0f / var;
+  const float sg = signf_(sd);
+  const float t = inv * sg * c;
+  const float m = mu * c;
+  const float g_m = g_num * t;
+  const float g_t = g_num * m + g_prec;
+  g_mu = g_m * c;
+  const float g_inv = g_t * c * sg;
+  g_sd = -g_inv * inv * inv * 2.0f * sd;
+}
+
+// (g_num, g_prec) from the adjoints of the product's (mean, std)
+__device__ __forceinline__ void poe_out_bwd(float num, float prec, float std, float g_mean,
+                                            float g_std, float& g_num, float& g_prec) {
+  const float m = num / prec;
+  if (m != m) g_mean = 0.0f;                         // value was overwritten by 0
+  g_num = g_mean / prec;
+  g_prec = -g_mean * num / (prec * prec) - 0.5f * g_std * std / prec;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+}  // namespace mdmm

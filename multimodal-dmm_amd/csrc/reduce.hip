@@ -1,0 +1,407 @@
+// Masked loss reductions (losses.py) and the stand-alone product / mixture of experts
+// (dgts.py:15-83).  All HBM-bound streaming kernels: one pass over the operands,
+// float4 loads where the trailing extent allows, per-wave shuffle reduction, one fp64
+// atomic per workgroup.
+#include "mdmm_device.h"
+#include "../../include/mdmm_hip.h"
+
+namespace {
+
+using namespace mdmm;
+
+constexpr int NT = 256;
+constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
+
+__device__ __forceinline__ void block_add(double v, double* out) {
+  __shared__ double part[NT / 64];
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) part[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < NT / 64; ++i) s += part[i];
+    atomicAdd(out, s);
+  }
+}
+
+inline int grid_for(int64_t n) {
+  int64_t g = (n + NT - 1) / NT;
+  if (g > 2048) g = 2048;   // 256 CUs x 8 workgroups, grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------- kld_gauss --------
+__global__ __launch_bounds__(NT) void kld_fwd_kernel(const float* __restrict__ m1,
+    const float* __restrict__ s1, const float* __restrict__ m2, const float* __restrict__ s2,
+    const float* __restrict__ mask, int64_t n, int inner, double* out) {
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    if (mask && mask[i / inner] == 0.f) continue;
+    const float a = s1[i], b = s2[i], d = m1[i] - m2[i];
+    acc += 2.0f * logf(b) - 2.0f * logf(a) + (a * a + d * d) / (b * b) - 1.0f;   // losses.py:15-17
+  }
+  block_add(0.5 * (double)acc, out);
+}
+
+__global__ __launch_bounds__(NT) void kld_bwd_kernel(const float* __restrict__ m1,
+    const float* __restrict__ s1, const float* __restrict__ m2, const float* __restrict__ s2,
+    const float* __restrict__ mask, int64_t n, int inner, float scale, float* g_m1, float* g_s1,
+    float* g_m2, float* g_s2, int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    float w = 0.5f * scale;
+    if (mask && mask[i / inner] == 0.f) w = 0.f;
+    float gm1 = 0.f, gs1 = 0.f, gm2 = 0.f, gs2 = 0.f;
+    if (w != 0.f) {
+      const float a = s1[i], b = s2[i], d = m1[i] - m2[i];
+      const float ib2 = 1.0f / (b * b);
+      gm1 = w * 2.0f * d * ib2;
+      gm2 = -gm1;
+      gs1 = w * (-2.0f / a + 2.0f * a * ib2);
+      gs2 = w * (2.0f / b - 2.0f * (a * a + d * d) * ib2 / b);
+    }
+    if (accumulate) {
+      if (g_m1) g_m1[i] += gm1;
+      if (g_s1) g_s1[i] += gs1;
+      if (g_m2) g_m2[i] += gm2;
+      if (g_s2) g_s2[i] += gs2;
+    } else {
+      if (g_m1) g_m1[i] = gm1;
+      if (g_s1) g_s1[i] = gs1;
+      if (g_m2) g_m2[i] = gm2;
+      if (g_s2) g_s2[i] = gs2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- nll_gauss --------
+__global__ __launch_bounds__(NT) void nllg_fwd_kernel(const float* __restrict__ mean,
+    const float* __restrict__ std, const float* __restrict__ x, const float* __restrict__ mask,
+    int64_t n, int inner, double* out) {
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const float xv = x[i];
+    if (xv != xv) continue;                                   // losses.py:79-82
+    if (mask && mask[i / inner] == 0.f) continue;
+    const float sd = std[i], r = (xv - mean[i]) / sd;
+    acc += 0.5f * r * r + logf(sd) + HALF_LOG_2PI;            // losses.py:85-86
+  }
+  block_add((double)acc, out);
+}
+
+__global__ __launch_bounds__(NT) void nllg_bwd_kernel(const float* __restrict__ mean,
+    const float* __restrict__ std, const float* __restrict__ x, const float* __restrict__ mask,
+    int64_t n, int inner, float scale, float* g_mean, float* g_std) {
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const float xv = x[i];
+    float gm = 0.f, gs = 0.f;
+    if (xv == xv && !(mask && mask[i / inner] == 0.f)) {
+      const float sd = std[i], d = xv - mean[i];
+      gm = -scale * d / (sd * sd);
+      gs = scale * (1.0f / sd - d * d / (sd * sd * sd));
+    }
+    if (g_mean) g_mean[i] = gm;
+    if (g_std) g_std[i] = gs;
+  }
+}
+
+// ---------------------------------------------------------------- nll_bernoulli ----
+__global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ theta,
+    const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
+    double* out) {
+  float acc = 0.f;
+  const bool vec = (inner & 3) == 0 && (n & 3) == 0;
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    const int inner4 = inner >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+      if (mask && mask[i / inner4] == 0.f) continue;
+      const float4 xv = reinterpret_cast<const float4*>(x)[i];
+      const float4 th = reinterpret_cast<const float4*>(theta)[i];
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ts[4] = {th.x, th.y, th.z, th.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (xs[j] != xs[j]) continue;
+        const float l1 = fmaxf(logf(ts[j]), -100.0f), l0 = fmaxf(log1pf(-ts[j]), -100.0f);
+        acc -= xs[j] * l1 + (1.0f - xs[j]) * l0;              // F.binary_cross_entropy
+      }
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+      const float xv = x[i];
+      if (xv != xv) continue;
+      if (mask && mask[i / inner] == 0.f) continue;
+      const float th = theta[i];
+      const float l1 = fmaxf(logf(th), -100.0f), l0 = fmaxf(log1pf(-th), -100.0f);
+      acc -= xv * l1 + (1.0f - xv) * l0;
+    }
+  }
+  block_add((double)acc, out);
+}
+
+__global__ __launch_bounds__(NT) void nllb_bwd_kernel(const float* __restrict__ theta,
+    const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
+    float scale, float* g_theta) {
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const float xv = x[i];
+    float g = 0.f;
+    if (xv == xv && !(mask && mask[i / inner] == 0.f)) {
+      const float th = theta[i];
+      g = scale * (th - xv) / fmaxf((1.0f - th) * th, 1e-12f);   // torch BCE backward
+    }
+    g_theta[i] = g;
+  }
+}
+
+// ---------------------------------------------------------------- nll_categorical --
+__global__ __launch_bounds__(NT) void nllc_fwd_kernel(const float* __restrict__ probs,
+    const float* __restrict__ x, const float* __restrict__ mask, int64_t rows, int n_cat,
+    double* out) {
+  float acc = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < rows; r += (int64_t)gridDim.x * NT) {
+    const float xv = x[r];
+    if (xv != xv) continue;
+    if (mask && mask[r] == 0.f) continue;
+    acc -= probs[r * n_cat + (int)xv];                          // losses.py:65 (probs, not logs)
+  }
+  block_add((double)acc, out);
+}
+
+__global__ __launch_bounds__(NT) void nllc_bwd_kernel(const float* __restrict__ x,
+    const float* __restrict__ mask, int64_t rows, int n_cat, float scale, float* g_probs) {
+  const int64_t n = rows * n_cat;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const int64_t r = i / n_cat;
+    const int c = (int)(i - r * n_cat);
+    const float xv = x[r];
+    float g = 0.f;
+    if (xv == xv && !(mask && mask[r] == 0.f) && (int)xv == c) g = -scale;
+    g_probs[i] = g;
+  }
+}
+
+// ---------------------------------------------------------------- PoE / MoE --------
+__device__ __forceinline__ float expert_mask(const float* mask, const float* std, int e, int64_t n,
+                                             int64_t N, int D) {
+  if (mask) return mask[(int64_t)e * N + n];
+  const float* row = std + ((int64_t)e * N + n) * D;       // dgts.py:44-45 / 75-76
+  for (int d = 0; d < D; ++d) if (row[d] != row[d]) return 0.f;
+  return 1.f;
+}
+
+__global__ __launch_bounds__(NT) void poe_fwd_kernel(const float* __restrict__ mean,
+    const float* __restrict__ std, const float* __restrict__ mask, int E, int64_t N, int D,
+    float* out_mean, float* out_std) {
+  const int64_t tot = N * D;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < tot; i += (int64_t)gridDim.x * NT) {
+    const int64_t n = i / D;
+    Poe q; q.init();
+    for (int e = 0; e < E; ++e)
+      q.add(mean[(int64_t)e * tot + i], std[(int64_t)e * tot + i], expert_mask(mask, std, e, n, N, D));
+    float m, s; q.finish(m, s);
+    out_mean[i] = m; out_std[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(NT) void poe_bwd_kernel(const float* __restrict__ mean,
+    const float* __restrict__ std, const float* __restrict__ mask, int E, int64_t N, int D,
+    const float* __restrict__ g_om, const float* __restrict__ g_os, float* g_mean, float* g_std) {
+  const int64_t tot = N * D;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < tot; i += (int64_t)gridDim.x * NT) {
+    const int64_t n = i / D;
+    Poe q; q.init();
+    for (int e = 0; e < E; ++e)
+      q.add(mean[(int64_t)e * tot + i], std[(int64_t)e * tot + i], expert_mask(mask, std, e, n, N, D));
+    float m, s; q.finish(m, s);
+    float g_num, g_prec;
+    poe_out_bwd(q.num, q.prec, s, g_om ? g_om[i] : 0.f, g_os ? g_os[i] : 0.f, g_num, g_prec);
+    for (int e = 0; e < E; ++e) {
+      float gm, gs;
+      poe_expert_bwd(mean[(int64_t)e * tot + i], std[(int64_t)e * tot + i],
+                     expert_mask(mask, std, e, n, N, D), g_num, g_prec, gm, gs);
+      g_mean[(int64_t)e * tot + i] = gm; g_std[(int64_t)e * tot + i] = gs;
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void moe_fwd_kernel(const float* __restrict__ mean,
+    const float* __restrict__ std, const float* __restrict__ mask, int E, int64_t N, int D,
+    float* out_mean, float* out_std) {
+  const int64_t tot = N * D;
+  const float inv = 1.0f / (float)E;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < tot; i += (int64_t)gridDim.x * NT) {
+    const int64_t n = i / D;
+    float sm = 0.f, sv = 0.f, sm2 = 0.f;
+    for (int e = 0; e < E; ++e) {
+      const float c = expert_mask(mask, std, e, n, N, D);
+      const float m = mean[(int64_t)e * tot + i] * c, s = std[(int64_t)e * tot + i];
+      sm += m; sv += s * s * c; sm2 += m * m;                   // dgts.py:77-81
+    }
+    const float mb = sm * inv;
+    out_mean[i] = mb;
+    out_std[i] = sqrtf(sv * inv + (sm2 * inv - mb * mb));
+  }
+}
+
+__global__ __launch_bounds__(NT) void moe_bwd_kernel(const float* __restrict__ mean,
+    const float* __restrict__ std, const float* __restrict__ mask, int E, int64_t N, int D,
+    const float* __restrict__ om, const float* __restrict__ os, const float* __restrict__ g_om,
+    const float* __restrict__ g_os, float* g_mean, float* g_std) {
+  const int64_t tot = N * D;
+  const float inv = 1.0f / (float)E;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < tot; i += (int64_t)gridDim.x * NT) {
+    const int64_t n = i / D;
+    const float mb = om[i], sb = os[i];
+    const float gmb = g_om ? g_om[i] : 0.f, gv = 0.5f * (g_os ? g_os[i] : 0.f) / sb;
+    for (int e = 0; e < E; ++e) {
+      const float c = expert_mask(mask, std, e, n, N, D);
+      const float m = mean[(int64_t)e * tot + i] * c, s = std[(int64_t)e * tot + i];
+      g_mean[(int64_t)e * tot + i] = c * (gmb * inv + gv * 2.0f * (m - mb) * inv);
+      g_std[(int64_t)e * tot + i] = gv * 2.0f * s * c * inv;
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void philox_kernel(uint64_t seed, uint64_t offset, int64_t n,
+                                                    float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+    out[i] = philox_normal(seed, offset, (uint64_t)i);
+}
+
+}  // namespace
+
+#define STREAM ((hipStream_t)stream)
+#define CHECK_LAUNCH() return (int)hipGetLastError()
+
+extern "C" int mdmm_kld_gauss_fwd(const float* m1, const float* s1, const float* m2,
+                                  const float* s2, const float* seq_mask, int64_t rows, int inner,
+                                  double* out, void* stream) {
+  if (!m1 || !s1 || !m2 || !s2 || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  hipLaunchKernelGGL(kld_fwd_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, m1, s1, m2, s2,
+                     seq_mask, n, inner, out);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_kld_gauss_bwd(const float* m1, const float* s1, const float* m2,
+                                  const float* s2, const float* seq_mask, int64_t rows, int inner,
+                                  float scale, float* g_m1, float* g_s1, float* g_m2, float* g_s2,
+                                  int accumulate, void* stream) {
+  if (!m1 || !s1 || !m2 || !s2 || rows < 0 || inner < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  hipLaunchKernelGGL(kld_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, m1, s1, m2, s2,
+                     seq_mask, n, inner, scale, g_m1, g_s1, g_m2, g_s2, accumulate);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_gauss_fwd(const float* mean, const float* std, const float* x,
+                                  const float* seq_mask, int64_t rows, int inner, double* out,
+                                  void* stream) {
+  if (!mean || !std || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  hipLaunchKernelGGL(nllg_fwd_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, mean, std, x,
+                     seq_mask, n, inner, out);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_gauss_bwd(const float* mean, const float* std, const float* x,
+                                  const float* seq_mask, int64_t rows, int inner, float scale,
+                                  float* g_mean, float* g_std, void* stream) {
+  if (!mean || !std || !x || rows < 0 || inner < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  hipLaunchKernelGGL(nllg_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, mean, std, x,
+                     seq_mask, n, inner, scale, g_mean, g_std);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_bernoulli_fwd(const float* theta, const float* x, const float* seq_mask,
+                                      int64_t rows, int inner, double* out, void* stream) {
+  if (!theta || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  hipLaunchKernelGGL(nllb_fwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, theta, x,
+                     seq_mask, n, inner, out);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const float* seq_mask,
+                                      int64_t rows, int inner, float scale, float* g_theta,
+                                      void* stream) {
+  if (!theta || !x || !g_theta || rows < 0 || inner < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  hipLaunchKernelGGL(nllb_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, theta, x, seq_mask,
+                     n, inner, scale, g_theta);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_categorical_fwd(const float* probs, const float* x, const float* seq_mask,
+                                        int64_t rows, int n_cat, double* out, void* stream) {
+  if (!probs || !x || !out || rows < 0 || n_cat < 1) return MDMM_E_ARG;
+  hipLaunchKernelGGL(nllc_fwd_kernel, dim3(grid_for(rows)), dim3(NT), 0, STREAM, probs, x, seq_mask,
+                     rows, n_cat, out);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_categorical_bwd(const float* probs, const float* x, const float* seq_mask,
+                                        int64_t rows, int n_cat, float scale, float* g_probs,
+                                        void* stream) {
+  (void)probs;
+  if (!x || !g_probs || rows < 0 || n_cat < 1) return MDMM_E_ARG;
+  hipLaunchKernelGGL(nllc_bwd_kernel, dim3(grid_for(rows * n_cat)), dim3(NT), 0, STREAM, x, seq_mask,
+                     rows, n_cat, scale, g_probs);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_poe_fwd(const float* mean, const float* std, const float* mask, int E, int64_t N,
+                            int D, float* out_mean, float* out_std, void* stream) {
+  if (!mean || !std || !out_mean || !out_std || E < 1 || N < 0 || D < 1) return MDMM_E_ARG;
+  hipLaunchKernelGGL(poe_fwd_kernel, dim3(grid_for(N * D)), dim3(NT), 0, STREAM, mean, std, mask, E,
+                     N, D, out_mean, out_std);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_poe_bwd(const float* mean, const float* std, const float* mask, int E, int64_t N,
+                            int D, const float* g_out_mean, const float* g_out_std, float* g_mean,
+                            float* g_std, void* stream) {
+  if (!mean || !std || !g_mean || !g_std || E < 1 || N < 0 || D < 1) return MDMM_E_ARG;
+  hipLaunchKernelGGL(poe_bwd_kernel, dim3(grid_for(N * D)), dim3(NT), 0, STREAM, mean, std, mask, E,
+                     N, D, g_out_mean, g_out_std, g_mean, g_std);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_moe_fwd(const float* mean, const float* std, const float* mask, int E, int64_t N,
+                            int D, float* out_mean, float* out_std, void* stream) {
+  if (!mean || !std || !out_mean || !out_std || E < 1 || N < 0 || D < 1) return MDMM_E_ARG;
+  hipLaunchKernelGGL(moe_fwd_kernel, dim3(grid_for(N * D)), dim3(NT), 0, STREAM, mean, std, mask, E,
+                     N, D, out_mean, out_std);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_moe_bwd(const float* mean, const float* std, const float* mask, int E, int64_t N,
+                            int D, const float* out_mean, const float* out_std,
+                            const float* g_out_mean, const float* g_out_std, float* g_mean,
+                            float* g_std, void* stream) {
+  if (!mean || !std || !out_mean || !out_std || !g_mean || !g_std || E < 1 || N < 0 || D < 1)
+    return MDMM_E_ARG;
+  hipLaunchKernelGGL(moe_bwd_kernel, dim3(grid_for(N * D)), dim3(NT), 0, STREAM, mean, std, mask, E,
+                     N, D, out_mean, out_std, g_out_mean, g_out_std, g_mean, g_std);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_philox_normal(uint64_t seed, uint64_t offset, int64_t n, float* out,
+                                  void* stream) {
+  if (!out || n < 0) return MDMM_E_ARG;
+  hipLaunchKernelGGL(philox_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, seed, offset, n, out);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_version(void) { return MDMM_ABI_VERSION; }
+
+extern "C" const char* mdmm_strerror(int code) {
+  if (code == 0) return "ok";
+  if (code == MDMM_E_ARG) return "mdmm: bad argument (size or NULL pointer)";
+  if (code == MDMM_E_LIMIT) return "mdmm: exceeds MDMM_MAX_* or the 160 KiB LDS budget";
+  if (code == MDMM_E_ALIGN) return "mdmm: packed weight buffers must be 16-byte aligned";
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "mdmm: unknown error";
+}

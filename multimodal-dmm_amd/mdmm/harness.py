@@ -1,0 +1,91 @@
+"""Step harness: the per-batch body of the reference trainer (trainer.py:225-252) plus the
+one thing the reference does not have -- data-parallel scaling over the GPUs of a node.
+
+Sequences are independent units of the ELBO step (every op of the sweep is row-wise in the
+batch), so a batch is split contiguously over ranks, each rank runs `model.step` on its
+shard, normalises by the GLOBAL number of time-points, and one all-reduce(SUM) of a single
+flat fp32 gradient bucket (RCCL over xGMI; gloo in the CPU tests) makes every rank's Adam
+step identical.  No collective touches the sweep itself.
+"""
+import torch
+import torch.distributed as dist
+
+
+def anneal(min_val, max_val, t, anneal_len):
+    """Linear KLD warm-up (utils.py:24-29)."""
+    if t >= anneal_len:
+        return max_val
+    return (max_val - min_val) * t / anneal_len
+
+
+def kld_multiplier(b_num, epoch, n_batches, kld_mult_max, kld_anneal):
+    """trainer.py:227-229 (epochs start at 1, trainer.py:520, so the first batch is not 0)."""
+    return anneal(0.0, kld_mult_max, b_num + epoch * n_batches, kld_anneal * n_batches)
+
+
+class GradBucket:
+    """All parameter gradients as views of ONE flat fp32 buffer: autograd accumulates in
+    place, `allreduce` is a single collective over the whole model (messages 77 KB for the
+    z=32 Spirals model, 30 MB for the Weizmann model -- SURVEY.md section 2)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('no trainable parameters')
+        dev, total = self.params[0].device, sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    def check_views(self):
+        """Re-attach any gradient that was replaced (e.g. zero_grad(set_to_none=True))."""
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            view = self.flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = view
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                p.grad = view
+            off += n
+
+    def allreduce(self, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
+
+def shard_batch(inputs, mask, lengths, rank, world):
+    """Contiguous split of the batch dimension (dim 1 of the time-first tensors)."""
+    b_dim = len(lengths)
+    per = (b_dim + world - 1) // world
+    lo, hi = min(rank * per, b_dim), min((rank + 1) * per, b_dim)
+    sl = slice(lo, hi)
+    return ({k: v[:, sl].contiguous() for k, v in inputs.items()}, mask[:, sl].contiguous(),
+            list(lengths[lo:hi]))
+
+
+def elbo_step(model, optimizer, bucket, inputs, mask, lengths, kld_mult, rec_mults,
+              targets=None, n_points_global=None, clip_grad=None, group=None, **train_args):
+    """One ELBO step = trainer.py:237-252 on this rank's shard.
+
+    Returns the un-normalised local loss (detached).  n_points_global = sum of lengths over
+    ALL ranks (defaults to the local sum for single-process runs)."""
+    if n_points_global is None:
+        n_points_global = sum(lengths)
+    loss = model.step(inputs, mask, kld_mult, rec_mults, targets=targets, lengths=lengths,
+                      **train_args)
+    (loss / n_points_global).backward()
+    bucket.check_views()
+    bucket.allreduce(group)
+    if clip_grad is not None and clip_grad > 0:
+        torch.nn.utils.clip_grad_norm_(bucket.params, clip_grad)
+    optimizer.step()
+    bucket.zero()
+    return loss.detach()

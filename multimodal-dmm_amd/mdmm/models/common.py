@@ -1,0 +1,198 @@
+"""Parameter holders with the reference's module tree (models/common.py).
+
+These classes exist so that `state_dict()` keys, shapes, default initialisation and
+optimizer behaviour are identical to the reference's (checkpoints interchange both
+ways).  GaussianMLP / CategoricalMLP / GaussianGTF are also callable as plain modules
+(stock PyTorch-ROCm ops on the GPU) because encoders and decoders are user-pluggable
+modules on the far side of the kernel boundary; inside the BFVI sweep the GTF weights
+are consumed by the HIP kernels directly (mdmm.ops.PackedGtf) and this forward is not
+used.  The conv stacks mirror common.py:70-290 and always run as ordinary PyTorch
+modules (MIOpen) -- they are out of scope for hand-written kernels.
+"""
+import torch.nn as nn
+
+
+def _mlp_trunk(in_dim, h_dim):
+    return nn.Sequential(nn.Linear(in_dim, h_dim), nn.ReLU())
+
+
+class CategoricalMLP(nn.Module):
+    """in -> h -> softmax probs; forward returns the 1-tuple (probs,).  common.py:9-23"""
+
+    def __init__(self, in_dim, out_dim, h_dim):
+        super().__init__()
+        self.in_to_h = _mlp_trunk(in_dim, h_dim)
+        self.h_to_out = nn.Sequential(nn.Linear(h_dim, out_dim), nn.Softmax(dim=1))
+
+    def forward(self, x):
+        return (self.h_to_out(self.in_to_h(x)),)
+
+
+class GaussianMLP(nn.Module):
+    """in -> h -> (mean, softplus std + min_std).  common.py:25-41"""
+
+    def __init__(self, in_dim, out_dim, h_dim, min_std=1e-3):
+        super().__init__()
+        self.min_std = min_std
+        self.in_to_h = _mlp_trunk(in_dim, h_dim)
+        self.h_to_mean = nn.Linear(h_dim, out_dim)
+        self.h_to_std = nn.Sequential(nn.Linear(h_dim, out_dim), nn.Softplus())
+
+    def forward(self, x):
+        hid = self.in_to_h(x)
+        return self.h_to_mean(hid), self.h_to_std(hid) + self.min_std
+
+
+class GaussianGTF(nn.Module):
+    """Gated transition function weights.  common.py:43-68"""
+
+    def __init__(self, z_dim, h_dim, min_std=0):
+        super().__init__()
+        self.min_std = min_std
+        self.z_to_gate = nn.Sequential(nn.Linear(z_dim, h_dim), nn.ReLU(),
+                                       nn.Linear(h_dim, z_dim), nn.Sigmoid())
+        self.z_lin = nn.Linear(z_dim, z_dim)
+        self.z_nonlin = nn.Sequential(nn.Linear(z_dim, h_dim), nn.ReLU(),
+                                      nn.Linear(h_dim, z_dim))
+        self.z_to_std = nn.Sequential(nn.Linear(z_dim, z_dim), nn.Softplus())
+
+    def forward(self, z):
+        g = self.z_to_gate(z)
+        nonlin = self.z_nonlin(z)
+        return (1 - g) * self.z_lin(z) + g * nonlin, self.z_to_std(nonlin) + self.min_std
+
+
+class _ConvBlock(nn.Module):
+    """Shared shape of Conv / Deconv / AudioConv / AudioDeconv (common.py:70-112, 177-219).
+
+    The reference registers the conv twice (as `.conv`/`.deconv` and as `net.0`), so both
+    keys appear in checkpoints; the same aliasing is kept here."""
+
+    attr = 'conv'
+
+    def __init__(self, op, norm, n_channels, n_kernels, kernel_size, stride, padding, last):
+        super().__init__()
+        layer = op(n_channels, n_kernels, kernel_size, stride, padding)
+        setattr(self, self.attr, layer)
+        self.net = layer if last else nn.Sequential(layer, norm(n_kernels), nn.ReLU())
+        nn.init.xavier_uniform_(layer.weight)
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class Conv(_ConvBlock):
+    def __init__(self, n_channels, n_kernels, kernel_size=3, stride=2, padding=1, last=False):
+        super().__init__(nn.Conv2d, nn.BatchNorm2d, n_channels, n_kernels, kernel_size, stride,
+                         padding, last)
+
+
+class Deconv(_ConvBlock):
+    attr = 'deconv'
+
+    def __init__(self, n_channels, n_kernels, kernel_size=4, stride=2, padding=1, last=False):
+        super().__init__(nn.ConvTranspose2d, nn.BatchNorm2d, n_channels, n_kernels, kernel_size,
+                         stride, padding, last)
+
+
+class AudioConv(_ConvBlock):
+    def __init__(self, n_channels, n_kernels, kernel_size=3, stride=2, padding=1, last=False):
+        super().__init__(nn.Conv1d, nn.BatchNorm1d, n_channels, n_kernels, kernel_size, stride,
+                         padding, last)
+
+
+class AudioDeconv(_ConvBlock):
+    attr = 'deconv'
+
+    def __init__(self, n_channels, n_kernels, kernel_size=3, stride=2, padding=1, last=False):
+        super().__init__(nn.ConvTranspose1d, nn.BatchNorm1d, n_channels, n_kernels, kernel_size,
+                         stride, padding, last)
+
+
+def _pyramid(block, n_in, n_kernels, n_layers):
+    """Channel schedule of the encoders: n_in -> nk/2^(L-1) -> ... -> nk (last layer bare)."""
+    widths = [n_kernels // 2 ** (n_layers - 1 - i) for i in range(n_layers)]
+    chans = [n_in] + widths
+    return [block(chans[i], chans[i + 1], last=(i == n_layers - 1)) for i in range(n_layers)]
+
+
+def _inverse_pyramid(block, n_out, n_kernels, n_layers):
+    """Channel schedule of the decoders: nk -> nk/2 -> ... -> n_out (last layer bare)."""
+    chans = [n_kernels // 2 ** i for i in range(n_layers)] + [n_out]
+    return [block(chans[i], chans[i + 1], last=(i == n_layers - 1)) for i in range(n_layers)]
+
+
+class _GaussHead(nn.Module):
+    def _make_heads(self, z_dim):
+        self.feat_to_z_mean = nn.Linear(self.feat_dim, z_dim)
+        self.feat_to_z_std = nn.Sequential(nn.Linear(self.feat_dim, z_dim), nn.Softplus())
+        nn.init.xavier_uniform_(self.feat_to_z_mean.weight)
+        nn.init.xavier_uniform_(self.feat_to_z_std[0].weight)
+
+    def forward(self, x):
+        feats = self.conv_stack(x)
+        if not self.gauss_out:
+            return feats
+        flat = feats.view(-1, self.feat_dim)
+        return self.feat_to_z_mean(flat), self.feat_to_z_std(flat)
+
+
+class ImageEncoder(_GaussHead):
+    """common.py:114-145"""
+
+    def __init__(self, z_dim, gauss_out=True, img_size=64, n_channels=3, n_kernels=64,
+                 n_layers=3):
+        super().__init__()
+        self.feat_size = img_size // 2 ** n_layers
+        self.feat_dim = self.feat_size ** 2 * n_kernels
+        self.conv_stack = nn.Sequential(*_pyramid(Conv, n_channels, n_kernels, n_layers))
+        self.gauss_out = gauss_out
+        if gauss_out:
+            self._make_heads(z_dim)
+
+
+class AudioEncoder(_GaussHead):
+    """common.py:221-258"""
+
+    def __init__(self, z_dim, gauss_out=True, n_freqs=1281, n_frames=5, n_kernels=16,
+                 n_layers=3):
+        super().__init__()
+        self.feat_size = (n_freqs - 1) // 2 ** n_layers + 1
+        self.feat_dim = self.feat_size * n_kernels
+        self.conv_stack = nn.Sequential(*_pyramid(AudioConv, n_frames * 2, n_kernels, n_layers))
+        self.gauss_out = gauss_out
+        if gauss_out:
+            self._make_heads(z_dim)
+
+
+class _ProbDecoder(nn.Module):
+    def _make(self, z_dim, block, n_out, n_kernels, n_layers):
+        self.z_to_feat = nn.Sequential(nn.Linear(z_dim, self.feat_dim), nn.ReLU())
+        self.deconv_stack = nn.Sequential(
+            *(_inverse_pyramid(block, n_out, n_kernels, n_layers) + [nn.Sigmoid()]))
+        nn.init.xavier_uniform_(self.z_to_feat[0].weight)
+
+    def forward(self, z):
+        return (self.deconv_stack(self.z_to_feat(z).view(-1, *self.feat_shape)),)
+
+
+class ImageDecoder(_ProbDecoder):
+    """common.py:147-175"""
+
+    def __init__(self, z_dim, img_size=64, n_channels=3, n_kernels=64, n_layers=3):
+        super().__init__()
+        self.feat_size = img_size // 2 ** n_layers
+        self.feat_dim = self.feat_size ** 2 * n_kernels
+        self.feat_shape = (n_kernels, self.feat_size, self.feat_size)
+        self._make(z_dim, Deconv, n_channels, n_kernels, n_layers)
+
+
+class AudioDecoder(_ProbDecoder):
+    """common.py:260-290"""
+
+    def __init__(self, z_dim, n_freqs=1281, n_frames=5, n_kernels=16, n_layers=3):
+        super().__init__()
+        self.feat_size = (n_freqs - 1) // 2 ** n_layers + 1
+        self.feat_dim = self.feat_size * n_kernels
+        self.feat_shape = (n_kernels, self.feat_size)
+        self._make(z_dim, AudioDeconv, n_frames * 2, n_kernels, n_layers)

@@ -1,0 +1,95 @@
+"""Base class of the deep generative time-series models (reference: models/dgts.py).
+
+Same public surface as the reference's MultiDGTS -- product_of_experts,
+mean_of_experts, step, loss, kld_loss, rec_loss, _sample_gauss -- with every tensor
+operation dispatched to the HIP kernels of libmdmm_hip.so through mdmm.ops.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..noise import PhiloxNoise
+
+
+class MultiDGTS(nn.Module):
+    noise = None    # PhiloxNoise by default (set lazily), or a ReplayNoise for parity runs
+
+    def _noise(self):
+        if self.noise is None:
+            self.noise = PhiloxNoise()
+        return self.noise
+
+    # ---- Gaussian algebra -----------------------------------------------------------
+    def product_of_experts(self, mean, std, mask=None, eps=1e-8):
+        """dgts.py:15-51.  `eps` is fixed at the reference default inside the kernel."""
+        if eps != 1e-8:
+            raise ValueError('the PoE kernel uses the reference default eps=1e-8')
+        return ops.product_of_experts(mean, std, mask)
+
+    def mean_of_experts(self, mean, std, mask=None):
+        """dgts.py:53-83"""
+        return ops.mean_of_experts(mean, std, mask)
+
+    def _sample_gauss(self, mean, std):
+        """dgts.py:177-180 (noise from the model's noise source, on the model's device)."""
+        eps = self._noise().normal(std.shape, std.device)
+        return eps * std + mean
+
+    # ---- losses ---------------------------------------------------------------------
+    def kld_loss(self, infer, prior, mask=None):
+        """dgts.py:147-152"""
+        return ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask)
+
+    def _nll(self, m, recon_m, target, mask, lead_dims=2):
+        dist = self.dists[m]
+        if dist == 'Bernoulli':
+            return ops.nll_bernoulli(recon_m[0], target, mask, lead_dims)
+        if dist == 'Categorical':
+            return ops.nll_categorical(recon_m[0], target, mask, lead_dims)
+        if dist == 'Normal':
+            return ops.nll_gauss(recon_m[0], recon_m[1], target, mask, lead_dims)
+        return None
+
+    def rec_loss(self, inputs, recon, mask=None, rec_mults={}):
+        """dgts.py:154-175"""
+        total = 0.0
+        for m in self.modalities:
+            if m not in inputs:
+                continue
+            mult = rec_mults.get(m, 1.0)
+            if mult == 0:
+                continue
+            term = self._nll(m, recon[m], inputs[m], mask)
+            if term is not None:
+                total = total + mult * term
+        return total
+
+    def loss(self, inputs, infer, prior, recon, mask=1, kld_mult=1.0, rec_mults={}, avg=False):
+        """dgts.py:132-145"""
+        total = kld_mult * self.kld_loss(infer, prior, mask if torch.is_tensor(mask) else None)
+        total = total + self.rec_loss(inputs, recon, mask if torch.is_tensor(mask) else None,
+                                      rec_mults)
+        if avg:
+            if torch.is_tensor(mask):
+                total = total / mask.sum()
+            else:
+                shp = inputs[self.modalities[-1]].shape
+                total = total / (shp[0] * shp[1])
+        return total
+
+    def step(self, inputs, mask, kld_mult, rec_mults, targets=None, uni_loss=True, **kwargs):
+        """Generic multimodal + unimodal ELBO step, dgts.py:85-130: one forward per pass."""
+        inputs = {m: inputs[m] for m in inputs if m in self.modalities}
+        if targets is None:
+            targets = inputs
+        total = 0
+        if len(self.modalities) > 1:
+            infer, prior, recon = self.forward(inputs, **kwargs)
+            total = total + self.loss(targets, infer, prior, recon, mask, kld_mult, rec_mults)
+        if not uni_loss:
+            return total
+        for m in self.modalities:
+            infer, prior, recon = self.forward({m: inputs[m]}, **kwargs)
+            total = total + self.loss({m: targets[m]}, infer, prior, recon, mask, kld_mult,
+                                      rec_mults)
+        return total

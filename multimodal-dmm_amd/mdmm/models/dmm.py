@@ -1,0 +1,349 @@
+"""Multimodal Deep Markov Model with BFVI inference (reference: models/dmm.py).
+
+Drop-in for the reference's `models.dmm.MultiDMM`: same constructor, attributes,
+state_dict layout and public methods.  What differs is how the work is executed:
+
+* the filtering / smoothing sweeps (z_filter, dmm.py:319-412) run as ONE persistent HIP
+  kernel per sweep (mdmm_bfvi_sweep_fwd) instead of ~150 aten launches per timestep,
+  and their gradients come from a hand-written reverse scan (mdmm_bfvi_sweep_bwd);
+* `step` sweeps the multimodal pass and all unimodal passes (dgts.py:119-129) TOGETHER:
+  each modality is encoded once (the reference re-encodes it in every pass with
+  identical results), the passes become extra rows of the same kernel launch, and only
+  the reconstructions that enter the loss are decoded;
+* KL / NLL terms are fused masked reductions (mdmm_kld_gauss_*, mdmm_nll_*).
+
+Noise: in-kernel Philox by default; assign `model.noise = ReplayNoise(draws)` to replay
+draws recorded from the reference's `_sample_gauss` in its own call order.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import common
+from .dgts import MultiDGTS
+
+FILTER_MODES = ('ffilter', 'bfilter')
+SMOOTH_MODES = ('fsmooth', 'bsmooth')
+
+
+def _n_draws(t_max, sample, n_particles, sample_init):
+    """How many _sample_gauss calls one z_filter makes (dmm.py:398)."""
+    if sample or n_particles > 1:
+        return t_max
+    return 1 if sample_init else 0
+
+
+class MultiDMM(MultiDGTS):
+    def __init__(self, modalities, dims, dists=None, encoders=None, decoders=None,
+                 h_dim=32, z_dim=32, z0_mean=0.0, z0_std=1.0, min_std=1e-3,
+                 device=torch.device('cuda:0')):
+        """Arguments as in the reference (dmm.py:29-60)."""
+        super().__init__()
+        self.modalities = modalities
+        self.n_mods = len(modalities)
+        self.dims = dict(zip(modalities, dims))
+        self.h_dim, self.z_dim = h_dim, z_dim
+        if dists is None:
+            dists = ['Normal'] * self.n_mods
+        self.dists = dict(zip(modalities, dists))
+
+        # q'(z|x_m): default MLP encoders (dmm.py:73-85), user modules override (86-90)
+        self.enc = nn.ModuleDict()
+        for m in self.modalities:
+            n_in = int(np.prod(self.dims[m]))
+            if self.dists[m] == 'Categorical':
+                self.enc[m] = nn.Sequential(nn.Embedding(n_in, h_dim), nn.ReLU(),
+                                            common.GaussianMLP(h_dim, z_dim, h_dim))
+            else:
+                self.enc[m] = common.GaussianMLP(n_in, z_dim, h_dim)
+        if encoders is not None:
+            self.enc.update(list(zip(modalities, encoders)) if type(encoders) is list
+                            else encoders)
+        # p(x_m|z): default MLP decoders (dmm.py:93-101)
+        self.dec = nn.ModuleDict()
+        for m in self.modalities:
+            n_out = int(np.prod(self.dims[m]))
+            if self.dists[m] == 'Categorical':
+                self.dec[m] = common.CategoricalMLP(z_dim, n_out, h_dim)
+            else:
+                self.dec[m] = common.GaussianMLP(z_dim, n_out, h_dim)
+        if decoders is not None:
+            self.dec.update(list(zip(modalities, decoders)) if type(decoders) is list
+                            else decoders)
+        # q'(z|z_prev) both ways (dmm.py:110-112) and the global prior (115-117)
+        self.trans = nn.ModuleDict()
+        self.trans['fwd'] = common.GaussianGTF(z_dim, h_dim, min_std=min_std)
+        self.trans['bwd'] = common.GaussianGTF(z_dim, h_dim, min_std=min_std)
+        self.z0_mean = nn.Parameter(z0_mean * torch.ones(1, z_dim))
+        self.z0_log_std = nn.Parameter((z0_std * torch.ones(1, z_dim)).log())
+        self.min_std = min_std
+        self.device = device if torch.cuda.is_available() else torch.device('cpu')
+        self.to(self.device)
+
+    # ---- small pieces ---------------------------------------------------------------
+    def prior(self, shape):
+        """dmm.py:124-129"""
+        mean = self.z0_mean.repeat(*shape)
+        std = (self.z0_log_std.exp() + self.min_std).repeat(*shape)
+        mask = torch.ones(shape[:-1], dtype=torch.uint8, device=mean.device)
+        return mean, std, mask
+
+    def _encode_one(self, m, x):
+        """One modality -> ((T,B,D) mean, (T,B,D) std, (T,B) bool seen).  dmm.py:164-177"""
+        t_max, b_dim = x.shape[:2]
+        nan = torch.isnan(x)
+        seen = ~nan.flatten(2, -1).any(dim=-1)
+        x = torch.where(nan, torch.zeros_like(x), x)
+        if self.dists[m] == 'Categorical':
+            x = x.long()
+        mean, std = self.enc[m](x.flatten(0, 1))
+        return mean.reshape(t_max, b_dim, -1), std.reshape(t_max, b_dim, -1), seen
+
+    def encode(self, inputs, combine=False):
+        """dmm.py:131-190"""
+        means, stds, masks = [], [], []
+        for m in self.modalities:
+            if m not in inputs:
+                continue
+            mu, sd, seen = self._encode_one(m, inputs[m])
+            means.append(mu); stds.append(sd); masks.append(seen)
+        z_mean, z_std, masks = torch.stack(means), torch.stack(stds), torch.stack(masks)
+        if combine:
+            z_mean, z_std = self.product_of_experts(z_mean, z_std, masks)
+            masks = masks.any(dim=0)
+        return z_mean, z_std, masks
+
+    def decode(self, z):
+        """dmm.py:192-212: every modality is decoded from (T,B,D) latents."""
+        t_max, b_dim = z.shape[:2]
+        recon = dict()
+        for m in self.modalities:
+            out = self.dec[m](z.reshape(-1, self.z_dim))
+            recon[m] = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
+        return recon
+
+    def _gtf(self, direction):
+        return ops.gtf_param_list(self.trans[direction])
+
+    def z_next(self, z, direction='fwd', glb_prior=None):
+        """dmm.py:214-258: transition prior from particles z (K,B,D) -> (B,D) mean, std.
+        The global prior is always the model's own (what every caller passes)."""
+        return ops.gtf_transition(z, self._gtf(direction), self.z0_mean, self.z0_log_std,
+                                  self.h_dim, self.min_std)
+
+    def z_sample(self, t_max, b_dim, direction='fwd', sample=True, n_particles=1, z_init=None,
+                 inclusive=False):
+        """dmm.py:260-317 (z_init is not supported: the reference's own handling of it,
+        line 292, cannot run)."""
+        if z_init is not None:
+            raise NotImplementedError('z_init: see dmm.py:292 -- unusable in the reference')
+        glb_mean, glb_std, _ = self.prior((b_dim, 1))
+        mean_t, std_t = glb_mean, glb_std
+        means, stds = [], []
+        if inclusive:
+            means.append(mean_t); stds.append(std_t)
+        for _ in range(t_max - int(inclusive)):
+            if sample or n_particles > 1:
+                z_t = self._sample_gauss(mean_t.expand(n_particles, -1, -1),
+                                         std_t.expand(n_particles, -1, -1))
+            else:
+                z_t = mean_t.unsqueeze(0)
+            mean_t, std_t = self.z_next(z_t, direction)
+            means.append(mean_t); stds.append(std_t)
+        if direction == 'bwd':
+            means.reverse(); stds.reverse()
+        return torch.stack(means), torch.stack(stds)
+
+    def sample(self, t_max, b_dim, direction='fwd'):
+        """dmm.py:414-418"""
+        z_mean, _ = self.z_sample(t_max, b_dim, direction, sample=True)
+        return self.decode(z_mean)
+
+    # ---- the sweeps -----------------------------------------------------------------
+    def _eps_or_stream(self, cfg_kw, t_max, b_dim, n_pass, k, sample, sample_init, reverse,
+                       draws_per_pass):
+        """Replay mode: build the (P,T,K,B,D) eps tensor from recorded draws (time-indexed);
+        Philox mode: reserve a stream id."""
+        noise = self._noise()
+        if not noise.replay:
+            cfg_kw['seed'], cfg_kw['offset'] = noise.stream()
+            return None
+        n = _n_draws(t_max, sample, k, sample_init)
+        if n == 0:
+            return None
+        eps = torch.zeros(n_pass, t_max, k, b_dim, self.z_dim, dtype=torch.float32)
+        for p in range(n_pass):
+            for i, d in enumerate(draws_per_pass[p]):
+                eps[p, (t_max - 1 - i) if reverse else i] = d.reshape(k, b_dim, self.z_dim)
+        return eps.to(self.z0_mean.device)
+
+    def _sweep(self, experts, t_max, b_dim, n_pass, direction, sample, n_particles,
+               sample_init, use_inv_prior, need_samples, draws=None):
+        reverse = direction == 'bwd'
+        kw = dict(T=t_max, B=b_dim, D=self.z_dim, H=self.h_dim, P=n_pass, K=n_particles,
+                  reverse=reverse, sample=sample, sample_init=sample_init,
+                  use_inv_prior=use_inv_prior, min_std=self.min_std, need_samples=need_samples)
+        eps = self._eps_or_stream(kw, t_max, b_dim, n_pass, n_particles, sample, sample_init,
+                                  reverse, draws)
+        cfg = ops.SweepCfg(**kw)
+        return ops.bfvi_sweep(cfg, self._gtf(direction), self.z0_mean, self.z0_log_std, experts,
+                              eps)
+
+    def z_filter(self, z_mean, z_std, z_masks, direction='fwd', sample=True, n_particles=1,
+                 sample_init=False):
+        """dmm.py:319-412 for one pass.  z_mean/z_std (E,T,B,D), z_masks (E,T,B)."""
+        n_exp, t_max, b_dim = z_mean.shape[:3]
+        masks = z_masks.to(torch.float32)
+        experts = [ops.ExpertSpec(z_mean[e], z_std[e], masks[e], 1, False) for e in range(n_exp)]
+        draws = None
+        if self._noise().replay:
+            draws = [self.noise.take(_n_draws(t_max, sample, n_particles, sample_init))]
+        im, is_, pm, ps, zs = self._sweep(experts, t_max, b_dim, 1, direction, sample,
+                                          n_particles, sample_init, False, True, draws)
+        return (im[0], is_[0]), (pm[0], ps[0]), zs[0]
+
+    def _run_passes(self, enc, pass_mods, t_max, b_dim, mode, sample, sample_init,
+                    flt_particles, smt_particles):
+        """All passes of one mode in one (filter) or two (filter + smoother) launches.
+
+        enc: {m: (mean, std, seen)}; pass_mods: per pass, the modalities it conditions on.
+        Returns infer (mean, std), prior (mean, std), samples, each (P,T,B,D)."""
+        n_pass = len(pass_mods)
+        obs = []
+        for m in self.modalities:
+            if m not in enc:
+                continue
+            bits = sum(1 << p for p, mods in enumerate(pass_mods) if m in mods)
+            if bits:
+                mu, sd, seen = enc[m]
+                obs.append(ops.ExpertSpec(mu, sd, seen.to(torch.float32), bits, False))
+        smoothing = mode in SMOOTH_MODES
+        flt_dir = 'fwd' if mode in ('ffilter', 'bsmooth') else 'bwd'
+        flt_init = sample_init if mode in FILTER_MODES else False
+        replay = self._noise().replay
+        f_draws = s_draws = None
+        if replay:      # the reference runs the passes one after the other (dgts.py:119-129)
+            f_draws, s_draws = [], []
+            for _ in range(n_pass):
+                f_draws.append(self.noise.take(_n_draws(t_max, sample, flt_particles, flt_init)))
+                if smoothing:
+                    s_draws.append(self.noise.take(
+                        _n_draws(t_max, sample, smt_particles, sample_init)))
+        im, is_, pm, ps, zs = self._sweep(obs, t_max, b_dim, n_pass, flt_dir, sample,
+                                          flt_particles, flt_init, False, not smoothing, f_draws)
+        if smoothing:
+            smt_dir = 'fwd' if mode == 'fsmooth' else 'bwd'
+            flt_mask = torch.ones(t_max, b_dim, device=pm.device, dtype=torch.float32)
+            flt_mask[-1] = 0.0                                   # dmm.py:481 (both directions)
+            all_bits = (1 << n_pass) - 1
+            experts = obs + [ops.ExpertSpec(pm, ps, flt_mask, all_bits, True)]   # dmm.py:479-485
+            im, is_, pm, ps, zs = self._sweep(experts, t_max, b_dim, n_pass, smt_dir, sample,
+                                              smt_particles, sample_init, True, True, s_draws)
+        return (im, is_), (pm, ps), zs
+
+    @staticmethod
+    def _shape_of(inputs, lengths):
+        if lengths is not None:
+            return max(lengths), len(lengths)
+        first = inputs[next(iter(inputs))]
+        return first.shape[0], first.shape[1]
+
+    def forward(self, inputs, **kwargs):
+        """dmm.py:420-494.  Returns (infer, prior, recon)."""
+        mode = kwargs.get('mode', 'fsmooth')
+        sample = kwargs.get('sample', True)
+        sample_init = kwargs.get('sample_init', False)
+        flt_particles = kwargs.get('flt_particles', 1)
+        smt_particles = kwargs.get('smt_particles', 1)
+        present = [m for m in self.modalities if m in inputs]
+        t_max, b_dim = self._shape_of({m: inputs[m] for m in present}, kwargs.get('lengths'))
+        enc = {m: self._encode_one(m, inputs[m]) for m in present}
+        infer, prior, zs = self._run_passes(enc, [present], t_max, b_dim, mode, sample,
+                                            sample_init, flt_particles, smt_particles)
+        recon = self.decode(zs[0])
+        return (infer[0][0], infer[1][0]), (prior[0][0], prior[1][0]), recon
+
+    def kld_prior(self, n_particles, direction='fwd'):
+        """dmm.py:496-501"""
+        glb_mean, glb_std, _ = self.prior((1, 1, 1))
+        nxt_mean, nxt_std = self.z_sample(1, 1, direction, True, n_particles)
+        return ops.kld_gauss(glb_mean, glb_std, nxt_mean, nxt_std)
+
+    # ---- the ELBO step ----------------------------------------------------------------
+    def _decode_for_loss(self, m, z_list):
+        """Decode modality m for a list of (T,B,D) latents -> list of parameter tuples.
+        One batched decoder call, unless the decoder holds BatchNorm in training mode
+        (per-call batch statistics must then stay per pass, as in the reference)."""
+        dec = self.dec[m]
+        t_max, b_dim = z_list[0].shape[:2]
+        has_bn = dec.training and any(isinstance(x, nn.modules.batchnorm._BatchNorm)
+                                      for x in dec.modules())
+        if has_bn or len(z_list) == 1:
+            outs = [dec(z.reshape(-1, self.z_dim)) for z in z_list]
+            return [tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in o) for o in outs]
+        n = len(z_list)
+        out = dec(torch.stack(z_list).reshape(-1, self.z_dim))
+        out = [r.reshape(n, t_max, b_dim, *r.shape[1:]) for r in out]
+        return [tuple(r[i] for r in out) for i in range(n)]
+
+    def _mode_loss(self, enc, targets, mask, kld_mult, rec_mults, pass_mods, loss_mods, t_max,
+                   b_dim, mode, sample, sample_init, flt_particles, smt_particles):
+        """sum over passes of [kld_mult*KLD + sum_m mult_m*NLL_m]  (dgts.py:119-129, 132-145)"""
+        infer, prior, zs = self._run_passes(enc, pass_mods, t_max, b_dim, mode, sample,
+                                            sample_init, flt_particles, smt_particles)
+        total = kld_mult * ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask)
+        for m in self.modalities:
+            mult = rec_mults.get(m, 1.0)
+            used = [p for p, mods in enumerate(loss_mods) if m in mods]
+            if mult == 0 or not used:
+                continue
+            for rec in self._decode_for_loss(m, [zs[p] for p in used]):
+                total = total + mult * self._nll(m, rec, targets[m], mask)
+        return total
+
+    def step(self, inputs, mask, kld_mult, rec_mults, targets=None, uni_loss=True, **kwargs):
+        """Bidirectional training step, dmm.py:503-554 (see the module docstring for how the
+        passes are fused).  Returns the un-normalised loss (caller divides by sum(lengths))."""
+        f_mode = kwargs.get('f_mode', 'bfilter')
+        s_mode = kwargs.get('s_mode', 'fsmooth')
+        f_mult, s_mult = kwargs.get('f_mult', 0.5), kwargs.get('s_mult', 0.5)
+        match_mult = kwargs.get('match_mult', 0.01)
+        train_particles = kwargs.get('train_particles', 25)
+        match_particles = kwargs.get('match_particles', 50)
+        sample = kwargs.get('sample', True)
+        sample_init = kwargs.get('sample_init', False)
+        smt_particles = kwargs.get('smt_particles', 1)
+
+        inputs = {m: inputs[m] for m in inputs if m in self.modalities}    # dgts.py:113
+        if targets is None:
+            targets = inputs
+        t_max, b_dim = mask.shape[:2]
+        mask = mask.to(self.z0_mean.device)
+
+        loss = 0
+        if match_mult > 0:                                                   # dmm.py:540-545
+            n_obs = mask.sum().float()
+            loss = loss + match_mult * kld_mult * n_obs * self.kld_prior(match_particles, 'fwd')
+            loss = loss + match_mult * kld_mult * n_obs * self.kld_prior(match_particles, 'bwd')
+
+        # pass list of MultiDGTS.step (dgts.py:119-129): the multimodal pass, then unimodal
+        pass_mods, loss_mods = [], []
+        if len(self.modalities) > 1:
+            pass_mods.append([m for m in self.modalities if m in inputs])
+            loss_mods.append([m for m in self.modalities if m in targets])
+        if uni_loss:
+            pass_mods += [[m] for m in self.modalities]
+            loss_mods += [[m] for m in self.modalities]
+        if not pass_mods:
+            return loss
+        enc = {m: self._encode_one(m, inputs[m]) for m in self.modalities if m in inputs}
+        # each pass scores the modalities it was given (targets restricted the same way)
+        loss = loss + f_mult * self._mode_loss(enc, targets, mask, kld_mult, rec_mults, pass_mods,
+                                               loss_mods, t_max, b_dim, f_mode, sample,
+                                               sample_init, kwargs.get('flt_particles', 1),
+                                               smt_particles)
+        loss = loss + s_mult * self._mode_loss(enc, targets, mask, kld_mult, rec_mults, pass_mods,
+                                               loss_mods, t_max, b_dim, s_mode, sample,
+                                               sample_init, train_particles, smt_particles)
+        return loss

@@ -1,0 +1,110 @@
+"""ctypes binding of include/mdmm_hip.h (libmdmm_hip.so).
+
+The structures below mirror the C structs field for field.  Every wrapper takes raw
+device addresses (ints) so that this module stays free of torch; `mdmm.ops` is the
+layer that owns tensors and streams.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmdmm_hip.so')
+
+MAX_EXPERTS = 8
+MAX_PASSES = 8
+ABI_VERSION = 1
+
+SYMBOLS = [
+    'mdmm_version', 'mdmm_strerror', 'mdmm_pad',
+    'mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd',
+    'mdmm_sweep_spill_width_g', 'mdmm_sweep_spill_width_x',
+    'mdmm_poe_fwd', 'mdmm_poe_bwd', 'mdmm_moe_fwd', 'mdmm_moe_bwd',
+    'mdmm_kld_gauss_fwd', 'mdmm_kld_gauss_bwd',
+    'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
+    'mdmm_nll_bernoulli_fwd', 'mdmm_nll_bernoulli_bwd',
+    'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
+    'mdmm_philox_normal',
+]
+
+_P = C.c_void_p
+
+
+class Gtf(C.Structure):
+    _fields_ = [(n, _P) for n in ('w_in', 'wt_in', 'b_in', 'w_gate', 'wt_gate', 'b_gate',
+                                  'w_nl', 'wt_nl', 'b_nl', 'w_std', 'wt_std', 'b_std')]
+
+
+class Expert(C.Structure):
+    _fields_ = [('mean', _P), ('std', _P), ('mask', _P), ('g_mean', _P), ('g_std', _P),
+                ('pass_stride', C.c_int64), ('pass_bits', C.c_uint32), ('reserved', C.c_uint32)]
+
+
+class Sweep(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('T', 'B', 'D', 'H', 'P', 'K', 'E', 'reverse', 'sample',
+                                          'sample_init', 'use_inv_prior', 'trans_only')] +
+                [('min_std', C.c_float), ('reserved0', C.c_float),
+                 ('seed', C.c_uint64), ('offset', C.c_uint64),
+                 ('eps', _P), ('z_rows', _P), ('z0_mean', _P), ('z0_log_std', _P),
+                 ('gtf', Gtf), ('experts', Expert * MAX_EXPERTS),
+                 ('infer_mean', _P), ('infer_std', _P), ('prior_mean', _P), ('prior_std', _P),
+                 ('samples', _P),
+                 ('g_infer_mean', _P), ('g_infer_std', _P), ('g_prior_mean', _P),
+                 ('g_prior_std', _P), ('g_samples', _P),
+                 ('g_z0_mean', _P), ('g_z0_sigma', _P), ('g_z_rows', _P),
+                 ('spill_g', _P), ('spill_x', _P), ('spill_rows', C.c_int64)])
+
+
+class MdmmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Fails loudly: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MdmmError(
+                'libmdmm_hip.so not found at %s -- build it with `python __graft_entry__.py` '
+                '(or `make -C multimodal-dmm_amd/csrc`); the MDMM hot path has no CPU fallback'
+                % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.mdmm_strerror.restype = C.c_char_p
+        L.mdmm_strerror.argtypes = [C.c_int]
+        L.mdmm_version.restype = C.c_int
+        for name in ('mdmm_pad',):
+            getattr(L, name).argtypes = [C.c_int]
+        for name in ('mdmm_sweep_spill_width_g', 'mdmm_sweep_spill_width_x'):
+            getattr(L, name).argtypes = [C.c_int, C.c_int]
+        for name in ('mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd'):
+            getattr(L, name).argtypes = [C.POINTER(Sweep), _P]
+        i64, i32, f32 = C.c_int64, C.c_int, C.c_float
+        L.mdmm_poe_fwd.argtypes = [_P, _P, _P, i32, i64, i32, _P, _P, _P]
+        L.mdmm_poe_bwd.argtypes = [_P, _P, _P, i32, i64, i32, _P, _P, _P, _P, _P]
+        L.mdmm_moe_fwd.argtypes = [_P, _P, _P, i32, i64, i32, _P, _P, _P]
+        L.mdmm_moe_bwd.argtypes = [_P, _P, _P, i32, i64, i32, _P, _P, _P, _P, _P, _P, _P]
+        L.mdmm_kld_gauss_fwd.argtypes = [_P, _P, _P, _P, _P, i64, i32, _P, _P]
+        L.mdmm_kld_gauss_bwd.argtypes = [_P, _P, _P, _P, _P, i64, i32, f32, _P, _P, _P, _P, i32, _P]
+        L.mdmm_nll_gauss_fwd.argtypes = [_P, _P, _P, _P, i64, i32, _P, _P]
+        L.mdmm_nll_gauss_bwd.argtypes = [_P, _P, _P, _P, i64, i32, f32, _P, _P, _P]
+        L.mdmm_nll_bernoulli_fwd.argtypes = [_P, _P, _P, i64, i32, _P, _P]
+        L.mdmm_nll_bernoulli_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
+        L.mdmm_nll_categorical_fwd.argtypes = [_P, _P, _P, i64, i32, _P, _P]
+        L.mdmm_nll_categorical_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
+        L.mdmm_philox_normal.argtypes = [C.c_uint64, C.c_uint64, i64, _P, _P]
+        if L.mdmm_version() != ABI_VERSION:
+            raise MdmmError('libmdmm_hip.so ABI %d != binding ABI %d'
+                            % (L.mdmm_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise MdmmError('%s failed: %s (code %d)' % (what, lib().mdmm_strerror(code).decode(), code))
+
+
+def pad(n):
+    return (int(n) + 3) & ~3

@@ -1,0 +1,571 @@
+"""torch.autograd glue around the C ABI (mdmm.native).
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and the autograd
+graph between the user's encoder / decoder modules and the hand-written kernels.  Every
+function launches HIP kernels from libmdmm_hip.so; none of them has a torch fallback
+and all of them raise when handed CPU tensors.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import torch
+
+from . import native
+from .native import pad
+
+ExpertSpec = namedtuple('ExpertSpec', 'mean std mask pass_bits per_pass')
+ExpertSpec.__doc__ = """One Gaussian expert of the per-step product (include/mdmm_hip.h,
+mdmm_expert_t): mean/std (T,B,D) or (P,T,B,D) when per_pass, mask (T,B) float or None."""
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise native.MdmmError(
+                'the MDMM kernels run on an MI355X only: got a %s tensor (no CPU fallback)'
+                % t.device)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class KernelTimer:
+    """Brackets every kernel launch of this module with HIP events recorded on the stream
+    the kernel is launched on (torch's current stream); used by bench.py for the roofline."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def add(self, tag, e0, e1):
+        self.spans.setdefault(tag, []).append((e0, e1))
+
+    def summary(self):
+        """{tag: (launches, total_ms)} -- call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.spans.items()}
+
+
+TIMER = None    # assign a KernelTimer to switch per-launch timing on
+
+
+def _call(name, *args, tag=None):
+    fn = getattr(native.lib(), name)
+    if TIMER is None:
+        native.check(fn(*args, _stream()), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    native.check(fn(*args, _stream()), name)
+    e1.record()
+    TIMER.add(tag or name, e0, e1)
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------
+# GTF weight packing (layout documented at mdmm_gtf_t in include/mdmm_hip.h)
+# ------------------------------------------------------------------------------------
+GTF_KEYS = ('z_to_gate.0', 'z_to_gate.2', 'z_lin', 'z_nonlin.0', 'z_nonlin.2', 'z_to_std.0')
+
+
+def gtf_param_list(gtf):
+    """12 tensors in GTF_KEYS order (weight, bias each) from a GaussianGTF holder."""
+    mods = (gtf.z_to_gate[0], gtf.z_to_gate[2], gtf.z_lin, gtf.z_nonlin[0], gtf.z_nonlin[2],
+            gtf.z_to_std[0])
+    out = []
+    for m in mods:
+        out += [m.weight, m.bias]
+    return out
+
+
+class PackedGtf:
+    """Padded, fused, both-orientation copy of one GaussianGTF's weights in ONE buffer."""
+
+    def __init__(self, params, D, H):
+        W1g, b1g, W2g, b2g, Wl, bl, W1n, b1n, W2n, b2n, Ws, bs = [p.detach() for p in params]
+        self.D, self.H = D, H
+        Dp, Hp = pad(D), pad(H)
+        self.Dp, self.Hp, self.F1 = Dp, Hp, 2 * Hp + Dp
+        dev = W1g.device
+
+        def padded(w, r, c):
+            if tuple(w.shape) == (r, c):
+                return w
+            out = torch.zeros(r, c, device=dev, dtype=torch.float32)
+            out[:w.shape[0], :w.shape[1]] = w
+            return out
+
+        def padded1(b, n):
+            if b.shape[0] == n:
+                return b
+            out = torch.zeros(n, device=dev, dtype=torch.float32)
+            out[:b.shape[0]] = b
+            return out
+
+        w_in = torch.cat([padded(W1g, Hp, Dp), padded(W1n, Hp, Dp), padded(Wl, Dp, Dp)], 0)
+        b_in = torch.cat([padded1(b1g, Hp), padded1(b1n, Hp), padded1(bl, Dp)])
+        w_gate, w_nl, w_std = padded(W2g, Dp, Hp), padded(W2n, Dp, Hp), padded(Ws, Dp, Dp)
+        pieces = [('w_in', w_in), ('wt_in', w_in.t()), ('b_in', b_in),
+                  ('w_gate', w_gate), ('wt_gate', w_gate.t()), ('b_gate', padded1(b2g, Dp)),
+                  ('w_nl', w_nl), ('wt_nl', w_nl.t()), ('b_nl', padded1(b2n, Dp)),
+                  ('w_std', w_std), ('wt_std', w_std.t()), ('b_std', padded1(bs, Dp))]
+        self.buf = torch.cat([p.reshape(-1) for _, p in pieces])   # every piece a multiple of 4
+        self.offsets, off = {}, 0
+        for name, p in pieces:
+            self.offsets[name] = off
+            off += p.numel()
+        assert self.buf.data_ptr() % 16 == 0
+
+    def fill(self, g):
+        base = self.buf.data_ptr()
+        for name, off in self.offsets.items():
+            setattr(g, name, base + 4 * off)
+
+    def unpack_grads(self, G, X, like):
+        """Weight/bias gradients of the 12 raw parameters from the spilled GEMM operands.
+        dW = G^T X per layer: plain GEMMs with the contraction over all transition rows."""
+        D, H, Dp, Hp, F1 = self.D, self.H, self.Dp, self.Hp, self.F1
+        if G is None or G.shape[0] == 0:
+            return [torch.zeros_like(p) for p in like]
+        gb = G.sum(0)
+        d_in = G[:, :F1].t() @ X[:, :Dp]
+        d_gate = G[:, F1:F1 + Dp].t() @ X[:, Dp:Dp + Hp]
+        d_nl = G[:, F1 + Dp:F1 + 2 * Dp].t() @ X[:, Dp + Hp:Dp + 2 * Hp]
+        d_std = G[:, F1 + 2 * Dp:].t() @ X[:, Dp + 2 * Hp:]
+        return [d_in[0:H, :D], gb[0:H],                                   # z_to_gate.0
+                d_gate[:D, :H], gb[F1:F1 + D],                            # z_to_gate.2
+                d_in[2 * Hp:2 * Hp + D, :D], gb[2 * Hp:2 * Hp + D],       # z_lin
+                d_in[Hp:Hp + H, :D], gb[Hp:Hp + H],                       # z_nonlin.0
+                d_nl[:D, :H], gb[F1 + Dp:F1 + Dp + D],                    # z_nonlin.2
+                d_std[:D, :D], gb[F1 + 2 * Dp:F1 + 2 * Dp + D]]           # z_to_std.0
+
+
+# ------------------------------------------------------------------------------------
+# The sweep
+# ------------------------------------------------------------------------------------
+class SweepCfg:
+    """Static description of one sweep launch (sizes + flags of mdmm_sweep_t)."""
+
+    def __init__(self, T, B, D, H, P=1, K=1, reverse=False, sample=True, sample_init=False,
+                 use_inv_prior=False, min_std=1e-3, seed=0, offset=0, need_samples=True,
+                 trans_only=False):
+        self.T, self.B, self.D, self.H, self.P, self.K = T, B, D, H, P, K
+        self.reverse, self.sample, self.sample_init = bool(reverse), bool(sample), bool(sample_init)
+        self.use_inv_prior, self.min_std = bool(use_inv_prior), float(min_std)
+        self.seed, self.offset = int(seed), int(offset)
+        self.need_samples, self.trans_only = bool(need_samples), bool(trans_only)
+
+
+def _sweep_tag(which, cfg):
+    if cfg.trans_only:
+        return 'trans_%s[K=%d]' % (which, cfg.K)
+    return 'sweep_%s[P=%d,K=%d,%s%s]' % (which, cfg.P, cfg.K, 'rev' if cfg.reverse else 'fwd',
+                                         ',inv' if cfg.use_inv_prior else '')
+
+
+def _fill_common(s, cfg, z0_mean, z0_log_std, packed, eps):
+    s.T, s.B, s.D, s.H, s.P, s.K = cfg.T, cfg.B, cfg.D, cfg.H, cfg.P, cfg.K
+    s.reverse, s.sample, s.sample_init = int(cfg.reverse), int(cfg.sample), int(cfg.sample_init)
+    s.use_inv_prior, s.trans_only = int(cfg.use_inv_prior), int(cfg.trans_only)
+    s.min_std = cfg.min_std
+    s.seed, s.offset = cfg.seed, cfg.offset
+    s.eps = _ptr(eps)
+    s.z0_mean, s.z0_log_std = _ptr(z0_mean), _ptr(z0_log_std)
+    packed.fill(s.gtf)
+
+
+class _SweepFn(torch.autograd.Function):
+    """MultiDMM.z_filter (dmm.py:319-412) for P passes at once -> mdmm_bfvi_sweep_fwd/_bwd."""
+
+    @staticmethod
+    def forward(ctx, cfg, eps, masks, bits, per_pass, z0_mean, z0_log_std, *tensors):
+        ctx.set_materialize_grads(False)
+        gtf_params, flat = tensors[:12], tensors[12:]
+        n_exp = len(flat) // 2
+        means = [_f32c(t) for t in flat[:n_exp]]
+        stds = [_f32c(t) for t in flat[n_exp:]]
+        _need_gpu(z0_mean, z0_log_std, *means, *stds)
+        if n_exp > native.MAX_EXPERTS or cfg.P > native.MAX_PASSES:
+            raise native.MdmmError('too many experts / passes for one sweep')
+        dev = z0_mean.device
+        packed = PackedGtf(gtf_params, cfg.D, cfg.H)
+        z0m, z0s = _f32c(z0_mean.detach().reshape(-1)), _f32c(z0_log_std.detach().reshape(-1))
+        shape = (cfg.P, cfg.T, cfg.B, cfg.D)
+        out = [torch.empty(shape, device=dev, dtype=torch.float32) for _ in range(4)]
+        smp = torch.empty(shape, device=dev, dtype=torch.float32) if cfg.need_samples else None
+        s = native.Sweep()
+        _fill_common(s, cfg, z0m, z0s, packed, eps)
+        s.E = n_exp
+        tbd = cfg.T * cfg.B * cfg.D
+        for e in range(n_exp):
+            ex = s.experts[e]
+            ex.mean, ex.std, ex.mask = _ptr(means[e]), _ptr(stds[e]), _ptr(masks[e])
+            ex.pass_stride = tbd if per_pass[e] else 0
+            ex.pass_bits = bits[e]
+        s.infer_mean, s.infer_std, s.prior_mean, s.prior_std = [_ptr(o) for o in out]
+        s.samples = _ptr(smp)
+        _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('fwd', cfg))
+        ctx.cfg, ctx.eps, ctx.masks, ctx.bits, ctx.per_pass = cfg, eps, masks, bits, per_pass
+        ctx.packed, ctx.n_exp = packed, n_exp
+        ctx.gtf_like = [p.detach() for p in gtf_params]
+        ctx.save_for_backward(z0m, z0s, out[0], out[1], out[2], out[3], *means, *stds)
+        ctx.z0_shapes = (z0_mean.shape, z0_log_std.shape)
+        ctx.in_shapes = [t.shape for t in flat]
+        if smp is None:
+            smp = out[0].new_empty(0)
+            ctx.mark_non_differentiable(smp)
+        return out[0], out[1], out[2], out[3], smp
+
+    @staticmethod
+    def backward(ctx, g_im, g_is, g_pm, g_ps, g_smp):
+        cfg, n_exp, packed = ctx.cfg, ctx.n_exp, ctx.packed
+        saved = ctx.saved_tensors
+        z0m, z0s, im, is_, pm, ps = saved[:6]
+        means, stds = saved[6:6 + n_exp], saved[6 + n_exp:]
+        dev = z0m.device
+        gin = [_f32c(g) for g in (g_im, g_is, g_pm, g_ps, g_smp if cfg.need_samples else None)]
+        s = native.Sweep()
+        _fill_common(s, cfg, z0m, z0s, packed, ctx.eps)
+        s.E = n_exp
+        tbd = cfg.T * cfg.B * cfg.D
+        g_means, g_stds = [], []
+        for e in range(n_exp):
+            ex = s.experts[e]
+            ex.mean, ex.std, ex.mask = _ptr(means[e]), _ptr(stds[e]), _ptr(ctx.masks[e])
+            ex.pass_stride = tbd if ctx.per_pass[e] else 0
+            ex.pass_bits = ctx.bits[e]
+            need = ctx.needs_input_grad[7 + 12 + e] or ctx.needs_input_grad[7 + 12 + n_exp + e]
+            if need:
+                # every element is written (passes without the expert write zeros via the
+                # shared-expert sum; per-pass experts are written only for their own passes)
+                gm = (torch.zeros_like(means[e]) if ctx.per_pass[e] else torch.empty_like(means[e]))
+                gs = (torch.zeros_like(stds[e]) if ctx.per_pass[e] else torch.empty_like(stds[e]))
+                ex.g_mean, ex.g_std = _ptr(gm), _ptr(gs)
+            else:
+                gm = gs = None
+            g_means.append(gm)
+            g_stds.append(gs)
+        s.infer_mean, s.infer_std, s.prior_mean, s.prior_std = _ptr(im), _ptr(is_), _ptr(pm), _ptr(ps)
+        (s.g_infer_mean, s.g_infer_std, s.g_prior_mean, s.g_prior_std,
+         s.g_samples) = [_ptr(g) for g in gin]
+        gz0 = torch.zeros(2, cfg.D, device=dev, dtype=torch.float32)
+        s.g_z0_mean, s.g_z0_sigma = gz0[0].data_ptr(), gz0[1].data_ptr()
+        rows = cfg.P * cfg.B * cfg.K * (cfg.T - 1)
+        G = X = None
+        if rows > 0:
+            L = native.lib()
+            G = torch.empty(rows, L.mdmm_sweep_spill_width_g(cfg.D, cfg.H), device=dev)
+            X = torch.empty(rows, L.mdmm_sweep_spill_width_x(cfg.D, cfg.H), device=dev)
+            s.spill_g, s.spill_x, s.spill_rows = _ptr(G), _ptr(X), rows
+        _call('mdmm_bfvi_sweep_bwd', C.byref(s), tag=_sweep_tag('bwd', cfg))
+        g_gtf = packed.unpack_grads(G, X, ctx.gtf_like)
+        g_z0_mean = gz0[0].reshape(ctx.z0_shapes[0])
+        g_z0_log = (gz0[1] * torch.exp(z0s)).reshape(ctx.z0_shapes[1])
+        g_flat = ([g.reshape(sh) if g is not None else None
+                   for g, sh in zip(g_means, ctx.in_shapes[:n_exp])] +
+                  [g.reshape(sh) if g is not None else None
+                   for g, sh in zip(g_stds, ctx.in_shapes[n_exp:])])
+        return (None, None, None, None, None, g_z0_mean, g_z0_log, *g_gtf, *g_flat)
+
+
+def bfvi_sweep(cfg, gtf_params, z0_mean, z0_log_std, experts, eps=None):
+    """Run one filtering / smoothing sweep for cfg.P passes.
+
+    experts: list of ExpertSpec.  Returns (infer_mean, infer_std, prior_mean, prior_std,
+    samples), each (P,T,B,D) (samples is empty when cfg.need_samples is False)."""
+    masks = [_f32c(e.mask) for e in experts]
+    bits = [int(e.pass_bits) for e in experts]
+    per_pass = [bool(e.per_pass) for e in experts]
+    _need_gpu(eps, *masks)
+    tensors = list(gtf_params) + [e.mean for e in experts] + [e.std for e in experts]
+    return _SweepFn.apply(cfg, _f32c(eps), masks, bits, per_pass, z0_mean, z0_log_std, *tensors)
+
+
+class _TransFn(torch.autograd.Function):
+    """MultiDMM.z_next (dmm.py:214-258) on given particles (K,B,D) -> (B,D) mean, std."""
+
+    @staticmethod
+    def forward(ctx, cfg, z_rows, z0_mean, z0_log_std, *gtf_params):
+        ctx.set_materialize_grads(False)
+        _need_gpu(z_rows, z0_mean, z0_log_std)
+        z = _f32c(z_rows)
+        dev = z.device
+        packed = PackedGtf(gtf_params, cfg.D, cfg.H)
+        z0m, z0s = _f32c(z0_mean.detach().reshape(-1)), _f32c(z0_log_std.detach().reshape(-1))
+        pm = torch.empty(cfg.B, cfg.D, device=dev, dtype=torch.float32)
+        ps = torch.empty_like(pm)
+        s = native.Sweep()
+        _fill_common(s, cfg, z0m, z0s, packed, None)
+        s.E = 0
+        s.z_rows = _ptr(z)
+        s.prior_mean, s.prior_std = _ptr(pm), _ptr(ps)
+        _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('fwd', cfg))
+        ctx.cfg, ctx.packed = cfg, packed
+        ctx.gtf_like = [p.detach() for p in gtf_params]
+        ctx.z0_shapes = (z0_mean.shape, z0_log_std.shape)
+        ctx.save_for_backward(z, z0m, z0s, pm, ps)
+        return pm, ps
+
+    @staticmethod
+    def backward(ctx, g_pm, g_ps):
+        cfg, packed = ctx.cfg, ctx.packed
+        z, z0m, z0s, pm, ps = ctx.saved_tensors
+        dev = z.device
+        s = native.Sweep()
+        _fill_common(s, cfg, z0m, z0s, packed, None)
+        s.E = 0
+        s.z_rows = _ptr(z)
+        s.prior_mean, s.prior_std = _ptr(pm), _ptr(ps)
+        g_pm, g_ps = _f32c(g_pm), _f32c(g_ps)
+        s.g_prior_mean, s.g_prior_std = _ptr(g_pm), _ptr(g_ps)
+        gz = torch.empty_like(z)
+        s.g_z_rows = _ptr(gz)
+        gz0 = torch.zeros(2, cfg.D, device=dev, dtype=torch.float32)
+        s.g_z0_mean, s.g_z0_sigma = gz0[0].data_ptr(), gz0[1].data_ptr()
+        rows = cfg.B * cfg.K
+        L = native.lib()
+        G = torch.empty(rows, L.mdmm_sweep_spill_width_g(cfg.D, cfg.H), device=dev)
+        X = torch.empty(rows, L.mdmm_sweep_spill_width_x(cfg.D, cfg.H), device=dev)
+        s.spill_g, s.spill_x, s.spill_rows = _ptr(G), _ptr(X), rows
+        _call('mdmm_bfvi_sweep_bwd', C.byref(s), tag=_sweep_tag('bwd', cfg))
+        g_gtf = packed.unpack_grads(G, X, ctx.gtf_like)
+        return (None, gz, gz0[0].reshape(ctx.z0_shapes[0]),
+                (gz0[1] * torch.exp(z0s)).reshape(ctx.z0_shapes[1]), *g_gtf)
+
+
+def gtf_transition(z_rows, gtf_params, z0_mean, z0_log_std, H, min_std):
+    K, B, D = z_rows.shape
+    cfg = SweepCfg(T=1, B=B, D=D, H=H, P=1, K=K, min_std=min_std, trans_only=True)
+    return _TransFn.apply(cfg, z_rows, z0_mean, z0_log_std, *gtf_params)
+
+
+# ------------------------------------------------------------------------------------
+# stand-alone product / mixture of experts
+# ------------------------------------------------------------------------------------
+def _mask_f32(mask, like):
+    if mask is None:
+        return None
+    return mask.to(device=like.device, dtype=torch.float32).contiguous()
+
+
+class _PoeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, std, mask):
+        ctx.set_materialize_grads(False)
+        _need_gpu(mean, std)
+        m, s = _f32c(mean), _f32c(std)
+        E, D = m.shape[0], m.shape[-1]
+        N = m[0].numel() // D
+        om, os_ = torch.empty_like(m[0]), torch.empty_like(m[0])
+        _call('mdmm_poe_fwd', _ptr(m), _ptr(s), _ptr(mask), E, N, D, _ptr(om),
+                                               _ptr(os_))
+        ctx.save_for_backward(m, s)
+        ctx.mask, ctx.dims = mask, (E, N, D)
+        return om, os_
+
+    @staticmethod
+    def backward(ctx, g_om, g_os):
+        m, s = ctx.saved_tensors
+        E, N, D = ctx.dims
+        gm, gs = torch.empty_like(m), torch.empty_like(s)
+        _call('mdmm_poe_bwd', _ptr(m), _ptr(s), _ptr(ctx.mask), E, N, D,
+                                               _ptr(_f32c(g_om)), _ptr(_f32c(g_os)), _ptr(gm),
+                                               _ptr(gs))
+        return gm, gs, None
+
+
+def product_of_experts(mean, std, mask=None):
+    """dgts.py:15-51 on the GPU (eps fixed at the reference default 1e-8)."""
+    return _PoeFn.apply(mean, std, _mask_f32(mask, mean))
+
+
+class _MoeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, std, mask):
+        ctx.set_materialize_grads(False)
+        _need_gpu(mean, std)
+        m, s = _f32c(mean), _f32c(std)
+        E, D = m.shape[0], m.shape[-1]
+        N = m[0].numel() // D
+        om, os_ = torch.empty_like(m[0]), torch.empty_like(m[0])
+        _call('mdmm_moe_fwd', _ptr(m), _ptr(s), _ptr(mask), E, N, D, _ptr(om),
+                                               _ptr(os_))
+        ctx.save_for_backward(m, s, om, os_)
+        ctx.mask, ctx.dims = mask, (E, N, D)
+        return om, os_
+
+    @staticmethod
+    def backward(ctx, g_om, g_os):
+        m, s, om, os_ = ctx.saved_tensors
+        E, N, D = ctx.dims
+        gm, gs = torch.empty_like(m), torch.empty_like(s)
+        _call('mdmm_moe_bwd', _ptr(m), _ptr(s), _ptr(ctx.mask), E, N, D, _ptr(om),
+                                               _ptr(os_), _ptr(_f32c(g_om)), _ptr(_f32c(g_os)),
+                                               _ptr(gm), _ptr(gs))
+        return gm, gs, None
+
+
+def mean_of_experts(mean, std, mask=None):
+    """dgts.py:53-83 on the GPU."""
+    return _MoeFn.apply(mean, std, _mask_f32(mask, mean))
+
+
+# ------------------------------------------------------------------------------------
+# loss reductions
+# ------------------------------------------------------------------------------------
+def _row_mask(mask, rows, like):
+    """(T,B,1)/(T,B) sequence mask -> float (rows,), tiled when passes are stacked."""
+    if mask is None or not torch.is_tensor(mask):
+        return None
+    m = mask.to(device=like.device, dtype=torch.float32).reshape(-1)
+    if m.numel() != rows:
+        if rows % m.numel():
+            raise ValueError('mask of %d entries does not tile %d rows' % (m.numel(), rows))
+        m = m.repeat(rows // m.numel())
+    return m.contiguous()
+
+
+def _scalar(acc):
+    return acc.to(torch.float32).reshape(())
+
+
+class _KldFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, m1, s1, m2, s2, mask, rows, inner):
+        _need_gpu(m1, s1, m2, s2)
+        t = [_f32c(x) for x in (m1, s1, m2, s2)]
+        acc = torch.zeros(1, dtype=torch.float64, device=t[0].device)
+        _call('mdmm_kld_gauss_fwd', *[_ptr(x) for x in t], _ptr(mask), rows, inner,
+                                                     _ptr(acc))
+        ctx.save_for_backward(*t)
+        ctx.mask, ctx.rows, ctx.inner = mask, rows, inner
+        return _scalar(acc)
+
+    @staticmethod
+    def backward(ctx, g):
+        t = ctx.saved_tensors
+        grads = [torch.empty_like(x) if need else None
+                 for x, need in zip(t, ctx.needs_input_grad[:4])]
+        # scale is applied on the device side of the tensor product to stay async
+        _call('mdmm_kld_gauss_bwd', *[_ptr(x) for x in t], _ptr(ctx.mask), ctx.rows,
+                                                     ctx.inner, 1.0, *[_ptr(x) for x in grads], 0)
+        return tuple(None if x is None else x * g for x in grads) + (None, None, None)
+
+
+def kld_gauss(mean_1, std_1, mean_2, std_2, mask=None):
+    """losses.py:14-21; all four tensors share one shape (..., D); mask covers the leading dims."""
+    mean_1, std_1, mean_2, std_2 = torch.broadcast_tensors(mean_1, std_1, mean_2, std_2)
+    inner = mean_1.shape[-1]
+    rows = mean_1.numel() // inner
+    return _KldFn.apply(mean_1, std_1, mean_2, std_2, _row_mask(mask, rows, mean_1), rows, inner)
+
+
+class _NllGaussFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, std, x, mask, rows, inner):
+        _need_gpu(mean, std, x)
+        m, s, xv = _f32c(mean), _f32c(std), _f32c(x)
+        acc = torch.zeros(1, dtype=torch.float64, device=m.device)
+        _call('mdmm_nll_gauss_fwd', _ptr(m), _ptr(s), _ptr(xv), _ptr(mask), rows,
+                                                     inner, _ptr(acc))
+        ctx.save_for_backward(m, s, xv)
+        ctx.mask, ctx.rows, ctx.inner = mask, rows, inner
+        return _scalar(acc)
+
+    @staticmethod
+    def backward(ctx, g):
+        m, s, xv = ctx.saved_tensors
+        gm, gs = torch.empty_like(m), torch.empty_like(s)
+        _call('mdmm_nll_gauss_bwd', _ptr(m), _ptr(s), _ptr(xv), _ptr(ctx.mask),
+                                                     ctx.rows, ctx.inner, 1.0, _ptr(gm), _ptr(gs))
+        return gm * g, gs * g, None, None, None, None
+
+
+def nll_gauss(mean, std, x, mask=None, lead_dims=2):
+    """losses.py:68-89.  The first `lead_dims` dims of x are (T,B) (or (P*T,B) ...)."""
+    rows = 1
+    for v in x.shape[:lead_dims]:
+        rows *= v
+    inner = x.numel() // rows
+    return _NllGaussFn.apply(mean, std, x, _row_mask(mask, rows, x), rows, inner)
+
+
+class _NllBernFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, theta, x, mask, rows, inner):
+        _need_gpu(theta, x)
+        th, xv = _f32c(theta), _f32c(x)
+        acc = torch.zeros(1, dtype=torch.float64, device=th.device)
+        _call('mdmm_nll_bernoulli_fwd', _ptr(th), _ptr(xv), _ptr(mask), rows, inner,
+                                                         _ptr(acc))
+        ctx.save_for_backward(th, xv)
+        ctx.mask, ctx.rows, ctx.inner = mask, rows, inner
+        return _scalar(acc)
+
+    @staticmethod
+    def backward(ctx, g):
+        th, xv = ctx.saved_tensors
+        gt = torch.empty_like(th)
+        _call('mdmm_nll_bernoulli_bwd', _ptr(th), _ptr(xv), _ptr(ctx.mask),
+                                                         ctx.rows, ctx.inner, 1.0, _ptr(gt))
+        return gt * g, None, None, None, None
+
+
+def nll_bernoulli(theta, x, mask=None, lead_dims=2):
+    """losses.py:23-42."""
+    rows = 1
+    for v in x.shape[:lead_dims]:
+        rows *= v
+    inner = x.numel() // rows
+    return _NllBernFn.apply(theta, x, _row_mask(mask, rows, x), rows, inner)
+
+
+class _NllCatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probs, x, mask, rows, n_cat):
+        _need_gpu(probs, x)
+        p, xv = _f32c(probs), _f32c(x)
+        acc = torch.zeros(1, dtype=torch.float64, device=p.device)
+        _call('mdmm_nll_categorical_fwd', _ptr(p), _ptr(xv), _ptr(mask), rows,
+                                                           n_cat, _ptr(acc))
+        ctx.save_for_backward(p, xv)
+        ctx.mask, ctx.rows, ctx.n_cat = mask, rows, n_cat
+        return _scalar(acc)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, xv = ctx.saved_tensors
+        gp = torch.empty_like(p)
+        _call('mdmm_nll_categorical_bwd', _ptr(p), _ptr(xv), _ptr(ctx.mask),
+                                                           ctx.rows, ctx.n_cat, 1.0, _ptr(gp))
+        return gp * g, None, None, None, None
+
+
+def nll_categorical(probs, x, mask=None, lead_dims=2):
+    """losses.py:44-66 (reference behaviour: minus the summed probability of the label).
+    probs (T,B,K), x (T,B,1) float labels with NaN = missing."""
+    rows = 1
+    for v in x.shape[:lead_dims]:
+        rows *= v
+    if x.numel() != rows:
+        raise ValueError('categorical targets must have one label per (t, b)')
+    n_cat = probs.numel() // rows
+    return _NllCatFn.apply(probs, x, _row_mask(mask, rows, x), rows, n_cat)
+
+
+def philox_normal(seed, offset, shape, device):
+    """The eps tensor a sweep with stream id (seed, offset) draws, materialised."""
+    out = torch.empty(tuple(shape), device=device, dtype=torch.float32)
+    _need_gpu(out)
+    _call('mdmm_philox_normal', seed, offset, out.numel(), _ptr(out))
+    return out
