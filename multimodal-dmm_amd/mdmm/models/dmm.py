@@ -244,9 +244,13 @@ class MultiDMM(MultiDGTS):
 
     @staticmethod
     def _shape_of(inputs, lengths):
-        if lengths is not None:
-            return max(lengths), len(lengths)
+        # the tensors carry (T,B); `lengths` (dmm.py:456) must describe the same batch.  A
+        # data-parallel shard keeps the global T even when its own longest sequence is shorter
+        # (padded steps are swept exactly as in the reference).
         first = inputs[next(iter(inputs))]
+        if lengths is not None and len(lengths) != first.shape[1]:
+            raise ValueError('lengths describes %d sequences, inputs hold %d'
+                             % (len(lengths), first.shape[1]))
         return first.shape[0], first.shape[1]
 
     def forward(self, inputs, **kwargs):

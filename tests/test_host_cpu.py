@@ -1,0 +1,238 @@
+"""CPU tests (no GPU needed): the C-ABI library loads and exports every symbol the header
+declares; the drop-in package keeps the reference's module tree / state_dict layout; the
+host logic (weight packing, replay-noise scheduling, harness arithmetic) is right; and the
+product refuses to run without a GPU instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from helpers import Golden
+from oracle import mdmm_oracle as orc
+
+
+def test_library_exports_every_declared_symbol():
+    from mdmm import native
+    header = open(os.path.join(helpers.REPO, 'include', 'mdmm_hip.h')).read()
+    declared = set(re.findall(r'\b(mdmm_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(native.SYMBOLS), declared ^ set(native.SYMBOLS)
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    L = native.lib()
+    assert L.mdmm_version() == native.ABI_VERSION
+    assert L.mdmm_pad(5) == 8 and L.mdmm_pad(32) == 32
+    assert L.mdmm_sweep_spill_width_g(32, 32) == 2 * 32 + 4 * 32
+    assert L.mdmm_sweep_spill_width_x(5, 20) == 2 * 8 + 2 * 20
+    assert b'LDS' in L.mdmm_strerror(-2)
+
+
+def test_binding_struct_layout_matches_header():
+    """ctypes mirrors of the C structs: sizes derived independently from the header text."""
+    from mdmm import native
+    assert ctypes.sizeof(native.Gtf) == 12 * 8
+    assert ctypes.sizeof(native.Expert) == 5 * 8 + 8 + 4 + 4
+    n_int = 12
+    expect = n_int * 4 + 8 + 16 + 4 * 8 + 96 + 8 * 56 + 5 * 8 + 5 * 8 + 3 * 8 + 2 * 8 + 8
+    assert ctypes.sizeof(native.Sweep) == expect
+
+
+def test_argument_errors_are_reported_not_swallowed():
+    from mdmm import native
+    L = native.lib()
+    s = native.Sweep()
+    assert L.mdmm_bfvi_sweep_fwd(ctypes.byref(s), None) == -1        # MDMM_E_ARG, no launch
+    s.T, s.B, s.D, s.H, s.K, s.P = 4, 2, 8, 8, 1, 9
+    assert L.mdmm_bfvi_sweep_fwd(ctypes.byref(s), None) == -2        # too many passes
+    with pytest.raises(native.MdmmError):
+        native.check(-3, 'x')
+
+
+def test_no_cpu_fallback():
+    """A model on the CPU can hold weights but cannot run: the hot path must fail loudly."""
+    from mdmm import models, native
+    m = models.MultiDMM(['a', 'b'], [1, 1], z_dim=5, h_dim=20, device=torch.device('cpu'))
+    x = {'a': torch.randn(4, 2, 1), 'b': torch.randn(4, 2, 1)}
+    mask = torch.ones(4, 2, 1, dtype=torch.bool)
+    with pytest.raises(native.MdmmError):
+        m(x, lengths=[4, 4])
+    with pytest.raises(native.MdmmError):
+        m.step(x, mask, 1.0, {}, lengths=[4, 4])
+    with pytest.raises(native.MdmmError):
+        m.product_of_experts(torch.zeros(2, 3, 4), torch.ones(2, 3, 4))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(helpers.PKG_DIR, 'mdmm')
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(root, f)).read()
+                assert 'oracle' not in src.replace('oracle/', '').lower() or f == 'noise.py' \
+                    or 'import oracle' not in src, f
+                assert 'from oracle' not in src and 'import oracle' not in src, f
+
+
+# ------------------------------------------------------------------ state_dict layout --
+def _ref_shapes(case):
+    g = Golden('g7_state_dicts.npz')
+    return {k: tuple(v.tolist()) for k, v in g.sub(case).items()}
+
+
+def _shapes(model):
+    return {k: tuple(v.shape) for k, v in model.state_dict().items()}
+
+
+def test_state_dict_layout_matches_reference():
+    from mdmm import models
+    C = models.common
+    cpu = torch.device('cpu')
+    got = _shapes(models.MultiDMM(['spiral-x', 'spiral-y'], [1, 1], h_dim=20, z_dim=5, device=cpu))
+    assert got == _ref_shapes('spirals_dmm')
+    assert list(got) == list(_ref_shapes('spirals_dmm'))            # same key order too
+    got = _shapes(models.MultiDKS(['spiral-x', 'spiral-y'], [1, 1], h_dim=20, z_dim=5, device=cpu))
+    assert got == _ref_shapes('spirals_dks')
+    mods, dims = ['video', 'mask', 'action'], [(3, 64, 64), (1, 64, 64), 10]
+    dists = ['Bernoulli', 'Bernoulli', 'Categorical']
+    wz = models.MultiDMM(
+        mods, dims, dists, encoders={'video': C.ImageEncoder(256, n_channels=3),
+                                     'mask': C.ImageEncoder(256, n_channels=1)},
+        decoders={'video': C.ImageDecoder(256, n_channels=3),
+                  'mask': C.ImageDecoder(256, n_channels=1)}, h_dim=256, z_dim=256, device=cpu)
+    assert _shapes(wz) == _ref_shapes('weizmann_dmm')     # incl. the aliased conv keys
+    assert sum(p.numel() for p in wz.parameters()) == 7489294
+    got = _shapes(models.MultiDKS(
+        mods, dims, dists,
+        encoders={'video': C.ImageEncoder(256, gauss_out=False, n_channels=3),
+                  'mask': C.ImageEncoder(256, gauss_out=False, n_channels=1)},
+        decoders={'video': C.ImageDecoder(256, n_channels=3),
+                  'mask': C.ImageDecoder(256, n_channels=1)}, h_dim=256, z_dim=256, device=cpu))
+    assert got == _ref_shapes('weizmann_dks')
+    got = _shapes(models.MultiDMM(
+        ['video', 'audio'], [(3, 64, 64), (10, 1281)], ['Bernoulli', 'Bernoulli'],
+        encoders={'video': C.ImageEncoder(256), 'audio': C.AudioEncoder(256)},
+        decoders={'video': C.ImageDecoder(256), 'audio': C.AudioDecoder(256)},
+        h_dim=256, z_dim=256, device=cpu))
+    assert got == _ref_shapes('vidtimit_dmm')
+
+
+def test_default_init_matches_reference_rng_order():
+    """Same seed -> same default initialisation as the reference (checkpoint-free parity):
+    the golden state_dict of g4/z5 was created by the reference under manual_seed(0)."""
+    from mdmm import models
+    g = Golden('g4_step.npz')
+    torch.manual_seed(0)
+    m = models.MultiDMM(['a', 'b'], [1, 1], h_dim=20, z_dim=5, device=torch.device('cpu'))
+    for k, v in g.sub('z5/sd').items():
+        assert torch.equal(m.state_dict()[k], v), k
+
+
+def test_models_registry_and_dropin_shim():
+    import sys
+    from mdmm import models
+    assert models.names == {'vrnn': 'MultiVRNN', 'dmm': 'MultiDMM', 'dks': 'MultiDKS'}
+    for cls in models.names.values():
+        assert hasattr(models, cls)
+    shim_dir = os.path.join(helpers.PKG_DIR, 'dropin')
+    saved = sys.modules.pop('models', None)
+    sys.path.insert(0, shim_dir)
+    try:
+        import importlib
+        shim = importlib.import_module('models')
+        assert shim.MultiDMM is models.MultiDMM
+        from models.common import GaussianGTF, ImageEncoder   # noqa: F401
+        assert getattr(shim, shim.names['dks']) is models.MultiDKS
+    finally:
+        sys.path.remove(shim_dir)
+        for k in [k for k in sys.modules if k == 'models' or k.startswith('models.')]:
+            del sys.modules[k]
+        if saved is not None:
+            sys.modules['models'] = saved
+
+
+# ------------------------------------------------------------------------ host logic --
+def test_gtf_packing_and_grad_unpacking_roundtrip():
+    """PackedGtf lays the 12 raw tensors out as mdmm_gtf_t documents; unpack_grads inverts the
+    layout: feed G = dL/d(pre-activations), X = activations of a torch GTF and recover
+    autograd's parameter gradients."""
+    from mdmm import ops
+    from mdmm.models.common import GaussianGTF
+    torch.manual_seed(1)
+    for D, H in ((5, 20), (32, 32), (6, 10)):
+        gtf = GaussianGTF(D, H, min_std=1e-3)
+        params = ops.gtf_param_list(gtf)
+        pk = ops.PackedGtf(params, D, H)
+        Dp, Hp, F1 = pk.Dp, pk.Hp, pk.F1
+        assert Dp % 4 == 0 and Hp % 4 == 0 and pk.buf.numel() == 2 * (F1 * Dp + 2 * Dp * Hp + Dp * Dp) + F1 + 3 * Dp
+        view = lambda name, r, c: pk.buf[pk.offsets[name]:pk.offsets[name] + r * c].reshape(r, c)  # noqa: E731
+        w_in = view('w_in', F1, Dp)
+        assert torch.equal(w_in[:H, :D], gtf.z_to_gate[0].weight)
+        assert torch.equal(w_in[Hp:Hp + H, :D], gtf.z_nonlin[0].weight)
+        assert torch.equal(w_in[2 * Hp:2 * Hp + D, :D], gtf.z_lin.weight)
+        assert torch.equal(view('wt_in', Dp, F1), w_in.t())
+        assert torch.equal(view('w_gate', Dp, Hp)[:D, :H], gtf.z_to_gate[2].weight)
+        assert torch.equal(view('wt_std', Dp, Dp), view('w_std', Dp, Dp).t())
+        # gradient round trip
+        n = 7
+        z = torch.randn(n, D)
+        a1 = gtf.z_to_gate[0](z); h1 = torch.relu(a1)
+        ag = gtf.z_to_gate[2](h1); gate = torch.sigmoid(ag)
+        lin = gtf.z_lin(z)
+        a2 = gtf.z_nonlin[0](z); h2 = torch.relu(a2)
+        nl = gtf.z_nonlin[2](h2)
+        pre = gtf.z_to_std[0](nl)
+        mean = (1 - gate) * lin + gate * nl
+        std = torch.nn.functional.softplus(pre) + 1e-3
+        cm, cs = torch.randn(n, D), torch.randn(n, D)
+        loss = (mean * cm).sum() + (std * cs).sum()
+        acts = [a1, ag, lin, a2, nl, pre]
+        g_a1, g_ag, g_lin, g_a2, g_nl, g_pre = torch.autograd.grad(loss, acts, retain_graph=True)
+        G = torch.zeros(n, F1 + 3 * Dp); X = torch.zeros(n, 2 * Dp + 2 * Hp)
+        G[:, :H] = g_a1; G[:, Hp:Hp + H] = g_a2; G[:, 2 * Hp:2 * Hp + D] = g_lin
+        G[:, F1:F1 + D] = g_ag; G[:, F1 + Dp:F1 + Dp + D] = g_nl; G[:, F1 + 2 * Dp:F1 + 2 * Dp + D] = g_pre
+        X[:, :D] = z; X[:, Dp:Dp + H] = h1; X[:, Dp + Hp:Dp + Hp + H] = h2
+        X[:, Dp + 2 * Hp:Dp + 2 * Hp + D] = nl
+        got = pk.unpack_grads(G.detach(), X.detach(), params)
+        want = torch.autograd.grad(loss, params)
+        for a, b in zip(got, want):
+            assert helpers.rel_err(a, b) < 1e-5
+
+
+def test_replay_noise_schedule_counts():
+    """The number of draws the fused step consumes equals what the reference drew."""
+    from mdmm.models.dmm import _n_draws
+    assert _n_draws(7, True, 1, False) == 7 and _n_draws(7, False, 25, False) == 7
+    assert _n_draws(7, False, 1, True) == 1 and _n_draws(7, False, 1, False) == 0
+    g = Golden('g4_step.npz')
+    # z5: 2 prior-matching draws + P*T (bfilter) + P*2T (fsmooth), P = 3, T = 6
+    assert len(g.seq('z5/eps')) == 2 + 3 * 6 + 3 * 12
+    assert len(g.seq('z5_nouni/eps')) == 2 + 6 + 12
+
+
+def test_harness_anneal_and_bucket():
+    from mdmm import harness
+    assert harness.anneal(0.0, 1.0, 24, 2400) == orc.anneal(0.0, 1.0, 24, 2400)
+    # first batch of epoch 1 with 24 batches / epoch and kld_anneal=100
+    assert harness.kld_multiplier(0, 1, 24, 1.0, 100) == pytest.approx(0.01)
+    lin = torch.nn.Linear(3, 2)
+    bucket = harness.GradBucket(lin.parameters())
+    lin(torch.ones(4, 3)).sum().backward()
+    assert bucket.flat.abs().sum() > 0
+    assert lin.weight.grad.data_ptr() == bucket.flat.data_ptr()
+    flat_before = bucket.flat.clone()
+    lin(torch.ones(4, 3)).sum().backward()                 # accumulates in place
+    assert torch.allclose(bucket.flat, 2 * flat_before)
+    lin.zero_grad(set_to_none=True)
+    lin(torch.ones(4, 3)).sum().backward()
+    bucket.check_views()
+    assert lin.weight.grad.data_ptr() == bucket.flat.data_ptr()
+    assert torch.allclose(bucket.flat, flat_before)
+    bucket.zero()
+    assert float(lin.bias.grad.abs().sum()) == 0.0
+    x = {'a': torch.arange(24.).reshape(3, 8, 1)}
+    xs, ms, ls = harness.shard_batch(x, torch.ones(3, 8, 1), [3] * 8, 1, 4)
+    assert xs['a'].shape == (3, 2, 1) and ls == [3, 3] and torch.equal(xs['a'], x['a'][:, 2:4])
