@@ -1,0 +1,31 @@
+// C-ABI entry points of the BFVI sweep: argument checks, then kernel-family dispatch.
+//   z_dim, h_dim <= 32, K <= 32 : register-chained f32 MFMA kernels (sweep_mfma.hip)
+//   everything else             : generic LDS-tiled fp32 kernels    (sweep_simt.hip)
+// MDMM_FORCE_GENERIC=1 in the environment pins the generic family (A/B runs, cross-checks).
+#include <stdlib.h>
+#include "sweep_internal.h"
+
+static bool force_generic() {
+  const char* v = getenv("MDMM_FORCE_GENERIC");
+  return v && v[0] == '1';
+}
+
+extern "C" int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream) {
+  int rc = mdmm_sweep_check_args(args, 0);
+  if (rc) return rc;
+  if (!force_generic()) {
+    rc = mdmm_mfma_sweep_fwd(args, (hipStream_t)stream);
+    if (rc != MDMM_UNSUPPORTED) return rc;
+  }
+  return mdmm_simt_sweep_fwd(args, (hipStream_t)stream);
+}
+
+extern "C" int mdmm_bfvi_sweep_bwd(const mdmm_sweep_t* args, void* stream) {
+  int rc = mdmm_sweep_check_args(args, 1);
+  if (rc) return rc;
+  if (!force_generic()) {
+    rc = mdmm_mfma_sweep_bwd(args, (hipStream_t)stream);
+    if (rc != MDMM_UNSUPPORTED) return rc;
+  }
+  return mdmm_simt_sweep_bwd(args, (hipStream_t)stream);
+}

@@ -1,0 +1,14 @@
+// Internal launch interface between the C-ABI entry points (sweep_api.hip) and the kernel
+// families.  A launcher returns MDMM_UNSUPPORTED when the shape is outside its family; the
+// entry point then tries the next one (generic SIMT kernels accept every shape).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/mdmm_hip.h"
+
+#define MDMM_UNSUPPORTED (-100)
+
+int mdmm_simt_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream);
+int mdmm_simt_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream);
+int mdmm_mfma_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream);
+int mdmm_mfma_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream);
+int mdmm_sweep_check_args(const mdmm_sweep_t* a, int bwd);

@@ -12,7 +12,7 @@
 // (T,B,D) posteriors instead of storing per-particle activations ("Activation
 // memory vs recompute"), and spills the weight-gradient GEMM operands (G, X) per row.
 #include "mdmm_device.h"
-#include "../../include/mdmm_hip.h"
+#include "sweep_internal.h"
 
 namespace {
 
@@ -557,7 +557,7 @@ constexpr size_t LDS_MAX = 160 * 1024;
 
 struct Launch { int S, RC, grid; size_t lds; };
 
-int plan(const mdmm_sweep_t* a, bool bwd, Launch* out) {
+int check_args(const mdmm_sweep_t* a) {
   if (!a) return MDMM_E_ARG;
   if (a->T < 1 || a->B < 1 || a->D < 1 || a->H < 1 || a->K < 1) return MDMM_E_ARG;
   if (a->P < 1 || a->P > MDMM_MAX_PASSES || a->E < 0 || a->E > MDMM_MAX_EXPERTS) return MDMM_E_LIMIT;
@@ -574,6 +574,10 @@ int plan(const mdmm_sweep_t* a, bool bwd, Launch* out) {
   }
   for (int e = 0; e < a->E; ++e)
     if (!a->experts[e].mean || !a->experts[e].std) return MDMM_E_ARG;
+  return 0;
+}
+
+int plan(const mdmm_sweep_t* a, bool bwd, Launch* out) {
   const int Dp = pad4(a->D), Hp = pad4(a->H), F1 = 2 * Hp + Dp;
   const int rows_per_seq = a->P * a->K;
   // sequences per workgroup: keep >= ~512 workgroups when the batch allows, <= 64 rows
@@ -606,32 +610,36 @@ extern "C" int mdmm_pad(int n) { return pad4(n); }
 extern "C" int mdmm_sweep_spill_width_g(int D, int H) { return 2 * pad4(H) + 4 * pad4(D); }
 extern "C" int mdmm_sweep_spill_width_x(int D, int H) { return 2 * pad4(D) + 2 * pad4(H); }
 
-extern "C" int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream) {
+int mdmm_sweep_check_args(const mdmm_sweep_t* a, int bwd) {
+  int rc = check_args(a);
+  if (rc) return rc;
+  if (bwd && (a->spill_g || a->spill_x)) {
+    if (!a->spill_g || !a->spill_x) return MDMM_E_ARG;
+    const int64_t need = a->trans_only ? (int64_t)a->B * a->K
+                                       : (int64_t)a->P * a->B * a->K * (a->T - 1);
+    if (a->spill_rows < need) return MDMM_E_ARG;
+  }
+  return 0;
+}
+
+int mdmm_simt_sweep_fwd(const mdmm_sweep_t* args, hipStream_t stream) {
   Launch L;
   int rc = plan(args, false, &L);
   if (rc) return rc;
   hipError_t e = hipFuncSetAttribute((const void*)sweep_fwd_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(sweep_fwd_kernel, dim3(L.grid), dim3(NT), L.lds, (hipStream_t)stream, *args,
-                     L.S, L.RC);
+  hipLaunchKernelGGL(sweep_fwd_kernel, dim3(L.grid), dim3(NT), L.lds, stream, *args, L.S, L.RC);
   return (int)hipGetLastError();
 }
 
-extern "C" int mdmm_bfvi_sweep_bwd(const mdmm_sweep_t* args, void* stream) {
+int mdmm_simt_sweep_bwd(const mdmm_sweep_t* args, hipStream_t stream) {
   Launch L;
   int rc = plan(args, true, &L);
   if (rc) return rc;
-  if (args->spill_g || args->spill_x) {
-    if (!args->spill_g || !args->spill_x) return MDMM_E_ARG;
-    const int64_t need = args->trans_only ? (int64_t)args->B * args->K
-                                          : (int64_t)args->P * args->B * args->K * (args->T - 1);
-    if (args->spill_rows < need) return MDMM_E_ARG;
-  }
   hipError_t e = hipFuncSetAttribute((const void*)sweep_bwd_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(sweep_bwd_kernel, dim3(L.grid), dim3(NT), L.lds, (hipStream_t)stream, *args,
-                     L.S, L.RC);
+  hipLaunchKernelGGL(sweep_bwd_kernel, dim3(L.grid), dim3(NT), L.lds, stream, *args, L.S, L.RC);
   return (int)hipGetLastError();
 }

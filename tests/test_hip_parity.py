@@ -33,6 +33,20 @@ def dev():
     return torch.device('cuda:0')
 
 
+@pytest.fixture(autouse=True, params=['auto', 'generic'])
+def kernel_family(request):
+    """Every parity test runs twice: with the library's own dispatch (register-chained MFMA
+    kernels for z, h <= 32) and with the generic LDS-tiled kernels pinned (sweep_api.hip)."""
+    import os
+    old = os.environ.get('MDMM_FORCE_GENERIC')
+    os.environ['MDMM_FORCE_GENERIC'] = '1' if request.param == 'generic' else '0'
+    yield request.param
+    if old is None:
+        os.environ.pop('MDMM_FORCE_GENERIC', None)
+    else:
+        os.environ['MDMM_FORCE_GENERIC'] = old
+
+
 def close(a, b, tol=TOL_OUT, what=''):
     e = rel_err(a, b)
     assert e < tol, '%s rel err %.3e (tol %.1e)' % (what, e, tol)
