@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 1
+#define MDMM_ABI_VERSION 2
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -69,7 +69,9 @@ typedef struct mdmm_gtf {
  * prior fed to the smoother, dmm.py:479).  mask is (T,B) float 0/1 or NULL (= ones).
  * pass_bits: bit p set <=> the expert takes part in pass p (a unimodal pass simply
  * leaves the other modalities out, dgts.py:126-129 / dmm.py:162-163).
- * g_mean/g_std (backward only, may be NULL): same layout as mean/std, overwritten. */
+ * g_mean/g_std (backward only, may be NULL): ALWAYS one slab per pass, (P,T,B,D), zeroed by
+ * the caller; the kernel writes the slabs of the passes the expert takes part in.  For a
+ * shared expert the caller adds the slabs up (a deterministic sum instead of atomics). */
 typedef struct mdmm_expert {
   const float* mean;
   const float* std;
@@ -126,10 +128,23 @@ typedef struct mdmm_sweep {
   float* spill_g;
   float* spill_x;
   int64_t spill_rows;    /* capacity; needs P*B*K*(T-1) (K*B for trans_only) */
+  /* In-kernel weight gradients (mdmm_sweep_bwd_mode() == 1): every workgroup writes ONE row of
+   * mdmm_sweep_dw_width(D,H) floats with its partial sums; the caller adds the rows up.
+   * Row layout with D16 = 16*ceil(D/16), H16 = 16*ceil(H/16):
+   *   dW_in [2*H16 + D16][D16] (row blocks as mdmm_gtf_t.w_in) | dW_gate [D16][H16] |
+   *   dW_nl [D16][H16] | dW_std [D16][D16] | db_in [2*H16 + D16] | db_gate [D16] | db_nl [D16] |
+   *   db_std [D16] | d z0_mean [D16] | d sigma0 [D16]        (g_z0_* are not written then) */
+  float* dw_partial;
+  int64_t dw_partial_rows; /* capacity; needs mdmm_sweep_dw_rows(args) */
 } mdmm_sweep_t;
 
 int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream);
 int mdmm_bfvi_sweep_bwd(const mdmm_sweep_t* args, void* stream);
+/* How mdmm_bfvi_sweep_bwd delivers the weight gradients for this shape:
+ *   0 = spill_g / spill_x rows (generic kernels), 1 = dw_partial rows (MFMA kernels). */
+int mdmm_sweep_bwd_mode(const mdmm_sweep_t* args);
+int mdmm_sweep_dw_width(int D, int H);
+int64_t mdmm_sweep_dw_rows(const mdmm_sweep_t* args);
 /* widths of one spill_g / spill_x row for (D,H) */
 int mdmm_sweep_spill_width_g(int D, int H);
 int mdmm_sweep_spill_width_x(int D, int H);

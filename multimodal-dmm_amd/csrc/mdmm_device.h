@@ -34,19 +34,31 @@ __device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, uint64_t st
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Box-Muller on the hardware transcendental units: v_log_f32 is log2, v_sin/v_cos take
+// their argument in revolutions, so u2 feeds them directly.  Every kernel family and the
+// materialiser (mdmm_philox_normal) share this function, so they draw identical eps.
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+  const float rad = __builtin_amdgcn_sqrtf(-1.38629436111989062f * __builtin_amdgcn_logf(u1));
+  n0 = rad * __builtin_amdgcn_cosf(u2);
+  n1 = rad * __builtin_amdgcn_sinf(u2);
+}
+
+// the 4 normals of Philox counter idx4 = (element index) >> 2
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t offset, uint64_t idx4,
+                                               float out[4]) {
+  uint32_t r[4];
+  philox4(seed, idx4, offset, r);
+  box_muller(r[0], r[1], out[0], out[1]);
+  box_muller(r[2], r[3], out[2], out[3]);
+}
+
 // standard normal for element `idx` of the stream (seed, offset)
 __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, uint64_t idx) {
-  uint32_t r[4];
-  philox4(seed, idx >> 2, offset, r);
-  const int pair = (int)((idx >> 1) & 1);
-  const uint32_t a = r[2 * pair], b = r[2 * pair + 1];
-  // u1 in (0,1], u2 in [0,1)
-  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);
-  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
-  const float rad = sqrtf(-2.0f * logf(u1));
-  float s, c;
-  sincosf(6.28318530717958647692f * u2, &s, &c);
-  return (idx & 1) ? rad * s : rad * c;
+  float n[4];
+  philox_normal4(seed, offset, idx >> 2, n);
+  return n[idx & 3];
 }
 
 // ---------------------------------------------------------------------------------
@@ -108,6 +120,44 @@ __device__ __forceinline__ void poe_out_bwd(float num, float prec, float std, fl
   g_num = g_mean / prec;
   g_prec = -g_mean * num / (prec * prec) - 0.5f * g_std * std / prec;
 }
+
+// ---------------------------------------------------------------------------------
+// 1-ulp hardware forms (v_rcp/v_sqrt/v_exp/v_log) for the MFMA kernels, where the
+// correctly-rounded sequences (10+ instructions per divide) made the sweep VALU-bound.
+// ---------------------------------------------------------------------------------
+namespace fast {
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+__device__ __forceinline__ float sigmoid(float x) { return rcp(1.0f + exp(-x)); }
+// softplus = max(x,0) + log1p(exp(-|x|)); the log1p is a short series where 1 + y would
+// lose the low bits of y (std = softplus + 1e-3 must keep ~1e-6 relative accuracy)
+__device__ __forceinline__ float softplus(float x) {
+  if (x > 20.0f) return x;
+  const float y = exp(-fabsf(x));
+  const float l = y < 0.01f ? y * (1.0f - y * (0.5f - y * (1.0f / 3.0f))) : log(1.0f + y);
+  return fmaxf(x, 0.0f) + l;
+}
+__device__ __forceinline__ float softplus_grad(float x) { return x > 20.0f ? 1.0f : sigmoid(x); }
+
+struct Poe {   // same algebra as mdmm::Poe with 1-ulp reciprocals
+  float num, prec;
+  __device__ __forceinline__ void init() { num = 0.0f; prec = 0.0f; }
+  __device__ __forceinline__ void add(float mu, float sd, float c) {
+    const float t = rcp(sd * sd + MDMM_POE_EPS) * signf_(sd) * c;
+    num += (mu * c) * t;
+    prec += t;
+  }
+  __device__ __forceinline__ void add_pre(float m_t, float t) { num += m_t; prec += t; }
+  __device__ __forceinline__ void finish(float& mean, float& std) const {
+    const float r = rcp(prec);
+    const float m = num * r;
+    mean = (m != m) ? 0.0f : m;
+    std = sqrt(r);
+  }
+};
+}  // namespace fast
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -29,3 +29,15 @@ extern "C" int mdmm_bfvi_sweep_bwd(const mdmm_sweep_t* args, void* stream) {
   }
   return mdmm_simt_sweep_bwd(args, (hipStream_t)stream);
 }
+
+extern "C" int mdmm_sweep_bwd_mode(const mdmm_sweep_t* args) {
+  if (!args || force_generic()) return 0;
+  return mdmm_mfma_bwd_supported(args);
+}
+
+extern "C" int mdmm_sweep_dw_width(int D, int H) { return mdmm_mfma_dw_width(D, H); }
+
+extern "C" int64_t mdmm_sweep_dw_rows(const mdmm_sweep_t* args) {
+  if (!args || force_generic()) return 0;
+  return mdmm_mfma_dw_rows(args);
+}

@@ -33,26 +33,13 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t offset, uint64_t idx4,
-                                               float out[4]) {
-  uint32_t r[4];
-  philox4(seed, idx4, offset, r);
-#pragma unroll
-  for (int pair = 0; pair < 2; ++pair) {
-    const float u1 = ((float)(r[2 * pair] >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    const float u2 = (float)(r[2 * pair + 1] >> 8) * (1.0f / 16777216.0f);
-    const float rad = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincosf(6.28318530717958647692f * u2, &s, &c);
-    out[2 * pair] = rad * c;
-    out[2 * pair + 1] = rad * s;
-  }
-}
-
-// Weight fragments: dst[(it*FT + ft)*64 + lane] = { W[row0 + 16it + i][16ft + 4g + r] : r = 0..3 }
-// with i = lane & 15, g = lane >> 4; entries outside (n_rows, n_cols) are zero.
+// Weight fragments: dst[(it*DST_FT + ft_off + ft)*64 + lane] =
+//   { W[row0 + 16it + i][col0 + 16ft + 4g + r] : r = 0..3 },  i = lane & 15, g = lane >> 4;
+// entries outside (n_rows, n_cols) are zero.
 __device__ __forceinline__ void stage_frag(float4* dst, const float* __restrict__ src, int ld,
-                                           int row0, int n_rows, int n_cols, int IT, int FT) {
+                                           int row0, int n_rows, int n_cols, int IT, int FT,
+                                           int col0 = 0, int dst_ft = -1, int ft_off = 0) {
+  if (dst_ft < 0) dst_ft = FT;
   for (int idx = threadIdx.x; idx < IT * FT * 64; idx += NT) {
     const int lane = idx & 63, tile = idx >> 6;
     const int ft = tile % FT, it = tile / FT;
@@ -60,8 +47,9 @@ __device__ __forceinline__ void stage_frag(float4* dst, const float* __restrict_
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      v[r] = (row < n_rows && col + r < n_cols) ? src[(size_t)(row0 + row) * ld + col + r] : 0.f;
-    dst[idx] = make_float4(v[0], v[1], v[2], v[3]);
+      v[r] = (row < n_rows && col + r < n_cols)
+          ? src[(size_t)(row0 + row) * ld + col0 + col + r] : 0.f;
+    dst[(it * dst_ft + ft_off + ft) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -116,16 +104,22 @@ __device__ __forceinline__ f32x4 ld_frag(const float4* p) {
   return o;
 }
 
-// out[it][ct] = bias[it] + sum_{ft,r} W_frag[it][ft][r] (x) in[ft][ct][r]
-template <int IT, int FT, int CT>
+// out[it][ct] (=|+=) [bias[it] +] sum_{ft,r} W_frag[it][ft][r] (x) in[ft][ct][r]
+// MODE 0: start from zero, 1: start from the bias fragment, 2: accumulate into `out`
+template <int IT, int FT, int CT, int MODE = 1>
 __device__ __forceinline__ void gemm_chain(const float4* wfrag, const float4* bfrag, int lane,
                                            const f32x4 (&in)[FT][CT], f32x4 (&out)[IT][CT]) {
   const int g = lane >> 4;
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
-    const f32x4 b = ld_frag(bfrag + it * 4 + g);
+    if (MODE == 1) {
+      const f32x4 b = ld_frag(bfrag + it * 4 + g);
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) out[it][ct] = b;
+      for (int ct = 0; ct < CT; ++ct) out[it][ct] = b;
+    } else if (MODE == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) out[it][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) {
       const f32x4 w = ld_frag(wfrag + (it * FT + ft) * 64 + lane);
@@ -175,10 +169,10 @@ __device__ __forceinline__ void transition_rows(const float4* lds, int lane, flo
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float gt = sigmoidf_(gate[dt][ct][r]);
+        const float gt = fast::sigmoid(gate[dt][ct][r]);
         const float muq = (1.0f - gt) * a1[2 * HT + dt][ct][r] + gt * nl[dt][ct][r];
-        const float sq = softplusf_(pre[dt][ct][r]) + min_std;
-        Poe q; q.init(); q.add(mu0[dt][r], sg0[dt][r], 1.0f); q.add(muq, sq, 1.0f);
+        const float sq = fast::softplus(pre[dt][ct][r]) + min_std;
+        fast::Poe q; q.init(); q.add(mu0[dt][r], sg0[dt][r], 1.0f); q.add(muq, sq, 1.0f);
         float m, s; q.finish(m, s);
         tm[dt][ct][r] = m; ts[dt][ct][r] = s;
       }
@@ -254,7 +248,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
               sm = row16_sum(sm); sv = row16_sum(sv); sm2 = row16_sum(sm2);
               const float mb = sm * inv_k;                                   // dgts.py:79-83
               pm[dt][0][r] = mb;
-              ps[dt][0][r] = sqrtf(sv * inv_k + (sm2 * inv_k - mb * mb));
+              ps[dt][0][r] = fast::sqrt(sv * inv_k + (sm2 * inv_k - mb * mb));
             }
         }
       } else {
@@ -272,7 +266,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
       const int p = p_[n], b = b_[n];
       const bool row_ok = PART ? true : live[n];
       const size_t tb = (size_t)t * B + b;
-      Poe q[DT][4];
+      fast::Poe q[DT][4];
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -406,6 +400,576 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
   }
 }
 
+// =====================================================================================
+// backward: reverse scan with recompute, weight gradients accumulated in MFMA accumulators
+// =====================================================================================
+template <int DT, int HT>
+struct LdsB {
+  using F = Lds<DT, HT>;
+  static constexpr int IT1 = F::IT1;
+  static constexpr int TS = F::FWD_END;              // wt_std : [DT out = nl idx ][DT k = std idx]
+  static constexpr int TG = TS + DT * DT * 64;       // wt_gate: [HT out = hidden ][DT k = d]
+  static constexpr int TN = TG + HT * DT * 64;       // wt_nl  : [HT][DT]
+  static constexpr int T1 = TN + HT * DT * 64;       // wt_in  : [DT out = z idx  ][IT1 k = in-layer rows]
+  static constexpr int WEND = T1 + DT * IT1 * 64;    // float4 units
+  // one output row of partial sums (floats), see mdmm_sweep_t.dw_partial
+  static constexpr int D16 = 16 * DT, H16 = 16 * HT, F16 = 16 * IT1;
+  static constexpr int O_W1 = 0;
+  static constexpr int O_WG = O_W1 + F16 * D16;
+  static constexpr int O_WN = O_WG + D16 * H16;
+  static constexpr int O_WS = O_WN + D16 * H16;
+  static constexpr int O_B1 = O_WS + D16 * D16;
+  static constexpr int O_BG = O_B1 + F16;
+  static constexpr int O_BN = O_BG + D16;
+  static constexpr int O_BS = O_BN + D16;
+  static constexpr int O_ZM = O_BS + D16;
+  static constexpr int O_ZS = O_ZM + D16;
+  static constexpr int WIDTH = O_ZS + D16;
+};
+
+template <int DT, int HT>
+__device__ __forceinline__ void stage_backward_weights(const mdmm_sweep_t& a, float4* lds) {
+  using L = LdsB<DT, HT>;
+  const int D = a.D, H = a.H, Dp = (D + 3) & ~3, Hp = (H + 3) & ~3, F1 = 2 * Hp + Dp;
+  stage_frag(lds + L::TS, a.gtf.wt_std, Dp, 0, D, D, DT, DT);
+  stage_frag(lds + L::TG, a.gtf.wt_gate, Dp, 0, H, D, HT, DT);
+  stage_frag(lds + L::TN, a.gtf.wt_nl, Dp, 0, H, D, HT, DT);
+  // wt_in is [Dp][F1]: its columns are the three row blocks of w_in
+  stage_frag(lds + L::T1, a.gtf.wt_in, F1, 0, D, H, DT, HT, 0, L::IT1, 0);
+  stage_frag(lds + L::T1, a.gtf.wt_in, F1, 0, D, H, DT, HT, Hp, L::IT1, HT);
+  stage_frag(lds + L::T1, a.gtf.wt_in, F1, 0, D, D, DT, DT, 2 * Hp, L::IT1, 2 * HT);
+}
+
+// acc[ot][kt] += sum_rows G[16ot + .][row] * X[16kt + .][row]   (G, X in C layout).
+// The contraction runs over rows, which live on lanes: both operands go through a per-wave
+// LDS scratch as [feature][row] images and come back as A / B fragments (row(s,g) = 4*CT*g + s).
+template <int OT, int KT, int CT>
+__device__ __forceinline__ void dw_accumulate(float* scratch, int lane, const f32x4 (&G)[OT][CT],
+                                              const f32x4 (&X)[KT][CT], f32x4 (&acc)[OT][KT]) {
+  constexpr int RS = 16 * CT + 4;
+  const int j = lane & 15, g = lane >> 4;
+  float* gt = scratch;
+  float* xt = scratch + OT * 16 * RS;
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gt[(16 * ot + 4 * g + r) * RS + 16 * ct + j] = G[ot][ct][r];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xt[(16 * kt + 4 * g + r) * RS + 16 * ct + j] = X[kt][ct][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  f32x4 b[KT][CT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      b[kt][c] = ld_frag(reinterpret_cast<const float4*>(xt + (16 * kt + j) * RS + 4 * CT * g + 4 * c));
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) {
+    f32x4 av[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      av[c] = ld_frag(reinterpret_cast<const float4*>(gt + (16 * ot + j) * RS + 4 * CT * g + 4 * c));
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ot][kt] = mfma16(av[c][r], b[kt][c][r], acc[ot][kt]);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int N, int CT>
+__device__ __forceinline__ void bias_accumulate(const f32x4 (&G)[N][CT], f32x4 (&acc)[N]) {
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[n] += G[n][ct];
+}
+
+__device__ __forceinline__ f32x4 ld4_guard(const float* base, size_t off, bool vec, int d0, int D) {
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  if (!base) return o;
+  if (vec && d0 < D) {
+    const float4 v = *reinterpret_cast<const float4*>(base + off + d0);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (d0 + r < D) o[r] = base[off + d0 + r];
+  }
+  return o;
+}
+
+__device__ __forceinline__ void st4_guard(float* base, size_t off, bool vec, int d0, int D,
+                                          const f32x4& v) {
+  if (!base) return;
+  if (vec && d0 < D) {
+    *reinterpret_cast<float4*>(base + off + d0) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (d0 + r < D) base[off + d0 + r] = v[r];
+  }
+}
+
+template <int DT, int HT, int CT, bool PART>
+__global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a, int n_tasks) {
+  extern __shared__ __attribute__((aligned(16))) float4 lds[];
+  using L = Lds<DT, HT>;
+  using LB = LdsB<DT, HT>;
+  constexpr int IT1 = LB::IT1;
+  constexpr int NS = PART ? 1 : CT;
+  constexpr int SCR = (IT1 + DT) * 16 * (16 * CT + 4);       // floats of scratch per wave
+  stage_forward_weights<DT, HT>(a, lds);
+  stage_backward_weights<DT, HT>(a, lds);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  float* scratch0 = reinterpret_cast<float*>(lds + LB::WEND);
+  float* scratch = scratch0 + wave * SCR;
+  const int T = a.T, B = a.B, D = a.D, K = a.K;
+  const bool vec = (D & 3) == 0;
+  const float inv_k = 1.0f / (float)K;
+  const size_t tbd = (size_t)T * B * D;
+
+  float mu0[DT][4], sg0[DT][4], t0c[DT][4];
+  bool fvalid[DT][4];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int d = 16 * dt + 4 * g + r;
+      fvalid[dt][r] = d < D;
+      mu0[dt][r] = fvalid[dt][r] ? a.z0_mean[d] : 0.f;
+      sg0[dt][r] = fvalid[dt][r] ? expf(a.z0_log_std[d]) + a.min_std : 1.f;
+      t0c[dt][r] = fast::rcp(sg0[dt][r] * sg0[dt][r] + MDMM_POE_EPS);
+    }
+
+  // weight / bias / z0 gradient accumulators of this wave (all of its tasks)
+  f32x4 dW1[IT1][DT], dWg[DT][HT], dWn[DT][HT], dWs[DT][DT];
+  f32x4 db1[IT1], dbg[DT], dbn[DT], dbs[DT];
+  f32x4 gzm_row[DT], gzs_row[DT];     // per-row contributions (summed over lanes at the end)
+  f32x4 gzm_wav[DT], gzs_wav[DT];     // PART: per-wave contributions (identical in all j lanes)
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int x = 0; x < IT1; ++x) { db1[x] = zero4;
+#pragma unroll
+    for (int y = 0; y < DT; ++y) dW1[x][y] = zero4; }
+#pragma unroll
+  for (int x = 0; x < DT; ++x) {
+    dbg[x] = dbn[x] = dbs[x] = zero4; gzm_row[x] = gzs_row[x] = gzm_wav[x] = gzs_wav[x] = zero4;
+#pragma unroll
+    for (int y = 0; y < HT; ++y) { dWg[x][y] = zero4; dWn[x][y] = zero4; }
+#pragma unroll
+    for (int y = 0; y < DT; ++y) dWs[x][y] = zero4;
+  }
+
+  for (int task = blockIdx.x * (NT / 64) + wave; task < n_tasks; task += gridDim.x * (NT / 64)) {
+    int p_[CT], b_[CT];
+    bool live[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      if (PART) { p_[ct] = task / B; b_[ct] = task - p_[ct] * B; live[ct] = (16 * ct + j) < K; }
+      else {
+        const int q = task * 16 * CT + 16 * ct + j;
+        live[ct] = q < a.P * B;
+        const int qq = live[ct] ? q : 0;
+        p_[ct] = qq / B; b_[ct] = qq - p_[ct] * B;
+      }
+    }
+    f32x4 adjA[DT][NS], adjB[DT][NS];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int n = 0; n < NS; ++n) { adjA[dt][n] = zero4; adjB[dt][n] = zero4; }
+
+    for (int i = T - 1; i >= 0; --i) {
+      const int t = a.reverse ? T - 1 - i : i;
+      const bool sampled = a.sample || K > 1 || (i == 0 && a.sample_init);
+      f32x4 gpm[DT][NS], gps[DT][NS], pmv[DT][NS], psv[DT][NS];
+      // ---------- adjoint of sampling + product of experts at step i ----------
+#pragma unroll
+      for (int n = 0; n < NS; ++n) {
+        const int p = p_[n], b = b_[n];
+        const bool row_ok = PART ? true : live[n];
+        const size_t tb = (size_t)t * B + b;
+        const size_t o = (size_t)p * tbd + tb * D;
+        fast::Poe q[DT][4];
+        f32x4 g_im[DT], g_is[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d0 = 16 * dt + 4 * g;
+          pmv[dt][n] = row_ok ? ld4_guard(a.prior_mean, o, vec, d0, D) : zero4;
+          psv[dt][n] = row_ok ? ld4_guard(a.prior_std, o, vec, d0, D) : f32x4{1.f, 1.f, 1.f, 1.f};
+          const f32x4 gsm = row_ok ? ld4_guard(a.g_samples, o, vec, d0, D) : zero4;
+          g_im[dt] = (row_ok ? ld4_guard(a.g_infer_mean, o, vec, d0, D) : zero4) + adjA[dt][n] + gsm;
+          g_is[dt] = row_ok ? ld4_guard(a.g_infer_std, o, vec, d0, D) : zero4;
+          if (sampled) {
+            g_is[dt] += adjB[dt][n];
+            if (a.g_samples) {          // d samples / d std = mean_k eps_k  (dmm.py:399-402)
+              f32x4 se = zero4;
+              const int kmax = PART ? CT : 1;
+#pragma unroll
+              for (int c = 0; c < kmax; ++c) {
+                const int k = PART ? 16 * c + j : 0;
+                if (PART ? live[c] : row_ok) {
+                  const uint64_t idx = ((((uint64_t)p * T + t) * K + k) * B + b) * (uint64_t)D + d0;
+                  float e4[4] = {0.f, 0.f, 0.f, 0.f};
+                  if (d0 < D) {
+                    if (a.eps) { for (int r = 0; r < 4; ++r) e4[r] = (d0 + r < D) ? a.eps[idx + r] : 0.f; }
+                    else if (vec) philox_normal4(a.seed, a.offset, idx >> 2, e4);
+                    else { for (int r = 0; r < 4; ++r) e4[r] = (d0 + r < D) ? philox_normal(a.seed, a.offset, idx + r) : 0.f; }
+                  }
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) se[r] += e4[r];
+                }
+              }
+              if (PART) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) se[r] = row16_sum(se[r]) * inv_k;
+              }
+              g_is[dt] += gsm * se;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { q[dt][r].init(); q[dt][r].add(pmv[dt][n][r], psv[dt][n][r], 1.0f); }
+        }
+        if (row_ok) {
+          for (int e = 0; e < a.E; ++e) {
+            const mdmm_expert_t& ex = a.experts[e];
+            if (!((ex.pass_bits >> p) & 1u)) continue;
+            const float c = ex.mask ? ex.mask[tb] : 1.0f;
+            const size_t off = (size_t)p * ex.pass_stride + tb * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              const int d0 = 16 * dt + 4 * g;
+              const f32x4 mv = ld4_guard(ex.mean, off, vec, d0, D);
+              f32x4 sv = ld4_guard(ex.std, off, vec, d0, D);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(mv[r], sv[r], c);
+            }
+          }
+          if (a.use_inv_prior) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(mu0[dt][r], -sg0[dt][r], 1.0f);
+          }
+        }
+        // adjoints of the product: d/d num, d/d prec per feature
+        f32x4 g_num[DT], g_prec[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float rp = fast::rcp(q[dt][r].prec);
+            const float m = q[dt][r].num * rp, sd = fast::sqrt(rp);
+            float gm = g_im[dt][r];
+            if (m != m) gm = 0.f;
+            const bool ok = fvalid[dt][r] && row_ok;
+            g_num[dt][r] = ok ? gm * rp : 0.f;
+            g_prec[dt][r] = ok ? (-gm * q[dt][r].num * rp * rp - 0.5f * g_is[dt][r] * sd * rp) : 0.f;
+            // the sweep's own prior expert (mask 1)
+            const float var = psv[dt][n][r] * psv[dt][n][r] + MDMM_POE_EPS;
+            const float iv = fast::rcp(var), sg = signf_(psv[dt][n][r]);
+            const float g_t = g_num[dt][r] * pmv[dt][n][r] + g_prec[dt][r];
+            gpm[dt][n][r] = g_num[dt][r] * iv * sg;
+            gps[dt][n][r] = -g_t * sg * iv * iv * 2.0f * psv[dt][n][r];
+          }
+        // expert gradients, one (T,B,D) slab per pass
+        if (row_ok && (PART ? j == 0 : true)) {
+          for (int e = 0; e < a.E; ++e) {
+            const mdmm_expert_t& ex = a.experts[e];
+            if (!((ex.pass_bits >> p) & 1u) || (!ex.g_mean && !ex.g_std)) continue;
+            const float c = ex.mask ? ex.mask[tb] : 1.0f;
+            const size_t off = (size_t)p * ex.pass_stride + tb * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              const int d0 = 16 * dt + 4 * g;
+              const f32x4 mv = ld4_guard(ex.mean, off, vec, d0, D);
+              const f32x4 sv = ld4_guard(ex.std, off, vec, d0, D);
+              f32x4 gm4, gs4;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float iv = fast::rcp(sv[r] * sv[r] + MDMM_POE_EPS), sg = signf_(sv[r]);
+                const float tt = iv * sg * c;
+                const float g_t = g_num[dt][r] * (mv[r] * c) + g_prec[dt][r];
+                gm4[r] = g_num[dt][r] * tt * c;
+                gs4[r] = -(g_t * c * sg) * iv * iv * 2.0f * sv[r];
+              }
+              st4_guard(ex.g_mean, o, vec, d0, D, gm4);
+              st4_guard(ex.g_std, o, vec, d0, D, gs4);
+            }
+          }
+        }
+        // inverse global prior expert and (first processed step) the global prior itself
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float gm0 = 0.f, gs0 = 0.f;
+            if (a.use_inv_prior) {      // expert (mu0, -sg0): sign = -1
+              const float g_t = g_num[dt][r] * mu0[dt][r] + g_prec[dt][r];
+              gm0 += g_num[dt][r] * (-t0c[dt][r]);
+              // std of the expert is -sigma0: d/d sigma0 = -(d/d std) = +2 g_t t0^2 sigma0
+              gs0 += 2.0f * g_t * t0c[dt][r] * t0c[dt][r] * sg0[dt][r];
+            }
+            if (i == 0) {
+              gpm[dt][n][r] += a.g_prior_mean ? ld4_guard(a.g_prior_mean, o, vec, 16 * dt + 4 * g, D)[r] : 0.f;
+              gps[dt][n][r] += a.g_prior_std ? ld4_guard(a.g_prior_std, o, vec, 16 * dt + 4 * g, D)[r] : 0.f;
+              if (fvalid[dt][r] && row_ok) { gm0 += gpm[dt][n][r]; gs0 += gps[dt][n][r]; }
+            }
+            if (PART) { gzm_wav[dt][r] += gm0; gzs_wav[dt][r] += gs0; }
+            else { gzm_row[dt][r] += gm0; gzs_row[dt][r] += gs0; }
+          }
+        if (i > 0) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            if (row_ok) {
+              gpm[dt][n] += ld4_guard(a.g_prior_mean, o, vec, d0, D);
+              gps[dt][n] += ld4_guard(a.g_prior_std, o, vec, d0, D);
+            }
+          }
+        }
+      }
+      if (i == 0) break;
+
+      // ---------- adjoint of the transition: rows = particles of the previous step ----------
+      const int t_prev = a.reverse ? t + 1 : t - 1;
+      const bool sampled_prev = a.sample || K > 1 || (i == 1 && a.sample_init);
+      f32x4 z[DT][CT], ev[DT][CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int k = PART ? (16 * ct + j) : 0;
+        const size_t o = (size_t)p_[ct] * tbd + ((size_t)t_prev * B + b_[ct]) * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d0 = 16 * dt + 4 * g;
+          const f32x4 zm = live[ct] ? ld4_guard(a.infer_mean, o, vec, d0, D) : zero4;
+          const f32x4 zs = live[ct] ? ld4_guard(a.infer_std, o, vec, d0, D) : zero4;
+          float e4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (sampled_prev && live[ct] && d0 < D) {
+            const uint64_t idx = ((((uint64_t)p_[ct] * T + t_prev) * K + k) * B + b_[ct]) * (uint64_t)D + d0;
+            if (a.eps) { for (int r = 0; r < 4; ++r) e4[r] = (d0 + r < D) ? a.eps[idx + r] : 0.f; }
+            else if (vec) philox_normal4(a.seed, a.offset, idx >> 2, e4);
+            else { for (int r = 0; r < 4; ++r) e4[r] = (d0 + r < D) ? philox_normal(a.seed, a.offset, idx + r) : 0.f; }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ev[dt][ct][r] = e4[r];
+            z[dt][ct][r] = (live[ct] && fvalid[dt][r]) ? (sampled_prev ? fmaf(e4[r], zs[r], zm[r]) : zm[r]) : 0.f;
+          }
+        }
+      }
+      // forward recompute (kept: relu hidden, z_lin, gate, nonlin, std pre-activation)
+      f32x4 a1[IT1][CT];
+      gemm_chain<IT1, DT, CT>(lds + L::W1, lds + L::B1, lane, z, a1);
+      f32x4 h1[HT][CT], h2[HT][CT];
+#pragma unroll
+      for (int ft = 0; ft < HT; ++ft)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            h1[ft][ct][r] = fmaxf(a1[ft][ct][r], 0.f);
+            h2[ft][ct][r] = fmaxf(a1[HT + ft][ct][r], 0.f);
+          }
+      f32x4 gate[DT][CT], nl[DT][CT], pre[DT][CT];
+      gemm_chain<DT, HT, CT>(lds + L::WG, lds + L::BG, lane, h1, gate);
+      gemm_chain<DT, HT, CT>(lds + L::WN, lds + L::BN, lane, h2, nl);
+      gemm_chain<DT, DT, CT>(lds + L::WS, lds + L::BS, lane, nl, pre);
+      // elementwise adjoints per (row, feature); afterwards
+      //   pre <- d/d std-pre, gate <- d/d gate-pre, gnl <- direct part of d/d nonlin, a1[2HT..] <- d/d z_lin
+      f32x4 gnl[DT][CT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const int n = PART ? 0 : ct;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gt = fast::sigmoid(gate[dt][ct][r]);
+            const float lin = a1[2 * HT + dt][ct][r], nlv = nl[dt][ct][r], prv = pre[dt][ct][r];
+            const float muq = (1.0f - gt) * lin + gt * nlv;
+            const float sq = fast::softplus(prv) + a.min_std;
+            const float tq = fast::rcp(sq * sq + MDMM_POE_EPS);
+            const float num = mu0[dt][r] * t0c[dt][r] + muq * tq, prec = t0c[dt][r] + tq;
+            const float rp = fast::rcp(prec);
+            const float m = num * rp, sd = fast::sqrt(rp);
+            float g_m, g_sd;
+            if (PART) {         // moment matching, dgts.py:79-83
+              const float g_v = 0.5f * gps[dt][0][r] * fast::rcp(psv[dt][0][r]);
+              g_m = gpm[dt][0][r] * inv_k + g_v * 2.0f * (m - pmv[dt][0][r]) * inv_k;
+              g_sd = g_v * 2.0f * sd * inv_k;
+            } else { g_m = gpm[dt][n][r]; g_sd = gps[dt][n][r]; }
+            if (!(live[ct] && fvalid[dt][r])) { g_m = 0.f; g_sd = 0.f; }
+            if (m != m) g_m = 0.f;
+            const float g_num = g_m * rp;
+            const float g_prec = -g_m * num * rp * rp - 0.5f * g_sd * sd * rp;
+            // global prior expert
+            const float g_t0 = g_num * mu0[dt][r] + g_prec;
+            gzm_row[dt][r] += g_num * t0c[dt][r];
+            gzs_row[dt][r] += -g_t0 * t0c[dt][r] * t0c[dt][r] * 2.0f * sg0[dt][r];
+            // transition expert (std > 0)
+            const float g_muq = g_num * tq;
+            const float g_tq = g_num * muq + g_prec;
+            const float g_sq = -g_tq * tq * tq * 2.0f * sq;
+            pre[dt][ct][r] = g_sq * fast::softplus_grad(prv);
+            gnl[dt][ct][r] = g_muq * gt;
+            a1[2 * HT + dt][ct][r] = g_muq * (1.0f - gt);
+            gate[dt][ct][r] = g_muq * (nlv - lin) * gt * (1.0f - gt);
+          }
+        }
+      // d/d nonlin += W_std^T d/d std-pre ; weight grads of z_to_std
+      gemm_chain<DT, DT, CT, 2>(lds + LB::TS, nullptr, lane, pre, gnl);
+      dw_accumulate<DT, DT, CT>(scratch, lane, pre, nl, dWs);
+      bias_accumulate<DT, CT>(pre, dbs);
+      // gate branch
+      {
+        f32x4 gh[HT][CT];
+        gemm_chain<HT, DT, CT, 0>(lds + LB::TG, nullptr, lane, gate, gh);
+        dw_accumulate<DT, HT, CT>(scratch, lane, gate, h1, dWg);
+        bias_accumulate<DT, CT>(gate, dbg);
+#pragma unroll
+        for (int ft = 0; ft < HT; ++ft)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[ft][ct][r] = h1[ft][ct][r] > 0.f ? gh[ft][ct][r] : 0.f;
+      }
+      // nonlin branch
+      {
+        f32x4 gh[HT][CT];
+        gemm_chain<HT, DT, CT, 0>(lds + LB::TN, nullptr, lane, gnl, gh);
+        dw_accumulate<DT, HT, CT>(scratch, lane, gnl, h2, dWn);
+        bias_accumulate<DT, CT>(gnl, dbn);
+#pragma unroll
+        for (int ft = 0; ft < HT; ++ft)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[HT + ft][ct][r] = h2[ft][ct][r] > 0.f ? gh[ft][ct][r] : 0.f;
+      }
+      // d/dz = W_in^T [d/d gate-hidden | d/d nl-hidden | d/d z_lin] ; weight grads of the in layer
+      f32x4 gz[DT][CT];
+      gemm_chain<DT, IT1, CT, 0>(lds + LB::T1, nullptr, lane, a1, gz);
+      dw_accumulate<IT1, DT, CT>(scratch, lane, a1, z, dW1);
+      bias_accumulate<IT1, CT>(a1, db1);
+      // adjoints of the previous step's particles
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        if (PART) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sa = 0.f, sb = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              sa += gz[dt][ct][r];                      // dead rows / pad features carry zeros
+              sb = fmaf(gz[dt][ct][r], ev[dt][ct][r], sb);
+            }
+            adjA[dt][0][r] = row16_sum(sa);
+            adjB[dt][0][r] = sampled_prev ? row16_sum(sb) : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            adjA[dt][ct] = gz[dt][ct];
+            adjB[dt][ct] = sampled_prev ? gz[dt][ct] * ev[dt][ct] : zero4;
+          }
+        }
+      }
+    }
+  }
+
+  // ---------- combine the waves of the workgroup, write one partial row ----------
+  __syncthreads();
+  float* acc = scratch0;
+  for (int idx = threadIdx.x; idx < LB::WIDTH; idx += NT) acc[idx] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < NT / 64; ++w) {
+    if (wave == w) {
+      auto put_w = [&](int off, int ld, int ot, int kt, const f32x4& v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[off + (16 * ot + 4 * g + r) * ld + 16 * kt + j] += v[r];
+      };
+#pragma unroll
+      for (int x = 0; x < IT1; ++x)
+#pragma unroll
+        for (int y = 0; y < DT; ++y) put_w(LB::O_W1, LB::D16, x, y, dW1[x][y]);
+#pragma unroll
+      for (int x = 0; x < DT; ++x) {
+#pragma unroll
+        for (int y = 0; y < HT; ++y) { put_w(LB::O_WG, LB::H16, x, y, dWg[x][y]); put_w(LB::O_WN, LB::H16, x, y, dWn[x][y]); }
+#pragma unroll
+        for (int y = 0; y < DT; ++y) put_w(LB::O_WS, LB::D16, x, y, dWs[x][y]);
+      }
+      auto put_b = [&](int off, int tile, const f32x4& v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s = row16_sum(v[r]);
+          if (j == 0) acc[off + 16 * tile + 4 * g + r] += s;
+        }
+      };
+#pragma unroll
+      for (int x = 0; x < IT1; ++x) put_b(LB::O_B1, x, db1[x]);
+#pragma unroll
+      for (int x = 0; x < DT; ++x) {
+        put_b(LB::O_BG, x, dbg[x]); put_b(LB::O_BN, x, dbn[x]); put_b(LB::O_BS, x, dbs[x]);
+        put_b(LB::O_ZM, x, gzm_row[x]); put_b(LB::O_ZS, x, gzs_row[x]);
+        if (PART && j == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc[LB::O_ZM + 16 * x + 4 * g + r] += gzm_wav[x][r];
+            acc[LB::O_ZS + 16 * x + 4 * g + r] += gzs_wav[x][r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* out = a.dw_partial + (size_t)blockIdx.x * LB::WIDTH;
+  for (int idx = threadIdx.x; idx < LB::WIDTH; idx += NT) out[idx] = acc[idx];
+}
+
+constexpr int BWD_MAX_BLOCKS = 256;     // one 4-wave workgroup per CU (LDS-bound), persistent
+
+template <int DT, int HT, int CT, bool PART>
+int bwd_tasks(const mdmm_sweep_t* a) {
+  return PART ? a->P * a->B : (a->P * a->B + 16 * CT - 1) / (16 * CT);
+}
+
+template <int DT, int HT, int CT, bool PART>
+int launch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
+  using LB = LdsB<DT, HT>;
+  const int n_tasks = bwd_tasks<DT, HT, CT, PART>(a);
+  int grid = (n_tasks + 3) / 4;
+  if (grid > BWD_MAX_BLOCKS) grid = BWD_MAX_BLOCKS;
+  if (!a->dw_partial || a->dw_partial_rows < grid) return MDMM_E_ARG;
+  const size_t scr = (size_t)(NT / 64) * (LB::IT1 + DT) * 16 * (16 * CT + 4) * sizeof(float);
+  const size_t red = (size_t)LB::WIDTH * sizeof(float);
+  const size_t lds = (size_t)LB::WEND * sizeof(float4) + (scr > red ? scr : red);
+  auto kern = sweep_mfma_bwd_kernel<DT, HT, CT, PART>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, *a, n_tasks);
+  return (int)hipGetLastError();
+}
+
+template <int DT, int HT>
+int dispatch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
+  if (a->K == 1) return launch_bwd<DT, HT, 2, false>(a, stream);
+  if (a->K <= 16) return launch_bwd<DT, HT, 1, true>(a, stream);
+  if (a->K <= 32) return launch_bwd<DT, HT, 2, true>(a, stream);
+  return MDMM_UNSUPPORTED;
+}
+
 template <int DT, int HT, int CT, bool PART>
 int launch_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   const int n_tasks = PART ? a->P * a->B : (a->P * a->B + 16 * CT - 1) / (16 * CT);
@@ -428,9 +992,38 @@ int dispatch_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
 
 }  // namespace
 
+static bool mfma_shape(const mdmm_sweep_t* a) {
+  return !a->trans_only && a->D <= 32 && a->H <= 32 && a->K <= 32;
+}
+
+template <int DT, int HT>
+int64_t dw_rows_for(const mdmm_sweep_t* a) {
+  int n_tasks;
+  if (a->K == 1) n_tasks = bwd_tasks<DT, HT, 2, false>(a);
+  else n_tasks = a->P * a->B;
+  int64_t grid = (n_tasks + 3) / 4;
+  return grid > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : grid;
+}
+
+int mdmm_mfma_bwd_supported(const mdmm_sweep_t* a) { return mfma_shape(a) ? 1 : 0; }
+
+int mdmm_mfma_dw_width(int D, int H) {
+  const int d16 = 16 * ((D + 15) / 16), h16 = 16 * ((H + 15) / 16), f16 = 2 * h16 + d16;
+  return f16 * d16 + 2 * d16 * h16 + d16 * d16 + f16 + 5 * d16;
+}
+
+int64_t mdmm_mfma_dw_rows(const mdmm_sweep_t* a) {
+  if (!mfma_shape(a)) return 0;
+  return dw_rows_for<1, 1>(a);      // the task count does not depend on the tile shape
+}
+
 int mdmm_mfma_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
-  (void)a; (void)stream;
-  return MDMM_UNSUPPORTED;
+  if (!mfma_shape(a)) return MDMM_UNSUPPORTED;
+  const int dt = (a->D + 15) / 16, ht = (a->H + 15) / 16;
+  if (dt == 1 && ht == 1) return dispatch_bwd<1, 1>(a, stream);
+  if (dt == 1 && ht == 2) return dispatch_bwd<1, 2>(a, stream);
+  if (dt == 2 && ht == 1) return dispatch_bwd<2, 1>(a, stream);
+  return dispatch_bwd<2, 2>(a, stream);
 }
 
 int mdmm_mfma_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {

@@ -333,9 +333,6 @@ __global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int
         }
         const size_t tb = (size_t)t * g.B + b;
         const float mu0 = a.z0_mean[d], sg0 = expf(a.z0_log_std[d]) + a.min_std;
-        float ge_m[MDMM_MAX_EXPERTS], ge_s[MDMM_MAX_EXPERTS];
-#pragma unroll
-        for (int e = 0; e < MDMM_MAX_EXPERTS; ++e) { ge_m[e] = 0.f; ge_s[e] = 0.f; }
         float g_mu0 = 0.f, g_sg0 = 0.f;
         for (int p = 0; p < g.P; ++p) {
           const int it = (p * g.S + s) * g.Dp + d;
@@ -367,33 +364,20 @@ __global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int
           gpm[it] = gm + (a.g_prior_mean ? a.g_prior_mean[o] : 0.f);
           gps[it] = gs + (a.g_prior_std ? a.g_prior_std[o] : 0.f);
           pmu[it] = prm; psg[it] = prs;
-#pragma unroll
-          for (int e = 0; e < MDMM_MAX_EXPERTS; ++e) {
-            if (e >= a.E) break;
+          for (int e = 0; e < a.E; ++e) {
             const mdmm_expert_t& ex = a.experts[e];
             if (!((ex.pass_bits >> p) & 1u)) continue;
             const float c = ex.mask ? ex.mask[tb] : 1.0f;
             const size_t off = (size_t)p * ex.pass_stride + tb * g.D + d;
             poe_expert_bwd(ex.mean[off], ex.std[off], c, g_num, g_prec, gm, gs);
-            if (ex.pass_stride) {
-              if (ex.g_mean) ex.g_mean[off] = gm;
-              if (ex.g_std) ex.g_std[off] = gs;
-            } else { ge_m[e] += gm; ge_s[e] += gs; }
+            if (ex.g_mean) ex.g_mean[o] = gm;      // one slab per pass, (P,T,B,D)
+            if (ex.g_std) ex.g_std[o] = gs;
           }
           if (a.use_inv_prior) {
             poe_expert_bwd(mu0, -sg0, 1.0f, g_num, g_prec, gm, gs);
             g_mu0 += gm; g_sg0 -= gs;
           }
           if (i == 0) { g_mu0 += gpm[it]; g_sg0 += gps[it]; }   // first step: prior = p(z)
-        }
-#pragma unroll
-        for (int e = 0; e < MDMM_MAX_EXPERTS; ++e) {
-          if (e >= a.E) break;
-          const mdmm_expert_t& ex = a.experts[e];
-          if (ex.pass_stride) continue;
-          const size_t off = tb * g.D + d;
-          if (ex.g_mean) ex.g_mean[off] = ge_m[e];
-          if (ex.g_std) ex.g_std[off] = ge_s[e];
         }
         if (g_mu0 != 0.f) atomicAdd(&gz0[d], g_mu0);
         if (g_sg0 != 0.f) atomicAdd(&gz0[g.Dp + d], g_sg0);

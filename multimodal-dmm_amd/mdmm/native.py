@@ -12,12 +12,13 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libmdmm_hip.so')
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SYMBOLS = [
     'mdmm_version', 'mdmm_strerror', 'mdmm_pad',
     'mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd',
     'mdmm_sweep_spill_width_g', 'mdmm_sweep_spill_width_x',
+    'mdmm_sweep_bwd_mode', 'mdmm_sweep_dw_width', 'mdmm_sweep_dw_rows',
     'mdmm_poe_fwd', 'mdmm_poe_bwd', 'mdmm_moe_fwd', 'mdmm_moe_bwd',
     'mdmm_kld_gauss_fwd', 'mdmm_kld_gauss_bwd',
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
@@ -51,7 +52,8 @@ class Sweep(C.Structure):
                  ('g_infer_mean', _P), ('g_infer_std', _P), ('g_prior_mean', _P),
                  ('g_prior_std', _P), ('g_samples', _P),
                  ('g_z0_mean', _P), ('g_z0_sigma', _P), ('g_z_rows', _P),
-                 ('spill_g', _P), ('spill_x', _P), ('spill_rows', C.c_int64)])
+                 ('spill_g', _P), ('spill_x', _P), ('spill_rows', C.c_int64),
+                 ('dw_partial', _P), ('dw_partial_rows', C.c_int64)])
 
 
 class MdmmError(RuntimeError):
@@ -80,6 +82,10 @@ def lib():
             getattr(L, name).argtypes = [C.c_int, C.c_int]
         for name in ('mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd'):
             getattr(L, name).argtypes = [C.POINTER(Sweep), _P]
+        L.mdmm_sweep_bwd_mode.argtypes = [C.POINTER(Sweep)]
+        L.mdmm_sweep_dw_width.argtypes = [C.c_int, C.c_int]
+        L.mdmm_sweep_dw_rows.argtypes = [C.POINTER(Sweep)]
+        L.mdmm_sweep_dw_rows.restype = C.c_int64
         i64, i32, f32 = C.c_int64, C.c_int, C.c_float
         L.mdmm_poe_fwd.argtypes = [_P, _P, _P, i32, i64, i32, _P, _P, _P]
         L.mdmm_poe_bwd.argtypes = [_P, _P, _P, i32, i64, i32, _P, _P, _P, _P, _P]

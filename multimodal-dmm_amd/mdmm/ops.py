@@ -150,6 +150,32 @@ class PackedGtf:
                 d_std[:D, :D], gb[F1 + 2 * Dp:F1 + 2 * Dp + D]]           # z_to_std.0
 
 
+def unpack_dw_partials(part, D, H, like):
+    """Sum the per-workgroup rows of mdmm_sweep_t.dw_partial and slice out the gradients of the
+    12 raw GTF parameters plus d/d z0_mean and d/d sigma0 (layout: include/mdmm_hip.h)."""
+    row = part.sum(0)
+    d16, h16 = 16 * ((D + 15) // 16), 16 * ((H + 15) // 16)
+    f16 = 2 * h16 + d16
+    off = [0]
+
+    def take(n, shape=None):
+        v = row[off[0]:off[0] + n]
+        off[0] += n
+        return v.view(*shape) if shape else v
+
+    w_in, w_gate, w_nl = take(f16 * d16, (f16, d16)), take(d16 * h16, (d16, h16)), take(d16 * h16, (d16, h16))
+    w_std = take(d16 * d16, (d16, d16))
+    b_in, b_gate, b_nl, b_std = take(f16), take(d16), take(d16), take(d16)
+    g_z0m, g_z0s = take(d16)[:D], take(d16)[:D]
+    grads = [w_in[0:H, :D], b_in[0:H],
+             w_gate[:D, :H], b_gate[:D],
+             w_in[2 * h16:2 * h16 + D, :D], b_in[2 * h16:2 * h16 + D],
+             w_in[h16:h16 + H, :D], b_in[h16:h16 + H],
+             w_nl[:D, :H], b_nl[:D],
+             w_std[:D, :D], b_std[:D]]
+    return [g.contiguous() for g in grads], g_z0m, g_z0s
+
+
 # ------------------------------------------------------------------------------------
 # The sweep
 # ------------------------------------------------------------------------------------
@@ -238,6 +264,7 @@ class _SweepFn(torch.autograd.Function):
         _fill_common(s, cfg, z0m, z0s, packed, ctx.eps)
         s.E = n_exp
         tbd = cfg.T * cfg.B * cfg.D
+        shape_p = (cfg.P, cfg.T, cfg.B, cfg.D)
         g_means, g_stds = [], []
         for e in range(n_exp):
             ex = s.experts[e]
@@ -245,11 +272,9 @@ class _SweepFn(torch.autograd.Function):
             ex.pass_stride = tbd if ctx.per_pass[e] else 0
             ex.pass_bits = ctx.bits[e]
             need = ctx.needs_input_grad[7 + 12 + e] or ctx.needs_input_grad[7 + 12 + n_exp + e]
-            if need:
-                # every element is written (passes without the expert write zeros via the
-                # shared-expert sum; per-pass experts are written only for their own passes)
-                gm = (torch.zeros_like(means[e]) if ctx.per_pass[e] else torch.empty_like(means[e]))
-                gs = (torch.zeros_like(stds[e]) if ctx.per_pass[e] else torch.empty_like(stds[e]))
+            if need:    # one slab per pass, written only for the passes the expert is part of
+                gm = torch.zeros(shape_p, device=dev, dtype=torch.float32)
+                gs = torch.zeros(shape_p, device=dev, dtype=torch.float32)
                 ex.g_mean, ex.g_std = _ptr(gm), _ptr(gs)
             else:
                 gm = gs = None
@@ -258,19 +283,30 @@ class _SweepFn(torch.autograd.Function):
         s.infer_mean, s.infer_std, s.prior_mean, s.prior_std = _ptr(im), _ptr(is_), _ptr(pm), _ptr(ps)
         (s.g_infer_mean, s.g_infer_std, s.g_prior_mean, s.g_prior_std,
          s.g_samples) = [_ptr(g) for g in gin]
+        L = native.lib()
         gz0 = torch.zeros(2, cfg.D, device=dev, dtype=torch.float32)
         s.g_z0_mean, s.g_z0_sigma = gz0[0].data_ptr(), gz0[1].data_ptr()
-        rows = cfg.P * cfg.B * cfg.K * (cfg.T - 1)
-        G = X = None
-        if rows > 0:
-            L = native.lib()
-            G = torch.empty(rows, L.mdmm_sweep_spill_width_g(cfg.D, cfg.H), device=dev)
-            X = torch.empty(rows, L.mdmm_sweep_spill_width_x(cfg.D, cfg.H), device=dev)
-            s.spill_g, s.spill_x, s.spill_rows = _ptr(G), _ptr(X), rows
+        G = X = part = None
+        if L.mdmm_sweep_bwd_mode(C.byref(s)) == 1:      # weight gradients accumulated in-kernel
+            n_rows = L.mdmm_sweep_dw_rows(C.byref(s))
+            part = torch.empty(n_rows, L.mdmm_sweep_dw_width(cfg.D, cfg.H), device=dev)
+            s.dw_partial, s.dw_partial_rows = _ptr(part), n_rows
+        else:                                           # GEMM operands spilled per row
+            rows = cfg.P * cfg.B * cfg.K * (cfg.T - 1)
+            if rows > 0:
+                G = torch.empty(rows, L.mdmm_sweep_spill_width_g(cfg.D, cfg.H), device=dev)
+                X = torch.empty(rows, L.mdmm_sweep_spill_width_x(cfg.D, cfg.H), device=dev)
+                s.spill_g, s.spill_x, s.spill_rows = _ptr(G), _ptr(X), rows
         _call('mdmm_bfvi_sweep_bwd', C.byref(s), tag=_sweep_tag('bwd', cfg))
-        g_gtf = packed.unpack_grads(G, X, ctx.gtf_like)
+        if part is not None:
+            g_gtf, g0m, g0s = unpack_dw_partials(part, cfg.D, cfg.H, ctx.gtf_like)
+            gz0 = torch.stack([g0m, g0s])
+        else:
+            g_gtf = packed.unpack_grads(G, X, ctx.gtf_like)
         g_z0_mean = gz0[0].reshape(ctx.z0_shapes[0])
         g_z0_log = (gz0[1] * torch.exp(z0s)).reshape(ctx.z0_shapes[1])
+        g_means = [g if (g is None or pp) else g.sum(0) for g, pp in zip(g_means, ctx.per_pass)]
+        g_stds = [g if (g is None or pp) else g.sum(0) for g, pp in zip(g_stds, ctx.per_pass)]
         g_flat = ([g.reshape(sh) if g is not None else None
                    for g, sh in zip(g_means, ctx.in_shapes[:n_exp])] +
                   [g.reshape(sh) if g is not None else None
