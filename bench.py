@@ -173,9 +173,9 @@ def main():
         p_pass = 3
         rows = p_pass * b_dim * (T_MAX - 1)          # transition rows per particle
         k = TRAIN_PARTICLES if 'K=%d' % TRAIN_PARTICLES in tag else 1
-        # algorithmic flops of one launch: GTF forward (fwd sweep) or GTF recompute + input-
-        # gradient contractions (bwd sweep; weight-gradient GEMMs are separate launches)
-        per_row = gtf_flops(Z_DIM, H_DIM) * (2 if tag.startswith('sweep_bwd') else 1)
+        # algorithmic flops of one launch: GTF forward (fwd sweep); GTF recompute + input-gradient
+        # + weight-gradient contractions (bwd sweep, all three inside the MFMA kernel for z,h<=32)
+        per_row = gtf_flops(Z_DIM, H_DIM) * (3 if tag.startswith('sweep_bwd') else 1)
         flops = rows * k * per_row
         avg_ms = tot_ms / n_launch
         achieved = flops / (avg_ms * 1e-3) / 1e12

@@ -14,9 +14,11 @@ namespace mdmm {
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2,
                                               uint32_t& c3, uint32_t k0, uint32_t k1) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-  uint32_t h0 = __umulhi(M0, c0), l0 = M0 * c0;
-  uint32_t h1 = __umulhi(M1, c2), l1 = M1 * c2;
+  // one 32x32->64 multiply (v_mad_u64_u32) per product instead of separate mul_hi / mul_lo:
+  // 32-bit integer multiplies are quarter-rate and Philox is a third of the sweep's VALU time
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+  const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
   uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
   c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }

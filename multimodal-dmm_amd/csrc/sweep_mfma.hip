@@ -33,6 +33,28 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Noise for the 4 consecutive latent dims a lane holds per register quad.  The hot loop carries
+// only the aligned in-kernel Philox path; recorded eps (parity runs) and z_dim % 4 != 0 go through
+// an out-of-line call so the compiler cannot if-convert them into the loop body.
+__device__ __noinline__ float4 eps4_slow(const float* eps, uint64_t seed, uint64_t offset,
+                                         uint64_t idx, int n_valid) {
+  float e[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    e[r] = r < n_valid ? (eps ? eps[idx + r] : philox_normal(seed, offset, idx + r)) : 0.f;
+  return make_float4(e[0], e[1], e[2], e[3]);
+}
+
+__device__ __forceinline__ void eps4(const mdmm_sweep_t& a, bool fast_path, uint64_t idx, int d0,
+                                     int D, float e4[4]) {
+  if (fast_path) {
+    philox_normal4(a.seed, a.offset, idx >> 2, e4);
+  } else {
+    const float4 v = eps4_slow(a.eps, a.seed, a.offset, idx, D - d0);
+    e4[0] = v.x; e4[1] = v.y; e4[2] = v.z; e4[3] = v.w;
+  }
+}
+
 // Weight fragments: dst[(it*DST_FT + ft_off + ft)*64 + lane] =
 //   { W[row0 + 16it + i][col0 + 16ft + 4g + r] : r = 0..3 },  i = lane & 15, g = lane >> 4;
 // entries outside (n_rows, n_cols) are zero.
@@ -120,22 +142,35 @@ __device__ __forceinline__ void gemm_chain(const float4* wfrag, const float4* bf
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) out[it][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  }
+  // k-steps outermost: the IT*CT accumulators are independent dependency chains, so back-to-back
+  // MFMAs never wait for the 40-cycle accumulator latency
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) {
-      const f32x4 w = ld_frag(wfrag + (it * FT + ft) * 64 + lane);
+  for (int ft = 0; ft < FT; ++ft) {
+    f32x4 w[IT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+    for (int it = 0; it < IT; ++it) w[it] = ld_frag(wfrag + (it * FT + ft) * 64 + lane);
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma16(w[r], in[ft][ct][r], out[it][ct]);
-    }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma16(w[it][r], in[ft][ct][r], out[it][ct]);
   }
 }
 
-__device__ __forceinline__ float row16_sum(float v) {   // all-reduce over the 16 lanes of a column tile
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
+// all-reduce over the 16 lanes of a column tile with DPP row operations (no LDS traffic):
+// xor 1, xor 2 inside quads, then mirror within 8 and within 16 lanes.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int m = __builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true);
+  return v + __int_as_float(m);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);    // row_half_mirror
+  v = dpp_add<0x140>(v);    // row_mirror
   return v;
 }
 
@@ -143,8 +178,8 @@ __device__ __forceinline__ float row16_sum(float v) {   // all-reduce over the 1
 // with the global prior (dmm.py:239-252).  Keeps nothing but the outputs.
 template <int DT, int HT, int CT>
 __device__ __forceinline__ void transition_rows(const float4* lds, int lane, float min_std,
-                                                const f32x4 (&z)[DT][CT], const float (&mu0)[DT][4],
-                                                const float (&sg0)[DT][4], f32x4 (&tm)[DT][CT],
+                                                const f32x4 (&z)[DT][CT], const float (&m0t)[DT][4],
+                                                const float (&t0c)[DT][4], f32x4 (&tm)[DT][CT],
                                                 f32x4 (&ts)[DT][CT]) {
   using L = Lds<DT, HT>;
   f32x4 a1[2 * HT + DT][CT];
@@ -172,13 +207,16 @@ __device__ __forceinline__ void transition_rows(const float4* lds, int lane, flo
         const float gt = fast::sigmoid(gate[dt][ct][r]);
         const float muq = (1.0f - gt) * a1[2 * HT + dt][ct][r] + gt * nl[dt][ct][r];
         const float sq = fast::softplus(pre[dt][ct][r]) + min_std;
-        fast::Poe q; q.init(); q.add(mu0[dt][r], sg0[dt][r], 1.0f); q.add(muq, sq, 1.0f);
+        // product with the global prior: its precision / weighted mean are loop invariants
+        fast::Poe q; q.num = m0t[dt][r]; q.prec = t0c[dt][r];
+        const float tq = fast::rcp(sq * sq + MDMM_POE_EPS);
+        q.add_pre(muq * tq, tq);
         float m, s; q.finish(m, s);
         tm[dt][ct][r] = m; ts[dt][ct][r] = s;
       }
 }
 
-template <int DT, int HT, int CT, bool PART>
+template <int DT, int HT, int CT, bool PART, bool FULL>
 __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a, int n_tasks) {
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   stage_forward_weights<DT, HT>(a, lds);
@@ -187,7 +225,9 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
   const int task = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
   if (task >= n_tasks) return;          // no workgroup-level synchronisation below this line
   const int T = a.T, B = a.B, D = a.D, K = a.K;
-  const bool vec = (D & 3) == 0;
+  const bool vec = FULL || (D & 3) == 0;
+  const int Dg = FULL ? (1 << 30) : D;      // guard extent: FULL (z_dim == 16*DT) needs no masks
+  const bool fast_noise = vec && !a.eps;
   const float inv_k = 1.0f / (float)K;
 
   // rows of this wave: PART -> particle k = 16ct + j of (p_, b_); SEQ -> pair q = task*16CT + 16ct + j
@@ -203,16 +243,18 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
       p_[ct] = qq / B; b_[ct] = qq - p_[ct] * B;
     }
   }
-  float mu0[DT][4], sg0[DT][4];
+  float mu0[DT][4], sg0[DT][4], t0c[DT][4], m0t[DT][4];
   bool fvalid[DT][4];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int d = 16 * dt + 4 * g + r;
-      fvalid[dt][r] = d < D;
+      fvalid[dt][r] = FULL || d < D;
       mu0[dt][r] = fvalid[dt][r] ? a.z0_mean[d] : 0.f;
       sg0[dt][r] = fvalid[dt][r] ? expf(a.z0_log_std[d]) + a.min_std : 1.f;
+      t0c[dt][r] = fast::rcp(sg0[dt][r] * sg0[dt][r] + MDMM_POE_EPS);
+      m0t[dt][r] = mu0[dt][r] * t0c[dt][r];
     }
 
   // posterior of the previously processed step: PART -> per wave (index 0 used), SEQ -> per row
@@ -232,7 +274,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
           for (int r = 0; r < 4; ++r) { pm[dt][n][r] = mu0[dt][r]; ps[dt][n][r] = sg0[dt][r]; }
     } else {
       f32x4 tm[DT][CT], ts[DT][CT];
-      transition_rows<DT, HT, CT>(lds, lane, a.min_std, z, mu0, sg0, tm, ts);
+      transition_rows<DT, HT, CT>(lds, lane, a.min_std, z, m0t, t0c, tm, ts);
       if (PART) {
         {
 #pragma unroll
@@ -281,7 +323,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
           for (int dt = 0; dt < DT; ++dt) {
             const int d0 = 16 * dt + 4 * g;
             float mv[4], sv[4];
-            if (vec && d0 < D) {
+            if (vec && d0 < Dg) {
               const float4 m4 = *reinterpret_cast<const float4*>(ex.mean + off + d0);
               const float4 s4 = *reinterpret_cast<const float4*>(ex.std + off + d0);
               mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
@@ -323,17 +365,9 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
       for (int dt = 0; dt < DT; ++dt) {
         float e4[4] = {0.f, 0.f, 0.f, 0.f};
         const int d0 = 16 * dt + 4 * g;
-        if (sampled && live[ct] && d0 < D) {
+        if (sampled && live[ct] && d0 < Dg) {
           const uint64_t idx = ((((uint64_t)p_[ct] * T + t) * K + k) * B + b_[ct]) * (uint64_t)D + d0;
-          if (a.eps) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e4[r] = fvalid[dt][r] ? a.eps[idx + r] : 0.f;
-          } else if (vec) {
-            philox_normal4(a.seed, a.offset, idx >> 2, e4);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e4[r] = fvalid[dt][r] ? philox_normal(a.seed, a.offset, idx + r) : 0.f;
-          }
+          eps4(a, fast_noise, idx, d0, Dg, e4);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -377,7 +411,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           const int d0 = 16 * dt + 4 * g;
-          if (vec && d0 < D) {
+          if (vec && d0 < Dg) {
             auto st = [&](float* base, const f32x4& v) {
               *reinterpret_cast<float4*>(base + o + d0) = make_float4(v[0], v[1], v[2], v[3]);
             };
@@ -518,14 +552,14 @@ __device__ __forceinline__ void st4_guard(float* base, size_t off, bool vec, int
   }
 }
 
-template <int DT, int HT, int CT, bool PART>
+template <int DT, int HT, int CT, bool PART, bool FULL>
 __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a, int n_tasks) {
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   using L = Lds<DT, HT>;
   using LB = LdsB<DT, HT>;
   constexpr int IT1 = LB::IT1;
   constexpr int NS = PART ? 1 : CT;
-  constexpr int SCR = (IT1 + DT) * 16 * (16 * CT + 4);       // floats of scratch per wave
+  constexpr int SCR = (IT1 + DT) * 16 * (16 + 4);            // floats of scratch per wave (16-row tiles)
   stage_forward_weights<DT, HT>(a, lds);
   stage_backward_weights<DT, HT>(a, lds);
   __syncthreads();
@@ -533,7 +567,9 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
   float* scratch0 = reinterpret_cast<float*>(lds + LB::WEND);
   float* scratch = scratch0 + wave * SCR;
   const int T = a.T, B = a.B, D = a.D, K = a.K;
-  const bool vec = (D & 3) == 0;
+  const bool vec = FULL || (D & 3) == 0;
+  const int Dg = FULL ? (1 << 30) : D;      // guard extent: FULL (z_dim == 16*DT) needs no masks
+  const bool fast_noise = vec && !a.eps;
   const float inv_k = 1.0f / (float)K;
   const size_t tbd = (size_t)T * B * D;
 
@@ -544,7 +580,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int d = 16 * dt + 4 * g + r;
-      fvalid[dt][r] = d < D;
+      fvalid[dt][r] = FULL || d < D;
       mu0[dt][r] = fvalid[dt][r] ? a.z0_mean[d] : 0.f;
       sg0[dt][r] = fvalid[dt][r] ? expf(a.z0_log_std[d]) + a.min_std : 1.f;
       t0c[dt][r] = fast::rcp(sg0[dt][r] * sg0[dt][r] + MDMM_POE_EPS);
@@ -604,11 +640,11 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           const int d0 = 16 * dt + 4 * g;
-          pmv[dt][n] = row_ok ? ld4_guard(a.prior_mean, o, vec, d0, D) : zero4;
-          psv[dt][n] = row_ok ? ld4_guard(a.prior_std, o, vec, d0, D) : f32x4{1.f, 1.f, 1.f, 1.f};
-          const f32x4 gsm = row_ok ? ld4_guard(a.g_samples, o, vec, d0, D) : zero4;
-          g_im[dt] = (row_ok ? ld4_guard(a.g_infer_mean, o, vec, d0, D) : zero4) + adjA[dt][n] + gsm;
-          g_is[dt] = row_ok ? ld4_guard(a.g_infer_std, o, vec, d0, D) : zero4;
+          pmv[dt][n] = row_ok ? ld4_guard(a.prior_mean, o, vec, d0, Dg) : zero4;
+          psv[dt][n] = row_ok ? ld4_guard(a.prior_std, o, vec, d0, Dg) : f32x4{1.f, 1.f, 1.f, 1.f};
+          const f32x4 gsm = row_ok ? ld4_guard(a.g_samples, o, vec, d0, Dg) : zero4;
+          g_im[dt] = (row_ok ? ld4_guard(a.g_infer_mean, o, vec, d0, Dg) : zero4) + adjA[dt][n] + gsm;
+          g_is[dt] = row_ok ? ld4_guard(a.g_infer_std, o, vec, d0, Dg) : zero4;
           if (sampled) {
             g_is[dt] += adjB[dt][n];
             if (a.g_samples) {          // d samples / d std = mean_k eps_k  (dmm.py:399-402)
@@ -620,10 +656,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
                 if (PART ? live[c] : row_ok) {
                   const uint64_t idx = ((((uint64_t)p * T + t) * K + k) * B + b) * (uint64_t)D + d0;
                   float e4[4] = {0.f, 0.f, 0.f, 0.f};
-                  if (d0 < D) {
-                    if (a.eps) { for (int r = 0; r < 4; ++r) e4[r] = (d0 + r < D) ? a.eps[idx + r] : 0.f; }
-                    else if (vec) philox_normal4(a.seed, a.offset, idx >> 2, e4);
-                    else { for (int r = 0; r < 4; ++r) e4[r] = (d0 + r < D) ? philox_normal(a.seed, a.offset, idx + r) : 0.f; }
+                  if (d0 < Dg) {
+                    eps4(a, fast_noise, idx, d0, Dg, e4);
                   }
 #pragma unroll
                   for (int r = 0; r < 4; ++r) se[r] += e4[r];
@@ -648,8 +682,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
               const int d0 = 16 * dt + 4 * g;
-              const f32x4 mv = ld4_guard(ex.mean, off, vec, d0, D);
-              f32x4 sv = ld4_guard(ex.std, off, vec, d0, D);
+              const f32x4 mv = ld4_guard(ex.mean, off, vec, d0, Dg);
+              f32x4 sv = ld4_guard(ex.std, off, vec, d0, Dg);
 #pragma unroll
               for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(mv[r], sv[r], c);
             }
@@ -691,8 +725,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
               const int d0 = 16 * dt + 4 * g;
-              const f32x4 mv = ld4_guard(ex.mean, off, vec, d0, D);
-              const f32x4 sv = ld4_guard(ex.std, off, vec, d0, D);
+              const f32x4 mv = ld4_guard(ex.mean, off, vec, d0, Dg);
+              const f32x4 sv = ld4_guard(ex.std, off, vec, d0, Dg);
               f32x4 gm4, gs4;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
@@ -702,8 +736,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
                 gm4[r] = g_num[dt][r] * tt * c;
                 gs4[r] = -(g_t * c * sg) * iv * iv * 2.0f * sv[r];
               }
-              st4_guard(ex.g_mean, o, vec, d0, D, gm4);
-              st4_guard(ex.g_std, o, vec, d0, D, gs4);
+              st4_guard(ex.g_mean, o, vec, d0, Dg, gm4);
+              st4_guard(ex.g_std, o, vec, d0, Dg, gs4);
             }
           }
         }
@@ -720,8 +754,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
               gs0 += 2.0f * g_t * t0c[dt][r] * t0c[dt][r] * sg0[dt][r];
             }
             if (i == 0) {
-              gpm[dt][n][r] += a.g_prior_mean ? ld4_guard(a.g_prior_mean, o, vec, 16 * dt + 4 * g, D)[r] : 0.f;
-              gps[dt][n][r] += a.g_prior_std ? ld4_guard(a.g_prior_std, o, vec, 16 * dt + 4 * g, D)[r] : 0.f;
+              gpm[dt][n][r] += a.g_prior_mean ? ld4_guard(a.g_prior_mean, o, vec, 16 * dt + 4 * g, Dg)[r] : 0.f;
+              gps[dt][n][r] += a.g_prior_std ? ld4_guard(a.g_prior_std, o, vec, 16 * dt + 4 * g, Dg)[r] : 0.f;
               if (fvalid[dt][r] && row_ok) { gm0 += gpm[dt][n][r]; gs0 += gps[dt][n][r]; }
             }
             if (PART) { gzm_wav[dt][r] += gm0; gzs_wav[dt][r] += gs0; }
@@ -732,8 +766,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
           for (int dt = 0; dt < DT; ++dt) {
             const int d0 = 16 * dt + 4 * g;
             if (row_ok) {
-              gpm[dt][n] += ld4_guard(a.g_prior_mean, o, vec, d0, D);
-              gps[dt][n] += ld4_guard(a.g_prior_std, o, vec, d0, D);
+              gpm[dt][n] += ld4_guard(a.g_prior_mean, o, vec, d0, Dg);
+              gps[dt][n] += ld4_guard(a.g_prior_std, o, vec, d0, Dg);
             }
           }
         }
@@ -741,61 +775,61 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
       if (i == 0) break;
 
       // ---------- adjoint of the transition: rows = particles of the previous step ----------
+      // One 16-row column tile at a time: every transient below is [..][1] (half the registers
+      // of a 32-row pass); the tiles only meet in the adjoint sums and the weight accumulators.
       const int t_prev = a.reverse ? t + 1 : t - 1;
       const bool sampled_prev = a.sample || K > 1 || (i == 1 && a.sample_init);
-      f32x4 z[DT][CT], ev[DT][CT];
+      f32x4 sumA[DT], sumB[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { sumA[dt] = zero4; sumB[dt] = zero4; }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const int k = PART ? (16 * ct + j) : 0;
-        const size_t o = (size_t)p_[ct] * tbd + ((size_t)t_prev * B + b_[ct]) * D;
+        const int n = PART ? 0 : ct;
+        f32x4 z[DT][1], ev[DT][1];
+        {
+          const int k = PART ? (16 * ct + j) : 0;
+          const size_t o = (size_t)p_[ct] * tbd + ((size_t)t_prev * B + b_[ct]) * D;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          const int d0 = 16 * dt + 4 * g;
-          const f32x4 zm = live[ct] ? ld4_guard(a.infer_mean, o, vec, d0, D) : zero4;
-          const f32x4 zs = live[ct] ? ld4_guard(a.infer_std, o, vec, d0, D) : zero4;
-          float e4[4] = {0.f, 0.f, 0.f, 0.f};
-          if (sampled_prev && live[ct] && d0 < D) {
-            const uint64_t idx = ((((uint64_t)p_[ct] * T + t_prev) * K + k) * B + b_[ct]) * (uint64_t)D + d0;
-            if (a.eps) { for (int r = 0; r < 4; ++r) e4[r] = (d0 + r < D) ? a.eps[idx + r] : 0.f; }
-            else if (vec) philox_normal4(a.seed, a.offset, idx >> 2, e4);
-            else { for (int r = 0; r < 4; ++r) e4[r] = (d0 + r < D) ? philox_normal(a.seed, a.offset, idx + r) : 0.f; }
-          }
+          for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = 16 * dt + 4 * g;
+            const f32x4 zm = live[ct] ? ld4_guard(a.infer_mean, o, vec, d0, Dg) : zero4;
+            const f32x4 zs = live[ct] ? ld4_guard(a.infer_std, o, vec, d0, Dg) : zero4;
+            float e4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (sampled_prev && live[ct] && d0 < Dg) {
+              const uint64_t idx = ((((uint64_t)p_[ct] * T + t_prev) * K + k) * B + b_[ct]) * (uint64_t)D + d0;
+              eps4(a, fast_noise, idx, d0, Dg, e4);
+            }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            ev[dt][ct][r] = e4[r];
-            z[dt][ct][r] = (live[ct] && fvalid[dt][r]) ? (sampled_prev ? fmaf(e4[r], zs[r], zm[r]) : zm[r]) : 0.f;
+            for (int r = 0; r < 4; ++r) {
+              ev[dt][0][r] = e4[r];
+              z[dt][0][r] = (live[ct] && fvalid[dt][r]) ? (sampled_prev ? fmaf(e4[r], zs[r], zm[r]) : zm[r]) : 0.f;
+            }
           }
         }
-      }
-      // forward recompute (kept: relu hidden, z_lin, gate, nonlin, std pre-activation)
-      f32x4 a1[IT1][CT];
-      gemm_chain<IT1, DT, CT>(lds + L::W1, lds + L::B1, lane, z, a1);
-      f32x4 h1[HT][CT], h2[HT][CT];
+        // forward recompute (kept: relu hidden, z_lin, gate, nonlin, std pre-activation)
+        f32x4 a1[IT1][1];
+        gemm_chain<IT1, DT, 1>(lds + L::W1, lds + L::B1, lane, z, a1);
+        f32x4 h1[HT][1], h2[HT][1];
 #pragma unroll
-      for (int ft = 0; ft < HT; ++ft)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int ft = 0; ft < HT; ++ft)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            h1[ft][ct][r] = fmaxf(a1[ft][ct][r], 0.f);
-            h2[ft][ct][r] = fmaxf(a1[HT + ft][ct][r], 0.f);
+            h1[ft][0][r] = fmaxf(a1[ft][0][r], 0.f);
+            h2[ft][0][r] = fmaxf(a1[HT + ft][0][r], 0.f);
           }
-      f32x4 gate[DT][CT], nl[DT][CT], pre[DT][CT];
-      gemm_chain<DT, HT, CT>(lds + L::WG, lds + L::BG, lane, h1, gate);
-      gemm_chain<DT, HT, CT>(lds + L::WN, lds + L::BN, lane, h2, nl);
-      gemm_chain<DT, DT, CT>(lds + L::WS, lds + L::BS, lane, nl, pre);
-      // elementwise adjoints per (row, feature); afterwards
-      //   pre <- d/d std-pre, gate <- d/d gate-pre, gnl <- direct part of d/d nonlin, a1[2HT..] <- d/d z_lin
-      f32x4 gnl[DT][CT];
+        f32x4 gate[DT][1], nl[DT][1], pre[DT][1];
+        gemm_chain<DT, HT, 1>(lds + L::WG, lds + L::BG, lane, h1, gate);
+        gemm_chain<DT, HT, 1>(lds + L::WN, lds + L::BN, lane, h2, nl);
+        gemm_chain<DT, DT, 1>(lds + L::WS, lds + L::BS, lane, nl, pre);
+        // elementwise adjoints per (row, feature); afterwards
+        //   pre <- d/d std-pre, gate <- d/d gate-pre, gnl <- direct part of d/d nonlin, a1[2HT..] <- d/d z_lin
+        f32x4 gnl[DT][1];
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const int n = PART ? 0 : ct;
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float gt = fast::sigmoid(gate[dt][ct][r]);
-            const float lin = a1[2 * HT + dt][ct][r], nlv = nl[dt][ct][r], prv = pre[dt][ct][r];
+            const float gt = fast::sigmoid(gate[dt][0][r]);
+            const float lin = a1[2 * HT + dt][0][r], nlv = nl[dt][0][r], prv = pre[dt][0][r];
             const float muq = (1.0f - gt) * lin + gt * nlv;
             const float sq = fast::softplus(prv) + a.min_std;
             const float tq = fast::rcp(sq * sq + MDMM_POE_EPS);
@@ -820,69 +854,63 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
             const float g_muq = g_num * tq;
             const float g_tq = g_num * muq + g_prec;
             const float g_sq = -g_tq * tq * tq * 2.0f * sq;
-            pre[dt][ct][r] = g_sq * fast::softplus_grad(prv);
-            gnl[dt][ct][r] = g_muq * gt;
-            a1[2 * HT + dt][ct][r] = g_muq * (1.0f - gt);
-            gate[dt][ct][r] = g_muq * (nlv - lin) * gt * (1.0f - gt);
+            pre[dt][0][r] = g_sq * fast::softplus_grad(prv);
+            gnl[dt][0][r] = g_muq * gt;
+            a1[2 * HT + dt][0][r] = g_muq * (1.0f - gt);
+            gate[dt][0][r] = g_muq * (nlv - lin) * gt * (1.0f - gt);
+          }
+        // d/d nonlin += W_std^T d/d std-pre ; weight grads of z_to_std
+        gemm_chain<DT, DT, 1, 2>(lds + LB::TS, nullptr, lane, pre, gnl);
+        dw_accumulate<DT, DT, 1>(scratch, lane, pre, nl, dWs);
+        bias_accumulate<DT, 1>(pre, dbs);
+        // gate branch
+        {
+          f32x4 gh[HT][1];
+          gemm_chain<HT, DT, 1, 0>(lds + LB::TG, nullptr, lane, gate, gh);
+          dw_accumulate<DT, HT, 1>(scratch, lane, gate, h1, dWg);
+          bias_accumulate<DT, 1>(gate, dbg);
+#pragma unroll
+          for (int ft = 0; ft < HT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[ft][0][r] = h1[ft][0][r] > 0.f ? gh[ft][0][r] : 0.f;
+        }
+        // nonlin branch
+        {
+          f32x4 gh[HT][1];
+          gemm_chain<HT, DT, 1, 0>(lds + LB::TN, nullptr, lane, gnl, gh);
+          dw_accumulate<DT, HT, 1>(scratch, lane, gnl, h2, dWn);
+          bias_accumulate<DT, 1>(gnl, dbn);
+#pragma unroll
+          for (int ft = 0; ft < HT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[HT + ft][0][r] = h2[ft][0][r] > 0.f ? gh[ft][0][r] : 0.f;
+        }
+        // d/dz = W_in^T [d/d gate-hidden | d/d nl-hidden | d/d z_lin] ; weight grads of the in layer
+        f32x4 gz[DT][1];
+        gemm_chain<DT, IT1, 1, 0>(lds + LB::T1, nullptr, lane, a1, gz);
+        dw_accumulate<IT1, DT, 1>(scratch, lane, a1, z, dW1);
+        bias_accumulate<IT1, 1>(a1, db1);
+        // adjoints of the previous step's particles
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          if (PART) {       // dead rows / pad features carry zeros
+            sumA[dt] += gz[dt][0];
+            sumB[dt] += gz[dt][0] * ev[dt][0];
+          } else {
+            adjA[dt][ct] = gz[dt][0];
+            adjB[dt][ct] = sampled_prev ? gz[dt][0] * ev[dt][0] : zero4;
           }
         }
-      // d/d nonlin += W_std^T d/d std-pre ; weight grads of z_to_std
-      gemm_chain<DT, DT, CT, 2>(lds + LB::TS, nullptr, lane, pre, gnl);
-      dw_accumulate<DT, DT, CT>(scratch, lane, pre, nl, dWs);
-      bias_accumulate<DT, CT>(pre, dbs);
-      // gate branch
-      {
-        f32x4 gh[HT][CT];
-        gemm_chain<HT, DT, CT, 0>(lds + LB::TG, nullptr, lane, gate, gh);
-        dw_accumulate<DT, HT, CT>(scratch, lane, gate, h1, dWg);
-        bias_accumulate<DT, CT>(gate, dbg);
-#pragma unroll
-        for (int ft = 0; ft < HT; ++ft)
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a1[ft][ct][r] = h1[ft][ct][r] > 0.f ? gh[ft][ct][r] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);      // keep the column tiles from being interleaved
       }
-      // nonlin branch
-      {
-        f32x4 gh[HT][CT];
-        gemm_chain<HT, DT, CT, 0>(lds + LB::TN, nullptr, lane, gnl, gh);
-        dw_accumulate<DT, HT, CT>(scratch, lane, gnl, h2, dWn);
-        bias_accumulate<DT, CT>(gnl, dbn);
+      if (PART) {
 #pragma unroll
-        for (int ft = 0; ft < HT; ++ft)
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a1[HT + ft][ct][r] = h2[ft][ct][r] > 0.f ? gh[ft][ct][r] : 0.f;
-      }
-      // d/dz = W_in^T [d/d gate-hidden | d/d nl-hidden | d/d z_lin] ; weight grads of the in layer
-      f32x4 gz[DT][CT];
-      gemm_chain<DT, IT1, CT, 0>(lds + LB::T1, nullptr, lane, a1, gz);
-      dw_accumulate<IT1, DT, CT>(scratch, lane, a1, z, dW1);
-      bias_accumulate<IT1, CT>(a1, db1);
-      // adjoints of the previous step's particles
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        if (PART) {
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float sa = 0.f, sb = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-              sa += gz[dt][ct][r];                      // dead rows / pad features carry zeros
-              sb = fmaf(gz[dt][ct][r], ev[dt][ct][r], sb);
-            }
-            adjA[dt][0][r] = row16_sum(sa);
-            adjB[dt][0][r] = sampled_prev ? row16_sum(sb) : 0.f;
+            adjA[dt][0][r] = row16_sum(sumA[dt][r]);
+            adjB[dt][0][r] = sampled_prev ? row16_sum(sumB[dt][r]) : 0.f;
           }
-        } else {
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            adjA[dt][ct] = gz[dt][ct];
-            adjB[dt][ct] = sampled_prev ? gz[dt][ct] * ev[dt][ct] : zero4;
-          }
-        }
       }
     }
   }
@@ -939,22 +967,26 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
 
 constexpr int BWD_MAX_BLOCKS = 256;     // one 4-wave workgroup per CU (LDS-bound), persistent
 
+// K = 1 (SEQ): rows per wave.  The sweep is a latency chain of T dependent steps, so spread the
+// (pass, sequence) rows over as many waves as the chip has SIMDs before doubling up.
+static inline int seq_ct(const mdmm_sweep_t* a) { return (a->P * a->B > 16 * 1024) ? 2 : 1; }
+
 template <int DT, int HT, int CT, bool PART>
 int bwd_tasks(const mdmm_sweep_t* a) {
   return PART ? a->P * a->B : (a->P * a->B + 16 * CT - 1) / (16 * CT);
 }
 
-template <int DT, int HT, int CT, bool PART>
-int launch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
+template <int DT, int HT, int CT, bool PART, bool FULL>
+int launch_bwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   using LB = LdsB<DT, HT>;
   const int n_tasks = bwd_tasks<DT, HT, CT, PART>(a);
   int grid = (n_tasks + 3) / 4;
   if (grid > BWD_MAX_BLOCKS) grid = BWD_MAX_BLOCKS;
   if (!a->dw_partial || a->dw_partial_rows < grid) return MDMM_E_ARG;
-  const size_t scr = (size_t)(NT / 64) * (LB::IT1 + DT) * 16 * (16 * CT + 4) * sizeof(float);
+  const size_t scr = (size_t)(NT / 64) * (LB::IT1 + DT) * 16 * (16 + 4) * sizeof(float);
   const size_t red = (size_t)LB::WIDTH * sizeof(float);
   const size_t lds = (size_t)LB::WEND * sizeof(float4) + (scr > red ? scr : red);
-  auto kern = sweep_mfma_bwd_kernel<DT, HT, CT, PART>;
+  auto kern = sweep_mfma_bwd_kernel<DT, HT, CT, PART, FULL>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -962,19 +994,27 @@ int launch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+template <int DT, int HT, int CT, bool PART>
+int launch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
+  return a->D == 16 * DT ? launch_bwd_<DT, HT, CT, PART, true>(a, stream)
+                         : launch_bwd_<DT, HT, CT, PART, false>(a, stream);
+}
+
 template <int DT, int HT>
 int dispatch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
-  if (a->K == 1) return launch_bwd<DT, HT, 2, false>(a, stream);
+  if (a->K == 1)
+    return seq_ct(a) == 2 ? launch_bwd<DT, HT, 2, false>(a, stream)
+                          : launch_bwd<DT, HT, 1, false>(a, stream);
   if (a->K <= 16) return launch_bwd<DT, HT, 1, true>(a, stream);
   if (a->K <= 32) return launch_bwd<DT, HT, 2, true>(a, stream);
   return MDMM_UNSUPPORTED;
 }
 
-template <int DT, int HT, int CT, bool PART>
-int launch_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
+template <int DT, int HT, int CT, bool PART, bool FULL>
+int launch_fwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   const int n_tasks = PART ? a->P * a->B : (a->P * a->B + 16 * CT - 1) / (16 * CT);
   const size_t lds = (size_t)Lds<DT, HT>::FWD_END * sizeof(float4);
-  auto kern = sweep_mfma_fwd_kernel<DT, HT, CT, PART>;
+  auto kern = sweep_mfma_fwd_kernel<DT, HT, CT, PART, FULL>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -982,9 +1022,17 @@ int launch_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+template <int DT, int HT, int CT, bool PART>
+int launch_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
+  return a->D == 16 * DT ? launch_fwd_<DT, HT, CT, PART, true>(a, stream)
+                         : launch_fwd_<DT, HT, CT, PART, false>(a, stream);
+}
+
 template <int DT, int HT>
 int dispatch_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
-  if (a->K == 1) return launch_fwd<DT, HT, 2, false>(a, stream);
+  if (a->K == 1)
+    return seq_ct(a) == 2 ? launch_fwd<DT, HT, 2, false>(a, stream)
+                          : launch_fwd<DT, HT, 1, false>(a, stream);
   if (a->K <= 16) return launch_fwd<DT, HT, 1, true>(a, stream);
   if (a->K <= 32) return launch_fwd<DT, HT, 2, true>(a, stream);
   return MDMM_UNSUPPORTED;
@@ -999,7 +1047,7 @@ static bool mfma_shape(const mdmm_sweep_t* a) {
 template <int DT, int HT>
 int64_t dw_rows_for(const mdmm_sweep_t* a) {
   int n_tasks;
-  if (a->K == 1) n_tasks = bwd_tasks<DT, HT, 2, false>(a);
+  if (a->K == 1) n_tasks = (a->P * a->B + 16 * seq_ct(a) - 1) / (16 * seq_ct(a));
   else n_tasks = a->P * a->B;
   int64_t grid = (n_tasks + 3) / 4;
   return grid > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : grid;
