@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 2
+#define MDMM_ABI_VERSION 4
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -136,6 +136,10 @@ typedef struct mdmm_sweep {
    *   db_std [D16] | d z0_mean [D16] | d sigma0 [D16]        (g_z0_* are not written then) */
   float* dw_partial;
   int64_t dw_partial_rows; /* capacity; needs mdmm_sweep_dw_rows(args) */
+  /* Optional device-resident addend to `offset` (read by the kernel at launch): lets a
+   * hipGraph-captured step draw fresh noise on every replay -- the host bumps the counter with
+   * a captured device op instead of re-recording kernel arguments.  NULL = 0.  */
+  const uint64_t* offset_dev;
 } mdmm_sweep_t;
 
 int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream);
@@ -200,11 +204,92 @@ int mdmm_nll_categorical_bwd(const float* probs, const float* x, const float* se
                              void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * MultiDKS (models/dks.py): the two sequential recurrences of the RNN structured-inference
+ * model.  Everything time-parallel (input projections W_ih x_t for all t, the combiner's
+ * feature columns) is left to the caller as plain GEMMs; these kernels run the scans.
+ *
+ * GRU with skip updates, dks.py:219-231 around nn.GRU on a length-1 sequence:
+ *   gh = W_hh h + b_hh;  r = s(gi_r + gh_r);  u = s(gi_z + gh_z);  n = tanh(gi_n + r*gh_n)
+ *   h_new = (1-u)*n + u*h;  h <- mask*h_new + (1-mask)*h   (skip) or h <- h_new.
+ * One call = one layer of one modality.  Hp = mdmm_pad(H); gate blocks [r|z|n] of Hp rows.  */
+typedef struct mdmm_gru {
+  int32_t T, B, H;
+  int32_t reverse;      /* 1: t = T-1 .. 0 (rnn_dir 'bwd', dks.py:218) */
+  int32_t skip;         /* rnn_skip, dks.py:224-227 */
+  int32_t reserved;
+  const float* gi;      /* (T,B,3H) = W_ih x_t + b_ih, gates [r|z|n] */
+  const float* w_hh;    /* [3Hp][Hp] */
+  const float* wt_hh;   /* [Hp][3Hp] */
+  const float* b_hh;    /* [3Hp] */
+  const float* h0;      /* (H), dks.py:216 */
+  const float* mask;    /* (T,B) float 0/1 or NULL */
+  float* h_new;         /* (T,B,H) GRU output before the skip blend (input of the next layer) */
+  float* h_seq;         /* (T,B,H) state after step t (time-indexed; top layer = h_out) */
+  /* backward */
+  const float* g_h_new; /* upstream, may be NULL */
+  const float* g_h_seq; /* upstream, may be NULL */
+  float* g_gi;          /* (T,B,3H) */
+  float* g_gh;          /* (T,B,3Hp) d/d(W_hh h + b_hh): caller forms dW_hh = g_gh^T h_prev */
+  float* g_h0;          /* (H) += (atomic; zero first) */
+} mdmm_gru_t;
+int mdmm_gru_skip_fwd(const mdmm_gru_t* args, void* stream);
+int mdmm_gru_skip_bwd(const mdmm_gru_t* args, void* stream);
+
+/* Combiner recurrence, dks.py:246-280: prior_t = GTF(z_{t-1}) (t > 0; fixed (z0_mean, z0_std)
+ * at t = 0 with z_{-1} := z0_mean), hidden = relu(W_z z_{t-1} + u_t), (mean, std) =
+ * (W_m hidden + b_m, softplus(W_s hidden + b_s) + min_std_comb), infer_t = combiner output for
+ * t <= t_stop[b] else prior_t, z_t = infer_mean + infer_std * eps or infer_mean.
+ * u_t = (columns of combiner.in_to_h that multiply [h_out_t, feat_t]) . [h_out_t, feat_t] + bias. */
+typedef struct mdmm_dks {
+  int32_t T, B, D, H;
+  int32_t sample, sample_init;
+  float min_std_gtf, min_std_comb;
+  uint64_t seed, offset;
+  const uint64_t* offset_dev;
+  const float* eps;       /* (T,B,D) or NULL -> Philox */
+  mdmm_gtf_t gtf;         /* self.fwd, packed as for the sweep */
+  const float* w_z;       /* [Hp][Dp] combiner.in_to_h.0.weight[:, :D] */
+  const float* wt_z;      /* [Dp][Hp] */
+  const float* w_m;       /* [Dp][Hp] combiner.h_to_mean */
+  const float* wt_m;      /* [Hp][Dp] */
+  const float* b_m;       /* [Dp] */
+  const float* w_s;       /* [Dp][Hp] combiner.h_to_std.0 */
+  const float* wt_s;      /* [Hp][Dp] */
+  const float* b_s;       /* [Dp] */
+  const float* u;         /* (T,B,H) */
+  const float* z0_mean;   /* (D) dks.py:154 */
+  const float* z0_std;    /* (D) dks.py:155 */
+  const int32_t* t_stop;  /* (B) dks.py:242-244 */
+  float* infer_mean;      /* (T,B,D) outputs; the backward kernel reads z back */
+  float* infer_std;
+  float* prior_mean;
+  float* prior_std;
+  float* z;
+  /* backward: upstream gradients (NULL = 0) */
+  const float* g_infer_mean;
+  const float* g_infer_std;
+  const float* g_prior_mean;
+  const float* g_prior_std;
+  const float* g_z;
+  float* g_u;             /* (T,B,H) */
+  /* weight-gradient GEMM operands: GTF rows as mdmm_sweep_t.spill_* (row = (t-1)*B + b, t >= 1);
+   * combiner rows (row = t*B + b): G_c [Hp | Dp | Dp] = d/d(hidden-pre | mean | std-pre),
+   * X_c [Dp | Hp] = (z_{t-1} | hidden) */
+  float* spill_g;
+  float* spill_x;
+  float* spill_gc;
+  float* spill_xc;
+} mdmm_dks_t;
+int mdmm_dks_combiner_fwd(const mdmm_dks_t* args, void* stream);
+int mdmm_dks_combiner_bwd(const mdmm_dks_t* args, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * The noise the sweeps draw when eps == NULL: out[i] = N(0,1) sample number i of the
- * Philox4x32-10 stream (seed, offset), i in [0, n).  Element i is the eps of the
+ * Philox4x32-10 stream (seed, offset + *offset_dev), i in [0, n).  Element i is the eps of the
  * (p,t,k,b,d) entry with flat index i of a (P,T,K,B,D) tensor, so a caller can
  * materialise exactly what a sweep used (replaces dgts.py:179 `normal_()`).  */
-int mdmm_philox_normal(uint64_t seed, uint64_t offset, int64_t n, float* out, void* stream);
+int mdmm_philox_normal(uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t n,
+                       float* out, void* stream);
 
 #ifdef __cplusplus
 }

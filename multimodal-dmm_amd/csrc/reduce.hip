@@ -263,8 +263,10 @@ __global__ __launch_bounds__(NT) void moe_bwd_kernel(const float* __restrict__ m
   }
 }
 
-__global__ __launch_bounds__(NT) void philox_kernel(uint64_t seed, uint64_t offset, int64_t n,
+__global__ __launch_bounds__(NT) void philox_kernel(uint64_t seed, uint64_t offset,
+                                                    const uint64_t* offset_dev, int64_t n,
                                                     float* out) {
+  if (offset_dev) offset += *offset_dev;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
     out[i] = philox_normal(seed, offset, (uint64_t)i);
 }
@@ -388,10 +390,11 @@ extern "C" int mdmm_moe_bwd(const float* mean, const float* std, const float* ma
   CHECK_LAUNCH();
 }
 
-extern "C" int mdmm_philox_normal(uint64_t seed, uint64_t offset, int64_t n, float* out,
-                                  void* stream) {
+extern "C" int mdmm_philox_normal(uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                  int64_t n, float* out, void* stream) {
   if (!out || n < 0) return MDMM_E_ARG;
-  hipLaunchKernelGGL(philox_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, seed, offset, n, out);
+  hipLaunchKernelGGL(philox_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, seed, offset, offset_dev, n,
+                     out);
   CHECK_LAUNCH();
 }
 

@@ -45,12 +45,12 @@ __device__ __noinline__ float4 eps4_slow(const float* eps, uint64_t seed, uint64
   return make_float4(e[0], e[1], e[2], e[3]);
 }
 
-__device__ __forceinline__ void eps4(const mdmm_sweep_t& a, bool fast_path, uint64_t idx, int d0,
-                                     int D, float e4[4]) {
+__device__ __forceinline__ void eps4(const mdmm_sweep_t& a, uint64_t noise_offset, bool fast_path,
+                                     uint64_t idx, int d0, int D, float e4[4]) {
   if (fast_path) {
-    philox_normal4(a.seed, a.offset, idx >> 2, e4);
+    philox_normal4(a.seed, noise_offset, idx >> 2, e4);
   } else {
-    const float4 v = eps4_slow(a.eps, a.seed, a.offset, idx, D - d0);
+    const float4 v = eps4_slow(a.eps, a.seed, noise_offset, idx, D - d0);
     e4[0] = v.x; e4[1] = v.y; e4[2] = v.z; e4[3] = v.w;
   }
 }
@@ -228,6 +228,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
   const bool vec = FULL || (D & 3) == 0;
   const int Dg = FULL ? (1 << 30) : D;      // guard extent: FULL (z_dim == 16*DT) needs no masks
   const bool fast_noise = vec && !a.eps;
+  const uint64_t noise_offset = a.offset + (a.offset_dev ? *a.offset_dev : 0);
   const float inv_k = 1.0f / (float)K;
 
   // rows of this wave: PART -> particle k = 16ct + j of (p_, b_); SEQ -> pair q = task*16CT + 16ct + j
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
         const int d0 = 16 * dt + 4 * g;
         if (sampled && live[ct] && d0 < Dg) {
           const uint64_t idx = ((((uint64_t)p_[ct] * T + t) * K + k) * B + b_[ct]) * (uint64_t)D + d0;
-          eps4(a, fast_noise, idx, d0, Dg, e4);
+          eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -570,6 +571,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
   const bool vec = FULL || (D & 3) == 0;
   const int Dg = FULL ? (1 << 30) : D;      // guard extent: FULL (z_dim == 16*DT) needs no masks
   const bool fast_noise = vec && !a.eps;
+  const uint64_t noise_offset = a.offset + (a.offset_dev ? *a.offset_dev : 0);
   const float inv_k = 1.0f / (float)K;
   const size_t tbd = (size_t)T * B * D;
 
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
                   const uint64_t idx = ((((uint64_t)p * T + t) * K + k) * B + b) * (uint64_t)D + d0;
                   float e4[4] = {0.f, 0.f, 0.f, 0.f};
                   if (d0 < Dg) {
-                    eps4(a, fast_noise, idx, d0, Dg, e4);
+                    eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
                   }
 #pragma unroll
                   for (int r = 0; r < 4; ++r) se[r] += e4[r];
@@ -797,7 +799,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
             float e4[4] = {0.f, 0.f, 0.f, 0.f};
             if (sampled_prev && live[ct] && d0 < Dg) {
               const uint64_t idx = ((((uint64_t)p_[ct] * T + t_prev) * K + k) * B + b_[ct]) * (uint64_t)D + d0;
-              eps4(a, fast_noise, idx, d0, Dg, e4);
+              eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -987,9 +989,13 @@ int launch_bwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   const size_t red = (size_t)LB::WIDTH * sizeof(float);
   const size_t lds = (size_t)LB::WEND * sizeof(float4) + (scr > red ? scr : red);
   auto kern = sweep_mfma_bwd_kernel<DT, HT, CT, PART, FULL>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds);
-  if (e != hipSuccess) return (int)e;
+  static size_t attr_lds = 0;         // per template instantiation (LDS size depends on CT only)
+  if (attr_lds < lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_lds = lds;
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, *a, n_tasks);
   return (int)hipGetLastError();
 }
@@ -1015,9 +1021,13 @@ int launch_fwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   const int n_tasks = PART ? a->P * a->B : (a->P * a->B + 16 * CT - 1) / (16 * CT);
   const size_t lds = (size_t)Lds<DT, HT>::FWD_END * sizeof(float4);
   auto kern = sweep_mfma_fwd_kernel<DT, HT, CT, PART, FULL>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds);
-  if (e != hipSuccess) return (int)e;
+  static bool attr_set = false;       // per template instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
   hipLaunchKernelGGL(kern, dim3((n_tasks + 3) / 4), dim3(NT), lds, stream, *a, n_tasks);
   return (int)hipGetLastError();
 }

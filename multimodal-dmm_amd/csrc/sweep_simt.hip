@@ -11,100 +11,17 @@
 // The backward kernel is a reverse scan that recomputes the transition from the saved
 // (T,B,D) posteriors instead of storing per-particle activations ("Activation
 // memory vs recompute"), and spills the weight-gradient GEMM operands (G, X) per row.
-#include "mdmm_device.h"
+#include "simt_tiles.h"
 #include "sweep_internal.h"
 
 namespace {
 
 using namespace mdmm;
-
-constexpr int NT = 256;
-
-__host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-
-// out[f][r] = epi(f, bias[f] + sum_k wt[k][f] * in[k][r])   for f < F, r < RC
-// wt: global, [Kd][ldw] (ldw >= F, multiples of 4); in/out: LDS, row length RC.
-template <class Epi>
-__device__ __forceinline__ void gemm_lds(const float* __restrict__ wt, int ldw,
-                                         const float* __restrict__ bias, const float* in,
-                                         float* out, int Kd, int F, int RC, Epi epi) {
-  const int nfq = F >> 2, ngr = RC >> 2;
-  for (int task = threadIdx.x; task < nfq * ngr; task += NT) {
-    const int fq = task % nfq, g = task / nfq;
-    const int f0 = fq << 2, r0 = g << 2;
-    float4 acc[4];
-    float4 b = bias ? ld4(bias + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    acc[0] = make_float4(b.x, b.x, b.x, b.x);
-    acc[1] = make_float4(b.y, b.y, b.y, b.y);
-    acc[2] = make_float4(b.z, b.z, b.z, b.z);
-    acc[3] = make_float4(b.w, b.w, b.w, b.w);
-    const float* wp = wt + f0;
-    const float* ip = in + r0;
-#pragma unroll 4
-    for (int k = 0; k < Kd; ++k) {
-      const float4 w = ld4(wp + (size_t)k * ldw);
-      const float4 x = ld4(ip + k * RC);
-      acc[0].x = fmaf(w.x, x.x, acc[0].x); acc[0].y = fmaf(w.x, x.y, acc[0].y);
-      acc[0].z = fmaf(w.x, x.z, acc[0].z); acc[0].w = fmaf(w.x, x.w, acc[0].w);
-      acc[1].x = fmaf(w.y, x.x, acc[1].x); acc[1].y = fmaf(w.y, x.y, acc[1].y);
-      acc[1].z = fmaf(w.y, x.z, acc[1].z); acc[1].w = fmaf(w.y, x.w, acc[1].w);
-      acc[2].x = fmaf(w.z, x.x, acc[2].x); acc[2].y = fmaf(w.z, x.y, acc[2].y);
-      acc[2].z = fmaf(w.z, x.z, acc[2].z); acc[2].w = fmaf(w.z, x.w, acc[2].w);
-      acc[3].x = fmaf(w.w, x.x, acc[3].x); acc[3].y = fmaf(w.w, x.y, acc[3].y);
-      acc[3].z = fmaf(w.w, x.z, acc[3].z); acc[3].w = fmaf(w.w, x.w, acc[3].w);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      epi(f0 + j, r0, acc[j]);
-      st4(out + (f0 + j) * RC + r0, acc[j]);
-    }
-  }
-}
-
-struct EpiNone {
-  __device__ __forceinline__ void operator()(int, int, float4&) const {}
-};
-struct EpiReluBelow {  // relu for f < n (hidden units), identity above (z_lin rows)
-  int n;
-  __device__ __forceinline__ void operator()(int f, int, float4& v) const {
-    if (f < n) {
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
-  }
-};
-struct EpiSigmoid {
-  __device__ __forceinline__ void operator()(int, int, float4& v) const {
-    v.x = sigmoidf_(v.x); v.y = sigmoidf_(v.y); v.z = sigmoidf_(v.z); v.w = sigmoidf_(v.w);
-  }
-};
-struct EpiSoftplusMin {
-  float min_std;
-  __device__ __forceinline__ void operator()(int, int, float4& v) const {
-    v.x = softplusf_(v.x) + min_std; v.y = softplusf_(v.y) + min_std;
-    v.z = softplusf_(v.z) + min_std; v.w = softplusf_(v.w) + min_std;
-  }
-};
-struct EpiAddLds {  // v += other[f][r..r+3]
-  const float* other; int RC;
-  __device__ __forceinline__ void operator()(int f, int r0, float4& v) const {
-    const float4 o = ld4(other + f * RC + r0);
-    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-  }
-};
-struct EpiReluMask {  // v *= (act[f][r] > 0)
-  const float* act; int RC;
-  __device__ __forceinline__ void operator()(int f, int r0, float4& v) const {
-    const float4 h = ld4(act + f * RC + r0);
-    v.x = h.x > 0.f ? v.x : 0.f; v.y = h.y > 0.f ? v.y : 0.f;
-    v.z = h.z > 0.f ? v.z : 0.f; v.w = h.w > 0.f ? v.w : 0.f;
-  }
-};
+using namespace mdmm_simt;
 
 struct Geo {
   int T, B, D, Dp, Hp, F1, P, K, S, PS, R, RC, s0;
+  uint64_t noise_offset;
 };
 
 __device__ __forceinline__ Geo make_geo(const mdmm_sweep_t& a, int S, int RC) {
@@ -112,13 +29,14 @@ __device__ __forceinline__ Geo make_geo(const mdmm_sweep_t& a, int S, int RC) {
   g.T = a.T; g.B = a.B; g.D = a.D; g.Dp = pad4(a.D); g.Hp = pad4(a.H);
   g.F1 = 2 * g.Hp + g.Dp; g.P = a.P; g.K = a.K; g.S = S; g.PS = a.P * S;
   g.R = g.PS * a.K; g.RC = RC; g.s0 = blockIdx.x * S;
+  g.noise_offset = a.offset + (a.offset_dev ? *a.offset_dev : 0);
   return g;
 }
 
 __device__ __forceinline__ float eps_at(const mdmm_sweep_t& a, const Geo& g, int p, int t, int k,
                                         int b, int d) {
   const uint64_t idx = ((((uint64_t)p * g.T + t) * g.K + k) * g.B + b) * (uint64_t)g.D + d;
-  return a.eps ? a.eps[idx] : philox_normal(a.seed, a.offset, idx);
+  return a.eps ? a.eps[idx] : philox_normal(a.seed, g.noise_offset, idx);
 }
 
 // Fill zT[d][rr] for chunk rows [c0, c0+RC): particles of the previously processed step
@@ -610,9 +528,13 @@ int mdmm_simt_sweep_fwd(const mdmm_sweep_t* args, hipStream_t stream) {
   Launch L;
   int rc = plan(args, false, &L);
   if (rc) return rc;
-  hipError_t e = hipFuncSetAttribute((const void*)sweep_fwd_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-  if (e != hipSuccess) return (int)e;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_fwd_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
   hipLaunchKernelGGL(sweep_fwd_kernel, dim3(L.grid), dim3(NT), L.lds, stream, *args, L.S, L.RC);
   return (int)hipGetLastError();
 }
@@ -621,9 +543,13 @@ int mdmm_simt_sweep_bwd(const mdmm_sweep_t* args, hipStream_t stream) {
   Launch L;
   int rc = plan(args, true, &L);
   if (rc) return rc;
-  hipError_t e = hipFuncSetAttribute((const void*)sweep_bwd_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-  if (e != hipSuccess) return (int)e;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)sweep_bwd_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
   hipLaunchKernelGGL(sweep_bwd_kernel, dim3(L.grid), dim3(NT), L.lds, stream, *args, L.S, L.RC);
   return (int)hipGetLastError();
 }

@@ -89,3 +89,52 @@ def elbo_step(model, optimizer, bucket, inputs, mask, lengths, kld_mult, rec_mul
     optimizer.step()
     bucket.zero()
     return loss.detach()
+
+
+class GraphedElboStep:
+    """The ELBO step replayed from HIP graphs (the step is ~1000 small launches; eager it is
+    host-bound).  Two graphs with the collective between them, so nothing RCCL-related is ever
+    captured:   [model.step + backward]  ->  all_reduce(flat grads)  ->  [Adam + zero grads].
+    Shapes and tensors are static (the batch buffers are filled in place by the caller);
+    fresh noise per replay comes from the Philox device counter (PhiloxNoise.advance)."""
+
+    def __init__(self, model, optimizer, bucket, inputs, mask, lengths, kld_mult, rec_mults,
+                 targets=None, n_points_global=None, group=None, warmup=3, **train_args):
+        from . import ops
+        self.model, self.optimizer, self.bucket, self.group = model, optimizer, bucket, group
+        n_points = sum(lengths) if n_points_global is None else n_points_global
+        noise = model._noise()
+
+        def fwd_bwd():
+            loss = model.step(inputs, mask, kld_mult, rec_mults, targets=targets,
+                              lengths=lengths, **train_args)
+            (loss / n_points).backward()
+            return loss.detach()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                      # eager warm-up on the capture stream
+                fwd_bwd()
+                bucket.check_views()
+                bucket.allreduce(group)
+                optimizer.step()
+                bucket.zero()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ops.clear_caches(model.parameters())
+        self.g_step, self.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_step):
+            self.loss = fwd_bwd()
+            if hasattr(noise, 'advance'):
+                noise.advance()
+        bucket.check_views()
+        with torch.cuda.graph(self.g_opt, pool=self.g_step.pool()):
+            optimizer.step()
+            bucket.zero()
+
+    def __call__(self):
+        self.g_step.replay()
+        self.bucket.allreduce(self.group)
+        self.g_opt.replay()
+        return self.loss

@@ -10,6 +10,15 @@ used.  The conv stacks mirror common.py:70-290 and always run as ordinary PyTorc
 modules (MIOpen) -- they are out of scope for hand-written kernels.
 """
 import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _lin(x, layer):
+    """Linear holder applied through the split-K weight-gradient path on the GPU."""
+    if x.is_cuda and x.dim() == 2:
+        from ..ops import tall_linear
+        return tall_linear(x, layer)
+    return layer(x)
 
 
 def _mlp_trunk(in_dim, h_dim):
@@ -25,7 +34,8 @@ class CategoricalMLP(nn.Module):
         self.h_to_out = nn.Sequential(nn.Linear(h_dim, out_dim), nn.Softmax(dim=1))
 
     def forward(self, x):
-        return (self.h_to_out(self.in_to_h(x)),)
+        hid = F.relu(_lin(x, self.in_to_h[0]))
+        return (F.softmax(_lin(hid, self.h_to_out[0]), dim=1),)
 
 
 class GaussianMLP(nn.Module):
@@ -39,8 +49,8 @@ class GaussianMLP(nn.Module):
         self.h_to_std = nn.Sequential(nn.Linear(h_dim, out_dim), nn.Softplus())
 
     def forward(self, x):
-        hid = self.in_to_h(x)
-        return self.h_to_mean(hid), self.h_to_std(hid) + self.min_std
+        hid = F.relu(_lin(x, self.in_to_h[0]))
+        return _lin(hid, self.h_to_mean), F.softplus(_lin(hid, self.h_to_std[0])) + self.min_std
 
 
 class GaussianGTF(nn.Module):

@@ -168,6 +168,7 @@ class MultiDMM(MultiDGTS):
         noise = self._noise()
         if not noise.replay:
             cfg_kw['seed'], cfg_kw['offset'] = noise.stream()
+            cfg_kw['offset_dev'] = noise.device_counter(self.z0_mean.device)
             return None
         n = _n_draws(t_max, sample, k, sample_init)
         if n == 0:

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libmdmm_hip.so')
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 2
+ABI_VERSION = 4
 
 SYMBOLS = [
     'mdmm_version', 'mdmm_strerror', 'mdmm_pad',
@@ -25,6 +25,7 @@ SYMBOLS = [
     'mdmm_nll_bernoulli_fwd', 'mdmm_nll_bernoulli_bwd',
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
     'mdmm_philox_normal',
+    'mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd', 'mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd',
 ]
 
 _P = C.c_void_p
@@ -53,7 +54,25 @@ class Sweep(C.Structure):
                  ('g_prior_std', _P), ('g_samples', _P),
                  ('g_z0_mean', _P), ('g_z0_sigma', _P), ('g_z_rows', _P),
                  ('spill_g', _P), ('spill_x', _P), ('spill_rows', C.c_int64),
-                 ('dw_partial', _P), ('dw_partial_rows', C.c_int64)])
+                 ('dw_partial', _P), ('dw_partial_rows', C.c_int64), ('offset_dev', _P)])
+
+
+class Gru(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('T', 'B', 'H', 'reverse', 'skip', 'reserved')] +
+                [(n, _P) for n in ('gi', 'w_hh', 'wt_hh', 'b_hh', 'h0', 'mask', 'h_new', 'h_seq',
+                                   'g_h_new', 'g_h_seq', 'g_gi', 'g_gh', 'g_h0')])
+
+
+class Dks(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('T', 'B', 'D', 'H', 'sample', 'sample_init')] +
+                [('min_std_gtf', C.c_float), ('min_std_comb', C.c_float),
+                 ('seed', C.c_uint64), ('offset', C.c_uint64), ('offset_dev', _P), ('eps', _P),
+                 ('gtf', Gtf)] +
+                [(n, _P) for n in ('w_z', 'wt_z', 'w_m', 'wt_m', 'b_m', 'w_s', 'wt_s', 'b_s', 'u',
+                                   'z0_mean', 'z0_std', 't_stop', 'infer_mean', 'infer_std',
+                                   'prior_mean', 'prior_std', 'z', 'g_infer_mean', 'g_infer_std',
+                                   'g_prior_mean', 'g_prior_std', 'g_z', 'g_u', 'spill_g',
+                                   'spill_x', 'spill_gc', 'spill_xc')])
 
 
 class MdmmError(RuntimeError):
@@ -82,6 +101,10 @@ def lib():
             getattr(L, name).argtypes = [C.c_int, C.c_int]
         for name in ('mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd'):
             getattr(L, name).argtypes = [C.POINTER(Sweep), _P]
+        for name in ('mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd'):
+            getattr(L, name).argtypes = [C.POINTER(Gru), _P]
+        for name in ('mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd'):
+            getattr(L, name).argtypes = [C.POINTER(Dks), _P]
         L.mdmm_sweep_bwd_mode.argtypes = [C.POINTER(Sweep)]
         L.mdmm_sweep_dw_width.argtypes = [C.c_int, C.c_int]
         L.mdmm_sweep_dw_rows.argtypes = [C.POINTER(Sweep)]
@@ -99,7 +122,7 @@ def lib():
         L.mdmm_nll_bernoulli_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_categorical_fwd.argtypes = [_P, _P, _P, i64, i32, _P, _P]
         L.mdmm_nll_categorical_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
-        L.mdmm_philox_normal.argtypes = [C.c_uint64, C.c_uint64, i64, _P, _P]
+        L.mdmm_philox_normal.argtypes = [C.c_uint64, C.c_uint64, _P, i64, _P, _P]
         if L.mdmm_version() != ABI_VERSION:
             raise MdmmError('libmdmm_hip.so ABI %d != binding ABI %d'
                             % (L.mdmm_version(), ABI_VERSION))

@@ -9,23 +9,41 @@ import torch
 
 
 class PhiloxNoise:
+    """Stream ids for the in-kernel generator.
+
+    offset = host counter (one new value per launch) + device counter.  The device counter is
+    what makes a hipGraph-captured step draw fresh noise on every replay: kernel arguments are
+    frozen at capture time, the counter tensor is bumped by a captured device op
+    (`advance()`), and every kernel adds it to its offset when it starts."""
+
+    replay = False
+    STRIDE = 1 << 20         # host counters stay far below this within one step
+
     def __init__(self, seed=None):
         self.seed = int(torch.initial_seed() if seed is None else seed) & ((1 << 63) - 1)
         self.counter = 0
-
-    replay = False
+        self._dev = None
 
     def stream(self):
         """A fresh Philox stream id for one kernel launch."""
         self.counter += 1
         return self.seed, self.counter
 
+    def device_counter(self, device):
+        if self._dev is None or self._dev.device != torch.device(device):
+            self._dev = torch.zeros(1, dtype=torch.int64, device=device)
+        return self._dev
+
+    def advance(self):
+        """Device-side bump (capturable); call once per replayed step."""
+        if self._dev is not None:
+            self._dev.add_(self.STRIDE)
+
     def normal(self, shape, device):
-        """Host-visible draws (used outside the sweeps, e.g. z_sample / DKS)."""
-        g = torch.Generator(device=device)
-        self.counter += 1
-        g.manual_seed((self.seed * 1000003 + self.counter) & ((1 << 63) - 1))
-        return torch.randn(tuple(shape), generator=g, device=device, dtype=torch.float32)
+        """Draws used outside the sweeps (z_sample, DKS): same generator, own stream id."""
+        from . import ops
+        seed, off = self.stream()
+        return ops.philox_normal(seed, off, shape, device, self.device_counter(device))
 
 
 class ReplayNoise:

@@ -176,6 +176,26 @@ def unpack_dw_partials(part, D, H, like):
     return [g.contiguous() for g in grads], g_z0m, g_z0s
 
 
+def packed_gtf(params, D, H):
+    """PackedGtf of the given parameters, reused while none of them has been modified (every
+    sweep of one ELBO step shares the two directions' packs).  The cache lives ON the first
+    parameter object, so it can never outlive the model or be hit by another model whose
+    tensors happen to reuse the same addresses."""
+    key = tuple((p.data_ptr(), p._version) for p in params) + (D, H)
+    hit = getattr(params[0], '_mdmm_pack', None)
+    if hit is None or hit[0] != key:
+        hit = (key, PackedGtf(params, D, H))
+        params[0]._mdmm_pack = hit
+    return hit[1]
+
+
+def clear_caches(params=()):
+    """Drop host-side caches (call before capturing a step into a HIP graph)."""
+    for p in params:
+        if hasattr(p, '_mdmm_pack'):
+            del p._mdmm_pack
+
+
 # ------------------------------------------------------------------------------------
 # The sweep
 # ------------------------------------------------------------------------------------
@@ -184,12 +204,13 @@ class SweepCfg:
 
     def __init__(self, T, B, D, H, P=1, K=1, reverse=False, sample=True, sample_init=False,
                  use_inv_prior=False, min_std=1e-3, seed=0, offset=0, need_samples=True,
-                 trans_only=False):
+                 trans_only=False, offset_dev=None):
         self.T, self.B, self.D, self.H, self.P, self.K = T, B, D, H, P, K
         self.reverse, self.sample, self.sample_init = bool(reverse), bool(sample), bool(sample_init)
         self.use_inv_prior, self.min_std = bool(use_inv_prior), float(min_std)
         self.seed, self.offset = int(seed), int(offset)
         self.need_samples, self.trans_only = bool(need_samples), bool(trans_only)
+        self.offset_dev = offset_dev        # int64 device tensor added to `offset` in-kernel
 
 
 def _sweep_tag(which, cfg):
@@ -205,6 +226,7 @@ def _fill_common(s, cfg, z0_mean, z0_log_std, packed, eps):
     s.use_inv_prior, s.trans_only = int(cfg.use_inv_prior), int(cfg.trans_only)
     s.min_std = cfg.min_std
     s.seed, s.offset = cfg.seed, cfg.offset
+    s.offset_dev = _ptr(cfg.offset_dev)
     s.eps = _ptr(eps)
     s.z0_mean, s.z0_log_std = _ptr(z0_mean), _ptr(z0_log_std)
     packed.fill(s.gtf)
@@ -224,7 +246,7 @@ class _SweepFn(torch.autograd.Function):
         if n_exp > native.MAX_EXPERTS or cfg.P > native.MAX_PASSES:
             raise native.MdmmError('too many experts / passes for one sweep')
         dev = z0_mean.device
-        packed = PackedGtf(gtf_params, cfg.D, cfg.H)
+        packed = packed_gtf(gtf_params, cfg.D, cfg.H)
         z0m, z0s = _f32c(z0_mean.detach().reshape(-1)), _f32c(z0_log_std.detach().reshape(-1))
         shape = (cfg.P, cfg.T, cfg.B, cfg.D)
         out = [torch.empty(shape, device=dev, dtype=torch.float32) for _ in range(4)]
@@ -336,7 +358,7 @@ class _TransFn(torch.autograd.Function):
         _need_gpu(z_rows, z0_mean, z0_log_std)
         z = _f32c(z_rows)
         dev = z.device
-        packed = PackedGtf(gtf_params, cfg.D, cfg.H)
+        packed = packed_gtf(gtf_params, cfg.D, cfg.H)
         z0m, z0s = _f32c(z0_mean.detach().reshape(-1)), _f32c(z0_log_std.detach().reshape(-1))
         pm = torch.empty(cfg.B, cfg.D, device=dev, dtype=torch.float32)
         ps = torch.empty_like(pm)
@@ -599,9 +621,57 @@ def nll_categorical(probs, x, mask=None, lead_dims=2):
     return _NllCatFn.apply(probs, x, _row_mask(mask, rows, x), rows, n_cat)
 
 
-def philox_normal(seed, offset, shape, device):
-    """The eps tensor a sweep with stream id (seed, offset) draws, materialised."""
+def philox_normal(seed, offset, shape, device, offset_dev=None):
+    """The eps tensor a sweep with stream id (seed, offset [+ *offset_dev]) draws, materialised."""
     out = torch.empty(tuple(shape), device=device, dtype=torch.float32)
     _need_gpu(out)
-    _call('mdmm_philox_normal', seed, offset, out.numel(), _ptr(out))
+    _call('mdmm_philox_normal', seed, offset, _ptr(offset_dev), out.numel(), _ptr(out))
     return out
+
+
+# ------------------------------------------------------------------------------------
+# Linear layers of the default MLP encoders / decoders
+# ------------------------------------------------------------------------------------
+class _TallLinearFn(torch.autograd.Function):
+    """y = x W^T + b for x with ~1e5 rows and a handful of features (the default
+    GaussianMLP / CategoricalMLP emission and encoder layers, common.py:9-41, applied to all
+    T*B frames at once).  Forward and input gradient are ordinary GEMMs; the weight gradient
+    g^T x contracts over the rows into a tiny (out x in) matrix -- handed to the BLAS as one
+    GEMM it runs in a single workgroup (0.44 ms per layer at cfg2), so it is issued as a
+    batched split-K product over row chunks and summed."""
+
+    CHUNKS = 256
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            n, c = x.shape[0], _TallLinearFn.CHUNKS
+            if n >= 64 * c:
+                per = n // c
+                head = per * c
+                gw = torch.bmm(g[:head].view(c, per, -1).transpose(1, 2),
+                               x[:head].reshape(c, per, -1)).sum(0)
+                if head < n:
+                    gw = gw + g[head:].t() @ x[head:]
+            else:
+                gw = g.t() @ x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb
+
+
+def tall_linear(x, layer):
+    """Apply an nn.Linear holder to a (rows, in) activation through _TallLinearFn."""
+    if x.dim() != 2 or not x.is_floating_point():
+        return layer(x)
+    return _TallLinearFn.apply(x, layer.weight, layer.bias)
