@@ -6,6 +6,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import ops
 from . import common
 from .dgts import MultiDGTS
 
@@ -71,8 +72,113 @@ class MultiDKS(MultiDGTS):
         self.z0_mean = z0_mean * torch.ones(1, z_dim).to(self.device)
         self.z0_std = z0_std * torch.ones(1, z_dim).to(self.device)
 
+    def _features(self, inputs, t_max, b_dim):
+        """dks.py:190-209: missing modality -> zeros + zero mask; NaN -> mask and zero fill."""
+        dev = self.combiner.h_to_mean.weight.device
+        feats, masks = dict(), dict()
+        for m in self.modalities:
+            if m not in inputs:
+                if self.dists[m] == 'Categorical':
+                    shape = (t_max, b_dim, 1)
+                elif type(self.dims[m]) == tuple:
+                    shape = (t_max, b_dim) + tuple(self.dims[m])
+                else:
+                    shape = (t_max, b_dim, self.dims[m])
+                x = torch.zeros(shape, device=dev)
+                masks[m] = torch.zeros(t_max, b_dim, device=dev, dtype=torch.bool)
+            else:
+                x = inputs[m]
+                nan = torch.isnan(x)
+                masks[m] = ~nan.flatten(2, -1).any(dim=-1)
+                x = torch.where(nan, torch.zeros_like(x), x)
+            if self.dists[m] == 'Categorical':
+                x = x.long()
+            feats[m] = self.enc[m](x.flatten(0, 1)).reshape(t_max, b_dim, -1)
+        return feats, masks
+
+    def _rnn(self, m, feat, mask):
+        """Inference GRU of modality m scanned over time (dks.py:216-239) -> (T,B,H) top-layer
+        states in natural time order."""
+        t_max, b_dim = feat.shape[:2]
+        gru = self.rnn[m]
+        x = feat.reshape(t_max * b_dim, -1)
+        h_seq = None
+        for layer in range(gru.num_layers):
+            w_ih = getattr(gru, 'weight_ih_l%d' % layer)
+            w_hh = getattr(gru, 'weight_hh_l%d' % layer)
+            b_ih = getattr(gru, 'bias_ih_l%d' % layer) if gru.bias else None
+            b_hh = getattr(gru, 'bias_hh_l%d' % layer) if gru.bias else None
+            gi = ops._TallLinearFn.apply(x, w_ih, b_ih).reshape(t_max, b_dim, -1)
+            h_new, h_seq = ops.gru_skip(gi, w_hh, b_hh, self.h0[m][layer, 0],
+                                        mask.to(torch.float32) if self.rnn_skip else None,
+                                        self.rnn_dir == 'bwd', self.rnn_skip)
+            x = h_new.reshape(t_max * b_dim, -1)
+        return h_seq
+
     def forward(self, inputs, **kwargs):
-        raise NotImplementedError('MultiDKS.forward: HIP recurrence kernels not built yet')
+        """dks.py:157-297.  Returns (infer, prior, recon)."""
+        lengths, sample = kwargs.get('lengths'), kwargs.get('sample', True)
+        sample_init = kwargs.get('sample_init', False)
+        present = [m for m in self.modalities if m in inputs]
+        if present:
+            t_max, b_dim = inputs[present[0]].shape[:2]
+        else:
+            t_max, b_dim = max(lengths), len(lengths)
+        feats, masks = self._features(inputs, t_max, b_dim)
+        h_out = torch.cat([self._rnn(m, feats[m], masks[m]) for m in self.modalities], dim=-1)
+        # last step at which every modality is observed (mask_to_extent on the product mask,
+        # dks.py:242-244): the largest observed t, 0 when nothing is observed
+        both = torch.stack([masks[m] for m in self.modalities]).all(dim=0)
+        steps = torch.arange(t_max, device=both.device).unsqueeze(1)
+        t_stop = (both.long() * steps).max(dim=0).values.to(torch.int32).contiguous()
+        # combiner: the columns of in_to_h that see [h_out_t, feat_t] are time-parallel
+        w_in = self.combiner.in_to_h[0].weight
+        rest = [h_out] + ([feats[m] for m in self.modalities] if self.feat_to_z else [])
+        rest = torch.cat(rest, dim=-1).reshape(t_max * b_dim, -1)
+        u = ops._TallLinearFn.apply(rest, w_in[:, self.z_dim:], self.combiner.in_to_h[0].bias)
+        u = u.reshape(t_max, b_dim, self.h_dim)
+        noise = self._noise()
+        cfg = dict(T=t_max, B=b_dim, D=self.z_dim, H=self.h_dim, sample=sample,
+                   sample_init=sample_init, min_std_gtf=float(self.fwd.min_std),
+                   min_std_comb=float(self.combiner.min_std), seed=0, offset=0)
+        eps = None
+        if noise.replay:
+            n = t_max if sample else (1 if sample_init else 0)
+            if n:
+                eps = torch.zeros(t_max, b_dim, self.z_dim)
+                for t, d in enumerate(noise.take(n)):
+                    eps[t] = d.reshape(b_dim, self.z_dim)
+                eps = eps.to(u.device)
+        else:
+            cfg['seed'], cfg['offset'] = noise.stream()
+            cfg['offset_dev'] = noise.device_counter(u.device)
+        im, is_, pm, ps, z = ops.dks_combiner(
+            cfg, eps, t_stop, self.z0_mean.to(u.device), self.z0_std.to(u.device), u,
+            w_in[:, :self.z_dim], self.combiner.h_to_mean.weight, self.combiner.h_to_mean.bias,
+            self.combiner.h_to_std[0].weight, self.combiner.h_to_std[0].bias,
+            ops.gtf_param_list(self.fwd))
+        recon = dict()
+        for m in self.modalities:                                   # dks.py:285-291
+            out = self.dec[m](z.reshape(-1, self.z_dim))
+            recon[m] = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
+        return (im, is_), (pm, ps), recon
 
     def sample(self, t_max, b_dim):
-        raise NotImplementedError('MultiDKS.sample: HIP recurrence kernels not built yet')
+        """dks.py:299-342: ancestral sampling from the transition prior (not a hot path: the
+        transition runs through the GaussianGTF holder's stock-op forward)."""
+        z_samples = []
+        z_t = None
+        for t in range(t_max):
+            if t > 0:
+                p_mean, p_std = self.fwd(z_t)
+            else:
+                p_mean = self.z0_mean.repeat(b_dim, 1)
+                p_std = self.z0_std.repeat(b_dim, 1)
+            z_t = self._sample_gauss(p_mean, p_std)
+            z_samples.append(z_t)
+        z_samples = torch.stack(z_samples, dim=0)
+        recon = dict()
+        for m in self.modalities:
+            out = self.dec[m](z_samples.reshape(-1, self.z_dim))
+            recon[m] = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
+        return recon

@@ -675,3 +675,171 @@ def tall_linear(x, layer):
     if x.dim() != 2 or not x.is_floating_point():
         return layer(x)
     return _TallLinearFn.apply(x, layer.weight, layer.bias)
+
+
+# ------------------------------------------------------------------------------------
+# MultiDKS recurrences
+# ------------------------------------------------------------------------------------
+def _pad2(w, r, c):
+    if tuple(w.shape) == (r, c):
+        return w
+    out = torch.zeros(r, c, device=w.device, dtype=torch.float32)
+    out[:w.shape[0], :w.shape[1]] = w
+    return out
+
+
+def _pad1(b, n):
+    if b.shape[0] == n:
+        return b
+    out = torch.zeros(n, device=b.device, dtype=torch.float32)
+    out[:b.shape[0]] = b
+    return out
+
+
+class _GruSkipFn(torch.autograd.Function):
+    """One GRU layer of one modality scanned over time with skip updates (dks.py:219-231):
+    mdmm_gru_skip_fwd/_bwd.  gi = W_ih x + b_ih for all t is the caller's (time-parallel) GEMM."""
+
+    @staticmethod
+    def forward(ctx, T, B, H, reverse, skip, gi, w_hh, b_hh, h0, mask):
+        ctx.set_materialize_grads(False)
+        _need_gpu(gi, w_hh, h0)
+        dev = gi.device
+        Hp = pad(H)
+        w = w_hh.detach()
+        blocks = [_pad2(w[g * H:(g + 1) * H], Hp, Hp) for g in range(3)]
+        w_pad = torch.cat(blocks, 0)                                   # [3Hp][Hp]
+        bias = (torch.cat([_pad1(b_hh.detach()[g * H:(g + 1) * H], Hp) for g in range(3)])
+                if b_hh is not None else torch.zeros(3 * Hp, device=dev))
+        buf = torch.cat([w_pad.reshape(-1), w_pad.t().reshape(-1), bias])
+        gi = _f32c(gi)
+        h0v = _f32c(h0.detach().reshape(-1))
+        h_new = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        h_seq = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        a = native.Gru()
+        a.T, a.B, a.H, a.reverse, a.skip = T, B, H, int(reverse), int(skip)
+        base = buf.data_ptr()
+        a.w_hh, a.wt_hh, a.b_hh = base, base + 4 * 3 * Hp * Hp, base + 8 * 3 * Hp * Hp
+        a.gi, a.h0, a.mask = _ptr(gi), _ptr(h0v), _ptr(mask)
+        a.h_new, a.h_seq = _ptr(h_new), _ptr(h_seq)
+        _call('mdmm_gru_skip_fwd', C.byref(a), tag='gru_fwd[H=%d]' % H)
+        ctx.dims = (T, B, H, int(reverse), int(skip))
+        ctx.buf, ctx.mask, ctx.has_bias = buf, mask, b_hh is not None
+        ctx.h0_shape = h0.shape
+        ctx.save_for_backward(gi, h0v, h_seq)
+        return h_new, h_seq
+
+    @staticmethod
+    def backward(ctx, g_h_new, g_h_seq):
+        T, B, H, reverse, skip = ctx.dims
+        gi, h0v, h_seq = ctx.saved_tensors
+        dev, Hp = gi.device, pad(H)
+        g_h_new, g_h_seq = _f32c(g_h_new), _f32c(g_h_seq)
+        g_gi = torch.empty(T, B, 3 * H, device=dev, dtype=torch.float32)
+        g_gh = torch.zeros(T, B, 3 * Hp, device=dev, dtype=torch.float32)
+        g_h0 = torch.zeros(H, device=dev, dtype=torch.float32)
+        a = native.Gru()
+        a.T, a.B, a.H, a.reverse, a.skip = T, B, H, reverse, skip
+        base = ctx.buf.data_ptr()
+        a.w_hh, a.wt_hh, a.b_hh = base, base + 4 * 3 * Hp * Hp, base + 8 * 3 * Hp * Hp
+        a.gi, a.h0, a.mask, a.h_seq = _ptr(gi), _ptr(h0v), _ptr(ctx.mask), _ptr(h_seq)
+        a.g_h_new, a.g_h_seq = _ptr(g_h_new), _ptr(g_h_seq)
+        a.g_gi, a.g_gh, a.g_h0 = _ptr(g_gi), _ptr(g_gh), _ptr(g_h0)
+        _call('mdmm_gru_skip_bwd', C.byref(a), tag='gru_bwd[H=%d]' % H)
+        # state before each step, time-indexed: the previous processed step's state (h0 first)
+        first = h0v.reshape(1, 1, H).expand(1, B, H)
+        h_prev = torch.cat([h_seq[1:], first], 0) if reverse else torch.cat([first, h_seq[:-1]], 0)
+        hp = h_prev.reshape(T * B, H)
+        gg = g_gh.reshape(T * B, 3 * Hp)
+        g_w = torch.cat([gg[:, g * Hp:g * Hp + H].t() @ hp for g in range(3)], 0)
+        g_b = None
+        if ctx.has_bias:
+            sb = gg.sum(0)
+            g_b = torch.cat([sb[g * Hp:g * Hp + H] for g in range(3)])
+        return (None, None, None, None, None, g_gi, g_w, g_b, g_h0.reshape(ctx.h0_shape), None)
+
+
+def gru_skip(gi, w_hh, b_hh, h0, mask, reverse, skip):
+    """gi (T,B,3H) -> (h_new, h_seq), each (T,B,H) time-indexed."""
+    T, B, H3 = gi.shape
+    return _GruSkipFn.apply(T, B, H3 // 3, reverse, skip, gi, w_hh, b_hh, h0,
+                            _f32c(mask) if mask is not None else None)
+
+
+class _DksCombinerFn(torch.autograd.Function):
+    """dks.py:246-280 as one scan: mdmm_dks_combiner_fwd/_bwd."""
+
+    @staticmethod
+    def forward(ctx, cfg, eps, t_stop, z0_mean, z0_std, u, w_z, w_m, b_m, w_s, b_s, *gtf_params):
+        ctx.set_materialize_grads(False)
+        _need_gpu(u, w_z, z0_mean)
+        T, B, D, H = cfg['T'], cfg['B'], cfg['D'], cfg['H']
+        dev = u.device
+        Dp, Hp = pad(D), pad(H)
+        packed = packed_gtf(gtf_params, D, H)
+        wz, wm, ws = _pad2(w_z.detach(), Hp, Dp), _pad2(w_m.detach(), Dp, Hp), _pad2(w_s.detach(), Dp, Hp)
+        pieces = [wz, wz.t(), wm, wm.t(), _pad1(b_m.detach(), Dp), ws, ws.t(), _pad1(b_s.detach(), Dp)]
+        buf = torch.cat([p.reshape(-1) for p in pieces])
+        offs, o = [], 0
+        for p in pieces:
+            offs.append(o)
+            o += p.numel()
+        u = _f32c(u)
+        z0m, z0s = _f32c(z0_mean.reshape(-1)), _f32c(z0_std.reshape(-1))
+        outs = [torch.empty(T, B, D, device=dev, dtype=torch.float32) for _ in range(5)]
+        a = native.Dks()
+        _DksCombinerFn._fill(a, cfg, eps, packed, buf, offs, u, z0m, z0s, t_stop)
+        a.infer_mean, a.infer_std, a.prior_mean, a.prior_std, a.z = [_ptr(x) for x in outs]
+        _call('mdmm_dks_combiner_fwd', C.byref(a), tag='dks_fwd[D=%d,H=%d]' % (D, H))
+        ctx.cfg, ctx.eps, ctx.packed, ctx.buf, ctx.offs, ctx.t_stop = cfg, eps, packed, buf, offs, t_stop
+        ctx.gtf_like = [p.detach() for p in gtf_params]
+        ctx.save_for_backward(u, z0m, z0s, outs[4])
+        return tuple(outs)
+
+    @staticmethod
+    def _fill(a, cfg, eps, packed, buf, offs, u, z0m, z0s, t_stop):
+        a.T, a.B, a.D, a.H = cfg['T'], cfg['B'], cfg['D'], cfg['H']
+        a.sample, a.sample_init = int(cfg['sample']), int(cfg['sample_init'])
+        a.min_std_gtf, a.min_std_comb = cfg['min_std_gtf'], cfg['min_std_comb']
+        a.seed, a.offset, a.offset_dev = cfg['seed'], cfg['offset'], _ptr(cfg.get('offset_dev'))
+        a.eps = _ptr(eps)
+        packed.fill(a.gtf)
+        base = buf.data_ptr()
+        (a.w_z, a.wt_z, a.w_m, a.wt_m, a.b_m, a.w_s, a.wt_s, a.b_s) = [base + 4 * o for o in offs]
+        a.u, a.z0_mean, a.z0_std, a.t_stop = _ptr(u), _ptr(z0m), _ptr(z0s), _ptr(t_stop)
+
+    @staticmethod
+    def backward(ctx, g_im, g_is, g_pm, g_ps, g_z):
+        cfg = ctx.cfg
+        T, B, D, H = cfg['T'], cfg['B'], cfg['D'], cfg['H']
+        u, z0m, z0s, z = ctx.saved_tensors
+        dev, Dp, Hp = u.device, pad(D), pad(H)
+        L = native.lib()
+        a = native.Dks()
+        _DksCombinerFn._fill(a, cfg, ctx.eps, ctx.packed, ctx.buf, ctx.offs, u, z0m, z0s, ctx.t_stop)
+        a.z = _ptr(z)
+        grads = [_f32c(g) for g in (g_im, g_is, g_pm, g_ps, g_z)]
+        (a.g_infer_mean, a.g_infer_std, a.g_prior_mean, a.g_prior_std, a.g_z) = [_ptr(g) for g in grads]
+        g_u = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        a.g_u = _ptr(g_u)
+        G = X = None
+        if T > 1:
+            G = torch.empty((T - 1) * B, L.mdmm_sweep_spill_width_g(D, H), device=dev)
+            X = torch.empty((T - 1) * B, L.mdmm_sweep_spill_width_x(D, H), device=dev)
+            a.spill_g, a.spill_x = _ptr(G), _ptr(X)
+        Gc = torch.empty(T * B, Hp + 2 * Dp, device=dev)
+        Xc = torch.empty(T * B, Dp + Hp, device=dev)
+        a.spill_gc, a.spill_xc = _ptr(Gc), _ptr(Xc)
+        _call('mdmm_dks_combiner_bwd', C.byref(a), tag='dks_bwd[D=%d,H=%d]' % (D, H))
+        g_gtf = ctx.packed.unpack_grads(G, X, ctx.gtf_like)
+        gsum = Gc.sum(0)
+        g_wz = (Gc[:, :Hp].t() @ Xc[:, :Dp])[:H, :D]
+        g_wm = (Gc[:, Hp:Hp + Dp].t() @ Xc[:, Dp:])[:D, :H]
+        g_ws = (Gc[:, Hp + Dp:].t() @ Xc[:, Dp:])[:D, :H]
+        g_bm, g_bs = gsum[Hp:Hp + D], gsum[Hp + Dp:Hp + Dp + D]
+        return (None, None, None, None, None, g_u, g_wz, g_wm, g_bm, g_ws, g_bs, *g_gtf)
+
+
+def dks_combiner(cfg, eps, t_stop, z0_mean, z0_std, u, w_z, w_m, b_m, w_s, b_s, gtf_params):
+    return _DksCombinerFn.apply(cfg, _f32c(eps), t_stop, z0_mean, z0_std, u, w_z, w_m, b_m, w_s,
+                                b_s, *gtf_params)

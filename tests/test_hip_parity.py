@@ -435,3 +435,156 @@ def test_graphed_step_replays_with_fresh_noise(dev, kernel_family):
     assert l1 == l2 and torch.equal(w1, w2)
     assert all(np.isfinite(l1)) and len(set(l1)) == len(l1)
     assert l1[-1] < l1[0]
+
+
+# ------------------------------------------------------------------------------- DKS --
+DKS_SPEC = [('a', 2, 'Normal'), ('c', 3, 'Categorical'), ('b', 4, 'Normal')]
+
+
+def hip_dks(g, c, dev):
+    from helpers import FeatEncoder
+    from mdmm import models
+    encs = {'b': FeatEncoder(4, 9)} if bool(g.scalar(c + '/custom_enc')) else None
+    m = models.MultiDKS([s[0] for s in DKS_SPEC], [s[1] for s in DKS_SPEC],
+                        [s[2] for s in DKS_SPEC], encoders=encs, h_dim=10, z_dim=6,
+                        feat_to_z=bool(g.scalar(c + '/feat_to_z')),
+                        rnn_dir='bwd' if g.scalar(c + '/rnn_bwd') else 'fwd',
+                        rnn_skip=bool(g.scalar(c + '/rnn_skip')),
+                        rnn_layers=int(g.scalar(c + '/rnn_layers')), device=dev)
+    m.load_state_dict(g.sub(c + '/sd'))
+    return m
+
+
+def test_dks_forward_and_step_golden(dev, kernel_family):
+    """MultiDKS (GRU-skip scan + combiner scan kernels) against the reference: b-skip / f-skip /
+    b-mask / f-mask x feat_to_z x rnn_layers, multimodal / unimodal (t_stop = 0) / MAP forward,
+    and the ELBO step with every parameter gradient."""
+    if kernel_family == 'generic':
+        pytest.skip('the DKS kernels have one family')
+    from mdmm.noise import ReplayNoise
+    g = Golden('g5_dks.npz')
+    names = ['a', 'c', 'b']
+    for c in [c for c in g.cases() if c.startswith('case')]:
+        m = hip_dks(g, c, dev)
+        inputs, targets = cuda(g.sub(c + '/inputs'), dev), cuda(g.sub(c + '/targets'), dev)
+        lengths = g.t(c + '/lengths').tolist()
+        mask = orc.len_to_mask(lengths).to(dev)
+        rec_mults = {k: float(v) for k, v in g.sub(c + '/rec_mults').items()}
+        for tag, sub, sample in (('all', names, True), ('only_a', ['a'], True), ('map', names, False)):
+            p = c + '/fwd_' + tag
+            m.noise = ReplayNoise(g.seq(p + '/eps') if g.has(p + '/eps/#len') else [])
+            with torch.no_grad():
+                infer, prior, recon = m({k: inputs[k] for k in sub}, lengths=lengths, sample=sample)
+            assert m.noise.exhausted
+            close(infer[0], g.t(p + '/infer_mean'), what=p); close(infer[1], g.t(p + '/infer_std'), what=p)
+            close(prior[0], g.t(p + '/prior_mean'), what=p); close(prior[1], g.t(p + '/prior_std'), what=p)
+            for k in names:
+                assert type(recon[k]) is tuple
+                for i, r in enumerate(g.seq(p + '/recon/' + k)):
+                    close(recon[k][i], r, what=p + ' recon ' + k)
+        for tag, uni in (('step_uni', True), ('step_nouni', False)):
+            p = c + '/' + tag
+            m.noise = ReplayNoise(g.seq(p + '/eps'))
+            m.zero_grad()
+            loss = m.step(inputs, mask, float(g.scalar(p + '/kld_mult')), rec_mults,
+                          targets=targets, uni_loss=uni, lengths=lengths)
+            assert m.noise.exhausted
+            close(loss, g.t(p + '/loss'), TOL_LOSS, p + ' loss')
+            (loss / sum(lengths)).backward()
+            for k, prm in m.named_parameters():
+                ref = g.t(p + '/grads/' + k)
+                got = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+                if float(ref.abs().max()) < 1e-6:
+                    assert float(got.abs().max()) < 1e-5, (c, k)
+                    continue
+                grad_close(got, ref, '%s %s %s' % (c, tag, k))
+
+
+def test_dks_philox_matches_oracle_weizmann_like_dims(dev, kernel_family):
+    """Production noise, larger dims (z = h = 64, 3 modalities, 2 GRU layers): materialise the
+    eps each forward drew and replay it into the oracle."""
+    if kernel_family == 'generic':
+        pytest.skip('the DKS kernels have one family')
+    from mdmm import models, ops
+    from mdmm.noise import PhiloxNoise
+    torch.manual_seed(3)
+    spec = [('a', 5, 'Normal'), ('b', 7, 'Normal')]
+    T, lengths, D, H = 12, [12, 12, 9, 5, 3], 64, 64
+    B = len(lengths)
+    kw = dict(h_dim=H, z_dim=D, rnn_layers=2, feat_to_z=True, rnn_dir='bwd', rnn_skip=True)
+    m = models.MultiDKS(['a', 'b'], [5, 7], device=dev, **kw)
+    o = orc.OracleDKS(['a', 'b'], [5, 7], **kw)
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    targets = make_inputs(spec, T, lengths, seed=8)
+    inputs = {k: v.clone() for k, v in targets.items()}
+    inputs['a'][3:6, 1] = float('nan'); inputs['b'][8:, 0] = float('nan')
+    mask = orc.len_to_mask(lengths)
+    rec = {'a': 1.0, 'b': 0.5}
+    m.noise = PhiloxNoise(seed=77)
+    loss = m.step(cuda(inputs, dev), mask.to(dev), 0.9, rec, targets=cuda(targets, dev), lengths=lengths)
+    (loss / sum(lengths)).backward()
+    noise = PhiloxNoise(seed=77)
+    draws = []
+    for _ in range(3):                       # multimodal pass + 2 unimodal passes
+        sd, off = noise.stream()
+        eps = ops.philox_normal(sd, off, (T, B, D), dev).cpu()
+        draws += [eps[t] for t in range(T)]
+    o.noise = orc.ReplayNoise(draws)
+    oloss = o.step(inputs, mask, 0.9, rec, targets=targets, lengths=lengths)
+    (oloss / sum(lengths)).backward()
+    close(loss, oloss, TOL_LOSS, 'dks philox loss')
+    og = dict(o.named_parameters())
+    for k, p in m.named_parameters():
+        ref = og[k].grad if og[k].grad is not None else torch.zeros_like(og[k])
+        if float(ref.abs().max()) < 1e-7:
+            continue
+        grad_close(p.grad, ref, k)
+
+
+def test_step_z256_matches_oracle(dev, kernel_family):
+    """Weizmann latent sizes (z = h = 256, 3 modalities incl. a categorical one, 25 particles):
+    the generic kernels stream the 1.5 MB transition weights from L2 and chunk the particle rows
+    through LDS; checked against the oracle with the kernels' own Philox noise."""
+    if kernel_family == 'generic':
+        pytest.skip('z = 256 always runs on the generic family')
+    from mdmm import models, ops
+    from mdmm.noise import PhiloxNoise
+    torch.manual_seed(5)
+    spec = [('v', 6, 'Normal'), ('m', 3, 'Normal'), ('a', 10, 'Categorical')]
+    names, dims, dists = [s[0] for s in spec], [s[1] for s in spec], [s[2] for s in spec]
+    T, lengths, D, H, K = 5, [5, 4, 2], 256, 256, 25
+    B = len(lengths)
+    m = models.MultiDMM(names, dims, dists, h_dim=H, z_dim=D, device=dev)
+    o = orc.OracleDMM(names, dims, dists, h_dim=H, z_dim=D)
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    targets = make_inputs(spec, T, lengths, seed=9)
+    inputs = {k: v.clone() for k, v in targets.items()}
+    inputs['v'][1:3, 0] = float('nan')
+    mask = orc.len_to_mask(lengths)
+    rec = {'v': 1.0, 'm': 1.0, 'a': 10.0}
+    m.noise = PhiloxNoise(seed=21)
+    kw = dict(train_particles=K, match_particles=50)
+    loss = m.step(cuda(inputs, dev), mask.to(dev), 1.0, rec, targets=cuda(targets, dev),
+                  lengths=lengths, **kw)
+    (loss / sum(lengths)).backward()
+    noise = PhiloxNoise(seed=21)
+    draws = [noise.normal((50, 1, D), dev).cpu(), noise.normal((50, 1, D), dev).cpu()]
+    P, sweeps = 4, []
+    for k in (1, K, 1):
+        sd, off = noise.stream()
+        sweeps.append(ops.philox_normal(sd, off, (P, T, k, B, D), dev).cpu())
+    for p in range(P):
+        draws += [sweeps[0][p, t] for t in reversed(range(T))]
+    for p in range(P):
+        draws += [sweeps[1][p, t] for t in reversed(range(T))]
+        draws += [sweeps[2][p, t] for t in range(T)]
+    o.noise = orc.ReplayNoise(draws)
+    oloss = o.step(inputs, mask, 1.0, rec, targets=targets, lengths=lengths, **kw)
+    (oloss / sum(lengths)).backward()
+    close(loss, oloss, TOL_LOSS, 'z256 step loss')
+    og = dict(o.named_parameters())
+    for k, p in m.named_parameters():
+        ref = og[k].grad if og[k].grad is not None else torch.zeros_like(og[k])
+        if float(ref.abs().max()) < 1e-7:
+            continue
+        grad_close(p.grad, ref, k)
