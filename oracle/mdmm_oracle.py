@@ -563,6 +563,89 @@ class OracleDKS(_OracleDGTS):
 
 
 # --------------------------------------------------------------------------------------
+# MultiVRNN restatement (vrnn.py)
+# --------------------------------------------------------------------------------------
+
+class OracleVRNN(_OracleDGTS):
+    """Multimodal VRNN; mirrors vrnn.py:27-235 (forward only -- the reference's `step` cannot
+    run for this class because forward returns recon as a (dict, dict) pair, dgts.py:164-174)."""
+
+    def __init__(self, modalities, dims, dists=None, encoders=None, decoders=None, h_dim=16,
+                 z_dim=16, z0_mean=0.0, z0_std=1.0, n_layers=1, bias=True,
+                 recur_mode='no_inputs'):
+        super().__init__()
+        self.modalities = list(modalities)
+        self.dims = dict(zip(self.modalities, dims))
+        self.h_dim, self.z_dim, self.recur_mode = h_dim, z_dim, recur_mode
+        dists = dists if dists is not None else ['Normal'] * len(self.modalities)
+        self.dists = dict(zip(self.modalities, dists))
+        self.phi = nn.ModuleDict({m: nn.Sequential(nn.Linear(self.dims[m], h_dim), nn.ReLU())
+                                  for m in self.modalities})           # vrnn.py:74-78
+        self.phi_z = nn.Sequential(nn.Linear(z_dim, h_dim), nn.ReLU())  # vrnn.py:79-81
+        self.enc = nn.ModuleDict({m: GaussianMLP(2 * h_dim, z_dim, h_dim) for m in self.modalities})
+        self.dec = nn.ModuleDict({m: GaussianMLP(2 * h_dim, self.dims[m], h_dim)
+                                  for m in self.modalities})
+        for table, given in ((self.enc, encoders), (self.dec, decoders)):
+            if given is not None:
+                if isinstance(given, list):
+                    given = list(zip(self.modalities, given))
+                table.update(given)
+        self.prior = GaussianMLP(h_dim, z_dim, h_dim)                   # vrnn.py:105
+        n_in = (len(self.modalities) + 1) * h_dim if recur_mode == 'use_inputs' else h_dim
+        self.rnn = nn.GRU(n_in, h_dim, n_layers, bias)                  # vrnn.py:108-111
+        self.h0 = nn.Parameter(torch.zeros(n_layers, 1, h_dim))
+        self.z0_mean = z0_mean * torch.ones(1, z_dim)
+        self.z0_std = z0_std * torch.ones(1, z_dim)
+
+    def forward(self, inputs, **kw):                        # vrnn.py:123-235
+        lengths, sample = kw.get('lengths'), kw.get('sample', True)
+        b_dim, t_max = len(lengths), max(lengths)
+        pm, ps, im, is_ = [], [], [], []
+        rec_mean = {m: [] for m in self.modalities}
+        rec_std = {m: [] for m in self.modalities}
+        h = self.h0.repeat(1, b_dim, 1)
+        for t in range(t_max):
+            if t > 0:
+                p_mean, p_std = self.prior(h[-1])
+            else:
+                p_mean, p_std = self.z0_mean.repeat(b_dim, 1), self.z0_std.repeat(b_dim, 1)
+            means, stds = [p_mean], [p_std]
+            masks = [torch.ones(b_dim, dtype=torch.bool)]
+            for m in self.modalities:
+                if m not in inputs:
+                    continue
+                x = inputs[m][t]
+                masks.append(~torch.isnan(x).any(dim=1))
+                x = torch.where(torch.isnan(x), torch.zeros_like(x), x).detach()
+                mu, sd = self.enc[m](torch.cat([self.phi[m](x), h[-1]], 1))
+                means.append(mu); stds.append(sd)
+            i_mean, i_std = poe(torch.stack(means), torch.stack(stds), torch.stack(masks))
+            zq = self._sample(i_mean, i_std) if sample else i_mean
+            phi_zq = self.phi_z(zq)
+            dec_in = torch.cat([phi_zq, h[-1]], 1)
+            for m in self.modalities:
+                r_mean, r_std = self.dec[m](dec_in)
+                rec_mean[m].append(r_mean); rec_std[m].append(r_std)
+            if self.recur_mode == 'use_inputs':                         # vrnn.py:205-221
+                feats = []
+                for m in self.modalities:
+                    if m not in inputs:
+                        x = rec_mean[m][-1].detach()
+                    else:
+                        x = inputs[m][t].clone().detach()
+                        nan = torch.isnan(x)
+                        x[nan] = rec_mean[m][-1][nan]
+                    feats.append(self.phi[m](x))
+                _, h = self.rnn(torch.cat(feats + [phi_zq], 1).unsqueeze(0), h)
+            else:
+                _, h = self.rnn(phi_zq.unsqueeze(0), h)
+            pm.append(p_mean); ps.append(p_std); im.append(i_mean); is_.append(i_std)
+        recon = ({m: torch.stack(rec_mean[m]) for m in self.modalities},
+                 {m: torch.stack(rec_std[m]) for m in self.modalities})
+        return (torch.stack(im), torch.stack(is_)), (torch.stack(pm), torch.stack(ps)), recon
+
+
+# --------------------------------------------------------------------------------------
 # Trainer-side arithmetic the harness restates (utils.py:24-29, trainer.py:225-252)
 # --------------------------------------------------------------------------------------
 

@@ -440,6 +440,49 @@ def g5_dks():
     save_npz(os.path.join(HERE, 'g5_dks.npz'), out)
 
 
+# ---------------------------------------------------------------------------- VRNN --
+def g6_vrnn():
+    """MultiVRNN.forward, both recur modes.  The reference class needs one harness-side
+    injection to be constructible at all (vrnn.py:105 uses GaussianMLP unqualified)."""
+    import models.vrnn as ref_vrnn
+    ref_vrnn.GaussianMLP = ref_models.common.GaussianMLP
+    out = {}
+    spec = [('a', 3, 'Normal'), ('b', 2, 'Normal')]
+    names = [s[0] for s in spec]; dims = [s[1] for s in spec]
+    lengths = [6, 5, 3]
+    n = 0
+    for recur in ('no_inputs', 'use_inputs'):
+        for layers in (1, 2):
+            torch.manual_seed(7)
+            kw = dict(h_dim=8, z_dim=5, n_layers=layers, recur_mode=recur)
+            ref = ref_models.MultiVRNN(names, dims, device=CPU, **kw)
+            o = orc.OracleVRNN(names, dims, **kw)
+            o.load_state_dict(ref.state_dict())
+            x = make_inputs(spec, 6, lengths, seed=20 + n, nan_spans=[('a', 1, 3, 0), ('b', 2, 4, 1)])
+            case = {'use_inputs': np.array(recur == 'use_inputs'), 'n_layers': np.array(layers),
+                    'sd': ref.state_dict(), 'x': x, 'lengths': np.array(lengths)}
+            for tag, sub, sample in (('all', names, True), ('only_a', ['a'], True), ('map', names, False)):
+                RECORD.clear()
+                torch.manual_seed(500 + n)
+                xin = {m: x[m] for m in sub}
+                with torch.no_grad():
+                    infer, prior, recon = ref(xin, lengths=lengths, sample=sample)
+                eps = list(RECORD)
+                o.noise = orc.ReplayNoise(eps)
+                with torch.no_grad():
+                    oi, op, orec = o(xin, lengths=lengths, sample=sample)
+                check('vrnn', oi[0], infer[0]); check('vrnn', oi[1], infer[1])
+                check('vrnn', op[0], prior[0]); check('vrnn', op[1], prior[1])
+                for m in names:
+                    check('vrnn rec', orec[0][m], recon[0][m]); check('vrnn rec', orec[1][m], recon[1][m])
+                case['fwd_' + tag] = {'eps': eps, 'infer_mean': infer[0], 'infer_std': infer[1],
+                                      'prior_mean': prior[0], 'prior_std': prior[1],
+                                      'rec_mean': recon[0], 'rec_std': recon[1]}
+            out['case%02d' % n] = case
+            n += 1
+    save_npz(os.path.join(HERE, 'g6_vrnn.npz'), out)
+
+
 # ------------------------------------------------------------------------ state dict --
 def g7_state_dicts():
     out = {}
@@ -477,7 +520,7 @@ def g7_state_dicts():
 
 
 if __name__ == '__main__':
-    for fn in (g1_primitives, g2_zfilter, g3_forward, g4_step, g5_dks, g7_state_dicts):
+    for fn in (g1_primitives, g2_zfilter, g3_forward, g4_step, g5_dks, g6_vrnn, g7_state_dicts):
         print(fn.__name__)
         fn()
     for f in sorted(os.listdir(HERE)):

@@ -588,3 +588,32 @@ def test_step_z256_matches_oracle(dev, kernel_family):
         if float(ref.abs().max()) < 1e-7:
             continue
         grad_close(p.grad, ref, k)
+
+
+def test_vrnn_forward_golden(dev, kernel_family):
+    """MultiVRNN.forward (API mirror; PoE on the HIP kernel) against the reference, both
+    recurrence modes, 1 and 2 GRU layers, with input gradients flowing through the PoE kernel."""
+    if kernel_family == 'generic':
+        pytest.skip('no sweep in the VRNN')
+    from mdmm import models
+    from mdmm.noise import ReplayNoise
+    g = Golden('g6_vrnn.npz')
+    names = ['a', 'b']
+    for c in [c for c in g.cases() if c.startswith('case')]:
+        m = models.MultiVRNN(names, [3, 2], h_dim=8, z_dim=5, n_layers=int(g.scalar(c + '/n_layers')),
+                             recur_mode='use_inputs' if g.scalar(c + '/use_inputs') else 'no_inputs',
+                             device=dev)
+        m.load_state_dict(g.sub(c + '/sd'))
+        x, lengths = cuda(g.sub(c + '/x'), dev), g.t(c + '/lengths').tolist()
+        for tag, sub, sample in (('all', names, True), ('only_a', ['a'], True), ('map', names, False)):
+            p = c + '/fwd_' + tag
+            m.noise = ReplayNoise(g.seq(p + '/eps') if g.has(p + '/eps/#len') else [])
+            infer, prior, recon = m({k: x[k] for k in sub}, lengths=lengths, sample=sample)
+            assert m.noise.exhausted
+            close(infer[0], g.t(p + '/infer_mean'), what=p); close(infer[1], g.t(p + '/infer_std'), what=p)
+            close(prior[0], g.t(p + '/prior_mean'), what=p); close(prior[1], g.t(p + '/prior_std'), what=p)
+            assert isinstance(recon, tuple) and len(recon) == 2
+            for k in names:
+                close(recon[0][k], g.t(p + '/rec_mean/' + k), what=p); close(recon[1][k], g.t(p + '/rec_std/' + k), what=p)
+        (infer[0].sum() + recon[0]['a'].sum()).backward()
+        assert all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None)

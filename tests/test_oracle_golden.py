@@ -260,3 +260,24 @@ def test_dks_forward_and_step():
 def test_anneal():
     assert orc.anneal(0.0, 1.0, 24, 2400) == pytest.approx(0.01)
     assert orc.anneal(0.0, 0.5, 5000, 2400) == 0.5
+
+
+def test_vrnn_forward():
+    g = Golden('g6_vrnn.npz')
+    names = ['a', 'b']
+    cases = [c for c in g.cases() if c.startswith('case')]
+    assert len(cases) == 4
+    for c in cases:
+        o = orc.OracleVRNN(names, [3, 2], h_dim=8, z_dim=5, n_layers=int(g.scalar(c + '/n_layers')),
+                           recur_mode='use_inputs' if g.scalar(c + '/use_inputs') else 'no_inputs')
+        o.load_state_dict(g.sub(c + '/sd'))
+        x, lengths = g.sub(c + '/x'), g.t(c + '/lengths').tolist()
+        for tag, sub, sample in (('all', names, True), ('only_a', ['a'], True), ('map', names, False)):
+            p = c + '/fwd_' + tag
+            o.noise = orc.ReplayNoise(g.seq(p + '/eps')) if g.has(p + '/eps/#len') else None
+            with torch.no_grad():
+                infer, prior, recon = o({m: x[m] for m in sub}, lengths=lengths, sample=sample)
+            close(infer[0], g.t(p + '/infer_mean')); close(infer[1], g.t(p + '/infer_std'))
+            close(prior[0], g.t(p + '/prior_mean')); close(prior[1], g.t(p + '/prior_std'))
+            for m in names:
+                close(recon[0][m], g.t(p + '/rec_mean/' + m)); close(recon[1][m], g.t(p + '/rec_std/' + m))

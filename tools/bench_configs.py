@@ -1,0 +1,72 @@
+"""GPU box: time one ELBO step of the other BASELINE configs (shape-only, synthetic, reduced
+batch where noted).  Not the contract bench (bench.py = cfg2); evidence for DESIGN.md."""
+import json, os, sys, time
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'multimodal-dmm_amd'))
+import torch
+from mdmm import models, ops
+from mdmm.harness import GradBucket, elbo_step
+from mdmm.noise import PhiloxNoise
+
+dev = torch.device('cuda:0')
+C = models.common
+
+
+def timed(step, n=3, warm=1):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    ops.TIMER = ops.KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    spans, ops.TIMER = ops.TIMER.summary(), None
+    return dt, {k: round(v[1] / n, 3) for k, v in sorted(spans.items(), key=lambda kv: -kv[1][1])[:8]}
+
+
+def weizmann(kind, B, T=40):
+    torch.manual_seed(0)
+    mods, dims = ['video', 'mask', 'action'], [(3, 64, 64), (1, 64, 64), 10]
+    dists = ['Bernoulli', 'Bernoulli', 'Categorical']
+    if kind == 'dmm':
+        m = models.MultiDMM(mods, dims, dists,
+                            encoders={'video': C.ImageEncoder(256, n_channels=3), 'mask': C.ImageEncoder(256, n_channels=1)},
+                            decoders={'video': C.ImageDecoder(256, n_channels=3), 'mask': C.ImageDecoder(256, n_channels=1)},
+                            h_dim=256, z_dim=256, device=dev)
+    else:
+        m = models.MultiDKS(mods, dims, dists,
+                            encoders={'video': C.ImageEncoder(256, gauss_out=False, n_channels=3),
+                                      'mask': C.ImageEncoder(256, gauss_out=False, n_channels=1)},
+                            decoders={'video': C.ImageDecoder(256, n_channels=3), 'mask': C.ImageDecoder(256, n_channels=1)},
+                            h_dim=256, z_dim=256, feat_to_z=True, rnn_dir='bwd', rnn_skip=True, device=dev)
+    m.noise = PhiloxNoise(seed=1)
+    g = torch.Generator().manual_seed(1234)
+    tg = {'video': torch.rand(T, B, 3, 64, 64, generator=g).to(dev),
+          'mask': (torch.rand(T, B, 1, 64, 64, generator=g) < 0.5).float().to(dev),
+          'action': torch.randint(0, 10, (1, B, 1), generator=g).float().expand(T, B, 1).contiguous().to(dev)}
+    x = {k: v.clone() for k, v in tg.items()}
+    burst = T // 5
+    for k in x:
+        st = torch.randint(0, T - burst + 1, (B,), generator=g)
+        for b in range(B):
+            x[k][st[b]:st[b] + burst, b] = float('nan')
+    mask = torch.ones(T, B, 1, dtype=torch.bool, device=dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    bucket = GradBucket(m.parameters())
+    rec = {'video': 1.0, 'mask': 1.0, 'action': 10.0}
+    return lambda: elbo_step(m, opt, bucket, x, mask, [T] * B, 1.0, rec, targets=tg)
+
+
+out = {}
+for name, kind, B in (('cfg3 Weizmann DMM z256 T40', 'dmm', int(os.environ.get('B3', 32))),
+                      ('cfg4 Weizmann DKS b-skip z256 T40', 'dks', int(os.environ.get('B4', 64)))):
+    try:
+        dt, top = timed(weizmann(kind, B))
+        out[name] = {'batch': B, 's_per_step': round(dt, 4), 'seq_per_s': round(B / dt, 2), 'top_kernels_ms': top,
+                     'max_mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 2)}
+    except Exception as e:   # noqa
+        out[name] = {'error': repr(e)[:300]}
+    print(name, json.dumps(out[name]), flush=True)
+    torch.cuda.empty_cache()
