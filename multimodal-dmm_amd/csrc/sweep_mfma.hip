@@ -478,9 +478,13 @@ __device__ __forceinline__ void stage_backward_weights(const mdmm_sweep_t& a, fl
 // acc[ot][kt] += sum_rows G[16ot + .][row] * X[16kt + .][row]   (G, X in C layout).
 // The contraction runs over rows, which live on lanes: both operands go through a per-wave
 // LDS scratch as [feature][row] images and come back as A / B fragments (row(s,g) = 4*CT*g + s).
+// db[ot] (per lane: feature 16ot + (lane & 15), rows 4g..4g+3 of the tile) += row sums of G, taken
+// from the A fragments that are loaded anyway -- one float per output tile instead of a C-layout
+// f32x4 per tile (the bias accumulators were a third of the backward kernel's live registers).
 template <int OT, int KT, int CT>
 __device__ __forceinline__ void dw_accumulate(float* scratch, int lane, const f32x4 (&G)[OT][CT],
-                                              const f32x4 (&X)[KT][CT], f32x4 (&acc)[OT][KT]) {
+                                              const f32x4 (&X)[KT][CT], f32x4 (&acc)[OT][KT],
+                                              float (&db)[OT]) {
   constexpr int RS = 16 * CT + 4;
   const int j = lane & 15, g = lane >> 4;
   float* gt = scratch;
@@ -509,8 +513,10 @@ __device__ __forceinline__ void dw_accumulate(float* scratch, int lane, const f3
   for (int ot = 0; ot < OT; ++ot) {
     f32x4 av[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
+    for (int c = 0; c < CT; ++c) {
       av[c] = ld_frag(reinterpret_cast<const float4*>(gt + (16 * ot + j) * RS + 4 * CT * g + 4 * c));
+      db[ot] += (av[c][0] + av[c][1]) + (av[c][2] + av[c][3]);
+    }
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -575,32 +581,41 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
   const float inv_k = 1.0f / (float)K;
   const size_t tbd = (size_t)T * B * D;
 
-  float mu0[DT][4], sg0[DT][4], t0c[DT][4];
+  // per-feature constants of the global prior live in LDS (mu0 | sigma0 | 1/(sigma0^2+eps)) and
+  // are re-read at each use: 24 fewer live registers in a kernel that sits at the 512 limit
+  float* cst = scratch0 + (NT / 64) * SCR;
+  for (int d = threadIdx.x; d < 16 * DT; d += NT) {
+    const bool ok = d < D;
+    const float m0 = ok ? a.z0_mean[d] : 0.f;
+    const float s0 = ok ? expf(a.z0_log_std[d]) + a.min_std : 1.f;
+    cst[d] = m0; cst[16 * DT + d] = s0; cst[32 * DT + d] = fast::rcp(s0 * s0 + MDMM_POE_EPS);
+  }
+  __syncthreads();
+  // PART: contributions that are per (pass, sequence) rather than per row (inverse prior expert,
+  // first-step prior) accumulate in a per-wave LDS strip, written by the j == 0 lanes only
+  float* zwav = cst + 48 * DT + (NT / 64) * 32 * DT + (threadIdx.x >> 6) * 32 * DT;
+  for (int d = lane; d < 32 * DT; d += 64) zwav[d] = 0.f;
+  auto MU0 = [&](int dt, int r) { return cst[16 * dt + 4 * g + r]; };
+  auto SG0 = [&](int dt, int r) { return cst[16 * DT + 16 * dt + 4 * g + r]; };
+  auto T0C = [&](int dt, int r) { return cst[32 * DT + 16 * dt + 4 * g + r]; };
   bool fvalid[DT][4];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int d = 16 * dt + 4 * g + r;
-      fvalid[dt][r] = FULL || d < D;
-      mu0[dt][r] = fvalid[dt][r] ? a.z0_mean[d] : 0.f;
-      sg0[dt][r] = fvalid[dt][r] ? expf(a.z0_log_std[d]) + a.min_std : 1.f;
-      t0c[dt][r] = fast::rcp(sg0[dt][r] * sg0[dt][r] + MDMM_POE_EPS);
-    }
+    for (int r = 0; r < 4; ++r) fvalid[dt][r] = FULL || (16 * dt + 4 * g + r) < D;
 
   // weight / bias / z0 gradient accumulators of this wave (all of its tasks)
   f32x4 dW1[IT1][DT], dWg[DT][HT], dWn[DT][HT], dWs[DT][DT];
-  f32x4 db1[IT1], dbg[DT], dbn[DT], dbs[DT];
+  float db1[IT1], dbg[DT], dbn[DT], dbs[DT];
   f32x4 gzm_row[DT], gzs_row[DT];     // per-row contributions (summed over lanes at the end)
-  f32x4 gzm_wav[DT], gzs_wav[DT];     // PART: per-wave contributions (identical in all j lanes)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int x = 0; x < IT1; ++x) { db1[x] = zero4;
+  for (int x = 0; x < IT1; ++x) { db1[x] = 0.f;
 #pragma unroll
     for (int y = 0; y < DT; ++y) dW1[x][y] = zero4; }
 #pragma unroll
   for (int x = 0; x < DT; ++x) {
-    dbg[x] = dbn[x] = dbs[x] = zero4; gzm_row[x] = gzs_row[x] = gzm_wav[x] = gzs_wav[x] = zero4;
+    dbg[x] = dbn[x] = dbs[x] = 0.f; gzm_row[x] = gzs_row[x] = zero4;
 #pragma unroll
     for (int y = 0; y < HT; ++y) { dWg[x][y] = zero4; dWn[x][y] = zero4; }
 #pragma unroll
@@ -694,7 +709,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(mu0[dt][r], -sg0[dt][r], 1.0f);
+              for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(MU0(dt, r), -SG0(dt, r), 1.0f);
           }
         }
         // adjoints of the product: d/d num, d/d prec per feature
@@ -750,17 +765,19 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
           for (int r = 0; r < 4; ++r) {
             float gm0 = 0.f, gs0 = 0.f;
             if (a.use_inv_prior) {      // expert (mu0, -sg0): sign = -1
-              const float g_t = g_num[dt][r] * mu0[dt][r] + g_prec[dt][r];
-              gm0 += g_num[dt][r] * (-t0c[dt][r]);
+              const float g_t = g_num[dt][r] * MU0(dt, r) + g_prec[dt][r];
+              gm0 += g_num[dt][r] * (-T0C(dt, r));
               // std of the expert is -sigma0: d/d sigma0 = -(d/d std) = +2 g_t t0^2 sigma0
-              gs0 += 2.0f * g_t * t0c[dt][r] * t0c[dt][r] * sg0[dt][r];
+              gs0 += 2.0f * g_t * T0C(dt, r) * T0C(dt, r) * SG0(dt, r);
             }
             if (i == 0) {
               gpm[dt][n][r] += a.g_prior_mean ? ld4_guard(a.g_prior_mean, o, vec, 16 * dt + 4 * g, Dg)[r] : 0.f;
               gps[dt][n][r] += a.g_prior_std ? ld4_guard(a.g_prior_std, o, vec, 16 * dt + 4 * g, Dg)[r] : 0.f;
               if (fvalid[dt][r] && row_ok) { gm0 += gpm[dt][n][r]; gs0 += gps[dt][n][r]; }
             }
-            if (PART) { gzm_wav[dt][r] += gm0; gzs_wav[dt][r] += gs0; }
+            if (PART) {
+              if (j == 0) { zwav[16 * dt + 4 * g + r] += gm0; zwav[16 * DT + 16 * dt + 4 * g + r] += gs0; }
+            }
             else { gzm_row[dt][r] += gm0; gzs_row[dt][r] += gs0; }
           }
         if (i > 0) {
@@ -775,6 +792,24 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
         }
       }
       if (i == 0) break;
+      // PART: the per-wave moment-matching coefficients go through a tiny LDS stash so that they
+      // are not live registers across the transition section:  c1 = g_mean/K - c2*mean,
+      // c2 = g_std/(K*std)  ->  g_m = c1 + c2*m,  g_sd = c2*sd
+      float* stash = cst + 48 * DT + (threadIdx.x >> 6) * 32 * DT;
+      if (PART) {
+        if (j == 0) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float c2 = gps[dt][0][r] * fast::rcp(psv[dt][0][r]) * inv_k;
+              stash[16 * dt + 4 * g + r] = gpm[dt][0][r] * inv_k - c2 * pmv[dt][0][r];
+              stash[16 * DT + 16 * dt + 4 * g + r] = c2;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
 
       // ---------- adjoint of the transition: rows = particles of the previous step ----------
       // One 16-row column tile at a time: every transient below is [..][1] (half the registers
@@ -835,23 +870,23 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
             const float muq = (1.0f - gt) * lin + gt * nlv;
             const float sq = fast::softplus(prv) + a.min_std;
             const float tq = fast::rcp(sq * sq + MDMM_POE_EPS);
-            const float num = mu0[dt][r] * t0c[dt][r] + muq * tq, prec = t0c[dt][r] + tq;
+            const float num = MU0(dt, r) * T0C(dt, r) + muq * tq, prec = T0C(dt, r) + tq;
             const float rp = fast::rcp(prec);
             const float m = num * rp, sd = fast::sqrt(rp);
             float g_m, g_sd;
-            if (PART) {         // moment matching, dgts.py:79-83
-              const float g_v = 0.5f * gps[dt][0][r] * fast::rcp(psv[dt][0][r]);
-              g_m = gpm[dt][0][r] * inv_k + g_v * 2.0f * (m - pmv[dt][0][r]) * inv_k;
-              g_sd = g_v * 2.0f * sd * inv_k;
+            if (PART) {         // moment matching, dgts.py:79-83 (coefficients from the stash)
+              const float c2 = stash[16 * DT + 16 * dt + 4 * g + r];
+              g_m = stash[16 * dt + 4 * g + r] + c2 * m;
+              g_sd = c2 * sd;
             } else { g_m = gpm[dt][n][r]; g_sd = gps[dt][n][r]; }
             if (!(live[ct] && fvalid[dt][r])) { g_m = 0.f; g_sd = 0.f; }
             if (m != m) g_m = 0.f;
             const float g_num = g_m * rp;
             const float g_prec = -g_m * num * rp * rp - 0.5f * g_sd * sd * rp;
             // global prior expert
-            const float g_t0 = g_num * mu0[dt][r] + g_prec;
-            gzm_row[dt][r] += g_num * t0c[dt][r];
-            gzs_row[dt][r] += -g_t0 * t0c[dt][r] * t0c[dt][r] * 2.0f * sg0[dt][r];
+            const float g_t0 = g_num * MU0(dt, r) + g_prec;
+            gzm_row[dt][r] += g_num * T0C(dt, r);
+            gzs_row[dt][r] += -g_t0 * T0C(dt, r) * T0C(dt, r) * 2.0f * SG0(dt, r);
             // transition expert (std > 0)
             const float g_muq = g_num * tq;
             const float g_tq = g_num * muq + g_prec;
@@ -863,14 +898,12 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
           }
         // d/d nonlin += W_std^T d/d std-pre ; weight grads of z_to_std
         gemm_chain<DT, DT, 1, 2>(lds + LB::TS, nullptr, lane, pre, gnl);
-        dw_accumulate<DT, DT, 1>(scratch, lane, pre, nl, dWs);
-        bias_accumulate<DT, 1>(pre, dbs);
+        dw_accumulate<DT, DT, 1>(scratch, lane, pre, nl, dWs, dbs);
         // gate branch
         {
           f32x4 gh[HT][1];
           gemm_chain<HT, DT, 1, 0>(lds + LB::TG, nullptr, lane, gate, gh);
-          dw_accumulate<DT, HT, 1>(scratch, lane, gate, h1, dWg);
-          bias_accumulate<DT, 1>(gate, dbg);
+          dw_accumulate<DT, HT, 1>(scratch, lane, gate, h1, dWg, dbg);
 #pragma unroll
           for (int ft = 0; ft < HT; ++ft)
 #pragma unroll
@@ -880,8 +913,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
         {
           f32x4 gh[HT][1];
           gemm_chain<HT, DT, 1, 0>(lds + LB::TN, nullptr, lane, gnl, gh);
-          dw_accumulate<DT, HT, 1>(scratch, lane, gnl, h2, dWn);
-          bias_accumulate<DT, 1>(gnl, dbn);
+          dw_accumulate<DT, HT, 1>(scratch, lane, gnl, h2, dWn, dbn);
 #pragma unroll
           for (int ft = 0; ft < HT; ++ft)
 #pragma unroll
@@ -890,8 +922,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
         // d/dz = W_in^T [d/d gate-hidden | d/d nl-hidden | d/d z_lin] ; weight grads of the in layer
         f32x4 gz[DT][1];
         gemm_chain<DT, IT1, 1, 0>(lds + LB::T1, nullptr, lane, a1, gz);
-        dw_accumulate<IT1, DT, 1>(scratch, lane, a1, z, dW1);
-        bias_accumulate<IT1, 1>(a1, db1);
+        dw_accumulate<IT1, DT, 1>(scratch, lane, a1, z, dW1, db1);
         // adjoints of the previous step's particles
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -939,24 +970,29 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
 #pragma unroll
         for (int y = 0; y < DT; ++y) put_w(LB::O_WS, LB::D16, x, y, dWs[x][y]);
       }
-      auto put_b = [&](int off, int tile, const f32x4& v) {
+      auto put_b = [&](int off, int tile, const f32x4& v) {      // C layout: sum over the 16 rows
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float s = row16_sum(v[r]);
           if (j == 0) acc[off + 16 * tile + 4 * g + r] += s;
         }
       };
+      auto put_db = [&](int off, int tile, float v) {            // A-fragment layout: sum over g
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) acc[off + 16 * tile + j] += v;
+      };
 #pragma unroll
-      for (int x = 0; x < IT1; ++x) put_b(LB::O_B1, x, db1[x]);
+      for (int x = 0; x < IT1; ++x) put_db(LB::O_B1, x, db1[x]);
 #pragma unroll
       for (int x = 0; x < DT; ++x) {
-        put_b(LB::O_BG, x, dbg[x]); put_b(LB::O_BN, x, dbn[x]); put_b(LB::O_BS, x, dbs[x]);
+        put_db(LB::O_BG, x, dbg[x]); put_db(LB::O_BN, x, dbn[x]); put_db(LB::O_BS, x, dbs[x]);
         put_b(LB::O_ZM, x, gzm_row[x]); put_b(LB::O_ZS, x, gzs_row[x]);
         if (PART && j == 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            acc[LB::O_ZM + 16 * x + 4 * g + r] += gzm_wav[x][r];
-            acc[LB::O_ZS + 16 * x + 4 * g + r] += gzs_wav[x][r];
+            acc[LB::O_ZM + 16 * x + 4 * g + r] += zwav[16 * x + 4 * g + r];
+            acc[LB::O_ZS + 16 * x + 4 * g + r] += zwav[16 * DT + 16 * x + 4 * g + r];
           }
         }
       }
@@ -987,7 +1023,8 @@ int launch_bwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   if (!a->dw_partial || a->dw_partial_rows < grid) return MDMM_E_ARG;
   const size_t scr = (size_t)(NT / 64) * (LB::IT1 + DT) * 16 * (16 + 4) * sizeof(float);
   const size_t red = (size_t)LB::WIDTH * sizeof(float);
-  const size_t lds = (size_t)LB::WEND * sizeof(float4) + (scr > red ? scr : red);
+  const size_t lds = (size_t)LB::WEND * sizeof(float4) + (scr > red ? scr : red) +
+                     (48 * DT + 2 * (NT / 64) * 32 * DT) * sizeof(float);
   auto kern = sweep_mfma_bwd_kernel<DT, HT, CT, PART, FULL>;
   static size_t attr_lds = 0;         // per template instantiation (LDS size depends on CT only)
   if (attr_lds < lds) {

@@ -163,6 +163,110 @@ class MultiDKS(MultiDGTS):
             recon[m] = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
         return (im, is_), (pm, ps), recon
 
+    # ---- fused ELBO step ---------------------------------------------------------------
+    def _zero_input(self, m, t_max, b_dim, dev):
+        if self.dists[m] == 'Categorical':
+            shape = (t_max, b_dim, 1)
+        elif type(self.dims[m]) == tuple:
+            shape = (t_max, b_dim) + tuple(self.dims[m])
+        else:
+            shape = (t_max, b_dim, self.dims[m])
+        x = torch.zeros(shape, device=dev)
+        return x.long() if self.dists[m] == 'Categorical' else x
+
+    def step(self, inputs, mask, kld_mult, rec_mults, targets=None, uni_loss=True, **kwargs):
+        """MultiDGTS.step (dgts.py:85-130) for the DKS with the passes fused: the multimodal pass
+        and the unimodal passes share each modality's encoder + inference GRU run (a modality a
+        pass leaves out contributes the zero-input features and, with skip updates, the untouched
+        initial state -- dks.py:192-200, 224-227), and the combiner scans of all passes run as
+        ONE launch over P*B rows.  Same loss and gradients as one forward per pass."""
+        sample, sample_init = kwargs.get('sample', True), kwargs.get('sample_init', False)
+        inputs = {m: inputs[m] for m in inputs if m in self.modalities}
+        if targets is None:
+            targets = inputs
+        passes, loss_mods = [], []
+        if len(self.modalities) > 1:
+            passes.append([m for m in self.modalities if m in inputs])
+            loss_mods.append([m for m in self.modalities if m in targets])
+        if uni_loss:
+            passes += [[m] for m in self.modalities]
+            loss_mods += [[m] for m in self.modalities]
+        if not passes:
+            return 0
+        t_max, b_dim = mask.shape[:2]
+        dev = self.combiner.h_to_mean.weight.device
+        mask = mask.to(dev)
+        n_pass = len(passes)
+        # features / inference-RNN states: observed version and left-out version per modality
+        real, left = dict(), dict()
+        for m in self.modalities:
+            if any(m in ps for ps in passes):
+                x = inputs[m]
+                nan = torch.isnan(x)
+                seen = ~nan.flatten(2, -1).any(dim=-1)
+                x = torch.where(nan, torch.zeros_like(x), x)
+                if self.dists[m] == 'Categorical':
+                    x = x.long()
+                feat = self.enc[m](x.flatten(0, 1)).reshape(t_max, b_dim, -1)
+                real[m] = (feat, self._rnn(m, feat, seen), seen)
+            if any(m not in ps for ps in passes):
+                feat = self.enc[m](self._zero_input(m, t_max, b_dim, dev).flatten(0, 1))
+                feat = feat.reshape(t_max, b_dim, -1)
+                gone = torch.zeros(t_max, b_dim, device=dev, dtype=torch.bool)
+                if self.rnn_skip:       # never updated: stays at the initial state of the top layer
+                    h = self.h0[m][-1].reshape(1, 1, -1).expand(t_max, b_dim, -1)
+                else:                   # zero-masked inputs: every sequence sees the same features
+                    h = self._rnn(m, feat[:, :1].contiguous(), gone[:, :1]).expand(-1, b_dim, -1)
+                left[m] = (feat, h, gone)
+        rest, stops = [], []
+        for ps in passes:
+            pick = [real[m] if m in ps else left[m] for m in self.modalities]
+            cols = [v[1] for v in pick] + ([v[0] for v in pick] if self.feat_to_z else [])
+            rest.append(torch.cat(cols, dim=-1))
+            both = torch.stack([v[2] for v in pick]).all(dim=0)
+            steps = torch.arange(t_max, device=dev).unsqueeze(1)
+            stops.append((both.long() * steps).max(dim=0).values)
+        rest = torch.cat(rest, dim=1)                              # (T, P*B, .)
+        t_stop = torch.cat(stops).to(torch.int32).contiguous()     # (P*B)
+        rows = n_pass * b_dim
+        w_in = self.combiner.in_to_h[0].weight
+        u = ops._TallLinearFn.apply(rest.reshape(t_max * rows, -1), w_in[:, self.z_dim:],
+                                    self.combiner.in_to_h[0].bias).reshape(t_max, rows, self.h_dim)
+        noise = self._noise()
+        cfg = dict(T=t_max, B=rows, D=self.z_dim, H=self.h_dim, sample=sample,
+                   sample_init=sample_init, min_std_gtf=float(self.fwd.min_std),
+                   min_std_comb=float(self.combiner.min_std), seed=0, offset=0)
+        eps = None
+        if noise.replay:        # the reference draws pass after pass (dgts.py:119-129)
+            n = t_max if sample else (1 if sample_init else 0)
+            if n:
+                eps = torch.zeros(t_max, n_pass, b_dim, self.z_dim)
+                for p in range(n_pass):
+                    for t, d in enumerate(noise.take(n)):
+                        eps[t, p] = d.reshape(b_dim, self.z_dim)
+                eps = eps.reshape(t_max, rows, self.z_dim).to(dev)
+        else:
+            cfg['seed'], cfg['offset'] = noise.stream()
+            cfg['offset_dev'] = noise.device_counter(dev)
+        im, is_, pm, ps_, z = ops.dks_combiner(
+            cfg, eps, t_stop, self.z0_mean.to(dev), self.z0_std.to(dev), u,
+            w_in[:, :self.z_dim], self.combiner.h_to_mean.weight, self.combiner.h_to_mean.bias,
+            self.combiner.h_to_std[0].weight, self.combiner.h_to_std[0].bias,
+            ops.gtf_param_list(self.fwd))
+        big_mask = mask.reshape(t_max, 1, b_dim).expand(t_max, n_pass, b_dim).reshape(t_max, rows, 1)
+        total = kld_mult * ops.kld_gauss(im, is_, pm, ps_, big_mask)
+        for m in self.modalities:
+            mult = rec_mults.get(m, 1.0)
+            used = [p for p, mods in enumerate(loss_mods) if m in mods]
+            if mult == 0 or not used:
+                continue
+            for p in used:
+                zp = z[:, p * b_dim:(p + 1) * b_dim].reshape(-1, self.z_dim)
+                out = self.dec[m](zp)
+                rec = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
+                total = total + mult * self._nll(m, rec, targets[m], mask)
+        return total
+
     def sample(self, t_max, b_dim):
         """dks.py:299-342: ancestral sampling from the transition prior (not a hot path: the
         transition runs through the GaussianGTF holder's stock-op forward)."""

@@ -35,6 +35,8 @@ def _n_draws(t_max, sample, n_particles, sample_init):
 
 
 class MultiDMM(MultiDGTS):
+    _side_stream = None
+
     def __init__(self, modalities, dims, dists=None, encoders=None, decoders=None,
                  h_dim=32, z_dim=32, z0_mean=0.0, z0_std=1.0, min_std=1e-3,
                  device=torch.device('cuda:0')):
@@ -343,12 +345,30 @@ class MultiDMM(MultiDGTS):
         if not pass_mods:
             return loss
         enc = {m: self._encode_one(m, inputs[m]) for m in self.modalities if m in inputs}
-        # each pass scores the modalities it was given (targets restricted the same way)
-        loss = loss + f_mult * self._mode_loss(enc, targets, mask, kld_mult, rec_mults, pass_mods,
-                                               loss_mods, t_max, b_dim, f_mode, sample,
-                                               sample_init, kwargs.get('flt_particles', 1),
-                                               smt_particles)
-        loss = loss + s_mult * self._mode_loss(enc, targets, mask, kld_mult, rec_mults, pass_mods,
-                                               loss_mods, t_max, b_dim, s_mode, sample,
-                                               sample_init, train_particles, smt_particles)
-        return loss
+        # each pass scores the modalities it was given (targets restricted the same way).
+        # The filtering-mode and the smoothing-mode losses are independent given the encoder
+        # outputs: the former (K = 1 sweeps, a latency chain that fills a fraction of the chip)
+        # runs on a side stream next to the latter; autograd replays each backward on the stream
+        # of its forward, so the overlap holds for the backward sweeps too.
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.z0_mean.device)
+        side = self._side_stream
+        # shared inputs of both streams: pack the transition weights once, on the main stream,
+        # and tell the allocator the encoder outputs are also read on the side stream
+        for direction in ('fwd', 'bwd'):
+            ops.packed_gtf(self._gtf(direction), self.z_dim, self.h_dim)
+        for mu, sd, seen in enc.values():
+            for x in (mu, sd, seen):
+                x.record_stream(side)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            loss_f = f_mult * self._mode_loss(enc, targets, mask, kld_mult, rec_mults, pass_mods,
+                                              loss_mods, t_max, b_dim, f_mode, sample,
+                                              sample_init, kwargs.get('flt_particles', 1),
+                                              smt_particles)
+        loss_s = s_mult * self._mode_loss(enc, targets, mask, kld_mult, rec_mults, pass_mods,
+                                          loss_mods, t_max, b_dim, s_mode, sample,
+                                          sample_init, train_particles, smt_particles)
+        main.wait_stream(side)
+        return loss + loss_f + loss_s
