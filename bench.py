@@ -146,9 +146,22 @@ def main():
                              targets=targets, n_points_global=n_points_global,
                              train_particles=TRAIN_PARTICLES)
     else:   # same step, captured once into two HIP graphs (collective in between, eager)
-        step = GraphedElboStep(model, optimizer, bucket, inputs, mask, lengths, 1.0, rec,
-                               targets=targets, n_points_global=n_points_global,
-                               train_particles=TRAIN_PARTICLES)
+        try:
+            step = GraphedElboStep(model, optimizer, bucket, inputs, mask, lengths, 1.0, rec,
+                                   targets=targets, n_points_global=n_points_global,
+                                   train_particles=TRAIN_PARTICLES)
+        except Exception as exc:        # noqa: BLE001 -- never lose the run to a capture problem
+            print('bench: HIP-graph capture failed (%r); running the step eagerly' % (exc,),
+                  file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            args.eager = True
+            bucket.check_views()
+            bucket.zero()
+
+            def step():
+                return elbo_step(model, optimizer, bucket, inputs, mask, lengths, 1.0, rec,
+                                 targets=targets, n_points_global=n_points_global,
+                                 train_particles=TRAIN_PARTICLES)
 
     def barrier():
         if world > 1:

@@ -20,14 +20,14 @@ using namespace mdmm;
 using namespace mdmm_simt;
 
 struct Geo {
-  int T, B, D, Dp, Hp, F1, P, K, S, PS, R, RC, s0;
+  int T, B, D, Dp, Hp, F1, P, p0, K, S, PS, R, RC, s0;   // P = passes of THIS workgroup, from p0
   uint64_t noise_offset;
 };
 
-__device__ __forceinline__ Geo make_geo(const mdmm_sweep_t& a, int S, int RC) {
+__device__ __forceinline__ Geo make_geo(const mdmm_sweep_t& a, int S, int RC, int Pl) {
   Geo g;
   g.T = a.T; g.B = a.B; g.D = a.D; g.Dp = pad4(a.D); g.Hp = pad4(a.H);
-  g.F1 = 2 * g.Hp + g.Dp; g.P = a.P; g.K = a.K; g.S = S; g.PS = a.P * S;
+  g.F1 = 2 * g.Hp + g.Dp; g.P = Pl; g.p0 = blockIdx.y * Pl; g.K = a.K; g.S = S; g.PS = Pl * S;
   g.R = g.PS * a.K; g.RC = RC; g.s0 = blockIdx.x * S;
   g.noise_offset = a.offset + (a.offset_dev ? *a.offset_dev : 0);
   return g;
@@ -57,7 +57,7 @@ __device__ __forceinline__ void build_z_rows(const mdmm_sweep_t& a, const Geo& g
           z = a.z_rows[((size_t)k * g.B + b) * g.D + d];
         } else {
           z = cur_mu[ps * g.Dp + d];
-          if (sampled_prev) z = fmaf(eps_at(a, g, p, t_prev, k, b, d), cur_sig[ps * g.Dp + d], z);
+          if (sampled_prev) z = fmaf(eps_at(a, g, g.p0 + p, t_prev, k, b, d), cur_sig[ps * g.Dp + d], z);
         }
       }
     }
@@ -68,9 +68,9 @@ __device__ __forceinline__ void build_z_rows(const mdmm_sweep_t& a, const Geo& g
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void sweep_fwd_kernel(const mdmm_sweep_t a, int S, int RC) {
+__global__ __launch_bounds__(NT) void sweep_fwd_kernel(const mdmm_sweep_t a, int S, int RC, int Pl) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Geo g = make_geo(a, S, RC);
+  const Geo g = make_geo(a, S, RC, Pl);
   const int nitem = g.PS * g.Dp;
   float* cur_mu = smem;
   float* cur_sig = cur_mu + nitem;
@@ -166,22 +166,22 @@ __global__ __launch_bounds__(NT) void sweep_fwd_kernel(const mdmm_sweep_t a, int
       q.add(pr_mu[it], pr_sig[it], 1.0f);
       for (int e = 0; e < a.E; ++e) {
         const mdmm_expert_t& ex = a.experts[e];
-        if (!((ex.pass_bits >> p) & 1u)) continue;
+        if (!((ex.pass_bits >> (g.p0 + p)) & 1u)) continue;
         const float c = ex.mask ? ex.mask[tb] : 1.0f;
-        const size_t off = (size_t)p * ex.pass_stride + tb * g.D + d;
+        const size_t off = (size_t)(g.p0 + p) * ex.pass_stride + tb * g.D + d;
         q.add(ex.mean[off], ex.std[off], c);
       }
       if (a.use_inv_prior) q.add(a.z0_mean[d], -(expf(a.z0_log_std[d]) + a.min_std), 1.0f);
       float im, is; q.finish(im, is);
       cur_mu[it] = im; cur_sig[it] = is;
-      const size_t o = ((size_t)p * g.T + t) * g.B * g.D + (size_t)b * g.D + d;
+      const size_t o = ((size_t)(g.p0 + p) * g.T + t) * g.B * g.D + (size_t)b * g.D + d;
       a.infer_mean[o] = im; a.infer_std[o] = is;
       a.prior_mean[o] = pr_mu[it]; a.prior_std[o] = pr_sig[it];
       if (a.samples) {
         float zs = im;
         if (sampled) {
           float acc = 0.f;
-          for (int k = 0; k < g.K; ++k) acc += fmaf(eps_at(a, g, p, t, k, b, d), is, im);
+          for (int k = 0; k < g.K; ++k) acc += fmaf(eps_at(a, g, g.p0 + p, t, k, b, d), is, im);
           zs = acc * inv_k;   // z_t.mean(dim=0), dmm.py:402
         }
         a.samples[o] = zs;
@@ -194,9 +194,9 @@ __global__ __launch_bounds__(NT) void sweep_fwd_kernel(const mdmm_sweep_t a, int
 // ---------------------------------------------------------------------------------
 // backward (reverse scan with recompute)
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int S, int RC) {
+__global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int S, int RC, int Pl) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Geo g = make_geo(a, S, RC);
+  const Geo g = make_geo(a, S, RC, Pl);
   const int nitem = g.PS * g.Dp;
   // per (pass, sequence, dim) state
   float* adj_a = smem;               // sum_k d/dz^k of the current step (from the later step)
@@ -254,13 +254,13 @@ __global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int
         float g_mu0 = 0.f, g_sg0 = 0.f;
         for (int p = 0; p < g.P; ++p) {
           const int it = (p * g.S + s) * g.Dp + d;
-          const size_t o = ((size_t)p * g.T + t) * g.B * g.D + (size_t)b * g.D + d;
+          const size_t o = ((size_t)(g.p0 + p) * g.T + t) * g.B * g.D + (size_t)b * g.D + d;
           const float gsmp = a.g_samples ? a.g_samples[o] : 0.f;
           float g_im = (a.g_infer_mean ? a.g_infer_mean[o] : 0.f) + adj_a[it] + gsmp;
           float g_is = (a.g_infer_std ? a.g_infer_std[o] : 0.f);
           if (sampled) {
             float se = 0.f;
-            if (gsmp != 0.f) { for (int k = 0; k < g.K; ++k) se += eps_at(a, g, p, t, k, b, d); }
+            if (gsmp != 0.f) { for (int k = 0; k < g.K; ++k) se += eps_at(a, g, g.p0 + p, t, k, b, d); }
             g_is += adj_b[it] + gsmp * se * inv_k;
           }
           // recompute the product (same order as forward)
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int
           Poe q; q.init(); q.add(prm, prs, 1.0f);
           for (int e = 0; e < a.E; ++e) {
             const mdmm_expert_t& ex = a.experts[e];
-            if (!((ex.pass_bits >> p) & 1u)) continue;
+            if (!((ex.pass_bits >> (g.p0 + p)) & 1u)) continue;
             const float c = ex.mask ? ex.mask[tb] : 1.0f;
-            const size_t off = (size_t)p * ex.pass_stride + tb * g.D + d;
+            const size_t off = (size_t)(g.p0 + p) * ex.pass_stride + tb * g.D + d;
             q.add(ex.mean[off], ex.std[off], c);
           }
           if (a.use_inv_prior) q.add(mu0, -sg0, 1.0f);
@@ -284,9 +284,9 @@ __global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int
           pmu[it] = prm; psg[it] = prs;
           for (int e = 0; e < a.E; ++e) {
             const mdmm_expert_t& ex = a.experts[e];
-            if (!((ex.pass_bits >> p) & 1u)) continue;
+            if (!((ex.pass_bits >> (g.p0 + p)) & 1u)) continue;
             const float c = ex.mask ? ex.mask[tb] : 1.0f;
-            const size_t off = (size_t)p * ex.pass_stride + tb * g.D + d;
+            const size_t off = (size_t)(g.p0 + p) * ex.pass_stride + tb * g.D + d;
             poe_expert_bwd(ex.mean[off], ex.std[off], c, g_num, g_prec, gm, gs);
             if (ex.g_mean) ex.g_mean[o] = gm;      // one slab per pass, (P,T,B,D)
             if (ex.g_std) ex.g_std[o] = gs;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int
         const int p = ps / g.S, s = ps - p * g.S, b = g.s0 + s;
         float m = 0.f, sd = 0.f;
         if (d < g.D && b < g.B) {
-          const size_t o = ((size_t)p * g.T + t_prev) * g.B * g.D + (size_t)b * g.D + d;
+          const size_t o = ((size_t)(g.p0 + p) * g.T + t_prev) * g.B * g.D + (size_t)b * g.D + d;
           m = a.infer_mean[o]; sd = a.infer_std[o];
         }
         zmu[it] = m; zsg[it] = sd; nxt_a[it] = 0.f; nxt_b[it] = 0.f;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int
           const int ps = r / g.K, k = r - ps * g.K, p = ps / g.S, s = ps - p * g.S, b = g.s0 + s;
           if (b >= g.B) continue;
           const int64_t row = a.trans_only ? ((int64_t)b * g.K + k)
-              : ((((int64_t)(i - 1) * g.P + p) * g.B + b) * g.K + k);
+              : ((((int64_t)(i - 1) * a.P + g.p0 + p) * g.B + b) * g.K + k);
           float v;
           if (f < g.F1) v = G1[f * RC + rr];
           else if (f < g.F1 + 2 * g.Dp) v = G2[(f - g.F1) * RC + rr];
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int
           const int ps = r / g.K, k = r - ps * g.K, p = ps / g.S, s = ps - p * g.S, b = g.s0 + s;
           if (b >= g.B) continue;
           const int64_t row = a.trans_only ? ((int64_t)b * g.K + k)
-              : ((((int64_t)(i - 1) * g.P + p) * g.B + b) * g.K + k);
+              : ((((int64_t)(i - 1) * a.P + g.p0 + p) * g.B + b) * g.K + k);
           float v;
           if (f < g.Dp) v = zT[f * RC + rr];
           else if (f < g.Dp + 2 * g.Hp) v = a1[(f - g.Dp) * RC + rr];
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int
           for (int r = rlo; r < rhi; ++r) {
             const float gz = zT[d * RC + (r - c0)];
             sa += gz;
-            if (sampled_prev) sb = fmaf(gz, eps_at(a, g, p, t_prev, r - ps * g.K, b, d), sb);
+            if (sampled_prev) sb = fmaf(gz, eps_at(a, g, g.p0 + p, t_prev, r - ps * g.K, b, d), sb);
           }
           nxt_a[it] += sa; nxt_b[it] += sb;
         }
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(NT) void sweep_bwd_kernel(const mdmm_sweep_t a, int
 // ---------------------------------------------------------------------------------
 constexpr size_t LDS_MAX = 160 * 1024;
 
-struct Launch { int S, RC, grid; size_t lds; };
+struct Launch { int S, RC, grid, Pl; size_t lds; };
 
 int check_args(const mdmm_sweep_t* a) {
   if (!a) return MDMM_E_ARG;
@@ -481,7 +481,11 @@ int check_args(const mdmm_sweep_t* a) {
 
 int plan(const mdmm_sweep_t* a, bool bwd, Launch* out) {
   const int Dp = pad4(a->D), Hp = pad4(a->H), F1 = 2 * Hp + Dp;
-  const int rows_per_seq = a->P * a->K;
+  // With particles every pass of a sequence is K rows of its own: give each pass its own
+  // workgroup (grid.y) -- P times the parallelism and a P times smaller LDS state.  K = 1 sweeps
+  // keep the passes of a sequence together (few rows per workgroup as it is).
+  const int Pl = (a->K > 1) ? 1 : a->P;
+  const int rows_per_seq = Pl * a->K;
   // sequences per workgroup: keep >= ~512 workgroups when the batch allows, <= 64 rows
   int S = a->B / 512;
   if (S > 64 / rows_per_seq) S = 64 / rows_per_seq;
@@ -489,15 +493,15 @@ int plan(const mdmm_sweep_t* a, bool bwd, Launch* out) {
   const size_t per_row = (size_t)(bwd ? (7 * Dp + 2 * F1) : (4 * Dp + F1)) * sizeof(float);
   const size_t budget = (Dp <= 64) ? 64 * 1024 : LDS_MAX - 1024;
   for (;; --S) {
-    const size_t state = (size_t)(bwd ? 10 : 7) * a->P * S * Dp * sizeof(float) +
+    const size_t state = (size_t)(bwd ? 10 : 7) * Pl * S * Dp * sizeof(float) +
                          (bwd ? 2 * Dp * sizeof(float) : 0);
-    const int R = a->P * S * a->K;
+    const int R = Pl * S * a->K;
     if (state + 4 * per_row <= LDS_MAX) {
       size_t avail = (state + 4 * per_row <= budget ? budget : LDS_MAX) - state;
       int RC = (int)(avail / per_row) & ~3;
       if (RC > ((R + 3) & ~3)) RC = (R + 3) & ~3;
       if (RC >= 4) {
-        out->S = S; out->RC = RC; out->grid = (a->B + S - 1) / S;
+        out->S = S; out->RC = RC; out->grid = (a->B + S - 1) / S; out->Pl = Pl;
         out->lds = state + (size_t)RC * per_row;
         return 0;
       }
@@ -535,7 +539,8 @@ int mdmm_simt_sweep_fwd(const mdmm_sweep_t* args, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(sweep_fwd_kernel, dim3(L.grid), dim3(NT), L.lds, stream, *args, L.S, L.RC);
+  hipLaunchKernelGGL(sweep_fwd_kernel, dim3(L.grid, args->P / L.Pl), dim3(NT), L.lds, stream, *args, L.S,
+                     L.RC, L.Pl);
   return (int)hipGetLastError();
 }
 
@@ -550,6 +555,7 @@ int mdmm_simt_sweep_bwd(const mdmm_sweep_t* args, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(sweep_bwd_kernel, dim3(L.grid), dim3(NT), L.lds, stream, *args, L.S, L.RC);
+  hipLaunchKernelGGL(sweep_bwd_kernel, dim3(L.grid, args->P / L.Pl), dim3(NT), L.lds, stream, *args, L.S,
+                     L.RC, L.Pl);
   return (int)hipGetLastError();
 }

@@ -124,12 +124,15 @@ class GraphedElboStep:
         torch.cuda.synchronize()
         ops.clear_caches(model.parameters())
         self.g_step, self.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_step):
+        # thread_local: other threads (the RCCL watchdog of torch.distributed polls events) must
+        # not invalidate the capture
+        with torch.cuda.graph(self.g_step, capture_error_mode='thread_local'):
             self.loss = fwd_bwd()
             if hasattr(noise, 'advance'):
                 noise.advance()
         bucket.check_views()
-        with torch.cuda.graph(self.g_opt, pool=self.g_step.pool()):
+        with torch.cuda.graph(self.g_opt, pool=self.g_step.pool(),
+                              capture_error_mode='thread_local'):
             optimizer.step()
             bucket.zero()
 

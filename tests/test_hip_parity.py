@@ -617,3 +617,36 @@ def test_vrnn_forward_golden(dev, kernel_family):
                 close(recon[0][k], g.t(p + '/rec_mean/' + k), what=p); close(recon[1][k], g.t(p + '/rec_std/' + k), what=p)
         (infer[0].sum() + recon[0]['a'].sum()).backward()
         assert all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None)
+
+
+def test_eval_forward_200_particles(dev, kernel_family):
+    """The reference's evaluation call for --method bfvi (trainer.py:358-361, 296): fsmooth with
+    flt_particles=200, sample=False (sampling is still forced in the particle filter, dmm.py:398).
+    200 particles per sequence run on the generic kernels (row chunks through LDS)."""
+    if kernel_family == 'generic':
+        pytest.skip('200 particles always run on the generic family')
+    from mdmm import models, ops
+    from mdmm.noise import PhiloxNoise
+    torch.manual_seed(2)
+    spec = [('a', 1, 'Normal'), ('b', 1, 'Normal')]
+    T, lengths, D, H, K = 14, [14, 11, 6], 32, 32, 200
+    B = len(lengths)
+    m = models.MultiDMM(['a', 'b'], [1, 1], h_dim=H, z_dim=D, device=dev).eval()
+    o = orc.OracleDMM(['a', 'b'], [1, 1], h_dim=H, z_dim=D).eval()
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    x = make_inputs(spec, T, lengths, seed=12, nan_spans=[('a', 3, 8, 0), ('b', 0, 2, 1)])
+    mask = orc.len_to_mask(lengths)
+    m.noise = PhiloxNoise(seed=5)
+    with torch.no_grad():
+        infer, prior, recon = m(cuda(x, dev), lengths=lengths, sample=False, flt_particles=K)
+    noise = PhiloxNoise(seed=5)
+    sd, off = noise.stream()
+    eps = ops.philox_normal(sd, off, (1, T, K, B, D), dev).cpu()
+    o.noise = orc.ReplayNoise([eps[0, t] for t in reversed(range(T))])   # backward filter only
+    with torch.no_grad():
+        oi, op, orec = o(x, lengths=lengths, sample=False, flt_particles=K)
+    assert o.noise.pos == T
+    close(infer[0], oi[0], what='infer mean'); close(infer[1], oi[1], what='infer std')
+    close(prior[0], op[0], what='prior mean'); close(prior[1], op[1], what='prior std')
+    close(m.kld_loss(infer, prior, mask.to(dev)), o.kld_loss(oi, op, mask), TOL_LOSS, 'kld')
+    close(m.rec_loss(cuda(x, dev), recon, mask.to(dev), {}), o.rec_loss(x, orec, mask, {}), TOL_LOSS, 'rec')
