@@ -22,11 +22,17 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ wt, int ldw,
                                          const float* __restrict__ bias, const float* in,
                                          float* out, int Kd, int F, int RC, Epi epi) {
   const int nfq = F >> 2, ngr = RC >> 2;
-  for (int task = threadIdx.x; task < nfq * ngr; task += NT) {
+  const int ntask = nfq * ngr;
+  // Few rows (K = 1 sweeps, DKS scans at z = 256): fewer 4x4 tiles than threads, and each tile
+  // is a serial chain of Kd dependent L2 loads.  Split the contraction over KS adjacent lanes
+  // (interleaved k) and combine with two DPP-class shuffles, so the whole workgroup streams.
+  const int KS = (ntask * 4 <= NT) ? 4 : ((ntask * 2 <= NT) ? 2 : 1);
+  for (int vt = threadIdx.x; vt < ntask * KS; vt += NT) {
+    const int task = vt / KS, part = vt - task * KS;
     const int fq = task % nfq, g = task / nfq;
     const int f0 = fq << 2, r0 = g << 2;
     float4 acc[4];
-    float4 b = bias ? ld4(bias + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 b = (bias && part == 0) ? ld4(bias + f0) : make_float4(0.f, 0.f, 0.f, 0.f);
     acc[0] = make_float4(b.x, b.x, b.x, b.x);
     acc[1] = make_float4(b.y, b.y, b.y, b.y);
     acc[2] = make_float4(b.z, b.z, b.z, b.z);
@@ -34,7 +40,7 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ wt, int ldw,
     const float* wp = wt + f0;
     const float* ip = in + r0;
 #pragma unroll 4
-    for (int k = 0; k < Kd; ++k) {
+    for (int k = part; k < Kd; k += KS) {
       const float4 w = ld4(wp + (size_t)k * ldw);
       const float4 x = ld4(ip + k * RC);
       acc[0].x = fmaf(w.x, x.x, acc[0].x); acc[0].y = fmaf(w.x, x.y, acc[0].y);
@@ -46,10 +52,23 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ wt, int ldw,
       acc[3].x = fmaf(w.w, x.x, acc[3].x); acc[3].y = fmaf(w.w, x.y, acc[3].y);
       acc[3].z = fmaf(w.w, x.z, acc[3].z); acc[3].w = fmaf(w.w, x.w, acc[3].w);
     }
+    if (KS > 1) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      epi(f0 + j, r0, acc[j]);
-      st4(out + (f0 + j) * RC + r0, acc[j]);
+      for (int j = 0; j < 4; ++j) {
+        acc[j].x += __shfl_xor(acc[j].x, 1, 64); acc[j].y += __shfl_xor(acc[j].y, 1, 64);
+        acc[j].z += __shfl_xor(acc[j].z, 1, 64); acc[j].w += __shfl_xor(acc[j].w, 1, 64);
+        if (KS > 2) {
+          acc[j].x += __shfl_xor(acc[j].x, 2, 64); acc[j].y += __shfl_xor(acc[j].y, 2, 64);
+          acc[j].z += __shfl_xor(acc[j].z, 2, 64); acc[j].w += __shfl_xor(acc[j].w, 2, 64);
+        }
+      }
+    }
+    if (part == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        epi(f0 + j, r0, acc[j]);
+        st4(out + (f0 + j) * RC + r0, acc[j]);
+      }
     }
   }
 }
