@@ -39,7 +39,9 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ wt, int ldw,
     acc[3] = make_float4(b.w, b.w, b.w, b.w);
     const float* wp = wt + f0;
     const float* ip = in + r0;
-#pragma unroll 4
+    // 8 independent (weight, activation) load pairs in flight per thread: at z = 256 a workgroup
+    // is alone on its CU (LDS-bound), so memory latency is hidden by unrolling, not by occupancy
+#pragma unroll 8
     for (int k = part; k < Kd; k += KS) {
       const float4 w = ld4(wp + (size_t)k * ldw);
       const float4 x = ld4(ip + k * RC);

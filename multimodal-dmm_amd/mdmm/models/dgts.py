@@ -13,6 +13,19 @@ from ..noise import PhiloxNoise
 
 class MultiDGTS(nn.Module):
     noise = None    # PhiloxNoise by default (set lazily), or a ReplayNoise for parity runs
+    # Set to torch.bfloat16 to run the user-pluggable encoder / decoder modules (conv stacks,
+    # MIOpen) under autocast, as BASELINE cfg3 asks; the latent state, the sweeps, the products of
+    # experts and every loss reduction stay fp32.  None (default) = everything fp32.
+    plugin_dtype = None
+
+    def _plug(self, module, x):
+        if self.plugin_dtype is None or not x.is_cuda:
+            return module(x)
+        with torch.autocast('cuda', dtype=self.plugin_dtype):
+            out = module(x)
+        if isinstance(out, tuple):
+            return tuple(o.float() for o in out)
+        return out.float()
 
     def _noise(self):
         if self.noise is None:

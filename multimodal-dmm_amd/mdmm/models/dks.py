@@ -93,7 +93,7 @@ class MultiDKS(MultiDGTS):
                 x = torch.where(nan, torch.zeros_like(x), x)
             if self.dists[m] == 'Categorical':
                 x = x.long()
-            feats[m] = self.enc[m](x.flatten(0, 1)).reshape(t_max, b_dim, -1)
+            feats[m] = self._plug(self.enc[m], x.flatten(0, 1)).reshape(t_max, b_dim, -1)
         return feats, masks
 
     def _rnn(self, m, feat, mask):
@@ -159,7 +159,7 @@ class MultiDKS(MultiDGTS):
             ops.gtf_param_list(self.fwd))
         recon = dict()
         for m in self.modalities:                                   # dks.py:285-291
-            out = self.dec[m](z.reshape(-1, self.z_dim))
+            out = self._plug(self.dec[m], z.reshape(-1, self.z_dim))
             recon[m] = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
         return (im, is_), (pm, ps), recon
 
@@ -207,10 +207,10 @@ class MultiDKS(MultiDGTS):
                 x = torch.where(nan, torch.zeros_like(x), x)
                 if self.dists[m] == 'Categorical':
                     x = x.long()
-                feat = self.enc[m](x.flatten(0, 1)).reshape(t_max, b_dim, -1)
+                feat = self._plug(self.enc[m], x.flatten(0, 1)).reshape(t_max, b_dim, -1)
                 real[m] = (feat, self._rnn(m, feat, seen), seen)
             if any(m not in ps for ps in passes):
-                feat = self.enc[m](self._zero_input(m, t_max, b_dim, dev).flatten(0, 1))
+                feat = self._plug(self.enc[m], self._zero_input(m, t_max, b_dim, dev).flatten(0, 1))
                 feat = feat.reshape(t_max, b_dim, -1)
                 gone = torch.zeros(t_max, b_dim, device=dev, dtype=torch.bool)
                 if self.rnn_skip:       # never updated: stays at the initial state of the top layer
@@ -262,7 +262,7 @@ class MultiDKS(MultiDGTS):
                 continue
             for p in used:
                 zp = z[:, p * b_dim:(p + 1) * b_dim].reshape(-1, self.z_dim)
-                out = self.dec[m](zp)
+                out = self._plug(self.dec[m], zp)
                 rec = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
                 total = total + mult * self._nll(m, rec, targets[m], mask)
         return total
@@ -283,6 +283,6 @@ class MultiDKS(MultiDGTS):
         z_samples = torch.stack(z_samples, dim=0)
         recon = dict()
         for m in self.modalities:
-            out = self.dec[m](z_samples.reshape(-1, self.z_dim))
+            out = self._plug(self.dec[m], z_samples.reshape(-1, self.z_dim))
             recon[m] = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
         return recon

@@ -99,7 +99,7 @@ class MultiDMM(MultiDGTS):
         x = torch.where(nan, torch.zeros_like(x), x)
         if self.dists[m] == 'Categorical':
             x = x.long()
-        mean, std = self.enc[m](x.flatten(0, 1))
+        mean, std = self._plug(self.enc[m], x.flatten(0, 1))
         return mean.reshape(t_max, b_dim, -1), std.reshape(t_max, b_dim, -1), seen
 
     def encode(self, inputs, combine=False):
@@ -121,7 +121,7 @@ class MultiDMM(MultiDGTS):
         t_max, b_dim = z.shape[:2]
         recon = dict()
         for m in self.modalities:
-            out = self.dec[m](z.reshape(-1, self.z_dim))
+            out = self._plug(self.dec[m], z.reshape(-1, self.z_dim))
             recon[m] = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
         return recon
 
@@ -287,10 +287,10 @@ class MultiDMM(MultiDGTS):
         has_bn = dec.training and any(isinstance(x, nn.modules.batchnorm._BatchNorm)
                                       for x in dec.modules())
         if has_bn or len(z_list) == 1:
-            outs = [dec(z.reshape(-1, self.z_dim)) for z in z_list]
+            outs = [self._plug(dec, z.reshape(-1, self.z_dim)) for z in z_list]
             return [tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in o) for o in outs]
         n = len(z_list)
-        out = dec(torch.stack(z_list).reshape(-1, self.z_dim))
+        out = self._plug(dec, torch.stack(z_list).reshape(-1, self.z_dim))
         out = [r.reshape(n, t_max, b_dim, *r.shape[1:]) for r in out]
         return [tuple(r[i] for r in out) for i in range(n)]
 
