@@ -12,10 +12,10 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libmdmm_hip.so')
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SYMBOLS = [
-    'mdmm_version', 'mdmm_strerror', 'mdmm_pad',
+    'mdmm_version', 'mdmm_strerror', 'mdmm_pad', 'mdmm_sizeof',
     'mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd',
     'mdmm_sweep_spill_width_g', 'mdmm_sweep_spill_width_x',
     'mdmm_sweep_bwd_mode', 'mdmm_sweep_dw_width', 'mdmm_sweep_dw_rows',
@@ -26,6 +26,8 @@ SYMBOLS = [
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
     'mdmm_philox_normal',
     'mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd', 'mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd',
+    'mdmm_stage_sample', 'mdmm_stage_step_fwd', 'mdmm_stage_fuse_bwd', 'mdmm_stage_trans_bwd',
+    'mdmm_stage_adj_reduce',
 ]
 
 _P = C.c_void_p
@@ -55,6 +57,13 @@ class Sweep(C.Structure):
                  ('g_z0_mean', _P), ('g_z0_sigma', _P), ('g_z_rows', _P),
                  ('spill_g', _P), ('spill_x', _P), ('spill_rows', C.c_int64),
                  ('dw_partial', _P), ('dw_partial_rows', C.c_int64), ('offset_dev', _P)])
+
+
+class Stage(C.Structure):
+    _fields_ = ([('sw', Sweep)] +
+                [(n, C.c_int32) for n in ('t', 't_prev', 'first', 'sampled', 'sampled_prev', 'reserved')] +
+                [(n, _P) for n in ('Z', 'A1', 'GATE', 'NL', 'PRE', 'G1', 'GG', 'GN', 'G3', 'GZ', 'GZ0',
+                                   'GZF', 'adj_a', 'adj_b', 'gpm', 'gps')])
 
 
 class Gru(C.Structure):
@@ -101,6 +110,9 @@ def lib():
             getattr(L, name).argtypes = [C.c_int, C.c_int]
         for name in ('mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd'):
             getattr(L, name).argtypes = [C.POINTER(Sweep), _P]
+        for name in ('mdmm_stage_sample', 'mdmm_stage_step_fwd', 'mdmm_stage_fuse_bwd',
+                     'mdmm_stage_trans_bwd', 'mdmm_stage_adj_reduce'):
+            getattr(L, name).argtypes = [C.POINTER(Stage), _P]
         for name in ('mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd'):
             getattr(L, name).argtypes = [C.POINTER(Gru), _P]
         for name in ('mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd'):
@@ -126,6 +138,12 @@ def lib():
         if L.mdmm_version() != ABI_VERSION:
             raise MdmmError('libmdmm_hip.so ABI %d != binding ABI %d'
                             % (L.mdmm_version(), ABI_VERSION))
+        L.mdmm_sizeof.argtypes = [C.c_int]
+        L.mdmm_sizeof.restype = C.c_size_t
+        for which, st in enumerate((Gtf, Expert, Sweep, Stage, Gru, Dks)):
+            if L.mdmm_sizeof(which) != C.sizeof(st):
+                raise MdmmError('struct %s: library %d bytes, binding %d bytes'
+                                % (st.__name__, L.mdmm_sizeof(which), C.sizeof(st)))
         _lib = L
     return _lib
 

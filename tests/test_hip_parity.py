@@ -332,6 +332,15 @@ def test_step_philox_matches_oracle(dev):
     _philox_step_vs_oracle(dev, 9, [9, 9, 7, 4, 2], 8, 12, 6, [('a', 2, 5, 1), ('b', 0, 2, 0)], 7)
 
 
+def test_step_philox_staged_odd_dims(dev, kernel_family, monkeypatch):
+    """Stage-wise sweep (csrc/staged.hip) at latent sizes that are no multiple of anything."""
+    if kernel_family == 'generic':
+        pytest.skip('MDMM_FORCE_GENERIC pins the persistent kernels')
+    from mdmm import ops
+    monkeypatch.setattr(ops, 'STAGED_MIN_ROWS', 1)
+    _philox_step_vs_oracle(dev, 12, [12, 12, 9, 5, 1], 40, 52, 7, [('a', 3, 6, 1), ('b', 0, 3, 0)], 13)
+
+
 def test_step_philox_long_sequence_z32(dev):
     """cfg2 latent sizes (z = h = 32, T = 100, 25 particles) on a batch the oracle can do."""
     _philox_step_vs_oracle(dev, 100, [100, 100, 90, 61, 30, 7], 32, 32, 25,
@@ -541,13 +550,16 @@ def test_dks_philox_matches_oracle_weizmann_like_dims(dev, kernel_family):
         grad_close(p.grad, ref, k)
 
 
-def test_step_z256_matches_oracle(dev, kernel_family):
-    """Weizmann latent sizes (z = h = 256, 3 modalities incl. a categorical one, 25 particles):
-    the generic kernels stream the 1.5 MB transition weights from L2 and chunk the particle rows
-    through LDS; checked against the oracle with the kernels' own Philox noise."""
+@pytest.mark.parametrize('path', ['persistent', 'staged'])
+def test_step_z256_matches_oracle(dev, kernel_family, path, monkeypatch):
+    """Weizmann latent sizes (z = h = 256, 3 modalities incl. a categorical one, 25 particles),
+    checked against the oracle with the kernels' own Philox noise.  'persistent': the generic
+    kernels stream the 1.5 MB transition weights from L2 and chunk the particle rows through LDS;
+    'staged': host time loop, library GEMMs + csrc/staged.hip (what large batches run)."""
     if kernel_family == 'generic':
-        pytest.skip('z = 256 always runs on the generic family')
+        pytest.skip('z = 256 never runs on the MFMA family')
     from mdmm import models, ops
+    monkeypatch.setattr(ops, 'STAGED_MIN_ROWS', 1 if path == 'staged' else 1 << 40)
     from mdmm.noise import PhiloxNoise
     torch.manual_seed(5)
     spec = [('v', 6, 'Normal'), ('m', 3, 'Normal'), ('a', 10, 'Categorical')]
