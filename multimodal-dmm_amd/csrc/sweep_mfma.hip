@@ -62,7 +62,7 @@ __device__ __forceinline__ void stage_frag(float4* dst, const float* __restrict_
                                            int row0, int n_rows, int n_cols, int IT, int FT,
                                            int col0 = 0, int dst_ft = -1, int ft_off = 0) {
   if (dst_ft < 0) dst_ft = FT;
-  for (int idx = threadIdx.x; idx < IT * FT * 64; idx += NT) {
+  for (int idx = threadIdx.x; idx < IT * FT * 64; idx += blockDim.x) {
     const int lane = idx & 63, tile = idx >> 6;
     const int ft = tile % FT, it = tile / FT;
     const int row = 16 * it + (lane & 15), col = 16 * ft + 4 * (lane >> 4);
@@ -78,7 +78,7 @@ __device__ __forceinline__ void stage_frag(float4* dst, const float* __restrict_
 // bias fragments: dst[it*4 + g] = { b[off + 16it + 4g + r] }
 __device__ __forceinline__ void stage_bias(float4* dst, const float* __restrict__ b, int off, int n,
                                            int IT) {
-  for (int idx = threadIdx.x; idx < IT * 4; idx += NT) {
+  for (int idx = threadIdx.x; idx < IT * 4; idx += blockDim.x) {
     const int f = 16 * (idx >> 2) + 4 * (idx & 3);
     float v[4];
 #pragma unroll
@@ -1003,6 +1003,541 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
   for (int idx = threadIdx.x; idx < LB::WIDTH; idx += NT) out[idx] = acc[idx];
 }
 
+
+// =====================================================================================
+// backward, K > 1 (PART): cooperative workgroup of 8 waves
+// =====================================================================================
+// One wave = one 16-particle tile of a (pass, sequence); the CT tiles of a (pass, sequence) are
+// neighbouring waves.  Every wave runs the reverse scan of its tile (recompute + adjoints, as
+// above) but the weight gradients are accumulated cooperatively: per step the waves put their
+// [feature][row] images of G and X into one LDS buffer (128 rows), and each wave owns 1/8 of the
+// (output tile, row half) units -- 24 accumulator registers instead of 96, which brings the kernel
+// under 256 registers = two waves per SIMD (the matrix pipe of one wave overlaps the vector
+// work of its SIMD partner).  The tiles of a (pass, sequence) meet only in three per-feature sums
+// (d/dz, d/dz * eps, eps) exchanged through LDS.  Fixed summation order: deterministic.
+constexpr int NTC = 512;
+constexpr int NWC = NTC / 64;
+constexpr int RSC = 16 * NWC + 4;       // image row stride (floats)
+
+template <int DT, int HT>
+struct LdsC {
+  using LB = LdsB<DT, HT>;
+  static constexpr int IT1 = LB::IT1;
+  // phase 1 images: G = [std-pre (DT) | gate-pre (DT) | nonlin (DT)], X = [nonlin (DT) | h1 (HT) | h2 (HT)]
+  static constexpr int G1_PRE = 0, G1_GATE = DT, G1_GNL = 2 * DT;
+  static constexpr int X1_NL = 3 * DT, X1_H1 = 4 * DT, X1_H2 = 4 * DT + HT;
+  static constexpr int P1_TILES = 4 * DT + 2 * HT;
+  // phase 2 images: G = in-layer adjoint (IT1), X = z (DT)
+  static constexpr int G2_A1 = 0, X2_Z = IT1;
+  static constexpr int P2_TILES = IT1 + DT;
+  static constexpr int IMG_TILES = P1_TILES > P2_TILES ? P1_TILES : P2_TILES;
+  static constexpr int IMG_FLOATS = IMG_TILES * 16 * RSC;
+  static constexpr int N1 = DT * DT + 2 * DT * HT, N2 = IT1 * DT;      // output tiles per phase
+  static constexpr int NSL1 = (2 * N1 + NWC - 1) / NWC, NSL2 = (2 * N2 + NWC - 1) / NWC;
+  static constexpr int EXTRA = 48 * DT + 2 * NWC * 32 * DT + NWC * 3 * 16 * DT;       // floats
+  static constexpr size_t BYTES = (size_t)LB::WEND * 16 + (size_t)(IMG_FLOATS + EXTRA) * 4;
+};
+
+struct CoopUnit {       // one (output tile, row half) of the weight gradient, wave-uniform
+  int g_off, x_off;     // image offsets (floats) of the G / X feature tiles
+  int out_off, ld;      // where the tile goes in the partial row
+  int b_off;            // bias gradient offset, or -1 (the kt == 0 unit of an output row tile owns it)
+  bool valid;
+};
+
+template <int DT, int HT>
+__device__ __forceinline__ CoopUnit coop_unit(int phase, int u) {
+  using LB = LdsB<DT, HT>;
+  using LC = LdsC<DT, HT>;
+  CoopUnit c;
+  const int tile = u >> 1;
+  int gt, xt, ot, kt;
+  if (phase == 1) {
+    c.valid = tile < LC::N1;
+    if (tile < DT * DT) {
+      ot = tile / DT; kt = tile % DT; gt = LC::G1_PRE + ot; xt = LC::X1_NL + kt;
+      c.out_off = LB::O_WS + 16 * ot * LB::D16 + 16 * kt; c.ld = LB::D16; c.b_off = LB::O_BS + 16 * ot;
+    } else if (tile < DT * DT + DT * HT) {
+      const int q = tile - DT * DT;
+      ot = q / HT; kt = q % HT; gt = LC::G1_GATE + ot; xt = LC::X1_H1 + kt;
+      c.out_off = LB::O_WG + 16 * ot * LB::H16 + 16 * kt; c.ld = LB::H16; c.b_off = LB::O_BG + 16 * ot;
+    } else {
+      const int q = tile - DT * DT - DT * HT;
+      ot = q / HT; kt = q % HT; gt = LC::G1_GNL + ot; xt = LC::X1_H2 + kt;
+      c.out_off = LB::O_WN + 16 * ot * LB::H16 + 16 * kt; c.ld = LB::H16; c.b_off = LB::O_BN + 16 * ot;
+    }
+  } else {
+    c.valid = tile < LC::N2;
+    ot = tile / DT; kt = tile % DT; gt = LC::G2_A1 + ot; xt = LC::X2_Z + kt;
+    c.out_off = LB::O_W1 + 16 * ot * LB::D16 + 16 * kt; c.ld = LB::D16; c.b_off = LB::O_B1 + 16 * ot;
+  }
+  if (kt != 0) c.b_off = -1;
+  c.g_off = gt * 16 * RSC; c.x_off = xt * 16 * RSC;
+  return c;
+}
+
+// rows of this wave (16*wave + j) of N feature tiles, [feature][row] image
+template <int N>
+__device__ __forceinline__ void put_image(float* img, int tile0, int wave, int lane,
+                                          const f32x4 (&V)[N][1]) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int n = 0; n < N; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) img[((tile0 + n) * 16 + 4 * g + r) * RSC + 16 * wave + j] = V[n][0][r];
+}
+
+// acc[u] += G_tile(u) . X_tile(u)^T over the 64 rows of the unit's half
+template <int NSL>
+__device__ __forceinline__ void coop_mfma(const float* img, int lane, int half, const CoopUnit (&un)[NSL],
+                                          f32x4 (&acc)[NSL], float (&db)[NSL]) {
+  const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < NWC / 2; ++s) {
+    const int col = 16 * (half * (NWC / 2) + s) + 4 * g;
+    f32x4 av[NSL], bv[NSL];
+#pragma unroll
+    for (int u = 0; u < NSL; ++u) {
+      av[u] = ld_frag(reinterpret_cast<const float4*>(img + un[u].g_off + j * RSC + col));
+      bv[u] = ld_frag(reinterpret_cast<const float4*>(img + un[u].x_off + j * RSC + col));
+    }
+#pragma unroll
+    for (int u = 0; u < NSL; ++u)
+      if (un[u].b_off >= 0) db[u] += (av[u][0] + av[u][1]) + (av[u][2] + av[u][3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int u = 0; u < NSL; ++u) acc[u] = mfma16(av[u][r], bv[u][r], acc[u]);
+  }
+}
+
+
+// Diagnostic build only (-DMDMM_STAMPS): per-phase s_memtime totals of waves 0 and 4 of workgroup 0.
+#ifdef MDMM_STAMPS
+__device__ unsigned long long mdmm_stamp_buf[2][16];
+#define STAMP_INIT() unsigned long long st_acc[16] = {}; unsigned long long st_last = __builtin_amdgcn_s_memtime()
+#define STAMP(kk) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[kk] += now_ - st_last; st_last = now_; } while (0)
+#define STAMP_FLUSH() do { if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0) for (int q_ = 0; q_ < 16; ++q_) mdmm_stamp_buf[wave >> 2][q_] = st_acc[q_]; } while (0)
+#else
+#define STAMP_INIT()
+#define STAMP(kk)
+#define STAMP_FLUSH()
+#endif
+
+template <int DT, int HT, int CT, bool FULL>
+__global__ __launch_bounds__(NTC) void sweep_mfma_bwd_coop_kernel(const mdmm_sweep_t a, int n_tasks,
+                                                                  int n_rounds) {
+  extern __shared__ __attribute__((aligned(16))) float4 lds[];
+  using L = Lds<DT, HT>;
+  using LB = LdsB<DT, HT>;
+  using LC = LdsC<DT, HT>;
+  constexpr int IT1 = LB::IT1;
+  constexpr int TPB = NWC / CT;             // (pass, sequence) pairs per workgroup
+  constexpr int XS = 3 * 16 * DT;           // floats of one wave's exchange record
+  constexpr int NE = 2;                     // experts prefetched per step; further ones load in place
+  constexpr int NF = (DT + CT - 1) / CT;    // features per lane in the per-pair section
+  stage_forward_weights<DT, HT>(a, lds);
+  stage_backward_weights<DT, HT>(a, lds);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int slot = wave / CT, c = wave % CT;
+  float* img = reinterpret_cast<float*>(lds + LB::WEND);
+  float* cst = img + LC::IMG_FLOATS;                          // mu0 | sigma0 | 1/(sigma0^2+eps)
+  float* stash = cst + 48 * DT + slot * 32 * DT;              // moment-matching coefficients of the pair
+  float* zwav = cst + 48 * DT + NWC * 32 * DT + wave * 32 * DT;   // d/d(mu0, sigma0) row sums of this wave
+  float* xchg = cst + 48 * DT + 2 * NWC * 32 * DT;            // [wave][A | B | E][16 DT]
+  const int T = a.T, B = a.B, D = a.D, K = a.K;
+  const bool vec = FULL || (D & 3) == 0;
+  const int Dg = FULL ? (1 << 30) : D;
+  const bool fast_noise = vec && !a.eps;
+  const uint64_t noise_offset = a.offset + (a.offset_dev ? *a.offset_dev : 0);
+  const float inv_k = 1.0f / (float)K;
+  const size_t tbd = (size_t)T * B * D;
+  for (int idx = threadIdx.x; idx < LC::IMG_FLOATS; idx += NTC) img[idx] = 0.f;
+  for (int d = threadIdx.x; d < 16 * DT; d += NTC) {
+    const bool ok = d < D;
+    const float m0 = ok ? a.z0_mean[d] : 0.f;
+    const float s0 = ok ? expf(a.z0_log_std[d]) + a.min_std : 1.f;
+    cst[d] = m0; cst[16 * DT + d] = s0; cst[32 * DT + d] = fast::rcp(s0 * s0 + MDMM_POE_EPS);
+  }
+  for (int d = threadIdx.x; d < NWC * 32 * DT; d += NTC) cst[48 * DT + NWC * 32 * DT + d] = 0.f;
+  __syncthreads();
+  auto MU0 = [&](int dt, int r) { return cst[16 * dt + 4 * g + r]; };
+  auto SG0 = [&](int dt, int r) { return cst[16 * DT + 16 * dt + 4 * g + r]; };
+  auto T0C = [&](int dt, int r) { return cst[32 * DT + 16 * dt + 4 * g + r]; };
+  bool fvalid[DT][4];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fvalid[dt][r] = FULL || (16 * dt + 4 * g + r) < D;
+
+  // this wave's share of the weight gradient
+  const int half = wave & 1;
+  CoopUnit un1[LC::NSL1], un2[LC::NSL2];
+  f32x4 acc1[LC::NSL1], acc2[LC::NSL2];
+  float db1[LC::NSL1], db2[LC::NSL2];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < LC::NSL1; ++u) { un1[u] = coop_unit<DT, HT>(1, wave + NWC * u); acc1[u] = zero4; db1[u] = 0.f;
+    if (!un1[u].valid) { un1[u].g_off = un1[u].x_off = 0; un1[u].b_off = -1; } }
+#pragma unroll
+  for (int u = 0; u < LC::NSL2; ++u) { un2[u] = coop_unit<DT, HT>(2, wave + NWC * u); acc2[u] = zero4; db2[u] = 0.f;
+    if (!un2[u].valid) { un2[u].g_off = un2[u].x_off = 0; un2[u].b_off = -1; } }
+
+  // Per-pair section (adjoint of sampling + product of experts): the CT waves of a (pass, sequence)
+  // split its 16 DT latent features, ONE feature per lane j (replicated over g) -- scalar loads, a
+  // dozen registers of prefetch, no redundant arithmetic.  feature(n) = 16 * (c + n CT) + j.
+  float zacc_m[NF], zacc_s[NF];       // d/d mu0, d/d sigma0 of the per-pair terms (inverse prior, first step)
+#pragma unroll
+  for (int n = 0; n < NF; ++n) { zacc_m[n] = 0.f; zacc_s[n] = 0.f; }
+
+  STAMP_INIT();
+  for (int round = 0; round < n_rounds; ++round) {
+    const int task = (round * gridDim.x + blockIdx.x) * TPB + slot;
+    const bool task_ok = task < n_tasks;
+    const int p = task_ok ? task / B : 0, b = task_ok ? task - p * B : 0;
+    const int k = 16 * c + j;
+    const bool live = task_ok && k < K;
+    if (!task_ok)       // idle wave: its image columns must read as zeros in the cooperative phases
+      for (int f = g; f < LC::IMG_TILES * 16; f += 4) img[f * RSC + 16 * wave + j] = 0.f;
+    float* xw = xchg + wave * XS;
+    const float* xr = xchg + slot * CT * XS;
+    {   // exchange record the first processed step reads: no adjoints yet, eps sums of that step
+      const int t = a.reverse ? 0 : T - 1;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        float e4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.g_samples && live && d0 < Dg) {
+          const uint64_t idx = ((((uint64_t)p * T + t) * K + k) * B + b) * (uint64_t)D + d0;
+          eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float se = row16_sum(e4[r]);
+          if (j == 0) { xw[d0 + r] = 0.f; xw[16 * DT + d0 + r] = 0.f; xw[32 * DT + d0 + r] = se; }
+        }
+      }
+    }
+    // active experts of this pass (wave-uniform); the first NE are loaded ahead with the step inputs
+    int act[NE];
+    bool more = false;
+#pragma unroll
+    for (int n = 0; n < NE; ++n) act[n] = -1;
+    for (int e = 0; e < a.E; ++e) {
+      if (!((a.experts[e].pass_bits >> p) & 1u)) continue;
+      bool placed = false;
+#pragma unroll
+      for (int n = 0; n < NE; ++n) if (!placed && act[n] < 0) { act[n] = e; placed = true; }
+      if (!placed) more = true;
+    }
+
+    // ---- per-pair section, split in "issue the loads" and "compute" so the HBM latency of a step's
+    // inputs hides behind a cooperative MFMA phase ----
+    float f_pm[NF], f_ps[NF], f_gsm[NF], f_gim[NF], f_gis[NF], f_gqm[NF], f_gqs[NF];
+    float f_em[NE][NF], f_es[NE][NF], f_cm[NE];
+    auto pair_loads = [&](int ii) {
+      const int tt = a.reverse ? T - 1 - ii : ii;
+      const size_t tb = (size_t)tt * B + b;
+      const size_t o = (size_t)p * tbd + tb * D;
+#pragma unroll
+      for (int n = 0; n < NE; ++n) {
+        f_cm[n] = 1.0f;
+        if (act[n] >= 0 && a.experts[act[n]].mask) f_cm[n] = a.experts[act[n]].mask[tb];
+      }
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int f = 16 * (c + n * CT) + j;
+        const bool ok = (c + n * CT) < DT && f < D;
+        auto ld = [&](const float* ptr, size_t off, float dflt) { return (ok && ptr) ? ptr[off + f] : dflt; };
+        f_pm[n] = ld(a.prior_mean, o, 0.f);
+        f_ps[n] = ld(a.prior_std, o, 1.f);
+        f_gsm[n] = ld(a.g_samples, o, 0.f);
+        f_gim[n] = ld(a.g_infer_mean, o, 0.f);
+        f_gis[n] = ld(a.g_infer_std, o, 0.f);
+        f_gqm[n] = ld(a.g_prior_mean, o, 0.f);
+        f_gqs[n] = ld(a.g_prior_std, o, 0.f);
+#pragma unroll
+        for (int m = 0; m < NE; ++m) {
+          f_em[m][n] = 0.f; f_es[m][n] = 1.f;
+          if (act[m] >= 0) {
+            const mdmm_expert_t& ex = a.experts[act[m]];
+            const size_t off = (size_t)p * ex.pass_stride + tb * D;
+            f_em[m][n] = ld(ex.mean, off, 0.f);
+            f_es[m][n] = ld(ex.std, off, 1.f);
+          }
+        }
+      }
+    };
+    auto pair_compute = [&](int ii) {
+      const int tt = a.reverse ? T - 1 - ii : ii;
+      const size_t tb = (size_t)tt * B + b;
+      const size_t o = (size_t)p * tbd + tb * D;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int dt = c + n * CT;
+        const int f = 16 * dt + j;
+        const bool ok = dt < DT && f < D;
+        if (dt >= DT) continue;         // wave-uniform
+        float adjA = 0.f, adjB = 0.f, se = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) {
+          adjA += xr[cc * XS + f]; adjB += xr[cc * XS + 16 * DT + f]; se += xr[cc * XS + 32 * DT + f];
+        }
+        const float mu0 = cst[f], sg0 = cst[16 * DT + f], t0c = cst[32 * DT + f];
+        const float pmv = f_pm[n], psv = f_ps[n];
+        const float g_im = f_gim[n] + adjA + f_gsm[n];
+        const float g_is = f_gis[n] + adjB + f_gsm[n] * se * inv_k;
+        fast::Poe q; q.init(); q.add(pmv, psv, 1.0f);
+#pragma unroll
+        for (int m = 0; m < NE; ++m) if (act[m] >= 0 && ok) q.add(f_em[m][n], f_es[m][n], f_cm[m]);
+        if (more && ok) {
+          for (int e = act[NE - 1] + 1; e < a.E; ++e) {
+            const mdmm_expert_t& ex = a.experts[e];
+            if (!((ex.pass_bits >> p) & 1u)) continue;
+            const size_t off = (size_t)p * ex.pass_stride + tb * D + f;
+            q.add(ex.mean[off], ex.std[off], ex.mask ? ex.mask[tb] : 1.0f);
+          }
+        }
+        if (a.use_inv_prior && ok) q.add(mu0, -sg0, 1.0f);
+        const float rp = fast::rcp(q.prec);
+        const float m_ = q.num * rp, sd = fast::sqrt(rp);
+        float gm = g_im;
+        if (m_ != m_) gm = 0.f;
+        const float g_num = ok ? gm * rp : 0.f;
+        const float g_prec = ok ? (-gm * q.num * rp * rp - 0.5f * g_is * sd * rp) : 0.f;
+        const float iv = fast::rcp(psv * psv + MDMM_POE_EPS), sg = signf_(psv);
+        float gpm = g_num * iv * sg;
+        float gps = -(g_num * pmv + g_prec) * sg * iv * iv * 2.0f * psv;
+        // expert gradients, one (T,B,D) slab per pass
+        auto expert_grad = [&](const mdmm_expert_t& ex, float cm, float mv, float sv) {
+          const float ive = fast::rcp(sv * sv + MDMM_POE_EPS), sge = signf_(sv);
+          const float g_t = g_num * (mv * cm) + g_prec;
+          if (ex.g_mean) ex.g_mean[o + f] = g_num * (ive * sge * cm) * cm;
+          if (ex.g_std) ex.g_std[o + f] = -(g_t * cm * sge) * ive * ive * 2.0f * sv;
+        };
+        if (ok && g == 0) {
+#pragma unroll
+          for (int m = 0; m < NE; ++m)
+            if (act[m] >= 0) expert_grad(a.experts[act[m]], f_cm[m], f_em[m][n], f_es[m][n]);
+          if (more) {
+            for (int e = act[NE - 1] + 1; e < a.E; ++e) {
+              const mdmm_expert_t& ex = a.experts[e];
+              if (!((ex.pass_bits >> p) & 1u)) continue;
+              const size_t off = (size_t)p * ex.pass_stride + tb * D + f;
+              expert_grad(ex, ex.mask ? ex.mask[tb] : 1.0f, ex.mean[off], ex.std[off]);
+            }
+          }
+        }
+        float gm0 = 0.f, gs0 = 0.f;
+        if (a.use_inv_prior) {      // expert (mu0, -sigma0)
+          gm0 += g_num * (-t0c);
+          gs0 += 2.0f * (g_num * mu0 + g_prec) * t0c * t0c * sg0;
+        }
+        gpm += f_gqm[n]; gps += f_gqs[n];
+        if (ii == 0 && ok) { gm0 += gpm; gs0 += gps; }       // first processed step: prior = global prior
+        zacc_m[n] += gm0; zacc_s[n] += gs0;
+        if (ii > 0 && g == 0) {
+          // moment-matching coefficients: c1 = g_mean/K - c2*mean, c2 = g_std/(K*std)
+          const float c2 = gps * fast::rcp(psv) * inv_k;
+          stash[f] = gpm * inv_k - c2 * pmv;
+          stash[16 * DT + f] = c2;
+        }
+      }
+    };
+    // posterior of the step whose particles the transition adjoint re-creates (C layout)
+    f32x4 f_zm[DT], f_zs[DT];
+    auto infer_loads = [&](int ii) {
+      const int tt = a.reverse ? T - 1 - ii : ii;
+      const int tp = a.reverse ? tt + 1 : tt - 1;
+      const size_t oz = (size_t)p * tbd + ((size_t)tp * B + b) * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        f_zm[dt] = ld4_guard(a.infer_mean, oz, vec, 16 * dt + 4 * g, Dg);
+        f_zs[dt] = ld4_guard(a.infer_std, oz, vec, 16 * dt + 4 * g, Dg);
+      }
+    };
+
+    if (task_ok) { pair_loads(T - 1); if (T > 1) infer_loads(T - 1); }
+    __syncthreads();                    // exchange records of the first step
+    if (task_ok) pair_compute(T - 1);
+    __syncthreads();                    // its coefficients
+
+    for (int i = T - 1; i >= 1; --i) {
+      const int t = a.reverse ? T - 1 - i : i;
+      f32x4 a1[IT1][1], z[DT][1];
+      STAMP(0);
+      if (task_ok) {
+        // ---------- adjoint of the transition for this wave's particles of the previous step ----------
+        const int t_prev = a.reverse ? t + 1 : t - 1;
+        f32x4 ev[DT][1];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d0 = 16 * dt + 4 * g;
+          float e4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (live && d0 < Dg) {
+            const uint64_t idx = ((((uint64_t)p * T + t_prev) * K + k) * B + b) * (uint64_t)D + d0;
+            eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ev[dt][0][r] = e4[r];
+            z[dt][0][r] = (live && fvalid[dt][r]) ? fmaf(e4[r], f_zs[dt][r], f_zm[dt][r]) : 0.f;
+          }
+        }
+        STAMP(2);
+        gemm_chain<IT1, DT, 1>(lds + L::W1, lds + L::B1, lane, z, a1);
+        f32x4 h1[HT][1], h2[HT][1];
+#pragma unroll
+        for (int ft = 0; ft < HT; ++ft)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            h1[ft][0][r] = fmaxf(a1[ft][0][r], 0.f);
+            h2[ft][0][r] = fmaxf(a1[HT + ft][0][r], 0.f);
+          }
+        f32x4 gate[DT][1], nl[DT][1], pre[DT][1];
+        gemm_chain<DT, HT, 1>(lds + L::WG, lds + L::BG, lane, h1, gate);
+        gemm_chain<DT, HT, 1>(lds + L::WN, lds + L::BN, lane, h2, nl);
+        gemm_chain<DT, DT, 1>(lds + L::WS, lds + L::BS, lane, nl, pre);
+        put_image<DT>(img, LC::X1_NL, wave, lane, nl);
+        put_image<HT>(img, LC::X1_H1, wave, lane, h1);
+        put_image<HT>(img, LC::X1_H2, wave, lane, h2);
+        STAMP(3);
+        f32x4 gnl[DT][1];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gt = fast::sigmoid(gate[dt][0][r]);
+            const float lin = a1[2 * HT + dt][0][r], nlv = nl[dt][0][r], prv = pre[dt][0][r];
+            const float muq = (1.0f - gt) * lin + gt * nlv;
+            const float sq = fast::softplus(prv) + a.min_std;
+            const float tq = fast::rcp(sq * sq + MDMM_POE_EPS);
+            const float num = MU0(dt, r) * T0C(dt, r) + muq * tq, prec = T0C(dt, r) + tq;
+            const float rp = fast::rcp(prec);
+            const float m = num * rp, sd = fast::sqrt(rp);
+            const float c2 = stash[16 * DT + 16 * dt + 4 * g + r];
+            float g_m = stash[16 * dt + 4 * g + r] + c2 * m;        // moment matching, dgts.py:79-83
+            float g_sd = c2 * sd;
+            if (!(live && fvalid[dt][r])) { g_m = 0.f; g_sd = 0.f; }
+            if (m != m) g_m = 0.f;
+            const float g_num = g_m * rp;
+            const float g_prec = -g_m * num * rp * rp - 0.5f * g_sd * sd * rp;
+            const float g_t0 = g_num * MU0(dt, r) + g_prec;
+            // global prior expert: sums over the tile's rows go straight to the wave's LDS strip
+            const float zm = row16_sum(g_num * T0C(dt, r));
+            const float zs = row16_sum(-g_t0 * T0C(dt, r) * T0C(dt, r) * 2.0f * SG0(dt, r));
+            if (j == 0) { zwav[16 * dt + 4 * g + r] += zm; zwav[16 * DT + 16 * dt + 4 * g + r] += zs; }
+            const float g_muq = g_num * tq;
+            const float g_tq = g_num * muq + g_prec;
+            const float g_sq = -g_tq * tq * tq * 2.0f * sq;
+            pre[dt][0][r] = g_sq * fast::softplus_grad(prv);
+            gnl[dt][0][r] = g_muq * gt;
+            a1[2 * HT + dt][0][r] = g_muq * (1.0f - gt);
+            gate[dt][0][r] = g_muq * (nlv - lin) * gt * (1.0f - gt);
+          }
+        STAMP(4);
+        put_image<DT>(img, LC::G1_PRE, wave, lane, pre);
+        put_image<DT>(img, LC::G1_GATE, wave, lane, gate);
+        gemm_chain<DT, DT, 1, 2>(lds + LB::TS, nullptr, lane, pre, gnl);     // += W_std^T d/d std-pre
+        put_image<DT>(img, LC::G1_GNL, wave, lane, gnl);
+        {
+          f32x4 gh[HT][1];
+          gemm_chain<HT, DT, 1, 0>(lds + LB::TG, nullptr, lane, gate, gh);
+#pragma unroll
+          for (int ft = 0; ft < HT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[ft][0][r] = a1[ft][0][r] > 0.f ? gh[ft][0][r] : 0.f;
+        }
+        {
+          f32x4 gh[HT][1];
+          gemm_chain<HT, DT, 1, 0>(lds + LB::TN, nullptr, lane, gnl, gh);
+#pragma unroll
+          for (int ft = 0; ft < HT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a1[HT + ft][0][r] = a1[HT + ft][0][r] > 0.f ? gh[ft][0][r] : 0.f;
+        }
+        f32x4 gz[DT][1];
+        gemm_chain<DT, IT1, 1, 0>(lds + LB::T1, nullptr, lane, a1, gz);
+        STAMP(5);
+        // this tile's part of the three per-feature sums the pair section of the next step needs
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sa = row16_sum(gz[dt][0][r]);
+            const float sb = row16_sum(gz[dt][0][r] * ev[dt][0][r]);
+            const float se = row16_sum(ev[dt][0][r]);
+            if (j == 0) {
+              xw[16 * dt + 4 * g + r] = sa; xw[16 * DT + 16 * dt + 4 * g + r] = sb;
+              xw[32 * DT + 16 * dt + 4 * g + r] = se;
+            }
+          }
+        pair_loads(i - 1);
+      }
+      STAMP(6);
+      __syncthreads();                                  // phase-1 images + exchange records complete
+      STAMP(7);
+      coop_mfma<LC::NSL1>(img, lane, half, un1, acc1, db1);
+      STAMP(8);
+      if (task_ok) pair_compute(i - 1);
+      STAMP(1);
+      __syncthreads();                                  // images consumed, coefficients of step i-1 visible
+      STAMP(9);
+      if (task_ok) {
+        put_image<IT1>(img, LC::G2_A1, wave, lane, a1);
+        put_image<DT>(img, LC::X2_Z, wave, lane, z);
+        if (i > 1) infer_loads(i - 1);
+      }
+      STAMP(10);
+      __syncthreads();
+      STAMP(11);
+      coop_mfma<LC::NSL2>(img, lane, half, un2, acc2, db2);
+      STAMP(12);
+      __syncthreads();
+      STAMP(13);
+    }
+  }
+
+  // ---------- combine the waves of the workgroup, write one partial row ----------
+  float* acc = img;
+  for (int idx = threadIdx.x; idx < LB::WIDTH; idx += NTC) acc[idx] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < NWC; ++w) {
+    if (wave == w) {
+      auto put_unit = [&](const CoopUnit& u, const f32x4& v, float db) {
+        if (!u.valid) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[u.out_off + (4 * g + r) * u.ld + j] += v[r];
+        if (u.b_off >= 0) {
+          db += __shfl_xor(db, 16, 64);
+          db += __shfl_xor(db, 32, 64);
+          if (g == 0) acc[u.b_off + j] += db;
+        }
+      };
+#pragma unroll
+      for (int u = 0; u < LC::NSL1; ++u) put_unit(un1[u], acc1[u], db1[u]);
+#pragma unroll
+      for (int u = 0; u < LC::NSL2; ++u) put_unit(un2[u], acc2[u], db2[u]);
+      if (lane < 16 * DT) {
+        acc[LB::O_ZM + lane] += zwav[lane];
+        acc[LB::O_ZS + lane] += zwav[16 * DT + lane];
+      }
+      if (g == 0) {
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+          const int dt = c + n * CT;
+          if (dt < DT) { acc[LB::O_ZM + 16 * dt + j] += zacc_m[n]; acc[LB::O_ZS + 16 * dt + j] += zacc_s[n]; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* out = a.dw_partial + (size_t)blockIdx.x * LB::WIDTH;
+  for (int idx = threadIdx.x; idx < LB::WIDTH; idx += NTC) out[idx] = acc[idx];
+  STAMP_FLUSH();
+}
+
 constexpr int BWD_MAX_BLOCKS = 256;     // one 4-wave workgroup per CU (LDS-bound), persistent
 
 // K = 1 (SEQ): rows per wave.  The sweep is a latency chain of T dependent steps, so spread the
@@ -1043,13 +1578,54 @@ int launch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
                          : launch_bwd_<DT, HT, CT, PART, false>(a, stream);
 }
 
+// K > 1: cooperative 8-wave workgroups, CT waves per (pass, sequence)
+static inline int coop_grid(const mdmm_sweep_t* a, int ct) {
+  const int tpb = NWC / ct, blocks = (a->P * a->B + tpb - 1) / tpb;
+  return blocks > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : blocks;
+}
+
+template <int DT, int HT, int CT, bool FULL>
+int launch_bwd_coop_(const mdmm_sweep_t* a, hipStream_t stream) {
+  using LC = LdsC<DT, HT>;
+  constexpr int TPB = NWC / CT;
+  const int n_tasks = a->P * a->B, blocks = (n_tasks + TPB - 1) / TPB, grid = coop_grid(a, CT);
+  const int n_rounds = (blocks + grid - 1) / grid;
+  if (!a->dw_partial || a->dw_partial_rows < grid) return MDMM_E_ARG;
+  auto kern = sweep_mfma_bwd_coop_kernel<DT, HT, CT, FULL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LC::BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTC), LC::BYTES, stream, *a, n_tasks, n_rounds);
+  return (int)hipGetLastError();
+}
+
+template <int DT, int HT, int CT>
+int launch_bwd_coop(const mdmm_sweep_t* a, hipStream_t stream) {
+  return a->D == 16 * DT ? launch_bwd_coop_<DT, HT, CT, true>(a, stream)
+                         : launch_bwd_coop_<DT, HT, CT, false>(a, stream);
+}
+
+static bool legacy_part_bwd() {
+  static const int v = [] { const char* e = getenv("MDMM_PART_BWD"); return (e && e[0] == 'o') ? 1 : 0; }();
+  return v != 0;
+}
+
 template <int DT, int HT>
 int dispatch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->K == 1)
     return seq_ct(a) == 2 ? launch_bwd<DT, HT, 2, false>(a, stream)
                           : launch_bwd<DT, HT, 1, false>(a, stream);
-  if (a->K <= 16) return launch_bwd<DT, HT, 1, true>(a, stream);
-  if (a->K <= 32) return launch_bwd<DT, HT, 2, true>(a, stream);
+  if (legacy_part_bwd()) {
+    if (a->K <= 16) return launch_bwd<DT, HT, 1, true>(a, stream);
+    if (a->K <= 32) return launch_bwd<DT, HT, 2, true>(a, stream);
+    return MDMM_UNSUPPORTED;
+  }
+  if (a->K <= 16) return launch_bwd_coop<DT, HT, 1>(a, stream);
+  if (a->K <= 32) return launch_bwd_coop<DT, HT, 2>(a, stream);
   return MDMM_UNSUPPORTED;
 }
 
@@ -1095,6 +1671,7 @@ template <int DT, int HT>
 int64_t dw_rows_for(const mdmm_sweep_t* a) {
   int n_tasks;
   if (a->K == 1) n_tasks = (a->P * a->B + 16 * seq_ct(a) - 1) / (16 * seq_ct(a));
+  else if (!legacy_part_bwd()) return coop_grid(a, a->K <= 16 ? 1 : 2);
   else n_tasks = a->P * a->B;
   int64_t grid = (n_tasks + 3) / 4;
   return grid > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : grid;
@@ -1129,3 +1706,9 @@ int mdmm_mfma_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (dt == 2 && ht == 1) return dispatch_fwd<2, 1>(a, stream);
   return dispatch_fwd<2, 2>(a, stream);
 }
+
+#ifdef MDMM_STAMPS
+extern "C" int mdmm_debug_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mdmm_stamp_buf), sizeof(unsigned long long) * 32);
+}
+#endif
