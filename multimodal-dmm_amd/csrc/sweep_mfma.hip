@@ -174,6 +174,42 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// Row sums of N values at once (N = 4, 8, 16): instead of N butterflies of 4 DPP steps, every step
+// halves the number of live values -- lane pairs exchange the half the partner keeps -- so lane j
+// ends with the 16-lane total of v[multi_idx(j)] (N + N/2 + .. DPP adds instead of 4N).  The select
+// bits are chosen so that the partners of every DPP pattern (xor 1, xor 2, half-row mirror, row
+// mirror) agree on which value they are summing.
+__device__ __forceinline__ int multi_idx(int j, int n) {
+  const int b3 = (j >> 3) & 1, b2 = ((j >> 2) & 1) ^ b3, b1 = ((j >> 1) & 1) ^ ((j >> 2) & 1), b0 = (j & 1) ^ ((j >> 2) & 1);
+  return (b0 + 2 * b1 + 4 * b2 + 8 * b3) & (n - 1);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_comb(bool b, float x0, float x1) {
+  const float keep = b ? x1 : x0, send = b ? x0 : x1;
+  return keep + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), CTRL, 0xF, 0xF, true));
+}
+template <int N>
+__device__ __forceinline__ float multi_row16_sum(const float (&v)[N], int j) {
+  static_assert(N == 4 || N == 8 || N == 16, "N");
+  const bool b3 = (j >> 3) & 1, b2 = (((j >> 2) ^ (j >> 3)) & 1), b1 = (((j >> 1) ^ (j >> 2)) & 1),
+             b0 = ((j ^ (j >> 2)) & 1);
+  float w1[N / 2];
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) w1[i] = dpp_comb<0xB1>(b0, v[2 * i], v[2 * i + 1]);
+  float w2[N / 4];
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) w2[i] = dpp_comb<0x4E>(b1, w1[2 * i], w1[2 * i + 1]);
+  if constexpr (N == 4) {
+    return dpp_add<0x140>(dpp_add<0x141>(w2[0]));
+  } else {
+    float w3[N / 8];
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i) w3[i] = dpp_comb<0x141>(b2, w2[2 * i], w2[2 * i + 1]);
+    if constexpr (N == 8) return dpp_add<0x140>(w3[0]);
+    else return dpp_comb<0x140>(b3, w3[0], w3[1]);
+  }
+}
+
 // GTF forward on z (C layout) -> per (row, feature): transition mean / std after the product
 // with the global prior (dmm.py:239-252).  Keeps nothing but the outputs.
 template <int DT, int HT, int CT>
@@ -1034,7 +1070,7 @@ struct LdsC {
   static constexpr int IMG_FLOATS = IMG_TILES * 16 * RSC;
   static constexpr int N1 = DT * DT + 2 * DT * HT, N2 = IT1 * DT;      // output tiles per phase
   static constexpr int NSL1 = (2 * N1 + NWC - 1) / NWC, NSL2 = (2 * N2 + NWC - 1) / NWC;
-  static constexpr int EXTRA = 48 * DT + 2 * NWC * 32 * DT + NWC * 3 * 16 * DT;       // floats
+  static constexpr int EXTRA = 48 * DT + NWC * 32 * DT + NWC * 3 * 16 * DT;           // floats
   static constexpr size_t BYTES = (size_t)LB::WEND * 16 + (size_t)(IMG_FLOATS + EXTRA) * 4;
 };
 
@@ -1144,8 +1180,7 @@ __global__ __launch_bounds__(NTC) void sweep_mfma_bwd_coop_kernel(const mdmm_swe
   float* img = reinterpret_cast<float*>(lds + LB::WEND);
   float* cst = img + LC::IMG_FLOATS;                          // mu0 | sigma0 | 1/(sigma0^2+eps)
   float* stash = cst + 48 * DT + slot * 32 * DT;              // moment-matching coefficients of the pair
-  float* zwav = cst + 48 * DT + NWC * 32 * DT + wave * 32 * DT;   // d/d(mu0, sigma0) row sums of this wave
-  float* xchg = cst + 48 * DT + 2 * NWC * 32 * DT;            // [wave][A | B | E][16 DT]
+  float* xchg = cst + 48 * DT + NWC * 32 * DT;                // [wave][A | B | E][16 DT]
   const int T = a.T, B = a.B, D = a.D, K = a.K;
   const bool vec = FULL || (D & 3) == 0;
   const int Dg = FULL ? (1 << 30) : D;
@@ -1160,11 +1195,7 @@ __global__ __launch_bounds__(NTC) void sweep_mfma_bwd_coop_kernel(const mdmm_swe
     const float s0 = ok ? expf(a.z0_log_std[d]) + a.min_std : 1.f;
     cst[d] = m0; cst[16 * DT + d] = s0; cst[32 * DT + d] = fast::rcp(s0 * s0 + MDMM_POE_EPS);
   }
-  for (int d = threadIdx.x; d < NWC * 32 * DT; d += NTC) cst[48 * DT + NWC * 32 * DT + d] = 0.f;
   __syncthreads();
-  auto MU0 = [&](int dt, int r) { return cst[16 * dt + 4 * g + r]; };
-  auto SG0 = [&](int dt, int r) { return cst[16 * DT + 16 * dt + 4 * g + r]; };
-  auto T0C = [&](int dt, int r) { return cst[32 * DT + 16 * dt + 4 * g + r]; };
   bool fvalid[DT][4];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
@@ -1188,6 +1219,7 @@ __global__ __launch_bounds__(NTC) void sweep_mfma_bwd_coop_kernel(const mdmm_swe
   // split its 16 DT latent features, ONE feature per lane j (replicated over g) -- scalar loads, a
   // dozen registers of prefetch, no redundant arithmetic.  feature(n) = 16 * (c + n CT) + j.
   float zacc_m[NF], zacc_s[NF];       // d/d mu0, d/d sigma0 of the per-pair terms (inverse prior, first step)
+  float zsum = 0.f;                   // ... of the per-row terms: lane j holds value multi_idx(j, 8 DT)
 #pragma unroll
   for (int n = 0; n < NF; ++n) { zacc_m[n] = 0.f; zacc_s[n] = 0.f; }
 
@@ -1404,8 +1436,14 @@ __global__ __launch_bounds__(NTC) void sweep_mfma_bwd_coop_kernel(const mdmm_swe
         put_image<HT>(img, LC::X1_H2, wave, lane, h2);
         STAMP(3);
         f32x4 gnl[DT][1];
+        float zv[8 * DT];             // per row: d/d mu0 (4 DT values), d/d sigma0 (4 DT values)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt) {
+          const f32x4 mu0 = ld_frag(reinterpret_cast<const float4*>(cst + 16 * dt + 4 * g));
+          const f32x4 sg0 = ld_frag(reinterpret_cast<const float4*>(cst + 16 * DT + 16 * dt + 4 * g));
+          const f32x4 t0c = ld_frag(reinterpret_cast<const float4*>(cst + 32 * DT + 16 * dt + 4 * g));
+          const f32x4 c1v = ld_frag(reinterpret_cast<const float4*>(stash + 16 * dt + 4 * g));
+          const f32x4 c2v = ld_frag(reinterpret_cast<const float4*>(stash + 16 * DT + 16 * dt + 4 * g));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float gt = fast::sigmoid(gate[dt][0][r]);
@@ -1413,21 +1451,18 @@ __global__ __launch_bounds__(NTC) void sweep_mfma_bwd_coop_kernel(const mdmm_swe
             const float muq = (1.0f - gt) * lin + gt * nlv;
             const float sq = fast::softplus(prv) + a.min_std;
             const float tq = fast::rcp(sq * sq + MDMM_POE_EPS);
-            const float num = MU0(dt, r) * T0C(dt, r) + muq * tq, prec = T0C(dt, r) + tq;
+            const float num = mu0[r] * t0c[r] + muq * tq, prec = t0c[r] + tq;
             const float rp = fast::rcp(prec);
             const float m = num * rp, sd = fast::sqrt(rp);
-            const float c2 = stash[16 * DT + 16 * dt + 4 * g + r];
-            float g_m = stash[16 * dt + 4 * g + r] + c2 * m;        // moment matching, dgts.py:79-83
-            float g_sd = c2 * sd;
+            float g_m = c1v[r] + c2v[r] * m;                          // moment matching, dgts.py:79-83
+            float g_sd = c2v[r] * sd;
             if (!(live && fvalid[dt][r])) { g_m = 0.f; g_sd = 0.f; }
             if (m != m) g_m = 0.f;
             const float g_num = g_m * rp;
             const float g_prec = -g_m * num * rp * rp - 0.5f * g_sd * sd * rp;
-            const float g_t0 = g_num * MU0(dt, r) + g_prec;
-            // global prior expert: sums over the tile's rows go straight to the wave's LDS strip
-            const float zm = row16_sum(g_num * T0C(dt, r));
-            const float zs = row16_sum(-g_t0 * T0C(dt, r) * T0C(dt, r) * 2.0f * SG0(dt, r));
-            if (j == 0) { zwav[16 * dt + 4 * g + r] += zm; zwav[16 * DT + 16 * dt + 4 * g + r] += zs; }
+            const float g_t0 = g_num * mu0[r] + g_prec;
+            zv[4 * dt + r] = g_num * t0c[r];                          // global prior expert
+            zv[4 * DT + 4 * dt + r] = -g_t0 * t0c[r] * t0c[r] * 2.0f * sg0[r];
             const float g_muq = g_num * tq;
             const float g_tq = g_num * muq + g_prec;
             const float g_sq = -g_tq * tq * tq * 2.0f * sq;
@@ -1436,6 +1471,8 @@ __global__ __launch_bounds__(NTC) void sweep_mfma_bwd_coop_kernel(const mdmm_swe
             a1[2 * HT + dt][0][r] = g_muq * (1.0f - gt);
             gate[dt][0][r] = g_muq * (nlv - lin) * gt * (1.0f - gt);
           }
+        }
+        zsum += multi_row16_sum<8 * DT>(zv, j);
         STAMP(4);
         put_image<DT>(img, LC::G1_PRE, wave, lane, pre);
         put_image<DT>(img, LC::G1_GATE, wave, lane, gate);
@@ -1461,18 +1498,23 @@ __global__ __launch_bounds__(NTC) void sweep_mfma_bwd_coop_kernel(const mdmm_swe
         gemm_chain<DT, IT1, 1, 0>(lds + LB::T1, nullptr, lane, a1, gz);
         STAMP(5);
         // this tile's part of the three per-feature sums the pair section of the next step needs
+        {
+          float sv[8 * DT], se[4 * DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+          for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float sa = row16_sum(gz[dt][0][r]);
-            const float sb = row16_sum(gz[dt][0][r] * ev[dt][0][r]);
-            const float se = row16_sum(ev[dt][0][r]);
-            if (j == 0) {
-              xw[16 * dt + 4 * g + r] = sa; xw[16 * DT + 16 * dt + 4 * g + r] = sb;
-              xw[32 * DT + 16 * dt + 4 * g + r] = se;
+            for (int r = 0; r < 4; ++r) {
+              sv[4 * dt + r] = gz[dt][0][r];
+              sv[4 * DT + 4 * dt + r] = gz[dt][0][r] * ev[dt][0][r];
+              se[4 * dt + r] = ev[dt][0][r];
             }
-          }
+          const float s_ab = multi_row16_sum<8 * DT>(sv, j);
+          const float s_e = multi_row16_sum<4 * DT>(se, j);
+          const int n_ab = multi_idx(j, 8 * DT), n_e = multi_idx(j, 4 * DT);
+          // value n = 4 dt + r (+ 4 DT for the eps-weighted sum) -> feature 16 dt + 4 g + r
+          xw[(n_ab / (4 * DT)) * 16 * DT + 16 * ((n_ab % (4 * DT)) >> 2) + 4 * g + (n_ab & 3)] = s_ab;
+          if (j < 4 * DT) xw[32 * DT + 16 * (n_e >> 2) + 4 * g + (n_e & 3)] = s_e;
+        }
         pair_loads(i - 1);
       }
       STAMP(6);
@@ -1519,9 +1561,9 @@ __global__ __launch_bounds__(NTC) void sweep_mfma_bwd_coop_kernel(const mdmm_swe
       for (int u = 0; u < LC::NSL1; ++u) put_unit(un1[u], acc1[u], db1[u]);
 #pragma unroll
       for (int u = 0; u < LC::NSL2; ++u) put_unit(un2[u], acc2[u], db2[u]);
-      if (lane < 16 * DT) {
-        acc[LB::O_ZM + lane] += zwav[lane];
-        acc[LB::O_ZS + lane] += zwav[16 * DT + lane];
+      if (j < 8 * DT) {       // lanes j >= 8 DT hold duplicates (DT == 1)
+        const int n = multi_idx(j, 8 * DT), q = n % (4 * DT);
+        acc[(n >= 4 * DT ? LB::O_ZS : LB::O_ZM) + 16 * (q >> 2) + 4 * g + (q & 3)] += zsum;
       }
       if (g == 0) {
 #pragma unroll
