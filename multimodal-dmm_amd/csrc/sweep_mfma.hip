@@ -1651,21 +1651,12 @@ int launch_bwd_coop(const mdmm_sweep_t* a, hipStream_t stream) {
                          : launch_bwd_coop_<DT, HT, CT, false>(a, stream);
 }
 
-static bool legacy_part_bwd() {
-  static const int v = [] { const char* e = getenv("MDMM_PART_BWD"); return (e && e[0] == 'o') ? 1 : 0; }();
-  return v != 0;
-}
 
 template <int DT, int HT>
 int dispatch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->K == 1)
     return seq_ct(a) == 2 ? launch_bwd<DT, HT, 2, false>(a, stream)
                           : launch_bwd<DT, HT, 1, false>(a, stream);
-  if (legacy_part_bwd()) {
-    if (a->K <= 16) return launch_bwd<DT, HT, 1, true>(a, stream);
-    if (a->K <= 32) return launch_bwd<DT, HT, 2, true>(a, stream);
-    return MDMM_UNSUPPORTED;
-  }
   if (a->K <= 16) return launch_bwd_coop<DT, HT, 1>(a, stream);
   if (a->K <= 32) return launch_bwd_coop<DT, HT, 2>(a, stream);
   return MDMM_UNSUPPORTED;
@@ -1713,8 +1704,7 @@ template <int DT, int HT>
 int64_t dw_rows_for(const mdmm_sweep_t* a) {
   int n_tasks;
   if (a->K == 1) n_tasks = (a->P * a->B + 16 * seq_ct(a) - 1) / (16 * seq_ct(a));
-  else if (!legacy_part_bwd()) return coop_grid(a, a->K <= 16 ? 1 : 2);
-  else n_tasks = a->P * a->B;
+  else return coop_grid(a, a->K <= 16 ? 1 : 2);
   int64_t grid = (n_tasks + 3) / 4;
   return grid > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : grid;
 }

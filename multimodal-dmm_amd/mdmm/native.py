@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libmdmm_hip.so')
+LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip.so')   # MDMM_LIB: A/B builds
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
