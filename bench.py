@@ -155,8 +155,7 @@ def main():
                   file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             args.eager = True
-            bucket.check_views()
-            bucket.zero()
+            bucket.release()
 
             def step():
                 return elbo_step(model, optimizer, bucket, inputs, mask, lengths, 1.0, rec,

@@ -24,9 +24,14 @@ def kld_multiplier(b_num, epoch, n_batches, kld_mult_max, kld_anneal):
 
 
 class GradBucket:
-    """All parameter gradients as views of ONE flat fp32 buffer: autograd accumulates in
-    place, `allreduce` is a single collective over the whole model (messages 77 KB for the
-    z=32 Spirals model, 30 MB for the Weizmann model -- SURVEY.md section 2)."""
+    """All parameter gradients as views of ONE flat fp32 buffer, so that `allreduce` is a single
+    collective over the whole model (messages 77 KB for the z=32 Spirals model, 30 MB for the
+    Weizmann model -- SURVEY.md section 2).
+
+    Two ways to fill it: autograd accumulates into the views in place (one add_ per parameter,
+    plus `zero()` per step), or -- what `elbo_step` does -- the gradients are released before the
+    backward (`release()`), autograd hands over its own buffers, and `check_views()` gathers
+    them with one `cat` and re-attaches the views (no zero fill, no per-parameter add)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -43,13 +48,33 @@ class GradBucket:
     def zero(self):
         self.flat.zero_()
 
+    def release(self):
+        """Drop the gradients: the next backward starts from None instead of accumulating."""
+        for p in self.params:
+            p.grad = None
+
+    def _views(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            yield p, self.flat[off:off + n].view_as(p)
+            off += n
+
     def check_views(self):
-        """Re-attach any gradient that was replaced (e.g. zero_grad(set_to_none=True))."""
+        """Re-attach any gradient that was replaced (release(), zero_grad(set_to_none=True))."""
+        views = list(self._views())
+        if all(p.grad is not None and p.grad.data_ptr() != v.data_ptr() and p.grad.is_contiguous()
+               for p, v in views):
+            torch.cat([p.grad.reshape(-1) for p, _ in views], out=self.flat)    # one launch
+            for p, v in views:
+                p.grad = v
+            return
         off = 0
         for p in self.params:
             n = p.numel()
             view = self.flat[off:off + n].view_as(p)
-            if p.grad is None:
+            if p.grad is None:          # no gradient this step: the view may hold the last step's
+                view.zero_()
                 p.grad = view
             elif p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad)
@@ -87,7 +112,7 @@ def elbo_step(model, optimizer, bucket, inputs, mask, lengths, kld_mult, rec_mul
     if clip_grad is not None and clip_grad > 0:
         torch.nn.utils.clip_grad_norm_(bucket.params, clip_grad)
     optimizer.step()
-    bucket.zero()
+    bucket.release()
     return loss.detach()
 
 
@@ -115,26 +140,26 @@ class GraphedElboStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                      # eager warm-up on the capture stream
+                bucket.release()
                 fwd_bwd()
                 bucket.check_views()
                 bucket.allreduce(group)
                 optimizer.step()
-                bucket.zero()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops.clear_caches(model.parameters())
         self.g_step, self.g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: other threads (the RCCL watchdog of torch.distributed polls events) must
         # not invalidate the capture
+        bucket.release()        # the captured backward writes autograd's own gradient buffers ...
         with torch.cuda.graph(self.g_step, capture_error_mode='thread_local'):
             self.loss = fwd_bwd()
+            bucket.check_views()                         # ... gathered into the flat buffer by one cat
             if hasattr(noise, 'advance'):
                 noise.advance()
-        bucket.check_views()
         with torch.cuda.graph(self.g_opt, pool=self.g_step.pool(),
                               capture_error_mode='thread_local'):
             optimizer.step()
-            bucket.zero()
 
     def __call__(self):
         self.g_step.replay()

@@ -350,6 +350,28 @@ def _staged_bwd(cfg, sweep, gtf):
     return [g.contiguous() for g in grads], g_z0m, g_z0s
 
 
+def _fold_passes(g, bits, per_pass, n_pass):
+    """(P,T,B,D) per-pass gradient slabs of one expert -> gradient of its input: the slabs of the
+    passes it took part in are summed (shared (T,B,D) input) or kept (per-pass input, the slabs of
+    the other passes are zero).  Slabs of inactive passes were never written."""
+    if g is None:
+        return None
+    act = [p for p in range(n_pass) if (bits >> p) & 1]
+    if per_pass:
+        for p in range(n_pass):
+            if p not in act:
+                g[p].zero_()
+        return g
+    if not act:
+        return torch.zeros_like(g[0])
+    if len(act) == 1:
+        return g[act[0]]
+    out = torch.add(g[act[0]], g[act[1]])
+    for p in act[2:]:
+        out.add_(g[p])
+    return out
+
+
 class _SweepFn(torch.autograd.Function):
     """MultiDMM.z_filter (dmm.py:319-412) for P passes at once -> mdmm_bfvi_sweep_fwd/_bwd."""
 
@@ -417,8 +439,9 @@ class _SweepFn(torch.autograd.Function):
             ex.pass_bits = ctx.bits[e]
             need = ctx.needs_input_grad[7 + 12 + e] or ctx.needs_input_grad[7 + 12 + n_exp + e]
             if need:    # one slab per pass, written only for the passes the expert is part of
-                gm = torch.zeros(shape_p, device=dev, dtype=torch.float32)
-                gs = torch.zeros(shape_p, device=dev, dtype=torch.float32)
+                # the kernels write the whole (T,B,D) slab of every pass the expert is part of
+                gm = torch.empty(shape_p, device=dev, dtype=torch.float32)
+                gs = torch.empty(shape_p, device=dev, dtype=torch.float32)
                 ex.g_mean, ex.g_std = _ptr(gm), _ptr(gs)
             else:
                 gm = gs = None
@@ -453,8 +476,8 @@ class _SweepFn(torch.autograd.Function):
                 g_gtf = packed.unpack_grads(G, X, ctx.gtf_like)
         g_z0_mean = gz0[0].reshape(ctx.z0_shapes[0])
         g_z0_log = (gz0[1] * torch.exp(z0s)).reshape(ctx.z0_shapes[1])
-        g_means = [g if (g is None or pp) else g.sum(0) for g, pp in zip(g_means, ctx.per_pass)]
-        g_stds = [g if (g is None or pp) else g.sum(0) for g, pp in zip(g_stds, ctx.per_pass)]
+        g_means = [_fold_passes(g, b, pp, cfg.P) for g, b, pp in zip(g_means, ctx.bits, ctx.per_pass)]
+        g_stds = [_fold_passes(g, b, pp, cfg.P) for g, b, pp in zip(g_stds, ctx.bits, ctx.per_pass)]
         g_flat = ([g.reshape(sh) if g is not None else None
                    for g, sh in zip(g_means, ctx.in_shapes[:n_exp])] +
                   [g.reshape(sh) if g is not None else None
