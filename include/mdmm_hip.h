@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 5
+#define MDMM_ABI_VERSION 6
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -36,7 +36,7 @@ extern "C" {
 int mdmm_version(void);
 const char* mdmm_strerror(int code);
 /* sizeof() of an argument struct as the library was compiled, for a binding to check its own
- * declaration against at load time: 0 gtf, 1 expert, 2 sweep, 3 stage, 4 gru, 5 dks; 0 if unknown */
+ * declaration against at load time: 0 gtf, 1 expert, 2 sweep, 3 stage, 4 gru, 5 dks, 6 mlp; 0 if unknown */
 size_t mdmm_sizeof(int which);
 /* round n up to the padded width the packed weights use (multiple of 4) */
 int mdmm_pad(int n);
@@ -336,6 +336,35 @@ int mdmm_dks_combiner_bwd(const mdmm_dks_t* args, void* stream);
  * materialise exactly what a sweep used (replaces dgts.py:179 `normal_()`).  */
 int mdmm_philox_normal(uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t n,
                        float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused GaussianMLP holder (common.py:25-41):  x (N,I) -> h = relu(W1 x + b1) ->
+ * mean = Wm h + bm,  std = softplus(Ws h + bs) + min_std.  One launch forward, one backward, for
+ * the small encoder / decoder MLPs (every dim <= 32; mdmm_gauss_mlp_supported).  nan_to_zero: NaN
+ * inputs read as 0 and seen[n] = 0 for rows holding a NaN (the masking of MultiDMM.encode,
+ * dmm.py:164-177).  The backward recomputes h from x, writes g_x if non-NULL, and one row of
+ * weight-gradient partial sums per workgroup, every dim padded to a multiple of 16 (h16 = 16 *
+ * ceil(H/16) ...):  dW1 (h16,i16) | db1 (h16) | dWm (o16,h16) | dbm (o16) | dWs (o16,h16) | dbs (o16);
+ * the caller sums the rows and slices.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int64_t N;
+  int32_t I, H, O;
+  int32_t nan_to_zero;
+  float min_std;
+  int32_t reserved;
+  const float *x, *w1, *b1, *wm, *bm, *ws, *bs;
+  float *mean, *std, *seen;            /* forward outputs: (N,O), (N,O), (N) or NULL             */
+  const float *g_mean, *g_std;         /* backward inputs (N,O); NULL = zero                     */
+  float* g_x;                          /* (N,I) or NULL                                          */
+  float* dw_partial;                   /* (dw_partial_rows, mdmm_gauss_mlp_dw_width(I,H,O))      */
+  int64_t dw_partial_rows;             /* >= mdmm_gauss_mlp_dw_rows(N)                           */
+} mdmm_mlp_t;
+int mdmm_gauss_mlp_supported(int I, int H, int O);
+int mdmm_gauss_mlp_dw_width(int I, int H, int O);
+int64_t mdmm_gauss_mlp_dw_rows(int64_t N);
+int mdmm_gauss_mlp_fwd(const mdmm_mlp_t* a, void* stream);
+int mdmm_gauss_mlp_bwd(const mdmm_mlp_t* a, void* stream);
 
 #ifdef __cplusplus
 }

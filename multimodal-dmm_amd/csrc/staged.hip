@@ -298,6 +298,7 @@ extern "C" size_t mdmm_sizeof(int which) {
     case 3: return sizeof(mdmm_stage_t);
     case 4: return sizeof(mdmm_gru_t);
     case 5: return sizeof(mdmm_dks_t);
+    case 6: return sizeof(mdmm_mlp_t);
     default: return 0;
   }
 }

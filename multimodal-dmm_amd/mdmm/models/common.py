@@ -49,6 +49,10 @@ class GaussianMLP(nn.Module):
         self.h_to_std = nn.Sequential(nn.Linear(h_dim, out_dim), nn.Softplus())
 
     def forward(self, x):
+        if x.is_cuda and x.dim() == 2:
+            from .. import ops
+            if ops.gauss_mlp_supported(x, self):         # one launch each way (csrc/mlp.hip)
+                return ops.gauss_mlp(x, self)[:2]
         hid = F.relu(_lin(x, self.in_to_h[0]))
         return _lin(hid, self.h_to_mean), F.softplus(_lin(hid, self.h_to_std[0])) + self.min_std
 

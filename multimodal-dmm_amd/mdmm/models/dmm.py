@@ -95,6 +95,13 @@ class MultiDMM(MultiDGTS):
     def _encode_one(self, m, x):
         """One modality -> ((T,B,D) mean, (T,B,D) std, (T,B) bool seen).  dmm.py:164-177"""
         t_max, b_dim = x.shape[:2]
+        enc = self.enc[m]
+        if (isinstance(enc, common.GaussianMLP) and self.plugin_dtype is None and x.dim() == 3
+                and ops.gauss_mlp_supported(x.flatten(0, 1), enc)):
+            # NaN -> 0, the "seen" flag and the MLP in one launch (csrc/mlp.hip); seen stays fp32
+            mean, std, seen = ops.gauss_mlp(x.flatten(0, 1), enc, nan_to_zero=True)
+            return (mean.reshape(t_max, b_dim, -1), std.reshape(t_max, b_dim, -1),
+                    seen.reshape(t_max, b_dim))
         nan = torch.isnan(x)
         seen = ~nan.flatten(2, -1).any(dim=-1)
         x = torch.where(nan, torch.zeros_like(x), x)
@@ -110,7 +117,8 @@ class MultiDMM(MultiDGTS):
             if m not in inputs:
                 continue
             mu, sd, seen = self._encode_one(m, inputs[m])
-            means.append(mu); stds.append(sd); masks.append(seen)
+            means.append(mu); stds.append(sd)
+            masks.append(seen if seen.dtype == torch.bool else seen > 0)
         z_mean, z_std, masks = torch.stack(means), torch.stack(stds), torch.stack(masks)
         if combine:
             z_mean, z_std = self.product_of_experts(z_mean, z_std, masks)
@@ -357,6 +365,11 @@ class MultiDMM(MultiDGTS):
         # The prior-matching term (dmm.py:540-545) is ~40 tiny launches forward and ~60 backward
         # that depend on nothing else in the step: a stream of its own, so that neither lands on
         # the chain of the long sweeps (measured: 13.5 -> 12.9 ms per cfg2 step).
+        # Every stream reads the packed transition weights: pack both directions once, HERE, on
+        # the main stream before any stream forks off (a pack built on a forked stream would be
+        # cached and then read by the others without a dependency -- a race under graph replay).
+        for direction in ('fwd', 'bwd'):
+            ops.packed_gtf(self._gtf(direction), self.z_dim, self.h_dim)
         if match_mult > 0:
             if self._match_stream is None:
                 self._match_stream = torch.cuda.Stream(device=self.z0_mean.device)
@@ -377,10 +390,7 @@ class MultiDMM(MultiDGTS):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.z0_mean.device)
         side = self._side_stream
-        # shared inputs of both streams: pack the transition weights once, on the main stream,
-        # and tell the allocator the encoder outputs are also read on the side stream
-        for direction in ('fwd', 'bwd'):
-            ops.packed_gtf(self._gtf(direction), self.z_dim, self.h_dim)
+        # tell the allocator the encoder outputs are also read on the side stream
         for mu, sd, seen in enc.values():
             for x in (mu, sd, seen):
                 x.record_stream(side)

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 SYMBOLS = [
     'mdmm_version', 'mdmm_strerror', 'mdmm_pad', 'mdmm_sizeof',
@@ -28,6 +28,8 @@ SYMBOLS = [
     'mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd', 'mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd',
     'mdmm_stage_sample', 'mdmm_stage_step_fwd', 'mdmm_stage_fuse_bwd', 'mdmm_stage_trans_bwd',
     'mdmm_stage_adj_reduce',
+    'mdmm_gauss_mlp_supported', 'mdmm_gauss_mlp_dw_width', 'mdmm_gauss_mlp_dw_rows',
+    'mdmm_gauss_mlp_fwd', 'mdmm_gauss_mlp_bwd',
 ]
 
 _P = C.c_void_p
@@ -84,6 +86,14 @@ class Dks(C.Structure):
                                    'spill_x', 'spill_gc', 'spill_xc')])
 
 
+class Mlp(C.Structure):
+    _fields_ = ([('N', C.c_int64), ('I', C.c_int32), ('H', C.c_int32), ('O', C.c_int32),
+                 ('nan_to_zero', C.c_int32), ('min_std', C.c_float), ('reserved', C.c_int32)] +
+                [(n, _P) for n in ('x', 'w1', 'b1', 'wm', 'bm', 'ws', 'bs', 'mean', 'std', 'seen',
+                                   'g_mean', 'g_std', 'g_x', 'dw_partial')] +
+                [('dw_partial_rows', C.c_int64)])
+
+
 class MdmmError(RuntimeError):
     pass
 
@@ -138,9 +148,15 @@ def lib():
         if L.mdmm_version() != ABI_VERSION:
             raise MdmmError('libmdmm_hip.so ABI %d != binding ABI %d'
                             % (L.mdmm_version(), ABI_VERSION))
+        L.mdmm_gauss_mlp_supported.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.mdmm_gauss_mlp_dw_width.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.mdmm_gauss_mlp_dw_rows.argtypes = [C.c_int64]
+        L.mdmm_gauss_mlp_dw_rows.restype = C.c_int64
+        L.mdmm_gauss_mlp_fwd.argtypes = [C.POINTER(Mlp), _P]
+        L.mdmm_gauss_mlp_bwd.argtypes = [C.POINTER(Mlp), _P]
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
-        for which, st in enumerate((Gtf, Expert, Sweep, Stage, Gru, Dks)):
+        for which, st in enumerate((Gtf, Expert, Sweep, Stage, Gru, Dks, Mlp)):
             if L.mdmm_sizeof(which) != C.sizeof(st):
                 raise MdmmError('struct %s: library %d bytes, binding %d bytes'
                                 % (st.__name__, L.mdmm_sizeof(which), C.sizeof(st)))

@@ -829,6 +829,81 @@ def tall_linear(x, layer):
 # ------------------------------------------------------------------------------------
 # MultiDKS recurrences
 # ------------------------------------------------------------------------------------
+class _GaussMlpFn(torch.autograd.Function):
+    """GaussianMLP holder in one launch each way (csrc/mlp.hip).  Only x is saved; the backward
+    recomputes the hidden layer.  Returns (mean, std, seen); seen (N,) is 1.0 where the row holds
+    no NaN (all ones unless nan_to_zero)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, wm, bm, ws, bs, min_std, nan_to_zero):
+        _need_gpu(x, w1)
+        x = _f32c(x.detach())
+        wts = [_f32c(t.detach()) for t in (w1, b1, wm, bm, ws, bs)]
+        n, i_dim = x.shape
+        h_dim, o_dim = wts[0].shape[0], wts[2].shape[0]
+        mean = torch.empty(n, o_dim, device=x.device, dtype=torch.float32)
+        std = torch.empty_like(mean)
+        seen = torch.empty(n, device=x.device, dtype=torch.float32) if nan_to_zero else None
+        a = native.Mlp()
+        a.N, a.I, a.H, a.O = n, i_dim, h_dim, o_dim
+        a.nan_to_zero, a.min_std = int(bool(nan_to_zero)), float(min_std)
+        a.x = _ptr(x)
+        a.w1, a.b1, a.wm, a.bm, a.ws, a.bs = [_ptr(t) for t in wts]
+        a.mean, a.std, a.seen = _ptr(mean), _ptr(std), _ptr(seen)
+        _call('mdmm_gauss_mlp_fwd', C.byref(a), tag='gauss_mlp_fwd')
+        ctx.save_for_backward(x, *wts)
+        ctx.cfg = (float(min_std), bool(nan_to_zero))
+        if seen is None:
+            seen = torch.ones((), device=x.device).expand(n)
+        ctx.mark_non_differentiable(seen)
+        return mean, std, seen
+
+    @staticmethod
+    def backward(ctx, g_mean, g_std, _g_seen):
+        x, *wts = ctx.saved_tensors
+        n, i_dim = x.shape
+        h_dim, o_dim = wts[0].shape[0], wts[2].shape[0]
+        L = native.lib()
+        rows = L.mdmm_gauss_mlp_dw_rows(n)
+        width = L.mdmm_gauss_mlp_dw_width(i_dim, h_dim, o_dim)
+        part = torch.empty(rows, width, device=x.device, dtype=torch.float32)
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        a = native.Mlp()
+        a.N, a.I, a.H, a.O = n, i_dim, h_dim, o_dim
+        a.min_std, a.nan_to_zero = ctx.cfg[0], int(ctx.cfg[1])
+        a.x = _ptr(x)
+        a.w1, a.b1, a.wm, a.bm, a.ws, a.bs = [_ptr(t) for t in wts]
+        g_mean, g_std = _f32c(g_mean), _f32c(g_std)      # (kept referenced until after the launch)
+        a.g_mean, a.g_std = _ptr(g_mean), _ptr(g_std)
+        a.g_x, a.dw_partial, a.dw_partial_rows = _ptr(g_x), _ptr(part), rows
+        _call('mdmm_gauss_mlp_bwd', C.byref(a), tag='gauss_mlp_bwd')
+        row = part.sum(0)           # every dim padded to a multiple of 16 (csrc/mlp.hip, LdsM)
+        i16, h16, o16 = (16 * ((d + 15) // 16) for d in (i_dim, h_dim, o_dim))
+        w1, b1, wm, bm, ws, bs = row.split([h16 * i16, h16, o16 * h16, o16, o16 * h16, o16])
+        grads = [w1.view(h16, i16)[:h_dim, :i_dim], b1[:h_dim],
+                 wm.view(o16, h16)[:o_dim, :h_dim], bm[:o_dim],
+                 ws.view(o16, h16)[:o_dim, :h_dim], bs[:o_dim]]
+        return (g_x, *[g.contiguous() for g in grads], None, None)
+
+
+def gauss_mlp_supported(x, module):
+    """True when the fused GaussianMLP kernels apply: fp32 rows on the GPU, every dim <= 32."""
+    if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
+        return False
+    w1 = module.in_to_h[0].weight
+    if w1.dtype != torch.float32 or not w1.is_cuda:
+        return False
+    return bool(native.lib().mdmm_gauss_mlp_supported(w1.shape[1], w1.shape[0],
+                                                      module.h_to_mean.weight.shape[0]))
+
+
+def gauss_mlp(x, module, nan_to_zero=False):
+    """(mean, std, seen) of a models.common.GaussianMLP through the fused kernels."""
+    l1, lm, ls = module.in_to_h[0], module.h_to_mean, module.h_to_std[0]
+    return _GaussMlpFn.apply(x, l1.weight, l1.bias, lm.weight, lm.bias, ls.weight, ls.bias,
+                             float(module.min_std), bool(nan_to_zero))
+
+
 def _pad2(w, r, c):
     if tuple(w.shape) == (r, c):
         return w

@@ -158,6 +158,38 @@ def test_loss_kernels(dev):
     close(pr.grad, g.t('nll_categorical/g_probs'))
 
 
+@pytest.mark.parametrize('dims', [(1, 32, 32), (32, 32, 1), (3, 20, 5), (17, 9, 32), (8, 16, 4)])
+def test_fused_gauss_mlp_matches_stock_modules(dims, dev):
+    """csrc/mlp.hip vs the holder's plain PyTorch forward (common.py:25-41) in fp64 on the CPU:
+    outputs, input gradient, all six parameter gradients; NaN rows -> zeros + seen flag."""
+    from mdmm import ops
+    from mdmm.models import common
+    i_dim, h_dim, o_dim = dims
+    torch.manual_seed(3)
+    n = 128 * 5 + 37                                    # a ragged last tile
+    mod = common.GaussianMLP(i_dim, o_dim, h_dim).to(dev)
+    ref = common.GaussianMLP(i_dim, o_dim, h_dim).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in mod.state_dict().items()})
+    x = torch.randn(n, i_dim)
+    x[5, 0] = float('nan'); x[n - 1, i_dim - 1] = float('nan')
+    xr = torch.where(torch.isnan(x), torch.zeros_like(x), x).double().requires_grad_()
+    xg = x.to(dev).requires_grad_()
+    assert ops.gauss_mlp_supported(xg, mod)
+    mean, std, seen = ops.gauss_mlp(xg, mod, nan_to_zero=True)
+    r_mean, r_std = ref(xr)
+    assert torch.equal(seen.cpu() > 0, ~torch.isnan(x).any(dim=1))
+    close(mean, r_mean.float(), 1e-5, 'mean'); close(std, r_std.float(), 1e-5, 'std')
+    gm, gs = torch.randn(n, o_dim), torch.randn(n, o_dim)
+    (mean * gm.to(dev) + std * gs.to(dev)).sum().backward()
+    (r_mean * gm.double() + r_std * gs.double()).sum().backward()
+    close(xg.grad, xr.grad.float(), 1e-4, 'g_x')
+    for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        close(p.grad, q.grad.float(), 1e-4, k)
+    # module forward takes the same path (no NaN handling there)
+    m2, s2 = mod(torch.nan_to_num(xg.detach()))
+    close(m2, mean.detach(), 1e-6, 'module mean'); close(s2, std.detach(), 1e-6, 'module std')
+
+
 @pytest.mark.parametrize('case,zd,hd', [('gtf_z5', 5, 20), ('gtf_z32', 32, 32)])
 def test_transition_kernel_vs_golden_gtf(case, zd, hd, dev):
     """z_next on K=1 rows == PoE(global prior, GTF(z)); the golden pins the GTF itself, the
@@ -427,6 +459,10 @@ def test_graphed_step_replays_with_fresh_noise(dev, kernel_family):
     mask = torch.ones(T, B, 1, dtype=torch.bool, device=dev)
 
     def run():
+        # recycled allocator blocks full of garbage: a missing cross-stream dependency or an
+        # unwritten output in the captured step then shows up as run-to-run differences
+        junk = [torch.randn(1 << 24, device=dev) * 1e3 for _ in range(8)]
+        del junk
         torch.manual_seed(0)
         m = models.MultiDMM(['x', 'y'], [1, 1], h_dim=32, z_dim=32, device=dev)
         m.noise = PhiloxNoise(seed=9)
@@ -440,8 +476,9 @@ def test_graphed_step_replays_with_fresh_noise(dev, kernel_family):
         return losses, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
 
     l1, w1 = run()
-    l2, w2 = run()
-    assert l1 == l2 and torch.equal(w1, w2)
+    for _ in range(3):
+        l2, w2 = run()
+        assert l1 == l2 and torch.equal(w1, w2)
     assert all(np.isfinite(l1)) and len(set(l1)) == len(l1)
     assert l1[-1] < l1[0]
 

@@ -1,0 +1,38 @@
+"""GPU box: poison every torch.empty / empty_like made inside mdmm.ops with NaN and run one eager step:
+a NaN loss or gradient means a kernel leaves part of an output unwritten that someone reads."""
+import os, sys
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'multimodal-dmm_amd'))
+import torch
+from mdmm import models, ops
+from mdmm.harness import GradBucket, elbo_step
+from mdmm.noise import PhiloxNoise
+dev = torch.device('cuda:0')
+
+class _T:
+    def __getattr__(self, k):
+        return getattr(torch, k)
+    @staticmethod
+    def empty(*a, **k):
+        t = torch.empty(*a, **k)
+        return t.fill_(float('nan')) if t.is_floating_point() else t
+    @staticmethod
+    def empty_like(*a, **k):
+        t = torch.empty_like(*a, **k)
+        return t.fill_(float('nan')) if t.is_floating_point() else t
+ops.torch = _T()
+T, B = 20, 64
+g = torch.Generator().manual_seed(3)
+x = {'x': torch.randn(T, B, 1, generator=g).to(dev), 'y': torch.randn(T, B, 1, generator=g).to(dev)}
+x['x'][3:5, 2] = float('nan')
+mask = torch.ones(T, B, 1, dtype=torch.bool, device=dev)
+for K in (8, 25):
+    torch.manual_seed(0)
+    m = models.MultiDMM(['x', 'y'], [1, 1], h_dim=32, z_dim=32, device=dev)
+    m.noise = PhiloxNoise(seed=9)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    bucket = GradBucket(m.parameters())
+    loss = m.step(x, mask, 1.0, {'x': .5, 'y': .5}, train_particles=K)
+    (loss / (T * B)).backward()
+    bad = [k for k, p in m.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    print('K', K, 'loss', float(loss), 'non-finite grads:', bad)

@@ -36,6 +36,18 @@ enc = census('encode (2 modalities)', lambda: {x: m._encode_one(x, inputs[x]) fo
 census('kld_prior x2', lambda: m.kld_prior(50, 'fwd') + m.kld_prior(50, 'bwd'))
 for mode, k in (('bfilter', 1), ('fsmooth', 25)):
     census('mode_loss fwd ' + mode, lambda: m._mode_loss(enc, targets, mask, 1.0, rec, pass_mods, pass_mods, 100, 1024, mode, True, False, k, 1))
+def piece_bwd(fn):
+    out = fn()
+    ts = [t for t in (out if isinstance(out, (list, tuple)) else [out]) if torch.is_tensor(t) and t.requires_grad]
+    return lambda: torch.autograd.backward([t.sum() for t in ts], retain_graph=True)
+census('encode bwd', piece_bwd(lambda: [t for x in mods for t in m._encode_one(x, inputs[x])[:2]]))
+census('kld_prior x2 bwd', piece_bwd(lambda: m.kld_prior(50, 'fwd') + m.kld_prior(50, 'bwd')))
+z = torch.randn(2, 100, 1024, 32, device=dev, requires_grad=True)
+census('decode(2 passes)+nll fwd', lambda: sum(m._nll('spiral-x', r, targets['spiral-x'], mask) for r in m._decode_for_loss('spiral-x', [z[0], z[1]])))
+census('decode(2 passes)+nll bwd', piece_bwd(lambda: sum(m._nll('spiral-x', r, targets['spiral-x'], mask) for r in m._decode_for_loss('spiral-x', [z[0], z[1]]))))
+enc_d = {x: tuple(t.detach().requires_grad_() if t.dtype.is_floating_point else t for t in enc[x]) for x in mods}
+for mode, k in (('bfilter', 1), ('fsmooth', 25)):
+    census('mode_loss bwd ' + mode, piece_bwd(lambda: m._mode_loss(enc_d, targets, mask, 1.0, rec, pass_mods, pass_mods, 100, 1024, mode, True, False, k, 1)))
 loss = census('whole step fwd', lambda: m.step(inputs, mask, 1.0, rec, targets=targets, lengths=lengths))
 def fb():
     l = m.step(inputs, mask, 1.0, rec, targets=targets, lengths=lengths); (l / 102400).backward()
