@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 6
+#define MDMM_ABI_VERSION 7
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -175,36 +175,38 @@ int mdmm_moe_bwd(const float* mean, const float* std, const float* mask, int E, 
  * Masked loss reductions, losses.py.  `rows` = T*B (times P when passes are stacked),
  * `inner` = product of the trailing dims, seq_mask is (rows) float 0/1 or NULL.
  * Forward kernels ADD the sum into *out (fp64 accumulator, zero it first); backward
- * kernels write scale * d(sum)/d(input) (or add it, when `accumulate` != 0).  */
+ * kernels write scale * (*scale_dev) * d(sum)/d(input) (or add it, when `accumulate` != 0);
+ * scale_dev is an optional device scalar (NULL = 1): the upstream gradient of the loss, so that
+ * a caller need not read it back or rescale the result with another pass over the tensors.  */
 /* losses.py:14-21 kld_gauss(infer || prior) */
 int mdmm_kld_gauss_fwd(const float* m1, const float* s1, const float* m2, const float* s2,
                        const float* seq_mask, int64_t rows, int inner, double* out,
                        void* stream);
 int mdmm_kld_gauss_bwd(const float* m1, const float* s1, const float* m2, const float* s2,
                        const float* seq_mask, int64_t rows, int inner, float scale,
-                       float* g_m1, float* g_s1, float* g_m2, float* g_s2, int accumulate,
-                       void* stream);
+                       const float* scale_dev, float* g_m1, float* g_s1, float* g_m2, float* g_s2,
+                       int accumulate, void* stream);
 /* losses.py:68-89 nll_gauss; x may hold NaN (= missing, excluded) */
 int mdmm_nll_gauss_fwd(const float* mean, const float* std, const float* x,
                        const float* seq_mask, int64_t rows, int inner, double* out,
                        void* stream);
 int mdmm_nll_gauss_bwd(const float* mean, const float* std, const float* x,
                        const float* seq_mask, int64_t rows, int inner, float scale,
-                       float* g_mean, float* g_std, void* stream);
+                       const float* scale_dev, float* g_mean, float* g_std, void* stream);
 /* losses.py:23-42 nll_bernoulli = F.binary_cross_entropy(sum), log clamped at -100 */
 int mdmm_nll_bernoulli_fwd(const float* theta, const float* x, const float* seq_mask,
                            int64_t rows, int inner, double* out, void* stream);
 int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const float* seq_mask,
-                           int64_t rows, int inner, float scale, float* g_theta,
-                           void* stream);
+                           int64_t rows, int inner, float scale, const float* scale_dev,
+                           float* g_theta, void* stream);
 /* losses.py:44-66 nll_categorical: reference behaviour = minus the summed PROBABILITY of
  * the observed class (F.nll_loss on probs).  probs (rows, n_cat), x (rows) labels as
  * float (NaN = missing).  */
 int mdmm_nll_categorical_fwd(const float* probs, const float* x, const float* seq_mask,
                              int64_t rows, int n_cat, double* out, void* stream);
 int mdmm_nll_categorical_bwd(const float* probs, const float* x, const float* seq_mask,
-                             int64_t rows, int n_cat, float scale, float* g_probs,
-                             void* stream);
+                             int64_t rows, int n_cat, float scale, const float* scale_dev,
+                             float* g_probs, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Stage-wise sweep for large latent sizes (z_dim or h_dim > 32): the host runs the time loop

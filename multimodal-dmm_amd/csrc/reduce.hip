@@ -47,8 +47,10 @@ __global__ __launch_bounds__(NT) void kld_fwd_kernel(const float* __restrict__ m
 
 __global__ __launch_bounds__(NT) void kld_bwd_kernel(const float* __restrict__ m1,
     const float* __restrict__ s1, const float* __restrict__ m2, const float* __restrict__ s2,
-    const float* __restrict__ mask, int64_t n, int inner, float scale, float* g_m1, float* g_s1,
-    float* g_m2, float* g_s2, int accumulate) {
+    const float* __restrict__ mask, int64_t n, int inner, float scale,
+    const float* __restrict__ scale_dev, float* g_m1, float* g_s1, float* g_m2, float* g_s2,
+    int accumulate) {
+  if (scale_dev) scale *= *scale_dev;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
     float w = 0.5f * scale;
     if (mask && mask[i / inner] == 0.f) w = 0.f;
@@ -92,7 +94,9 @@ __global__ __launch_bounds__(NT) void nllg_fwd_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(NT) void nllg_bwd_kernel(const float* __restrict__ mean,
     const float* __restrict__ std, const float* __restrict__ x, const float* __restrict__ mask,
-    int64_t n, int inner, float scale, float* g_mean, float* g_std) {
+    int64_t n, int inner, float scale, const float* __restrict__ scale_dev, float* g_mean,
+    float* g_std) {
+  if (scale_dev) scale *= *scale_dev;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
     const float xv = x[i];
     float gm = 0.f, gs = 0.f;
@@ -142,7 +146,8 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const float* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
-    float scale, float* g_theta) {
+    float scale, const float* __restrict__ scale_dev, float* g_theta) {
+  if (scale_dev) scale *= *scale_dev;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
     const float xv = x[i];
     float g = 0.f;
@@ -169,7 +174,9 @@ __global__ __launch_bounds__(NT) void nllc_fwd_kernel(const float* __restrict__ 
 }
 
 __global__ __launch_bounds__(NT) void nllc_bwd_kernel(const float* __restrict__ x,
-    const float* __restrict__ mask, int64_t rows, int n_cat, float scale, float* g_probs) {
+    const float* __restrict__ mask, int64_t rows, int n_cat, float scale,
+    const float* __restrict__ scale_dev, float* g_probs) {
+  if (scale_dev) scale *= *scale_dev;
   const int64_t n = rows * n_cat;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
     const int64_t r = i / n_cat;
@@ -288,12 +295,12 @@ extern "C" int mdmm_kld_gauss_fwd(const float* m1, const float* s1, const float*
 
 extern "C" int mdmm_kld_gauss_bwd(const float* m1, const float* s1, const float* m2,
                                   const float* s2, const float* seq_mask, int64_t rows, int inner,
-                                  float scale, float* g_m1, float* g_s1, float* g_m2, float* g_s2,
-                                  int accumulate, void* stream) {
+                                  float scale, const float* scale_dev, float* g_m1, float* g_s1,
+                                  float* g_m2, float* g_s2, int accumulate, void* stream) {
   if (!m1 || !s1 || !m2 || !s2 || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL(kld_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, m1, s1, m2, s2,
-                     seq_mask, n, inner, scale, g_m1, g_s1, g_m2, g_s2, accumulate);
+                     seq_mask, n, inner, scale, scale_dev, g_m1, g_s1, g_m2, g_s2, accumulate);
   CHECK_LAUNCH();
 }
 
@@ -309,11 +316,12 @@ extern "C" int mdmm_nll_gauss_fwd(const float* mean, const float* std, const flo
 
 extern "C" int mdmm_nll_gauss_bwd(const float* mean, const float* std, const float* x,
                                   const float* seq_mask, int64_t rows, int inner, float scale,
-                                  float* g_mean, float* g_std, void* stream) {
+                                  const float* scale_dev, float* g_mean, float* g_std,
+                                  void* stream) {
   if (!mean || !std || !x || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL(nllg_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, mean, std, x,
-                     seq_mask, n, inner, scale, g_mean, g_std);
+                     seq_mask, n, inner, scale, scale_dev, g_mean, g_std);
   CHECK_LAUNCH();
 }
 
@@ -327,12 +335,12 @@ extern "C" int mdmm_nll_bernoulli_fwd(const float* theta, const float* x, const 
 }
 
 extern "C" int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const float* seq_mask,
-                                      int64_t rows, int inner, float scale, float* g_theta,
-                                      void* stream) {
+                                      int64_t rows, int inner, float scale,
+                                      const float* scale_dev, float* g_theta, void* stream) {
   if (!theta || !x || !g_theta || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL(nllb_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, theta, x, seq_mask,
-                     n, inner, scale, g_theta);
+                     n, inner, scale, scale_dev, g_theta);
   CHECK_LAUNCH();
 }
 
@@ -345,12 +353,12 @@ extern "C" int mdmm_nll_categorical_fwd(const float* probs, const float* x, cons
 }
 
 extern "C" int mdmm_nll_categorical_bwd(const float* probs, const float* x, const float* seq_mask,
-                                        int64_t rows, int n_cat, float scale, float* g_probs,
-                                        void* stream) {
+                                        int64_t rows, int n_cat, float scale,
+                                        const float* scale_dev, float* g_probs, void* stream) {
   (void)probs;
   if (!x || !g_probs || rows < 0 || n_cat < 1) return MDMM_E_ARG;
   hipLaunchKernelGGL(nllc_bwd_kernel, dim3(grid_for(rows * n_cat)), dim3(NT), 0, STREAM, x, seq_mask,
-                     rows, n_cat, scale, g_probs);
+                     rows, n_cat, scale, scale_dev, g_probs);
   CHECK_LAUNCH();
 }
 

@@ -312,7 +312,10 @@ class MultiDMM(MultiDGTS):
         """sum over passes of [kld_mult*KLD + sum_m mult_m*NLL_m]  (dgts.py:119-129, 132-145)"""
         infer, prior, zs = self._run_passes(enc, pass_mods, t_max, b_dim, mode, sample,
                                             sample_init, flt_particles, smt_particles)
-        total = kld_mult * ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask)
+        # mask: (T,B) fp32 row mask, or the pair (row mask, row mask tiled over the passes) that
+        # `step` prepares once for all its loss terms
+        mask, mask_kld = mask if isinstance(mask, tuple) else (mask, mask)
+        total = kld_mult * ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld)
         for m in self.modalities:
             mult = rec_mults.get(m, 1.0)
             used = [p for p, mods in enumerate(loss_mods) if m in mods]
@@ -381,6 +384,9 @@ class MultiDMM(MultiDGTS):
                 loss_m = match_loss()
             loss_m.record_stream(torch.cuda.current_stream())
         enc = {m: self._encode_one(m, inputs[m]) for m in self.modalities if m in inputs}
+        # fp32 row masks for all the loss reductions of the step, made once (both streams read them)
+        mask_f = mask.to(torch.float32).reshape(-1)
+        mask_kld = mask_f.repeat(len(pass_mods)) if len(pass_mods) > 1 else mask_f
         # each pass scores the modalities it was given (targets restricted the same way).
         # The filtering-mode and the smoothing-mode losses are independent given the encoder
         # outputs: the former (K = 1 sweeps, a latency chain that fills a fraction of the chip)
@@ -394,13 +400,14 @@ class MultiDMM(MultiDGTS):
         for mu, sd, seen in enc.values():
             for x in (mu, sd, seen):
                 x.record_stream(side)
+        mask_f.record_stream(side); mask_kld.record_stream(side)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            loss_f = f_mult * self._mode_loss(enc, targets, mask, kld_mult, rec_mults, pass_mods,
+            loss_f = f_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
                                               loss_mods, t_max, b_dim, f_mode, sample,
                                               sample_init, kwargs.get('flt_particles', 1),
                                               smt_particles)
-        loss_s = s_mult * self._mode_loss(enc, targets, mask, kld_mult, rec_mults, pass_mods,
+        loss_s = s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
                                           loss_mods, t_max, b_dim, s_mode, sample,
                                           sample_init, train_particles, smt_particles)
         main.wait_stream(side)

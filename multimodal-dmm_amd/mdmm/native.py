@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 SYMBOLS = [
     'mdmm_version', 'mdmm_strerror', 'mdmm_pad', 'mdmm_sizeof',
@@ -137,13 +137,13 @@ def lib():
         L.mdmm_moe_fwd.argtypes = [_P, _P, _P, i32, i64, i32, _P, _P, _P]
         L.mdmm_moe_bwd.argtypes = [_P, _P, _P, i32, i64, i32, _P, _P, _P, _P, _P, _P, _P]
         L.mdmm_kld_gauss_fwd.argtypes = [_P, _P, _P, _P, _P, i64, i32, _P, _P]
-        L.mdmm_kld_gauss_bwd.argtypes = [_P, _P, _P, _P, _P, i64, i32, f32, _P, _P, _P, _P, i32, _P]
+        L.mdmm_kld_gauss_bwd.argtypes = [_P, _P, _P, _P, _P, i64, i32, f32, _P, _P, _P, _P, _P, i32, _P]
         L.mdmm_nll_gauss_fwd.argtypes = [_P, _P, _P, _P, i64, i32, _P, _P]
-        L.mdmm_nll_gauss_bwd.argtypes = [_P, _P, _P, _P, i64, i32, f32, _P, _P, _P]
+        L.mdmm_nll_gauss_bwd.argtypes = [_P, _P, _P, _P, i64, i32, f32, _P, _P, _P, _P]
         L.mdmm_nll_bernoulli_fwd.argtypes = [_P, _P, _P, i64, i32, _P, _P]
-        L.mdmm_nll_bernoulli_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
+        L.mdmm_nll_bernoulli_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
         L.mdmm_nll_categorical_fwd.argtypes = [_P, _P, _P, i64, i32, _P, _P]
-        L.mdmm_nll_categorical_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
+        L.mdmm_nll_categorical_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
         L.mdmm_philox_normal.argtypes = [C.c_uint64, C.c_uint64, _P, i64, _P, _P]
         if L.mdmm_version() != ABI_VERSION:
             raise MdmmError('libmdmm_hip.so ABI %d != binding ABI %d'

@@ -634,6 +634,9 @@ def _row_mask(mask, rows, like):
     """(T,B,1)/(T,B) sequence mask -> float (rows,), tiled when passes are stacked."""
     if mask is None or not torch.is_tensor(mask):
         return None
+    if mask.dtype == torch.float32 and mask.is_contiguous() and mask.numel() == rows \
+            and mask.device == like.device:
+        return mask.reshape(-1)                 # already a float row mask (MultiDMM.step makes one)
     m = mask.to(device=like.device, dtype=torch.float32).reshape(-1)
     if m.numel() != rows:
         if rows % m.numel():
@@ -644,6 +647,12 @@ def _row_mask(mask, rows, like):
 
 def _scalar(acc):
     return acc.to(torch.float32).reshape(())
+
+
+def _gdev(g):
+    """Upstream gradient of a scalar loss as a contiguous fp32 device scalar (the backward kernels
+    multiply by it in place of a second pass over the gradient tensors)."""
+    return g.detach().to(torch.float32).reshape(1).contiguous()
 
 
 class _KldFn(torch.autograd.Function):
@@ -664,9 +673,10 @@ class _KldFn(torch.autograd.Function):
         grads = [torch.empty_like(x) if need else None
                  for x, need in zip(t, ctx.needs_input_grad[:4])]
         # scale is applied on the device side of the tensor product to stay async
+        gd = _gdev(g)
         _call('mdmm_kld_gauss_bwd', *[_ptr(x) for x in t], _ptr(ctx.mask), ctx.rows,
-                                                     ctx.inner, 1.0, *[_ptr(x) for x in grads], 0)
-        return tuple(None if x is None else x * g for x in grads) + (None, None, None)
+                                                     ctx.inner, 1.0, _ptr(gd), *[_ptr(x) for x in grads], 0)
+        return tuple(grads) + (None, None, None)
 
 
 def kld_gauss(mean_1, std_1, mean_2, std_2, mask=None):
@@ -693,9 +703,10 @@ class _NllGaussFn(torch.autograd.Function):
     def backward(ctx, g):
         m, s, xv = ctx.saved_tensors
         gm, gs = torch.empty_like(m), torch.empty_like(s)
+        gd = _gdev(g)
         _call('mdmm_nll_gauss_bwd', _ptr(m), _ptr(s), _ptr(xv), _ptr(ctx.mask),
-                                                     ctx.rows, ctx.inner, 1.0, _ptr(gm), _ptr(gs))
-        return gm * g, gs * g, None, None, None, None
+                                                     ctx.rows, ctx.inner, 1.0, _ptr(gd), _ptr(gm), _ptr(gs))
+        return gm, gs, None, None, None, None
 
 
 def nll_gauss(mean, std, x, mask=None, lead_dims=2):
@@ -723,9 +734,10 @@ class _NllBernFn(torch.autograd.Function):
     def backward(ctx, g):
         th, xv = ctx.saved_tensors
         gt = torch.empty_like(th)
+        gd = _gdev(g)
         _call('mdmm_nll_bernoulli_bwd', _ptr(th), _ptr(xv), _ptr(ctx.mask),
-                                                         ctx.rows, ctx.inner, 1.0, _ptr(gt))
-        return gt * g, None, None, None, None
+                                                         ctx.rows, ctx.inner, 1.0, _ptr(gd), _ptr(gt))
+        return gt, None, None, None, None
 
 
 def nll_bernoulli(theta, x, mask=None, lead_dims=2):
@@ -753,9 +765,10 @@ class _NllCatFn(torch.autograd.Function):
     def backward(ctx, g):
         p, xv = ctx.saved_tensors
         gp = torch.empty_like(p)
+        gd = _gdev(g)
         _call('mdmm_nll_categorical_bwd', _ptr(p), _ptr(xv), _ptr(ctx.mask),
-                                                           ctx.rows, ctx.n_cat, 1.0, _ptr(gp))
-        return gp * g, None, None, None, None
+                                                           ctx.rows, ctx.n_cat, 1.0, _ptr(gd), _ptr(gp))
+        return gp, None, None, None, None
 
 
 def nll_categorical(probs, x, mask=None, lead_dims=2):
