@@ -385,13 +385,25 @@ __device__ __forceinline__ void stage_backward_weights(const mdmm_sweep_t& a, fl
   stage_frag(lds + L::T1, a.gtf.wt_in, F1, 0, D, D, DT, DT, 2 * Hp, L::IT1, 2 * HT);
 }
 
-template <int DT, int HT, int CT, bool PART, bool FULL>
+// K = 1 (one row per (pass, sequence), 16 CT rows per wave).  The sweep is a latency chain of T
+// dependent steps on a fraction of the chip's SIMDs (one wave each), so everything a step reads
+// from HBM is loaded ONE STEP AHEAD into a second register set (PF: CT == 1; 512 registers are
+// there for the single resident wave) and the chain never waits on memory.
+template <int DT, int NE>
+struct SeqIn {            // what one processed step reads for one 16-row tile (C layout)
+  f32x4 pm[DT], ps[DT], gsm[DT], gim[DT], gis[DT], gqm[DT], gqs[DT], zm[DT], zs[DT];
+  f32x4 em[NE][DT], es[NE][DT];
+  float cm[NE];           // mask weight of expert e for the row, 0 when the expert is not in its pass
+};
+
+template <int DT, int HT, int CT, bool FULL>
 __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a, int n_tasks) {
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   using L = Lds<DT, HT>;
   using LB = LdsB<DT, HT>;
   constexpr int IT1 = LB::IT1;
-  constexpr int NS = PART ? 1 : CT;
+  constexpr int NE = 3;                                      // experts loaded ahead; further ones in place
+  constexpr bool PF = CT == 1;
   constexpr int SCR = (IT1 + DT) * 16 * (16 + 4);            // floats of scratch per wave (16-row tiles)
   stage_forward_weights<DT, HT>(a, lds);
   stage_backward_weights<DT, HT>(a, lds);
@@ -399,16 +411,14 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   float* scratch0 = reinterpret_cast<float*>(lds + LB::WEND);
   float* scratch = scratch0 + wave * SCR;
-  const int T = a.T, B = a.B, D = a.D, K = a.K;
+  const int T = a.T, B = a.B, D = a.D;
   const bool vec = FULL || (D & 3) == 0;
   const int Dg = FULL ? (1 << 30) : D;      // guard extent: FULL (z_dim == 16*DT) needs no masks
   const bool fast_noise = vec && !a.eps;
   const uint64_t noise_offset = a.offset + (a.offset_dev ? *a.offset_dev : 0);
-  const float inv_k = 1.0f / (float)K;
   const size_t tbd = (size_t)T * B * D;
 
-  // per-feature constants of the global prior live in LDS (mu0 | sigma0 | 1/(sigma0^2+eps)) and
-  // are re-read at each use: 24 fewer live registers in a kernel that sits at the 512 limit
+  // per-feature constants of the global prior live in LDS (mu0 | sigma0 | 1/(sigma0^2+eps))
   float* cst = scratch0 + (NT / 64) * SCR;
   for (int d = threadIdx.x; d < 16 * DT; d += NT) {
     const bool ok = d < D;
@@ -417,10 +427,6 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
     cst[d] = m0; cst[16 * DT + d] = s0; cst[32 * DT + d] = fast::rcp(s0 * s0 + MDMM_POE_EPS);
   }
   __syncthreads();
-  // PART: contributions that are per (pass, sequence) rather than per row (inverse prior expert,
-  // first-step prior) accumulate in a per-wave LDS strip, written by the j == 0 lanes only
-  float* zwav = cst + 48 * DT + (NT / 64) * 32 * DT + (threadIdx.x >> 6) * 32 * DT;
-  for (int d = lane; d < 32 * DT; d += 64) zwav[d] = 0.f;
   auto MU0 = [&](int dt, int r) { return cst[16 * dt + 4 * g + r]; };
   auto SG0 = [&](int dt, int r) { return cst[16 * DT + 16 * dt + 4 * g + r]; };
   auto T0C = [&](int dt, int r) { return cst[32 * DT + 16 * dt + 4 * g + r]; };
@@ -435,6 +441,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
   float db1[IT1], dbg[DT], dbn[DT], dbs[DT];
   f32x4 gzm_row[DT], gzs_row[DT];     // per-row contributions (summed over lanes at the end)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
   for (int x = 0; x < IT1; ++x) { db1[x] = 0.f;
 #pragma unroll
@@ -447,35 +454,85 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
 #pragma unroll
     for (int y = 0; y < DT; ++y) dWs[x][y] = zero4;
   }
+  const bool more = a.E > NE;
 
   for (int task = blockIdx.x * (NT / 64) + wave; task < n_tasks; task += gridDim.x * (NT / 64)) {
     int p_[CT], b_[CT];
     bool live[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      if (PART) { p_[ct] = task / B; b_[ct] = task - p_[ct] * B; live[ct] = (16 * ct + j) < K; }
-      else {
-        const int q = task * 16 * CT + 16 * ct + j;
-        live[ct] = q < a.P * B;
-        const int qq = live[ct] ? q : 0;
-        p_[ct] = qq / B; b_[ct] = qq - p_[ct] * B;
-      }
+      const int q = task * 16 * CT + 16 * ct + j;
+      live[ct] = q < a.P * B;
+      const int qq = live[ct] ? q : 0;
+      p_[ct] = qq / B; b_[ct] = qq - p_[ct] * B;
     }
-    f32x4 adjA[DT][NS], adjB[DT][NS];
+    // everything step ii reads from HBM for row tile ct
+    auto load_step = [&](SeqIn<DT, NE>& in, int ii, int ct) {
+      const int tt = a.reverse ? T - 1 - ii : ii;
+      const int p = p_[ct], b = b_[ct];
+      const bool ok = live[ct];
+      const size_t tb = (size_t)tt * B + b;
+      const size_t o = (size_t)p * tbd + tb * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d0 = 16 * dt + 4 * g;
+        in.pm[dt] = ok ? ld4_guard(a.prior_mean, o, vec, d0, Dg) : zero4;
+        in.ps[dt] = ok ? ld4_guard(a.prior_std, o, vec, d0, Dg) : one4;
+        in.gsm[dt] = ok ? ld4_guard(a.g_samples, o, vec, d0, Dg) : zero4;
+        in.gim[dt] = ok ? ld4_guard(a.g_infer_mean, o, vec, d0, Dg) : zero4;
+        in.gis[dt] = ok ? ld4_guard(a.g_infer_std, o, vec, d0, Dg) : zero4;
+        in.gqm[dt] = ok ? ld4_guard(a.g_prior_mean, o, vec, d0, Dg) : zero4;
+        in.gqs[dt] = ok ? ld4_guard(a.g_prior_std, o, vec, d0, Dg) : zero4;
+      }
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        in.cm[e] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { in.em[e][dt] = zero4; in.es[e][dt] = one4; }
+        if (e < a.E) {
+          const mdmm_expert_t& ex = a.experts[e];
+          if (ok && ((ex.pass_bits >> p) & 1u)) {
+            in.cm[e] = ex.mask ? ex.mask[tb] : 1.0f;
+            const size_t off = (size_t)p * ex.pass_stride + tb * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              in.em[e][dt] = ld4_guard(ex.mean, off, vec, 16 * dt + 4 * g, Dg);
+              in.es[e][dt] = ld4_guard(ex.std, off, vec, 16 * dt + 4 * g, Dg);
+            }
+          }
+        }
+      }
+      if (ii > 0) {       // posterior of the step whose rows the transition adjoint re-creates
+        const int tp = a.reverse ? tt + 1 : tt - 1;
+        const size_t oz = (size_t)p * tbd + ((size_t)tp * B + b) * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          in.zm[dt] = ok ? ld4_guard(a.infer_mean, oz, vec, 16 * dt + 4 * g, Dg) : zero4;
+          in.zs[dt] = ok ? ld4_guard(a.infer_std, oz, vec, 16 * dt + 4 * g, Dg) : zero4;
+        }
+      }
+    };
+
+    f32x4 adjA[DT][CT], adjB[DT][CT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int n = 0; n < NS; ++n) { adjA[dt][n] = zero4; adjB[dt][n] = zero4; }
+      for (int n = 0; n < CT; ++n) { adjA[dt][n] = zero4; adjB[dt][n] = zero4; }
+    SeqIn<DT, NE> nxt;
+    if (PF) load_step(nxt, T - 1, 0);
 
     for (int i = T - 1; i >= 0; --i) {
       const int t = a.reverse ? T - 1 - i : i;
-      const bool sampled = a.sample || K > 1 || (i == 0 && a.sample_init);
-      f32x4 gpm[DT][NS], gps[DT][NS], pmv[DT][NS], psv[DT][NS];
+      const bool sampled = a.sample || (i == 0 && a.sample_init);
+      f32x4 gpm[DT][CT], gps[DT][CT], zm_[DT][CT], zs_[DT][CT];
       // ---------- adjoint of sampling + product of experts at step i ----------
 #pragma unroll
-      for (int n = 0; n < NS; ++n) {
+      for (int n = 0; n < CT; ++n) {
+        SeqIn<DT, NE> in;
+        if (PF) in = nxt;
+        else load_step(in, i, n);
         const int p = p_[n], b = b_[n];
-        const bool row_ok = PART ? true : live[n];
+        const bool row_ok = live[n];
         const size_t tb = (size_t)t * B + b;
         const size_t o = (size_t)p * tbd + tb * D;
         fast::Poe q[DT][4];
@@ -483,60 +540,48 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           const int d0 = 16 * dt + 4 * g;
-          pmv[dt][n] = row_ok ? ld4_guard(a.prior_mean, o, vec, d0, Dg) : zero4;
-          psv[dt][n] = row_ok ? ld4_guard(a.prior_std, o, vec, d0, Dg) : f32x4{1.f, 1.f, 1.f, 1.f};
-          const f32x4 gsm = row_ok ? ld4_guard(a.g_samples, o, vec, d0, Dg) : zero4;
-          g_im[dt] = (row_ok ? ld4_guard(a.g_infer_mean, o, vec, d0, Dg) : zero4) + adjA[dt][n] + gsm;
-          g_is[dt] = row_ok ? ld4_guard(a.g_infer_std, o, vec, d0, Dg) : zero4;
+          zm_[dt][n] = in.zm[dt]; zs_[dt][n] = in.zs[dt];
+          g_im[dt] = in.gim[dt] + adjA[dt][n] + in.gsm[dt];
+          g_is[dt] = in.gis[dt];
           if (sampled) {
             g_is[dt] += adjB[dt][n];
-            if (a.g_samples) {          // d samples / d std = mean_k eps_k  (dmm.py:399-402)
-              f32x4 se = zero4;
-              const int kmax = PART ? CT : 1;
+            if (a.g_samples && row_ok && d0 < Dg) {          // d sample / d std = eps  (dmm.py:399-402)
+              const uint64_t idx = (((uint64_t)p * T + t) * B + b) * (uint64_t)D + d0;
+              float e4[4] = {0.f, 0.f, 0.f, 0.f};
+              eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
 #pragma unroll
-              for (int c = 0; c < kmax; ++c) {
-                const int k = PART ? 16 * c + j : 0;
-                if (PART ? live[c] : row_ok) {
-                  const uint64_t idx = ((((uint64_t)p * T + t) * K + k) * B + b) * (uint64_t)D + d0;
-                  float e4[4] = {0.f, 0.f, 0.f, 0.f};
-                  if (d0 < Dg) {
-                    eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
-                  }
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) se[r] += e4[r];
-                }
-              }
-              if (PART) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) se[r] = row16_sum(se[r]) * inv_k;
-              }
-              g_is[dt] += gsm * se;
+              for (int r = 0; r < 4; ++r) g_is[dt][r] += in.gsm[dt][r] * e4[r];
             }
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { q[dt][r].init(); q[dt][r].add(pmv[dt][n][r], psv[dt][n][r], 1.0f); }
+          for (int r = 0; r < 4; ++r) { q[dt][r].init(); q[dt][r].add(in.pm[dt][r], in.ps[dt][r], 1.0f); }
         }
-        if (row_ok) {
-          for (int e = 0; e < a.E; ++e) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(in.em[e][dt][r], in.es[e][dt][r], in.cm[e]);
+        if (more && row_ok) {
+          for (int e = NE; e < a.E; ++e) {
             const mdmm_expert_t& ex = a.experts[e];
             if (!((ex.pass_bits >> p) & 1u)) continue;
             const float c = ex.mask ? ex.mask[tb] : 1.0f;
             const size_t off = (size_t)p * ex.pass_stride + tb * D;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-              const int d0 = 16 * dt + 4 * g;
-              const f32x4 mv = ld4_guard(ex.mean, off, vec, d0, Dg);
-              f32x4 sv = ld4_guard(ex.std, off, vec, d0, Dg);
+              const f32x4 mv = ld4_guard(ex.mean, off, vec, 16 * dt + 4 * g, Dg);
+              const f32x4 sv = ld4_guard(ex.std, off, vec, 16 * dt + 4 * g, Dg);
 #pragma unroll
               for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(mv[r], sv[r], c);
             }
           }
-          if (a.use_inv_prior) {
+        }
+        if (a.use_inv_prior && row_ok) {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+          for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(MU0(dt, r), -SG0(dt, r), 1.0f);
-          }
+            for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(MU0(dt, r), -SG0(dt, r), 1.0f);
         }
         // adjoints of the product: d/d num, d/d prec per feature
         f32x4 g_num[DT], g_prec[DT];
@@ -552,35 +597,44 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
             g_num[dt][r] = ok ? gm * rp : 0.f;
             g_prec[dt][r] = ok ? (-gm * q[dt][r].num * rp * rp - 0.5f * g_is[dt][r] * sd * rp) : 0.f;
             // the sweep's own prior expert (mask 1)
-            const float var = psv[dt][n][r] * psv[dt][n][r] + MDMM_POE_EPS;
-            const float iv = fast::rcp(var), sg = signf_(psv[dt][n][r]);
-            const float g_t = g_num[dt][r] * pmv[dt][n][r] + g_prec[dt][r];
+            const float psv = in.ps[dt][r];
+            const float iv = fast::rcp(psv * psv + MDMM_POE_EPS), sg = signf_(psv);
+            const float g_t = g_num[dt][r] * in.pm[dt][r] + g_prec[dt][r];
             gpm[dt][n][r] = g_num[dt][r] * iv * sg;
-            gps[dt][n][r] = -g_t * sg * iv * iv * 2.0f * psv[dt][n][r];
+            gps[dt][n][r] = -g_t * sg * iv * iv * 2.0f * psv;
           }
         // expert gradients, one (T,B,D) slab per pass
-        if (row_ok && (PART ? j == 0 : true)) {
-          for (int e = 0; e < a.E; ++e) {
+        auto expert_grad = [&](const mdmm_expert_t& ex, float c, const f32x4& mv, const f32x4& sv, int dt) {
+          f32x4 gm4, gs4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float iv = fast::rcp(sv[r] * sv[r] + MDMM_POE_EPS), sg = signf_(sv[r]);
+            const float g_t = g_num[dt][r] * (mv[r] * c) + g_prec[dt][r];
+            gm4[r] = g_num[dt][r] * (iv * sg * c) * c;
+            gs4[r] = -(g_t * c * sg) * iv * iv * 2.0f * sv[r];
+          }
+          st4_guard(ex.g_mean, o, vec, 16 * dt + 4 * g, Dg, gm4);
+          st4_guard(ex.g_std, o, vec, 16 * dt + 4 * g, Dg, gs4);
+        };
+        if (row_ok) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            if (e >= a.E) continue;
             const mdmm_expert_t& ex = a.experts[e];
             if (!((ex.pass_bits >> p) & 1u) || (!ex.g_mean && !ex.g_std)) continue;
-            const float c = ex.mask ? ex.mask[tb] : 1.0f;
-            const size_t off = (size_t)p * ex.pass_stride + tb * D;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-              const int d0 = 16 * dt + 4 * g;
-              const f32x4 mv = ld4_guard(ex.mean, off, vec, d0, Dg);
-              const f32x4 sv = ld4_guard(ex.std, off, vec, d0, Dg);
-              f32x4 gm4, gs4;
+            for (int dt = 0; dt < DT; ++dt) expert_grad(ex, in.cm[e], in.em[e][dt], in.es[e][dt], dt);
+          }
+          if (more) {
+            for (int e = NE; e < a.E; ++e) {
+              const mdmm_expert_t& ex = a.experts[e];
+              if (!((ex.pass_bits >> p) & 1u) || (!ex.g_mean && !ex.g_std)) continue;
+              const float c = ex.mask ? ex.mask[tb] : 1.0f;
+              const size_t off = (size_t)p * ex.pass_stride + tb * D;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float iv = fast::rcp(sv[r] * sv[r] + MDMM_POE_EPS), sg = signf_(sv[r]);
-                const float tt = iv * sg * c;
-                const float g_t = g_num[dt][r] * (mv[r] * c) + g_prec[dt][r];
-                gm4[r] = g_num[dt][r] * tt * c;
-                gs4[r] = -(g_t * c * sg) * iv * iv * 2.0f * sv[r];
-              }
-              st4_guard(ex.g_mean, o, vec, d0, Dg, gm4);
-              st4_guard(ex.g_std, o, vec, d0, Dg, gs4);
+              for (int dt = 0; dt < DT; ++dt)
+                expert_grad(ex, c, ld4_guard(ex.mean, off, vec, 16 * dt + 4 * g, Dg),
+                            ld4_guard(ex.std, off, vec, 16 * dt + 4 * g, Dg), dt);
             }
           }
         }
@@ -596,77 +650,35 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
               // std of the expert is -sigma0: d/d sigma0 = -(d/d std) = +2 g_t t0^2 sigma0
               gs0 += 2.0f * g_t * T0C(dt, r) * T0C(dt, r) * SG0(dt, r);
             }
-            if (i == 0) {
-              gpm[dt][n][r] += a.g_prior_mean ? ld4_guard(a.g_prior_mean, o, vec, 16 * dt + 4 * g, Dg)[r] : 0.f;
-              gps[dt][n][r] += a.g_prior_std ? ld4_guard(a.g_prior_std, o, vec, 16 * dt + 4 * g, Dg)[r] : 0.f;
-              if (fvalid[dt][r] && row_ok) { gm0 += gpm[dt][n][r]; gs0 += gps[dt][n][r]; }
-            }
-            if (PART) {
-              if (j == 0) { zwav[16 * dt + 4 * g + r] += gm0; zwav[16 * DT + 16 * dt + 4 * g + r] += gs0; }
-            }
-            else { gzm_row[dt][r] += gm0; gzs_row[dt][r] += gs0; }
+            gpm[dt][n][r] += in.gqm[dt][r]; gps[dt][n][r] += in.gqs[dt][r];
+            if (i == 0 && fvalid[dt][r] && row_ok) { gm0 += gpm[dt][n][r]; gs0 += gps[dt][n][r]; }
+            gzm_row[dt][r] += gm0; gzs_row[dt][r] += gs0;
           }
-        if (i > 0) {
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const int d0 = 16 * dt + 4 * g;
-            if (row_ok) {
-              gpm[dt][n] += ld4_guard(a.g_prior_mean, o, vec, d0, Dg);
-              gps[dt][n] += ld4_guard(a.g_prior_std, o, vec, d0, Dg);
-            }
-          }
-        }
       }
       if (i == 0) break;
-      // PART: the per-wave moment-matching coefficients go through a tiny LDS stash so that they
-      // are not live registers across the transition section:  c1 = g_mean/K - c2*mean,
-      // c2 = g_std/(K*std)  ->  g_m = c1 + c2*m,  g_sd = c2*sd
-      float* stash = cst + 48 * DT + (threadIdx.x >> 6) * 32 * DT;
-      if (PART) {
-        if (j == 0) {
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float c2 = gps[dt][0][r] * fast::rcp(psv[dt][0][r]) * inv_k;
-              stash[16 * dt + 4 * g + r] = gpm[dt][0][r] * inv_k - c2 * pmv[dt][0][r];
-              stash[16 * DT + 16 * dt + 4 * g + r] = c2;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
+      // the next step's inputs: issued here, where this step's set is dead, to land during the
+      // transition section below
+      if (PF) load_step(nxt, i - 1, 0);
 
-      // ---------- adjoint of the transition: rows = particles of the previous step ----------
-      // One 16-row column tile at a time: every transient below is [..][1] (half the registers
-      // of a 32-row pass); the tiles only meet in the adjoint sums and the weight accumulators.
+      // ---------- adjoint of the transition: rows of the previous step, one 16-row tile at a time ----------
       const int t_prev = a.reverse ? t + 1 : t - 1;
-      const bool sampled_prev = a.sample || K > 1 || (i == 1 && a.sample_init);
-      f32x4 sumA[DT], sumB[DT];
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) { sumA[dt] = zero4; sumB[dt] = zero4; }
+      const bool sampled_prev = a.sample || (i == 1 && a.sample_init);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const int n = PART ? 0 : ct;
         f32x4 z[DT][1], ev[DT][1];
-        {
-          const int k = PART ? (16 * ct + j) : 0;
-          const size_t o = (size_t)p_[ct] * tbd + ((size_t)t_prev * B + b_[ct]) * D;
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const int d0 = 16 * dt + 4 * g;
-            const f32x4 zm = live[ct] ? ld4_guard(a.infer_mean, o, vec, d0, Dg) : zero4;
-            const f32x4 zs = live[ct] ? ld4_guard(a.infer_std, o, vec, d0, Dg) : zero4;
-            float e4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (sampled_prev && live[ct] && d0 < Dg) {
-              const uint64_t idx = ((((uint64_t)p_[ct] * T + t_prev) * K + k) * B + b_[ct]) * (uint64_t)D + d0;
-              eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
-            }
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d0 = 16 * dt + 4 * g;
+          float e4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (sampled_prev && live[ct] && d0 < Dg) {
+            const uint64_t idx = (((uint64_t)p_[ct] * T + t_prev) * B + b_[ct]) * (uint64_t)D + d0;
+            eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
+          }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              ev[dt][0][r] = e4[r];
-              z[dt][0][r] = (live[ct] && fvalid[dt][r]) ? (sampled_prev ? fmaf(e4[r], zs[r], zm[r]) : zm[r]) : 0.f;
-            }
+          for (int r = 0; r < 4; ++r) {
+            ev[dt][0][r] = e4[r];
+            z[dt][0][r] = (live[ct] && fvalid[dt][r])
+                ? (sampled_prev ? fmaf(e4[r], zs_[dt][ct][r], zm_[dt][ct][r]) : zm_[dt][ct][r]) : 0.f;
           }
         }
         // forward recompute (kept: relu hidden, z_lin, gate, nonlin, std pre-activation)
@@ -699,12 +711,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
             const float num = MU0(dt, r) * T0C(dt, r) + muq * tq, prec = T0C(dt, r) + tq;
             const float rp = fast::rcp(prec);
             const float m = num * rp, sd = fast::sqrt(rp);
-            float g_m, g_sd;
-            if (PART) {         // moment matching, dgts.py:79-83 (coefficients from the stash)
-              const float c2 = stash[16 * DT + 16 * dt + 4 * g + r];
-              g_m = stash[16 * dt + 4 * g + r] + c2 * m;
-              g_sd = c2 * sd;
-            } else { g_m = gpm[dt][n][r]; g_sd = gps[dt][n][r]; }
+            float g_m = gpm[dt][ct][r], g_sd = gps[dt][ct][r];
             if (!(live[ct] && fvalid[dt][r])) { g_m = 0.f; g_sd = 0.f; }
             if (m != m) g_m = 0.f;
             const float g_num = g_m * rp;
@@ -725,8 +732,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
         // d/d nonlin += W_std^T d/d std-pre ; weight grads of z_to_std
         gemm_chain<DT, DT, 1, 2>(lds + LB::TS, nullptr, lane, pre, gnl);
         dw_accumulate<DT, DT, 1>(scratch, lane, pre, nl, dWs, dbs);
-        // gate branch
-        {
+        {   // gate branch
           f32x4 gh[HT][1];
           gemm_chain<HT, DT, 1, 0>(lds + LB::TG, nullptr, lane, gate, gh);
           dw_accumulate<DT, HT, 1>(scratch, lane, gate, h1, dWg, dbg);
@@ -735,8 +741,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
 #pragma unroll
             for (int r = 0; r < 4; ++r) a1[ft][0][r] = h1[ft][0][r] > 0.f ? gh[ft][0][r] : 0.f;
         }
-        // nonlin branch
-        {
+        {   // nonlin branch
           f32x4 gh[HT][1];
           gemm_chain<HT, DT, 1, 0>(lds + LB::TN, nullptr, lane, gnl, gh);
           dw_accumulate<DT, HT, 1>(scratch, lane, gnl, h2, dWn, dbn);
@@ -749,27 +754,12 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
         f32x4 gz[DT][1];
         gemm_chain<DT, IT1, 1, 0>(lds + LB::T1, nullptr, lane, a1, gz);
         dw_accumulate<IT1, DT, 1>(scratch, lane, a1, z, dW1, db1);
-        // adjoints of the previous step's particles
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          if (PART) {       // dead rows / pad features carry zeros
-            sumA[dt] += gz[dt][0];
-            sumB[dt] += gz[dt][0] * ev[dt][0];
-          } else {
-            adjA[dt][ct] = gz[dt][0];
-            adjB[dt][ct] = sampled_prev ? gz[dt][0] * ev[dt][0] : zero4;
-          }
+          adjA[dt][ct] = gz[dt][0];
+          adjB[dt][ct] = sampled_prev ? gz[dt][0] * ev[dt][0] : zero4;
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the column tiles from being interleaved
-      }
-      if (PART) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            adjA[dt][0][r] = row16_sum(sumA[dt][r]);
-            adjB[dt][0][r] = sampled_prev ? row16_sum(sumB[dt][r]) : 0.f;
-          }
       }
     }
   }
@@ -814,13 +804,6 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
       for (int x = 0; x < DT; ++x) {
         put_db(LB::O_BG, x, dbg[x]); put_db(LB::O_BN, x, dbn[x]); put_db(LB::O_BS, x, dbs[x]);
         put_b(LB::O_ZM, x, gzm_row[x]); put_b(LB::O_ZS, x, gzs_row[x]);
-        if (PART && j == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            acc[LB::O_ZM + 16 * x + 4 * g + r] += zwav[16 * x + 4 * g + r];
-            acc[LB::O_ZS + 16 * x + 4 * g + r] += zwav[16 * DT + 16 * x + 4 * g + r];
-          }
-        }
       }
     }
     __syncthreads();
@@ -1376,15 +1359,13 @@ constexpr int BWD_MAX_BLOCKS = 256;     // one 4-wave workgroup per CU (LDS-boun
 // (pass, sequence) rows over as many waves as the chip has SIMDs before doubling up.
 static inline int seq_ct(const mdmm_sweep_t* a) { return (a->P * a->B > 16 * 1024) ? 2 : 1; }
 
-template <int DT, int HT, int CT, bool PART>
-int bwd_tasks(const mdmm_sweep_t* a) {
-  return PART ? a->P * a->B : (a->P * a->B + 16 * CT - 1) / (16 * CT);
-}
+template <int CT>
+int bwd_tasks(const mdmm_sweep_t* a) { return (a->P * a->B + 16 * CT - 1) / (16 * CT); }
 
-template <int DT, int HT, int CT, bool PART, bool FULL>
+template <int DT, int HT, int CT, bool FULL>
 int launch_bwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   using LB = LdsB<DT, HT>;
-  const int n_tasks = bwd_tasks<DT, HT, CT, PART>(a);
+  const int n_tasks = bwd_tasks<CT>(a);
   int grid = (n_tasks + 3) / 4;
   if (grid > BWD_MAX_BLOCKS) grid = BWD_MAX_BLOCKS;
   if (!a->dw_partial || a->dw_partial_rows < grid) return MDMM_E_ARG;
@@ -1392,7 +1373,7 @@ int launch_bwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   const size_t red = (size_t)LB::WIDTH * sizeof(float);
   const size_t lds = (size_t)LB::WEND * sizeof(float4) + (scr > red ? scr : red) +
                      (48 * DT + 2 * (NT / 64) * 32 * DT) * sizeof(float);
-  auto kern = sweep_mfma_bwd_kernel<DT, HT, CT, PART, FULL>;
+  auto kern = sweep_mfma_bwd_kernel<DT, HT, CT, FULL>;
   static size_t attr_lds = 0;         // per template instantiation (LDS size depends on CT only)
   if (attr_lds < lds) {
     hipError_t e = hipFuncSetAttribute((const void*)kern,
@@ -1404,10 +1385,10 @@ int launch_bwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <int DT, int HT, int CT, bool PART>
+template <int DT, int HT, int CT>
 int launch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
-  return a->D == 16 * DT ? launch_bwd_<DT, HT, CT, PART, true>(a, stream)
-                         : launch_bwd_<DT, HT, CT, PART, false>(a, stream);
+  return a->D == 16 * DT ? launch_bwd_<DT, HT, CT, true>(a, stream)
+                         : launch_bwd_<DT, HT, CT, false>(a, stream);
 }
 
 // K > 1: cooperative 8-wave workgroups, CT waves per (pass, sequence)
@@ -1445,8 +1426,8 @@ int launch_bwd_coop(const mdmm_sweep_t* a, hipStream_t stream) {
 template <int DT, int HT>
 int dispatch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->K == 1)
-    return seq_ct(a) == 2 ? launch_bwd<DT, HT, 2, false>(a, stream)
-                          : launch_bwd<DT, HT, 1, false>(a, stream);
+    return seq_ct(a) == 2 ? launch_bwd<DT, HT, 2>(a, stream)
+                          : launch_bwd<DT, HT, 1>(a, stream);
   if (a->K <= 16) return launch_bwd_coop<DT, HT, 1>(a, stream);
   if (a->K <= 32) return launch_bwd_coop<DT, HT, 2>(a, stream);
   return MDMM_UNSUPPORTED;
