@@ -304,7 +304,9 @@ class MultiDMM(MultiDGTS):
             return [tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in o) for o in outs]
         n = len(z_list)
         out = self._plug(dec, torch.stack(z_list).reshape(-1, self.z_dim))
-        out = [r.reshape(n, t_max, b_dim, *r.shape[1:]) for r in out]
+        # unbind, not r[i]: its backward is ONE stack of the per-pass gradients, where every
+        # integer index would zero-fill and add a full-size tensor
+        out = [r.reshape(n, t_max, b_dim, *r.shape[1:]).unbind(0) for r in out]
         return [tuple(r[i] for r in out) for i in range(n)]
 
     def _mode_loss(self, enc, targets, mask, kld_mult, rec_mults, pass_mods, loss_mods, t_max,
@@ -316,6 +318,7 @@ class MultiDMM(MultiDGTS):
         # `step` prepares once for all its loss terms
         mask, mask_kld = mask if isinstance(mask, tuple) else (mask, mask)
         total = kld_mult * ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld)
+        zs = zs.unbind(0)               # per-pass views whose backward is one stack (see _decode_for_loss)
         for m in self.modalities:
             mult = rec_mults.get(m, 1.0)
             used = [p for p, mods in enumerate(loss_mods) if m in mods]
