@@ -61,9 +61,43 @@ def weizmann(kind, B, T=40):
     return lambda: elbo_step(m, opt, bucket, x, mask, [T] * B, 1.0, rec, targets=tg)
 
 
+def spirals_cfg1(B=25, T=100, graph=True):
+    """cfg1: the reference's own CPU-runnable case (Spirals, z=5, h=20, B=25, T=100, 25 particles)."""
+    from mdmm.harness import GraphedElboStep
+    torch.manual_seed(0)
+    m = models.MultiDMM(['spiral-x', 'spiral-y'], [1, 1], h_dim=20, z_dim=5, device=dev)
+    m.noise = PhiloxNoise(seed=1)
+    g = torch.Generator().manual_seed(1234)
+    tg = {k: torch.randn(T, B, 1, generator=g).to(dev) for k in ('spiral-x', 'spiral-y')}
+    x = {k: v.clone() for k, v in tg.items()}
+    for k in x:
+        st = torch.randint(0, T - 10 + 1, (B,), generator=g)
+        for b in range(B):
+            x[k][st[b]:st[b] + 10, b] = float('nan')
+    mask = torch.ones(T, B, 1, dtype=torch.bool, device=dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=graph)
+    bucket = GradBucket(m.parameters())
+    rec = {'spiral-x': .5, 'spiral-y': .5}
+    if graph:
+        return GraphedElboStep(m, opt, bucket, x, mask, [T] * B, 1.0, rec, targets=tg, train_particles=25)
+    return lambda: elbo_step(m, opt, bucket, x, mask, [T] * B, 1.0, rec, targets=tg)
+
+
 out = {}
+if os.environ.get('CFG1', '1') != '0':
+    step = spirals_cfg1()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(50):
+        step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
+    print('cfg1 Spirals z5 h20 T100 (graph replay)', json.dumps({'batch': 25, 's_per_step': round(dt, 5), 'seq_per_s': round(25 / dt, 1)}), flush=True)
+    del step
 for name, kind, B in (('cfg3 Weizmann DMM z256 T40', 'dmm', int(os.environ.get('B3', 32))),
                       ('cfg4 Weizmann DKS b-skip z256 T40', 'dks', int(os.environ.get('B4', 64)))):
+    if B <= 0:
+        continue
     try:
         dt, top = timed(weizmann(kind, B))
         out[name] = {'batch': B, 's_per_step': round(dt, 4), 'seq_per_s': round(B / dt, 2), 'top_kernels_ms': top,
