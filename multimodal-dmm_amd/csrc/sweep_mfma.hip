@@ -345,6 +345,164 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
   }
 }
 
+// K > 32 forward (evaluation runs the filter with 200 particles, trainer.py:264-323 / spirals.py):
+// wave = one (pass, sequence) as in PART mode, but the particle tiles are walked one after the
+// other -- a tile's particles are drawn, pushed through the transition and folded into the running
+// moment sums, nothing per-particle is kept -- so any K fits in the same registers.
+template <int DT, int HT, bool FULL>
+__global__ __launch_bounds__(NT) void sweep_mfma_fwd_long_kernel(const mdmm_sweep_t a, int n_tasks) {
+  extern __shared__ __attribute__((aligned(16))) float4 lds[];
+  stage_forward_weights<DT, HT>(a, lds);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+  const int task = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (task >= n_tasks) return;          // no workgroup-level synchronisation below this line
+  const int T = a.T, B = a.B, D = a.D, K = a.K, n_tiles = (K + 15) / 16;
+  const bool vec = FULL || (D & 3) == 0;
+  const int Dg = FULL ? (1 << 30) : D;
+  const bool fast_noise = vec && !a.eps;
+  const uint64_t noise_offset = a.offset + (a.offset_dev ? *a.offset_dev : 0);
+  const float inv_k = 1.0f / (float)K;
+  const int p = task / B, b = task - p * B;
+  float mu0[DT][4], sg0[DT][4], t0c[DT][4], m0t[DT][4];
+  bool fvalid[DT][4];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int d = 16 * dt + 4 * g + r;
+      fvalid[dt][r] = FULL || d < D;
+      mu0[dt][r] = fvalid[dt][r] ? a.z0_mean[d] : 0.f;
+      sg0[dt][r] = fvalid[dt][r] ? expf(a.z0_log_std[d]) + a.min_std : 1.f;
+      t0c[dt][r] = fast::rcp(sg0[dt][r] * sg0[dt][r] + MDMM_POE_EPS);
+      m0t[dt][r] = mu0[dt][r] * t0c[dt][r];
+    }
+  f32x4 im[DT], is[DT];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // particles of tile c at time tt from the posterior (im, is) of that step; returns the tile's rows
+  auto draw = [&](int c, int tt, f32x4 (&z)[DT][1]) {
+    const int k = 16 * c + j;
+    const bool live = k < K;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d0 = 16 * dt + 4 * g;
+      float e4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (live && d0 < Dg) {
+        const uint64_t idx = ((((uint64_t)p * T + tt) * K + k) * B + b) * (uint64_t)D + d0;
+        eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        z[dt][0][r] = (live && fvalid[dt][r]) ? fmaf(e4[r], is[dt][r], im[dt][r]) : 0.f;
+    }
+    return live;
+  };
+  auto put_samples = [&](int tt, const f32x4 (&zsum)[DT]) {       // z_t.mean(dim=0), dmm.py:402
+    const size_t o = (((size_t)p * T + tt) * B + b) * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = row16_sum(zsum[dt][r]) * inv_k;
+        if (j == 0 && fvalid[dt][r]) a.samples[o + 16 * dt + 4 * g + r] = v;
+      }
+  };
+
+  for (int i = 0; i < T; ++i) {
+    const int t = a.reverse ? T - 1 - i : i;
+    f32x4 pm[DT], ps[DT];
+    if (i == 0) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pm[dt][r] = mu0[dt][r]; ps[dt][r] = sg0[dt][r]; }
+    } else {
+      const int t_prev = a.reverse ? t + 1 : t - 1;
+      f32x4 sm[DT], sv[DT], sm2[DT], zsum[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) { sm[dt] = zero4; sv[dt] = zero4; sm2[dt] = zero4; zsum[dt] = zero4; }
+      for (int c = 0; c < n_tiles; ++c) {
+        f32x4 z[DT][1], tm[DT][1], ts[DT][1];
+        const bool live = draw(c, t_prev, z);
+        transition_rows<DT, HT, 1>(lds, lane, a.min_std, z, m0t, t0c, tm, ts);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          zsum[dt] += z[dt][0];             // dead rows hold 0
+          if (live) { sm[dt] += tm[dt][0]; sv[dt] += ts[dt][0] * ts[dt][0]; sm2[dt] += tm[dt][0] * tm[dt][0]; }
+        }
+      }
+      if (a.samples) put_samples(t_prev, zsum);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mb = row16_sum(sm[dt][r]) * inv_k;                         // dgts.py:79-83
+          pm[dt][r] = mb;
+          ps[dt][r] = fast::sqrt(row16_sum(sv[dt][r]) * inv_k + (row16_sum(sm2[dt][r]) * inv_k - mb * mb));
+        }
+    }
+    // ---- product of experts at step t (dmm.py:387-395) ----
+    const size_t tb = (size_t)t * B + b;
+    fast::Poe q[DT][4];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { q[dt][r].init(); q[dt][r].add(pm[dt][r], ps[dt][r], 1.0f); }
+    for (int e = 0; e < a.E; ++e) {
+      const mdmm_expert_t& ex = a.experts[e];
+      if (!((ex.pass_bits >> p) & 1u)) continue;
+      const float cw = ex.mask ? ex.mask[tb] : 1.0f;
+      const size_t off = (size_t)p * ex.pass_stride + tb * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const f32x4 mv = ld4_guard(ex.mean, off, vec, 16 * dt + 4 * g, Dg);
+        const f32x4 sv = ld4_guard(ex.std, off, vec, 16 * dt + 4 * g, Dg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(mv[r], sv[r], cw);
+      }
+    }
+    if (a.use_inv_prior) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(mu0[dt][r], -sg0[dt][r], 1.0f);
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float m, sd; q[dt][r].finish(m, sd);
+        im[dt][r] = fvalid[dt][r] ? m : 0.f;
+        is[dt][r] = fvalid[dt][r] ? sd : 0.f;
+      }
+    if (j == 0) {
+      const size_t o = (((size_t)p * T + t) * B + b) * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (!fvalid[dt][r]) continue;
+          const size_t oo = o + 16 * dt + 4 * g + r;
+          a.infer_mean[oo] = im[dt][r]; a.infer_std[oo] = is[dt][r];
+          a.prior_mean[oo] = pm[dt][r]; a.prior_std[oo] = ps[dt][r];
+        }
+    }
+    if (i == T - 1 && a.samples) {       // the last step's particles feed no transition: draw them for the mean
+      f32x4 zsum[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) zsum[dt] = zero4;
+      for (int c = 0; c < n_tiles; ++c) {
+        f32x4 z[DT][1];
+        draw(c, t, z);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) zsum[dt] += z[dt][0];
+      }
+      put_samples(t, zsum);
+    }
+  }
+}
+
 // =====================================================================================
 // backward: reverse scan with recompute, weight gradients accumulated in MFMA accumulators
 // =====================================================================================
@@ -1462,7 +1620,14 @@ int dispatch_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
                           : launch_fwd<DT, HT, 1, false>(a, stream);
   if (a->K <= 16) return launch_fwd<DT, HT, 1, true>(a, stream);
   if (a->K <= 32) return launch_fwd<DT, HT, 2, true>(a, stream);
-  return MDMM_UNSUPPORTED;
+  // more particles than two tiles (evaluation): sequential tile loop, any K
+  const int n_tasks = a->P * a->B;
+  const size_t lds = (size_t)Lds<DT, HT>::FWD_END * sizeof(float4);
+  if (a->D == 16 * DT)
+    hipLaunchKernelGGL((sweep_mfma_fwd_long_kernel<DT, HT, true>), dim3((n_tasks + 3) / 4), dim3(NT), lds, stream, *a, n_tasks);
+  else
+    hipLaunchKernelGGL((sweep_mfma_fwd_long_kernel<DT, HT, false>), dim3((n_tasks + 3) / 4), dim3(NT), lds, stream, *a, n_tasks);
+  return (int)hipGetLastError();
 }
 
 }  // namespace

@@ -9,16 +9,17 @@ are consumed by the HIP kernels directly (mdmm.ops.PackedGtf) and this forward i
 used.  The conv stacks mirror common.py:70-290 and always run as ordinary PyTorch
 modules (MIOpen) -- they are out of scope for hand-written kernels.
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 
 def _lin(x, layer):
     """Linear holder applied through the split-K weight-gradient path on the GPU."""
-    if x.is_cuda and x.dim() == 2:
+    if x.is_cuda and x.dim() == 2 and not torch.is_autocast_enabled() and x.dtype == layer.weight.dtype:
         from ..ops import tall_linear
         return tall_linear(x, layer)
-    return layer(x)
+    return layer(x)         # under autocast (plugin_dtype) the stock module casts for itself
 
 
 def _mlp_trunk(in_dim, h_dim):
@@ -49,7 +50,7 @@ class GaussianMLP(nn.Module):
         self.h_to_std = nn.Sequential(nn.Linear(h_dim, out_dim), nn.Softplus())
 
     def forward(self, x):
-        if x.is_cuda and x.dim() == 2:
+        if x.is_cuda and x.dim() == 2 and not torch.is_autocast_enabled():
             from .. import ops
             if ops.gauss_mlp_supported(x, self):         # one launch each way (csrc/mlp.hip)
                 return ops.gauss_mlp(x, self)[:2]

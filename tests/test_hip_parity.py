@@ -668,17 +668,18 @@ def test_vrnn_forward_golden(dev, kernel_family):
         assert all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None)
 
 
-def test_eval_forward_200_particles(dev, kernel_family):
+@pytest.mark.parametrize('dims', [(32, 32, 200), (8, 12, 40)])
+def test_eval_forward_200_particles(dims, dev, kernel_family):
     """The reference's evaluation call for --method bfvi (trainer.py:358-361, 296): fsmooth with
     flt_particles=200, sample=False (sampling is still forced in the particle filter, dmm.py:398).
-    200 particles per sequence run on the generic kernels (row chunks through LDS)."""
-    if kernel_family == 'generic':
-        pytest.skip('200 particles always run on the generic family')
+    More than 32 particles per sequence: the MFMA family walks the particle tiles one after the
+    other (sweep_mfma_fwd_long_kernel), the generic family chunks the rows through LDS."""
     from mdmm import models, ops
     from mdmm.noise import PhiloxNoise
     torch.manual_seed(2)
     spec = [('a', 1, 'Normal'), ('b', 1, 'Normal')]
-    T, lengths, D, H, K = 14, [14, 11, 6], 32, 32, 200
+    D, H, K = dims
+    T, lengths = 14, [14, 11, 6]
     B = len(lengths)
     m = models.MultiDMM(['a', 'b'], [1, 1], h_dim=H, z_dim=D, device=dev).eval()
     o = orc.OracleDMM(['a', 'b'], [1, 1], h_dim=H, z_dim=D).eval()
