@@ -83,7 +83,46 @@ def spirals_cfg1(B=25, T=100, graph=True):
     return lambda: elbo_step(m, opt, bucket, x, mask, [T] * B, 1.0, rec, targets=tg)
 
 
+def vidtimit(B, T=128):
+    """cfg5 shapes: video (3,64,64) + audio (10,1281), both Bernoulli, each (t,b,modality) missing
+    with p = 0.5, ragged lengths U{64..128} sorted descending, z = h = 256."""
+    torch.manual_seed(0)
+    mods, dims = ['video', 'audio'], [(3, 64, 64), (10, 1281)]
+    m = models.MultiDMM(mods, dims, ['Bernoulli', 'Bernoulli'],
+                        encoders={'video': C.ImageEncoder(256), 'audio': C.AudioEncoder(256)},
+                        decoders={'video': C.ImageDecoder(256), 'audio': C.AudioDecoder(256)},
+                        h_dim=256, z_dim=256, device=dev)
+    m.noise = PhiloxNoise(seed=1)
+    g = torch.Generator().manual_seed(1234)
+    lengths = sorted(torch.randint(T // 2, T + 1, (B,), generator=g).tolist(), reverse=True)
+    lengths[0] = T
+    tg = {'video': torch.rand(T, B, 3, 64, 64, generator=g).to(dev),
+          'audio': torch.rand(T, B, 10, 1281, generator=g).to(dev)}
+    mask = torch.zeros(T, B, 1, dtype=torch.bool)
+    for b, n in enumerate(lengths):
+        mask[:n, b] = True
+    for k in tg:
+        tg[k][~mask.squeeze(-1).to(dev)] = float('nan')
+    x = {k: v.clone() for k, v in tg.items()}
+    for k in x:
+        x[k][(torch.rand(T, B, generator=g) < 0.5).to(dev)] = float('nan')
+    mask = mask.to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    bucket = GradBucket(m.parameters())
+    return lambda: elbo_step(m, opt, bucket, x, mask, lengths, 1.0, {'video': 1.0, 'audio': 1.0}, targets=tg)
+
+
 out = {}
+if int(os.environ.get('B5', 0)) > 0:
+    B = int(os.environ['B5'])
+    try:
+        dt, top = timed(vidtimit(B), n=2)
+        res = {'batch': B, 's_per_step': round(dt, 4), 'seq_per_s': round(B / dt, 2), 'top_kernels_ms': top,
+               'max_mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 2)}
+    except Exception as e:   # noqa
+        res = {'error': repr(e)[:300]}
+    print('cfg5 vidTIMIT-shaped DMM z256 T128', json.dumps(res), flush=True)
+    torch.cuda.empty_cache()
 if os.environ.get('CFG1', '1') != '0':
     step = spirals_cfg1()
     for _ in range(5):
