@@ -220,4 +220,107 @@ __device__ __forceinline__ void st4_guard(float* base, size_t off, bool vec, int
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// fp32 contractions on the bf16 matrix pipe.  The f32-input MFMA issues through the vector ALU
+// (its cycles ADD to the elementwise work of a wave); v_mfma_f32_16x16x32_bf16 runs on the matrix
+// core beside it.  Every fp32 operand is split exactly into three bf16 chunks, x = h + m + l
+// (8 + 8 + 8 significand bits), and a product keeps the six chunk products down to 2^-23 of |x w|
+// (h*h, h*m, m*h, h*l, l*h, m*m; bf16 x bf16 is exact in fp32, accumulation is fp32): the result
+// agrees with the f32 MFMA chain to a unit or two in the last place.  One MFMA contracts 32
+// features: the two C-layout feature tiles a lane holds (2 x 4 values) are its 8 k-slots, slot
+// (g, q) = feature 16*(q/4) + 4g + q%4, and the weight fragments are stored in the same order.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Split3 { bf16x8 h, m, l; };
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float r1 = x - (float)h;
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);
+}
+
+__device__ __forceinline__ Split3 split_operand(const f32x4& t0, const f32x4& t1) {
+  Split3 s;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    __bf16 h, m, l;
+    split3(t0[q], h, m, l); s.h[q] = h; s.m[q] = m; s.l[q] = l;
+    split3(t1[q], h, m, l); s.h[4 + q] = h; s.m[4 + q] = m; s.l[4 + q] = l;
+  }
+  return s;
+}
+
+// dst[(plane * IT + it) * KC + kc) * 64 + lane] = chunks of { W[row0 + 16it + i][col0 + 32kc + slot(g, q)] : q = 0..7 }
+__device__ __forceinline__ void stage_frag_split(bf16x8* dst, const float* __restrict__ src, int ld,
+                                                 int row0, int n_rows, int n_cols, int IT, int KC,
+                                                 int col0 = 0, int dst_kc = -1, int kc_off = 0) {
+  if (dst_kc < 0) dst_kc = KC;
+  for (int idx = threadIdx.x; idx < IT * KC * 64; idx += blockDim.x) {
+    const int lane = idx & 63, tile = idx >> 6;
+    const int kc = tile % KC, it = tile / KC;
+    const int row = 16 * it + (lane & 15), g = lane >> 4;
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int col = 32 * kc + 16 * (q >> 2) + 4 * g + (q & 3);
+      const float v = (row < n_rows && col < n_cols) ? src[(size_t)(row0 + row) * ld + col0 + col] : 0.f;
+      __bf16 vh, vm, vl;
+      split3(v, vh, vm, vl); h[q] = vh; m[q] = vm; l[q] = vl;
+    }
+    dst[((0 * IT + it) * dst_kc + kc_off + kc) * 64 + lane] = h;
+    dst[((1 * IT + it) * dst_kc + kc_off + kc) * 64 + lane] = m;
+    dst[((2 * IT + it) * dst_kc + kc_off + kc) * 64 + lane] = l;
+  }
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(const bf16x8& a, const bf16x8& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// out[it][ct] (=|+=) [bias[it] +] sum over the 32 KC input features; MODE as gemm_chain
+template <int IT, int KC, int CT, int MODE = 1>
+__device__ __forceinline__ void gemm_chain_split(const bf16x8* wsp, const float4* bfrag, int lane,
+                                                 const f32x4 (&in)[2 * KC][CT], f32x4 (&out)[IT][CT]) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    if (MODE == 1) {
+      const f32x4 b = ld_frag(bfrag + it * 4 + g);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) out[it][ct] = b;
+    } else if (MODE == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) out[it][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    Split3 b[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) b[ct] = split_operand(in[2 * kc][ct], in[2 * kc + 1][ct]);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const bf16x8 ah = wsp[((0 * IT + it) * KC + kc) * 64 + lane];
+      const bf16x8 am = wsp[((1 * IT + it) * KC + kc) * 64 + lane];
+      const bf16x8 al = wsp[((2 * IT + it) * KC + kc) * 64 + lane];
+      // small terms first; the CT accumulators are independent chains
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(al, b[ct].h, out[it][ct]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(ah, b[ct].l, out[it][ct]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(am, b[ct].m, out[it][ct]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(am, b[ct].h, out[it][ct]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(ah, b[ct].m, out[it][ct]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(ah, b[ct].h, out[it][ct]);
+    }
+  }
+}
+
 }  // namespace

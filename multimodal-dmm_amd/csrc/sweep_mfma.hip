@@ -65,6 +65,21 @@ struct Lds {
   static constexpr int FWD_END = BS + DT * 4;        // float4 units
 };
 
+#ifdef MDMM_NO_SPLIT
+constexpr bool kSplitOk = false;
+#else
+constexpr bool kSplitOk = true;
+#endif
+
+// Forward weights as bf16 chunk planes (gemm_chain_split), z = h = 32 only: [3][IT][KC][64] bf16x8
+struct LdsSplit {
+  static constexpr int W1 = 0;                    // IT = 6, KC = 1
+  static constexpr int WG = W1 + 3 * 6 * 64;      // IT = 2
+  static constexpr int WN = WG + 3 * 2 * 64;
+  static constexpr int WS = WN + 3 * 2 * 64;
+  static constexpr int END = WS + 3 * 2 * 64;     // bf16x8 (16-byte) units
+};
+
 template <int DT, int HT>
 __device__ __forceinline__ void stage_forward_weights(const mdmm_sweep_t& a, float4* lds) {
   using L = Lds<DT, HT>;
@@ -86,6 +101,92 @@ __device__ __forceinline__ void stage_forward_weights(const mdmm_sweep_t& a, flo
 
 // GTF forward on z (C layout) -> per (row, feature): transition mean / std after the product
 // with the global prior (dmm.py:239-252).  Keeps nothing but the outputs.
+// backward (transposed) weights as chunk planes, after the forward planes
+struct LdsSplitB {
+  static constexpr int TS = LdsSplit::END;        // IT = 2 (nonlin idx), KC = 1
+  static constexpr int TG = TS + 3 * 2 * 64;      // IT = 2 (hidden), KC = 1
+  static constexpr int TN = TG + 3 * 2 * 64;
+  static constexpr int T1 = TN + 3 * 2 * 64;      // IT = 2 (z idx), KC = 3 (gate hidden | nonlin hidden | z_lin)
+  static constexpr int END = T1 + 3 * 2 * 3 * 64;
+};
+
+// z = h = 32: the same transition with the four contractions on the bf16 matrix pipe (mfma_tiles.h)
+template <int CT>
+__device__ __forceinline__ void transition_rows_split(const bf16x8* wsp, const float4* lds, int lane,
+                                                      float min_std, const f32x4 (&z)[2][CT],
+                                                      const float (&m0t)[2][4], const float (&t0c)[2][4],
+                                                      f32x4 (&tm)[2][CT], f32x4 (&ts)[2][CT]) {
+  using L = Lds<2, 2>;
+  f32x4 a1[6][CT];
+  gemm_chain_split<6, 1, CT>(wsp + LdsSplit::W1, lds + L::B1, lane, z, a1);
+  f32x4 h1[2][CT], h2[2][CT];
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        h1[ft][ct][r] = fmaxf(a1[ft][ct][r], 0.f);
+        h2[ft][ct][r] = fmaxf(a1[2 + ft][ct][r], 0.f);
+      }
+  f32x4 gate[2][CT], nl[2][CT], pre[2][CT];
+  gemm_chain_split<2, 1, CT>(wsp + LdsSplit::WG, lds + L::BG, lane, h1, gate);
+  gemm_chain_split<2, 1, CT>(wsp + LdsSplit::WN, lds + L::BN, lane, h2, nl);
+  gemm_chain_split<2, 1, CT>(wsp + LdsSplit::WS, lds + L::BS, lane, nl, pre);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gt = fast::sigmoid(gate[dt][ct][r]);
+        const float muq = (1.0f - gt) * a1[4 + dt][ct][r] + gt * nl[dt][ct][r];
+        const float sq = fast::softplus(pre[dt][ct][r]) + min_std;
+        fast::Poe q; q.num = m0t[dt][r]; q.prec = t0c[dt][r];
+        const float tq = fast::rcp(sq * sq + MDMM_POE_EPS);
+        q.add_pre(muq * tq, tq);
+        float m, s; q.finish(m, s);
+        tm[dt][ct][r] = m; ts[dt][ct][r] = s;
+      }
+}
+
+__device__ __forceinline__ void stage_forward_weights_split(const mdmm_sweep_t& a, bf16x8* wsp) {
+  const int D = a.D, H = a.H, Dp = (D + 3) & ~3, Hp = (H + 3) & ~3;
+  // w_in row blocks: [0,Hp) gate hidden, [Hp,2Hp) nonlin hidden, [2Hp,2Hp+Dp) z_lin -> output tiles 0-1, 2-3, 4-5
+  bf16x8* w1 = wsp + LdsSplit::W1;
+  // one call per row block so that each lands on its own output tiles; planes are strided by IT = 6
+  for (int blk = 0; blk < 3; ++blk) {
+    const int row0 = blk == 0 ? 0 : (blk == 1 ? Hp : 2 * Hp), n_rows = blk == 2 ? D : H;
+    for (int idx = threadIdx.x; idx < 2 * 64; idx += blockDim.x) {
+      const int lane = idx & 63, itl = idx >> 6, it = 2 * blk + itl;
+      const int row = 16 * itl + (lane & 15), g = lane >> 4;
+      bf16x8 h, m, l;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int col = 16 * (q >> 2) + 4 * g + (q & 3);
+        const float v = (row < n_rows && col < D) ? a.gtf.w_in[(size_t)(row0 + row) * Dp + col] : 0.f;
+        __bf16 vh, vm, vl;
+        split3(v, vh, vm, vl); h[q] = vh; m[q] = vm; l[q] = vl;
+      }
+      w1[(0 * 6 + it) * 64 + lane] = h; w1[(1 * 6 + it) * 64 + lane] = m; w1[(2 * 6 + it) * 64 + lane] = l;
+    }
+  }
+  stage_frag_split(wsp + LdsSplit::WG, a.gtf.w_gate, Hp, 0, D, H, 2, 1);
+  stage_frag_split(wsp + LdsSplit::WN, a.gtf.w_nl, Hp, 0, D, H, 2, 1);
+  stage_frag_split(wsp + LdsSplit::WS, a.gtf.w_std, Dp, 0, D, D, 2, 1);
+}
+
+__device__ __forceinline__ void stage_backward_weights_split(const mdmm_sweep_t& a, bf16x8* wsp) {
+  const int D = a.D, H = a.H, Dp = (D + 3) & ~3, Hp = (H + 3) & ~3, F1 = 2 * Hp + Dp;
+  stage_frag_split(wsp + LdsSplitB::TS, a.gtf.wt_std, Dp, 0, D, D, 2, 1);
+  stage_frag_split(wsp + LdsSplitB::TG, a.gtf.wt_gate, Dp, 0, H, D, 2, 1);
+  stage_frag_split(wsp + LdsSplitB::TN, a.gtf.wt_nl, Dp, 0, H, D, 2, 1);
+  // wt_in is [Dp][F1]: its columns are the three row blocks of w_in, one 32-feature chunk each
+  stage_frag_split(wsp + LdsSplitB::T1, a.gtf.wt_in, F1, 0, D, H, 2, 1, 0, 3, 0);
+  stage_frag_split(wsp + LdsSplitB::T1, a.gtf.wt_in, F1, 0, D, H, 2, 1, Hp, 3, 1);
+  stage_frag_split(wsp + LdsSplitB::T1, a.gtf.wt_in, F1, 0, D, D, 2, 1, 2 * Hp, 3, 2);
+}
+
 template <int DT, int HT, int CT>
 __device__ __forceinline__ void transition_rows(const float4* lds, int lane, float min_std,
                                                 const f32x4 (&z)[DT][CT], const float (&m0t)[DT][4],
@@ -129,7 +230,10 @@ __device__ __forceinline__ void transition_rows(const float4* lds, int lane, flo
 template <int DT, int HT, int CT, bool PART, bool FULL>
 __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a, int n_tasks) {
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
+  constexpr bool SPLIT = kSplitOk && DT == 2 && HT == 2;
+  bf16x8* wsp = reinterpret_cast<bf16x8*>(lds + Lds<DT, HT>::FWD_END);
   stage_forward_weights<DT, HT>(a, lds);
+  if (SPLIT) stage_forward_weights_split(a, wsp);
   __syncthreads();
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int task = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -185,7 +289,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
           for (int r = 0; r < 4; ++r) { pm[dt][n][r] = mu0[dt][r]; ps[dt][n][r] = sg0[dt][r]; }
     } else {
       f32x4 tm[DT][CT], ts[DT][CT];
-      transition_rows<DT, HT, CT>(lds, lane, a.min_std, z, m0t, t0c, tm, ts);
+      if constexpr (SPLIT) transition_rows_split<CT>(wsp, lds, lane, a.min_std, z, m0t, t0c, tm, ts);
+      else transition_rows<DT, HT, CT>(lds, lane, a.min_std, z, m0t, t0c, tm, ts);
       if (PART) {
         {
 #pragma unroll
@@ -352,7 +457,10 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
 template <int DT, int HT, bool FULL>
 __global__ __launch_bounds__(NT) void sweep_mfma_fwd_long_kernel(const mdmm_sweep_t a, int n_tasks) {
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
+  constexpr bool SPLIT = kSplitOk && DT == 2 && HT == 2;
+  bf16x8* wsp = reinterpret_cast<bf16x8*>(lds + Lds<DT, HT>::FWD_END);
   stage_forward_weights<DT, HT>(a, lds);
+  if (SPLIT) stage_forward_weights_split(a, wsp);
   __syncthreads();
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const int task = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -425,7 +533,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_long_kernel(const mdmm_swee
       for (int c = 0; c < n_tiles; ++c) {
         f32x4 z[DT][1], tm[DT][1], ts[DT][1];
         const bool live = draw(c, t_prev, z);
-        transition_rows<DT, HT, 1>(lds, lane, a.min_std, z, m0t, t0c, tm, ts);
+        if constexpr (SPLIT) transition_rows_split<1>(wsp, lds, lane, a.min_std, z, m0t, t0c, tm, ts);
+        else transition_rows<DT, HT, 1>(lds, lane, a.min_std, z, m0t, t0c, tm, ts);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           zsum[dt] += z[dt][0];             // dead rows hold 0
@@ -563,11 +672,27 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
   constexpr int NE = 3;                                      // experts loaded ahead; further ones in place
   constexpr bool PF = CT == 1;
   constexpr int SCR = (IT1 + DT) * 16 * (16 + 4);            // floats of scratch per wave (16-row tiles)
-  stage_forward_weights<DT, HT>(a, lds);
-  stage_backward_weights<DT, HT>(a, lds);
+  // z = h = 32: the eight chained contractions run on the bf16 matrix pipe from chunk planes (the
+  // fp32 fragments are then not staged; only their bias part of the layout is used)
+  constexpr bool SPLIT = kSplitOk && DT == 2 && HT == 2;
+  constexpr int W_END = SPLIT ? L::FWD_END + LdsSplitB::END : LB::WEND;     // 16-byte units
+  bf16x8* wsp = reinterpret_cast<bf16x8*>(lds + L::FWD_END);
+  if (SPLIT) {
+    stage_bias(lds + L::B1, a.gtf.b_in, 0, a.H, HT);
+    stage_bias(lds + L::B1 + HT * 4, a.gtf.b_in, (a.H + 3) & ~3, a.H, HT);
+    stage_bias(lds + L::B1 + 2 * HT * 4, a.gtf.b_in, 2 * ((a.H + 3) & ~3), a.D, DT);
+    stage_bias(lds + L::BG, a.gtf.b_gate, 0, a.D, DT);
+    stage_bias(lds + L::BN, a.gtf.b_nl, 0, a.D, DT);
+    stage_bias(lds + L::BS, a.gtf.b_std, 0, a.D, DT);
+    stage_forward_weights_split(a, wsp);
+    stage_backward_weights_split(a, wsp);
+  } else {
+    stage_forward_weights<DT, HT>(a, lds);
+    stage_backward_weights<DT, HT>(a, lds);
+  }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  float* scratch0 = reinterpret_cast<float*>(lds + LB::WEND);
+  float* scratch0 = reinterpret_cast<float*>(lds + W_END);
   float* scratch = scratch0 + wave * SCR;
   const int T = a.T, B = a.B, D = a.D;
   const bool vec = FULL || (D & 3) == 0;
@@ -841,7 +966,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
         }
         // forward recompute (kept: relu hidden, z_lin, gate, nonlin, std pre-activation)
         f32x4 a1[IT1][1];
-        gemm_chain<IT1, DT, 1>(lds + L::W1, lds + L::B1, lane, z, a1);
+        if constexpr (SPLIT) gemm_chain_split<6, 1, 1>(wsp + LdsSplit::W1, lds + L::B1, lane, z, a1);
+        else gemm_chain<IT1, DT, 1>(lds + L::W1, lds + L::B1, lane, z, a1);
         f32x4 h1[HT][1], h2[HT][1];
 #pragma unroll
         for (int ft = 0; ft < HT; ++ft)
@@ -851,9 +977,15 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
             h2[ft][0][r] = fmaxf(a1[HT + ft][0][r], 0.f);
           }
         f32x4 gate[DT][1], nl[DT][1], pre[DT][1];
-        gemm_chain<DT, HT, 1>(lds + L::WG, lds + L::BG, lane, h1, gate);
-        gemm_chain<DT, HT, 1>(lds + L::WN, lds + L::BN, lane, h2, nl);
-        gemm_chain<DT, DT, 1>(lds + L::WS, lds + L::BS, lane, nl, pre);
+        if constexpr (SPLIT) {
+          gemm_chain_split<2, 1, 1>(wsp + LdsSplit::WG, lds + L::BG, lane, h1, gate);
+          gemm_chain_split<2, 1, 1>(wsp + LdsSplit::WN, lds + L::BN, lane, h2, nl);
+          gemm_chain_split<2, 1, 1>(wsp + LdsSplit::WS, lds + L::BS, lane, nl, pre);
+        } else {
+          gemm_chain<DT, HT, 1>(lds + L::WG, lds + L::BG, lane, h1, gate);
+          gemm_chain<DT, HT, 1>(lds + L::WN, lds + L::BN, lane, h2, nl);
+          gemm_chain<DT, DT, 1>(lds + L::WS, lds + L::BS, lane, nl, pre);
+        }
         // elementwise adjoints per (row, feature); afterwards
         //   pre <- d/d std-pre, gate <- d/d gate-pre, gnl <- direct part of d/d nonlin, a1[2HT..] <- d/d z_lin
         f32x4 gnl[DT][1];
@@ -888,11 +1020,13 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
             gate[dt][0][r] = g_muq * (nlv - lin) * gt * (1.0f - gt);
           }
         // d/d nonlin += W_std^T d/d std-pre ; weight grads of z_to_std
-        gemm_chain<DT, DT, 1, 2>(lds + LB::TS, nullptr, lane, pre, gnl);
+        if constexpr (SPLIT) gemm_chain_split<2, 1, 1, 2>(wsp + LdsSplitB::TS, nullptr, lane, pre, gnl);
+        else gemm_chain<DT, DT, 1, 2>(lds + LB::TS, nullptr, lane, pre, gnl);
         dw_accumulate<DT, DT, 1>(scratch, lane, pre, nl, dWs, dbs);
         {   // gate branch
           f32x4 gh[HT][1];
-          gemm_chain<HT, DT, 1, 0>(lds + LB::TG, nullptr, lane, gate, gh);
+          if constexpr (SPLIT) gemm_chain_split<2, 1, 1, 0>(wsp + LdsSplitB::TG, nullptr, lane, gate, gh);
+          else gemm_chain<HT, DT, 1, 0>(lds + LB::TG, nullptr, lane, gate, gh);
           dw_accumulate<DT, HT, 1>(scratch, lane, gate, h1, dWg, dbg);
 #pragma unroll
           for (int ft = 0; ft < HT; ++ft)
@@ -901,7 +1035,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
         }
         {   // nonlin branch
           f32x4 gh[HT][1];
-          gemm_chain<HT, DT, 1, 0>(lds + LB::TN, nullptr, lane, gnl, gh);
+          if constexpr (SPLIT) gemm_chain_split<2, 1, 1, 0>(wsp + LdsSplitB::TN, nullptr, lane, gnl, gh);
+          else gemm_chain<HT, DT, 1, 0>(lds + LB::TN, nullptr, lane, gnl, gh);
           dw_accumulate<DT, HT, 1>(scratch, lane, gnl, h2, dWn, dbn);
 #pragma unroll
           for (int ft = 0; ft < HT; ++ft)
@@ -910,7 +1045,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
         }
         // d/dz = W_in^T [d/d gate-hidden | d/d nl-hidden | d/d z_lin] ; weight grads of the in layer
         f32x4 gz[DT][1];
-        gemm_chain<DT, IT1, 1, 0>(lds + LB::T1, nullptr, lane, a1, gz);
+        if constexpr (SPLIT) gemm_chain_split<2, 3, 1, 0>(wsp + LdsSplitB::T1, nullptr, lane, a1, gz);
+        else gemm_chain<DT, IT1, 1, 0>(lds + LB::T1, nullptr, lane, a1, gz);
         dw_accumulate<IT1, DT, 1>(scratch, lane, a1, z, dW1, db1);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -1529,7 +1665,9 @@ int launch_bwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   if (!a->dw_partial || a->dw_partial_rows < grid) return MDMM_E_ARG;
   const size_t scr = (size_t)(NT / 64) * (LB::IT1 + DT) * 16 * (16 + 4) * sizeof(float);
   const size_t red = (size_t)LB::WIDTH * sizeof(float);
-  const size_t lds = (size_t)LB::WEND * sizeof(float4) + (scr > red ? scr : red) +
+  const size_t w_end = (kSplitOk && DT == 2 && HT == 2) ? (size_t)Lds<DT, HT>::FWD_END + LdsSplitB::END
+                                                        : (size_t)LB::WEND;
+  const size_t lds = w_end * sizeof(float4) + (scr > red ? scr : red) +
                      (48 * DT + 2 * (NT / 64) * 32 * DT) * sizeof(float);
   auto kern = sweep_mfma_bwd_kernel<DT, HT, CT, FULL>;
   static size_t attr_lds = 0;         // per template instantiation (LDS size depends on CT only)
@@ -1594,7 +1732,8 @@ int dispatch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
 template <int DT, int HT, int CT, bool PART, bool FULL>
 int launch_fwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   const int n_tasks = PART ? a->P * a->B : (a->P * a->B + 16 * CT - 1) / (16 * CT);
-  const size_t lds = (size_t)Lds<DT, HT>::FWD_END * sizeof(float4);
+  const size_t lds = (size_t)Lds<DT, HT>::FWD_END * sizeof(float4) +
+                     ((kSplitOk && DT == 2 && HT == 2) ? (size_t)LdsSplit::END * 16 : 0);
   auto kern = sweep_mfma_fwd_kernel<DT, HT, CT, PART, FULL>;
   static bool attr_set = false;       // per template instantiation
   if (!attr_set) {
@@ -1622,7 +1761,8 @@ int dispatch_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->K <= 32) return launch_fwd<DT, HT, 2, true>(a, stream);
   // more particles than two tiles (evaluation): sequential tile loop, any K
   const int n_tasks = a->P * a->B;
-  const size_t lds = (size_t)Lds<DT, HT>::FWD_END * sizeof(float4);
+  const size_t lds = (size_t)Lds<DT, HT>::FWD_END * sizeof(float4) +
+                     ((kSplitOk && DT == 2 && HT == 2) ? (size_t)LdsSplit::END * 16 : 0);
   if (a->D == 16 * DT)
     hipLaunchKernelGGL((sweep_mfma_fwd_long_kernel<DT, HT, true>), dim3((n_tasks + 3) / 4), dim3(NT), lds, stream, *a, n_tasks);
   else
