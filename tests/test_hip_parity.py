@@ -226,6 +226,73 @@ def test_transition_kernel_vs_golden_gtf(case, zd, hd, dev):
                 close(p.grad, og[k].grad, 1e-4, k)
 
 
+SWEEP_SHAPES = [
+    # (D, H, K, P, B, T, reverse, inv): tile / task / step boundaries of the MFMA kernels
+    (32, 32, 25, 3, 5, 7, True, False),     # cfg2 tiles; B not a multiple of the pairs per workgroup
+    (32, 32, 16, 2, 9, 5, True, False),     # exactly one particle tile
+    (32, 32, 17, 1, 3, 4, False, False),    # two tiles, the second nearly empty; single pass
+    (32, 32, 2, 3, 4, 3, True, False),      # K = 2
+    (20, 9, 25, 3, 6, 6, True, False),      # DT = 2, HT = 1, partial feature tiles
+    (5, 20, 7, 2, 11, 8, False, False),     # DT = 1, HT = 2
+    (16, 16, 32, 1, 2, 2, True, False),     # full second tile, T = 2
+    (32, 32, 1, 3, 37, 6, False, True),     # K = 1 smoother: inverse prior + per-pass expert, ragged tile
+    (32, 32, 1, 3, 16, 1, True, False),     # T = 1
+    (12, 30, 1, 2, 5, 9, True, False),      # K = 1, partial feature tiles
+    (32, 32, 40, 2, 3, 5, True, False),     # > 32 particles: MFMA forward (tile walk), generic backward
+]
+
+
+@pytest.mark.parametrize('shape', SWEEP_SHAPES)
+def test_sweep_mfma_family_matches_generic_family(shape, dev, kernel_family):
+    """One sweep (forward outputs + every gradient) on the register-chained MFMA kernels against
+    the generic LDS-tiled kernels, which the goldens pin independently: same Philox noise, same
+    inputs, shapes that sit on the tile / task / step boundaries of the MFMA family."""
+    if kernel_family == 'generic':
+        pytest.skip('compares the two families itself')
+    import os
+    from mdmm import ops
+    D, H, K, P, B, T, reverse, inv = shape
+    g = torch.Generator().manual_seed(hash(shape) % 1000)
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(dev)                 # noqa: E731
+    w_shapes = [(H, D), (H,), (D, H), (D,), (D, D), (D,), (H, D), (H,), (D, H), (D,), (D, D), (D,)]
+    # small weights: a contracting transition (0.4 * randn at 32 dims is expansive and amplifies the
+    # last-bit differences between the families' elementwise math tenfold per step)
+    base = {'gtf': [0.12 * rnd(*sh) for sh in w_shapes], 'z0m': 0.1 * rnd(D), 'z0s': 0.1 * rnd(D)}
+    n_obs = max(P - 1, 1)
+    obs = []
+    for m in range(n_obs):
+        bits = (1 | (1 << (m + 1))) if P > 1 else 1
+        obs.append((rnd(T, B, D), rnd(T, B, D).abs() + 0.3, (torch.rand(T, B, generator=g) > 0.2).float().to(dev), bits, False))
+    if inv:     # stds well below the global prior's: the product stays well conditioned with its inverse in
+        flt_mask = torch.ones(T, B, device=dev); flt_mask[-1] = 0
+        flt_mask[0] = 1
+        obs.append((rnd(P, T, B, D), 0.3 + 0.3 * torch.rand(P, T, B, D, generator=g).to(dev), flt_mask, (1 << P) - 1, True))
+        obs[0] = (obs[0][0], 0.3 + 0.3 * torch.rand(T, B, D, generator=g).to(dev), torch.ones(T, B, device=dev), obs[0][3], False)
+    up = [rnd(P, T, B, D) for _ in range(5)]
+
+    def run(force_generic):
+        os.environ['MDMM_FORCE_GENERIC'] = '1' if force_generic else '0'
+        leaves = [t.clone().requires_grad_() for t in base['gtf']] + [base['z0m'].clone().requires_grad_(),
+                                                                     base['z0s'].clone().requires_grad_()]
+        ex, ex_leaves = [], []
+        for mean, std, mask, bits, pp in obs:
+            mu, sd = mean.clone().requires_grad_(), std.clone().requires_grad_()
+            ex_leaves += [mu, sd]
+            ex.append(ops.ExpertSpec(mu, sd, mask, bits, pp))
+        cfg = ops.SweepCfg(T, B, D, H, P=P, K=K, reverse=reverse, sample=True, use_inv_prior=inv, seed=11, offset=3)
+        outs = ops.bfvi_sweep(cfg, leaves[:12], leaves[12], leaves[13], ex)
+        loss = sum((o * u).sum() for o, u in zip(outs, up) if o.numel())
+        loss.backward()
+        return [o.detach() for o in outs], [t.grad for t in leaves + ex_leaves]
+
+    outs_m, grads_m = run(False)
+    outs_g, grads_g = run(True)
+    for i, (a, b) in enumerate(zip(outs_m, outs_g)):
+        close(a, b, 2e-5, 'output %d' % i)
+    for i, (a, b) in enumerate(zip(grads_m, grads_g)):
+        grad_close(a, b, 'gradient %d' % i)
+
+
 # ------------------------------------------------------------------------- z_filter --
 def test_zfilter_golden(dev):
     from mdmm.noise import ReplayNoise
