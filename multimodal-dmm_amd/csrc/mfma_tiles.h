@@ -280,7 +280,10 @@ __device__ __forceinline__ f32x4 mfma_bf16(const bf16x8& a, const bf16x8& b, f32
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// out[it][ct] (=|+=) [bias[it] +] sum over the 32 KC input features; MODE as gemm_chain
+// out[it][ct] (=|+=) [bias[it] +] sum over the 32 KC input features; MODE as gemm_chain.
+// The six chunk products of one accumulator are a dependent MFMA chain, so the output tiles are
+// walked in groups of up to three with the product loop outermost: G * CT independent chains
+// keep the matrix pipe issuing back to back.
 template <int IT, int KC, int CT, int MODE = 1>
 __device__ __forceinline__ void gemm_chain_split(const bf16x8* wsp, const float4* bfrag, int lane,
                                                  const f32x4 (&in)[2 * KC][CT], f32x4 (&out)[IT][CT]) {
@@ -296,29 +299,37 @@ __device__ __forceinline__ void gemm_chain_split(const bf16x8* wsp, const float4
       for (int ct = 0; ct < CT; ++ct) out[it][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
+  constexpr int G = CT >= 2 ? 1 : (IT < 3 ? IT : 3);     // CT tiles already give independent chains
 #pragma unroll
   for (int kc = 0; kc < KC; ++kc) {
     Split3 b[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) b[ct] = split_operand(in[2 * kc][ct], in[2 * kc + 1][ct]);
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const bf16x8 ah = wsp[((0 * IT + it) * KC + kc) * 64 + lane];
-      const bf16x8 am = wsp[((1 * IT + it) * KC + kc) * 64 + lane];
-      const bf16x8 al = wsp[((2 * IT + it) * KC + kc) * 64 + lane];
-      // small terms first; the CT accumulators are independent chains
+    for (int i0 = 0; i0 < IT; i0 += G) {
+      bf16x8 ah[G], am[G], al[G];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(al, b[ct].h, out[it][ct]);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(ah, b[ct].l, out[it][ct]);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(am, b[ct].m, out[it][ct]);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(am, b[ct].h, out[it][ct]);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(ah, b[ct].m, out[it][ct]);
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) out[it][ct] = mfma_bf16(ah, b[ct].h, out[it][ct]);
+      for (int u = 0; u < G; ++u) {
+        if (i0 + u < IT) {
+          ah[u] = wsp[((0 * IT + i0 + u) * KC + kc) * 64 + lane];
+          am[u] = wsp[((1 * IT + i0 + u) * KC + kc) * 64 + lane];
+          al[u] = wsp[((2 * IT + i0 + u) * KC + kc) * 64 + lane];
+        }
+      }
+      // small terms first
+#define MDMM_SPLIT_PRODUCT(A, B)                                                              \
+      _Pragma("unroll") for (int u = 0; u < G; ++u)                                           \
+        if (i0 + u < IT) {                                                                    \
+          _Pragma("unroll") for (int ct = 0; ct < CT; ++ct)                                   \
+            out[i0 + u][ct] = mfma_bf16(A[u], b[ct].B, out[i0 + u][ct]);                      \
+        }
+      MDMM_SPLIT_PRODUCT(al, h)
+      MDMM_SPLIT_PRODUCT(ah, l)
+      MDMM_SPLIT_PRODUCT(am, m)
+      MDMM_SPLIT_PRODUCT(am, h)
+      MDMM_SPLIT_PRODUCT(ah, m)
+      MDMM_SPLIT_PRODUCT(ah, h)
+#undef MDMM_SPLIT_PRODUCT
     }
   }
 }
