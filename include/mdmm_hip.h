@@ -72,9 +72,10 @@ typedef struct mdmm_gtf {
  * prior fed to the smoother, dmm.py:479).  mask is (T,B) float 0/1 or NULL (= ones).
  * pass_bits: bit p set <=> the expert takes part in pass p (a unimodal pass simply
  * leaves the other modalities out, dgts.py:126-129 / dmm.py:162-163).
- * g_mean/g_std (backward only, may be NULL): ALWAYS one slab per pass, (P,T,B,D), zeroed by
- * the caller; the kernel writes the slabs of the passes the expert takes part in.  For a
- * shared expert the caller adds the slabs up (a deterministic sum instead of atomics). */
+ * g_mean/g_std (backward only, may be NULL): ALWAYS one slab per pass, (P,T,B,D).  The kernel
+ * writes the WHOLE (T,B,D) slab of every pass the expert takes part in and leaves the others
+ * untouched (no need to zero the buffer: read only the slabs of the expert's passes).  For a
+ * shared expert the caller adds those slabs up (a deterministic sum instead of atomics). */
 typedef struct mdmm_expert {
   const float* mean;
   const float* std;
