@@ -23,7 +23,7 @@ def run(graph):
         step = lambda: elbo_step(m, opt, bucket, x, mask, [T] * B, 1.0, {'x': .5, 'y': .5}, train_particles=8)
     out = [float(step()) for _ in range(4)]
     torch.cuda.synchronize()
-    for k, (mean, std, seen) in getattr(m, '_dbg', {}).items():
+    for k, (mean, std, seen) in {}.items():
         print('      dbg', k, 'seen min/max/sum', float(seen.min()), float(seen.max()), float(seen.sum()), 'mean finite', bool(torch.isfinite(mean).all()), float(mean.abs().sum()))
     return out
 for graph in (False, True):
