@@ -519,8 +519,102 @@ def g7_state_dicts():
     save_npz(os.path.join(HERE, 'g7_state_dicts.npz'), out)
 
 
+# ------------------------------------------------------------------ G8 trajectory --
+def g8_trajectory():
+    """The Spirals trainer's inner loop (trainer.py:218-252) for three batches of the
+    reference's own Spirals data, then its evaluation forward (trainer.py:281-296): the
+    reference's dataset generator writes the csv files into a scratch directory inside the
+    repo, its dataset class / collate / burst_delete / rand_delete / keep_segment prepare
+    the batches, `SpiralsTrainer.build_model`'s constructor arguments build the model.
+    Stored: the prepared batches, every eps draw, the loss of every step, the parameters
+    after the last Adam step and the evaluation outputs + metrics."""
+    import shutil
+    import numpy.random as nrand
+    from datasets import multiseq as mseq
+    from datasets import spirals as ref_spirals
+    tmp = os.path.join(HERE, '_spirals_tmp')
+    shutil.rmtree(tmp, ignore_errors=True)
+    ref_spirals.gen_dataset(data_dir=tmp)                       # rand.seed(1) inside
+    mods = ['spiral-x', 'spiral-y']
+    data = ref_spirals.SpiralsDataset(mods, tmp, 'train', truncate=True, item_as_dict=True)
+    B, N_STEPS, LR = 4, 3, 1e-3
+    torch.manual_seed(0)
+    ref = ref_models.MultiDMM(mods, dims=(1 for _ in mods), z_dim=5, h_dim=20, device=CPU)
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    o = orc.OracleDMM(mods, [1, 1], h_dim=20, z_dim=5)
+    o.load_state_dict(sd0)
+    opt = torch.optim.Adam(ref.parameters(), lr=LR)
+    oopt = torch.optim.Adam(o.parameters(), lr=LR)
+    rec_mults = {m: 0.5 for m in mods}                          # spirals.py:70-72 ('auto')
+    n_batches = len(data) // 100                                # the trainer's batch_size 100
+    nrand.seed(7)
+    out = {'sd0': sd0, 'lr': np.array(LR), 'n_steps': np.array(N_STEPS)}
+    ref.train()
+    for b_num in range(N_STEPS):
+        targets, mask, lengths, order, ids = mseq.seq_collate_dict(
+            [data[i] for i in range(b_num * B, (b_num + 1) * B)])
+        targets = {m: targets[m] for m in mods}
+        # epoch 1 of trainer.run_train (epochs start at 1, trainer.py:520)
+        b_tot = b_num + 1 * n_batches
+        kld_mult = (1.0 - 0.0) * b_tot / (100 * n_batches) if b_tot < 100 * n_batches else 1.0
+        inputs = mseq.burst_delete(targets, 0.1, lengths)
+        inputs = {m: inputs[m] for m in mods}
+        RECORD.clear()
+        loss = ref.step(inputs, mask, kld_mult, rec_mults, targets=targets, lengths=lengths)
+        (loss / sum(lengths)).backward()
+        opt.step()
+        opt.zero_grad()
+        eps = list(RECORD)
+        o.noise = orc.ReplayNoise(eps)
+        oloss = o.step(inputs, mask, kld_mult, rec_mults, targets=targets, lengths=lengths)
+        (oloss / sum(lengths)).backward()
+        oopt.step()
+        oopt.zero_grad()
+        check('trajectory loss %d' % b_num, oloss, loss, 1e-5)
+        print('  step %d  kld_mult %.5f  loss %.6f' % (b_num, kld_mult, float(loss)))
+        out['step%d' % b_num] = {'inputs': inputs, 'targets': targets,
+                                 'lengths': np.array(lengths), 'kld_mult': np.array(kld_mult),
+                                 'eps': eps, 'loss': loss.detach()}
+    out['sd_final'] = {k: v.clone() for k, v in ref.state_dict().items()}
+    for k, v in o.state_dict().items():
+        assert float((v - out['sd_final'][k]).abs().max()) < 2e-2 * LR * N_STEPS, k
+    # evaluation of the trained model on two test sequences (defaults of spirals.py:33-44)
+    test = ref_spirals.SpiralsDataset(mods, tmp, 'test', truncate=True, item_as_dict=True)
+    targets, mask, lengths, order, ids = mseq.seq_collate_dict([test[i] for i in range(2)])
+    targets = {m: targets[m] for m in mods}
+    inputs = mseq.rand_delete(targets, 0.5, lengths)
+    inputs = mseq.keep_segment(inputs, 0.25, 0.75, lengths)
+    inputs = {m: inputs[m] for m in mods}
+    ref.eval()
+    o.eval()
+    RECORD.clear()
+    with torch.no_grad():
+        infer, prior, recon = ref(inputs, lengths=lengths, sample=False, flt_particles=200)
+        eps = list(RECORD)
+        kld = ref.kld_loss(infer, prior, mask)
+        rec = ref.rec_loss(targets, recon, mask, rec_mults)
+        mse = sum((recon[m][0] - targets[m]).pow(2) for m in mods).sum(dim=2)
+        mse[~mask.squeeze(-1).bool()] = 0.0
+        mse = mse.sum(dim=0) / torch.tensor(lengths, dtype=torch.float32)
+        o.noise = orc.ReplayNoise(eps)
+        oinfer, oprior, orecon = o(inputs, lengths=lengths, sample=False, flt_particles=200)
+    check('eval infer mean', oinfer[0], infer[0], 1e-4)
+    check('eval recon', orecon['spiral-x'][0], recon['spiral-x'][0], 1e-4)
+    print('  eval  kld %.4f  rec %.4f  mse %s' % (float(kld), float(rec), mse.tolist()))
+    out['eval'] = {'inputs': inputs, 'targets': targets, 'lengths': np.array(lengths),
+                   'eps': eps, 'infer': list(infer), 'prior': list(prior),
+                   'recon': {m: list(recon[m]) for m in mods},
+                   'kld_loss': kld, 'rec_loss': rec, 'mse': mse}
+    shutil.rmtree(tmp, ignore_errors=True)
+    save_npz(os.path.join(HERE, 'g8_trajectory.npz'), out)
+
+
 if __name__ == '__main__':
-    for fn in (g1_primitives, g2_zfilter, g3_forward, g4_step, g5_dks, g6_vrnn, g7_state_dicts):
+    only = sys.argv[1:]
+    for fn in (g1_primitives, g2_zfilter, g3_forward, g4_step, g5_dks, g6_vrnn, g7_state_dicts,
+               g8_trajectory):
+        if only and fn.__name__ not in only:
+            continue
         print(fn.__name__)
         fn()
     for f in sorted(os.listdir(HERE)):

@@ -381,6 +381,57 @@ def test_step_golden(case, dev):
         grad_close(got, ref, k)
 
 
+# ----------------------------------------------------------------- trainer trajectory --
+def test_trajectory_of_the_spirals_trainer_golden(dev):
+    """harness.elbo_step (gradient bucket + Adam) over the three recorded batches of the
+    reference's Spirals trainer, then its evaluation forward with 200 filter particles."""
+    from mdmm import models
+    from mdmm.harness import GradBucket, elbo_step
+    from mdmm.noise import ReplayNoise
+    g = Golden('g8_trajectory.npz')
+    mods = ['spiral-x', 'spiral-y']
+    m = models.MultiDMM(mods, (1 for _ in mods), h_dim=20, z_dim=5, device=dev)
+    m.load_state_dict(g.sub('sd0'))
+    lr, n_steps = float(g.scalar('lr')), int(g.scalar('n_steps'))
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    bucket = GradBucket(m.parameters())
+    rec_mults = {k: 0.5 for k in mods}
+    m.train()
+    for i in range(n_steps):
+        c = 'step%d' % i
+        lengths = g.t(c + '/lengths').tolist()
+        m.noise = ReplayNoise(g.seq(c + '/eps'))
+        loss = elbo_step(m, opt, bucket, cuda(g.sub(c + '/inputs'), dev),
+                         orc.len_to_mask(lengths).to(dev), lengths, float(g.scalar(c + '/kld_mult')),
+                         rec_mults, targets=cuda(g.sub(c + '/targets'), dev))
+        assert m.noise.exhausted
+        close(loss, g.t(c + '/loss'), TOL_LOSS, 'loss of step %d' % i)
+    final = g.sub('sd_final')
+    for k, v in m.state_dict().items():
+        assert float((v.cpu() - final[k]).abs().max()) < 2e-2 * lr * n_steps, k
+    m.load_state_dict(final)
+    m.eval()
+    lengths = g.t('eval/lengths').tolist()
+    mask = orc.len_to_mask(lengths).to(dev)
+    m.noise = ReplayNoise(g.seq('eval/eps'))
+    with torch.no_grad():
+        infer, prior, recon = m(cuda(g.sub('eval/inputs'), dev), lengths=lengths, sample=False,
+                                flt_particles=200)
+        assert m.noise.exhausted
+        for got, ref in zip(list(infer) + list(prior), g.seq('eval/infer') + g.seq('eval/prior')):
+            close(got, ref, 1e-4, 'eval infer/prior')
+        for k in mods:
+            assert type(recon[k]) is tuple
+            for got, ref in zip(recon[k], g.seq('eval/recon/' + k)):
+                close(got, ref, 1e-4, 'eval recon ' + k)
+        targets = cuda(g.sub('eval/targets'), dev)
+        close(m.kld_loss(infer, prior, mask), g.t('eval/kld_loss'), 1e-4, 'eval kld')
+        close(m.rec_loss(targets, recon, mask, rec_mults), g.t('eval/rec_loss'), 1e-4, 'eval rec')
+        mse = sum((recon[k][0] - targets[k]).pow(2) for k in mods).sum(dim=2)
+        mse = (mse * mask.squeeze(-1).float()).sum(dim=0) / torch.tensor(lengths, device=dev).float()
+        close(mse, g.t('eval/mse'), 1e-4, 'eval mse')
+
+
 def _philox_step_vs_oracle(dev, T, lengths, D, H, K, nan_spans, seed, grad_tol=TOL_GRAD):
     """Production mode (in-kernel Philox): recover the noise each sweep drew with
     mdmm_philox_normal, replay it into the CPU oracle, compare loss and gradients."""

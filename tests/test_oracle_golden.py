@@ -257,6 +257,52 @@ def test_dks_forward_and_step():
                 assert rel_err(got, ref) < 1e-3 or float(ref.abs().max()) < 1e-6, (c, k)
 
 
+# --------------------------------------------------------------------------- G8 --
+def test_trajectory_of_the_spirals_trainer():
+    """Three Adam steps on the reference's Spirals batches (trainer.py:218-252) and its
+    evaluation forward with 200 filter particles (trainer.py:281-296, spirals.py:93-111)."""
+    g = Golden('g8_trajectory.npz')
+    mods = ['spiral-x', 'spiral-y']
+    o = orc.OracleDMM(mods, [1, 1], h_dim=20, z_dim=5)
+    o.load_state_dict(g.sub('sd0'))
+    lr, n_steps = float(g.scalar('lr')), int(g.scalar('n_steps'))
+    opt = torch.optim.Adam(o.parameters(), lr=lr)
+    rec_mults = {m: 0.5 for m in mods}
+    o.train()
+    for i in range(n_steps):
+        c = 'step%d' % i
+        lengths = g.t(c + '/lengths').tolist()
+        o.noise = orc.ReplayNoise(g.seq(c + '/eps'))
+        loss = o.step(g.sub(c + '/inputs'), orc.len_to_mask(lengths), float(g.scalar(c + '/kld_mult')),
+                      rec_mults, targets=g.sub(c + '/targets'), lengths=lengths)
+        assert o.noise.pos == len(o.noise.tensors)
+        close(loss, g.t(c + '/loss'), 1e-5)
+        (loss / sum(lengths)).backward()
+        opt.step()
+        opt.zero_grad()
+    final = g.sub('sd_final')
+    for k, v in o.state_dict().items():
+        assert float((v - final[k]).abs().max()) < 2e-2 * lr * n_steps, k
+    o.load_state_dict(final)
+    o.eval()
+    lengths = g.t('eval/lengths').tolist()
+    mask = orc.len_to_mask(lengths)
+    o.noise = orc.ReplayNoise(g.seq('eval/eps'))
+    with torch.no_grad():
+        infer, prior, recon = o(g.sub('eval/inputs'), lengths=lengths, sample=False, flt_particles=200)
+        for got, ref in zip(infer + prior, g.seq('eval/infer') + g.seq('eval/prior')):
+            close(got, ref, 1e-4)
+        for m in mods:
+            for got, ref in zip(recon[m], g.seq('eval/recon/' + m)):
+                close(got, ref, 1e-4)
+        targets = g.sub('eval/targets')
+        close(o.kld_loss(infer, prior, mask), g.t('eval/kld_loss'), 1e-4)
+        close(o.rec_loss(targets, recon, mask, rec_mults), g.t('eval/rec_loss'), 1e-4)
+        mse = sum((recon[m][0] - targets[m]).pow(2) for m in mods).sum(dim=2)     # spirals.py:104-110
+        mse = (mse * mask.squeeze(-1).float()).sum(dim=0) / torch.tensor(lengths).float()
+        close(mse, g.t('eval/mse'), 1e-4)
+
+
 def test_anneal():
     assert orc.anneal(0.0, 1.0, 24, 2400) == pytest.approx(0.01)
     assert orc.anneal(0.0, 0.5, 5000, 2400) == 0.5
