@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 7
+#define MDMM_ABI_VERSION 8
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -175,13 +175,14 @@ int mdmm_moe_bwd(const float* mean, const float* std, const float* mask, int E, 
 /* ---------------------------------------------------------------------------------
  * Masked loss reductions, losses.py.  `rows` = T*B (times P when passes are stacked),
  * `inner` = product of the trailing dims, seq_mask is (rows) float 0/1 or NULL.
- * Forward kernels ADD the sum into *out (fp64 accumulator, zero it first); backward
+ * Forward kernels ADD weight * sum into *out (fp64 accumulator, zero it first; the terms of one
+ * weighted loss sum share one accumulator, so the sum costs no launches of its own); backward
  * kernels write scale * (*scale_dev) * d(sum)/d(input) (or add it, when `accumulate` != 0);
  * scale_dev is an optional device scalar (NULL = 1): the upstream gradient of the loss, so that
  * a caller need not read it back or rescale the result with another pass over the tensors.  */
 /* losses.py:14-21 kld_gauss(infer || prior) */
 int mdmm_kld_gauss_fwd(const float* m1, const float* s1, const float* m2, const float* s2,
-                       const float* seq_mask, int64_t rows, int inner, double* out,
+                       const float* seq_mask, int64_t rows, int inner, float weight, double* out,
                        void* stream);
 int mdmm_kld_gauss_bwd(const float* m1, const float* s1, const float* m2, const float* s2,
                        const float* seq_mask, int64_t rows, int inner, float scale,
@@ -189,14 +190,14 @@ int mdmm_kld_gauss_bwd(const float* m1, const float* s1, const float* m2, const 
                        int accumulate, void* stream);
 /* losses.py:68-89 nll_gauss; x may hold NaN (= missing, excluded) */
 int mdmm_nll_gauss_fwd(const float* mean, const float* std, const float* x,
-                       const float* seq_mask, int64_t rows, int inner, double* out,
+                       const float* seq_mask, int64_t rows, int inner, float weight, double* out,
                        void* stream);
 int mdmm_nll_gauss_bwd(const float* mean, const float* std, const float* x,
                        const float* seq_mask, int64_t rows, int inner, float scale,
                        const float* scale_dev, float* g_mean, float* g_std, void* stream);
 /* losses.py:23-42 nll_bernoulli = F.binary_cross_entropy(sum), log clamped at -100 */
 int mdmm_nll_bernoulli_fwd(const float* theta, const float* x, const float* seq_mask,
-                           int64_t rows, int inner, double* out, void* stream);
+                           int64_t rows, int inner, float weight, double* out, void* stream);
 int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const float* seq_mask,
                            int64_t rows, int inner, float scale, const float* scale_dev,
                            float* g_theta, void* stream);
@@ -204,7 +205,7 @@ int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const float* seq_
  * the observed class (F.nll_loss on probs).  probs (rows, n_cat), x (rows) labels as
  * float (NaN = missing).  */
 int mdmm_nll_categorical_fwd(const float* probs, const float* x, const float* seq_mask,
-                             int64_t rows, int n_cat, double* out, void* stream);
+                             int64_t rows, int n_cat, float weight, double* out, void* stream);
 int mdmm_nll_categorical_bwd(const float* probs, const float* x, const float* seq_mask,
                              int64_t rows, int n_cat, float scale, const float* scale_dev,
                              float* g_probs, void* stream);
@@ -339,6 +340,11 @@ int mdmm_dks_combiner_bwd(const mdmm_dks_t* args, void* stream);
  * materialise exactly what a sweep used (replaces dgts.py:179 `normal_()`).  */
 int mdmm_philox_normal(uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t n,
                        float* out, void* stream);
+
+/* Measurement aid: one-thread kernel that stores the device's constant-rate wall clock
+ * (wall_clock64, 100 MHz) into *out when the stream reaches it -- timestamps between the nodes of
+ * a captured HIP graph, where events cannot be recorded (tools/step_stamps.py).  */
+int mdmm_debug_clock(unsigned long long* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused GaussianMLP holder (common.py:25-41):  x (N,I) -> h = relu(W1 x + b1) ->

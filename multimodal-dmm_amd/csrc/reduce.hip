@@ -35,14 +35,14 @@ inline int grid_for(int64_t n) {
 // ---------------------------------------------------------------- kld_gauss --------
 __global__ __launch_bounds__(NT) void kld_fwd_kernel(const float* __restrict__ m1,
     const float* __restrict__ s1, const float* __restrict__ m2, const float* __restrict__ s2,
-    const float* __restrict__ mask, int64_t n, int inner, double* out) {
+    const float* __restrict__ mask, int64_t n, int inner, float weight, double* out) {
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
     if (mask && mask[i / inner] == 0.f) continue;
     const float a = s1[i], b = s2[i], d = m1[i] - m2[i];
     acc += 2.0f * logf(b) - 2.0f * logf(a) + (a * a + d * d) / (b * b) - 1.0f;   // losses.py:15-17
   }
-  block_add(0.5 * (double)acc, out);
+  block_add(0.5 * (double)weight * (double)acc, out);
 }
 
 __global__ __launch_bounds__(NT) void kld_bwd_kernel(const float* __restrict__ m1,
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NT) void kld_bwd_kernel(const float* __restrict__ m
 // ---------------------------------------------------------------- nll_gauss --------
 __global__ __launch_bounds__(NT) void nllg_fwd_kernel(const float* __restrict__ mean,
     const float* __restrict__ std, const float* __restrict__ x, const float* __restrict__ mask,
-    int64_t n, int inner, double* out) {
+    int64_t n, int inner, float weight, double* out) {
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
     const float xv = x[i];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(NT) void nllg_fwd_kernel(const float* __restrict__ 
     const float sd = std[i], r = (xv - mean[i]) / sd;
     acc += 0.5f * r * r + logf(sd) + HALF_LOG_2PI;            // losses.py:85-86
   }
-  block_add((double)acc, out);
+  block_add((double)weight * (double)acc, out);
 }
 
 __global__ __launch_bounds__(NT) void nllg_bwd_kernel(const float* __restrict__ mean,
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NT) void nllg_bwd_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------- nll_bernoulli ----
 __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
-    double* out) {
+    float weight, double* out) {
   float acc = 0.f;
   const bool vec = (inner & 3) == 0 && (n & 3) == 0;
   if (vec) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ 
       acc -= xv * l1 + (1.0f - xv) * l0;
     }
   }
-  block_add((double)acc, out);
+  block_add((double)weight * (double)acc, out);
 }
 
 __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const float* __restrict__ theta,
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------- nll_categorical --
 __global__ __launch_bounds__(NT) void nllc_fwd_kernel(const float* __restrict__ probs,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t rows, int n_cat,
-    double* out) {
+    float weight, double* out) {
   float acc = 0.f;
   for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < rows; r += (int64_t)gridDim.x * NT) {
     const float xv = x[r];
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NT) void nllc_fwd_kernel(const float* __restrict__ 
     if (mask && mask[r] == 0.f) continue;
     acc -= probs[r * n_cat + (int)xv];                          // losses.py:65 (probs, not logs)
   }
-  block_add((double)acc, out);
+  block_add((double)weight * (double)acc, out);
 }
 
 __global__ __launch_bounds__(NT) void nllc_bwd_kernel(const float* __restrict__ x,
@@ -285,11 +285,11 @@ __global__ __launch_bounds__(NT) void philox_kernel(uint64_t seed, uint64_t offs
 
 extern "C" int mdmm_kld_gauss_fwd(const float* m1, const float* s1, const float* m2,
                                   const float* s2, const float* seq_mask, int64_t rows, int inner,
-                                  double* out, void* stream) {
+                                  float weight, double* out, void* stream) {
   if (!m1 || !s1 || !m2 || !s2 || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL(kld_fwd_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, m1, s1, m2, s2,
-                     seq_mask, n, inner, out);
+                     seq_mask, n, inner, weight, out);
   CHECK_LAUNCH();
 }
 
@@ -305,12 +305,12 @@ extern "C" int mdmm_kld_gauss_bwd(const float* m1, const float* s1, const float*
 }
 
 extern "C" int mdmm_nll_gauss_fwd(const float* mean, const float* std, const float* x,
-                                  const float* seq_mask, int64_t rows, int inner, double* out,
-                                  void* stream) {
+                                  const float* seq_mask, int64_t rows, int inner, float weight,
+                                  double* out, void* stream) {
   if (!mean || !std || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL(nllg_fwd_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, mean, std, x,
-                     seq_mask, n, inner, out);
+                     seq_mask, n, inner, weight, out);
   CHECK_LAUNCH();
 }
 
@@ -326,11 +326,12 @@ extern "C" int mdmm_nll_gauss_bwd(const float* mean, const float* std, const flo
 }
 
 extern "C" int mdmm_nll_bernoulli_fwd(const float* theta, const float* x, const float* seq_mask,
-                                      int64_t rows, int inner, double* out, void* stream) {
+                                      int64_t rows, int inner, float weight, double* out,
+                                      void* stream) {
   if (!theta || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL(nllb_fwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, theta, x,
-                     seq_mask, n, inner, out);
+                     seq_mask, n, inner, weight, out);
   CHECK_LAUNCH();
 }
 
@@ -345,10 +346,11 @@ extern "C" int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const 
 }
 
 extern "C" int mdmm_nll_categorical_fwd(const float* probs, const float* x, const float* seq_mask,
-                                        int64_t rows, int n_cat, double* out, void* stream) {
+                                        int64_t rows, int n_cat, float weight, double* out,
+                                        void* stream) {
   if (!probs || !x || !out || rows < 0 || n_cat < 1) return MDMM_E_ARG;
   hipLaunchKernelGGL(nllc_fwd_kernel, dim3(grid_for(rows)), dim3(NT), 0, STREAM, probs, x, seq_mask,
-                     rows, n_cat, out);
+                     rows, n_cat, weight, out);
   CHECK_LAUNCH();
 }
 
@@ -403,6 +405,14 @@ extern "C" int mdmm_philox_normal(uint64_t seed, uint64_t offset, const uint64_t
   if (!out || n < 0) return MDMM_E_ARG;
   hipLaunchKernelGGL(philox_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, seed, offset, offset_dev, n,
                      out);
+  CHECK_LAUNCH();
+}
+
+__global__ void clock_kernel(unsigned long long* out) { *out = wall_clock64(); }
+
+extern "C" int mdmm_debug_clock(unsigned long long* out, void* stream) {
+  if (!out) return MDMM_E_ARG;
+  hipLaunchKernelGGL(clock_kernel, dim3(1), dim3(1), 0, STREAM, out);
   CHECK_LAUNCH();
 }
 

@@ -53,14 +53,15 @@ class MultiDGTS(nn.Module):
         """dgts.py:147-152"""
         return ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask)
 
-    def _nll(self, m, recon_m, target, mask, lead_dims=2):
+    def _nll(self, m, recon_m, target, mask, lead_dims=2, weight=1.0, into=None):
+        """weight / into: the term is added, weighted, to an ops.LossSum."""
         dist = self.dists[m]
         if dist == 'Bernoulli':
-            return ops.nll_bernoulli(recon_m[0], target, mask, lead_dims)
+            return ops.nll_bernoulli(recon_m[0], target, mask, lead_dims, weight, into)
         if dist == 'Categorical':
-            return ops.nll_categorical(recon_m[0], target, mask, lead_dims)
+            return ops.nll_categorical(recon_m[0], target, mask, lead_dims, weight, into)
         if dist == 'Normal':
-            return ops.nll_gauss(recon_m[0], recon_m[1], target, mask, lead_dims)
+            return ops.nll_gauss(recon_m[0], recon_m[1], target, mask, lead_dims, weight, into)
         return None
 
     def rec_loss(self, inputs, recon, mask=None, rec_mults={}):

@@ -254,7 +254,8 @@ class MultiDKS(MultiDGTS):
             self.combiner.h_to_std[0].weight, self.combiner.h_to_std[0].bias,
             ops.gtf_param_list(self.fwd))
         big_mask = mask.reshape(t_max, 1, b_dim).expand(t_max, n_pass, b_dim).reshape(t_max, rows, 1)
-        total = kld_mult * ops.kld_gauss(im, is_, pm, ps_, big_mask)
+        total = ops.LossSum(im.device)              # all terms add into one device accumulator
+        ops.kld_gauss(im, is_, pm, ps_, big_mask, float(kld_mult), total)
         for m in self.modalities:
             mult = rec_mults.get(m, 1.0)
             used = [p for p, mods in enumerate(loss_mods) if m in mods]
@@ -264,8 +265,8 @@ class MultiDKS(MultiDGTS):
                 zp = z[:, p * b_dim:(p + 1) * b_dim].reshape(-1, self.z_dim)
                 out = self._plug(self.dec[m], zp)
                 rec = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
-                total = total + mult * self._nll(m, rec, targets[m], mask)
-        return total
+                self._nll(m, rec, targets[m], mask, weight=float(mult), into=total)
+        return total.total()
 
     def sample(self, t_max, b_dim):
         """dks.py:299-342: ancestral sampling from the transition prior (not a hot path: the

@@ -34,6 +34,33 @@ def _n_draws(t_max, sample, n_particles, sample_init):
     return 1 if sample_init else 0
 
 
+class _EagerGradFn(torch.autograd.Function):
+    """fn() -> scalar loss that depends only on `params`: the forward computes the value and,
+    right away, d loss / d params; the backward only scales them by the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, fn, *params):
+        with torch.enable_grad():
+            loss = fn()
+            need = [p for p in params if p.requires_grad]
+            grads = torch.autograd.grad(loss, need, allow_unused=True) if need else ()
+        ctx.slots, kept = [], []
+        it = iter(grads)
+        for p in params:
+            g = next(it) if p.requires_grad else None
+            ctx.slots.append(None if g is None else len(kept))
+            if g is not None:
+                kept.append(g)
+        ctx.save_for_backward(*kept)
+        return loss.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        kept = ctx.saved_tensors
+        scaled = torch._foreach_mul(list(kept), g) if kept else []
+        return (None,) + tuple(None if i is None else scaled[i] for i in ctx.slots)
+
+
 class MultiDMM(MultiDGTS):
     _side_stream = None
     _match_stream = None
@@ -317,7 +344,9 @@ class MultiDMM(MultiDGTS):
         # mask: (T,B) fp32 row mask, or the pair (row mask, row mask tiled over the passes) that
         # `step` prepares once for all its loss terms
         mask, mask_kld = mask if isinstance(mask, tuple) else (mask, mask)
-        total = kld_mult * ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld)
+        # every term adds itself, weighted, to one device accumulator (ops.LossSum)
+        total = ops.LossSum(infer[0].device)
+        ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld, float(kld_mult), total)
         zs = zs.unbind(0)               # per-pass views whose backward is one stack (see _decode_for_loss)
         for m in self.modalities:
             mult = rec_mults.get(m, 1.0)
@@ -325,8 +354,8 @@ class MultiDMM(MultiDGTS):
             if mult == 0 or not used:
                 continue
             for rec in self._decode_for_loss(m, [zs[p] for p in used]):
-                total = total + mult * self._nll(m, rec, targets[m], mask)
-        return total
+                self._nll(m, rec, targets[m], mask, weight=float(mult), into=total)
+        return total.total()
 
     def step(self, inputs, mask, kld_mult, rec_mults, targets=None, uni_loss=True, **kwargs):
         """Bidirectional training step, dmm.py:503-554 (see the module docstring for how the
@@ -384,7 +413,12 @@ class MultiDMM(MultiDGTS):
                 x.record_stream(third)
             third.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(third):
-                loss_m = match_loss()
+                # value AND parameter gradients now, in the forward phase: left to the backward
+                # pass, these ~60 launches are the last thing the autograd engine issues, their
+                # accumulation into the transition gradients waits for the long K-particle sweep,
+                # and they end up as a 0.4 ms tail behind it (tools/step_stamps.py)
+                loss_m = _EagerGradFn.apply(match_loss, self.z0_mean, self.z0_log_std,
+                                            *self._gtf('fwd'), *self._gtf('bwd'))
             loss_m.record_stream(torch.cuda.current_stream())
         enc = {m: self._encode_one(m, inputs[m]) for m in self.modalities if m in inputs}
         # fp32 row masks for all the loss reductions of the step, made once (both streams read them)

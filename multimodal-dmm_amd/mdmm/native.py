@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 SYMBOLS = [
     'mdmm_version', 'mdmm_strerror', 'mdmm_pad', 'mdmm_sizeof',
@@ -24,7 +24,7 @@ SYMBOLS = [
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
     'mdmm_nll_bernoulli_fwd', 'mdmm_nll_bernoulli_bwd',
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
-    'mdmm_philox_normal',
+    'mdmm_philox_normal', 'mdmm_debug_clock',
     'mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd', 'mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd',
     'mdmm_stage_sample', 'mdmm_stage_step_fwd', 'mdmm_stage_fuse_bwd', 'mdmm_stage_trans_bwd',
     'mdmm_stage_adj_reduce',
@@ -136,15 +136,16 @@ def lib():
         L.mdmm_poe_bwd.argtypes = [_P, _P, _P, i32, i64, i32, _P, _P, _P, _P, _P]
         L.mdmm_moe_fwd.argtypes = [_P, _P, _P, i32, i64, i32, _P, _P, _P]
         L.mdmm_moe_bwd.argtypes = [_P, _P, _P, i32, i64, i32, _P, _P, _P, _P, _P, _P, _P]
-        L.mdmm_kld_gauss_fwd.argtypes = [_P, _P, _P, _P, _P, i64, i32, _P, _P]
+        L.mdmm_kld_gauss_fwd.argtypes = [_P, _P, _P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_kld_gauss_bwd.argtypes = [_P, _P, _P, _P, _P, i64, i32, f32, _P, _P, _P, _P, _P, i32, _P]
-        L.mdmm_nll_gauss_fwd.argtypes = [_P, _P, _P, _P, i64, i32, _P, _P]
+        L.mdmm_nll_gauss_fwd.argtypes = [_P, _P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_gauss_bwd.argtypes = [_P, _P, _P, _P, i64, i32, f32, _P, _P, _P, _P]
-        L.mdmm_nll_bernoulli_fwd.argtypes = [_P, _P, _P, i64, i32, _P, _P]
+        L.mdmm_nll_bernoulli_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_bernoulli_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
-        L.mdmm_nll_categorical_fwd.argtypes = [_P, _P, _P, i64, i32, _P, _P]
+        L.mdmm_nll_categorical_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_categorical_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
         L.mdmm_philox_normal.argtypes = [C.c_uint64, C.c_uint64, _P, i64, _P, _P]
+        L.mdmm_debug_clock.argtypes = [_P, _P]
         if L.mdmm_version() != ABI_VERSION:
             raise MdmmError('libmdmm_hip.so ABI %d != binding ABI %d'
                             % (L.mdmm_version(), ABI_VERSION))

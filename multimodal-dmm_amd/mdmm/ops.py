@@ -655,17 +655,62 @@ def _gdev(g):
     return g.detach().to(torch.float32).reshape(1).contiguous()
 
 
+class LossSum:
+    """One weighted sum of loss terms, `sum_i w_i * term_i` (dgts.py:132-145), without a launch
+    per weight or per addition: every term's forward kernel adds `w_i * term_i` into the same
+    fp64 device accumulator, `total()` is one cast, and every term's backward kernel scales by
+    `w_i` times the upstream gradient read from the device.  Pass it as `into=` to kld_gauss /
+    nll_gauss / nll_bernoulli / nll_categorical (which then return nothing of value)."""
+
+    def __init__(self, device):
+        self.acc = torch.zeros(1, dtype=torch.float64, device=device)
+        self.handles = []
+
+    def total(self):
+        """0-dim fp32 loss; call once, after the last term."""
+        return _LossTotalFn.apply(self.acc, *self.handles)
+
+
+class _LossTotalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, acc, *handles):
+        ctx.n = len(handles)
+        return _scalar(acc)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + (g,) * ctx.n
+
+
+def _term_out(acc, into, dev):
+    """What a term's forward returns: its own value, or -- inside a LossSum -- a handle that only
+    ties the term into the autograd graph of LossSum.total() (its value is never read)."""
+    if into is None:
+        return _scalar(acc)
+    return torch.empty((), dtype=torch.float32, device=dev)
+
+
+def _term_acc(into, dev):
+    return into.acc if into is not None else torch.zeros(1, dtype=torch.float64, device=dev)
+
+
+def _term_done(out, into):
+    if into is not None:
+        into.handles.append(out)
+    return out
+
+
 class _KldFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, m1, s1, m2, s2, mask, rows, inner):
+    def forward(ctx, m1, s1, m2, s2, mask, rows, inner, weight, into):
         _need_gpu(m1, s1, m2, s2)
         t = [_f32c(x) for x in (m1, s1, m2, s2)]
-        acc = torch.zeros(1, dtype=torch.float64, device=t[0].device)
-        _call('mdmm_kld_gauss_fwd', *[_ptr(x) for x in t], _ptr(mask), rows, inner,
-                                                     _ptr(acc))
+        acc = _term_acc(into, t[0].device)
+        _call('mdmm_kld_gauss_fwd', *[_ptr(x) for x in t], _ptr(mask), rows, inner, weight,
+              _ptr(acc))
         ctx.save_for_backward(*t)
-        ctx.mask, ctx.rows, ctx.inner = mask, rows, inner
-        return _scalar(acc)
+        ctx.mask, ctx.rows, ctx.inner, ctx.weight = mask, rows, inner, weight
+        return _term_out(acc, into, t[0].device)
 
     @staticmethod
     def backward(ctx, g):
@@ -675,29 +720,31 @@ class _KldFn(torch.autograd.Function):
         # scale is applied on the device side of the tensor product to stay async
         gd = _gdev(g)
         _call('mdmm_kld_gauss_bwd', *[_ptr(x) for x in t], _ptr(ctx.mask), ctx.rows,
-                                                     ctx.inner, 1.0, _ptr(gd), *[_ptr(x) for x in grads], 0)
-        return tuple(grads) + (None, None, None)
+              ctx.inner, ctx.weight, _ptr(gd), *[_ptr(x) for x in grads], 0)
+        return tuple(grads) + (None, None, None, None, None)
 
 
-def kld_gauss(mean_1, std_1, mean_2, std_2, mask=None):
-    """losses.py:14-21; all four tensors share one shape (..., D); mask covers the leading dims."""
+def kld_gauss(mean_1, std_1, mean_2, std_2, mask=None, weight=1.0, into=None):
+    """losses.py:14-21; all four tensors share one shape (..., D); mask covers the leading dims.
+    weight / into: see LossSum."""
     mean_1, std_1, mean_2, std_2 = torch.broadcast_tensors(mean_1, std_1, mean_2, std_2)
     inner = mean_1.shape[-1]
     rows = mean_1.numel() // inner
-    return _KldFn.apply(mean_1, std_1, mean_2, std_2, _row_mask(mask, rows, mean_1), rows, inner)
+    return _term_done(_KldFn.apply(mean_1, std_1, mean_2, std_2, _row_mask(mask, rows, mean_1),
+                                   rows, inner, float(weight), into), into)
 
 
 class _NllGaussFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mean, std, x, mask, rows, inner):
+    def forward(ctx, mean, std, x, mask, rows, inner, weight, into):
         _need_gpu(mean, std, x)
         m, s, xv = _f32c(mean), _f32c(std), _f32c(x)
-        acc = torch.zeros(1, dtype=torch.float64, device=m.device)
-        _call('mdmm_nll_gauss_fwd', _ptr(m), _ptr(s), _ptr(xv), _ptr(mask), rows,
-                                                     inner, _ptr(acc))
+        acc = _term_acc(into, m.device)
+        _call('mdmm_nll_gauss_fwd', _ptr(m), _ptr(s), _ptr(xv), _ptr(mask), rows, inner, weight,
+              _ptr(acc))
         ctx.save_for_backward(m, s, xv)
-        ctx.mask, ctx.rows, ctx.inner = mask, rows, inner
-        return _scalar(acc)
+        ctx.mask, ctx.rows, ctx.inner, ctx.weight = mask, rows, inner, weight
+        return _term_out(acc, into, m.device)
 
     @staticmethod
     def backward(ctx, g):
@@ -705,30 +752,36 @@ class _NllGaussFn(torch.autograd.Function):
         gm, gs = torch.empty_like(m), torch.empty_like(s)
         gd = _gdev(g)
         _call('mdmm_nll_gauss_bwd', _ptr(m), _ptr(s), _ptr(xv), _ptr(ctx.mask),
-                                                     ctx.rows, ctx.inner, 1.0, _ptr(gd), _ptr(gm), _ptr(gs))
-        return gm, gs, None, None, None, None
+              ctx.rows, ctx.inner, ctx.weight, _ptr(gd), _ptr(gm), _ptr(gs))
+        return gm, gs, None, None, None, None, None, None
 
 
-def nll_gauss(mean, std, x, mask=None, lead_dims=2):
-    """losses.py:68-89.  The first `lead_dims` dims of x are (T,B) (or (P*T,B) ...)."""
+def _lead_rows(x, lead_dims):
     rows = 1
     for v in x.shape[:lead_dims]:
         rows *= v
+    return rows
+
+
+def nll_gauss(mean, std, x, mask=None, lead_dims=2, weight=1.0, into=None):
+    """losses.py:68-89.  The first `lead_dims` dims of x are (T,B) (or (P*T,B) ...)."""
+    rows = _lead_rows(x, lead_dims)
     inner = x.numel() // rows
-    return _NllGaussFn.apply(mean, std, x, _row_mask(mask, rows, x), rows, inner)
+    return _term_done(_NllGaussFn.apply(mean, std, x, _row_mask(mask, rows, x), rows, inner,
+                                        float(weight), into), into)
 
 
 class _NllBernFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, theta, x, mask, rows, inner):
+    def forward(ctx, theta, x, mask, rows, inner, weight, into):
         _need_gpu(theta, x)
         th, xv = _f32c(theta), _f32c(x)
-        acc = torch.zeros(1, dtype=torch.float64, device=th.device)
-        _call('mdmm_nll_bernoulli_fwd', _ptr(th), _ptr(xv), _ptr(mask), rows, inner,
-                                                         _ptr(acc))
+        acc = _term_acc(into, th.device)
+        _call('mdmm_nll_bernoulli_fwd', _ptr(th), _ptr(xv), _ptr(mask), rows, inner, weight,
+              _ptr(acc))
         ctx.save_for_backward(th, xv)
-        ctx.mask, ctx.rows, ctx.inner = mask, rows, inner
-        return _scalar(acc)
+        ctx.mask, ctx.rows, ctx.inner, ctx.weight = mask, rows, inner, weight
+        return _term_out(acc, into, th.device)
 
     @staticmethod
     def backward(ctx, g):
@@ -736,30 +789,29 @@ class _NllBernFn(torch.autograd.Function):
         gt = torch.empty_like(th)
         gd = _gdev(g)
         _call('mdmm_nll_bernoulli_bwd', _ptr(th), _ptr(xv), _ptr(ctx.mask),
-                                                         ctx.rows, ctx.inner, 1.0, _ptr(gd), _ptr(gt))
-        return gt, None, None, None, None
+              ctx.rows, ctx.inner, ctx.weight, _ptr(gd), _ptr(gt))
+        return gt, None, None, None, None, None, None
 
 
-def nll_bernoulli(theta, x, mask=None, lead_dims=2):
+def nll_bernoulli(theta, x, mask=None, lead_dims=2, weight=1.0, into=None):
     """losses.py:23-42."""
-    rows = 1
-    for v in x.shape[:lead_dims]:
-        rows *= v
+    rows = _lead_rows(x, lead_dims)
     inner = x.numel() // rows
-    return _NllBernFn.apply(theta, x, _row_mask(mask, rows, x), rows, inner)
+    return _term_done(_NllBernFn.apply(theta, x, _row_mask(mask, rows, x), rows, inner,
+                                       float(weight), into), into)
 
 
 class _NllCatFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, probs, x, mask, rows, n_cat):
+    def forward(ctx, probs, x, mask, rows, n_cat, weight, into):
         _need_gpu(probs, x)
         p, xv = _f32c(probs), _f32c(x)
-        acc = torch.zeros(1, dtype=torch.float64, device=p.device)
-        _call('mdmm_nll_categorical_fwd', _ptr(p), _ptr(xv), _ptr(mask), rows,
-                                                           n_cat, _ptr(acc))
+        acc = _term_acc(into, p.device)
+        _call('mdmm_nll_categorical_fwd', _ptr(p), _ptr(xv), _ptr(mask), rows, n_cat, weight,
+              _ptr(acc))
         ctx.save_for_backward(p, xv)
-        ctx.mask, ctx.rows, ctx.n_cat = mask, rows, n_cat
-        return _scalar(acc)
+        ctx.mask, ctx.rows, ctx.n_cat, ctx.weight = mask, rows, n_cat, weight
+        return _term_out(acc, into, p.device)
 
     @staticmethod
     def backward(ctx, g):
@@ -767,20 +819,19 @@ class _NllCatFn(torch.autograd.Function):
         gp = torch.empty_like(p)
         gd = _gdev(g)
         _call('mdmm_nll_categorical_bwd', _ptr(p), _ptr(xv), _ptr(ctx.mask),
-                                                           ctx.rows, ctx.n_cat, 1.0, _ptr(gd), _ptr(gp))
-        return gp, None, None, None, None
+              ctx.rows, ctx.n_cat, ctx.weight, _ptr(gd), _ptr(gp))
+        return gp, None, None, None, None, None, None
 
 
-def nll_categorical(probs, x, mask=None, lead_dims=2):
+def nll_categorical(probs, x, mask=None, lead_dims=2, weight=1.0, into=None):
     """losses.py:44-66 (reference behaviour: minus the summed probability of the label).
     probs (T,B,K), x (T,B,1) float labels with NaN = missing."""
-    rows = 1
-    for v in x.shape[:lead_dims]:
-        rows *= v
+    rows = _lead_rows(x, lead_dims)
     if x.numel() != rows:
         raise ValueError('categorical targets must have one label per (t, b)')
     n_cat = probs.numel() // rows
-    return _NllCatFn.apply(probs, x, _row_mask(mask, rows, x), rows, n_cat)
+    return _term_done(_NllCatFn.apply(probs, x, _row_mask(mask, rows, x), rows, n_cat,
+                                      float(weight), into), into)
 
 
 def philox_normal(seed, offset, shape, device, offset_dev=None):
