@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 8
+#define MDMM_ABI_VERSION 9
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -355,6 +355,11 @@ int mdmm_debug_clock(unsigned long long* out, void* stream);
  * weight-gradient partial sums per workgroup, every dim padded to a multiple of 16 (h16 = 16 *
  * ceil(H/16) ...):  dW1 (h16,i16) | db1 (h16) | dWm (o16,h16) | dbm (o16) | dWs (o16,h16) | dbs (o16);
  * the caller sums the rows and slices.
+ * Gaussian NLL head (losses.py:68-89), for a decoder whose output is only scored: with nll_target
+ * set, row n is scored against observation row n % nll_rows (passes stacked over one batch; NaN =
+ * missing, nll_mask row 0 = padded).  Forward: *nll_out += nll_weight * NLL, mean / std may be NULL.
+ * Backward: g_mean / g_std are not read -- the kernel forms d(nll_weight * *nll_scale_dev * NLL)
+ * itself, so mean, std and their gradients never exist in HBM.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   int64_t N;
@@ -368,6 +373,13 @@ typedef struct {
   float* g_x;                          /* (N,I) or NULL                                          */
   float* dw_partial;                   /* (dw_partial_rows, mdmm_gauss_mlp_dw_width(I,H,O))      */
   int64_t dw_partial_rows;             /* >= mdmm_gauss_mlp_dw_rows(N)                           */
+  const float* nll_target;             /* (nll_rows, O) or NULL = no NLL head                    */
+  const float* nll_mask;               /* (nll_rows) float 0/1 or NULL                           */
+  int64_t nll_rows;
+  double* nll_out;                     /* forward: fp64 accumulator (shared by a weighted sum)   */
+  const float* nll_scale_dev;          /* backward: upstream gradient, device scalar or NULL = 1 */
+  float nll_weight;
+  int32_t reserved2;
 } mdmm_mlp_t;
 int mdmm_gauss_mlp_supported(int I, int H, int O);
 int mdmm_gauss_mlp_dw_width(int I, int H, int O);

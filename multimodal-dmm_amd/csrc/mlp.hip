@@ -21,6 +21,7 @@ namespace {
 constexpr int NT = 256;
 constexpr int NW = NT / 64;
 constexpr int MAX_BLOCKS = 512;
+constexpr float HALF_LOG_2PI = 0.91893853320467274178f;
 
 template <int IT, int HT, int OT>
 struct LdsM {
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mdmm_mlp_t a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   const bool vec_o = (a.O & 3) == 0;
   const int64_t tiles = (a.N + 15) / 16;
+  float nll = 0.f;
   for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < tiles; tile += (int64_t)gridDim.x * NW) {
     const int64_t row = tile * 16 + j;
     const bool live = row < a.N;
@@ -112,16 +114,33 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mdmm_mlp_t a) {
     gemm_chain<OT, HT, 1>(lds + L::WM, lds + L::BM, lane, a1, mean);
     gemm_chain<OT, HT, 1>(lds + L::WS, lds + L::BS, lane, a1, pre);
     if (live) {
+      const int64_t trow = a.nll_target ? row % a.nll_rows : 0;
+      const bool scored = a.nll_target && !(a.nll_mask && a.nll_mask[trow] == 0.f);
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) {
         f32x4 sd;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sd[r] = softplusf_(pre[ot][0][r]) + a.min_std;
-        st4_guard(a.mean, (size_t)row * a.O, vec_o, 16 * ot + 4 * g, a.O, mean[ot][0]);
-        st4_guard(a.std, (size_t)row * a.O, vec_o, 16 * ot + 4 * g, a.O, sd);
+        if (a.mean) st4_guard(a.mean, (size_t)row * a.O, vec_o, 16 * ot + 4 * g, a.O, mean[ot][0]);
+        if (a.std) st4_guard(a.std, (size_t)row * a.O, vec_o, 16 * ot + 4 * g, a.O, sd);
+        if (scored) {                                            // losses.py:79-86
+          const f32x4 xv = ld4_guard(a.nll_target, (size_t)trow * a.O, vec_o, 16 * ot + 4 * g, a.O);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (16 * ot + 4 * g + r >= a.O || xv[r] != xv[r]) continue;
+            const float q = (xv[r] - mean[ot][0][r]) / sd[r];
+            nll += 0.5f * q * q + logf(sd[r]) + HALF_LOG_2PI;
+          }
+        }
       }
       if (a.seen && g == 0) a.seen[row] = seen;
     }
+  }
+  if (a.nll_target) {                     // one fp64 atomic per wave
+    double v = (double)nll;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) atomicAdd(a.nll_out, (double)a.nll_weight * v);
   }
 }
 
@@ -139,6 +158,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mdmm_mlp_t a) {
   float* scratch = scratch0 + wave * L::SCR;
   const bool vec_i = (a.I & 3) == 0, vec_o = (a.O & 3) == 0;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const float nll_scale = a.nll_weight * (a.nll_scale_dev ? *a.nll_scale_dev : 1.0f);
   f32x4 dW1[HT][IT], dWm[OT][HT], dWs[OT][HT];
   float db1[HT], dbm[OT], dbs[OT];
 #pragma unroll
@@ -162,13 +182,37 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mdmm_mlp_t a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[ht][0][r] = fmaxf(a1[ht][0][r], 0.f);
     gemm_chain<OT, HT, 1>(lds + L::WS, lds + L::BS, lane, h, pre);
+    if (a.nll_target) {
+      // adjoints of the fused NLL head: needs the mean too (one more chained contraction)
+      f32x4 mean[OT][1];
+      gemm_chain<OT, HT, 1>(lds + L::WM, lds + L::BM, lane, h, mean);
+      const int64_t trow = live ? row % a.nll_rows : 0;
+      const bool scored = live && !(a.nll_mask && a.nll_mask[trow] == 0.f);
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) {
-      const int d0 = 16 * ot + 4 * g;
-      gm[ot][0] = live ? ld4_guard(a.g_mean, (size_t)row * a.O, vec_o, d0, a.O) : zero4;
-      const f32x4 gs = live ? ld4_guard(a.g_std, (size_t)row * a.O, vec_o, d0, a.O) : zero4;
+      for (int ot = 0; ot < OT; ++ot) {
+        const int d0 = 16 * ot + 4 * g;
+        const f32x4 xv = scored ? ld4_guard(a.nll_target, (size_t)trow * a.O, vec_o, d0, a.O) : zero4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gp[ot][0][r] = gs[r] * softplus_grad_(pre[ot][0][r]);
+        for (int r = 0; r < 4; ++r) {
+          float g_m = 0.f, g_s = 0.f;
+          if (scored && d0 + r < a.O && xv[r] == xv[r]) {
+            const float sd = softplusf_(pre[ot][0][r]) + a.min_std, d = xv[r] - mean[ot][0][r];
+            g_m = -nll_scale * d / (sd * sd);
+            g_s = nll_scale * (1.0f / sd - d * d / (sd * sd * sd));
+          }
+          gm[ot][0][r] = g_m;
+          gp[ot][0][r] = g_s * softplus_grad_(pre[ot][0][r]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const int d0 = 16 * ot + 4 * g;
+        gm[ot][0] = live ? ld4_guard(a.g_mean, (size_t)row * a.O, vec_o, d0, a.O) : zero4;
+        const f32x4 gs = live ? ld4_guard(a.g_std, (size_t)row * a.O, vec_o, d0, a.O) : zero4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gp[ot][0][r] = gs[r] * softplus_grad_(pre[ot][0][r]);
+      }
     }
     // hidden adjoint through both heads and the ReLU
     f32x4 ga[HT][1];
@@ -276,7 +320,7 @@ extern "C" int64_t mdmm_gauss_mlp_dw_rows(int64_t N) { return grid_for(N); }
 extern "C" int mdmm_gauss_mlp_fwd(const mdmm_mlp_t* a, void* stream) {
   int rc = check(a);
   if (rc) return rc;
-  if (!a->mean || !a->std) return MDMM_E_ARG;
+  if (a->nll_target ? (!a->nll_out || a->nll_rows < 1) : (!a->mean || !a->std)) return MDMM_E_ARG;
   if (a->N == 0) return 0;
   return dispatch(a, false, (hipStream_t)stream);
 }
@@ -285,5 +329,6 @@ extern "C" int mdmm_gauss_mlp_bwd(const mdmm_mlp_t* a, void* stream) {
   int rc = check(a);
   if (rc) return rc;
   if (!a->dw_partial || a->dw_partial_rows < grid_for(a->N)) return MDMM_E_ARG;
+  if (a->nll_target ? a->nll_rows < 1 : (!a->g_mean || !a->g_std)) return MDMM_E_ARG;
   return dispatch(a, true, (hipStream_t)stream);
 }

@@ -336,6 +336,12 @@ class MultiDMM(MultiDGTS):
         out = [r.reshape(n, t_max, b_dim, *r.shape[1:]).unbind(0) for r in out]
         return [tuple(r[i] for r in out) for i in range(n)]
 
+    def _fused_nll(self, m, z):
+        dec = self.dec[m]
+        return (self.dists[m] == 'Normal' and type(dec) is common.GaussianMLP
+                and self.plugin_dtype is None and not torch.is_autocast_enabled()
+                and z.dtype == torch.float32 and ops.gauss_mlp_supported(z.reshape(-1, self.z_dim), dec))
+
     def _mode_loss(self, enc, targets, mask, kld_mult, rec_mults, pass_mods, loss_mods, t_max,
                    b_dim, mode, sample, sample_init, flt_particles, smt_particles):
         """sum over passes of [kld_mult*KLD + sum_m mult_m*NLL_m]  (dgts.py:119-129, 132-145)"""
@@ -347,11 +353,22 @@ class MultiDMM(MultiDGTS):
         # every term adds itself, weighted, to one device accumulator (ops.LossSum)
         total = ops.LossSum(infer[0].device)
         ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld, float(kld_mult), total)
+        zs_all = zs
         zs = zs.unbind(0)               # per-pass views whose backward is one stack (see _decode_for_loss)
         for m in self.modalities:
             mult = rec_mults.get(m, 1.0)
             used = [p for p, mods in enumerate(loss_mods) if m in mods]
             if mult == 0 or not used:
+                continue
+            if self._fused_nll(m, zs_all):
+                # stock GaussianMLP decoder scored by nll_gauss: one launch each way, the
+                # reconstruction itself is never written (csrc/mlp.hip, NLL head)
+                if used == list(range(used[0], used[-1] + 1)):
+                    z = zs_all[used[0]:used[-1] + 1]
+                else:
+                    z = torch.stack([zs[p] for p in used])
+                ops.gauss_mlp_nll(z.reshape(-1, self.z_dim), self.dec[m], targets[m], mask,
+                                  weight=float(mult), into=total)
                 continue
             for rec in self._decode_for_loss(m, [zs[p] for p in used]):
                 self._nll(m, rec, targets[m], mask, weight=float(mult), into=total)

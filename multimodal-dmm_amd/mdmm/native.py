@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 SYMBOLS = [
     'mdmm_version', 'mdmm_strerror', 'mdmm_pad', 'mdmm_sizeof',
@@ -91,7 +91,9 @@ class Mlp(C.Structure):
                  ('nan_to_zero', C.c_int32), ('min_std', C.c_float), ('reserved', C.c_int32)] +
                 [(n, _P) for n in ('x', 'w1', 'b1', 'wm', 'bm', 'ws', 'bs', 'mean', 'std', 'seen',
                                    'g_mean', 'g_std', 'g_x', 'dw_partial')] +
-                [('dw_partial_rows', C.c_int64)])
+                [('dw_partial_rows', C.c_int64), ('nll_target', _P), ('nll_mask', _P),
+                 ('nll_rows', C.c_int64), ('nll_out', _P), ('nll_scale_dev', _P),
+                 ('nll_weight', C.c_float), ('reserved2', C.c_int32)])
 
 
 class MdmmError(RuntimeError):

@@ -941,13 +941,7 @@ class _GaussMlpFn(torch.autograd.Function):
         a.g_mean, a.g_std = _ptr(g_mean), _ptr(g_std)
         a.g_x, a.dw_partial, a.dw_partial_rows = _ptr(g_x), _ptr(part), rows
         _call('mdmm_gauss_mlp_bwd', C.byref(a), tag='gauss_mlp_bwd')
-        row = part.sum(0)           # every dim padded to a multiple of 16 (csrc/mlp.hip, LdsM)
-        i16, h16, o16 = (16 * ((d + 15) // 16) for d in (i_dim, h_dim, o_dim))
-        w1, b1, wm, bm, ws, bs = row.split([h16 * i16, h16, o16 * h16, o16, o16 * h16, o16])
-        grads = [w1.view(h16, i16)[:h_dim, :i_dim], b1[:h_dim],
-                 wm.view(o16, h16)[:o_dim, :h_dim], bm[:o_dim],
-                 ws.view(o16, h16)[:o_dim, :h_dim], bs[:o_dim]]
-        return (g_x, *[g.contiguous() for g in grads], None, None)
+        return (g_x, *_mlp_weight_grads(part, i_dim, h_dim, o_dim), None, None)
 
 
 def gauss_mlp_supported(x, module):
@@ -966,6 +960,76 @@ def gauss_mlp(x, module, nan_to_zero=False):
     l1, lm, ls = module.in_to_h[0], module.h_to_mean, module.h_to_std[0]
     return _GaussMlpFn.apply(x, l1.weight, l1.bias, lm.weight, lm.bias, ls.weight, ls.bias,
                              float(module.min_std), bool(nan_to_zero))
+
+
+class _GaussMlpNllFn(torch.autograd.Function):
+    """GaussianMLP decoder + Gaussian NLL of its output in one launch each way (csrc/mlp.hip,
+    nll_* fields of mdmm_mlp_t): rows of x are P stacked passes over one batch, every row is scored
+    against observation row n % nll_rows; mean, std and their gradients never reach HBM."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, wm, bm, ws, bs, min_std, target, mask, weight, into):
+        _need_gpu(x, w1, target)
+        x = _f32c(x.detach())
+        wts = [_f32c(t.detach()) for t in (w1, b1, wm, bm, ws, bs)]
+        target = _f32c(target)
+        acc = _term_acc(into, x.device)
+        a = _GaussMlpNllFn._args(x, wts, min_std, target, mask, weight)
+        a.nll_out = _ptr(acc)
+        _call('mdmm_gauss_mlp_fwd', C.byref(a), tag='gauss_mlp_nll_fwd')
+        ctx.save_for_backward(x, target, *wts)
+        ctx.cfg = (float(min_std), mask, float(weight))
+        return _term_out(acc, into, x.device)
+
+    @staticmethod
+    def _args(x, wts, min_std, target, mask, weight):
+        n, i_dim = x.shape
+        a = native.Mlp()
+        a.N, a.I, a.H, a.O = n, i_dim, wts[0].shape[0], wts[2].shape[0]
+        a.nan_to_zero, a.min_std = 0, float(min_std)
+        a.x = _ptr(x)
+        a.w1, a.b1, a.wm, a.bm, a.ws, a.bs = [_ptr(t) for t in wts]
+        a.nll_target, a.nll_mask = _ptr(target), _ptr(mask)
+        a.nll_rows, a.nll_weight = target.shape[0], float(weight)
+        return a
+
+    @staticmethod
+    def backward(ctx, g):
+        x, target, *wts = ctx.saved_tensors
+        min_std, mask, weight = ctx.cfg
+        n, i_dim = x.shape
+        h_dim, o_dim = wts[0].shape[0], wts[2].shape[0]
+        L = native.lib()
+        rows = L.mdmm_gauss_mlp_dw_rows(n)
+        part = torch.empty(rows, L.mdmm_gauss_mlp_dw_width(i_dim, h_dim, o_dim), device=x.device,
+                           dtype=torch.float32)
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        a = _GaussMlpNllFn._args(x, wts, min_std, target, mask, weight)
+        gd = _gdev(g)
+        a.nll_scale_dev = _ptr(gd)
+        a.g_x, a.dw_partial, a.dw_partial_rows = _ptr(g_x), _ptr(part), rows
+        _call('mdmm_gauss_mlp_bwd', C.byref(a), tag='gauss_mlp_nll_bwd')
+        return (g_x, *_mlp_weight_grads(part, i_dim, h_dim, o_dim), None, None, None, None, None)
+
+
+def _mlp_weight_grads(part, i_dim, h_dim, o_dim):
+    row = part.sum(0)           # every dim padded to a multiple of 16 (csrc/mlp.hip, LdsM)
+    i16, h16, o16 = (16 * ((d + 15) // 16) for d in (i_dim, h_dim, o_dim))
+    w1, b1, wm, bm, ws, bs = row.split([h16 * i16, h16, o16 * h16, o16, o16 * h16, o16])
+    grads = [w1.view(h16, i16)[:h_dim, :i_dim], b1[:h_dim],
+             wm.view(o16, h16)[:o_dim, :h_dim], bm[:o_dim],
+             ws.view(o16, h16)[:o_dim, :h_dim], bs[:o_dim]]
+    return [g.contiguous() for g in grads]
+
+
+def gauss_mlp_nll(x, module, target, mask=None, weight=1.0, into=None):
+    """nll_gauss(*GaussianMLP(x), target) (common.py:25-41 + losses.py:68-89), fused.
+    x (P*R, I) stacked passes, target (R, O) with NaN = missing, mask covers the R rows."""
+    l1, lm, ls = module.in_to_h[0], module.h_to_mean, module.h_to_std[0]
+    target = target.reshape(-1, lm.weight.shape[0])
+    return _term_done(_GaussMlpNllFn.apply(
+        x, l1.weight, l1.bias, lm.weight, lm.bias, ls.weight, ls.bias, float(module.min_std),
+        target, _row_mask(mask, target.shape[0], target), float(weight), into), into)
 
 
 def _pad2(w, r, c):
