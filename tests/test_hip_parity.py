@@ -190,6 +190,43 @@ def test_fused_gauss_mlp_matches_stock_modules(dims, dev):
     close(m2, mean.detach(), 1e-6, 'module mean'); close(s2, std.detach(), 1e-6, 'module std')
 
 
+@pytest.mark.parametrize('dims', [(32, 32, 1), (5, 20, 3), (17, 9, 32), (8, 16, 4)])
+def test_fused_decoder_nll_head_matches_oracle(dims, dev):
+    """GaussianMLP decoder + nll_gauss in one launch each way (csrc/mlp.hip NLL head) vs the
+    oracle's nll_gauss (losses.py:68-89) of the holder's plain fp64 forward: two stacked passes
+    over one batch, NaN observations, padded rows, a weight, inside an ops.LossSum."""
+    from mdmm import ops
+    from mdmm.models import common
+    i_dim, h_dim, o_dim = dims
+    torch.manual_seed(5)
+    t_max, b_dim, n_pass = 9, 13, 2
+    rows = t_max * b_dim
+    mod = common.GaussianMLP(i_dim, o_dim, h_dim).to(dev)
+    ref = common.GaussianMLP(i_dim, o_dim, h_dim).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in mod.state_dict().items()})
+    z = torch.randn(n_pass * rows, i_dim)
+    target = torch.randn(t_max, b_dim, o_dim)
+    target[2, 3] = float('nan'); target[5, 1, o_dim - 1] = float('nan')
+    mask = orc.len_to_mask([9, 9, 8, 8, 7, 7, 6, 5, 4, 3, 2, 1, 1])
+    zr = z.double().requires_grad_()
+    zg = z.to(dev).requires_grad_()
+    acc = ops.LossSum(dev)
+    ops.gauss_mlp_nll(zg, mod, target.to(dev), mask.to(dev), weight=0.7, into=acc)
+    ops.kld_gauss(zg[:4], zg[:4].abs() + 1, zg[4:8], zg[4:8].abs() + 2, None, 0.25, acc)
+    loss = acc.total()
+    r_mean, r_std = ref(zr)
+    want = sum(0.7 * orc.nll_gauss(r_mean[p * rows:(p + 1) * rows].reshape(t_max, b_dim, o_dim),
+                                   r_std[p * rows:(p + 1) * rows].reshape(t_max, b_dim, o_dim),
+                                   target.double(), mask) for p in range(n_pass))
+    want = want + 0.25 * orc.kld_gauss(zr[:4], zr[:4].abs() + 1, zr[4:8], zr[4:8].abs() + 2)
+    close(loss, want.float(), 1e-5, 'loss')
+    (loss * 1.5).backward()
+    (want * 1.5).backward()
+    close(zg.grad, zr.grad.float(), 1e-4, 'g_z')
+    for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        close(p.grad, q.grad.float(), 1e-4, k)
+
+
 @pytest.mark.parametrize('case,zd,hd', [('gtf_z5', 5, 20), ('gtf_z32', 32, 32)])
 def test_transition_kernel_vs_golden_gtf(case, zd, hd, dev):
     """z_next on K=1 rows == PoE(global prior, GTF(z)); the golden pins the GTF itself, the
