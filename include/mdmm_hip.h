@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 9
+#define MDMM_ABI_VERSION 10
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -65,6 +65,18 @@ typedef struct mdmm_gtf {
   const float* wt_std;  /* [Dp][Dp] */
   const float* b_std;   /* [Dp]     */
 } mdmm_gtf_t;
+
+/* Pack the 12 raw GaussianGTF tensors (PyTorch [out][in] weights + biases, in the module order
+ * of common.py:45-60: z_to_gate.0, z_to_gate.2, z_lin, z_nonlin.0, z_nonlin.2, z_to_std.0, each
+ * weight then bias) into one buffer of mdmm_gtf_pack_size(D,H) floats laid out in the field
+ * order of mdmm_gtf_t: w_in | wt_in | b_in | w_gate | wt_gate | b_gate | w_nl | wt_nl | b_nl | w_std
+ * | wt_std | b_std, padding zero-filled: one launch per direction per optimizer step.  */
+typedef struct {
+  const float *w_gate0, *b_gate0, *w_gate2, *b_gate2, *w_lin, *b_lin,
+              *w_nl0, *b_nl0, *w_nl2, *b_nl2, *w_std0, *b_std0;
+} mdmm_gtf_raw_t;
+int64_t mdmm_gtf_pack_size(int D, int H);
+int mdmm_gtf_pack(const mdmm_gtf_raw_t* raw, int D, int H, float* out, void* stream);
 
 /* One Gaussian expert entering the per-step product of experts (dgts.py:15-51).
  * mean/std are (T,B,D) (pass_stride == 0: shared by all passes, e.g. an encoder

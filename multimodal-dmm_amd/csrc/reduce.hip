@@ -408,6 +408,66 @@ extern "C" int mdmm_philox_normal(uint64_t seed, uint64_t offset, const uint64_t
   CHECK_LAUNCH();
 }
 
+// ---------------------------------------------------------------- GTF weight packing --
+// element idx of the packed buffer (field order of mdmm_gtf_t) <- the raw module tensors
+__global__ __launch_bounds__(NT) void gtf_pack_kernel(const mdmm_gtf_raw_t raw, int D, int H, int Dp,
+                                                      int Hp, float* __restrict__ out) {
+  const int F1 = 2 * Hp + Dp;
+  const int n_in = F1 * Dp, n_dh = Dp * Hp, n_dd = Dp * Dp;
+  const int total = 2 * n_in + F1 + 2 * (2 * n_dh + Dp) + 2 * n_dd + Dp;
+  // w_in[f][d]: the three row blocks of the first layer (gate.0 | nonlin.0 | lin)
+  auto w_in = [&](int f, int d) -> float {
+    if (d >= D) return 0.f;
+    if (f < Hp) return f < H ? raw.w_gate0[f * D + d] : 0.f;
+    if (f < 2 * Hp) return f - Hp < H ? raw.w_nl0[(f - Hp) * D + d] : 0.f;
+    return f - 2 * Hp < D ? raw.w_lin[(f - 2 * Hp) * D + d] : 0.f;
+  };
+  auto b_in = [&](int f) -> float {
+    if (f < Hp) return f < H ? raw.b_gate0[f] : 0.f;
+    if (f < 2 * Hp) return f - Hp < H ? raw.b_nl0[f - Hp] : 0.f;
+    return f - 2 * Hp < D ? raw.b_lin[f - 2 * Hp] : 0.f;
+  };
+  for (int i = blockIdx.x * NT + threadIdx.x; i < total; i += gridDim.x * NT) {
+    int k = i;
+    float v;
+    if (k < n_in) v = w_in(k / Dp, k % Dp);
+    else if ((k -= n_in) < n_in) v = w_in(k % F1, k / F1);                       // wt_in [Dp][F1]
+    else if ((k -= n_in) < F1) v = b_in(k);
+    else {
+      k -= F1;
+      // three second-layer blocks: (w [Dp][X], wt [X][Dp], b [Dp]) with X = Hp, Hp, Dp
+      const float* w[3] = {raw.w_gate2, raw.w_nl2, raw.w_std0};
+      const float* b[3] = {raw.b_gate2, raw.b_nl2, raw.b_std0};
+      v = 0.f;
+      for (int blk = 0; blk < 3; ++blk) {
+        const int X = blk < 2 ? Hp : Dp, Xv = blk < 2 ? H : D, n = Dp * X;
+        if (k < n) { const int r = k / X, c = k % X; v = (r < D && c < Xv) ? w[blk][r * Xv + c] : 0.f; break; }
+        k -= n;
+        if (k < n) { const int c = k / Dp, r = k % Dp; v = (r < D && c < Xv) ? w[blk][r * Xv + c] : 0.f; break; }
+        k -= n;
+        if (k < Dp) { v = k < D ? b[blk][k] : 0.f; break; }
+        k -= Dp;
+      }
+    }
+    out[i] = v;
+  }
+}
+
+extern "C" int64_t mdmm_gtf_pack_size(int D, int H) {
+  const int64_t Dp = (D + 3) & ~3, Hp = (H + 3) & ~3, F1 = 2 * Hp + Dp;
+  return 2 * F1 * Dp + F1 + 2 * (2 * Dp * Hp + Dp) + 2 * Dp * Dp + Dp;
+}
+
+extern "C" int mdmm_gtf_pack(const mdmm_gtf_raw_t* raw, int D, int H, float* out, void* stream) {
+  if (!raw || !out || D < 1 || H < 1) return MDMM_E_ARG;
+  const float* const* p = reinterpret_cast<const float* const*>(raw);
+  for (int i = 0; i < 12; ++i) if (!p[i]) return MDMM_E_ARG;
+  const int64_t total = mdmm_gtf_pack_size(D, H);
+  hipLaunchKernelGGL(gtf_pack_kernel, dim3(grid_for(total)), dim3(NT), 0, STREAM, *raw, D, H,
+                     (D + 3) & ~3, (H + 3) & ~3, out);
+  CHECK_LAUNCH();
+}
+
 __global__ void clock_kernel(unsigned long long* out) { *out = wall_clock64(); }
 
 extern "C" int mdmm_debug_clock(unsigned long long* out, void* stream) {

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 SYMBOLS = [
     'mdmm_version', 'mdmm_strerror', 'mdmm_pad', 'mdmm_sizeof',
@@ -24,7 +24,7 @@ SYMBOLS = [
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
     'mdmm_nll_bernoulli_fwd', 'mdmm_nll_bernoulli_bwd',
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
-    'mdmm_philox_normal', 'mdmm_debug_clock',
+    'mdmm_philox_normal', 'mdmm_debug_clock', 'mdmm_gtf_pack_size', 'mdmm_gtf_pack',
     'mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd', 'mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd',
     'mdmm_stage_sample', 'mdmm_stage_step_fwd', 'mdmm_stage_fuse_bwd', 'mdmm_stage_trans_bwd',
     'mdmm_stage_adj_reduce',
@@ -38,6 +38,11 @@ _P = C.c_void_p
 class Gtf(C.Structure):
     _fields_ = [(n, _P) for n in ('w_in', 'wt_in', 'b_in', 'w_gate', 'wt_gate', 'b_gate',
                                   'w_nl', 'wt_nl', 'b_nl', 'w_std', 'wt_std', 'b_std')]
+
+
+class GtfRaw(C.Structure):
+    _fields_ = [(n, _P) for n in ('w_gate0', 'b_gate0', 'w_gate2', 'b_gate2', 'w_lin', 'b_lin',
+                                  'w_nl0', 'b_nl0', 'w_nl2', 'b_nl2', 'w_std0', 'b_std0')]
 
 
 class Expert(C.Structure):
@@ -148,6 +153,9 @@ def lib():
         L.mdmm_nll_categorical_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
         L.mdmm_philox_normal.argtypes = [C.c_uint64, C.c_uint64, _P, i64, _P, _P]
         L.mdmm_debug_clock.argtypes = [_P, _P]
+        L.mdmm_gtf_pack_size.argtypes = [C.c_int, C.c_int]
+        L.mdmm_gtf_pack_size.restype = C.c_int64
+        L.mdmm_gtf_pack.argtypes = [C.POINTER(GtfRaw), C.c_int, C.c_int, _P, _P]
         if L.mdmm_version() != ABI_VERSION:
             raise MdmmError('libmdmm_hip.so ABI %d != binding ABI %d'
                             % (L.mdmm_version(), ABI_VERSION))

@@ -112,18 +112,31 @@ class PackedGtf:
             out[:b.shape[0]] = b
             return out
 
-        w_in = torch.cat([padded(W1g, Hp, Dp), padded(W1n, Hp, Dp), padded(Wl, Dp, Dp)], 0)
-        b_in = torch.cat([padded1(b1g, Hp), padded1(b1n, Hp), padded1(bl, Dp)])
-        w_gate, w_nl, w_std = padded(W2g, Dp, Hp), padded(W2n, Dp, Hp), padded(Ws, Dp, Dp)
-        pieces = [('w_in', w_in), ('wt_in', w_in.t()), ('b_in', b_in),
-                  ('w_gate', w_gate), ('wt_gate', w_gate.t()), ('b_gate', padded1(b2g, Dp)),
-                  ('w_nl', w_nl), ('wt_nl', w_nl.t()), ('b_nl', padded1(b2n, Dp)),
-                  ('w_std', w_std), ('wt_std', w_std.t()), ('b_std', padded1(bs, Dp))]
-        self.buf = torch.cat([p.reshape(-1) for _, p in pieces])   # every piece a multiple of 4
+        F1 = self.F1
+        sizes = [('w_in', F1 * Dp), ('wt_in', Dp * F1), ('b_in', F1),
+                 ('w_gate', Dp * Hp), ('wt_gate', Hp * Dp), ('b_gate', Dp),
+                 ('w_nl', Dp * Hp), ('wt_nl', Hp * Dp), ('b_nl', Dp),
+                 ('w_std', Dp * Dp), ('wt_std', Dp * Dp), ('b_std', Dp)]
         self.offsets, off = {}, 0
-        for name, p in pieces:
+        for name, n in sizes:               # every piece a multiple of 4 floats
             self.offsets[name] = off
-            off += p.numel()
+            off += n
+        if dev.type == 'cuda':              # one launch (mdmm_gtf_pack) instead of ~7 copies and cats
+            raw = native.GtfRaw()
+            keep = [_f32c(p.detach()) for p in params]
+            for (name, _), t in zip(native.GtfRaw._fields_, keep):
+                setattr(raw, name, _ptr(t))
+            assert off == native.lib().mdmm_gtf_pack_size(D, H)
+            self.buf = torch.empty(off, device=dev, dtype=torch.float32)
+            _call('mdmm_gtf_pack', C.byref(raw), D, H, _ptr(self.buf))
+        else:                               # host-side layout reference (CPU tests of the layout)
+            w_in = torch.cat([padded(W1g, Hp, Dp), padded(W1n, Hp, Dp), padded(Wl, Dp, Dp)], 0)
+            b_in = torch.cat([padded1(b1g, Hp), padded1(b1n, Hp), padded1(bl, Dp)])
+            w_gate, w_nl, w_std = padded(W2g, Dp, Hp), padded(W2n, Dp, Hp), padded(Ws, Dp, Dp)
+            pieces = [w_in, w_in.t(), b_in, w_gate, w_gate.t(), padded1(b2g, Dp),
+                      w_nl, w_nl.t(), padded1(b2n, Dp), w_std, w_std.t(), padded1(bs, Dp)]
+            self.buf = torch.cat([p.reshape(-1) for p in pieces])
+            assert self.buf.numel() == off
         assert self.buf.data_ptr() % 16 == 0
 
     def fill(self, g):

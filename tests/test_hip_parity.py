@@ -227,6 +227,19 @@ def test_fused_decoder_nll_head_matches_oracle(dims, dev):
         close(p.grad, q.grad.float(), 1e-4, k)
 
 
+@pytest.mark.parametrize('zd,hd', [(5, 20), (6, 12), (32, 32), (17, 9), (1, 3)])
+def test_gtf_pack_kernel_matches_host_layout(zd, hd, dev):
+    """mdmm_gtf_pack (one launch) == the documented mdmm_gtf_t layout built with torch ops."""
+    from mdmm import ops
+    from mdmm.models import common
+    torch.manual_seed(11)
+    gtf = common.GaussianGTF(zd, hd)
+    host = ops.PackedGtf(ops.gtf_param_list(gtf), zd, hd)
+    gpu = ops.PackedGtf(ops.gtf_param_list(gtf.to(dev)), zd, hd)
+    assert host.offsets == gpu.offsets
+    assert torch.equal(gpu.buf.cpu(), host.buf)
+
+
 @pytest.mark.parametrize('case,zd,hd', [('gtf_z5', 5, 20), ('gtf_z32', 32, 32)])
 def test_transition_kernel_vs_golden_gtf(case, zd, hd, dev):
     """z_next on K=1 rows == PoE(global prior, GTF(z)); the golden pins the GTF itself, the
