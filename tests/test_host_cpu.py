@@ -236,3 +236,27 @@ def test_harness_anneal_and_bucket():
     x = {'a': torch.arange(24.).reshape(3, 8, 1)}
     xs, ms, ls = harness.shard_batch(x, torch.ones(3, 8, 1), [3] * 8, 1, 4)
     assert xs['a'].shape == (3, 2, 1) and ls == [3, 3] and torch.equal(xs['a'], x['a'][:, 2:4])
+
+
+def test_eager_grad_function_matches_plain_autograd():
+    """models/dmm.py::_EagerGradFn (value and parameter gradients computed in the forward phase,
+    scaled in the backward) is the same function of its parameters as running fn() directly."""
+    from mdmm.models.dmm import _EagerGradFn
+    torch.manual_seed(0)
+    a = torch.randn(3, 4, requires_grad=True)
+    b = torch.randn(4, requires_grad=True)
+    c = torch.randn(2, requires_grad=True)           # not used by fn: gradient stays None
+    frozen = torch.randn(4)                          # requires_grad False
+
+    def fn():
+        return ((a * frozen).sum(0) * b).pow(2).sum()
+
+    scale = torch.tensor(0.37, requires_grad=True)
+    out = _EagerGradFn.apply(fn, a, b, c, frozen) * scale
+    out.backward()
+    got = (a.grad.clone(), b.grad.clone(), c.grad, scale.grad.clone())
+    for t in (a, b, scale):
+        t.grad = None
+    (fn() * scale).backward()
+    assert torch.allclose(got[0], a.grad) and torch.allclose(got[1], b.grad)
+    assert got[2] is None and torch.allclose(got[3], scale.grad)
