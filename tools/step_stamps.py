@@ -39,6 +39,8 @@ def wrap_bwd(cls, label):       # stamps around a Function's backward (runs on t
     cls.backward = staticmethod(backward)
 wrap_bwd(ops._SweepFn, lambda ctx: 'sweep K=%d %s' % (ctx.cfg.K, 'rev' if ctx.cfg.reverse else 'fwd'))
 wrap_bwd(ops._GaussMlpFn, lambda ctx: 'mlp')
+wrap_bwd(ops._GaussMlpNllFn, lambda ctx: 'decoder+nll')
+wrap_bwd(ops._LossTotalFn, lambda ctx: 'loss total (%d terms)' % ctx.n)
 wrap_bwd(ops._KldFn, lambda ctx: 'kld rows=%d' % ctx.rows)
 
 orig_enc, orig_run, orig_mode, orig_step = m._encode_one, m._run_passes, m._mode_loss, m.step
@@ -61,7 +63,8 @@ orig_opt = opt.step
 def opt_step(*a, **kw):
     out = orig_opt(*a, **kw); stamp('adam done'); return out
 opt.step = opt_step
-g = GraphedElboStep(m, opt, bucket, inputs, mask, lengths, 1.0, rec, targets=targets, train_particles=K)
+extra = {'match_mult': 0.0} if os.environ.get('MATCH') == '0' else {}
+g = GraphedElboStep(m, opt, bucket, inputs, mask, lengths, 1.0, rec, targets=targets, train_particles=K, **extra)
 live[0] = False
 for _ in range(5): g()
 torch.cuda.synchronize(); t0 = time.perf_counter()
