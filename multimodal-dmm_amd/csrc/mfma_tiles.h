@@ -142,10 +142,10 @@ __device__ __forceinline__ float multi_row16_sum(const float (&v)[N], int j) {
 // db[ot] (per lane: feature 16ot + (lane & 15), rows 4g..4g+3 of the tile) += row sums of G, taken
 // from the A fragments that are loaded anyway -- one float per output tile instead of a C-layout
 // f32x4 per tile (the bias accumulators were a third of the backward kernel's live registers).
+// first half: the [feature][row] images of G and X into LDS
 template <int OT, int KT, int CT>
-__device__ __forceinline__ void dw_accumulate(float* scratch, int lane, const f32x4 (&G)[OT][CT],
-                                              const f32x4 (&X)[KT][CT], f32x4 (&acc)[OT][KT],
-                                              float (&db)[OT]) {
+__device__ __forceinline__ void dw_put(float* scratch, int lane, const f32x4 (&G)[OT][CT],
+                                       const f32x4 (&X)[KT][CT]) {
   constexpr int RS = 16 * CT + 4;
   const int j = lane & 15, g = lane >> 4;
   float* gt = scratch;
@@ -162,8 +162,16 @@ __device__ __forceinline__ void dw_accumulate(float* scratch, int lane, const f3
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) xt[(16 * kt + 4 * g + r) * RS + 16 * ct + j] = X[kt][ct][r];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+}
+
+// second half: A / B fragments back from the images, accumulate (any wave may do this part)
+template <int OT, int KT, int CT>
+__device__ __forceinline__ void dw_take(const float* scratch, int lane, f32x4 (&acc)[OT][KT],
+                                        float (&db)[OT]) {
+  constexpr int RS = 16 * CT + 4;
+  const int j = lane & 15, g = lane >> 4;
+  const float* gt = scratch;
+  const float* xt = scratch + OT * 16 * RS;
   f32x4 b[KT][CT];
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt)
@@ -185,6 +193,16 @@ __device__ __forceinline__ void dw_accumulate(float* scratch, int lane, const f3
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[ot][kt] = mfma16(av[c][r], b[kt][c][r], acc[ot][kt]);
   }
+}
+
+template <int OT, int KT, int CT>
+__device__ __forceinline__ void dw_accumulate(float* scratch, int lane, const f32x4 (&G)[OT][CT],
+                                              const f32x4 (&X)[KT][CT], f32x4 (&acc)[OT][KT],
+                                              float (&db)[OT]) {
+  dw_put<OT, KT, CT>(scratch, lane, G, X);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  dw_take<OT, KT, CT>(scratch, lane, acc, db);
   __builtin_amdgcn_wave_barrier();
 }
 

@@ -663,15 +663,26 @@ struct SeqIn {            // what one processed step reads for one 16-row tile (
   float cm[NE];           // mask weight of expert e for the row, 0 when the expert is not in its pass
 };
 
-template <int DT, int HT, int CT, bool FULL>
+// WS (wave-specialised, CT == 1): the four waves of a workgroup are two producers, which run the
+// reverse scan of one 16-row tile each exactly as below but only PUT the [feature][row] images of
+// the weight-gradient operands into LDS, and two consumers, which own the weight-gradient
+// accumulators and do the fragment loads and the 96 MFMAs per step while their producer is already
+// in the next step (two workgroup barriers per step: images written / images consumed).  The scan
+// is an issue-bound chain on one wave; this takes ~15 % of the instructions (and 100 accumulator
+// registers) off it.
+constexpr int WS_IMG = 20 * 16 * (16 + 4);      // floats: images of one step of one tile (20 tiles)
+
+template <int DT, int HT, int CT, bool FULL, bool WS = false>
 __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a, int n_tasks) {
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   using L = Lds<DT, HT>;
   using LB = LdsB<DT, HT>;
+  static_assert(!WS || (CT == 1 && DT == 2 && HT == 2), "wave-specialised variant: z = h = 32, one tile per wave");
   constexpr int IT1 = LB::IT1;
   constexpr int NE = 3;                                      // experts loaded ahead; further ones in place
   constexpr bool PF = CT == 1;
-  constexpr int SCR = (IT1 + DT) * 16 * (16 + 4);            // floats of scratch per wave (16-row tiles)
+  constexpr int SCR = WS ? WS_IMG / 2                        // WS: one image set per producer (NT/128 of them)
+                         : (IT1 + DT) * 16 * (16 + 4);       // floats of scratch per wave (16-row tiles)
   // z = h = 32: the eight chained contractions run on the bf16 matrix pipe from chunk planes (the
   // fp32 fragments are then not staged; only their bias part of the layout is used)
   constexpr bool SPLIT = kSplitOk && DT == 2 && HT == 2;
@@ -693,7 +704,12 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   float* scratch0 = reinterpret_cast<float*>(lds + W_END);
-  float* scratch = scratch0 + wave * SCR;
+  constexpr int NPAIR = NT / 128;
+  const bool consumer = WS && wave >= NPAIR;
+  const int pair = wave & (NPAIR - 1);
+  float* scratch = WS ? scratch0 + pair * WS_IMG : scratch0 + wave * SCR;
+  // image offsets of the four weight-gradient products inside one WS image set
+  constexpr int IMG_S = 0, IMG_G = 4 * 320, IMG_N = 8 * 320, IMG_1 = 12 * 320;
   const int T = a.T, B = a.B, D = a.D;
   const bool vec = FULL || (D & 3) == 0;
   const int Dg = FULL ? (1 << 30) : D;      // guard extent: FULL (z_dim == 16*DT) needs no masks
@@ -739,7 +755,25 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
   }
   const bool more = a.E > NE;
 
-  for (int task = blockIdx.x * (NT / 64) + wave; task < n_tasks; task += gridDim.x * (NT / 64)) {
+  // WS: every wave runs the same number of rounds (a tile index past the end is a tile of dead rows)
+  constexpr int TPW = WS ? NPAIR : NT / 64;
+  const int n_round = (n_tasks + gridDim.x * TPW - 1) / (gridDim.x * TPW);
+  for (int round = 0; round < n_round; ++round) {
+    const int task = (round * gridDim.x + blockIdx.x) * TPW + (WS ? pair : wave);
+    if (!WS && task >= n_tasks) break;
+    if (consumer) {
+      if constexpr (WS) {
+        for (int i = T - 1; i >= 1; --i) {
+          __syncthreads();                      // (B) the producers may overwrite the images
+          __syncthreads();                      // (A) the images of step i are complete
+          dw_take<DT, DT, 1>(scratch + IMG_S, lane, dWs, dbs);
+          dw_take<DT, HT, 1>(scratch + IMG_G, lane, dWg, dbg);
+          dw_take<DT, HT, 1>(scratch + IMG_N, lane, dWn, dbn);
+          dw_take<IT1, DT, 1>(scratch + IMG_1, lane, dW1, db1);
+        }
+      }
+      continue;
+    }
     int p_[CT], b_[CT];
     bool live[CT];
 #pragma unroll
@@ -1022,12 +1056,18 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
         // d/d nonlin += W_std^T d/d std-pre ; weight grads of z_to_std
         if constexpr (SPLIT) gemm_chain_split<2, 1, 1, 2>(wsp + LdsSplitB::TS, nullptr, lane, pre, gnl);
         else gemm_chain<DT, DT, 1, 2>(lds + LB::TS, nullptr, lane, pre, gnl);
-        dw_accumulate<DT, DT, 1>(scratch, lane, pre, nl, dWs, dbs);
+        if constexpr (WS) {
+          __syncthreads();                      // (B) the consumers are done with the previous step's images
+          dw_put<DT, DT, 1>(scratch + IMG_S, lane, pre, nl);
+        } else {
+          dw_accumulate<DT, DT, 1>(scratch, lane, pre, nl, dWs, dbs);
+        }
         {   // gate branch
           f32x4 gh[HT][1];
           if constexpr (SPLIT) gemm_chain_split<2, 1, 1, 0>(wsp + LdsSplitB::TG, nullptr, lane, gate, gh);
           else gemm_chain<HT, DT, 1, 0>(lds + LB::TG, nullptr, lane, gate, gh);
-          dw_accumulate<DT, HT, 1>(scratch, lane, gate, h1, dWg, dbg);
+          if constexpr (WS) dw_put<DT, HT, 1>(scratch + IMG_G, lane, gate, h1);
+          else dw_accumulate<DT, HT, 1>(scratch, lane, gate, h1, dWg, dbg);
 #pragma unroll
           for (int ft = 0; ft < HT; ++ft)
 #pragma unroll
@@ -1037,7 +1077,8 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
           f32x4 gh[HT][1];
           if constexpr (SPLIT) gemm_chain_split<2, 1, 1, 0>(wsp + LdsSplitB::TN, nullptr, lane, gnl, gh);
           else gemm_chain<HT, DT, 1, 0>(lds + LB::TN, nullptr, lane, gnl, gh);
-          dw_accumulate<DT, HT, 1>(scratch, lane, gnl, h2, dWn, dbn);
+          if constexpr (WS) dw_put<DT, HT, 1>(scratch + IMG_N, lane, gnl, h2);
+          else dw_accumulate<DT, HT, 1>(scratch, lane, gnl, h2, dWn, dbn);
 #pragma unroll
           for (int ft = 0; ft < HT; ++ft)
 #pragma unroll
@@ -1047,7 +1088,12 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
         f32x4 gz[DT][1];
         if constexpr (SPLIT) gemm_chain_split<2, 3, 1, 0>(wsp + LdsSplitB::T1, nullptr, lane, a1, gz);
         else gemm_chain<DT, IT1, 1, 0>(lds + LB::T1, nullptr, lane, a1, gz);
-        dw_accumulate<IT1, DT, 1>(scratch, lane, a1, z, dW1, db1);
+        if constexpr (WS) {
+          dw_put<IT1, DT, 1>(scratch + IMG_1, lane, a1, z);
+          __syncthreads();                      // (A) this step's images are complete
+        } else {
+          dw_accumulate<IT1, DT, 1>(scratch, lane, a1, z, dW1, db1);
+        }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           adjA[dt][ct] = gz[dt][0];
@@ -1656,20 +1702,37 @@ static inline int seq_ct(const mdmm_sweep_t* a) { return (a->P * a->B > 16 * 102
 template <int CT>
 int bwd_tasks(const mdmm_sweep_t* a) { return (a->P * a->B + 16 * CT - 1) / (16 * CT); }
 
+// K = 1 at z = h = 32 with one tile per wave: the wave-specialised variant (2 tiles per workgroup)
+#ifdef MDMM_NO_WS
+constexpr bool kWsOk = false;
+#else
+constexpr bool kWsOk = true;
+#endif
+template <int DT, int HT, int CT>
+constexpr bool ws_variant() { return kWsOk && kSplitOk && DT == 2 && HT == 2 && CT == 1; }
+
+template <int DT, int HT, int CT>
+int bwd_grid(int n_tasks) {
+  const int tpw = ws_variant<DT, HT, CT>() ? NT / 128 : NT / 64;
+  const int grid = (n_tasks + tpw - 1) / tpw;
+  return grid > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : grid;
+}
+
 template <int DT, int HT, int CT, bool FULL>
 int launch_bwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   using LB = LdsB<DT, HT>;
+  constexpr bool WS = ws_variant<DT, HT, CT>();
   const int n_tasks = bwd_tasks<CT>(a);
-  int grid = (n_tasks + 3) / 4;
-  if (grid > BWD_MAX_BLOCKS) grid = BWD_MAX_BLOCKS;
+  const int grid = bwd_grid<DT, HT, CT>(n_tasks);
   if (!a->dw_partial || a->dw_partial_rows < grid) return MDMM_E_ARG;
-  const size_t scr = (size_t)(NT / 64) * (LB::IT1 + DT) * 16 * (16 + 4) * sizeof(float);
+  const size_t scr = WS ? (size_t)(NT / 128) * WS_IMG * sizeof(float)
+                        : (size_t)(NT / 64) * (LB::IT1 + DT) * 16 * (16 + 4) * sizeof(float);
   const size_t red = (size_t)LB::WIDTH * sizeof(float);
   const size_t w_end = (kSplitOk && DT == 2 && HT == 2) ? (size_t)Lds<DT, HT>::FWD_END + LdsSplitB::END
                                                         : (size_t)LB::WEND;
   const size_t lds = w_end * sizeof(float4) + (scr > red ? scr : red) +
                      (48 * DT + 2 * (NT / 64) * 32 * DT) * sizeof(float);
-  auto kern = sweep_mfma_bwd_kernel<DT, HT, CT, FULL>;
+  auto kern = sweep_mfma_bwd_kernel<DT, HT, CT, FULL, WS>;
   static size_t attr_lds = 0;         // per template instantiation (LDS size depends on CT only)
   if (attr_lds < lds) {
     hipError_t e = hipFuncSetAttribute((const void*)kern,
@@ -1778,11 +1841,9 @@ static bool mfma_shape(const mdmm_sweep_t* a) {
 
 template <int DT, int HT>
 int64_t dw_rows_for(const mdmm_sweep_t* a) {
-  int n_tasks;
-  if (a->K == 1) n_tasks = (a->P * a->B + 16 * seq_ct(a) - 1) / (16 * seq_ct(a));
-  else return coop_grid(a, a->K <= 16 ? 1 : 2);
-  int64_t grid = (n_tasks + 3) / 4;
-  return grid > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : grid;
+  if (a->K != 1) return coop_grid(a, a->K <= 16 ? 1 : 2);
+  const int n_tasks = (a->P * a->B + 16 * seq_ct(a) - 1) / (16 * seq_ct(a));
+  return seq_ct(a) == 2 ? bwd_grid<DT, HT, 2>(n_tasks) : bwd_grid<DT, HT, 1>(n_tasks);
 }
 
 int mdmm_mfma_bwd_supported(const mdmm_sweep_t* a) { return mfma_shape(a) ? 1 : 0; }
@@ -1794,7 +1855,8 @@ int mdmm_mfma_dw_width(int D, int H) {
 
 int64_t mdmm_mfma_dw_rows(const mdmm_sweep_t* a) {
   if (!mfma_shape(a)) return 0;
-  return dw_rows_for<1, 1>(a);      // the task count does not depend on the tile shape
+  const int dt = (a->D + 15) / 16, ht = (a->H + 15) / 16;
+  return (dt == 2 && ht == 2) ? dw_rows_for<2, 2>(a) : dw_rows_for<1, 1>(a);
 }
 
 int mdmm_mfma_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {

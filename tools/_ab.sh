@@ -1,0 +1,4 @@
+for lib in "" ab_putonly.so; do
+  if [ -n "$lib" ]; then export MDMM_LIB=$PWD/multimodal-dmm_amd/mdmm/lib/$lib; else unset MDMM_LIB; fi
+  TAG=${lib:-base} python tools/bench_sweep.py K=1 inv=1 rev=0 n=10 2>&1 | grep sweep_
+done
