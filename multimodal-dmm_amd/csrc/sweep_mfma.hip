@@ -758,11 +758,62 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
   // WS: every wave runs the same number of rounds (a tile index past the end is a tile of dead rows)
   constexpr int TPW = WS ? NPAIR : NT / 64;
   const int n_round = (n_tasks + gridDim.x * TPW - 1) / (gridDim.x * TPW);
-  for (int round = 0; round < n_round; ++round) {
-    const int task = (round * gridDim.x + blockIdx.x) * TPW + (WS ? pair : wave);
-    if (!WS && task >= n_tasks) break;
-    if (consumer) {
-      if constexpr (WS) {
+  // ---------- combine the waves of the workgroup, write one partial row ----------
+  // (with_dw / with_gz: what the calling wave holds -- WS consumers the weight gradients, WS
+  // producers the z0 rows, everyone both otherwise; every wave runs the same barriers)
+  auto epilogue = [&](bool with_dw, bool with_gz) {
+    __syncthreads();
+    float* acc = scratch0;
+    for (int idx = threadIdx.x; idx < LB::WIDTH; idx += NT) acc[idx] = 0.f;
+    __syncthreads();
+    for (int w = 0; w < NT / 64; ++w) {
+      if (wave == w) {
+        auto put_w = [&](int off, int ld, int ot, int kt, const f32x4& v) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[off + (16 * ot + 4 * g + r) * ld + 16 * kt + j] += v[r];
+        };
+        auto put_b = [&](int off, int tile, const f32x4& v) {      // C layout: sum over the 16 rows
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float s = row16_sum(v[r]);
+            if (j == 0) acc[off + 16 * tile + 4 * g + r] += s;
+          }
+        };
+        auto put_db = [&](int off, int tile, float v) {            // A-fragment layout: sum over g
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (g == 0) acc[off + 16 * tile + j] += v;
+        };
+        if (with_dw) {
+#pragma unroll
+          for (int x = 0; x < IT1; ++x) {
+            put_db(LB::O_B1, x, db1[x]);
+#pragma unroll
+            for (int y = 0; y < DT; ++y) put_w(LB::O_W1, LB::D16, x, y, dW1[x][y]);
+          }
+#pragma unroll
+          for (int x = 0; x < DT; ++x) {
+            put_db(LB::O_BG, x, dbg[x]); put_db(LB::O_BN, x, dbn[x]); put_db(LB::O_BS, x, dbs[x]);
+#pragma unroll
+            for (int y = 0; y < HT; ++y) { put_w(LB::O_WG, LB::H16, x, y, dWg[x][y]); put_w(LB::O_WN, LB::H16, x, y, dWn[x][y]); }
+#pragma unroll
+            for (int y = 0; y < DT; ++y) put_w(LB::O_WS, LB::D16, x, y, dWs[x][y]);
+          }
+        }
+        if (with_gz) {
+#pragma unroll
+          for (int x = 0; x < DT; ++x) { put_b(LB::O_ZM, x, gzm_row[x]); put_b(LB::O_ZS, x, gzs_row[x]); }
+        }
+      }
+      __syncthreads();
+    }
+    float* out = a.dw_partial + (size_t)blockIdx.x * LB::WIDTH;
+    for (int idx = threadIdx.x; idx < LB::WIDTH; idx += NT) out[idx] = acc[idx];
+  };
+
+  if constexpr (WS) {
+    if (consumer) {           // a path of its own: the accumulators are live nowhere else
+      for (int round = 0; round < n_round; ++round)
         for (int i = T - 1; i >= 1; --i) {
           __syncthreads();                      // (B) the producers may overwrite the images
           __syncthreads();                      // (A) the images of step i are complete
@@ -771,9 +822,13 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
           dw_take<DT, HT, 1>(scratch + IMG_N, lane, dWn, dbn);
           dw_take<IT1, DT, 1>(scratch + IMG_1, lane, dW1, db1);
         }
-      }
-      continue;
+      epilogue(true, false);
+      return;
     }
+  }
+  for (int round = 0; round < n_round; ++round) {
+    const int task = (round * gridDim.x + blockIdx.x) * TPW + (WS ? pair : wave);
+    if (!WS && task >= n_tasks) break;
     int p_[CT], b_[CT];
     bool live[CT];
 #pragma unroll
@@ -1104,52 +1159,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_bwd_kernel(const mdmm_sweep_t a
     }
   }
 
-  // ---------- combine the waves of the workgroup, write one partial row ----------
-  __syncthreads();
-  float* acc = scratch0;
-  for (int idx = threadIdx.x; idx < LB::WIDTH; idx += NT) acc[idx] = 0.f;
-  __syncthreads();
-  for (int w = 0; w < NT / 64; ++w) {
-    if (wave == w) {
-      auto put_w = [&](int off, int ld, int ot, int kt, const f32x4& v) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[off + (16 * ot + 4 * g + r) * ld + 16 * kt + j] += v[r];
-      };
-#pragma unroll
-      for (int x = 0; x < IT1; ++x)
-#pragma unroll
-        for (int y = 0; y < DT; ++y) put_w(LB::O_W1, LB::D16, x, y, dW1[x][y]);
-#pragma unroll
-      for (int x = 0; x < DT; ++x) {
-#pragma unroll
-        for (int y = 0; y < HT; ++y) { put_w(LB::O_WG, LB::H16, x, y, dWg[x][y]); put_w(LB::O_WN, LB::H16, x, y, dWn[x][y]); }
-#pragma unroll
-        for (int y = 0; y < DT; ++y) put_w(LB::O_WS, LB::D16, x, y, dWs[x][y]);
-      }
-      auto put_b = [&](int off, int tile, const f32x4& v) {      // C layout: sum over the 16 rows
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float s = row16_sum(v[r]);
-          if (j == 0) acc[off + 16 * tile + 4 * g + r] += s;
-        }
-      };
-      auto put_db = [&](int off, int tile, float v) {            // A-fragment layout: sum over g
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (g == 0) acc[off + 16 * tile + j] += v;
-      };
-#pragma unroll
-      for (int x = 0; x < IT1; ++x) put_db(LB::O_B1, x, db1[x]);
-#pragma unroll
-      for (int x = 0; x < DT; ++x) {
-        put_db(LB::O_BG, x, dbg[x]); put_db(LB::O_BN, x, dbn[x]); put_db(LB::O_BS, x, dbs[x]);
-        put_b(LB::O_ZM, x, gzm_row[x]); put_b(LB::O_ZS, x, gzs_row[x]);
-      }
-    }
-    __syncthreads();
-  }
-  float* out = a.dw_partial + (size_t)blockIdx.x * LB::WIDTH;
-  for (int idx = threadIdx.x; idx < LB::WIDTH; idx += NT) out[idx] = acc[idx];
+  epilogue(!WS, true);
 }
 
 
