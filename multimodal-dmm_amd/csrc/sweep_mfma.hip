@@ -227,17 +227,33 @@ __device__ __forceinline__ void transition_rows(const float4* lds, int lane, flo
       }
 }
 
-template <int DT, int HT, int CT, bool PART, bool FULL>
+// WS (K = 1 rows, CT == 1): the scan is a latency chain on one wave per tile with four fifths of
+// the chip idle, and nearly half of a step does not depend on the chain at all -- the expert
+// loads, their part of the product of experts (and the inverse prior's), the Philox draw.  Two of
+// the workgroup's four waves are helpers that compute exactly that for the NEXT step of their
+// producer's tile, lane for lane, and hand it over through LDS (sums of num / prec, eps: 3 DT
+// float4 per lane, double-buffered by step parity, one workgroup barrier per step).
+template <int DT, int HT, int CT, bool PART, bool FULL, bool WS = false>
 __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a, int n_tasks) {
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
+  static_assert(!WS || (CT == 1 && !PART), "helper waves: one 16-row tile of K = 1 rows per producer");
   constexpr bool SPLIT = kSplitOk && DT == 2 && HT == 2;
   bf16x8* wsp = reinterpret_cast<bf16x8*>(lds + Lds<DT, HT>::FWD_END);
   stage_forward_weights<DT, HT>(a, lds);
   if (SPLIT) stage_forward_weights_split(a, wsp);
   __syncthreads();
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
-  const int task = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-  if (task >= n_tasks) return;          // no workgroup-level synchronisation below this line
+  constexpr int NPAIR = NT / 128;
+  const int wave_ = threadIdx.x >> 6;
+  const bool helper = WS && wave_ >= NPAIR;
+  const int task = WS ? blockIdx.x * NPAIR + (wave_ & (NPAIR - 1)) : blockIdx.x * (NT / 64) + wave_;
+  if (!WS && task >= n_tasks) return;   // no workgroup-level synchronisation below this line (WS: a
+                                        // tile past the end is a tile of dead rows)
+  // WS hand-over: [parity][pair][slot = num dt | prec dt | eps dt][lane] float4
+  float4* hand = lds + Lds<DT, HT>::FWD_END + (SPLIT ? LdsSplit::END : 0);
+  auto hslot = [&](int parity, int slot) {
+    return hand + ((parity * NPAIR + (wave_ & (NPAIR - 1))) * 3 * DT + slot) * 64 + lane;
+  };
   const int T = a.T, B = a.B, D = a.D, K = a.K;
   const bool vec = FULL || (D & 3) == 0;
   const int Dg = FULL ? (1 << 30) : D;      // guard extent: FULL (z_dim == 16*DT) needs no masks
@@ -272,6 +288,62 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
       m0t[dt][r] = mu0[dt][r] * t0c[dt][r];
     }
 
+  if constexpr (WS) {
+    if (helper) {
+      // chain-independent part of step ii for the row of this lane: experts (+ inverse prior) and eps
+      auto prepare = [&](int ii) {
+        const int tt = a.reverse ? T - 1 - ii : ii;
+        const int p = p_[0], b = b_[0];
+        const size_t tb = (size_t)tt * B + b;
+        const bool smp = a.sample || (ii == 0 && a.sample_init);
+        fast::Poe q[DT][4];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) q[dt][r].init();
+        if (live[0]) {
+          for (int e = 0; e < a.E; ++e) {
+            const mdmm_expert_t& ex = a.experts[e];
+            if (!((ex.pass_bits >> p) & 1u)) continue;
+            const float c = ex.mask ? ex.mask[tb] : 1.0f;
+            const size_t off = (size_t)p * ex.pass_stride + tb * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              const f32x4 mv = ld4_guard(ex.mean, off, vec, 16 * dt + 4 * g, Dg);
+              f32x4 sv = ld4_guard(ex.std, off, vec, 16 * dt + 4 * g, Dg);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(mv[r], sv[r], c);
+            }
+          }
+          if (a.use_inv_prior) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) if (fvalid[dt][r]) q[dt][r].add(mu0[dt][r], -sg0[dt][r], 1.0f);
+          }
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d0 = 16 * dt + 4 * g;
+          float e4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (smp && live[0] && d0 < Dg) {
+            const uint64_t idx = ((((uint64_t)p * T + tt) * K + 0) * B + b) * (uint64_t)D + d0;
+            eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
+          }
+          *hslot(ii & 1, dt) = make_float4(q[dt][0].num, q[dt][1].num, q[dt][2].num, q[dt][3].num);
+          *hslot(ii & 1, DT + dt) = make_float4(q[dt][0].prec, q[dt][1].prec, q[dt][2].prec, q[dt][3].prec);
+          *hslot(ii & 1, 2 * DT + dt) = make_float4(e4[0], e4[1], e4[2], e4[3]);
+        }
+      };
+      prepare(0);
+      for (int i = 0; i < T; ++i) {
+        __syncthreads();                    // step i's hand-over is complete
+        if (i + 1 < T) prepare(i + 1);
+      }
+      return;
+    }
+  }
+
   // posterior of the previously processed step: PART -> per wave (index 0 used), SEQ -> per row
   constexpr int NS = PART ? 1 : CT;
   f32x4 im[DT][NS], is[DT][NS];
@@ -279,6 +351,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
 
   for (int i = 0; i < T; ++i) {
     const int t = a.reverse ? T - 1 - i : i;
+    if constexpr (WS) __syncthreads();      // the helper's hand-over for this step is in LDS
     f32x4 pm[DT][NS], ps[DT][NS];
     if (i == 0) {
 #pragma unroll
@@ -329,7 +402,14 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { q[dt][r].init(); q[dt][r].add(pm[dt][n][r], ps[dt][n][r], 1.0f); }
-      if (row_ok) {
+      if constexpr (WS) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const float4 hn = *hslot(i & 1, dt), hp = *hslot(i & 1, DT + dt);
+          q[dt][0].add_pre(hn.x, hp.x); q[dt][1].add_pre(hn.y, hp.y);
+          q[dt][2].add_pre(hn.z, hp.z); q[dt][3].add_pre(hn.w, hp.w);
+        }
+      } else if (row_ok) {
         for (int e = 0; e < a.E; ++e) {
           const mdmm_expert_t& ex = a.experts[e];
           if (!((ex.pass_bits >> p) & 1u)) continue;
@@ -381,7 +461,10 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
       for (int dt = 0; dt < DT; ++dt) {
         float e4[4] = {0.f, 0.f, 0.f, 0.f};
         const int d0 = 16 * dt + 4 * g;
-        if (sampled && live[ct] && d0 < Dg) {
+        if constexpr (WS) {
+          const float4 he = *hslot(i & 1, 2 * DT + dt);
+          e4[0] = he.x; e4[1] = he.y; e4[2] = he.z; e4[3] = he.w;
+        } else if (sampled && live[ct] && d0 < Dg) {
           const uint64_t idx = ((((uint64_t)p_[ct] * T + t) * K + k) * B + b_[ct]) * (uint64_t)D + d0;
           eps4(a, noise_offset, fast_noise, idx, d0, Dg, e4);
         }
@@ -1805,9 +1888,12 @@ int dispatch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
 template <int DT, int HT, int CT, bool PART, bool FULL>
 int launch_fwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   const int n_tasks = PART ? a->P * a->B : (a->P * a->B + 16 * CT - 1) / (16 * CT);
+  // K = 1 rows, one tile per wave: two producers + two helper waves per workgroup
+  constexpr bool WS = kWsOk && !PART && CT == 1;
   const size_t lds = (size_t)Lds<DT, HT>::FWD_END * sizeof(float4) +
-                     ((kSplitOk && DT == 2 && HT == 2) ? (size_t)LdsSplit::END * 16 : 0);
-  auto kern = sweep_mfma_fwd_kernel<DT, HT, CT, PART, FULL>;
+                     ((kSplitOk && DT == 2 && HT == 2) ? (size_t)LdsSplit::END * 16 : 0) +
+                     (WS ? (size_t)2 * (NT / 128) * 3 * DT * 64 * sizeof(float4) : 0);
+  auto kern = sweep_mfma_fwd_kernel<DT, HT, CT, PART, FULL, WS>;
   static bool attr_set = false;       // per template instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern,
@@ -1815,7 +1901,8 @@ int launch_fwd_(const mdmm_sweep_t* a, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((n_tasks + 3) / 4), dim3(NT), lds, stream, *a, n_tasks);
+  const int tpw = WS ? NT / 128 : NT / 64;
+  hipLaunchKernelGGL(kern, dim3((n_tasks + tpw - 1) / tpw), dim3(NT), lds, stream, *a, n_tasks);
   return (int)hipGetLastError();
 }
 
