@@ -289,6 +289,7 @@ SWEEP_SHAPES = [
     (32, 32, 1, 3, 16, 1, True, False),     # T = 1
     (12, 30, 1, 2, 5, 9, True, False),      # K = 1, partial feature tiles
     (32, 32, 40, 2, 3, 5, True, False),     # > 32 particles: MFMA forward (tile walk), generic backward
+    (32, 32, 1, 3, 3000, 3, True, False),   # K = 1, 563 tiles: two rounds of the wave-specialised backward
 ]
 
 
