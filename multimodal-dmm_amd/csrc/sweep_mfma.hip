@@ -1880,6 +1880,14 @@ int dispatch_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->K == 1)
     return seq_ct(a) == 2 ? launch_bwd<DT, HT, 2>(a, stream)
                           : launch_bwd<DT, HT, 1>(a, stream);
+  return MDMM_UNSUPPORTED;      // K > 1: mdmm_mfma_coop_bwd (sweep_coop.hip)
+}
+
+// K > 1 backward: instantiated only where MDMM_COOP_TU is defined (sweep_coop.hip, compiled without
+// the SLP vectoriser: the packed-f32 code it forms costs the cooperative kernel 1.7 %, while the
+// other kernels of this file gain 3-8 % from it)
+template <int DT, int HT>
+int dispatch_bwd_coop(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->K <= 16) return launch_bwd_coop<DT, HT, 1>(a, stream);
   if (a->K <= 32) return launch_bwd_coop<DT, HT, 2>(a, stream);
   return MDMM_UNSUPPORTED;
@@ -1932,6 +1940,16 @@ int dispatch_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef MDMM_COOP_TU
+int mdmm_mfma_coop_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
+  const int dt = (a->D + 15) / 16, ht = (a->H + 15) / 16;
+  if (dt == 1 && ht == 1) return dispatch_bwd_coop<1, 1>(a, stream);
+  if (dt == 1 && ht == 2) return dispatch_bwd_coop<1, 2>(a, stream);
+  if (dt == 2 && ht == 1) return dispatch_bwd_coop<2, 1>(a, stream);
+  return dispatch_bwd_coop<2, 2>(a, stream);
+}
+#else
+
 static bool mfma_shape(const mdmm_sweep_t* a) {
   return !a->trans_only && a->D <= 32 && a->H <= 32 && a->K <= 32;
 }
@@ -1958,6 +1976,7 @@ int64_t mdmm_mfma_dw_rows(const mdmm_sweep_t* a) {
 
 int mdmm_mfma_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (!mfma_shape(a)) return MDMM_UNSUPPORTED;
+  if (a->K > 1) return mdmm_mfma_coop_bwd(a, stream);
   const int dt = (a->D + 15) / 16, ht = (a->H + 15) / 16;
   if (dt == 1 && ht == 1) return dispatch_bwd<1, 1>(a, stream);
   if (dt == 1 && ht == 2) return dispatch_bwd<1, 2>(a, stream);
@@ -1974,7 +1993,9 @@ int mdmm_mfma_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   return dispatch_fwd<2, 2>(a, stream);
 }
 
-#ifdef MDMM_STAMPS
+#endif  // MDMM_COOP_TU
+
+#if defined(MDMM_STAMPS) && defined(MDMM_COOP_TU)
 extern "C" int mdmm_debug_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mdmm_stamp_buf), sizeof(unsigned long long) * 32);
 }
