@@ -112,13 +112,14 @@ struct LdsSplitB {
 
 // z = h = 32: the same transition with the four contractions on the bf16 matrix pipe (mfma_tiles.h)
 template <int CT>
-__device__ __forceinline__ void transition_rows_split(const bf16x8* wsp, const float4* lds, int lane,
+__device__ __forceinline__ void transition_rows_split(const bf16x8* wsp, const float4* bias, int lane,
                                                       float min_std, const f32x4 (&z)[2][CT],
                                                       const float (&m0t)[2][4], const float (&t0c)[2][4],
                                                       f32x4 (&tm)[2][CT], f32x4 (&ts)[2][CT]) {
-  using L = Lds<2, 2>;
+  using L = Lds<2, 2>;      // bias = the B1 | BG | BN | BS block of that layout, wherever it was staged
+  constexpr int OG = L::BG - L::B1, ON = L::BN - L::B1, OS = L::BS - L::B1;
   f32x4 a1[6][CT];
-  gemm_chain_split<6, 1, CT>(wsp + LdsSplit::W1, lds + L::B1, lane, z, a1);
+  gemm_chain_split<6, 1, CT>(wsp + LdsSplit::W1, bias, lane, z, a1);
   f32x4 h1[2][CT], h2[2][CT];
 #pragma unroll
   for (int ft = 0; ft < 2; ++ft)
@@ -130,9 +131,9 @@ __device__ __forceinline__ void transition_rows_split(const bf16x8* wsp, const f
         h2[ft][ct][r] = fmaxf(a1[2 + ft][ct][r], 0.f);
       }
   f32x4 gate[2][CT], nl[2][CT], pre[2][CT];
-  gemm_chain_split<2, 1, CT>(wsp + LdsSplit::WG, lds + L::BG, lane, h1, gate);
-  gemm_chain_split<2, 1, CT>(wsp + LdsSplit::WN, lds + L::BN, lane, h2, nl);
-  gemm_chain_split<2, 1, CT>(wsp + LdsSplit::WS, lds + L::BS, lane, nl, pre);
+  gemm_chain_split<2, 1, CT>(wsp + LdsSplit::WG, bias + OG, lane, h1, gate);
+  gemm_chain_split<2, 1, CT>(wsp + LdsSplit::WN, bias + ON, lane, h2, nl);
+  gemm_chain_split<2, 1, CT>(wsp + LdsSplit::WS, bias + OS, lane, nl, pre);
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -233,14 +234,42 @@ __device__ __forceinline__ void transition_rows(const float4* lds, int lane, flo
 // the workgroup's four waves are helpers that compute exactly that for the NEXT step of their
 // producer's tile, lane for lane, and hand it over through LDS (sums of num / prec, eps: 3 DT
 // float4 per lane, double-buffered by step parity, one workgroup barrier per step).
+// Occupancy: the 25-particle forward of cfg2 is 768 workgroups; at two waves per SIMD 512 are
+// resident and the launch takes a full round plus a half-empty one (1.67 ms; 1.11 ms for <= 512).  A
+// third wave costs a resident round almost nothing (the scan is latency-bound), so the kernel is
+// built for three: <= 168 registers (amdgpu_waves_per_eu; the allocator meets it without spills) and
+// <= 53 KB of LDS -- in SPLIT mode only the bias block of the fp32 layout is staged, in front of the
+// bf16 planes (FwdLds), instead of the 24.5 KB of fp32 fragments nothing would read.
+template <int DT, int HT, bool SPLIT>
+struct FwdLds {
+  using L = Lds<DT, HT>;
+  static constexpr int NBIAS = L::FWD_END - L::B1;                       // B1 | BG | BN | BS
+  static constexpr int BIAS = SPLIT ? 0 : L::B1;
+  static constexpr int PLANES = SPLIT ? NBIAS : L::FWD_END;              // bf16 chunk planes (SPLIT)
+  static constexpr int END = SPLIT ? NBIAS + LdsSplit::END : L::FWD_END; // float4 units
+};
+
 template <int DT, int HT, int CT, bool PART, bool FULL, bool WS = false>
-__global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a, int n_tasks) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(PART ? 3 : 2)))
+void sweep_mfma_fwd_kernel(const mdmm_sweep_t a, int n_tasks) {
   extern __shared__ __attribute__((aligned(16))) float4 lds[];
   static_assert(!WS || (CT == 1 && !PART), "helper waves: one 16-row tile of K = 1 rows per producer");
   constexpr bool SPLIT = kSplitOk && DT == 2 && HT == 2;
-  bf16x8* wsp = reinterpret_cast<bf16x8*>(lds + Lds<DT, HT>::FWD_END);
-  stage_forward_weights<DT, HT>(a, lds);
-  if (SPLIT) stage_forward_weights_split(a, wsp);
+  using FL = FwdLds<DT, HT, SPLIT>;
+  bf16x8* wsp = reinterpret_cast<bf16x8*>(lds + FL::PLANES);
+  const float4* bias = lds + FL::BIAS;
+  if constexpr (SPLIT) {
+    const int Hp = (a.H + 3) & ~3;
+    stage_bias(lds, a.gtf.b_in, 0, a.H, HT);
+    stage_bias(lds + HT * 4, a.gtf.b_in, Hp, a.H, HT);
+    stage_bias(lds + 2 * HT * 4, a.gtf.b_in, 2 * Hp, a.D, DT);
+    stage_bias(lds + (Lds<DT, HT>::BG - Lds<DT, HT>::B1), a.gtf.b_gate, 0, a.D, DT);
+    stage_bias(lds + (Lds<DT, HT>::BN - Lds<DT, HT>::B1), a.gtf.b_nl, 0, a.D, DT);
+    stage_bias(lds + (Lds<DT, HT>::BS - Lds<DT, HT>::B1), a.gtf.b_std, 0, a.D, DT);
+    stage_forward_weights_split(a, wsp);
+  } else {
+    stage_forward_weights<DT, HT>(a, lds);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
   constexpr int NPAIR = NT / 128;
@@ -250,7 +279,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
   if (!WS && task >= n_tasks) return;   // no workgroup-level synchronisation below this line (WS: a
                                         // tile past the end is a tile of dead rows)
   // WS hand-over: [parity][pair][slot = num dt | prec dt | eps dt][lane] float4
-  float4* hand = lds + Lds<DT, HT>::FWD_END + (SPLIT ? LdsSplit::END : 0);
+  float4* hand = lds + FL::END;
   auto hslot = [&](int parity, int slot) {
     return hand + ((parity * NPAIR + (wave_ & (NPAIR - 1))) * 3 * DT + slot) * 64 + lane;
   };
@@ -362,7 +391,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_kernel(const mdmm_sweep_t a
           for (int r = 0; r < 4; ++r) { pm[dt][n][r] = mu0[dt][r]; ps[dt][n][r] = sg0[dt][r]; }
     } else {
       f32x4 tm[DT][CT], ts[DT][CT];
-      if constexpr (SPLIT) transition_rows_split<CT>(wsp, lds, lane, a.min_std, z, m0t, t0c, tm, ts);
+      if constexpr (SPLIT) transition_rows_split<CT>(wsp, bias, lane, a.min_std, z, m0t, t0c, tm, ts);
       else transition_rows<DT, HT, CT>(lds, lane, a.min_std, z, m0t, t0c, tm, ts);
       if (PART) {
         {
@@ -616,7 +645,7 @@ __global__ __launch_bounds__(NT) void sweep_mfma_fwd_long_kernel(const mdmm_swee
       for (int c = 0; c < n_tiles; ++c) {
         f32x4 z[DT][1], tm[DT][1], ts[DT][1];
         const bool live = draw(c, t_prev, z);
-        if constexpr (SPLIT) transition_rows_split<1>(wsp, lds, lane, a.min_std, z, m0t, t0c, tm, ts);
+        if constexpr (SPLIT) transition_rows_split<1>(wsp, lds + Lds<DT, HT>::B1, lane, a.min_std, z, m0t, t0c, tm, ts);
         else transition_rows<DT, HT, 1>(lds, lane, a.min_std, z, m0t, t0c, tm, ts);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
@@ -1898,8 +1927,7 @@ int launch_fwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   const int n_tasks = PART ? a->P * a->B : (a->P * a->B + 16 * CT - 1) / (16 * CT);
   // K = 1 rows, one tile per wave: two producers + two helper waves per workgroup
   constexpr bool WS = kWsOk && !PART && CT == 1;
-  const size_t lds = (size_t)Lds<DT, HT>::FWD_END * sizeof(float4) +
-                     ((kSplitOk && DT == 2 && HT == 2) ? (size_t)LdsSplit::END * 16 : 0) +
+  const size_t lds = (size_t)FwdLds<DT, HT, kSplitOk && DT == 2 && HT == 2>::END * sizeof(float4) +
                      (WS ? (size_t)2 * (NT / 128) * 3 * DT * 64 * sizeof(float4) : 0);
   auto kern = sweep_mfma_fwd_kernel<DT, HT, CT, PART, FULL, WS>;
   static bool attr_set = false;       // per template instantiation
