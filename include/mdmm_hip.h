@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 10
+#define MDMM_ABI_VERSION 11
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -77,6 +77,24 @@ typedef struct {
 } mdmm_gtf_raw_t;
 int64_t mdmm_gtf_pack_size(int D, int H);
 int mdmm_gtf_pack(const mdmm_gtf_raw_t* raw, int D, int H, float* out, void* stream);
+
+/* "Wide" family, z_dim = h_dim = 256 (Weizmann / vidTIMIT, weizmann.py:61-62, vidTIMIT.py:52): the
+ * six dense layers of common.py:62-68 run on the matrix cores with the weights streamed from L2
+ * as ready-made MFMA operand fragments.  precision selects the operand type of every contraction
+ * (accumulation, latent state, products of experts and reductions are fp32 either way):
+ *   MDMM_PREC_F32  fp32 operands, v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 FMA chain)
+ *   MDMM_PREC_BF16 bf16 operands, v_mfma_f32_32x32x16_bf16 (16x the rate)
+ * Pack layout (bytes): 12 layers of 8 n-tiles x NCH chunks x 64 lanes x 16 B, then 6 x 256 fp32
+ * biases.  Layers 0-5 = z_to_gate.0, z_nonlin.0, z_lin, z_to_gate.2, z_nonlin.2, z_to_std.0 as
+ * [out][in]; layers 6-11 = the transposes of z_to_std.0, z_nonlin.2, z_to_gate.2, z_to_gate.0,
+ * z_nonlin.0, z_lin (the backward sweep contracts over the output index).  Chunk c of n-tile j,
+ * lane l (n = 32j + l%32, h = l/32) holds W[n][k0 .. k0+e) with e = 8, k0 = 16c + 8h (bf16,
+ * NCH = 16) or e = 4, k0 = 8c + 4h (fp32, NCH = 32).  Biases: the six layers in order 0-5.  */
+#define MDMM_PREC_F32 0
+#define MDMM_PREC_BF16 1
+int64_t mdmm_gtf_frag_bytes(int D, int H, int precision);   /* 0: (D,H) outside the wide family */
+int mdmm_gtf_frag_pack(const mdmm_gtf_raw_t* raw, int D, int H, int precision, void* out,
+                       void* stream);
 
 /* One Gaussian expert entering the per-step product of experts (dgts.py:15-51).
  * mean/std are (T,B,D) (pass_stride == 0: shared by all passes, e.g. an encoder
@@ -156,14 +174,28 @@ typedef struct mdmm_sweep {
    * hipGraph-captured step draw fresh noise on every replay -- the host bumps the counter with
    * a captured device op instead of re-recording kernel arguments.  NULL = 0.  */
   const uint64_t* offset_dev;
+  /* Wide family (see mdmm_gtf_frag_pack): when gtf_frag is set and mdmm_sweep_wide(args) != 0 the
+   * sweep runs on the wide MFMA kernels (gtf may then be left zero for the forward sweep).  The
+   * backward sweep (mdmm_sweep_bwd_mode() == 2) needs wide_ws of mdmm_sweep_wide_ws_bytes(args)
+   * bytes: it spills the weight-gradient operands there as MFMA fragments, contracts them over all
+   * transition rows with a kernel of its own and writes ONE row of dw_partial (layout above).  */
+  const void* gtf_frag;
+  int32_t precision;     /* MDMM_PREC_* of gtf_frag */
+  int32_t reserved1;
+  void* wide_ws;
+  int64_t wide_ws_bytes;
 } mdmm_sweep_t;
 
 int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream);
 int mdmm_bfvi_sweep_bwd(const mdmm_sweep_t* args, void* stream);
 /* How mdmm_bfvi_sweep_bwd delivers the weight gradients for this shape:
- *   0 = spill_g / spill_x rows (generic kernels), 1 = dw_partial rows (MFMA kernels). */
+ *   0 = spill_g / spill_x rows (generic kernels), 1 = dw_partial rows (MFMA kernels),
+ *   2 = one dw_partial row, wide_ws required (wide family). */
 int mdmm_sweep_bwd_mode(const mdmm_sweep_t* args);
 int mdmm_sweep_dw_width(int D, int H);
+/* != 0 if this sweep (sizes, K, gtf_frag) runs on the wide family */
+int mdmm_sweep_wide(const mdmm_sweep_t* args);
+int64_t mdmm_sweep_wide_ws_bytes(const mdmm_sweep_t* args);
 int64_t mdmm_sweep_dw_rows(const mdmm_sweep_t* args);
 /* widths of one spill_g / spill_x row for (D,H) */
 int mdmm_sweep_spill_width_g(int D, int H);

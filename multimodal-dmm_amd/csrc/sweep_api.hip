@@ -1,5 +1,6 @@
 // C-ABI entry points of the BFVI sweep: argument checks, then kernel-family dispatch.
 //   z_dim, h_dim <= 32, K <= 32 : register-chained f32 MFMA kernels (sweep_mfma.hip)
+//   z_dim = h_dim = 256 with a fragment pack (gtf_frag) : wide MFMA kernels (sweep_wide.hip)
 //   everything else             : generic LDS-tiled fp32 kernels    (sweep_simt.hip)
 // MDMM_FORCE_GENERIC=1 in the environment pins the generic family (A/B runs, cross-checks).
 #include <stdlib.h>
@@ -14,6 +15,8 @@ extern "C" int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream) {
   int rc = mdmm_sweep_check_args(args, 0);
   if (rc) return rc;
   if (!force_generic()) {
+    rc = mdmm_wide_sweep_fwd(args, (hipStream_t)stream);
+    if (rc != MDMM_UNSUPPORTED) return rc;
     rc = mdmm_mfma_sweep_fwd(args, (hipStream_t)stream);
     if (rc != MDMM_UNSUPPORTED) return rc;
   }
@@ -24,6 +27,7 @@ extern "C" int mdmm_bfvi_sweep_bwd(const mdmm_sweep_t* args, void* stream) {
   int rc = mdmm_sweep_check_args(args, 1);
   if (rc) return rc;
   if (!force_generic()) {
+    if (args->wide_ws && mdmm_wide_bwd_supported(args)) return mdmm_wide_sweep_bwd(args, (hipStream_t)stream);
     rc = mdmm_mfma_sweep_bwd(args, (hipStream_t)stream);
     if (rc != MDMM_UNSUPPORTED) return rc;
   }
@@ -32,6 +36,7 @@ extern "C" int mdmm_bfvi_sweep_bwd(const mdmm_sweep_t* args, void* stream) {
 
 extern "C" int mdmm_sweep_bwd_mode(const mdmm_sweep_t* args) {
   if (!args || force_generic()) return 0;
+  if (mdmm_wide_bwd_supported(args)) return 2;
   return mdmm_mfma_bwd_supported(args);
 }
 
@@ -39,5 +44,6 @@ extern "C" int mdmm_sweep_dw_width(int D, int H) { return mdmm_mfma_dw_width(D, 
 
 extern "C" int64_t mdmm_sweep_dw_rows(const mdmm_sweep_t* args) {
   if (!args || force_generic()) return 0;
+  if (mdmm_wide_bwd_supported(args)) return 1;
   return mdmm_mfma_dw_rows(args);
 }

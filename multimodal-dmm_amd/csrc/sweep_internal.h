@@ -12,6 +12,9 @@ int mdmm_simt_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream);
 int mdmm_mfma_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream);
 int mdmm_mfma_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream);
 int mdmm_mfma_coop_bwd(const mdmm_sweep_t* a, hipStream_t stream);   /* sweep_coop.hip */
+int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream);    /* sweep_wide.hip */
+int mdmm_wide_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream);
+int mdmm_wide_bwd_supported(const mdmm_sweep_t* a);
 int mdmm_sweep_check_args(const mdmm_sweep_t* a, int bwd);
 int mdmm_mfma_bwd_supported(const mdmm_sweep_t* a);
 int mdmm_mfma_dw_width(int D, int H);

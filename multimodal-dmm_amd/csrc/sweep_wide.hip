@@ -1,0 +1,1045 @@
+// BFVI sweep for z_dim = h_dim = 256 ("wide" family): MultiDMM.z_filter (dmm.py:319-412) with
+// z_next (214-258), the gated transition (common.py:62-68), product_of_experts (dgts.py:15-51),
+// mean_of_experts (53-83) and _sample_gauss (177-180) as ONE persistent launch per sweep.
+//
+// Workgroup = 8 waves = R = 32*RT transition rows for the whole time loop (wide_tiles.h).  Rows:
+//   K = 1 : row = (pass, sequence); 32*RT pairs per workgroup;
+//   K > 1 : a (pass, sequence) owns TPP = ceil(K/32) whole row tiles, its particles are rows
+//           0..K-1 of them (rows >= K are dead: zero activations, masked out of every sum).
+// Per step (i > 0) the six layers run as five contraction phases between workgroup barriers;
+// the activations live in two LDS images (Z / NL and one hidden layer at a time):
+//   1  hg  = relu(W1g z + b)            Z -> H        4  nl = W2n hn + b          H -> (barrier) H
+//   2  x   = W2g hg + b  (gate pre-act) H             5a acc = e^x * nl  += Wl z   Z
+//   3  hn  = relu(W1n z + b)            Z -> H           muq = (1 - g)(acc + bl) = (1-g) lin + g nl
+//                                                      5b pre = Ws nl + b          H
+// (5a pre-loads the accumulator with e^x * nl so that z_lin lands on top of it: the gate, the
+// linear and the non-linear branch never have to be live together -- 128 instead of 192
+// accumulator registers at RT = 4; x is clamped to +-30, where sigmoid is 0 / 1 to 1e-13.)
+// Then, on the accumulator registers: product with the global prior per particle, moments over
+// the particles, product with the step's experts, outputs, the next particles -> Z image.
+#include "sweep_internal.h"
+#include "wide_tiles.h"
+
+namespace {
+
+using namespace mdmm;
+using namespace wide;
+
+struct WideGeo {
+  int n_pairs;     // P * B
+  int NP;          // (pass, sequence) pairs per workgroup
+  int TPP;         // row tiles per pair (K > 1), 1 for K = 1
+  int ntab;        // slots in the pair table
+};
+
+struct PairRef { int p, b; };      // p < 0: slot unused
+
+template <bool F32, int RT>
+struct FwdLds {
+  static constexpr int IMG = 32 * RT * Op<F32>::RS;
+  static constexpr int OFF_Z = 0, OFF_H = IMG, OFF_TAB = 2 * IMG;
+  static constexpr int OFF_ROW = OFF_TAB + 32 * RT * (int)sizeof(PairRef);
+  static constexpr int BYTES = OFF_ROW + 32 * RT * 8;
+};
+
+__device__ __forceinline__ uint64_t noise_off(const mdmm_sweep_t& a) {
+  return a.offset + (a.offset_dev ? *a.offset_dev : 0);
+}
+
+// tables shared by the forward and the backward kernel: pair of every slot, noise row base of
+// every row (flat index of element (p, t=0, k, b, d=0) of the (P,T,K,B,D) noise tensor; ~0 = dead)
+template <int RT, bool K1>
+__device__ __forceinline__ void build_tables(const mdmm_sweep_t& a, const WideGeo& g, PairRef* tab,
+                                             uint64_t* rowbase) {
+  const int R = 32 * RT;
+  for (int r = threadIdx.x; r < R; r += NTHR) {
+    const int slot = K1 ? r : (r >> 5) / g.TPP;
+    const int k = K1 ? 0 : (r - 32 * g.TPP * slot);
+    const int64_t pair = (int64_t)blockIdx.x * g.NP + slot;
+    const bool live = slot < g.NP && pair < g.n_pairs && k < a.K;
+    int p = -1, b = 0;
+    if (slot < g.NP && pair < g.n_pairs) { p = (int)(pair / a.B); b = (int)(pair - (int64_t)p * a.B); }
+    if (K1 || (r & 31) == 0) {
+      // K > 1: one entry per row TILE (all tiles of a pair carry the pair)
+      PairRef e; e.p = p; e.b = b;
+      tab[K1 ? r : (r >> 5)] = e;
+    }
+    rowbase[r] = live ? ((((uint64_t)p * a.T) * a.K + k) * a.B + b) * (uint64_t)WD : ~0ull;
+  }
+}
+
+// N(0,1) draws of the four rows (registers 4q .. 4q+3) of one accumulator register group:
+// e[j] = eps(row j, feature n).  Philox yields four consecutive features per counter, so lane u
+// of a quad draws row u's four features and the quad transposes (wide_tiles.h).
+__device__ __forceinline__ void eps_group(const mdmm_sweep_t& a, uint64_t noff, uint64_t t_term,
+                                          const uint64_t* rowbase_r0, int n, float (&e)[4]) {
+  if (a.eps) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t rb = rowbase_r0[j];
+      e[j] = (rb != ~0ull) ? a.eps[rb + t_term + n] : 0.f;
+    }
+    return;
+  }
+  const int u = n & 3;
+  const uint64_t rb = rowbase_r0[u];
+  philox_normal4(a.seed, noff, (rb + t_term + (uint64_t)(n & ~3)) >> 2, e);
+  quad_transpose(e, u);
+}
+
+// per-tile sums -> total of the pair the tile belongs to (TPP = 1, 2 or 4 tiles per pair)
+template <int RT>
+__device__ __forceinline__ float pair_total(const float (&s)[RT], int rt, int tpp) {
+  float v = s[rt];
+  if constexpr (RT >= 2) { if (tpp >= 2) v += s[rt ^ 1]; }
+  if constexpr (RT >= 4) { if (tpp == 4) v += s[rt ^ 2] + s[rt ^ 3]; }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+template <bool F32, int RT, bool K1>
+__global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, const WideGeo g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = FwdLds<F32, RT>;
+  using O = Op<F32>;
+  char* imgZ = smem + L::OFF_Z;
+  char* imgH = smem + L::OFF_H;
+  PairRef* tab = reinterpret_cast<PairRef*>(smem + L::OFF_TAB);
+  uint64_t* rowbase = reinterpret_cast<uint64_t*>(smem + L::OFF_ROW);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, n = 32 * wave + (lane & 31);
+  const int T = a.T, B = a.B, K = a.K;
+  const uint64_t noff = noise_off(a);
+  const float inv_k = 1.0f / (float)K;
+
+  build_tables<RT, K1>(a, g, tab, rowbase);
+
+  // this lane's fragment pointer of every layer, A-operand addresses, biases, global prior
+  const uint4* frag = reinterpret_cast<const uint4*>(a.gtf_frag) + (size_t)wave * O::NCH * 64 + lane;
+  const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(a.gtf_frag) +
+                                                     (size_t)N_LAYER * O::LAYER_U4);
+  auto W = [&](int layer) { return frag + (size_t)layer * O::LAYER_U4; };
+  const int arow = (lane & 31) * O::RS + 16 * h;
+  const float b1g = bias[B_1G * WD + n], b1n = bias[B_1N * WD + n], bl = bias[B_L * WD + n];
+  const float b2g = bias[B_2G * WD + n], b2n = bias[B_2N * WD + n], bs = bias[B_S * WD + n];
+  const float mu0 = a.z0_mean[n], sg0 = fast::exp(a.z0_log_std[n]) + a.min_std;
+  const float t0 = fast::rcp(sg0 * sg0 + MDMM_POE_EPS), num0 = mu0 * t0;
+
+  uint4 ring[PF];
+  ring_fill(ring, W(L_W1G));
+  __syncthreads();
+
+  for (int i = 0; i < T; ++i) {
+    const int t = a.reverse ? T - 1 - i : i;
+    f32x16 m_[RT], sd_[RT];        // per particle: p(z) * q'(z | z_prev)  (dmm.py:239-252)
+    if (i > 0) {
+      f32x16 acc[RT], x[RT];
+      // 1: gate hidden
+      zero_acc(acc);
+      gemm_tile<F32, RT>(acc, imgZ + arow, W(L_W1G), W(L_W2G), ring);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = fmaxf(acc[rt][r] + b1g, 0.f);
+      store_image<F32, RT>(imgH, acc, wave, lane);
+      __syncthreads();
+      // 2: gate pre-activation
+      zero_acc(x);
+      gemm_tile<F32, RT>(x, imgH + arow, W(L_W2G), W(L_W1N), ring);
+      __syncthreads();
+      // 3: non-linear hidden
+      zero_acc(acc);
+      gemm_tile<F32, RT>(acc, imgZ + arow, W(L_W1N), W(L_W2N), ring);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] = fmaxf(acc[rt][r] + b1n, 0.f);
+      store_image<F32, RT>(imgH, acc, wave, lane);
+      __syncthreads();
+      // 4: non-linear branch
+      zero_acc(acc);
+      gemm_tile<F32, RT>(acc, imgH + arow, W(L_W2N), W(L_WL), ring);
+      __syncthreads();
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] += b2n;
+      store_image<F32, RT>(imgH, acc, wave, lane);
+      // 5a: acc = e^x nl + lin;  muq = (1 - g)(acc + bl)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float ex = fast::exp(fminf(fmaxf(x[rt][r] + b2g, -30.f), 30.f));
+          x[rt][r] = fast::rcp(1.0f + ex);              // 1 - gate
+          acc[rt][r] *= ex;
+        }
+      gemm_tile<F32, RT>(acc, imgZ + arow, W(L_WL), W(L_WS), ring);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m_[rt][r] = x[rt][r] * (acc[rt][r] + bl);   // muq
+      __syncthreads();
+      // 5b: std pre-activation
+      zero_acc(acc);
+      gemm_tile<F32, RT>(acc, imgH + arow, W(L_WS), W(L_W1G), ring);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sq = fast::softplus(acc[rt][r] + bs) + a.min_std;          // common.py:66
+          const float tq = fast::rcp(sq * sq + MDMM_POE_EPS);
+          const float rp = fast::rcp(t0 + tq);
+          const float mm = (num0 + m_[rt][r] * tq) * rp;
+          m_[rt][r] = (mm != mm) ? 0.f : mm;
+          sd_[rt][r] = fast::sqrt(rp);
+        }
+    }
+
+    const bool sampled = a.sample || K > 1 || (i == 0 && a.sample_init);
+    const bool last = (i == T - 1);
+    const uint64_t t_term = (uint64_t)t * K * B * WD;
+    f32x16 z[RT];
+
+    if constexpr (K1) {
+      // slot = row: prior of the row is its own (m, sd)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float e[4] = {0.f, 0.f, 0.f, 0.f};
+          const int r0 = 32 * rt + 8 * q + 4 * h;
+          // (the draw of the last step only enters `samples`)
+          if (sampled && (!last || a.samples)) eps_group(a, noff, t_term, rowbase + r0, n, e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int reg = 4 * q + j;
+            const PairRef pr = tab[r0 + j];
+            const float pm = (i > 0) ? m_[rt][reg] : mu0, ps = (i > 0) ? sd_[rt][reg] : sg0;
+            float zz = 0.f;
+            if (pr.p >= 0) {
+              const size_t tb = (size_t)t * B + pr.b;
+              fast::Poe pq; pq.init(); pq.add(pm, ps, 1.0f);
+              for (int ex = 0; ex < a.E; ++ex) {
+                const mdmm_expert_t& xp = a.experts[ex];
+                if (!((xp.pass_bits >> pr.p) & 1u)) continue;
+                const float c = xp.mask ? xp.mask[tb] : 1.0f;
+                const size_t off = (size_t)pr.p * xp.pass_stride + tb * WD + n;
+                pq.add(xp.mean[off], xp.std[off], c);
+              }
+              if (a.use_inv_prior) pq.add(mu0, -sg0, 1.0f);
+              float im, is; pq.finish(im, is);
+              const size_t o = (((size_t)pr.p * T + t) * B + pr.b) * WD + n;
+              a.infer_mean[o] = im; a.infer_std[o] = is;
+              a.prior_mean[o] = pm; a.prior_std[o] = ps;
+              zz = sampled ? fmaf(e[j], is, im) : im;
+              if (a.samples) a.samples[o] = zz;
+            }
+            z[rt][reg] = zz;
+          }
+        }
+      }
+    } else {
+      // per row tile: moments over the pair's particles (dgts.py:79-83), fusion, particles
+      float pm[RT], ps[RT];
+      if (i > 0) {
+        float s1[RT], s2[RT], s3[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int k0 = 32 * (rt & (g.TPP - 1)) + 4 * h;
+          float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const bool live = k0 + acc_row(0, reg) < K;
+            const float mm = live ? m_[rt][reg] : 0.f, ss = live ? sd_[rt][reg] : 0.f;
+            a1 += mm; a2 = fmaf(ss, ss, a2); a3 = fmaf(mm, mm, a3);
+          }
+          s1[rt] = a1 + other_half(a1); s2[rt] = a2 + other_half(a2); s3[rt] = a3 + other_half(a3);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const float a1 = pair_total(s1, rt, g.TPP), a2 = pair_total(s2, rt, g.TPP),
+                      a3 = pair_total(s3, rt, g.TPP);
+          const float mb = a1 * inv_k;
+          pm[rt] = mb;
+          ps[rt] = fast::sqrt(a2 * inv_k + (a3 * inv_k - mb * mb));
+        }
+      } else {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) { pm[rt] = mu0; ps[rt] = sg0; }
+      }
+      float zsum[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const PairRef pr = tab[rt];
+        float im = 0.f, is = 0.f;
+        size_t o = 0;
+        if (pr.p >= 0) {
+          const size_t tb = (size_t)t * B + pr.b;
+          fast::Poe pq; pq.init(); pq.add(pm[rt], ps[rt], 1.0f);
+          for (int ex = 0; ex < a.E; ++ex) {
+            const mdmm_expert_t& xp = a.experts[ex];
+            if (!((xp.pass_bits >> pr.p) & 1u)) continue;
+            const float c = xp.mask ? xp.mask[tb] : 1.0f;
+            const size_t off = (size_t)pr.p * xp.pass_stride + tb * WD + n;
+            pq.add(xp.mean[off], xp.std[off], c);
+          }
+          if (a.use_inv_prior) pq.add(mu0, -sg0, 1.0f);
+          pq.finish(im, is);
+          o = (((size_t)pr.p * T + t) * B + pr.b) * WD + n;
+          if (h == 0 && (rt & (g.TPP - 1)) == 0) {
+            a.infer_mean[o] = im; a.infer_std[o] = is;
+            a.prior_mean[o] = pm[rt]; a.prior_std[o] = ps[rt];
+          }
+        }
+        const int k0 = 32 * (rt & (g.TPP - 1)) + 4 * h;
+        float zs = 0.f;
+        const bool need = pr.p >= 0 && (!last || a.samples);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float e[4] = {0.f, 0.f, 0.f, 0.f};
+          if (need) eps_group(a, noff, t_term, rowbase + 32 * rt + 8 * q + 4 * h, n, e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool live = pr.p >= 0 && k0 + 8 * q + j < K;
+            const float zz = live ? fmaf(e[j], is, im) : 0.f;
+            z[rt][4 * q + j] = zz;
+            zs += zz;
+          }
+        }
+        zsum[rt] = zs + other_half(zs);
+      }
+      if (a.samples) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const float zs = pair_total(zsum, rt, g.TPP);
+          const PairRef pr = tab[rt];
+          if (pr.p >= 0 && h == 0 && (rt & (g.TPP - 1)) == 0)
+            a.samples[(((size_t)pr.p * T + t) * B + pr.b) * WD + n] = zs * inv_k;   // dmm.py:402
+        }
+      }
+    }
+    if (!last) {
+      __syncthreads();               // every wave is done with the H image (5b) and Z (5a)
+      store_image<F32, RT>(imgZ, z, wave, lane);
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward: reverse scan with recompute.  Per step: adjoint of sampling + product of experts
+// (per pair), then the transition into the step: recompute (R1-R4), elementwise adjoint (E),
+// input-gradient contractions (D1-D3).  Four LDS images; the weight-gradient operands leave as
+// MFMA operand chunks (wide_tiles.h, acc_chunk) and are contracted over all rows afterwards.
+// ---------------------------------------------------------------------------------------
+enum Spill { S_Z = 0, S_HG, S_HN, S_NL, S_GHG, S_GHN, S_GLIN, S_GG, S_GN, S_G3, N_SPILL };
+
+template <bool F32, int RT>
+struct BwdLds {
+  static constexpr int IMG = 32 * RT * Op<F32>::RS;
+  static constexpr int OFF_TAB = 4 * IMG;
+  static constexpr int OFF_ROW = OFF_TAB + 32 * RT * (int)sizeof(PairRef);
+  static constexpr int BYTES = OFF_ROW + 32 * RT * 8;
+};
+
+// workspace of one backward sweep (device pointers into mdmm_sweep_t.wide_ws)
+struct WideWs {
+  uint4* spill;      // [workgroup][step][N_SPILL][wave][chunk][lane]
+  float* db;         // [workgroup][6][256] bias-gradient partial sums
+  float* dz0;        // [workgroup][2][256] d/d(mu0, sigma0) partial sums
+  float* slab;       // [split][6][256][256] weight-gradient partial sums
+  int64_t n_wg, n_step;
+  int split;
+};
+
+__device__ __forceinline__ void poe_out_bwd_f(float num, float rp, float sd, float g_mean, float g_std,
+                                              float& g_num, float& g_prec) {
+  const float m = num * rp;
+  if (m != m) g_mean = 0.f;
+  g_num = g_mean * rp;
+  g_prec = -g_mean * num * rp * rp - 0.5f * g_std * sd * rp;
+}
+__device__ __forceinline__ void poe_expert_bwd_f(float mu, float sd, float c, float g_num, float g_prec,
+                                                 float& g_mu, float& g_sd) {
+  const float inv = fast::rcp(sd * sd + MDMM_POE_EPS);
+  const float sg = signf_(sd);
+  const float t = inv * sg * c;
+  g_mu = g_num * t * c;
+  const float g_inv = (g_num * mu * c + g_prec) * c * sg;
+  g_sd = -g_inv * inv * inv * 2.0f * sd;
+}
+
+struct FuseAdj { float gpm, gps, prm, prs; };
+
+// adjoint of sampling + product of experts of ONE (pass, sequence) at step t, feature n
+// (dmm.py:387-405 backwards).  `owner`: this lane writes the expert gradients and counts the
+// pair's d/d(mu0, sigma0) (the pair's values are replicated over lanes / tiles).
+__device__ __forceinline__ FuseAdj fuse_bwd(const mdmm_sweep_t& a, PairRef pr, int t, int n, float mu0,
+                                            float sg0, float adj_a, float adj_b, float se,
+                                            bool sampled, float inv_k, bool first, bool owner,
+                                            float& g_mu0, float& g_sg0) {
+  FuseAdj r; r.gpm = 0.f; r.gps = 0.f; r.prm = 0.f; r.prs = 1.f;
+  if (pr.p < 0) return r;
+  const size_t tb = (size_t)t * a.B + pr.b;
+  const size_t o = (((size_t)pr.p * a.T + t) * a.B + pr.b) * WD + n;
+  const float gsmp = a.g_samples ? a.g_samples[o] : 0.f;
+  float g_im = (a.g_infer_mean ? a.g_infer_mean[o] : 0.f) + adj_a + gsmp;
+  float g_is = a.g_infer_std ? a.g_infer_std[o] : 0.f;
+  if (sampled) g_is += adj_b + gsmp * se * inv_k;
+  const float prm = a.prior_mean[o], prs = a.prior_std[o];
+  fast::Poe q; q.init(); q.add(prm, prs, 1.0f);
+  for (int e = 0; e < a.E; ++e) {
+    const mdmm_expert_t& ex = a.experts[e];
+    if (!((ex.pass_bits >> pr.p) & 1u)) continue;
+    const float c = ex.mask ? ex.mask[tb] : 1.0f;
+    const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
+    q.add(ex.mean[off], ex.std[off], c);
+  }
+  if (a.use_inv_prior) q.add(mu0, -sg0, 1.0f);
+  const float rp = fast::rcp(q.prec), is = fast::sqrt(rp);
+  float g_num, g_prec, gm, gs;
+  poe_out_bwd_f(q.num, rp, is, g_im, g_is, g_num, g_prec);
+  poe_expert_bwd_f(prm, prs, 1.0f, g_num, g_prec, gm, gs);
+  r.gpm = gm + (a.g_prior_mean ? a.g_prior_mean[o] : 0.f);
+  r.gps = gs + (a.g_prior_std ? a.g_prior_std[o] : 0.f);
+  r.prm = prm; r.prs = prs;
+  for (int e = 0; e < a.E; ++e) {
+    const mdmm_expert_t& ex = a.experts[e];
+    if (!((ex.pass_bits >> pr.p) & 1u)) continue;
+    const float c = ex.mask ? ex.mask[tb] : 1.0f;
+    const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
+    poe_expert_bwd_f(ex.mean[off], ex.std[off], c, g_num, g_prec, gm, gs);
+    if (owner) {
+      if (ex.g_mean) ex.g_mean[o] = gm;       // one slab per pass, (P,T,B,D)
+      if (ex.g_std) ex.g_std[o] = gs;
+    }
+  }
+  if (owner) {
+    if (a.use_inv_prior) {
+      poe_expert_bwd_f(mu0, -sg0, 1.0f, g_num, g_prec, gm, gs);
+      g_mu0 += gm; g_sg0 -= gs;
+    }
+    if (first) { g_mu0 += r.gpm; g_sg0 += r.gps; }     // first step: prior = p(z)
+  }
+  return r;
+}
+
+template <bool F32, int RT>
+__device__ __forceinline__ void spill_tiles(uint4* dst, const f32x16 (&v)[RT]) {
+  constexpr int CT = Op<F32>::CH_TILE;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int s = 0; s < CT; ++s) dst[(rt * CT + s) * 64] = acc_chunk<F32>(v[rt], s);
+}
+
+template <int RT>
+__device__ __forceinline__ float tile_sum(const f32x16 (&v)[RT]) {
+  float s = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += v[rt][r];
+  return s;
+}
+
+template <bool F32, int RT, bool K1>
+__global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, const WideGeo g,
+                                                        const WideWs ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = BwdLds<F32, RT>;
+  using O = Op<F32>;
+  constexpr int CH = RT * O::CH_TILE;            // chunks of one spilled array slice
+  char* img0 = smem;
+  char* img1 = smem + L::IMG;
+  char* img2 = smem + 2 * L::IMG;
+  char* img3 = smem + 3 * L::IMG;
+  PairRef* tab = reinterpret_cast<PairRef*>(smem + L::OFF_TAB);
+  uint64_t* rowbase = reinterpret_cast<uint64_t*>(smem + L::OFF_ROW);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, n = 32 * wave + (lane & 31);
+  const int T = a.T, B = a.B, K = a.K;
+  const uint64_t noff = noise_off(a);
+  const float inv_k = 1.0f / (float)K;
+
+  build_tables<RT, K1>(a, g, tab, rowbase);
+
+  const uint4* frag = reinterpret_cast<const uint4*>(a.gtf_frag) + (size_t)wave * O::NCH * 64 + lane;
+  const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(a.gtf_frag) +
+                                                     (size_t)N_LAYER * O::LAYER_U4);
+  auto W = [&](int layer) { return frag + (size_t)layer * O::LAYER_U4; };
+  const int arow = (lane & 31) * O::RS + 16 * h;
+  const float b1g = bias[B_1G * WD + n], b1n = bias[B_1N * WD + n], bl = bias[B_L * WD + n];
+  const float b2g = bias[B_2G * WD + n], b2n = bias[B_2N * WD + n], bs = bias[B_S * WD + n];
+  const float mu0 = a.z0_mean[n], sg0 = fast::exp(a.z0_log_std[n]) + a.min_std;
+  const float t0 = fast::rcp(sg0 * sg0 + MDMM_POE_EPS), num0 = mu0 * t0;
+
+  constexpr int NS = K1 ? 16 * RT : RT;          // pair slots held by a lane
+  float adj_a[NS], adj_b[NS], se[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { adj_a[s] = 0.f; adj_b[s] = 0.f; se[s] = 0.f; }
+  float g_mu0 = 0.f, g_sg0 = 0.f;
+  float db1g = 0.f, db1n = 0.f, dbl = 0.f, db2g = 0.f, db2n = 0.f, dbs = 0.f;
+
+  uint4 ring[PF];
+  ring_fill(ring, W(L_W1G));
+  __syncthreads();
+
+  // sum over the particles of the noise of the LAST processed step (enters through `samples`)
+  if (a.g_samples && (a.sample || K > 1 || (T == 1 && a.sample_init))) {
+    const int t = a.reverse ? 0 : T - 1;
+    const uint64_t t_term = (uint64_t)t * K * B * WD;
+    float part[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float e[4];
+        const int r0 = 32 * rt + 8 * q + 4 * h;
+        eps_group(a, noff, t_term, rowbase + r0, n, e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool live = rowbase[r0 + j] != ~0ull;
+          if constexpr (K1) se[rt * 16 + 4 * q + j] = live ? e[j] : 0.f;
+          else acc += live ? e[j] : 0.f;
+        }
+      }
+      part[rt] = acc + other_half(acc);
+    }
+    if constexpr (!K1) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) se[rt] = pair_total(part, rt, g.TPP);
+    }
+  }
+
+  uint4* my_spill = ws.spill + ((size_t)blockIdx.x * ws.n_step * N_SPILL * NWAVE + wave) * CH * 64 + lane;
+  auto spill_at = [&](int step, int arr) {
+    return my_spill + ((size_t)step * N_SPILL + arr) * NWAVE * CH * 64;
+  };
+
+  for (int i = T - 1; i >= 0; --i) {
+    const int t = a.reverse ? T - 1 - i : i;
+    const bool sampled = a.sample || K > 1 || (i == 0 && a.sample_init);
+    // ---- (A) adjoint of sampling + fusion at step i
+    FuseAdj fa[NS];
+    if constexpr (K1) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int s = rt * 16 + reg;
+          fa[s] = fuse_bwd(a, tab[acc_row(rt, reg) + 4 * h], t, n, mu0, sg0, adj_a[s], adj_b[s], se[s],
+                           sampled, inv_k, i == 0, true, g_mu0, g_sg0);
+        }
+    } else {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        fa[rt] = fuse_bwd(a, tab[rt], t, n, mu0, sg0, adj_a[rt], adj_b[rt], se[rt], sampled, inv_k,
+                          i == 0, h == 0 && (rt & (g.TPP - 1)) == 0, g_mu0, g_sg0);
+    }
+    if (i == 0) break;
+
+    // ---- (B) transition into step i: rows = particles of step i-1
+    const int t_prev = a.reverse ? t + 1 : t - 1;
+    const bool sampled_prev = a.sample || K > 1 || (i == 1 && a.sample_init);
+    const uint64_t t_term = (uint64_t)t_prev * K * B * WD;
+    f32x16 ep[RT];                 // eps of the rows (0 on dead rows)
+    unsigned live_bits[RT];
+    f32x16 acc[RT], nl[RT], omg[RT], muq[RT];
+    // R1: particles
+    {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float zm_t = 0.f, zs_t = 0.f;
+        PairRef prt; prt.p = -1; prt.b = 0;
+        if constexpr (!K1) {
+          prt = tab[rt];
+          if (prt.p >= 0) {
+            const size_t o = (((size_t)prt.p * T + t_prev) * B + prt.b) * WD + n;
+            zm_t = a.infer_mean[o]; zs_t = a.infer_std[o];
+          }
+        }
+        unsigned lb = 0;
+        float esum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float e[4] = {0.f, 0.f, 0.f, 0.f};
+          const int r0 = 32 * rt + 8 * q + 4 * h;
+          if (sampled_prev) eps_group(a, noff, t_term, rowbase + r0, n, e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int reg = 4 * q + j;
+            const bool live = rowbase[r0 + j] != ~0ull;
+            float zm = zm_t, zs = zs_t;
+            if constexpr (K1) {
+              const PairRef pr = tab[r0 + j];
+              if (pr.p >= 0) {
+                const size_t o = (((size_t)pr.p * T + t_prev) * B + pr.b) * WD + n;
+                zm = a.infer_mean[o]; zs = a.infer_std[o];
+              }
+            }
+            const float ee = live ? e[j] : 0.f;
+            ep[rt][reg] = ee;
+            acc[rt][reg] = live ? fmaf(ee, zs, zm) : 0.f;
+            lb |= live ? (1u << reg) : 0u;
+            if constexpr (K1) se[rt * 16 + reg] = ee; else esum += ee;
+          }
+        }
+        live_bits[rt] = lb;
+        if constexpr (!K1) se[rt] = esum + other_half(esum);
+      }
+      if constexpr (!K1) {
+        float tmp[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) tmp[rt] = se[rt];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) se[rt] = pair_total(tmp, rt, g.TPP);
+      }
+      store_image<F32, RT>(img0, acc, wave, lane);
+      spill_tiles<F32, RT>(spill_at(i - 1, S_Z), acc);
+    }
+    __syncthreads();
+    // R2: hidden layers
+    unsigned mask_g[RT], mask_n[RT];
+    zero_acc(acc);
+    gemm_tile<F32, RT>(acc, img0 + arow, W(L_W1G), W(L_W1N), ring);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      unsigned mb = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[rt][r] + b1g;
+        mb |= (v > 0.f) ? (1u << r) : 0u;
+        acc[rt][r] = fmaxf(v, 0.f);
+      }
+      mask_g[rt] = mb;
+    }
+    store_image<F32, RT>(img1, acc, wave, lane);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_HG), acc);
+    zero_acc(acc);
+    gemm_tile<F32, RT>(acc, img0 + arow, W(L_W1N), W(L_W2G), ring);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      unsigned mb = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[rt][r] + b1n;
+        mb |= (v > 0.f) ? (1u << r) : 0u;
+        acc[rt][r] = fmaxf(v, 0.f);
+      }
+      mask_n[rt] = mb;
+    }
+    store_image<F32, RT>(img2, acc, wave, lane);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_HN), acc);
+    __syncthreads();
+    // R3: gate, non-linear branch, mean
+    zero_acc(omg);
+    gemm_tile<F32, RT>(omg, img1 + arow, W(L_W2G), W(L_W2N), ring);
+    zero_acc(nl);
+    gemm_tile<F32, RT>(nl, img2 + arow, W(L_W2N), W(L_WL), ring);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        nl[rt][r] += b2n;
+        const float ex = fast::exp(fminf(fmaxf(omg[rt][r] + b2g, -30.f), 30.f));
+        omg[rt][r] = fast::rcp(1.0f + ex);
+        muq[rt][r] = nl[rt][r] * ex;
+      }
+    store_image<F32, RT>(img3, nl, wave, lane);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_NL), nl);
+    gemm_tile<F32, RT>(muq, img0 + arow, W(L_WL), W(L_WS), ring);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) muq[rt][r] = omg[rt][r] * (muq[rt][r] + bl);
+    __syncthreads();
+    // R4: std pre-activation
+    zero_acc(acc);
+    gemm_tile<F32, RT>(acc, img3 + arow, W(L_WS), W(T_WS), ring);
+    // E: elementwise adjoint; acc: pre -> G3, omg -> Glin, nl -> direct part of GN, muq -> GG
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      float gv2k = 0.f, gpmk = 0.f, mb = 0.f;
+      if constexpr (!K1) {
+        gv2k = fa[rt].gps * fast::rcp(fa[rt].prs) * inv_k;      // 2 g_v / K  (dgts.py:79-83)
+        gpmk = fa[rt].gpm * inv_k; mb = fa[rt].prm;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pre = acc[rt][r] + bs;
+        const float sq = fast::softplus(pre) + a.min_std;
+        const float tq = fast::rcp(sq * sq + MDMM_POE_EPS);
+        const float rp = fast::rcp(t0 + tq);
+        const float num = num0 + muq[rt][r] * tq;
+        const float mraw = num * rp, m = (mraw != mraw) ? 0.f : mraw, sd = fast::sqrt(rp);
+        float g_m, g_sd;
+        if constexpr (K1) { g_m = fa[rt * 16 + r].gpm; g_sd = fa[rt * 16 + r].gps; }
+        else { g_m = gpmk + gv2k * (m - mb); g_sd = gv2k * sd; }
+        const bool live = (live_bits[rt] >> r) & 1u;
+        if (!live) { g_m = 0.f; g_sd = 0.f; }
+        float g_num, g_prec, gm0, gs0, g_muq, g_sq;
+        poe_out_bwd_f(num, rp, sd, g_m, g_sd, g_num, g_prec);
+        poe_expert_bwd_f(mu0, sg0, 1.0f, g_num, g_prec, gm0, gs0);
+        poe_expert_bwd_f(muq[rt][r], sq, 1.0f, g_num, g_prec, g_muq, g_sq);
+        g_mu0 += gm0; g_sg0 += gs0;
+        const float gate = 1.0f - omg[rt][r];
+        acc[rt][r] = g_sq * fast::softplus_grad(pre);                       // d/d std pre-act
+        const float gg = g_muq * gate * (nl[rt][r] - muq[rt][r]);           // d/d gate pre-act
+        nl[rt][r] = g_muq * gate;                                           // direct part of d/d nl
+        omg[rt][r] = g_muq * omg[rt][r];                                    // d/d z_lin
+        muq[rt][r] = gg;
+      }
+    }
+    store_image<F32, RT>(img1, acc, wave, lane);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_G3), acc);
+    store_image<F32, RT>(img2, muq, wave, lane);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_GG), muq);
+    store_image<F32, RT>(img0, omg, wave, lane);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_GLIN), omg);
+    dbs += tile_sum(acc); db2g += tile_sum(muq); dbl += tile_sum(omg);
+    __syncthreads();
+    // D1: d/d nl = direct + W_std^T d/d std-pre
+    gemm_tile<F32, RT>(nl, img1 + arow, W(T_WS), W(T_W2G), ring);
+    store_image<F32, RT>(img3, nl, wave, lane);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_GN), nl);
+    db2n += tile_sum(nl);
+    __syncthreads();
+    // D2: hidden adjoints through the relus
+    zero_acc(acc);
+    gemm_tile<F32, RT>(acc, img2 + arow, W(T_W2G), W(T_W2N), ring);
+    zero_acc(muq);
+    gemm_tile<F32, RT>(muq, img3 + arow, W(T_W2N), W(T_W1G), ring);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (!((mask_g[rt] >> r) & 1u)) acc[rt][r] = 0.f;
+        if (!((mask_n[rt] >> r) & 1u)) muq[rt][r] = 0.f;
+      }
+    store_image<F32, RT>(img1, acc, wave, lane);       // G3 image: every wave is past D1
+    spill_tiles<F32, RT>(spill_at(i - 1, S_GHG), acc);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_GHN), muq);
+    db1g += tile_sum(acc); db1n += tile_sum(muq);
+    __syncthreads();                                    // every wave is done with the GG image
+    store_image<F32, RT>(img2, muq, wave, lane);
+    __syncthreads();
+    // D3: d/dz of the previous particles
+    zero_acc(acc);
+    gemm_tile<F32, RT>(acc, img1 + arow, W(T_W1G), W(T_W1N), ring);
+    gemm_tile<F32, RT>(acc, img2 + arow, W(T_W1N), W(T_WL), ring);
+    gemm_tile<F32, RT>(acc, img0 + arow, W(T_WL), W(L_W1G), ring);
+    if constexpr (K1) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          adj_a[rt * 16 + r] = acc[rt][r];
+          adj_b[rt * 16 + r] = acc[rt][r] * ep[rt][r];
+        }
+    } else {
+      float pa[RT], pb[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool live = (live_bits[rt] >> r) & 1u;
+          const float gz = live ? acc[rt][r] : 0.f;
+          sa += gz; sb = fmaf(gz, ep[rt][r], sb);
+        }
+        pa[rt] = sa + other_half(sa); pb[rt] = sb + other_half(sb);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) { adj_a[rt] = pair_total(pa, rt, g.TPP); adj_b[rt] = pair_total(pb, rt, g.TPP); }
+    }
+    __syncthreads();
+  }
+
+  // partial sums of this workgroup
+  {
+    float* db = ws.db + (size_t)blockIdx.x * 6 * WD;
+    const float v[6] = {db1g, db1n, dbl, db2g, db2n, dbs};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float tot = v[k] + other_half(v[k]);
+      if (h == 0) db[k * WD + n] = tot;
+    }
+    float* dz = ws.dz0 + (size_t)blockIdx.x * 2 * WD;
+    const float m0 = g_mu0 + other_half(g_mu0), s0 = g_sg0 + other_half(g_sg0);
+    if (h == 0) { dz[n] = m0; dz[WD + n] = s0; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradients: dW[block] = G^T X over every spilled row.  grid = (6 blocks, split);
+// wave (wa, wb) owns G tiles {2wa, 2wa+1} x X tiles {4wb .. 4wb+3} of the 256 x 256 block.
+// ---------------------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int CH) {
+  const int blk = blockIdx.x, sp = blockIdx.y;
+  const int garr = S_GHG + blk;                           // Ghg, Ghn, Glin, GG, GN, G3
+  const int xarr = blk < 3 ? S_Z : (blk == 3 ? S_HG : (blk == 4 ? S_HN : S_NL));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wa = wave >> 1, wb = wave & 1;
+  const int64_t items = ws.n_wg * ws.n_step;
+  const int64_t per = (items + ws.split - 1) / ws.split;
+  const int64_t lo = sp * per, hi = (lo + per < items) ? lo + per : items;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const size_t arr_u4 = (size_t)NWAVE * CH * 64;
+  for (int64_t it = lo; it < hi; ++it) {
+    const uint4* gp = ws.spill + ((size_t)it * N_SPILL + garr) * arr_u4 + (size_t)(2 * wa) * CH * 64 + lane;
+    const uint4* xp = ws.spill + ((size_t)it * N_SPILL + xarr) * arr_u4 + (size_t)(4 * wb) * CH * 64 + lane;
+    for (int c = 0; c < CH; ++c) {
+      uint4 ga[2], xb[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ga[i] = gp[((size_t)i * CH + c) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xb[j] = xp[((size_t)j * CH + c) * 64];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma<F32>(acc[i][j], ga[i], xb[j]);
+    }
+  }
+  float* slab = ws.slab + ((size_t)sp * 6 + blk) * WD * WD;
+  const int hh = lane >> 5, col = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * (2 * wa + i) + acc_row(0, r) + 4 * hh;
+        slab[(size_t)row * WD + 32 * (4 * wb + j) + col] = acc[i][j][r];
+      }
+}
+
+// slabs / per-workgroup partials -> one row in the dw_partial layout (include/mdmm_hip.h):
+//   dW_in [768][256] (z_to_gate.0 | z_nonlin.0 | z_lin) | dW_gate | dW_nl | dW_std | db_in [768] |
+//   db_gate | db_nl | db_std | d z0_mean | d sigma0
+__global__ __launch_bounds__(256) void wide_reduce_kernel(const WideWs ws, float* out) {
+  const int NW = 6 * WD * WD;
+  const int total = NW + 6 * WD + 2 * WD;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    float s = 0.f;
+    if (idx < NW) {
+      // slab blocks (Ghg,Z) (Ghn,Z) (Glin,Z) (GG,HG) (GN,HN) (G3,NL) are already in output order
+      for (int sp = 0; sp < ws.split; ++sp) s += ws.slab[(size_t)sp * NW + idx];
+    } else if (idx < NW + 6 * WD) {
+      const int k = idx - NW;
+      for (int64_t w = 0; w < ws.n_wg; ++w) s += ws.db[(size_t)w * 6 * WD + k];
+    } else {
+      const int k = idx - NW - 6 * WD;
+      for (int64_t w = 0; w < ws.n_wg; ++w) s += ws.dz0[(size_t)w * 2 * WD + k];
+    }
+    out[idx] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// fragment pack
+// ---------------------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void frag_pack_kernel(const mdmm_gtf_raw_t raw, uint4* out) {
+  using O = Op<F32>;
+  const int total = N_LAYER * O::LAYER_U4;
+  const float* src[6] = {raw.w_gate0, raw.w_nl0, raw.w_lin, raw.w_gate2, raw.w_nl2, raw.w_std0};
+  // layers 6..11: transposes of (z_to_std.0, z_nonlin.2, z_to_gate.2, z_to_gate.0, z_nonlin.0, z_lin)
+  const int tsrc[6] = {5, 4, 3, 0, 1, 2};
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int lane = idx & 63, c = (idx >> 6) % O::NCH, tile = (idx >> 6) / O::NCH % NWAVE;
+    const int layer = idx / O::LAYER_U4;
+    const int nn = 32 * tile + (lane & 31), hh = lane >> 5;
+    const bool tr = layer >= 6;
+    const float* w = src[tr ? tsrc[layer - 6] : layer];
+    uint4 o;
+    if constexpr (F32) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 8 * c + 4 * hh + j;
+        v[j] = tr ? w[(size_t)k * WD + nn] : w[(size_t)nn * WD + k];
+      }
+      o.x = __float_as_uint(v[0]); o.y = __float_as_uint(v[1]);
+      o.z = __float_as_uint(v[2]); o.w = __float_as_uint(v[3]);
+    } else {
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 16 * c + 8 * hh + j;
+        v[j] = (__bf16)(tr ? w[(size_t)k * WD + nn] : w[(size_t)nn * WD + k]);
+      }
+      o = __builtin_bit_cast(uint4, v);
+    }
+    out[idx] = o;
+  }
+  // biases behind the layers (fp32)
+  float* bo = reinterpret_cast<float*>(out + total);
+  const float* bsrc[6] = {raw.b_gate0, raw.b_nl0, raw.b_lin, raw.b_gate2, raw.b_nl2, raw.b_std0};
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < N_BIAS * WD; idx += gridDim.x * 256)
+    bo[idx] = bsrc[idx / WD][idx % WD];
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+template <typename Kern>
+int set_lds(Kern kern, int bytes) {
+  // per device, not per process: a second GPU driven by the same process needs its own call
+  static bool done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (done[dev]) return 0;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done[dev] = true;
+  return 0;
+}
+
+template <bool F32, int RT, bool K1>
+int launch_fwd(const mdmm_sweep_t* a, const WideGeo& g, hipStream_t stream) {
+  using L = FwdLds<F32, RT>;
+  auto kern = wide_fwd_kernel<F32, RT, K1>;
+  int rc = set_lds(kern, L::BYTES);
+  if (rc) return rc;
+  const int grid = (g.n_pairs + g.NP - 1) / g.NP;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), L::BYTES, stream, *a, g);
+  return (int)hipGetLastError();
+}
+
+template <bool F32, int RT, bool K1>
+int launch_bwd(const mdmm_sweep_t* a, const WideGeo& g, const WideWs& ws, hipStream_t stream) {
+  using L = BwdLds<F32, RT>;
+  auto kern = wide_bwd_kernel<F32, RT, K1>;
+  int rc = set_lds(kern, L::BYTES);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)ws.n_wg), dim3(NTHR), L::BYTES, stream, *a, g, ws);
+  return (int)hipGetLastError();
+}
+
+// Row tiles per workgroup (0 = outside the family).  One geometry serves the forward and the
+// backward sweep of a precision only where stated: the forward packs more rows (two LDS images,
+// fewer live registers), the backward needs four images.
+//            K = 1    1 < K <= 32   K <= 64   K <= 128
+//   fwd bf16   1          4            4         4
+//   bwd bf16   1          2            2         -
+//   fwd f32    1          1            -         -
+//   bwd f32    1          1            -         -
+int plan(const mdmm_sweep_t* a, bool bwd, WideGeo* g) {
+  if (!a || a->D != WD || a->H != WD || !a->gtf_frag || a->trans_only) return 0;
+  if (a->precision != MDMM_PREC_F32 && a->precision != MDMM_PREC_BF16) return 0;
+  if ((int64_t)a->P * a->T * a->B * WD >= (1ll << 40)) return 0;
+  const bool f32 = a->precision == MDMM_PREC_F32;
+  g->n_pairs = a->P * a->B;
+  if (a->K == 1) { g->TPP = 1; g->NP = 32; g->ntab = 32; return 1; }
+  const int RT = f32 ? 1 : (bwd ? 2 : 4);
+  int tpp = (a->K + 31) / 32;
+  if (tpp == 3) tpp = 4;
+  if (tpp > RT) return 0;
+  g->TPP = tpp; g->NP = RT / tpp; g->ntab = RT;
+  return RT;
+}
+
+// carve the backward workspace; returns the bytes needed
+int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
+  const bool f32 = a->precision == MDMM_PREC_F32;
+  const int CH = RT * (f32 ? 4 : 2);
+  const int64_t n_wg = (g.n_pairs + g.NP - 1) / g.NP, n_step = a->T - 1;
+  const int64_t items = n_wg * n_step;
+  int split = 64;
+  if (split > items) split = items > 0 ? (int)items : 1;
+  auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+  const int64_t b_spill = up(items * N_SPILL * NWAVE * CH * 64 * 16);
+  const int64_t b_db = up(n_wg * 6 * WD * 4), b_dz = up(n_wg * 2 * WD * 4);
+  const int64_t b_slab = up((int64_t)split * 6 * WD * WD * 4);
+  if (ws) {
+    char* p = reinterpret_cast<char*>(a->wide_ws);
+    ws->spill = reinterpret_cast<uint4*>(p); p += b_spill;
+    ws->db = reinterpret_cast<float*>(p); p += b_db;
+    ws->dz0 = reinterpret_cast<float*>(p); p += b_dz;
+    ws->slab = reinterpret_cast<float*>(p);
+    ws->n_wg = n_wg; ws->n_step = n_step; ws->split = split;
+  }
+  return b_spill + b_db + b_dz + b_slab;
+}
+
+}  // namespace
+
+int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
+  WideGeo g;
+  const int RT = plan(a, false, &g);
+  if (!RT) return MDMM_UNSUPPORTED;
+  if (((uintptr_t)a->gtf_frag) & 15) return MDMM_E_ALIGN;
+  const bool f32 = a->precision == MDMM_PREC_F32;
+  if (a->K == 1) return f32 ? launch_fwd<true, 1, true>(a, g, stream) : launch_fwd<false, 1, true>(a, g, stream);
+  return f32 ? launch_fwd<true, 1, false>(a, g, stream) : launch_fwd<false, 4, false>(a, g, stream);
+}
+
+int mdmm_wide_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
+  WideGeo g;
+  const int RT = plan(a, true, &g);
+  if (!RT) return MDMM_UNSUPPORTED;
+  if ((((uintptr_t)a->gtf_frag) | ((uintptr_t)a->wide_ws)) & 15) return MDMM_E_ALIGN;
+  if (!a->wide_ws || !a->dw_partial || a->dw_partial_rows < 1) return MDMM_E_ARG;
+  WideWs ws;
+  if (a->wide_ws_bytes < carve(a, g, RT, &ws)) return MDMM_E_ARG;
+  const bool f32 = a->precision == MDMM_PREC_F32;
+  int rc;
+  if (a->K == 1) rc = f32 ? launch_bwd<true, 1, true>(a, g, ws, stream) : launch_bwd<false, 1, true>(a, g, ws, stream);
+  else rc = f32 ? launch_bwd<true, 1, false>(a, g, ws, stream) : launch_bwd<false, 2, false>(a, g, ws, stream);
+  if (rc) return rc;
+  const int CH = RT * (f32 ? 4 : 2);
+  if (f32) hipLaunchKernelGGL(wide_wgrad_kernel<true>, dim3(6, ws.split), dim3(NTHR), 0, stream, ws, CH);
+  else hipLaunchKernelGGL(wide_wgrad_kernel<false>, dim3(6, ws.split), dim3(NTHR), 0, stream, ws, CH);
+  rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(wide_reduce_kernel, dim3(512), dim3(256), 0, stream, ws, a->dw_partial);
+  return (int)hipGetLastError();
+}
+
+int mdmm_wide_bwd_supported(const mdmm_sweep_t* a) {
+  WideGeo g;
+  return plan(a, true, &g) != 0;
+}
+
+extern "C" int mdmm_sweep_wide(const mdmm_sweep_t* a) {
+  WideGeo g;
+  return plan(a, false, &g) != 0;
+}
+
+extern "C" int64_t mdmm_sweep_wide_ws_bytes(const mdmm_sweep_t* a) {
+  WideGeo g;
+  const int RT = plan(a, true, &g);
+  return RT ? carve(a, g, RT, nullptr) : 0;
+}
+
+extern "C" int64_t mdmm_gtf_frag_bytes(int D, int H, int precision) {
+  if (D != WD || H != WD) return 0;
+  if (precision == MDMM_PREC_F32) return (int64_t)N_LAYER * Op<true>::LAYER_U4 * 16 + N_BIAS * WD * 4;
+  if (precision == MDMM_PREC_BF16) return (int64_t)N_LAYER * Op<false>::LAYER_U4 * 16 + N_BIAS * WD * 4;
+  return 0;
+}
+
+extern "C" int mdmm_gtf_frag_pack(const mdmm_gtf_raw_t* raw, int D, int H, int precision, void* out,
+                                  void* stream) {
+  if (!raw || !out || !mdmm_gtf_frag_bytes(D, H, precision)) return MDMM_E_ARG;
+  if (((uintptr_t)out) & 15) return MDMM_E_ALIGN;
+  if (precision == MDMM_PREC_F32)
+    hipLaunchKernelGGL(frag_pack_kernel<true>, dim3(512), dim3(256), 0, (hipStream_t)stream, *raw, (uint4*)out);
+  else
+    hipLaunchKernelGGL(frag_pack_kernel<false>, dim3(512), dim3(256), 0, (hipStream_t)stream, *raw, (uint4*)out);
+  return (int)hipGetLastError();
+}

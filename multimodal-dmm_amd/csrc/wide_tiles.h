@@ -1,0 +1,168 @@
+// Building blocks of the "wide" kernel family (z_dim = h_dim = 256; sweep_wide.hip, wide_wgrad.hip).
+//
+// Geometry.  A workgroup is 8 waves (512 threads, two waves per SIMD); it owns R = 32*RT
+// transition rows (pass, sequence, particle) for the whole time loop.  Wave w owns the output
+// features n in [32w, 32w + 32) of EVERY 256-wide layer output, all R rows of it: one MFMA
+// accumulator tile (32 rows x 32 features) per row tile.  Tiles are computed as
+//     Y[r][n] = sum_k X[r][k] * W[n][k]      A operand = X (rows r on the lanes), B operand = W
+// so that the accumulator has its FEATURE on the lane (n = 32w + lane % 32) and its 16 ROWS in
+// the registers (r = 32*rt + 8*(reg / 4) + 4*(lane / 32) + reg % 4):
+//   * everything per (row, feature) is elementwise on the accumulator registers,
+//   * sums over the particles of a sequence are in-lane adds plus ONE exchange between the two
+//     lane halves -- no butterflies,
+//   * loads / stores of (T,B,D) tensors have the latent index on the lanes (coalesced 128 B).
+// Activations cross waves through LDS images X[row][feature] (bf16 or fp32, rows padded by 16 B:
+// every ds_read_b128 of an A operand is bank-conflict free); the weights never touch LDS: they
+// are packed once per optimizer step as ready-made B-operand fragments (mdmm_gtf_frag_pack) and
+// each wave streams exactly the fragments of its own feature slice from L2 with 1 KB coalesced
+// loads, a few chunks ahead of the MFMAs (every weight byte is read once per workgroup-step).
+//
+// Operand precision is a template switch: `F32` = fp32 operands on v_mfma_f32_32x32x2_f32 (exact
+// fp32 FMA chain, parity mode), otherwise bf16 operands on v_mfma_f32_32x32x16_bf16.  One
+// "chunk" is 16 bytes of A and 16 bytes of B per lane: one bf16 MFMA (16 deep) or four fp32
+// MFMAs (2 deep each; element j of lane half h contracts k = 8c + 4h + j on both operands).
+#pragma once
+#include "mdmm_device.h"
+
+namespace wide {
+
+using namespace mdmm;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WD = 256;     // z_dim = h_dim of the family
+constexpr int NWAVE = 8;
+constexpr int NTHR = 64 * NWAVE;
+
+// layer indices of the fragment pack (include/mdmm_hip.h, mdmm_gtf_frag_pack)
+enum Layer { L_W1G = 0, L_W1N, L_WL, L_W2G, L_W2N, L_WS, T_WS, T_W2N, T_W2G, T_W1G, T_W1N, T_WL, N_LAYER };
+enum Bias { B_1G = 0, B_1N, B_L, B_2G, B_2N, B_S, N_BIAS };
+
+template <bool F32>
+struct Op {
+  static constexpr int ESZ = F32 ? 4 : 2;            // bytes per operand element
+  static constexpr int ROWB = WD * ESZ;              // one activation row in LDS
+  static constexpr int RS = ROWB + 16;               // padded row stride
+  static constexpr int NCH = ROWB / 32;              // operand chunks per 256-deep contraction
+  static constexpr int LAYER_U4 = NWAVE * NCH * 64;  // uint4 per packed layer
+  static constexpr int CH_TILE = F32 ? 4 : 2;        // chunks holding one 32-row accumulator tile
+};
+
+template <bool F32>
+__device__ __forceinline__ void mma(f32x16& acc, const uint4& a, const uint4& b) {
+  if constexpr (F32) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                  __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+}
+
+template <int RT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT]) {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
+}
+
+constexpr int PF = 4;   // weight chunks in flight per wave ahead of the MFMAs
+
+// first PF chunks of a layer slice into the ring (w = this lane's fragment pointer of the layer)
+__device__ __forceinline__ void ring_fill(uint4 (&ring)[PF], const uint4* __restrict__ w) {
+#pragma unroll
+  for (int c = 0; c < PF; ++c) ring[c] = w[c * 64];
+}
+
+// acc[rt] += X[32rt .. 32rt+32)[0..256) . W_slice^T.  `xrow` = this lane's A-operand address in
+// the LDS image (row lane % 32 of tile 0, 16*(lane/32) bytes in); `w` = this lane's fragment
+// pointer into the layer (chunk c at w[64c]).  The ring holds chunks 0..PF-1 of `w` on entry and
+// chunks 0..PF-1 of `wnext` (the layer the wave contracts with next) on exit, so the weight
+// stream never drains at a phase boundary.
+template <bool F32, int RT>
+__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[RT], const char* xrow,
+                                          const uint4* __restrict__ w,
+                                          const uint4* __restrict__ wnext, uint4 (&ring)[PF]) {
+  constexpr int NCH = Op<F32>::NCH, RS = Op<F32>::RS;
+  static_assert(NCH % PF == 0, "ring depth");
+  // a real loop over groups of PF chunks: fully unrolled, the compiler hoists every weight load
+  // of the phase to its top and spills
+#pragma unroll 1
+  for (int c0 = 0; c0 < NCH; c0 += PF) {
+    const uint4* nxt = (c0 + PF < NCH) ? w + (c0 + PF) * 64 : wnext;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const uint4 b = ring[u];
+      ring[u] = nxt[u * 64];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const uint4 av = *reinterpret_cast<const uint4*>(xrow + rt * 32 * RS + 32 * (c0 + u));
+        mma<F32>(acc[rt], av, b);
+      }
+    }
+  }
+}
+
+// row of accumulator register `reg` in tile rt for lane half h
+__device__ __forceinline__ constexpr int acc_row(int rt, int reg) {
+  return 32 * rt + 8 * (reg >> 2) + (reg & 3);      // + 4 * h
+}
+
+// accumulator tiles -> LDS image X[row][32w + lane%32] (this wave's feature slice)
+template <bool F32, int RT>
+__device__ __forceinline__ void store_image(char* img, const f32x16 (&v)[RT], int wave, int lane) {
+  constexpr int RS = Op<F32>::RS, ESZ = Op<F32>::ESZ;
+  char* base = img + 4 * (lane >> 5) * RS + (32 * wave + (lane & 31)) * ESZ;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      char* p = base + acc_row(rt, reg) * RS;
+      if constexpr (F32) *reinterpret_cast<float*>(p) = v[rt][reg];
+      else *reinterpret_cast<__bf16*>(p) = (__bf16)v[rt][reg];
+    }
+}
+
+// one 16-byte operand chunk of an accumulator tile, as the weight-gradient contraction over rows
+// takes it (A or B operand alike: both sides pair lane half h, element j with the same row).
+//   bf16: chunk s (0,1) = registers 8s .. 8s+7, rounded to bf16
+//   fp32: chunk s (0..3) = registers 4s .. 4s+3
+template <bool F32>
+__device__ __forceinline__ uint4 acc_chunk(const f32x16& v, int s) {
+  uint4 o;
+  if constexpr (F32) {
+    o.x = __float_as_uint(v[4 * s]); o.y = __float_as_uint(v[4 * s + 1]);
+    o.z = __float_as_uint(v[4 * s + 2]); o.w = __float_as_uint(v[4 * s + 3]);
+  } else {
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[8 * s + j];
+    o = __builtin_bit_cast(uint4, b);
+  }
+  return o;
+}
+
+// 4 x 4 transpose across the four lanes of a quad: lane u hands in e[v] = M[u][v] and gets
+// e[j] = M[j][u] (two DPP exchange rounds, xor 1 then xor 2).
+__device__ __forceinline__ float quad_x1(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_x2(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose(float (&e)[4], int u) {
+  const bool o1 = u & 1, o2 = u & 2;
+  const float r0 = quad_x1(o1 ? e[0] : e[1]), r2 = quad_x1(o1 ? e[2] : e[3]);
+  if (o1) { e[0] = r0; e[2] = r2; } else { e[1] = r0; e[3] = r2; }
+  const float ra = quad_x2(o2 ? e[0] : e[2]), rb = quad_x2(o2 ? e[1] : e[3]);
+  if (o2) { e[0] = ra; e[1] = rb; } else { e[2] = ra; e[3] = rb; }
+}
+
+// value of the other lane half (lane ^ 32)
+__device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32, 64); }
+
+}  // namespace wide

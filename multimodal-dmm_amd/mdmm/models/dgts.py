@@ -17,6 +17,11 @@ class MultiDGTS(nn.Module):
     # MIOpen) under autocast, as BASELINE cfg3 asks; the latent state, the sweeps, the products of
     # experts and every loss reduction stay fp32.  None (default) = everything fp32.
     plugin_dtype = None
+    # Operand type of the dense contractions inside the z = h = 256 sweeps (csrc/sweep_wide.hip):
+    # torch.float32 (default; fp32 operands on the f32 MFMA, the parity mode) or torch.bfloat16
+    # (bf16 operands, fp32 accumulation: 16x the matrix rate, what BASELINE cfg3 is quoted in).
+    # The latent state, products of experts, moments and reductions are fp32 in both.
+    sweep_dtype = torch.float32
 
     def _plug(self, module, x):
         if self.plugin_dtype is None or not x.is_cuda:

@@ -225,7 +225,8 @@ class MultiDMM(MultiDGTS):
         reverse = direction == 'bwd'
         kw = dict(T=t_max, B=b_dim, D=self.z_dim, H=self.h_dim, P=n_pass, K=n_particles,
                   reverse=reverse, sample=sample, sample_init=sample_init,
-                  use_inv_prior=use_inv_prior, min_std=self.min_std, need_samples=need_samples)
+                  use_inv_prior=use_inv_prior, min_std=self.min_std, need_samples=need_samples,
+                  precision=self.sweep_dtype)
         eps = self._eps_or_stream(kw, t_max, b_dim, n_pass, n_particles, sample, sample_init,
                                   reverse, draws)
         cfg = ops.SweepCfg(**kw)

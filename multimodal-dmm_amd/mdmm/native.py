@@ -12,13 +12,15 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 10
+ABI_VERSION = 11
+PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
     'mdmm_version', 'mdmm_strerror', 'mdmm_pad', 'mdmm_sizeof',
     'mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd',
     'mdmm_sweep_spill_width_g', 'mdmm_sweep_spill_width_x',
     'mdmm_sweep_bwd_mode', 'mdmm_sweep_dw_width', 'mdmm_sweep_dw_rows',
+    'mdmm_sweep_wide', 'mdmm_sweep_wide_ws_bytes', 'mdmm_gtf_frag_bytes', 'mdmm_gtf_frag_pack',
     'mdmm_poe_fwd', 'mdmm_poe_bwd', 'mdmm_moe_fwd', 'mdmm_moe_bwd',
     'mdmm_kld_gauss_fwd', 'mdmm_kld_gauss_bwd',
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
@@ -63,7 +65,9 @@ class Sweep(C.Structure):
                  ('g_prior_std', _P), ('g_samples', _P),
                  ('g_z0_mean', _P), ('g_z0_sigma', _P), ('g_z_rows', _P),
                  ('spill_g', _P), ('spill_x', _P), ('spill_rows', C.c_int64),
-                 ('dw_partial', _P), ('dw_partial_rows', C.c_int64), ('offset_dev', _P)])
+                 ('dw_partial', _P), ('dw_partial_rows', C.c_int64), ('offset_dev', _P),
+                 ('gtf_frag', _P), ('precision', C.c_int32), ('reserved1', C.c_int32),
+                 ('wide_ws', _P), ('wide_ws_bytes', C.c_int64)])
 
 
 class Stage(C.Structure):
@@ -156,6 +160,12 @@ def lib():
         L.mdmm_gtf_pack_size.argtypes = [C.c_int, C.c_int]
         L.mdmm_gtf_pack_size.restype = C.c_int64
         L.mdmm_gtf_pack.argtypes = [C.POINTER(GtfRaw), C.c_int, C.c_int, _P, _P]
+        L.mdmm_gtf_frag_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.mdmm_gtf_frag_bytes.restype = C.c_int64
+        L.mdmm_gtf_frag_pack.argtypes = [C.POINTER(GtfRaw), C.c_int, C.c_int, C.c_int, _P, _P]
+        L.mdmm_sweep_wide.argtypes = [C.POINTER(Sweep)]
+        L.mdmm_sweep_wide_ws_bytes.argtypes = [C.POINTER(Sweep)]
+        L.mdmm_sweep_wide_ws_bytes.restype = C.c_int64
         if L.mdmm_version() != ABI_VERSION:
             raise MdmmError('libmdmm_hip.so ABI %d != binding ABI %d'
                             % (L.mdmm_version(), ABI_VERSION))

@@ -202,11 +202,59 @@ def packed_gtf(params, D, H):
     return hit[1]
 
 
+class FragPack:
+    """Fragment-ordered operand pack of one GaussianGTF for the wide family (z = h = 256):
+    include/mdmm_hip.h, mdmm_gtf_frag_pack."""
+
+    def __init__(self, params, D, H, precision):
+        L = native.lib()
+        nbytes = L.mdmm_gtf_frag_bytes(D, H, precision)
+        if not nbytes:
+            raise native.MdmmError('no fragment pack for z_dim=%d h_dim=%d' % (D, H))
+        raw = native.GtfRaw()
+        keep = [_f32c(p.detach()) for p in params]
+        for (name, _), t in zip(native.GtfRaw._fields_, keep):
+            setattr(raw, name, _ptr(t))
+        self.precision = precision
+        self.buf = torch.empty(nbytes, device=params[0].device, dtype=torch.uint8)
+        assert self.buf.data_ptr() % 16 == 0
+        _call('mdmm_gtf_frag_pack', C.byref(raw), D, H, precision, _ptr(self.buf))
+
+
+def packed_frag(params, D, H, precision):
+    """FragPack of the given parameters, cached on the first parameter like packed_gtf."""
+    key = tuple((p.data_ptr(), p._version) for p in params) + (D, H, precision)
+    hit = getattr(params[0], '_mdmm_frag', None)
+    if hit is None or hit[0] != key:
+        hit = (key, FragPack(params, D, H, precision))
+        params[0]._mdmm_frag = hit
+    return hit[1]
+
+
+PRECISIONS = {None: native.PREC_F32, 'fp32': native.PREC_F32, torch.float32: native.PREC_F32,
+              'bf16': native.PREC_BF16, torch.bfloat16: native.PREC_BF16}
+
+
+def wide_shape(cfg, bwd=False):
+    """Sizes the wide MFMA family takes (csrc/sweep_wide.hip, table at `plan`): z = h = 256, the
+    K particles of a (pass, sequence) within one workgroup's rows."""
+    if cfg.D != 256 or cfg.H != 256 or cfg.trans_only:
+        return False
+    import os
+    if os.environ.get('MDMM_FORCE_GENERIC') == '1' or os.environ.get('MDMM_NO_WIDE') == '1':
+        return False
+    if PRECISIONS[cfg.precision] == native.PREC_F32:
+        return cfg.K <= 32
+    return cfg.K <= (64 if bwd else 128)
+
+
 def clear_caches(params=()):
     """Drop host-side caches (call before capturing a step into a HIP graph)."""
     for p in params:
         if hasattr(p, '_mdmm_pack'):
             del p._mdmm_pack
+        if hasattr(p, '_mdmm_frag'):
+            del p._mdmm_frag
 
 
 # ------------------------------------------------------------------------------------
@@ -217,13 +265,16 @@ class SweepCfg:
 
     def __init__(self, T, B, D, H, P=1, K=1, reverse=False, sample=True, sample_init=False,
                  use_inv_prior=False, min_std=1e-3, seed=0, offset=0, need_samples=True,
-                 trans_only=False, offset_dev=None):
+                 trans_only=False, offset_dev=None, precision=None):
         self.T, self.B, self.D, self.H, self.P, self.K = T, B, D, H, P, K
         self.reverse, self.sample, self.sample_init = bool(reverse), bool(sample), bool(sample_init)
         self.use_inv_prior, self.min_std = bool(use_inv_prior), float(min_std)
         self.seed, self.offset = int(seed), int(offset)
         self.need_samples, self.trans_only = bool(need_samples), bool(trans_only)
         self.offset_dev = offset_dev        # int64 device tensor added to `offset` in-kernel
+        if precision not in PRECISIONS:
+            raise ValueError('sweep precision %r: use torch.float32 or torch.bfloat16' % (precision,))
+        self.precision = precision          # operand type of the wide family's contractions
 
 
 def _sweep_tag(which, cfg):
@@ -399,8 +450,10 @@ class _SweepFn(torch.autograd.Function):
         if n_exp > native.MAX_EXPERTS or cfg.P > native.MAX_PASSES:
             raise native.MdmmError('too many experts / passes for one sweep')
         dev = z0_mean.device
+        wide = wide_shape(cfg)
         staged = _use_staged(cfg)
         packed = None if staged else packed_gtf(gtf_params, cfg.D, cfg.H)
+        frag = packed_frag(gtf_params, cfg.D, cfg.H, PRECISIONS[cfg.precision]) if wide else None
         z0m, z0s = _f32c(z0_mean.detach().reshape(-1)), _f32c(z0_log_std.detach().reshape(-1))
         shape = (cfg.P, cfg.T, cfg.B, cfg.D)
         out = [torch.empty(shape, device=dev, dtype=torch.float32) for _ in range(4)]
@@ -416,12 +469,20 @@ class _SweepFn(torch.autograd.Function):
             ex.pass_bits = bits[e]
         s.infer_mean, s.infer_std, s.prior_mean, s.prior_std = [_ptr(o) for o in out]
         s.samples = _ptr(smp)
-        if staged:
+        if wide:
+            if packed is None:      # the entry point checks the fp32 pack too (generic fallback)
+                packed_gtf(gtf_params, cfg.D, cfg.H).fill(s.gtf)
+            s.gtf_frag, s.precision = _ptr(frag.buf), frag.precision
+            if not native.lib().mdmm_sweep_wide(C.byref(s)):
+                raise native.MdmmError('wide sweep refused a shape wide_shape() accepted')
+            _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('wide_fwd', cfg))
+        elif staged:
             _staged_fwd(cfg, s, gtf_params)
         else:
             _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('fwd', cfg))
         ctx.cfg, ctx.eps, ctx.masks, ctx.bits, ctx.per_pass = cfg, eps, masks, bits, per_pass
         ctx.packed, ctx.n_exp, ctx.staged = packed, n_exp, staged
+        ctx.frag = frag if wide and wide_shape(cfg, bwd=True) else None
         ctx.gtf_like = [p.detach() for p in gtf_params]
         ctx.save_for_backward(z0m, z0s, out[0], out[1], out[2], out[3], *means, *stds)
         ctx.z0_shapes = (z0_mean.shape, z0_log_std.shape)
@@ -467,7 +528,19 @@ class _SweepFn(torch.autograd.Function):
         gz0 = torch.zeros(2, cfg.D, device=dev, dtype=torch.float32)
         s.g_z0_mean, s.g_z0_sigma = gz0[0].data_ptr(), gz0[1].data_ptr()
         G = X = part = None
-        if ctx.staged:                                  # stage-wise reverse scan (large z)
+        if ctx.frag is not None:                        # wide family: spills + own contraction
+            if packed is None:
+                packed_gtf(ctx.gtf_like, cfg.D, cfg.H).fill(s.gtf)
+            s.gtf_frag, s.precision = _ptr(ctx.frag.buf), ctx.frag.precision
+            assert L.mdmm_sweep_bwd_mode(C.byref(s)) == 2
+            ws = torch.empty(L.mdmm_sweep_wide_ws_bytes(C.byref(s)), device=dev, dtype=torch.uint8)
+            part = torch.empty(1, L.mdmm_sweep_dw_width(cfg.D, cfg.H), device=dev)
+            s.wide_ws, s.wide_ws_bytes = _ptr(ws), ws.numel()
+            s.dw_partial, s.dw_partial_rows = _ptr(part), 1
+            _call('mdmm_bfvi_sweep_bwd', C.byref(s), tag=_sweep_tag('wide_bwd', cfg))
+            g_gtf, g0m, g0s = unpack_dw_partials(part, cfg.D, cfg.H, ctx.gtf_like)
+            gz0 = torch.stack([g0m, g0s])
+        elif ctx.staged:                                # stage-wise reverse scan (large z)
             g_gtf, g0m, g0s = _staged_bwd(cfg, s, ctx.gtf_like)
             gz0 = torch.stack([g0m, g0s])
         elif L.mdmm_sweep_bwd_mode(C.byref(s)) == 1:    # weight gradients accumulated in-kernel
@@ -480,7 +553,7 @@ class _SweepFn(torch.autograd.Function):
                 G = torch.empty(rows, L.mdmm_sweep_spill_width_g(cfg.D, cfg.H), device=dev)
                 X = torch.empty(rows, L.mdmm_sweep_spill_width_x(cfg.D, cfg.H), device=dev)
                 s.spill_g, s.spill_x, s.spill_rows = _ptr(G), _ptr(X), rows
-        if not ctx.staged:
+        if not ctx.staged and ctx.frag is None:
             _call('mdmm_bfvi_sweep_bwd', C.byref(s), tag=_sweep_tag('bwd', cfg))
             if part is not None:
                 g_gtf, g0m, g0s = unpack_dw_partials(part, cfg.D, cfg.H, ctx.gtf_like)
