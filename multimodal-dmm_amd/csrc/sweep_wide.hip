@@ -17,6 +17,7 @@
 // accumulator registers at RT = 4; x is clamped to +-30, where sigmoid is 0 / 1 to 1e-13.)
 // Then, on the accumulator registers: product with the global prior per particle, moments over
 // the particles, product with the step's experts, outputs, the next particles -> Z image.
+#include <stdlib.h>
 #include "sweep_internal.h"
 #include "wide_tiles.h"
 
@@ -30,7 +31,20 @@ struct WideGeo {
   int NP;          // (pass, sequence) pairs per workgroup
   int TPP;         // row tiles per pair (K > 1), 1 for K = 1
   int ntab;        // slots in the pair table
+  unsigned long long* stamps;   // diagnostic builds (-DWIDE_STAMPS): cycle stamps of one step
 };
+
+// In-kernel stamps (diagnostic build only; the pointer comes from MDMM_STAMP_PTR): wave w of
+// workgroup 0 stores s_memtime at point k of step 3 into stamps[32 w + k].
+#ifdef WIDE_STAMPS
+#define STAMP(k)                                                                              \
+  do {                                                                                        \
+    if (g.stamps && blockIdx.x == 0 && lane == 0 && (i == 3 || i == a.T - 4))                 \
+      g.stamps[32 * wave + (k)] = __builtin_amdgcn_s_memtime();                                \
+  } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 
 struct PairRef { int p, b; };      // p < 0: slot unused
 
@@ -106,19 +120,20 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
   using O = Op<F32>;
   char* imgZ = smem + L::OFF_Z;
   char* imgH = smem + L::OFF_H;
-  PairRef* tab = reinterpret_cast<PairRef*>(smem + L::OFF_TAB);
-  uint64_t* rowbase = reinterpret_cast<uint64_t*>(smem + L::OFF_ROW);
-
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, n = 32 * wave + (lane & 31);
   const int T = a.T, B = a.B, K = a.K;
   const uint64_t noff = noise_off(a);
   const float inv_k = 1.0f / (float)K;
 
-  build_tables<RT, K1>(a, g, tab, rowbase);
+  build_tables<RT, K1>(a, g, reinterpret_cast<PairRef*>(smem + L::OFF_TAB),
+                       reinterpret_cast<uint64_t*>(smem + L::OFF_ROW));
+  const PairRef* tab = reinterpret_cast<const PairRef*>(smem + L::OFF_TAB);
+  const uint64_t* rowbase = reinterpret_cast<const uint64_t*>(smem + L::OFF_ROW);
 
   // this lane's fragment pointer of every layer, A-operand addresses, biases, global prior
-  const uint4* frag = reinterpret_cast<const uint4*>(a.gtf_frag) + (size_t)wave * O::NCH * 64 + lane;
+  const uint4* const frag0 = reinterpret_cast<const uint4*>(a.gtf_frag) + (size_t)wave * O::NCH * 64 + lane;
+  const uint4* frag = frag0;
   const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(a.gtf_frag) +
                                                      (size_t)N_LAYER * O::LAYER_U4);
   auto W = [&](int layer) { return frag + (size_t)layer * O::LAYER_U4; };
@@ -128,77 +143,98 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
   const float mu0 = a.z0_mean[n], sg0 = fast::exp(a.z0_log_std[n]) + a.min_std;
   const float t0 = fast::rcp(sg0 * sg0 + MDMM_POE_EPS), num0 = mu0 * t0;
 
-  uint4 ring[PF];
+  uint4 ring[Pf<RT>::N];
   ring_fill(ring, W(L_W1G));
   __syncthreads();
 
+  const PairRef* const tab0 = tab;
+  const uint64_t* const rowbase0 = rowbase;
   for (int i = 0; i < T; ++i) {
+    // the tables never change, so the compiler would hoist every read of them out of the time
+    // loop and keep ~100 registers of (pair, noise base) alive across it: re-derive the pointers
+    // from an opaque zero every step
+    int oz = 0;
+    asm volatile("" : "+s"(oz));
+    tab = tab0 + oz; rowbase = rowbase0 + oz;
+    const mdmm_expert_t* exs = a.experts + oz;       // (the same for the expert descriptors
+    frag = frag0 + oz;                               //  and the per-layer weight pointers)
     const int t = a.reverse ? T - 1 - i : i;
-    f32x16 m_[RT], sd_[RT];        // per particle: p(z) * q'(z | z_prev)  (dmm.py:239-252)
+    f32x16 m_[RT], var_[RT];       // per particle: p(z) * q'(z | z_prev)  (dmm.py:239-252)
     if (i > 0) {
       f32x16 acc[RT], x[RT];
+      STAMP(0);
       // 1: gate hidden
-      zero_acc(acc);
-      gemm_tile<F32, RT>(acc, imgZ + arow, W(L_W1G), W(L_W2G), ring);
+      fill_acc(acc, b1g);
+      gemm_tile<F32, RT, Pf<RT>::N>(acc, imgZ + arow, W(L_W1G), W(L_W2G), ring);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][r] = fmaxf(acc[rt][r] + b1g, 0.f);
+        for (int r = 0; r < 16; ++r) acc[rt][r] = fmaxf(acc[rt][r], 0.f);
+      STAMP(1);
       store_image<F32, RT>(imgH, acc, wave, lane);
+      STAMP(2);
       __syncthreads();
+      STAMP(3);
       // 2: gate pre-activation
-      zero_acc(x);
-      gemm_tile<F32, RT>(x, imgH + arow, W(L_W2G), W(L_W1N), ring);
+      fill_acc(x, b2g);
+      gemm_tile<F32, RT, Pf<RT>::N>(x, imgH + arow, W(L_W2G), W(L_W1N), ring);
+      STAMP(4);
       __syncthreads();
+      STAMP(5);
       // 3: non-linear hidden
-      zero_acc(acc);
-      gemm_tile<F32, RT>(acc, imgZ + arow, W(L_W1N), W(L_W2N), ring);
+      fill_acc(acc, b1n);
+      gemm_tile<F32, RT, Pf<RT>::N>(acc, imgZ + arow, W(L_W1N), W(L_W2N), ring);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][r] = fmaxf(acc[rt][r] + b1n, 0.f);
+        for (int r = 0; r < 16; ++r) acc[rt][r] = fmaxf(acc[rt][r], 0.f);
       store_image<F32, RT>(imgH, acc, wave, lane);
+      STAMP(6);
       __syncthreads();
+      STAMP(7);
       // 4: non-linear branch
-      zero_acc(acc);
-      gemm_tile<F32, RT>(acc, imgH + arow, W(L_W2N), W(L_WL), ring);
+      fill_acc(acc, b2n);
+      gemm_tile<F32, RT, Pf<RT>::N>(acc, imgH + arow, W(L_W2N), W(L_WL), ring);
       __syncthreads();
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][r] += b2n;
       store_image<F32, RT>(imgH, acc, wave, lane);
-      // 5a: acc = e^x nl + lin;  muq = (1 - g)(acc + bl)
+      STAMP(8);
+      // 5a: acc = e^x nl + bl + Wl z;  muq = (1 - g) acc
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float ex = fast::exp(fminf(fmaxf(x[rt][r] + b2g, -30.f), 30.f));
+          const float ex = fast::exp(__builtin_amdgcn_fmed3f(x[rt][r], -30.f, 30.f));
           x[rt][r] = fast::rcp(1.0f + ex);              // 1 - gate
-          acc[rt][r] *= ex;
+          acc[rt][r] = fmaf(acc[rt][r], ex, bl);
         }
-      gemm_tile<F32, RT>(acc, imgZ + arow, W(L_WL), W(L_WS), ring);
+      gemm_tile<F32, RT, Pf<RT>::N>(acc, imgZ + arow, W(L_WL), W(L_WS), ring);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m_[rt][r] = x[rt][r] * (acc[rt][r] + bl);   // muq
+        for (int r = 0; r < 16; ++r) m_[rt][r] = x[rt][r] * acc[rt][r];          // muq
+      STAMP(9);
       __syncthreads();
-      // 5b: std pre-activation
-      zero_acc(acc);
-      gemm_tile<F32, RT>(acc, imgH + arow, W(L_WS), W(L_W1G), ring);
+      STAMP(10);
+      // 5b: std pre-activation, then p(z) * q'(z | z_prev) per particle:
+      //   v = sq^2 + eps, u = 1 / (t0 v + 1):  var = v u,  mean = muq u + num0 var
+      fill_acc(acc, bs);
+      gemm_tile<F32, RT, Pf<RT>::N>(acc, imgH + arow, W(L_WS), W(L_W1G), ring);
+      STAMP(16);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float sq = fast::softplus(acc[rt][r] + bs) + a.min_std;          // common.py:66
-          const float tq = fast::rcp(sq * sq + MDMM_POE_EPS);
-          const float rp = fast::rcp(t0 + tq);
-          const float mm = (num0 + m_[rt][r] * tq) * rp;
-          m_[rt][r] = (mm != mm) ? 0.f : mm;
-          sd_[rt][r] = fast::sqrt(rp);
+          const float sq = softplus_w<F32>(acc[rt][r]) + a.min_std;               // common.py:66
+          const float v = fmaf(sq, sq, MDMM_POE_EPS);
+          const float u = fast::rcp(fmaf(t0, v, 1.0f));
+          const float var = v * u;
+          const float mm = fmaf(m_[rt][r], u, num0 * var);
+          m_[rt][r] = (mm != mm) ? 0.f : mm;                                      // dgts.py:49
+          var_[rt][r] = var;
         }
     }
 
+    STAMP(11);
     const bool sampled = a.sample || K > 1 || (i == 0 && a.sample_init);
     const bool last = (i == T - 1);
     const uint64_t t_term = (uint64_t)t * K * B * WD;
@@ -218,13 +254,13 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           for (int j = 0; j < 4; ++j) {
             const int reg = 4 * q + j;
             const PairRef pr = tab[r0 + j];
-            const float pm = (i > 0) ? m_[rt][reg] : mu0, ps = (i > 0) ? sd_[rt][reg] : sg0;
+            const float pm = (i > 0) ? m_[rt][reg] : mu0, ps = (i > 0) ? fast::sqrt(var_[rt][reg]) : sg0;
             float zz = 0.f;
             if (pr.p >= 0) {
               const size_t tb = (size_t)t * B + pr.b;
               fast::Poe pq; pq.init(); pq.add(pm, ps, 1.0f);
               for (int ex = 0; ex < a.E; ++ex) {
-                const mdmm_expert_t& xp = a.experts[ex];
+                const mdmm_expert_t& xp = exs[ex];
                 if (!((xp.pass_bits >> pr.p) & 1u)) continue;
                 const float c = xp.mask ? xp.mask[tb] : 1.0f;
                 const size_t off = (size_t)pr.p * xp.pass_stride + tb * WD + n;
@@ -249,15 +285,26 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
         float s1[RT], s2[RT], s3[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          const int k0 = 32 * (rt & (g.TPP - 1)) + 4 * h;
+          const int kb = 32 * (rt & (g.TPP - 1));
           float a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const bool live = k0 + acc_row(0, reg) < K;
-            const float mm = live ? m_[rt][reg] : 0.f, ss = live ? sd_[rt][reg] : 0.f;
-            a1 += mm; a2 = fmaf(ss, ss, a2); a3 = fmaf(mm, mm, a3);
+          for (int q = 0; q < 4; ++q) {
+            if (kb + 8 * q + 8 <= K) {           // whole register group live (uniform)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float mm = m_[rt][4 * q + j];
+                a1 += mm; a2 += var_[rt][4 * q + j]; a3 = fmaf(mm, mm, a3);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const bool live = kb + 8 * q + 4 * h + j < K;
+                const float mm = live ? m_[rt][4 * q + j] : 0.f;
+                a1 += mm; a2 += live ? var_[rt][4 * q + j] : 0.f; a3 = fmaf(mm, mm, a3);
+              }
+            }
           }
-          s1[rt] = a1 + other_half(a1); s2[rt] = a2 + other_half(a2); s3[rt] = a3 + other_half(a3);
+          s1[rt] = half_sum(a1); s2[rt] = half_sum(a2); s3[rt] = half_sum(a3);
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -271,17 +318,18 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) { pm[rt] = mu0; ps[rt] = sg0; }
       }
+      STAMP(12);
       float zsum[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const PairRef pr = tab[rt];
+        PairRef pr = tab[rt];          // a tile's pair is wave-uniform: scalar address math
+        pr.p = __builtin_amdgcn_readfirstlane(pr.p); pr.b = __builtin_amdgcn_readfirstlane(pr.b);
         float im = 0.f, is = 0.f;
-        size_t o = 0;
         if (pr.p >= 0) {
           const size_t tb = (size_t)t * B + pr.b;
           fast::Poe pq; pq.init(); pq.add(pm[rt], ps[rt], 1.0f);
           for (int ex = 0; ex < a.E; ++ex) {
-            const mdmm_expert_t& xp = a.experts[ex];
+            const mdmm_expert_t& xp = exs[ex];
             if (!((xp.pass_bits >> pr.p) & 1u)) continue;
             const float c = xp.mask ? xp.mask[tb] : 1.0f;
             const size_t off = (size_t)pr.p * xp.pass_stride + tb * WD + n;
@@ -289,28 +337,37 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           }
           if (a.use_inv_prior) pq.add(mu0, -sg0, 1.0f);
           pq.finish(im, is);
-          o = (((size_t)pr.p * T + t) * B + pr.b) * WD + n;
+          const size_t o = (((size_t)pr.p * T + t) * B + pr.b) * WD + n;
           if (h == 0 && (rt & (g.TPP - 1)) == 0) {
             a.infer_mean[o] = im; a.infer_std[o] = is;
             a.prior_mean[o] = pm[rt]; a.prior_std[o] = ps[rt];
           }
         }
-        const int k0 = 32 * (rt & (g.TPP - 1)) + 4 * h;
+        const int kb = 32 * (rt & (g.TPP - 1));
         float zs = 0.f;
         const bool need = pr.p >= 0 && (!last || a.samples);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float e[4] = {0.f, 0.f, 0.f, 0.f};
-          if (need) eps_group(a, noff, t_term, rowbase + 32 * rt + 8 * q + 4 * h, n, e);
+          if (need && kb + 8 * q < K) eps_group(a, noff, t_term, rowbase + 32 * rt + 8 * q + 4 * h, n, e);
+          if (pr.p >= 0 && kb + 8 * q + 8 <= K) {          // whole register group live (uniform)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const bool live = pr.p >= 0 && k0 + 8 * q + j < K;
-            const float zz = live ? fmaf(e[j], is, im) : 0.f;
-            z[rt][4 * q + j] = zz;
-            zs += zz;
+            for (int j = 0; j < 4; ++j) {
+              const float zz = fmaf(e[j], is, im);
+              z[rt][4 * q + j] = zz;
+              zs += zz;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool live = pr.p >= 0 && kb + 8 * q + 4 * h + j < K;
+              const float zz = live ? fmaf(e[j], is, im) : 0.f;
+              z[rt][4 * q + j] = zz;
+              zs += zz;
+            }
           }
         }
-        zsum[rt] = zs + other_half(zs);
+        zsum[rt] = half_sum(zs);
       }
       if (a.samples) {
 #pragma unroll
@@ -322,10 +379,13 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
         }
       }
     }
+    STAMP(13);
     if (!last) {
       __syncthreads();               // every wave is done with the H image (5b) and Z (5a)
+      STAMP(14);
       store_image<F32, RT>(imgZ, z, wave, lane);
       __syncthreads();
+      STAMP(15);
     }
   }
 }
@@ -378,7 +438,7 @@ struct FuseAdj { float gpm, gps, prm, prs; };
 // adjoint of sampling + product of experts of ONE (pass, sequence) at step t, feature n
 // (dmm.py:387-405 backwards).  `owner`: this lane writes the expert gradients and counts the
 // pair's d/d(mu0, sigma0) (the pair's values are replicated over lanes / tiles).
-__device__ __forceinline__ FuseAdj fuse_bwd(const mdmm_sweep_t& a, PairRef pr, int t, int n, float mu0,
+__device__ __forceinline__ FuseAdj fuse_bwd(const mdmm_sweep_t& a, const mdmm_expert_t* exs, PairRef pr, int t, int n, float mu0,
                                             float sg0, float adj_a, float adj_b, float se,
                                             bool sampled, float inv_k, bool first, bool owner,
                                             float& g_mu0, float& g_sg0) {
@@ -393,7 +453,7 @@ __device__ __forceinline__ FuseAdj fuse_bwd(const mdmm_sweep_t& a, PairRef pr, i
   const float prm = a.prior_mean[o], prs = a.prior_std[o];
   fast::Poe q; q.init(); q.add(prm, prs, 1.0f);
   for (int e = 0; e < a.E; ++e) {
-    const mdmm_expert_t& ex = a.experts[e];
+    const mdmm_expert_t& ex = exs[e];
     if (!((ex.pass_bits >> pr.p) & 1u)) continue;
     const float c = ex.mask ? ex.mask[tb] : 1.0f;
     const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
@@ -408,7 +468,7 @@ __device__ __forceinline__ FuseAdj fuse_bwd(const mdmm_sweep_t& a, PairRef pr, i
   r.gps = gs + (a.g_prior_std ? a.g_prior_std[o] : 0.f);
   r.prm = prm; r.prs = prs;
   for (int e = 0; e < a.E; ++e) {
-    const mdmm_expert_t& ex = a.experts[e];
+    const mdmm_expert_t& ex = exs[e];
     if (!((ex.pass_bits >> pr.p) & 1u)) continue;
     const float c = ex.mask ? ex.mask[tb] : 1.0f;
     const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
@@ -458,18 +518,19 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
   char* img1 = smem + L::IMG;
   char* img2 = smem + 2 * L::IMG;
   char* img3 = smem + 3 * L::IMG;
-  PairRef* tab = reinterpret_cast<PairRef*>(smem + L::OFF_TAB);
-  uint64_t* rowbase = reinterpret_cast<uint64_t*>(smem + L::OFF_ROW);
-
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, n = 32 * wave + (lane & 31);
   const int T = a.T, B = a.B, K = a.K;
   const uint64_t noff = noise_off(a);
   const float inv_k = 1.0f / (float)K;
 
-  build_tables<RT, K1>(a, g, tab, rowbase);
+  build_tables<RT, K1>(a, g, reinterpret_cast<PairRef*>(smem + L::OFF_TAB),
+                       reinterpret_cast<uint64_t*>(smem + L::OFF_ROW));
+  const PairRef* tab = reinterpret_cast<const PairRef*>(smem + L::OFF_TAB);
+  const uint64_t* rowbase = reinterpret_cast<const uint64_t*>(smem + L::OFF_ROW);
 
-  const uint4* frag = reinterpret_cast<const uint4*>(a.gtf_frag) + (size_t)wave * O::NCH * 64 + lane;
+  const uint4* const frag0 = reinterpret_cast<const uint4*>(a.gtf_frag) + (size_t)wave * O::NCH * 64 + lane;
+  const uint4* frag = frag0;
   const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(a.gtf_frag) +
                                                      (size_t)N_LAYER * O::LAYER_U4);
   auto W = [&](int layer) { return frag + (size_t)layer * O::LAYER_U4; };
@@ -479,6 +540,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
   const float mu0 = a.z0_mean[n], sg0 = fast::exp(a.z0_log_std[n]) + a.min_std;
   const float t0 = fast::rcp(sg0 * sg0 + MDMM_POE_EPS), num0 = mu0 * t0;
 
+  const float dt0 = -2.0f * sg0 * t0 * t0;       // d t0 / d sigma0
   constexpr int NS = K1 ? 16 * RT : RT;          // pair slots held by a lane
   float adj_a[NS], adj_b[NS], se[NS];
 #pragma unroll
@@ -486,7 +548,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
   float g_mu0 = 0.f, g_sg0 = 0.f;
   float db1g = 0.f, db1n = 0.f, dbl = 0.f, db2g = 0.f, db2n = 0.f, dbs = 0.f;
 
-  uint4 ring[PF];
+  uint4 ring[Pf<RT>::N];
   ring_fill(ring, W(L_W1G));
   __syncthreads();
 
@@ -510,7 +572,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
           else acc += live ? e[j] : 0.f;
         }
       }
-      part[rt] = acc + other_half(acc);
+      part[rt] = half_sum(acc);
     }
     if constexpr (!K1) {
 #pragma unroll
@@ -523,7 +585,14 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     return my_spill + ((size_t)step * N_SPILL + arr) * NWAVE * CH * 64;
   };
 
+  const PairRef* const tab0 = tab;
+  const uint64_t* const rowbase0 = rowbase;
   for (int i = T - 1; i >= 0; --i) {
+    int oz = 0;                     // see the forward kernel: keeps invariant reads inside the loop
+    asm volatile("" : "+s"(oz));
+    tab = tab0 + oz; rowbase = rowbase0 + oz;
+    const mdmm_expert_t* exs = a.experts + oz;
+    frag = frag0 + oz;
     const int t = a.reverse ? T - 1 - i : i;
     const bool sampled = a.sample || K > 1 || (i == 0 && a.sample_init);
     // ---- (A) adjoint of sampling + fusion at step i
@@ -534,13 +603,13 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int s = rt * 16 + reg;
-          fa[s] = fuse_bwd(a, tab[acc_row(rt, reg) + 4 * h], t, n, mu0, sg0, adj_a[s], adj_b[s], se[s],
+          fa[s] = fuse_bwd(a, exs, tab[acc_row(rt, reg) + 4 * h], t, n, mu0, sg0, adj_a[s], adj_b[s], se[s],
                            sampled, inv_k, i == 0, true, g_mu0, g_sg0);
         }
     } else {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
-        fa[rt] = fuse_bwd(a, tab[rt], t, n, mu0, sg0, adj_a[rt], adj_b[rt], se[rt], sampled, inv_k,
+        fa[rt] = fuse_bwd(a, exs, tab[rt], t, n, mu0, sg0, adj_a[rt], adj_b[rt], se[rt], sampled, inv_k,
                           i == 0, h == 0 && (rt & (g.TPP - 1)) == 0, g_mu0, g_sg0);
     }
     if (i == 0) break;
@@ -571,7 +640,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
         for (int q = 0; q < 4; ++q) {
           float e[4] = {0.f, 0.f, 0.f, 0.f};
           const int r0 = 32 * rt + 8 * q + 4 * h;
-          if (sampled_prev) eps_group(a, noff, t_term, rowbase + r0, n, e);
+          if (sampled_prev && (!K1 || 32 * rt + 8 * q < g.NP)) eps_group(a, noff, t_term, rowbase + r0, n, e);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int reg = 4 * q + j;
@@ -592,7 +661,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
           }
         }
         live_bits[rt] = lb;
-        if constexpr (!K1) se[rt] = esum + other_half(esum);
+        if constexpr (!K1) se[rt] = half_sum(esum);
       }
       if constexpr (!K1) {
         float tmp[RT];
@@ -607,31 +676,29 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     __syncthreads();
     // R2: hidden layers
     unsigned mask_g[RT], mask_n[RT];
-    zero_acc(acc);
-    gemm_tile<F32, RT>(acc, img0 + arow, W(L_W1G), W(L_W1N), ring);
+    fill_acc(acc, b1g);
+    gemm_tile<F32, RT, Pf<RT>::N>(acc, img0 + arow, W(L_W1G), W(L_W1N), ring);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       unsigned mb = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = acc[rt][r] + b1g;
-        mb |= (v > 0.f) ? (1u << r) : 0u;
-        acc[rt][r] = fmaxf(v, 0.f);
+        mb |= (acc[rt][r] > 0.f) ? (1u << r) : 0u;
+        acc[rt][r] = fmaxf(acc[rt][r], 0.f);
       }
       mask_g[rt] = mb;
     }
     store_image<F32, RT>(img1, acc, wave, lane);
     spill_tiles<F32, RT>(spill_at(i - 1, S_HG), acc);
-    zero_acc(acc);
-    gemm_tile<F32, RT>(acc, img0 + arow, W(L_W1N), W(L_W2G), ring);
+    fill_acc(acc, b1n);
+    gemm_tile<F32, RT, Pf<RT>::N>(acc, img0 + arow, W(L_W1N), W(L_W2G), ring);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       unsigned mb = 0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = acc[rt][r] + b1n;
-        mb |= (v > 0.f) ? (1u << r) : 0u;
-        acc[rt][r] = fmaxf(v, 0.f);
+        mb |= (acc[rt][r] > 0.f) ? (1u << r) : 0u;
+        acc[rt][r] = fmaxf(acc[rt][r], 0.f);
       }
       mask_n[rt] = mb;
     }
@@ -639,31 +706,32 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     spill_tiles<F32, RT>(spill_at(i - 1, S_HN), acc);
     __syncthreads();
     // R3: gate, non-linear branch, mean
-    zero_acc(omg);
-    gemm_tile<F32, RT>(omg, img1 + arow, W(L_W2G), W(L_W2N), ring);
-    zero_acc(nl);
-    gemm_tile<F32, RT>(nl, img2 + arow, W(L_W2N), W(L_WL), ring);
+    fill_acc(omg, b2g);
+    gemm_tile<F32, RT, Pf<RT>::N>(omg, img1 + arow, W(L_W2G), W(L_W2N), ring);
+    fill_acc(nl, b2n);
+    gemm_tile<F32, RT, Pf<RT>::N>(nl, img2 + arow, W(L_W2N), W(L_WL), ring);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        nl[rt][r] += b2n;
-        const float ex = fast::exp(fminf(fmaxf(omg[rt][r] + b2g, -30.f), 30.f));
+        const float ex = fast::exp(__builtin_amdgcn_fmed3f(omg[rt][r], -30.f, 30.f));
         omg[rt][r] = fast::rcp(1.0f + ex);
-        muq[rt][r] = nl[rt][r] * ex;
+        muq[rt][r] = fmaf(nl[rt][r], ex, bl);
       }
     store_image<F32, RT>(img3, nl, wave, lane);
     spill_tiles<F32, RT>(spill_at(i - 1, S_NL), nl);
-    gemm_tile<F32, RT>(muq, img0 + arow, W(L_WL), W(L_WS), ring);
+    gemm_tile<F32, RT, Pf<RT>::N>(muq, img0 + arow, W(L_WL), W(L_WS), ring);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) muq[rt][r] = omg[rt][r] * (muq[rt][r] + bl);
+      for (int r = 0; r < 16; ++r) muq[rt][r] *= omg[rt][r];
     __syncthreads();
     // R4: std pre-activation
-    zero_acc(acc);
-    gemm_tile<F32, RT>(acc, img3 + arow, W(L_WS), W(T_WS), ring);
-    // E: elementwise adjoint; acc: pre -> G3, omg -> Glin, nl -> direct part of GN, muq -> GG
+    fill_acc(acc, bs);
+    gemm_tile<F32, RT, Pf<RT>::N>(acc, img3 + arow, W(L_WS), W(T_WS), ring);
+    // E: elementwise adjoint; acc: pre -> G3, omg -> Glin, nl -> direct part of GN, muq -> GG.
+    // Product with the global prior as in the forward kernel (v = sq^2 + eps, u = 1/(t0 v + 1)):
+    //   var = v u, mean = muq u + num0 var;  d mean/d muq = u,  d/d sq via tq = 1/v.
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       float gv2k = 0.f, gpmk = 0.f, mb = 0.f;
@@ -673,22 +741,28 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pre = acc[rt][r] + bs;
-        const float sq = fast::softplus(pre) + a.min_std;
-        const float tq = fast::rcp(sq * sq + MDMM_POE_EPS);
-        const float rp = fast::rcp(t0 + tq);
-        const float num = num0 + muq[rt][r] * tq;
-        const float mraw = num * rp, m = (mraw != mraw) ? 0.f : mraw, sd = fast::sqrt(rp);
+        const float pre = acc[rt][r];
+        const float sq = softplus_w<F32>(pre) + a.min_std;
+        const float v = fmaf(sq, sq, MDMM_POE_EPS);
+        const float u = fast::rcp(fmaf(t0, v, 1.0f));
+        const float rp = v * u;                                  // variance of the product
+        const float mraw = fmaf(muq[rt][r], u, num0 * rp), sd = fast::sqrt(rp);
+        const float m = (mraw != mraw) ? 0.f : mraw;                            // dgts.py:49
         float g_m, g_sd;
         if constexpr (K1) { g_m = fa[rt * 16 + r].gpm; g_sd = fa[rt * 16 + r].gps; }
         else { g_m = gpmk + gv2k * (m - mb); g_sd = gv2k * sd; }
         const bool live = (live_bits[rt] >> r) & 1u;
-        if (!live) { g_m = 0.f; g_sd = 0.f; }
-        float g_num, g_prec, gm0, gs0, g_muq, g_sq;
-        poe_out_bwd_f(num, rp, sd, g_m, g_sd, g_num, g_prec);
-        poe_expert_bwd_f(mu0, sg0, 1.0f, g_num, g_prec, gm0, gs0);
-        poe_expert_bwd_f(muq[rt][r], sq, 1.0f, g_num, g_prec, g_muq, g_sq);
-        g_mu0 += gm0; g_sg0 += gs0;
+        if (!live || mraw != mraw) g_m = 0.f;                    // (the mean was overwritten by 0)
+        if (!live) g_sd = 0.f;
+        // d/d(num, prec) of the product, then the two experts (dgts.py:39-51 backwards)
+        const float g_num = g_m * rp;
+        const float g_prec = -(g_m * m + 0.5f * g_sd * sd) * rp;
+        const float g_t0 = fmaf(g_num, mu0, g_prec);             // d/d prec of the global prior
+        g_mu0 = fmaf(g_num, t0, g_mu0);
+        g_sg0 = fmaf(g_t0, dt0, g_sg0);
+        const float tq = fast::rcp(v);
+        const float g_muq = g_num * tq;
+        const float g_sq = -fmaf(g_num, muq[rt][r], g_prec) * tq * tq * 2.0f * sq;
         const float gate = 1.0f - omg[rt][r];
         acc[rt][r] = g_sq * fast::softplus_grad(pre);                       // d/d std pre-act
         const float gg = g_muq * gate * (nl[rt][r] - muq[rt][r]);           // d/d gate pre-act
@@ -706,16 +780,16 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     dbs += tile_sum(acc); db2g += tile_sum(muq); dbl += tile_sum(omg);
     __syncthreads();
     // D1: d/d nl = direct + W_std^T d/d std-pre
-    gemm_tile<F32, RT>(nl, img1 + arow, W(T_WS), W(T_W2G), ring);
+    gemm_tile<F32, RT, Pf<RT>::N>(nl, img1 + arow, W(T_WS), W(T_W2G), ring);
     store_image<F32, RT>(img3, nl, wave, lane);
     spill_tiles<F32, RT>(spill_at(i - 1, S_GN), nl);
     db2n += tile_sum(nl);
     __syncthreads();
     // D2: hidden adjoints through the relus
     zero_acc(acc);
-    gemm_tile<F32, RT>(acc, img2 + arow, W(T_W2G), W(T_W2N), ring);
+    gemm_tile<F32, RT, Pf<RT>::N>(acc, img2 + arow, W(T_W2G), W(T_W2N), ring);
     zero_acc(muq);
-    gemm_tile<F32, RT>(muq, img3 + arow, W(T_W2N), W(T_W1G), ring);
+    gemm_tile<F32, RT, Pf<RT>::N>(muq, img3 + arow, W(T_W2N), W(T_W1G), ring);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -732,9 +806,9 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     __syncthreads();
     // D3: d/dz of the previous particles
     zero_acc(acc);
-    gemm_tile<F32, RT>(acc, img1 + arow, W(T_W1G), W(T_W1N), ring);
-    gemm_tile<F32, RT>(acc, img2 + arow, W(T_W1N), W(T_WL), ring);
-    gemm_tile<F32, RT>(acc, img0 + arow, W(T_WL), W(L_W1G), ring);
+    gemm_tile<F32, RT, Pf<RT>::N>(acc, img1 + arow, W(T_W1G), W(T_W1N), ring);
+    gemm_tile<F32, RT, Pf<RT>::N>(acc, img2 + arow, W(T_W1N), W(T_WL), ring);
+    gemm_tile<F32, RT, Pf<RT>::N>(acc, img0 + arow, W(T_WL), W(L_W1G), ring);
     if constexpr (K1) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -754,7 +828,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
           const float gz = live ? acc[rt][r] : 0.f;
           sa += gz; sb = fmaf(gz, ep[rt][r], sb);
         }
-        pa[rt] = sa + other_half(sa); pb[rt] = sb + other_half(sb);
+        pa[rt] = half_sum(sa); pb[rt] = half_sum(sb);
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) { adj_a[rt] = pair_total(pa, rt, g.TPP); adj_b[rt] = pair_total(pb, rt, g.TPP); }
@@ -768,11 +842,11 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     const float v[6] = {db1g, db1n, dbl, db2g, db2n, dbs};
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const float tot = v[k] + other_half(v[k]);
+      const float tot = half_sum(v[k]);
       if (h == 0) db[k * WD + n] = tot;
     }
     float* dz = ws.dz0 + (size_t)blockIdx.x * 2 * WD;
-    const float m0 = g_mu0 + other_half(g_mu0), s0 = g_sg0 + other_half(g_sg0);
+    const float m0 = half_sum(g_mu0), s0 = half_sum(g_sg0);
     if (h == 0) { dz[n] = m0; dz[WD + n] = s0; }
   }
 }
@@ -944,7 +1018,17 @@ int plan(const mdmm_sweep_t* a, bool bwd, WideGeo* g) {
   if ((int64_t)a->P * a->T * a->B * WD >= (1ll << 40)) return 0;
   const bool f32 = a->precision == MDMM_PREC_F32;
   g->n_pairs = a->P * a->B;
-  if (a->K == 1) { g->TPP = 1; g->NP = 32; g->ntab = 32; return 1; }
+  g->stamps = nullptr;
+#ifdef WIDE_STAMPS
+  if (const char* e = getenv("MDMM_STAMP_PTR")) g->stamps = (unsigned long long*)strtoull(e, nullptr, 16);
+#endif
+  if (a->K == 1) {
+    // K = 1 sweeps are latency chains: few rows per workgroup, as many workgroups as the chip has
+    // CUs (rows >= NP of the tile are dead; the matrix work they waste is idle anyway)
+    g->TPP = 1; g->ntab = 32;
+    g->NP = g->n_pairs <= 8 * 256 ? 8 : (g->n_pairs <= 16 * 256 ? 16 : 32);
+    return 1;
+  }
   const int RT = f32 ? 1 : (bwd ? 2 : 4);
   int tpp = (a->K + 31) / 32;
   if (tpp == 3) tpp = 4;

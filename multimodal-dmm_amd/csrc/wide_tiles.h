@@ -69,10 +69,31 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT]) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
 }
+// accumulators start at the bias of the lane's output feature (the add costs nothing that way)
+template <int RT>
+__device__ __forceinline__ void fill_acc(f32x16 (&acc)[RT], float b) {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[rt][i] = b;
+}
 
-constexpr int PF = 4;   // weight chunks in flight per wave ahead of the MFMAs
+// weight chunks in flight per wave ahead of the MFMAs.  The stream is latency-bound, not
+// bandwidth-bound (1 KB per wave-instruction, ~1-2 us from L2 under load): the fewer MFMAs a
+// chunk feeds (RT of them), the more chunks have to be in flight.
+#ifndef WIDE_PF_RT1
+#define WIDE_PF_RT1 8
+#endif
+#ifndef WIDE_PF_RT2
+#define WIDE_PF_RT2 4
+#endif
+#ifndef WIDE_PF_RT4
+#define WIDE_PF_RT4 4
+#endif
+template <int RT> struct Pf { static constexpr int N = RT == 1 ? WIDE_PF_RT1 : (RT == 2 ? WIDE_PF_RT2 : WIDE_PF_RT4); };
 
 // first PF chunks of a layer slice into the ring (w = this lane's fragment pointer of the layer)
+template <int PF>
 __device__ __forceinline__ void ring_fill(uint4 (&ring)[PF], const uint4* __restrict__ w) {
 #pragma unroll
   for (int c = 0; c < PF; ++c) ring[c] = w[c * 64];
@@ -83,7 +104,7 @@ __device__ __forceinline__ void ring_fill(uint4 (&ring)[PF], const uint4* __rest
 // pointer into the layer (chunk c at w[64c]).  The ring holds chunks 0..PF-1 of `w` on entry and
 // chunks 0..PF-1 of `wnext` (the layer the wave contracts with next) on exit, so the weight
 // stream never drains at a phase boundary.
-template <bool F32, int RT>
+template <bool F32, int RT, int PF>
 __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[RT], const char* xrow,
                                           const uint4* __restrict__ w,
                                           const uint4* __restrict__ wnext, uint4 (&ring)[PF]) {
@@ -113,6 +134,7 @@ __device__ __forceinline__ constexpr int acc_row(int rt, int reg) {
 }
 
 // accumulator tiles -> LDS image X[row][32w + lane%32] (this wave's feature slice)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 template <bool F32, int RT>
 __device__ __forceinline__ void store_image(char* img, const f32x16 (&v)[RT], int wave, int lane) {
   constexpr int RS = Op<F32>::RS, ESZ = Op<F32>::ESZ;
@@ -120,10 +142,17 @@ __device__ __forceinline__ void store_image(char* img, const f32x16 (&v)[RT], in
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      char* p = base + acc_row(rt, reg) * RS;
-      if constexpr (F32) *reinterpret_cast<float*>(p) = v[rt][reg];
-      else *reinterpret_cast<__bf16*>(p) = (__bf16)v[rt][reg];
+    for (int reg = 0; reg < 16; reg += 2) {
+      char* p = base + acc_row(rt, reg) * RS;       // rows of reg and reg + 1 are neighbours
+      if constexpr (F32) {
+        *reinterpret_cast<float*>(p) = v[rt][reg];
+        *reinterpret_cast<float*>(p + RS) = v[rt][reg + 1];
+      } else {
+        bf16x2 pk;                                  // one v_cvt_pk_bf16_f32, two 16-bit stores
+        pk[0] = (__bf16)v[rt][reg]; pk[1] = (__bf16)v[rt][reg + 1];
+        *reinterpret_cast<__bf16*>(p) = pk[0];
+        *reinterpret_cast<__bf16*>(p + RS) = pk[1];
+      }
     }
 }
 
@@ -162,7 +191,20 @@ __device__ __forceinline__ void quad_transpose(float (&e)[4], int u) {
   if (o2) { e[0] = ra; e[1] = rb; } else { e[2] = ra; e[3] = rb; }
 }
 
+// softplus of the std head: the bf16-operand kernels take the short form (no series for tiny
+// exp(-|x|): its error, 6e-8 absolute, is far below their operand rounding)
+template <bool F32>
+__device__ __forceinline__ float softplus_w(float x) {
+  if constexpr (F32) return fast::softplus(x);
+  else return fmaxf(x, 0.f) + fast::log(1.0f + fast::exp(-fabsf(x)));
+}
+
 // value of the other lane half (lane ^ 32)
 __device__ __forceinline__ float other_half(float v) { return __shfl_xor(v, 32, 64); }
+// v(lane) + v(lane ^ 32) in every lane: one v_permlane32_swap instead of an LDS permute
+__device__ __forceinline__ float half_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 }  // namespace wide
