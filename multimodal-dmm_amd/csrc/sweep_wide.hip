@@ -47,6 +47,7 @@ struct WideGeo {
 #endif
 
 struct PairRef { int p, b; };      // p < 0: slot unused
+typedef const __attribute__((address_space(4))) mdmm_sweep_t KArgs;   // the descriptor in kernarg memory
 
 template <bool F32, int RT>
 struct FwdLds {
@@ -85,7 +86,8 @@ __device__ __forceinline__ void build_tables(const mdmm_sweep_t& a, const WideGe
 // N(0,1) draws of the four rows (registers 4q .. 4q+3) of one accumulator register group:
 // e[j] = eps(row j, feature n).  Philox yields four consecutive features per counter, so lane u
 // of a quad draws row u's four features and the quad transposes (wide_tiles.h).
-__device__ __forceinline__ void eps_group(const mdmm_sweep_t& a, uint64_t noff, uint64_t t_term,
+template <class A>
+__device__ __forceinline__ void eps_group(const A& a, uint64_t noff, uint64_t t_term,
                                           const uint64_t* rowbase_r0, int n, float (&e)[4]) {
   if (a.eps) {
 #pragma unroll
@@ -153,11 +155,15 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
     // the tables never change, so the compiler would hoist every read of them out of the time
     // loop and keep ~100 registers of (pair, noise base) alive across it: re-derive the pointers
     // from an opaque zero every step
-    int oz = 0;
-    asm volatile("" : "+s"(oz));
-    tab = tab0 + oz; rowbase = rowbase0 + oz;
-    const mdmm_expert_t* exs = a.experts + oz;       // (the same for the expert descriptors
-    frag = frag0 + oz;                               //  and the per-layer weight pointers)
+    tab = tab0; rowbase = rowbase0; frag = frag0;    // (the same for the per-layer weight pointers)
+    asm volatile("" : "+v"(tab), "+v"(rowbase), "+v"(frag));
+    // ... and for the launch arguments: inside the loop they are read through an opaque copy of
+    // the kernarg pointer (the sweep descriptor is the first kernel argument), so that pointers,
+    // expert descriptors and Philox keys are scalar loads at their use, not ~150 hoisted SGPRs
+    KArgs* kap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kap));
+    KArgs& a = *kap;
+    const auto* exs = a.experts;
     const int t = a.reverse ? T - 1 - i : i;
     f32x16 m_[RT], var_[RT];       // per particle: p(z) * q'(z | z_prev)  (dmm.py:239-252)
     if (i > 0) {
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
               const size_t tb = (size_t)t * B + pr.b;
               fast::Poe pq; pq.init(); pq.add(pm, ps, 1.0f);
               for (int ex = 0; ex < a.E; ++ex) {
-                const mdmm_expert_t& xp = exs[ex];
+                const auto& xp = exs[ex];
                 if (!((xp.pass_bits >> pr.p) & 1u)) continue;
                 const float c = xp.mask ? xp.mask[tb] : 1.0f;
                 const size_t off = (size_t)pr.p * xp.pass_stride + tb * WD + n;
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           const size_t tb = (size_t)t * B + pr.b;
           fast::Poe pq; pq.init(); pq.add(pm[rt], ps[rt], 1.0f);
           for (int ex = 0; ex < a.E; ++ex) {
-            const mdmm_expert_t& xp = exs[ex];
+            const auto& xp = exs[ex];
             if (!((xp.pass_bits >> pr.p) & 1u)) continue;
             const float c = xp.mask ? xp.mask[tb] : 1.0f;
             const size_t off = (size_t)pr.p * xp.pass_stride + tb * WD + n;
@@ -409,7 +415,7 @@ struct BwdLds {
 // workspace of one backward sweep (device pointers into mdmm_sweep_t.wide_ws)
 struct WideWs {
   uint4* spill;      // [workgroup][step][N_SPILL][wave][chunk][lane]
-  float* db;         // [workgroup][6][256] bias-gradient partial sums
+  float* db;         // [split][6][256] bias-gradient partial sums (written by the wgrad kernel)
   float* dz0;        // [workgroup][2][256] d/d(mu0, sigma0) partial sums
   float* slab;       // [split][6][256][256] weight-gradient partial sums
   int64_t n_wg, n_step;
@@ -438,7 +444,8 @@ struct FuseAdj { float gpm, gps, prm, prs; };
 // adjoint of sampling + product of experts of ONE (pass, sequence) at step t, feature n
 // (dmm.py:387-405 backwards).  `owner`: this lane writes the expert gradients and counts the
 // pair's d/d(mu0, sigma0) (the pair's values are replicated over lanes / tiles).
-__device__ __forceinline__ FuseAdj fuse_bwd(const mdmm_sweep_t& a, const mdmm_expert_t* exs, PairRef pr, int t, int n, float mu0,
+template <class A, class E>
+__device__ __forceinline__ FuseAdj fuse_bwd(const A& a, const E* exs, PairRef pr, int t, int n, float mu0,
                                             float sg0, float adj_a, float adj_b, float se,
                                             bool sampled, float inv_k, bool first, bool owner,
                                             float& g_mu0, float& g_sg0) {
@@ -453,7 +460,7 @@ __device__ __forceinline__ FuseAdj fuse_bwd(const mdmm_sweep_t& a, const mdmm_ex
   const float prm = a.prior_mean[o], prs = a.prior_std[o];
   fast::Poe q; q.init(); q.add(prm, prs, 1.0f);
   for (int e = 0; e < a.E; ++e) {
-    const mdmm_expert_t& ex = exs[e];
+    const auto& ex = exs[e];
     if (!((ex.pass_bits >> pr.p) & 1u)) continue;
     const float c = ex.mask ? ex.mask[tb] : 1.0f;
     const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
@@ -468,7 +475,7 @@ __device__ __forceinline__ FuseAdj fuse_bwd(const mdmm_sweep_t& a, const mdmm_ex
   r.gps = gs + (a.g_prior_std ? a.g_prior_std[o] : 0.f);
   r.prm = prm; r.prs = prs;
   for (int e = 0; e < a.E; ++e) {
-    const mdmm_expert_t& ex = exs[e];
+    const auto& ex = exs[e];
     if (!((ex.pass_bits >> pr.p) & 1u)) continue;
     const float c = ex.mask ? ex.mask[tb] : 1.0f;
     const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
@@ -546,7 +553,6 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
 #pragma unroll
   for (int s = 0; s < NS; ++s) { adj_a[s] = 0.f; adj_b[s] = 0.f; se[s] = 0.f; }
   float g_mu0 = 0.f, g_sg0 = 0.f;
-  float db1g = 0.f, db1n = 0.f, dbl = 0.f, db2g = 0.f, db2n = 0.f, dbs = 0.f;
 
   uint4 ring[Pf<RT>::N];
   ring_fill(ring, W(L_W1G));
@@ -581,20 +587,25 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
   }
 
   uint4* my_spill = ws.spill + ((size_t)blockIdx.x * ws.n_step * N_SPILL * NWAVE + wave) * CH * 64 + lane;
+  uint4* spill_it = my_spill;
   auto spill_at = [&](int step, int arr) {
-    return my_spill + ((size_t)step * N_SPILL + arr) * NWAVE * CH * 64;
+    return spill_it + ((size_t)step * N_SPILL + arr) * NWAVE * CH * 64;
   };
 
   const PairRef* const tab0 = tab;
   const uint64_t* const rowbase0 = rowbase;
   for (int i = T - 1; i >= 0; --i) {
-    int oz = 0;                     // see the forward kernel: keeps invariant reads inside the loop
-    asm volatile("" : "+s"(oz));
-    tab = tab0 + oz; rowbase = rowbase0 + oz;
-    const mdmm_expert_t* exs = a.experts + oz;
-    frag = frag0 + oz;
+    // see the forward kernel: keeps invariant reads and address arithmetic inside the loop
+    tab = tab0; rowbase = rowbase0; frag = frag0;
+    spill_it = my_spill;
+    asm volatile("" : "+v"(tab), "+v"(rowbase), "+v"(frag), "+v"(spill_it));
+    KArgs* kap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kap));
+    KArgs& a = *kap;
+    const auto* exs = a.experts;
     const int t = a.reverse ? T - 1 - i : i;
     const bool sampled = a.sample || K > 1 || (i == 0 && a.sample_init);
+    STAMP(0);
     // ---- (A) adjoint of sampling + fusion at step i
     FuseAdj fa[NS];
     if constexpr (K1) {
@@ -612,13 +623,13 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
         fa[rt] = fuse_bwd(a, exs, tab[rt], t, n, mu0, sg0, adj_a[rt], adj_b[rt], se[rt], sampled, inv_k,
                           i == 0, h == 0 && (rt & (g.TPP - 1)) == 0, g_mu0, g_sg0);
     }
+    STAMP(1);
     if (i == 0) break;
 
     // ---- (B) transition into step i: rows = particles of step i-1
     const int t_prev = a.reverse ? t + 1 : t - 1;
     const bool sampled_prev = a.sample || K > 1 || (i == 1 && a.sample_init);
     const uint64_t t_term = (uint64_t)t_prev * K * B * WD;
-    f32x16 ep[RT];                 // eps of the rows (0 on dead rows)
     unsigned live_bits[RT];
     f32x16 acc[RT], nl[RT], omg[RT], muq[RT];
     // R1: particles
@@ -640,7 +651,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
         for (int q = 0; q < 4; ++q) {
           float e[4] = {0.f, 0.f, 0.f, 0.f};
           const int r0 = 32 * rt + 8 * q + 4 * h;
-          if (sampled_prev && (!K1 || 32 * rt + 8 * q < g.NP)) eps_group(a, noff, t_term, rowbase + r0, n, e);
+          if (sampled_prev && (K1 ? 32 * rt + 8 * q < g.NP : 32 * (rt & (g.TPP - 1)) + 8 * q < K))
+            eps_group(a, noff, t_term, rowbase + r0, n, e);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int reg = 4 * q + j;
@@ -654,7 +666,6 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
               }
             }
             const float ee = live ? e[j] : 0.f;
-            ep[rt][reg] = ee;
             acc[rt][reg] = live ? fmaf(ee, zs, zm) : 0.f;
             lb |= live ? (1u << reg) : 0u;
             if constexpr (K1) se[rt * 16 + reg] = ee; else esum += ee;
@@ -673,7 +684,9 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
       store_image<F32, RT>(img0, acc, wave, lane);
       spill_tiles<F32, RT>(spill_at(i - 1, S_Z), acc);
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     // R2: hidden layers
     unsigned mask_g[RT], mask_n[RT];
     fill_acc(acc, b1g);
@@ -704,7 +717,9 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     }
     store_image<F32, RT>(img2, acc, wave, lane);
     spill_tiles<F32, RT>(spill_at(i - 1, S_HN), acc);
+    STAMP(4);
     __syncthreads();
+    STAMP(5);
     // R3: gate, non-linear branch, mean
     fill_acc(omg, b2g);
     gemm_tile<F32, RT, Pf<RT>::N>(omg, img1 + arow, W(L_W2G), W(L_W2N), ring);
@@ -725,10 +740,13 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) muq[rt][r] *= omg[rt][r];
+    STAMP(6);
     __syncthreads();
+    STAMP(7);
     // R4: std pre-activation
     fill_acc(acc, bs);
     gemm_tile<F32, RT, Pf<RT>::N>(acc, img3 + arow, W(L_WS), W(T_WS), ring);
+    STAMP(8);
     // E: elementwise adjoint; acc: pre -> G3, omg -> Glin, nl -> direct part of GN, muq -> GG.
     // Product with the global prior as in the forward kernel (v = sq^2 + eps, u = 1/(t0 v + 1)):
     //   var = v u, mean = muq u + num0 var;  d mean/d muq = u,  d/d sq via tq = 1/v.
@@ -769,22 +787,28 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
         nl[rt][r] = g_muq * gate;                                           // direct part of d/d nl
         omg[rt][r] = g_muq * omg[rt][r];                                    // d/d z_lin
         muq[rt][r] = gg;
+        // keep the scheduler from interleaving all 16 * RT elements: that needs more registers
+        // than there are and the phase ends up waiting on scratch reloads
+        if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    STAMP(9);
     store_image<F32, RT>(img1, acc, wave, lane);
     spill_tiles<F32, RT>(spill_at(i - 1, S_G3), acc);
     store_image<F32, RT>(img2, muq, wave, lane);
     spill_tiles<F32, RT>(spill_at(i - 1, S_GG), muq);
     store_image<F32, RT>(img0, omg, wave, lane);
     spill_tiles<F32, RT>(spill_at(i - 1, S_GLIN), omg);
-    dbs += tile_sum(acc); db2g += tile_sum(muq); dbl += tile_sum(omg);
+    STAMP(10);
     __syncthreads();
+    STAMP(11);
     // D1: d/d nl = direct + W_std^T d/d std-pre
     gemm_tile<F32, RT, Pf<RT>::N>(nl, img1 + arow, W(T_WS), W(T_W2G), ring);
     store_image<F32, RT>(img3, nl, wave, lane);
     spill_tiles<F32, RT>(spill_at(i - 1, S_GN), nl);
-    db2n += tile_sum(nl);
+    STAMP(12);
     __syncthreads();
+    STAMP(13);
     // D2: hidden adjoints through the relus
     zero_acc(acc);
     gemm_tile<F32, RT, Pf<RT>::N>(acc, img2 + arow, W(T_W2G), W(T_W2N), ring);
@@ -800,51 +824,53 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     store_image<F32, RT>(img1, acc, wave, lane);       // G3 image: every wave is past D1
     spill_tiles<F32, RT>(spill_at(i - 1, S_GHG), acc);
     spill_tiles<F32, RT>(spill_at(i - 1, S_GHN), muq);
-    db1g += tile_sum(acc); db1n += tile_sum(muq);
+    STAMP(14);
     __syncthreads();                                    // every wave is done with the GG image
     store_image<F32, RT>(img2, muq, wave, lane);
     __syncthreads();
+    STAMP(15);
     // D3: d/dz of the previous particles
     zero_acc(acc);
     gemm_tile<F32, RT, Pf<RT>::N>(acc, img1 + arow, W(T_W1G), W(T_W1N), ring);
     gemm_tile<F32, RT, Pf<RT>::N>(acc, img2 + arow, W(T_W1N), W(T_WL), ring);
     gemm_tile<F32, RT, Pf<RT>::N>(acc, img0 + arow, W(T_WL), W(L_W1G), ring);
-    if constexpr (K1) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          adj_a[rt * 16 + r] = acc[rt][r];
-          adj_b[rt * 16 + r] = acc[rt][r] * ep[rt][r];
-        }
-    } else {
+    // sums over the particles of d/dz and d/dz * eps; the noise is drawn again here instead of
+    // being kept alive across the step (32 registers that spilled)
+    {
       float pa[RT], pb[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         float sa = 0.f, sb = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool live = (live_bits[rt] >> r) & 1u;
-          const float gz = live ? acc[rt][r] : 0.f;
-          sa += gz; sb = fmaf(gz, ep[rt][r], sb);
+        for (int q = 0; q < 4; ++q) {
+          float e[4] = {0.f, 0.f, 0.f, 0.f};
+          const int r0 = 32 * rt + 8 * q + 4 * h;
+          const bool group = K1 ? (32 * rt + 8 * q < g.NP)
+                                : (__builtin_amdgcn_readfirstlane(tab[rt].p) >= 0 && 32 * (rt & (g.TPP - 1)) + 8 * q < K);
+          if (sampled_prev && group) eps_group(a, noff, t_term, rowbase + r0, n, e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * q + j;
+            const bool live = (live_bits[rt] >> r) & 1u;
+            const float gz = live ? acc[rt][r] : 0.f;
+            if constexpr (K1) { adj_a[rt * 16 + r] = gz; adj_b[rt * 16 + r] = gz * e[j]; }
+            else { sa += gz; sb = fmaf(gz, e[j], sb); }
+          }
         }
         pa[rt] = half_sum(sa); pb[rt] = half_sum(sb);
       }
+      if constexpr (!K1) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) { adj_a[rt] = pair_total(pa, rt, g.TPP); adj_b[rt] = pair_total(pb, rt, g.TPP); }
+        for (int rt = 0; rt < RT; ++rt) { adj_a[rt] = pair_total(pa, rt, g.TPP); adj_b[rt] = pair_total(pb, rt, g.TPP); }
+      }
     }
+    STAMP(16);
     __syncthreads();
+    STAMP(17);
   }
 
   // partial sums of this workgroup
   {
-    float* db = ws.db + (size_t)blockIdx.x * 6 * WD;
-    const float v[6] = {db1g, db1n, dbl, db2g, db2n, dbs};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const float tot = half_sum(v[k]);
-      if (h == 0) db[k * WD + n] = tot;
-    }
     float* dz = ws.dz0 + (size_t)blockIdx.x * 2 * WD;
     const float m0 = half_sum(g_mu0), s0 = half_sum(g_sg0);
     if (h == 0) { dz[n] = m0; dz[WD + n] = s0; }
@@ -865,13 +891,19 @@ __global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int C
   const int64_t items = ws.n_wg * ws.n_step;
   const int64_t per = (items + ws.split - 1) / ws.split;
   const int64_t lo = sp * per, hi = (lo + per < items) ? lo + per : items;
-  f32x16 acc[2][4];
+  f32x16 acc[2][4], accb[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  // bias gradient of the block's layer = sum over rows of its G operand: G^T . 1 on the same pipe
+  uint4 ones;
+  ones.x = ones.y = ones.z = ones.w = F32 ? 0x3F800000u : 0x3F803F80u;
   const size_t arr_u4 = (size_t)NWAVE * CH * 64;
   for (int64_t it = lo; it < hi; ++it) {
     const uint4* gp = ws.spill + ((size_t)it * N_SPILL + garr) * arr_u4 + (size_t)(2 * wa) * CH * 64 + lane;
@@ -886,7 +918,18 @@ __global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int C
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) mma<F32>(acc[i][j], ga[i], xb[j]);
+      if (wb == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) mma<F32>(accb[i], ga[i], ones);
+      }
     }
+  }
+  if (wb == 0 && (lane & 31) == 0) {            // every column of accb holds the row sums
+    float* db = ws.db + ((size_t)sp * 6 + blk) * WD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) db[32 * (2 * wa + i) + acc_row(0, r) + 4 * (lane >> 5)] = accb[i][r];
   }
   float* slab = ws.slab + ((size_t)sp * 6 + blk) * WD * WD;
   const int hh = lane >> 5, col = lane & 31;
@@ -914,7 +957,7 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const WideWs ws, float
       for (int sp = 0; sp < ws.split; ++sp) s += ws.slab[(size_t)sp * NW + idx];
     } else if (idx < NW + 6 * WD) {
       const int k = idx - NW;
-      for (int64_t w = 0; w < ws.n_wg; ++w) s += ws.db[(size_t)w * 6 * WD + k];
+      for (int sp = 0; sp < ws.split; ++sp) s += ws.db[(size_t)sp * 6 * WD + k];
     } else {
       const int k = idx - NW - 6 * WD;
       for (int64_t w = 0; w < ws.n_wg; ++w) s += ws.dz0[(size_t)w * 2 * WD + k];
@@ -1047,7 +1090,7 @@ int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
   if (split > items) split = items > 0 ? (int)items : 1;
   auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
   const int64_t b_spill = up(items * N_SPILL * NWAVE * CH * 64 * 16);
-  const int64_t b_db = up(n_wg * 6 * WD * 4), b_dz = up(n_wg * 2 * WD * 4);
+  const int64_t b_db = up((int64_t)split * 6 * WD * 4), b_dz = up(n_wg * 2 * WD * 4);
   const int64_t b_slab = up((int64_t)split * 6 * WD * WD * 4);
   if (ws) {
     char* p = reinterpret_cast<char*>(a->wide_ws);
