@@ -1,18 +1,27 @@
 #!/usr/bin/env python
 """ELBO-step benchmark of the MI355X-native MDMM path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg3|cfg2]
 
-One "step" = the body of trainer.py:237-252 on one synthetic batch already resident in
-HBM:  loss = model.step(...); (loss / n_points).backward(); [all-reduce]; Adam.step();
-zero_grad.  Workload at N = 1: BASELINE configs[1] ("cfg2": Spirals-synthetic, MultiDMM
-BFVI, 2 modalities, z = h = 32, T = 100, batch 1024, fp32, 10 % burst NaN per sequence).
-For N > 1 every rank gets its own 1024-sequence shard (weak scaling, one process per GPU,
-one RCCL all-reduce of the flat gradient bucket per step).
+One "step" = the body of trainer.py:237-252 on one synthetic batch already resident in HBM:
+loss = model.step(...); (loss / n_points).backward(); [all-reduce]; Adam.step(); zero_grad.
+
+Workload (default, the configuration BASELINE.json's targets are quoted on): configs[2] "cfg3",
+Weizmann-shaped synthetic -- video (3,64,64) + mask (1,64,64) Bernoulli, action Categorical(10),
+conv encoders / decoders of weizmann.py:63-68, MultiDMM BFVI, z = h = 256, T = 40, 256 sequences
+per GPU, 20 % burst NaN, 25 training particles; the dense contractions of the sweeps run with bf16
+operands (MultiDGTS.sweep_dtype), everything else fp32.  `--config cfg2` is the Spirals-synthetic
+z = h = 32 case of round 1 (graph replay); its result also rides along as `extra.cfg2` at N = 1.
+
+`--gpus N` with N > 1 starts N ranks itself (torch.distributed.run, one process per GPU, RCCL)
+unless it already runs under a launcher (WORLD_SIZE set, which must then equal N).  Every rank
+gets its own shard (weak scaling); one all-reduce of the flat gradient bucket per step.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the dominant kernel of the step, timed live with HIP events on the launch
-                  stream (mdmm.ops.KernelTimer), against the f32 MFMA/vector peak;
+  roofline     -- the library call with the largest device time in the step (HIP events on the
+                  launch stream, mdmm.ops.KernelTimer) against the matrix-pipe peak of its operand
+                  type; `achieved` counts ALGORITHMIC flops (backward = 2 x forward),
+                  `executed_flops` what the kernels really do (recompute included);
   cpu_baseline -- the CPU oracle (oracle/mdmm_oracle.py, a per-timestep torch-CPU port of the
                   reference) timed on this box's host cores on a bounded sample of the same
                   workload (rank 0, N = 1 only).
@@ -20,6 +29,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,140 +38,231 @@ for _p in (REPO, os.path.join(REPO, 'multimodal-dmm_amd')):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch                                       # noqa: E402
-import torch.distributed as dist                   # noqa: E402
-
-T_MAX, BATCH, Z_DIM, H_DIM = 100, 1024, 32, 32
 TRAIN_PARTICLES = 25
 F32_PEAK_TFLOPS = 157.3          # MI355X dense f32 (vector = f32-input MFMA), MI355X_MICROARCH.md
-WORKLOAD = ('cfg2: Spirals-synthetic MultiDMM BFVI, M=2, z=32, h=32, T=100, B=%d per GPU, '
-            '10%% burst NaN, train_particles=25' % BATCH)
-
-
-def synth_batch(t_max, b_dim, seed, device):
-    """x, y ~ N(0,1) (T,B,1); inputs = targets with a 10 % NaN burst per
-    sequence and modality; full lengths; mask of ones."""
-    g = torch.Generator().manual_seed(seed)
-    targets = {m: torch.randn(t_max, b_dim, 1, generator=g) for m in ('spiral-x', 'spiral-y')}
-    inputs = {m: v.clone() for m, v in targets.items()}
-    burst = max(1, t_max // 10)
-    for m in inputs:
-        start = torch.randint(0, t_max - burst + 1, (b_dim,), generator=g)
-        idx = torch.arange(t_max).unsqueeze(1)
-        hole = (idx >= start.unsqueeze(0)) & (idx < (start + burst).unsqueeze(0))
-        inputs[m][hole.unsqueeze(-1)] = float('nan')
-    mask = torch.ones(t_max, b_dim, 1, dtype=torch.bool)
-    dev = lambda d: {k: v.to(device) for k, v in d.items()}   # noqa: E731
-    return dev(inputs), dev(targets), mask.to(device), [t_max] * b_dim
+BF16_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA
 
 
 def gtf_flops(d, h):
     return 8 * d * h + 4 * d * d          # common.py:62-68, SURVEY 8a-3
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """Oracle ELBO step (fwd + bwd + Adam) on the host cores, bounded sample."""
-    from oracle import mdmm_oracle as orc
-    b_dim = 32
-    torch.manual_seed(0)
-    model = orc.OracleDMM(['spiral-x', 'spiral-y'], [1, 1], h_dim=H_DIM, z_dim=Z_DIM)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    inputs, targets, mask, lengths = synth_batch(T_MAX, b_dim, 1234, 'cpu')
+def burst_nan(x, t_max, frac, g):
+    """multiseq.py burst deletion, vectorised: one NaN burst of frac*T steps per sequence."""
+    import torch
+    b_dim = x.shape[1]
+    burst = max(1, int(t_max * frac))
+    start = torch.randint(0, t_max - burst + 1, (b_dim,), generator=g)
+    idx = torch.arange(t_max).unsqueeze(1)
+    hole = (idx >= start.unsqueeze(0)) & (idx < (start + burst).unsqueeze(0))
+    x[hole] = float('nan')
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# cfg2: Spirals-synthetic, z = h = 32
+# ---------------------------------------------------------------------------------------------
+class Cfg2:
+    name, T, B, D, H, M = 'cfg2', 100, 1024, 32, 32, 2
+    dtype, peak, lr = 'f32', F32_PEAK_TFLOPS, 1e-3
     rec = {'spiral-x': .5, 'spiral-y': .5}
+    workload = ('cfg2: Spirals-synthetic MultiDMM BFVI, M=2, z=32, h=32, T=100, B=%d per GPU, '
+                '10%% burst NaN, train_particles=25')
+
+    @staticmethod
+    def batch(t_max, b_dim, seed, device):
+        """x, y ~ N(0,1) (T,B,1); inputs = targets with a 10 % NaN burst."""
+        import torch
+        g = torch.Generator().manual_seed(seed)
+        targets = {m: torch.randn(t_max, b_dim, 1, generator=g) for m in ('spiral-x', 'spiral-y')}
+        inputs = {m: burst_nan(v.clone(), t_max, 0.1, g) for m, v in targets.items()}
+        mask = torch.ones(t_max, b_dim, 1, dtype=torch.bool)
+        dev = lambda d: {k: v.to(device) for k, v in d.items()}   # noqa: E731
+        return dev(inputs), dev(targets), mask.to(device), [t_max] * b_dim
+
+    @staticmethod
+    def model(models, device):
+        return models.MultiDMM(['spiral-x', 'spiral-y'], [1, 1], h_dim=32, z_dim=32, device=device)
+
+    @staticmethod
+    def oracle(orc):
+        return orc.OracleDMM(['spiral-x', 'spiral-y'], [1, 1], h_dim=32, z_dim=32)
+
+
+def synth_batch(t_max, b_dim, seed, device):      # kept for the tools that import it
+    return Cfg2.batch(t_max, b_dim, seed, device)
+
+
+# ---------------------------------------------------------------------------------------------
+# cfg3: Weizmann-shaped, z = h = 256, conv plug-ins
+# ---------------------------------------------------------------------------------------------
+class Cfg3:
+    name, T, B, D, H, M = 'cfg3', 40, 256, 256, 256, 3
+    dtype, peak, lr = 'bf16', BF16_PEAK_TFLOPS, 1e-4
+    rec = {'video': 1.0, 'mask': 1.0, 'action': 10.0}
+    workload = ('cfg3: Weizmann-shaped synthetic (video 3x64x64 + mask 1x64x64 Bernoulli, action '
+                'Categorical(10)), MultiDMM BFVI, conv encoders/decoders, z=h=256, T=40, B=%d per GPU, '
+                '20%% burst NaN, train_particles=25, sweep contractions bf16 / fp32 accumulate')
+    mods, dims = ['video', 'mask', 'action'], [(3, 64, 64), (1, 64, 64), 10]
+    dists = ['Bernoulli', 'Bernoulli', 'Categorical']
+
+    @staticmethod
+    def batch(t_max, b_dim, seed, device):
+        """video U(0,1), mask Bernoulli(.5), action constant over time; 20 % burst."""
+        import torch
+        g = torch.Generator().manual_seed(seed)
+        tg = {'video': torch.rand(t_max, b_dim, 3, 64, 64, generator=g),
+              'mask': (torch.rand(t_max, b_dim, 1, 64, 64, generator=g) < 0.5).float(),
+              'action': torch.randint(0, 10, (1, b_dim, 1), generator=g).float().expand(t_max, b_dim, 1).contiguous()}
+        x = {k: burst_nan(v.clone(), t_max, 0.2, g) for k, v in tg.items()}
+        mask = torch.ones(t_max, b_dim, 1, dtype=torch.bool)
+        dev = lambda d: {k: v.to(device) for k, v in d.items()}   # noqa: E731
+        return dev(x), dev(tg), mask.to(device), [t_max] * b_dim
+
+    @classmethod
+    def _plugins(cls, C):
+        enc = {'video': C.ImageEncoder(256, n_channels=3), 'mask': C.ImageEncoder(256, n_channels=1)}
+        dec = {'video': C.ImageDecoder(256, n_channels=3), 'mask': C.ImageDecoder(256, n_channels=1)}
+        return enc, dec
+
+    @classmethod
+    def model(cls, models, device):
+        import torch
+        enc, dec = cls._plugins(models.common)
+        m = models.MultiDMM(cls.mods, cls.dims, cls.dists, encoders=enc, decoders=dec, h_dim=256,
+                            z_dim=256, device=device)
+        m.sweep_dtype = torch.bfloat16
+        return m
+
+    @classmethod
+    def oracle(cls, orc):
+        from mdmm.models import common as C       # the plug-in conv stacks are plain torch modules
+        enc, dec = cls._plugins(C)
+        return orc.OracleDMM(cls.mods, cls.dims, cls.dists, encoders=enc, decoders=dec, h_dim=256,
+                             z_dim=256)
+
+
+CONFIGS = {'cfg2': Cfg2, 'cfg3': Cfg3}
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """Oracle ELBO step (fwd + bwd + Adam) on the host cores, bounded sample of the workload."""
+    import torch
+    from oracle import mdmm_oracle as orc
+    b_dim = 32 if cfg is Cfg2 else 8
+    torch.manual_seed(0)
+    model = cfg.oracle(orc)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+    inputs, targets, mask, lengths = cfg.batch(cfg.T, b_dim, 1234, 'cpu')
 
     def one():
-        loss = model.step(inputs, mask, 1.0, rec, targets=targets, lengths=lengths)
+        loss = model.step(inputs, mask, 1.0, cfg.rec, targets=targets, lengths=lengths)
         (loss / sum(lengths)).backward()
         opt.step()
         opt.zero_grad()
 
-    # The path is thousands of tiny ops per step, so more threads is not faster: time one
-    # step at a few thread counts, keep the best, then spend the rest of the budget there.
+    # Thousands of small ops per step: more threads is not always faster.  Time one step at a few
+    # thread counts, keep the best, spend the rest of the budget there.
     all_cores = torch.get_num_threads()
-    trial = {}
-    for nt in sorted({1, 8, min(32, all_cores), all_cores}):
+    trial, spent = {}, 0.0
+    for nt in sorted({1, 8, min(32, all_cores), all_cores}, reverse=cfg is Cfg3):
         torch.set_num_threads(nt)
-        one()                               # warm-up at this setting
         t0 = time.perf_counter()
+        one()                               # warm-up at this setting
         one()
-        trial[nt] = time.perf_counter() - t0
-        if sum(trial.values()) * 2 > seconds_budget:
+        dt2 = time.perf_counter() - t0
+        trial[nt] = dt2 / 2
+        spent += dt2
+        if spent > 0.6 * seconds_budget:
             break
     best = min(trial, key=trial.get)
     torch.set_num_threads(best)
     t0, n = time.perf_counter(), 0
-    while n < 1 or (time.perf_counter() - t0 < max(2.0, seconds_budget - 2 * sum(trial.values()))
-                    and n < 8):
+    while n < 1 or (time.perf_counter() - t0 < seconds_budget - spent and n < 8):
         one()
         n += 1
     dt = (time.perf_counter() - t0) / n
     torch.set_num_threads(all_cores)
     return {'value': round(b_dim / dt, 3), 'unit': 'sequences/s', 'cores': best, 'kind': 'port',
-            'sample': '%d steps of the same cfg2 step at B=%d (seq/s is ~flat in B on CPU), T=100, '
-                      'z=h=32, 25 particles, torch-CPU oracle at its best thread count of %s '
-                      '(s/step by threads: %s; host has %d), %.2f s/step'
-                      % (n, b_dim, best, {k: round(v, 2) for k, v in trial.items()}, all_cores, dt)}
+            'sample': '%d steps of the same %s step at B=%d (the full batch would take minutes per step; '
+                      'a lower bound of the CPU rate if it grows with B), torch-CPU oracle at its best '
+                      'thread count of %s (s/step by threads: %s; host has %d), %.2f s/step'
+                      % (n, cfg.name, b_dim, best, {k: round(v, 2) for k, v in trial.items()}, all_cores, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=BATCH, help='sequences per GPU')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--eager', action='store_true', help='no HIP-graph replay of the step')
-    args = ap.parse_args()
+def roofline_of(cfg, spans, n_steps, b_dim):
+    """The library call with the largest device time; algorithmic flops of one launch."""
+    tag, (n_launch, tot_ms) = max(spans.items(), key=lambda kv: kv[1][1])
+    p_pass = 1 + cfg.M
+    k = TRAIN_PARTICLES if 'K=%d' % TRAIN_PARTICLES in tag else 1
+    rows = p_pass * b_dim * (cfg.T - 1) * k          # transition rows of one sweep launch
+    fwd = rows * gtf_flops(cfg.D, cfg.H)
+    if 'bwd' in tag:
+        # SURVEY 8d: backward = 2 x forward (input + weight gradients); the kernels also recompute
+        # the forward transition (executed = 3 x)
+        flops, executed = 2 * fwd, 3 * fwd
+    else:
+        flops = executed = fwd
+    avg_ms = tot_ms / n_launch
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    wide = tag.startswith('sweep_wide') and cfg.dtype == 'bf16'
+    peak = BF16_PEAK_TFLOPS if wide else F32_PEAK_TFLOPS
+    return {'bound': 'mfma', 'kernel': tag, 'achieved': round(achieved, 3), 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(achieved / peak, 4), 'traffic': None, 'launch_ms': round(avg_ms, 4),
+            'launches': n_launch, 'flops_per_launch': flops, 'executed_flops': executed,
+            'operands': 'bf16' if wide else 'f32'}
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the MDMM hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=device)
 
+def attach_traffic(rf):
+    """HBM bytes per launch from the PMC pass kept under profiles/ (tools/pmc_traffic.sh): counters
+    cannot be collected from inside the benchmark process."""
+    path = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
+    if not os.path.exists(path):
+        return
+    try:
+        table = json.load(open(path))
+    except ValueError:
+        return
+    for key, rec in table.items():
+        if key in rf['kernel']:
+            rf['traffic'] = rec.get('bytes_per_launch')
+            rf['traffic_source'] = rec.get('source')
+            return
+
+
+def run(cfg, args, world, rank, device, graph):
+    """Time args.steps steps of cfg on this rank; returns the result dict (rank 0) or None."""
+    import torch
+    import torch.distributed as dist
     from mdmm import models, ops
     from mdmm.harness import GradBucket, GraphedElboStep, elbo_step
     from mdmm.noise import PhiloxNoise
 
     torch.manual_seed(0)                    # identical weights on every rank
-    model = models.MultiDMM(['spiral-x', 'spiral-y'], [1, 1], h_dim=H_DIM, z_dim=Z_DIM,
-                            device=device)
+    model = cfg.model(models, device)
     model.noise = PhiloxNoise(seed=1000 + rank)
-    # fused: the whole Adam update of the 50 parameter tensors in one launch (same arithmetic)
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=not args.eager, fused=True)
+    optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr, capturable=graph, fused=True)
     bucket = GradBucket(model.parameters())
-    b_dim = args.batch
-    inputs, targets, mask, lengths = synth_batch(T_MAX, b_dim, 1234 + rank, device)
-    rec = {'spiral-x': .5, 'spiral-y': .5}
+    b_dim = args.batch or cfg.B
+    inputs, targets, mask, lengths = cfg.batch(cfg.T, b_dim, 1234 + rank, device)
     n_points_global = sum(lengths) * world
+    kw = dict(targets=targets, n_points_global=n_points_global, train_particles=TRAIN_PARTICLES)
 
-    if args.eager:
-        def step():
-            return elbo_step(model, optimizer, bucket, inputs, mask, lengths, 1.0, rec,
-                             targets=targets, n_points_global=n_points_global,
-                             train_particles=TRAIN_PARTICLES)
-    else:   # same step, captured once into two HIP graphs (collective in between, eager)
+    def eager_step():
+        return elbo_step(model, optimizer, bucket, inputs, mask, lengths, 1.0, cfg.rec, **kw)
+
+    execution = 'eager'
+    step = eager_step
+    if graph:       # same step, captured once into two HIP graphs (collective in between, eager)
         try:
-            step = GraphedElboStep(model, optimizer, bucket, inputs, mask, lengths, 1.0, rec,
-                                   targets=targets, n_points_global=n_points_global,
-                                   train_particles=TRAIN_PARTICLES)
+            step = GraphedElboStep(model, optimizer, bucket, inputs, mask, lengths, 1.0, cfg.rec, **kw)
+            execution = 'hipgraph'
         except Exception as exc:        # noqa: BLE001 -- never lose the run to a capture problem
             print('bench: HIP-graph capture failed (%r); running the step eagerly' % (exc,),
                   file=sys.stderr, flush=True)
             torch.cuda.synchronize()
-            args.eager = True
             bucket.release()
-
-            def step():
-                return elbo_step(model, optimizer, bucket, inputs, mask, lengths, 1.0, rec,
-                                 targets=targets, n_points_global=n_points_global,
-                                 train_particles=TRAIN_PARTICLES)
+            execution = 'eager (graph capture failed)'
 
     def barrier():
         if world > 1:
@@ -171,7 +272,7 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     barrier()
-    if args.eager:
+    if execution != 'hipgraph':
         ops.TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -183,54 +284,93 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    timing_note = 'HIP events around every launch of the timed steps'
+    n_probe = args.steps
+    timing_note = 'HIP events on the launch stream around every library call of the timed steps'
     if timer is None and rank == 0:
         # Graph replay leaves no place for events between nodes: re-run the same step eagerly
-        # (not part of `value`) with HIP events on the launch stream around every library launch.
+        # (not part of `value`) with HIP events around every library call.
         n_probe = min(args.steps, 3)
         ops.TIMER = ops.KernelTimer()
         for _ in range(n_probe):
-            elbo_step(model, optimizer, bucket, inputs, mask, lengths, 1.0, rec, targets=targets,
-                      n_points_global=n_points_global, train_particles=TRAIN_PARTICLES)
+            eager_step()
         torch.cuda.synchronize()
         timer, ops.TIMER = ops.TIMER, None
-        timing_note = ('HIP events around every launch of %d eager re-runs of the same step, '
+        timing_note = ('HIP events around every library call of %d eager re-runs of the same step, '
                        'right after the graph-replayed timed region' % n_probe)
     if world > 1:
         dist.barrier()
     loss_val = float(loss)
+    if rank != 0:
+        return None
+    spans = timer.summary()
+    rf = roofline_of(cfg, spans, n_probe, b_dim)
+    rf['timing'] = timing_note
+    attach_traffic(rf)
+    return {
+        'metric': 'sequences/sec (ELBO step)', 'value': round(world * b_dim * args.steps / elapsed, 2),
+        'unit': 'sequences/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': cfg.dtype, 'data': 'synthetic',
+        'config': {'workload': cfg.workload % b_dim, 'global_batch': world * b_dim, 'seq_len': cfg.T,
+                   'parallelism': 'dp%d' % world, 'loss': round(loss_val, 3), 'execution': execution},
+        'roofline': rf,
+        'kernels_ms_per_step': {t_: round(v[1] / n_probe, 4) for t_, v in
+                                sorted(spans.items(), key=lambda kv: -kv[1][1])[:16]},
+    }
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg3')
+    ap.add_argument('--batch', type=int, default=0, help='sequences per GPU (default: the config\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the cfg2 line that rides along')
+    ap.add_argument('--eager', action='store_true', help='no HIP-graph replay of the step (cfg2)')
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.steps is None:
+        args.steps = 5 if cfg is Cfg3 else 10
+    if args.warmup is None:
+        args.warmup = 2 if cfg is Cfg3 else 3
+
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        # start the ranks ourselves, BEFORE anything in this process touches the GPU
+        port = os.environ.get('MASTER_PORT', str(29500 + os.getpid() % 2000))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+    world = int(env_world or '1')
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks'
+                         % (args.gpus, world))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the MDMM hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    # cfg3 runs eagerly (MIOpen plug-ins; the sweeps are one launch each); cfg2 replays HIP graphs
+    out = run(cfg, args, world, rank, device, graph=(cfg is Cfg2 and not args.eager))
     if rank == 0:
-        ms = 1e3 * elapsed / args.steps
-        spans = timer.summary()
-        # dominant kernel = largest total device time among the library's launches
-        tag, (n_launch, tot_ms) = max(spans.items(), key=lambda kv: kv[1][1])
-        p_pass = 3
-        rows = p_pass * b_dim * (T_MAX - 1)          # transition rows per particle
-        k = TRAIN_PARTICLES if 'K=%d' % TRAIN_PARTICLES in tag else 1
-        # algorithmic flops of one launch: GTF forward (fwd sweep); GTF recompute + input-gradient
-        # + weight-gradient contractions (bwd sweep, all three inside the MFMA kernel for z,h<=32)
-        per_row = gtf_flops(Z_DIM, H_DIM) * (3 if tag.startswith('sweep_bwd') else 1)
-        flops = rows * k * per_row
-        avg_ms = tot_ms / n_launch
-        achieved = flops / (avg_ms * 1e-3) / 1e12
-        out = {
-            'metric': 'sequences/sec (ELBO step)', 'value': round(world * b_dim * args.steps / elapsed, 2),
-            'unit': 'sequences/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': WORKLOAD, 'global_batch': world * b_dim, 'seq_len': T_MAX,
-                       'parallelism': 'dp%d' % world, 'loss': round(loss_val, 3)},
-            'roofline': {'bound': 'mfma', 'kernel': tag, 'achieved': round(achieved, 3),
-                         'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / F32_PEAK_TFLOPS, 4), 'traffic': None,
-                         'launch_ms': round(avg_ms, 4), 'launches': n_launch, 'timing': timing_note,
-                         'flops_per_launch': flops},
-            'kernels_ms_per_step': {t_: round(v[1] / n_launch, 4) for t_, v in
-                                    sorted(spans.items(), key=lambda kv: -kv[1][1])},
-        }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(cfg)
+        if world == 1 and cfg is Cfg3 and not args.no_extra:
+            torch.cuda.empty_cache()
+            a2 = argparse.Namespace(**vars(args))
+            a2.steps, a2.warmup, a2.batch = 10, 3, 0
+            r2 = run(Cfg2, a2, 1, 0, device, graph=True)
+            out['extra'] = {'cfg2': {k: r2[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline')}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -36,7 +36,7 @@ extern "C" {
 int mdmm_version(void);
 const char* mdmm_strerror(int code);
 /* sizeof() of an argument struct as the library was compiled, for a binding to check its own
- * declaration against at load time: 0 gtf, 1 expert, 2 sweep, 3 stage, 4 gru, 5 dks, 6 mlp; 0 if unknown */
+ * declaration against at load time: 0 gtf, 1 expert, 2 sweep, 4 gru, 5 dks, 6 mlp; 0 if unknown */
 size_t mdmm_sizeof(int which);
 /* round n up to the padded width the packed weights use (multiple of 4) */
 int mdmm_pad(int n);
@@ -200,6 +200,14 @@ int64_t mdmm_sweep_dw_rows(const mdmm_sweep_t* args);
 /* widths of one spill_g / spill_x row for (D,H) */
 int mdmm_sweep_spill_width_g(int D, int H);
 int mdmm_sweep_spill_width_x(int D, int H);
+/* Weight gradients from spilled operands (mode 0, and the mdmm_dks_t spills): for one layer
+ * dW[n][k] = sum_rows G[row][gcol0 + n] * X[row][xcol0 + k], n < gcols, k < xcols (replaces the
+ * reference's autograd of nn.Linear, common.py:48-60).  The rows are split `splits` ways
+ * (mdmm_spill_wgrad_splits gives a good value); out holds `splits` slabs of gcols x xcols floats
+ * which the caller adds up.  */
+int mdmm_spill_wgrad_splits(int64_t rows, int gcols, int xcols);
+int mdmm_spill_wgrad(const float* G, int ldg, int gcol0, int gcols, const float* X, int ldx,
+                     int xcol0, int xcols, int64_t rows, int splits, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Stand-alone product / mixture of experts: MultiDGTS.product_of_experts
@@ -253,49 +261,6 @@ int mdmm_nll_categorical_fwd(const float* probs, const float* x, const float* se
 int mdmm_nll_categorical_bwd(const float* probs, const float* x, const float* seq_mask,
                              int64_t rows, int n_cat, float scale, const float* scale_dev,
                              float* g_probs, void* stream);
-
-/* ---------------------------------------------------------------------------------
- * Stage-wise sweep for large latent sizes (z_dim or h_dim > 32): the host runs the time loop
- * (dmm.py:373-405) and every timestep handles ALL rows (pass, sequence, particle) at once --
- * the four contractions of the gated transition are plain GEMMs issued by the caller (weights
- * read once per stage instead of once per handful of rows), these kernels are the fused
- * elementwise / reduction parts in between.  Row-major stage buffers, rows ordered
- * (p, b, k), R = P*B*K rows, F1 = 2H + D (no padding):
- *   Z [R][D] particles of the previous step        A1 [R][F1] = [relu gate-hid | relu nl-hid | z_lin]
- *   GATE / NL / PRE [R][D] gate pre-act, nonlin, std pre-act
- *   G1 [R][F1], GG / GN / G3 / GZ [R][D] adjoints (in-layer, gate pre-act, nonlin, std pre-act, z)
- *   adj_a / adj_b / gpm / gps [P*B][D]; GZ0 [2][R][D] and GZF [2][P*B][D] accumulate d/d(mu0,
- *   sigma0) over the steps (zero them first, reduce once at the end).
- * `sw` carries sizes, flags, noise, experts, outputs and upstream gradients as for the fused
- * sweep (gtf / spill / dw_partial fields unused).  */
-typedef struct mdmm_stage {
-  mdmm_sweep_t sw;
-  int32_t t, t_prev;        /* time index of the step and of the previously processed step */
-  int32_t first;            /* first processed step: prior = global prior, no transition */
-  int32_t sampled, sampled_prev;
-  int32_t reserved;
-  float* Z;
-  float* A1;
-  float* GATE;
-  float* NL;
-  float* PRE;
-  float* G1;
-  float* GG;
-  float* GN;
-  float* G3;
-  float* GZ;
-  float* GZ0;
-  float* GZF;
-  float* adj_a;
-  float* adj_b;
-  float* gpm;
-  float* gps;
-} mdmm_stage_t;
-int mdmm_stage_sample(const mdmm_stage_t* s, void* stream);    /* Z <- particles of t_prev        */
-int mdmm_stage_step_fwd(const mdmm_stage_t* s, void* stream);  /* stage outputs -> prior/infer/z  */
-int mdmm_stage_fuse_bwd(const mdmm_stage_t* s, void* stream);  /* adjoint of PoE + sampling at t  */
-int mdmm_stage_trans_bwd(const mdmm_stage_t* s, void* stream); /* elementwise transition adjoint  */
-int mdmm_stage_adj_reduce(const mdmm_stage_t* s, void* stream);/* GZ -> adj_a / adj_b             */
 
 /* ---------------------------------------------------------------------------------
  * MultiDKS (models/dks.py): the two sequential recurrences of the RNN structured-inference

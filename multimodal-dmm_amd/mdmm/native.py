@@ -18,7 +18,7 @@ PREC_F32, PREC_BF16 = 0, 1
 SYMBOLS = [
     'mdmm_version', 'mdmm_strerror', 'mdmm_pad', 'mdmm_sizeof',
     'mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd',
-    'mdmm_sweep_spill_width_g', 'mdmm_sweep_spill_width_x',
+    'mdmm_sweep_spill_width_g', 'mdmm_sweep_spill_width_x', 'mdmm_spill_wgrad', 'mdmm_spill_wgrad_splits',
     'mdmm_sweep_bwd_mode', 'mdmm_sweep_dw_width', 'mdmm_sweep_dw_rows',
     'mdmm_sweep_wide', 'mdmm_sweep_wide_ws_bytes', 'mdmm_gtf_frag_bytes', 'mdmm_gtf_frag_pack',
     'mdmm_poe_fwd', 'mdmm_poe_bwd', 'mdmm_moe_fwd', 'mdmm_moe_bwd',
@@ -28,8 +28,6 @@ SYMBOLS = [
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
     'mdmm_philox_normal', 'mdmm_debug_clock', 'mdmm_gtf_pack_size', 'mdmm_gtf_pack',
     'mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd', 'mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd',
-    'mdmm_stage_sample', 'mdmm_stage_step_fwd', 'mdmm_stage_fuse_bwd', 'mdmm_stage_trans_bwd',
-    'mdmm_stage_adj_reduce',
     'mdmm_gauss_mlp_supported', 'mdmm_gauss_mlp_dw_width', 'mdmm_gauss_mlp_dw_rows',
     'mdmm_gauss_mlp_fwd', 'mdmm_gauss_mlp_bwd',
 ]
@@ -68,13 +66,6 @@ class Sweep(C.Structure):
                  ('dw_partial', _P), ('dw_partial_rows', C.c_int64), ('offset_dev', _P),
                  ('gtf_frag', _P), ('precision', C.c_int32), ('reserved1', C.c_int32),
                  ('wide_ws', _P), ('wide_ws_bytes', C.c_int64)])
-
-
-class Stage(C.Structure):
-    _fields_ = ([('sw', Sweep)] +
-                [(n, C.c_int32) for n in ('t', 't_prev', 'first', 'sampled', 'sampled_prev', 'reserved')] +
-                [(n, _P) for n in ('Z', 'A1', 'GATE', 'NL', 'PRE', 'G1', 'GG', 'GN', 'G3', 'GZ', 'GZ0',
-                                   'GZF', 'adj_a', 'adj_b', 'gpm', 'gps')])
 
 
 class Gru(C.Structure):
@@ -131,13 +122,13 @@ def lib():
             getattr(L, name).argtypes = [C.c_int, C.c_int]
         for name in ('mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd'):
             getattr(L, name).argtypes = [C.POINTER(Sweep), _P]
-        for name in ('mdmm_stage_sample', 'mdmm_stage_step_fwd', 'mdmm_stage_fuse_bwd',
-                     'mdmm_stage_trans_bwd', 'mdmm_stage_adj_reduce'):
-            getattr(L, name).argtypes = [C.POINTER(Stage), _P]
         for name in ('mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd'):
             getattr(L, name).argtypes = [C.POINTER(Gru), _P]
         for name in ('mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd'):
             getattr(L, name).argtypes = [C.POINTER(Dks), _P]
+        L.mdmm_spill_wgrad_splits.argtypes = [C.c_int64, C.c_int, C.c_int]
+        L.mdmm_spill_wgrad.argtypes = [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                       C.c_int, _P, _P]
         L.mdmm_sweep_bwd_mode.argtypes = [C.POINTER(Sweep)]
         L.mdmm_sweep_dw_width.argtypes = [C.c_int, C.c_int]
         L.mdmm_sweep_dw_rows.argtypes = [C.POINTER(Sweep)]
@@ -177,7 +168,7 @@ def lib():
         L.mdmm_gauss_mlp_bwd.argtypes = [C.POINTER(Mlp), _P]
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
-        for which, st in enumerate((Gtf, Expert, Sweep, Stage, Gru, Dks, Mlp)):
+        for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp)):
             if L.mdmm_sizeof(which) != C.sizeof(st):
                 raise MdmmError('struct %s: library %d bytes, binding %d bytes'
                                 % (st.__name__, L.mdmm_sizeof(which), C.sizeof(st)))

@@ -88,6 +88,18 @@ def gtf_param_list(gtf):
     return out
 
 
+def spill_wgrad(G, gcol0, gcols, X, xcol0, xcols):
+    """dW (gcols, xcols) = G[:, gcol0:gcol0+gcols]^T X[:, xcol0:xcol0+xcols] on spilled operand
+    rows (csrc/spill_wgrad.hip): the rows are split over workgroups, the slabs added here."""
+    rows = G.shape[0]
+    L = native.lib()
+    splits = L.mdmm_spill_wgrad_splits(rows, gcols, xcols)
+    out = torch.empty(splits, gcols, xcols, device=G.device, dtype=torch.float32)
+    _call('mdmm_spill_wgrad', _ptr(G), G.stride(0), gcol0, gcols, _ptr(X), X.stride(0), xcol0, xcols,
+          rows, splits, _ptr(out))
+    return out[0] if splits == 1 else out.sum(0)
+
+
 class PackedGtf:
     """Padded, fused, both-orientation copy of one GaussianGTF's weights in ONE buffer."""
 
@@ -144,17 +156,19 @@ class PackedGtf:
         for name, off in self.offsets.items():
             setattr(g, name, base + 4 * off)
 
-    def unpack_grads(self, G, X, like):
+    def unpack_grads(self, G, X, like, contract=None):
         """Weight/bias gradients of the 12 raw parameters from the spilled GEMM operands.
-        dW = G^T X per layer: plain GEMMs with the contraction over all transition rows."""
+        dW = G^T X per layer, contracted over all transition rows by csrc/spill_wgrad.hip
+        (`contract` lets the host-side layout test supply its own contraction)."""
+        spill_wgrad = contract or globals()['spill_wgrad']
         D, H, Dp, Hp, F1 = self.D, self.H, self.Dp, self.Hp, self.F1
         if G is None or G.shape[0] == 0:
             return [torch.zeros_like(p) for p in like]
         gb = G.sum(0)
-        d_in = G[:, :F1].t() @ X[:, :Dp]
-        d_gate = G[:, F1:F1 + Dp].t() @ X[:, Dp:Dp + Hp]
-        d_nl = G[:, F1 + Dp:F1 + 2 * Dp].t() @ X[:, Dp + Hp:Dp + 2 * Hp]
-        d_std = G[:, F1 + 2 * Dp:].t() @ X[:, Dp + 2 * Hp:]
+        d_in = spill_wgrad(G, 0, F1, X, 0, Dp)
+        d_gate = spill_wgrad(G, F1, Dp, X, Dp, Hp)
+        d_nl = spill_wgrad(G, F1 + Dp, Dp, X, Dp + Hp, Hp)
+        d_std = spill_wgrad(G, F1 + 2 * Dp, Dp, X, Dp + 2 * Hp, Dp)
         return [d_in[0:H, :D], gb[0:H],                                   # z_to_gate.0
                 d_gate[:D, :H], gb[F1:F1 + D],                            # z_to_gate.2
                 d_in[2 * Hp:2 * Hp + D, :D], gb[2 * Hp:2 * Hp + D],       # z_lin
@@ -297,123 +311,6 @@ def _fill_common(s, cfg, z0_mean, z0_log_std, packed, eps):
         packed.fill(s.gtf)
 
 
-STAGED_MIN_ROWS = 512      # (pass, sequence, particle) rows from which the stage-wise path pays
-
-
-def _use_staged(cfg):
-    """Large latent sizes with enough rows run stage-wise (csrc/staged.hip): the time loop on the
-    host, every timestep = 4 chip-wide GEMMs + fused elementwise kernels over all rows."""
-    import os
-    if cfg.trans_only or (cfg.D <= 32 and cfg.H <= 32):
-        return False
-    if os.environ.get('MDMM_FORCE_GENERIC') == '1':
-        return False
-    return cfg.P * cfg.B * cfg.K >= STAGED_MIN_ROWS
-
-
-class _StagedWeights:
-    def __init__(self, gtf):
-        W1g, b1g, W2g, b2g, Wl, bl, W1n, b1n, W2n, b2n, Ws, bs = [p.detach() for p in gtf]
-        self.H, self.D = W1g.shape
-        self.W_in = torch.cat([W1g, W1n, Wl], 0).contiguous()        # (F1, D)
-        self.W_in_t = self.W_in.t().contiguous()                     # (D, F1)
-        self.b_in = torch.cat([b1g, b1n, bl])
-        self.W2g, self.W2n, self.Ws = W2g.contiguous(), W2n.contiguous(), Ws.contiguous()
-        self.W2g_t, self.W2n_t, self.Ws_t = W2g.t().contiguous(), W2n.t().contiguous(), Ws.t().contiguous()
-        self.b2g, self.b2n, self.bs = b2g, b2n, bs
-
-
-def _stage_steps(cfg):
-    """(i, t, t_prev, sampled, sampled_prev) per processed step, dmm.py:367-405."""
-    out = []
-    for i in range(cfg.T):
-        t = cfg.T - 1 - i if cfg.reverse else i
-        t_prev = (t + 1 if cfg.reverse else t - 1) if i > 0 else 0
-        sampled = cfg.sample or cfg.K > 1 or (i == 0 and cfg.sample_init)
-        sampled_prev = cfg.sample or cfg.K > 1 or (i == 1 and cfg.sample_init)
-        out.append((i, t, t_prev, int(sampled), int(sampled_prev)))
-    return out
-
-
-def _stage_transition(st, w, buf, tag):
-    """Particles of the previous step through the gated transition (common.py:62-68): four GEMMs."""
-    H = w.H
-    _call('mdmm_stage_sample', C.byref(st), tag='stage_sample' + tag)
-    torch.addmm(w.b_in, buf['Z'], w.W_in_t, out=buf['A1'])
-    buf['A1'][:, :2 * H].relu_()
-    torch.addmm(w.b2g, buf['A1'][:, :H], w.W2g_t, out=buf['GATE'])
-    torch.addmm(w.b2n, buf['A1'][:, H:2 * H], w.W2n_t, out=buf['NL'])
-    torch.addmm(w.bs, buf['NL'], w.Ws_t, out=buf['PRE'])
-
-
-def _staged_fwd(cfg, sweep, gtf):
-    dev = gtf[0].device
-    w = _StagedWeights(gtf)
-    D, H = cfg.D, cfg.H
-    R, F1 = cfg.P * cfg.B * cfg.K, 2 * H + D
-    buf = {'Z': torch.empty(R, D, device=dev), 'A1': torch.empty(R, F1, device=dev),
-           'GATE': torch.empty(R, D, device=dev), 'NL': torch.empty(R, D, device=dev),
-           'PRE': torch.empty(R, D, device=dev)}
-    st = native.Stage()
-    st.sw = sweep
-    for k, v in buf.items():
-        setattr(st, k, _ptr(v))
-    tag = '[P=%d,K=%d,D=%d]' % (cfg.P, cfg.K, D)
-    for i, t, t_prev, sampled, sampled_prev in _stage_steps(cfg):
-        st.t, st.t_prev, st.first, st.sampled, st.sampled_prev = t, t_prev, int(i == 0), sampled, sampled_prev
-        if i > 0:
-            _stage_transition(st, w, buf, tag)
-        _call('mdmm_stage_step_fwd', C.byref(st), tag='stage_step_fwd' + tag)
-
-
-def _staged_bwd(cfg, sweep, gtf):
-    """Reverse scan, stage-wise.  Returns (12 GTF gradients, d/d z0_mean, d/d sigma0)."""
-    dev = gtf[0].device
-    w = _StagedWeights(gtf)
-    D, H = cfg.D, cfg.H
-    PB = cfg.P * cfg.B
-    R, F1 = PB * cfg.K, 2 * H + D
-    new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)      # noqa: E731
-    zer = lambda *sh: torch.zeros(*sh, device=dev, dtype=torch.float32)      # noqa: E731
-    buf = {'Z': new(R, D), 'A1': new(R, F1), 'GATE': new(R, D), 'NL': new(R, D), 'PRE': new(R, D),
-           'G1': new(R, F1), 'GG': new(R, D), 'GN': new(R, D), 'G3': new(R, D), 'GZ': new(R, D),
-           'GZ0': zer(2, R, D), 'GZF': zer(2, PB, D), 'adj_a': zer(PB, D), 'adj_b': zer(PB, D),
-           'gpm': new(PB, D), 'gps': new(PB, D)}
-    tmp_h = new(R, H)
-    dW_in, db_in = zer(F1, D), zer(F1)
-    dW2g, db2g, dW2n, db2n = zer(D, H), zer(D), zer(D, H), zer(D)
-    dWs, dbs = zer(D, D), zer(D)
-    st = native.Stage()
-    st.sw = sweep
-    for k, v in buf.items():
-        setattr(st, k, _ptr(v))
-    tag = '[P=%d,K=%d,D=%d]' % (cfg.P, cfg.K, D)
-    A1, G1 = buf['A1'], buf['G1']
-    for i, t, t_prev, sampled, sampled_prev in reversed(_stage_steps(cfg)):
-        st.t, st.t_prev, st.first, st.sampled, st.sampled_prev = t, t_prev, int(i == 0), sampled, sampled_prev
-        _call('mdmm_stage_fuse_bwd', C.byref(st), tag='stage_fuse_bwd' + tag)
-        if i == 0:
-            break
-        _stage_transition(st, w, buf, tag)                      # recompute
-        _call('mdmm_stage_trans_bwd', C.byref(st), tag='stage_trans_bwd' + tag)
-        buf['GN'].addmm_(buf['G3'], w.Ws)                        # d/d nonlin += d/d std-pre . W_std
-        torch.mm(buf['GG'], w.W2g, out=tmp_h)
-        G1[:, :H] = tmp_h * (A1[:, :H] > 0)
-        torch.mm(buf['GN'], w.W2n, out=tmp_h)
-        G1[:, H:2 * H] = tmp_h * (A1[:, H:2 * H] > 0)
-        torch.mm(G1, w.W_in, out=buf['GZ'])                      # d/dz of the previous particles
-        dWs.addmm_(buf['G3'].t(), buf['NL']); dbs += buf['G3'].sum(0)
-        dW2g.addmm_(buf['GG'].t(), A1[:, :H]); db2g += buf['GG'].sum(0)
-        dW2n.addmm_(buf['GN'].t(), A1[:, H:2 * H]); db2n += buf['GN'].sum(0)
-        dW_in.addmm_(G1.t(), buf['Z']); db_in += G1.sum(0)
-        _call('mdmm_stage_adj_reduce', C.byref(st), tag='stage_adj_reduce' + tag)
-    g_z0m = buf['GZ0'][0].sum(0) + buf['GZF'][0].sum(0)
-    g_z0s = buf['GZ0'][1].sum(0) + buf['GZF'][1].sum(0)
-    grads = [dW_in[:H], db_in[:H], dW2g, db2g, dW_in[2 * H:], db_in[2 * H:],
-             dW_in[H:2 * H], db_in[H:2 * H], dW2n, db2n, dWs, dbs]
-    return [g.contiguous() for g in grads], g_z0m, g_z0s
-
-
 def _fold_passes(g, bits, per_pass, n_pass):
     """(P,T,B,D) per-pass gradient slabs of one expert -> gradient of its input: the slabs of the
     passes it took part in are summed (shared (T,B,D) input) or kept (per-pass input, the slabs of
@@ -451,8 +348,7 @@ class _SweepFn(torch.autograd.Function):
             raise native.MdmmError('too many experts / passes for one sweep')
         dev = z0_mean.device
         wide = wide_shape(cfg)
-        staged = _use_staged(cfg)
-        packed = None if staged else packed_gtf(gtf_params, cfg.D, cfg.H)
+        packed = packed_gtf(gtf_params, cfg.D, cfg.H)
         frag = packed_frag(gtf_params, cfg.D, cfg.H, PRECISIONS[cfg.precision]) if wide else None
         z0m, z0s = _f32c(z0_mean.detach().reshape(-1)), _f32c(z0_log_std.detach().reshape(-1))
         shape = (cfg.P, cfg.T, cfg.B, cfg.D)
@@ -470,18 +366,14 @@ class _SweepFn(torch.autograd.Function):
         s.infer_mean, s.infer_std, s.prior_mean, s.prior_std = [_ptr(o) for o in out]
         s.samples = _ptr(smp)
         if wide:
-            if packed is None:      # the entry point checks the fp32 pack too (generic fallback)
-                packed_gtf(gtf_params, cfg.D, cfg.H).fill(s.gtf)
             s.gtf_frag, s.precision = _ptr(frag.buf), frag.precision
             if not native.lib().mdmm_sweep_wide(C.byref(s)):
                 raise native.MdmmError('wide sweep refused a shape wide_shape() accepted')
             _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('wide_fwd', cfg))
-        elif staged:
-            _staged_fwd(cfg, s, gtf_params)
         else:
             _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('fwd', cfg))
         ctx.cfg, ctx.eps, ctx.masks, ctx.bits, ctx.per_pass = cfg, eps, masks, bits, per_pass
-        ctx.packed, ctx.n_exp, ctx.staged = packed, n_exp, staged
+        ctx.packed, ctx.n_exp = packed, n_exp
         ctx.frag = frag if wide and wide_shape(cfg, bwd=True) else None
         ctx.gtf_like = [p.detach() for p in gtf_params]
         ctx.save_for_backward(z0m, z0s, out[0], out[1], out[2], out[3], *means, *stds)
@@ -529,8 +421,6 @@ class _SweepFn(torch.autograd.Function):
         s.g_z0_mean, s.g_z0_sigma = gz0[0].data_ptr(), gz0[1].data_ptr()
         G = X = part = None
         if ctx.frag is not None:                        # wide family: spills + own contraction
-            if packed is None:
-                packed_gtf(ctx.gtf_like, cfg.D, cfg.H).fill(s.gtf)
             s.gtf_frag, s.precision = _ptr(ctx.frag.buf), ctx.frag.precision
             assert L.mdmm_sweep_bwd_mode(C.byref(s)) == 2
             ws = torch.empty(L.mdmm_sweep_wide_ws_bytes(C.byref(s)), device=dev, dtype=torch.uint8)
@@ -539,9 +429,6 @@ class _SweepFn(torch.autograd.Function):
             s.dw_partial, s.dw_partial_rows = _ptr(part), 1
             _call('mdmm_bfvi_sweep_bwd', C.byref(s), tag=_sweep_tag('wide_bwd', cfg))
             g_gtf, g0m, g0s = unpack_dw_partials(part, cfg.D, cfg.H, ctx.gtf_like)
-            gz0 = torch.stack([g0m, g0s])
-        elif ctx.staged:                                # stage-wise reverse scan (large z)
-            g_gtf, g0m, g0s = _staged_bwd(cfg, s, ctx.gtf_like)
             gz0 = torch.stack([g0m, g0s])
         elif L.mdmm_sweep_bwd_mode(C.byref(s)) == 1:    # weight gradients accumulated in-kernel
             n_rows = L.mdmm_sweep_dw_rows(C.byref(s))
@@ -553,7 +440,7 @@ class _SweepFn(torch.autograd.Function):
                 G = torch.empty(rows, L.mdmm_sweep_spill_width_g(cfg.D, cfg.H), device=dev)
                 X = torch.empty(rows, L.mdmm_sweep_spill_width_x(cfg.D, cfg.H), device=dev)
                 s.spill_g, s.spill_x, s.spill_rows = _ptr(G), _ptr(X), rows
-        if not ctx.staged and ctx.frag is None:
+        if ctx.frag is None:
             _call('mdmm_bfvi_sweep_bwd', C.byref(s), tag=_sweep_tag('bwd', cfg))
             if part is not None:
                 g_gtf, g0m, g0s = unpack_dw_partials(part, cfg.D, cfg.H, ctx.gtf_like)

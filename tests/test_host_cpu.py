@@ -197,7 +197,8 @@ def test_gtf_packing_and_grad_unpacking_roundtrip():
         G[:, F1:F1 + D] = g_ag; G[:, F1 + Dp:F1 + Dp + D] = g_nl; G[:, F1 + 2 * Dp:F1 + 2 * Dp + D] = g_pre
         X[:, :D] = z; X[:, Dp:Dp + H] = h1; X[:, Dp + Hp:Dp + Hp + H] = h2
         X[:, Dp + 2 * Hp:Dp + 2 * Hp + D] = nl
-        got = pk.unpack_grads(G.detach(), X.detach(), params)
+        ref_contract = lambda G_, g0, gc, X_, x0, xc: G_[:, g0:g0 + gc].t() @ X_[:, x0:x0 + xc]  # noqa: E731
+        got = pk.unpack_grads(G.detach(), X.detach(), params, contract=ref_contract)
         want = torch.autograd.grad(loss, params)
         for a, b in zip(got, want):
             assert helpers.rel_err(a, b) < 1e-5
