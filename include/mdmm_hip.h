@@ -36,7 +36,7 @@ extern "C" {
 int mdmm_version(void);
 const char* mdmm_strerror(int code);
 /* sizeof() of an argument struct as the library was compiled, for a binding to check its own
- * declaration against at load time: 0 gtf, 1 expert, 2 sweep, 4 gru, 5 dks, 6 mlp; 0 if unknown */
+ * declaration against at load time: 0 gtf, 1 expert, 2 sweep, 4 gru, 5 dks, 6 mlp, 7 bn; 0 if unknown */
 size_t mdmm_sizeof(int which);
 /* round n up to the padded width the packed weights use (multiple of 4) */
 int mdmm_pad(int n);
@@ -395,6 +395,31 @@ int mdmm_gauss_mlp_dw_width(int I, int H, int O);
 int64_t mdmm_gauss_mlp_dw_rows(int64_t N);
 int mdmm_gauss_mlp_fwd(const mdmm_mlp_t* a, void* stream);
 int mdmm_gauss_mlp_bwd(const mdmm_mlp_t* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm + ReLU of the conv plug-ins (common.py:80-84, 103-107: Conv2d /
+ * ConvTranspose2d / Conv1d -> BatchNorm -> ReLU), torch.nn.BatchNorm{1,2}d semantics: x, y, dy, dx
+ * are (N, C, L) fp32 contiguous with L = H*W; batch statistics over (N, L) per channel, biased
+ * variance for the normalisation, running_mean / running_var (may be NULL) updated with `momentum`
+ * and the unbiased variance.  relu != 0 applies max(0, .) to the output and the matching mask in
+ * the backward pass (re-derived from x: neither the normalised tensor nor a mask is stored).
+ * partial: workspace of C * splits * 2 doubles (mdmm_bn_splits gives a good `splits`).
+ * Forward writes y, save_mean, save_invstd (C each); backward reads them and writes dx, dgamma,
+ * dbeta (the last two may be NULL).  */
+typedef struct mdmm_bn {
+  int64_t N, L;
+  int32_t C, relu, splits, reserved;
+  float eps, momentum;
+  const float *x, *gamma, *beta;          /* gamma / beta NULL = 1 / 0 */
+  float *running_mean, *running_var;
+  float *y, *save_mean, *save_invstd;
+  const float* dy;
+  float *dx, *dgamma, *dbeta;
+  double* partial;
+} mdmm_bn_t;
+int mdmm_bn_splits(int64_t N, int C, int64_t L);
+int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream);
+int mdmm_bn_relu_bwd(const mdmm_bn_t* a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,289 @@
+// Training-mode BatchNorm (+ ReLU) of the conv plug-ins (common.py:80-84: Conv2d / ConvTranspose2d
+// -> BatchNorm2d -> ReLU, and the 1-d audio twins) as two streaming passes each way over the
+// (N, C, L) fp32 activations, L = H*W: HBM-bound, every element read twice forward (statistics,
+// normalise) and written once; backward reads (dy, x) twice and writes dx once.  The ReLU is
+// folded in: its mask is re-derived from x, so neither the normalised tensor nor the mask exist.
+//   grid = (C, S): workgroup (c, s) streams images [s*per, (s+1)*per) of channel c -- contiguous
+//   L-element rows, 16-byte loads when L % 4 == 0 -- and leaves a partial (sum, sum of squares) /
+//   (sum g, sum g*xhat); the apply kernels fold the S partials of their channel in fp64.
+#include "mdmm_device.h"
+#include "../../include/mdmm_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
+  a = mdmm::wave_sum_d(a); b = mdmm::wave_sum_d(b);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh[2 * w] = a; sh[2 * w + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0, sb = 0;
+    for (int i = 0; i < NT / 64; ++i) { sa += sh[2 * i]; sb += sh[2 * i + 1]; }
+    sh[0] = sa; sh[1] = sb;
+  }
+  __syncthreads();
+  a = sh[0]; b = sh[1];
+  __syncthreads();
+}
+
+struct Span { int64_t n_lo, n_hi; };
+__device__ __forceinline__ Span span_of(int64_t N) {
+  const int64_t per = (N + gridDim.y - 1) / gridDim.y;
+  Span s; s.n_lo = blockIdx.y * per; s.n_hi = s.n_lo + per < N ? s.n_lo + per : N;
+  return s;
+}
+
+// ---- forward ------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ x, int64_t N, int C,
+                                                      int64_t L, double* __restrict__ partial) {
+  __shared__ double sh[2 * NT / 64];
+  const int c = blockIdx.x;
+  const Span sp = span_of(N);
+  float s1 = 0.f, s2 = 0.f;
+  double d1 = 0, d2 = 0;
+  int cnt = 0;
+  if (VEC) {
+    const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
+    for (int64_t i = threadIdx.x; i < tot; i += NT) {
+      const int64_t n = sp.n_lo + i / L4, l = i % L4;
+      const float4 v = reinterpret_cast<const float4*>(x + (n * C + c) * L)[l];
+      s1 += (v.x + v.y) + (v.z + v.w);
+      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      if (++cnt == 256) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }   // short fp32 runs only
+    }
+  } else {
+    const int64_t tot = (sp.n_hi - sp.n_lo) * L;
+    for (int64_t i = threadIdx.x; i < tot; i += NT) {
+      const int64_t n = sp.n_lo + i / L, l = i % L;
+      const float v = x[(n * C + c) * L + l];
+      s1 += v; s2 += v * v;
+      if (++cnt == 1024) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
+    }
+  }
+  d1 += s1; d2 += s2;
+  block_sum2(d1, d2, sh);
+  if (threadIdx.x == 0) {
+    partial[((size_t)c * gridDim.y + blockIdx.y) * 2] = d1;
+    partial[((size_t)c * gridDim.y + blockIdx.y) * 2 + 1] = d2;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, int64_t N, int C,
+                                                      int64_t L, const double* __restrict__ partial,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, int relu,
+                                                      float momentum, float* running_mean,
+                                                      float* running_var, float* __restrict__ y,
+                                                      float* save_mean, float* save_invstd) {
+  const int c = blockIdx.x;
+  double d1 = 0, d2 = 0;
+  for (int s = 0; s < (int)gridDim.y; ++s) {
+    d1 += partial[((size_t)c * gridDim.y + s) * 2];
+    d2 += partial[((size_t)c * gridDim.y + s) * 2 + 1];
+  }
+  const double M = (double)N * (double)L;
+  const double mean = d1 / M;
+  double var = d2 / M - mean * mean;            // biased (normalisation)
+  if (var < 0) var = 0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
+    save_mean[c] = (float)mean; save_invstd[c] = invstd;
+    if (running_mean) {                          // torch: unbiased variance into the running stat
+      const double unb = M > 1 ? var * M / (M - 1) : var;
+      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+  const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+  const float scale = g * invstd, shift = b - (float)mean * scale;
+  const Span sp = span_of(N);
+  if (VEC) {
+    const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
+    for (int64_t i = threadIdx.x; i < tot; i += NT) {
+      const int64_t n = sp.n_lo + i / L4, l = i % L4;
+      const float4 v = reinterpret_cast<const float4*>(x + (n * C + c) * L)[l];
+      float4 o;
+      o.x = fmaf(v.x, scale, shift); o.y = fmaf(v.y, scale, shift);
+      o.z = fmaf(v.z, scale, shift); o.w = fmaf(v.w, scale, shift);
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      reinterpret_cast<float4*>(y + (n * C + c) * L)[l] = o;
+    }
+  } else {
+    const int64_t tot = (sp.n_hi - sp.n_lo) * L;
+    for (int64_t i = threadIdx.x; i < tot; i += NT) {
+      const int64_t n = sp.n_lo + i / L, l = i % L;
+      float o = fmaf(x[(n * C + c) * L + l], scale, shift);
+      if (relu) o = fmaxf(o, 0.f);
+      y[(n * C + c) * L + l] = o;
+    }
+  }
+}
+
+// ---- backward -----------------------------------------------------------------------------
+// g = dy * [bn(x) > 0] (with ReLU);  partial = (sum g, sum g * xhat)
+template <bool VEC>
+__global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restrict__ dy,
+                                                          const float* __restrict__ x, int64_t N, int C,
+                                                          int64_t L, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ save_mean,
+                                                          const float* __restrict__ save_invstd, int relu,
+                                                          double* __restrict__ partial) {
+  __shared__ double sh[2 * NT / 64];
+  const int c = blockIdx.x;
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  const float g_ = gamma ? gamma[c] : 1.0f, b_ = beta ? beta[c] : 0.0f;
+  const float scale = g_ * invstd, shift = b_ - mean * scale;     // as the forward pass forms them
+  const Span sp = span_of(N);
+  float s1 = 0.f, s2 = 0.f;
+  double d1 = 0, d2 = 0;
+  int cnt = 0;
+  auto acc = [&](float dyv, float xv) {
+    const float xh = (xv - mean) * invstd;
+    const float gv = (relu && fmaf(xv, scale, shift) <= 0.f) ? 0.f : dyv;
+    s1 += gv; s2 = fmaf(gv, xh, s2);
+  };
+  if (VEC) {
+    const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
+    for (int64_t i = threadIdx.x; i < tot; i += NT) {
+      const int64_t n = sp.n_lo + i / L4, l = i % L4;
+      const float4 v = reinterpret_cast<const float4*>(x + (n * C + c) * L)[l];
+      const float4 d = reinterpret_cast<const float4*>(dy + (n * C + c) * L)[l];
+      acc(d.x, v.x); acc(d.y, v.y); acc(d.z, v.z); acc(d.w, v.w);
+      if (++cnt == 256) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
+    }
+  } else {
+    const int64_t tot = (sp.n_hi - sp.n_lo) * L;
+    for (int64_t i = threadIdx.x; i < tot; i += NT) {
+      const int64_t n = sp.n_lo + i / L, l = i % L;
+      acc(dy[(n * C + c) * L + l], x[(n * C + c) * L + l]);
+      if (++cnt == 1024) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
+    }
+  }
+  d1 += s1; d2 += s2;
+  block_sum2(d1, d2, sh);
+  if (threadIdx.x == 0) {
+    partial[((size_t)c * gridDim.y + blockIdx.y) * 2] = d1;
+    partial[((size_t)c * gridDim.y + blockIdx.y) * 2 + 1] = d2;
+  }
+}
+
+// dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));  d gamma = sum g xhat, d beta = sum g
+template <bool VEC>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ dy,
+                                                          const float* __restrict__ x, int64_t N, int C,
+                                                          int64_t L, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ save_mean,
+                                                          const float* __restrict__ save_invstd, int relu,
+                                                          const double* __restrict__ partial,
+                                                          float* __restrict__ dx, float* dgamma,
+                                                          float* dbeta) {
+  const int c = blockIdx.x;
+  double d1 = 0, d2 = 0;
+  for (int s = 0; s < (int)gridDim.y; ++s) {
+    d1 += partial[((size_t)c * gridDim.y + s) * 2];
+    d2 += partial[((size_t)c * gridDim.y + s) * 2 + 1];
+  }
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
+    if (dgamma) dgamma[c] = (float)d2;
+    if (dbeta) dbeta[c] = (float)d1;
+  }
+  const double M = (double)N * (double)L;
+  const float mg = (float)(d1 / M), mgx = (float)(d2 / M);
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  const float g_ = gamma ? gamma[c] : 1.0f, b_ = beta ? beta[c] : 0.0f;
+  const float k = g_ * invstd, shift = b_ - mean * k;
+  const Span sp = span_of(N);
+  auto one = [&](float dyv, float xv) {
+    const float xh = (xv - mean) * invstd;
+    const float gv = (relu && fmaf(xv, k, shift) <= 0.f) ? 0.f : dyv;
+    return k * (gv - mg - xh * mgx);
+  };
+  if (VEC) {
+    const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
+    for (int64_t i = threadIdx.x; i < tot; i += NT) {
+      const int64_t n = sp.n_lo + i / L4, l = i % L4;
+      const float4 v = reinterpret_cast<const float4*>(x + (n * C + c) * L)[l];
+      const float4 d = reinterpret_cast<const float4*>(dy + (n * C + c) * L)[l];
+      float4 o;
+      o.x = one(d.x, v.x); o.y = one(d.y, v.y); o.z = one(d.z, v.z); o.w = one(d.w, v.w);
+      reinterpret_cast<float4*>(dx + (n * C + c) * L)[l] = o;
+    }
+  } else {
+    const int64_t tot = (sp.n_hi - sp.n_lo) * L;
+    for (int64_t i = threadIdx.x; i < tot; i += NT) {
+      const int64_t n = sp.n_lo + i / L, l = i % L;
+      dx[(n * C + c) * L + l] = one(dy[(n * C + c) * L + l], x[(n * C + c) * L + l]);
+    }
+  }
+}
+
+bool vec_ok(const mdmm_bn_t* a) {
+  return a->L % 4 == 0 && !(((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->dy | (uintptr_t)a->dx) & 15);
+}
+
+int check(const mdmm_bn_t* a) {
+  if (!a || a->N < 1 || a->C < 1 || a->L < 1 || !a->x || !a->partial || !a->save_mean || !a->save_invstd)
+    return MDMM_E_ARG;
+  if (a->splits < 1 || a->splits > 65535) return MDMM_E_ARG;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mdmm_bn_splits(int64_t N, int C, int64_t L) {
+  // ~8 workgroups per CU, at least ~64 KB of a channel per workgroup
+  int64_t s = (2048 + C - 1) / C;
+  const int64_t cap = (N * L * 4 + 65535) / 65536;
+  if (s > cap) s = cap;
+  if (s > N) s = N;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+extern "C" int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream) {
+  int rc = check(a);
+  if (rc) return rc;
+  if (!a->y) return MDMM_E_ARG;
+  const dim3 grid(a->C, a->splits);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(a)) {
+    hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial);
+    hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial,
+                       a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
+                       a->y, a->save_mean, a->save_invstd);
+  } else {
+    hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial);
+    hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial,
+                       a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
+                       a->y, a->save_mean, a->save_invstd);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int mdmm_bn_relu_bwd(const mdmm_bn_t* a, void* stream) {
+  int rc = check(a);
+  if (rc) return rc;
+  if (!a->dy || !a->dx) return MDMM_E_ARG;
+  const dim3 grid(a->C, a->splits);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec_ok(a)) {
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<true>, grid, dim3(NT), 0, st, a->dy, a->x, a->N, a->C, a->L,
+                       a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(NT), 0, st, a->dy, a->x, a->N, a->C, a->L,
+                       a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial, a->dx,
+                       a->dgamma, a->dbeta);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<false>, grid, dim3(NT), 0, st, a->dy, a->x, a->N, a->C, a->L,
+                       a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(NT), 0, st, a->dy, a->x, a->N, a->C, a->L,
+                       a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial, a->dx,
+                       a->dgamma, a->dbeta);
+  }
+  return (int)hipGetLastError();
+}

@@ -76,6 +76,7 @@ extern "C" size_t mdmm_sizeof(int which) {
     case 4: return sizeof(mdmm_gru_t);
     case 5: return sizeof(mdmm_dks_t);
     case 6: return sizeof(mdmm_mlp_t);
+    case 7: return sizeof(mdmm_bn_t);
     default: return 0;
   }
 }

@@ -6,8 +6,9 @@ ways).  GaussianMLP / CategoricalMLP / GaussianGTF are also callable as plain mo
 (stock PyTorch-ROCm ops on the GPU) because encoders and decoders are user-pluggable
 modules on the far side of the kernel boundary; inside the BFVI sweep the GTF weights
 are consumed by the HIP kernels directly (mdmm.ops.PackedGtf) and this forward is not
-used.  The conv stacks mirror common.py:70-290 and always run as ordinary PyTorch
-modules (MIOpen) -- they are out of scope for hand-written kernels.
+used.  The conv stacks mirror common.py:70-290: the convolutions themselves run as ordinary
+PyTorch modules (MIOpen); the BatchNorm + ReLU behind each of them is fused into two streaming
+passes each way (csrc/batchnorm.hip) when the module trains on the GPU in fp32.
 """
 import torch
 import torch.nn as nn
@@ -93,6 +94,15 @@ class _ConvBlock(nn.Module):
         nn.init.xavier_uniform_(layer.weight)
 
     def forward(self, x):
+        if isinstance(self.net, nn.Sequential):
+            y = self.net[0](x)
+            bn = self.net[1]
+            # BatchNorm + ReLU in training mode: two fused streaming passes each way
+            # (csrc/batchnorm.hip) instead of the library's norm kernels + a ReLU pass
+            from .. import ops
+            if ops.batchnorm_relu_supported(y, bn):
+                return ops.batchnorm_relu(y, bn)
+            return self.net[2](bn(y))
         return self.net(x)
 
 

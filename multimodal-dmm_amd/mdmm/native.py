@@ -30,6 +30,7 @@ SYMBOLS = [
     'mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd', 'mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd',
     'mdmm_gauss_mlp_supported', 'mdmm_gauss_mlp_dw_width', 'mdmm_gauss_mlp_dw_rows',
     'mdmm_gauss_mlp_fwd', 'mdmm_gauss_mlp_bwd',
+    'mdmm_bn_splits', 'mdmm_bn_relu_fwd', 'mdmm_bn_relu_bwd',
 ]
 
 _P = C.c_void_p
@@ -94,6 +95,14 @@ class Mlp(C.Structure):
                 [('dw_partial_rows', C.c_int64), ('nll_target', _P), ('nll_mask', _P),
                  ('nll_rows', C.c_int64), ('nll_out', _P), ('nll_scale_dev', _P),
                  ('nll_weight', C.c_float), ('reserved2', C.c_int32)])
+
+
+class Bn(C.Structure):
+    _fields_ = ([('N', C.c_int64), ('L', C.c_int64)] +
+                [(n, C.c_int32) for n in ('C', 'relu', 'splits', 'reserved')] +
+                [('eps', C.c_float), ('momentum', C.c_float)] +
+                [(n, _P) for n in ('x', 'gamma', 'beta', 'running_mean', 'running_var', 'y', 'save_mean',
+                                   'save_invstd', 'dy', 'dx', 'dgamma', 'dbeta', 'partial')])
 
 
 class MdmmError(RuntimeError):
@@ -166,9 +175,12 @@ def lib():
         L.mdmm_gauss_mlp_dw_rows.restype = C.c_int64
         L.mdmm_gauss_mlp_fwd.argtypes = [C.POINTER(Mlp), _P]
         L.mdmm_gauss_mlp_bwd.argtypes = [C.POINTER(Mlp), _P]
+        L.mdmm_bn_splits.argtypes = [C.c_int64, C.c_int, C.c_int64]
+        L.mdmm_bn_relu_fwd.argtypes = [C.POINTER(Bn), _P]
+        L.mdmm_bn_relu_bwd.argtypes = [C.POINTER(Bn), _P]
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
-        for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp)):
+        for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp), (7, Bn)):
             if L.mdmm_sizeof(which) != C.sizeof(st):
                 raise MdmmError('struct %s: library %d bytes, binding %d bytes'
                                 % (st.__name__, L.mdmm_sizeof(which), C.sizeof(st)))

@@ -866,6 +866,73 @@ def tall_linear(x, layer):
 # ------------------------------------------------------------------------------------
 # MultiDKS recurrences
 # ------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------
+# BatchNorm + ReLU of the conv plug-ins (csrc/batchnorm.hip)
+# ------------------------------------------------------------------------------------
+class _BnReluFn(torch.autograd.Function):
+    """Training-mode nn.BatchNorm{1,2}d followed by ReLU on (N, C, ...) fp32: two streaming passes
+    each way; updates the module's running statistics exactly as the stock module does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, relu):
+        ctx.set_materialize_grads(False)
+        _need_gpu(x)
+        x = _f32c(x)
+        N, Cc = x.shape[0], x.shape[1]
+        Ln = x[0, 0].numel()
+        a = native.Bn()
+        a.N, a.C, a.L, a.relu = N, Cc, Ln, int(relu)
+        a.splits = native.lib().mdmm_bn_splits(N, Cc, Ln)
+        a.eps = bn.eps
+        y = torch.empty_like(x)
+        stats = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
+        part = torch.empty(Cc * a.splits * 2, device=x.device, dtype=torch.float64)
+        g = None if gamma is None else _f32c(gamma.detach())
+        b = None if beta is None else _f32c(beta.detach())
+        a.x, a.gamma, a.beta, a.y = _ptr(x), _ptr(g), _ptr(b), _ptr(y)
+        a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
+        if bn.track_running_stats and bn.running_mean is not None:
+            bn.num_batches_tracked.add_(1)
+            # momentum None = cumulative average (torch: 1 / num_batches_tracked)
+            a.momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            a.running_mean, a.running_var = _ptr(bn.running_mean), _ptr(bn.running_var)
+        _call('mdmm_bn_relu_fwd', C.byref(a))
+        ctx.save_for_backward(x, stats, g, b)
+        ctx.meta = (N, Cc, Ln, int(relu), a.splits, bn.eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None, None, None
+        x, stats, g, b = ctx.saved_tensors
+        N, Cc, Ln, relu, splits, eps = ctx.meta
+        dy = _f32c(dy)
+        a = native.Bn()
+        a.N, a.C, a.L, a.relu, a.splits, a.eps = N, Cc, Ln, relu, splits, eps
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
+        part = torch.empty(Cc * splits * 2, device=x.device, dtype=torch.float64)
+        a.x, a.gamma, a.beta, a.dy, a.dx = _ptr(x), _ptr(g), _ptr(b), _ptr(dy), _ptr(dx)
+        a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
+        a.dgamma, a.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
+        _call('mdmm_bn_relu_bwd', C.byref(a))
+        return (dx, dgb[0] if ctx.needs_input_grad[1] else None,
+                dgb[1] if ctx.needs_input_grad[2] else None, None, None)
+
+
+def batchnorm_relu_supported(x, bn):
+    """The fused kernels take what the conv plug-ins hand them in training: fp32 on the GPU, batch
+    statistics (module in training mode), affine or not."""
+    return (x.is_cuda and x.dtype == torch.float32 and bn.training and x.dim() >= 3
+            and not torch.is_autocast_enabled())
+
+
+def batchnorm_relu(x, bn, relu=True):
+    """nn.Sequential(bn, nn.ReLU())(x) for a BatchNorm1d / BatchNorm2d holder in training mode."""
+    return _BnReluFn.apply(x, bn.weight, bn.bias, bn, relu)
+
+
 class _GaussMlpFn(torch.autograd.Function):
     """GaussianMLP holder in one launch each way (csrc/mlp.hip).  Only x is saved; the backward
     recomputes the hidden layer.  Returns (mean, std, seen); seen (N,) is 1.0 where the row holds

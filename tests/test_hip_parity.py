@@ -15,6 +15,7 @@ dec.b.in_to_h of golden case z5, where every other tensor agrees to 1e-4..1e-7.)
 import numpy as np
 import pytest
 import torch
+import torch.nn as nn
 
 from helpers import (FlatGaussEnc, Golden, ShapedBernoulliDec, make_inputs, rel_err)
 from oracle import mdmm_oracle as orc
@@ -953,3 +954,31 @@ def test_eval_forward_200_particles(dims, dev, kernel_family):
     close(prior[0], op[0], what='prior mean'); close(prior[1], op[1], what='prior std')
     close(m.kld_loss(infer, prior, mask.to(dev)), o.kld_loss(oi, op, mask), TOL_LOSS, 'kld')
     close(m.rec_loss(cuda(x, dev), recon, mask.to(dev), {}), o.rec_loss(x, orec, mask, {}), TOL_LOSS, 'rec')
+
+
+@pytest.mark.parametrize('shape', [(24, 16, 32, 32), (13, 32, 16, 16), (9, 8, 641), (5, 4, 7, 9)])
+def test_batchnorm_relu_matches_torch(dev, kernel_family, shape):
+    """csrc/batchnorm.hip against nn.BatchNorm{1,2}d + ReLU in training mode (common.py:80-84):
+    output, input / affine gradients, running statistics after two batches."""
+    if kernel_family == 'generic':
+        pytest.skip('no sweep involved')
+    from mdmm import ops
+    torch.manual_seed(3)
+    cls = nn.BatchNorm2d if len(shape) == 4 else nn.BatchNorm1d
+    ref, got = cls(shape[1]).to(dev), cls(shape[1]).to(dev)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5); ref.bias.normal_(0, 0.3)
+    got.load_state_dict(ref.state_dict())
+    for it in range(2):
+        x = (torch.randn(*shape, device=dev) * 1.7 + 0.4)
+        xr, xg = x.clone().requires_grad_(), x.clone().requires_grad_()
+        w = torch.randn(*shape, device=dev)
+        yr = torch.relu(ref(xr)); (yr * w).sum().backward()
+        assert ops.batchnorm_relu_supported(xg, got)
+        yg = ops.batchnorm_relu(xg, got); (yg * w).sum().backward()
+        close(yg, yr, 2e-5, 'bn out'); close(xg.grad, xr.grad, 1e-4, 'bn dx')
+        close(got.weight.grad, ref.weight.grad, 1e-4, 'bn dgamma'); close(got.bias.grad, ref.bias.grad, 1e-4, 'bn dbeta')
+        ref.zero_grad(); got.zero_grad()
+    close(got.running_mean, ref.running_mean, 1e-5, 'running mean')
+    close(got.running_var, ref.running_var, 1e-5, 'running var')
+    assert int(got.num_batches_tracked) == int(ref.num_batches_tracked) == 2
