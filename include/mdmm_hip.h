@@ -253,6 +253,17 @@ int mdmm_nll_bernoulli_fwd(const float* theta, const float* x, const float* seq_
 int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const float* seq_mask,
                            int64_t rows, int inner, float scale, const float* scale_dev,
                            float* g_theta, void* stream);
+/* the same with the decoder's final nn.Sigmoid (common.py:163-165) folded in: `logits` are the
+ * pre-sigmoid activations, theta = sigmoid(logits) is formed in registers with the arithmetic the
+ * stock modules use (value and -100 clamp identical); the backward returns d/d logits.  */
+int mdmm_nll_bernoulli_logits_fwd(const float* logits, const float* x, const float* seq_mask,
+                                  int64_t rows, int inner, float weight, double* out, void* stream);
+int mdmm_nll_bernoulli_logits_bwd(const float* logits, const float* x, const float* seq_mask,
+                                  int64_t rows, int inner, float scale, const float* scale_dev,
+                                  float* g_logits, void* stream);
+/* NaN -> 0 and the per-row "seen" flag of MultiDMM.encode (dmm.py:164-166) in one pass:
+ * out[r][i] = isnan(x[r][i]) ? 0 : x[r][i];  seen[r] = no NaN in row r  (float 0 / 1).  */
+int mdmm_nan_to_zero(const float* x, int64_t rows, int inner, float* out, float* seen, void* stream);
 /* losses.py:44-66 nll_categorical: reference behaviour = minus the summed PROBABILITY of
  * the observed class (F.nll_loss on probs).  probs (rows, n_cat), x (rows) labels as
  * float (NaN = missing).  */

@@ -111,6 +111,12 @@ __global__ __launch_bounds__(NT) void nllg_bwd_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------- nll_bernoulli ----
+// LOGITS: `theta` holds the pre-sigmoid activations of the decoder; theta = 1 / (1 + exp(-l)) is
+// formed in registers exactly as nn.Sigmoid would have stored it (so the value, including the
+// -100 clamp on saturated pixels, is the reference's), but it never travels through HBM.
+__device__ __forceinline__ float sigmoid_ref(float l) { return 1.0f / (1.0f + expf(-l)); }
+
+template <bool LOGITS>
 __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
     float weight, double* out) {
@@ -123,10 +129,12 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ 
       if (mask && mask[i / inner4] == 0.f) continue;
       const float4 xv = reinterpret_cast<const float4*>(x)[i];
       const float4 th = reinterpret_cast<const float4*>(theta)[i];
-      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ts[4] = {th.x, th.y, th.z, th.w};
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      float ts[4] = {th.x, th.y, th.z, th.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (xs[j] != xs[j]) continue;
+        if (LOGITS) ts[j] = sigmoid_ref(ts[j]);
         const float l1 = fmaxf(logf(ts[j]), -100.0f), l0 = fmaxf(log1pf(-ts[j]), -100.0f);
         acc -= xs[j] * l1 + (1.0f - xs[j]) * l0;              // F.binary_cross_entropy
       }
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ 
       const float xv = x[i];
       if (xv != xv) continue;
       if (mask && mask[i / inner] == 0.f) continue;
-      const float th = theta[i];
+      const float th = LOGITS ? sigmoid_ref(theta[i]) : theta[i];
       const float l1 = fmaxf(logf(th), -100.0f), l0 = fmaxf(log1pf(-th), -100.0f);
       acc -= xv * l1 + (1.0f - xv) * l0;
     }
@@ -144,6 +152,7 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ 
   block_add((double)weight * (double)acc, out);
 }
 
+template <bool LOGITS>
 __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const float* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
     float scale, const float* __restrict__ scale_dev, float* g_theta) {
@@ -152,8 +161,9 @@ __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const float* __restrict__ 
     const float xv = x[i];
     float g = 0.f;
     if (xv == xv && !(mask && mask[i / inner] == 0.f)) {
-      const float th = theta[i];
+      const float th = LOGITS ? sigmoid_ref(theta[i]) : theta[i];
       g = scale * (th - xv) / fmaxf((1.0f - th) * th, 1e-12f);   // torch BCE backward
+      if (LOGITS) g *= (1.0f - th) * th;                           // torch sigmoid backward
     }
     g_theta[i] = g;
   }
@@ -278,6 +288,41 @@ __global__ __launch_bounds__(NT) void philox_kernel(uint64_t seed, uint64_t offs
     out[i] = philox_normal(seed, offset, (uint64_t)i);
 }
 
+// ---------------------------------------------------------------- NaN -> 0 + seen ----
+// one workgroup per row (t, b): inputs of the image / audio encoders (dmm.py:164-166)
+__global__ __launch_bounds__(NT) void nan_to_zero_kernel(const float* __restrict__ x, int64_t rows,
+                                                         int inner, float* __restrict__ out,
+                                                         float* __restrict__ seen) {
+  __shared__ int any_nan;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    if (threadIdx.x == 0) any_nan = 0;
+    __syncthreads();
+    const float* xr = x + r * inner;
+    float* orow = out + r * inner;
+    bool bad = false;
+    if ((inner & 3) == 0 && !(((uintptr_t)xr | (uintptr_t)orow) & 15)) {
+      for (int i = threadIdx.x; i < inner / 4; i += NT) {
+        float4 v = reinterpret_cast<const float4*>(xr)[i];
+        if (v.x != v.x) { v.x = 0.f; bad = true; }
+        if (v.y != v.y) { v.y = 0.f; bad = true; }
+        if (v.z != v.z) { v.z = 0.f; bad = true; }
+        if (v.w != v.w) { v.w = 0.f; bad = true; }
+        reinterpret_cast<float4*>(orow)[i] = v;
+      }
+    } else {
+      for (int i = threadIdx.x; i < inner; i += NT) {
+        float v = xr[i];
+        if (v != v) { v = 0.f; bad = true; }
+        orow[i] = v;
+      }
+    }
+    if (bad) any_nan = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) seen[r] = any_nan ? 0.f : 1.f;
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 #define STREAM ((hipStream_t)stream)
@@ -330,8 +375,28 @@ extern "C" int mdmm_nll_bernoulli_fwd(const float* theta, const float* x, const 
                                       void* stream) {
   if (!theta || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
-  hipLaunchKernelGGL(nllb_fwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, theta, x,
+  hipLaunchKernelGGL(nllb_fwd_kernel<false>, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, theta, x,
                      seq_mask, n, inner, weight, out);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_bernoulli_logits_fwd(const float* logits, const float* x, const float* seq_mask,
+                                             int64_t rows, int inner, float weight, double* out,
+                                             void* stream) {
+  if (!logits || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  hipLaunchKernelGGL(nllb_fwd_kernel<true>, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, logits, x,
+                     seq_mask, n, inner, weight, out);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_bernoulli_logits_bwd(const float* logits, const float* x, const float* seq_mask,
+                                             int64_t rows, int inner, float scale,
+                                             const float* scale_dev, float* g_logits, void* stream) {
+  if (!logits || !x || !g_logits || rows < 0 || inner < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  hipLaunchKernelGGL(nllb_bwd_kernel<true>, dim3(grid_for(n)), dim3(NT), 0, STREAM, logits, x, seq_mask,
+                     n, inner, scale, scale_dev, g_logits);
   CHECK_LAUNCH();
 }
 
@@ -340,7 +405,7 @@ extern "C" int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const 
                                       const float* scale_dev, float* g_theta, void* stream) {
   if (!theta || !x || !g_theta || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
-  hipLaunchKernelGGL(nllb_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, STREAM, theta, x, seq_mask,
+  hipLaunchKernelGGL(nllb_bwd_kernel<false>, dim3(grid_for(n)), dim3(NT), 0, STREAM, theta, x, seq_mask,
                      n, inner, scale, scale_dev, g_theta);
   CHECK_LAUNCH();
 }
@@ -485,4 +550,13 @@ extern "C" const char* mdmm_strerror(int code) {
   if (code == MDMM_E_ALIGN) return "mdmm: packed weight buffers must be 16-byte aligned";
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "mdmm: unknown error";
+}
+
+extern "C" int mdmm_nan_to_zero(const float* x, int64_t rows, int inner, float* out, float* seen,
+                                void* stream) {
+  if (!x || !out || !seen || rows < 0 || inner < 1) return MDMM_E_ARG;
+  if (rows == 0) return 0;
+  const int64_t g = rows < 65536 ? rows : 65536;
+  hipLaunchKernelGGL(nan_to_zero_kernel, dim3((unsigned)g), dim3(NT), 0, STREAM, x, rows, inner, out, seen);
+  CHECK_LAUNCH();
 }

@@ -197,8 +197,13 @@ class _ProbDecoder(nn.Module):
             *(_inverse_pyramid(block, n_out, n_kernels, n_layers) + [nn.Sigmoid()]))
         nn.init.xavier_uniform_(self.z_to_feat[0].weight)
 
-    def forward(self, z):
-        return (self.deconv_stack(self.z_to_feat(z).view(-1, *self.feat_shape)),)
+    def forward(self, z, logits=False):
+        x = self.z_to_feat(z).view(-1, *self.feat_shape)
+        if logits:      # everything but the final nn.Sigmoid (for the fused sigmoid + BCE loss)
+            for layer in list(self.deconv_stack)[:-1]:
+                x = layer(x)
+            return (x,)
+        return (self.deconv_stack(x),)
 
 
 class ImageDecoder(_ProbDecoder):

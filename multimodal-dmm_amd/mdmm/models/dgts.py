@@ -23,14 +23,31 @@ class MultiDGTS(nn.Module):
     # The latent state, products of experts, moments and reductions are fp32 in both.
     sweep_dtype = torch.float32
 
-    def _plug(self, module, x):
+    def _plug(self, module, x, **kw):
         if self.plugin_dtype is None or not x.is_cuda:
-            return module(x)
+            return module(x, **kw)
         with torch.autocast('cuda', dtype=self.plugin_dtype):
-            out = module(x)
+            out = module(x, **kw)
         if isinstance(out, tuple):
             return tuple(o.float() for o in out)
         return out.float()
+
+    @staticmethod
+    def _clean(x):
+        """dmm.py:164-166 / dks.py:202-204: NaN -> 0 and the per-(t,b) "seen" flag -- one fused pass
+        over the (T,B,...) tensor on the GPU (csrc/reduce.hip, mdmm_nan_to_zero)."""
+        if x.is_cuda and x.dtype == torch.float32:
+            x0, seen = ops.nan_to_zero(x)
+            return x0, seen > 0
+        nan = torch.isnan(x)
+        return torch.where(nan, torch.zeros_like(x), x), ~nan.flatten(2, -1).any(dim=-1)
+
+    def _logit_decoder(self, m):
+        """Bernoulli decoders of the stock conv family end in nn.Sigmoid (common.py:163-165): the
+        loss can then take their pre-sigmoid activations and fuse sigmoid + BCE + masks."""
+        from . import common
+        return (self.dists[m] == 'Bernoulli' and isinstance(self.dec[m], common._ProbDecoder)
+                and self.plugin_dtype is None and not torch.is_autocast_enabled())
 
     def _noise(self):
         if self.noise is None:

@@ -87,10 +87,7 @@ class MultiDKS(MultiDGTS):
                 x = torch.zeros(shape, device=dev)
                 masks[m] = torch.zeros(t_max, b_dim, device=dev, dtype=torch.bool)
             else:
-                x = inputs[m]
-                nan = torch.isnan(x)
-                masks[m] = ~nan.flatten(2, -1).any(dim=-1)
-                x = torch.where(nan, torch.zeros_like(x), x)
+                x, masks[m] = self._clean(inputs[m])
             if self.dists[m] == 'Categorical':
                 x = x.long()
             feats[m] = self._plug(self.enc[m], x.flatten(0, 1)).reshape(t_max, b_dim, -1)
@@ -201,10 +198,7 @@ class MultiDKS(MultiDGTS):
         real, left = dict(), dict()
         for m in self.modalities:
             if any(m in ps for ps in passes):
-                x = inputs[m]
-                nan = torch.isnan(x)
-                seen = ~nan.flatten(2, -1).any(dim=-1)
-                x = torch.where(nan, torch.zeros_like(x), x)
+                x, seen = self._clean(inputs[m])
                 if self.dists[m] == 'Categorical':
                     x = x.long()
                 feat = self._plug(self.enc[m], x.flatten(0, 1)).reshape(t_max, b_dim, -1)
@@ -263,6 +257,11 @@ class MultiDKS(MultiDGTS):
                 continue
             for p in used:
                 zp = z[:, p * b_dim:(p + 1) * b_dim].reshape(-1, self.z_dim)
+                if self._logit_decoder(m):      # sigmoid + BCE + masks in one pass each way
+                    lg = self._plug(self.dec[m], zp, logits=True)[0]
+                    ops.nll_bernoulli_logits(lg.reshape(t_max, b_dim, *lg.shape[1:]), targets[m], mask, 2,
+                                             float(mult), total)
+                    continue
                 out = self._plug(self.dec[m], zp)
                 rec = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
                 self._nll(m, rec, targets[m], mask, weight=float(mult), into=total)

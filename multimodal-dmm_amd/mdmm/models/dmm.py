@@ -129,9 +129,7 @@ class MultiDMM(MultiDGTS):
             mean, std, seen = ops.gauss_mlp(x.flatten(0, 1), enc, nan_to_zero=True)
             return (mean.reshape(t_max, b_dim, -1), std.reshape(t_max, b_dim, -1),
                     seen.reshape(t_max, b_dim))
-        nan = torch.isnan(x)
-        seen = ~nan.flatten(2, -1).any(dim=-1)
-        x = torch.where(nan, torch.zeros_like(x), x)
+        x, seen = self._clean(x)
         if self.dists[m] == 'Categorical':
             x = x.long()
         mean, std = self._plug(self.enc[m], x.flatten(0, 1))
@@ -319,7 +317,7 @@ class MultiDMM(MultiDGTS):
         return ops.kld_gauss(glb_mean, glb_std, nxt_mean, nxt_std)
 
     # ---- the ELBO step ----------------------------------------------------------------
-    def _decode_for_loss(self, m, z_list):
+    def _decode_for_loss(self, m, z_list, **kw):
         """Decode modality m for a list of (T,B,D) latents -> list of parameter tuples.
         One batched decoder call, unless the decoder holds BatchNorm in training mode
         (per-call batch statistics must then stay per pass, as in the reference)."""
@@ -328,10 +326,10 @@ class MultiDMM(MultiDGTS):
         has_bn = dec.training and any(isinstance(x, nn.modules.batchnorm._BatchNorm)
                                       for x in dec.modules())
         if has_bn or len(z_list) == 1:
-            outs = [self._plug(dec, z.reshape(-1, self.z_dim)) for z in z_list]
+            outs = [self._plug(dec, z.reshape(-1, self.z_dim), **kw) for z in z_list]
             return [tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in o) for o in outs]
         n = len(z_list)
-        out = self._plug(dec, torch.stack(z_list).reshape(-1, self.z_dim))
+        out = self._plug(dec, torch.stack(z_list).reshape(-1, self.z_dim), **kw)
         # unbind, not r[i]: its backward is ONE stack of the per-pass gradients, where every
         # integer index would zero-fill and add a full-size tensor
         out = [r.reshape(n, t_max, b_dim, *r.shape[1:]).unbind(0) for r in out]
@@ -370,6 +368,10 @@ class MultiDMM(MultiDGTS):
                     z = torch.stack([zs[p] for p in used])
                 ops.gauss_mlp_nll(z.reshape(-1, self.z_dim), self.dec[m], targets[m], mask,
                                   weight=float(mult), into=total)
+                continue
+            if self._logit_decoder(m):      # sigmoid + BCE + masks in one pass each way
+                for rec in self._decode_for_loss(m, [zs[p] for p in used], logits=True):
+                    ops.nll_bernoulli_logits(rec[0], targets[m], mask, 2, float(mult), total)
                 continue
             for rec in self._decode_for_loss(m, [zs[p] for p in used]):
                 self._nll(m, rec, targets[m], mask, weight=float(mult), into=total)

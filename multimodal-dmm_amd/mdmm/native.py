@@ -25,6 +25,7 @@ SYMBOLS = [
     'mdmm_kld_gauss_fwd', 'mdmm_kld_gauss_bwd',
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
     'mdmm_nll_bernoulli_fwd', 'mdmm_nll_bernoulli_bwd',
+    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero',
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
     'mdmm_philox_normal', 'mdmm_debug_clock', 'mdmm_gtf_pack_size', 'mdmm_gtf_pack',
     'mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd', 'mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd',
@@ -153,6 +154,9 @@ def lib():
         L.mdmm_nll_gauss_bwd.argtypes = [_P, _P, _P, _P, i64, i32, f32, _P, _P, _P, _P]
         L.mdmm_nll_bernoulli_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_bernoulli_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
+        L.mdmm_nll_bernoulli_logits_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
+        L.mdmm_nll_bernoulli_logits_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
+        L.mdmm_nan_to_zero.argtypes = [_P, i64, i32, _P, _P, _P]
         L.mdmm_nll_categorical_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_categorical_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
         L.mdmm_philox_normal.argtypes = [C.c_uint64, C.c_uint64, _P, i64, _P, _P]

@@ -774,6 +774,49 @@ def nll_bernoulli(theta, x, mask=None, lead_dims=2, weight=1.0, into=None):
                                        float(weight), into), into)
 
 
+class _NllBernLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, x, mask, rows, inner, weight, into):
+        _need_gpu(logits, x)
+        lg, xv = _f32c(logits), _f32c(x)
+        acc = _term_acc(into, lg.device)
+        _call('mdmm_nll_bernoulli_logits_fwd', _ptr(lg), _ptr(xv), _ptr(mask), rows, inner, weight,
+              _ptr(acc))
+        ctx.save_for_backward(lg, xv)
+        ctx.mask, ctx.rows, ctx.inner, ctx.weight = mask, rows, inner, weight
+        return _term_out(acc, into, lg.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, xv = ctx.saved_tensors
+        gl = torch.empty_like(lg)
+        gd = _gdev(g)
+        _call('mdmm_nll_bernoulli_logits_bwd', _ptr(lg), _ptr(xv), _ptr(ctx.mask),
+              ctx.rows, ctx.inner, ctx.weight, _ptr(gd), _ptr(gl))
+        return gl, None, None, None, None, None, None
+
+
+def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None):
+    """losses.py:23-42 on the pre-sigmoid activations of a decoder whose last module is nn.Sigmoid
+    (common.py:163-165): sigmoid + binary cross entropy + masks in one pass each way."""
+    rows = _lead_rows(x, lead_dims)
+    inner = x.numel() // rows
+    return _term_done(_NllBernLogitsFn.apply(logits, x, _row_mask(mask, rows, x), rows, inner,
+                                             float(weight), into), into)
+
+
+def nan_to_zero(x, lead_dims=2):
+    """dmm.py:164-166 on the GPU in one pass: (x with NaN -> 0, per-row seen flag (fp32 0/1))."""
+    _need_gpu(x)
+    xv = _f32c(x)
+    rows = _lead_rows(x, lead_dims)
+    inner = xv.numel() // rows
+    out = torch.empty_like(xv)
+    seen = torch.empty(xv.shape[:lead_dims], device=xv.device, dtype=torch.float32)
+    _call('mdmm_nan_to_zero', _ptr(xv), rows, inner, _ptr(out), _ptr(seen))
+    return out, seen
+
+
 class _NllCatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, probs, x, mask, rows, n_cat, weight, into):

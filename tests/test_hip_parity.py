@@ -982,3 +982,98 @@ def test_batchnorm_relu_matches_torch(dev, kernel_family, shape):
     close(got.running_mean, ref.running_mean, 1e-5, 'running mean')
     close(got.running_var, ref.running_var, 1e-5, 'running var')
     assert int(got.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+
+
+def test_step_conv_plugins_matches_oracle(dev, kernel_family):
+    """Weizmann-style plug-ins at toy size (conv encoders / decoders with BatchNorm, Bernoulli
+    images, a categorical label): exercises the fused NaN cleaning, BatchNorm + ReLU and
+    sigmoid + BCE kernels inside a full ELBO step against the oracle running the same modules
+    as stock PyTorch on the CPU (common.py:70-175, losses.py:23-42)."""
+    if kernel_family == 'generic':
+        pytest.skip('plug-in glue, one family is enough')
+    from mdmm import models, ops
+    from mdmm.models import common as C
+    from mdmm.noise import PhiloxNoise
+    torch.manual_seed(6)
+    mods, dims = ['video', 'mask', 'action'], [(3, 16, 16), (1, 16, 16), 10]
+    dists = ['Bernoulli', 'Bernoulli', 'Categorical']
+    D = H = 32
+
+    def plugins():
+        enc = {'video': C.ImageEncoder(D, img_size=16, n_channels=3, n_kernels=16, n_layers=2),
+               'mask': C.ImageEncoder(D, img_size=16, n_channels=1, n_kernels=16, n_layers=2)}
+        dec = {'video': C.ImageDecoder(D, img_size=16, n_channels=3, n_kernels=16, n_layers=2),
+               'mask': C.ImageDecoder(D, img_size=16, n_channels=1, n_kernels=16, n_layers=2)}
+        return enc, dec
+    enc, dec = plugins()
+    m = models.MultiDMM(mods, dims, dists, encoders=enc, decoders=dec, h_dim=H, z_dim=D, device=dev)
+    enc, dec = plugins()
+    o = orc.OracleDMM(mods, dims, dists, encoders=enc, decoders=dec, h_dim=H, z_dim=D)
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    T, lengths, K = 6, [6, 6, 5, 3], 25
+    B = len(lengths)
+    g = torch.Generator().manual_seed(2)
+    targets = {'video': torch.rand(T, B, 3, 16, 16, generator=g),
+               'mask': (torch.rand(T, B, 1, 16, 16, generator=g) < 0.5).float(),
+               'action': torch.randint(0, 10, (1, B, 1), generator=g).float().expand(T, B, 1).contiguous()}
+    for k in targets:
+        for b, n in enumerate(lengths):
+            targets[k][n:, b] = float('nan')
+    inputs = {k: v.clone() for k, v in targets.items()}
+    inputs['video'][1:3, 0] = float('nan'); inputs['mask'][2:4, 1] = float('nan')
+    mask = orc.len_to_mask(lengths)
+    rec = {'video': 1.0, 'mask': 1.0, 'action': 10.0}
+    m.noise = PhiloxNoise(seed=31)
+    kw = dict(train_particles=K, match_particles=50)
+    loss = m.step(cuda(inputs, dev), mask.to(dev), 1.0, rec, targets=cuda(targets, dev), lengths=lengths, **kw)
+    (loss / sum(lengths)).backward()
+    noise = PhiloxNoise(seed=31)
+    draws = [noise.normal((50, 1, D), dev).cpu(), noise.normal((50, 1, D), dev).cpu()]
+    P, sweeps = 4, []
+    for k in (1, K, 1):
+        sd, off = noise.stream()
+        sweeps.append(ops.philox_normal(sd, off, (P, T, k, B, D), dev).cpu())
+    for p in range(P):
+        draws += [sweeps[0][p, t] for t in reversed(range(T))]
+    for p in range(P):
+        draws += [sweeps[1][p, t] for t in reversed(range(T))]
+        draws += [sweeps[2][p, t] for t in range(T)]
+    o.noise = orc.ReplayNoise(draws)
+    oloss = o.step(inputs, mask, 1.0, rec, targets=targets, lengths=lengths, **kw)
+    (oloss / sum(lengths)).backward()
+    close(loss, oloss, 2e-5, 'conv step loss')
+    og = dict(o.named_parameters())
+    gmax = max(float(v.grad.abs().max()) for v in og.values() if v.grad is not None)
+    for k, p in m.named_parameters():
+        ref = og[k].grad if og[k].grad is not None else torch.zeros_like(og[k])
+        # a conv bias in front of a BatchNorm has an exactly zero gradient (the norm removes the
+        # mean): what either side holds there is rounding noise
+        if float(ref.abs().max()) < 1e-5 * gmax:
+            assert float(p.grad.abs().max()) < 1e-4 * gmax, k
+            continue
+        l2 = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30))
+        assert l2 < 5e-3, 'conv step grad %s: L2 %.3e' % (k, l2)
+
+
+def test_nan_to_zero_and_logits_bce(dev, kernel_family):
+    """mdmm_nan_to_zero and the sigmoid-fused Bernoulli NLL against their torch spellings."""
+    if kernel_family == 'generic':
+        pytest.skip('no sweep involved')
+    from mdmm import ops
+    torch.manual_seed(8)
+    x = torch.randn(5, 7, 3, 6, 6, device=dev)
+    x[1, 2, 0, 3, 3] = float('nan'); x[4, 6] = float('nan'); x[0, 0, 2, 5, 5] = float('nan')
+    x0, seen = ops.nan_to_zero(x)
+    assert torch.equal(x0, torch.where(torch.isnan(x), torch.zeros_like(x), x))
+    assert torch.equal(seen > 0, ~torch.isnan(x).flatten(2, -1).any(-1))
+    for shape in ((5, 7, 3, 6, 6), (4, 3, 1, 5)):
+        lg = (torch.randn(*shape, device=dev) * 6).requires_grad_()
+        lg.data.view(-1)[:3] = torch.tensor([120.0, -120.0, 30.0], device=dev)     # saturated pixels
+        tgt = (torch.rand(*shape, device=dev) < 0.5).float()
+        tgt.view(-1)[:3] = torch.tensor([0.0, 1.0, 0.0], device=dev)
+        tgt[1, 2] = float('nan')
+        msk = torch.ones(shape[0], shape[1], 1, device=dev, dtype=torch.bool); msk[-1, 0] = False
+        a = ops.nll_bernoulli_logits(lg, tgt, msk); a.backward()
+        ga, lg.grad = lg.grad.clone(), None
+        b = ops.nll_bernoulli(torch.sigmoid(lg), tgt, msk); b.backward()
+        close(a, b, 1e-6, 'logits bce'); close(ga, lg.grad, 1e-5, 'logits bce grad')
