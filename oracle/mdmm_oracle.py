@@ -363,6 +363,10 @@ class OracleDMM(_OracleDGTS):
             stds.reverse()
         return torch.stack(means), torch.stack(stds)
 
+    def sample(self, t_max, b_dim, direction='fwd'):        # dmm.py:414-418
+        z_mean, _ = self.z_sample(t_max, b_dim, direction, sample=True)
+        return self.decode(z_mean)
+
     def z_filter(self, e_mean, e_std, e_mask, direction='fwd', sample=True,
                  n_particles=1, sample_init=False):         # dmm.py:319-412
         t_max, b_dim = e_mean.shape[1:3]
@@ -492,6 +496,22 @@ class OracleDKS(_OracleDGTS):
         self.combiner = GaussianMLP(comb_dim, z_dim, h_dim)
         self.z0_mean = z0_mean * torch.ones(1, z_dim)       # plain tensors, dks.py:154-155
         self.z0_std = z0_std * torch.ones(1, z_dim)
+
+    def sample(self, t_max, b_dim):                         # dks.py:299-342
+        zs, z_t = [], None
+        for t in range(t_max):
+            if t > 0:
+                p_mean, p_std = self.fwd(z_t)
+            else:
+                p_mean, p_std = self.z0_mean.repeat(b_dim, 1), self.z0_std.repeat(b_dim, 1)
+            z_t = self._sample(p_mean, p_std)
+            zs.append(z_t)
+        zs = torch.stack(zs, dim=0)
+        recon = {}
+        for m in self.modalities:
+            out = self.dec[m](zs.view(-1, self.z_dim))
+            recon[m] = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
+        return recon
 
     def forward(self, inputs, **kw):                        # dks.py:157-297
         lengths, sample = kw.get('lengths'), kw.get('sample', True)

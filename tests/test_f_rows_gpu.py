@@ -1,0 +1,140 @@
+"""SURVEY 8(f) rows on the GPU: on-device batch preparation (f2) against the loop restatement of
+datasets/multiseq.py:405-448, the sampling API (f4: dmm.py:414-418, dks.py:299-342) against the
+oracle, and the data-parallel harness entered through RCCL (8e) with a one-rank group."""
+import os
+
+import pytest
+import torch
+
+import helpers  # noqa: F401
+from oracle import mdmm_oracle as orc
+from test_batch_cpu import _batch, _loop_delete, _same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _cpu(d):
+    return {k: v.cpu() for k, v in d.items()}
+
+
+def test_batch_ops_on_device_match_loop(dev):
+    from mdmm import batch
+    x, lengths = _batch()
+    xd = {k: v.to(dev) for k, v in x.items()}
+    assert torch.equal(batch.len_to_mask(lengths, device=dev).cpu(), orc.len_to_mask(lengths))
+    g = torch.Generator().manual_seed(1)
+    starts = {m: torch.stack([torch.randint(0, n, (1,), generator=g)[0] for n in lengths]) for m in x}
+    frac = 0.3
+    ref = _loop_delete(x, lambda m, b, n: list(range(int(starts[m][b]), min(int(starts[m][b]) + int(frac * n), n))), lengths)
+    out = batch.burst_delete(xd, frac, lengths, t_start=starts)
+    assert all(v.is_cuda for v in out.values())
+    _same(_cpu(out), ref)
+    scores = {m: torch.rand(12, 5, generator=g) for m in x}
+    ref = _loop_delete(x, lambda m, b, n: torch.argsort(scores[m][:n, b])[:int(0.4 * n)].tolist(), lengths)
+    _same(_cpu(batch.rand_delete(xd, 0.4, lengths, scores=scores)), ref)
+    keep = _loop_delete(x, lambda m, b, n: list(range(0, int(0.25 * n))) + list(range(int(0.75 * n), n)), lengths)
+    _same(_cpu(batch.keep_segment(xd, 0.25, 0.75, lengths)), keep)
+    dele = _loop_delete(x, lambda m, b, n: list(range(int(0.25 * n), int(0.75 * n))), lengths)
+    _same(_cpu(batch.del_segment(xd, 0.25, 0.75, lengths)), dele)
+    # random draws on the device generator: right number of deletions, padding untouched
+    out = batch.burst_delete(xd, frac, lengths, generator=torch.Generator(device=dev).manual_seed(3))
+    for m in x:
+        for b, n in enumerate(lengths):
+            new = torch.isnan(out[m][:n, b]).flatten(1).any(1).sum().item()
+            assert new <= int(frac * n) and (int(frac * n) == 0 or new >= 1)
+            assert torch.isnan(out[m][n:, b]).all()
+    # feeds straight into a step: the deleted batch is what the model sees
+    from mdmm import models
+    m = models.MultiDMM(['a', 'b'], [3, 4], h_dim=8, z_dim=4, device=dev)
+    flat = lambda d: {k: v.flatten(2) for k, v in d.items()}      # noqa: E731
+    loss = m.step(flat(out), batch.len_to_mask(lengths, device=dev), 1.0, {}, targets=flat(xd),
+                  lengths=lengths)
+    assert torch.isfinite(loss)
+
+
+@pytest.mark.parametrize('direction', ['fwd', 'bwd'])
+def test_dmm_sample_matches_oracle(dev, direction):
+    from mdmm import models
+    from mdmm.noise import ReplayNoise
+    torch.manual_seed(1)
+    names, dims = ['a', 'b'], [3, 2]
+    m = models.MultiDMM(names, dims, h_dim=12, z_dim=6, device=dev).eval()
+    o = orc.OracleDMM(names, dims, h_dim=12, z_dim=6).eval()
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    T, B = 7, 4
+    g = torch.Generator().manual_seed(4)
+    draws = [torch.randn(1, B, 6, generator=g) for _ in range(T)]
+    m.noise = ReplayNoise([d.clone() for d in draws])
+    o.noise = orc.ReplayNoise([d.clone() for d in draws])
+    with torch.no_grad():
+        got, want = m.sample(T, B, direction), o.sample(T, B, direction)
+    assert m.noise.exhausted and o.noise.pos == T
+    assert set(got) == set(names)
+    for k in names:
+        assert isinstance(got[k], tuple) and len(got[k]) == len(want[k])
+        for a, b in zip(got[k], want[k]):
+            assert a.shape == (T, B, dims[names.index(k)])
+            assert helpers.rel_err(a, b) < 2e-5
+
+
+def test_dks_sample_matches_oracle(dev):
+    from mdmm import models
+    from mdmm.noise import ReplayNoise
+    torch.manual_seed(2)
+    names, dims = ['a', 'b'], [3, 2]
+    m = models.MultiDKS(names, dims, h_dim=10, z_dim=5, device=dev).eval()
+    o = orc.OracleDKS(names, dims, h_dim=10, z_dim=5).eval()
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    T, B = 6, 3
+    g = torch.Generator().manual_seed(5)
+    draws = [torch.randn(B, 5, generator=g) for _ in range(T)]
+    m.noise = ReplayNoise([d.clone() for d in draws])
+    o.noise = orc.ReplayNoise([d.clone() for d in draws])
+    with torch.no_grad():
+        got, want = m.sample(T, B), o.sample(T, B)
+    for k in names:
+        for a, b in zip(got[k], want[k]):
+            assert helpers.rel_err(a, b) < 2e-5
+
+
+def test_elbo_step_through_rccl_world_one(dev):
+    """mdmm.harness with a real NCCL (= RCCL) process group of one rank: the collective path of
+    bench.py --gpus N is entered on hardware; its result equals the group-less step."""
+    import torch.distributed as dist
+    from mdmm import models
+    from mdmm.harness import GradBucket, elbo_step
+    from mdmm.noise import PhiloxNoise
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29700 + os.getpid() % 200))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        spec = [('a', 2, 'Normal'), ('b', 1, 'Normal')]
+        x = {k: v.to(dev) for k, v in helpers.make_inputs(spec, 8, [8, 6, 3], seed=3).items()}
+        mask = orc.len_to_mask([8, 6, 3]).to(dev)
+        res = []
+        for use_group in (True, False):
+            torch.manual_seed(0)
+            m = models.MultiDMM(['a', 'b'], [2, 1], h_dim=8, z_dim=4, device=dev)
+            m.noise = PhiloxNoise(seed=9)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+            bucket = GradBucket(m.parameters())
+            if use_group:
+                t = torch.ones(3, device=dev)
+                dist.all_reduce(t)                       # the collective really runs
+                assert torch.equal(t.cpu(), torch.ones(3))
+            loss = elbo_step(m, opt, bucket, x, mask, [8, 6, 3], 1.0, {}, targets=x,
+                             group=dist.group.WORLD if use_group else None)
+            res.append((float(loss), torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()))
+        assert res[0][0] == res[1][0]
+        assert torch.equal(res[0][1], res[1][1])
+    finally:
+        if created:
+            dist.destroy_process_group()
