@@ -750,6 +750,10 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     // E: elementwise adjoint; acc: pre -> G3, omg -> Glin, nl -> direct part of GN, muq -> GG.
     // Product with the global prior as in the forward kernel (v = sq^2 + eps, u = 1/(t0 v + 1)):
     //   var = v u, mean = muq u + num0 var;  d mean/d muq = u,  d/d sq via tq = 1/v.
+    // The results leave in groups of one operand chunk (8 rows bf16, 4 rows fp32): LDS images for
+    // the input-gradient contractions, MFMA chunks for the weight gradients -- so that the three
+    // arrays read here never hold outputs as well (that cost ~100 spilled registers per lane).
+    constexpr int CG = F32 ? 4 : 8;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       float gv2k = 0.f, gpmk = 0.f, mb = 0.f;
@@ -758,47 +762,50 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
         gpmk = fa[rt].gpm * inv_k; mb = fa[rt].prm;
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pre = acc[rt][r];
-        const float sq = softplus_w<F32>(pre) + a.min_std;
-        const float v = fmaf(sq, sq, MDMM_POE_EPS);
-        const float u = fast::rcp(fmaf(t0, v, 1.0f));
-        const float rp = v * u;                                  // variance of the product
-        const float mraw = fmaf(muq[rt][r], u, num0 * rp), sd = fast::sqrt(rp);
-        const float m = (mraw != mraw) ? 0.f : mraw;                            // dgts.py:49
-        float g_m, g_sd;
-        if constexpr (K1) { g_m = fa[rt * 16 + r].gpm; g_sd = fa[rt * 16 + r].gps; }
-        else { g_m = gpmk + gv2k * (m - mb); g_sd = gv2k * sd; }
-        const bool live = (live_bits[rt] >> r) & 1u;
-        if (!live || mraw != mraw) g_m = 0.f;                    // (the mean was overwritten by 0)
-        if (!live) g_sd = 0.f;
-        // d/d(num, prec) of the product, then the two experts (dgts.py:39-51 backwards)
-        const float g_num = g_m * rp;
-        const float g_prec = -(g_m * m + 0.5f * g_sd * sd) * rp;
-        const float g_t0 = fmaf(g_num, mu0, g_prec);             // d/d prec of the global prior
-        g_mu0 = fmaf(g_num, t0, g_mu0);
-        g_sg0 = fmaf(g_t0, dt0, g_sg0);
-        const float tq = fast::rcp(v);
-        const float g_muq = g_num * tq;
-        const float g_sq = -fmaf(g_num, muq[rt][r], g_prec) * tq * tq * 2.0f * sq;
-        const float gate = 1.0f - omg[rt][r];
-        acc[rt][r] = g_sq * fast::softplus_grad(pre);                       // d/d std pre-act
-        const float gg = g_muq * gate * (nl[rt][r] - muq[rt][r]);           // d/d gate pre-act
-        nl[rt][r] = g_muq * gate;                                           // direct part of d/d nl
-        omg[rt][r] = g_muq * omg[rt][r];                                    // d/d z_lin
-        muq[rt][r] = gg;
-        // keep the scheduler from interleaving all 16 * RT elements: that needs more registers
-        // than there are and the phase ends up waiting on scratch reloads
-        if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      for (int c0 = 0; c0 < 16; c0 += CG) {
+        float o_g3[CG], o_gg[CG], o_gl[CG];
+#pragma unroll
+        for (int k = 0; k < CG; ++k) {
+          const int r = c0 + k;
+          const float pre = acc[rt][r];
+          const float sq = softplus_w<F32>(pre) + a.min_std;
+          const float v = fmaf(sq, sq, MDMM_POE_EPS);
+          const float u = fast::rcp(fmaf(t0, v, 1.0f));
+          const float rp = v * u;                                  // variance of the product
+          const float mraw = fmaf(muq[rt][r], u, num0 * rp), sd = fast::sqrt(rp);
+          const float m = (mraw != mraw) ? 0.f : mraw;                            // dgts.py:49
+          float g_m, g_sd;
+          if constexpr (K1) { g_m = fa[rt * 16 + r].gpm; g_sd = fa[rt * 16 + r].gps; }
+          else { g_m = gpmk + gv2k * (m - mb); g_sd = gv2k * sd; }
+          const bool live = (live_bits[rt] >> r) & 1u;
+          if (!live || mraw != mraw) g_m = 0.f;                    // (the mean was overwritten by 0)
+          if (!live) g_sd = 0.f;
+          // d/d(num, prec) of the product, then the two experts (dgts.py:39-51 backwards)
+          const float g_num = g_m * rp;
+          const float g_prec = -(g_m * m + 0.5f * g_sd * sd) * rp;
+          const float g_t0 = fmaf(g_num, mu0, g_prec);             // d/d prec of the global prior
+          g_mu0 = fmaf(g_num, t0, g_mu0);
+          g_sg0 = fmaf(g_t0, dt0, g_sg0);
+          const float tq = fast::rcp(v);
+          const float g_muq = g_num * tq;
+          const float g_sq = -fmaf(g_num, muq[rt][r], g_prec) * tq * tq * 2.0f * sq;
+          const float gate = 1.0f - omg[rt][r];
+          o_g3[k] = g_sq * fast::softplus_grad(pre);                          // d/d std pre-act
+          o_gg[k] = g_muq * gate * (nl[rt][r] - muq[rt][r]);                  // d/d gate pre-act
+          o_gl[k] = g_muq * omg[rt][r];                                       // d/d z_lin
+          nl[rt][r] = g_muq * gate;                                           // direct part of d/d nl
+        }
+        store_image_part<F32, CG>(img1, o_g3, rt, c0, wave, lane);
+        store_image_part<F32, CG>(img2, o_gg, rt, c0, wave, lane);
+        store_image_part<F32, CG>(img0, o_gl, rt, c0, wave, lane);
+        const int ch = rt * O::CH_TILE + c0 / CG;
+        spill_at(i - 1, S_G3)[ch * 64] = pack_chunk<F32, CG>(o_g3);
+        spill_at(i - 1, S_GG)[ch * 64] = pack_chunk<F32, CG>(o_gg);
+        spill_at(i - 1, S_GLIN)[ch * 64] = pack_chunk<F32, CG>(o_gl);
+        __builtin_amdgcn_sched_barrier(0);     // one group at a time
       }
     }
     STAMP(9);
-    store_image<F32, RT>(img1, acc, wave, lane);
-    spill_tiles<F32, RT>(spill_at(i - 1, S_G3), acc);
-    store_image<F32, RT>(img2, muq, wave, lane);
-    spill_tiles<F32, RT>(spill_at(i - 1, S_GG), muq);
-    store_image<F32, RT>(img0, omg, wave, lane);
-    spill_tiles<F32, RT>(spill_at(i - 1, S_GLIN), omg);
     STAMP(10);
     __syncthreads();
     STAMP(11);

@@ -175,6 +175,44 @@ __device__ __forceinline__ uint4 acc_chunk(const f32x16& v, int s) {
   return o;
 }
 
+// the same for a run of N accumulator registers (reg0 .. reg0 + N - 1 of row tile rt) held in a
+// plain array: lets a phase hand its results over group by group instead of array by array
+template <bool F32, int N>
+__device__ __forceinline__ void store_image_part(char* img, const float (&v)[N], int rt, int reg0,
+                                                 int tile, int lane) {
+  constexpr int RS = Op<F32>::RS, ESZ = Op<F32>::ESZ;
+  char* base = img + 4 * (lane >> 5) * RS + (32 * tile + (lane & 31)) * ESZ;
+#pragma unroll
+  for (int k = 0; k < N; k += 2) {
+    char* p = base + acc_row(rt, reg0 + k) * RS;
+    if constexpr (F32) {
+      *reinterpret_cast<float*>(p) = v[k];
+      *reinterpret_cast<float*>(p + RS) = v[k + 1];
+    } else {
+      bf16x2 pk;
+      pk[0] = (__bf16)v[k]; pk[1] = (__bf16)v[k + 1];
+      *reinterpret_cast<__bf16*>(p) = pk[0];
+      *reinterpret_cast<__bf16*>(p + RS) = pk[1];
+    }
+  }
+}
+// one operand chunk (acc_chunk) from such a run: N = 8 (bf16) or 4 (fp32)
+template <bool F32, int N>
+__device__ __forceinline__ uint4 pack_chunk(const float (&v)[N]) {
+  static_assert(N == (F32 ? 4 : 8), "chunk size");
+  uint4 o;
+  if constexpr (F32) {
+    o.x = __float_as_uint(v[0]); o.y = __float_as_uint(v[1]);
+    o.z = __float_as_uint(v[2]); o.w = __float_as_uint(v[3]);
+  } else {
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
+    o = __builtin_bit_cast(uint4, b);
+  }
+  return o;
+}
+
 // 4 x 4 transpose across the four lanes of a quad: lane u hands in e[v] = M[u][v] and gets
 // e[j] = M[j][u] (two DPP exchange rounds, xor 1 then xor 2).
 __device__ __forceinline__ float quad_x1(float v) {
