@@ -24,6 +24,7 @@ pytestmark = pytest.mark.gpu
 
 MODES = ['fsmooth', 'bsmooth', 'ffilter', 'bfilter']
 TOL_OUT, TOL_LOSS, TOL_GRAD = 2e-5, 1e-5, 2e-3
+TOL_GRAD_TIGHT = 2e-5      # every golden step case but the knife-edge one (measured: < 1e-6)
 SPEC_AB = [('a', 1, 'Normal'), ('b', 1, 'Normal')]
 SPEC_MIX = [('g', 3, 'Normal'), ('c', 4, 'Categorical'), ('v', (2, 3), 'Bernoulli')]
 
@@ -430,7 +431,15 @@ def test_step_golden(case, dev):
         if float(ref.abs().max()) < 1e-6:
             assert float(got.abs().max()) < 1e-5, k
             continue
-        grad_close(got, ref, k)
+        if case == 'z5':
+            # this fixture holds a knife-edge relu gate (one hidden pre-activation of dec.b is exactly
+            # 0.0 in fp32): a 2e-7 relative change of the decoder's input moves this gradient by
+            # 9.7e-4 or not at all (tests/test_oracle_golden.py::test_golden_z5_knife_edge_relu), so
+            # either value is right here; everywhere else the tolerance is 100 times tighter
+            grad_close(got, ref, k)
+        else:
+            l2 = float((got.detach().double().cpu() - ref.double()).norm() / ref.double().norm())
+            assert l2 < TOL_GRAD_TIGHT, '%s %s grad rel err L2 %.3e' % (case, k, l2)
 
 
 # ----------------------------------------------------------------- trainer trajectory --
