@@ -122,6 +122,13 @@ def lib():
                 'libmdmm_hip.so not found at %s -- build it with `python __graft_entry__.py` '
                 '(or `make -C multimodal-dmm_amd/csrc`); the MDMM hot path has no CPU fallback'
                 % LIB_PATH)
+        # PyTorch-ROCm ships its own libamdhip64: load torch first so that the library binds to
+        # THAT runtime -- loaded ahead of torch it pulls in /opt/rocm's copy, the process ends up
+        # with two HIP runtimes and every launch from here fails with hipErrorNoDevice
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.mdmm_strerror.restype = C.c_char_p
         L.mdmm_strerror.argtypes = [C.c_int]
