@@ -427,6 +427,9 @@ typedef struct mdmm_bn {
   const float* dy;
   float *dx, *dgamma, *dbeta;
   double* partial;
+  /* optional (C): added to the batch mean in the running_mean update only -- the bias of the
+   * convolution in front when the caller leaves it out of x (BatchNorm(x + b) == BatchNorm(x)) */
+  const float* mean_shift;
 } mdmm_bn_t;
 int mdmm_bn_splits(int64_t N, int C, int64_t L);
 int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream);

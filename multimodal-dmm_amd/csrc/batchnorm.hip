@@ -77,7 +77,8 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, int relu,
                                                       float momentum, float* running_mean,
-                                                      float* running_var, float* __restrict__ y,
+                                                      float* running_var, const float* mean_shift,
+                                                      float* __restrict__ y,
                                                       float* save_mean, float* save_invstd) {
   const int c = blockIdx.x;
   double d1 = 0, d2 = 0;
@@ -94,7 +95,10 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
     save_mean[c] = (float)mean; save_invstd[c] = invstd;
     if (running_mean) {                          // torch: unbiased variance into the running stat
       const double unb = M > 1 ? var * M / (M - 1) : var;
-      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+      // mean_shift: the bias of the convolution in front, left out of x (it cancels in the
+      // normalisation) but part of the statistic the stock modules track
+      const float ms = mean_shift ? mean_shift[c] : 0.0f;
+      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * ((float)mean + ms);
       running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
     }
   }
@@ -256,12 +260,12 @@ extern "C" int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream) {
     hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial);
     hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial,
                        a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
-                       a->y, a->save_mean, a->save_invstd);
+                       a->mean_shift, a->y, a->save_mean, a->save_invstd);
   } else {
     hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial);
     hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial,
                        a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
-                       a->y, a->save_mean, a->save_invstd);
+                       a->mean_shift, a->y, a->save_mean, a->save_invstd);
   }
   return (int)hipGetLastError();
 }

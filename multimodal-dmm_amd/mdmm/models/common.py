@@ -93,16 +93,26 @@ class _ConvBlock(nn.Module):
         self.net = layer if last else nn.Sequential(layer, norm(n_kernels), nn.ReLU())
         nn.init.xavier_uniform_(layer.weight)
 
+    @staticmethod
+    def _conv_nobias(layer, x):
+        if isinstance(layer, (nn.Conv1d, nn.Conv2d)):
+            return layer._conv_forward(x, layer.weight, None)
+        fn = F.conv_transpose2d if isinstance(layer, nn.ConvTranspose2d) else F.conv_transpose1d
+        return fn(x, layer.weight, None, layer.stride, layer.padding, layer.output_padding,
+                  layer.groups, layer.dilation)
+
     def forward(self, x):
         if isinstance(self.net, nn.Sequential):
-            y = self.net[0](x)
-            bn = self.net[1]
+            layer, bn = self.net[0], self.net[1]
             # BatchNorm + ReLU in training mode: two fused streaming passes each way
-            # (csrc/batchnorm.hip) instead of the library's norm kernels + a ReLU pass
+            # (csrc/batchnorm.hip) instead of the library's norm kernels + a ReLU pass.  The
+            # convolution's bias cancels in the normalisation: it is not added (one pass over the
+            # activations forward, one reduction backward less per layer) and only enters the
+            # running mean, as in the stock modules.
             from .. import ops
-            if ops.batchnorm_relu_supported(y, bn):
-                return ops.batchnorm_relu(y, bn)
-            return self.net[2](bn(y))
+            if ops.batchnorm_relu_supported(x, bn) and x.is_cuda:
+                return ops.batchnorm_relu(self._conv_nobias(layer, x), bn, shift=layer.bias)
+            return self.net[2](bn(layer(x)))
         return self.net(x)
 
 

@@ -103,7 +103,7 @@ class Bn(C.Structure):
                 [(n, C.c_int32) for n in ('C', 'relu', 'splits', 'reserved')] +
                 [('eps', C.c_float), ('momentum', C.c_float)] +
                 [(n, _P) for n in ('x', 'gamma', 'beta', 'running_mean', 'running_var', 'y', 'save_mean',
-                                   'save_invstd', 'dy', 'dx', 'dgamma', 'dbeta', 'partial')])
+                                   'save_invstd', 'dy', 'dx', 'dgamma', 'dbeta', 'partial', 'mean_shift')])
 
 
 class MdmmError(RuntimeError):

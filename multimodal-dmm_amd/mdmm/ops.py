@@ -917,7 +917,7 @@ class _BnReluFn(torch.autograd.Function):
     each way; updates the module's running statistics exactly as the stock module does."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn, relu):
+    def forward(ctx, x, gamma, beta, bn, relu, shift):
         ctx.set_materialize_grads(False)
         _need_gpu(x)
         x = _f32c(x)
@@ -939,15 +939,21 @@ class _BnReluFn(torch.autograd.Function):
             # momentum None = cumulative average (torch: 1 / num_batches_tracked)
             a.momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             a.running_mean, a.running_var = _ptr(bn.running_mean), _ptr(bn.running_var)
+            sh = None if shift is None else _f32c(shift.detach())
+            a.mean_shift = _ptr(sh)
         _call('mdmm_bn_relu_fwd', C.byref(a))
         ctx.save_for_backward(x, stats, g, b)
         ctx.meta = (N, Cc, Ln, int(relu), a.splits, bn.eps)
+        ctx.shift_like = None if shift is None else shift.detach()
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        shift_grad = None          # a bias in front of the norm has an exactly zero gradient
+        if ctx.shift_like is not None and ctx.needs_input_grad[5]:
+            shift_grad = torch.zeros_like(ctx.shift_like)
         if dy is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, shift_grad
         x, stats, g, b = ctx.saved_tensors
         N, Cc, Ln, relu, splits, eps = ctx.meta
         dy = _f32c(dy)
@@ -961,7 +967,7 @@ class _BnReluFn(torch.autograd.Function):
         a.dgamma, a.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
         _call('mdmm_bn_relu_bwd', C.byref(a))
         return (dx, dgb[0] if ctx.needs_input_grad[1] else None,
-                dgb[1] if ctx.needs_input_grad[2] else None, None, None)
+                dgb[1] if ctx.needs_input_grad[2] else None, None, None, shift_grad)
 
 
 def batchnorm_relu_supported(x, bn):
@@ -971,9 +977,11 @@ def batchnorm_relu_supported(x, bn):
             and not torch.is_autocast_enabled())
 
 
-def batchnorm_relu(x, bn, relu=True):
-    """nn.Sequential(bn, nn.ReLU())(x) for a BatchNorm1d / BatchNorm2d holder in training mode."""
-    return _BnReluFn.apply(x, bn.weight, bn.bias, bn, relu)
+def batchnorm_relu(x, bn, relu=True, shift=None):
+    """nn.Sequential(bn, nn.ReLU())(x) for a BatchNorm1d / BatchNorm2d holder in training mode.
+    shift: the bias of the convolution that produced x when the caller left it out (it cancels in
+    the normalisation; it still enters the running mean, and its gradient is exactly zero)."""
+    return _BnReluFn.apply(x, bn.weight, bn.bias, bn, relu, shift)
 
 
 class _GaussMlpFn(torch.autograd.Function):

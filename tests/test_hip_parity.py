@@ -1086,3 +1086,25 @@ def test_nan_to_zero_and_logits_bce(dev, kernel_family):
         ga, lg.grad = lg.grad.clone(), None
         b = ops.nll_bernoulli(torch.sigmoid(lg), tgt, msk); b.backward()
         close(a, b, 1e-6, 'logits bce'); close(ga, lg.grad, 1e-5, 'logits bce grad')
+
+
+def test_batchnorm_relu_with_elided_conv_bias(dev, kernel_family):
+    """BatchNorm(x + b) == BatchNorm(x): the conv blocks leave the convolution's bias out and hand
+    it to the fused kernel as a shift of the running mean only (common.py:80-84)."""
+    if kernel_family == 'generic':
+        pytest.skip('no sweep involved')
+    from mdmm import ops
+    torch.manual_seed(5)
+    ref, got = nn.BatchNorm2d(12).to(dev), nn.BatchNorm2d(12).to(dev)
+    b = torch.randn(12, device=dev, requires_grad=True)
+    x = torch.randn(9, 12, 8, 8, device=dev)
+    xr, xg = x.clone().requires_grad_(), x.clone().requires_grad_()
+    w = torch.randn_like(x)
+    yr = torch.relu(ref(xr + b.view(1, -1, 1, 1))); (yr * w).sum().backward()
+    gb_ref, b.grad = b.grad.clone(), None
+    yg = ops.batchnorm_relu(xg, got, shift=b); (yg * w).sum().backward()
+    close(yg, yr, 2e-5, 'bn out'); close(xg.grad, xr.grad, 1e-4, 'bn dx')
+    close(got.running_mean, ref.running_mean, 1e-5, 'running mean')
+    close(got.running_var, ref.running_var, 1e-5, 'running var')
+    assert b.grad is not None and float(b.grad.abs().max()) == 0.0
+    assert float(gb_ref.abs().max()) < 1e-3 * float(w.abs().sum())      # the stock gradient is rounding noise
