@@ -1194,7 +1194,8 @@ class _GruSkipFn(torch.autograd.Function):
         h_prev = torch.cat([h_seq[1:], first], 0) if reverse else torch.cat([first, h_seq[:-1]], 0)
         hp = h_prev.reshape(T * B, H)
         gg = g_gh.reshape(T * B, 3 * Hp)
-        g_w = torch.cat([gg[:, g * Hp:g * Hp + H].t() @ hp for g in range(3)], 0)
+        hp = hp.contiguous()
+        g_w = torch.cat([spill_wgrad(gg, g * Hp, H, hp, 0, H) for g in range(3)], 0)     # dW_hh = g_gh^T h_prev
         g_b = None
         if ctx.has_bias:
             sb = gg.sum(0)
@@ -1276,9 +1277,9 @@ class _DksCombinerFn(torch.autograd.Function):
         _call('mdmm_dks_combiner_bwd', C.byref(a), tag='dks_bwd[D=%d,H=%d]' % (D, H))
         g_gtf = ctx.packed.unpack_grads(G, X, ctx.gtf_like)
         gsum = Gc.sum(0)
-        g_wz = (Gc[:, :Hp].t() @ Xc[:, :Dp])[:H, :D]
-        g_wm = (Gc[:, Hp:Hp + Dp].t() @ Xc[:, Dp:])[:D, :H]
-        g_ws = (Gc[:, Hp + Dp:].t() @ Xc[:, Dp:])[:D, :H]
+        g_wz = spill_wgrad(Gc, 0, H, Xc, 0, D)                  # own contraction over the T*B rows
+        g_wm = spill_wgrad(Gc, Hp, D, Xc, Dp, H)
+        g_ws = spill_wgrad(Gc, Hp + Dp, D, Xc, Dp, H)
         g_bm, g_bs = gsum[Hp:Hp + D], gsum[Hp + Dp:Hp + Dp + D]
         return (None, None, None, None, None, g_u, g_wz, g_wm, g_bm, g_ws, g_bs, *g_gtf)
 
