@@ -96,6 +96,19 @@ int64_t mdmm_gtf_frag_bytes(int D, int H, int precision);   /* 0: (D,H) outside 
 int mdmm_gtf_frag_pack(const mdmm_gtf_raw_t* raw, int D, int H, int precision, void* out,
                        void* stream);
 
+/* The same fragment layout for any list of 256 x 256 layers (the DKS recurrences' W_hh gate blocks,
+ * the combiner's W_z / W_m / W_s): layer i of the pack is w[i] ([out][in] row-major with leading
+ * dimension ld[i]; transposed first when tr[i] != 0).  mdmm_layers_frag_bytes(n, precision) bytes.  */
+#define MDMM_MAX_FRAG_LAYERS 12
+typedef struct mdmm_frag_layers {
+  const float* w[MDMM_MAX_FRAG_LAYERS];
+  int32_t ld[MDMM_MAX_FRAG_LAYERS];
+  int32_t tr[MDMM_MAX_FRAG_LAYERS];
+  int32_t n, reserved;
+} mdmm_frag_layers_t;
+int64_t mdmm_layers_frag_bytes(int n_layers, int precision);
+int mdmm_layers_frag_pack(const mdmm_frag_layers_t* layers, int precision, void* out, void* stream);
+
 /* One Gaussian expert entering the per-step product of experts (dgts.py:15-51).
  * mean/std are (T,B,D) (pass_stride == 0: shared by all passes, e.g. an encoder
  * output) or (P,T,B,D) (pass_stride == T*B*D: one slab per pass, e.g. the filter-pass
@@ -301,6 +314,11 @@ typedef struct mdmm_gru {
   float* g_gi;          /* (T,B,3H) */
   float* g_gh;          /* (T,B,3Hp) d/d(W_hh h + b_hh): caller forms dW_hh = g_gh^T h_prev */
   float* g_h0;          /* (H) += (atomic; zero first) */
+  /* H = 256: with w_frag set (mdmm_layers_frag_pack of the three [H][H] gate blocks of W_hh, then
+   * their transposes) the scan runs on the wide MFMA kernels (csrc/dks_wide.hip); precision as
+   * for the sweeps.  w_hh / wt_hh are then unused, b_hh still is.  */
+  const void* w_frag;
+  int32_t precision, reserved1;
 } mdmm_gru_t;
 int mdmm_gru_skip_fwd(const mdmm_gru_t* args, void* stream);
 int mdmm_gru_skip_bwd(const mdmm_gru_t* args, void* stream);
@@ -349,6 +367,12 @@ typedef struct mdmm_dks {
   float* spill_x;
   float* spill_gc;
   float* spill_xc;
+  /* D = H = 256: with gtf_frag (mdmm_gtf_frag_pack of self.fwd) and comb_frag
+   * (mdmm_layers_frag_pack of W_z, W_m, W_s, W_z^T, W_m^T, W_s^T) set the scan runs on the wide
+   * MFMA kernels; the spill_* rows keep their layout.  */
+  const void* gtf_frag;
+  const void* comb_frag;
+  int32_t precision, reserved1;
 } mdmm_dks_t;
 int mdmm_dks_combiner_fwd(const mdmm_dks_t* args, void* stream);
 int mdmm_dks_combiner_bwd(const mdmm_dks_t* args, void* stream);

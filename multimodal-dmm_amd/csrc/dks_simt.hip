@@ -5,7 +5,7 @@
 // a 4x4 register-tiled GEMM stage against weights streamed from L2 (simt_tiles.h).  The
 // backward kernels are reverse scans that recompute the step from the saved (T,B,.) states.
 #include "simt_tiles.h"
-#include "../../include/mdmm_hip.h"
+#include "sweep_internal.h"
 
 namespace {
 
@@ -385,18 +385,30 @@ int check_dks(const mdmm_dks_t* a, bool bwd) {
 }  // namespace
 
 extern "C" int mdmm_gru_skip_fwd(const mdmm_gru_t* a, void* stream) {
+  if (a && a->w_frag) {                       // wide family first (dks_wide.hip)
+    const int wrc = mdmm_gru_wide(a, 0, (hipStream_t)stream);
+    if (wrc != MDMM_UNSUPPORTED) return wrc;
+  }
   int rc = check_gru(a, false);
   if (rc) return rc;
   return launch(gru_fwd_kernel, a, a->B, (size_t)4 * pad4(a->H) * sizeof(float), (hipStream_t)stream);
 }
 
 extern "C" int mdmm_gru_skip_bwd(const mdmm_gru_t* a, void* stream) {
+  if (a && a->w_frag) {                       // wide family first (dks_wide.hip)
+    const int wrc = mdmm_gru_wide(a, 1, (hipStream_t)stream);
+    if (wrc != MDMM_UNSUPPORTED) return wrc;
+  }
   int rc = check_gru(a, true);
   if (rc) return rc;
   return launch(gru_bwd_kernel, a, a->B, (size_t)9 * pad4(a->H) * sizeof(float), (hipStream_t)stream);
 }
 
 extern "C" int mdmm_dks_combiner_fwd(const mdmm_dks_t* a, void* stream) {
+  if (a && a->gtf_frag) {                       // wide family first (dks_wide.hip)
+    const int wrc = mdmm_dks_wide(a, 0, (hipStream_t)stream);
+    if (wrc != MDMM_UNSUPPORTED) return wrc;
+  }
   int rc = check_dks(a, false);
   if (rc) return rc;
   const int Dp = pad4(a->D), Hp = pad4(a->H);
@@ -404,6 +416,10 @@ extern "C" int mdmm_dks_combiner_fwd(const mdmm_dks_t* a, void* stream) {
 }
 
 extern "C" int mdmm_dks_combiner_bwd(const mdmm_dks_t* a, void* stream) {
+  if (a && a->gtf_frag) {                       // wide family first (dks_wide.hip)
+    const int wrc = mdmm_dks_wide(a, 1, (hipStream_t)stream);
+    if (wrc != MDMM_UNSUPPORTED) return wrc;
+  }
   int rc = check_dks(a, true);
   if (rc) return rc;
   const int Dp = pad4(a->D), Hp = pad4(a->H);

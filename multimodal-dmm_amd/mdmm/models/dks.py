@@ -108,7 +108,7 @@ class MultiDKS(MultiDGTS):
             gi = ops._TallLinearFn.apply(x, w_ih, b_ih).reshape(t_max, b_dim, -1)
             h_new, h_seq = ops.gru_skip(gi, w_hh, b_hh, self.h0[m][layer, 0],
                                         mask.to(torch.float32) if self.rnn_skip else None,
-                                        self.rnn_dir == 'bwd', self.rnn_skip)
+                                        self.rnn_dir == 'bwd', self.rnn_skip, precision=self.sweep_dtype)
             x = h_new.reshape(t_max * b_dim, -1)
         return h_seq
 
@@ -137,7 +137,8 @@ class MultiDKS(MultiDGTS):
         noise = self._noise()
         cfg = dict(T=t_max, B=b_dim, D=self.z_dim, H=self.h_dim, sample=sample,
                    sample_init=sample_init, min_std_gtf=float(self.fwd.min_std),
-                   min_std_comb=float(self.combiner.min_std), seed=0, offset=0)
+                   min_std_comb=float(self.combiner.min_std), seed=0, offset=0,
+                   precision=self.sweep_dtype)
         eps = None
         if noise.replay:
             n = t_max if sample else (1 if sample_init else 0)
@@ -229,7 +230,8 @@ class MultiDKS(MultiDGTS):
         noise = self._noise()
         cfg = dict(T=t_max, B=rows, D=self.z_dim, H=self.h_dim, sample=sample,
                    sample_init=sample_init, min_std_gtf=float(self.fwd.min_std),
-                   min_std_comb=float(self.combiner.min_std), seed=0, offset=0)
+                   min_std_comb=float(self.combiner.min_std), seed=0, offset=0,
+                   precision=self.sweep_dtype)
         eps = None
         if noise.replay:        # the reference draws pass after pass (dgts.py:119-129)
             n = t_max if sample else (1 if sample_init else 0)

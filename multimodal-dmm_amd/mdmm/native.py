@@ -29,6 +29,7 @@ SYMBOLS = [
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
     'mdmm_philox_normal', 'mdmm_debug_clock', 'mdmm_gtf_pack_size', 'mdmm_gtf_pack',
     'mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd', 'mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd',
+    'mdmm_layers_frag_bytes', 'mdmm_layers_frag_pack',
     'mdmm_gauss_mlp_supported', 'mdmm_gauss_mlp_dw_width', 'mdmm_gauss_mlp_dw_rows',
     'mdmm_gauss_mlp_fwd', 'mdmm_gauss_mlp_bwd',
     'mdmm_bn_splits', 'mdmm_bn_relu_fwd', 'mdmm_bn_relu_bwd',
@@ -70,10 +71,19 @@ class Sweep(C.Structure):
                  ('wide_ws', _P), ('wide_ws_bytes', C.c_int64)])
 
 
+MAX_FRAG_LAYERS = 12
+
+
+class FragLayers(C.Structure):
+    _fields_ = [('w', _P * MAX_FRAG_LAYERS), ('ld', C.c_int32 * MAX_FRAG_LAYERS),
+                ('tr', C.c_int32 * MAX_FRAG_LAYERS), ('n', C.c_int32), ('reserved', C.c_int32)]
+
+
 class Gru(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('T', 'B', 'H', 'reverse', 'skip', 'reserved')] +
                 [(n, _P) for n in ('gi', 'w_hh', 'wt_hh', 'b_hh', 'h0', 'mask', 'h_new', 'h_seq',
-                                   'g_h_new', 'g_h_seq', 'g_gi', 'g_gh', 'g_h0')])
+                                   'g_h_new', 'g_h_seq', 'g_gi', 'g_gh', 'g_h0', 'w_frag')] +
+                [('precision', C.c_int32), ('reserved1', C.c_int32)])
 
 
 class Dks(C.Structure):
@@ -85,7 +95,8 @@ class Dks(C.Structure):
                                    'z0_mean', 'z0_std', 't_stop', 'infer_mean', 'infer_std',
                                    'prior_mean', 'prior_std', 'z', 'g_infer_mean', 'g_infer_std',
                                    'g_prior_mean', 'g_prior_std', 'g_z', 'g_u', 'spill_g',
-                                   'spill_x', 'spill_gc', 'spill_xc')])
+                                   'spill_x', 'spill_gc', 'spill_xc', 'gtf_frag', 'comb_frag')] +
+                [('precision', C.c_int32), ('reserved1', C.c_int32)])
 
 
 class Mlp(C.Structure):
@@ -174,6 +185,9 @@ def lib():
         L.mdmm_gtf_frag_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
         L.mdmm_gtf_frag_bytes.restype = C.c_int64
         L.mdmm_gtf_frag_pack.argtypes = [C.POINTER(GtfRaw), C.c_int, C.c_int, C.c_int, _P, _P]
+        L.mdmm_layers_frag_bytes.argtypes = [C.c_int, C.c_int]
+        L.mdmm_layers_frag_bytes.restype = C.c_int64
+        L.mdmm_layers_frag_pack.argtypes = [C.POINTER(FragLayers), C.c_int, _P, _P]
         L.mdmm_sweep_wide.argtypes = [C.POINTER(Sweep)]
         L.mdmm_sweep_wide_ws_bytes.argtypes = [C.POINTER(Sweep)]
         L.mdmm_sweep_wide_ws_bytes.restype = C.c_int64

@@ -245,6 +245,46 @@ def packed_frag(params, D, H, precision):
     return hit[1]
 
 
+class LayersPack:
+    """Fragment-ordered pack of a list of 256 x 256 layers (fp32 [out][in] views with unit column
+    stride; transposed first where flagged): include/mdmm_hip.h, mdmm_layers_frag_pack."""
+
+    def __init__(self, layers, precision):
+        fl = native.FragLayers()
+        for i, (w, tr) in enumerate(layers):
+            if w.dtype != torch.float32 or tuple(w.shape) != (256, 256) or w.stride(1) != 1:
+                raise native.MdmmError('fragment packs take fp32 256 x 256 layers')
+            fl.w[i], fl.ld[i], fl.tr[i] = w.data_ptr(), w.stride(0), int(tr)
+        fl.n = len(layers)
+        nbytes = native.lib().mdmm_layers_frag_bytes(fl.n, precision)
+        self.precision = precision
+        self.buf = torch.empty(nbytes, device=layers[0][0].device, dtype=torch.uint8)
+        _call('mdmm_layers_frag_pack', C.byref(fl), precision, _ptr(self.buf))
+
+
+def packed_layers(params, slot, layers_of, precision):
+    """LayersPack cached on params[0] under `slot`; layers_of() lists the (view, transposed) pairs."""
+    key = tuple((p.data_ptr(), p._version) for p in params) + (precision,)
+    name = '_mdmm_lfrag_' + slot
+    hit = getattr(params[0], name, None)
+    if hit is None or hit[0] != key:
+        hit = (key, LayersPack(layers_of(), precision))
+        setattr(params[0], name, hit)
+    return hit[1]
+
+
+def wide_dks(D, H, precision):
+    """The DKS recurrences run on the wide MFMA kernels (csrc/dks_wide.hip) at z = h = 256 with
+    bf16 operands.  With fp32 operands those kernels are exact but no faster than the generic
+    fp32 kernels (a T-step latency chain on the 2-deep fp32 MFMA), so fp32 stays on the generic
+    ones unless MDMM_DKS_WIDE_F32=1 (the parity tests pin the wide kernels' logic that way)."""
+    import os
+    if D != 256 or H != 256 or os.environ.get('MDMM_FORCE_GENERIC') == '1' \
+            or os.environ.get('MDMM_NO_WIDE') == '1':
+        return False
+    return PRECISIONS[precision] == native.PREC_BF16 or os.environ.get('MDMM_DKS_WIDE_F32') == '1'
+
+
 PRECISIONS = {None: native.PREC_F32, 'fp32': native.PREC_F32, torch.float32: native.PREC_F32,
               'bf16': native.PREC_BF16, torch.bfloat16: native.PREC_BF16}
 
@@ -269,6 +309,8 @@ def clear_caches(params=()):
             del p._mdmm_pack
         if hasattr(p, '_mdmm_frag'):
             del p._mdmm_frag
+        for name in [n for n in vars(p) if n.startswith('_mdmm_lfrag_')]:
+            delattr(p, name)
 
 
 # ------------------------------------------------------------------------------------
@@ -1144,33 +1186,46 @@ class _GruSkipFn(torch.autograd.Function):
     mdmm_gru_skip_fwd/_bwd.  gi = W_ih x + b_ih for all t is the caller's (time-parallel) GEMM."""
 
     @staticmethod
-    def forward(ctx, T, B, H, reverse, skip, gi, w_hh, b_hh, h0, mask):
+    def forward(ctx, T, B, H, reverse, skip, gi, w_hh, b_hh, h0, mask, precision):
         ctx.set_materialize_grads(False)
         _need_gpu(gi, w_hh, h0)
         dev = gi.device
         Hp = pad(H)
-        w = w_hh.detach()
-        blocks = [_pad2(w[g * H:(g + 1) * H], Hp, Hp) for g in range(3)]
-        w_pad = torch.cat(blocks, 0)                                   # [3Hp][Hp]
-        bias = (torch.cat([_pad1(b_hh.detach()[g * H:(g + 1) * H], Hp) for g in range(3)])
-                if b_hh is not None else torch.zeros(3 * Hp, device=dev))
-        buf = torch.cat([w_pad.reshape(-1), w_pad.t().reshape(-1), bias])
         gi = _f32c(gi)
         h0v = _f32c(h0.detach().reshape(-1))
         h_new = torch.empty(T, B, H, device=dev, dtype=torch.float32)
         h_seq = torch.empty(T, B, H, device=dev, dtype=torch.float32)
         a = native.Gru()
         a.T, a.B, a.H, a.reverse, a.skip = T, B, H, int(reverse), int(skip)
-        base = buf.data_ptr()
-        a.w_hh, a.wt_hh, a.b_hh = base, base + 4 * 3 * Hp * Hp, base + 8 * 3 * Hp * Hp
+        ctx.frag = ctx.buf = None
+        if wide_dks(H, H, precision) and w_hh.dtype == torch.float32 and w_hh.is_contiguous():
+            blocks = lambda: ([(w_hh.detach()[g * H:(g + 1) * H], False) for g in range(3)] +
+                              [(w_hh.detach()[g * H:(g + 1) * H], True) for g in range(3)])
+            ctx.frag = packed_layers([w_hh], 'gru', blocks, PRECISIONS[precision])
+            ctx.bias = _f32c(b_hh.detach()) if b_hh is not None else torch.zeros(3 * H, device=dev)
+        else:
+            w = w_hh.detach()
+            w_pad = torch.cat([_pad2(w[g * H:(g + 1) * H], Hp, Hp) for g in range(3)], 0)       # [3Hp][Hp]
+            bias = (torch.cat([_pad1(b_hh.detach()[g * H:(g + 1) * H], Hp) for g in range(3)])
+                    if b_hh is not None else torch.zeros(3 * Hp, device=dev))
+            ctx.buf = torch.cat([w_pad.reshape(-1), w_pad.t().reshape(-1), bias])
+        _GruSkipFn._weights(a, ctx, Hp)
         a.gi, a.h0, a.mask = _ptr(gi), _ptr(h0v), _ptr(mask)
         a.h_new, a.h_seq = _ptr(h_new), _ptr(h_seq)
         _call('mdmm_gru_skip_fwd', C.byref(a), tag='gru_fwd[H=%d]' % H)
         ctx.dims = (T, B, H, int(reverse), int(skip))
-        ctx.buf, ctx.mask, ctx.has_bias = buf, mask, b_hh is not None
+        ctx.mask, ctx.has_bias = mask, b_hh is not None
         ctx.h0_shape = h0.shape
         ctx.save_for_backward(gi, h0v, h_seq)
         return h_new, h_seq
+
+    @staticmethod
+    def _weights(a, ctx, Hp):
+        if ctx.frag is not None:
+            a.w_frag, a.precision, a.b_hh = _ptr(ctx.frag.buf), ctx.frag.precision, _ptr(ctx.bias)
+        else:
+            base = ctx.buf.data_ptr()
+            a.w_hh, a.wt_hh, a.b_hh = base, base + 4 * 3 * Hp * Hp, base + 8 * 3 * Hp * Hp
 
     @staticmethod
     def backward(ctx, g_h_new, g_h_seq):
@@ -1183,8 +1238,7 @@ class _GruSkipFn(torch.autograd.Function):
         g_h0 = torch.zeros(H, device=dev, dtype=torch.float32)
         a = native.Gru()
         a.T, a.B, a.H, a.reverse, a.skip = T, B, H, reverse, skip
-        base = ctx.buf.data_ptr()
-        a.w_hh, a.wt_hh, a.b_hh = base, base + 4 * 3 * Hp * Hp, base + 8 * 3 * Hp * Hp
+        _GruSkipFn._weights(a, ctx, Hp)
         a.gi, a.h0, a.mask, a.h_seq = _ptr(gi), _ptr(h0v), _ptr(ctx.mask), _ptr(h_seq)
         a.g_h_new, a.g_h_seq = _ptr(g_h_new), _ptr(g_h_seq)
         a.g_gi, a.g_gh, a.g_h0 = _ptr(g_gi), _ptr(g_gh), _ptr(g_h0)
@@ -1200,14 +1254,15 @@ class _GruSkipFn(torch.autograd.Function):
         if ctx.has_bias:
             sb = gg.sum(0)
             g_b = torch.cat([sb[g * Hp:g * Hp + H] for g in range(3)])
-        return (None, None, None, None, None, g_gi, g_w, g_b, g_h0.reshape(ctx.h0_shape), None)
+        return (None, None, None, None, None, g_gi, g_w, g_b, g_h0.reshape(ctx.h0_shape), None, None)
 
 
-def gru_skip(gi, w_hh, b_hh, h0, mask, reverse, skip):
-    """gi (T,B,3H) -> (h_new, h_seq), each (T,B,H) time-indexed."""
+def gru_skip(gi, w_hh, b_hh, h0, mask, reverse, skip, precision=None):
+    """gi (T,B,3H) -> (h_new, h_seq), each (T,B,H) time-indexed.  precision: operand type of the
+    recurrent GEMMs where the wide kernels run (H = 256); fp32 otherwise."""
     T, B, H3 = gi.shape
     return _GruSkipFn.apply(T, B, H3 // 3, reverse, skip, gi, w_hh, b_hh, h0,
-                            _f32c(mask) if mask is not None else None)
+                            _f32c(mask) if mask is not None else None, precision)
 
 
 class _DksCombinerFn(torch.autograd.Function):
@@ -1231,8 +1286,15 @@ class _DksCombinerFn(torch.autograd.Function):
         u = _f32c(u)
         z0m, z0s = _f32c(z0_mean.reshape(-1)), _f32c(z0_std.reshape(-1))
         outs = [torch.empty(T, B, D, device=dev, dtype=torch.float32) for _ in range(5)]
+        ctx.frags = None
+        if wide_dks(D, H, cfg.get('precision')) and all(w.dtype == torch.float32 for w in (w_z, w_m, w_s)):
+            prec = PRECISIONS[cfg.get('precision')]
+            views = (w_z.detach(), w_m.detach(), w_s.detach())
+            comb = packed_layers([w_z._base if w_z._base is not None else w_z, w_m, w_s], 'comb',
+                                 lambda: [(v, False) for v in views] + [(v, True) for v in views], prec)
+            ctx.frags = (packed_frag(gtf_params, D, H, prec), comb)
         a = native.Dks()
-        _DksCombinerFn._fill(a, cfg, eps, packed, buf, offs, u, z0m, z0s, t_stop)
+        _DksCombinerFn._fill(a, cfg, eps, packed, buf, offs, u, z0m, z0s, t_stop, ctx.frags)
         a.infer_mean, a.infer_std, a.prior_mean, a.prior_std, a.z = [_ptr(x) for x in outs]
         _call('mdmm_dks_combiner_fwd', C.byref(a), tag='dks_fwd[D=%d,H=%d]' % (D, H))
         ctx.cfg, ctx.eps, ctx.packed, ctx.buf, ctx.offs, ctx.t_stop = cfg, eps, packed, buf, offs, t_stop
@@ -1241,7 +1303,9 @@ class _DksCombinerFn(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
-    def _fill(a, cfg, eps, packed, buf, offs, u, z0m, z0s, t_stop):
+    def _fill(a, cfg, eps, packed, buf, offs, u, z0m, z0s, t_stop, frags=None):
+        if frags is not None:
+            a.gtf_frag, a.comb_frag, a.precision = _ptr(frags[0].buf), _ptr(frags[1].buf), frags[0].precision
         a.T, a.B, a.D, a.H = cfg['T'], cfg['B'], cfg['D'], cfg['H']
         a.sample, a.sample_init = int(cfg['sample']), int(cfg['sample_init'])
         a.min_std_gtf, a.min_std_comb = cfg['min_std_gtf'], cfg['min_std_comb']
@@ -1260,7 +1324,8 @@ class _DksCombinerFn(torch.autograd.Function):
         dev, Dp, Hp = u.device, pad(D), pad(H)
         L = native.lib()
         a = native.Dks()
-        _DksCombinerFn._fill(a, cfg, ctx.eps, ctx.packed, ctx.buf, ctx.offs, u, z0m, z0s, ctx.t_stop)
+        _DksCombinerFn._fill(a, cfg, ctx.eps, ctx.packed, ctx.buf, ctx.offs, u, z0m, z0s, ctx.t_stop,
+                             ctx.frags)
         a.z = _ptr(z)
         grads = [_f32c(g) for g in (g_im, g_is, g_pm, g_ps, g_z)]
         (a.g_infer_mean, a.g_infer_std, a.g_prior_mean, a.g_prior_std, a.g_z) = [_ptr(g) for g in grads]

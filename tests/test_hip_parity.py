@@ -764,11 +764,16 @@ def test_dks_philox_matches_oracle_weizmann_like_dims(dev, kernel_family):
         grad_close(p.grad, ref, k)
 
 
-def test_dks_cfg4_shape_matches_oracle(dev, kernel_family):
+@pytest.mark.parametrize('path', ['generic', 'wide_f32', 'wide_bf16'])
+def test_dks_cfg4_shape_matches_oracle(dev, kernel_family, path, monkeypatch):
     """BASELINE cfg4 shape on a batch the oracle can do: MultiDKS b-skip, feat_to_z, uni_loss,
-    z = h = 256, feature encoders 4096 / 4096 / 256 wide (dks.py:102-106; comb_dim 9472)."""
-    if kernel_family == 'generic':
-        pytest.skip('the DKS kernels have one family')
+    z = h = 256, feature encoders 4096 / 4096 / 256 wide (dks.py:102-106; comb_dim 9472).
+    'generic' = the fp32 SIMT recurrences (csrc/dks_simt.hip); 'wide_*' = the MFMA recurrences of
+    csrc/dks_wide.hip with fp32 operands (same tolerance) and bf16 operands (TOL_*_BF16)."""
+    if kernel_family == 'generic' and path != 'generic':
+        pytest.skip('MDMM_FORCE_GENERIC pins the generic kernels')
+    monkeypatch.setenv('MDMM_NO_WIDE', '1' if path == 'generic' else '0')
+    monkeypatch.setenv('MDMM_DKS_WIDE_F32', '1' if path == 'wide_f32' else '0')
     from mdmm import models, ops
     from mdmm.noise import PhiloxNoise
     from helpers import FeatEncoder
@@ -780,6 +785,7 @@ def test_dks_cfg4_shape_matches_oracle(dev, kernel_family):
     kw = dict(h_dim=H, z_dim=D, rnn_layers=1, feat_to_z=True, rnn_dir='bwd', rnn_skip=True)
     mk = lambda: [FeatEncoder(5, 4096), FeatEncoder(7, 4096), FeatEncoder(3, 256)]   # noqa: E731
     m = models.MultiDKS(names, dims, encoders=mk(), device=dev, **kw)
+    m.sweep_dtype = torch.bfloat16 if path == 'wide_bf16' else torch.float32
     o = orc.OracleDKS(names, dims, encoders=mk(), **kw)
     o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
     targets = make_inputs(spec, T, lengths, seed=8)
@@ -799,13 +805,18 @@ def test_dks_cfg4_shape_matches_oracle(dev, kernel_family):
     o.noise = orc.ReplayNoise(draws)
     oloss = o.step(inputs, mask, 0.9, rec, targets=targets, lengths=lengths)
     (oloss / sum(lengths)).backward()
-    close(loss, oloss, TOL_LOSS, 'dks cfg4 loss')
+    bf16 = path == 'wide_bf16'
+    close(loss, oloss, TOL_LOSS_BF16 if bf16 else TOL_LOSS, 'dks cfg4 loss')
     og = dict(o.named_parameters())
     for k, p in m.named_parameters():
         ref = og[k].grad if og[k].grad is not None else torch.zeros_like(og[k])
         if float(ref.abs().max()) < 1e-7:
             continue
-        grad_close(p.grad, ref, k)
+        if bf16:
+            e = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30))
+            assert e < TOL_GRAD_BF16, 'dks cfg4 bf16 grad %s: %.3e' % (k, e)
+        else:
+            grad_close(p.grad, ref, k)
 
 
 # Tolerances of the bf16-operand mode of the wide sweeps (MultiDGTS.sweep_dtype = torch.bfloat16):

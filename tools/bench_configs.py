@@ -42,6 +42,8 @@ def weizmann(kind, B, T=40):
                             decoders={'video': C.ImageDecoder(256, n_channels=3), 'mask': C.ImageDecoder(256, n_channels=1)},
                             h_dim=256, z_dim=256, feat_to_z=True, rnn_dir='bwd', rnn_skip=True, device=dev)
     m.noise = PhiloxNoise(seed=1)
+    if os.environ.get('SWEEP_BF16', '1') == '1':     # the headline mode of bench.py (bf16 operands)
+        m.sweep_dtype = torch.bfloat16
     if os.environ.get('AMP') == '1':
         m.plugin_dtype = torch.bfloat16
     g = torch.Generator().manual_seed(1234)
