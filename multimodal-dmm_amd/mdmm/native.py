@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 11
+ABI_VERSION = 12
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
