@@ -1,6 +1,7 @@
 // C-ABI entry points of the BFVI sweep: argument checks, then kernel-family dispatch.
 //   z_dim, h_dim <= 32, K <= 32 : register-chained f32 MFMA kernels (sweep_mfma.hip)
-//   z_dim = h_dim = 256 with a fragment pack (gtf_frag) : wide MFMA kernels (sweep_wide.hip)
+//   z_dim = h_dim = 256 with a fragment pack (gtf_frag) : wide MFMA kernels (sweep_wide.hip;
+//                                 stand-alone z_next: trans_wide.hip)
 //   everything else             : generic LDS-tiled fp32 kernels    (sweep_simt.hip)
 // MDMM_FORCE_GENERIC=1 in the environment pins the generic family (A/B runs, cross-checks).
 #include <stdlib.h>
@@ -15,6 +16,10 @@ extern "C" int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream) {
   int rc = mdmm_sweep_check_args(args, 0);
   if (rc) return rc;
   if (!force_generic()) {
+    if (args->trans_only && args->gtf_frag) {
+      rc = mdmm_wide_trans(args, 0, (hipStream_t)stream);
+      if (rc != MDMM_UNSUPPORTED) return rc;
+    }
     rc = mdmm_wide_sweep_fwd(args, (hipStream_t)stream);
     if (rc != MDMM_UNSUPPORTED) return rc;
     rc = mdmm_mfma_sweep_fwd(args, (hipStream_t)stream);
@@ -27,6 +32,10 @@ extern "C" int mdmm_bfvi_sweep_bwd(const mdmm_sweep_t* args, void* stream) {
   int rc = mdmm_sweep_check_args(args, 1);
   if (rc) return rc;
   if (!force_generic()) {
+    if (args->trans_only && args->gtf_frag) {
+      rc = mdmm_wide_trans(args, 1, (hipStream_t)stream);
+      if (rc != MDMM_UNSUPPORTED) return rc;
+    }
     if (args->wide_ws && mdmm_wide_bwd_supported(args)) return mdmm_wide_sweep_bwd(args, (hipStream_t)stream);
     rc = mdmm_mfma_sweep_bwd(args, (hipStream_t)stream);
     if (rc != MDMM_UNSUPPORTED) return rc;

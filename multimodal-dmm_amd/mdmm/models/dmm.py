@@ -166,7 +166,7 @@ class MultiDMM(MultiDGTS):
         """dmm.py:214-258: transition prior from particles z (K,B,D) -> (B,D) mean, std.
         The global prior is always the model's own (what every caller passes)."""
         return ops.gtf_transition(z, self._gtf(direction), self.z0_mean, self.z0_log_std,
-                                  self.h_dim, self.min_std)
+                                  self.h_dim, self.min_std, precision=self.sweep_dtype)
 
     def z_sample(self, t_max, b_dim, direction='fwd', sample=True, n_particles=1, z_init=None,
                  inclusive=False, eps=None):
@@ -424,7 +424,7 @@ class MultiDMM(MultiDGTS):
         # the main stream before any stream forks off (a pack built on a forked stream would be
         # cached and then read by the others without a dependency -- a race under graph replay).
         for direction in ('fwd', 'bwd'):
-            ops.packed_gtf(self._gtf(direction), self.z_dim, self.h_dim)
+            ops.prepack_gtf(self._gtf(direction), self.z_dim, self.h_dim, self.sweep_dtype)
         if match_mult > 0:
             if self._match_stream is None:
                 self._match_stream = torch.cuda.Stream(device=self.z0_mean.device)

@@ -302,6 +302,28 @@ def wide_shape(cfg, bwd=False):
     return cfg.K <= (64 if bwd else 128)
 
 
+def prepack_gtf(params, D, H, precision):
+    """Build (or refresh) every cached operand pack of one GaussianGTF on the current stream.  A
+    step that forks streams calls this before the fork: a pack built on a forked stream would be
+    cached and then read by the other streams without a dependency."""
+    packed_gtf(params, D, H)
+    import os
+    if D == 256 and H == 256 and os.environ.get('MDMM_FORCE_GENERIC') != '1' \
+            and os.environ.get('MDMM_NO_WIDE') != '1':
+        packed_frag(params, D, H, PRECISIONS[precision])
+
+
+def wide_trans(cfg):
+    """Stand-alone z_next on the wide tiles (csrc/trans_wide.hip): z = h = 256, K <= 64 particles
+    with bf16 operands, K <= 32 with fp32 operands."""
+    import os
+    if not cfg.trans_only or cfg.D != 256 or cfg.H != 256:
+        return False
+    if os.environ.get('MDMM_FORCE_GENERIC') == '1' or os.environ.get('MDMM_NO_WIDE') == '1':
+        return False
+    return cfg.K <= (32 if PRECISIONS[cfg.precision] == native.PREC_F32 else 64)
+
+
 def clear_caches(params=()):
     """Drop host-side caches (call before capturing a step into a HIP graph)."""
     for p in params:
@@ -523,6 +545,7 @@ class _TransFn(torch.autograd.Function):
         z = _f32c(z_rows)
         dev = z.device
         packed = packed_gtf(gtf_params, cfg.D, cfg.H)
+        frag = packed_frag(gtf_params, cfg.D, cfg.H, PRECISIONS[cfg.precision]) if wide_trans(cfg) else None
         z0m, z0s = _f32c(z0_mean.detach().reshape(-1)), _f32c(z0_log_std.detach().reshape(-1))
         pm = torch.empty(cfg.B, cfg.D, device=dev, dtype=torch.float32)
         ps = torch.empty_like(pm)
@@ -531,8 +554,10 @@ class _TransFn(torch.autograd.Function):
         s.E = 0
         s.z_rows = _ptr(z)
         s.prior_mean, s.prior_std = _ptr(pm), _ptr(ps)
+        if frag is not None:
+            s.gtf_frag, s.precision = _ptr(frag.buf), frag.precision
         _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('fwd', cfg))
-        ctx.cfg, ctx.packed = cfg, packed
+        ctx.cfg, ctx.packed, ctx.frag = cfg, packed, frag
         ctx.gtf_like = [p.detach() for p in gtf_params]
         ctx.z0_shapes = (z0_mean.shape, z0_log_std.shape)
         ctx.save_for_backward(z, z0m, z0s, pm, ps)
@@ -559,15 +584,18 @@ class _TransFn(torch.autograd.Function):
         G = torch.empty(rows, L.mdmm_sweep_spill_width_g(cfg.D, cfg.H), device=dev)
         X = torch.empty(rows, L.mdmm_sweep_spill_width_x(cfg.D, cfg.H), device=dev)
         s.spill_g, s.spill_x, s.spill_rows = _ptr(G), _ptr(X), rows
+        if ctx.frag is not None:
+            s.gtf_frag, s.precision = _ptr(ctx.frag.buf), ctx.frag.precision
         _call('mdmm_bfvi_sweep_bwd', C.byref(s), tag=_sweep_tag('bwd', cfg))
         g_gtf = packed.unpack_grads(G, X, ctx.gtf_like)
         return (None, gz, gz0[0].reshape(ctx.z0_shapes[0]),
                 (gz0[1] * torch.exp(z0s)).reshape(ctx.z0_shapes[1]), *g_gtf)
 
 
-def gtf_transition(z_rows, gtf_params, z0_mean, z0_log_std, H, min_std):
+def gtf_transition(z_rows, gtf_params, z0_mean, z0_log_std, H, min_std, precision=None):
     K, B, D = z_rows.shape
-    cfg = SweepCfg(T=1, B=B, D=D, H=H, P=1, K=K, min_std=min_std, trans_only=True)
+    cfg = SweepCfg(T=1, B=B, D=D, H=H, P=1, K=K, min_std=min_std, trans_only=True,
+                   precision=precision)
     return _TransFn.apply(cfg, z_rows, z0_mean, z0_log_std, *gtf_params)
 
 

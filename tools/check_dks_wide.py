@@ -68,11 +68,32 @@ def comb_case(seed, T, B, sample, sample_init):
     return run
 
 
+def trans_case(seed, K, B):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    shapes = [(H, D), (H,), (D, H), (D,), (D, D), (D,), (H, D), (H,), (D, H), (D,), (D, D), (D,)]
+    gtf = [(r(*s) * (0.06 if len(s) == 2 else 0.1)).requires_grad_() for s in shapes]
+    z = r(K, B, D).requires_grad_()
+    z0m, z0s = (r(D) * 0.1).requires_grad_(), (r(D) * 0.1).requires_grad_()
+    c1, c2 = r(B, D), r(B, D)
+    leaves = [z, z0m, z0s] + gtf
+
+    def run(prec):
+        for t in leaves:
+            t.grad = None
+        pm, ps = ops.gtf_transition(z, gtf, z0m, z0s, H, 1e-3, precision=prec)
+        ((pm * c1).sum() + (ps * c2).sum()).backward()
+        return [pm.detach(), ps.detach()], [t.grad.clone() for t in leaves]
+    return run
+
+
 def compare(name, run):
     os.environ['MDMM_NO_WIDE'] = '1'
     ref, gref = run(torch.float32)
     os.environ['MDMM_NO_WIDE'] = '0'
     for prec in (torch.float32, torch.bfloat16):
+        if 'f32-generic' in name and prec is torch.float32:
+            continue
         got, ggot = run(prec)
         tag = 'f32' if prec is torch.float32 else 'bf16'
         print('%-34s %-4s out %.2e  grad max %.2e  grad L2 %.2e' % (
@@ -88,6 +109,11 @@ for ci, (T, B, rev, skip) in enumerate([(5, 11, 0, 1), (6, 37, 1, 1), (4, 3, 0, 
     compare('gru T=%d B=%d rev=%d skip=%d' % (T, B, rev, skip), gru_case(ci, T, B, rev, skip))
 for ci, (T, B, smp, sinit) in enumerate([(5, 11, 1, 0), (6, 37, 0, 1), (1, 3, 1, 0), (4, 300, 1, 0), (4, 5, 0, 0)]):
     compare('comb T=%d B=%d smp=%d init=%d' % (T, B, smp, sinit), comb_case(ci, T, B, smp, sinit))
+
+for ci, (K, B) in enumerate([(25, 3), (32, 1), (7, 2)]):
+    compare('trans K=%d B=%d' % (K, B), trans_case(ci, K, B))
+for ci, (K, B) in enumerate([(50, 1), (64, 3), (33, 2)]):
+    compare('trans K=%d B=%d (f32-generic)' % (K, B), trans_case(ci, K, B))
 
 if kw['time']:
     for name, mk in (('gru T=32 B=256', lambda: gru_case(1, 32, 256, 0, 1)),
