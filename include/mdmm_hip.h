@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 12
+#define MDMM_ABI_VERSION 13
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -458,6 +458,33 @@ typedef struct mdmm_bn {
 int mdmm_bn_splits(int64_t N, int C, int64_t L);
 int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream);
 int mdmm_bn_relu_bwd(const mdmm_bn_t* a, void* stream);
+
+/* Stride-2 convolution pyramids of the image plug-ins (common.py:70-112, 114-175): Conv =
+ * nn.Conv2d(k3, s2, p1), Deconv = nn.ConvTranspose2d(k4, s2, p1) on 64 x 64 frames.  A layer
+ * links a SMALL side (S x S, CS channels) and a BIG side (2S x 2S, CB channels); the weight
+ * tensor is torch's, [CS][CB][KS][KS] (Conv: small = output; Deconv: small = input).  fp32 NCHW
+ * activations, bf16 operands, fp32 accumulation (csrc/conv_tiles.hip).
+ *   mdmm_conv_up    big   = conv_transpose(small)      Deconv forward / Conv input gradient
+ *   mdmm_conv_down  small = conv(big)                  Conv forward / Deconv input gradient
+ *   mdmm_conv_wgrad dW[cs][cb][ky][kx] over N images   (small, big = the layer's two activations
+ *                                                       or one activation and one gradient)
+ * `wfrag` = mdmm_conv_pack(args, up, weight): the weights as MFMA fragments for that direction.
+ * `bias` (optional) is added per output channel.  mdmm_conv_supported: (S, CS, CB) in
+ * {(8,64,32), (16,32,16), (32,16,1..4)}, KS in {3,4}.  */
+typedef struct mdmm_conv {
+  int32_t N, S, CS, CB, KS, reserved;
+  float* small;          /* (N, CS, S, S)    */
+  float* big;            /* (N, CB, 2S, 2S)  */
+  const void* wfrag;
+  const float* bias;
+} mdmm_conv_t;
+int mdmm_conv_supported(const mdmm_conv_t* args);
+int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* args, int up);
+int mdmm_conv_pack(const mdmm_conv_t* args, int up, const float* weight, void* out, void* stream);
+int mdmm_conv_up(const mdmm_conv_t* args, void* stream);
+int mdmm_conv_down(const mdmm_conv_t* args, void* stream);
+int64_t mdmm_conv_wgrad_ws_bytes(const mdmm_conv_t* args);
+int mdmm_conv_wgrad(const mdmm_conv_t* args, void* ws, float* dw, void* stream);
 
 #ifdef __cplusplus
 }

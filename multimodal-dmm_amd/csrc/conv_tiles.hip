@@ -1,0 +1,508 @@
+// Stride-2 convolution pyramids of the image plug-ins (common.py:70-112: Conv = Conv2d(k3,s2,p1),
+// Deconv = ConvTranspose2d(k4,s2,p1); ImageEncoder / ImageDecoder common.py:114-175) as implicit
+// GEMMs on the bf16 matrix cores.  fp32 NCHW activations in HBM, operands rounded to bf16 when
+// they are staged, fp32 accumulation.
+//
+// A layer links a SMALL side (S x S pixels, CS channels) and a BIG side (2S x 2S pixels, CB
+// channels); torch's weight tensor is [CS][CB][KS][KS] for both layer kinds (Conv: small = output,
+// Deconv: small = input).  Three kernels cover forward, input gradient and weight gradient of both:
+//   up    (small -> big): Deconv forward / Conv input gradient.  Output pixels split into the four
+//         (row, column) parity classes; each class is a 2 x 2-tap stride-1 convolution of the small
+//         side (taps a Conv's 3 x 3 kernel does not have carry zero weights).  One wave per class.
+//   down  (big -> small): Conv forward / Deconv input gradient: KS x KS taps gathered at stride 2.
+//   wgrad : dW[cs][cb][ky][kx] = sum over images and small pixels of small * shifted big.
+// In all three a workgroup stages whole images in LDS (channels-last bf16 with a zero halo, or for
+// wgrad column-parity planes so that eight consecutive pixels are 16 contiguous bytes), the weights
+// are MFMA A operands (rows = output channels) and the pixels are the B operand's 32 columns, so
+// that a lane ends up with one pixel x 16 channels and stores along x.
+// Shapes: (S, CS, CB) in {(8,64,32), (16,32,16), (32,16,1..4)}, KS in {3,4}: the 64 x 64 pyramids
+// of the reference's image models (n_kernels = 64, n_layers = 3).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mdmm_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mma(f32x16& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                acc, 0, 0, 0);
+}
+__device__ __forceinline__ constexpr int acc_row(int reg) { return 8 * (reg >> 2) + (reg & 3); }   // + 4 h
+
+template <int S, int CS, int CB>
+struct Shape {
+  static constexpr int CBP = CB;                          // big-side channels as staged (4 = padded 1..4)
+  static constexpr bool THIN = CB == 4;
+  static constexpr int B2 = 2 * S;                        // big grid
+  static constexpr int MT_S = (CS + 31) / 32;             // row tiles over the small-side channels
+  // up: patch of the small side, channels-last, halo 1
+  static constexpr int UP_PS = CS * 2 + 16, UP_PW = S + 2;
+  static constexpr int UP_CH = 4 * CS / 16;               // operand chunks per class (2 x 2 taps)
+  static constexpr int UP_LDS = UP_PW * UP_PW * UP_PS;
+  // down: patch of the big side, channels-last, halo 1
+  static constexpr int DN_PS = THIN ? 8 : CB * 2 + 16, DN_PW = B2 + 2;
+  static constexpr int DN_LDS_P = DN_PW * DN_PW * DN_PS;
+};
+template <int S, int CS, int CB, int KS>
+struct Down {
+  using G = Shape<S, CS, CB>;
+  static constexpr int CH = G::THIN ? KS : KS * KS * CB / 16;    // chunks of the contraction
+  static constexpr int W_LDS = G::MT_S * CH * 1024;
+  static constexpr int LDS = W_LDS + G::DN_LDS_P;
+};
+
+// ------------------------------------------------------------------------------ packs ----
+// A-operand fragments: entry [tile][chunk][lane] = 8 bf16, row m = 32 tile + lane % 32,
+// contraction index k = 16 chunk + 8 (lane / 32) + j.
+template <int S, int CS, int CB>
+__global__ void pack_up_kernel(const float* w, int cb, int KS, uint4* out) {
+  using G = Shape<S, CS, CB>;
+  const int total = 4 * G::UP_CH * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, c = (idx >> 6) % G::UP_CH, cls = (idx >> 6) / G::UP_CH;
+    const int py = cls >> 1, px = cls & 1, m = lane & 31, h = lane >> 5;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * c + 8 * h + j, tap = k / CS, ci = k % CS;
+      const int ky = 3 - py - 2 * (tap >> 1), kx = 3 - px - 2 * (tap & 1);
+      float x = 0.f;
+      if (m < cb && ky < KS && kx < KS) x = w[((size_t)(ci * cb + m) * KS + ky) * KS + kx];
+      v[j] = (__bf16)x;
+    }
+    out[idx] = __builtin_bit_cast(uint4, v);
+  }
+}
+
+template <int S, int CS, int CB, int KS>
+__global__ void pack_down_kernel(const float* w, int cb, uint4* out) {
+  using G = Shape<S, CS, CB>;
+  using D = Down<S, CS, CB, KS>;
+  const int total = G::MT_S * D::CH * 64;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, c = (idx >> 6) % D::CH, mt = (idx >> 6) / D::CH;
+    const int m = 32 * mt + (lane & 31), h = lane >> 5;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int ky, kx, ch;
+      if (G::THIN) { ky = c; kx = (8 * h + j) >> 2; ch = (8 * h + j) & 3; }
+      else { const int k = 16 * c + 8 * h + j, tap = k / CB; ch = k % CB; ky = tap / KS; kx = tap % KS; }
+      float x = 0.f;
+      if (m < CS && ch < cb && kx < KS && ky < KS) x = w[((size_t)(m * cb + ch) * KS + ky) * KS + kx];
+      v[j] = (__bf16)x;
+    }
+    out[idx] = __builtin_bit_cast(uint4, v);
+  }
+}
+
+// --------------------------------------------------------------------------------- up ----
+// big[n][m][2y+py][2x+px] = bias[m] + sum_{ci, a, b} small[n][ci][y+py+a-1][x+px+b-1] W[ci][m][3-py-2a][3-px-2b]
+template <int S, int CS, int CB>
+__global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
+  using G = Shape<S, CS, CB>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const int py = wave >> 1, px = wave & 1, cb = a.CB;
+  // this class's weights stay in registers for the whole kernel
+  uint4 wf[G::UP_CH];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.wfrag) + (size_t)wave * G::UP_CH * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < G::UP_CH; ++c) wf[c] = src[c * 64];
+  }
+  for (int i = threadIdx.x; i < G::UP_LDS / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
+  float bias[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = acc_row(r) + 4 * h;
+    bias[r] = (a.bias && m < cb) ? a.bias[m] : 0.f;
+  }
+  __syncthreads();
+  constexpr int NPIX = S * S, NCG = CS / 8;
+  for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
+    const float* src = a.small + (size_t)n * CS * NPIX;
+    for (int it = threadIdx.x; it < NPIX * NCG; it += 256) {
+      const int p = it % NPIX, cg = it / NPIX, y = p / S, x = p % S;
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (__bf16)src[(size_t)(cg * 8 + j) * NPIX + p];
+      *reinterpret_cast<uint4*>(smem + ((y + 1) * G::UP_PW + x + 1) * G::UP_PS + cg * 16) = __builtin_bit_cast(uint4, v);
+    }
+    __syncthreads();
+    float* dst = a.big + (size_t)n * cb * (4 * NPIX);
+    for (int tile = 0; tile < NPIX / 32; ++tile) {
+      const int p = tile * 32 + (lane & 31), y = p / S, x = p % S;
+      const char* base = smem + ((y + py) * G::UP_PW + x + px) * G::UP_PS + 16 * h;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = bias[r];
+#pragma unroll
+      for (int c = 0; c < G::UP_CH; ++c) {
+        const int tap = (16 * c) / CS, off = (16 * c) % CS;
+        const uint4 bv = *reinterpret_cast<const uint4*>(base + ((tap >> 1) * G::UP_PW + (tap & 1)) * G::UP_PS + off * 2);
+        mma(acc, wf[c], bv);
+      }
+      float* o = dst + (size_t)(2 * y + py) * G::B2 + 2 * x + px;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = acc_row(r) + 4 * h;
+        if (m < cb) o[(size_t)m * (4 * NPIX)] = acc[r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------- down ----
+// small[n][m][y][x] = bias[m] + sum_{ch, ky, kx} big[n][ch][2y-1+ky][2x-1+kx] W[m][ch][ky][kx]
+template <int S, int CS, int CB, int KS>
+__global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
+  using G = Shape<S, CS, CB>;
+  using D = Down<S, CS, CB, KS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wl = smem;
+  char* patch = smem + D::W_LDS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, cb = a.CB;
+  for (int i = threadIdx.x; i < D::W_LDS / 16; i += 256)
+    reinterpret_cast<uint4*>(wl)[i] = reinterpret_cast<const uint4*>(a.wfrag)[i];
+  for (int i = threadIdx.x; i < G::DN_LDS_P / 16; i += 256) reinterpret_cast<uint4*>(patch)[i] = uint4{0, 0, 0, 0};
+  __syncthreads();
+  constexpr int NPIX = S * S, BPIX = 4 * NPIX, B2 = G::B2;
+  for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
+    const float* src = a.big + (size_t)n * cb * BPIX;
+    if constexpr (G::THIN) {
+      for (int p = threadIdx.x; p < BPIX; p += 256) {
+        const int y = p / B2, x = p % B2;
+        bf16x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (__bf16)(j < cb ? src[(size_t)j * BPIX + p] : 0.f);
+        *reinterpret_cast<uint2*>(patch + ((y + 1) * G::DN_PW + x + 1) * 8) = __builtin_bit_cast(uint2, v);
+      }
+    } else {
+      constexpr int NCG = CB / 8;
+      for (int it = threadIdx.x; it < BPIX * NCG; it += 256) {
+        const int p = it % BPIX, cg = it / BPIX, y = p / B2, x = p % B2;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)src[(size_t)(cg * 8 + j) * BPIX + p];
+        *reinterpret_cast<uint4*>(patch + ((y + 1) * G::DN_PW + x + 1) * G::DN_PS + cg * 16) = __builtin_bit_cast(uint4, v);
+      }
+    }
+    __syncthreads();
+    float* dst = a.small + (size_t)n * CS * NPIX;
+    constexpr int NT = NPIX / 32;
+    for (int job = wave; job < NT * G::MT_S; job += 4) {
+      const int tile = job % NT, mt = job / NT;
+      const int p = tile * 32 + (lane & 31), y = p / S, x = p % S;
+      const char* base = patch + ((2 * y) * G::DN_PW + 2 * x) * G::DN_PS;
+      const uint4* wrow = reinterpret_cast<const uint4*>(wl) + (size_t)mt * D::CH * 64 + lane;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * mt + acc_row(r) + 4 * h;
+        acc[r] = (a.bias && m < CS) ? a.bias[m] : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < D::CH; ++c) {
+        uint4 bv;
+        if constexpr (G::THIN) {
+          bv = *reinterpret_cast<const uint4*>(base + (c * G::DN_PW + 2 * h) * 8);
+        } else {
+          const int tap = (16 * c) / CB, off = (16 * c) % CB + 8 * h;
+          bv = *reinterpret_cast<const uint4*>(base + ((tap / KS) * G::DN_PW + tap % KS) * G::DN_PS + off * 2);
+        }
+        mma(acc, wrow[c * 64], bv);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * mt + acc_row(r) + 4 * h;
+        if (m < CS) dst[(size_t)m * NPIX + p] = acc[r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------ wgrad ----
+// part[wg][cs][n = tap * cb + b] = sum over the workgroup's images and small pixels (y, x) of
+//   small[cs][y][x] * big[b][2y-1+ky][2x-1+kx],  tap = ky * KS + kx.
+// LDS: small planar [cs][S*S] bf16; big as four column planes per channel, plane q(kx) holding
+// column 2x - 1 + kx at index x (kx = 0..3), rows with a halo: [q][b][2S+2][S].
+template <int S, int CS, int CB, int KS>
+struct Wg {
+  using G = Shape<S, CS, CB>;
+  static constexpr int NPIX = S * S;
+  static constexpr int SM_RS = NPIX * 2 + 16;                    // row stride of the small image
+  static constexpr int SM_LDS = CS * SM_RS;
+  static constexpr int PL_ROWS = 2 * S + 2;
+  static constexpr int PL_LDS = 4 * CB * PL_ROWS * S * 2;
+  static constexpr int LDS = SM_LDS + PL_LDS;
+  static constexpr int KCH = NPIX / 16;                           // contraction chunks per image
+};
+
+template <int S, int CS, int CB, int KS>
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, float* part, int NT) {
+  using G = Shape<S, CS, CB>;
+  using W = Wg<S, CS, CB, KS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sm = smem;
+  char* pl = smem + W::SM_LDS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, cb = a.CB;
+  const int NCOL = KS * KS * cb;                                  // columns (tap, b)
+  const int jobs = G::MT_S * NT;                                  // output tiles
+  // waves share the tiles; with fewer tiles than waves the contraction is split instead
+  const int ksplit = jobs >= 8 ? 1 : 8 / jobs;
+  const int my_ks = jobs >= 8 ? 0 : wave / jobs;
+  const bool idle = my_ks >= ksplit;                              // 8 is not a multiple of `jobs`
+  constexpr int MAXJ = 4;
+  f32x16 acc[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  for (int i = threadIdx.x; i < W::LDS / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
+  // per job: this lane's column -> byte offset of its plane row set (or -1)
+  int col_off[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int job = (jobs >= 8 ? wave : wave % jobs) + 8 * j;
+    col_off[j] = -1;
+    if (job < jobs) {
+      const int nt = job % NT, col = 32 * nt + (lane & 31);
+      if (col < NCOL) {
+        const int tap = col / cb, b = col % cb, ky = tap / KS, kx = tap % KS;
+        col_off[j] = ((kx * CB + b) * W::PL_ROWS + ky) * S * 2;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NPIX = W::NPIX, BPIX = 4 * NPIX, B2 = 2 * S;
+  for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
+    const float* ssrc = a.small + (size_t)n * CS * NPIX;
+    for (int it = threadIdx.x; it < CS * NPIX / 8; it += 512) {
+      const int c = it / (NPIX / 8), g8 = it % (NPIX / 8);
+      const float4 u0 = *reinterpret_cast<const float4*>(ssrc + (size_t)c * NPIX + g8 * 8);
+      const float4 u1 = *reinterpret_cast<const float4*>(ssrc + (size_t)c * NPIX + g8 * 8 + 4);
+      bf16x8 v;
+      v[0] = (__bf16)u0.x; v[1] = (__bf16)u0.y; v[2] = (__bf16)u0.z; v[3] = (__bf16)u0.w;
+      v[4] = (__bf16)u1.x; v[5] = (__bf16)u1.y; v[6] = (__bf16)u1.z; v[7] = (__bf16)u1.w;
+      *reinterpret_cast<uint4*>(sm + c * W::SM_RS + g8 * 16) = __builtin_bit_cast(uint4, v);
+    }
+    const float* bsrc = a.big + (size_t)n * cb * BPIX;
+    for (int it = threadIdx.x; it < cb * B2 * S; it += 512) {
+      const int x = it % S, Y = (it / S) % B2, b = it / (S * B2);
+      const float2 u = *reinterpret_cast<const float2*>(bsrc + ((size_t)b * B2 + Y) * B2 + 2 * x);
+      const __bf16 e = (__bf16)u.x, o = (__bf16)u.y;
+      auto at = [&](int q, int xi) {
+        return reinterpret_cast<__bf16*>(pl + (((q * CB + b) * W::PL_ROWS + Y + 1) * S + xi) * 2);
+      };
+      *at(1, x) = e;                            // kx = 1: column 2x
+      *at(2, x) = o;                            // kx = 2: column 2x + 1
+      if (x + 1 < S) *at(0, x + 1) = o;         // kx = 0: column 2x' - 1 at x' = x + 1
+      if (x >= 1) *at(3, x - 1) = e;            // kx = 3: column 2x' + 2 at x' = x - 1
+    }
+    __syncthreads();
+    for (int c = idle ? W::KCH : my_ks; c < W::KCH; c += ksplit) {
+      // 16 consecutive small pixels; lane half h takes 8 of them: all in one row y
+      const int p0 = 16 * c + 8 * h, y = p0 / S, x0 = p0 % S;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        const int job = (jobs >= 8 ? wave : wave % jobs) + 8 * j;
+        if (job >= jobs) break;
+        const int mt = job / NT;
+        const uint4 av = *reinterpret_cast<const uint4*>(sm + (32 * mt + (lane & 31)) * W::SM_RS + p0 * 2);
+        uint4 bv = uint4{0, 0, 0, 0};
+        if (col_off[j] >= 0) bv = *reinterpret_cast<const uint4*>(pl + col_off[j] + (2 * y * S + x0) * 2);
+        mma(acc[j], av, bv);
+      }
+    }
+    __syncthreads();
+  }
+  // partial sums: part[(wg * ksplit + ks)][cs][col]
+  if (idle) return;
+  float* out = part + ((size_t)blockIdx.x * ksplit + my_ks) * CS * (32 * NT);
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int job = (jobs >= 8 ? wave : wave % jobs) + 8 * j;
+    if (job >= jobs) break;
+    const int nt = job % NT, mt = job / NT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = 32 * mt + acc_row(r) + 4 * h;
+      if (m < CS) out[(size_t)m * (32 * NT) + 32 * nt + (lane & 31)] = acc[j][r];
+    }
+  }
+}
+
+// dW[cs][b][ky][kx] = sum over parts of part[.][cs][tap * cb + b]
+__global__ void conv_wgrad_reduce_kernel(const float* part, int parts, int CS, int cb, int KS, int ld, float* dw) {
+  const int total = CS * cb * KS * KS;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int kx = idx % KS, ky = (idx / KS) % KS, b = (idx / (KS * KS)) % cb, m = idx / (KS * KS * cb);
+  const int col = (ky * KS + kx) * cb + b;
+  float s = 0.f;
+  for (int p = 0; p < parts; ++p) s += part[((size_t)p * CS + m) * ld + col];
+  dw[idx] = s;
+}
+
+int shape_id(const mdmm_conv_t* a) {
+  if (!a || a->N < 1 || (a->KS != 3 && a->KS != 4)) return -1;
+  if (a->S == 8 && a->CS == 64 && a->CB == 32) return 0;
+  if (a->S == 16 && a->CS == 32 && a->CB == 16) return 1;
+  if (a->S == 32 && a->CS == 16 && a->CB >= 1 && a->CB <= 4) return 2;
+  return -1;
+}
+
+template <typename Kern>
+int set_lds(Kern kern, int bytes) {
+  static bool done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (done[dev]) return 0;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done[dev] = true;
+  return 0;
+}
+
+int grid_for(int N, int per_cu) { const int g = 256 * per_cu; return N < g ? N : g; }
+
+template <int S, int CS, int CB>
+int run_up(const mdmm_conv_t* a, hipStream_t st) {
+  using G = Shape<S, CS, CB>;
+  auto k = conv_up_kernel<S, CS, CB>;
+  int rc = set_lds(k, G::UP_LDS);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2)), dim3(256), G::UP_LDS, st, *a);
+  return (int)hipGetLastError();
+}
+template <int S, int CS, int CB, int KS>
+int run_down(const mdmm_conv_t* a, hipStream_t st) {
+  using D = Down<S, CS, CB, KS>;
+  auto k = conv_down_kernel<S, CS, CB, KS>;
+  int rc = set_lds(k, D::LDS);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k, dim3(grid_for(a->N, D::LDS <= 80 * 1024 ? 2 : 1)), dim3(256), D::LDS, st, *a);
+  return (int)hipGetLastError();
+}
+constexpr int WGRAD_GRID = 256;
+int wgrad_nt(const mdmm_conv_t* a) { return (a->KS * a->KS * a->CB + 31) / 32; }
+int wgrad_parts(const mdmm_conv_t* a) {
+  const int mt = (a->CS + 31) / 32, jobs = mt * wgrad_nt(a);
+  const int grid = a->N < WGRAD_GRID ? a->N : WGRAD_GRID;
+  return grid * (jobs >= 8 ? 1 : 8 / jobs);
+}
+template <int S, int CS, int CB, int KS>
+int run_wgrad(const mdmm_conv_t* a, float* part, hipStream_t st) {
+  using W = Wg<S, CS, CB, KS>;
+  auto k = conv_wgrad_kernel<S, CS, CB, KS>;
+  int rc = set_lds(k, W::LDS);
+  if (rc) return rc;
+  const int grid = a->N < WGRAD_GRID ? a->N : WGRAD_GRID;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), W::LDS, st, *a, part, wgrad_nt(a));
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int mdmm_conv_supported(const mdmm_conv_t* a) { return shape_id(a) >= 0; }
+
+extern "C" int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* a, int up) {
+  const int id = shape_id(a);
+  if (id < 0) return 0;
+  if (up) return (int64_t)4 * (4 * a->CS / 16) * 1024;
+  const int ch = id == 2 ? a->KS : a->KS * a->KS * a->CB / 16;
+  return (int64_t)((a->CS + 31) / 32) * ch * 1024;
+}
+
+extern "C" int mdmm_conv_pack(const mdmm_conv_t* a, int up, const float* w, void* out, void* stream) {
+  const int id = shape_id(a);
+  if (id < 0 || !w || !out) return MDMM_E_ARG;
+  if (((uintptr_t)out) & 15) return MDMM_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  uint4* o = (uint4*)out;
+  if (up) {
+    if (id == 0) hipLaunchKernelGGL((pack_up_kernel<8, 64, 32>), dim3(16), dim3(256), 0, st, w, a->CB, a->KS, o);
+    else if (id == 1) hipLaunchKernelGGL((pack_up_kernel<16, 32, 16>), dim3(16), dim3(256), 0, st, w, a->CB, a->KS, o);
+    else hipLaunchKernelGGL((pack_up_kernel<32, 16, 4>), dim3(16), dim3(256), 0, st, w, a->CB, a->KS, o);
+  } else if (a->KS == 4) {
+    if (id == 0) hipLaunchKernelGGL((pack_down_kernel<8, 64, 32, 4>), dim3(16), dim3(256), 0, st, w, a->CB, o);
+    else if (id == 1) hipLaunchKernelGGL((pack_down_kernel<16, 32, 16, 4>), dim3(16), dim3(256), 0, st, w, a->CB, o);
+    else hipLaunchKernelGGL((pack_down_kernel<32, 16, 4, 4>), dim3(16), dim3(256), 0, st, w, a->CB, o);
+  } else {
+    if (id == 0) hipLaunchKernelGGL((pack_down_kernel<8, 64, 32, 3>), dim3(16), dim3(256), 0, st, w, a->CB, o);
+    else if (id == 1) hipLaunchKernelGGL((pack_down_kernel<16, 32, 16, 3>), dim3(16), dim3(256), 0, st, w, a->CB, o);
+    else hipLaunchKernelGGL((pack_down_kernel<32, 16, 4, 3>), dim3(16), dim3(256), 0, st, w, a->CB, o);
+  }
+  return (int)hipGetLastError();
+}
+
+static int check_io(const mdmm_conv_t* a) {
+  if (shape_id(a) < 0) return MDMM_E_ARG;
+  if (!a->small || !a->big) return MDMM_E_ARG;
+  return 0;
+}
+
+extern "C" int mdmm_conv_up(const mdmm_conv_t* a, void* stream) {
+  int rc = check_io(a);
+  if (rc) return rc;
+  if (!a->wfrag) return MDMM_E_ARG;
+  if (((uintptr_t)a->wfrag) & 15) return MDMM_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  switch (shape_id(a)) {
+    case 0: return run_up<8, 64, 32>(a, st);
+    case 1: return run_up<16, 32, 16>(a, st);
+    default: return run_up<32, 16, 4>(a, st);
+  }
+}
+
+extern "C" int mdmm_conv_down(const mdmm_conv_t* a, void* stream) {
+  int rc = check_io(a);
+  if (rc) return rc;
+  if (!a->wfrag) return MDMM_E_ARG;
+  if (((uintptr_t)a->wfrag) & 15) return MDMM_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int id = shape_id(a);
+  if (a->KS == 4) {
+    if (id == 0) return run_down<8, 64, 32, 4>(a, st);
+    if (id == 1) return run_down<16, 32, 16, 4>(a, st);
+    return run_down<32, 16, 4, 4>(a, st);
+  }
+  if (id == 0) return run_down<8, 64, 32, 3>(a, st);
+  if (id == 1) return run_down<16, 32, 16, 3>(a, st);
+  return run_down<32, 16, 4, 3>(a, st);
+}
+
+extern "C" int64_t mdmm_conv_wgrad_ws_bytes(const mdmm_conv_t* a) {
+  if (shape_id(a) < 0) return 0;
+  return (int64_t)wgrad_parts(a) * a->CS * 32 * wgrad_nt(a) * 4;
+}
+
+extern "C" int mdmm_conv_wgrad(const mdmm_conv_t* a, void* ws, float* dw, void* stream) {
+  int rc = check_io(a);
+  if (rc) return rc;
+  if (!ws || !dw) return MDMM_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int id = shape_id(a);
+  float* part = (float*)ws;
+  if (a->KS == 4) {
+    if (id == 0) rc = run_wgrad<8, 64, 32, 4>(a, part, st);
+    else if (id == 1) rc = run_wgrad<16, 32, 16, 4>(a, part, st);
+    else rc = run_wgrad<32, 16, 4, 4>(a, part, st);
+  } else {
+    if (id == 0) rc = run_wgrad<8, 64, 32, 3>(a, part, st);
+    else if (id == 1) rc = run_wgrad<16, 32, 16, 3>(a, part, st);
+    else rc = run_wgrad<32, 16, 4, 3>(a, part, st);
+  }
+  if (rc) return rc;
+  const int total = a->CS * a->CB * a->KS * a->KS;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, wgrad_parts(a),
+                     a->CS, a->CB, a->KS, 32 * wgrad_nt(a), dw);
+  return (int)hipGetLastError();
+}

@@ -77,6 +77,8 @@ extern "C" size_t mdmm_sizeof(int which) {
     case 5: return sizeof(mdmm_dks_t);
     case 6: return sizeof(mdmm_mlp_t);
     case 7: return sizeof(mdmm_bn_t);
+    case 8: return sizeof(mdmm_conv_t);
+    case 9: return sizeof(mdmm_frag_layers_t);
     default: return 0;
   }
 }

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 12
+ABI_VERSION = 13
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -33,6 +33,8 @@ SYMBOLS = [
     'mdmm_gauss_mlp_supported', 'mdmm_gauss_mlp_dw_width', 'mdmm_gauss_mlp_dw_rows',
     'mdmm_gauss_mlp_fwd', 'mdmm_gauss_mlp_bwd',
     'mdmm_bn_splits', 'mdmm_bn_relu_fwd', 'mdmm_bn_relu_bwd',
+    'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_up', 'mdmm_conv_down',
+    'mdmm_conv_wgrad_ws_bytes', 'mdmm_conv_wgrad',
 ]
 
 _P = C.c_void_p
@@ -115,6 +117,11 @@ class Bn(C.Structure):
                 [('eps', C.c_float), ('momentum', C.c_float)] +
                 [(n, _P) for n in ('x', 'gamma', 'beta', 'running_mean', 'running_var', 'y', 'save_mean',
                                    'save_invstd', 'dy', 'dx', 'dgamma', 'dbeta', 'partial', 'mean_shift')])
+
+
+class Conv(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB', 'KS', 'reserved')] +
+                [(n, _P) for n in ('small', 'big', 'wfrag', 'bias')])
 
 
 class MdmmError(RuntimeError):
@@ -203,9 +210,19 @@ def lib():
         L.mdmm_bn_splits.argtypes = [C.c_int64, C.c_int, C.c_int64]
         L.mdmm_bn_relu_fwd.argtypes = [C.POINTER(Bn), _P]
         L.mdmm_bn_relu_bwd.argtypes = [C.POINTER(Bn), _P]
+        L.mdmm_conv_supported.argtypes = [C.POINTER(Conv)]
+        L.mdmm_conv_pack_bytes.argtypes = [C.POINTER(Conv), C.c_int]
+        L.mdmm_conv_pack_bytes.restype = C.c_int64
+        L.mdmm_conv_pack.argtypes = [C.POINTER(Conv), C.c_int, _P, _P, _P]
+        L.mdmm_conv_up.argtypes = [C.POINTER(Conv), _P]
+        L.mdmm_conv_down.argtypes = [C.POINTER(Conv), _P]
+        L.mdmm_conv_wgrad_ws_bytes.argtypes = [C.POINTER(Conv)]
+        L.mdmm_conv_wgrad_ws_bytes.restype = C.c_int64
+        L.mdmm_conv_wgrad.argtypes = [C.POINTER(Conv), _P, _P, _P]
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
-        for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp), (7, Bn)):
+        for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp), (7, Bn), (8, Conv),
+                          (9, FragLayers)):
             if L.mdmm_sizeof(which) != C.sizeof(st):
                 raise MdmmError('struct %s: library %d bytes, binding %d bytes'
                                 % (st.__name__, L.mdmm_sizeof(which), C.sizeof(st)))

@@ -1054,6 +1054,137 @@ def batchnorm_relu(x, bn, relu=True, shift=None):
     return _BnReluFn.apply(x, bn.weight, bn.bias, bn, relu, shift)
 
 
+# ------------------------------------------------------------------------------------
+# stride-2 conv pyramids of the image plug-ins on the bf16 matrix cores (csrc/conv_tiles.hip)
+# ------------------------------------------------------------------------------------
+CONV_OPERANDS = None        # torch.bfloat16 while a model with conv_dtype = bfloat16 runs its plug-ins
+
+
+class conv_operands:
+    """Context: the Conv / Deconv blocks of models.common run on csrc/conv_tiles.hip (bf16 operands,
+    fp32 activations and accumulation) instead of the library's fp32 convolutions."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global CONV_OPERANDS
+        self.prev, CONV_OPERANDS = CONV_OPERANDS, self.dtype
+
+    def __exit__(self, *exc):
+        global CONV_OPERANDS
+        CONV_OPERANDS = self.prev
+
+
+def _conv_desc(n, small_shape, big_shape, ks):
+    a = native.Conv()
+    a.N, a.S, a.CS, a.CB, a.KS = n, small_shape[-1], small_shape[1], big_shape[1], ks
+    return a
+
+
+def conv_tiles_supported(layer, x):
+    """Conv2d(k3,s2,p1) / ConvTranspose2d(k4,s2,p1) of the 64 x 64 pyramids, fp32 on the GPU, while
+    conv_operands(torch.bfloat16) is active."""
+    import torch.nn as nn
+    if CONV_OPERANDS is not torch.bfloat16 or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        return False
+    if torch.is_autocast_enabled() or x.shape[2] != x.shape[3]:
+        return False
+    tr = isinstance(layer, nn.ConvTranspose2d)
+    if not tr and not isinstance(layer, nn.Conv2d):
+        return False
+    ks = 4 if tr else 3
+    if (tuple(layer.kernel_size) != (ks, ks) or tuple(layer.stride) != (2, 2) or tuple(layer.padding) != (1, 1)
+            or tuple(layer.dilation) != (1, 1) or layer.groups != 1 or layer.padding_mode != 'zeros'):
+        return False
+    if tr and tuple(layer.output_padding) != (0, 0):
+        return False
+    cs, cb = layer.weight.shape[0], layer.weight.shape[1]
+    s = x.shape[2] if tr else x.shape[2] // 2
+    if x.shape[1] != (cs if tr else cb) or (not tr and x.shape[2] % 2):
+        return False
+    a = native.Conv()
+    a.N, a.S, a.CS, a.CB, a.KS = x.shape[0], s, cs, cb, ks
+    return bool(native.lib().mdmm_conv_supported(C.byref(a)))
+
+
+def _conv_pack(weight, a, up):
+    """MFMA fragment pack of a layer's weights for one direction, cached on the parameter."""
+    key = (weight.data_ptr(), weight._version, a.S, a.KS)
+    name = '_mdmm_conv_up' if up else '_mdmm_conv_down'
+    hit = getattr(weight, name, None)
+    if hit is None or hit[0] != key:
+        buf = torch.empty(native.lib().mdmm_conv_pack_bytes(C.byref(a), int(up)), device=weight.device,
+                          dtype=torch.uint8)
+        _call('mdmm_conv_pack', C.byref(a), int(up), _ptr(_f32c(weight.detach())), _ptr(buf))
+        hit = (key, buf)
+        setattr(weight, name, hit)
+    return hit[1]
+
+
+class _ConvTilesFn(torch.autograd.Function):
+    """One stride-2 layer of the image pyramids: transposed = ConvTranspose2d(k4,s2,p1) (small ->
+    big), else Conv2d(k3,s2,p1) (big -> small).  weight is torch's [CS][CB][KS][KS] either way."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, transposed):
+        ctx.set_materialize_grads(False)
+        x = _f32c(x)
+        n, ks = x.shape[0], weight.shape[-1]
+        cs, cb = weight.shape[0], weight.shape[1]
+        if transposed:
+            s = x.shape[2]
+            y = torch.empty(n, cb, 2 * s, 2 * s, device=x.device, dtype=torch.float32)
+            small, big = x, y
+        else:
+            s = x.shape[2] // 2
+            y = torch.empty(n, cs, s, s, device=x.device, dtype=torch.float32)
+            small, big = y, x
+        a = _conv_desc(n, small.shape, big.shape, ks)
+        a.small, a.big = _ptr(small), _ptr(big)
+        a.bias = _ptr(_f32c(bias.detach())) if bias is not None else None
+        keep = _conv_pack(weight, a, transposed)
+        a.wfrag = _ptr(keep)
+        _call('mdmm_conv_up' if transposed else 'mdmm_conv_down', C.byref(a),
+              tag='conv_%s[S=%d]' % ('up' if transposed else 'down', s))
+        ctx.transposed, ctx.has_bias = transposed, bias is not None
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _f32c(gy)
+        n, ks = x.shape[0], weight.shape[-1]
+        transposed = ctx.transposed
+        small, big = (x, gy) if transposed else (gy, x)
+        gx = gw = gb = None
+        a = _conv_desc(n, small.shape, big.shape, ks)
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            a.small, a.big = (_ptr(gx), _ptr(gy)) if transposed else (_ptr(gy), _ptr(gx))
+            keep = _conv_pack(weight, a, not transposed)
+            a.wfrag = _ptr(keep)
+            _call('mdmm_conv_down' if transposed else 'mdmm_conv_up', C.byref(a),
+                  tag='conv_%s[S=%d]' % ('down' if transposed else 'up', a.S))
+        if ctx.needs_input_grad[1]:
+            a.small, a.big, a.wfrag = _ptr(small), _ptr(big), None
+            ws = torch.empty(native.lib().mdmm_conv_wgrad_ws_bytes(C.byref(a)), device=x.device, dtype=torch.uint8)
+            gw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
+            _call('mdmm_conv_wgrad', C.byref(a), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % a.S)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb, None
+
+
+def conv_tiles(layer, x, bias=True):
+    """layer(x) for a Conv2d / ConvTranspose2d that conv_tiles_supported accepts (bias=False leaves
+    the layer's bias out, as the blocks in front of a BatchNorm do)."""
+    import torch.nn as nn
+    return _ConvTilesFn.apply(x, layer.weight, layer.bias if bias else None,
+                              isinstance(layer, nn.ConvTranspose2d))
+
+
 class _GaussMlpFn(torch.autograd.Function):
     """GaussianMLP holder in one launch each way (csrc/mlp.hip).  Only x is saved; the backward
     recomputes the hidden layer.  Returns (mean, std, seen); seen (N,) is 1.0 where the row holds
