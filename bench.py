@@ -111,7 +111,7 @@ class Cfg3:
     rec = {'video': 1.0, 'mask': 1.0, 'action': 10.0}
     workload = ('cfg3: Weizmann-shaped synthetic (video 3x64x64 + mask 1x64x64 Bernoulli, action '
                 'Categorical(10)), MultiDMM BFVI, conv encoders/decoders, z=h=256, T=40, B=%d per GPU, '
-                '20%% burst NaN, train_particles=25, sweep contractions bf16 / fp32 accumulate')
+                '20%% burst NaN, train_particles=25, sweep and conv contractions bf16 operands / fp32 accumulate')
     mods, dims = ['video', 'mask', 'action'], [(3, 64, 64), (1, 64, 64), 10]
     dists = ['Bernoulli', 'Bernoulli', 'Categorical']
 
@@ -141,6 +141,7 @@ class Cfg3:
         m = models.MultiDMM(cls.mods, cls.dims, cls.dists, encoders=enc, decoders=dec, h_dim=256,
                             z_dim=256, device=device)
         m.sweep_dtype = torch.bfloat16
+        m.conv_dtype = torch.bfloat16
         return m
 
     @classmethod

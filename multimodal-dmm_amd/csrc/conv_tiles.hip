@@ -126,12 +126,21 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   constexpr int NPIX = S * S, NCG = CS / 8;
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
     const float* src = a.small + (size_t)n * CS * NPIX;
-    for (int it = threadIdx.x; it < NPIX * NCG; it += 256) {
-      const int p = it % NPIX, cg = it / NPIX, y = p / S, x = p % S;
-      bf16x8 v;
+    for (int it = threadIdx.x; it < (NPIX / 4) * NCG; it += 256) {
+      const int p = 4 * (it % (NPIX / 4)), cg = it / (NPIX / 4), y = p / S, x = p % S;
+      float4 u[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (__bf16)src[(size_t)(cg * 8 + j) * NPIX + p];
-      *reinterpret_cast<uint4*>(smem + ((y + 1) * G::UP_PW + x + 1) * G::UP_PS + cg * 16) = __builtin_bit_cast(uint4, v);
+      for (int j = 0; j < 8; ++j) u[j] = *reinterpret_cast<const float4*>(src + (size_t)(cg * 8 + j) * NPIX + p);
+      bf16x8 v0, v1, v2, v3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v0[j] = (__bf16)u[j].x; v1[j] = (__bf16)u[j].y; v2[j] = (__bf16)u[j].z; v3[j] = (__bf16)u[j].w;
+      }
+      char* at = smem + ((y + 1) * G::UP_PW + x + 1) * G::UP_PS + cg * 16;
+      *reinterpret_cast<uint4*>(at) = __builtin_bit_cast(uint4, v0);
+      *reinterpret_cast<uint4*>(at + G::UP_PS) = __builtin_bit_cast(uint4, v1);
+      *reinterpret_cast<uint4*>(at + 2 * G::UP_PS) = __builtin_bit_cast(uint4, v2);
+      *reinterpret_cast<uint4*>(at + 3 * G::UP_PS) = __builtin_bit_cast(uint4, v3);
     }
     __syncthreads();
     float* dst = a.big + (size_t)n * cb * (4 * NPIX);
@@ -176,21 +185,41 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
     const float* src = a.big + (size_t)n * cb * BPIX;
     if constexpr (G::THIN) {
-      for (int p = threadIdx.x; p < BPIX; p += 256) {
-        const int y = p / B2, x = p % B2;
-        bf16x4 v;
+      // four consecutive x per item: one float4 per channel, 32 contiguous bytes of the patch
+      for (int it = threadIdx.x; it < BPIX / 4; it += 256) {
+        const int p = 4 * it, y = p / B2, x = p % B2;
+        float4 u[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (__bf16)(j < cb ? src[(size_t)j * BPIX + p] : 0.f);
-        *reinterpret_cast<uint2*>(patch + ((y + 1) * G::DN_PW + x + 1) * 8) = __builtin_bit_cast(uint2, v);
+        for (int j = 0; j < 4; ++j)
+          u[j] = j < cb ? *reinterpret_cast<const float4*>(src + (size_t)j * BPIX + p) : float4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 lo, hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          lo[j] = (__bf16)u[j].x; lo[4 + j] = (__bf16)u[j].y; hi[j] = (__bf16)u[j].z; hi[4 + j] = (__bf16)u[j].w;
+        }
+        char* at = patch + ((y + 1) * G::DN_PW + x + 1) * 8;          // 8-byte aligned (x + 1 is odd)
+        *reinterpret_cast<uint2*>(at) = uint2{__builtin_bit_cast(uint4, lo).x, __builtin_bit_cast(uint4, lo).y};
+        *reinterpret_cast<uint4*>(at + 8) = uint4{__builtin_bit_cast(uint4, lo).z, __builtin_bit_cast(uint4, lo).w,
+                                                  __builtin_bit_cast(uint4, hi).x, __builtin_bit_cast(uint4, hi).y};
+        *reinterpret_cast<uint2*>(at + 24) = uint2{__builtin_bit_cast(uint4, hi).z, __builtin_bit_cast(uint4, hi).w};
       }
     } else {
       constexpr int NCG = CB / 8;
-      for (int it = threadIdx.x; it < BPIX * NCG; it += 256) {
-        const int p = it % BPIX, cg = it / BPIX, y = p / B2, x = p % B2;
-        bf16x8 v;
+      for (int it = threadIdx.x; it < (BPIX / 4) * NCG; it += 256) {
+        const int p = 4 * (it % (BPIX / 4)), cg = it / (BPIX / 4), y = p / B2, x = p % B2;
+        float4 u[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (__bf16)src[(size_t)(cg * 8 + j) * BPIX + p];
-        *reinterpret_cast<uint4*>(patch + ((y + 1) * G::DN_PW + x + 1) * G::DN_PS + cg * 16) = __builtin_bit_cast(uint4, v);
+        for (int j = 0; j < 8; ++j) u[j] = *reinterpret_cast<const float4*>(src + (size_t)(cg * 8 + j) * BPIX + p);
+        bf16x8 v0, v1, v2, v3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v0[j] = (__bf16)u[j].x; v1[j] = (__bf16)u[j].y; v2[j] = (__bf16)u[j].z; v3[j] = (__bf16)u[j].w;
+        }
+        char* at = patch + ((y + 1) * G::DN_PW + x + 1) * G::DN_PS + cg * 16;
+        *reinterpret_cast<uint4*>(at) = __builtin_bit_cast(uint4, v0);
+        *reinterpret_cast<uint4*>(at + G::DN_PS) = __builtin_bit_cast(uint4, v1);
+        *reinterpret_cast<uint4*>(at + 2 * G::DN_PS) = __builtin_bit_cast(uint4, v2);
+        *reinterpret_cast<uint4*>(at + 3 * G::DN_PS) = __builtin_bit_cast(uint4, v3);
       }
     }
     __syncthreads();
@@ -231,8 +260,10 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
 // ------------------------------------------------------------------------------ wgrad ----
 // part[wg][cs][n = tap * cb + b] = sum over the workgroup's images and small pixels (y, x) of
 //   small[cs][y][x] * big[b][2y-1+ky][2x-1+kx],  tap = ky * KS + kx.
-// LDS: small planar [cs][S*S] bf16; big as four column planes per channel, plane q(kx) holding
-// column 2x - 1 + kx at index x (kx = 0..3), rows with a halo: [q][b][2S+2][S].
+// LDS: small planar [cs][S*S] bf16; big as its even and odd columns, [plane][b][2S+2 rows][S] with
+// 16 zero bytes between rows: eight consecutive x are 16 contiguous bytes of E (kx = 1), O (kx = 2),
+// or the same run moved one element (kx = 0: O from x - 1, kx = 3: E from x + 1), which a lane
+// builds from the aligned run and the dword before / after it.
 template <int S, int CS, int CB, int KS>
 struct Wg {
   using G = Shape<S, CS, CB>;
@@ -240,10 +271,13 @@ struct Wg {
   static constexpr int SM_RS = NPIX * 2 + 16;                    // row stride of the small image
   static constexpr int SM_LDS = CS * SM_RS;
   static constexpr int PL_ROWS = 2 * S + 2;
-  static constexpr int PL_LDS = 4 * CB * PL_ROWS * S * 2;
+  static constexpr int PL_RS = S * 2 + 16;                        // 16 zero bytes, then S bf16
+  static constexpr int PL_LDS = 2 * CB * PL_ROWS * PL_RS + 16;
   static constexpr int LDS = SM_LDS + PL_LDS;
   static constexpr int KCH = NPIX / 16;                           // contraction chunks per image
 };
+
+__device__ __forceinline__ uint32_t shift16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbyte(hi, lo, 2); }
 
 template <int S, int CS, int CB, int KS>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, float* part, int NT) {
@@ -266,17 +300,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   for (int i = threadIdx.x; i < W::LDS / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
-  // per job: this lane's column -> byte offset of its plane row set (or -1)
-  int col_off[MAXJ];
+  // per job: this lane's column -> byte offset of its plane rows (or -1) and its shift (-1, 0, +1)
+  int col_off[MAXJ], col_sh[MAXJ];
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
     const int job = (jobs >= 8 ? wave : wave % jobs) + 8 * j;
-    col_off[j] = -1;
+    col_off[j] = -1; col_sh[j] = 0;
     if (job < jobs) {
       const int nt = job % NT, col = 32 * nt + (lane & 31);
       if (col < NCOL) {
         const int tap = col / cb, b = col % cb, ky = tap / KS, kx = tap % KS;
-        col_off[j] = ((kx * CB + b) * W::PL_ROWS + ky) * S * 2;
+        const int plane = (kx & 1) ? 0 : 1;                        // E holds the even columns
+        col_off[j] = ((plane * CB + b) * W::PL_ROWS + ky) * W::PL_RS + 16;
+        col_sh[j] = kx == 0 ? -1 : (kx == 3 ? 1 : 0);
       }
     }
   }
@@ -294,17 +330,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
       *reinterpret_cast<uint4*>(sm + c * W::SM_RS + g8 * 16) = __builtin_bit_cast(uint4, v);
     }
     const float* bsrc = a.big + (size_t)n * cb * BPIX;
-    for (int it = threadIdx.x; it < cb * B2 * S; it += 512) {
-      const int x = it % S, Y = (it / S) % B2, b = it / (S * B2);
-      const float2 u = *reinterpret_cast<const float2*>(bsrc + ((size_t)b * B2 + Y) * B2 + 2 * x);
-      const __bf16 e = (__bf16)u.x, o = (__bf16)u.y;
-      auto at = [&](int q, int xi) {
-        return reinterpret_cast<__bf16*>(pl + (((q * CB + b) * W::PL_ROWS + Y + 1) * S + xi) * 2);
-      };
-      *at(1, x) = e;                            // kx = 1: column 2x
-      *at(2, x) = o;                            // kx = 2: column 2x + 1
-      if (x + 1 < S) *at(0, x + 1) = o;         // kx = 0: column 2x' - 1 at x' = x + 1
-      if (x >= 1) *at(3, x - 1) = e;            // kx = 3: column 2x' + 2 at x' = x - 1
+    for (int it = threadIdx.x; it < cb * B2 * (B2 / 8); it += 512) {
+      const int xg = it % (B2 / 8), Y = (it / (B2 / 8)) % B2, b = it / ((B2 / 8) * B2);
+      const float* src = bsrc + ((size_t)b * B2 + Y) * B2 + 8 * xg;
+      const float4 u0 = *reinterpret_cast<const float4*>(src), u1 = *reinterpret_cast<const float4*>(src + 4);
+      bf16x4 e, o;
+      e[0] = (__bf16)u0.x; o[0] = (__bf16)u0.y; e[1] = (__bf16)u0.z; o[1] = (__bf16)u0.w;
+      e[2] = (__bf16)u1.x; o[2] = (__bf16)u1.y; e[3] = (__bf16)u1.z; o[3] = (__bf16)u1.w;
+      char* row = pl + ((size_t)b * W::PL_ROWS + Y + 1) * W::PL_RS + 16 + xg * 8;
+      *reinterpret_cast<uint2*>(row) = __builtin_bit_cast(uint2, e);
+      *reinterpret_cast<uint2*>(row + CB * W::PL_ROWS * W::PL_RS) = __builtin_bit_cast(uint2, o);
     }
     __syncthreads();
     for (int c = idle ? W::KCH : my_ks; c < W::KCH; c += ksplit) {
@@ -317,18 +352,39 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
         const int mt = job / NT;
         const uint4 av = *reinterpret_cast<const uint4*>(sm + (32 * mt + (lane & 31)) * W::SM_RS + p0 * 2);
         uint4 bv = uint4{0, 0, 0, 0};
-        if (col_off[j] >= 0) bv = *reinterpret_cast<const uint4*>(pl + col_off[j] + (2 * y * S + x0) * 2);
+        if (col_off[j] >= 0) {
+          const char* at = pl + col_off[j] + 2 * y * W::PL_RS + x0 * 2;
+          const uint4 m = *reinterpret_cast<const uint4*>(at);
+          const uint32_t prev = *reinterpret_cast<const uint32_t*>(at - 4);
+          const uint32_t next = *reinterpret_cast<const uint32_t*>(at + 16);
+          bv = m;
+          if (col_sh[j] < 0) bv = uint4{shift16(m.x, prev), shift16(m.y, m.x), shift16(m.z, m.y), shift16(m.w, m.z)};
+          if (col_sh[j] > 0) bv = uint4{shift16(m.y, m.x), shift16(m.z, m.y), shift16(m.w, m.z), shift16(next, m.w)};
+        }
         mma(acc[j], av, bv);
       }
     }
     __syncthreads();
   }
-  // partial sums: part[(wg * ksplit + ks)][cs][col]
-  if (idle) return;
-  float* out = part + ((size_t)blockIdx.x * ksplit + my_ks) * CS * (32 * NT);
+  // fold the contraction splits of the workgroup through LDS, then one slab per workgroup
+  if (ksplit > 1) {
+    float* red = reinterpret_cast<float*>(smem);
+    if (!idle && my_ks > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][r];
+    }
+    __syncthreads();
+    if (my_ks == 0) {
+      for (int k = 1; k < ksplit; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] += red[((wave + k * jobs) * 16 + r) * 64 + lane];
+    }
+  }
+  if (idle || my_ks > 0) return;
+  float* out = part + (size_t)blockIdx.x * CS * (32 * NT);
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
-    const int job = (jobs >= 8 ? wave : wave % jobs) + 8 * j;
+    const int job = wave + 8 * j;
     if (job >= jobs) break;
     const int nt = job % NT, mt = job / NT;
 #pragma unroll
@@ -337,6 +393,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
       if (m < CS) out[(size_t)m * (32 * NT) + 32 * nt + (lane & 31)] = acc[j][r];
     }
   }
+}
+
+// dst[g][e] = sum over p = g, g + groups, ... of src[p][e]
+__global__ void conv_fold_kernel(const float* src, int parts, int64_t elems, int groups, float* dst) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (e >= elems) return;
+  float s = 0.f;
+  for (int p = g; p < parts; p += groups) s += src[(size_t)p * elems + e];
+  dst[(size_t)g * elems + e] = s;
 }
 
 // dW[cs][b][ky][kx] = sum over parts of part[.][cs][tap * cb + b]
@@ -391,21 +457,16 @@ int run_down(const mdmm_conv_t* a, hipStream_t st) {
   hipLaunchKernelGGL(k, dim3(grid_for(a->N, D::LDS <= 80 * 1024 ? 2 : 1)), dim3(256), D::LDS, st, *a);
   return (int)hipGetLastError();
 }
-constexpr int WGRAD_GRID = 256;
+constexpr int WGRAD_GRID = 512, WGRAD_FOLD = 16;        // two workgroups per CU; second-stage groups
 int wgrad_nt(const mdmm_conv_t* a) { return (a->KS * a->KS * a->CB + 31) / 32; }
-int wgrad_parts(const mdmm_conv_t* a) {
-  const int mt = (a->CS + 31) / 32, jobs = mt * wgrad_nt(a);
-  const int grid = a->N < WGRAD_GRID ? a->N : WGRAD_GRID;
-  return grid * (jobs >= 8 ? 1 : 8 / jobs);
-}
+int wgrad_parts(const mdmm_conv_t* a) { return a->N < WGRAD_GRID ? a->N : WGRAD_GRID; }
 template <int S, int CS, int CB, int KS>
 int run_wgrad(const mdmm_conv_t* a, float* part, hipStream_t st) {
   using W = Wg<S, CS, CB, KS>;
   auto k = conv_wgrad_kernel<S, CS, CB, KS>;
   int rc = set_lds(k, W::LDS);
   if (rc) return rc;
-  const int grid = a->N < WGRAD_GRID ? a->N : WGRAD_GRID;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(512), W::LDS, st, *a, part, wgrad_nt(a));
+  hipLaunchKernelGGL(k, dim3(wgrad_parts(a)), dim3(512), W::LDS, st, *a, part, wgrad_nt(a));
   return (int)hipGetLastError();
 }
 
@@ -481,7 +542,7 @@ extern "C" int mdmm_conv_down(const mdmm_conv_t* a, void* stream) {
 
 extern "C" int64_t mdmm_conv_wgrad_ws_bytes(const mdmm_conv_t* a) {
   if (shape_id(a) < 0) return 0;
-  return (int64_t)wgrad_parts(a) * a->CS * 32 * wgrad_nt(a) * 4;
+  return (int64_t)(wgrad_parts(a) + WGRAD_FOLD) * a->CS * 32 * wgrad_nt(a) * 4;
 }
 
 extern "C" int mdmm_conv_wgrad(const mdmm_conv_t* a, void* ws, float* dw, void* stream) {
@@ -501,8 +562,17 @@ extern "C" int mdmm_conv_wgrad(const mdmm_conv_t* a, void* ws, float* dw, void* 
     else rc = run_wgrad<32, 16, 4, 3>(a, part, st);
   }
   if (rc) return rc;
-  const int total = a->CS * a->CB * a->KS * a->KS;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, part, wgrad_parts(a),
-                     a->CS, a->CB, a->KS, 32 * wgrad_nt(a), dw);
+  const int total = a->CS * a->CB * a->KS * a->KS, ld = 32 * wgrad_nt(a), parts = wgrad_parts(a);
+  const int64_t elems = (int64_t)a->CS * ld;
+  const float* src = part;
+  int n_src = parts;
+  if (parts > WGRAD_FOLD) {
+    float* folded = part + (size_t)parts * elems;
+    hipLaunchKernelGGL(conv_fold_kernel, dim3((unsigned)((elems + 255) / 256), WGRAD_FOLD), dim3(256), 0, st, part,
+                       parts, elems, WGRAD_FOLD, folded);
+    src = folded; n_src = WGRAD_FOLD;
+  }
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, n_src,
+                     a->CS, a->CB, a->KS, ld, dw);
   return (int)hipGetLastError();
 }

@@ -95,6 +95,9 @@ class _ConvBlock(nn.Module):
 
     @staticmethod
     def _conv_nobias(layer, x):
+        from .. import ops
+        if ops.conv_tiles_supported(layer, x):          # own bf16-operand kernels (csrc/conv_tiles.hip)
+            return ops.conv_tiles(layer, x, bias=False)
         if isinstance(layer, (nn.Conv1d, nn.Conv2d)):
             return layer._conv_forward(x, layer.weight, None)
         fn = F.conv_transpose2d if isinstance(layer, nn.ConvTranspose2d) else F.conv_transpose1d
@@ -113,6 +116,9 @@ class _ConvBlock(nn.Module):
             if ops.batchnorm_relu_supported(x, bn) and x.is_cuda:
                 return ops.batchnorm_relu(self._conv_nobias(layer, x), bn, shift=layer.bias)
             return self.net[2](bn(layer(x)))
+        from .. import ops
+        if ops.conv_tiles_supported(self.net, x):
+            return ops.conv_tiles(self.net, x)
         return self.net(x)
 
 

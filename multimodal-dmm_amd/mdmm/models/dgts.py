@@ -22,8 +22,16 @@ class MultiDGTS(nn.Module):
     # (bf16 operands, fp32 accumulation: 16x the matrix rate, what BASELINE cfg3 is quoted in).
     # The latent state, products of experts, moments and reductions are fp32 in both.
     sweep_dtype = torch.float32
+    # Operand type of the stock image plug-ins' stride-2 convolutions (models.common.Conv / Deconv
+    # on 64 x 64 frames): torch.float32 (default; the library's fp32 convolutions) or
+    # torch.bfloat16 (csrc/conv_tiles.hip: bf16 operands on the matrix cores, fp32 activations and
+    # accumulation -- the same contract as sweep_dtype).
+    conv_dtype = torch.float32
 
     def _plug(self, module, x, **kw):
+        if self.plugin_dtype is None and self.conv_dtype is torch.bfloat16 and x.is_cuda:
+            with ops.conv_operands(torch.bfloat16):
+                return module(x, **kw)
         if self.plugin_dtype is None or not x.is_cuda:
             return module(x, **kw)
         with torch.autocast('cuda', dtype=self.plugin_dtype):

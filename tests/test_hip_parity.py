@@ -1119,3 +1119,110 @@ def test_batchnorm_relu_with_elided_conv_bias(dev, kernel_family):
     close(got.running_var, ref.running_var, 1e-5, 'running var')
     assert b.grad is not None and float(b.grad.abs().max()) == 0.0
     assert float(gb_ref.abs().max()) < 1e-3 * float(w.abs().sum())      # the stock gradient is rounding noise
+
+
+CONV_LAYERS = [('deconv', 64, 32, 8), ('deconv', 32, 16, 16), ('deconv', 16, 3, 32), ('deconv', 16, 1, 32),
+               ('conv', 3, 16, 64), ('conv', 1, 16, 64), ('conv', 16, 32, 32), ('conv', 32, 64, 16)]
+
+
+@pytest.mark.parametrize('kind,c_in,c_out,size', CONV_LAYERS)
+def test_conv_tiles_match_torch(dev, kind, c_in, c_out, size):
+    """csrc/conv_tiles.hip (Conv2d k3 s2 p1 / ConvTranspose2d k4 s2 p1 of the 64 x 64 image pyramids,
+    common.py:70-112) against torch on the same bf16-rounded operands: products of bf16 numbers are
+    exact in fp32, so forward, input gradient and weight gradient agree to summation order."""
+    import torch.nn as nn
+    from mdmm import ops
+    torch.manual_seed(c_in * 100 + c_out)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)      # noqa: E731
+    tr = kind == 'deconv'
+    for n in (1, 7, 130):
+        layer = (nn.ConvTranspose2d(c_in, c_out, 4, 2, 1) if tr else nn.Conv2d(c_in, c_out, 3, 2, 1)).to(dev)
+        x = torch.randn(n, c_in, size, size, device=dev, requires_grad=True)
+        with ops.conv_operands(torch.bfloat16):
+            assert ops.conv_tiles_supported(layer, x)
+            y = ops.conv_tiles(layer, x)
+        assert not ops.conv_tiles_supported(layer, x)           # fp32 models keep the library path
+        gy = torch.randn_like(y)
+        gx, gw, gb = torch.autograd.grad(y, [x, layer.weight, layer.bias], gy)
+        fn = torch.nn.functional.conv_transpose2d if tr else torch.nn.functional.conv2d
+        xr, wr = rb(x.detach()).requires_grad_(), rb(layer.weight.detach()).requires_grad_()
+        close(y, fn(xr, wr, layer.bias.detach(), 2, 1), 1e-5, 'conv fwd')
+        gxr, gwr = torch.autograd.grad(fn(xr, wr, None, 2, 1), [xr, wr], rb(gy))
+        close(gx, gxr, 1e-5, 'conv dgrad')
+        close(gw, gwr, 1e-5, 'conv wgrad')
+        close(gb, gy.sum((0, 2, 3)), 1e-5, 'conv bias grad')
+
+
+def test_step_weizmann_frames_conv_bf16_matches_oracle(dev, kernel_family):
+    """Full-size Weizmann plug-ins (64 x 64 frames, the stock ImageEncoder / ImageDecoder pyramids)
+    with conv_dtype = bfloat16 (own bf16-operand convolutions, fused BatchNorm + ReLU, sigmoid + BCE)
+    in a full ELBO step against the oracle running stock fp32 modules on the CPU; small latent so
+    that the oracle is quick.  Tolerances: the bf16-operand ones stated above."""
+    if kernel_family == 'generic':
+        pytest.skip('plug-in path, one family is enough')
+    from mdmm import models, ops
+    from mdmm.models import common as C
+    from mdmm.noise import PhiloxNoise
+    torch.manual_seed(16)
+    mods, dims = ['video', 'mask', 'action'], [(3, 64, 64), (1, 64, 64), 10]
+    dists = ['Bernoulli', 'Bernoulli', 'Categorical']
+    D = H = 32
+
+    def plugins():
+        enc = {'video': C.ImageEncoder(D, n_channels=3), 'mask': C.ImageEncoder(D, n_channels=1)}
+        dec = {'video': C.ImageDecoder(D, n_channels=3), 'mask': C.ImageDecoder(D, n_channels=1)}
+        return enc, dec
+    enc, dec = plugins()
+    m = models.MultiDMM(mods, dims, dists, encoders=enc, decoders=dec, h_dim=H, z_dim=D, device=dev)
+    m.conv_dtype = torch.bfloat16
+    enc, dec = plugins()
+    o = orc.OracleDMM(mods, dims, dists, encoders=enc, decoders=dec, h_dim=H, z_dim=D)
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    T, lengths, K = 5, [5, 4, 2], 25
+    B = len(lengths)
+    g = torch.Generator().manual_seed(3)
+    targets = {'video': torch.rand(T, B, 3, 64, 64, generator=g),
+               'mask': (torch.rand(T, B, 1, 64, 64, generator=g) < 0.5).float(),
+               'action': torch.randint(0, 10, (1, B, 1), generator=g).float().expand(T, B, 1).contiguous()}
+    for k in targets:
+        for b, n in enumerate(lengths):
+            targets[k][n:, b] = float('nan')
+    inputs = {k: v.clone() for k, v in targets.items()}
+    inputs['video'][1:3, 0] = float('nan'); inputs['mask'][2:4, 1] = float('nan')
+    mask = orc.len_to_mask(lengths)
+    rec = {'video': 1.0, 'mask': 1.0, 'action': 10.0}
+    m.noise = PhiloxNoise(seed=33)
+    kw = dict(train_particles=K, match_particles=50)
+    ops.TIMER = timer = ops.KernelTimer()
+    try:
+        loss = m.step(cuda(inputs, dev), mask.to(dev), 1.0, rec, targets=cuda(targets, dev), lengths=lengths, **kw)
+        (loss / sum(lengths)).backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.TIMER = None
+    tags = set(timer.spans)
+    assert any(t.startswith('conv_up') for t in tags) and any(t.startswith('conv_down') for t in tags) \
+        and any(t.startswith('conv_wgrad') for t in tags), tags
+    noise = PhiloxNoise(seed=33)
+    draws = [noise.normal((50, 1, D), dev).cpu(), noise.normal((50, 1, D), dev).cpu()]
+    P, sweeps = 4, []
+    for k in (1, K, 1):
+        sd, off = noise.stream()
+        sweeps.append(ops.philox_normal(sd, off, (P, T, k, B, D), dev).cpu())
+    for p in range(P):
+        draws += [sweeps[0][p, t] for t in reversed(range(T))]
+    for p in range(P):
+        draws += [sweeps[1][p, t] for t in reversed(range(T))]
+        draws += [sweeps[2][p, t] for t in range(T)]
+    o.noise = orc.ReplayNoise(draws)
+    oloss = o.step(inputs, mask, 1.0, rec, targets=targets, lengths=lengths, **kw)
+    (oloss / sum(lengths)).backward()
+    close(loss, oloss, TOL_LOSS_BF16, 'weizmann-frames conv bf16 step loss')
+    og = dict(o.named_parameters())
+    gmax = max(float(v.grad.abs().max()) for v in og.values() if v.grad is not None)
+    for k, p in m.named_parameters():
+        ref = og[k].grad if og[k].grad is not None else torch.zeros_like(og[k])
+        if float(ref.abs().max()) < 1e-4 * gmax:      # conv biases in front of a BatchNorm: exactly zero
+            continue
+        e = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30))
+        assert e < TOL_GRAD_BF16, 'conv bf16 grad %s: %.3e' % (k, e)
