@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 13
+#define MDMM_ABI_VERSION 14
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -485,6 +485,29 @@ int mdmm_conv_up(const mdmm_conv_t* args, void* stream);
 int mdmm_conv_down(const mdmm_conv_t* args, void* stream);
 int64_t mdmm_conv_wgrad_ws_bytes(const mdmm_conv_t* args);
 int mdmm_conv_wgrad(const mdmm_conv_t* args, void* ws, float* dw, void* stream);
+
+/* Time-parallel projections (every nn.Linear applied to all T*B rows at once: dks.py:219-231,
+ * 246-280 GRU input projections / combiner feature columns; the Linear heads of the image
+ * plug-ins, common.py:114-175) as one bf16-operand GEMM (csrc/gemm_tiles.hip):
+ *   c[i*ldc + j] = bias[j] + sum_l A(i,l) B(j,l),  A(i,l) = a[i*lda + l] or (ta) a[l*lda + i],
+ *   B likewise; fp32 in memory, operands rounded to bf16, fp32 accumulation.
+ *   y = x W^T: A = x, B = W;  dx = g W: A = g, B = W with tb;  dW = g^T x: A = g with ta, B = x with
+ *   tb and split > 1 (the contraction over the rows is cut into `split` slices summed through
+ *   `ws`, mdmm_gemm_ws_bytes).  Contiguous dimensions and leading dimensions multiples of 4.  */
+typedef struct mdmm_gemm {
+  int32_t I, J, L, ta, tb, split;
+  const float* a;
+  int64_t lda;
+  const float* b;
+  int64_t ldb;
+  const float* bias;     /* (J) or NULL */
+  float* c;
+  int64_t ldc;
+  float* ws;             /* split > 1: split * I * J floats */
+} mdmm_gemm_t;
+int mdmm_gemm_supported(const mdmm_gemm_t* args);
+int64_t mdmm_gemm_ws_bytes(const mdmm_gemm_t* args);
+int mdmm_gemm_bf16(const mdmm_gemm_t* args, void* stream);
 
 #ifdef __cplusplus
 }

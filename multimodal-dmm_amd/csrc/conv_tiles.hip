@@ -381,16 +381,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
     }
   }
   if (idle || my_ks > 0) return;
-  float* out = part + (size_t)blockIdx.x * CS * (32 * NT);
+  // slab of this workgroup, already in dW's layout [cs][b][ky][kx]
+  float* out = part + (size_t)blockIdx.x * CS * NCOL;
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
     const int job = wave + 8 * j;
     if (job >= jobs) break;
-    const int nt = job % NT, mt = job / NT;
+    const int nt = job % NT, mt = job / NT, col = 32 * nt + (lane & 31);
+    if (col >= NCOL) continue;
+    const int tap = col / cb, b = col % cb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = 32 * mt + acc_row(r) + 4 * h;
-      if (m < CS) out[(size_t)m * (32 * NT) + 32 * nt + (lane & 31)] = acc[j][r];
+      if (m < CS) out[(size_t)m * NCOL + b * (KS * KS) + tap] = acc[j][r];
     }
   }
 }
@@ -403,18 +406,6 @@ __global__ void conv_fold_kernel(const float* src, int parts, int64_t elems, int
   float s = 0.f;
   for (int p = g; p < parts; p += groups) s += src[(size_t)p * elems + e];
   dst[(size_t)g * elems + e] = s;
-}
-
-// dW[cs][b][ky][kx] = sum over parts of part[.][cs][tap * cb + b]
-__global__ void conv_wgrad_reduce_kernel(const float* part, int parts, int CS, int cb, int KS, int ld, float* dw) {
-  const int total = CS * cb * KS * KS;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int kx = idx % KS, ky = (idx / KS) % KS, b = (idx / (KS * KS)) % cb, m = idx / (KS * KS * cb);
-  const int col = (ky * KS + kx) * cb + b;
-  float s = 0.f;
-  for (int p = 0; p < parts; ++p) s += part[((size_t)p * CS + m) * ld + col];
-  dw[idx] = s;
 }
 
 int shape_id(const mdmm_conv_t* a) {
@@ -459,7 +450,10 @@ int run_down(const mdmm_conv_t* a, hipStream_t st) {
 }
 constexpr int WGRAD_GRID = 512, WGRAD_FOLD = 16;        // two workgroups per CU; second-stage groups
 int wgrad_nt(const mdmm_conv_t* a) { return (a->KS * a->KS * a->CB + 31) / 32; }
-int wgrad_parts(const mdmm_conv_t* a) { return a->N < WGRAD_GRID ? a->N : WGRAD_GRID; }
+int wgrad_parts(const mdmm_conv_t* a) {
+  const int g = a->S == 8 ? WGRAD_GRID / 2 : WGRAD_GRID;      // S = 8: 128 KB slabs, one workgroup per CU
+  return a->N < g ? a->N : g;
+}
 template <int S, int CS, int CB, int KS>
 int run_wgrad(const mdmm_conv_t* a, float* part, hipStream_t st) {
   using W = Wg<S, CS, CB, KS>;
@@ -542,7 +536,7 @@ extern "C" int mdmm_conv_down(const mdmm_conv_t* a, void* stream) {
 
 extern "C" int64_t mdmm_conv_wgrad_ws_bytes(const mdmm_conv_t* a) {
   if (shape_id(a) < 0) return 0;
-  return (int64_t)(wgrad_parts(a) + WGRAD_FOLD) * a->CS * 32 * wgrad_nt(a) * 4;
+  return (int64_t)(wgrad_parts(a) + WGRAD_FOLD) * a->CS * a->CB * a->KS * a->KS * 4;
 }
 
 extern "C" int mdmm_conv_wgrad(const mdmm_conv_t* a, void* ws, float* dw, void* stream) {
@@ -562,17 +556,15 @@ extern "C" int mdmm_conv_wgrad(const mdmm_conv_t* a, void* ws, float* dw, void* 
     else rc = run_wgrad<32, 16, 4, 3>(a, part, st);
   }
   if (rc) return rc;
-  const int total = a->CS * a->CB * a->KS * a->KS, ld = 32 * wgrad_nt(a), parts = wgrad_parts(a);
-  const int64_t elems = (int64_t)a->CS * ld;
-  const float* src = part;
-  int n_src = parts;
-  if (parts > WGRAD_FOLD) {
+  const int parts = wgrad_parts(a);
+  const int64_t elems = (int64_t)a->CS * a->CB * a->KS * a->KS;
+  const unsigned blocks = (unsigned)((elems + 255) / 256);
+  if (parts > 4 * WGRAD_FOLD) {
     float* folded = part + (size_t)parts * elems;
-    hipLaunchKernelGGL(conv_fold_kernel, dim3((unsigned)((elems + 255) / 256), WGRAD_FOLD), dim3(256), 0, st, part,
-                       parts, elems, WGRAD_FOLD, folded);
-    src = folded; n_src = WGRAD_FOLD;
+    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, WGRAD_FOLD), dim3(256), 0, st, part, parts, elems, WGRAD_FOLD, folded);
+    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, 1), dim3(256), 0, st, folded, WGRAD_FOLD, elems, 1, dw);
+  } else {
+    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, 1), dim3(256), 0, st, part, parts, elems, 1, dw);
   }
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, src, n_src,
-                     a->CS, a->CB, a->KS, ld, dw);
   return (int)hipGetLastError();
 }

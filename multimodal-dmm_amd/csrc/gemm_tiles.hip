@@ -1,0 +1,191 @@
+// Time-parallel projections of the step (every nn.Linear applied to all T*B rows at once: the
+// GRU input projections and combiner feature columns of MultiDKS dks.py:219-231, 246-280, the
+// Linear heads of the image plug-ins common.py:114-175) as one bf16-operand GEMM kernel:
+//   C[i][j] = bias[j] + sum_l A(i, l) B(j, l),   fp32 in HBM, operands rounded to bf16 when staged,
+//   fp32 accumulation; A(i, l) = a[i*lda + l] or (ta) a[l*lda + i], likewise B.
+//     forward          y  = x W^T   : A = x (M x K),   B = W (N x K)
+//     input gradient   dx = g W     : A = g (M x N),   B = W read transposed (tb)
+//     weight gradient  dW = g^T x   : A = g read transposed (ta), B = x read transposed (tb),
+//                                     the contraction over the M rows split across workgroups
+// Workgroup = 4 waves on a 128 x 128 tile of C, 32 contraction steps at a time through LDS
+// ([row][32 l] bf16, 80-byte rows), each wave a 64 x 64 quadrant (2 x 2 MFMA 32x32x16 tiles);
+// the next step's global loads are in flight while the current one is multiplied.  Transposed
+// operands are staged eight contraction rows at a time (eight coalesced float4 loads, four
+// 16-byte LDS writes), so all three products stream their operands at full line width.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mdmm_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BT = 128;            // tile of C: BT x BT
+constexpr int BL = 32;             // contraction depth per step
+constexpr int RS = BL * 2 + 16;    // LDS row stride (bytes)
+constexpr int TILE_LDS = BT * RS;
+
+__device__ __forceinline__ constexpr int acc_row(int reg) { return 8 * (reg >> 2) + (reg & 3); }   // + 4 h
+
+// One operand tile (BT rows x BL) of the step starting at l0: registers <- global.
+//   direct:      item = (row, l-group of 4): one float4                    -> 4 items / thread
+//   transposed:  item = (l-group of 8, row-group of 4): eight float4       -> 1 item / thread
+struct Regs { float4 v[8]; };
+
+template <bool T>
+__device__ __forceinline__ void load_tile(const float* src, int64_t ld, int rows, int L, int row0, int l0,
+                                          int tid, Regs& r) {
+  if constexpr (!T) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int it = tid + 256 * q, row = it >> 3, lg = it & 7;
+      float4 v = float4{0.f, 0.f, 0.f, 0.f};
+      if (row0 + row < rows && l0 + 4 * lg < L) v = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + row) * ld + l0 + 4 * lg);
+      r.v[q] = v;
+    }
+  } else {
+    const int lg = tid >> 5, rg = tid & 31;          // 4 l-groups x 32 row-groups = 128 threads ...
+    // ... 256 threads: two halves of the l range? no: 32 l = 4 groups of 8, 128 rows = 32 groups of 4
+    // -> 128 items; threads 128..255 take no item (their registers stay zero)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float4 v = float4{0.f, 0.f, 0.f, 0.f};
+      const int l = l0 + 8 * lg + q;
+      if (tid < 128 && l < L && row0 + 4 * rg < rows) v = *reinterpret_cast<const float4*>(src + (int64_t)l * ld + row0 + 4 * rg);
+      r.v[q] = v;
+    }
+  }
+}
+
+template <bool T>
+__device__ __forceinline__ void store_tile(char* lds, int tid, const Regs& r) {
+  if constexpr (!T) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int it = tid + 256 * q, row = it >> 3, lg = it & 7;
+      bf16x4 b;
+      b[0] = (__bf16)r.v[q].x; b[1] = (__bf16)r.v[q].y; b[2] = (__bf16)r.v[q].z; b[3] = (__bf16)r.v[q].w;
+      *reinterpret_cast<uint2*>(lds + row * RS + lg * 8) = __builtin_bit_cast(uint2, b);
+    }
+  } else {
+    if (tid >= 128) return;
+    const int lg = tid >> 5, rg = tid & 31;
+    bf16x8 b0, b1, b2, b3;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      b0[q] = (__bf16)r.v[q].x; b1[q] = (__bf16)r.v[q].y; b2[q] = (__bf16)r.v[q].z; b3[q] = (__bf16)r.v[q].w;
+    }
+    char* at = lds + (4 * rg) * RS + lg * 16;
+    *reinterpret_cast<uint4*>(at) = __builtin_bit_cast(uint4, b0);
+    *reinterpret_cast<uint4*>(at + RS) = __builtin_bit_cast(uint4, b1);
+    *reinterpret_cast<uint4*>(at + 2 * RS) = __builtin_bit_cast(uint4, b2);
+    *reinterpret_cast<uint4*>(at + 3 * RS) = __builtin_bit_cast(uint4, b3);
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(const mdmm_gemm_t g) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2 * TILE_LDS];     // [buffer][A tile | B tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int j0 = blockIdx.x * BT, i0 = blockIdx.y * BT;
+  // contraction range of this workgroup (split > 1: blockIdx.z takes a slice, in steps of BL)
+  const int steps_all = (g.L + BL - 1) / BL;
+  const int per = (steps_all + g.split - 1) / g.split;
+  const int s_lo = blockIdx.z * per, s_hi = min(steps_all, s_lo + per);
+  const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  Regs ra, rb;
+  if (s_lo < s_hi) {
+    load_tile<TA>(g.a, g.lda, g.I, g.L, i0, s_lo * BL, tid, ra);
+    load_tile<TB>(g.b, g.ldb, g.J, g.L, j0, s_lo * BL, tid, rb);
+  }
+  for (int s = s_lo; s < s_hi; ++s) {
+    char* buf = lds[(s - s_lo) & 1];
+    store_tile<TA>(buf, tid, ra);
+    store_tile<TB>(buf + TILE_LDS, tid, rb);
+    __syncthreads();                       // (two buffers: the tile read two steps ago is free)
+    if (s + 1 < s_hi) {
+      load_tile<TA>(g.a, g.lda, g.I, g.L, i0, (s + 1) * BL, tid, ra);
+      load_tile<TB>(g.b, g.ldb, g.J, g.L, j0, (s + 1) * BL, tid, rb);
+    }
+    const char* pa = buf + (wi + (lane & 31)) * RS + 16 * h;
+    const char* pb = buf + TILE_LDS + (wj + (lane & 31)) * RS + 16 * h;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint4 a0 = *reinterpret_cast<const uint4*>(pa + 32 * c), a1 = *reinterpret_cast<const uint4*>(pa + 32 * RS + 32 * c);
+      const uint4 b0 = *reinterpret_cast<const uint4*>(pb + 32 * c), b1 = *reinterpret_cast<const uint4*>(pb + 32 * RS + 32 * c);
+      const bf16x8 A0 = __builtin_bit_cast(bf16x8, a0), A1 = __builtin_bit_cast(bf16x8, a1);
+      const bf16x8 B0 = __builtin_bit_cast(bf16x8, b0), B1 = __builtin_bit_cast(bf16x8, b1);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[1][1], 0, 0, 0);
+    }
+  }
+  // C rows = A rows (registers), C columns = B rows (lanes)
+  float* c = g.split > 1 ? g.ws + (size_t)blockIdx.z * g.I * g.J : g.c;
+  const int64_t ldc = g.split > 1 ? g.J : g.ldc;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int j = j0 + wj + 32 * y + (lane & 31);
+      if (j >= g.J) continue;
+      const float bias = (g.bias && g.split == 1) ? g.bias[j] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi + 32 * x + acc_row(r) + 4 * h;
+        if (i < g.I) c[(int64_t)i * ldc + j] = acc[x][y][r] + bias;
+      }
+    }
+}
+
+// c[i][j] = bias[j] + sum over the split slabs
+__global__ void gemm_fold_kernel(const mdmm_gemm_t g) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, n = (int64_t)g.I * g.J;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < g.split; ++z) s += g.ws[(size_t)z * n + e];
+  const int64_t i = e / g.J, j = e % g.J;
+  g.c[i * g.ldc + j] = s + (g.bias ? g.bias[j] : 0.f);
+}
+
+}  // namespace
+
+extern "C" int mdmm_gemm_supported(const mdmm_gemm_t* g) {
+  if (!g || g->I < 1 || g->J < 1 || g->L < 1 || g->split < 1) return 0;
+  // float4 loads: contiguous dimension of each operand a multiple of 4, 16-byte aligned rows
+  const int64_t ca = g->ta ? g->I : g->L, cb = g->tb ? g->J : g->L;
+  if ((ca & 3) || (cb & 3) || (g->lda & 3) || (g->ldb & 3)) return 0;
+  return 1;
+}
+
+extern "C" int64_t mdmm_gemm_ws_bytes(const mdmm_gemm_t* g) {
+  if (!g || g->split <= 1) return 0;
+  return (int64_t)g->split * g->I * g->J * 4;
+}
+
+extern "C" int mdmm_gemm_bf16(const mdmm_gemm_t* g, void* stream) {
+  if (!mdmm_gemm_supported(g) || !g->a || !g->b || !g->c) return MDMM_E_ARG;
+  if ((((uintptr_t)g->a) | ((uintptr_t)g->b)) & 15) return MDMM_E_ALIGN;
+  if (g->split > 1 && !g->ws) return MDMM_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((g->J + BT - 1) / BT, (g->I + BT - 1) / BT, g->split);
+  if (!g->ta && !g->tb) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, st, *g);
+  else if (!g->ta && g->tb) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, st, *g);
+  else if (g->ta && g->tb) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, st, *g);
+  else hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, st, *g);
+  int rc = (int)hipGetLastError();
+  if (rc || g->split == 1) return rc;
+  const int64_t n = (int64_t)g->I * g->J;
+  hipLaunchKernelGGL(gemm_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *g);
+  return (int)hipGetLastError();
+}

@@ -175,7 +175,9 @@ class _GaussHead(nn.Module):
         if not self.gauss_out:
             return feats
         flat = feats.view(-1, self.feat_dim)
-        return self.feat_to_z_mean(flat), self.feat_to_z_std(flat)
+        from .. import ops
+        return ops.plug_linear(self.feat_to_z_mean, flat), \
+            self.feat_to_z_std[1](ops.plug_linear(self.feat_to_z_std[0], flat))
 
 
 class ImageEncoder(_GaussHead):
@@ -214,7 +216,8 @@ class _ProbDecoder(nn.Module):
         nn.init.xavier_uniform_(self.z_to_feat[0].weight)
 
     def forward(self, z, logits=False):
-        x = self.z_to_feat(z).view(-1, *self.feat_shape)
+        from .. import ops
+        x = self.z_to_feat[1](ops.plug_linear(self.z_to_feat[0], z)).view(-1, *self.feat_shape)
         if logits:      # everything but the final nn.Sigmoid (for the fused sigmoid + BCE loss)
             for layer in list(self.deconv_stack)[:-1]:
                 x = layer(x)

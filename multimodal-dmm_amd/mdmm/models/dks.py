@@ -105,7 +105,7 @@ class MultiDKS(MultiDGTS):
             w_hh = getattr(gru, 'weight_hh_l%d' % layer)
             b_ih = getattr(gru, 'bias_ih_l%d' % layer) if gru.bias else None
             b_hh = getattr(gru, 'bias_hh_l%d' % layer) if gru.bias else None
-            gi = ops._TallLinearFn.apply(x, w_ih, b_ih).reshape(t_max, b_dim, -1)
+            gi = ops.tall_projection(x, w_ih, b_ih, self.sweep_dtype).reshape(t_max, b_dim, -1)
             h_new, h_seq = ops.gru_skip(gi, w_hh, b_hh, self.h0[m][layer, 0],
                                         mask.to(torch.float32) if self.rnn_skip else None,
                                         self.rnn_dir == 'bwd', self.rnn_skip, precision=self.sweep_dtype)
@@ -132,7 +132,7 @@ class MultiDKS(MultiDGTS):
         w_in = self.combiner.in_to_h[0].weight
         rest = [h_out] + ([feats[m] for m in self.modalities] if self.feat_to_z else [])
         rest = torch.cat(rest, dim=-1).reshape(t_max * b_dim, -1)
-        u = ops._TallLinearFn.apply(rest, w_in[:, self.z_dim:], self.combiner.in_to_h[0].bias)
+        u = ops.tall_projection(rest, w_in[:, self.z_dim:], self.combiner.in_to_h[0].bias, self.sweep_dtype)
         u = u.reshape(t_max, b_dim, self.h_dim)
         noise = self._noise()
         cfg = dict(T=t_max, B=b_dim, D=self.z_dim, H=self.h_dim, sample=sample,
@@ -225,8 +225,8 @@ class MultiDKS(MultiDGTS):
         t_stop = torch.cat(stops).to(torch.int32).contiguous()     # (P*B)
         rows = n_pass * b_dim
         w_in = self.combiner.in_to_h[0].weight
-        u = ops._TallLinearFn.apply(rest.reshape(t_max * rows, -1), w_in[:, self.z_dim:],
-                                    self.combiner.in_to_h[0].bias).reshape(t_max, rows, self.h_dim)
+        u = ops.tall_projection(rest.reshape(t_max * rows, -1), w_in[:, self.z_dim:],
+                                self.combiner.in_to_h[0].bias, self.sweep_dtype).reshape(t_max, rows, self.h_dim)
         noise = self._noise()
         cfg = dict(T=t_max, B=rows, D=self.z_dim, H=self.h_dim, sample=sample,
                    sample_init=sample_init, min_std_gtf=float(self.fwd.min_std),

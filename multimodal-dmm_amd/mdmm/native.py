@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 13
+ABI_VERSION = 14
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -35,6 +35,7 @@ SYMBOLS = [
     'mdmm_bn_splits', 'mdmm_bn_relu_fwd', 'mdmm_bn_relu_bwd',
     'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_up', 'mdmm_conv_down',
     'mdmm_conv_wgrad_ws_bytes', 'mdmm_conv_wgrad',
+    'mdmm_gemm_supported', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
 ]
 
 _P = C.c_void_p
@@ -122,6 +123,12 @@ class Bn(C.Structure):
 class Conv(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB', 'KS', 'reserved')] +
                 [(n, _P) for n in ('small', 'big', 'wfrag', 'bias')])
+
+
+class Gemm(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('I', 'J', 'L', 'ta', 'tb', 'split')] +
+                [('a', _P), ('lda', C.c_int64), ('b', _P), ('ldb', C.c_int64), ('bias', _P), ('c', _P),
+                 ('ldc', C.c_int64), ('ws', _P)])
 
 
 class MdmmError(RuntimeError):
@@ -219,10 +226,14 @@ def lib():
         L.mdmm_conv_wgrad_ws_bytes.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_wgrad_ws_bytes.restype = C.c_int64
         L.mdmm_conv_wgrad.argtypes = [C.POINTER(Conv), _P, _P, _P]
+        L.mdmm_gemm_supported.argtypes = [C.POINTER(Gemm)]
+        L.mdmm_gemm_ws_bytes.argtypes = [C.POINTER(Gemm)]
+        L.mdmm_gemm_ws_bytes.restype = C.c_int64
+        L.mdmm_gemm_bf16.argtypes = [C.POINTER(Gemm), _P]
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
         for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp), (7, Bn), (8, Conv),
-                          (9, FragLayers)):
+                          (9, FragLayers), (10, Gemm)):
             if L.mdmm_sizeof(which) != C.sizeof(st):
                 raise MdmmError('struct %s: library %d bytes, binding %d bytes'
                                 % (st.__name__, L.mdmm_sizeof(which), C.sizeof(st)))

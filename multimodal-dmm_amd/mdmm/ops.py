@@ -976,6 +976,99 @@ def tall_linear(x, layer):
     return _TallLinearFn.apply(x, layer.weight, layer.bias)
 
 
+def _rows(t):
+    """2-D fp32 view with unit column stride (a row-major matrix, possibly a column slice)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.stride(1) != 1 or t.stride(0) < t.shape[1] or t.stride(0) % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm'):
+    """c (I,J) = bias + A B^T on csrc/gemm_tiles.hip; a, b are _rows() matrices.  With fewer
+    128 x 128 tiles than two per CU the contraction is split across workgroups and summed."""
+    tiles, steps = ((I + 127) // 128) * ((J + 127) // 128), (L + 31) // 32
+    split = 1 if tiles >= 512 else max(1, min(steps // 8, (512 + tiles - 1) // tiles, 64))
+    g = native.Gemm()
+    g.I, g.J, g.L, g.ta, g.tb, g.split = I, J, L, int(ta), int(tb), split
+    g.a, g.lda, g.b, g.ldb = _ptr(a), a.stride(0), _ptr(b), b.stride(0)
+    c = torch.empty(I, J, device=a.device, dtype=torch.float32)
+    g.c, g.ldc, g.bias = _ptr(c), J, _ptr(bias)
+    ws = None
+    if split > 1:
+        ws = torch.empty(split * I * J, device=a.device, dtype=torch.float32)
+        g.ws = _ptr(ws)
+    _call('mdmm_gemm_bf16', C.byref(g), tag=tag)
+    return c
+
+
+def linear_tiles_supported(x, weight):
+    """Shapes the own GEMM takes: fp32 on the GPU, every dimension a multiple of 4 and enough rows
+    that the projection is worth a launch of 128 x 128 tiles."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32):
+        return False
+    if torch.is_autocast_enabled():
+        return False
+    m, k = x.shape
+    n = weight.shape[0]
+    return m >= 512 and m % 4 == 0 and k % 4 == 0 and n % 4 == 0 and k >= 32 and n >= 32
+
+
+class _LinearTilesFn(torch.autograd.Function):
+    """y = x W^T + b with bf16 operands / fp32 accumulation on csrc/gemm_tiles.hip, forward, input
+    gradient and weight gradient (the contraction over the rows split across workgroups)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.set_materialize_grads(False)
+        x, w = _rows(x), _rows(weight.detach())
+        m, k = x.shape
+        n = w.shape[0]
+        y = _gemm_bf16(x, False, w, False, m, n, k, _f32c(bias.detach()) if bias is not None else None,
+                       tag='linear_fwd[%dx%d]' % (k, n))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        if g is None:
+            return None, None, None
+        g = _rows(g)
+        m, k = x.shape
+        n = w.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _gemm_bf16(g, False, w, True, m, k, n, tag='linear_dgrad[%dx%d]' % (k, n))
+        if ctx.needs_input_grad[1]:
+            gw = _gemm_bf16(g, True, x, True, n, k, m, tag='linear_wgrad[%dx%d]' % (k, n))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb
+
+
+def linear_tiles(x, weight, bias):
+    return _LinearTilesFn.apply(x, weight, bias)
+
+
+def plug_linear(layer, x):
+    """An nn.Linear of a stock plug-in: on the own bf16-operand GEMM while conv_operands(bfloat16)
+    is active, else the module itself."""
+    if CONV_OPERANDS is torch.bfloat16 and linear_tiles_supported(x, layer.weight):
+        return _LinearTilesFn.apply(x, layer.weight, layer.bias)
+    return layer(x)
+
+
+def tall_projection(x, weight, bias, precision=None):
+    """Time-parallel projection of the DKS step (dks.py:219-231, 246-280): own bf16-operand GEMM
+    when the model's contractions run in bf16, else the fp32 library GEMM of _TallLinearFn."""
+    if PRECISIONS[precision] == native.PREC_BF16 and linear_tiles_supported(x, weight):
+        return _LinearTilesFn.apply(x, weight, bias)
+    return _TallLinearFn.apply(x, weight, bias)
+
+
 # ------------------------------------------------------------------------------------
 # MultiDKS recurrences
 # ------------------------------------------------------------------------------------

@@ -1226,3 +1226,28 @@ def test_step_weizmann_frames_conv_bf16_matches_oracle(dev, kernel_family):
             continue
         e = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30))
         assert e < TOL_GRAD_BF16, 'conv bf16 grad %s: %.3e' % (k, e)
+
+
+@pytest.mark.parametrize('m,k,n', [(512, 32, 32), (1000, 36, 40), (2048, 256, 4096), (4096, 4096, 256), (640, 260, 132)])
+def test_linear_tiles_match_torch(dev, m, k, n):
+    """csrc/gemm_tiles.hip (the time-parallel projections, dks.py:219-231, 246-280, and the Linear heads
+    of the image plug-ins) against torch on the same bf16-rounded operands: forward, input gradient and
+    the split weight gradient; a column slice of a wider weight as the combiner passes it."""
+    import torch.nn as nn
+    from mdmm import ops
+    torch.manual_seed(m + k + n)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)      # noqa: E731
+    x = torch.randn(m, k, device=dev, requires_grad=True)
+    wide = (torch.randn(n, k + 8, device=dev) / k ** 0.5).requires_grad_()
+    bias = torch.randn(n, device=dev, requires_grad=True)
+    for w in (wide[:, 8:], wide[:, :k]):
+        assert ops.linear_tiles_supported(x, w)
+        y = ops.linear_tiles(x, w, bias)
+        gy = torch.randn_like(y)
+        gx, gwide, gb = torch.autograd.grad(y, [x, wide, bias], gy)
+        xr, wr = rb(x.detach()), rb(w.detach())
+        close(y, xr @ wr.t() + bias.detach(), 2e-5, 'linear fwd')
+        close(gx, rb(gy) @ wr, 2e-5, 'linear dgrad')
+        gw = gwide[:, 8:] if w.data_ptr() != wide.data_ptr() else gwide[:, :k]
+        close(gw, rb(gy).t() @ xr, 2e-5, 'linear wgrad')
+        close(gb, gy.sum(0), 1e-5, 'linear bias grad')

@@ -82,3 +82,37 @@ if kw['time']:
         gb_f = (x.numel() + y.numel()) * 4 / 1e9
         print('%-22s N=%d  library fwd %.3f bwd %.3f ms | own fwd %.3f bwd %.3f ms | fwd traffic %.2f GB = %.3f ms at 4 TB/s'
               % (name, N, res[0][0], res[0][1], res[1][0], res[1][1], gb_f, gb_f / 4.0), flush=True)
+
+# ---- the bf16-operand GEMM (csrc/gemm_tiles.hip) against torch on the rounded operands
+print('linear tiles:')
+for (m, k, n) in [(512, 32, 32), (1000, 36, 40), (2048, 256, 4096), (10240, 4096, 256), (4096, 9216, 256), (640, 260, 132)]:
+    x = torch.randn(m, k, device=dev, requires_grad=True)
+    lin = nn.Linear(k, n).to(dev)
+    assert ops.linear_tiles_supported(x, lin.weight), (m, k, n)
+    y = ops.linear_tiles(x, lin.weight, lin.bias)
+    gy = torch.randn_like(y)
+    gx, gw, gb = torch.autograd.grad(y, [x, lin.weight, lin.bias], gy)
+    xr, wr = rb(x.detach()).requires_grad_(), rb(lin.weight.detach()).requires_grad_()
+    yr = torch.nn.functional.linear(xr, wr, lin.bias.detach())
+    gxr = rb(gy) @ wr.detach()
+    gwr = rb(gy).t() @ xr.detach()
+    print('  M=%-6d K=%-5d N=%-5d fwd %.1e dgrad %.1e wgrad %.1e' % (m, k, n, err(y, yr), err(gx, gxr), err(gw, gwr)), flush=True)
+    if kw['time'] and m >= 2048:
+        for own in (False, True):
+            f = (lambda: ops.linear_tiles(x, lin.weight, lin.bias)) if own else (lambda: lin(x))
+            t = []
+            for what in ('fwd', 'bwd'):
+                for _ in range(2):
+                    y = f()
+                    if what == 'bwd':
+                        torch.autograd.grad(y, [x, lin.weight], gy)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    y = f()
+                    if what == 'bwd':
+                        torch.autograd.grad(y, [x, lin.weight], gy)
+                e1.record(); torch.cuda.synchronize()
+                t.append(e0.elapsed_time(e1) / 5)
+            print('      %s fwd %.3f ms  bwd %.3f ms' % ('own    ' if own else 'library', t[0], t[1] - t[0]), flush=True)
