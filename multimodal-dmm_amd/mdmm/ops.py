@@ -331,7 +331,7 @@ def clear_caches(params=()):
             del p._mdmm_pack
         if hasattr(p, '_mdmm_frag'):
             del p._mdmm_frag
-        for name in [n for n in vars(p) if n.startswith('_mdmm_lfrag_')]:
+        for name in [n for n in vars(p) if n.startswith('_mdmm_lfrag_') or n.startswith('_mdmm_conv_')]:
             delattr(p, name)
 
 
