@@ -16,12 +16,19 @@ def timed(step, n=3, warm=1):
     for _ in range(warm):
         step()
     torch.cuda.synchronize()
-    ops.TIMER = ops.KernelTimer()
+    probe = getattr(step, 'eager', None)        # graph replay: time it, then per-call events on eager re-runs
+    if probe is None:
+        ops.TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(n):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    if probe is not None:
+        ops.TIMER = ops.KernelTimer()
+        for _ in range(n):
+            probe()
+        torch.cuda.synchronize()
     spans, ops.TIMER = ops.TIMER.summary(), None
     return dt, {k: round(v[1] / n, 3) for k, v in sorted(spans.items(), key=lambda kv: -kv[1][1])[:8]}
 
@@ -58,10 +65,17 @@ def weizmann(kind, B, T=40):
         for b in range(B):
             x[k][st[b]:st[b] + burst, b] = float('nan')
     mask = torch.ones(T, B, 1, dtype=torch.bool, device=dev)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    graph = os.environ.get('GRAPH', '1') == '1'
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, capturable=graph, fused=True)
     bucket = GradBucket(m.parameters())
     rec = {'video': 1.0, 'mask': 1.0, 'action': 10.0}
-    return lambda: elbo_step(m, opt, bucket, x, mask, [T] * B, 1.0, rec, targets=tg)
+    eager = lambda: elbo_step(m, opt, bucket, x, mask, [T] * B, 1.0, rec, targets=tg)     # noqa: E731
+    if not graph:
+        return eager
+    from mdmm.harness import GraphedElboStep
+    step = GraphedElboStep(m, opt, bucket, x, mask, [T] * B, 1.0, rec, targets=tg)
+    step.eager = eager          # per-call HIP-event timing needs eager launches (timed())
+    return step
 
 
 def spirals_cfg1(B=25, T=100, graph=True):
