@@ -111,7 +111,8 @@ class Cfg3:
     rec = {'video': 1.0, 'mask': 1.0, 'action': 10.0}
     workload = ('cfg3: Weizmann-shaped synthetic (video 3x64x64 + mask 1x64x64 Bernoulli, action '
                 'Categorical(10)), MultiDMM BFVI, conv encoders/decoders, z=h=256, T=40, B=%d per GPU, '
-                '20%% burst NaN, train_particles=25, sweep and conv contractions bf16 operands / fp32 accumulate')
+                '20%% burst NaN, train_particles=25, sweep / conv / projection contractions with bf16 operands and fp32 '
+                'accumulation, conv-chain activations stored as bf16; latents, statistics, reductions fp32')
     mods, dims = ['video', 'mask', 'action'], [(3, 64, 64), (1, 64, 64), 10]
     dists = ['Bernoulli', 'Bernoulli', 'Categorical']
 
@@ -142,6 +143,7 @@ class Cfg3:
                             z_dim=256, device=device)
         m.sweep_dtype = torch.bfloat16
         m.conv_dtype = torch.bfloat16
+        m.act_dtype = torch.bfloat16
         return m
 
     @classmethod

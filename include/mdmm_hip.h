@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 14
+#define MDMM_ABI_VERSION 15
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -274,6 +274,12 @@ int mdmm_nll_bernoulli_logits_fwd(const float* logits, const float* x, const flo
 int mdmm_nll_bernoulli_logits_bwd(const float* logits, const float* x, const float* seq_mask,
                                   int64_t rows, int inner, float scale, const float* scale_dev,
                                   float* g_logits, void* stream);
+/* the same with the logits and their gradient stored as bf16 (bf16-activation plug-ins) */
+int mdmm_nll_bernoulli_logits_bf16_fwd(const void* logits, const float* x, const float* seq_mask,
+                                       int64_t rows, int inner, float weight, double* out, void* stream);
+int mdmm_nll_bernoulli_logits_bf16_bwd(const void* logits, const float* x, const float* seq_mask,
+                                       int64_t rows, int inner, float scale, const float* scale_dev,
+                                       void* g_logits, void* stream);
 /* NaN -> 0 and the per-row "seen" flag of MultiDMM.encode (dmm.py:164-166) in one pass:
  * out[r][i] = isnan(x[r][i]) ? 0 : x[r][i];  seen[r] = no NaN in row r  (float 0 / 1).  */
 int mdmm_nan_to_zero(const float* x, int64_t rows, int inner, float* out, float* seen, void* stream);
@@ -443,13 +449,17 @@ int mdmm_gauss_mlp_bwd(const mdmm_mlp_t* a, void* stream);
  * dbeta (the last two may be NULL).  */
 typedef struct mdmm_bn {
   int64_t N, L;
-  int32_t C, relu, splits, reserved;
+  int32_t C, relu, splits;
+  int32_t bf16_io;                        /* 1: x, y, dy, dx are bf16 in memory (arithmetic fp32) */
   float eps, momentum;
-  const float *x, *gamma, *beta;          /* gamma / beta NULL = 1 / 0 */
+  const void* x;
+  const float *gamma, *beta;              /* gamma / beta NULL = 1 / 0 */
   float *running_mean, *running_var;
-  float *y, *save_mean, *save_invstd;
-  const float* dy;
-  float *dx, *dgamma, *dbeta;
+  void* y;
+  float *save_mean, *save_invstd;
+  const void* dy;
+  void* dx;
+  float *dgamma, *dbeta;
   double* partial;
   /* optional (C): added to the batch mean in the running_mean update only -- the bias of the
    * convolution in front when the caller leaves it out of x (BatchNorm(x + b) == BatchNorm(x)) */
@@ -470,11 +480,14 @@ int mdmm_bn_relu_bwd(const mdmm_bn_t* a, void* stream);
  *                                                       or one activation and one gradient)
  * `wfrag` = mdmm_conv_pack(args, up, weight): the weights as MFMA fragments for that direction.
  * `bias` (optional) is added per output channel.  mdmm_conv_supported: (S, CS, CB) in
- * {(8,64,32), (16,32,16), (32,16,1..4)}, KS in {3,4}.  */
+ * {(8,64,32), (16,32,16), (32,16,1..4)}, KS in {3,4}.
+ * Either side may be stored as bf16 instead of fp32 (flags; weights, bias and dW stay fp32).  */
+#define MDMM_CONV_SMALL_BF16 1
+#define MDMM_CONV_BIG_BF16 2
 typedef struct mdmm_conv {
-  int32_t N, S, CS, CB, KS, reserved;
-  float* small;          /* (N, CS, S, S)    */
-  float* big;            /* (N, CB, 2S, 2S)  */
+  int32_t N, S, CS, CB, KS, flags;
+  void* small;           /* (N, CS, S, S)    fp32 or bf16 */
+  void* big;             /* (N, CB, 2S, 2S)  fp32 or bf16 */
   const void* wfrag;
   const float* bias;
 } mdmm_conv_t;
@@ -496,12 +509,13 @@ int mdmm_conv_wgrad(const mdmm_conv_t* args, void* ws, float* dw, void* stream);
  *   `ws`, mdmm_gemm_ws_bytes).  Contiguous dimensions and leading dimensions multiples of 4.  */
 typedef struct mdmm_gemm {
   int32_t I, J, L, ta, tb, split;
-  const float* a;
+  int32_t a_bf16, b_bf16, c_bf16, reserved;   /* 1: that matrix is bf16 in memory instead of fp32 */
+  const void* a;
   int64_t lda;
-  const float* b;
+  const void* b;
   int64_t ldb;
   const float* bias;     /* (J) or NULL */
-  float* c;
+  void* c;
   int64_t ldc;
   float* ws;             /* split > 1: split * I * J floats */
 } mdmm_gemm_t;

@@ -12,6 +12,20 @@
 namespace {
 
 constexpr int NT = 256;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// activations are fp32 or bf16 in memory (mdmm_bn_t.bf16_io); arithmetic is fp32 either way
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void st4(float* p, const float4& o) { *reinterpret_cast<float4*>(p) = o; }
+__device__ __forceinline__ void st4(__bf16* p, const float4& o) {
+  bf16x4 v;
+  v[0] = (__bf16)o.x; v[1] = (__bf16)o.y; v[2] = (__bf16)o.z; v[3] = (__bf16)o.w;
+  *reinterpret_cast<bf16x4*>(p) = v;
+}
 
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
   a = mdmm::wave_sum_d(a); b = mdmm::wave_sum_d(b);
@@ -36,8 +50,8 @@ __device__ __forceinline__ Span span_of(int64_t N) {
 }
 
 // ---- forward ------------------------------------------------------------------------------
-template <bool VEC>
-__global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ x, int64_t N, int C,
+template <bool VEC, typename T>
+__global__ __launch_bounds__(NT) void bn_stats_kernel(const T* __restrict__ x, int64_t N, int C,
                                                       int64_t L, double* __restrict__ partial) {
   __shared__ double sh[2 * NT / 64];
   const int c = blockIdx.x;
@@ -49,7 +63,7 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
     const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
       const int64_t n = sp.n_lo + i / L4, l = i % L4;
-      const float4 v = reinterpret_cast<const float4*>(x + (n * C + c) * L)[l];
+      const float4 v = ld4(x + (n * C + c) * L + 4 * l);
       s1 += (v.x + v.y) + (v.z + v.w);
       s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
       if (++cnt == 256) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }   // short fp32 runs only
@@ -58,7 +72,7 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
       const int64_t n = sp.n_lo + i / L, l = i % L;
-      const float v = x[(n * C + c) * L + l];
+      const float v = (float)x[(n * C + c) * L + l];
       s1 += v; s2 += v * v;
       if (++cnt == 1024) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
     }
@@ -71,14 +85,14 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
   }
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, int64_t N, int C,
+template <bool VEC, typename T>
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, int64_t N, int C,
                                                       int64_t L, const double* __restrict__ partial,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps, int relu,
                                                       float momentum, float* running_mean,
                                                       float* running_var, const float* mean_shift,
-                                                      float* __restrict__ y,
+                                                      T* __restrict__ y,
                                                       float* save_mean, float* save_invstd) {
   const int c = blockIdx.x;
   double d1 = 0, d2 = 0;
@@ -109,29 +123,29 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
     const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
       const int64_t n = sp.n_lo + i / L4, l = i % L4;
-      const float4 v = reinterpret_cast<const float4*>(x + (n * C + c) * L)[l];
+      const float4 v = ld4(x + (n * C + c) * L + 4 * l);
       float4 o;
       o.x = fmaf(v.x, scale, shift); o.y = fmaf(v.y, scale, shift);
       o.z = fmaf(v.z, scale, shift); o.w = fmaf(v.w, scale, shift);
       if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-      reinterpret_cast<float4*>(y + (n * C + c) * L)[l] = o;
+      st4(y + (n * C + c) * L + 4 * l, o);
     }
   } else {
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
       const int64_t n = sp.n_lo + i / L, l = i % L;
-      float o = fmaf(x[(n * C + c) * L + l], scale, shift);
+      float o = fmaf((float)x[(n * C + c) * L + l], scale, shift);
       if (relu) o = fmaxf(o, 0.f);
-      y[(n * C + c) * L + l] = o;
+      y[(n * C + c) * L + l] = (T)o;
     }
   }
 }
 
 // ---- backward -----------------------------------------------------------------------------
 // g = dy * [bn(x) > 0] (with ReLU);  partial = (sum g, sum g * xhat)
-template <bool VEC>
-__global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restrict__ dy,
-                                                          const float* __restrict__ x, int64_t N, int C,
+template <bool VEC, typename T>
+__global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const T* __restrict__ dy,
+                                                          const T* __restrict__ x, int64_t N, int C,
                                                           int64_t L, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ save_mean,
@@ -155,8 +169,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
     const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
       const int64_t n = sp.n_lo + i / L4, l = i % L4;
-      const float4 v = reinterpret_cast<const float4*>(x + (n * C + c) * L)[l];
-      const float4 d = reinterpret_cast<const float4*>(dy + (n * C + c) * L)[l];
+      const float4 v = ld4(x + (n * C + c) * L + 4 * l);
+      const float4 d = ld4(dy + (n * C + c) * L + 4 * l);
       acc(d.x, v.x); acc(d.y, v.y); acc(d.z, v.z); acc(d.w, v.w);
       if (++cnt == 256) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
     }
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
       const int64_t n = sp.n_lo + i / L, l = i % L;
-      acc(dy[(n * C + c) * L + l], x[(n * C + c) * L + l]);
+      acc((float)dy[(n * C + c) * L + l], (float)x[(n * C + c) * L + l]);
       if (++cnt == 1024) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
     }
   }
@@ -177,15 +191,15 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const float* __restric
 }
 
 // dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));  d gamma = sum g xhat, d beta = sum g
-template <bool VEC>
-__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ dy,
-                                                          const float* __restrict__ x, int64_t N, int C,
+template <bool VEC, typename T>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ dy,
+                                                          const T* __restrict__ x, int64_t N, int C,
                                                           int64_t L, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ save_mean,
                                                           const float* __restrict__ save_invstd, int relu,
                                                           const double* __restrict__ partial,
-                                                          float* __restrict__ dx, float* dgamma,
+                                                          T* __restrict__ dx, float* dgamma,
                                                           float* dbeta) {
   const int c = blockIdx.x;
   double d1 = 0, d2 = 0;
@@ -212,23 +226,24 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
     const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
       const int64_t n = sp.n_lo + i / L4, l = i % L4;
-      const float4 v = reinterpret_cast<const float4*>(x + (n * C + c) * L)[l];
-      const float4 d = reinterpret_cast<const float4*>(dy + (n * C + c) * L)[l];
+      const float4 v = ld4(x + (n * C + c) * L + 4 * l);
+      const float4 d = ld4(dy + (n * C + c) * L + 4 * l);
       float4 o;
       o.x = one(d.x, v.x); o.y = one(d.y, v.y); o.z = one(d.z, v.z); o.w = one(d.w, v.w);
-      reinterpret_cast<float4*>(dx + (n * C + c) * L)[l] = o;
+      st4(dx + (n * C + c) * L + 4 * l, o);
     }
   } else {
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
       const int64_t n = sp.n_lo + i / L, l = i % L;
-      dx[(n * C + c) * L + l] = one(dy[(n * C + c) * L + l], x[(n * C + c) * L + l]);
+      dx[(n * C + c) * L + l] = (T)one((float)dy[(n * C + c) * L + l], (float)x[(n * C + c) * L + l]);
     }
   }
 }
 
 bool vec_ok(const mdmm_bn_t* a) {
-  return a->L % 4 == 0 && !(((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->dy | (uintptr_t)a->dx) & 15);
+  const uintptr_t m = a->bf16_io ? 7 : 15;
+  return a->L % 4 == 0 && !(((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->dy | (uintptr_t)a->dx) & m);
 }
 
 int check(const mdmm_bn_t* a) {
@@ -250,23 +265,34 @@ extern "C" int mdmm_bn_splits(int64_t N, int C, int64_t L) {
   return (int)s;
 }
 
+namespace {
+template <bool VEC, typename T>
+void launch_fwd(const mdmm_bn_t* a, hipStream_t st) {
+  const dim3 grid(a->C, a->splits);
+  hipLaunchKernelGGL((bn_stats_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->x, a->N, a->C, a->L, a->partial);
+  hipLaunchKernelGGL((bn_apply_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->x, a->N, a->C, a->L, a->partial,
+                     a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
+                     a->mean_shift, (T*)a->y, a->save_mean, a->save_invstd);
+}
+template <bool VEC, typename T>
+void launch_bwd(const mdmm_bn_t* a, hipStream_t st) {
+  const dim3 grid(a->C, a->splits);
+  hipLaunchKernelGGL((bn_bwd_stats_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->dy, (const T*)a->x, a->N, a->C,
+                     a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->dy, (const T*)a->x, a->N, a->C,
+                     a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial, (T*)a->dx,
+                     a->dgamma, a->dbeta);
+}
+
+}  // namespace
+
 extern "C" int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream) {
   int rc = check(a);
   if (rc) return rc;
   if (!a->y) return MDMM_E_ARG;
-  const dim3 grid(a->C, a->splits);
   hipStream_t st = (hipStream_t)stream;
-  if (vec_ok(a)) {
-    hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial);
-    hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial,
-                       a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
-                       a->mean_shift, a->y, a->save_mean, a->save_invstd);
-  } else {
-    hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial);
-    hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(NT), 0, st, a->x, a->N, a->C, a->L, a->partial,
-                       a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
-                       a->mean_shift, a->y, a->save_mean, a->save_invstd);
-  }
+  if (a->bf16_io) { if (vec_ok(a)) launch_fwd<true, __bf16>(a, st); else launch_fwd<false, __bf16>(a, st); }
+  else { if (vec_ok(a)) launch_fwd<true, float>(a, st); else launch_fwd<false, float>(a, st); }
   return (int)hipGetLastError();
 }
 
@@ -274,20 +300,8 @@ extern "C" int mdmm_bn_relu_bwd(const mdmm_bn_t* a, void* stream) {
   int rc = check(a);
   if (rc) return rc;
   if (!a->dy || !a->dx) return MDMM_E_ARG;
-  const dim3 grid(a->C, a->splits);
   hipStream_t st = (hipStream_t)stream;
-  if (vec_ok(a)) {
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<true>, grid, dim3(NT), 0, st, a->dy, a->x, a->N, a->C, a->L,
-                       a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(NT), 0, st, a->dy, a->x, a->N, a->C, a->L,
-                       a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial, a->dx,
-                       a->dgamma, a->dbeta);
-  } else {
-    hipLaunchKernelGGL(bn_bwd_stats_kernel<false>, grid, dim3(NT), 0, st, a->dy, a->x, a->N, a->C, a->L,
-                       a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(NT), 0, st, a->dy, a->x, a->N, a->C, a->L,
-                       a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial, a->dx,
-                       a->dgamma, a->dbeta);
-  }
+  if (a->bf16_io) { if (vec_ok(a)) launch_bwd<true, __bf16>(a, st); else launch_bwd<false, __bf16>(a, st); }
+  else { if (vec_ok(a)) launch_bwd<true, float>(a, st); else launch_bwd<false, float>(a, st); }
   return (int)hipGetLastError();
 }

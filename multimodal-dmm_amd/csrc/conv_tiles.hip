@@ -33,6 +33,37 @@ __device__ __forceinline__ void mma(f32x16& acc, const uint4& a, const uint4& b)
 }
 __device__ __forceinline__ constexpr int acc_row(int reg) { return 8 * (reg >> 2) + (reg & 3); }   // + 4 h
 
+// Activations live in HBM as fp32 or as bf16 (mdmm_conv_t.flags): BF selects the element type of one
+// side.  load4 / load8: consecutive elements starting at element index idx (a multiple of 4 / 8).
+template <bool BF>
+__device__ __forceinline__ bf16x4 load4(const void* base, size_t idx) {
+  if constexpr (BF) {
+    return *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) + idx);
+  } else {
+    const float4 u = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + idx);
+    bf16x4 v;
+    v[0] = (__bf16)u.x; v[1] = (__bf16)u.y; v[2] = (__bf16)u.z; v[3] = (__bf16)u.w;
+    return v;
+  }
+}
+template <bool BF>
+__device__ __forceinline__ bf16x8 load8(const void* base, size_t idx) {
+  if constexpr (BF) {
+    return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(base) + idx);
+  } else {
+    const bf16x4 lo = load4<false>(base, idx), hi = load4<false>(base, idx + 4);
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+    return v;
+  }
+}
+template <bool BF>
+__device__ __forceinline__ void store1(void* base, size_t idx, float v) {
+  if constexpr (BF) reinterpret_cast<__bf16*>(base)[idx] = (__bf16)v;
+  else reinterpret_cast<float*>(base)[idx] = v;
+}
+
 template <int S, int CS, int CB>
 struct Shape {
   static constexpr int CBP = CB;                          // big-side channels as staged (4 = padded 1..4)
@@ -102,7 +133,7 @@ __global__ void pack_down_kernel(const float* w, int cb, uint4* out) {
 
 // --------------------------------------------------------------------------------- up ----
 // big[n][m][2y+py][2x+px] = bias[m] + sum_{ci, a, b} small[n][ci][y+py+a-1][x+px+b-1] W[ci][m][3-py-2a][3-px-2b]
-template <int S, int CS, int CB>
+template <int S, int CS, int CB, bool SB, bool BB>
 __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   using G = Shape<S, CS, CB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,17 +156,15 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   __syncthreads();
   constexpr int NPIX = S * S, NCG = CS / 8;
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
-    const float* src = a.small + (size_t)n * CS * NPIX;
+    const size_t src0 = (size_t)n * CS * NPIX;
     for (int it = threadIdx.x; it < (NPIX / 4) * NCG; it += 256) {
       const int p = 4 * (it % (NPIX / 4)), cg = it / (NPIX / 4), y = p / S, x = p % S;
-      float4 u[8];
+      bf16x4 u[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) u[j] = *reinterpret_cast<const float4*>(src + (size_t)(cg * 8 + j) * NPIX + p);
+      for (int j = 0; j < 8; ++j) u[j] = load4<SB>(a.small, src0 + (size_t)(cg * 8 + j) * NPIX + p);
       bf16x8 v0, v1, v2, v3;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v0[j] = (__bf16)u[j].x; v1[j] = (__bf16)u[j].y; v2[j] = (__bf16)u[j].z; v3[j] = (__bf16)u[j].w;
-      }
+      for (int j = 0; j < 8; ++j) { v0[j] = u[j][0]; v1[j] = u[j][1]; v2[j] = u[j][2]; v3[j] = u[j][3]; }
       char* at = smem + ((y + 1) * G::UP_PW + x + 1) * G::UP_PS + cg * 16;
       *reinterpret_cast<uint4*>(at) = __builtin_bit_cast(uint4, v0);
       *reinterpret_cast<uint4*>(at + G::UP_PS) = __builtin_bit_cast(uint4, v1);
@@ -143,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
       *reinterpret_cast<uint4*>(at + 3 * G::UP_PS) = __builtin_bit_cast(uint4, v3);
     }
     __syncthreads();
-    float* dst = a.big + (size_t)n * cb * (4 * NPIX);
+    const size_t dst0 = (size_t)n * cb * (4 * NPIX);
     for (int tile = 0; tile < NPIX / 32; ++tile) {
       const int p = tile * 32 + (lane & 31), y = p / S, x = p % S;
       const char* base = smem + ((y + py) * G::UP_PW + x + px) * G::UP_PS + 16 * h;
@@ -156,11 +185,11 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
         const uint4 bv = *reinterpret_cast<const uint4*>(base + ((tap >> 1) * G::UP_PW + (tap & 1)) * G::UP_PS + off * 2);
         mma(acc, wf[c], bv);
       }
-      float* o = dst + (size_t)(2 * y + py) * G::B2 + 2 * x + px;
+      const size_t o = dst0 + (size_t)(2 * y + py) * G::B2 + 2 * x + px;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = acc_row(r) + 4 * h;
-        if (m < cb) o[(size_t)m * (4 * NPIX)] = acc[r];
+        if (m < cb) store1<BB>(a.big, o + (size_t)m * (4 * NPIX), acc[r]);
       }
     }
     __syncthreads();
@@ -169,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
 
 // ------------------------------------------------------------------------------- down ----
 // small[n][m][y][x] = bias[m] + sum_{ch, ky, kx} big[n][ch][2y-1+ky][2x-1+kx] W[m][ch][ky][kx]
-template <int S, int CS, int CB, int KS>
+template <int S, int CS, int CB, int KS, bool SB, bool BB>
 __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   using G = Shape<S, CS, CB>;
   using D = Down<S, CS, CB, KS>;
@@ -183,20 +212,20 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   __syncthreads();
   constexpr int NPIX = S * S, BPIX = 4 * NPIX, B2 = G::B2;
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
-    const float* src = a.big + (size_t)n * cb * BPIX;
+    const size_t src0 = (size_t)n * cb * BPIX;
     if constexpr (G::THIN) {
-      // four consecutive x per item: one float4 per channel, 32 contiguous bytes of the patch
+      // four consecutive x per item: four elements per channel, 32 contiguous bytes of the patch
       for (int it = threadIdx.x; it < BPIX / 4; it += 256) {
         const int p = 4 * it, y = p / B2, x = p % B2;
-        float4 u[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          u[j] = j < cb ? *reinterpret_cast<const float4*>(src + (size_t)j * BPIX + p) : float4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 lo, hi;
+        bf16x4 u[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          lo[j] = (__bf16)u[j].x; lo[4 + j] = (__bf16)u[j].y; hi[j] = (__bf16)u[j].z; hi[4 + j] = (__bf16)u[j].w;
+          if (j < cb) u[j] = load4<BB>(a.big, src0 + (size_t)j * BPIX + p);
+          else u[j] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
         }
+        bf16x8 lo, hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lo[j] = u[j][0]; lo[4 + j] = u[j][1]; hi[j] = u[j][2]; hi[4 + j] = u[j][3]; }
         char* at = patch + ((y + 1) * G::DN_PW + x + 1) * 8;          // 8-byte aligned (x + 1 is odd)
         *reinterpret_cast<uint2*>(at) = uint2{__builtin_bit_cast(uint4, lo).x, __builtin_bit_cast(uint4, lo).y};
         *reinterpret_cast<uint4*>(at + 8) = uint4{__builtin_bit_cast(uint4, lo).z, __builtin_bit_cast(uint4, lo).w,
@@ -207,14 +236,12 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
       constexpr int NCG = CB / 8;
       for (int it = threadIdx.x; it < (BPIX / 4) * NCG; it += 256) {
         const int p = 4 * (it % (BPIX / 4)), cg = it / (BPIX / 4), y = p / B2, x = p % B2;
-        float4 u[8];
+        bf16x4 u[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) u[j] = *reinterpret_cast<const float4*>(src + (size_t)(cg * 8 + j) * BPIX + p);
+        for (int j = 0; j < 8; ++j) u[j] = load4<BB>(a.big, src0 + (size_t)(cg * 8 + j) * BPIX + p);
         bf16x8 v0, v1, v2, v3;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          v0[j] = (__bf16)u[j].x; v1[j] = (__bf16)u[j].y; v2[j] = (__bf16)u[j].z; v3[j] = (__bf16)u[j].w;
-        }
+        for (int j = 0; j < 8; ++j) { v0[j] = u[j][0]; v1[j] = u[j][1]; v2[j] = u[j][2]; v3[j] = u[j][3]; }
         char* at = patch + ((y + 1) * G::DN_PW + x + 1) * G::DN_PS + cg * 16;
         *reinterpret_cast<uint4*>(at) = __builtin_bit_cast(uint4, v0);
         *reinterpret_cast<uint4*>(at + G::DN_PS) = __builtin_bit_cast(uint4, v1);
@@ -223,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
       }
     }
     __syncthreads();
-    float* dst = a.small + (size_t)n * CS * NPIX;
+    const size_t dst0 = (size_t)n * CS * NPIX;
     constexpr int NT = NPIX / 32;
     for (int job = wave; job < NT * G::MT_S; job += 4) {
       const int tile = job % NT, mt = job / NT;
@@ -250,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = 32 * mt + acc_row(r) + 4 * h;
-        if (m < CS) dst[(size_t)m * NPIX + p] = acc[r];
+        if (m < CS) store1<SB>(a.small, dst0 + (size_t)m * NPIX + p, acc[r]);
       }
     }
     __syncthreads();
@@ -279,7 +306,7 @@ struct Wg {
 
 __device__ __forceinline__ uint32_t shift16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbyte(hi, lo, 2); }
 
-template <int S, int CS, int CB, int KS>
+template <int S, int CS, int CB, int KS, bool SB, bool BB>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, float* part, int NT) {
   using G = Shape<S, CS, CB>;
   using W = Wg<S, CS, CB, KS>;
@@ -319,24 +346,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   __syncthreads();
   constexpr int NPIX = W::NPIX, BPIX = 4 * NPIX, B2 = 2 * S;
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
-    const float* ssrc = a.small + (size_t)n * CS * NPIX;
+    const size_t ssrc = (size_t)n * CS * NPIX;
     for (int it = threadIdx.x; it < CS * NPIX / 8; it += 512) {
       const int c = it / (NPIX / 8), g8 = it % (NPIX / 8);
-      const float4 u0 = *reinterpret_cast<const float4*>(ssrc + (size_t)c * NPIX + g8 * 8);
-      const float4 u1 = *reinterpret_cast<const float4*>(ssrc + (size_t)c * NPIX + g8 * 8 + 4);
-      bf16x8 v;
-      v[0] = (__bf16)u0.x; v[1] = (__bf16)u0.y; v[2] = (__bf16)u0.z; v[3] = (__bf16)u0.w;
-      v[4] = (__bf16)u1.x; v[5] = (__bf16)u1.y; v[6] = (__bf16)u1.z; v[7] = (__bf16)u1.w;
+      const bf16x8 v = load8<SB>(a.small, ssrc + (size_t)c * NPIX + g8 * 8);
       *reinterpret_cast<uint4*>(sm + c * W::SM_RS + g8 * 16) = __builtin_bit_cast(uint4, v);
     }
-    const float* bsrc = a.big + (size_t)n * cb * BPIX;
+    const size_t bsrc = (size_t)n * cb * BPIX;
     for (int it = threadIdx.x; it < cb * B2 * (B2 / 8); it += 512) {
       const int xg = it % (B2 / 8), Y = (it / (B2 / 8)) % B2, b = it / ((B2 / 8) * B2);
-      const float* src = bsrc + ((size_t)b * B2 + Y) * B2 + 8 * xg;
-      const float4 u0 = *reinterpret_cast<const float4*>(src), u1 = *reinterpret_cast<const float4*>(src + 4);
+      const bf16x8 u = load8<BB>(a.big, bsrc + ((size_t)b * B2 + Y) * B2 + 8 * xg);
       bf16x4 e, o;
-      e[0] = (__bf16)u0.x; o[0] = (__bf16)u0.y; e[1] = (__bf16)u0.z; o[1] = (__bf16)u0.w;
-      e[2] = (__bf16)u1.x; o[2] = (__bf16)u1.y; e[3] = (__bf16)u1.z; o[3] = (__bf16)u1.w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { e[j] = u[2 * j]; o[j] = u[2 * j + 1]; }
       char* row = pl + ((size_t)b * W::PL_ROWS + Y + 1) * W::PL_RS + 16 + xg * 8;
       *reinterpret_cast<uint2*>(row) = __builtin_bit_cast(uint2, e);
       *reinterpret_cast<uint2*>(row + CB * W::PL_ROWS * W::PL_RS) = __builtin_bit_cast(uint2, o);
@@ -430,38 +452,71 @@ int set_lds(Kern kern, int bytes) {
 
 int grid_for(int N, int per_cu) { const int g = 256 * per_cu; return N < g ? N : g; }
 
-template <int S, int CS, int CB>
-int run_up(const mdmm_conv_t* a, hipStream_t st) {
+// storage of the two sides (mdmm_conv_t.flags): fp32 / fp32, bf16 / bf16, or bf16 small side with an
+// fp32 big side (the first encoder layer reads the fp32 frames)
+int io_of(const mdmm_conv_t* a) {
+  const bool sb = a->flags & MDMM_CONV_SMALL_BF16, bb = a->flags & MDMM_CONV_BIG_BF16;
+  return sb ? (bb ? 1 : 2) : (bb ? -1 : 0);
+}
+template <int S, int CS, int CB, bool SB, bool BB>
+int run_up_io(const mdmm_conv_t* a, hipStream_t st) {
   using G = Shape<S, CS, CB>;
-  auto k = conv_up_kernel<S, CS, CB>;
+  auto k = conv_up_kernel<S, CS, CB, SB, BB>;
   int rc = set_lds(k, G::UP_LDS);
   if (rc) return rc;
   hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2)), dim3(256), G::UP_LDS, st, *a);
   return (int)hipGetLastError();
 }
-template <int S, int CS, int CB, int KS>
-int run_down(const mdmm_conv_t* a, hipStream_t st) {
+template <int S, int CS, int CB>
+int run_up(const mdmm_conv_t* a, hipStream_t st) {
+  switch (io_of(a)) {
+    case 0: return run_up_io<S, CS, CB, false, false>(a, st);
+    case 1: return run_up_io<S, CS, CB, true, true>(a, st);
+    case 2: return run_up_io<S, CS, CB, true, false>(a, st);
+    default: return MDMM_E_ARG;
+  }
+}
+template <int S, int CS, int CB, int KS, bool SB, bool BB>
+int run_down_io(const mdmm_conv_t* a, hipStream_t st) {
   using D = Down<S, CS, CB, KS>;
-  auto k = conv_down_kernel<S, CS, CB, KS>;
+  auto k = conv_down_kernel<S, CS, CB, KS, SB, BB>;
   int rc = set_lds(k, D::LDS);
   if (rc) return rc;
   hipLaunchKernelGGL(k, dim3(grid_for(a->N, D::LDS <= 80 * 1024 ? 2 : 1)), dim3(256), D::LDS, st, *a);
   return (int)hipGetLastError();
 }
+template <int S, int CS, int CB, int KS>
+int run_down(const mdmm_conv_t* a, hipStream_t st) {
+  switch (io_of(a)) {
+    case 0: return run_down_io<S, CS, CB, KS, false, false>(a, st);
+    case 1: return run_down_io<S, CS, CB, KS, true, true>(a, st);
+    case 2: return run_down_io<S, CS, CB, KS, true, false>(a, st);
+    default: return MDMM_E_ARG;
+  }
+}
 constexpr int WGRAD_GRID = 512, WGRAD_FOLD = 16;        // two workgroups per CU; second-stage groups
 int wgrad_nt(const mdmm_conv_t* a) { return (a->KS * a->KS * a->CB + 31) / 32; }
 int wgrad_parts(const mdmm_conv_t* a) {
-  const int g = a->S == 8 ? WGRAD_GRID / 2 : WGRAD_GRID;      // S = 8: 128 KB slabs, one workgroup per CU
+  const int g = a->S == 8 ? WGRAD_GRID * 3 / 2 : WGRAD_GRID;  // S = 8: 46 KB of LDS, three workgroups per CU
   return a->N < g ? a->N : g;
 }
-template <int S, int CS, int CB, int KS>
-int run_wgrad(const mdmm_conv_t* a, float* part, hipStream_t st) {
+template <int S, int CS, int CB, int KS, bool SB, bool BB>
+int run_wgrad_io(const mdmm_conv_t* a, float* part, hipStream_t st) {
   using W = Wg<S, CS, CB, KS>;
-  auto k = conv_wgrad_kernel<S, CS, CB, KS>;
+  auto k = conv_wgrad_kernel<S, CS, CB, KS, SB, BB>;
   int rc = set_lds(k, W::LDS);
   if (rc) return rc;
   hipLaunchKernelGGL(k, dim3(wgrad_parts(a)), dim3(512), W::LDS, st, *a, part, wgrad_nt(a));
   return (int)hipGetLastError();
+}
+template <int S, int CS, int CB, int KS>
+int run_wgrad(const mdmm_conv_t* a, float* part, hipStream_t st) {
+  switch (io_of(a)) {
+    case 0: return run_wgrad_io<S, CS, CB, KS, false, false>(a, part, st);
+    case 1: return run_wgrad_io<S, CS, CB, KS, true, true>(a, part, st);
+    case 2: return run_wgrad_io<S, CS, CB, KS, true, false>(a, part, st);
+    default: return MDMM_E_ARG;
+  }
 }
 
 }  // namespace

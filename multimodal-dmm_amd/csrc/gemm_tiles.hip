@@ -34,15 +34,24 @@ __device__ __forceinline__ constexpr int acc_row(int reg) { return 8 * (reg >> 2
 //   transposed:  item = (l-group of 8, row-group of 4): eight float4       -> 1 item / thread
 struct Regs { float4 v[8]; };
 
+// four consecutive elements at element offset `at`, fp32 or bf16 in memory
+__device__ __forceinline__ float4 ld4(const void* src, int64_t at, bool bf) {
+  if (bf) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(src) + at);
+    return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + at);
+}
+
 template <bool T>
-__device__ __forceinline__ void load_tile(const float* src, int64_t ld, int rows, int L, int row0, int l0,
+__device__ __forceinline__ void load_tile(const void* src, bool bf, int64_t ld, int rows, int L, int row0, int l0,
                                           int tid, Regs& r) {
   if constexpr (!T) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int it = tid + 256 * q, row = it >> 3, lg = it & 7;
       float4 v = float4{0.f, 0.f, 0.f, 0.f};
-      if (row0 + row < rows && l0 + 4 * lg < L) v = *reinterpret_cast<const float4*>(src + (int64_t)(row0 + row) * ld + l0 + 4 * lg);
+      if (row0 + row < rows && l0 + 4 * lg < L) v = ld4(src, (int64_t)(row0 + row) * ld + l0 + 4 * lg, bf);
       r.v[q] = v;
     }
   } else {
@@ -53,7 +62,7 @@ __device__ __forceinline__ void load_tile(const float* src, int64_t ld, int rows
     for (int q = 0; q < 8; ++q) {
       float4 v = float4{0.f, 0.f, 0.f, 0.f};
       const int l = l0 + 8 * lg + q;
-      if (tid < 128 && l < L && row0 + 4 * rg < rows) v = *reinterpret_cast<const float4*>(src + (int64_t)l * ld + row0 + 4 * rg);
+      if (tid < 128 && l < L && row0 + 4 * rg < rows) v = ld4(src, (int64_t)l * ld + row0 + 4 * rg, bf);
       r.v[q] = v;
     }
   }
@@ -104,8 +113,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mdmm_gemm_t g) {
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
   Regs ra, rb;
   if (s_lo < s_hi) {
-    load_tile<TA>(g.a, g.lda, g.I, g.L, i0, s_lo * BL, tid, ra);
-    load_tile<TB>(g.b, g.ldb, g.J, g.L, j0, s_lo * BL, tid, rb);
+    load_tile<TA>(g.a, g.a_bf16, g.lda, g.I, g.L, i0, s_lo * BL, tid, ra);
+    load_tile<TB>(g.b, g.b_bf16, g.ldb, g.J, g.L, j0, s_lo * BL, tid, rb);
   }
   for (int s = s_lo; s < s_hi; ++s) {
     char* buf = lds[(s - s_lo) & 1];
@@ -113,8 +122,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mdmm_gemm_t g) {
     store_tile<TB>(buf + TILE_LDS, tid, rb);
     __syncthreads();                       // (two buffers: the tile read two steps ago is free)
     if (s + 1 < s_hi) {
-      load_tile<TA>(g.a, g.lda, g.I, g.L, i0, (s + 1) * BL, tid, ra);
-      load_tile<TB>(g.b, g.ldb, g.J, g.L, j0, (s + 1) * BL, tid, rb);
+      load_tile<TA>(g.a, g.a_bf16, g.lda, g.I, g.L, i0, (s + 1) * BL, tid, ra);
+      load_tile<TB>(g.b, g.b_bf16, g.ldb, g.J, g.L, j0, (s + 1) * BL, tid, rb);
     }
     const char* pa = buf + (wi + (lane & 31)) * RS + 16 * h;
     const char* pb = buf + TILE_LDS + (wj + (lane & 31)) * RS + 16 * h;
@@ -131,8 +140,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mdmm_gemm_t g) {
     }
   }
   // C rows = A rows (registers), C columns = B rows (lanes)
-  float* c = g.split > 1 ? g.ws + (size_t)blockIdx.z * g.I * g.J : g.c;
+  float* c = g.split > 1 ? g.ws + (size_t)blockIdx.z * g.I * g.J : reinterpret_cast<float*>(g.c);
   const int64_t ldc = g.split > 1 ? g.J : g.ldc;
+  const bool cbf = g.c_bf16 && g.split == 1;
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -143,7 +153,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mdmm_gemm_t g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = i0 + wi + 32 * x + acc_row(r) + 4 * h;
-        if (i < g.I) c[(int64_t)i * ldc + j] = acc[x][y][r] + bias;
+        if (i >= g.I) continue;
+        if (cbf) reinterpret_cast<__bf16*>(g.c)[(int64_t)i * ldc + j] = (__bf16)(acc[x][y][r] + bias);
+        else c[(int64_t)i * ldc + j] = acc[x][y][r] + bias;
       }
     }
 }
@@ -155,7 +167,9 @@ __global__ void gemm_fold_kernel(const mdmm_gemm_t g) {
   float s = 0.f;
   for (int z = 0; z < g.split; ++z) s += g.ws[(size_t)z * n + e];
   const int64_t i = e / g.J, j = e % g.J;
-  g.c[i * g.ldc + j] = s + (g.bias ? g.bias[j] : 0.f);
+  const float v = s + (g.bias ? g.bias[j] : 0.f);
+  if (g.c_bf16) reinterpret_cast<__bf16*>(g.c)[i * g.ldc + j] = (__bf16)v;
+  else reinterpret_cast<float*>(g.c)[i * g.ldc + j] = v;
 }
 
 }  // namespace
@@ -175,7 +189,7 @@ extern "C" int64_t mdmm_gemm_ws_bytes(const mdmm_gemm_t* g) {
 
 extern "C" int mdmm_gemm_bf16(const mdmm_gemm_t* g, void* stream) {
   if (!mdmm_gemm_supported(g) || !g->a || !g->b || !g->c) return MDMM_E_ARG;
-  if ((((uintptr_t)g->a) | ((uintptr_t)g->b)) & 15) return MDMM_E_ALIGN;
+  if ((((uintptr_t)g->a) & (g->a_bf16 ? 7 : 15)) || (((uintptr_t)g->b) & (g->b_bf16 ? 7 : 15))) return MDMM_E_ALIGN;
   if (g->split > 1 && !g->ws) return MDMM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((g->J + BT - 1) / BT, (g->I + BT - 1) / BT, g->split);

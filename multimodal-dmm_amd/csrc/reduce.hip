@@ -116,8 +116,16 @@ __global__ __launch_bounds__(NT) void nllg_bwd_kernel(const float* __restrict__ 
 // -100 clamp on saturated pixels, is the reference's), but it never travels through HBM.
 __device__ __forceinline__ float sigmoid_ref(float l) { return 1.0f / (1.0f + expf(-l)); }
 
-template <bool LOGITS>
-__global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ theta,
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4f(const float* p, int64_t i) { return reinterpret_cast<const float4*>(p)[i]; }
+__device__ __forceinline__ float4 ld4f(const __bf16* p, int64_t i) {
+  const bf16x4_t v = reinterpret_cast<const bf16x4_t*>(p)[i];
+  return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+// T = storage type of theta / g_theta (fp32, or bf16 for the logits of the bf16-activation plug-ins)
+template <bool LOGITS, typename T>
+__global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
     float weight, double* out) {
   float acc = 0.f;
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ 
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
       if (mask && mask[i / inner4] == 0.f) continue;
       const float4 xv = reinterpret_cast<const float4*>(x)[i];
-      const float4 th = reinterpret_cast<const float4*>(theta)[i];
+      const float4 th = ld4f(theta, i);
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
       float ts[4] = {th.x, th.y, th.z, th.w};
 #pragma unroll
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ 
       const float xv = x[i];
       if (xv != xv) continue;
       if (mask && mask[i / inner] == 0.f) continue;
-      const float th = LOGITS ? sigmoid_ref(theta[i]) : theta[i];
+      const float th = LOGITS ? sigmoid_ref((float)theta[i]) : (float)theta[i];
       const float l1 = fmaxf(logf(th), -100.0f), l0 = fmaxf(log1pf(-th), -100.0f);
       acc -= xv * l1 + (1.0f - xv) * l0;
     }
@@ -152,20 +160,20 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const float* __restrict__ 
   block_add((double)weight * (double)acc, out);
 }
 
-template <bool LOGITS>
-__global__ __launch_bounds__(NT) void nllb_bwd_kernel(const float* __restrict__ theta,
+template <bool LOGITS, typename T>
+__global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
-    float scale, const float* __restrict__ scale_dev, float* g_theta) {
+    float scale, const float* __restrict__ scale_dev, T* g_theta) {
   if (scale_dev) scale *= *scale_dev;
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
     const float xv = x[i];
     float g = 0.f;
     if (xv == xv && !(mask && mask[i / inner] == 0.f)) {
-      const float th = LOGITS ? sigmoid_ref(theta[i]) : theta[i];
+      const float th = LOGITS ? sigmoid_ref((float)theta[i]) : (float)theta[i];
       g = scale * (th - xv) / fmaxf((1.0f - th) * th, 1e-12f);   // torch BCE backward
       if (LOGITS) g *= (1.0f - th) * th;                           // torch sigmoid backward
     }
-    g_theta[i] = g;
+    g_theta[i] = (T)g;
   }
 }
 
@@ -375,7 +383,7 @@ extern "C" int mdmm_nll_bernoulli_fwd(const float* theta, const float* x, const 
                                       void* stream) {
   if (!theta || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
-  hipLaunchKernelGGL(nllb_fwd_kernel<false>, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, theta, x,
+  hipLaunchKernelGGL((nllb_fwd_kernel<false, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, theta, x,
                      seq_mask, n, inner, weight, out);
   CHECK_LAUNCH();
 }
@@ -385,7 +393,7 @@ extern "C" int mdmm_nll_bernoulli_logits_fwd(const float* logits, const float* x
                                              void* stream) {
   if (!logits || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
-  hipLaunchKernelGGL(nllb_fwd_kernel<true>, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, logits, x,
+  hipLaunchKernelGGL((nllb_fwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, logits, x,
                      seq_mask, n, inner, weight, out);
   CHECK_LAUNCH();
 }
@@ -395,8 +403,28 @@ extern "C" int mdmm_nll_bernoulli_logits_bwd(const float* logits, const float* x
                                              const float* scale_dev, float* g_logits, void* stream) {
   if (!logits || !x || !g_logits || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
-  hipLaunchKernelGGL(nllb_bwd_kernel<true>, dim3(grid_for(n)), dim3(NT), 0, STREAM, logits, x, seq_mask,
+  hipLaunchKernelGGL((nllb_bwd_kernel<true, float>), dim3(grid_for(n)), dim3(NT), 0, STREAM, logits, x, seq_mask,
                      n, inner, scale, scale_dev, g_logits);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_bernoulli_logits_bf16_fwd(const void* logits, const float* x, const float* seq_mask,
+                                                  int64_t rows, int inner, float weight, double* out,
+                                                  void* stream) {
+  if (!logits || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  hipLaunchKernelGGL((nllb_fwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
+                     (const __bf16*)logits, x, seq_mask, n, inner, weight, out);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_bernoulli_logits_bf16_bwd(const void* logits, const float* x, const float* seq_mask,
+                                                  int64_t rows, int inner, float scale,
+                                                  const float* scale_dev, void* g_logits, void* stream) {
+  if (!logits || !x || !g_logits || rows < 0 || inner < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  hipLaunchKernelGGL((nllb_bwd_kernel<true, __bf16>), dim3(grid_for(n)), dim3(NT), 0, STREAM, (const __bf16*)logits,
+                     x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits);
   CHECK_LAUNCH();
 }
 
@@ -405,7 +433,7 @@ extern "C" int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const 
                                       const float* scale_dev, float* g_theta, void* stream) {
   if (!theta || !x || !g_theta || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
-  hipLaunchKernelGGL(nllb_bwd_kernel<false>, dim3(grid_for(n)), dim3(NT), 0, STREAM, theta, x, seq_mask,
+  hipLaunchKernelGGL((nllb_bwd_kernel<false, float>), dim3(grid_for(n)), dim3(NT), 0, STREAM, theta, x, seq_mask,
                      n, inner, scale, scale_dev, g_theta);
   CHECK_LAUNCH();
 }

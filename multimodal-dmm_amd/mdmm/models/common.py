@@ -217,7 +217,7 @@ class _ProbDecoder(nn.Module):
 
     def forward(self, z, logits=False):
         from .. import ops
-        x = self.z_to_feat[1](ops.plug_linear(self.z_to_feat[0], z)).view(-1, *self.feat_shape)
+        x = self.z_to_feat[1](ops.plug_linear(self.z_to_feat[0], z, act_out=True)).view(-1, *self.feat_shape)
         if logits:      # everything but the final nn.Sigmoid (for the fused sigmoid + BCE loss)
             for layer in list(self.deconv_stack)[:-1]:
                 x = layer(x)

@@ -27,11 +27,18 @@ class MultiDGTS(nn.Module):
     # torch.bfloat16 (csrc/conv_tiles.hip: bf16 operands on the matrix cores, fp32 activations and
     # accumulation -- the same contract as sweep_dtype).
     conv_dtype = torch.float32
+    # Storage type of the activations inside those plug-ins when conv_dtype is bfloat16: fp32 (default)
+    # or bfloat16 (what autocast would store; halves the HBM traffic that bounds the conv / BatchNorm /
+    # BCE chain).  Frames, latents, weights, statistics and every reduction stay fp32.
+    act_dtype = torch.float32
 
     def _plug(self, module, x, **kw):
         if self.plugin_dtype is None and self.conv_dtype is torch.bfloat16 and x.is_cuda:
-            with ops.conv_operands(torch.bfloat16):
-                return module(x, **kw)
+            with ops.conv_operands(torch.bfloat16, act=self.act_dtype):
+                out = module(x, **kw)
+            if kw.get('logits'):        # pre-sigmoid activations for the fused BCE: kept as stored
+                return out
+            return tuple(o.float() for o in out) if isinstance(out, tuple) else out.float()
         if self.plugin_dtype is None or not x.is_cuda:
             return module(x, **kw)
         with torch.autocast('cuda', dtype=self.plugin_dtype):

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 14
+ABI_VERSION = 15
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -36,6 +36,7 @@ SYMBOLS = [
     'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_up', 'mdmm_conv_down',
     'mdmm_conv_wgrad_ws_bytes', 'mdmm_conv_wgrad',
     'mdmm_gemm_supported', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
+    'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
 ]
 
 _P = C.c_void_p
@@ -114,19 +115,20 @@ class Mlp(C.Structure):
 
 class Bn(C.Structure):
     _fields_ = ([('N', C.c_int64), ('L', C.c_int64)] +
-                [(n, C.c_int32) for n in ('C', 'relu', 'splits', 'reserved')] +
+                [(n, C.c_int32) for n in ('C', 'relu', 'splits', 'bf16_io')] +
                 [('eps', C.c_float), ('momentum', C.c_float)] +
                 [(n, _P) for n in ('x', 'gamma', 'beta', 'running_mean', 'running_var', 'y', 'save_mean',
                                    'save_invstd', 'dy', 'dx', 'dgamma', 'dbeta', 'partial', 'mean_shift')])
 
 
 class Conv(C.Structure):
-    _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB', 'KS', 'reserved')] +
+    _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB', 'KS', 'flags')] +
                 [(n, _P) for n in ('small', 'big', 'wfrag', 'bias')])
 
 
 class Gemm(C.Structure):
-    _fields_ = ([(n, C.c_int32) for n in ('I', 'J', 'L', 'ta', 'tb', 'split')] +
+    _fields_ = ([(n, C.c_int32) for n in ('I', 'J', 'L', 'ta', 'tb', 'split', 'a_bf16', 'b_bf16', 'c_bf16',
+                                          'reserved')] +
                 [('a', _P), ('lda', C.c_int64), ('b', _P), ('ldb', C.c_int64), ('bias', _P), ('c', _P),
                  ('ldc', C.c_int64), ('ws', _P)])
 
@@ -188,6 +190,8 @@ def lib():
         L.mdmm_nll_bernoulli_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
         L.mdmm_nll_bernoulli_logits_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_bernoulli_logits_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
+        L.mdmm_nll_bernoulli_logits_bf16_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
+        L.mdmm_nll_bernoulli_logits_bf16_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
         L.mdmm_nan_to_zero.argtypes = [_P, i64, i32, _P, _P, _P]
         L.mdmm_nll_categorical_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_categorical_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]

@@ -848,10 +848,11 @@ class _NllBernLogitsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, x, mask, rows, inner, weight, into):
         _need_gpu(logits, x)
-        lg, xv = _f32c(logits), _f32c(x)
+        lg, xv = _act(logits), _f32c(x)
         acc = _term_acc(into, lg.device)
-        _call('mdmm_nll_bernoulli_logits_fwd', _ptr(lg), _ptr(xv), _ptr(mask), rows, inner, weight,
-              _ptr(acc))
+        ctx.bf = lg.dtype == torch.bfloat16
+        _call('mdmm_nll_bernoulli_logits_bf16_fwd' if ctx.bf else 'mdmm_nll_bernoulli_logits_fwd', _ptr(lg), _ptr(xv),
+              _ptr(mask), rows, inner, weight, _ptr(acc), tag='mdmm_nll_bernoulli_logits_fwd')
         ctx.save_for_backward(lg, xv)
         ctx.mask, ctx.rows, ctx.inner, ctx.weight = mask, rows, inner, weight
         return _term_out(acc, into, lg.device)
@@ -861,8 +862,8 @@ class _NllBernLogitsFn(torch.autograd.Function):
         lg, xv = ctx.saved_tensors
         gl = torch.empty_like(lg)
         gd = _gdev(g)
-        _call('mdmm_nll_bernoulli_logits_bwd', _ptr(lg), _ptr(xv), _ptr(ctx.mask),
-              ctx.rows, ctx.inner, ctx.weight, _ptr(gd), _ptr(gl))
+        _call('mdmm_nll_bernoulli_logits_bf16_bwd' if ctx.bf else 'mdmm_nll_bernoulli_logits_bwd', _ptr(lg), _ptr(xv),
+              _ptr(ctx.mask), ctx.rows, ctx.inner, ctx.weight, _ptr(gd), _ptr(gl), tag='mdmm_nll_bernoulli_logits_bwd')
         return gl, None, None, None, None, None, None
 
 
@@ -976,16 +977,23 @@ def tall_linear(x, layer):
     return _TallLinearFn.apply(x, layer.weight, layer.bias)
 
 
+def _act(t):
+    """Contiguous activation tensor in its own storage type (fp32 or bf16)."""
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    return t.contiguous()
+
+
 def _rows(t):
-    """2-D fp32 view with unit column stride (a row-major matrix, possibly a column slice)."""
-    if t.dtype != torch.float32:
+    """2-D fp32 or bf16 view with unit column stride (a row-major matrix, possibly a column slice)."""
+    if t.dtype not in (torch.float32, torch.bfloat16):
         t = t.float()
     if t.stride(1) != 1 or t.stride(0) < t.shape[1] or t.stride(0) % 4 or t.data_ptr() % 16:
         t = t.contiguous()
     return t
 
 
-def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm'):
+def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.float32):
     """c (I,J) = bias + A B^T on csrc/gemm_tiles.hip; a, b are _rows() matrices.  With fewer
     128 x 128 tiles than two per CU the contraction is split across workgroups and summed."""
     tiles, steps = ((I + 127) // 128) * ((J + 127) // 128), (L + 31) // 32
@@ -993,8 +1001,9 @@ def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm'):
     g = native.Gemm()
     g.I, g.J, g.L, g.ta, g.tb, g.split = I, J, L, int(ta), int(tb), split
     g.a, g.lda, g.b, g.ldb = _ptr(a), a.stride(0), _ptr(b), b.stride(0)
-    c = torch.empty(I, J, device=a.device, dtype=torch.float32)
-    g.c, g.ldc, g.bias = _ptr(c), J, _ptr(bias)
+    g.a_bf16, g.b_bf16 = int(a.dtype == torch.bfloat16), int(b.dtype == torch.bfloat16)
+    c = torch.empty(I, J, device=a.device, dtype=out_dtype)
+    g.c, g.ldc, g.bias, g.c_bf16 = _ptr(c), J, _ptr(bias), int(out_dtype == torch.bfloat16)
     ws = None
     if split > 1:
         ws = torch.empty(split * I * J, device=a.device, dtype=torch.float32)
@@ -1006,7 +1015,8 @@ def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm'):
 def linear_tiles_supported(x, weight):
     """Shapes the own GEMM takes: fp32 on the GPU, every dimension a multiple of 4 and enough rows
     that the projection is worth a launch of 128 x 128 tiles."""
-    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32):
+    if not (x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16)
+            and weight.dtype == torch.float32):
         return False
     if torch.is_autocast_enabled():
         return False
@@ -1020,13 +1030,13 @@ class _LinearTilesFn(torch.autograd.Function):
     gradient and weight gradient (the contraction over the rows split across workgroups)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, out_dtype=torch.float32):
         ctx.set_materialize_grads(False)
         x, w = _rows(x), _rows(weight.detach())
         m, k = x.shape
         n = w.shape[0]
         y = _gemm_bf16(x, False, w, False, m, n, k, _f32c(bias.detach()) if bias is not None else None,
-                       tag='linear_fwd[%dx%d]' % (k, n))
+                       tag='linear_fwd[%dx%d]' % (k, n), out_dtype=out_dtype)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         return y
@@ -1035,29 +1045,32 @@ class _LinearTilesFn(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         if g is None:
-            return None, None, None
+            return None, None, None, None
         g = _rows(g)
         m, k = x.shape
         n = w.shape[0]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _gemm_bf16(g, False, w, True, m, k, n, tag='linear_dgrad[%dx%d]' % (k, n))
+            gx = _gemm_bf16(g, False, w, True, m, k, n, tag='linear_dgrad[%dx%d]' % (k, n), out_dtype=x.dtype)
         if ctx.needs_input_grad[1]:
             gw = _gemm_bf16(g, True, x, True, n, k, m, tag='linear_wgrad[%dx%d]' % (k, n))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(0)
-        return gx, gw, gb
+            gb = g.sum(0, dtype=torch.float32)
+        return gx, gw, gb, None
 
 
 def linear_tiles(x, weight, bias):
     return _LinearTilesFn.apply(x, weight, bias)
 
 
-def plug_linear(layer, x):
+def plug_linear(layer, x, act_out=False):
     """An nn.Linear of a stock plug-in: on the own bf16-operand GEMM while conv_operands(bfloat16)
-    is active, else the module itself."""
+    is active, else the module itself.  act_out: the output is an activation of the conv chain
+    (stored as ACT_STORAGE) rather than a latent-side quantity (always fp32)."""
     if CONV_OPERANDS is torch.bfloat16 and linear_tiles_supported(x, layer.weight):
-        return _LinearTilesFn.apply(x, layer.weight, layer.bias)
+        return _LinearTilesFn.apply(x, layer.weight, layer.bias, ACT_STORAGE if act_out else torch.float32)
+    if x.dtype != layer.weight.dtype:
+        x = x.to(layer.weight.dtype)
     return layer(x)
 
 
@@ -1083,11 +1096,12 @@ class _BnReluFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, bn, relu, shift):
         ctx.set_materialize_grads(False)
         _need_gpu(x)
-        x = _f32c(x)
+        x = _act(x)
         N, Cc = x.shape[0], x.shape[1]
         Ln = x[0, 0].numel()
         a = native.Bn()
         a.N, a.C, a.L, a.relu = N, Cc, Ln, int(relu)
+        a.bf16_io = int(x.dtype == torch.bfloat16)
         a.splits = native.lib().mdmm_bn_splits(N, Cc, Ln)
         a.eps = bn.eps
         y = torch.empty_like(x)
@@ -1119,9 +1133,12 @@ class _BnReluFn(torch.autograd.Function):
             return None, None, None, None, None, shift_grad
         x, stats, g, b = ctx.saved_tensors
         N, Cc, Ln, relu, splits, eps = ctx.meta
-        dy = _f32c(dy)
+        dy = _act(dy)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         a = native.Bn()
         a.N, a.C, a.L, a.relu, a.splits, a.eps = N, Cc, Ln, relu, splits, eps
+        a.bf16_io = int(x.dtype == torch.bfloat16)
         dx = torch.empty_like(x)
         dgb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
         part = torch.empty(Cc * splits * 2, device=x.device, dtype=torch.float64)
@@ -1136,7 +1153,7 @@ class _BnReluFn(torch.autograd.Function):
 def batchnorm_relu_supported(x, bn):
     """The fused kernels take what the conv plug-ins hand them in training: fp32 on the GPU, batch
     statistics (module in training mode), affine or not."""
-    return (x.is_cuda and x.dtype == torch.float32 and bn.training and x.dim() >= 3
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and bn.training and x.dim() >= 3
             and not torch.is_autocast_enabled())
 
 
@@ -1151,22 +1168,30 @@ def batchnorm_relu(x, bn, relu=True, shift=None):
 # stride-2 conv pyramids of the image plug-ins on the bf16 matrix cores (csrc/conv_tiles.hip)
 # ------------------------------------------------------------------------------------
 CONV_OPERANDS = None        # torch.bfloat16 while a model with conv_dtype = bfloat16 runs its plug-ins
+ACT_STORAGE = torch.float32  # storage type of the activations those kernels write
 
 
 class conv_operands:
-    """Context: the Conv / Deconv blocks of models.common run on csrc/conv_tiles.hip (bf16 operands,
-    fp32 activations and accumulation) instead of the library's fp32 convolutions."""
+    """Context: the Conv / Deconv blocks and Linear heads of models.common run on csrc/conv_tiles.hip
+    and csrc/gemm_tiles.hip (bf16 operands, fp32 accumulation) instead of the library's fp32 kernels;
+    act = the storage type of the activations between them (fp32, or bf16: half the HBM traffic of
+    the conv / BatchNorm / BCE chain, which is what bounds it)."""
 
-    def __init__(self, dtype):
-        self.dtype = dtype
+    def __init__(self, dtype, act=torch.float32):
+        self.dtype, self.act = dtype, act
 
     def __enter__(self):
-        global CONV_OPERANDS
-        self.prev, CONV_OPERANDS = CONV_OPERANDS, self.dtype
+        global CONV_OPERANDS, ACT_STORAGE
+        self.prev = (CONV_OPERANDS, ACT_STORAGE)
+        CONV_OPERANDS, ACT_STORAGE = self.dtype, self.act
 
     def __exit__(self, *exc):
-        global CONV_OPERANDS
-        CONV_OPERANDS = self.prev
+        global CONV_OPERANDS, ACT_STORAGE
+        CONV_OPERANDS, ACT_STORAGE = self.prev
+
+
+def _conv_flags(small, big):
+    return (1 if small.dtype == torch.bfloat16 else 0) | (2 if big.dtype == torch.bfloat16 else 0)
 
 
 def _conv_desc(n, small_shape, big_shape, ks):
@@ -1179,7 +1204,9 @@ def conv_tiles_supported(layer, x):
     """Conv2d(k3,s2,p1) / ConvTranspose2d(k4,s2,p1) of the 64 x 64 pyramids, fp32 on the GPU, while
     conv_operands(torch.bfloat16) is active."""
     import torch.nn as nn
-    if CONV_OPERANDS is not torch.bfloat16 or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+    if CONV_OPERANDS is not torch.bfloat16 or not x.is_cuda or x.dim() != 4:
+        return False
+    if x.dtype not in (torch.float32, torch.bfloat16):
         return False
     if torch.is_autocast_enabled() or x.shape[2] != x.shape[3]:
         return False
@@ -1222,18 +1249,23 @@ class _ConvTilesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, transposed):
         ctx.set_materialize_grads(False)
-        x = _f32c(x)
+        x = _act(x)
         n, ks = x.shape[0], weight.shape[-1]
         cs, cb = weight.shape[0], weight.shape[1]
+        # a small side in fp32 next to a bf16 big side is the one pairing the kernels do not carry
+        out_dtype = torch.float32 if (transposed and x.dtype == torch.float32) else ACT_STORAGE
         if transposed:
             s = x.shape[2]
-            y = torch.empty(n, cb, 2 * s, 2 * s, device=x.device, dtype=torch.float32)
+            y = torch.empty(n, cb, 2 * s, 2 * s, device=x.device, dtype=out_dtype)
             small, big = x, y
         else:
             s = x.shape[2] // 2
-            y = torch.empty(n, cs, s, s, device=x.device, dtype=torch.float32)
+            if x.dtype == torch.bfloat16:
+                out_dtype = torch.bfloat16
+            y = torch.empty(n, cs, s, s, device=x.device, dtype=out_dtype)
             small, big = y, x
         a = _conv_desc(n, small.shape, big.shape, ks)
+        a.flags = _conv_flags(small, big)
         a.small, a.big = _ptr(small), _ptr(big)
         a.bias = _ptr(_f32c(bias.detach())) if bias is not None else None
         keep = _conv_pack(weight, a, transposed)
@@ -1247,12 +1279,13 @@ class _ConvTilesFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        gy = _f32c(gy)
+        gy = _act(gy)
         n, ks = x.shape[0], weight.shape[-1]
         transposed = ctx.transposed
         small, big = (x, gy) if transposed else (gy, x)
         gx = gw = gb = None
         a = _conv_desc(n, small.shape, big.shape, ks)
+        a.flags = _conv_flags(small, big)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             a.small, a.big = (_ptr(gx), _ptr(gy)) if transposed else (_ptr(gy), _ptr(gx))
@@ -1266,7 +1299,7 @@ class _ConvTilesFn(torch.autograd.Function):
             gw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
             _call('mdmm_conv_wgrad', C.byref(a), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % a.S)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3))
+            gb = gy.sum((0, 2, 3), dtype=torch.float32)
         return gx, gw, gb, None
 
 

@@ -1002,6 +1002,17 @@ def test_batchnorm_relu_matches_torch(dev, kernel_family, shape):
     close(got.running_mean, ref.running_mean, 1e-5, 'running mean')
     close(got.running_var, ref.running_var, 1e-5, 'running var')
     assert int(got.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+    # bf16-stored activations (MultiDGTS.act_dtype): the same passes reading / writing bf16, fp32 arithmetic;
+    # against the stock modules on the same bf16 values, outputs and gradients rounded to bf16 once
+    xb = (torch.randn(*shape, device=dev) * 1.7 + 0.4).to(torch.bfloat16)
+    wb = torch.randn(*shape, device=dev).to(torch.bfloat16)
+    xr, xg = xb.float().requires_grad_(), xb.clone().requires_grad_()
+    yr = torch.relu(ref(xr)); (yr * wb.float()).sum().backward()
+    yg = ops.batchnorm_relu(xg, got); (yg * wb).sum().backward()
+    assert yg.dtype == torch.bfloat16 and xg.grad.dtype == torch.bfloat16
+    close(yg.float(), yr, 8e-3, 'bn out, bf16 storage'); close(xg.grad.float(), xr.grad, 1e-2, 'bn dx, bf16 storage')
+    close(got.weight.grad, ref.weight.grad, 1e-3, 'bn dgamma, bf16 storage')
+    close(got.bias.grad, ref.bias.grad, 1e-3, 'bn dbeta, bf16 storage')
 
 
 def test_step_conv_plugins_matches_oracle(dev, kernel_family):
@@ -1151,9 +1162,24 @@ def test_conv_tiles_match_torch(dev, kind, c_in, c_out, size):
         close(gx, gxr, 1e-5, 'conv dgrad')
         close(gw, gwr, 1e-5, 'conv wgrad')
         close(gb, gy.sum((0, 2, 3)), 1e-5, 'conv bias grad')
+        # activations stored as bf16 (MultiDGTS.act_dtype): same contractions, outputs rounded once more
+        if c_in in (1, 3) and not tr:
+            xb = x.detach().requires_grad_()               # the first encoder layer reads the fp32 frames
+        else:
+            xb = x.detach().to(torch.bfloat16).requires_grad_()
+        with ops.conv_operands(torch.bfloat16, act=torch.bfloat16):
+            yb = ops.conv_tiles(layer, xb)
+        assert yb.dtype == torch.bfloat16
+        gyb = gy.to(torch.bfloat16)
+        gxb, gwb = torch.autograd.grad(yb, [xb, layer.weight], gyb)
+        assert gxb.dtype == xb.dtype
+        close(yb.float(), fn(xr, wr, layer.bias.detach(), 2, 1), 8e-3, 'conv fwd, bf16 storage')
+        close(gxb.float(), gxr, 8e-3, 'conv dgrad, bf16 storage')
+        close(gwb, gwr, 1e-5, 'conv wgrad, bf16 storage')
 
 
-def test_step_weizmann_frames_conv_bf16_matches_oracle(dev, kernel_family):
+@pytest.mark.parametrize('act', ['act_fp32', 'act_bf16'])
+def test_step_weizmann_frames_conv_bf16_matches_oracle(dev, kernel_family, act):
     """Full-size Weizmann plug-ins (64 x 64 frames, the stock ImageEncoder / ImageDecoder pyramids)
     with conv_dtype = bfloat16 (own bf16-operand convolutions, fused BatchNorm + ReLU, sigmoid + BCE)
     in a full ELBO step against the oracle running stock fp32 modules on the CPU; small latent so
@@ -1175,6 +1201,7 @@ def test_step_weizmann_frames_conv_bf16_matches_oracle(dev, kernel_family):
     enc, dec = plugins()
     m = models.MultiDMM(mods, dims, dists, encoders=enc, decoders=dec, h_dim=H, z_dim=D, device=dev)
     m.conv_dtype = torch.bfloat16
+    m.act_dtype = torch.bfloat16 if act == 'act_bf16' else torch.float32     # storage of the conv activations
     enc, dec = plugins()
     o = orc.OracleDMM(mods, dims, dists, encoders=enc, decoders=dec, h_dim=H, z_dim=D)
     o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
@@ -1251,3 +1278,15 @@ def test_linear_tiles_match_torch(dev, m, k, n):
         gw = gwide[:, 8:] if w.data_ptr() != wide.data_ptr() else gwide[:, :k]
         close(gw, rb(gy).t() @ xr, 2e-5, 'linear wgrad')
         close(gb, gy.sum(0), 1e-5, 'linear bias grad')
+    # bf16-stored input / output (the activations either side of the plug-ins' Linear heads)
+    xb = x.detach().to(torch.bfloat16).requires_grad_()
+    w = wide[:, :k]
+    yb = ops._LinearTilesFn.apply(xb, w, bias, torch.bfloat16)
+    assert yb.dtype == torch.bfloat16
+    gyb = torch.randn_like(yb)
+    gxb, gwb = torch.autograd.grad(yb, [xb, wide], gyb)
+    assert gxb.dtype == torch.bfloat16
+    xr, wr = xb.detach().float(), rb(w.detach())
+    close(yb.float(), xr @ wr.t() + bias.detach(), 8e-3, 'linear fwd, bf16 storage')
+    close(gxb.float(), gyb.float() @ wr, 8e-3, 'linear dgrad, bf16 storage')
+    close(gwb[:, :k], gyb.float().t() @ xr, 2e-5, 'linear wgrad, bf16 storage')

@@ -52,6 +52,7 @@ def weizmann(kind, B, T=40):
     if os.environ.get('SWEEP_BF16', '1') == '1':     # the headline mode of bench.py (bf16 operands)
         m.sweep_dtype = torch.bfloat16
         m.conv_dtype = torch.bfloat16
+        m.act_dtype = torch.bfloat16 if os.environ.get('ACT_BF16', '1') == '1' else torch.float32
     if os.environ.get('AMP') == '1':
         m.plugin_dtype = torch.bfloat16
     g = torch.Generator().manual_seed(1234)
