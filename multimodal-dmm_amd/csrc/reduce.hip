@@ -123,6 +123,13 @@ __device__ __forceinline__ float4 ld4f(const __bf16* p, int64_t i) {
   return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 
+// bf16-stored logits carry 8 significant bits: their loss terms take the short forms
+//   log sigmoid(l) = -softplus(-l),  log(1 - sigmoid(l)) = -softplus(l)   (one exp, one log, no division;
+// the -100 clamps of F.binary_cross_entropy cannot bind below |l| = 100) on the hardware exp / log.
+__device__ __forceinline__ float softplus_fast(float l) {
+  return fmaxf(l, 0.f) + mdmm::fast::log(1.0f + mdmm::fast::exp(-fabsf(l)));
+}
+
 // T = storage type of theta / g_theta (fp32, or bf16 for the logits of the bf16-activation plug-ins)
 template <bool LOGITS, typename T>
 __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ theta,
@@ -142,6 +149,11 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ thet
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (xs[j] != xs[j]) continue;
+        if constexpr (LOGITS && sizeof(T) == 2) {
+          const float sp = softplus_fast(ts[j]);                // -log(1 - theta); -log(theta) = sp - l
+          acc += sp - xs[j] * ts[j];
+          continue;
+        }
         if (LOGITS) ts[j] = sigmoid_ref(ts[j]);
         const float l1 = fmaxf(logf(ts[j]), -100.0f), l0 = fmaxf(log1pf(-ts[j]), -100.0f);
         acc -= xs[j] * l1 + (1.0f - xs[j]) * l0;              // F.binary_cross_entropy
@@ -160,21 +172,48 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ thet
   block_add((double)weight * (double)acc, out);
 }
 
+__device__ __forceinline__ void st4g(float* p, int64_t i, const float (&g)[4]) {
+  reinterpret_cast<float4*>(p)[i] = float4{g[0], g[1], g[2], g[3]};
+}
+__device__ __forceinline__ void st4g(__bf16* p, int64_t i, const float (&g)[4]) {
+  bf16x4_t v;
+  v[0] = (__bf16)g[0]; v[1] = (__bf16)g[1]; v[2] = (__bf16)g[2]; v[3] = (__bf16)g[3];
+  reinterpret_cast<bf16x4_t*>(p)[i] = v;
+}
+
+template <bool LOGITS, typename T>
+__device__ __forceinline__ float nllb_grad(float t, float xv, bool on, float scale) {
+  if (!(xv == xv) || !on) return 0.f;
+  if constexpr (LOGITS && sizeof(T) == 2) {
+    return scale * (mdmm::fast::sigmoid(t) - xv);                  // d/dl of softplus(l) - x l
+  } else {
+    const float th = LOGITS ? sigmoid_ref(t) : t;
+    float g = scale * (th - xv) / fmaxf((1.0f - th) * th, 1e-12f);   // torch BCE backward
+    if (LOGITS) g *= (1.0f - th) * th;                               // torch sigmoid backward
+    return g;
+  }
+}
+
 template <bool LOGITS, typename T>
 __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
     float scale, const float* __restrict__ scale_dev, T* g_theta) {
   if (scale_dev) scale *= *scale_dev;
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-    const float xv = x[i];
-    float g = 0.f;
-    if (xv == xv && !(mask && mask[i / inner] == 0.f)) {
-      const float th = LOGITS ? sigmoid_ref((float)theta[i]) : (float)theta[i];
-      g = scale * (th - xv) / fmaxf((1.0f - th) * th, 1e-12f);   // torch BCE backward
-      if (LOGITS) g *= (1.0f - th) * th;                           // torch sigmoid backward
+  if ((inner & 3) == 0 && (n & 3) == 0) {
+    const int64_t n4 = n >> 2;
+    const int inner4 = inner >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+      const bool on = !(mask && mask[i / inner4] == 0.f);
+      const float4 xv = reinterpret_cast<const float4*>(x)[i];
+      const float4 th = ld4f(theta, i);
+      const float g[4] = {nllb_grad<LOGITS, T>(th.x, xv.x, on, scale), nllb_grad<LOGITS, T>(th.y, xv.y, on, scale),
+                          nllb_grad<LOGITS, T>(th.z, xv.z, on, scale), nllb_grad<LOGITS, T>(th.w, xv.w, on, scale)};
+      st4g(g_theta, i, g);
     }
-    g_theta[i] = (T)g;
+    return;
   }
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+    g_theta[i] = (T)nllb_grad<LOGITS, T>((float)theta[i], x[i], !(mask && mask[i / inner] == 0.f), scale);
 }
 
 // ---------------------------------------------------------------- nll_categorical --
@@ -403,7 +442,7 @@ extern "C" int mdmm_nll_bernoulli_logits_bwd(const float* logits, const float* x
                                              const float* scale_dev, float* g_logits, void* stream) {
   if (!logits || !x || !g_logits || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
-  hipLaunchKernelGGL((nllb_bwd_kernel<true, float>), dim3(grid_for(n)), dim3(NT), 0, STREAM, logits, x, seq_mask,
+  hipLaunchKernelGGL((nllb_bwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, logits, x, seq_mask,
                      n, inner, scale, scale_dev, g_logits);
   CHECK_LAUNCH();
 }
@@ -423,7 +462,7 @@ extern "C" int mdmm_nll_bernoulli_logits_bf16_bwd(const void* logits, const floa
                                                   const float* scale_dev, void* g_logits, void* stream) {
   if (!logits || !x || !g_logits || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
-  hipLaunchKernelGGL((nllb_bwd_kernel<true, __bf16>), dim3(grid_for(n)), dim3(NT), 0, STREAM, (const __bf16*)logits,
+  hipLaunchKernelGGL((nllb_bwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, (const __bf16*)logits,
                      x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits);
   CHECK_LAUNCH();
 }
