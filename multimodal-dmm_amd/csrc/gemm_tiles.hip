@@ -10,8 +10,8 @@
 // Workgroup = 4 waves on a 128 x 128 tile of C, 32 contraction steps at a time through LDS
 // ([row][32 l] bf16, 80-byte rows), each wave a 64 x 64 quadrant (2 x 2 MFMA 32x32x16 tiles);
 // the next step's global loads are in flight while the current one is multiplied.  Transposed
-// operands are staged eight contraction rows at a time (eight coalesced float4 loads, four
-// 16-byte LDS writes), so all three products stream their operands at full line width.
+// operands are staged four contraction rows at a time (four coalesced float4 loads, four
+// 8-byte LDS writes), so all three products stream their operands at full line width.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mdmm_hip.h"
@@ -31,8 +31,8 @@ __device__ __forceinline__ constexpr int acc_row(int reg) { return 8 * (reg >> 2
 
 // One operand tile (BT rows x BL) of the step starting at l0: registers <- global.
 //   direct:      item = (row, l-group of 4): one float4                    -> 4 items / thread
-//   transposed:  item = (l-group of 8, row-group of 4): eight float4       -> 1 item / thread
-struct Regs { float4 v[8]; };
+//   transposed:  item = (l-group of 4, row-group of 4): four float4        -> 1 item / thread
+struct Regs { float4 v[4]; };
 
 // four consecutive elements at element offset `at`, fp32 or bf16 in memory
 __device__ __forceinline__ float4 ld4(const void* src, int64_t at, bool bf) {
@@ -55,14 +55,13 @@ __device__ __forceinline__ void load_tile(const void* src, bool bf, int64_t ld, 
       r.v[q] = v;
     }
   } else {
-    const int lg = tid >> 5, rg = tid & 31;          // 4 l-groups x 32 row-groups = 128 threads ...
-    // ... 256 threads: two halves of the l range? no: 32 l = 4 groups of 8, 128 rows = 32 groups of 4
-    // -> 128 items; threads 128..255 take no item (their registers stay zero)
+    // item = (l-group of 4 contraction rows, row-group of 4): 8 x 32 = 256 items, one per thread
+    const int lg = tid >> 5, rg = tid & 31;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4; ++q) {
       float4 v = float4{0.f, 0.f, 0.f, 0.f};
-      const int l = l0 + 8 * lg + q;
-      if (tid < 128 && l < L && row0 + 4 * rg < rows) v = ld4(src, (int64_t)l * ld + row0 + 4 * rg, bf);
+      const int l = l0 + 4 * lg + q;
+      if (l < L && row0 + 4 * rg < rows) v = ld4(src, (int64_t)l * ld + row0 + 4 * rg, bf);
       r.v[q] = v;
     }
   }
@@ -79,18 +78,17 @@ __device__ __forceinline__ void store_tile(char* lds, int tid, const Regs& r) {
       *reinterpret_cast<uint2*>(lds + row * RS + lg * 8) = __builtin_bit_cast(uint2, b);
     }
   } else {
-    if (tid >= 128) return;
     const int lg = tid >> 5, rg = tid & 31;
-    bf16x8 b0, b1, b2, b3;
+    bf16x4 b0, b1, b2, b3;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4; ++q) {
       b0[q] = (__bf16)r.v[q].x; b1[q] = (__bf16)r.v[q].y; b2[q] = (__bf16)r.v[q].z; b3[q] = (__bf16)r.v[q].w;
     }
-    char* at = lds + (4 * rg) * RS + lg * 16;
-    *reinterpret_cast<uint4*>(at) = __builtin_bit_cast(uint4, b0);
-    *reinterpret_cast<uint4*>(at + RS) = __builtin_bit_cast(uint4, b1);
-    *reinterpret_cast<uint4*>(at + 2 * RS) = __builtin_bit_cast(uint4, b2);
-    *reinterpret_cast<uint4*>(at + 3 * RS) = __builtin_bit_cast(uint4, b3);
+    char* at = lds + (4 * rg) * RS + lg * 8;
+    *reinterpret_cast<uint2*>(at) = __builtin_bit_cast(uint2, b0);
+    *reinterpret_cast<uint2*>(at + RS) = __builtin_bit_cast(uint2, b1);
+    *reinterpret_cast<uint2*>(at + 2 * RS) = __builtin_bit_cast(uint2, b2);
+    *reinterpret_cast<uint2*>(at + 3 * RS) = __builtin_bit_cast(uint2, b3);
   }
 }
 
