@@ -22,3 +22,16 @@ int mdmm_sweep_check_args(const mdmm_sweep_t* a, int bwd);
 int mdmm_mfma_bwd_supported(const mdmm_sweep_t* a);
 int mdmm_mfma_dw_width(int D, int H);
 int64_t mdmm_mfma_dw_rows(const mdmm_sweep_t* a);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: `done` is one slot array per
+// kernel (a function-local static of the caller), indexed by the current device.
+struct MdmmLdsGuard { size_t bytes[64] = {}; };
+inline int mdmm_lds_attr(MdmmLdsGuard& g, const void* kern, size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (g.bytes[dev] >= bytes) return 0;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  g.bytes[dev] = bytes;
+  return 0;
+}

@@ -1855,13 +1855,8 @@ int launch_bwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   const size_t lds = w_end * sizeof(float4) + (scr > red ? scr : red) +
                      (48 * DT + 2 * (NT / 64) * 32 * DT) * sizeof(float);
   auto kern = sweep_mfma_bwd_kernel<DT, HT, CT, FULL, WS>;
-  static size_t attr_lds = 0;         // per template instantiation (LDS size depends on CT only)
-  if (attr_lds < lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_lds = lds;
-  }
+  static MdmmLdsGuard guard;          // per template instantiation, per device
+  if (int e = mdmm_lds_attr(guard, (const void*)kern, lds)) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, stream, *a, n_tasks);
   return (int)hipGetLastError();
 }
@@ -1886,13 +1881,8 @@ int launch_bwd_coop_(const mdmm_sweep_t* a, hipStream_t stream) {
   const int n_rounds = (blocks + grid - 1) / grid;
   if (!a->dw_partial || a->dw_partial_rows < grid) return MDMM_E_ARG;
   auto kern = sweep_mfma_bwd_coop_kernel<DT, HT, CT, FULL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LC::BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static MdmmLdsGuard guard;
+  if (int e = mdmm_lds_attr(guard, (const void*)kern, (size_t)LC::BYTES)) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTC), LC::BYTES, stream, *a, n_tasks, n_rounds);
   return (int)hipGetLastError();
 }
@@ -1930,13 +1920,8 @@ int launch_fwd_(const mdmm_sweep_t* a, hipStream_t stream) {
   const size_t lds = (size_t)FwdLds<DT, HT, kSplitOk && DT == 2 && HT == 2>::END * sizeof(float4) +
                      (WS ? (size_t)2 * (NT / 128) * 3 * DT * 64 * sizeof(float4) : 0);
   auto kern = sweep_mfma_fwd_kernel<DT, HT, CT, PART, FULL, WS>;
-  static bool attr_set = false;       // per template instantiation
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static MdmmLdsGuard guard;          // per template instantiation, per device
+  if (int e = mdmm_lds_attr(guard, (const void*)kern, lds)) return e;
   const int tpw = WS ? NT / 128 : NT / 64;
   hipLaunchKernelGGL(kern, dim3((n_tasks + tpw - 1) / tpw), dim3(NT), lds, stream, *a, n_tasks);
   return (int)hipGetLastError();

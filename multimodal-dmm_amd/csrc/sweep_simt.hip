@@ -532,13 +532,8 @@ int mdmm_simt_sweep_fwd(const mdmm_sweep_t* args, hipStream_t stream) {
   Launch L;
   int rc = plan(args, false, &L);
   if (rc) return rc;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)sweep_fwd_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static MdmmLdsGuard guard;
+  if (int e = mdmm_lds_attr(guard, (const void*)sweep_fwd_kernel, LDS_MAX)) return e;
   hipLaunchKernelGGL(sweep_fwd_kernel, dim3(L.grid, args->P / L.Pl), dim3(NT), L.lds, stream, *args, L.S,
                      L.RC, L.Pl);
   return (int)hipGetLastError();
@@ -548,13 +543,8 @@ int mdmm_simt_sweep_bwd(const mdmm_sweep_t* args, hipStream_t stream) {
   Launch L;
   int rc = plan(args, true, &L);
   if (rc) return rc;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)sweep_bwd_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static MdmmLdsGuard guard;
+  if (int e = mdmm_lds_attr(guard, (const void*)sweep_bwd_kernel, LDS_MAX)) return e;
   hipLaunchKernelGGL(sweep_bwd_kernel, dim3(L.grid, args->P / L.Pl), dim3(NT), L.lds, stream, *args, L.S,
                      L.RC, L.Pl);
   return (int)hipGetLastError();

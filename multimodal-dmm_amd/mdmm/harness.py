@@ -121,11 +121,19 @@ class GraphedElboStep:
     host-bound).  Two graphs with the collective between them, so nothing RCCL-related is ever
     captured:   [model.step + backward]  ->  all_reduce(flat grads)  ->  [Adam + zero grads].
     Shapes and tensors are static (the batch buffers are filled in place by the caller);
-    fresh noise per replay comes from the Philox device counter (PhiloxNoise.advance)."""
+    fresh noise per replay comes from the Philox device counter (PhiloxNoise.advance).
+
+    For steady-state measurement and fixed-schedule training only: `kld_mult`, `rec_mults`, `lengths`
+    and the normalisation by the number of time-points are Python constants frozen into the captured
+    launches (a trainer that anneals the KLD weight, trainer.py:227-229, or changes the batch shape
+    re-captures, or uses `elbo_step`); gradient clipping is not part of the captured step; the
+    constructor's `warmup` eager steps are real optimizer steps on the given batch."""
 
     def __init__(self, model, optimizer, bucket, inputs, mask, lengths, kld_mult, rec_mults,
                  targets=None, n_points_global=None, group=None, warmup=3, **train_args):
         from . import ops
+        if train_args.pop('clip_grad', None):
+            raise ValueError('GraphedElboStep does not capture gradient clipping: use elbo_step')
         self.model, self.optimizer, self.bucket, self.group = model, optimizer, bucket, group
         n_points = sum(lengths) if n_points_global is None else n_points_global
         noise = model._noise()
