@@ -19,7 +19,7 @@
 // of the reference's image models (n_kernels = 64, n_layers = 3).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/mdmm_hip.h"
+#include "sweep_internal.h"
 
 namespace {
 
@@ -439,16 +439,7 @@ int shape_id(const mdmm_conv_t* a) {
 }
 
 template <typename Kern>
-int set_lds(Kern kern, int bytes) {
-  static bool done[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (done[dev]) return 0;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) return (int)e;
-  done[dev] = true;
-  return 0;
-}
+int set_lds(Kern kern, int bytes) { return mdmm_lds_attr_fn((const void*)kern, (size_t)bytes); }
 
 int grid_for(int N, int per_cu) { const int g = 256 * per_cu; return N < g ? N : g; }
 

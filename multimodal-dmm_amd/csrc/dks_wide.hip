@@ -572,16 +572,7 @@ __global__ __launch_bounds__(256) void layers_pack_kernel(const mdmm_frag_layers
 }
 
 template <typename Kern>
-int set_lds(Kern kern, int bytes) {
-  static bool done[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (done[dev]) return 0;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) return (int)e;
-  done[dev] = true;
-  return 0;
-}
+int set_lds(Kern kern, int bytes) { return mdmm_lds_attr_fn((const void*)kern, (size_t)bytes); }
 
 int rows_per_wg(int B) { return B <= 8 * 256 ? 8 : (B <= 16 * 256 ? 16 : 32); }
 

@@ -35,3 +35,22 @@ inline int mdmm_lds_attr(MdmmLdsGuard& g, const void* kern, size_t bytes) {
   g.bytes[dev] = bytes;
   return 0;
 }
+
+// The same keyed by the kernel's address, for launchers that are templates over the kernel (a
+// function-local static there would be shared by every kernel of the same signature).
+#include <map>
+#include <mutex>
+#include <utility>
+inline int mdmm_lds_attr_fn(const void* kern, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> seen;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = seen[std::make_pair(kern, dev)];
+  if (have >= bytes) return 0;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  have = bytes;
+  return 0;
+}

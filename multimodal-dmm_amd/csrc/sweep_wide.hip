@@ -1021,17 +1021,7 @@ __global__ __launch_bounds__(256) void frag_pack_kernel(const mdmm_gtf_raw_t raw
 // host side
 // ---------------------------------------------------------------------------------------
 template <typename Kern>
-int set_lds(Kern kern, int bytes) {
-  // per device, not per process: a second GPU driven by the same process needs its own call
-  static bool done[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (done[dev]) return 0;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) return (int)e;
-  done[dev] = true;
-  return 0;
-}
+int set_lds(Kern kern, int bytes) { return mdmm_lds_attr_fn((const void*)kern, (size_t)bytes); }
 
 template <bool F32, int RT, bool K1>
 int launch_fwd(const mdmm_sweep_t* a, const WideGeo& g, hipStream_t stream) {

@@ -294,16 +294,7 @@ __global__ __launch_bounds__(NTHR) void trans_wide_bwd_kernel(const mdmm_sweep_t
 }
 
 template <typename Kern>
-int set_lds(Kern kern, int bytes) {
-  static bool done[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (done[dev]) return 0;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) return (int)e;
-  done[dev] = true;
-  return 0;
-}
+int set_lds(Kern kern, int bytes) { return mdmm_lds_attr_fn((const void*)kern, (size_t)bytes); }
 
 template <typename Kern>
 int launch(Kern kern, const mdmm_sweep_t* a, int lds, hipStream_t stream) {

@@ -16,6 +16,8 @@ Noise: in-kernel Philox by default; assign `model.noise = ReplayNoise(draws)` to
 draws recorded from the reference's `_sample_gauss` in its own call order.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -425,10 +427,14 @@ class MultiDMM(MultiDGTS):
         # cached and then read by the others without a dependency -- a race under graph replay).
         for direction in ('fwd', 'bwd'):
             ops.prepack_gtf(self._gtf(direction), self.z_dim, self.h_dim, self.sweep_dtype)
+        if self.conv_dtype is torch.bfloat16:           # (the same for the conv plug-ins' weight packs)
+            ops.prepack_convs(list(self.enc.values()) + list(self.dec.values()))
         if match_mult > 0:
             if self._match_stream is None:
                 self._match_stream = torch.cuda.Stream(device=self.z0_mean.device)
             third = self._match_stream
+            if os.environ.get('MDMM_ONE_STREAM') == '1':        # A/B switch: everything on the caller's stream
+                third = torch.cuda.current_stream()
             for x in match_eps:
                 x.record_stream(third)
             third.wait_stream(torch.cuda.current_stream())
@@ -453,6 +459,8 @@ class MultiDMM(MultiDGTS):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.z0_mean.device)
         side = self._side_stream
+        if os.environ.get('MDMM_ONE_STREAM') == '1':
+            side = main
         # tell the allocator the encoder outputs are also read on the side stream
         for mu, sd, seen in enc.values():
             for x in (mu, sd, seen):

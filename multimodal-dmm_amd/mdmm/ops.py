@@ -1200,32 +1200,42 @@ def _conv_desc(n, small_shape, big_shape, ks):
     return a
 
 
-def conv_tiles_supported(layer, x):
-    """Conv2d(k3,s2,p1) / ConvTranspose2d(k4,s2,p1) of the 64 x 64 pyramids, fp32 on the GPU, while
-    conv_operands(torch.bfloat16) is active."""
+def _conv_shape_ok(layer, shape):
+    """(N, C, H, W) -> output shape of a Conv2d(k3,s2,p1) / ConvTranspose2d(k4,s2,p1) the tile kernels
+    take, or None."""
     import torch.nn as nn
-    if CONV_OPERANDS is not torch.bfloat16 or not x.is_cuda or x.dim() != 4:
-        return False
-    if x.dtype not in (torch.float32, torch.bfloat16):
-        return False
-    if torch.is_autocast_enabled() or x.shape[2] != x.shape[3]:
-        return False
+    if len(shape) != 4 or shape[2] != shape[3]:
+        return None
     tr = isinstance(layer, nn.ConvTranspose2d)
     if not tr and not isinstance(layer, nn.Conv2d):
-        return False
+        return None
     ks = 4 if tr else 3
     if (tuple(layer.kernel_size) != (ks, ks) or tuple(layer.stride) != (2, 2) or tuple(layer.padding) != (1, 1)
             or tuple(layer.dilation) != (1, 1) or layer.groups != 1 or layer.padding_mode != 'zeros'):
-        return False
+        return None
     if tr and tuple(layer.output_padding) != (0, 0):
-        return False
+        return None
+    if layer.weight.dtype != torch.float32:
+        return None
     cs, cb = layer.weight.shape[0], layer.weight.shape[1]
-    s = x.shape[2] if tr else x.shape[2] // 2
-    if x.shape[1] != (cs if tr else cb) or (not tr and x.shape[2] % 2):
-        return False
+    s = shape[2] if tr else shape[2] // 2
+    if shape[1] != (cs if tr else cb) or (not tr and shape[2] % 2):
+        return None
     a = native.Conv()
-    a.N, a.S, a.CS, a.CB, a.KS = x.shape[0], s, cs, cb, ks
-    return bool(native.lib().mdmm_conv_supported(C.byref(a)))
+    a.N, a.S, a.CS, a.CB, a.KS = shape[0], s, cs, cb, ks
+    if not native.lib().mdmm_conv_supported(C.byref(a)):
+        return None
+    return (shape[0], cb, 2 * s, 2 * s) if tr else (shape[0], cs, s, s)
+
+
+def conv_tiles_supported(layer, x):
+    """Conv2d(k3,s2,p1) / ConvTranspose2d(k4,s2,p1) of the 64 x 64 pyramids, fp32 or bf16 activations
+    on the GPU, while conv_operands(torch.bfloat16) is active."""
+    if CONV_OPERANDS is not torch.bfloat16 or not x.is_cuda or x.dim() != 4:
+        return False
+    if x.dtype not in (torch.float32, torch.bfloat16) or torch.is_autocast_enabled():
+        return False
+    return _conv_shape_ok(layer, tuple(x.shape)) is not None
 
 
 def _conv_pack(weight, a, up):
@@ -1240,6 +1250,30 @@ def _conv_pack(weight, a, up):
         hit = (key, buf)
         setattr(weight, name, hit)
     return hit[1]
+
+
+def prepack_convs(modules):
+    """Build (or refresh) both fragment packs of every stride-2 layer of the given plug-in modules on the
+    current stream.  A step that forks streams calls this before the fork: the packs are cached on the
+    weights, and one built on a forked stream would be read by the others without a dependency."""
+    import torch.nn as nn
+    table = {(64, 32): 8, (32, 16): 16}
+    for mod in modules:
+        for layer in mod.modules():
+            if not isinstance(layer, (nn.Conv2d, nn.ConvTranspose2d)) or not layer.weight.is_cuda:
+                continue
+            cs, cb = layer.weight.shape[0], layer.weight.shape[1]
+            s = table.get((cs, cb), 32 if (cs == 16 and cb <= 4) else None)
+            if s is None:
+                continue
+            tr = isinstance(layer, nn.ConvTranspose2d)
+            n_in = cs if tr else cb
+            if _conv_shape_ok(layer, (1, n_in, s if tr else 2 * s, s if tr else 2 * s)) is None:
+                continue
+            a = native.Conv()
+            a.N, a.S, a.CS, a.CB, a.KS = 1, s, cs, cb, layer.weight.shape[-1]
+            _conv_pack(layer.weight, a, True)
+            _conv_pack(layer.weight, a, False)
 
 
 class _ConvTilesFn(torch.autograd.Function):
