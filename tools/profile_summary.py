@@ -12,14 +12,14 @@ for d, _, fs in os.walk(os.path.join(src, tag + '_stats')):
             stats = os.path.join(d, f)
 shutil.copy(stats, os.path.join(R, 'profiles', tag + '_kernel_stats.csv'))
 rows = list(csv.DictReader(open(stats)))
-rf, cb = bench['roofline'], bench['cpu_baseline']
+rf, cb = bench['roofline'], bench.get('cpu_baseline')
 out = ['# ' + title, '',
-       '`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` (cfg2, MI355X).',
+       '`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py ...` (tools/prof_bench.sh / prof_cfg2.sh; MI355X; workload: %s).' % bench['config']['workload'][:60],
        'bench.py on the same box, same commit (`%s_bench.json`): %.3f ms/step = %.0f sequences/s; dominant kernel `%s`'
        % (tag, bench['ms_per_step'], bench['value'], rf['kernel']),
-       '%.3f ms/launch by HIP events -> %.1f TFLOP/s f32 = %.3f of the %.1f TFLOP/s peak.'
-       % (rf['launch_ms'], rf['achieved'], rf['frac'], rf['peak']),
-       'CPU oracle on the same box: %.3f sequences/s.' % cb['value'], '',
+       '%.3f ms/launch by HIP events -> %.1f TFLOP/s = %.3f of the %.1f TFLOP/s peak (%s operands).'
+       % (rf['launch_ms'], rf['achieved'], rf['frac'], rf['peak'], rf.get('operands', '')),
+       ('CPU oracle on the same box: %.3f sequences/s.' % cb['value']) if cb else 'CPU baseline: see the full bench line.', '',
        '| kernel | calls | total ms | avg us | % |', '|---|---|---|---|---|']
 def short(n):
     n = re.sub(r'\(anonymous namespace\)::', '', n); n = re.sub(r'^void ', '', n); n = n.replace('at::native::', '', 1)
