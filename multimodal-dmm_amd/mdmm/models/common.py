@@ -98,6 +98,8 @@ class _ConvBlock(nn.Module):
         from .. import ops
         if ops.conv_tiles_supported(layer, x):          # own bf16-operand kernels (csrc/conv_tiles.hip)
             return ops.conv_tiles(layer, x, bias=False)
+        if x.dtype != layer.weight.dtype:                # (a bf16-stored activation reaching a library layer)
+            x = x.to(layer.weight.dtype)
         if isinstance(layer, (nn.Conv1d, nn.Conv2d)):
             return layer._conv_forward(x, layer.weight, None)
         fn = F.conv_transpose2d if isinstance(layer, nn.ConvTranspose2d) else F.conv_transpose1d
@@ -119,6 +121,8 @@ class _ConvBlock(nn.Module):
         from .. import ops
         if ops.conv_tiles_supported(self.net, x):
             return ops.conv_tiles(self.net, x)
+        if x.dtype != self.net.weight.dtype:
+            x = x.to(self.net.weight.dtype)
         return self.net(x)
 
 
@@ -217,7 +221,11 @@ class _ProbDecoder(nn.Module):
 
     def forward(self, z, logits=False):
         from .. import ops
-        x = self.z_to_feat[1](ops.plug_linear(self.z_to_feat[0], z, act_out=True)).view(-1, *self.feat_shape)
+        first = getattr(self.deconv_stack[0], 'net', None)
+        first = first[0] if isinstance(first, nn.Sequential) else first
+        # bf16-stored activations only into a stack the tile kernels take (the audio stacks stay fp32)
+        act = ops.conv_chain_takes(first, (z.shape[0],) + tuple(self.feat_shape)) if z.is_cuda else False
+        x = self.z_to_feat[1](ops.plug_linear(self.z_to_feat[0], z, act_out=act)).view(-1, *self.feat_shape)
         if logits:      # everything but the final nn.Sigmoid (for the fused sigmoid + BCE loss)
             for layer in list(self.deconv_stack)[:-1]:
                 x = layer(x)

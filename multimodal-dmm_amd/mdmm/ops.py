@@ -1238,6 +1238,13 @@ def conv_tiles_supported(layer, x):
     return _conv_shape_ok(layer, tuple(x.shape)) is not None
 
 
+def conv_chain_takes(layer, shape):
+    """True when `layer` applied to an activation of this (N, C, H, W) shape runs on the tile kernels
+    now -- i.e. its input may be handed over in ACT_STORAGE instead of fp32."""
+    return CONV_OPERANDS is torch.bfloat16 and not torch.is_autocast_enabled() \
+        and _conv_shape_ok(layer, tuple(shape)) is not None
+
+
 def _conv_pack(weight, a, up):
     """MFMA fragment pack of a layer's weights for one direction, cached on the parameter."""
     key = (weight.data_ptr(), weight._version, a.S, a.KS)

@@ -1015,8 +1015,11 @@ def test_batchnorm_relu_matches_torch(dev, kernel_family, shape):
     close(got.bias.grad, ref.bias.grad, 1e-3, 'bn dbeta, bf16 storage')
 
 
-def test_step_conv_plugins_matches_oracle(dev, kernel_family):
-    """Weizmann-style plug-ins at toy size (conv encoders / decoders with BatchNorm, Bernoulli
+@pytest.mark.parametrize('switches', ['fp32', 'bf16_switches'])
+def test_step_conv_plugins_matches_oracle(dev, kernel_family, switches):
+    """(bf16_switches: conv_dtype = act_dtype = bfloat16 on plug-ins the tile kernels do NOT take --
+    16 x 16 frames -- must fall back to the library's fp32 layers without handing them bf16 tensors.)
+    Weizmann-style plug-ins at toy size (conv encoders / decoders with BatchNorm, Bernoulli
     images, a categorical label): exercises the fused NaN cleaning, BatchNorm + ReLU and
     sigmoid + BCE kernels inside a full ELBO step against the oracle running the same modules
     as stock PyTorch on the CPU (common.py:70-175, losses.py:23-42)."""
@@ -1038,6 +1041,8 @@ def test_step_conv_plugins_matches_oracle(dev, kernel_family):
         return enc, dec
     enc, dec = plugins()
     m = models.MultiDMM(mods, dims, dists, encoders=enc, decoders=dec, h_dim=H, z_dim=D, device=dev)
+    if switches == 'bf16_switches':
+        m.conv_dtype = m.act_dtype = m.sweep_dtype = torch.bfloat16
     enc, dec = plugins()
     o = orc.OracleDMM(mods, dims, dists, encoders=enc, decoders=dec, h_dim=H, z_dim=D)
     o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})

@@ -111,6 +111,10 @@ def vidtimit(B, T=128):
                         decoders={'video': C.ImageDecoder(256), 'audio': C.AudioDecoder(256)},
                         h_dim=256, z_dim=256, device=dev)
     m.noise = PhiloxNoise(seed=1)
+    if os.environ.get('SWEEP_BF16', '1') == '1':     # as bench.py's cfg3: bf16 operands / bf16-stored conv activations
+        m.sweep_dtype = torch.bfloat16
+        m.conv_dtype = torch.bfloat16
+        m.act_dtype = torch.bfloat16 if os.environ.get('ACT_BF16', '1') == '1' else torch.float32
     g = torch.Generator().manual_seed(1234)
     lengths = sorted(torch.randint(T // 2, T + 1, (B,), generator=g).tolist(), reverse=True)
     lengths[0] = T
