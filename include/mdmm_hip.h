@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 15
+#define MDMM_ABI_VERSION 16
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -498,6 +498,23 @@ int mdmm_conv_up(const mdmm_conv_t* args, void* stream);
 int mdmm_conv_down(const mdmm_conv_t* args, void* stream);
 int64_t mdmm_conv_wgrad_ws_bytes(const mdmm_conv_t* args);
 int mdmm_conv_wgrad(const mdmm_conv_t* args, void* ws, float* dw, void* stream);
+
+/* Stride-2 1-D convolution pyramids of the audio plug-ins (common.py:177-219, 221-290): AudioConv =
+ * nn.Conv1d(k3,s2,p1), AudioDeconv = nn.ConvTranspose1d(k3,s2,p1).  SMALL side (N, CS, S), BIG side
+ * (N, CB, 2S - 1), weight as torch stores it, [CS][CB][3] (Conv: small = output; Deconv: small = input),
+ * fp32 throughout (csrc/conv1d.hip); CS, CB <= 16.  up / down / wgrad as for mdmm_conv_t.  */
+typedef struct mdmm_conv1d {
+  int32_t N, S, CS, CB;
+  float* small;
+  float* big;
+  const float* weight;
+  const float* bias;     /* optional, per output channel of up / down */
+} mdmm_conv1d_t;
+int mdmm_conv1d_supported(const mdmm_conv1d_t* args);
+int mdmm_conv1d_up(const mdmm_conv1d_t* args, void* stream);
+int mdmm_conv1d_down(const mdmm_conv1d_t* args, void* stream);
+int64_t mdmm_conv1d_wgrad_ws_bytes(const mdmm_conv1d_t* args);
+int mdmm_conv1d_wgrad(const mdmm_conv1d_t* args, void* ws, float* dw, void* stream);
 
 /* Time-parallel projections (every nn.Linear applied to all T*B rows at once: dks.py:219-231,
  * 246-280 GRU input projections / combiner feature columns; the Linear heads of the image

@@ -80,6 +80,7 @@ extern "C" size_t mdmm_sizeof(int which) {
     case 8: return sizeof(mdmm_conv_t);
     case 9: return sizeof(mdmm_frag_layers_t);
     case 10: return sizeof(mdmm_gemm_t);
+    case 11: return sizeof(mdmm_conv1d_t);
     default: return 0;
   }
 }

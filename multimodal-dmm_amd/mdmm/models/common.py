@@ -98,6 +98,8 @@ class _ConvBlock(nn.Module):
         from .. import ops
         if ops.conv_tiles_supported(layer, x):          # own bf16-operand kernels (csrc/conv_tiles.hip)
             return ops.conv_tiles(layer, x, bias=False)
+        if ops.conv1d_tiles_supported(layer, x):        # the audio pyramids (csrc/conv1d.hip, fp32)
+            return ops.conv1d_tiles(layer, x, bias=False)
         if x.dtype != layer.weight.dtype:                # (a bf16-stored activation reaching a library layer)
             x = x.to(layer.weight.dtype)
         if isinstance(layer, (nn.Conv1d, nn.Conv2d)):
@@ -121,6 +123,8 @@ class _ConvBlock(nn.Module):
         from .. import ops
         if ops.conv_tiles_supported(self.net, x):
             return ops.conv_tiles(self.net, x)
+        if ops.conv1d_tiles_supported(self.net, x):
+            return ops.conv1d_tiles(self.net, x)
         if x.dtype != self.net.weight.dtype:
             x = x.to(self.net.weight.dtype)
         return self.net(x)

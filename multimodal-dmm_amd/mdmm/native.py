@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 15
+ABI_VERSION = 16
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -37,6 +37,7 @@ SYMBOLS = [
     'mdmm_conv_wgrad_ws_bytes', 'mdmm_conv_wgrad',
     'mdmm_gemm_supported', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
     'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
+    'mdmm_conv1d_supported', 'mdmm_conv1d_up', 'mdmm_conv1d_down', 'mdmm_conv1d_wgrad_ws_bytes', 'mdmm_conv1d_wgrad',
 ]
 
 _P = C.c_void_p
@@ -124,6 +125,10 @@ class Bn(C.Structure):
 class Conv(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB', 'KS', 'flags')] +
                 [(n, _P) for n in ('small', 'big', 'wfrag', 'bias')])
+
+
+class Conv1d(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB')] + [(n, _P) for n in ('small', 'big', 'weight', 'bias')])
 
 
 class Gemm(C.Structure):
@@ -230,6 +235,12 @@ def lib():
         L.mdmm_conv_wgrad_ws_bytes.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_wgrad_ws_bytes.restype = C.c_int64
         L.mdmm_conv_wgrad.argtypes = [C.POINTER(Conv), _P, _P, _P]
+        L.mdmm_conv1d_supported.argtypes = [C.POINTER(Conv1d)]
+        L.mdmm_conv1d_up.argtypes = [C.POINTER(Conv1d), _P]
+        L.mdmm_conv1d_down.argtypes = [C.POINTER(Conv1d), _P]
+        L.mdmm_conv1d_wgrad_ws_bytes.argtypes = [C.POINTER(Conv1d)]
+        L.mdmm_conv1d_wgrad_ws_bytes.restype = C.c_int64
+        L.mdmm_conv1d_wgrad.argtypes = [C.POINTER(Conv1d), _P, _P, _P]
         L.mdmm_gemm_supported.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_ws_bytes.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_ws_bytes.restype = C.c_int64
@@ -237,7 +248,7 @@ def lib():
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
         for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp), (7, Bn), (8, Conv),
-                          (9, FragLayers), (10, Gemm)):
+                          (9, FragLayers), (10, Gemm), (11, Conv1d)):
             if L.mdmm_sizeof(which) != C.sizeof(st):
                 raise MdmmError('struct %s: library %d bytes, binding %d bytes'
                                 % (st.__name__, L.mdmm_sizeof(which), C.sizeof(st)))

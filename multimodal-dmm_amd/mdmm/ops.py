@@ -1259,6 +1259,92 @@ def _conv_pack(weight, a, up):
     return hit[1]
 
 
+# ---- stride-2 1-D pyramids of the audio plug-ins (csrc/conv1d.hip, fp32) -----------------------------
+def _conv1d_desc(layer, shape):
+    """native.Conv1d of a Conv1d(k3,s2,p1) / ConvTranspose1d(k3,s2,p1) applied to (N, C, L), or None."""
+    import torch.nn as nn
+    tr = isinstance(layer, nn.ConvTranspose1d)
+    if not tr and not isinstance(layer, nn.Conv1d):
+        return None
+    if (tuple(layer.kernel_size) != (3,) or tuple(layer.stride) != (2,) or tuple(layer.padding) != (1,)
+            or tuple(layer.dilation) != (1,) or layer.groups != 1 or layer.padding_mode != 'zeros'
+            or layer.weight.dtype != torch.float32 or len(shape) != 3):
+        return None
+    if tr and tuple(layer.output_padding) != (0,):
+        return None
+    cs, cb = layer.weight.shape[0], layer.weight.shape[1]
+    n, c, ln = shape
+    if tr:
+        s = ln
+        if c != cs:
+            return None
+    else:
+        if c != cb or ln % 2 == 0:
+            return None
+        s = (ln + 1) // 2
+    a = native.Conv1d()
+    a.N, a.S, a.CS, a.CB = n, s, cs, cb
+    return a if native.lib().mdmm_conv1d_supported(C.byref(a)) else None
+
+
+def conv1d_tiles_supported(layer, x):
+    return (x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and _conv1d_desc(layer, tuple(x.shape)) is not None)
+
+
+class _Conv1dFn(torch.autograd.Function):
+    """One stride-2 layer of the audio pyramids on csrc/conv1d.hip (transposed = ConvTranspose1d)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer, transposed):
+        ctx.set_materialize_grads(False)
+        x = _f32c(x)
+        a = _conv1d_desc(layer, tuple(x.shape))
+        n, s = x.shape[0], a.S
+        w = _f32c(weight.detach())
+        if transposed:
+            y = torch.empty(n, a.CB, 2 * s - 1, device=x.device, dtype=torch.float32)
+            a.small, a.big = _ptr(x), _ptr(y)
+        else:
+            y = torch.empty(n, a.CS, s, device=x.device, dtype=torch.float32)
+            a.small, a.big = _ptr(y), _ptr(x)
+        a.weight = _ptr(w)
+        a.bias = _ptr(_f32c(bias.detach())) if bias is not None else None
+        _call('mdmm_conv1d_up' if transposed else 'mdmm_conv1d_down', C.byref(a), tag='conv1d_%s[S=%d]' % ('up' if transposed else 'down', s))
+        ctx.layer, ctx.transposed, ctx.has_bias = layer, transposed, bias is not None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        if gy is None:
+            return None, None, None, None, None
+        gy = _f32c(gy)
+        a = _conv1d_desc(ctx.layer, tuple(x.shape))
+        a.weight = _ptr(w)
+        gx = gw = gb = None
+        small, big = (x, gy) if ctx.transposed else (gy, x)
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            a.small, a.big = (_ptr(gx), _ptr(gy)) if ctx.transposed else (_ptr(gy), _ptr(gx))
+            _call('mdmm_conv1d_down' if ctx.transposed else 'mdmm_conv1d_up', C.byref(a), tag='conv1d_dgrad[S=%d]' % a.S)
+        if ctx.needs_input_grad[1]:
+            a.small, a.big = _ptr(small), _ptr(big)
+            ws = torch.empty(native.lib().mdmm_conv1d_wgrad_ws_bytes(C.byref(a)), device=x.device, dtype=torch.uint8)
+            gw = torch.empty_like(w)
+            _call('mdmm_conv1d_wgrad', C.byref(a), _ptr(ws), _ptr(gw), tag='conv1d_wgrad[S=%d]' % a.S)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2))
+        return gx, gw, gb, None, None
+
+
+def conv1d_tiles(layer, x, bias=True):
+    """layer(x) for a Conv1d / ConvTranspose1d that conv1d_tiles_supported accepts."""
+    import torch.nn as nn
+    return _Conv1dFn.apply(x, layer.weight, layer.bias if bias else None, layer, isinstance(layer, nn.ConvTranspose1d))
+
+
 def prepack_convs(modules):
     """Build (or refresh) both fragment packs of every stride-2 layer of the given plug-in modules on the
     current stream.  A step that forks streams calls this before the fork: the packs are cached on the

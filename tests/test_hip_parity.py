@@ -1295,3 +1295,27 @@ def test_linear_tiles_match_torch(dev, m, k, n):
     close(yb.float(), xr @ wr.t() + bias.detach(), 8e-3, 'linear fwd, bf16 storage')
     close(gxb.float(), gyb.float() @ wr, 8e-3, 'linear dgrad, bf16 storage')
     close(gwb[:, :k], gyb.float().t() @ xr, 2e-5, 'linear wgrad, bf16 storage')
+
+
+@pytest.mark.parametrize('kind,c_in,c_out,length', [('conv', 10, 4, 1281), ('conv', 4, 8, 641), ('conv', 8, 16, 321),
+                                                     ('deconv', 16, 8, 161), ('deconv', 8, 4, 321), ('deconv', 4, 10, 641),
+                                                     ('conv', 3, 5, 17), ('deconv', 5, 3, 9)])
+def test_conv1d_tiles_match_torch(dev, kind, c_in, c_out, length):
+    """csrc/conv1d.hip (Conv1d k3 s2 p1 / ConvTranspose1d k3 s2 p1 of the audio pyramids, common.py:177-219)
+    against the library's fp32 layers: forward, input, weight and bias gradients."""
+    import torch.nn as nn
+    from mdmm import ops
+    torch.manual_seed(c_in * 31 + c_out)
+    tr = kind == 'deconv'
+    for n in (1, 9, 300):
+        layer = (nn.ConvTranspose1d(c_in, c_out, 3, 2, 1) if tr else nn.Conv1d(c_in, c_out, 3, 2, 1)).to(dev)
+        x = torch.randn(n, c_in, length, device=dev, requires_grad=True)
+        assert ops.conv1d_tiles_supported(layer, x)
+        y = ops.conv1d_tiles(layer, x)
+        yr = layer(x)
+        gy = torch.randn_like(y)
+        g = torch.autograd.grad(y, [x, layer.weight, layer.bias], gy)
+        gr = torch.autograd.grad(yr, [x, layer.weight, layer.bias], gy)
+        close(y, yr, 1e-5, 'conv1d fwd')
+        for a_, b_, what in zip(g, gr, ('dgrad', 'wgrad', 'bias grad')):
+            close(a_, b_, 2e-5, 'conv1d ' + what)

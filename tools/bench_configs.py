@@ -129,9 +129,17 @@ def vidtimit(B, T=128):
     for k in x:
         x[k][(torch.rand(T, B, generator=g) < 0.5).to(dev)] = float('nan')
     mask = mask.to(dev)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    graph = os.environ.get('GRAPH', '1') == '1'
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, capturable=graph, fused=True)
     bucket = GradBucket(m.parameters())
-    return lambda: elbo_step(m, opt, bucket, x, mask, lengths, 1.0, {'video': 1.0, 'audio': 1.0}, targets=tg)
+    rec = {'video': 1.0, 'audio': 1.0}
+    eager = lambda: elbo_step(m, opt, bucket, x, mask, lengths, 1.0, rec, targets=tg)     # noqa: E731
+    if not graph:
+        return eager
+    from mdmm.harness import GraphedElboStep
+    step = GraphedElboStep(m, opt, bucket, x, mask, lengths, 1.0, rec, targets=tg)
+    step.eager = eager
+    return step
 
 
 out = {}
