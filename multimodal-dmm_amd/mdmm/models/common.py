@@ -119,6 +119,9 @@ class _ConvBlock(nn.Module):
             from .. import ops
             if ops.batchnorm_relu_supported(x, bn) and x.is_cuda:
                 return ops.batchnorm_relu(self._conv_nobias(layer, x), bn, shift=layer.bias)
+            # evaluation mode (running statistics) and CPU: the stock modules, in the weights' precision
+            if x.dtype != layer.weight.dtype:
+                x = x.to(layer.weight.dtype)
             return self.net[2](bn(layer(x)))
         from .. import ops
         if ops.conv_tiles_supported(self.net, x):

@@ -1319,3 +1319,31 @@ def test_conv1d_tiles_match_torch(dev, kind, c_in, c_out, length):
         close(y, yr, 1e-5, 'conv1d fwd')
         for a_, b_, what in zip(g, gr, ('dgrad', 'wgrad', 'bias grad')):
             close(a_, b_, 2e-5, 'conv1d ' + what)
+
+
+def test_conv_model_eval_mode_with_bf16_switches(dev, kernel_family):
+    """model.eval() (BatchNorm on its running statistics: the stock modules) with conv_dtype = act_dtype =
+    bfloat16: forward and sample() still run and agree with the same model without the switches."""
+    if kernel_family == 'generic':
+        pytest.skip('plug-in path, one family is enough')
+    from mdmm import models
+    from mdmm.models import common as C
+    from mdmm.noise import PhiloxNoise
+    torch.manual_seed(21)
+    mods, dims, dists = ['video', 'action'], [(3, 64, 64), 10], ['Bernoulli', 'Categorical']
+    m = models.MultiDMM(mods, dims, dists, encoders={'video': C.ImageEncoder(16, n_channels=3)},
+                        decoders={'video': C.ImageDecoder(16, n_channels=3)}, h_dim=16, z_dim=16, device=dev)
+    m.eval()
+    T, B = 3, 2
+    x = {'video': torch.rand(T, B, 3, 64, 64, device=dev), 'action': torch.randint(0, 10, (T, B, 1), device=dev).float()}
+    outs = []
+    for bf in (False, True):
+        m.conv_dtype = m.act_dtype = torch.bfloat16 if bf else torch.float32
+        m.noise = PhiloxNoise(seed=5)
+        with torch.no_grad():
+            infer, prior, recon = m(x, lengths=[T] * B, sample=False)
+            smp = m.sample(T, B)
+        outs.append((infer[0], recon['video'][0], smp['video'][0]))
+        assert all(t.dtype == torch.float32 for t in outs[-1])
+    for a_, b_ in zip(*outs):
+        close(b_, a_, 2e-2, 'eval forward with bf16 switches')
