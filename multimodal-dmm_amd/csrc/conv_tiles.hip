@@ -299,7 +299,10 @@ struct Wg {
   static constexpr int SM_LDS = CS * SM_RS;
   static constexpr int PL_ROWS = 2 * S + 2;
   static constexpr int PL_RS = S * 2 + 16;                        // 16 zero bytes, then S bf16
-  static constexpr int PL_LDS = 2 * CB * PL_ROWS * PL_RS + 16;
+  // bytes from one channel's rows to the next: = 16 (mod 256), so that the 16-byte operand reads of 16
+  // lanes on 16 channels fall on 16 different bank groups (the unpadded 576 / 1632 / 5280 collide 4- / 2-way)
+  static constexpr int PL_CS = ((PL_ROWS * PL_RS + 255 - 16) / 256) * 256 + 16;
+  static constexpr int PL_LDS = 2 * CB * PL_CS + 16;
   static constexpr int LDS = SM_LDS + PL_LDS;
   static constexpr int KCH = NPIX / 16;                           // contraction chunks per image
 };
@@ -329,61 +332,124 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   for (int i = threadIdx.x; i < W::LDS / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
   // per job: this lane's column -> byte offset of its plane rows (or -1) and its shift (-1, 0, +1)
   int col_off[MAXJ], col_sh[MAXJ];
+  bool mt_of[MAXJ];
+  int nj = 0;                                                       // jobs of this wave (uniform)
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
     const int job = (jobs >= 8 ? wave : wave % jobs) + 8 * j;
-    col_off[j] = -1; col_sh[j] = 0;
+    col_off[j] = -1; col_sh[j] = 0; mt_of[j] = false;
     if (job < jobs) {
+      nj = j + 1;
+      mt_of[j] = (job / NT) != 0;
       const int nt = job % NT, col = 32 * nt + (lane & 31);
       if (col < NCOL) {
         const int tap = col / cb, b = col % cb, ky = tap / KS, kx = tap % KS;
         const int plane = (kx & 1) ? 0 : 1;                        // E holds the even columns
-        col_off[j] = ((plane * CB + b) * W::PL_ROWS + ky) * W::PL_RS + 16;
+        col_off[j] = (plane * CB + b) * W::PL_CS + ky * W::PL_RS + 16;
         col_sh[j] = kx == 0 ? -1 : (kx == 3 ? 1 : 0);
       }
     }
   }
+  nj = __builtin_amdgcn_readfirstlane(nj);
+  // a tile whose 32 columns are one tap (CB = 32) needs the same shift in every lane: -1 / 0 / +1; 2 = mixed
+  int ush[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const int first = __builtin_amdgcn_readfirstlane(col_sh[j]);
+    const bool same = CB == 32 && __all((col_sh[j] == first && col_off[j] >= 0) ? 1 : 0);
+    ush[j] = same ? first : 2;
+  }
   __syncthreads();
   constexpr int NPIX = W::NPIX, BPIX = 4 * NPIX, B2 = 2 * S;
-  for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
-    const size_t ssrc = (size_t)n * CS * NPIX;
-    for (int it = threadIdx.x; it < CS * NPIX / 8; it += 512) {
-      const int c = it / (NPIX / 8), g8 = it % (NPIX / 8);
-      const bf16x8 v = load8<SB>(a.small, ssrc + (size_t)c * NPIX + g8 * 8);
-      *reinterpret_cast<uint4*>(sm + c * W::SM_RS + g8 * 16) = __builtin_bit_cast(uint4, v);
-    }
-    const size_t bsrc = (size_t)n * cb * BPIX;
-    for (int it = threadIdx.x; it < cb * B2 * (B2 / 8); it += 512) {
-      const int xg = it % (B2 / 8), Y = (it / (B2 / 8)) % B2, b = it / ((B2 / 8) * B2);
-      const bf16x8 u = load8<BB>(a.big, bsrc + ((size_t)b * B2 + Y) * B2 + 8 * xg);
-      bf16x4 e, o;
+  // Both sides of the next image travel through registers while the current one is contracted (one
+  // workgroup keeps one image in LDS; without this every image would pay the HBM latency in the open)
+  constexpr int SM_IT = (CS * NPIX / 8 + 511) / 512, BG_IT = (CB * B2 * (B2 / 8) + 511) / 512;
+  bf16x8 rs[SM_IT], rb[BG_IT];
+  auto fetch = [&](int n) {
+    const size_t ssrc = (size_t)n * CS * NPIX, bsrc = (size_t)n * cb * BPIX;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { e[j] = u[2 * j]; o[j] = u[2 * j + 1]; }
-      char* row = pl + ((size_t)b * W::PL_ROWS + Y + 1) * W::PL_RS + 16 + xg * 8;
-      *reinterpret_cast<uint2*>(row) = __builtin_bit_cast(uint2, e);
-      *reinterpret_cast<uint2*>(row + CB * W::PL_ROWS * W::PL_RS) = __builtin_bit_cast(uint2, o);
+    for (int q = 0; q < SM_IT; ++q) {
+      const int it = threadIdx.x + 512 * q;
+      if (it < CS * NPIX / 8) rs[q] = load8<SB>(a.small, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
     }
+#pragma unroll
+    for (int q = 0; q < BG_IT; ++q) {
+      const int it = threadIdx.x + 512 * q;
+      if (it < cb * B2 * (B2 / 8)) {
+        const int xg = it % (B2 / 8), Y = (it / (B2 / 8)) % B2, b = it / ((B2 / 8) * B2);
+        rb[q] = load8<BB>(a.big, bsrc + ((size_t)b * B2 + Y) * B2 + 8 * xg);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < SM_IT; ++q) {
+      const int it = threadIdx.x + 512 * q;
+      if (it < CS * NPIX / 8)
+        *reinterpret_cast<uint4*>(sm + (it / (NPIX / 8)) * W::SM_RS + (it % (NPIX / 8)) * 16) = __builtin_bit_cast(uint4, rs[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < BG_IT; ++q) {
+      const int it = threadIdx.x + 512 * q;
+      if (it < cb * B2 * (B2 / 8)) {
+        const int xg = it % (B2 / 8), Y = (it / (B2 / 8)) % B2, b = it / ((B2 / 8) * B2);
+        bf16x4 e, o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { e[j] = rb[q][2 * j]; o[j] = rb[q][2 * j + 1]; }
+        char* row = pl + (size_t)b * W::PL_CS + (Y + 1) * W::PL_RS + 16 + xg * 8;
+        *reinterpret_cast<uint2*>(row) = __builtin_bit_cast(uint2, e);
+        *reinterpret_cast<uint2*>(row + CB * W::PL_CS) = __builtin_bit_cast(uint2, o);
+      }
+    }
+  };
+  if ((int)blockIdx.x < a.N) fetch(blockIdx.x);
+  for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
+    commit();
     __syncthreads();
+    if (n + (int)gridDim.x < a.N) fetch(n + gridDim.x);
     for (int c = idle ? W::KCH : my_ks; c < W::KCH; c += ksplit) {
       // 16 consecutive small pixels; lane half h takes 8 of them: all in one row y
       const int p0 = 16 * c + 8 * h, y = p0 / S, x0 = p0 % S;
+      // the A operand is shared by every job of a row tile; B is built branch-free (the shift a lane
+      // needs depends on its column's tap)
+      const uint4 a0 = *reinterpret_cast<const uint4*>(sm + (lane & 31) * W::SM_RS + p0 * 2);
+      uint4 a1 = a0;
+      if constexpr (G::MT_S > 1) a1 = *reinterpret_cast<const uint4*>(sm + (32 + (lane & 31)) * W::SM_RS + p0 * 2);
+      const int rowoff = 2 * y * W::PL_RS + x0 * 2;
 #pragma unroll
       for (int j = 0; j < MAXJ; ++j) {
-        const int job = (jobs >= 8 ? wave : wave % jobs) + 8 * j;
-        if (job >= jobs) break;
-        const int mt = job / NT;
-        const uint4 av = *reinterpret_cast<const uint4*>(sm + (32 * mt + (lane & 31)) * W::SM_RS + p0 * 2);
-        uint4 bv = uint4{0, 0, 0, 0};
-        if (col_off[j] >= 0) {
-          const char* at = pl + col_off[j] + 2 * y * W::PL_RS + x0 * 2;
+        if (j < nj) {
+          const bool valid = col_off[j] >= 0;
+          const char* at = pl + (valid ? col_off[j] : 16) + rowoff;
           const uint4 m = *reinterpret_cast<const uint4*>(at);
-          const uint32_t prev = *reinterpret_cast<const uint32_t*>(at - 4);
-          const uint32_t next = *reinterpret_cast<const uint32_t*>(at + 16);
-          bv = m;
-          if (col_sh[j] < 0) bv = uint4{shift16(m.x, prev), shift16(m.y, m.x), shift16(m.z, m.y), shift16(m.w, m.z)};
-          if (col_sh[j] > 0) bv = uint4{shift16(m.y, m.x), shift16(m.z, m.y), shift16(m.w, m.z), shift16(next, m.w)};
+          uint4 bv = m;
+          if (CB != 32) {                         // (compile time) tiles mix taps: per-lane selects
+            const uint32_t prev = *reinterpret_cast<const uint32_t*>(at - 4);
+            const uint32_t next = *reinterpret_cast<const uint32_t*>(at + 16);
+            const int sh = col_sh[j];
+            bv.x = sh < 0 ? shift16(m.x, prev) : (sh > 0 ? shift16(m.y, m.x) : m.x);
+            bv.y = sh < 0 ? shift16(m.y, m.x) : (sh > 0 ? shift16(m.z, m.y) : m.y);
+            bv.z = sh < 0 ? shift16(m.z, m.y) : (sh > 0 ? shift16(m.w, m.z) : m.z);
+            bv.w = sh < 0 ? shift16(m.w, m.z) : (sh > 0 ? shift16(next, m.w) : m.w);
+            if (!valid) bv = uint4{0, 0, 0, 0};
+          } else if (ush[j] == -1) {              // wave-uniform branches: no per-lane selects, one extra read
+            const uint32_t prev = *reinterpret_cast<const uint32_t*>(at - 4);
+            bv = uint4{shift16(m.x, prev), shift16(m.y, m.x), shift16(m.z, m.y), shift16(m.w, m.z)};
+          } else if (ush[j] == 1) {
+            const uint32_t next = *reinterpret_cast<const uint32_t*>(at + 16);
+            bv = uint4{shift16(m.y, m.x), shift16(m.z, m.y), shift16(m.w, m.z), shift16(next, m.w)};
+          } else if (ush[j] == 2) {
+            const uint32_t prev = *reinterpret_cast<const uint32_t*>(at - 4);
+            const uint32_t next = *reinterpret_cast<const uint32_t*>(at + 16);
+            const int sh = col_sh[j];
+            bv.x = sh < 0 ? shift16(m.x, prev) : (sh > 0 ? shift16(m.y, m.x) : m.x);
+            bv.y = sh < 0 ? shift16(m.y, m.x) : (sh > 0 ? shift16(m.z, m.y) : m.y);
+            bv.z = sh < 0 ? shift16(m.z, m.y) : (sh > 0 ? shift16(m.w, m.z) : m.z);
+            bv.w = sh < 0 ? shift16(m.w, m.z) : (sh > 0 ? shift16(next, m.w) : m.w);
+            if (!valid) bv = uint4{0, 0, 0, 0};
+          }
+          mma(acc[j], mt_of[j] ? a1 : a0, bv);
         }
-        mma(acc[j], av, bv);
       }
     }
     __syncthreads();

@@ -8,7 +8,7 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'multimodal-dmm_amd'))
 import torch, torch.nn as nn
 from mdmm import ops
 
-kw = dict(time=1, N=10240)
+kw = dict(time=1, N=10240, act=0)
 for a in sys.argv[1:]:
     k, v = a.split('='); kw[k] = int(v)
 dev = torch.device('cuda:0')
@@ -50,15 +50,17 @@ for name, mk, shp in layers:
 
 if kw['time']:
     N = kw['N']
+    act = torch.bfloat16 if kw['act'] else torch.float32
     for name, mk, shp in layers:
         layer = mk().to(dev)
         x = torch.randn(N, *shp, device=dev, requires_grad=True)
+        xo = x.detach().to(act).requires_grad_() if (kw['act'] and shp[0] > 4) else x
         res = []
         for own in (False, True):
             def run():
                 if own:
-                    with ops.conv_operands(torch.bfloat16):
-                        y = ops.conv_tiles(layer, x)
+                    with ops.conv_operands(torch.bfloat16, act=act):
+                        y = ops.conv_tiles(layer, xo)
                 else:
                     y = layer(x)
                 return y
@@ -68,18 +70,18 @@ if kw['time']:
                 for _ in range(2):
                     y = run()
                     if what == 'bwd':
-                        torch.autograd.grad(y, [x, layer.weight], gy)
+                        torch.autograd.grad(y, [xo if own else x, layer.weight], gy.to(y.dtype))
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(5):
                     y = run()
                     if what == 'bwd':
-                        torch.autograd.grad(y, [x, layer.weight], gy)
+                        torch.autograd.grad(y, [xo if own else x, layer.weight], gy.to(y.dtype))
                 e1.record(); torch.cuda.synchronize()
                 t.append(e0.elapsed_time(e1) / 5)
             res.append((t[0], t[1] - t[0]))
-        gb_f = (x.numel() + y.numel()) * 4 / 1e9
+        gb_f = (xo.numel() * xo.element_size() + y.numel() * y.element_size()) / 1e9
         print('%-22s N=%d  library fwd %.3f bwd %.3f ms | own fwd %.3f bwd %.3f ms | fwd traffic %.2f GB = %.3f ms at 4 TB/s'
               % (name, N, res[0][0], res[0][1], res[1][0], res[1][1], gb_f, gb_f / 4.0), flush=True)
 
