@@ -298,11 +298,13 @@ def run(cfg, args, world, rank, device, graph):
         elapsed = float(t.item())
     n_probe = args.steps
     timing_note = 'HIP events on the launch stream around every library call of the timed steps'
-    if timer is None and rank == 0:
+    if timer is None:
         # Graph replay leaves no place for events between nodes: re-run the same step eagerly
-        # (not part of `value`) with HIP events around every library call.
+        # (not part of `value`) with HIP events around every library call.  Every rank takes the
+        # steps (they hold the gradient all-reduce); rank 0 keeps the timings.
         n_probe = min(args.steps, 3)
-        ops.TIMER = ops.KernelTimer()
+        if rank == 0:
+            ops.TIMER = ops.KernelTimer()
         for _ in range(n_probe):
             eager_step()
         torch.cuda.synchronize()
