@@ -20,6 +20,27 @@ __device__ __forceinline__ float4 ld4(const __bf16* p) {
   const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
   return float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
+// 16 bytes per lane either way: four fp32 or eight bf16
+template <typename T> struct VecW { static constexpr int W = sizeof(T) == 2 ? 8 : 4; };
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void ldv(const float* p, float (&v)[4]) {
+  const float4 u = *reinterpret_cast<const float4*>(p);
+  v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+}
+__device__ __forceinline__ void ldv(const __bf16* p, float (&v)[8]) {
+  const bf16x8v u = *reinterpret_cast<const bf16x8v*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)u[j];
+}
+__device__ __forceinline__ void stv(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = float4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void stv(__bf16* p, const float (&v)[8]) {
+  bf16x8v u;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) u[j] = (__bf16)v[j];
+  *reinterpret_cast<bf16x8v*>(p) = u;
+}
 __device__ __forceinline__ void st4(float* p, const float4& o) { *reinterpret_cast<float4*>(p) = o; }
 __device__ __forceinline__ void st4(__bf16* p, const float4& o) {
   bf16x4 v;
@@ -60,13 +81,15 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const T* __restrict__ x, i
   double d1 = 0, d2 = 0;
   int cnt = 0;
   if (VEC) {
-    const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
+    constexpr int W = VecW<T>::W;
+    const int64_t LW = L / W, tot = (sp.n_hi - sp.n_lo) * LW;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / L4, l = i % L4;
-      const float4 v = ld4(x + (n * C + c) * L + 4 * l);
-      s1 += (v.x + v.y) + (v.z + v.w);
-      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-      if (++cnt == 256) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }   // short fp32 runs only
+      const int64_t n = sp.n_lo + i / LW, l = i % LW;
+      float v[W];
+      ldv(x + (n * C + c) * L + W * l, v);
+#pragma unroll
+      for (int j = 0; j < W; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+      if (++cnt == 1024 / W) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }   // short fp32 runs only
     }
   } else {
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
@@ -120,15 +143,18 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
   const float scale = g * invstd, shift = b - (float)mean * scale;
   const Span sp = span_of(N);
   if (VEC) {
-    const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
+    constexpr int W = VecW<T>::W;
+    const int64_t LW = L / W, tot = (sp.n_hi - sp.n_lo) * LW;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / L4, l = i % L4;
-      const float4 v = ld4(x + (n * C + c) * L + 4 * l);
-      float4 o;
-      o.x = fmaf(v.x, scale, shift); o.y = fmaf(v.y, scale, shift);
-      o.z = fmaf(v.z, scale, shift); o.w = fmaf(v.w, scale, shift);
-      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-      st4(y + (n * C + c) * L + 4 * l, o);
+      const int64_t n = sp.n_lo + i / LW, l = i % LW;
+      float v[W];
+      ldv(x + (n * C + c) * L + W * l, v);
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        v[j] = fmaf(v[j], scale, shift);
+        if (relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      stv(y + (n * C + c) * L + W * l, v);
     }
   } else {
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
@@ -166,13 +192,16 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const T* __restrict__ 
     s1 += gv; s2 = fmaf(gv, xh, s2);
   };
   if (VEC) {
-    const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
+    constexpr int W = VecW<T>::W;
+    const int64_t LW = L / W, tot = (sp.n_hi - sp.n_lo) * LW;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / L4, l = i % L4;
-      const float4 v = ld4(x + (n * C + c) * L + 4 * l);
-      const float4 d = ld4(dy + (n * C + c) * L + 4 * l);
-      acc(d.x, v.x); acc(d.y, v.y); acc(d.z, v.z); acc(d.w, v.w);
-      if (++cnt == 256) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
+      const int64_t n = sp.n_lo + i / LW, l = i % LW;
+      float v[W], d[W];
+      ldv(x + (n * C + c) * L + W * l, v);
+      ldv(dy + (n * C + c) * L + W * l, d);
+#pragma unroll
+      for (int j = 0; j < W; ++j) acc(d[j], v[j]);
+      if (++cnt == 1024 / W) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
     }
   } else {
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
@@ -223,14 +252,16 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
     return k * (gv - mg - xh * mgx);
   };
   if (VEC) {
-    const int64_t L4 = L / 4, tot = (sp.n_hi - sp.n_lo) * L4;
+    constexpr int W = VecW<T>::W;
+    const int64_t LW = L / W, tot = (sp.n_hi - sp.n_lo) * LW;
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / L4, l = i % L4;
-      const float4 v = ld4(x + (n * C + c) * L + 4 * l);
-      const float4 d = ld4(dy + (n * C + c) * L + 4 * l);
-      float4 o;
-      o.x = one(d.x, v.x); o.y = one(d.y, v.y); o.z = one(d.z, v.z); o.w = one(d.w, v.w);
-      st4(dx + (n * C + c) * L + 4 * l, o);
+      const int64_t n = sp.n_lo + i / LW, l = i % LW;
+      float v[W], d[W];
+      ldv(x + (n * C + c) * L + W * l, v);
+      ldv(dy + (n * C + c) * L + W * l, d);
+#pragma unroll
+      for (int j = 0; j < W; ++j) v[j] = one(d[j], v[j]);
+      stv(dx + (n * C + c) * L + W * l, v);
     }
   } else {
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
@@ -242,8 +273,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
 }
 
 bool vec_ok(const mdmm_bn_t* a) {
-  const uintptr_t m = a->bf16_io ? 7 : 15;
-  return a->L % 4 == 0 && !(((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->dy | (uintptr_t)a->dx) & m);
+  const int w = a->bf16_io ? 8 : 4;             // 16 bytes per lane
+  return a->L % w == 0 && !(((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->dy | (uintptr_t)a->dx) & 15);
 }
 
 int check(const mdmm_bn_t* a) {
