@@ -1105,7 +1105,7 @@ int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
 int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   WideGeo g;
   const int RT = plan(a, false, &g);
-  if (!RT) return MDMM_UNSUPPORTED;
+  if (!RT) return mdmm_wide_sweep_fwd_long(a, stream);      // more particles than the row tiles hold
   if (((uintptr_t)a->gtf_frag) & 15) return MDMM_E_ALIGN;
   const bool f32 = a->precision == MDMM_PREC_F32;
   if (a->K == 1) return f32 ? launch_fwd<true, 1, true>(a, g, stream) : launch_fwd<false, 1, true>(a, g, stream);
@@ -1141,7 +1141,10 @@ int mdmm_wide_bwd_supported(const mdmm_sweep_t* a) {
 
 extern "C" int mdmm_sweep_wide(const mdmm_sweep_t* a) {
   WideGeo g;
-  return plan(a, false, &g) != 0;
+  if (plan(a, false, &g) != 0) return 1;
+  // any larger K: the chunked forward of sweep_wide_long.hip
+  return a && a->D == WD && a->H == WD && a->gtf_frag && !a->trans_only && a->K > 1 &&
+         (a->precision == MDMM_PREC_F32 || a->precision == MDMM_PREC_BF16);
 }
 
 extern "C" int64_t mdmm_sweep_wide_ws_bytes(const mdmm_sweep_t* a) {

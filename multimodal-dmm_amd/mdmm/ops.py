@@ -297,9 +297,11 @@ def wide_shape(cfg, bwd=False):
     import os
     if os.environ.get('MDMM_FORCE_GENERIC') == '1' or os.environ.get('MDMM_NO_WIDE') == '1':
         return False
+    if not bwd:
+        return True           # forward: any K (above 128 bf16 / 32 fp32 rows the chunked kernel, sweep_wide_long.hip)
     if PRECISIONS[cfg.precision] == native.PREC_F32:
         return cfg.K <= 32
-    return cfg.K <= (64 if bwd else 128)
+    return cfg.K <= 64
 
 
 def prepack_gtf(params, D, H, precision):

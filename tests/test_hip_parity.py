@@ -1347,3 +1347,33 @@ def test_conv_model_eval_mode_with_bf16_switches(dev, kernel_family):
         assert all(t.dtype == torch.float32 for t in outs[-1])
     for a_, b_ in zip(*outs):
         close(b_, a_, 2e-2, 'eval forward with bf16 switches')
+
+
+@pytest.mark.parametrize('K,prec', [(200, 'bf16'), (150, 'bf16'), (40, 'f32'), (70, 'f32')])
+def test_wide_forward_many_particles_matches_generic(dev, kernel_family, K, prec, monkeypatch):
+    """The chunked-particle forward of csrc/sweep_wide_long.hip (K above one workgroup's row tiles: the
+    evaluation filter's 200 particles, trainer.py:358-361) against the generic kernels on the same inputs
+    and the same Philox stream: fp32 operands exact, bf16 at the bf16 tolerance; samples included."""
+    if kernel_family == 'generic':
+        pytest.skip('compares the two families itself')
+    from mdmm import ops
+    torch.manual_seed(K)
+    T, B, D, P = 5, 3, 256, 2
+    gd = lambda *s: torch.randn(*s, device=dev)     # noqa: E731
+    shapes = [(D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,)]
+    gtf = [0.06 * gd(*s) for s in shapes]
+    z0m, z0s = gd(D) * 0.1, gd(D) * 0.1
+    experts = [ops.ExpertSpec(gd(T, B, D), gd(T, B, D).abs() + 0.3, (torch.rand(T, B, device=dev) > 0.2).float(),
+                              1 | (1 << m), False) for m in range(1)]
+    experts.append(ops.ExpertSpec(gd(T, B, D), gd(T, B, D).abs() + 0.3, None, 3, False))
+    dtype = torch.float32 if prec == 'f32' else torch.bfloat16
+    outs = {}
+    for fam in ('generic', 'wide'):
+        monkeypatch.setenv('MDMM_NO_WIDE', '1' if fam == 'generic' else '0')
+        cfg = ops.SweepCfg(T, B, D, D, P=P, K=K, reverse=True, sample=True, seed=11, precision=dtype, need_samples=True)
+        assert ops.wide_shape(cfg) == (fam == 'wide')
+        with torch.no_grad():
+            outs[fam] = [o.clone() for o in ops.bfvi_sweep(cfg, gtf, z0m, z0s, experts)]
+    tol = 2e-5 if prec == 'f32' else 8e-3
+    for name, a_, b_ in zip(('infer_mean', 'infer_std', 'prior_mean', 'prior_std', 'samples'), outs['wide'], outs['generic']):
+        close(a_, b_, tol, 'many-particle forward ' + name)
