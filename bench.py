@@ -154,7 +154,28 @@ class Cfg3:
                              z_dim=256)
 
 
-CONFIGS = {'cfg2': Cfg2, 'cfg3': Cfg3}
+class Cfg4(Cfg3):
+    """BASELINE configs[3] at its per-GPU size (2048 sequences on 8 GPUs): the same Weizmann-shaped batch and
+    plug-ins under MultiDKS, backward-RNN with skip updates (B-Skip), feat_to_z, uni_loss."""
+    name = 'cfg4'
+    workload = ('cfg4: Weizmann-shaped synthetic, MultiDKS backward RNN (B-Skip), feat_to_z, conv encoders/decoders, '
+                'z=h=256, T=40, B=%d per GPU, 20%% burst NaN; recurrence / projection / conv contractions with bf16 '
+                'operands and fp32 accumulation, conv-chain activations stored as bf16')
+
+    @classmethod
+    def model(cls, models, device):
+        import torch
+        C = models.common
+        enc = {'video': C.ImageEncoder(256, gauss_out=False, n_channels=3),
+               'mask': C.ImageEncoder(256, gauss_out=False, n_channels=1)}
+        dec = {'video': C.ImageDecoder(256, n_channels=3), 'mask': C.ImageDecoder(256, n_channels=1)}
+        m = models.MultiDKS(cls.mods, cls.dims, cls.dists, encoders=enc, decoders=dec, h_dim=256, z_dim=256,
+                            feat_to_z=True, rnn_dir='bwd', rnn_skip=True, device=device)
+        m.sweep_dtype = m.conv_dtype = m.act_dtype = torch.bfloat16
+        return m
+
+
+CONFIGS = {'cfg2': Cfg2, 'cfg3': Cfg3, 'cfg4': Cfg4}
 
 
 def cpu_baseline(cfg, seconds_budget=25.0):
@@ -317,9 +338,11 @@ def run(cfg, args, world, rank, device, graph):
     if rank != 0:
         return None
     spans = timer.summary()
-    rf = roofline_of(cfg, spans, n_probe, b_dim)
-    rf['timing'] = timing_note
-    attach_traffic(rf)
+    rf = None
+    if cfg is not Cfg4:         # (the roofline model below is the sweeps'; cfg4's recurrences are latency chains)
+        rf = roofline_of(cfg, spans, n_probe, b_dim)
+        rf['timing'] = timing_note
+        attach_traffic(rf)
     return {
         'metric': 'sequences/sec (ELBO step)', 'value': round(world * b_dim * args.steps / elapsed, 2),
         'unit': 'sequences/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -341,7 +364,7 @@ def main():
     ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg3')
     ap.add_argument('--batch', type=int, default=0, help='sequences per GPU (default: the config\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extra', action='store_true', help='skip the cfg2 line that rides along')
+    ap.add_argument('--no-extra', action='store_true', help='skip the cfg2 / cfg4 lines that ride along')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay of the step')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -386,6 +409,12 @@ def main():
             a2.steps, a2.warmup, a2.batch = 10, 3, 0
             r2 = run(Cfg2, a2, 1, 0, device, graph=True)
             out['extra'] = {'cfg2': {k: r2[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline')}}
+            torch.cuda.empty_cache()
+            a4 = argparse.Namespace(**vars(args))
+            a4.steps, a4.warmup, a4.batch = 5, 2, 0
+            r4 = run(Cfg4, a4, 1, 0, device, graph=not args.eager)
+            out['extra']['cfg4'] = {k: r4[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config',
+                                                       'kernels_ms_per_step')}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
