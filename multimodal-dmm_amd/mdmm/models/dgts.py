@@ -32,6 +32,14 @@ class MultiDGTS(nn.Module):
     # BCE chain).  Frames, latents, weights, statistics and every reduction stay fp32.
     act_dtype = torch.float32
 
+    def _fresh_packs(self):
+        """Drop the operand packs cached on the parameters (transition weights in kernel layout, MFMA
+        fragment packs, conv packs).  Every public entry point (step / forward / sample) starts with
+        this: the packs are shared by the sweeps and layers WITHIN one call and rebuilt on first use in
+        the next one.  (They used to be kept until a parameter's version counter moved; fused optimizers
+        update parameters without moving it, and a stale pack trains on old weights without any error.)"""
+        ops.clear_caches(self.parameters())
+
     def _plug(self, module, x, **kw):
         if self.plugin_dtype is None and self.conv_dtype is torch.bfloat16 and x.is_cuda:
             with ops.conv_operands(torch.bfloat16, act=self.act_dtype):

@@ -114,6 +114,7 @@ class MultiDKS(MultiDGTS):
 
     def forward(self, inputs, **kwargs):
         """dks.py:157-297.  Returns (infer, prior, recon)."""
+        self._fresh_packs()
         lengths, sample = kwargs.get('lengths'), kwargs.get('sample', True)
         sample_init = kwargs.get('sample_init', False)
         present = [m for m in self.modalities if m in inputs]
@@ -178,6 +179,7 @@ class MultiDKS(MultiDGTS):
         pass leaves out contributes the zero-input features and, with skip updates, the untouched
         initial state -- dks.py:192-200, 224-227), and the combiner scans of all passes run as
         ONE launch over P*B rows.  Same loss and gradients as one forward per pass."""
+        self._fresh_packs()
         sample, sample_init = kwargs.get('sample', True), kwargs.get('sample_init', False)
         inputs = {m: inputs[m] for m in inputs if m in self.modalities}
         if targets is None:
@@ -272,6 +274,7 @@ class MultiDKS(MultiDGTS):
     def sample(self, t_max, b_dim):
         """dks.py:299-342: ancestral sampling from the transition prior (not a hot path: the
         transition runs through the GaussianGTF holder's stock-op forward)."""
+        self._fresh_packs()
         z_samples = []
         z_t = None
         for t in range(t_max):

@@ -198,6 +198,7 @@ class MultiDMM(MultiDGTS):
 
     def sample(self, t_max, b_dim, direction='fwd'):
         """dmm.py:414-418"""
+        self._fresh_packs()
         z_mean, _ = self.z_sample(t_max, b_dim, direction, sample=True)
         return self.decode(z_mean)
 
@@ -298,6 +299,7 @@ class MultiDMM(MultiDGTS):
 
     def forward(self, inputs, **kwargs):
         """dmm.py:420-494.  Returns (infer, prior, recon)."""
+        self._fresh_packs()
         mode = kwargs.get('mode', 'fsmooth')
         sample = kwargs.get('sample', True)
         sample_init = kwargs.get('sample_init', False)
@@ -382,6 +384,7 @@ class MultiDMM(MultiDGTS):
     def step(self, inputs, mask, kld_mult, rec_mults, targets=None, uni_loss=True, **kwargs):
         """Bidirectional training step, dmm.py:503-554 (see the module docstring for how the
         passes are fused).  Returns the un-normalised loss (caller divides by sum(lengths))."""
+        self._fresh_packs()
         f_mode = kwargs.get('f_mode', 'bfilter')
         s_mode = kwargs.get('s_mode', 'fsmooth')
         f_mult, s_mult = kwargs.get('f_mult', 0.5), kwargs.get('s_mult', 0.5)

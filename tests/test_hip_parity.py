@@ -1377,3 +1377,43 @@ def test_wide_forward_many_particles_matches_generic(dev, kernel_family, K, prec
     tol = 2e-5 if prec == 'f32' else 8e-3
     for name, a_, b_ in zip(('infer_mean', 'infer_std', 'prior_mean', 'prior_std', 'samples'), outs['wide'], outs['generic']):
         close(a_, b_, tol, 'many-particle forward ' + name)
+
+
+@pytest.mark.parametrize('which', ['dmm_z32', 'dmm_z256_conv'])
+def test_packs_follow_fused_optimizer_updates(dev, kernel_family, which):
+    """Fused optimizers update parameters without moving their version counters: the cached operand
+    packs (transition weights, MFMA fragments, conv packs) must not outlive a step.  Three eager Adam
+    steps with fused=True and with the plain implementation give the same losses."""
+    if kernel_family == 'generic':
+        pytest.skip('host-side caching, one family is enough')
+    from mdmm import models
+    from mdmm.harness import GradBucket, elbo_step
+    from mdmm.models import common as C
+    from mdmm.noise import PhiloxNoise
+    losses = {}
+    for fused in (False, True):
+        torch.manual_seed(5)
+        if which == 'dmm_z32':
+            m = models.MultiDMM(['a', 'b'], [3, 2], h_dim=32, z_dim=32, device=dev)
+            T, B = 6, 5
+            g = torch.Generator().manual_seed(1)
+            x = {'a': torch.randn(T, B, 3, generator=g).to(dev), 'b': torch.randn(T, B, 2, generator=g).to(dev)}
+            rec = {'a': 1.0, 'b': 1.0}
+        else:
+            m = models.MultiDMM(['video', 'action'], [(3, 64, 64), 10], ['Bernoulli', 'Categorical'],
+                                encoders={'video': C.ImageEncoder(256, n_channels=3)},
+                                decoders={'video': C.ImageDecoder(256, n_channels=3)}, h_dim=256, z_dim=256, device=dev)
+            m.sweep_dtype = m.conv_dtype = m.act_dtype = torch.bfloat16
+            T, B = 4, 3
+            g = torch.Generator().manual_seed(1)
+            x = {'video': torch.rand(T, B, 3, 64, 64, generator=g).to(dev),
+                 'action': torch.randint(0, 10, (T, B, 1), generator=g).float().to(dev)}
+            rec = {'video': 1.0, 'action': 10.0}
+        m.noise = PhiloxNoise(seed=9)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2, fused=fused)
+        bucket = GradBucket(m.parameters())
+        mask = torch.ones(T, B, 1, dtype=torch.bool, device=dev)
+        losses[fused] = [float(elbo_step(m, opt, bucket, x, mask, [T] * B, 1.0, rec)) for _ in range(3)]
+    for a_, b_ in zip(losses[True], losses[False]):
+        assert abs(a_ - b_) <= 2e-4 * abs(b_), (losses[True], losses[False])
+    assert abs(losses[True][2] - losses[True][0]) > 1e-3 * abs(losses[True][0])      # (the steps did move the loss)
