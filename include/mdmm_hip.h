@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 16
+#define MDMM_ABI_VERSION 17
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -539,6 +539,98 @@ typedef struct mdmm_gemm {
 int mdmm_gemm_supported(const mdmm_gemm_t* args);
 int64_t mdmm_gemm_ws_bytes(const mdmm_gemm_t* args);
 int mdmm_gemm_bf16(const mdmm_gemm_t* args, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * MultiVRNN.forward (vrnn.py:123-235) as one scan over time and its adjoint: per step the prior
+ * GaussianMLP on the top GRU state, every present modality's feature extractor and encoder
+ * GaussianMLP on [features, h] (vrnn.py:150-170), the product of experts with the per-row NaN
+ * masks (dgts.py:15-51), the reparameterised sample, phi_z, every modality's decoder GaussianMLP on
+ * [phi_z, h] (vrnn.py:186-200) and the n_layers GRU update on phi_z or, recur_mode 'use_inputs', on
+ * [phi(x filled with the reconstruction mean where missing) ..., phi_z] (vrnn.py:205-221).
+ * One workgroup owns a tile of sequences for all T; activations feature-major in LDS, fp32 FMA
+ * GEMM stages against weights streamed from L2 (the generic family's building blocks).
+ *
+ * A dense layer y = W x (+ b) with W (F,K): `wt` = W^T as [Kp][Fp], `w` = W as [Fp][Kp], both
+ * zero padded to multiples of 4 PER CONCATENATED PART (a part = one h_dim / z_dim / dims[m] wide
+ * block of the layer's input or one GRU gate of its output), `b` = [Fp] or NULL; 16-byte aligned.
+ * The first layer of the encoders / decoders acts on a concatenation and is given as its two
+ * column blocks (enc_x | enc_h, dec_z | dec_h; bias on the first).  GRU rows in torch's gate order
+ * (r, z, n).
+ *
+ * Backward recomputes each step from h_seq and dumps, per (t, b) row, the step's activations
+ * (spill_x) and the adjoints of every layer's pre-activation (spill_g), both `rows`
+ * floats wide in the layout mdmm_vrnn_layout reports; the weight gradient of a layer is
+ * mdmm_spill_wgrad over its (output, input) column blocks and its bias gradient the column sum. */
+#define MDMM_VRNN_MAX_MODS 4
+#define MDMM_VRNN_MAX_LAYERS 4
+typedef struct mdmm_dense {
+  const float* wt;
+  const float* w;
+  const float* b;
+} mdmm_dense_t;
+
+typedef struct mdmm_vrnn {
+  int32_t T, B, H, Z, M, L;            /* steps, sequences, h_dim, z_dim, modalities, GRU layers */
+  int32_t dims[MDMM_VRNN_MAX_MODS];    /* width of each modality */
+  int32_t present[MDMM_VRNN_MAX_MODS]; /* 1: the modality is among the inputs (x[m] given) */
+  int32_t use_inputs, sample;          /* recur_mode == 'use_inputs'; sample = kwarg of forward */
+  float min_std;                       /* GaussianMLP min_std (common.py:25-41) */
+  int32_t reserved;
+  uint64_t seed, offset;               /* Philox stream of the (T,B,Z) draws when eps == NULL */
+  const uint64_t* offset_dev;
+  const float* eps;                    /* (T,B,Z) recorded draws or NULL */
+  const float* x[MDMM_VRNN_MAX_MODS];  /* (T,B,dims[m]) with NaNs where missing */
+  const float* h0;                     /* (L,H) */
+  const float* z0_mean;                /* (Z) */
+  const float* z0_std;                 /* (Z) */
+  mdmm_dense_t phi[MDMM_VRNN_MAX_MODS], phi_z, prior_h, prior_m, prior_s;
+  mdmm_dense_t enc_x[MDMM_VRNN_MAX_MODS], enc_h[MDMM_VRNN_MAX_MODS], enc_m[MDMM_VRNN_MAX_MODS],
+      enc_s[MDMM_VRNN_MAX_MODS];
+  mdmm_dense_t dec_z[MDMM_VRNN_MAX_MODS], dec_h[MDMM_VRNN_MAX_MODS], dec_m[MDMM_VRNN_MAX_MODS],
+      dec_s[MDMM_VRNN_MAX_MODS];
+  mdmm_dense_t gru_ih[MDMM_VRNN_MAX_LAYERS], gru_hh[MDMM_VRNN_MAX_LAYERS];
+  /* forward outputs; backward inputs for z and h_seq */
+  float* infer_mean;                   /* (T,B,Z) */
+  float* infer_std;
+  float* prior_mean;
+  float* prior_std;
+  float* z;                            /* (T,B,Z) the step's sample (mean when !sample) */
+  float* rec_mean[MDMM_VRNN_MAX_MODS]; /* (T,B,dims[m]) */
+  float* rec_std[MDMM_VRNN_MAX_MODS];
+  float* h_seq;                        /* (T,L,B,H) GRU state after each step */
+  /* backward */
+  const float* g_infer_mean;           /* any may be NULL */
+  const float* g_infer_std;
+  const float* g_prior_mean;
+  const float* g_prior_std;
+  const float* g_rec_mean[MDMM_VRNN_MAX_MODS];
+  const float* g_rec_std[MDMM_VRNN_MAX_MODS];
+  float* g_h0;                         /* (L,H), accumulated into (zeroed by the caller) */
+  float* spill_x;                      /* (T*B, rows) */
+  float* spill_g;                      /* (T*B, rows) */
+} mdmm_vrnn_t;
+
+/* column offsets (in floats) of every activation of one step in a spill row */
+typedef struct mdmm_vrnn_layout {
+  int32_t rows;                        /* width of a spill row */
+  int32_t Hp, Zp;
+  int32_t dp[MDMM_VRNN_MAX_MODS];
+  int32_t h[MDMM_VRNN_MAX_LAYERS];     /* GRU state before the step, per layer */
+  int32_t ph, pm, ps;                  /* prior hidden, mean, std pre-activation */
+  int32_t xin[MDMM_VRNN_MAX_MODS], fx[MDMM_VRNN_MAX_MODS], eh[MDMM_VRNN_MAX_MODS],
+      mu[MDMM_VRNN_MAX_MODS], sp[MDMM_VRNN_MAX_MODS];
+  int32_t z;
+  int32_t dh[MDMM_VRNN_MAX_MODS], rm[MDMM_VRNN_MAX_MODS], rs[MDMM_VRNN_MAX_MODS],
+      xf[MDMM_VRNN_MAX_MODS], feat[MDMM_VRNN_MAX_MODS];
+  int32_t fz;                          /* phi_z(z); directly behind feat[M-1] */
+  int32_t gi[MDMM_VRNN_MAX_LAYERS], gh[MDMM_VRNN_MAX_LAYERS], hn[MDMM_VRNN_MAX_LAYERS];
+} mdmm_vrnn_layout_t;
+int mdmm_vrnn_layout(const mdmm_vrnn_t* args, mdmm_vrnn_layout_t* out);
+/* 1 when a step's activations (forward) and adjoints (backward) of at least four sequences fit
+ * one CU's LDS */
+int mdmm_vrnn_supported(const mdmm_vrnn_t* args, int backward);
+int mdmm_vrnn_fwd(const mdmm_vrnn_t* args, void* stream);
+int mdmm_vrnn_bwd(const mdmm_vrnn_t* args, void* stream);
 
 #ifdef __cplusplus
 }

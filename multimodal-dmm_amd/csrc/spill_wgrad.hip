@@ -81,6 +81,8 @@ extern "C" size_t mdmm_sizeof(int which) {
     case 9: return sizeof(mdmm_frag_layers_t);
     case 10: return sizeof(mdmm_gemm_t);
     case 11: return sizeof(mdmm_conv1d_t);
+    case 12: return sizeof(mdmm_vrnn_t);
+    case 13: return sizeof(mdmm_vrnn_layout_t);
     default: return 0;
   }
 }

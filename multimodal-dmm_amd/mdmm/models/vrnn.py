@@ -3,15 +3,18 @@
 Constructor, attributes and state_dict layout mirror the reference's MultiVRNN (which itself
 needs a harness-side name injection to be constructed, vrnn.py:105, and whose `step` cannot run,
 SURVEY.md section 2 #3 -- so only `forward` has reference behaviour to match).  This class is
-the API-complete, lowest-priority member of the hot path: the per-step product of experts runs
-on the HIP kernel (mdmm_poe_fwd/_bwd), the per-step MLPs and the GRU cell are the holders'
-stock PyTorch-ROCm modules; the recurrence is not fused into one kernel yet.
+the API-complete, lowest-priority member of the hot path.  With the default GaussianMLP encoders and
+decoders the whole recurrence is one scan kernel each way (mdmm_vrnn_fwd / _bwd, csrc/vrnn.hip:
+prior, feature extractors, encoders, product of experts, sample, decoders and the GRU layers per
+step, states in LDS); custom encoder / decoder modules, or a step too wide for one CU's LDS, run
+step by step with the product of experts on its own kernel (mdmm_poe_fwd/_bwd).
 """
 import torch
 import torch.nn as nn
 
 from . import common
 from .dgts import MultiDGTS
+from .. import ops
 
 
 class MultiVRNN(MultiDGTS):
@@ -55,12 +58,103 @@ class MultiVRNN(MultiDGTS):
         self.z0_mean = z0_mean * torch.ones(1, z_dim).to(self.device)
         self.z0_std = z0_std * torch.ones(1, z_dim).to(self.device)
 
+    # ---- the scan kernel ------------------------------------------------------------
+    def _scan_layers(self):
+        """(parameters, layer table) for ops.vrnn_scan: every nn.Linear of a step and the GRU's
+        matrices, with the column blocks their inputs are concatenated from."""
+        H, Z, M = self.h_dim, self.z_dim, self.n_mods
+        params, layers = [self.h0], []
+
+        def ref(p):
+            params.append(p)
+            return len(params) - 1
+
+        def lin(field, index, mod, rb, cb, cols=None, w=None, bias=True):
+            w = ref(mod.weight) if w is None else w
+            b = ref(mod.bias) if (bias and mod.bias is not None) else -1
+            layers.append(ops.VrnnLayer(field, index, w, cols, b, rb, cb))
+            return w
+
+        for i, m in enumerate(self.modalities):
+            d = self.dims[m]
+            lin('phi', i, self.phi[m][0], [H], [d])
+            e, c = self.enc[m], self.dec[m]
+            w = lin('enc_x', i, e.in_to_h[0], [H], [H], cols=(0, H))
+            lin('enc_h', i, e.in_to_h[0], [H], [H], cols=(H, 2 * H), w=w, bias=False)
+            lin('enc_m', i, e.h_to_mean, [Z], [H])
+            lin('enc_s', i, e.h_to_std[0], [Z], [H])
+            w = lin('dec_z', i, c.in_to_h[0], [H], [H], cols=(0, H))
+            lin('dec_h', i, c.in_to_h[0], [H], [H], cols=(H, 2 * H), w=w, bias=False)
+            lin('dec_m', i, c.h_to_mean, [d], [H])
+            lin('dec_s', i, c.h_to_std[0], [d], [H])
+        lin('phi_z', None, self.phi_z[0], [H], [Z])
+        lin('prior_h', None, self.prior.in_to_h[0], [H], [H])
+        lin('prior_m', None, self.prior.h_to_mean, [Z], [H])
+        lin('prior_s', None, self.prior.h_to_std[0], [Z], [H])
+        for l in range(self.n_layers):
+            n_in = (M + 1 if self.recur_mode == 'use_inputs' else 1) if l == 0 else 1
+            for field, tag, cb in (('gru_ih', 'ih', [H] * n_in), ('gru_hh', 'hh', [H])):
+                w = ref(getattr(self.rnn, 'weight_%s_l%d' % (tag, l)))
+                b = ref(getattr(self.rnn, 'bias_%s_l%d' % (tag, l))) if self.rnn.bias else -1
+                layers.append(ops.VrnnLayer(field, l, w, None, b, [H] * 3, cb))
+        return params, layers
+
+    def _scan_spec(self, inputs, t_max, b_dim, sample):
+        """Arguments of the scan kernel, or None where it does not apply (custom encoder / decoder
+        modules, non-fp32 inputs, autocast, or a step wider than a CU's LDS)."""
+        if not self.h0.is_cuda or torch.is_autocast_enabled():
+            return None
+        mlps = [self.enc[m] for m in self.modalities] + [self.dec[m] for m in self.modalities] + [self.prior]
+        if any(type(q) is not common.GaussianMLP for q in mlps):
+            return None
+        if len({float(q.min_std) for q in mlps}) != 1:
+            return None
+        H, Z = self.h_dim, self.z_dim
+        for m in self.modalities:
+            if (self.enc[m].in_to_h[0].weight.shape != (H, 2 * H) or self.enc[m].h_to_mean.weight.shape != (Z, H) or
+                    self.dec[m].in_to_h[0].weight.shape != (H, 2 * H) or
+                    self.dec[m].h_to_mean.weight.shape != (self.dims[m], H)):
+                return None
+            if m in inputs and (inputs[m].dtype != torch.float32 or inputs[m].dim() != 3 or
+                                inputs[m].shape[2] != self.dims[m]):
+                return None
+        spec = dict(T=t_max, B=b_dim, H=H, Z=Z, M=self.n_mods, L=self.n_layers,
+                    dims=[self.dims[m] for m in self.modalities],
+                    present=[m in inputs for m in self.modalities],
+                    use_inputs=self.recur_mode == 'use_inputs', sample=bool(sample),
+                    min_std=float(self.prior.min_std), seed=0, offset=0,
+                    z0_mean=self.z0_mean.to(self.h0.device), z0_std=self.z0_std.to(self.h0.device))
+        if not ops.vrnn_supported(spec, torch.is_grad_enabled()):
+            return None
+        return spec
+
+    def _scan(self, spec, inputs):
+        params, spec['layers'] = self._scan_layers()
+        T, B, Z = spec['T'], spec['B'], spec['Z']
+        noise, eps = self._noise(), None
+        if noise.replay:
+            if spec['sample']:
+                eps = torch.stack([d.reshape(B, Z) for d in noise.take(T)]).to(self.h0.device)
+        else:
+            spec['seed'], spec['offset'] = noise.stream()
+            spec['offset_dev'] = noise.device_counter(self.h0.device)
+        xs = [inputs.get(m) for m in self.modalities]
+        out = ops.vrnn_scan(spec, eps, xs, params)
+        M = self.n_mods
+        recon = ({m: out[4 + i] for i, m in enumerate(self.modalities)},
+                 {m: out[4 + M + i] for i, m in enumerate(self.modalities)})
+        return (out[0], out[1]), (out[2], out[3]), recon
+
     def forward(self, inputs, **kwargs):
         """vrnn.py:123-235.  Returns (infer, prior, (rec_mean_dict, rec_std_dict))."""
         lengths, sample = kwargs.get('lengths'), kwargs.get('sample', True)
         present = [m for m in self.modalities if m in inputs]
         t_max, b_dim = inputs[present[0]].shape[:2] if present else (max(lengths), len(lengths))
         dev = self.h0.device
+        if kwargs.get('scan', True):
+            spec = self._scan_spec(inputs, t_max, b_dim, sample)
+            if spec is not None:
+                return self._scan(spec, inputs)
         prior_mean, prior_std, infer_mean, infer_std = [], [], [], []
         rec_mean = {m: [] for m in self.modalities}
         rec_std = {m: [] for m in self.modalities}

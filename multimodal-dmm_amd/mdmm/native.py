@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 16
+ABI_VERSION = 17
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -38,6 +38,7 @@ SYMBOLS = [
     'mdmm_gemm_supported', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
     'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
     'mdmm_conv1d_supported', 'mdmm_conv1d_up', 'mdmm_conv1d_down', 'mdmm_conv1d_wgrad_ws_bytes', 'mdmm_conv1d_wgrad',
+    'mdmm_vrnn_layout', 'mdmm_vrnn_supported', 'mdmm_vrnn_fwd', 'mdmm_vrnn_bwd',
 ]
 
 _P = C.c_void_p
@@ -129,6 +130,41 @@ class Conv(C.Structure):
 
 class Conv1d(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB')] + [(n, _P) for n in ('small', 'big', 'weight', 'bias')])
+
+
+VRNN_MAX_MODS = 4
+VRNN_MAX_LAYERS = 4
+_M, _L = VRNN_MAX_MODS, VRNN_MAX_LAYERS
+
+
+class Dense(C.Structure):
+    _fields_ = [('wt', _P), ('w', _P), ('b', _P)]
+
+
+class Vrnn(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('T', 'B', 'H', 'Z', 'M', 'L')] +
+                [('dims', C.c_int32 * _M), ('present', C.c_int32 * _M), ('use_inputs', C.c_int32),
+                 ('sample', C.c_int32), ('min_std', C.c_float), ('reserved', C.c_int32),
+                 ('seed', C.c_uint64), ('offset', C.c_uint64), ('offset_dev', _P), ('eps', _P),
+                 ('x', _P * _M), ('h0', _P), ('z0_mean', _P), ('z0_std', _P),
+                 ('phi', Dense * _M), ('phi_z', Dense), ('prior_h', Dense), ('prior_m', Dense),
+                 ('prior_s', Dense)] +
+                [(n, Dense * _M) for n in ('enc_x', 'enc_h', 'enc_m', 'enc_s', 'dec_z', 'dec_h', 'dec_m',
+                                           'dec_s')] +
+                [('gru_ih', Dense * _L), ('gru_hh', Dense * _L)] +
+                [(n, _P) for n in ('infer_mean', 'infer_std', 'prior_mean', 'prior_std', 'z')] +
+                [('rec_mean', _P * _M), ('rec_std', _P * _M), ('h_seq', _P)] +
+                [(n, _P) for n in ('g_infer_mean', 'g_infer_std', 'g_prior_mean', 'g_prior_std')] +
+                [('g_rec_mean', _P * _M), ('g_rec_std', _P * _M), ('g_h0', _P), ('spill_x', _P),
+                 ('spill_g', _P)])
+
+
+class VrnnLayout(C.Structure):
+    _fields_ = ([('rows', C.c_int32), ('Hp', C.c_int32), ('Zp', C.c_int32), ('dp', C.c_int32 * _M),
+                 ('h', C.c_int32 * _L), ('ph', C.c_int32), ('pm', C.c_int32), ('ps', C.c_int32)] +
+                [(n, C.c_int32 * _M) for n in ('xin', 'fx', 'eh', 'mu', 'sp')] + [('z', C.c_int32)] +
+                [(n, C.c_int32 * _M) for n in ('dh', 'rm', 'rs', 'xf', 'feat')] + [('fz', C.c_int32)] +
+                [(n, C.c_int32 * _L) for n in ('gi', 'gh', 'hn')])
 
 
 class Gemm(C.Structure):
@@ -245,10 +281,14 @@ def lib():
         L.mdmm_gemm_ws_bytes.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_ws_bytes.restype = C.c_int64
         L.mdmm_gemm_bf16.argtypes = [C.POINTER(Gemm), _P]
+        L.mdmm_vrnn_layout.argtypes = [C.POINTER(Vrnn), C.POINTER(VrnnLayout)]
+        L.mdmm_vrnn_supported.argtypes = [C.POINTER(Vrnn), C.c_int]
+        L.mdmm_vrnn_fwd.argtypes = [C.POINTER(Vrnn), _P]
+        L.mdmm_vrnn_bwd.argtypes = [C.POINTER(Vrnn), _P]
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
         for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp), (7, Bn), (8, Conv),
-                          (9, FragLayers), (10, Gemm), (11, Conv1d)):
+                          (9, FragLayers), (10, Gemm), (11, Conv1d), (12, Vrnn), (13, VrnnLayout)):
             if L.mdmm_sizeof(which) != C.sizeof(st):
                 raise MdmmError('struct %s: library %d bytes, binding %d bytes'
                                 % (st.__name__, L.mdmm_sizeof(which), C.sizeof(st)))

@@ -1766,3 +1766,184 @@ class _DksCombinerFn(torch.autograd.Function):
 def dks_combiner(cfg, eps, t_stop, z0_mean, z0_std, u, w_z, w_m, b_m, w_s, b_s, gtf_params):
     return _DksCombinerFn.apply(cfg, _f32c(eps), t_stop, z0_mean, z0_std, u, w_z, w_m, b_m, w_s,
                                 b_s, *gtf_params)
+
+
+# ---------------------------------------------------------------------------- VRNN scan --
+def _pad_blocks(w, rb, cb):
+    """Zero-pad every row block (sizes rb) and column block (sizes cb) of w to a multiple of 4."""
+    if all(r % 4 == 0 for r in rb) and all(c % 4 == 0 for c in cb):
+        return w
+    out = torch.zeros(sum(pad(r) for r in rb), sum(pad(c) for c in cb), device=w.device, dtype=torch.float32)
+    ro = po = 0
+    for r in rb:
+        co = qo = 0
+        for c in cb:
+            out[po:po + r, qo:qo + c] = w[ro:ro + r, co:co + c]
+            co, qo = co + c, qo + pad(c)
+        ro, po = ro + r, po + pad(r)
+    return out
+
+
+def _unpad_blocks(w, rb, cb):
+    if all(r % 4 == 0 for r in rb) and all(c % 4 == 0 for c in cb):
+        return w
+    rows, po = [], 0
+    for r in rb:
+        cols, qo = [], 0
+        for c in cb:
+            cols.append(w[po:po + r, qo:qo + c])
+            qo += pad(c)
+        rows.append(torch.cat(cols, 1))
+        po += pad(r)
+    return torch.cat(rows, 0)
+
+
+VrnnLayer = namedtuple('VrnnLayer', 'field index w cols b rb cb')
+# field / index: member of mdmm_vrnn_t; w, b: positions in the parameter list (b = -1: no bias);
+# cols: (lo, hi) column slice of the parameter this layer is, or None; rb / cb: row / column blocks
+
+
+def _vrnn_uses(spec, lay, layer):
+    """(output column, input column) blocks of a spill row for every use of a layer in a step."""
+    f, i, top = layer.field, layer.index, lay.h[spec['L'] - 1]
+    if f == 'phi':
+        uses = [(lay.fx[i], lay.xin[i])] if spec['present'][i] else []
+        return uses + ([(lay.feat[i], lay.xf[i])] if spec['use_inputs'] else [])
+    if f in ('enc_x', 'enc_h', 'enc_m', 'enc_s') and not spec['present'][i]:
+        return []
+    if f == 'gru_ih':
+        return [(lay.gi[i], lay.hn[i - 1] if i else (lay.feat[0] if spec['use_inputs'] else lay.fz))]
+    return [{'phi_z': lambda: (lay.fz, lay.z), 'prior_h': lambda: (lay.ph, top),
+             'prior_m': lambda: (lay.pm, lay.ph), 'prior_s': lambda: (lay.ps, lay.ph),
+             'enc_x': lambda: (lay.eh[i], lay.fx[i]), 'enc_h': lambda: (lay.eh[i], top),
+             'enc_m': lambda: (lay.mu[i], lay.eh[i]), 'enc_s': lambda: (lay.sp[i], lay.eh[i]),
+             'dec_z': lambda: (lay.dh[i], lay.fz), 'dec_h': lambda: (lay.dh[i], top),
+             'dec_m': lambda: (lay.rm[i], lay.dh[i]), 'dec_s': lambda: (lay.rs[i], lay.dh[i]),
+             'gru_hh': lambda: (lay.gh[i], lay.h[i])}[f]()]
+
+
+class _VrnnFn(torch.autograd.Function):
+    """MultiVRNN.forward (vrnn.py:123-235) as one scan: mdmm_vrnn_fwd / _bwd."""
+
+    @staticmethod
+    def _args(spec, eps, xs, h0, z0m, z0s, buf, offs):
+        a = native.Vrnn()
+        a.T, a.B, a.H, a.Z, a.M, a.L = (spec[k] for k in 'TBHZML')
+        for m in range(spec['M']):
+            a.dims[m], a.present[m] = spec['dims'][m], int(spec['present'][m])
+            a.x[m] = _ptr(xs[m])
+        a.use_inputs, a.sample, a.min_std = int(spec['use_inputs']), int(spec['sample']), spec['min_std']
+        a.seed, a.offset, a.offset_dev, a.eps = spec['seed'], spec['offset'], _ptr(spec.get('offset_dev')), _ptr(eps)
+        a.h0, a.z0_mean, a.z0_std = _ptr(h0), _ptr(z0m), _ptr(z0s)
+        base = buf.data_ptr()
+        for layer, (ow, owt, ob) in zip(spec['layers'], offs):
+            d = getattr(a, layer.field)
+            d = d[layer.index] if layer.index is not None else d
+            d.w, d.wt, d.b = base + 4 * ow, base + 4 * owt, (base + 4 * ob if ob >= 0 else None)
+        return a
+
+    @staticmethod
+    def forward(ctx, spec, eps, xs, *params):
+        ctx.set_materialize_grads(False)
+        h0 = params[0]
+        _need_gpu(h0)
+        dev = h0.device
+        T, B, H, Z, M, L = (spec[k] for k in 'TBHZML')
+        pieces, offs, o = [], [], 0
+        for layer in spec['layers']:
+            w = params[layer.w].detach()
+            if layer.cols is not None:
+                w = w[:, layer.cols[0]:layer.cols[1]]
+            wp = _pad_blocks(w, layer.rb, layer.cb)
+            bp = None
+            if layer.b >= 0:
+                bp = _pad_blocks(params[layer.b].detach().reshape(-1, 1).expand(-1, 4), layer.rb, [4])[:, 0]
+            entry = []
+            for piece in (wp, wp.t(), bp):
+                if piece is None:
+                    entry.append(-1)
+                    continue
+                entry.append(o)
+                pieces.append(piece.reshape(-1))
+                o += piece.numel() + (-piece.numel()) % 4
+                if piece.numel() % 4:
+                    pieces.append(torch.zeros((-piece.numel()) % 4, device=dev))
+            offs.append(tuple(entry))
+        buf = torch.cat([p.to(torch.float32) for p in pieces])
+        h0v = _f32c(h0.detach().reshape(L, H))
+        z0m, z0s = _f32c(spec['z0_mean'].reshape(-1)), _f32c(spec['z0_std'].reshape(-1))
+        xs = [(_f32c(x) if x is not None else None) for x in xs]
+        a = _VrnnFn._args(spec, eps, xs, h0v, z0m, z0s, buf, offs)
+        outs = [torch.empty(T, B, Z, device=dev, dtype=torch.float32) for _ in range(5)]
+        a.infer_mean, a.infer_std, a.prior_mean, a.prior_std, a.z = [_ptr(t) for t in outs]
+        rec_mean = [torch.empty(T, B, spec['dims'][m], device=dev, dtype=torch.float32) for m in range(M)]
+        rec_std = [torch.empty(T, B, spec['dims'][m], device=dev, dtype=torch.float32) for m in range(M)]
+        for m in range(M):
+            a.rec_mean[m], a.rec_std[m] = _ptr(rec_mean[m]), _ptr(rec_std[m])
+        h_seq = torch.empty(T, L, B, H, device=dev, dtype=torch.float32)
+        a.h_seq = _ptr(h_seq)
+        _call('mdmm_vrnn_fwd', C.byref(a), tag='vrnn_fwd[H=%d,Z=%d]' % (H, Z))
+        ctx.spec, ctx.eps, ctx.xs, ctx.buf, ctx.offs = spec, eps, xs, buf, offs
+        ctx.consts = (h0v, z0m, z0s)
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(h_seq)
+        return (*outs[:4], *rec_mean, *rec_std)
+
+    @staticmethod
+    def backward(ctx, g_im, g_is, g_pm, g_ps, *g_rec):
+        spec = ctx.spec
+        T, B, H, Z, M, L = (spec[k] for k in 'TBHZML')
+        h_seq, = ctx.saved_tensors
+        dev = h_seq.device
+        h0v, z0m, z0s = ctx.consts
+        a = _VrnnFn._args(spec, ctx.eps, ctx.xs, h0v, z0m, z0s, ctx.buf, ctx.offs)
+        a.h_seq = _ptr(h_seq)
+        keep = [_f32c(g) if g is not None else None for g in (g_im, g_is, g_pm, g_ps, *g_rec)]
+        a.g_infer_mean, a.g_infer_std, a.g_prior_mean, a.g_prior_std = [_ptr(g) for g in keep[:4]]
+        for m in range(M):
+            a.g_rec_mean[m], a.g_rec_std[m] = _ptr(keep[4 + m]), _ptr(keep[4 + M + m])
+        lay = native.VrnnLayout()
+        native.check(native.lib().mdmm_vrnn_layout(C.byref(a), C.byref(lay)), 'mdmm_vrnn_layout')
+        X = torch.empty(T * B, lay.rows, device=dev, dtype=torch.float32)
+        G = torch.empty(T * B, lay.rows, device=dev, dtype=torch.float32)
+        g_h0 = torch.zeros(L, H, device=dev, dtype=torch.float32)
+        a.spill_x, a.spill_g, a.g_h0 = _ptr(X), _ptr(G), _ptr(g_h0)
+        _call('mdmm_vrnn_bwd', C.byref(a), tag='vrnn_bwd[H=%d,Z=%d]' % (H, Z))
+        gsum = G.sum(0)
+        grads = [None] * len(ctx.shapes)
+        grads[0] = g_h0.reshape(ctx.shapes[0])
+
+        def acc(i, g, cols=None):
+            if grads[i] is None:
+                grads[i] = torch.zeros(ctx.shapes[i], device=dev, dtype=torch.float32)
+            if cols is None:
+                grads[i] += g.reshape(ctx.shapes[i])
+            else:
+                grads[i][:, cols[0]:cols[1]] += g
+
+        for layer in spec['layers']:
+            Fp, Kp = sum(pad(r) for r in layer.rb), sum(pad(c) for c in layer.cb)
+            for out_col, in_col in _vrnn_uses(spec, lay, layer):
+                dw = spill_wgrad(G, out_col, Fp, X, in_col, Kp)
+                acc(layer.w, _unpad_blocks(dw, layer.rb, layer.cb), layer.cols)
+                if layer.b >= 0:
+                    acc(layer.b, _unpad_blocks(gsum[out_col:out_col + Fp].reshape(-1, 1).expand(-1, 4),
+                                               layer.rb, [4])[:, 0])
+        return (None, None, None, *grads)
+
+
+def vrnn_supported(spec, backward):
+    a = native.Vrnn()
+    a.T, a.B, a.H, a.Z, a.M, a.L = (spec[k] for k in 'TBHZML')
+    for m in range(spec['M']):
+        a.dims[m] = spec['dims'][m]
+    return (spec['M'] <= native.VRNN_MAX_MODS and spec['L'] <= native.VRNN_MAX_LAYERS and
+            bool(native.lib().mdmm_vrnn_supported(C.byref(a), int(backward))))
+
+
+def vrnn_scan(spec, eps, xs, params):
+    """spec: T, B, H, Z, M, L, dims, present, use_inputs, sample, min_std, seed / offset / offset_dev,
+    z0_mean, z0_std, layers (VrnnLayer list over `params`, params[0] = h0); xs: per modality the
+    (T,B,dims[m]) inputs or None.  Returns (infer_mean, infer_std, prior_mean, prior_std,
+    rec_mean per modality ..., rec_std per modality ...)."""
+    return _VrnnFn.apply(spec, _f32c(eps) if eps is not None else None, xs, *params)

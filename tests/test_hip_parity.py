@@ -913,9 +913,11 @@ def test_step_cfg5_shape_matches_oracle(dev, kernel_family):
     _z256_step_vs_oracle(dev, 128, lengths, 25, torch.float32, nan_prob=0.5, seed=7, mods=2)
 
 
-def test_vrnn_forward_golden(dev, kernel_family):
-    """MultiVRNN.forward (API mirror; PoE on the HIP kernel) against the reference, both
-    recurrence modes, 1 and 2 GRU layers, with input gradients flowing through the PoE kernel."""
+@pytest.mark.parametrize('scan', [True, False], ids=['scan_kernel', 'stepwise'])
+def test_vrnn_forward_golden(scan, dev, kernel_family):
+    """MultiVRNN.forward against the reference, both recurrence modes, 1 and 2 GRU layers: as one
+    scan kernel (csrc/vrnn.hip; h = 8, z = 5, dims 3 and 2 exercise every padding) and step by step
+    (custom-module route, PoE on its own kernel)."""
     if kernel_family == 'generic':
         pytest.skip('no sweep in the VRNN')
     from mdmm import models
@@ -931,8 +933,9 @@ def test_vrnn_forward_golden(dev, kernel_family):
         for tag, sub, sample in (('all', names, True), ('only_a', ['a'], True), ('map', names, False)):
             p = c + '/fwd_' + tag
             m.noise = ReplayNoise(g.seq(p + '/eps') if g.has(p + '/eps/#len') else [])
-            infer, prior, recon = m({k: x[k] for k in sub}, lengths=lengths, sample=sample)
+            infer, prior, recon = m({k: x[k] for k in sub}, lengths=lengths, sample=sample, scan=scan)
             assert m.noise.exhausted
+            assert (infer[0].grad_fn.name().startswith('_VrnnFn')) == scan
             close(infer[0], g.t(p + '/infer_mean'), what=p); close(infer[1], g.t(p + '/infer_std'), what=p)
             close(prior[0], g.t(p + '/prior_mean'), what=p); close(prior[1], g.t(p + '/prior_std'), what=p)
             assert isinstance(recon, tuple) and len(recon) == 2
@@ -940,6 +943,105 @@ def test_vrnn_forward_golden(dev, kernel_family):
                 close(recon[0][k], g.t(p + '/rec_mean/' + k), what=p); close(recon[1][k], g.t(p + '/rec_std/' + k), what=p)
         (infer[0].sum() + recon[0]['a'].sum()).backward()
         assert all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None)
+
+
+VRNN_CASES = {
+    # h, z, dims, layers, recur_mode, modalities given, T, B
+    'h8_z5_use_inputs_2layers': (8, 5, [3, 2], 2, 'use_inputs', ['a', 'b'], 9, 7),
+    'h8_z5_no_inputs': (8, 5, [3, 2], 1, 'no_inputs', ['a', 'b'], 9, 7),
+    'h16_z16_absent_modality': (16, 16, [4, 6], 1, 'use_inputs', ['b'], 12, 37),
+    'h32_z12_three_modalities': (32, 12, [5, 1, 8], 2, 'use_inputs', ['a', 'b', 'c'], 6, 70),
+}
+
+
+@pytest.mark.parametrize('noise_kind', ['replay', 'philox', 'map'])
+@pytest.mark.parametrize('case', sorted(VRNN_CASES))
+def test_vrnn_scan_matches_oracle(case, noise_kind, dev, kernel_family):
+    """The VRNN scan kernels (mdmm_vrnn_fwd / _bwd) against the oracle: every output of forward and the
+    gradient of a random linear functional of them with respect to every parameter.  Inputs carry
+    whole missing rows (they drop the modality from the product of experts, vrnn.py:156-160) and
+    single missing elements (filled with the reconstruction mean in the recurrence, with gradient,
+    vrnn.py:209-216); Philox mode materialises the kernel's own draws and replays them into the oracle."""
+    if kernel_family == 'generic':
+        pytest.skip('no sweep in the VRNN')
+    from mdmm import models, ops
+    from mdmm.noise import PhiloxNoise, ReplayNoise
+    H, Z, dims, layers, mode, given, T, B = VRNN_CASES[case]
+    names = ['a', 'b', 'c'][:len(dims)]
+    torch.manual_seed(11)
+    m = models.MultiVRNN(names, dims, h_dim=H, z_dim=Z, n_layers=layers, recur_mode=mode, z0_std=0.8, device=dev)
+    with torch.no_grad():
+        m.h0.normal_(0, 0.3)
+    o = orc.OracleVRNN(names, dims, h_dim=H, z_dim=Z, n_layers=layers, recur_mode=mode, z0_std=0.8)
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    gen = torch.Generator().manual_seed(5)
+    x = {}
+    for k, d in zip(names, dims):
+        v = torch.randn(T, B, d, generator=gen)
+        v[torch.rand(T, B, generator=gen) < 0.2] = float('nan')                 # rows
+        v[torch.rand(T, B, d, generator=gen) < 0.1] = float('nan')              # elements
+        x[k] = v
+    x = {k: x[k] for k in given}
+    lengths = [T] * B
+    sample = noise_kind != 'map'
+    if noise_kind == 'philox':
+        m.noise = PhiloxNoise(seed=9)
+        probe = PhiloxNoise(seed=9)
+        sd, off = probe.stream()
+        eps = ops.philox_normal(sd, off, (T, B, Z), dev).cpu()
+    else:
+        eps = torch.randn(T, B, Z, generator=gen)
+        m.noise = ReplayNoise([eps[t] for t in range(T)] if sample else [])
+    o.noise = orc.ReplayNoise([eps[t] for t in range(T)] if sample else [])
+    infer, prior, recon = m(cuda(x, dev), lengths=lengths, sample=sample)
+    assert infer[0].grad_fn.name().startswith('_VrnnFn')
+    oi, op, orec = o(x, lengths=lengths, sample=sample)
+
+    def flat(i, p, r):
+        return [i[0], i[1], p[0], p[1]] + [r[0][k] for k in names] + [r[1][k] for k in names]
+
+    got, ref = flat(infer, prior, recon), flat(oi, op, orec)
+    for j, (a_, b_) in enumerate(zip(got, ref)):
+        close(a_, b_, what='%s output %d' % (case, j))
+    wgen = torch.Generator().manual_seed(3)
+    weights = [torch.randn(r.shape, generator=wgen) for r in ref]
+    sum((a_ * w.to(dev)).sum() for a_, w in zip(got, weights)).backward()
+    sum((b_ * w).sum() for b_, w in zip(ref, weights)).backward()
+    og = dict(o.named_parameters())
+    for k, q in m.named_parameters():
+        if og[k].grad is None:
+            assert q.grad is None or float(q.grad.abs().max()) == 0.0, k
+            continue
+        assert q.grad is not None, k
+        grad_close(q.grad, og[k].grad, what='%s %s' % (case, k))
+
+
+def test_vrnn_scan_matches_stepwise_large_batch(dev, kernel_family):
+    """Many workgroups, ragged last tile (B = 1003), T = 50: the scan kernels against the model's own
+    step-by-step route on the same replayed draws, outputs and every parameter gradient."""
+    if kernel_family == 'generic':
+        pytest.skip('no sweep in the VRNN')
+    from mdmm import models
+    from mdmm.noise import ReplayNoise
+    T, B, names, dims = 50, 1003, ['a', 'b'], [3, 2]
+    torch.manual_seed(4)
+    m = models.MultiVRNN(names, dims, h_dim=16, z_dim=16, n_layers=1, recur_mode='use_inputs', device=dev)
+    x = {k: torch.randn(T, B, d, device=dev) for k, d in zip(names, dims)}
+    for k in names:
+        x[k][torch.rand(T, B, device=dev) < 0.3] = float('nan')
+    eps = torch.randn(T, B, 16, device=dev)
+    res = []
+    for scan in (True, False):
+        m.zero_grad(set_to_none=True)
+        m.noise = ReplayNoise([eps[t] for t in range(T)])
+        infer, prior, recon = m(x, lengths=[T] * B, scan=scan)
+        outs = [infer[0], infer[1], prior[0], prior[1]] + [recon[j][k] for j in (0, 1) for k in names]
+        sum((o_ * (i + 1)).mean() for i, o_ in enumerate(outs)).backward()
+        res.append(([o_.detach() for o_ in outs], {k: q.grad.clone() for k, q in m.named_parameters()}))
+    for a_, b_ in zip(res[0][0], res[1][0]):
+        close(a_, b_, 1e-4, 'scan vs stepwise output')
+    for k in res[1][1]:
+        grad_close(res[0][1][k], res[1][1][k], what=k)
 
 
 @pytest.mark.parametrize('dims', [(32, 32, 200), (8, 12, 40)])
