@@ -885,12 +885,22 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
 }
 
 // ---------------------------------------------------------------------------------------
-// weight gradients: dW[block] = G^T X over every spilled row.  grid = (6 blocks, split);
-// wave (wa, wb) owns G tiles {2wa, 2wa+1} x X tiles {4wb .. 4wb+3} of the 256 x 256 block.
+// weight gradients: dW[block] = G^T X over every spilled row.  6 blocks x split slices of the rows,
+// one workgroup each (8 waves of 200+ registers: one workgroup per CU, so 6 * split <= 256 keeps the
+// launch to one round); wave (wa, wb) owns G tiles {2wa, 2wa+1} x X tiles {4wb .. 4wb+3} of the
+// 256 x 256 block.  Workgroups are dealt round-robin to the 8 XCDs: the id is turned so that the six
+// blocks of a slice (three of them read the same Z rows) sit on ONE XCD and share its L2.
+// An item's two operand arrays (32 KB each, fragment order) are fetched ONCE per workgroup into LDS,
+// the next item's in registers meanwhile; the waves read their fragments from there (every G tile is
+// used by two waves, every X tile by four: straight from memory that was up to 1.9x the unique bytes).
 // ---------------------------------------------------------------------------------------
-template <bool F32>
-__global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int CH) {
-  const int blk = blockIdx.x, sp = blockIdx.y;
+template <bool F32, int CH>
+__global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int xcd_turn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int id = blockIdx.x;
+  if (xcd_turn) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);        // gridDim.x is a multiple of 8
+  const int blk = id % 6, sp = id / 6;
+  if (sp >= ws.split) return;
   const int garr = S_GHG + blk;                           // Ghg, Ghn, Glin, GG, GN, G3
   const int xarr = blk < 3 ? S_Z : (blk == 3 ? S_HG : (blk == 4 ? S_HN : S_NL));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -911,16 +921,41 @@ __global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int C
   // bias gradient of the block's layer = sum over rows of its G operand: G^T . 1 on the same pipe
   uint4 ones;
   ones.x = ones.y = ones.z = ones.w = F32 ? 0x3F800000u : 0x3F803F80u;
-  const size_t arr_u4 = (size_t)NWAVE * CH * 64;
+  constexpr int arr_u4 = NWAVE * CH * 64;                  // uint4 per operand array of one item
+  constexpr int per_thr = arr_u4 / NTHR;                  // = CH
+  uint4* lds = reinterpret_cast<uint4*>(smem);            // [2 buffers][G | X][arr_u4]
+  // (staging registers as named scalars: as arrays they are left on the stack)
+  uint4 sg0, sg1, sg2, sg3, sg4, sg5, sg6, sg7, sx0, sx1, sx2, sx3, sx4, sx5, sx6, sx7;
+#define WG_EACH(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+#define WG_LOAD(u)                                                               \
+  if constexpr (u < per_thr) {                                                   \
+    sg##u = src[((size_t)(it + 1) * N_SPILL + garr) * arr_u4 + u * NTHR];        \
+    sx##u = src[((size_t)(it + 1) * N_SPILL + xarr) * arr_u4 + u * NTHR];        \
+  }
+#define WG_STORE(u) \
+  if constexpr (u < per_thr) { dst[u * NTHR] = sg##u; dst[arr_u4 + u * NTHR] = sx##u; }
+  const uint4* src = ws.spill + threadIdx.x;
+  if (lo < hi) {
+#pragma unroll
+    for (int u = 0; u < per_thr; ++u) {
+      lds[threadIdx.x + u * NTHR] = src[((size_t)lo * N_SPILL + garr) * arr_u4 + u * NTHR];
+      lds[arr_u4 + threadIdx.x + u * NTHR] = src[((size_t)lo * N_SPILL + xarr) * arr_u4 + u * NTHR];
+    }
+  }
+  __syncthreads();
   for (int64_t it = lo; it < hi; ++it) {
-    const uint4* gp = ws.spill + ((size_t)it * N_SPILL + garr) * arr_u4 + (size_t)(2 * wa) * CH * 64 + lane;
-    const uint4* xp = ws.spill + ((size_t)it * N_SPILL + xarr) * arr_u4 + (size_t)(4 * wb) * CH * 64 + lane;
+    const int buf = (int)((it - lo) & 1);
+    const bool more = it + 1 < hi;
+    if (more) { WG_EACH(WG_LOAD) }
+    const uint4* gp = lds + (size_t)buf * 2 * arr_u4 + (size_t)(2 * wa) * CH * 64 + lane;
+    const uint4* xp = lds + (size_t)buf * 2 * arr_u4 + arr_u4 + (size_t)(4 * wb) * CH * 64 + lane;
+#pragma unroll
     for (int c = 0; c < CH; ++c) {
       uint4 ga[2], xb[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) ga[i] = gp[((size_t)i * CH + c) * 64];
+      for (int i = 0; i < 2; ++i) ga[i] = gp[(i * CH + c) * 64];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xb[j] = xp[((size_t)j * CH + c) * 64];
+      for (int j = 0; j < 4; ++j) xb[j] = xp[(j * CH + c) * 64];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -930,7 +965,15 @@ __global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int C
         for (int i = 0; i < 2; ++i) mma<F32>(accb[i], ga[i], ones);
       }
     }
+    if (more) {                   // the other buffer's readers passed the barrier of the previous trip
+      uint4* dst = lds + (size_t)(buf ^ 1) * 2 * arr_u4 + threadIdx.x;
+      WG_EACH(WG_STORE)
+    }
+    __syncthreads();
   }
+#undef WG_EACH
+#undef WG_LOAD
+#undef WG_STORE
   if (wb == 0 && (lane & 31) == 0) {            // every column of accb holds the row sums
     float* db = ws.db + ((size_t)sp * 6 + blk) * WD;
 #pragma unroll
@@ -1083,7 +1126,8 @@ int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
   const int CH = RT * (f32 ? 4 : 2);
   const int64_t n_wg = (g.n_pairs + g.NP - 1) / g.NP, n_step = a->T - 1;
   const int64_t items = n_wg * n_step;
-  int split = 64;
+  int split = 42;                                   // 6 * 42 = 252 workgroups: one round of the 256 CUs
+  if (const char* e = getenv("MDMM_WGRAD_SPLIT")) split = atoi(e) > 0 ? atoi(e) : split;     // A/B switch
   if (split > items) split = items > 0 ? (int)items : 1;
   auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
   const int64_t b_spill = up(items * N_SPILL * NWAVE * CH * 64 * 16);
@@ -1126,8 +1170,18 @@ int mdmm_wide_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   else rc = f32 ? launch_bwd<true, 1, false>(a, g, ws, stream) : launch_bwd<false, 2, false>(a, g, ws, stream);
   if (rc) return rc;
   const int CH = RT * (f32 ? 4 : 2);
-  if (f32) hipLaunchKernelGGL(wide_wgrad_kernel<true>, dim3(6, ws.split), dim3(NTHR), 0, stream, ws, CH);
-  else hipLaunchKernelGGL(wide_wgrad_kernel<false>, dim3(6, ws.split), dim3(NTHR), 0, stream, ws, CH);
+  const char* turn_env = getenv("MDMM_WGRAD_XCD");                  // A/B switch, default on
+  const int turn = turn_env ? atoi(turn_env) : 1;
+  const int n_wgrad = (6 * ws.split + 7) & ~7;
+  const int wg_lds = 2 * 2 * NWAVE * CH * 64 * 16;                  // two buffers of (G, X)
+  auto wgrad = [&](auto kern) -> int {
+    if (int e = set_lds(kern, wg_lds)) return e;
+    hipLaunchKernelGGL(kern, dim3(n_wgrad), dim3(NTHR), wg_lds, stream, ws, turn);
+    return 0;
+  };
+  if (f32) rc = CH == 4 ? wgrad(wide_wgrad_kernel<true, 4>) : wgrad(wide_wgrad_kernel<true, 8>);
+  else rc = CH == 2 ? wgrad(wide_wgrad_kernel<false, 2>) : wgrad(wide_wgrad_kernel<false, 4>);
+  if (rc) return rc;
   rc = (int)hipGetLastError();
   if (rc) return rc;
   hipLaunchKernelGGL(wide_reduce_kernel, dim3(512), dim3(256), 0, stream, ws, a->dw_partial);
