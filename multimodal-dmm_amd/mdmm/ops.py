@@ -100,6 +100,16 @@ def spill_wgrad(G, gcol0, gcols, X, xcol0, xcols):
     return out[0] if splits == 1 else out.sum(0)
 
 
+def tiles_wgrad(G, gcol0, gcols, X, xcol0, xcols):
+    """spill_wgrad's contraction on the bf16-operand GEMM (csrc/gemm_tiles.hip): the DKS scans at
+    z = h = 256 when the model's contractions run in bf16 (T*B rows of 256 .. 768 columns: matrix work)."""
+    rows = G.shape[0]
+    if rows < 512 or gcols % 4 or xcols % 4 or gcols < 32 or xcols < 32 or gcol0 % 4 or xcol0 % 4:
+        return spill_wgrad(G, gcol0, gcols, X, xcol0, xcols)
+    return _gemm_bf16(_rows(G[:, gcol0:gcol0 + gcols]), True, _rows(X[:, xcol0:xcol0 + xcols]), True,
+                      gcols, xcols, rows, tag='scan_wgrad[%dx%d]' % (gcols, xcols))
+
+
 class PackedGtf:
     """Padded, fused, both-orientation copy of one GaussianGTF's weights in ONE buffer."""
 
@@ -1663,7 +1673,10 @@ class _GruSkipFn(torch.autograd.Function):
         hp = h_prev.reshape(T * B, H)
         gg = g_gh.reshape(T * B, 3 * Hp)
         hp = hp.contiguous()
-        g_w = torch.cat([spill_wgrad(gg, g * Hp, H, hp, 0, H) for g in range(3)], 0)     # dW_hh = g_gh^T h_prev
+        if ctx.frag is not None and ctx.frag.precision == native.PREC_BF16:      # (Hp = H on the wide path)
+            g_w = tiles_wgrad(gg, 0, 3 * H, hp, 0, H)
+        else:
+            g_w = torch.cat([spill_wgrad(gg, g * Hp, H, hp, 0, H) for g in range(3)], 0)     # dW_hh = g_gh^T h_prev
         g_b = None
         if ctx.has_bias:
             sb = gg.sum(0)
@@ -1754,11 +1767,13 @@ class _DksCombinerFn(torch.autograd.Function):
         Xc = torch.empty(T * B, Dp + Hp, device=dev)
         a.spill_gc, a.spill_xc = _ptr(Gc), _ptr(Xc)
         _call('mdmm_dks_combiner_bwd', C.byref(a), tag='dks_bwd[D=%d,H=%d]' % (D, H))
-        g_gtf = ctx.packed.unpack_grads(G, X, ctx.gtf_like)
+        bf16 = ctx.frags is not None and ctx.frags[0].precision == native.PREC_BF16
+        contract = tiles_wgrad if bf16 else spill_wgrad
+        g_gtf = ctx.packed.unpack_grads(G, X, ctx.gtf_like, contract if bf16 else None)
         gsum = Gc.sum(0)
-        g_wz = spill_wgrad(Gc, 0, H, Xc, 0, D)                  # own contraction over the T*B rows
-        g_wm = spill_wgrad(Gc, Hp, D, Xc, Dp, H)
-        g_ws = spill_wgrad(Gc, Hp + Dp, D, Xc, Dp, H)
+        g_wz = contract(Gc, 0, H, Xc, 0, D)                     # own contraction over the T*B rows
+        g_wm = contract(Gc, Hp, D, Xc, Dp, H)
+        g_ws = contract(Gc, Hp + Dp, D, Xc, Dp, H)
         g_bm, g_bs = gsum[Hp:Hp + D], gsum[Hp + Dp:Hp + Dp + D]
         return (None, None, None, None, None, g_u, g_wz, g_wm, g_bm, g_ws, g_bs, *g_gtf)
 
