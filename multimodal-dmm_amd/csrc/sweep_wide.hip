@@ -1110,6 +1110,7 @@ int plan(const mdmm_sweep_t* a, bool bwd, WideGeo* g) {
     // CUs (rows >= NP of the tile are dead; the matrix work they waste is idle anyway)
     g->TPP = 1; g->ntab = 32;
     g->NP = g->n_pairs <= 8 * 256 ? 8 : (g->n_pairs <= 16 * 256 ? 16 : 32);
+    if (const char* e = getenv("MDMM_K1_NP")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32) g->NP = v; }   // A/B switch
     return 1;
   }
   const int RT = f32 ? 1 : (bwd ? 2 : 4);
