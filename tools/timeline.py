@@ -1,6 +1,9 @@
-"""Per-millisecond picture of one graph-replayed step from a rocprofv3 kernel trace:
-which kernels are on the GPU in each 1-ms bin (device time inside the bin, workgroups per launch)
-and how many kernels run side by side.  usage: timeline.py KERNEL_TRACE.csv [bin_ms]"""
+"""Per-millisecond picture of one step from a rocprofv3 kernel trace of bench.py: which kernels are on
+the GPU in each 1-ms bin (device time inside the bin, workgroups per launch) and how many kernels run
+side by side.  usage: timeline.py KERNEL_TRACE.csv [bin_ms] [step]
+`step` indexes the gaps between optimizer launches: with bench.py --steps 3 --warmup 2 the first
+three are the harness's eager warm-up steps, 3..7 graph replays (5 = the first timed one), the last
+three the eager probe steps behind the timed region (-1, the default, is one of those: host-bound)."""
 import collections
 import csv
 import re
