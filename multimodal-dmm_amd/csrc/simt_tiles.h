@@ -17,17 +17,19 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 
 // out[f][r] = epi(f, bias[f] + sum_k wt[k][f] * in[k][r])   for f < F, r < RC
 // wt: global, [Kd][ldw] (ldw >= F, multiples of 4); in/out: LDS, row length RC.
+// `tid` of `nthr` threads run the stage (a whole workgroup, or one wave of it next to other waves
+// that run other, independent stages)
 template <class Epi>
-__device__ __forceinline__ void gemm_lds(const float* __restrict__ wt, int ldw,
-                                         const float* __restrict__ bias, const float* in,
-                                         float* out, int Kd, int F, int RC, Epi epi) {
+__device__ __forceinline__ void gemm_lds_sub(const float* __restrict__ wt, int ldw,
+                                             const float* __restrict__ bias, const float* in,
+                                             float* out, int Kd, int F, int RC, Epi epi, int tid, int nthr) {
   const int nfq = F >> 2, ngr = RC >> 2;
   const int ntask = nfq * ngr;
   // Few rows (K = 1 sweeps, DKS scans at z = 256): fewer 4x4 tiles than threads, and each tile
   // is a serial chain of Kd dependent L2 loads.  Split the contraction over KS adjacent lanes
   // (interleaved k) and combine with two DPP-class shuffles, so the whole workgroup streams.
-  const int KS = (ntask * 4 <= NT) ? 4 : ((ntask * 2 <= NT) ? 2 : 1);
-  for (int vt = threadIdx.x; vt < ntask * KS; vt += NT) {
+  const int KS = (ntask * 4 <= nthr) ? 4 : ((ntask * 2 <= nthr) ? 2 : 1);
+  for (int vt = tid; vt < ntask * KS; vt += nthr) {
     const int task = vt / KS, part = vt - task * KS;
     const int fq = task % nfq, g = task / nfq;
     const int f0 = fq << 2, r0 = g << 2;
@@ -73,6 +75,13 @@ __device__ __forceinline__ void gemm_lds(const float* __restrict__ wt, int ldw,
       }
     }
   }
+}
+
+template <class Epi>
+__device__ __forceinline__ void gemm_lds(const float* __restrict__ wt, int ldw,
+                                         const float* __restrict__ bias, const float* in,
+                                         float* out, int Kd, int F, int RC, Epi epi) {
+  gemm_lds_sub(wt, ldw, bias, in, out, Kd, F, RC, epi, (int)threadIdx.x, NT);
 }
 
 struct EpiNone {

@@ -92,22 +92,44 @@ __device__ __forceinline__ int gather_experts(const mdmm_vrnn_t& a, const VLay& 
 
 // One step of vrnn.py:139-228 on the tile: reads the GRU states F[y.h[l]], fills every other
 // buffer of F; STORE: writes the step's outputs.
+// Independent stages of one phase of a step are dealt to the workgroup's four waves when a stage is
+// small enough for one (h_dim / 4 x RC / 4 register tiles <= 16): a step is a chain of ~35 tiny
+// contractions, each a load -> FMA -> LDS round trip, and the chain's length is what bounds the scan.
+struct Stages {
+  int RC, wave, lane, slot;
+  bool wpar;
+  __device__ __forceinline__ void operator()(const mdmm_dense_t& d, const float* x, float* y, int Kp, int Fp,
+                                             bool add, bool relu) {
+    if (!wpar) { dense(d, x, y, Kp, Fp, RC, add, relu); return; }
+    if ((slot++ & 3) == wave)
+      gemm_lds_sub(d.wt, Fp, d.b, x, y, Kp, Fp, RC, EpiAddAct{add ? y : nullptr, RC, relu}, lane, 64);
+  }
+  __device__ __forceinline__ void end() { slot = 0; __syncthreads(); }
+};
+
+struct GradStages {      // the same for the adjoint stages (gx = W^T gy [+ gx], through act's relu)
+  int RC, wave, lane, slot;
+  bool wpar;
+  __device__ __forceinline__ void operator()(const mdmm_dense_t& d, const float* gy, float* gx, int Kp, int Fp,
+                                             bool add, const float* act) {
+    if (!wpar) { dgrad(d, gy, gx, Kp, Fp, RC, add, act); return; }
+    if ((slot++ & 3) == wave)
+      gemm_lds_sub(d.w, Kp, nullptr, gy, gx, Fp, Kp, RC, EpiAddMask{add ? gx : nullptr, act, RC}, lane, 64);
+  }
+  __device__ __forceinline__ void end() { slot = 0; __syncthreads(); }
+};
+
 template <bool STORE>
 __device__ __forceinline__ void vrnn_step(const mdmm_vrnn_t& a, const VLay& y, int RC, int s0, uint64_t noff, int t,
                                           float* F, float* cm) {
   const int Hp = y.Hp, Zp = y.Zp, B = a.B, H = a.H, Z = a.Z;
   const float* htop = F + y.h[a.L - 1] * RC;
-  if (t > 0) {                                                           // vrnn.py:141-143
-    dense(a.prior_h, htop, F + y.ph * RC, Hp, Hp, RC, false, true);
-    __syncthreads();
-    dense(a.prior_m, F + y.ph * RC, F + y.pm * RC, Hp, Zp, RC, false, false);
-    dense(a.prior_s, F + y.ph * RC, F + y.ps * RC, Hp, Zp, RC, false, false);
-  }
-  for (int m = 0; m < a.M; ++m) {
+  Stages st{RC, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, 0, (Hp >> 2) * (RC >> 2) <= 16};
+  for (int m = 0; m < a.M; ++m) {                                         // vrnn.py:156-160
     if (!a.present[m]) continue;
     const int dm = a.dims[m], dp = y.dp[m];
     const float* xg = a.x[m] + (size_t)t * B * dm;
-    for (int it = threadIdx.x; it < RC * dp; it += NT) {                  // vrnn.py:156-160
+    for (int it = threadIdx.x; it < RC * dp; it += NT) {
       const int r = it / dp, d = it - r * dp, b = s0 + r;
       float v = 0.f;
       if (d < dm && b < B) { v = xg[(size_t)b * dm + d]; v = (v != v) ? 0.f : v; }
@@ -119,17 +141,29 @@ __device__ __forceinline__ void vrnn_step(const mdmm_vrnn_t& a, const VLay& y, i
         for (int d = 0; d < dm; ++d) { const float v = xg[(size_t)(s0 + r) * dm + d]; if (v != v) c = 0.f; }
       cm[m * RC + r] = c;
     }
-    __syncthreads();
-    dense(a.phi[m], F + y.xin[m] * RC, F + y.fx[m] * RC, dp, Hp, RC, false, true);
-    __syncthreads();
-    dense(a.enc_x[m], F + y.fx[m] * RC, F + y.eh[m] * RC, Hp, Hp, RC, false, false);
-    __syncthreads();
-    dense(a.enc_h[m], htop, F + y.eh[m] * RC, Hp, Hp, RC, true, true);
-    __syncthreads();
-    dense(a.enc_m[m], F + y.eh[m] * RC, F + y.mu[m] * RC, Hp, Zp, RC, false, false);
-    dense(a.enc_s[m], F + y.eh[m] * RC, F + y.sp[m] * RC, Hp, Zp, RC, false, false);
   }
   __syncthreads();
+  // prior GaussianMLP(h) (vrnn.py:141-143) next to the modalities' phi and encoders (vrnn.py:161-170)
+  if (t > 0) st(a.prior_h, htop, F + y.ph * RC, Hp, Hp, false, true);
+  for (int m = 0; m < a.M; ++m)
+    if (a.present[m]) st(a.phi[m], F + y.xin[m] * RC, F + y.fx[m] * RC, y.dp[m], Hp, false, true);
+  st.end();
+  if (t > 0) {
+    st(a.prior_m, F + y.ph * RC, F + y.pm * RC, Hp, Zp, false, false);
+    st(a.prior_s, F + y.ph * RC, F + y.ps * RC, Hp, Zp, false, false);
+  }
+  for (int m = 0; m < a.M; ++m)
+    if (a.present[m]) st(a.enc_x[m], F + y.fx[m] * RC, F + y.eh[m] * RC, Hp, Hp, false, false);
+  st.end();
+  for (int m = 0; m < a.M; ++m)
+    if (a.present[m]) st(a.enc_h[m], htop, F + y.eh[m] * RC, Hp, Hp, true, true);
+  st.end();
+  for (int m = 0; m < a.M; ++m)
+    if (a.present[m]) {
+      st(a.enc_m[m], F + y.eh[m] * RC, F + y.mu[m] * RC, Hp, Zp, false, false);
+      st(a.enc_s[m], F + y.eh[m] * RC, F + y.sp[m] * RC, Hp, Zp, false, false);
+    }
+  st.end();
   for (int it = threadIdx.x; it < RC * Zp; it += NT) {                    // vrnn.py:173-181
     const int r = it / Zp, d = it - r * Zp, b = s0 + r;
     float zv = 0.f;
@@ -154,16 +188,19 @@ __device__ __forceinline__ void vrnn_step(const mdmm_vrnn_t& a, const VLay& y, i
   __syncthreads();
   dense(a.phi_z, F + y.z * RC, F + y.fz * RC, Zp, Hp, RC, false, true);   // vrnn.py:183
   __syncthreads();
-  for (int m = 0; m < a.M; ++m) {                                         // vrnn.py:186-200
-    const int dm = a.dims[m], dp = y.dp[m];
-    dense(a.dec_z[m], F + y.fz * RC, F + y.dh[m] * RC, Hp, Hp, RC, false, false);
-    __syncthreads();
-    dense(a.dec_h[m], htop, F + y.dh[m] * RC, Hp, Hp, RC, true, true);
-    __syncthreads();
-    dense(a.dec_m[m], F + y.dh[m] * RC, F + y.rm[m] * RC, Hp, dp, RC, false, false);
-    dense(a.dec_s[m], F + y.dh[m] * RC, F + y.rs[m] * RC, Hp, dp, RC, false, false);
-    __syncthreads();
-    if (STORE || a.use_inputs) {
+  for (int m = 0; m < a.M; ++m)                                           // vrnn.py:186-200
+    st(a.dec_z[m], F + y.fz * RC, F + y.dh[m] * RC, Hp, Hp, false, false);
+  st.end();
+  for (int m = 0; m < a.M; ++m) st(a.dec_h[m], htop, F + y.dh[m] * RC, Hp, Hp, true, true);
+  st.end();
+  for (int m = 0; m < a.M; ++m) {
+    st(a.dec_m[m], F + y.dh[m] * RC, F + y.rm[m] * RC, Hp, y.dp[m], false, false);
+    st(a.dec_s[m], F + y.dh[m] * RC, F + y.rs[m] * RC, Hp, y.dp[m], false, false);
+  }
+  st.end();
+  if (STORE || a.use_inputs) {
+    for (int m = 0; m < a.M; ++m) {
+      const int dm = a.dims[m], dp = y.dp[m];
       for (int it = threadIdx.x; it < RC * dp; it += NT) {
         const int r = it / dp, d = it - r * dp, b = s0 + r;
         float xf = 0.f;
@@ -176,19 +213,19 @@ __device__ __forceinline__ void vrnn_step(const mdmm_vrnn_t& a, const VLay& y, i
         }
         if (a.use_inputs) F[(y.xf[m] + d) * RC + r] = xf;
       }
-      if (a.use_inputs) {
-        __syncthreads();
-        dense(a.phi[m], F + y.xf[m] * RC, F + y.feat[m] * RC, dp, Hp, RC, false, true);
-      }
+    }
+    if (a.use_inputs) {
+      __syncthreads();
+      for (int m = 0; m < a.M; ++m) st(a.phi[m], F + y.xf[m] * RC, F + y.feat[m] * RC, y.dp[m], Hp, false, true);
     }
   }
-  __syncthreads();
+  st.end();
   for (int l = 0; l < a.L; ++l) {                                         // vrnn.py:219-228, nn.GRU
     const float* in = l ? F + y.hn[l - 1] * RC : (a.use_inputs ? F + y.feat[0] * RC : F + y.fz * RC);
     const int Kin = l ? Hp : (a.use_inputs ? (a.M + 1) * Hp : Hp);
-    dense(a.gru_ih[l], in, F + y.gi[l] * RC, Kin, 3 * Hp, RC, false, false);
-    dense(a.gru_hh[l], F + y.h[l] * RC, F + y.gh[l] * RC, Hp, 3 * Hp, RC, false, false);
-    __syncthreads();
+    st(a.gru_ih[l], in, F + y.gi[l] * RC, Kin, 3 * Hp, false, false);
+    st(a.gru_hh[l], F + y.h[l] * RC, F + y.gh[l] * RC, Hp, 3 * Hp, false, false);
+    st.end();
     const float* gi = F + y.gi[l] * RC;
     const float* gh = F + y.gh[l] * RC;
     for (int it = threadIdx.x; it < RC * Hp; it += NT) {
@@ -256,6 +293,7 @@ __global__ __launch_bounds__(NT) void vrnn_bwd_kernel(const mdmm_vrnn_t a, const
       for (int it = threadIdx.x; it < Hp * RC; it += NT) G[y.hn[l] * RC + it] = carry[l * Hp * RC + it];
     __syncthreads();
     // ---- GRU layers, top down
+    GradStages gs{RC, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, 0, (Hp >> 2) * (RC >> 2) <= 16};
     for (int l = L - 1; l >= 0; --l) {
       const float* gi = F + y.gi[l] * RC;
       const float* gh = F + y.gh[l] * RC;
@@ -284,27 +322,28 @@ __global__ __launch_bounds__(NT) void vrnn_bwd_kernel(const mdmm_vrnn_t a, const
       __syncthreads();
       float* Gin = l ? G + y.hn[l - 1] * RC : (a.use_inputs ? G + y.feat[0] * RC : G + y.fz * RC);
       const int Kin = l ? Hp : (a.use_inputs ? (a.M + 1) * Hp : Hp);
-      dgrad(a.gru_ih[l], G + y.gi[l] * RC, Gin, Kin, 3 * Hp, RC, true, nullptr);
-      dgrad(a.gru_hh[l], G + y.gh[l] * RC, G + y.h[l] * RC, Hp, 3 * Hp, RC, true, nullptr);
-      __syncthreads();
+      gs(a.gru_ih[l], G + y.gi[l] * RC, Gin, Kin, 3 * Hp, true, nullptr);
+      gs(a.gru_hh[l], G + y.gh[l] * RC, G + y.h[l] * RC, Hp, 3 * Hp, true, nullptr);
+      gs.end();
     }
     // ---- recurrence features of the inputs (vrnn.py:205-218): the reconstruction mean stands in
     //      for missing elements of a present modality and carries gradient; an absent modality's is detached
     if (a.use_inputs) {
+      for (int it = threadIdx.x; it < a.M * Hp * RC; it += NT) {             // feat[0 .. M) are adjacent
+        float* Gfeat = G + y.feat[0] * RC;
+        Gfeat[it] = F[y.feat[0] * RC + it] > 0.f ? Gfeat[it] : 0.f;
+      }
+      __syncthreads();
+      for (int m = 0; m < a.M; ++m) gs(a.phi[m], G + y.feat[m] * RC, G + y.xf[m] * RC, y.dp[m], Hp, false, nullptr);
+      gs.end();
       for (int m = 0; m < a.M; ++m) {
+        if (!a.present[m]) continue;
         const int dm = a.dims[m], dp = y.dp[m];
-        float* Gfeat = G + y.feat[m] * RC;
-        for (int it = threadIdx.x; it < Hp * RC; it += NT) Gfeat[it] = F[y.feat[m] * RC + it] > 0.f ? Gfeat[it] : 0.f;
-        __syncthreads();
-        dgrad(a.phi[m], Gfeat, G + y.xf[m] * RC, dp, Hp, RC, false, nullptr);
-        __syncthreads();
-        if (a.present[m]) {
-          for (int it = threadIdx.x; it < RC * dp; it += NT) {
-            const int r = it / dp, d = it - r * dp, b = s0 + r;
-            if (d < dm && b < B) {
-              const float v = a.x[m][((size_t)t * B + b) * dm + d];
-              if (v != v) G[(y.rm[m] + d) * RC + r] += G[(y.xf[m] + d) * RC + r];
-            }
+        for (int it = threadIdx.x; it < RC * dp; it += NT) {
+          const int r = it / dp, d = it - r * dp, b = s0 + r;
+          if (d < dm && b < B) {
+            const float v = a.x[m][((size_t)t * B + b) * dm + d];
+            if (v != v) G[(y.rm[m] + d) * RC + r] += G[(y.xf[m] + d) * RC + r];
           }
         }
       }
@@ -321,14 +360,16 @@ __global__ __launch_bounds__(NT) void vrnn_bwd_kernel(const mdmm_vrnn_t a, const
           if (a.g_rec_std[m]) G[(y.rs[m] + d) * RC + r] = a.g_rec_std[m][o] * softplus_grad_(F[(y.rs[m] + d) * RC + r]);
         }
       }
-      __syncthreads();
-      dgrad(a.dec_m[m], G + y.rm[m] * RC, G + y.dh[m] * RC, Hp, dp, RC, false, nullptr);
-      __syncthreads();
-      dgrad(a.dec_s[m], G + y.rs[m] * RC, G + y.dh[m] * RC, Hp, dp, RC, true, F + y.dh[m] * RC);
-      __syncthreads();
-      dgrad(a.dec_z[m], G + y.dh[m] * RC, G + y.fz * RC, Hp, Hp, RC, true, nullptr);
-      dgrad(a.dec_h[m], G + y.dh[m] * RC, Ghtop, Hp, Hp, RC, true, nullptr);
-      __syncthreads();
+    }
+    __syncthreads();
+    for (int m = 0; m < a.M; ++m) gs(a.dec_m[m], G + y.rm[m] * RC, G + y.dh[m] * RC, Hp, y.dp[m], false, nullptr);
+    gs.end();
+    for (int m = 0; m < a.M; ++m) gs(a.dec_s[m], G + y.rs[m] * RC, G + y.dh[m] * RC, Hp, y.dp[m], true, F + y.dh[m] * RC);
+    gs.end();
+    for (int m = 0; m < a.M; ++m) {            // (both accumulate into buffers all modalities share)
+      gs(a.dec_z[m], G + y.dh[m] * RC, G + y.fz * RC, Hp, Hp, true, nullptr);
+      gs(a.dec_h[m], G + y.dh[m] * RC, Ghtop, Hp, Hp, true, nullptr);
+      gs.end();
     }
     // ---- phi_z
     for (int it = threadIdx.x; it < Hp * RC; it += NT) G[y.fz * RC + it] = F[y.fz * RC + it] > 0.f ? G[y.fz * RC + it] : 0.f;
@@ -369,23 +410,24 @@ __global__ __launch_bounds__(NT) void vrnn_bwd_kernel(const mdmm_vrnn_t a, const
       }
     }
     __syncthreads();
-    // ---- encoders
-    for (int m = 0; m < a.M; ++m) {
+    // ---- encoders and prior: mean heads, then std heads (+ relu of the hidden layer), then the trunks
+    if (t > 0) gs(a.prior_m, G + y.pm * RC, G + y.ph * RC, Hp, Zp, false, nullptr);
+    for (int m = 0; m < a.M; ++m)
+      if (a.present[m]) gs(a.enc_m[m], G + y.mu[m] * RC, G + y.eh[m] * RC, Hp, Zp, false, nullptr);
+    gs.end();
+    if (t > 0) gs(a.prior_s, G + y.ps * RC, G + y.ph * RC, Hp, Zp, true, F + y.ph * RC);
+    for (int m = 0; m < a.M; ++m)
+      if (a.present[m]) gs(a.enc_s[m], G + y.sp[m] * RC, G + y.eh[m] * RC, Hp, Zp, true, F + y.eh[m] * RC);
+    gs.end();
+    for (int m = 0; m < a.M; ++m)
+      if (a.present[m]) gs(a.enc_x[m], G + y.eh[m] * RC, G + y.fx[m] * RC, Hp, Hp, false, F + y.fx[m] * RC);
+    gs.end();
+    for (int m = 0; m < a.M; ++m) {            // (Ghtop is shared: one at a time)
       if (!a.present[m]) continue;
-      dgrad(a.enc_m[m], G + y.mu[m] * RC, G + y.eh[m] * RC, Hp, Zp, RC, false, nullptr);
-      __syncthreads();
-      dgrad(a.enc_s[m], G + y.sp[m] * RC, G + y.eh[m] * RC, Hp, Zp, RC, true, F + y.eh[m] * RC);
-      __syncthreads();
-      dgrad(a.enc_x[m], G + y.eh[m] * RC, G + y.fx[m] * RC, Hp, Hp, RC, false, F + y.fx[m] * RC);
       dgrad(a.enc_h[m], G + y.eh[m] * RC, Ghtop, Hp, Hp, RC, true, nullptr);
       __syncthreads();
     }
-    // ---- prior
     if (t > 0) {
-      dgrad(a.prior_m, G + y.pm * RC, G + y.ph * RC, Hp, Zp, RC, false, nullptr);
-      __syncthreads();
-      dgrad(a.prior_s, G + y.ps * RC, G + y.ph * RC, Hp, Zp, RC, true, F + y.ph * RC);
-      __syncthreads();
       dgrad(a.prior_h, G + y.ph * RC, Ghtop, Hp, Hp, RC, true, nullptr);
       __syncthreads();
     }
