@@ -392,7 +392,10 @@ def main():
         port = os.environ.get('MASTER_PORT', str(29500 + os.getpid() % 2000))
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
                '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
-        rc = subprocess.run(cmd).returncode
+        try:        # (a healthy run takes two minutes: a hang counts as a failure of the first attempt)
+            rc = subprocess.run(cmd, timeout=900 if ours else None).returncode
+        except subprocess.TimeoutExpired:
+            rc = -1
         if rc != 0 and ours:        # never lose the run to the executor setting: once more with its default
             print('bench: ranks failed with %s=%s; retrying with the runtime default' % (GRAPH_QUEUES_ENV, GRAPH_QUEUES),
                   file=sys.stderr, flush=True)
