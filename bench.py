@@ -29,6 +29,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
 import argparse
 import json
 import os
+import signal
 import subprocess
 import sys
 import time
@@ -382,7 +383,8 @@ def main():
     # (4 by default).  With 5 the cfg3 step's two loss terms land on different ones more often:
     # 46.3 -> 44.3 ms per step, same kernels, same loss (7 and more crash the runtime).
     # Read by the runtime when it loads, so it is set before torch is imported; an exported value wins.
-    ours = not args.eager and GRAPH_QUEUES_ENV not in os.environ
+    ours = (not args.eager and GRAPH_QUEUES_ENV not in os.environ
+            and os.environ.get('MDMM_BENCH_DEFAULT_QUEUES') != '1')
     if ours:
         os.environ[GRAPH_QUEUES_ENV] = GRAPH_QUEUES
 
@@ -392,18 +394,27 @@ def main():
         port = os.environ.get('MASTER_PORT', str(29500 + os.getpid() % 2000))
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
                '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
-        try:        # (a healthy run takes two minutes: a hang counts as a failure of the first attempt)
-            rc = subprocess.run(cmd, timeout=900 if ours else None).returncode
-        except subprocess.TimeoutExpired:
-            rc = -1
+        def launch(env, timeout):
+            # own process group: a hung attempt is ended with every rank it started
+            p = subprocess.Popen(cmd, env=env, start_new_session=True)
+            try:
+                return p.wait(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                return -1
+
+        # (a healthy run takes two minutes: a hang counts as a failure of the first attempt)
+        rc = launch(None, 900 if ours else None)
         if rc != 0 and ours:        # never lose the run to the executor setting: once more with its default
             print('bench: ranks failed with %s=%s; retrying with the runtime default' % (GRAPH_QUEUES_ENV, GRAPH_QUEUES),
                   file=sys.stderr, flush=True)
             env = dict(os.environ)
             env.pop(GRAPH_QUEUES_ENV)
+            env['MDMM_BENCH_DEFAULT_QUEUES'] = '1'      # (the ranks would set it again)
             env['MASTER_PORT'] = str(int(port) + 1)
             cmd[cmd.index('--master-port') + 1] = env['MASTER_PORT']
-            rc = subprocess.run(cmd, env=env).returncode
+            rc = launch(env, None)
         raise SystemExit(rc)
     world = int(env_world or '1')
     if world != args.gpus:
