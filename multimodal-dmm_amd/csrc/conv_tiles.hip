@@ -173,23 +173,58 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
     }
     __syncthreads();
     const size_t dst0 = (size_t)n * cb * (4 * NPIX);
-    for (int tile = 0; tile < NPIX / 32; ++tile) {
-      const int p = tile * 32 + (lane & 31), y = p / S, x = p % S;
-      const char* base = smem + ((y + py) * G::UP_PW + x + px) * G::UP_PS + 16 * h;
-      f32x16 acc;
+    constexpr f32x16 ZERO = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (CB <= 4) {
+      // 1 .. 4 output channels: rows 0 .. 3 of a tile, all in the lower half-wave's registers 0 .. 3
+      // (sixteen lane-dependent `m < cb` tests per tile were most of this kernel's instructions).
+      // Two tiles at a time: a tile is a chain of UP_CH dependent MFMAs, two chains hide each other's
+      // latency; every chain starts from the constant zero, the bias joins the rows that are stored.
+      static_assert((NPIX / 32) % 2 == 0, "tile pairs");
+      for (int tile = 0; tile < NPIX / 32; tile += 2) {
+        const int p0 = tile * 32 + (lane & 31), y0 = p0 / S, x0 = p0 % S;
+        const int p1 = p0 + 32, y1 = p1 / S, x1 = p1 % S;
+        const char* base0 = smem + ((y0 + py) * G::UP_PW + x0 + px) * G::UP_PS + 16 * h;
+        const char* base1 = smem + ((y1 + py) * G::UP_PW + x1 + px) * G::UP_PS + 16 * h;
+        f32x16 acc0, acc1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = bias[r];
+        for (int c = 0; c < G::UP_CH; ++c) {
+          const int tap = (16 * c) / CS, off = (16 * c) % CS;
+          const int at = ((tap >> 1) * G::UP_PW + (tap & 1)) * G::UP_PS + off * 2;
+          const uint4 b0 = *reinterpret_cast<const uint4*>(base0 + at), b1 = *reinterpret_cast<const uint4*>(base1 + at);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, b0),
+                                                         c ? acc0 : ZERO, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, b1),
+                                                         c ? acc1 : ZERO, 0, 0, 0);
+        }
+        if (h == 0) {
+          const size_t o0 = dst0 + (size_t)(2 * y0 + py) * G::B2 + 2 * x0 + px;
+          const size_t o1 = dst0 + (size_t)(2 * y1 + py) * G::B2 + 2 * x1 + px;
 #pragma unroll
-      for (int c = 0; c < G::UP_CH; ++c) {
-        const int tap = (16 * c) / CS, off = (16 * c) % CS;
-        const uint4 bv = *reinterpret_cast<const uint4*>(base + ((tap >> 1) * G::UP_PW + (tap & 1)) * G::UP_PS + off * 2);
-        mma(acc, wf[c], bv);
+          for (int r = 0; r < 4; ++r)
+            if (r < cb) {
+              store1<BB>(a.big, o0 + (size_t)r * (4 * NPIX), acc0[r] + bias[r]);
+              store1<BB>(a.big, o1 + (size_t)r * (4 * NPIX), acc1[r] + bias[r]);
+            }
+        }
       }
-      const size_t o = dst0 + (size_t)(2 * y + py) * G::B2 + 2 * x + px;
+    } else {
+      for (int tile = 0; tile < NPIX / 32; ++tile) {
+        const int p = tile * 32 + (lane & 31), y = p / S, x = p % S;
+        const char* base = smem + ((y + py) * G::UP_PW + x + px) * G::UP_PS + 16 * h;
+        f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = acc_row(r) + 4 * h;
-        if (m < cb) store1<BB>(a.big, o + (size_t)m * (4 * NPIX), acc[r]);
+        for (int c = 0; c < G::UP_CH; ++c) {
+          const int tap = (16 * c) / CS, off = (16 * c) % CS;
+          const uint4 bv = *reinterpret_cast<const uint4*>(base + ((tap >> 1) * G::UP_PW + (tap & 1)) * G::UP_PS + off * 2);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, bv),
+                                                        c ? acc : ZERO, 0, 0, 0);
+        }
+        const size_t o = dst0 + (size_t)(2 * y + py) * G::B2 + 2 * x + px;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = acc_row(r) + 4 * h;
+          if (m < cb) store1<BB>(a.big, o + (size_t)m * (4 * NPIX), acc[r] + bias[r]);
+        }
       }
     }
     __syncthreads();
