@@ -133,6 +133,46 @@ __global__ void pack_down_kernel(const float* w, int cb, uint4* out) {
 
 // --------------------------------------------------------------------------------- up ----
 // big[n][m][2y+py][2x+px] = bias[m] + sum_{ci, a, b} small[n][ci][y+py+a-1][x+px+b-1] W[ci][m][3-py-2a][3-px-2b]
+// one image of the small side: global -> registers (the next image's, in flight while this one is
+// multiplied) and registers -> the channels-last LDS patch
+template <int S, int CS>
+struct UpStage {
+  static constexpr int NPIX = S * S, NCG = CS / 8, ITEMS = (NPIX / 4) * NCG, ITER = (ITEMS + 255) / 256;
+  bf16x4 u[ITER][8];
+};
+template <int S, int CS, bool SB>
+__device__ __forceinline__ void up_fetch(const mdmm_conv_t& a, int n, UpStage<S, CS>& st) {
+  using U = UpStage<S, CS>;
+  const size_t src0 = (size_t)n * CS * U::NPIX;
+#pragma unroll
+  for (int q = 0; q < U::ITER; ++q) {
+    const int it = threadIdx.x + 256 * q;
+    if (U::ITEMS % 256 != 0 && it >= U::ITEMS) continue;
+    const int p = 4 * (it % (U::NPIX / 4)), cg = it / (U::NPIX / 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st.u[q][j] = load4<SB>(a.small, src0 + (size_t)(cg * 8 + j) * U::NPIX + p);
+  }
+}
+template <int S, int CS, int CB>
+__device__ __forceinline__ void up_commit(char* smem, const UpStage<S, CS>& st) {
+  using U = UpStage<S, CS>;
+  using G = Shape<S, CS, CB>;
+#pragma unroll
+  for (int q = 0; q < U::ITER; ++q) {
+    const int it = threadIdx.x + 256 * q;
+    if (U::ITEMS % 256 != 0 && it >= U::ITEMS) continue;
+    const int p = 4 * (it % (U::NPIX / 4)), cg = it / (U::NPIX / 4), y = p / S, x = p % S;
+    bf16x8 v0, v1, v2, v3;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v0[j] = st.u[q][j][0]; v1[j] = st.u[q][j][1]; v2[j] = st.u[q][j][2]; v3[j] = st.u[q][j][3]; }
+    char* at = smem + ((y + 1) * G::UP_PW + x + 1) * G::UP_PS + cg * 16;
+    *reinterpret_cast<uint4*>(at) = __builtin_bit_cast(uint4, v0);
+    *reinterpret_cast<uint4*>(at + G::UP_PS) = __builtin_bit_cast(uint4, v1);
+    *reinterpret_cast<uint4*>(at + 2 * G::UP_PS) = __builtin_bit_cast(uint4, v2);
+    *reinterpret_cast<uint4*>(at + 3 * G::UP_PS) = __builtin_bit_cast(uint4, v3);
+  }
+}
+
 template <int S, int CS, int CB, bool SB, bool BB>
 __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   using G = Shape<S, CS, CB>;
@@ -154,24 +194,13 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
     bias[r] = (a.bias && m < cb) ? a.bias[m] : 0.f;
   }
   __syncthreads();
-  constexpr int NPIX = S * S, NCG = CS / 8;
+  constexpr int NPIX = S * S;
+  UpStage<S, CS> stage;
+  if ((int)blockIdx.x < a.N) up_fetch<S, CS, SB>(a, blockIdx.x, stage);
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
-    const size_t src0 = (size_t)n * CS * NPIX;
-    for (int it = threadIdx.x; it < (NPIX / 4) * NCG; it += 256) {
-      const int p = 4 * (it % (NPIX / 4)), cg = it / (NPIX / 4), y = p / S, x = p % S;
-      bf16x4 u[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) u[j] = load4<SB>(a.small, src0 + (size_t)(cg * 8 + j) * NPIX + p);
-      bf16x8 v0, v1, v2, v3;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { v0[j] = u[j][0]; v1[j] = u[j][1]; v2[j] = u[j][2]; v3[j] = u[j][3]; }
-      char* at = smem + ((y + 1) * G::UP_PW + x + 1) * G::UP_PS + cg * 16;
-      *reinterpret_cast<uint4*>(at) = __builtin_bit_cast(uint4, v0);
-      *reinterpret_cast<uint4*>(at + G::UP_PS) = __builtin_bit_cast(uint4, v1);
-      *reinterpret_cast<uint4*>(at + 2 * G::UP_PS) = __builtin_bit_cast(uint4, v2);
-      *reinterpret_cast<uint4*>(at + 3 * G::UP_PS) = __builtin_bit_cast(uint4, v3);
-    }
+    up_commit<S, CS, CB>(smem, stage);
     __syncthreads();
+    if (n + (int)gridDim.x < a.N) up_fetch<S, CS, SB>(a, n + gridDim.x, stage);
     const size_t dst0 = (size_t)n * cb * (4 * NPIX);
     constexpr f32x16 ZERO = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (CB <= 4) {
