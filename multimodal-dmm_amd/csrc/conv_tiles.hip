@@ -249,10 +249,12 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
                                                         c ? acc : ZERO, 0, 0, 0);
         }
         const size_t o = dst0 + (size_t)(2 * y + py) * G::B2 + 2 * x + px;
+        // cb == CB here (16 or 32 channels): the first CB / 2 accumulator registers hold the live rows in
+        // both half-waves -- no lane-dependent channel test per register
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < CB / 2; ++r) {
           const int m = acc_row(r) + 4 * h;
-          if (m < cb) store1<BB>(a.big, o + (size_t)m * (4 * NPIX), acc[r] + bias[r]);
+          store1<BB>(a.big, o + (size_t)m * (4 * NPIX), acc[r] + bias[r]);
         }
       }
     }
@@ -275,6 +277,16 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   for (int i = threadIdx.x; i < G::DN_LDS_P / 16; i += 256) reinterpret_cast<uint4*>(patch)[i] = uint4{0, 0, 0, 0};
   __syncthreads();
   constexpr int NPIX = S * S, BPIX = 4 * NPIX, B2 = G::B2;
+  // live accumulator registers of a 32-row tile of the small side's channels (CS = 16: rows 0 .. 15 are
+  // registers 0 .. 7 of both half-waves) and their bias, once per kernel (two row tiles at CS = 64)
+  constexpr int RV = CS >= 32 ? 16 : CS / 2;
+  float b0[RV], b1[RV];
+#pragma unroll
+  for (int r = 0; r < RV; ++r) {
+    const int m = acc_row(r) + 4 * h;
+    b0[r] = a.bias ? a.bias[m] : 0.f;
+    b1[r] = (a.bias && G::MT_S > 1) ? a.bias[32 + m] : 0.f;
+  }
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
     const size_t src0 = (size_t)n * cb * BPIX;
     if constexpr (G::THIN) {
@@ -323,11 +335,6 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
       const uint4* wrow = reinterpret_cast<const uint4*>(wl) + (size_t)mt * D::CH * 64 + lane;
       f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = 32 * mt + acc_row(r) + 4 * h;
-        acc[r] = (a.bias && m < CS) ? a.bias[m] : 0.f;
-      }
-#pragma unroll
       for (int c = 0; c < D::CH; ++c) {
         uint4 bv;
         if constexpr (G::THIN) {
@@ -336,12 +343,15 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
           const int tap = (16 * c) / CB, off = (16 * c) % CB + 8 * h;
           bv = *reinterpret_cast<const uint4*>(base + ((tap / KS) * G::DN_PW + tap % KS) * G::DN_PS + off * 2);
         }
-        mma(acc, wrow[c * 64], bv);
+        // (the chain starts from the constant zero; the bias joins the live rows at the store)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wrow[c * 64]), __builtin_bit_cast(bf16x8, bv),
+                                                      c ? acc : f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                                                       0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < RV; ++r) {
         const int m = 32 * mt + acc_row(r) + 4 * h;
-        if (m < CS) store1<SB>(a.small, dst0 + (size_t)m * NPIX + p, acc[r]);
+        store1<SB>(a.small, dst0 + (size_t)m * NPIX + p, acc[r] + ((G::MT_S > 1 && mt) ? b1[r] : b0[r]));
       }
     }
     __syncthreads();
