@@ -63,6 +63,23 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
   __syncthreads();
 }
 
+// i -> (i / len, i % len) for the flattened (image, position) loops: a 64-bit division per vector was a
+// third of these kernels' instructions (pmc: 25 lane-operations per element).  len is a power of two for
+// every layer of the image pyramids (shift + mask); otherwise 32-bit division when the count fits.
+struct Rows {
+  int64_t len;
+  int sh;          // log2(len) or -1
+  bool small;
+  __device__ __forceinline__ Rows(int64_t len_, int64_t tot) : len(len_), sh(-1), small(tot < (1ll << 31)) {
+    if (len_ > 0 && (len_ & (len_ - 1)) == 0) sh = 63 - __builtin_clzll((unsigned long long)len_);
+  }
+  __device__ __forceinline__ void split(int64_t i, int64_t& q, int64_t& r) const {
+    if (sh >= 0) { q = i >> sh; r = i & (len - 1); }
+    else if (small) { const uint32_t qq = (uint32_t)i / (uint32_t)len; q = qq; r = (uint32_t)i - qq * (uint32_t)len; }
+    else { q = i / len; r = i % len; }
+  }
+};
+
 struct Span { int64_t n_lo, n_hi; };
 __device__ __forceinline__ Span span_of(int64_t N) {
   const int64_t per = (N + gridDim.y - 1) / gridDim.y;
@@ -83,8 +100,11 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const T* __restrict__ x, i
   if (VEC) {
     constexpr int W = VecW<T>::W;
     const int64_t LW = L / W, tot = (sp.n_hi - sp.n_lo) * LW;
+    const Rows rows(LW, tot);
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / LW, l = i % LW;
+      int64_t n, l;
+      rows.split(i, n, l);
+      n += sp.n_lo;
       float v[W];
       ldv(x + (n * C + c) * L + W * l, v);
 #pragma unroll
@@ -93,8 +113,11 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const T* __restrict__ x, i
     }
   } else {
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
+    const Rows rows(L, tot);
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / L, l = i % L;
+      int64_t n, l;
+      rows.split(i, n, l);
+      n += sp.n_lo;
       const float v = (float)x[(n * C + c) * L + l];
       s1 += v; s2 += v * v;
       if (++cnt == 1024) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
@@ -145,8 +168,11 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
   if (VEC) {
     constexpr int W = VecW<T>::W;
     const int64_t LW = L / W, tot = (sp.n_hi - sp.n_lo) * LW;
+    const Rows rows(LW, tot);
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / LW, l = i % LW;
+      int64_t n, l;
+      rows.split(i, n, l);
+      n += sp.n_lo;
       float v[W];
       ldv(x + (n * C + c) * L + W * l, v);
 #pragma unroll
@@ -158,8 +184,11 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
     }
   } else {
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
+    const Rows rows(L, tot);
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / L, l = i % L;
+      int64_t n, l;
+      rows.split(i, n, l);
+      n += sp.n_lo;
       float o = fmaf((float)x[(n * C + c) * L + l], scale, shift);
       if (relu) o = fmaxf(o, 0.f);
       y[(n * C + c) * L + l] = (T)o;
@@ -194,8 +223,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const T* __restrict__ 
   if (VEC) {
     constexpr int W = VecW<T>::W;
     const int64_t LW = L / W, tot = (sp.n_hi - sp.n_lo) * LW;
+    const Rows rows(LW, tot);
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / LW, l = i % LW;
+      int64_t n, l;
+      rows.split(i, n, l);
+      n += sp.n_lo;
       float v[W], d[W];
       ldv(x + (n * C + c) * L + W * l, v);
       ldv(dy + (n * C + c) * L + W * l, d);
@@ -205,8 +237,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const T* __restrict__ 
     }
   } else {
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
+    const Rows rows(L, tot);
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / L, l = i % L;
+      int64_t n, l;
+      rows.split(i, n, l);
+      n += sp.n_lo;
       acc((float)dy[(n * C + c) * L + l], (float)x[(n * C + c) * L + l]);
       if (++cnt == 1024) { d1 += s1; d2 += s2; s1 = s2 = 0.f; cnt = 0; }
     }
@@ -254,8 +289,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
   if (VEC) {
     constexpr int W = VecW<T>::W;
     const int64_t LW = L / W, tot = (sp.n_hi - sp.n_lo) * LW;
+    const Rows rows(LW, tot);
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / LW, l = i % LW;
+      int64_t n, l;
+      rows.split(i, n, l);
+      n += sp.n_lo;
       float v[W], d[W];
       ldv(x + (n * C + c) * L + W * l, v);
       ldv(dy + (n * C + c) * L + W * l, d);
@@ -265,8 +303,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
     }
   } else {
     const int64_t tot = (sp.n_hi - sp.n_lo) * L;
+    const Rows rows(L, tot);
     for (int64_t i = threadIdx.x; i < tot; i += NT) {
-      const int64_t n = sp.n_lo + i / L, l = i % L;
+      int64_t n, l;
+      rows.split(i, n, l);
+      n += sp.n_lo;
       dx[(n * C + c) * L + l] = (T)one((float)dy[(n * C + c) * L + l], (float)x[(n * C + c) * L + l]);
     }
   }

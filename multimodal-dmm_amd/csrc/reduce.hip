@@ -150,6 +150,21 @@ __device__ __forceinline__ float softplus_fast(float l) {
   return fmaxf(l, 0.f) + mdmm::fast::log(1.0f + mdmm::fast::exp(-fabsf(l)));
 }
 
+// Row of element i in a grid-stride loop without a division per trip: i advances by a fixed stride, so
+// the row advances by stride / len and the position within it by stride % len (one carry test).
+struct RowWalk {
+  int64_t row;
+  int rem, qs, rs, len;
+  __device__ __forceinline__ RowWalk(int64_t i0, int64_t stride, int len_) : len(len_) {
+    row = i0 / len_; rem = (int)(i0 - row * len_);
+    qs = (int)(stride / len_); rs = (int)(stride - (int64_t)qs * len_);
+  }
+  __device__ __forceinline__ void next() {
+    row += qs; rem += rs;
+    if (rem >= len) { rem -= len; ++row; }
+  }
+};
+
 // T = storage type of theta / g_theta (fp32, or bf16 for the logits of the bf16-activation plug-ins)
 template <bool LOGITS, typename T>
 __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ theta,
@@ -160,8 +175,10 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ thet
   if (vec) {
     const int64_t n4 = n >> 2;
     const int inner4 = inner >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
-      if (mask && mask[i / inner4] == 0.f) continue;
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    RowWalk rw((int64_t)blockIdx.x * NT + threadIdx.x, stride, inner4);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride, rw.next()) {
+      if (mask && mask[rw.row] == 0.f) continue;
       const float4 xv = reinterpret_cast<const float4*>(x)[i];
       const float4 th = ld4f(theta, i);
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -222,8 +239,10 @@ __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ thet
   if ((inner & 3) == 0 && (n & 3) == 0) {
     const int64_t n4 = n >> 2;
     const int inner4 = inner >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
-      const bool on = !(mask && mask[i / inner4] == 0.f);
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    RowWalk rw((int64_t)blockIdx.x * NT + threadIdx.x, stride, inner4);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride, rw.next()) {
+      const bool on = !(mask && mask[rw.row] == 0.f);
       const float4 xv = reinterpret_cast<const float4*>(x)[i];
       const float4 th = ld4f(theta, i);
       const float g[4] = {nllb_grad<LOGITS, T>(th.x, xv.x, on, scale), nllb_grad<LOGITS, T>(th.y, xv.y, on, scale),
