@@ -43,15 +43,31 @@ __device__ __forceinline__ float4 ld4(const void* src, int64_t at, bool bf) {
   return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + at);
 }
 
-template <bool T>
-__device__ __forceinline__ void load_tile(const void* src, bool bf, int64_t ld, int rows, int L, int row0, int l0,
+// FULL: the workgroup's tile and every contraction step lie inside the matrices -- no bounds test per
+// load (the tests put a branch around every load and kept the eight loads of a step from being issued
+// back to back)
+template <bool T, bool FULL>
+__device__ __forceinline__ void load_tile(const void* src, bool bf, bool raw, int64_t ld, int rows, int L, int row0, int l0,
                                           int tid, Regs& r) {
   if constexpr (!T) {
+    if (raw) {
+      // bf16 in memory, read along the contraction: eight elements per item, moved as they are (a row
+      // of a step is 64 bytes: four 16-byte items; no conversion either way)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int it = tid + 256 * q, row = it >> 2, l8 = it & 3;
+        float4 v = float4{0.f, 0.f, 0.f, 0.f};
+        if (FULL || (row0 + row < rows && l0 + 8 * l8 < L))      // (L is a multiple of 8 here: see the launcher)
+          v = *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(src) + (int64_t)(row0 + row) * ld + l0 + 8 * l8);
+        r.v[q] = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int it = tid + 256 * q, row = it >> 3, lg = it & 7;
       float4 v = float4{0.f, 0.f, 0.f, 0.f};
-      if (row0 + row < rows && l0 + 4 * lg < L) v = ld4(src, (int64_t)(row0 + row) * ld + l0 + 4 * lg, bf);
+      if (FULL || (row0 + row < rows && l0 + 4 * lg < L)) v = ld4(src, (int64_t)(row0 + row) * ld + l0 + 4 * lg, bf);
       r.v[q] = v;
     }
   } else {
@@ -61,15 +77,23 @@ __device__ __forceinline__ void load_tile(const void* src, bool bf, int64_t ld, 
     for (int q = 0; q < 4; ++q) {
       float4 v = float4{0.f, 0.f, 0.f, 0.f};
       const int l = l0 + 4 * lg + q;
-      if (l < L && row0 + 4 * rg < rows) v = ld4(src, (int64_t)l * ld + row0 + 4 * rg, bf);
+      if (FULL || (l < L && row0 + 4 * rg < rows)) v = ld4(src, (int64_t)l * ld + row0 + 4 * rg, bf);
       r.v[q] = v;
     }
   }
 }
 
 template <bool T>
-__device__ __forceinline__ void store_tile(char* lds, int tid, const Regs& r) {
+__device__ __forceinline__ void store_tile(char* lds, int tid, const Regs& r, bool raw) {
   if constexpr (!T) {
+    if (raw) {                 // (load_tile's bf16 items)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int it = tid + 256 * q, row = it >> 2, l8 = it & 3;
+        *reinterpret_cast<float4*>(lds + row * RS + l8 * 16) = r.v[q];
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int it = tid + 256 * q, row = it >> 3, lg = it & 7;
@@ -92,9 +116,8 @@ __device__ __forceinline__ void store_tile(char* lds, int tid, const Regs& r) {
   }
 }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_kernel(const mdmm_gemm_t g) {
-  __shared__ __attribute__((aligned(16))) char lds[2][2 * TILE_LDS];     // [buffer][A tile | B tile]
+template <bool TA, bool TB, bool FULL>
+__device__ __forceinline__ void gemm_body(const mdmm_gemm_t& g, char (*lds)[2 * TILE_LDS]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int j0 = blockIdx.x * BT, i0 = blockIdx.y * BT;
   // contraction range of this workgroup (split > 1: blockIdx.z takes a slice, in steps of BL)
@@ -109,19 +132,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mdmm_gemm_t g) {
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  // raw: a bf16 operand read along the contraction whose rows are 16-byte aligned
+  const bool raw_a = !g.reserved && !TA && g.a_bf16 && (g.lda & 7) == 0 && (g.L & 7) == 0 && (((uintptr_t)g.a) & 15) == 0;
+  const bool raw_b = !g.reserved && !TB && g.b_bf16 && (g.ldb & 7) == 0 && (g.L & 7) == 0 && (((uintptr_t)g.b) & 15) == 0;
   Regs ra, rb;
   if (s_lo < s_hi) {
-    load_tile<TA>(g.a, g.a_bf16, g.lda, g.I, g.L, i0, s_lo * BL, tid, ra);
-    load_tile<TB>(g.b, g.b_bf16, g.ldb, g.J, g.L, j0, s_lo * BL, tid, rb);
+    load_tile<TA, FULL>(g.a, g.a_bf16, raw_a, g.lda, g.I, g.L, i0, s_lo * BL, tid, ra);
+    load_tile<TB, FULL>(g.b, g.b_bf16, raw_b, g.ldb, g.J, g.L, j0, s_lo * BL, tid, rb);
   }
   for (int s = s_lo; s < s_hi; ++s) {
     char* buf = lds[(s - s_lo) & 1];
-    store_tile<TA>(buf, tid, ra);
-    store_tile<TB>(buf + TILE_LDS, tid, rb);
+    store_tile<TA>(buf, tid, ra, raw_a);
+    store_tile<TB>(buf + TILE_LDS, tid, rb, raw_b);
     __syncthreads();                       // (two buffers: the tile read two steps ago is free)
     if (s + 1 < s_hi) {
-      load_tile<TA>(g.a, g.a_bf16, g.lda, g.I, g.L, i0, (s + 1) * BL, tid, ra);
-      load_tile<TB>(g.b, g.b_bf16, g.ldb, g.J, g.L, j0, (s + 1) * BL, tid, rb);
+      load_tile<TA, FULL>(g.a, g.a_bf16, raw_a, g.lda, g.I, g.L, i0, (s + 1) * BL, tid, ra);
+      load_tile<TB, FULL>(g.b, g.b_bf16, raw_b, g.ldb, g.J, g.L, j0, (s + 1) * BL, tid, rb);
     }
     const char* pa = buf + (wi + (lane & 31)) * RS + 16 * h;
     const char* pb = buf + TILE_LDS + (wj + (lane & 31)) * RS + 16 * h;
@@ -156,6 +182,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mdmm_gemm_t g) {
         else c[(int64_t)i * ldc + j] = acc[x][y][r] + bias;
       }
     }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(const mdmm_gemm_t g) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2 * TILE_LDS];     // [buffer][A tile | B tile]
+  const bool full = (int)(blockIdx.x + 1) * BT <= g.J && (int)(blockIdx.y + 1) * BT <= g.I && g.L % BL == 0;
+  if (full) gemm_body<TA, TB, true>(g, lds);
+  else gemm_body<TA, TB, false>(g, lds);
 }
 
 // c[i][j] = bias[j] + sum over the split slabs

@@ -6,6 +6,7 @@ function launches HIP kernels from libmdmm_hip.so; none of them has a torch fall
 and all of them raise when handed CPU tensors.
 """
 import ctypes as C
+import os
 from collections import namedtuple
 
 import torch
@@ -1012,6 +1013,7 @@ def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.flo
     split = 1 if tiles >= 512 else max(1, min(steps // 8, (512 + tiles - 1) // tiles, 64))
     g = native.Gemm()
     g.I, g.J, g.L, g.ta, g.tb, g.split = I, J, L, int(ta), int(tb), split
+    g.reserved = int(os.environ.get('MDMM_GEMM_NO_RAW') == '1')      # A/B switch: bf16 operands through the converting path
     g.a, g.lda, g.b, g.ldb = _ptr(a), a.stride(0), _ptr(b), b.stride(0)
     g.a_bf16, g.b_bf16 = int(a.dtype == torch.bfloat16), int(b.dtype == torch.bfloat16)
     c = torch.empty(I, J, device=a.device, dtype=out_dtype)
@@ -1047,7 +1049,11 @@ class _LinearTilesFn(torch.autograd.Function):
         x, w = _rows(x), _rows(weight.detach())
         m, k = x.shape
         n = w.shape[0]
-        y = _gemm_bf16(x, False, w, False, m, n, k, _f32c(bias.detach()) if bias is not None else None,
+        # forward: the weight as bf16 once per call -- what the kernel rounds it to while staging, so the
+        # result is bit-identical; bf16 operands read along the contraction are moved as they are (every
+        # row tile re-reads W from L2 at half the bytes).  The input gradient reads W transposed: fp32.
+        wf = w.to(torch.bfloat16) if k % 8 == 0 else w
+        y = _gemm_bf16(x, False, _rows(wf), False, m, n, k, _f32c(bias.detach()) if bias is not None else None,
                        tag='linear_fwd[%dx%d]' % (k, n), out_dtype=out_dtype)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
