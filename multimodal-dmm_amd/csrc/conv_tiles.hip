@@ -565,9 +565,17 @@ __global__ void conv_fold_kernel(const float* src, int parts, int64_t elems, int
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
   if (e >= elems) return;
-  float s = 0.f;
-  for (int p = g; p < parts; p += groups) s += src[(size_t)p * elems + e];
-  dst[(size_t)g * elems + e] = s;
+  // four running sums: the loads of a trip are independent of one another
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int p = g;
+  for (; p + 3 * groups < parts; p += 4 * groups) {
+    s0 += src[(size_t)p * elems + e];
+    s1 += src[(size_t)(p + groups) * elems + e];
+    s2 += src[(size_t)(p + 2 * groups) * elems + e];
+    s3 += src[(size_t)(p + 3 * groups) * elems + e];
+  }
+  for (; p < parts; p += groups) s0 += src[(size_t)p * elems + e];
+  dst[(size_t)g * elems + e] = (s0 + s1) + (s2 + s3);
 }
 
 int shape_id(const mdmm_conv_t* a) {
