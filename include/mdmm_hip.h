@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 17
+#define MDMM_ABI_VERSION 18
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -539,6 +539,11 @@ typedef struct mdmm_gemm {
 int mdmm_gemm_supported(const mdmm_gemm_t* args);
 int64_t mdmm_gemm_ws_bytes(const mdmm_gemm_t* args);
 int mdmm_gemm_bf16(const mdmm_gemm_t* args, void* stream);
+/* Column sums out[j] = sum_i a[i*lda + j] of a (rows x cols) fp32 or bf16 matrix: the bias gradient of
+ * those projections (autograd of nn.Linear's bias, common.py:114-175), which the row-major gradient
+ * makes a strided reduction.  cols, lda multiples of 4; ws = mdmm_colsum_splits(rows, cols) * cols floats. */
+int mdmm_colsum_splits(int64_t rows, int cols);
+int mdmm_colsum(const void* a, int a_bf16, int64_t rows, int cols, int64_t lda, float* ws, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * MultiVRNN.forward (vrnn.py:123-235) as one scan over time and its adjoint: per step the prior

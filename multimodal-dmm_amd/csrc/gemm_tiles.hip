@@ -204,7 +204,68 @@ __global__ void gemm_fold_kernel(const mdmm_gemm_t g) {
   else reinterpret_cast<float*>(g.c)[i * g.ldc + j] = v;
 }
 
+// ---- column sums: out[j] = sum_i a[i*lda + j]  (the bias gradient of a projection: g^T 1) ----------
+// A workgroup owns 64 columns and a slab of the rows: a 16-lane group reads one row's 64 columns (128
+// or 256 contiguous bytes), four rows per wave-instruction; per-thread fp32 sums over the slab, one LDS
+// reduction over the sixteen row lanes, slabs folded by a second launch (deterministic).
+constexpr int CS_COLS = 64, CS_SPLIT_MAX = 64;
+
+__global__ __launch_bounds__(256) void colsum_kernel(const void* a, int bf, int64_t rows, int cols, int64_t lda,
+                                                     float* part) {
+  __shared__ float red[16][CS_COLS + 4];
+  const int tid = threadIdx.x, rl = tid >> 4, cg = tid & 15;
+  const int j = blockIdx.x * CS_COLS + 4 * cg;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t lo = blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (j < cols) {
+    for (int64_t i = lo + rl; i < hi; i += 16) {
+      const float4 v = ld4(a, i * lda + j, bf != 0);
+      s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+    }
+  }
+  red[rl][4 * cg] = s0; red[rl][4 * cg + 1] = s1; red[rl][4 * cg + 2] = s2; red[rl][4 * cg + 3] = s3;
+  __syncthreads();
+  if (tid < CS_COLS && blockIdx.x * CS_COLS + tid < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[r][tid];
+    part[(size_t)blockIdx.y * cols + blockIdx.x * CS_COLS + tid] = s;
+  }
+}
+
+__global__ void colsum_fold_kernel(const float* part, int splits, int cols, float* out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(size_t)z * cols + j];
+  out[j] = s;
+}
+
 }  // namespace
+
+extern "C" int mdmm_colsum_splits(int64_t rows, int cols) {
+  const int tiles = (cols + CS_COLS - 1) / CS_COLS;
+  int64_t s = (2048 + tiles - 1) / tiles;                  // ~8 workgroups per CU
+  const int64_t cap = (rows + 255) / 256;                  // at least 16 trips of the 16 row lanes per slab
+  if (s > cap) s = cap;
+  if (s > CS_SPLIT_MAX) s = CS_SPLIT_MAX;
+  return s < 1 ? 1 : (int)s;
+}
+
+extern "C" int mdmm_colsum(const void* a, int a_bf16, int64_t rows, int cols, int64_t lda, float* ws, float* out,
+                           void* stream) {
+  if (!a || !ws || !out || rows < 1 || cols < 1 || (cols & 3) || (lda & 3)) return MDMM_E_ARG;
+  if (((uintptr_t)a) & (a_bf16 ? 7 : 15)) return MDMM_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const int splits = mdmm_colsum_splits(rows, cols);
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + CS_COLS - 1) / CS_COLS, splits), dim3(256), 0, st, a, a_bf16, rows, cols,
+                     lda, ws);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, (const float*)ws, splits, cols, out);
+  return (int)hipGetLastError();
+}
 
 extern "C" int mdmm_gemm_supported(const mdmm_gemm_t* g) {
   if (!g || g->I < 1 || g->J < 1 || g->L < 1 || g->split < 1) return 0;

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 17
+ABI_VERSION = 18
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -38,6 +38,7 @@ SYMBOLS = [
     'mdmm_gemm_supported', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
     'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
     'mdmm_conv1d_supported', 'mdmm_conv1d_up', 'mdmm_conv1d_down', 'mdmm_conv1d_wgrad_ws_bytes', 'mdmm_conv1d_wgrad',
+    'mdmm_colsum_splits', 'mdmm_colsum',
     'mdmm_vrnn_layout', 'mdmm_vrnn_supported', 'mdmm_vrnn_fwd', 'mdmm_vrnn_bwd',
 ]
 
@@ -281,6 +282,8 @@ def lib():
         L.mdmm_gemm_ws_bytes.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_ws_bytes.restype = C.c_int64
         L.mdmm_gemm_bf16.argtypes = [C.POINTER(Gemm), _P]
+        L.mdmm_colsum_splits.argtypes = [C.c_int64, C.c_int]
+        L.mdmm_colsum.argtypes = [_P, C.c_int, C.c_int64, C.c_int, C.c_int64, _P, _P, _P]
         L.mdmm_vrnn_layout.argtypes = [C.POINTER(Vrnn), C.POINTER(VrnnLayout)]
         L.mdmm_vrnn_supported.argtypes = [C.POINTER(Vrnn), C.c_int]
         L.mdmm_vrnn_fwd.argtypes = [C.POINTER(Vrnn), _P]

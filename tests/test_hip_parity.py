@@ -945,6 +945,24 @@ def test_vrnn_forward_golden(scan, dev, kernel_family):
         assert all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None)
 
 
+@pytest.mark.parametrize('shape', [(10240, 4096, torch.bfloat16), (2048, 260, torch.float32), (5000, 64, torch.bfloat16)])
+def test_colsum_matches_torch(shape, dev, kernel_family):
+    """Bias gradient of the projections (ops.colsum -> mdmm_colsum): column sums of a row-major fp32 / bf16
+    matrix in fp32, also for a column-slice view; against torch's fp64 sum."""
+    if kernel_family == 'generic':
+        pytest.skip('one kernel')
+    from mdmm import ops
+    rows, cols, dt = shape
+    torch.manual_seed(0)
+    g = torch.randn(rows, cols + 8, device=dev).to(dt)
+    for view in (g[:, :cols], g[:, 4:4 + cols]):
+        got = ops.colsum(view)
+        ref = view.double().sum(0)
+        assert got.dtype == torch.float32 and got.shape == (cols,)
+        err = float((got.double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, err
+
+
 VRNN_CASES = {
     # h, z, dims, layers, recur_mode, modalities given, T, B
     'h8_z5_use_inputs_2layers': (8, 5, [3, 2], 2, 'use_inputs', ['a', 'b'], 9, 7),
