@@ -1459,7 +1459,10 @@ class _ConvTilesFn(torch.autograd.Function):
             gw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
             _call('mdmm_conv_wgrad', C.byref(a), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % a.S)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3), dtype=torch.float32)
+            # per-channel sums over images and pixels: column sums of the (N, C*H*W) matrix on the own
+            # kernel (the images are the strided dimension), then C short rows
+            c = gy.shape[1]
+            gb = colsum(gy.reshape(n, -1)).reshape(c, -1).sum(1)
         return gx, gw, gb, None
 
 
