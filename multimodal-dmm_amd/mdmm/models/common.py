@@ -18,8 +18,12 @@ import torch.nn.functional as F
 def _lin(x, layer):
     """Linear holder applied through the split-K weight-gradient path on the GPU."""
     if x.is_cuda and x.dim() == 2 and not torch.is_autocast_enabled() and x.dtype == layer.weight.dtype:
-        from ..ops import tall_linear
-        return tall_linear(x, layer)
+        from .. import ops
+        # with the model's projections switched to bf16 operands (MultiDGTS.conv_dtype), the wide layers
+        # of the stock MLP holders run on the own GEMM like the image plug-ins' heads
+        if ops.CONV_OPERANDS is torch.bfloat16 and ops.linear_tiles_supported(x, layer.weight):
+            return ops.linear_tiles(x, layer.weight, layer.bias)
+        return ops.tall_linear(x, layer)
     return layer(x)         # under autocast (plugin_dtype) the stock module casts for itself
 
 
