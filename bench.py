@@ -9,9 +9,13 @@ loss = model.step(...); (loss / n_points).backward(); [all-reduce]; Adam.step();
 Workload (default, the configuration BASELINE.json's targets are quoted on): configs[2] "cfg3",
 Weizmann-shaped synthetic -- video (3,64,64) + mask (1,64,64) Bernoulli, action Categorical(10),
 conv encoders / decoders of weizmann.py:63-68, MultiDMM BFVI, z = h = 256, T = 40, 256 sequences
-per GPU, 20 % burst NaN, 25 training particles; the dense contractions of the sweeps run with bf16
-operands (MultiDGTS.sweep_dtype), everything else fp32.  `--config cfg2` is the Spirals-synthetic
-z = h = 32 case of round 1 (graph replay); its result also rides along as `extra.cfg2` at N = 1.
+per GPU, 20 % burst NaN, 25 training particles; the dense contractions of the sweeps, convolutions
+and projections run with bf16 operands and fp32 accumulation, the conv-chain activations are stored
+as bf16 (MultiDGTS.sweep_dtype / conv_dtype / act_dtype); latents, statistics, reductions fp32.  The
+step is replayed from HIP graphs (`--eager` opts out; `config.execution` says which, and names the
+graph executor's stream count this script asks for).  `--config cfg2` is the
+Spirals-synthetic z = h = 32 case of round 1; it and cfg4 (MultiDKS on the cfg3 batch) ride along as
+`extra.cfg2` / `extra.cfg4` at N = 1.
 
 `--gpus N` with N > 1 starts N ranks itself (torch.distributed.run, one process per GPU, RCCL)
 unless it already runs under a launcher (WORLD_SIZE set, which must then equal N).  Every rank
