@@ -262,3 +262,54 @@ def test_eager_grad_function_matches_plain_autograd():
     (fn() * scale).backward()
     assert torch.allclose(got[0], a.grad) and torch.allclose(got[1], b.grad)
     assert got[2] is None and torch.allclose(got[3], scale.grad)
+
+
+def test_vrnn_scan_layout_and_limits():
+    """Host side of the VRNN scan (csrc/vrnn.hip): the spill-row layout the weight gradients index, and
+    which widths one CU's LDS takes."""
+    from mdmm import native
+    L = native.lib()
+    a = native.Vrnn()
+    a.T, a.B, a.H, a.Z, a.M, a.L = 10, 64, 18, 5, 2, 2          # h = 18 -> 20, z = 5 -> 8
+    a.dims[0], a.dims[1] = 3, 2
+    lay = native.VrnnLayout()
+    assert L.mdmm_vrnn_layout(ctypes.byref(a), ctypes.byref(lay)) == 0
+    assert (lay.Hp, lay.Zp, lay.dp[0], lay.dp[1]) == (20, 8, 4, 4)
+    parts = (2 * 20 + 20 + 2 * 8 +                       # GRU states, prior hidden / mean / std
+             2 * (4 + 20 + 20 + 8 + 8) + 8 +             # per modality: x, phi, encoder hidden, mean, std; z
+             2 * (20 + 4 + 4 + 4) +                      # per modality: decoder hidden, mean, std, filled x
+             2 * 20 + 20 +                               # recurrence features, phi_z
+             2 * (60 + 60 + 20))                         # per GRU layer: input / state products, new state
+    assert lay.rows == parts
+    offs = [lay.h[0], lay.h[1], lay.ph, lay.pm, lay.ps, lay.z, lay.fz, lay.feat[0], lay.feat[1], lay.gi[1], lay.hn[1]]
+    assert all(o % 4 == 0 and 0 <= o < lay.rows for o in offs)
+    assert lay.feat[1] == lay.feat[0] + lay.Hp and lay.fz == lay.feat[1] + lay.Hp     # the GRU's input is one block
+    assert L.mdmm_vrnn_supported(ctypes.byref(a), 0) == 1 and L.mdmm_vrnn_supported(ctypes.byref(a), 1) == 1
+    a.H = a.Z = 256
+    assert L.mdmm_vrnn_supported(ctypes.byref(a), 0) == 1 and L.mdmm_vrnn_supported(ctypes.byref(a), 1) == 0
+    a.M = 5
+    assert L.mdmm_vrnn_supported(ctypes.byref(a), 0) == 0
+    assert L.mdmm_vrnn_fwd(ctypes.byref(a), None) < 0           # argument error, nothing launched
+
+
+def test_vrnn_block_padding_round_trip():
+    """Weights of the VRNN scan are zero-padded per concatenated part (GRU gates x input blocks)."""
+    from mdmm import ops
+    torch.manual_seed(0)
+    H, M = 5, 2
+    w = torch.randn(3 * H, (M + 1) * H)
+    p = ops._pad_blocks(w, [H] * 3, [H] * (M + 1))
+    assert p.shape == (3 * 8, (M + 1) * 8)
+    assert torch.equal(ops._unpad_blocks(p, [H] * 3, [H] * (M + 1)), w)
+    assert float(p.abs().sum()) == pytest.approx(float(w.abs().sum()))          # padding is zeros
+    assert torch.equal(p[8:8 + H, 16:16 + H], w[H:2 * H, 2 * H:3 * H])         # gate z, last input block
+    same = torch.randn(8, 12)
+    assert ops._pad_blocks(same, [8], [4, 8]) is same
+
+
+def test_colsum_launch_geometry():
+    from mdmm import native
+    L = native.lib()
+    assert 1 <= L.mdmm_colsum_splits(10240, 4096) <= 64
+    assert L.mdmm_colsum_splits(100, 64) == 1
+    assert L.mdmm_colsum(None, 0, 8, 8, 8, None, None, None) < 0
