@@ -17,37 +17,15 @@
 // accumulator registers at RT = 4; x is clamped to +-30, where sigmoid is 0 / 1 to 1e-13.)
 // Then, on the accumulator registers: product with the global prior per particle, moments over
 // the particles, product with the step's experts, outputs, the next particles -> Z image.
-#include <stdlib.h>
-#include "sweep_internal.h"
-#include "wide_tiles.h"
+#include "wide_sweep.h"
 
 namespace {
 
 using namespace mdmm;
 using namespace wide;
 
-struct WideGeo {
-  int n_pairs;     // P * B
-  int NP;          // (pass, sequence) pairs per workgroup
-  int TPP;         // row tiles per pair (K > 1), 1 for K = 1
-  int ntab;        // slots in the pair table
-  unsigned long long* stamps;   // diagnostic builds (-DWIDE_STAMPS): cycle stamps of one step
-};
 
-// In-kernel stamps (diagnostic build only; the pointer comes from MDMM_STAMP_PTR): wave w of
-// workgroup 0 stores s_memtime at point k of step 3 into stamps[32 w + k].
-#ifdef WIDE_STAMPS
-#define STAMP(k)                                                                              \
-  do {                                                                                        \
-    if (g.stamps && blockIdx.x == 0 && lane == 0 && (i == 3 || i == a.T - 4))                 \
-      g.stamps[32 * wave + (k)] = __builtin_amdgcn_s_memtime();                                \
-  } while (0)
-#else
-#define STAMP(k) do {} while (0)
-#endif
 
-struct PairRef { int p, b; };      // p < 0: slot unused
-typedef const __attribute__((address_space(4))) mdmm_sweep_t KArgs;   // the descriptor in kernarg memory
 
 template <bool F32, int RT>
 struct FwdLds {
@@ -57,60 +35,6 @@ struct FwdLds {
   static constexpr int BYTES = OFF_ROW + 32 * RT * 8;
 };
 
-__device__ __forceinline__ uint64_t noise_off(const mdmm_sweep_t& a) {
-  return a.offset + (a.offset_dev ? *a.offset_dev : 0);
-}
-
-// tables shared by the forward and the backward kernel: pair of every slot, noise row base of
-// every row (flat index of element (p, t=0, k, b, d=0) of the (P,T,K,B,D) noise tensor; ~0 = dead)
-template <int RT, bool K1>
-__device__ __forceinline__ void build_tables(const mdmm_sweep_t& a, const WideGeo& g, PairRef* tab,
-                                             uint64_t* rowbase) {
-  const int R = 32 * RT;
-  for (int r = threadIdx.x; r < R; r += NTHR) {
-    const int slot = K1 ? r : (r >> 5) / g.TPP;
-    const int k = K1 ? 0 : (r - 32 * g.TPP * slot);
-    const int64_t pair = (int64_t)blockIdx.x * g.NP + slot;
-    const bool live = slot < g.NP && pair < g.n_pairs && k < a.K;
-    int p = -1, b = 0;
-    if (slot < g.NP && pair < g.n_pairs) { p = (int)(pair / a.B); b = (int)(pair - (int64_t)p * a.B); }
-    if (K1 || (r & 31) == 0) {
-      // K > 1: one entry per row TILE (all tiles of a pair carry the pair)
-      PairRef e; e.p = p; e.b = b;
-      tab[K1 ? r : (r >> 5)] = e;
-    }
-    rowbase[r] = live ? ((((uint64_t)p * a.T) * a.K + k) * a.B + b) * (uint64_t)WD : ~0ull;
-  }
-}
-
-// N(0,1) draws of the four rows (registers 4q .. 4q+3) of one accumulator register group:
-// e[j] = eps(row j, feature n).  Philox yields four consecutive features per counter, so lane u
-// of a quad draws row u's four features and the quad transposes (wide_tiles.h).
-template <class A>
-__device__ __forceinline__ void eps_group(const A& a, uint64_t noff, uint64_t t_term,
-                                          const uint64_t* rowbase_r0, int n, float (&e)[4]) {
-  if (a.eps) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint64_t rb = rowbase_r0[j];
-      e[j] = (rb != ~0ull) ? a.eps[rb + t_term + n] : 0.f;
-    }
-    return;
-  }
-  const int u = n & 3;
-  const uint64_t rb = rowbase_r0[u];
-  philox_normal4(a.seed, noff, (rb + t_term + (uint64_t)(n & ~3)) >> 2, e);
-  quad_transpose(e, u);
-}
-
-// per-tile sums -> total of the pair the tile belongs to (TPP = 1, 2 or 4 tiles per pair)
-template <int RT>
-__device__ __forceinline__ float pair_total(const float (&s)[RT], int rt, int tpp) {
-  float v = s[rt];
-  if constexpr (RT >= 2) { if (tpp >= 2) v += s[rt ^ 1]; }
-  if constexpr (RT >= 4) { if (tpp == 4) v += s[rt ^ 2] + s[rt ^ 3]; }
-  return v;
-}
 
 // ---------------------------------------------------------------------------------------
 // forward
@@ -402,7 +326,6 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
 // input-gradient contractions (D1-D3).  Four LDS images; the weight-gradient operands leave as
 // MFMA operand chunks (wide_tiles.h, acc_chunk) and are contracted over all rows afterwards.
 // ---------------------------------------------------------------------------------------
-enum Spill { S_Z = 0, S_HG, S_HN, S_NL, S_GHG, S_GHN, S_GLIN, S_GG, S_GN, S_G3, N_SPILL };
 
 template <bool F32, int RT>
 struct BwdLds {
@@ -412,88 +335,6 @@ struct BwdLds {
   static constexpr int BYTES = OFF_ROW + 32 * RT * 8;
 };
 
-// workspace of one backward sweep (device pointers into mdmm_sweep_t.wide_ws)
-struct WideWs {
-  uint4* spill;      // [workgroup][step][N_SPILL][wave][chunk][lane]
-  float* db;         // [split][6][256] bias-gradient partial sums (written by the wgrad kernel)
-  float* dz0;        // [workgroup][2][256] d/d(mu0, sigma0) partial sums
-  float* slab;       // [split][6][256][256] weight-gradient partial sums
-  int64_t n_wg, n_step;
-  int split;
-};
-
-__device__ __forceinline__ void poe_out_bwd_f(float num, float rp, float sd, float g_mean, float g_std,
-                                              float& g_num, float& g_prec) {
-  const float m = num * rp;
-  if (m != m) g_mean = 0.f;
-  g_num = g_mean * rp;
-  g_prec = -g_mean * num * rp * rp - 0.5f * g_std * sd * rp;
-}
-__device__ __forceinline__ void poe_expert_bwd_f(float mu, float sd, float c, float g_num, float g_prec,
-                                                 float& g_mu, float& g_sd) {
-  const float inv = fast::rcp(sd * sd + MDMM_POE_EPS);
-  const float sg = signf_(sd);
-  const float t = inv * sg * c;
-  g_mu = g_num * t * c;
-  const float g_inv = (g_num * mu * c + g_prec) * c * sg;
-  g_sd = -g_inv * inv * inv * 2.0f * sd;
-}
-
-struct FuseAdj { float gpm, gps, prm, prs; };
-
-// adjoint of sampling + product of experts of ONE (pass, sequence) at step t, feature n
-// (dmm.py:387-405 backwards).  `owner`: this lane writes the expert gradients and counts the
-// pair's d/d(mu0, sigma0) (the pair's values are replicated over lanes / tiles).
-template <class A, class E>
-__device__ __forceinline__ FuseAdj fuse_bwd(const A& a, const E* exs, PairRef pr, int t, int n, float mu0,
-                                            float sg0, float adj_a, float adj_b, float se,
-                                            bool sampled, float inv_k, bool first, bool owner,
-                                            float& g_mu0, float& g_sg0) {
-  FuseAdj r; r.gpm = 0.f; r.gps = 0.f; r.prm = 0.f; r.prs = 1.f;
-  if (pr.p < 0) return r;
-  const size_t tb = (size_t)t * a.B + pr.b;
-  const size_t o = (((size_t)pr.p * a.T + t) * a.B + pr.b) * WD + n;
-  const float gsmp = a.g_samples ? a.g_samples[o] : 0.f;
-  float g_im = (a.g_infer_mean ? a.g_infer_mean[o] : 0.f) + adj_a + gsmp;
-  float g_is = a.g_infer_std ? a.g_infer_std[o] : 0.f;
-  if (sampled) g_is += adj_b + gsmp * se * inv_k;
-  const float prm = a.prior_mean[o], prs = a.prior_std[o];
-  fast::Poe q; q.init(); q.add(prm, prs, 1.0f);
-  for (int e = 0; e < a.E; ++e) {
-    const auto& ex = exs[e];
-    if (!((ex.pass_bits >> pr.p) & 1u)) continue;
-    const float c = ex.mask ? ex.mask[tb] : 1.0f;
-    const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
-    q.add(ex.mean[off], ex.std[off], c);
-  }
-  if (a.use_inv_prior) q.add(mu0, -sg0, 1.0f);
-  const float rp = fast::rcp(q.prec), is = fast::sqrt(rp);
-  float g_num, g_prec, gm, gs;
-  poe_out_bwd_f(q.num, rp, is, g_im, g_is, g_num, g_prec);
-  poe_expert_bwd_f(prm, prs, 1.0f, g_num, g_prec, gm, gs);
-  r.gpm = gm + (a.g_prior_mean ? a.g_prior_mean[o] : 0.f);
-  r.gps = gs + (a.g_prior_std ? a.g_prior_std[o] : 0.f);
-  r.prm = prm; r.prs = prs;
-  for (int e = 0; e < a.E; ++e) {
-    const auto& ex = exs[e];
-    if (!((ex.pass_bits >> pr.p) & 1u)) continue;
-    const float c = ex.mask ? ex.mask[tb] : 1.0f;
-    const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
-    poe_expert_bwd_f(ex.mean[off], ex.std[off], c, g_num, g_prec, gm, gs);
-    if (owner) {
-      if (ex.g_mean) ex.g_mean[o] = gm;       // one slab per pass, (P,T,B,D)
-      if (ex.g_std) ex.g_std[o] = gs;
-    }
-  }
-  if (owner) {
-    if (a.use_inv_prior) {
-      poe_expert_bwd_f(mu0, -sg0, 1.0f, g_num, g_prec, gm, gs);
-      g_mu0 += gm; g_sg0 -= gs;
-    }
-    if (first) { g_mu0 += r.gpm; g_sg0 += r.gps; }     // first step: prior = p(z)
-  }
-  return r;
-}
 
 template <bool F32, int RT>
 __device__ __forceinline__ void spill_tiles(uint4* dst, const f32x16 (&v)[RT]) {
@@ -1179,6 +1020,7 @@ int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
 }
 
 int mdmm_wide_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
+  if (mdmm_wide_bwd4_supported(a)) return mdmm_wide_sweep_bwd4(a, stream);     // K <= 25, bf16: one round
   WideGeo g;
   const int RT = plan(a, true, &g);
   if (!RT) return MDMM_UNSUPPORTED;
@@ -1191,7 +1033,10 @@ int mdmm_wide_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->K == 1) rc = f32 ? launch_bwd<true, 1, true>(a, g, ws, stream) : launch_bwd<false, 1, true>(a, g, ws, stream);
   else rc = f32 ? launch_bwd<true, 1, false>(a, g, ws, stream) : launch_bwd<false, 2, false>(a, g, ws, stream);
   if (rc) return rc;
-  const int CH = RT * (f32 ? 4 : 2);
+  return wide_wgrad_launch(ws, f32, RT * (f32 ? 4 : 2), a->dw_partial, stream);
+}
+
+int wide::wide_wgrad_launch(const WideWs& ws, bool f32, int CH, float* dw_partial, hipStream_t stream) {
   const char* turn_env = getenv("MDMM_WGRAD_XCD");                  // A/B switch, default on
   const int turn = turn_env ? atoi(turn_env) : 1;
   const int n_wgrad = (6 * ws.split + 7) & ~7;
@@ -1201,12 +1046,13 @@ int mdmm_wide_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(n_wgrad), dim3(NTHR), wg_lds, stream, ws, turn);
     return 0;
   };
+  int rc;
   if (f32) rc = CH == 4 ? wgrad(wide_wgrad_kernel<true, 4>) : wgrad(wide_wgrad_kernel<true, 8>);
   else rc = CH == 2 ? wgrad(wide_wgrad_kernel<false, 2>) : wgrad(wide_wgrad_kernel<false, 4>);
   if (rc) return rc;
   rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL(wide_reduce_kernel, dim3((6 * WD * WD + 8 * WD + 255) / 256), dim3(256), 0, stream, ws, a->dw_partial);
+  hipLaunchKernelGGL(wide_reduce_kernel, dim3((6 * WD * WD + 8 * WD + 255) / 256), dim3(256), 0, stream, ws, dw_partial);
   return (int)hipGetLastError();
 }
 
@@ -1224,6 +1070,7 @@ extern "C" int mdmm_sweep_wide(const mdmm_sweep_t* a) {
 }
 
 extern "C" int64_t mdmm_sweep_wide_ws_bytes(const mdmm_sweep_t* a) {
+  if (mdmm_wide_bwd4_supported(a)) return mdmm_wide_bwd4_ws_bytes(a);
   WideGeo g;
   const int RT = plan(a, true, &g);
   return RT ? carve(a, g, RT, nullptr) : 0;

@@ -59,7 +59,7 @@ def err(a, b):
 
 cases = [  # T, B, P, K, inv, reverse, sample, sample_init
     (5, 37, 3, 1, 0, 0, 1, 0), (5, 37, 3, 1, 1, 1, 0, 1), (6, 3, 1, 1, 0, 1, 1, 0),
-    (5, 5, 3, 25, 0, 0, 1, 0), (4, 6, 2, 25, 1, 1, 1, 0), (4, 3, 2, 40, 0, 0, 1, 0), (3, 2, 1, 100, 0, 1, 1, 0),
+    (5, 5, 3, 25, 0, 0, 1, 0), (4, 6, 2, 25, 1, 1, 1, 0), (6, 7, 4, 8, 0, 1, 1, 0), (1, 5, 2, 25, 0, 0, 1, 0), (3, 9, 1, 2, 0, 0, 1, 0), (4, 3, 2, 40, 0, 0, 1, 0), (3, 2, 1, 100, 0, 1, 1, 0),
 ]
 if kw['big']:
     cases = [(40, 32, 4, 25, 0, 0, 1, 0), (40, 32, 4, 1, 1, 1, 1, 0)]
@@ -75,6 +75,15 @@ for ci, (T, B, P, K, inv, rev, smp, sinit) in enumerate(cases):
         if (prec is torch.float32 and K > 32) or (kw['bwd'] and K > 64):
             continue
         got, ggot = run(ops.SweepCfg(precision=prec, **base), gtf, z0m, z0s, experts, kw['bwd'])
+        if prec is torch.bfloat16 and kw['bwd'] and 1 < K <= 25:
+            # the one-round backward (sweep_wide_bwd4.hip) against the two-round one, same operands
+            os.environ['MDMM_WIDE_BWD4'] = '0'
+            _, gold = run(ops.SweepCfg(precision=prec, **base), gtf, z0m, z0s, experts, 1)
+            os.environ['MDMM_WIDE_BWD4'] = '1'
+            l2 = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+            print('      bwd4 vs two-round bf16 backward: max-rel %.3e, L2 %.3e; two-round vs fp32 generic: L2 %.3e, bwd4 vs generic L2 %.3e'
+                  % (max(err(a, b) for a, b in zip(ggot, gold)), max(l2(a, b) for a, b in zip(ggot, gold)),
+                     max(l2(a, b) for a, b in zip(gold, gref)), max(l2(a, b) for a, b in zip(ggot, gref))), flush=True)
         names = ['infer_mean', 'infer_std', 'prior_mean', 'prior_std', 'samples']
         eo = max(err(a, b) for a, b in zip(got, ref) if b.numel())
         eg = max([err(a, b) for a, b in zip(ggot, gref)] or [0.0])

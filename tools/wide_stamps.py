@@ -49,6 +49,12 @@ else:
              11: 'barrier', 12: 'D1 gemm+store+spill', 13: 'barrier', 14: 'D2 2 gemms+store+spills', 15: 'barrier+store+barrier',
              16: 'D3 3 gemms+adj', 17: 'barrier'}
     order = list(range(18))
+    if os.environ.get('MDMM_WIDE_BWD4', '1') != '0' and 1 < K <= 25 and kw['bf16']:
+        names = {0: 'step start', 1: '(A) fuse adjoint -> park', 2: 'R1 particles (Philox), eps -> park', 3: 'barrier, Z store+spill, barrier',
+                 4: 'R2 2 gemms+relu+stores+spills', 5: 'barrier', 6: 'R3 gate gemm+code, nl gemm+spill', 7: 'barrier, nl store, lin gemm, muq -> park',
+                 8: 'barrier', 9: 'R4 gemm', 10: 'barrier', 11: 'E elementwise+stores+spills', 12: 'barrier',
+                 13: 'D1 2 gemms+masks+spills', 14: 'barrier, GHG store, GN from spill, barrier', 15: 'D2 2 gemms+mask+spill',
+                 16: 'barrier, GHN from spill, barrier', 17: 'D3 2 gemms + sums'}
 for w in (0, 7):
     print('wave %d (cycles since step start; delta)' % w)
     prev = int(s[w, 0])
