@@ -81,25 +81,32 @@ __device__ __forceinline__ u32x4 chunk8(const f32x16& v, int s) {
 // address of tile 0 in the image, `ts` = bytes between tiles (K rows).  Ring contract as gemm_tile.
 // The A operands of chunk c + 1 are read while chunk c's MFMAs issue (the read behind the last
 // chunk lands in the row pad and is dropped).
+struct NoTrip { __device__ __forceinline__ void operator()(int) const {} };
+template <bool NEXT = true, class Trip = NoTrip>
 __device__ __forceinline__ void gemm4(f32x16 (&acc)[RT], const char* x0, int ts, gw_t w, gw_t wnext,
-                                      u32x4 (&ring)[PF]) {
+                                      u32x4 (&ring)[PF], Trip trip = Trip()) {
   u32x4 an[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const u32x4*>(x0 + rt * ts);
 #pragma unroll 1
   for (int c0 = 0; c0 < NCH; c0 += PF) {
     gw_t nxt = (c0 + PF < NCH) ? w + (c0 + PF) * 64 : wnext;
+    trip(c0 / PF);
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       u32x4 ac[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) ac[rt] = an[rt];
 #pragma unroll
+#ifndef B4_NOA      // timing experiment: no A-operand reads in the loop (results are wrong)
       for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const u32x4*>(x0 + rt * ts + 32 * (c0 + u + 1));
+#endif
       __builtin_amdgcn_sched_barrier(0);      // (the scheduler would sink every read to its MFMA)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) mma16(acc[rt], ac[rt], ring[u]);
-      ring[u] = nxt[u * 64];                  // behind its last reader: no copy, a whole trip to land
+#ifndef B4_NOW      // timing experiment: no weight loads in the loop (results are wrong)
+      if (NEXT || c0 + PF < NCH) ring[u] = nxt[u * 64];   // behind its last reader: no copy, a whole trip to land
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -179,12 +186,25 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, const WideGeo g,
                                                          const WideWs ws, const B4Park park) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: scalar address math
-  const int h = lane >> 5, n = 32 * wave + (lane & 31);
+  // Everything derived from the lane id is RE-derived at the head of every phase (regeo) from an
+  // opaque read of the id: kept across the step these values are what the register allocator spills,
+  // and a reload from scratch is a vector-memory load -- it waits for every older store of the wave.
+  int lane, h, n, odd, kh, kh2, arow, srow;
+  unsigned sel;
   const int T = a.T, B = a.B, K = a.K;
   const int ts = K * RS, img = RT * ts;
-  const int kh = K - 4 * h;
+  auto regeo = [&]() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    lane = l; h = l >> 5; n = 32 * wave + (l & 31); odd = l & 1;
+    kh = K - 4 * h; kh2 = kh - odd;
+    arow = min(l & 31, K - 1) * RS + 16 * h;          // A operand: tile 0 (dead MFMA rows re-read row K - 1)
+    srow = (4 * h + odd) * RS + (n & ~1) * 2;         // image stores: see pair_word
+    sel = odd ? 0x03020706u : 0x05040100u;
+  };
+  regeo();
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);       // the second-dispatched half loses every arbitration otherwise
   const uint64_t noff = noise_off(a);
   const float inv_k = 1.0f / (float)K;
 
@@ -204,12 +224,6 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
   gs_t park_w = park0;
   auto W = [&](int layer) { return frag + (size_t)layer * LAYER_U4 + lane; };
   auto Bias = [&](int which) { return bias[which * WD + (lane & 31)]; };
-  // A-operand address of tile 0 (dead MFMA rows re-read row K - 1) and store address of row 4 h
-  const int arow = min(lane & 31, K - 1) * RS + 16 * h;
-  const int odd = lane & 1;
-  const int srow = (4 * h + odd) * RS + (n & ~1) * 2;          // image stores: see pair_word
-  const int kh2 = kh - odd;
-  const unsigned sel = odd ? 0x03020706u : 0x05040100u;
   const float mu0 = a.z0_mean[n], sg0 = fast::exp(a.z0_log_std[n]) + a.min_std;
 
   float adj_a[RT], adj_b[RT], se[RT];
@@ -283,6 +297,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     KArgs& a = *kap;
     const auto* exs = a.experts;
     const int t = a.reverse ? T - 1 - i : i;
+    regeo();
     STAMP(0);
     // ---- (A) adjoint of sampling + fusion at step i, merged per pair with R1, the particles of step
     // i-1: everything (A) reads from HBM is requested first, the Philox draws of the pair's particles
@@ -294,6 +309,28 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     unsigned pv = 0;                                  // bit rt: tile rt carries a pair
     f32x16 v0[RT];
     constexpr int EB = 4;                             // experts whose loads are batched
+    // the launch arguments this section reads, as one batch of scalar loads per step (read where they
+    // are used they were a dozen dependent scalar round trips per pair)
+    const float* const p_gsmp = a.g_samples;
+    const float* const p_gim = a.g_infer_mean;
+    const float* const p_gis = a.g_infer_std;
+    const float* const p_gpm = a.g_prior_mean;
+    const float* const p_gps = a.g_prior_std;
+    const float* const p_prm = a.prior_mean;
+    const float* const p_prs = a.prior_std;
+    const float* const p_im = a.infer_mean;
+    const float* const p_is = a.infer_std;
+    const int n_exp = a.E;
+    const bool inv_prior = a.use_inv_prior;
+    struct { const float *mean, *std, *mask; float *g_mean, *g_std; int64_t stride; unsigned bits; } ed[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+      const bool on = e < n_exp;
+      ed[e].mean = on ? exs[e].mean : nullptr; ed[e].std = on ? exs[e].std : nullptr;
+      ed[e].mask = on ? exs[e].mask : nullptr;
+      ed[e].g_mean = on ? exs[e].g_mean : nullptr; ed[e].g_std = on ? exs[e].g_std : nullptr;
+      ed[e].stride = on ? exs[e].pass_stride : 0; ed[e].bits = on ? exs[e].pass_bits : 0u;
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const PairRef prt = tab[rt];
@@ -309,28 +346,29 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       if (valid) {
         tb = (size_t)t * B + pb;
         o = (((size_t)pp * T + t) * B + pb) * WD + n;
-        if (a.g_samples) gsmp = a.g_samples[o];
-        if (a.g_infer_mean) g_im = a.g_infer_mean[o];
-        if (a.g_infer_std) g_is = a.g_infer_std[o];
-        prm = a.prior_mean[o]; prs = a.prior_std[o];
-        if (a.g_prior_mean) g_pm = a.g_prior_mean[o];
-        if (a.g_prior_std) g_ps = a.g_prior_std[o];
+        if (p_gsmp) gsmp = p_gsmp[o];
+        if (p_gim) g_im = p_gim[o];
+        if (p_gis) g_is = p_gis[o];
+        prm = p_prm[o]; prs = p_prs[o];
+        if (p_gpm) g_pm = p_gpm[o];
+        if (p_gps) g_ps = p_gps[o];
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
-          if (e < a.E && ((exs[e].pass_bits >> pp) & 1u)) {
-            const auto& ex = exs[e];
+          if ((ed[e].bits >> pp) & 1u) {
             e_on[e] = true;
-            e_c[e] = ex.mask ? ex.mask[tb] : 1.0f;
-            const size_t off = (size_t)pp * ex.pass_stride + tb * WD + n;
-            e_mu[e] = ex.mean[off]; e_sd[e] = ex.std[off];
+            e_c[e] = ed[e].mask ? ed[e].mask[tb] : 1.0f;
+            const size_t off = (size_t)pp * ed[e].stride + tb * WD + n;
+            e_mu[e] = ed[e].mean[off]; e_sd[e] = ed[e].std[off];
           }
         }
         if (trans) {
           const size_t o2 = (((size_t)pp * T + t_prev) * B + pb) * WD + n;
-          zm = a.infer_mean[o2]; zs = a.infer_std[o2];
+          zm = p_im[o2]; zs = p_is[o2];
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (rt == 0) STAMP(18);
+      if (rt == 3) STAMP(22);
       // the pair's particles: noise first (no memory operand), then z = mean + std * eps
       if (trans) {
         float e[16];
@@ -356,6 +394,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
             v0[rt][4 * q + j] = live ? fmaf(e[4 * q + j], zs, zm) : 0.f;
           }
       }
+      if (rt == 0) STAMP(19);
+      if (rt == 3) STAMP(23);
       // the fusion adjoint (dmm.py:387-405 backwards; wide_sweep.h, fuse_bwd)
       float gpm = 0.f, gps = 0.f;
       if (valid) {
@@ -365,14 +405,14 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
 #pragma unroll
         for (int e = 0; e < EB; ++e)
           if (e_on[e]) pq.add(e_mu[e], e_sd[e], e_c[e]);
-        for (int e = EB; e < a.E; ++e) {
+        for (int e = EB; e < n_exp; ++e) {
           const auto& ex = exs[e];
           if (!((ex.pass_bits >> pp) & 1u)) continue;
           const float c = ex.mask ? ex.mask[tb] : 1.0f;
           const size_t off = (size_t)pp * ex.pass_stride + tb * WD + n;
           pq.add(ex.mean[off], ex.std[off], c);
         }
-        if (a.use_inv_prior) pq.add(mu0, -sg0, 1.0f);
+        if (inv_prior) pq.add(mu0, -sg0, 1.0f);
         const float rp = fast::rcp(pq.prec), is = fast::sqrt(rp);
         float g_num, g_prec, gm, gs;
         poe_out_bwd_f(pq.num, rp, is, gi_m, gi_s, g_num, g_prec);
@@ -381,14 +421,13 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
 #pragma unroll
         for (int e = 0; e < EB; ++e)
           if (e_on[e]) {
-            const auto& ex = exs[e];
             poe_expert_bwd_f(e_mu[e], e_sd[e], e_c[e], g_num, g_prec, gm, gs);
             if (h == 0) {
-              if (ex.g_mean) ex.g_mean[o] = gm;       // one slab per pass, (P,T,B,D)
-              if (ex.g_std) ex.g_std[o] = gs;
+              if (ed[e].g_mean) ed[e].g_mean[o] = gm;       // one slab per pass, (P,T,B,D)
+              if (ed[e].g_std) ed[e].g_std[o] = gs;
             }
           }
-        for (int e = EB; e < a.E; ++e) {
+        for (int e = EB; e < n_exp; ++e) {
           const auto& ex = exs[e];
           if (!((ex.pass_bits >> pp) & 1u)) continue;
           const float c = ex.mask ? ex.mask[tb] : 1.0f;
@@ -400,7 +439,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
           }
         }
         if (h == 0) {
-          if (a.use_inv_prior) {
+          if (inv_prior) {
             poe_expert_bwd_f(mu0, -sg0, 1.0f, g_num, g_prec, gm, gs);
             g_mu0 += gm; g_sg0 -= gs;
           }
@@ -414,20 +453,25 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
         *park_at(PK_FA + rt) = ow;
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (rt == 0) STAMP(20);
+      if (rt == 2) STAMP(21);
+      if (rt == 3) STAMP(24);
     }
     STAMP(1);
     if (i == 0) break;
     STAMP(2);
     __syncthreads();                                  // image A: every wave is past D3 of the step before
+    regeo();
     put_arr(v0, i - 1, S_Z, smem + srow);
     __syncthreads();
     STAMP(3);
+    regeo();
     // R2: hidden layers (relu masks to the park)
     {
       u32x4 mk;
+      const float b1g = Bias(B_1G);
       zero_acc(v0);
       gemm4(v0, smem + arow, ts, W(L_W1G), W(L_W1N), ring);
-      const float b1g = Bias(B_1G);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         unsigned mb = 0;
@@ -441,9 +485,9 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       }
       *park_at(PK_MASK) = mk;
       put_arr(v0, i - 1, S_HG, smem + img + srow);
+      const float b1n = Bias(B_1N);
       zero_acc(v0);
       gemm4(v0, smem + arow, ts, W(L_W1N), W(L_W2G), ring);
-      const float b1n = Bias(B_1N);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         unsigned mb = 0;
@@ -461,12 +505,13 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     STAMP(4);
     __syncthreads();
     STAMP(5);
+    regeo();
     // R3: gate pre-activation (v1) -> 1 - gate; non-linear branch (v0)
     f32x16 v1[RT];
+    const float b2g = Bias(B_2G), b2n = Bias(B_2N);
     zero_acc(v1);
     gemm4(v1, smem + img + arow, ts, W(L_W2G), W(L_W2N), ring);
     {
-      const float b2g = Bias(B_2G);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -477,15 +522,13 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     }
     zero_acc(v0);
     gemm4(v0, smem + 2 * img + arow, ts, W(L_W2N), W(L_WL), ring);
-    {
-      const float b2n = Bias(B_2N);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v0[rt][r] += b2n;
-    }
+      for (int r = 0; r < 16; ++r) v0[rt][r] += b2n;
     STAMP(6);
     __syncthreads();                                  // every wave is done with B (hg) and C (hn)
+    regeo();
     // nl -> C and its spill; the gate code -> B (bf16 words in the image layout; the E phase takes both
     // back from there, each lane its own words); v0 = e^x nl + bl  (z_lin lands on top of it)
     put_arr(v0, i - 1, S_NL, smem + 2 * img + srow);
@@ -515,23 +558,34 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     STAMP(7);
     __syncthreads();                                  // nl image complete; A (Z) free
     STAMP(8);
-    // R4: std pre-activation
+    regeo();
+    // R4: std pre-activation ((A)'s per-pair results come back from the park meanwhile)
+    u32x4 fa4[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) fa4[rt] = *park_at(PK_FA + rt);
+    const float bs = Bias(B_S);
     zero_acc(v1);
+#ifdef WIDE_STAMPS
+    STAMP(25);
+    gemm4<true>(v1, smem + 2 * img + arow, ts, W(L_WS), W(T_WS), ring, [&](int k) { STAMP(26 + k); });
+#else
     gemm4(v1, smem + 2 * img + arow, ts, W(L_WS), W(T_WS), ring);
+#endif
     STAMP(9);
     __syncthreads();                                  // every wave is done with C (nl)
     STAMP(10);
+    regeo();
     // E: elementwise adjoint (see wide_bwd_kernel); v1: pre -> direct part of d/d nl, v0 = muq dies.
     // nl and the gate code come back from the images (this lane's own words), and G3 / GG take their
     // places; Glin -> A.
     {
-      const float bs = Bias(B_S);
+      const float min_std = a.min_std;
       const float t0 = fast::rcp(sg0 * sg0 + MDMM_POE_EPS), num0 = mu0 * t0;
       const float dt0 = -2.0f * sg0 * t0 * t0;       // d t0 / d sigma0
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const bool valid = (pv >> rt) & 1u;
-        const u32x4 f = *park_at(PK_FA + rt);
+        const u32x4 f = fa4[rt];
         const float gv2k = __uint_as_float(f.y) * fast::rcp(__uint_as_float(f.w)) * inv_k;   // 2 g_v / K  (dgts.py:79-83)
         const float gpmk = __uint_as_float(f.x) * inv_k, mb = __uint_as_float(f.z);
         char* const pa = smem + srow + rt * ts;
@@ -549,18 +603,22 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
             const int r = 4 * q + k;
             const float pre = v1[rt][r] + bs;
             const float muq = v0[rt][r];
-            const float sq = softplus_w<false>(pre) + a.min_std;
+            // softplus and its derivative from one exponential: y = e^-|pre|
+            const float y = fast::exp(-fabsf(pre));
+            const float r1 = fast::rcp(1.0f + y);
+            const float sq = fmaxf(pre, 0.f) + fast::log(1.0f + y) + min_std;       // common.py:66
+            const float dsp = pre >= 0.f ? r1 : y * r1;                                // sigmoid(pre)
             const float v = fmaf(sq, sq, MDMM_POE_EPS);
             const float u = fast::rcp(fmaf(t0, v, 1.0f));
             const float rp = v * u;                                  // variance of the product
-            const float mraw = fmaf(muq, u, num0 * rp), sd = fast::sqrt(rp);
-            const float m = (mraw != mraw) ? 0.f : mraw;                            // dgts.py:49
-            float g_m = gpmk + gv2k * (m - mb), g_sd = gv2k * sd;
+            const float mraw = fmaf(muq, u, num0 * rp);
             const bool live = valid && (8 * q + k < kh);
-            if (!live || mraw != mraw) g_m = 0.f;                    // (the mean was overwritten by 0)
-            if (!live) g_sd = 0.f;
+            const bool good = live && mraw == mraw;                  // (a NaN mean was overwritten by 0, dgts.py:49)
+            const float m = (mraw != mraw) ? 0.f : mraw;
+            const float g_m = good ? gpmk + gv2k * (m - mb) : 0.f;
+            const float gvl = live ? gv2k : 0.f;                     // g_sd * sd = gv2k * rp: no square root
             const float g_num = g_m * rp;
-            const float g_prec = -(g_m * m + 0.5f * g_sd * sd) * rp;
+            const float g_prec = -fmaf(g_m, m, 0.5f * gvl * rp) * rp;
             const float g_t0 = fmaf(g_num, mu0, g_prec);             // d/d prec of the global prior
             g_mu0 = fmaf(g_num, t0, g_mu0);
             g_sg0 = fmaf(g_t0, dt0, g_sg0);
@@ -569,7 +627,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
             const float g_sq = -fmaf(g_num, muq, g_prec) * tq * tq * 2.0f * sq;
             float gate, omg;
             gate_decode(gtv[k], gate, omg);
-            o_g3[k] = g_sq * fast::softplus_grad(pre);                          // d/d std pre-act
+            o_g3[k] = g_sq * dsp;                                                 // d/d std pre-act
             o_gg[k] = g_muq * gate * (nlv[k] - muq);                            // d/d gate pre-act
             o_gl[k] = g_muq * omg;                                              // d/d z_lin
             v1[rt][r] = g_muq * gate;                                           // direct part of d/d nl
@@ -601,12 +659,14 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     STAMP(11);
     __syncthreads();
     STAMP(12);
+    regeo();
     // D1: d/d nl = direct + W_std^T d/d std-pre (v1); gate-hidden adjoint (v0)
+    const u32x4 mkg = *park_at(PK_MASK);
     gemm4(v1, smem + img + arow, ts, W(T_WS), W(T_W2G), ring);
     zero_acc(v0);
     gemm4(v0, smem + 2 * img + arow, ts, W(T_W2G), W(T_W2N), ring);
     {
-      const u32x4 mk = *park_at(PK_MASK);
+      const u32x4 mk = mkg;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const bool valid = (pv >> rt) & 1u;
@@ -621,17 +681,20 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     }
     STAMP(13);
     __syncthreads();                                  // every wave is done with B (G3) and C (GG)
+    regeo();
     put_arr(v1, i - 1, S_GN, smem + img + srow);       // GN -> B
     put_arr(v0, i - 1, S_GHG, smem + 2 * img + srow);  // GHG -> C
     __syncthreads();
     STAMP(14);
+    regeo();
     // D2: nl-hidden adjoint (v1); d/dz from the gate hidden layer (v0)
+    const u32x4 mkn = *park_at(PK_MASK + 1);
     zero_acc(v1);
     gemm4(v1, smem + img + arow, ts, W(T_W2N), W(T_W1G), ring);
     zero_acc(v0);
     gemm4(v0, smem + 2 * img + arow, ts, W(T_W1G), W(T_W1N), ring);
     {
-      const u32x4 mk = *park_at(PK_MASK + 1);
+      const u32x4 mk = mkn;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const bool valid = (pv >> rt) & 1u;
@@ -643,9 +706,11 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     }
     STAMP(15);
     __syncthreads();                                  // every wave is done with B (GN)
+    regeo();
     put_arr(v1, i - 1, S_GHN, smem + img + srow);      // GHN -> B
     __syncthreads();
     STAMP(16);
+    regeo();
     // D3: d/dz of the previous particles; the noise comes back from the park meanwhile
     u32x4 ep[RT * 4];
 #pragma unroll
