@@ -151,9 +151,19 @@ __global__ void conv1d_fold_kernel(const float* src, int parts, int elems, float
   dst[e] = s;
 }
 
+// dynamic LDS of the three kernels for this layer (bytes)
+size_t lds_down(const mdmm_conv1d_t* a) { return (size_t)(a->CS * a->CB * 3 + a->CB * (2 * a->S - 1 + 2)) * 4; }
+size_t lds_up(const mdmm_conv1d_t* a) { return (size_t)(a->CS * a->CB * 3 + a->CS * (a->S + 1) + a->CB * (2 * a->S - 1)) * 4; }
+size_t lds_wgrad(const mdmm_conv1d_t* a) { return (size_t)(a->CS * a->S + a->CB * (2 * a->S - 1 + 2)) * 4; }
+constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;      // one CU's LDS, a little room for the runtime
+
 bool ok1d(const mdmm_conv1d_t* a) {
-  return a && a->N >= 1 && a->S >= 2 && a->S <= 2048 && a->CS >= 1 && a->CS <= MAXC && a->CB >= 1 && a->CB <= MAXC &&
-         a->CS * a->CB * 3 <= 512;
+  if (!(a && a->N >= 1 && a->S >= 2 && a->S <= 2048 && a->CS >= 1 && a->CS <= MAXC && a->CB >= 1 && a->CB <= MAXC &&
+        a->CS * a->CB * 3 <= 512))
+    return false;
+  // a wider or longer stack than the stock 1281-sample one must be reported unsupported (the caller then
+  // takes the library convolution), not fail in hipFuncSetAttribute
+  return lds_down(a) <= LDS_LIMIT && lds_up(a) <= LDS_LIMIT && lds_wgrad(a) <= LDS_LIMIT;
 }
 int grid1d(const mdmm_conv1d_t* a, int per_cu) { const int g = 256 * per_cu; return a->N < g ? a->N : g; }
 constexpr int WG1_GRID = 512;
@@ -165,8 +175,7 @@ extern "C" int mdmm_conv1d_supported(const mdmm_conv1d_t* a) { return ok1d(a) ? 
 
 extern "C" int mdmm_conv1d_down(const mdmm_conv1d_t* a, void* stream) {
   if (!ok1d(a) || !a->small || !a->big || !a->weight) return MDMM_E_ARG;
-  const int LB = 2 * a->S - 1;
-  const size_t lds = (size_t)(a->CS * a->CB * 3 + a->CB * (LB + 2)) * 4;
+  const size_t lds = lds_down(a);
   if (int e = mdmm_lds_attr_fn((const void*)conv1d_down_kernel, lds)) return e;
   hipLaunchKernelGGL(conv1d_down_kernel, dim3(grid1d(a, lds <= 40 * 1024 ? 4 : 2)), dim3(NT1), lds, (hipStream_t)stream, *a);
   return (int)hipGetLastError();
@@ -174,8 +183,7 @@ extern "C" int mdmm_conv1d_down(const mdmm_conv1d_t* a, void* stream) {
 
 extern "C" int mdmm_conv1d_up(const mdmm_conv1d_t* a, void* stream) {
   if (!ok1d(a) || !a->small || !a->big || !a->weight) return MDMM_E_ARG;
-  const int LB = 2 * a->S - 1;
-  const size_t lds = (size_t)(a->CS * a->CB * 3 + a->CS * (a->S + 1) + a->CB * LB) * 4;
+  const size_t lds = lds_up(a);
   if (int e = mdmm_lds_attr_fn((const void*)conv1d_up_kernel, lds)) return e;
   hipLaunchKernelGGL(conv1d_up_kernel, dim3(grid1d(a, lds <= 40 * 1024 ? 4 : 2)), dim3(NT1), lds, (hipStream_t)stream, *a);
   return (int)hipGetLastError();
@@ -189,8 +197,8 @@ extern "C" int64_t mdmm_conv1d_wgrad_ws_bytes(const mdmm_conv1d_t* a) {
 extern "C" int mdmm_conv1d_wgrad(const mdmm_conv1d_t* a, void* ws, float* dw, void* stream) {
   if (!ok1d(a) || !a->small || !a->big || !ws || !dw) return MDMM_E_ARG;
   if (a->CS * a->CB * 3 > 512) return MDMM_E_LIMIT;
-  const int LB = 2 * a->S - 1, nw = a->CS * a->CB * 3, parts = wg1_parts(a);
-  const size_t lds = (size_t)(a->CS * a->S + a->CB * (LB + 2)) * 4;
+  const int nw = a->CS * a->CB * 3, parts = wg1_parts(a);
+  const size_t lds = lds_wgrad(a);
   if (int e = mdmm_lds_attr_fn((const void*)conv1d_wgrad_kernel, lds)) return e;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(conv1d_wgrad_kernel, dim3(parts), dim3(512), lds, st, *a, (float*)ws);

@@ -41,9 +41,12 @@ class KernelTimer:
 
     def __init__(self):
         self.spans = {}
+        self.nbytes = {}        # tag -> algorithmic HBM bytes of its calls (where the caller states them)
 
-    def add(self, tag, e0, e1):
+    def add(self, tag, e0, e1, nbytes=0):
         self.spans.setdefault(tag, []).append((e0, e1))
+        if nbytes:
+            self.nbytes[tag] = self.nbytes.get(tag, 0) + int(nbytes)
 
     def summary(self):
         """{tag: (launches, total_ms)} -- call after torch.cuda.synchronize()."""
@@ -53,7 +56,8 @@ class KernelTimer:
 TIMER = None    # assign a KernelTimer to switch per-launch timing on
 
 
-def _call(name, *args, tag=None):
+def _call(name, *args, tag=None, nbytes=0):
+    """nbytes: the call's ALGORITHMIC HBM bytes (tensors it has to read / write once), for the timer."""
     fn = getattr(native.lib(), name)
     if TIMER is None:
         native.check(fn(*args, _stream()), name)
@@ -62,7 +66,7 @@ def _call(name, *args, tag=None):
     e0.record()
     native.check(fn(*args, _stream()), name)
     e1.record()
-    TIMER.add(tag or name, e0, e1)
+    TIMER.add(tag or name, e0, e1, nbytes)
 
 
 def _f32c(t):
@@ -426,7 +430,13 @@ class _SweepFn(torch.autograd.Function):
         dev = z0_mean.device
         wide = wide_shape(cfg)
         packed = packed_gtf(gtf_params, cfg.D, cfg.H)
-        frag = packed_frag(gtf_params, cfg.D, cfg.H, PRECISIONS[cfg.precision]) if wide else None
+        prec = PRECISIONS[cfg.precision]
+        if wide and prec == native.PREC_BF16 and not wide_shape(cfg, bwd=True) and any(ctx.needs_input_grad):
+            # more particles than the wide backward takes (K > 64): the backward runs on the generic fp32
+            # kernels, which recompute the forward transition in fp32 -- so the forward must be the fp32
+            # one too, or the gradients would belong to a slightly different forward
+            prec = native.PREC_F32
+        frag = packed_frag(gtf_params, cfg.D, cfg.H, prec) if wide else None
         z0m, z0s = _f32c(z0_mean.detach().reshape(-1)), _f32c(z0_log_std.detach().reshape(-1))
         shape = (cfg.P, cfg.T, cfg.B, cfg.D)
         out = [torch.empty(shape, device=dev, dtype=torch.float32) for _ in range(4)]
@@ -1153,7 +1163,7 @@ class _BnReluFn(torch.autograd.Function):
             a.running_mean, a.running_var = _ptr(bn.running_mean), _ptr(bn.running_var)
             sh = None if shift is None else _f32c(shift.detach())
             a.mean_shift = _ptr(sh)
-        _call('mdmm_bn_relu_fwd', C.byref(a))
+        _call('mdmm_bn_relu_fwd', C.byref(a), nbytes=x.numel() * (2 * x.element_size() + y.element_size()))
         ctx.save_for_backward(x, stats, g, b)
         ctx.meta = (N, Cc, Ln, int(relu), a.splits, bn.eps)
         ctx.shift_like = None if shift is None else shift.detach()
@@ -1180,7 +1190,7 @@ class _BnReluFn(torch.autograd.Function):
         a.x, a.gamma, a.beta, a.dy, a.dx = _ptr(x), _ptr(g), _ptr(b), _ptr(dy), _ptr(dx)
         a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
         a.dgamma, a.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
-        _call('mdmm_bn_relu_bwd', C.byref(a))
+        _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=x.numel() * (2 * x.element_size() + 2 * dy.element_size() + dx.element_size()))
         return (dx, dgb[0] if ctx.needs_input_grad[1] else None,
                 dgb[1] if ctx.needs_input_grad[2] else None, None, None, shift_grad)
 
@@ -1441,6 +1451,8 @@ class _ConvTilesFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
+        if gy is None:                  # (set_materialize_grads(False): an output that reaches no loss term)
+            return None, None, None, None
         gy = _act(gy)
         n, ks = x.shape[0], weight.shape[-1]
         transposed = ctx.transposed
@@ -1974,12 +1986,15 @@ class _VrnnFn(torch.autograd.Function):
 
 
 def vrnn_supported(spec, backward):
+    # the limits first: a.dims is a VRNN_MAX_MODS-element array (a fifth modality must mean "step by step",
+    # not an IndexError while the descriptor is filled)
+    if spec['M'] > native.VRNN_MAX_MODS or spec['L'] > native.VRNN_MAX_LAYERS:
+        return False
     a = native.Vrnn()
     a.T, a.B, a.H, a.Z, a.M, a.L = (spec[k] for k in 'TBHZML')
     for m in range(spec['M']):
         a.dims[m] = spec['dims'][m]
-    return (spec['M'] <= native.VRNN_MAX_MODS and spec['L'] <= native.VRNN_MAX_LAYERS and
-            bool(native.lib().mdmm_vrnn_supported(C.byref(a), int(backward))))
+    return bool(native.lib().mdmm_vrnn_supported(C.byref(a), int(backward)))
 
 
 def vrnn_scan(spec, eps, xs, params):

@@ -609,10 +609,83 @@ def g8_trajectory():
     save_npz(os.path.join(HERE, 'g8_trajectory.npz'), out)
 
 
+# ------------------------------------------------------------------ G9 conv plug-ins --
+G9_SPECS = {
+    # name: (class, kwargs, input shape without the batch)
+    'image_enc': ('ImageEncoder', dict(z_dim=8, n_channels=3), (3, 64, 64)),
+    'image_enc_feat': ('ImageEncoder', dict(z_dim=8, gauss_out=False, n_channels=1), (1, 64, 64)),
+    'image_dec': ('ImageDecoder', dict(z_dim=8, n_channels=3), (8,)),
+    'image_dec_mask': ('ImageDecoder', dict(z_dim=8, n_channels=1), (8,)),
+    'audio_enc': ('AudioEncoder', dict(z_dim=8), (10, 1281)),
+    'audio_enc_feat': ('AudioEncoder', dict(z_dim=8, gauss_out=False), (10, 1281)),
+    'audio_dec': ('AudioDecoder', dict(z_dim=8), (8,)),
+}
+
+
+def g9_plugins():
+    """The reference's conv plug-ins (common.py:70-290: ImageEncoder with and without the Gaussian
+    heads, ImageDecoder, AudioEncoder, AudioDecoder) as VALUES: state_dict, a seeded input, the
+    training-mode outputs (batch statistics), the gradient of a fixed linear functional of them with
+    respect to every parameter and to the input, the BatchNorm running statistics after that forward,
+    and the evaluation-mode outputs computed with them.  While generating, the product's own classes
+    (mdmm/models/common.py, stock torch ops on the CPU) are run on the same numbers and must agree."""
+    from mdmm.models import common as mine
+    C = ref_models.common
+    out = {}
+    N = 3
+    for name, (cls, kw, shape) in G9_SPECS.items():
+        torch.manual_seed(11)
+        ref = getattr(C, cls)(**kw)
+        sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+        g = torch.Generator().manual_seed(5)
+        x = torch.rand(N, *shape, generator=g) if len(shape) > 1 else torch.randn(N, *shape, generator=g)
+        x.requires_grad_()
+
+        def run(mod):
+            mod.train()
+            res = mod(x)
+            res = list(res) if isinstance(res, tuple) else [res]
+            wg = torch.Generator().manual_seed(9)
+            w = [torch.randn(r.shape, generator=wg) for r in res]
+            x.grad = None
+            mod.zero_grad()
+            sum((r * w_).sum() for r, w_ in zip(res, w)).backward()
+            grads = {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p))
+                     for k, p in mod.named_parameters()}
+            gx = x.grad.clone()
+            sd1 = {k: v.clone() for k, v in mod.state_dict().items()}
+            mod.eval()
+            with torch.no_grad():
+                ev = mod(x)
+            ev = list(ev) if isinstance(ev, tuple) else [ev]
+            return [r.detach() for r in res], w, grads, gx, sd1, ev
+
+        res, w, grads, gx, sd1, ev = run(ref)
+        m = getattr(mine, cls)(**kw)
+        m.load_state_dict(sd0)
+        res2, _, grads2, gx2, sd12, ev2 = run(m)
+        for a_, b_ in zip(res2, res):
+            check('g9 %s train output' % name, a_, b_, 1e-5)
+        for a_, b_ in zip(ev2, ev):
+            check('g9 %s eval output' % name, a_, b_, 1e-5)
+        check('g9 %s input grad' % name, gx2, gx, 1e-4)
+        gmax = max(float(v.abs().max()) for v in grads.values())
+        for k in grads:
+            if float(grads[k].abs().max()) > 1e-5 * gmax:
+                check('g9 %s grad %s' % (name, k), grads2[k], grads[k], 1e-4)
+        for k in sd1:
+            if 'running' in k:
+                check('g9 %s %s' % (name, k), sd12[k].float(), sd1[k].float(), 1e-5)
+        out[name] = {'sd': sd0, 'x': x.detach(), 'w': w, 'train': res, 'grads': grads, 'gx': gx,
+                     'running': {k: v for k, v in sd1.items() if 'running' in k}, 'eval': ev}
+        print('  %-16s outputs %s' % (name, [tuple(r.shape) for r in res]))
+    save_npz(os.path.join(HERE, 'g9_plugins.npz'), out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     for fn in (g1_primitives, g2_zfilter, g3_forward, g4_step, g5_dks, g6_vrnn, g7_state_dicts,
-               g8_trajectory):
+               g8_trajectory, g9_plugins):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -292,6 +292,31 @@ def test_vrnn_scan_layout_and_limits():
     assert L.mdmm_vrnn_fwd(ctypes.byref(a), None) < 0           # argument error, nothing launched
 
 
+def test_vrnn_supported_refuses_more_modalities_than_the_descriptor_holds():
+    """ops.vrnn_supported with five modalities: False (-> the model runs step by step), not an IndexError
+    from filling the four-element dims array of the descriptor."""
+    from mdmm import native, ops
+    spec = dict(T=6, B=4, H=16, Z=16, M=native.VRNN_MAX_MODS + 1, L=1, dims=[2] * (native.VRNN_MAX_MODS + 1))
+    assert ops.vrnn_supported(spec, backward=False) is False
+    spec = dict(T=6, B=4, H=16, Z=16, M=2, L=native.VRNN_MAX_LAYERS + 1, dims=[2, 3])
+    assert ops.vrnn_supported(spec, backward=True) is False
+
+
+def test_conv1d_supported_checks_the_lds_budget():
+    """mdmm_conv1d_supported: the stock audio pyramids fit one CU's LDS; a 16-channel, 2048-sample layer
+    (262 KB for the down kernel) is reported unsupported so that the caller takes the library convolution."""
+    from mdmm import native
+    L = native.lib()
+    a = native.Conv1d()
+    a.N, a.S, a.CS, a.CB = 8, 641, 4, 10            # first encoder layer of AudioEncoder (10 x 1281 -> 4 x 641)
+    assert L.mdmm_conv1d_supported(ctypes.byref(a)) == 1
+    a.S, a.CS, a.CB = 161, 16, 8                    # last encoder layer
+    assert L.mdmm_conv1d_supported(ctypes.byref(a)) == 1
+    a.S, a.CS, a.CB = 2048, 8, 16
+    assert L.mdmm_conv1d_supported(ctypes.byref(a)) == 0
+    assert L.mdmm_conv1d_wgrad_ws_bytes(ctypes.byref(a)) == 0
+
+
 def test_vrnn_block_padding_round_trip():
     """Weights of the VRNN scan are zero-padded per concatenated part (GRU gates x input blocks)."""
     from mdmm import ops

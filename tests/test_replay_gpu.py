@@ -1,0 +1,201 @@
+"""The execution mode bench.py times, at its shape (-m gpu): the ELBO step of the Weizmann-shaped
+configurations (BASELINE cfg3: MultiDMM, cfg4: MultiDKS; z = h = 256, the stock conv pyramids on
+64 x 64 frames, action Categorical(10), T = 40, 25 particles, every bf16 switch on) captured into HIP
+graphs by mdmm.harness.GraphedElboStep -- with the allocator dirtied first -- and replayed, against
+
+  (1) the same step run eagerly on the same weights and the same Philox stream (loss and every
+      gradient: replay adds no arithmetic, so the bound is reduction-order noise), and
+  (2) the CPU oracle with the very noise the kernels drew replayed into it, at the bf16-operand
+      tolerances of tests/test_hip_parity.py.
+
+(Three bugs of this project were green eagerly and wrong under replay: a pack built on a forked
+stream, a per-type "LDS attribute set" flag, a BatchNorm fusion that gave NaNs.)  The batch is small
+so that the oracle finishes; trainer.py:237-252 is what the step restates."""
+import pytest
+import torch
+
+import helpers  # noqa: F401
+import bench
+from oracle import mdmm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOSS_BF16, TOL_GRAD_BF16 = 5e-3, 1e-1        # as tests/test_hip_parity.py (operand rounding only)
+TOL_REPLAY_LOSS, TOL_REPLAY_GRAD = 1e-6, 1e-5    # replay vs eager: same kernels, same inputs
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _ragged_batch(cfg, lengths, dev):
+    inputs, targets, mask, _ = cfg.batch(cfg.T, len(lengths), 77, 'cpu')
+    for d in (inputs, targets):
+        for k in d:
+            for b, n in enumerate(lengths):
+                d[k][n:, b] = float('nan')
+    mask = orc.len_to_mask(lengths)
+    to = lambda d: {k: v.to(dev) for k, v in d.items()}      # noqa: E731
+    return inputs, targets, mask, to(inputs), to(targets), mask.to(dev)
+
+
+def _grads(model):
+    return {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize('name', ['cfg3', 'cfg4'])
+def test_graph_replay_matches_eager_and_oracle(name, dev):
+    from mdmm import models, ops
+    from mdmm.harness import GradBucket, GraphedElboStep
+    from mdmm.noise import PhiloxNoise
+    cfg = bench.CONFIGS[name]
+    lengths = [40, 40, 40, 31, 17, 6]
+    K, warm = bench.TRAIN_PARTICLES, 1
+    n_points = sum(lengths)
+    x_cpu, tg_cpu, mask_cpu, x, tg, mask = _ragged_batch(cfg, lengths, dev)
+    # recycled allocator blocks full of garbage: an unwritten output or a missing cross-stream
+    # dependency in the captured step then shows up as a difference
+    junk = [torch.randn(1 << 24, device=dev) * 1e3 for _ in range(8)]
+    del junk
+    torch.manual_seed(0)
+    model = cfg.model(models, dev)
+    model.noise = noise = PhiloxNoise(seed=4321)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, capturable=True, fused=True)
+    bucket = GradBucket(model.parameters())
+    kw = dict(targets=tg, train_particles=K) if name == 'cfg3' else dict(targets=tg)
+    c_before = noise.counter
+    step = GraphedElboStep(model, opt, bucket, x, mask, lengths, 1.0, cfg.rec, n_points_global=n_points,
+                           warmup=warm, **kw)
+    per_step = (noise.counter - c_before) // (warm + 1)        # stream ids one step takes
+    c_capture = noise.counter - per_step                       # host counter the captured launches start from
+    assert per_step > 0 and c_before + (warm + 1) * per_step == noise.counter
+    d0 = noise.device_counter(dev).clone()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    # ---- replay (the step graph only: the optimizer graph would move the weights)
+    step.g_step.replay()
+    torch.cuda.synchronize()
+    loss_r = float(step.loss)
+    g_r = _grads(model)
+    assert torch.isfinite(bucket.flat).all()
+
+    # ---- the same step eagerly: same weights, same stream ids, same device counter
+    noise.counter = c_capture
+    noise.device_counter(dev).copy_(d0)
+    bucket.release()
+    loss = model.step(x, mask, 1.0, cfg.rec, lengths=lengths, **kw)
+    (loss / n_points).backward()
+    torch.cuda.synchronize()
+    loss_e, g_e = float(loss), _grads(model)
+    assert abs(loss_r - loss_e) <= TOL_REPLAY_LOSS * abs(loss_e), (loss_r, loss_e)
+    gmax = max(float(v.abs().max()) for v in g_e.values() if v is not None)
+    for k, ge in g_e.items():
+        gr = g_r[k]
+        assert (ge is None) == (gr is None), k
+        if ge is None or float(ge.abs().max()) < 1e-6 * gmax:
+            continue
+        e = float((gr - ge).norm() / (ge.norm() + 1e-30))
+        assert e < TOL_REPLAY_GRAD, 'replay vs eager grad %s: %.3e' % (k, e)
+
+    # ---- the oracle, with the draws of that step replayed
+    o = cfg.oracle(orc) if name == 'cfg3' else _oracle_dks(cfg)
+    o.load_state_dict(sd)
+    o.train()
+    probe = PhiloxNoise(seed=4321)
+    probe.counter = c_capture
+    probe.device_counter(dev).copy_(d0)
+    D, T, B = cfg.D, cfg.T, len(lengths)
+    P = 1 + cfg.M
+    if name == 'cfg3':
+        draws = [probe.normal((50, 1, D), dev).cpu(), probe.normal((50, 1, D), dev).cpu()]
+        sweeps = []
+        for k in (1, K, 1):
+            s_, off = probe.stream()
+            sweeps.append(ops.philox_normal(s_, off, (P, T, k, B, D), dev, probe.device_counter(dev)).cpu())
+        for p in range(P):
+            draws += [sweeps[0][p, t] for t in reversed(range(T))]
+        for p in range(P):
+            draws += [sweeps[1][p, t] for t in reversed(range(T))]
+            draws += [sweeps[2][p, t] for t in range(T)]
+    else:
+        s_, off = probe.stream()                 # the fused step scans all 1 + M passes in one launch
+        eps = ops.philox_normal(s_, off, (T, P, B, D), dev, probe.device_counter(dev)).cpu()
+        draws = [eps[t, p] for p in range(P) for t in range(T)]
+    o.noise = orc.ReplayNoise(draws)
+    okw = dict(targets=tg_cpu, train_particles=K) if name == 'cfg3' else dict(targets=tg_cpu)
+    oloss = o.step(x_cpu, mask_cpu, 1.0, cfg.rec, lengths=lengths, **okw)
+    (oloss / n_points).backward()
+    assert o.noise.exhausted
+    rel = abs(loss_r - float(oloss)) / abs(float(oloss))
+    assert rel < TOL_LOSS_BF16, 'replayed %s loss vs oracle: %.3e' % (name, rel)
+    og = dict(o.named_parameters())
+    omax = max(float(v.grad.abs().max()) for v in og.values() if v.grad is not None)
+    for k, gr in g_r.items():
+        ref = og[k].grad if og[k].grad is not None else torch.zeros_like(og[k])
+        if float(ref.abs().max()) < 1e-4 * omax:      # conv biases in front of a BatchNorm: exactly zero
+            continue
+        e = float((gr.cpu() - ref).norm() / (ref.norm() + 1e-30))
+        assert e < TOL_GRAD_BF16, 'replayed %s grad %s vs oracle: %.3e' % (name, k, e)
+
+
+def _oracle_dks(cfg):
+    from mdmm.models import common as C       # the plug-in conv stacks are plain torch modules
+    enc = {'video': C.ImageEncoder(256, gauss_out=False, n_channels=3),
+           'mask': C.ImageEncoder(256, gauss_out=False, n_channels=1)}
+    dec = {'video': C.ImageDecoder(256, n_channels=3), 'mask': C.ImageDecoder(256, n_channels=1)}
+    return orc.OracleDKS(cfg.mods, cfg.dims, cfg.dists, encoders=enc, decoders=dec, h_dim=256, z_dim=256,
+                         feat_to_z=True, rnn_dir='bwd', rnn_skip=True)
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_step_cfg5_plugins_matches_oracle(mode, dev):
+    """BASELINE cfg5 end to end with its real plug-ins (vidTIMIT.py:50-69; common.py:114-175, 221-290):
+    ImageEncoder / ImageDecoder on 64 x 64 frames + AudioEncoder / AudioDecoder on 10 x 1281 spectrogram
+    slices, T = 128, ragged lengths 64..128, every (t, b, modality) missing independently with p = 0.5,
+    z = h = 256, 25 particles, against the oracle with the kernels' noise replayed.  fp32: every switch off
+    (fp32 tolerances of the suite); bf16: the switches bench.py times with (operand-rounding tolerances)."""
+    from mdmm import models, ops
+    from mdmm.noise import PhiloxNoise
+    cfg = bench.CONFIGS['cfg5']
+    lengths = [128, 97, 64]
+    K, T, B, D = bench.TRAIN_PARTICLES, cfg.T, len(lengths), cfg.D
+    x, tg, mask, _ = cfg.batch(T, B, 31, 'cpu', lengths=lengths)
+    to = lambda d: {k: v.to(dev) for k, v in d.items()}      # noqa: E731
+    torch.manual_seed(3)
+    m = cfg.model(models, dev)
+    if mode == 'fp32':
+        m.sweep_dtype = m.conv_dtype = m.act_dtype = torch.float32
+    o = cfg.oracle(orc)
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    n_points = sum(lengths)
+    m.noise = PhiloxNoise(seed=55)
+    kw = dict(train_particles=K, match_particles=50)
+    loss = m.step(to(x), mask.to(dev), 1.0, cfg.rec, targets=to(tg), lengths=lengths, **kw)
+    (loss / n_points).backward()
+    noise = PhiloxNoise(seed=55)
+    draws = [noise.normal((50, 1, D), dev).cpu(), noise.normal((50, 1, D), dev).cpu()]
+    P, sweeps = 1 + cfg.M, []
+    for k in (1, K, 1):
+        s_, off = noise.stream()
+        sweeps.append(ops.philox_normal(s_, off, (P, T, k, B, D), dev).cpu())
+    for p in range(P):
+        draws += [sweeps[0][p, t] for t in reversed(range(T))]
+    for p in range(P):
+        draws += [sweeps[1][p, t] for t in reversed(range(T))]
+        draws += [sweeps[2][p, t] for t in range(T)]
+    o.noise = orc.ReplayNoise(draws)
+    oloss = o.step(x, mask, 1.0, cfg.rec, targets=tg, lengths=lengths, **kw)
+    (oloss / n_points).backward()
+    bf16 = mode == 'bf16'
+    rel = abs(float(loss) - float(oloss)) / abs(float(oloss))
+    assert rel < (TOL_LOSS_BF16 if bf16 else 1e-5), 'cfg5 %s loss vs oracle: %.3e' % (mode, rel)
+    og = dict(o.named_parameters())
+    omax = max(float(v.grad.abs().max()) for v in og.values() if v.grad is not None)
+    for k, p in m.named_parameters():
+        ref = og[k].grad if og[k].grad is not None else torch.zeros_like(og[k])
+        if float(ref.abs().max()) < 1e-4 * omax:      # conv biases in front of a BatchNorm: exactly zero
+            continue
+        e = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30))
+        assert e < (TOL_GRAD_BF16 if bf16 else 2e-3), 'cfg5 %s grad %s vs oracle: %.3e' % (mode, k, e)
