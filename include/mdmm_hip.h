@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 18
+#define MDMM_ABI_VERSION 19
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -464,7 +464,20 @@ typedef struct mdmm_bn {
   /* optional (C): added to the batch mean in the running_mean update only -- the bias of the
    * convolution in front when the caller leaves it out of x (BatchNorm(x + b) == BatchNorm(x)) */
   const float* mean_shift;
+  /* Statistics over the batch of ALL data-parallel ranks (BatchNorm is the one cross-sequence
+   * coupling inside the plug-ins).  phase = MDMM_BN_STATS runs the reduction pass only and leaves this rank's
+   * partial sums in `partial` ([C][splits][2] doubles: (sum x, sum x^2) forward, (sum g, sum g xhat) backward);
+   * the caller folds them per channel, all-reduces the C x 2 sums and the element count over the ranks and
+   * calls again with phase = MDMM_BN_APPLY, global_sums (C x 2 doubles) and global_count set: the apply
+   * pass then normalises with the global mean / variance (forward; running statistics from them too) or
+   * forms dx with the global means of g and g xhat (backward; dgamma / dbeta stay this rank's own sums,
+   * the gradient all-reduce adds them up).  phase = 0 and global_sums = NULL: one rank, both passes.  */
+  int32_t phase, reserved;
+  const double* global_sums;
+  double global_count;
 } mdmm_bn_t;
+#define MDMM_BN_STATS 1
+#define MDMM_BN_APPLY 2
 int mdmm_bn_splits(int64_t N, int C, int64_t L);
 int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream);
 int mdmm_bn_relu_bwd(const mdmm_bn_t* a, void* stream);

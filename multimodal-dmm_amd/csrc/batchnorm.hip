@@ -139,14 +139,19 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
                                                       float momentum, float* running_mean,
                                                       float* running_var, const float* mean_shift,
                                                       T* __restrict__ y,
-                                                      float* save_mean, float* save_invstd) {
+                                                      float* save_mean, float* save_invstd,
+                                                      const double* __restrict__ gsum, double gcount) {
   const int c = blockIdx.x;
   double d1 = 0, d2 = 0;
-  for (int s = 0; s < (int)gridDim.y; ++s) {
-    d1 += partial[((size_t)c * gridDim.y + s) * 2];
-    d2 += partial[((size_t)c * gridDim.y + s) * 2 + 1];
+  if (gsum) {                                    // statistics of the GLOBAL batch (all ranks), see mdmm_bn_t
+    d1 = gsum[2 * c]; d2 = gsum[2 * c + 1];
+  } else {
+    for (int s = 0; s < (int)gridDim.y; ++s) {
+      d1 += partial[((size_t)c * gridDim.y + s) * 2];
+      d2 += partial[((size_t)c * gridDim.y + s) * 2 + 1];
+    }
   }
-  const double M = (double)N * (double)L;
+  const double M = gsum ? gcount : (double)N * (double)L;
   const double mean = d1 / M;
   double var = d2 / M - mean * mean;            // biased (normalisation)
   if (var < 0) var = 0;
@@ -264,18 +269,20 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
                                                           const float* __restrict__ save_invstd, int relu,
                                                           const double* __restrict__ partial,
                                                           T* __restrict__ dx, float* dgamma,
-                                                          float* dbeta) {
+                                                          float* dbeta, const double* __restrict__ gsum,
+                                                          double gcount) {
   const int c = blockIdx.x;
   double d1 = 0, d2 = 0;
   for (int s = 0; s < (int)gridDim.y; ++s) {
     d1 += partial[((size_t)c * gridDim.y + s) * 2];
     d2 += partial[((size_t)c * gridDim.y + s) * 2 + 1];
   }
-  if (blockIdx.y == 0 && threadIdx.x == 0) {
+  if (blockIdx.y == 0 && threadIdx.x == 0) {     // this rank's part of the parameter gradients
     if (dgamma) dgamma[c] = (float)d2;
     if (dbeta) dbeta[c] = (float)d1;
   }
-  const double M = (double)N * (double)L;
+  if (gsum) { d1 = gsum[2 * c]; d2 = gsum[2 * c + 1]; }      // means over the GLOBAL batch
+  const double M = gsum ? gcount : (double)N * (double)L;
   const float mg = (float)(d1 / M), mgx = (float)(d2 / M);
   const float mean = save_mean[c], invstd = save_invstd[c];
   const float g_ = gamma ? gamma[c] : 1.0f, b_ = beta ? beta[c] : 0.0f;
@@ -322,6 +329,8 @@ int check(const mdmm_bn_t* a) {
   if (!a || a->N < 1 || a->C < 1 || a->L < 1 || !a->x || !a->partial || !a->save_mean || !a->save_invstd)
     return MDMM_E_ARG;
   if (a->splits < 1 || a->splits > 65535) return MDMM_E_ARG;
+  if (a->phase < 0 || a->phase > MDMM_BN_APPLY) return MDMM_E_ARG;
+  if (a->global_sums && !(a->global_count >= 1.0)) return MDMM_E_ARG;
   return 0;
 }
 
@@ -341,19 +350,23 @@ namespace {
 template <bool VEC, typename T>
 void launch_fwd(const mdmm_bn_t* a, hipStream_t st) {
   const dim3 grid(a->C, a->splits);
-  hipLaunchKernelGGL((bn_stats_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->x, a->N, a->C, a->L, a->partial);
-  hipLaunchKernelGGL((bn_apply_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->x, a->N, a->C, a->L, a->partial,
-                     a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
-                     a->mean_shift, (T*)a->y, a->save_mean, a->save_invstd);
+  if (a->phase != MDMM_BN_APPLY)
+    hipLaunchKernelGGL((bn_stats_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->x, a->N, a->C, a->L, a->partial);
+  if (a->phase != MDMM_BN_STATS)
+    hipLaunchKernelGGL((bn_apply_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->x, a->N, a->C, a->L, a->partial,
+                       a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
+                       a->mean_shift, (T*)a->y, a->save_mean, a->save_invstd, a->global_sums, a->global_count);
 }
 template <bool VEC, typename T>
 void launch_bwd(const mdmm_bn_t* a, hipStream_t st) {
   const dim3 grid(a->C, a->splits);
-  hipLaunchKernelGGL((bn_bwd_stats_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->dy, (const T*)a->x, a->N, a->C,
-                     a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial);
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->dy, (const T*)a->x, a->N, a->C,
-                     a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial, (T*)a->dx,
-                     a->dgamma, a->dbeta);
+  if (a->phase != MDMM_BN_APPLY)
+    hipLaunchKernelGGL((bn_bwd_stats_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->dy, (const T*)a->x, a->N, a->C,
+                       a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial);
+  if (a->phase != MDMM_BN_STATS)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->dy, (const T*)a->x, a->N, a->C,
+                       a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial, (T*)a->dx,
+                       a->dgamma, a->dbeta, a->global_sums, a->global_count);
 }
 
 }  // namespace
@@ -361,7 +374,7 @@ void launch_bwd(const mdmm_bn_t* a, hipStream_t st) {
 extern "C" int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream) {
   int rc = check(a);
   if (rc) return rc;
-  if (!a->y) return MDMM_E_ARG;
+  if (!a->y && a->phase != MDMM_BN_STATS) return MDMM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (a->bf16_io) { if (vec_ok(a)) launch_fwd<true, __bf16>(a, st); else launch_fwd<false, __bf16>(a, st); }
   else { if (vec_ok(a)) launch_fwd<true, float>(a, st); else launch_fwd<false, float>(a, st); }
@@ -371,7 +384,7 @@ extern "C" int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream) {
 extern "C" int mdmm_bn_relu_bwd(const mdmm_bn_t* a, void* stream) {
   int rc = check(a);
   if (rc) return rc;
-  if (!a->dy || !a->dx) return MDMM_E_ARG;
+  if (!a->dy || (!a->dx && a->phase != MDMM_BN_STATS)) return MDMM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (a->bf16_io) { if (vec_ok(a)) launch_bwd<true, __bf16>(a, st); else launch_bwd<false, __bf16>(a, st); }
   else { if (vec_ok(a)) launch_bwd<true, float>(a, st); else launch_bwd<false, float>(a, st); }

@@ -126,6 +126,8 @@ class _ConvBlock(nn.Module):
             # evaluation mode (running statistics) and CPU: the stock modules, in the weights' precision
             if x.dtype != layer.weight.dtype:
                 x = x.to(layer.weight.dtype)
+            if bn.training and ops.bn_sync_group() is not None:      # statistics of every rank's batch (ops.bn_sync)
+                return ops.sync_batchnorm_relu_torch(layer(x), bn)
             return self.net[2](bn(layer(x)))
         from .. import ops
         if ops.conv_tiles_supported(self.net, x):

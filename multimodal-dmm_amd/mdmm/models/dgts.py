@@ -31,6 +31,11 @@ class MultiDGTS(nn.Module):
     # or bfloat16 (what autocast would store; halves the HBM traffic that bounds the conv / BatchNorm /
     # BCE chain).  Frames, latents, weights, statistics and every reduction stay fp32.
     act_dtype = torch.float32
+    # Data parallel (mdmm.harness): None = BatchNorm layers of the plug-ins normalise with their
+    # own rank's batch statistics (what DistributedDataParallel does without SyncBatchNorm); True or a
+    # torch.distributed process group = with the statistics of the global batch, one small all-reduce per
+    # layer and direction (ops.bn_sync) -- the N-rank ELBO then equals the single-process one.
+    bn_sync = None
 
     def _fresh_packs(self):
         """Drop the operand packs cached on the parameters (transition weights in kernel layout, MFMA
@@ -41,6 +46,9 @@ class MultiDGTS(nn.Module):
         ops.clear_caches(self.parameters())
 
     def _plug(self, module, x, **kw):
+        if self.bn_sync is not None and ops.BN_SYNC is None:
+            with ops.bn_sync(self.bn_sync):
+                return self._plug(module, x, **kw)
         if self.plugin_dtype is None and self.conv_dtype is torch.bfloat16 and x.is_cuda:
             with ops.conv_operands(torch.bfloat16, act=self.act_dtype):
                 out = module(x, **kw)

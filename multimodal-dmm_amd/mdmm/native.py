@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 18
+ABI_VERSION = 19
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -121,7 +121,11 @@ class Bn(C.Structure):
                 [(n, C.c_int32) for n in ('C', 'relu', 'splits', 'bf16_io')] +
                 [('eps', C.c_float), ('momentum', C.c_float)] +
                 [(n, _P) for n in ('x', 'gamma', 'beta', 'running_mean', 'running_var', 'y', 'save_mean',
-                                   'save_invstd', 'dy', 'dx', 'dgamma', 'dbeta', 'partial', 'mean_shift')])
+                                   'save_invstd', 'dy', 'dx', 'dgamma', 'dbeta', 'partial', 'mean_shift')] +
+                [('phase', C.c_int32), ('reserved', C.c_int32), ('global_sums', _P), ('global_count', C.c_double)])
+
+
+BN_STATS, BN_APPLY = 1, 2
 
 
 class Conv(C.Structure):

@@ -1176,7 +1176,19 @@ class _BnReluFn(torch.autograd.Function):
             a.running_mean, a.running_var = _ptr(bn.running_mean), _ptr(bn.running_var)
             sh = None if shift is None else _f32c(shift.detach())
             a.mean_shift = _ptr(sh)
-        _call('mdmm_bn_relu_fwd', C.byref(a), nbytes=x.numel() * (2 * x.element_size() + y.element_size()))
+        group = bn_sync_group()
+        nb = x.numel() * (2 * x.element_size() + y.element_size())
+        gcount = 0.0
+        if group is None:
+            _call('mdmm_bn_relu_fwd', C.byref(a), nbytes=nb)
+        else:
+            # statistics over the batch of every rank: reduction pass, one small all-reduce, apply pass
+            a.phase = native.BN_STATS
+            _call('mdmm_bn_relu_fwd', C.byref(a), nbytes=nb)
+            sums, gcount = _bn_allreduce(part, Cc, a.splits, float(N) * float(Ln), group)
+            a.phase, a.global_sums, a.global_count = native.BN_APPLY, _ptr(sums), gcount
+            _call('mdmm_bn_relu_fwd', C.byref(a))
+        ctx.sync = (group, gcount)
         ctx.save_for_backward(x, stats, g, b)
         ctx.meta = (N, Cc, Ln, int(relu), a.splits, bn.eps)
         ctx.shift_like = None if shift is None else shift.detach()
@@ -1203,9 +1215,121 @@ class _BnReluFn(torch.autograd.Function):
         a.x, a.gamma, a.beta, a.dy, a.dx = _ptr(x), _ptr(g), _ptr(b), _ptr(dy), _ptr(dx)
         a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
         a.dgamma, a.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
-        _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=x.numel() * (2 * x.element_size() + 2 * dy.element_size() + dx.element_size()))
+        nb = x.numel() * (2 * x.element_size() + 2 * dy.element_size() + dx.element_size())
+        group, gcount = ctx.sync
+        if group is None:
+            _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=nb)
+        else:
+            a.phase = native.BN_STATS
+            _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=nb)
+            sums, _ = _bn_allreduce(part, Cc, splits, None, group)
+            a.phase, a.global_sums, a.global_count = native.BN_APPLY, _ptr(sums), gcount
+            _call('mdmm_bn_relu_bwd', C.byref(a))
         return (dx, dgb[0] if ctx.needs_input_grad[1] else None,
                 dgb[1] if ctx.needs_input_grad[2] else None, None, None, shift_grad)
+
+
+# BatchNorm statistics over the batch of ALL data-parallel ranks (the one cross-sequence coupling
+# inside the plug-ins; without it an N-rank ELBO differs from the 1-rank ELBO by ~3e-4 on a conv model).
+BN_SYNC = None          # a torch.distributed process group (or True = the default group) while bn_sync() is active
+
+
+class bn_sync:
+    """Context: training-mode BatchNorm layers of models.common use the statistics of the global batch -- one
+    all-reduce of C x 2 sums (+ the element count) per layer and direction, between the kernels' reduction
+    and apply passes.  No-op while torch.distributed is not initialised or the group has one rank."""
+
+    def __init__(self, group=True):
+        self.group = group
+
+    def __enter__(self):
+        global BN_SYNC
+        self.prev, BN_SYNC = BN_SYNC, self.group
+
+    def __exit__(self, *exc):
+        global BN_SYNC
+        BN_SYNC = self.prev
+
+
+def bn_sync_group():
+    """The process group to synchronise BatchNorm statistics over, or None (single rank / switched off)."""
+    import torch.distributed as dist
+    if BN_SYNC is None or BN_SYNC is False or not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = None if BN_SYNC is True else BN_SYNC
+    if dist.get_world_size(group) < 2:
+        return None
+    return dist.group.WORLD if group is None else group
+
+
+def _bn_allreduce(part, channels, splits, count, group):
+    """Fold this rank's [C][splits][2] partial sums per channel, all-reduce them (and the element count,
+    when given) over the group: (C x 2 fp64 sums, global count)."""
+    import torch.distributed as dist
+    sums = part.view(channels, splits, 2).sum(1)         # (splits <= a few hundred: a single-block torch reduction)
+    if count is None:
+        dist.all_reduce(sums, group=group)
+        return sums.contiguous(), None
+    packed = torch.cat([sums.reshape(-1), sums.new_tensor([count])])
+    dist.all_reduce(packed, group=group)
+    return packed[:-1].reshape(channels, 2).contiguous(), float(packed[-1])
+
+
+class _SyncBnReluTorch(torch.autograd.Function):
+    """The same synchronised BatchNorm (+ ReLU) in plain torch ops, for modules that do not run on the own
+    kernels (CPU / gloo in the data-parallel tests, shapes or dtypes the kernels do not take)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, relu, group):
+        import torch.distributed as dist
+        dims = [0] + list(range(2, x.dim()))
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        xd = x.double()
+        packed = torch.cat([xd.sum(dims), (xd * xd).sum(dims), xd.new_tensor([x.numel() / x.shape[1]])])
+        dist.all_reduce(packed, group=group)
+        cc = x.shape[1]
+        cnt = float(packed[-1])
+        mean = packed[:cc] / cnt
+        var = (packed[cc:2 * cc] / cnt - mean * mean).clamp_min(0)
+        invstd = torch.rsqrt(var + bn.eps)
+        xhat = ((xd - mean.view(shape)) * invstd.view(shape)).to(x.dtype)
+        y = xhat
+        if gamma is not None:
+            y = y * gamma.view(shape) + beta.view(shape)
+        if relu:
+            y = y.clamp_min(0)
+        if bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():
+                bn.num_batches_tracked.add_(1)
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                unb = var * cnt / (cnt - 1) if cnt > 1 else var
+                bn.running_mean.mul_(1 - m).add_(m * mean.to(bn.running_mean.dtype))
+                bn.running_var.mul_(1 - m).add_(m * unb.to(bn.running_var.dtype))
+        ctx.save_for_backward(xhat, invstd.to(x.dtype), gamma, y if relu else None)
+        ctx.meta = (dims, shape, cnt, group)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        xhat, invstd, gamma, y = ctx.saved_tensors
+        dims, shape, cnt, group = ctx.meta
+        g = dy if y is None else dy * (y > 0).to(dy.dtype)
+        sg, sgx = g.double().sum(dims), (g * xhat).double().sum(dims)
+        d_gamma = sgx.to(dy.dtype) if gamma is not None else None      # this rank's part; the gradient all-reduce adds them
+        d_beta = sg.to(dy.dtype) if gamma is not None else None
+        packed = torch.cat([sg, sgx])
+        dist.all_reduce(packed, group=group)
+        cc = xhat.shape[1]
+        mg, mgx = (packed[:cc] / cnt).to(dy.dtype), (packed[cc:] / cnt).to(dy.dtype)
+        k = invstd if gamma is None else gamma * invstd
+        dx = k.view(shape) * (g - mg.view(shape) - xhat * mgx.view(shape))
+        return dx, d_gamma, d_beta, None, None, None
+
+
+def sync_batchnorm_relu_torch(x, bn, relu=True):
+    """nn.Sequential(bn, nn.ReLU())(x) in training mode with the statistics of the global batch (plain torch)."""
+    return _SyncBnReluTorch.apply(x, bn.weight, bn.bias, bn, relu, bn_sync_group())
 
 
 def batchnorm_relu_supported(x, bn):

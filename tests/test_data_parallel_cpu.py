@@ -189,3 +189,72 @@ def test_two_rank_conv_batchnorm_is_per_rank_and_elbo_drift_is_bounded(tmp_path)
     drift = abs(float(r[0]['loss'] + r[1]['loss']) - float(loss)) / abs(float(loss))
     print('ELBO drift with per-rank BatchNorm statistics: %.3e' % drift)
     assert drift < 1e-2
+
+
+# ---- the same with BatchNorm statistics synchronised over the ranks (MultiDGTS.bn_sync / ops.bn_sync) -------
+def _conv_sync_worker(rank, world, port, out_dir):
+    from mdmm import harness, ops
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = _conv_model()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    bucket = harness.GradBucket(model.parameters())
+    inputs, targets, mask = _conv_data()
+    xs, ms, ls = harness.shard_batch(inputs, mask, CONV_LENGTHS, rank, world)
+    ts, _, _ = harness.shard_batch(targets, mask, CONV_LENGTHS, rank, world)
+    per = (len(CONV_LENGTHS) + world - 1) // world
+    model.noise = ShardedNoise(rank * per, rank * per + len(ls), len(CONV_LENGTHS))
+    grads = {}
+    orig_step = opt.step
+
+    def spy_step(*a, **k):
+        grads['flat'] = bucket.flat.clone()
+        return orig_step(*a, **k)
+
+    opt.step = spy_step
+    with ops.bn_sync(True):         # (the product models enter it themselves when MultiDGTS.bn_sync is set)
+        loss = harness.elbo_step(model, opt, bucket, xs, ms, ls, 0.7, {'video': 1.0, 'b': 1.0}, targets=ts,
+                                 n_points_global=sum(CONV_LENGTHS), **KW)
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    torch.save({'loss': loss, 'grad': grads['flat'],
+                'weights': torch.cat([p.detach().reshape(-1) for p in model.parameters()]),
+                'running': torch.cat([torch.cat([b.running_mean, b.running_var]) for b in bns])},
+               os.path.join(out_dir, 'sync_rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_synced_batchnorm_equals_single_process(tmp_path):
+    """With the statistics all-reduced between the reduction and the apply pass of every BatchNorm layer,
+    the two-rank step IS the single-process step on the whole batch: ELBO, all-reduced gradient, weights
+    after Adam and the running statistics (BatchNorm was the one caveat of the sharding)."""
+    from mdmm import harness
+    world = 2
+    mp.spawn(_conv_sync_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), 'sync_rank%d.pt' % i)) for i in range(world)]
+    model = _conv_model()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    bucket = harness.GradBucket(model.parameters())
+    inputs, targets, mask = _conv_data()
+    model.noise = ShardedNoise(0, len(CONV_LENGTHS), len(CONV_LENGTHS))
+    loss = model.step(inputs, mask, 0.7, {'video': 1.0, 'b': 1.0}, targets=targets, lengths=CONV_LENGTHS, **KW)
+    (loss / sum(CONV_LENGTHS)).backward()
+    full_grad = bucket.flat.clone()
+    opt.step()
+    full_w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    running = torch.cat([torch.cat([b.running_mean, b.running_var]) for b in bns])
+    drift = abs(float(r[0]['loss'] + r[1]['loss']) - float(loss)) / abs(float(loss))
+    print('ELBO drift with synchronised BatchNorm statistics: %.3e' % drift)
+    assert drift < 1e-5
+    assert torch.equal(r[0]['grad'], r[1]['grad'])
+    assert helpers.rel_err(r[0]['grad'], full_grad) < 1e-4
+    assert torch.equal(r[0]['weights'], r[1]['weights'])
+    # (Adam moves a weight by lr * sign(g) however small g is: conv biases in front of a BatchNorm have an
+    # exactly zero gradient up to rounding noise, whose sign is not comparable -- leave those entries out)
+    live = full_grad.abs() > 1e-6 * full_grad.abs().max()
+    assert helpers.rel_err(r[0]['weights'][live], full_w[live]) < 1e-4
+    assert torch.equal(r[0]['running'], r[1]['running'])
+    assert helpers.rel_err(r[0]['running'], running) < 1e-5

@@ -138,3 +138,37 @@ def test_elbo_step_through_rccl_world_one(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_batchnorm_split_phases_equal_fused(dev, dtype, monkeypatch):
+    """The synchronised BatchNorm path of csrc/batchnorm.hip (reduction pass, all-reduce of C x 2 sums,
+    apply pass with global_sums / global_count; mdmm_bn_t.phase) with a one-rank "all-reduce" must be the
+    fused call: outputs, input / parameter gradients and running statistics."""
+    from mdmm import ops
+    torch.manual_seed(0)
+    x = torch.randn(37, 16, 32, 32, device=dev).to(dtype)
+    gy = torch.randn(37, 16, 32, 32, device=dev).to(dtype)
+    res = []
+    for sync in (False, True):
+        bn = torch.nn.BatchNorm2d(16).to(dev)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+        bn.weight.data.copy_(torch.linspace(0.5, 1.5, 16)); bn.bias.data.copy_(torch.linspace(-1, 1, 16))
+        xi = x.clone().requires_grad_()
+        if sync:
+            calls = []
+            monkeypatch.setattr(ops, 'bn_sync_group', lambda: 'one-rank')
+
+            def fake(part, channels, splits, count, group):
+                calls.append(count)
+                return part.view(channels, splits, 2).sum(1).contiguous(), count
+            monkeypatch.setattr(ops, '_bn_allreduce', fake)
+        y = ops.batchnorm_relu(xi, bn)
+        y.backward(gy)
+        if sync:
+            assert len(calls) == 2 and calls[0] == 37 * 32 * 32 and calls[1] is None
+        res.append((y.detach().float(), xi.grad.float(), bn.weight.grad, bn.bias.grad, bn.running_mean.clone(),
+                    bn.running_var.clone()))
+    for a_, b_ in zip(*res):
+        assert torch.equal(a_, b_) or float((a_ - b_).abs().max() / (b_.abs().max() + 1e-30)) < 1e-6
