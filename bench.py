@@ -368,12 +368,14 @@ def elbo_delta(cfg, oracle, inputs, targets, mask, lengths, device):
         m.noise = PhiloxNoise(seed=777)
         hip[name] = float(m.step(to(inputs), mask.to(device), 1.0, cfg.rec, targets=to(targets), lengths=lengths, **kw))
         del m
+    own_noise = oracle.noise
     oracle.noise = orc.ReplayNoise(step_draws(PhiloxNoise(seed=777), cfg, TRAIN_PARTICLES, b_dim, device))
     was_training = oracle.training
     oracle.train()
     with torch.no_grad():
         ref = float(oracle.step(inputs, mask, 1.0, cfg.rec, targets=targets, lengths=lengths, **kw))
     oracle.train(was_training)
+    oracle.noise = own_noise
     return {'rel': {k: round(abs(v - ref) / abs(ref), 9) for k, v in hip.items()}, 'loss_oracle': ref,
             'loss_hip': hip, 'sample': 'loss of one %s step at B=%d, same weights, the kernels\' Philox noise replayed '
                                        'into the CPU oracle (north star: 1e-4 relative)' % (cfg.name, b_dim)}
