@@ -735,6 +735,13 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
 // the next item's in registers meanwhile; the waves read their fragments from there (every G tile is
 // used by two waves, every X tile by four: straight from memory that was up to 1.9x the unique bytes).
 // ---------------------------------------------------------------------------------------
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load_u4(const uint4* p) {
+  const u32x4v v = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(p));
+  uint4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+  return o;
+}
+
 template <bool F32, int CH>
 __global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int xcd_turn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -768,10 +775,16 @@ __global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int x
   // (staging registers as named scalars: as arrays they are left on the stack)
   uint4 sg0, sg1, sg2, sg3, sg4, sg5, sg6, sg7, sx0, sx1, sx2, sx3, sx4, sx5, sx6, sx7;
 #define WG_EACH(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+// (the operand chunks are read once: streaming loads; A/B: -DWGRAD_LD_PLAIN)
+#ifdef WGRAD_LD_PLAIN
+#define WG_LD(p) (*(p))
+#else
+#define WG_LD(p) nt_load_u4(p)
+#endif
 #define WG_LOAD(u)                                                               \
   if constexpr (u < per_thr) {                                                   \
-    sg##u = src[((size_t)(it + 1) * N_SPILL + garr) * arr_u4 + u * NTHR];        \
-    sx##u = src[((size_t)(it + 1) * N_SPILL + xarr) * arr_u4 + u * NTHR];        \
+    sg##u = WG_LD(src + ((size_t)(it + 1) * N_SPILL + garr) * arr_u4 + u * NTHR);    \
+    sx##u = WG_LD(src + ((size_t)(it + 1) * N_SPILL + xarr) * arr_u4 + u * NTHR);    \
   }
 #define WG_STORE(u) \
   if constexpr (u < per_thr) { dst[u * NTHR] = sg##u; dst[arr_u4 + u * NTHR] = sx##u; }

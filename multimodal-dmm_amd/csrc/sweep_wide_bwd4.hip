@@ -61,6 +61,13 @@ struct B4Park { uint4* base; };
 // global-memory views of the packed weights, the spill and the park: as members of the argument
 // structs the pointers are generic, and generic (flat) loads count on the LDS counter too -- every
 // wait for an A operand would also wait for the weight chunks in flight
+// The spill is written once and read by another kernel much later: streaming stores, so that it does not
+// push the per-step park (re-read within the step) out of the caches on its way to HBM.  (A/B: -DB4_SPILL_PLAIN)
+#ifdef B4_SPILL_PLAIN
+#define SPILL_ST(p, v) (*(p) = (v))
+#else
+#define SPILL_ST(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));     // (a plain vector: HIP's uint4 class has no
 typedef const __attribute__((address_space(1))) u32x4* gw_t;    //  assignment across address spaces)
 typedef __attribute__((address_space(1))) u32x4* gs_t;
@@ -94,16 +101,24 @@ __device__ __forceinline__ void gemm4(f32x16 (&acc)[RT], const char* x0, int ts,
     trip(c0 / PF);
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
+#ifdef B4_ABUF2     // A/B: double-buffered A operands (32 registers; the live set of the step then spills more)
       u32x4 ac[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) ac[rt] = an[rt];
 #pragma unroll
-#ifndef B4_NOA      // timing experiment: no A-operand reads in the loop (results are wrong)
       for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const u32x4*>(x0 + rt * ts + 32 * (c0 + u + 1));
-#endif
       __builtin_amdgcn_sched_barrier(0);      // (the scheduler would sink every read to its MFMA)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) mma16(acc[rt], ac[rt], ring[u]);
+#else
+      // one set of A operands: the reads of chunk c + 1 are issued right behind chunk c's MFMAs (their latency is
+      // covered by the SIMD's other wave, which is in its own four MFMAs meanwhile)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) mma16(acc[rt], an[rt], ring[u]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const u32x4*>(x0 + rt * ts + 32 * (c0 + u + 1));
+#endif
 #ifndef B4_NOW      // timing experiment: no weight loads in the loop (results are wrong)
       if (NEXT || c0 + PF < NCH) ring[u] = nxt[u * 64];   // behind its last reader: no copy, a whole trip to land
 #endif
@@ -204,7 +219,9 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     sel = odd ? 0x03020706u : 0x05040100u;
   };
   regeo();
+#ifndef B4_NOPRIO
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);       // the second-dispatched half loses every arbitration otherwise
+#endif
   const uint64_t noff = noise_off(a);
   const float inv_k = 1.0f / (float)K;
 
@@ -274,8 +291,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       if (arr >= 0) {
         u32x4 c0, c1;
         c0.x = w[0]; c0.y = w[1]; c0.z = w[2]; c0.w = w[3]; c1.x = w[4]; c1.y = w[5]; c1.z = w[6]; c1.w = w[7];
-        *spill_at(step, arr, rt, 0) = c0;
-        *spill_at(step, arr, rt, 1) = c1;
+        SPILL_ST(spill_at(step, arr, rt, 0), c0);
+        SPILL_ST(spill_at(step, arr, rt, 1), c1);
       }
       if (p0) {
 #pragma unroll
@@ -646,11 +663,11 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
           } else {
             u32x4 c;
             c.x = h3[0]; c.y = h3[1]; c.z = w3[0]; c.w = w3[1];
-            *spill_at(i - 1, S_G3, rt, q >> 1) = c;
+            SPILL_ST(spill_at(i - 1, S_G3, rt, q >> 1), c);
             c.x = hg[0]; c.y = hg[1]; c.z = wg[0]; c.w = wg[1];
-            *spill_at(i - 1, S_GG, rt, q >> 1) = c;
+            SPILL_ST(spill_at(i - 1, S_GG, rt, q >> 1), c);
             c.x = hl[0]; c.y = hl[1]; c.z = wl[0]; c.w = wl[1];
-            *spill_at(i - 1, S_GLIN, rt, q >> 1) = c;
+            SPILL_ST(spill_at(i - 1, S_GLIN, rt, q >> 1), c);
           }
           __builtin_amdgcn_sched_barrier(0);     // one group at a time
         }
