@@ -336,13 +336,21 @@ struct BwdLds {
 };
 
 
+// `chs` = chunks per (array, wave) actually kept: all of them, or -- K = 1 with at most 16 (pass, sequence)
+// pairs per workgroup, bf16 -- only chunk 0 (rows 0..15; the rows of chunk 1 are all dead)
 template <bool F32, int RT>
-__device__ __forceinline__ void spill_tiles(uint4* dst, const f32x16 (&v)[RT]) {
+__device__ __forceinline__ void spill_tiles(uint4* dst, const f32x16 (&v)[RT], int chs) {
   constexpr int CT = Op<F32>::CH_TILE;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int s = 0; s < CT; ++s) dst[(rt * CT + s) * 64] = acc_chunk<F32>(v[rt], s);
+    for (int s = 0; s < CT; ++s)
+      if (rt * CT + s < chs) dst[(rt * CT + s) * 64] = acc_chunk<F32>(v[rt], s);
+}
+
+// chunks per (array, wave) of one spilled item for this launch (see spill_tiles)
+inline int spill_chunks(bool f32, int RT, bool k1, int NP) {
+  return (!f32 && k1 && NP <= 16) ? 1 : RT * (f32 ? 4 : 2);
 }
 
 template <int RT>
@@ -427,10 +435,11 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     }
   }
 
-  uint4* my_spill = ws.spill + ((size_t)blockIdx.x * ws.n_step * N_SPILL * NWAVE + wave) * CH * 64 + lane;
+  const int chs = (!F32 && K1 && g.NP <= 16) ? 1 : CH;
+  uint4* my_spill = ws.spill + ((size_t)blockIdx.x * ws.n_step * N_SPILL * NWAVE + wave) * chs * 64 + lane;
   uint4* spill_it = my_spill;
   auto spill_at = [&](int step, int arr) {
-    return spill_it + ((size_t)step * N_SPILL + arr) * NWAVE * CH * 64;
+    return spill_it + ((size_t)step * N_SPILL + arr) * NWAVE * chs * 64;
   };
 
   const PairRef* const tab0 = tab;
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
         for (int rt = 0; rt < RT; ++rt) se[rt] = pair_total(tmp, rt, g.TPP);
       }
       store_image<F32, RT>(img0, acc, wave, lane);
-      spill_tiles<F32, RT>(spill_at(i - 1, S_Z), acc);
+      spill_tiles<F32, RT>(spill_at(i - 1, S_Z), acc, chs);
     }
     STAMP(2);
     __syncthreads();
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
       mask_g[rt] = mb;
     }
     store_image<F32, RT>(img1, acc, wave, lane);
-    spill_tiles<F32, RT>(spill_at(i - 1, S_HG), acc);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_HG), acc, chs);
     fill_acc(acc, b1n);
     gemm_tile<F32, RT, Pf<RT>::N>(acc, img0 + arow, W(L_W1N), W(L_W2G), ring);
 #pragma unroll
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
       mask_n[rt] = mb;
     }
     store_image<F32, RT>(img2, acc, wave, lane);
-    spill_tiles<F32, RT>(spill_at(i - 1, S_HN), acc);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_HN), acc, chs);
     STAMP(4);
     __syncthreads();
     STAMP(5);
@@ -575,7 +584,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
         muq[rt][r] = fmaf(nl[rt][r], ex, bl);
       }
     store_image<F32, RT>(img3, nl, wave, lane);
-    spill_tiles<F32, RT>(spill_at(i - 1, S_NL), nl);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_NL), nl, chs);
     gemm_tile<F32, RT, Pf<RT>::N>(muq, img0 + arow, W(L_WL), W(L_WS), ring);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -640,9 +649,11 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
         store_image_part<F32, CG>(img2, o_gg, rt, c0, wave, lane);
         store_image_part<F32, CG>(img0, o_gl, rt, c0, wave, lane);
         const int ch = rt * O::CH_TILE + c0 / CG;
-        spill_at(i - 1, S_G3)[ch * 64] = pack_chunk<F32, CG>(o_g3);
-        spill_at(i - 1, S_GG)[ch * 64] = pack_chunk<F32, CG>(o_gg);
-        spill_at(i - 1, S_GLIN)[ch * 64] = pack_chunk<F32, CG>(o_gl);
+        if (ch < chs) {
+          spill_at(i - 1, S_G3)[ch * 64] = pack_chunk<F32, CG>(o_g3);
+          spill_at(i - 1, S_GG)[ch * 64] = pack_chunk<F32, CG>(o_gg);
+          spill_at(i - 1, S_GLIN)[ch * 64] = pack_chunk<F32, CG>(o_gl);
+        }
         __builtin_amdgcn_sched_barrier(0);     // one group at a time
       }
     }
@@ -653,7 +664,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     // D1: d/d nl = direct + W_std^T d/d std-pre
     gemm_tile<F32, RT, Pf<RT>::N>(nl, img1 + arow, W(T_WS), W(T_W2G), ring);
     store_image<F32, RT>(img3, nl, wave, lane);
-    spill_tiles<F32, RT>(spill_at(i - 1, S_GN), nl);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_GN), nl, chs);
     STAMP(12);
     __syncthreads();
     STAMP(13);
@@ -670,8 +681,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
         if (!((mask_n[rt] >> r) & 1u)) muq[rt][r] = 0.f;
       }
     store_image<F32, RT>(img1, acc, wave, lane);       // G3 image: every wave is past D1
-    spill_tiles<F32, RT>(spill_at(i - 1, S_GHG), acc);
-    spill_tiles<F32, RT>(spill_at(i - 1, S_GHN), muq);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_GHG), acc, chs);
+    spill_tiles<F32, RT>(spill_at(i - 1, S_GHN), muq, chs);
     STAMP(14);
     __syncthreads();                                    // every wave is done with the GG image
     store_image<F32, RT>(img2, muq, wave, lane);
@@ -999,7 +1010,7 @@ int plan(const mdmm_sweep_t* a, bool bwd, WideGeo* g) {
 // carve the backward workspace; returns the bytes needed
 int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
   const bool f32 = a->precision == MDMM_PREC_F32;
-  const int CH = RT * (f32 ? 4 : 2);
+  const int CH = spill_chunks(f32, RT, a->K == 1, g.NP);
   const int64_t n_wg = (g.n_pairs + g.NP - 1) / g.NP, n_step = a->T - 1;
   const int64_t items = n_wg * n_step;
   int split = 42;                                   // 6 * 42 = 252 workgroups: one round of the 256 CUs
@@ -1046,7 +1057,7 @@ int mdmm_wide_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->K == 1) rc = f32 ? launch_bwd<true, 1, true>(a, g, ws, stream) : launch_bwd<false, 1, true>(a, g, ws, stream);
   else rc = f32 ? launch_bwd<true, 1, false>(a, g, ws, stream) : launch_bwd<false, 2, false>(a, g, ws, stream);
   if (rc) return rc;
-  return wide_wgrad_launch(ws, f32, RT * (f32 ? 4 : 2), a->dw_partial, stream);
+  return wide_wgrad_launch(ws, f32, spill_chunks(f32, RT, a->K == 1, g.NP), a->dw_partial, stream);
 }
 
 int wide::wide_wgrad_launch(const WideWs& ws, bool f32, int CH, float* dw_partial, hipStream_t stream) {
@@ -1061,7 +1072,7 @@ int wide::wide_wgrad_launch(const WideWs& ws, bool f32, int CH, float* dw_partia
   };
   int rc;
   if (f32) rc = CH == 4 ? wgrad(wide_wgrad_kernel<true, 4>) : wgrad(wide_wgrad_kernel<true, 8>);
-  else rc = CH == 2 ? wgrad(wide_wgrad_kernel<false, 2>) : wgrad(wide_wgrad_kernel<false, 4>);
+  else rc = CH == 1 ? wgrad(wide_wgrad_kernel<false, 1>) : (CH == 2 ? wgrad(wide_wgrad_kernel<false, 2>) : wgrad(wide_wgrad_kernel<false, 4>));
   if (rc) return rc;
   rc = (int)hipGetLastError();
   if (rc) return rc;

@@ -219,9 +219,6 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     sel = odd ? 0x03020706u : 0x05040100u;
   };
   regeo();
-#ifndef B4_NOPRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);       // the second-dispatched half loses every arbitration otherwise
-#endif
   const uint64_t noff = noise_off(a);
   const float inv_k = 1.0f / (float)K;
 
