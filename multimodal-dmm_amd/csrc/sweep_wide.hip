@@ -180,22 +180,25 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           const int r0 = 32 * rt + 8 * q + 4 * h;
           // (the draw of the last step only enters `samples`)
           if (sampled && (!last || a.samples)) eps_group(a, noff, t_term, rowbase + r0, n, e);
+          // the four rows' expert loads as one batch, then the products (a dead group: nothing to load)
+          PairRef prs4[4];
+          ExpertVals ev[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            prs4[j] = tab[r0 + j];
+            ev[j].on = 0;
+            if (prs4[j].p >= 0) load_experts(a, exs, prs4[j], (size_t)t * B + prs4[j].b, n, ev[j]);
+          }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int reg = 4 * q + j;
-            const PairRef pr = tab[r0 + j];
+            const PairRef pr = prs4[j];
             const float pm = (i > 0) ? m_[rt][reg] : mu0, ps = (i > 0) ? fast::sqrt(var_[rt][reg]) : sg0;
             float zz = 0.f;
             if (pr.p >= 0) {
               const size_t tb = (size_t)t * B + pr.b;
               fast::Poe pq; pq.init(); pq.add(pm, ps, 1.0f);
-              for (int ex = 0; ex < a.E; ++ex) {
-                const auto& xp = exs[ex];
-                if (!((xp.pass_bits >> pr.p) & 1u)) continue;
-                const float c = xp.mask ? xp.mask[tb] : 1.0f;
-                const size_t off = (size_t)pr.p * xp.pass_stride + tb * WD + n;
-                pq.add(xp.mean[off], xp.std[off], c);
-              }
+              poe_experts(a, exs, pr, tb, n, ev[j], pq);
               if (a.use_inv_prior) pq.add(mu0, -sg0, 1.0f);
               float im, is; pq.finish(im, is);
               const size_t o = (((size_t)pr.p * T + t) * B + pr.b) * WD + n;
@@ -257,14 +260,10 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
         float im = 0.f, is = 0.f;
         if (pr.p >= 0) {
           const size_t tb = (size_t)t * B + pr.b;
+          ExpertVals ev;
+          load_experts(a, exs, pr, tb, n, ev);          // (one batch of loads per tile)
           fast::Poe pq; pq.init(); pq.add(pm[rt], ps[rt], 1.0f);
-          for (int ex = 0; ex < a.E; ++ex) {
-            const auto& xp = exs[ex];
-            if (!((xp.pass_bits >> pr.p) & 1u)) continue;
-            const float c = xp.mask ? xp.mask[tb] : 1.0f;
-            const size_t off = (size_t)pr.p * xp.pass_stride + tb * WD + n;
-            pq.add(xp.mean[off], xp.std[off], c);
-          }
+          poe_experts(a, exs, pr, tb, n, ev, pq);
           if (a.use_inv_prior) pq.add(mu0, -sg0, 1.0f);
           pq.finish(im, is);
           const size_t o = (((size_t)pr.p * T + t) * B + pr.b) * WD + n;

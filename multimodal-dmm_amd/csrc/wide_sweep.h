@@ -122,6 +122,47 @@ struct FuseAdj { float gpm, gps, prm, prs; };
 // adjoint of sampling + product of experts of ONE (pass, sequence) at step t, feature n
 // (dmm.py:387-405 backwards).  `owner`: this lane writes the expert gradients and counts the
 // pair's d/d(mu0, sigma0) (the pair's values are replicated over lanes / tiles).
+// Experts whose loads are issued as ONE batch (a loop that loads, waits and accumulates expert by expert
+// around dependent descriptor reads is a memory round trip per expert: it was most of a K = 1 step).
+constexpr int EXB = 4;
+
+// everything the per-step product of experts of pair (p, b) reads, requested together; experts >= EXB (none in
+// the reference's models) are left to the callers' plain loops
+struct ExpertVals {
+  float mu[EXB], sd[EXB], c[EXB];
+  unsigned on;                      // bit e: expert e takes part in this pair's pass
+};
+template <class A, class E>
+__device__ __forceinline__ void load_experts(const A& a, const E* exs, PairRef pr, size_t tb, int n, ExpertVals& v) {
+  v.on = 0;
+#pragma unroll
+  for (int e = 0; e < EXB; ++e) {
+    v.mu[e] = 0.f; v.sd[e] = 1.f; v.c[e] = 0.f;
+    if (e < a.E && ((exs[e].pass_bits >> pr.p) & 1u)) {
+      const auto& ex = exs[e];
+      v.on |= 1u << e;
+      v.c[e] = ex.mask ? ex.mask[tb] : 1.0f;
+      const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
+      v.mu[e] = ex.mean[off]; v.sd[e] = ex.std[off];
+    }
+  }
+}
+// the product itself (dgts.py:39-51), in the order the plain loop took: prior, experts, inverse prior
+template <class A, class E>
+__device__ __forceinline__ void poe_experts(const A& a, const E* exs, PairRef pr, size_t tb, int n, const ExpertVals& v,
+                                            fast::Poe& q) {
+#pragma unroll
+  for (int e = 0; e < EXB; ++e)
+    if ((v.on >> e) & 1u) q.add(v.mu[e], v.sd[e], v.c[e]);
+  for (int e = EXB; e < a.E; ++e) {
+    const auto& ex = exs[e];
+    if (!((ex.pass_bits >> pr.p) & 1u)) continue;
+    const float c = ex.mask ? ex.mask[tb] : 1.0f;
+    const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
+    q.add(ex.mean[off], ex.std[off], c);
+  }
+}
+
 template <class A, class E>
 __device__ __forceinline__ FuseAdj fuse_bwd(const A& a, const E* exs, PairRef pr, int t, int n, float mu0,
                                             float sg0, float adj_a, float adj_b, float se,
@@ -131,35 +172,47 @@ __device__ __forceinline__ FuseAdj fuse_bwd(const A& a, const E* exs, PairRef pr
   if (pr.p < 0) return r;
   const size_t tb = (size_t)t * a.B + pr.b;
   const size_t o = (((size_t)pr.p * a.T + t) * a.B + pr.b) * WD + n;
+  // every load of the pair first ...
   const float gsmp = a.g_samples ? a.g_samples[o] : 0.f;
-  float g_im = (a.g_infer_mean ? a.g_infer_mean[o] : 0.f) + adj_a + gsmp;
-  float g_is = a.g_infer_std ? a.g_infer_std[o] : 0.f;
-  if (sampled) g_is += adj_b + gsmp * se * inv_k;
+  const float l_gim = a.g_infer_mean ? a.g_infer_mean[o] : 0.f;
+  const float l_gis = a.g_infer_std ? a.g_infer_std[o] : 0.f;
   const float prm = a.prior_mean[o], prs = a.prior_std[o];
+  const float l_gpm = a.g_prior_mean ? a.g_prior_mean[o] : 0.f;
+  const float l_gps = a.g_prior_std ? a.g_prior_std[o] : 0.f;
+  ExpertVals ev;
+  load_experts(a, exs, pr, tb, n, ev);
+  // ... then the algebra
+  float g_im = l_gim + adj_a + gsmp;
+  float g_is = l_gis;
+  if (sampled) g_is += adj_b + gsmp * se * inv_k;
   fast::Poe q; q.init(); q.add(prm, prs, 1.0f);
-  for (int e = 0; e < a.E; ++e) {
-    const auto& ex = exs[e];
-    if (!((ex.pass_bits >> pr.p) & 1u)) continue;
-    const float c = ex.mask ? ex.mask[tb] : 1.0f;
-    const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
-    q.add(ex.mean[off], ex.std[off], c);
-  }
+  poe_experts(a, exs, pr, tb, n, ev, q);
   if (a.use_inv_prior) q.add(mu0, -sg0, 1.0f);
   const float rp = fast::rcp(q.prec), is = fast::sqrt(rp);
   float g_num, g_prec, gm, gs;
   poe_out_bwd_f(q.num, rp, is, g_im, g_is, g_num, g_prec);
   poe_expert_bwd_f(prm, prs, 1.0f, g_num, g_prec, gm, gs);
-  r.gpm = gm + (a.g_prior_mean ? a.g_prior_mean[o] : 0.f);
-  r.gps = gs + (a.g_prior_std ? a.g_prior_std[o] : 0.f);
+  r.gpm = gm + l_gpm;
+  r.gps = gs + l_gps;
   r.prm = prm; r.prs = prs;
-  for (int e = 0; e < a.E; ++e) {
+#pragma unroll
+  for (int e = 0; e < EXB; ++e)
+    if ((ev.on >> e) & 1u) {
+      const auto& ex = exs[e];
+      poe_expert_bwd_f(ev.mu[e], ev.sd[e], ev.c[e], g_num, g_prec, gm, gs);
+      if (owner) {
+        if (ex.g_mean) ex.g_mean[o] = gm;       // one slab per pass, (P,T,B,D)
+        if (ex.g_std) ex.g_std[o] = gs;
+      }
+    }
+  for (int e = EXB; e < a.E; ++e) {
     const auto& ex = exs[e];
     if (!((ex.pass_bits >> pr.p) & 1u)) continue;
     const float c = ex.mask ? ex.mask[tb] : 1.0f;
     const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
     poe_expert_bwd_f(ex.mean[off], ex.std[off], c, g_num, g_prec, gm, gs);
     if (owner) {
-      if (ex.g_mean) ex.g_mean[o] = gm;       // one slab per pass, (P,T,B,D)
+      if (ex.g_mean) ex.g_mean[o] = gm;
       if (ex.g_std) ex.g_std[o] = gs;
     }
   }
