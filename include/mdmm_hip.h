@@ -197,6 +197,13 @@ typedef struct mdmm_sweep {
   int32_t reserved1;
   void* wide_ws;
   int64_t wide_ws_bytes;
+  /* Optional, wide family with K particles: the forward sweep leaves the noise it drew here
+   * (mdmm_sweep_noise_park_bytes(args) bytes, 0 = this shape has no use for it; fp32, in the backward
+   * kernel's own row order) and the backward sweep reads it back instead of drawing it again -- Philox +
+   * Box-Muller for every particle row was a tenth of that kernel.  NULL on either side = draw (forward: do
+   * not keep; backward: regenerate from seed / offset, as ever).  Same pointer for both calls of one sweep.  */
+  void* noise_park;
+  int64_t noise_park_bytes;
 } mdmm_sweep_t;
 
 int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream);
@@ -209,6 +216,7 @@ int mdmm_sweep_dw_width(int D, int H);
 /* != 0 if this sweep (sizes, K, gtf_frag) runs on the wide family */
 int mdmm_sweep_wide(const mdmm_sweep_t* args);
 int64_t mdmm_sweep_wide_ws_bytes(const mdmm_sweep_t* args);
+int64_t mdmm_sweep_noise_park_bytes(const mdmm_sweep_t* args);
 int64_t mdmm_sweep_dw_rows(const mdmm_sweep_t* args);
 /* widths of one spill_g / spill_x row for (D,H) */
 int mdmm_sweep_spill_width_g(int D, int H);

@@ -179,7 +179,9 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           float e[4] = {0.f, 0.f, 0.f, 0.f};
           const int r0 = 32 * rt + 8 * q + 4 * h;
           // (the draw of the last step only enters `samples`)
-          if (sampled && (!last || a.samples)) eps_group(a, noff, t_term, rowbase + r0, n, e);
+          // (a register group none of whose rows carries a pair draws nothing: at 8 pairs per workgroup that is
+          //  three of the four Philox calls of a step)
+          if (sampled && (!last || a.samples) && 32 * rt + 8 * q < g.NP) eps_group(a, noff, t_term, rowbase + r0, n, e);
           // the four rows' expert loads as one batch, then the products (a dead group: nothing to load)
           PairRef prs4[4];
           ExpertVals ev[4];
@@ -291,8 +293,19 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
             for (int j = 0; j < 4; ++j) {
               const bool live = pr.p >= 0 && kb + 8 * q + 4 * h + j < K;
               const float zz = live ? fmaf(e[j], is, im) : 0.f;
+              e[j] = live ? e[j] : 0.f;
               z[rt][4 * q + j] = zz;
               zs += zz;
+            }
+          }
+          if constexpr (RT == 4 && !F32) {
+            // the noise of this step for the one-round backward (sweep_wide_bwd4.hip): its park slot of
+            // (workgroup, time, wave, tile, register group), dead rows as zeros
+            if (a.noise_park) {
+              typedef float f32x4 __attribute__((ext_vector_type(4)));
+              const f32x4 o = {e[0], e[1], e[2], e[3]};
+              __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(a.noise_park) +
+                                                 ((((size_t)blockIdx.x * T + t) * NWAVE + wave) * 16 + rt * 4 + q) * 64 + lane);
             }
           }
         }
@@ -1039,6 +1052,9 @@ int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (((uintptr_t)a->gtf_frag) & 15) return MDMM_E_ALIGN;
   const bool f32 = a->precision == MDMM_PREC_F32;
   if (a->K == 1) return f32 ? launch_fwd<true, 1, true>(a, g, stream) : launch_fwd<false, 1, true>(a, g, stream);
+  if (a->noise_park && (f32 || !mdmm_wide_bwd4_supported(a) || a->noise_park_bytes < mdmm_wide_noise_park_bytes(a) ||
+                        (((uintptr_t)a->noise_park) & 15)))
+    return MDMM_E_ARG;                      // (a park only where the one-round backward will read it)
   return f32 ? launch_fwd<true, 1, false>(a, g, stream) : launch_fwd<false, 4, false>(a, g, stream);
 }
 
@@ -1091,6 +1107,8 @@ extern "C" int mdmm_sweep_wide(const mdmm_sweep_t* a) {
   return a && a->D == WD && a->H == WD && a->gtf_frag && !a->trans_only && a->K > 1 &&
          (a->precision == MDMM_PREC_F32 || a->precision == MDMM_PREC_BF16);
 }
+
+extern "C" int64_t mdmm_sweep_noise_park_bytes(const mdmm_sweep_t* a) { return mdmm_wide_noise_park_bytes(a); }
 
 extern "C" int64_t mdmm_sweep_wide_ws_bytes(const mdmm_sweep_t* a) {
   if (mdmm_wide_bwd4_supported(a)) return mdmm_wide_bwd4_ws_bytes(a);

@@ -232,6 +232,9 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
   const gf_t bias0 = (gf_t)((gw_t)a.gtf_frag + (size_t)N_LAYER * LAYER_U4) + 32 * wave;
   const gs_t spill0 = (gs_t)ws.spill + ((size_t)blockIdx.x * ws.n_step * 2 * N_SPILL * NWAVE + wave) * 256;
   const gs_t park0 = (gs_t)park.base + ((size_t)blockIdx.x * NWAVE + wave) * (PK_SLOTS * 64);
+  // the forward sweep's noise park of this (workgroup, wave): [time][wave][slot][lane], or null
+  const gw_t fwd_noise0 = a.noise_park ? (gw_t)a.noise_park + ((size_t)blockIdx.x * T * NWAVE + wave) * (16 * 64) : (gw_t)nullptr;
+  gw_t fwd_noise = fwd_noise0;
   gw_t frag = frag0;
   gf_t bias = bias0;
   gs_t spill_w = spill0;
@@ -304,8 +307,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     // keep invariant reads and address arithmetic inside the loop (see wide_fwd_kernel)
     tab = tab0; rowbase = rowbase0;
     asm volatile("" : "+v"(tab), "+v"(rowbase));
-    frag = frag0; bias = bias0; spill_w = spill0; park_w = park0;
-    asm volatile("" : "+s"(frag), "+s"(bias), "+s"(spill_w), "+s"(park_w));
+    frag = frag0; bias = bias0; spill_w = spill0; park_w = park0; fwd_noise = fwd_noise0;
+    asm volatile("" : "+s"(frag), "+s"(bias), "+s"(spill_w), "+s"(park_w), "+s"(fwd_noise));
     KArgs* kap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kap));
     KArgs& a = *kap;
@@ -386,18 +389,28 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       // the pair's particles: noise first (no memory operand), then z = mean + std * eps
       if (trans) {
         float e[16];
+        if (fwd_noise) {
+          // the forward sweep kept the noise of step t_prev in this layout (mdmm_sweep_t.noise_park)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float eq[4] = {0.f, 0.f, 0.f, 0.f};
-          if (valid && 8 * q < K) eps_group(a, noff, t_term, rowbase + 32 * rt + 8 * q + 4 * h, n, eq);
-          u32x4 ow;
+          for (int q = 0; q < 4; ++q) {
+            const u32x4 ow = fwd_noise[(((size_t)t_prev * NWAVE) * 16 + rt * 4 + q) * 64 + lane];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const bool live = valid && 8 * q + j < kh;
-            e[4 * q + j] = live ? eq[j] : 0.f;
-            ow[j] = __float_as_uint(e[4 * q + j]);
+            for (int j = 0; j < 4; ++j) e[4 * q + j] = __uint_as_float(ow[j]);
           }
-          *park_at(PK_EPS + rt * 4 + q) = ow;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float eq[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid && 8 * q < K) eps_group(a, noff, t_term, rowbase + 32 * rt + 8 * q + 4 * h, n, eq);
+            u32x4 ow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool live = valid && 8 * q + j < kh;
+              e[4 * q + j] = live ? eq[j] : 0.f;
+              ow[j] = __float_as_uint(e[4 * q + j]);
+            }
+            *park_at(PK_EPS + rt * 4 + q) = ow;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -728,7 +741,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     // D3: d/dz of the previous particles; the noise comes back from the park meanwhile
     u32x4 ep[RT * 4];
 #pragma unroll
-    for (int u = 0; u < RT * 4; ++u) ep[u] = *park_at(PK_EPS + u);
+    for (int u = 0; u < RT * 4; ++u)
+      ep[u] = fwd_noise ? fwd_noise[(((size_t)t_prev * NWAVE) * 16 + u) * 64 + lane] : *park_at(PK_EPS + u);
     gemm4(v0, smem + img + arow, ts, W(T_W1N), W(T_WL), ring);
     gemm4(v0, smem + arow, ts, W(T_WL), W(L_W1G), ring);
     // sums over the particles of d/dz, d/dz * eps and eps
@@ -804,6 +818,12 @@ int64_t b4_carve(const mdmm_sweep_t* a, WideGeo* g, WideWs* ws, B4Park* park) {
 
 int mdmm_wide_bwd4_supported(const mdmm_sweep_t* a) { return b4_shape(a) ? 1 : 0; }
 
+int64_t mdmm_wide_noise_park_bytes(const mdmm_sweep_t* a) {
+  if (!b4_shape(a)) return 0;
+  const int64_t n_wg = ((int64_t)a->P * a->B + RT - 1) / RT;
+  return n_wg * a->T * NWAVE * 16 * 64 * 16;
+}
+
 int64_t mdmm_wide_bwd4_ws_bytes(const mdmm_sweep_t* a) {
   return b4_shape(a) ? b4_carve(a, nullptr, nullptr, nullptr) : 0;
 }
@@ -814,6 +834,8 @@ int mdmm_wide_sweep_bwd4(const mdmm_sweep_t* a, hipStream_t stream) {
   if (!a->wide_ws || !a->dw_partial || a->dw_partial_rows < 1) return MDMM_E_ARG;
   WideGeo g; WideWs ws; B4Park park;
   if (a->wide_ws_bytes < b4_carve(a, &g, &ws, &park)) return MDMM_E_ARG;
+  if (a->noise_park && (a->noise_park_bytes < mdmm_wide_noise_park_bytes(a) || (((uintptr_t)a->noise_park) & 15)))
+    return MDMM_E_ARG;
   const int lds = 3 * RT * a->K * RS + TAB_BYTES;
   if (int rc = mdmm_lds_attr_fn((const void*)wide_bwd4_kernel, (size_t)lds)) return rc;
   hipLaunchKernelGGL(wide_bwd4_kernel, dim3((unsigned)ws.n_wg), dim3(NTHR), lds, stream, *a, g, ws, park);

@@ -452,10 +452,17 @@ class _SweepFn(torch.autograd.Function):
             ex.pass_bits = bits[e]
         s.infer_mean, s.infer_std, s.prior_mean, s.prior_std = [_ptr(o) for o in out]
         s.samples = _ptr(smp)
+        ctx.noise_park = None
         if wide:
             s.gtf_frag, s.precision = _ptr(frag.buf), frag.precision
             if not native.lib().mdmm_sweep_wide(C.byref(s)):
                 raise native.MdmmError('wide sweep refused a shape wide_shape() accepted')
+            if any(ctx.needs_input_grad) and os.environ.get('MDMM_NOISE_PARK') != '0':
+                # the backward sweep reads the noise this sweep draws instead of drawing it again
+                nb = native.lib().mdmm_sweep_noise_park_bytes(C.byref(s))
+                if nb > 0:
+                    ctx.noise_park = torch.empty(nb, device=dev, dtype=torch.uint8)
+                    s.noise_park, s.noise_park_bytes = _ptr(ctx.noise_park), nb
             _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('wide_fwd', cfg))
         else:
             _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('fwd', cfg))
@@ -509,6 +516,8 @@ class _SweepFn(torch.autograd.Function):
         G = X = part = None
         if ctx.frag is not None:                        # wide family: spills + own contraction
             s.gtf_frag, s.precision = _ptr(ctx.frag.buf), ctx.frag.precision
+            if ctx.noise_park is not None:
+                s.noise_park, s.noise_park_bytes = _ptr(ctx.noise_park), ctx.noise_park.numel()
             assert L.mdmm_sweep_bwd_mode(C.byref(s)) == 2
             ws = torch.empty(L.mdmm_sweep_wide_ws_bytes(C.byref(s)), device=dev, dtype=torch.uint8)
             part = torch.empty(1, L.mdmm_sweep_dw_width(cfg.D, cfg.H), device=dev)
