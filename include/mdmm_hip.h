@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 19
+#define MDMM_ABI_VERSION 20
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -544,7 +544,10 @@ int mdmm_conv1d_wgrad(const mdmm_conv1d_t* args, void* ws, float* dw, void* stre
  *   B likewise; fp32 in memory, operands rounded to bf16, fp32 accumulation.
  *   y = x W^T: A = x, B = W;  dx = g W: A = g, B = W with tb;  dW = g^T x: A = g with ta, B = x with
  *   tb and split > 1 (the contraction over the rows is cut into `split` slices summed through
- *   `ws`, mdmm_gemm_ws_bytes).  Contiguous dimensions and leading dimensions multiples of 4.  */
+ *   `ws`, mdmm_gemm_ws_bytes).  Contiguous dimensions and leading dimensions multiples of 4.
+ *   mdmm_gemm_split: the number of slices the library wants for a call (its `split` field is ignored); the caller
+ *   sets split to it.  The plug-in heads' shapes -- one 256-wide side, bf16 operands in memory, no transposition
+ *   flags -- run on shape-specialised kernels (csrc/gemm_heads.hip) behind the same entry point.  */
 typedef struct mdmm_gemm {
   int32_t I, J, L, ta, tb, split;
   int32_t a_bf16, b_bf16, c_bf16, reserved;   /* 1: that matrix is bf16 in memory instead of fp32 */
@@ -558,6 +561,7 @@ typedef struct mdmm_gemm {
   float* ws;             /* split > 1: split * I * J floats */
 } mdmm_gemm_t;
 int mdmm_gemm_supported(const mdmm_gemm_t* args);
+int mdmm_gemm_split(const mdmm_gemm_t* args);
 int64_t mdmm_gemm_ws_bytes(const mdmm_gemm_t* args);
 int mdmm_gemm_bf16(const mdmm_gemm_t* args, void* stream);
 /* Column sums out[j] = sum_i a[i*lda + j] of a (rows x cols) fp32 or bf16 matrix: the bias gradient of

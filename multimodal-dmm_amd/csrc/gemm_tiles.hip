@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mdmm_hip.h"
+#include "gemm_heads.h"
 
 namespace {
 
@@ -133,21 +134,27 @@ __device__ __forceinline__ void gemm_body(const mdmm_gemm_t& g, char (*lds)[2 * 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
   // raw: a bf16 operand read along the contraction whose rows are 16-byte aligned
-  const bool raw_a = !g.reserved && !TA && g.a_bf16 && (g.lda & 7) == 0 && (g.L & 7) == 0 && (((uintptr_t)g.a) & 15) == 0;
-  const bool raw_b = !g.reserved && !TB && g.b_bf16 && (g.ldb & 7) == 0 && (g.L & 7) == 0 && (((uintptr_t)g.b) & 15) == 0;
+  const bool raw_a = !(g.reserved & 1) && !TA && g.a_bf16 && (g.lda & 7) == 0 && (g.L & 7) == 0 && (((uintptr_t)g.a) & 15) == 0;
+  const bool raw_b = !(g.reserved & 1) && !TB && g.b_bf16 && (g.ldb & 7) == 0 && (g.L & 7) == 0 && (((uintptr_t)g.b) & 15) == 0;
   Regs ra, rb;
-  if (s_lo < s_hi) {
-    load_tile<TA, FULL>(g.a, g.a_bf16, raw_a, g.lda, g.I, g.L, i0, s_lo * BL, tid, ra);
-    load_tile<TB, FULL>(g.b, g.b_bf16, raw_b, g.ldb, g.J, g.L, j0, s_lo * BL, tid, rb);
+  // workgroups start their contraction range at different steps and wrap around: tiles of one launch do
+  // not walk the same address bits (rows are a power of two apart) through the memory channels in step
+  const int nst = s_hi - s_lo;
+  int cur = 0;
+  if (nst > 0) {
+    cur = (g.reserved & 2) ? (int)((blockIdx.y * 5u + blockIdx.x * 3u + blockIdx.z * 7u) % (unsigned)nst) : 0;
+    load_tile<TA, FULL>(g.a, g.a_bf16, raw_a, g.lda, g.I, g.L, i0, (s_lo + cur) * BL, tid, ra);
+    load_tile<TB, FULL>(g.b, g.b_bf16, raw_b, g.ldb, g.J, g.L, j0, (s_lo + cur) * BL, tid, rb);
   }
-  for (int s = s_lo; s < s_hi; ++s) {
-    char* buf = lds[(s - s_lo) & 1];
+  for (int s = 0; s < nst; ++s) {
+    char* buf = lds[s & 1];
     store_tile<TA>(buf, tid, ra, raw_a);
     store_tile<TB>(buf + TILE_LDS, tid, rb, raw_b);
     __syncthreads();                       // (two buffers: the tile read two steps ago is free)
-    if (s + 1 < s_hi) {
-      load_tile<TA, FULL>(g.a, g.a_bf16, raw_a, g.lda, g.I, g.L, i0, (s + 1) * BL, tid, ra);
-      load_tile<TB, FULL>(g.b, g.b_bf16, raw_b, g.ldb, g.J, g.L, j0, (s + 1) * BL, tid, rb);
+    if (s + 1 < nst) {
+      cur = cur + 1 == nst ? 0 : cur + 1;
+      load_tile<TA, FULL>(g.a, g.a_bf16, raw_a, g.lda, g.I, g.L, i0, (s_lo + cur) * BL, tid, ra);
+      load_tile<TB, FULL>(g.b, g.b_bf16, raw_b, g.ldb, g.J, g.L, j0, (s_lo + cur) * BL, tid, rb);
     }
     const char* pa = buf + (wi + (lane & 31)) * RS + 16 * h;
     const char* pb = buf + TILE_LDS + (wj + (lane & 31)) * RS + 16 * h;
@@ -301,6 +308,25 @@ extern "C" int mdmm_gemm_supported(const mdmm_gemm_t* g) {
   return 1;
 }
 
+// The number of contraction slices mdmm_gemm_bf16 wants for this call (args->split is ignored): the caller sets
+// split to it and provides ws of mdmm_gemm_ws_bytes.
+extern "C" int mdmm_gemm_split(const mdmm_gemm_t* g) {
+  if (!g || g->I < 1 || g->J < 1 || g->L < 1) return 1;
+  mdmm_gemm_t t = *g;
+  t.split = 1;
+  if (heads::expand_ok(&t)) return 1;
+  if (heads::contract_ok(&t)) return heads::contract_split(&t);
+  if (heads::wgrad_ok(&t)) return heads::wgrad_split(&t);
+  // generic tiles: with fewer than two 128 x 128 tiles per CU the contraction is cut, eight steps per slice at least
+  const int64_t tiles = (int64_t)((g->I + BT - 1) / BT) * ((g->J + BT - 1) / BT), steps = (g->L + BL - 1) / BL;
+  if (tiles >= 512) return 1;
+  int64_t s = steps / 8;
+  const int64_t want = (512 + tiles - 1) / tiles;
+  if (s > want) s = want;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : (int)s;
+}
+
 extern "C" int64_t mdmm_gemm_ws_bytes(const mdmm_gemm_t* g) {
   if (!g || g->split <= 1) return 0;
   return (int64_t)g->split * g->I * g->J * 4;
@@ -311,6 +337,9 @@ extern "C" int mdmm_gemm_bf16(const mdmm_gemm_t* g, void* stream) {
   if ((((uintptr_t)g->a) & (g->a_bf16 ? 7 : 15)) || (((uintptr_t)g->b) & (g->b_bf16 ? 7 : 15))) return MDMM_E_ALIGN;
   if (g->split > 1 && !g->ws) return MDMM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (heads::expand_ok(g)) return heads::expand_launch(g, st);
+  if (heads::contract_ok(g)) return heads::contract_launch(g, st);
+  if (heads::wgrad_ok(g)) return heads::wgrad_launch(g, st);
   const dim3 grid((g->J + BT - 1) / BT, (g->I + BT - 1) / BT, g->split);
   if (!g->ta && !g->tb) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, st, *g);
   else if (!g->ta && g->tb) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, st, *g);

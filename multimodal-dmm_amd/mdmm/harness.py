@@ -82,7 +82,9 @@ class GradBucket:
             off += n
 
     def allreduce(self, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        """Sum the flat gradient over the ranks.  A group handed over explicitly is always entered (a group of
+        one rank too: the hardware test of the collective path); the default group only when it has peers."""
+        if dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
 
 

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 19
+ABI_VERSION = 20
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -35,7 +35,7 @@ SYMBOLS = [
     'mdmm_bn_splits', 'mdmm_bn_relu_fwd', 'mdmm_bn_relu_bwd',
     'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_up', 'mdmm_conv_down',
     'mdmm_conv_wgrad_ws_bytes', 'mdmm_conv_wgrad',
-    'mdmm_gemm_supported', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
+    'mdmm_gemm_supported', 'mdmm_gemm_split', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
     'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
     'mdmm_conv1d_supported', 'mdmm_conv1d_up', 'mdmm_conv1d_down', 'mdmm_conv1d_wgrad_ws_bytes', 'mdmm_conv1d_wgrad',
     'mdmm_colsum_splits', 'mdmm_colsum',
@@ -285,6 +285,7 @@ def lib():
         L.mdmm_conv1d_wgrad_ws_bytes.restype = C.c_int64
         L.mdmm_conv1d_wgrad.argtypes = [C.POINTER(Conv1d), _P, _P, _P]
         L.mdmm_gemm_supported.argtypes = [C.POINTER(Gemm)]
+        L.mdmm_gemm_split.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_ws_bytes.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_ws_bytes.restype = C.c_int64
         L.mdmm_gemm_bf16.argtypes = [C.POINTER(Gemm), _P]

@@ -1028,17 +1028,19 @@ def _rows(t):
 
 
 def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.float32):
-    """c (I,J) = bias + A B^T on csrc/gemm_tiles.hip; a, b are _rows() matrices.  With fewer
-    128 x 128 tiles than two per CU the contraction is split across workgroups and summed."""
-    tiles, steps = ((I + 127) // 128) * ((J + 127) // 128), (L + 31) // 32
-    split = 1 if tiles >= 512 else max(1, min(steps // 8, (512 + tiles - 1) // tiles, 64))
+    """c (I,J) = bias + A B^T on csrc/gemm_tiles.hip / gemm_heads.hip; a, b are _rows() matrices.  The library
+    says into how many slices it cuts the contraction (mdmm_gemm_split; their slabs are summed through ws)."""
     g = native.Gemm()
-    g.I, g.J, g.L, g.ta, g.tb, g.split = I, J, L, int(ta), int(tb), split
-    g.reserved = int(os.environ.get('MDMM_GEMM_NO_RAW') == '1')      # A/B switch: bf16 operands through the converting path
+    g.I, g.J, g.L, g.ta, g.tb, g.split = I, J, L, int(ta), int(tb), 1
+    # A/B switches: bit 0 = bf16 operands through the converting path, bit 1 = staggered contraction start,
+    # bit 2 = the generic tile kernel where a shape-specialised one (csrc/gemm_heads.hip) would be taken
+    g.reserved = (int(os.environ.get('MDMM_GEMM_NO_RAW') == '1') | (2 * int(os.environ.get('MDMM_GEMM_ROT', '0') == '1'))
+                  | (4 * int(os.environ.get('MDMM_GEMM_GENERIC', '0') == '1')) | (8 * int(os.environ.get('MDMM_GEMM_MODE', '0'))))
     g.a, g.lda, g.b, g.ldb = _ptr(a), a.stride(0), _ptr(b), b.stride(0)
     g.a_bf16, g.b_bf16 = int(a.dtype == torch.bfloat16), int(b.dtype == torch.bfloat16)
     c = torch.empty(I, J, device=a.device, dtype=out_dtype)
     g.c, g.ldc, g.bias, g.c_bf16 = _ptr(c), J, _ptr(bias), int(out_dtype == torch.bfloat16)
+    g.split = split = native.lib().mdmm_gemm_split(C.byref(g))
     ws = None
     if split > 1:
         ws = torch.empty(split * I * J, device=a.device, dtype=torch.float32)
@@ -1086,9 +1088,32 @@ def linear_tiles_supported(x, weight):
     return m >= 512 and m % 4 == 0 and k % 4 == 0 and n % 4 == 0 and k >= 32 and n >= 32
 
 
+def _heads_shape(k, n):
+    """True for the shapes csrc/gemm_heads.hip carries: one side 256 wide, the other a multiple of 256 (the
+    plug-ins' 4096 <-> 256 Linear heads); these take every operand as bf16 in memory."""
+    return (k == 256 and n % 256 == 0) or (n == 256 and k % 256 == 0 and k >= 512)
+
+
+def _lin_pack(weight):
+    """(W, W^T) of a head's fp32 weight as contiguous bf16 matrices -- what the GEMM kernels round the weight to
+    while staging, done once per step instead (cached on the parameter like the conv packs: dropped by
+    clear_caches at every public entry point, built before streams fork by prepack_convs)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = getattr(weight, '_mdmm_conv_lin', None)
+    if hit is None or hit[0] != key:
+        w = weight.detach()
+        wb = w.to(torch.bfloat16).contiguous()
+        hit = (key, wb, wb.t().contiguous())
+        weight._mdmm_conv_lin = hit
+    return hit[1], hit[2]
+
+
 class _LinearTilesFn(torch.autograd.Function):
     """y = x W^T + b with bf16 operands / fp32 accumulation on csrc/gemm_tiles.hip, forward, input
-    gradient and weight gradient (the contraction over the rows split across workgroups)."""
+    gradient and weight gradient (the contraction over the rows split across workgroups).  The plug-ins'
+    4096 <-> 256 heads run on the shape-specialised kernels of csrc/gemm_heads.hip: every operand is handed
+    over as bf16 (the 256-wide activation / gradient rounded here, by the same round-to-nearest-even the
+    generic kernel applies while staging, the weight and its transpose from _lin_pack)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, out_dtype=torch.float32):
@@ -1096,31 +1121,48 @@ class _LinearTilesFn(torch.autograd.Function):
         x, w = _rows(x), _rows(weight.detach())
         m, k = x.shape
         n = w.shape[0]
-        # forward: the weight as bf16 once per call -- what the kernel rounds it to while staging, so the
-        # result is bit-identical; bf16 operands read along the contraction are moved as they are (every
-        # row tile re-reads W from L2 at half the bytes).  The input gradient reads W transposed: fp32.
-        wf = w.to(torch.bfloat16) if k % 8 == 0 else w
+        ctx.gx_dtype = x.dtype
+        # (the 4096-wide side must be bf16 already -- activations stored as bf16, ACT_STORAGE: rounding 84 MB here
+        # would cost more than the kernels save)
+        heads = (_heads_shape(k, n) and os.environ.get('MDMM_GEMM_GENERIC') != '1'
+                 and (k == 256 or x.dtype == torch.bfloat16) and (n == 256 or out_dtype == torch.bfloat16))
+        if heads:
+            wf = _lin_pack(weight)[0]
+            if x.dtype != torch.bfloat16:
+                x = x.to(torch.bfloat16)            # (the saved copy too: half the bytes)
+        else:
+            # the weight as bf16 once per call -- what the kernel rounds it to while staging, so the
+            # result is bit-identical; bf16 operands read along the contraction are moved as they are
+            wf = w.to(torch.bfloat16) if k % 8 == 0 else w
         y = _gemm_bf16(x, False, _rows(wf), False, m, n, k, _f32c(bias.detach()) if bias is not None else None,
                        tag='linear_fwd[%dx%d]' % (k, n), out_dtype=out_dtype)
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias, ctx.heads = bias is not None, heads
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
+        x, weight = ctx.saved_tensors
         if g is None:
             return None, None, None, None
         g = _rows(g)
+        w = _rows(weight.detach())
         m, k = x.shape
         n = w.shape[0]
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = _gemm_bf16(g, False, w, True, m, k, n, tag='linear_dgrad[%dx%d]' % (k, n), out_dtype=x.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = colsum(g)                          # (of the gradient as it came, before any rounding)
+        gx_dtype = ctx.gx_dtype
+        if ctx.heads:
+            if g.dtype != torch.bfloat16:
+                g = g.to(torch.bfloat16)
+            if ctx.needs_input_grad[0]:
+                gx = _gemm_bf16(g, False, _lin_pack(weight)[1], False, m, k, n, tag='linear_dgrad[%dx%d]' % (k, n),
+                                out_dtype=gx_dtype)
+        elif ctx.needs_input_grad[0]:
+            gx = _gemm_bf16(g, False, w, True, m, k, n, tag='linear_dgrad[%dx%d]' % (k, n), out_dtype=gx_dtype)
         if ctx.needs_input_grad[1]:
             gw = _gemm_bf16(g, True, x, True, n, k, m, tag='linear_wgrad[%dx%d]' % (k, n))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = colsum(g)
         return gx, gw, gb, None
 
 
@@ -1544,6 +1586,10 @@ def prepack_convs(modules):
     table = {(64, 32): 8, (32, 16): 16}
     for mod in modules:
         for layer in mod.modules():
+            if isinstance(layer, nn.Linear) and layer.weight.is_cuda and layer.weight.dtype == torch.float32 \
+                    and _heads_shape(layer.in_features, layer.out_features):
+                _lin_pack(layer.weight)             # (the Linear heads' bf16 weight and its transpose)
+                continue
             if not isinstance(layer, (nn.Conv2d, nn.ConvTranspose2d)) or not layer.weight.is_cuda:
                 continue
             cs, cb = layer.weight.shape[0], layer.weight.shape[1]

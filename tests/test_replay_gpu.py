@@ -147,6 +147,63 @@ def test_graph_replay_matches_eager_and_oracle(name, dev):
         assert e < tol, 'replayed %s grad %s vs oracle: %.3e' % (name, k, e)
 
 
+def test_graphed_conv_step_through_rccl_world_one(dev, monkeypatch):
+    """bench.py --gpus N per rank, on hardware with a real NCCL (= RCCL) group of one rank and the conv model of
+    cfg3: [graph: step + backward] -> all_reduce of the flat gradient (eager, between the graphs) -> [graph: Adam].
+    The collective really runs once per step, on the buffer the captured backward filled and the captured Adam
+    reads; losses and weights equal those of the group-less replayed step."""
+    import os
+    import torch.distributed as dist
+    from mdmm import models
+    from mdmm.harness import GradBucket, GraphedElboStep
+    from mdmm.noise import PhiloxNoise
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 200))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    calls = []
+    real = dist.all_reduce
+
+    def counted(t, *a, **kw):
+        calls.append((t.data_ptr(), t.numel()))
+        return real(t, *a, **kw)
+    monkeypatch.setattr(dist, 'all_reduce', counted)
+    try:
+        assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+        cfg = bench.CONFIGS['cfg3']
+        lengths = [40, 33, 12, 5]
+        _, _, _, x, tg, mask = _ragged_batch(cfg, lengths, dev)
+        res = []
+        for group in (dist.group.WORLD, None):
+            torch.manual_seed(0)
+            model = cfg.model(models, dev)
+            model.bn_sync = True                     # one rank: the fused BatchNorm path (ops.bn_sync_group)
+            model.noise = PhiloxNoise(seed=99)
+            opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, capturable=True, fused=True)
+            bucket = GradBucket(model.parameters())
+            n0 = len(calls)
+            step = GraphedElboStep(model, opt, bucket, x, mask, lengths, 1.0, cfg.rec, targets=tg, group=group,
+                                   warmup=1, train_particles=bench.TRAIN_PARTICLES)
+            losses = [float(step()) for _ in range(3)]
+            torch.cuda.synchronize()
+            if group is not None:
+                mine = calls[n0:]
+                assert len(mine) == 1 + 3, mine          # the warm-up step and the three replayed ones
+                assert all(c == (bucket.flat.data_ptr(), bucket.flat.numel()) for c in mine)
+            else:
+                assert len(calls) == n0
+            res.append((losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()))
+        for a, b in zip(res[0][0], res[1][0]):
+            assert abs(a - b) <= 1e-5 * abs(b), (res[0][0], res[1][0])
+        # three Adam steps of lr each: a gradient at rounding level may flip its sign, nothing else may differ
+        assert float((res[0][1] - res[1][1]).abs().max()) <= 6.0 * cfg.lr
+        assert float((res[0][1] - res[1][1]).norm() / res[1][1].norm()) < 1e-3
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def _oracle_dks(cfg):
     from mdmm.models import common as C       # the plug-in conv stacks are plain torch modules
     enc = {'video': C.ImageEncoder(256, gauss_out=False, n_channels=3),
