@@ -480,7 +480,11 @@ typedef struct mdmm_bn {
    * pass then normalises with the global mean / variance (forward; running statistics from them too) or
    * forms dx with the global means of g and g xhat (backward; dgamma / dbeta stay this rank's own sums,
    * the gradient all-reduce adds them up).  phase = 0 and global_sums = NULL: one rank, both passes.  */
-  int32_t phase, reserved;
+  int32_t phase;
+  int32_t groups;        /* > 1: x holds `groups` batches of N images one after the other, each normalised with its own
+                          * statistics (save_mean / save_invstd: [groups][C]; partial: groups x C x splits x 2), the running
+                          * statistics updated group by group, dgamma / dbeta summed over them -- successive calls of the
+                          * stock module (one per pass, dgts.py:132-145) as one launch.  One rank, phase 0 only.  */
   const double* global_sums;
   double global_count;
 } mdmm_bn_t;

@@ -93,6 +93,8 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const T* __restrict__ x, i
                                                       int64_t L, double* __restrict__ partial) {
   __shared__ double sh[2 * NT / 64];
   const int c = blockIdx.x;
+  x += (size_t)blockIdx.z * N * C * L;                 // group blockIdx.z of the batch: N images of its own
+  partial += (size_t)blockIdx.z * C * gridDim.y * 2;
   const Span sp = span_of(N);
   float s1 = 0.f, s2 = 0.f;
   double d1 = 0, d2 = 0;
@@ -142,31 +144,46 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
                                                       float* save_mean, float* save_invstd,
                                                       const double* __restrict__ gsum, double gcount) {
   const int c = blockIdx.x;
-  double d1 = 0, d2 = 0;
-  if (gsum) {                                    // statistics of the GLOBAL batch (all ranks), see mdmm_bn_t
-    d1 = gsum[2 * c]; d2 = gsum[2 * c + 1];
-  } else {
-    for (int s = 0; s < (int)gridDim.y; ++s) {
-      d1 += partial[((size_t)c * gridDim.y + s) * 2];
-      d2 += partial[((size_t)c * gridDim.y + s) * 2 + 1];
-    }
-  }
+  const int grp = blockIdx.z, n_grp = gridDim.z;       // groups: each N images with statistics of their own
   const double M = gsum ? gcount : (double)N * (double)L;
-  const double mean = d1 / M;
-  double var = d2 / M - mean * mean;            // biased (normalisation)
-  if (var < 0) var = 0;
+  auto stats_of = [&](int gi, double& mean, double& var) {
+    double d1 = 0, d2 = 0;
+    if (gsum) {                                  // statistics of the GLOBAL batch (all ranks), see mdmm_bn_t
+      d1 = gsum[2 * c]; d2 = gsum[2 * c + 1];
+    } else {
+      const double* p = partial + (size_t)gi * C * gridDim.y * 2;
+      for (int s = 0; s < (int)gridDim.y; ++s) {
+        d1 += p[((size_t)c * gridDim.y + s) * 2];
+        d2 += p[((size_t)c * gridDim.y + s) * 2 + 1];
+      }
+    }
+    mean = d1 / M;
+    var = d2 / M - mean * mean;                  // biased (normalisation)
+    if (var < 0) var = 0;
+  };
+  double mean, var;
+  stats_of(grp, mean, var);
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   if (blockIdx.y == 0 && threadIdx.x == 0) {
-    save_mean[c] = (float)mean; save_invstd[c] = invstd;
-    if (running_mean) {                          // torch: unbiased variance into the running stat
-      const double unb = M > 1 ? var * M / (M - 1) : var;
-      // mean_shift: the bias of the convolution in front, left out of x (it cancels in the
-      // normalisation) but part of the statistic the stock modules track
+    save_mean[(size_t)grp * C + c] = (float)mean; save_invstd[(size_t)grp * C + c] = invstd;
+    if (running_mean && grp == 0) {              // torch: unbiased variance into the running stat
+      // the groups are successive calls of the stock module: their updates in that order
       const float ms = mean_shift ? mean_shift[c] : 0.0f;
-      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * ((float)mean + ms);
-      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+      float rm = running_mean[c], rv = running_var[c];
+      for (int gi = 0; gi < n_grp; ++gi) {
+        double mg = mean, vg = var;
+        if (gi > 0) stats_of(gi, mg, vg);
+        const double unb = M > 1 ? vg * M / (M - 1) : vg;
+        // mean_shift: the bias of the convolution in front, left out of x (it cancels in the
+        // normalisation) but part of the statistic the stock modules track
+        rm = (1.0f - momentum) * rm + momentum * ((float)mg + ms);
+        rv = (1.0f - momentum) * rv + momentum * (float)unb;
+      }
+      running_mean[c] = rm; running_var[c] = rv;
     }
   }
+  x += (size_t)grp * N * C * L;
+  y += (size_t)grp * N * C * L;
   const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
   const float scale = g * invstd, shift = b - (float)mean * scale;
   const Span sp = span_of(N);
@@ -213,7 +230,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const T* __restrict__ 
                                                           double* __restrict__ partial) {
   __shared__ double sh[2 * NT / 64];
   const int c = blockIdx.x;
-  const float mean = save_mean[c], invstd = save_invstd[c];
+  const size_t goff = (size_t)blockIdx.z * N * C * L;
+  dy += goff; x += goff;
+  partial += (size_t)blockIdx.z * C * gridDim.y * 2;
+  const float mean = save_mean[(size_t)blockIdx.z * C + c], invstd = save_invstd[(size_t)blockIdx.z * C + c];
   const float g_ = gamma ? gamma[c] : 1.0f, b_ = beta ? beta[c] : 0.0f;
   const float scale = g_ * invstd, shift = b_ - mean * scale;     // as the forward pass forms them
   const Span sp = span_of(N);
@@ -272,19 +292,33 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
                                                           float* dbeta, const double* __restrict__ gsum,
                                                           double gcount) {
   const int c = blockIdx.x;
-  double d1 = 0, d2 = 0;
-  for (int s = 0; s < (int)gridDim.y; ++s) {
-    d1 += partial[((size_t)c * gridDim.y + s) * 2];
-    d2 += partial[((size_t)c * gridDim.y + s) * 2 + 1];
-  }
-  if (blockIdx.y == 0 && threadIdx.x == 0) {     // this rank's part of the parameter gradients
-    if (dgamma) dgamma[c] = (float)d2;
-    if (dbeta) dbeta[c] = (float)d1;
+  const int grp = blockIdx.z, n_grp = gridDim.z;
+  auto sums_of = [&](int gi, double& d1, double& d2) {
+    const double* p = partial + (size_t)gi * C * gridDim.y * 2;
+    d1 = 0; d2 = 0;
+    for (int s = 0; s < (int)gridDim.y; ++s) {
+      d1 += p[((size_t)c * gridDim.y + s) * 2];
+      d2 += p[((size_t)c * gridDim.y + s) * 2 + 1];
+    }
+  };
+  double d1, d2;
+  sums_of(grp, d1, d2);
+  if (blockIdx.y == 0 && threadIdx.x == 0 && grp == 0) {     // this rank's part of the parameter gradients
+    double t1 = d1, t2 = d2;                     // (the affine parameters are shared by the groups)
+    for (int gi = 1; gi < n_grp; ++gi) {
+      double e1, e2;
+      sums_of(gi, e1, e2);
+      t1 += e1; t2 += e2;
+    }
+    if (dgamma) dgamma[c] = (float)t2;
+    if (dbeta) dbeta[c] = (float)t1;
   }
   if (gsum) { d1 = gsum[2 * c]; d2 = gsum[2 * c + 1]; }      // means over the GLOBAL batch
   const double M = gsum ? gcount : (double)N * (double)L;
   const float mg = (float)(d1 / M), mgx = (float)(d2 / M);
-  const float mean = save_mean[c], invstd = save_invstd[c];
+  const size_t goff = (size_t)grp * N * C * L;
+  dy += goff; x += goff; dx += goff;
+  const float mean = save_mean[(size_t)grp * C + c], invstd = save_invstd[(size_t)grp * C + c];
   const float g_ = gamma ? gamma[c] : 1.0f, b_ = beta ? beta[c] : 0.0f;
   const float k = g_ * invstd, shift = b_ - mean * k;
   const Span sp = span_of(N);
@@ -322,7 +356,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
 
 bool vec_ok(const mdmm_bn_t* a) {
   const int w = a->bf16_io ? 8 : 4;             // 16 bytes per lane
-  return a->L % w == 0 && !(((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->dy | (uintptr_t)a->dx) & 15);
+  return a->L % w == 0 && !(((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->dy | (uintptr_t)a->dx) & 15);     // (group offsets are multiples of L)
 }
 
 int check(const mdmm_bn_t* a) {
@@ -331,6 +365,7 @@ int check(const mdmm_bn_t* a) {
   if (a->splits < 1 || a->splits > 65535) return MDMM_E_ARG;
   if (a->phase < 0 || a->phase > MDMM_BN_APPLY) return MDMM_E_ARG;
   if (a->global_sums && !(a->global_count >= 1.0)) return MDMM_E_ARG;
+  if (a->groups < 0 || a->groups > 65535 || (a->groups > 1 && (a->phase != 0 || a->global_sums))) return MDMM_E_ARG;
   return 0;
 }
 
@@ -349,7 +384,7 @@ extern "C" int mdmm_bn_splits(int64_t N, int C, int64_t L) {
 namespace {
 template <bool VEC, typename T>
 void launch_fwd(const mdmm_bn_t* a, hipStream_t st) {
-  const dim3 grid(a->C, a->splits);
+  const dim3 grid(a->C, a->splits, a->groups > 1 ? a->groups : 1);
   if (a->phase != MDMM_BN_APPLY)
     hipLaunchKernelGGL((bn_stats_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->x, a->N, a->C, a->L, a->partial);
   if (a->phase != MDMM_BN_STATS)
@@ -359,7 +394,7 @@ void launch_fwd(const mdmm_bn_t* a, hipStream_t st) {
 }
 template <bool VEC, typename T>
 void launch_bwd(const mdmm_bn_t* a, hipStream_t st) {
-  const dim3 grid(a->C, a->splits);
+  const dim3 grid(a->C, a->splits, a->groups > 1 ? a->groups : 1);
   if (a->phase != MDMM_BN_APPLY)
     hipLaunchKernelGGL((bn_bwd_stats_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->dy, (const T*)a->x, a->N, a->C,
                        a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial);

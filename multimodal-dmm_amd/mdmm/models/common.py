@@ -126,6 +126,11 @@ class _ConvBlock(nn.Module):
             # evaluation mode (running statistics) and CPU: the stock modules, in the weights' precision
             if x.dtype != layer.weight.dtype:
                 x = x.to(layer.weight.dtype)
+            if bn.training and ops.BN_GROUPS > 1:         # the batch holds several passes (ops.bn_groups): one by one
+                chunks = layer(x).chunk(ops.BN_GROUPS)
+                if ops.bn_sync_group() is not None:
+                    return torch.cat([ops.sync_batchnorm_relu_torch(c, bn) for c in chunks])
+                return torch.cat([self.net[2](bn(c)) for c in chunks])
             if bn.training and ops.bn_sync_group() is not None:      # statistics of every rank's batch (ops.bn_sync)
                 return ops.sync_batchnorm_relu_torch(layer(x), bn)
             return self.net[2](bn(layer(x)))

@@ -323,21 +323,35 @@ class MultiDMM(MultiDGTS):
     # ---- the ELBO step ----------------------------------------------------------------
     def _decode_for_loss(self, m, z_list, **kw):
         """Decode modality m for a list of (T,B,D) latents -> list of parameter tuples.
-        One batched decoder call, unless the decoder holds BatchNorm in training mode
-        (per-call batch statistics must then stay per pass, as in the reference)."""
+        One batched decoder call.  A decoder that holds BatchNorm in training mode keeps per-pass batch
+        statistics, as in the reference (dgts.py:132-145 decodes pass by pass): the stock conv blocks of
+        models.common take the batched call under ops.bn_groups (every BatchNorm layer normalises each pass
+        with its own statistics and updates the running ones pass by pass, one launch per layer and
+        direction); any other module with BatchNorm is called once per pass."""
         dec = self.dec[m]
         t_max, b_dim = z_list[0].shape[:2]
-        has_bn = dec.training and any(isinstance(x, nn.modules.batchnorm._BatchNorm)
-                                      for x in dec.modules())
-        if has_bn or len(z_list) == 1:
+        bns = [x for x in dec.modules() if isinstance(x, nn.modules.batchnorm._BatchNorm)] if dec.training else []
+        grouped = bool(bns) and self._bn_in_blocks(dec, bns) and os.environ.get('MDMM_BN_GROUPS') != '0'
+        if (bns and not grouped) or len(z_list) == 1:
             outs = [self._plug(dec, z.reshape(-1, self.z_dim), **kw) for z in z_list]
             return [tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in o) for o in outs]
         n = len(z_list)
-        out = self._plug(dec, torch.stack(z_list).reshape(-1, self.z_dim), **kw)
+        with ops.bn_groups(n if grouped else 1):
+            out = self._plug(dec, torch.stack(z_list).reshape(-1, self.z_dim), **kw)
         # unbind, not r[i]: its backward is ONE stack of the per-pass gradients, where every
         # integer index would zero-fill and add a full-size tensor
         out = [r.reshape(n, t_max, b_dim, *r.shape[1:]).unbind(0) for r in out]
         return [tuple(r[i] for r in out) for i in range(n)]
+
+    @staticmethod
+    def _bn_in_blocks(dec, bns):
+        """Every BatchNorm of the module sits inside a conv block of models.common (the ones that honour
+        ops.bn_groups)."""
+        inside = set()
+        for blk in dec.modules():
+            if isinstance(blk, common._ConvBlock) and isinstance(blk.net, nn.Sequential):
+                inside.add(id(blk.net[1]))
+        return all(id(b) in inside for b in bns)
 
     def _fused_nll(self, m, z):
         dec = self.dec[m]

@@ -122,7 +122,7 @@ class Bn(C.Structure):
                 [('eps', C.c_float), ('momentum', C.c_float)] +
                 [(n, _P) for n in ('x', 'gamma', 'beta', 'running_mean', 'running_var', 'y', 'save_mean',
                                    'save_invstd', 'dy', 'dx', 'dgamma', 'dbeta', 'partial', 'mean_shift')] +
-                [('phase', C.c_int32), ('reserved', C.c_int32), ('global_sums', _P), ('global_count', C.c_double)])
+                [('phase', C.c_int32), ('groups', C.c_int32), ('global_sums', _P), ('global_count', C.c_double)])
 
 
 BN_STATS, BN_APPLY = 1, 2

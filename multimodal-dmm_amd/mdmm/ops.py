@@ -1208,20 +1208,24 @@ class _BnReluFn(torch.autograd.Function):
         x = _act(x)
         N, Cc = x.shape[0], x.shape[1]
         Ln = x[0, 0].numel()
+        # groups (bn_groups): the batch holds G passes one after the other, each normalised with its own
+        # statistics, the running statistics updated pass by pass -- G calls of the stock module in one launch
+        G = bn_groups_for(N, bn)
+        N //= G
         a = native.Bn()
-        a.N, a.C, a.L, a.relu = N, Cc, Ln, int(relu)
+        a.N, a.C, a.L, a.relu, a.groups = N, Cc, Ln, int(relu), G
         a.bf16_io = int(x.dtype == torch.bfloat16)
-        a.splits = native.lib().mdmm_bn_splits(N, Cc, Ln)
+        a.splits = max(1, native.lib().mdmm_bn_splits(N, Cc, Ln) // G) if G > 1 else native.lib().mdmm_bn_splits(N, Cc, Ln)
         a.eps = bn.eps
         y = torch.empty_like(x)
-        stats = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
-        part = torch.empty(Cc * a.splits * 2, device=x.device, dtype=torch.float64)
+        stats = torch.empty(2, G, Cc, device=x.device, dtype=torch.float32)
+        part = torch.empty(G * Cc * a.splits * 2, device=x.device, dtype=torch.float64)
         g = None if gamma is None else _f32c(gamma.detach())
         b = None if beta is None else _f32c(beta.detach())
         a.x, a.gamma, a.beta, a.y = _ptr(x), _ptr(g), _ptr(b), _ptr(y)
         a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
         if bn.track_running_stats and bn.running_mean is not None:
-            bn.num_batches_tracked.add_(1)
+            bn.num_batches_tracked.add_(G)
             # momentum None = cumulative average (torch: 1 / num_batches_tracked)
             a.momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             a.running_mean, a.running_var = _ptr(bn.running_mean), _ptr(bn.running_var)
@@ -1241,7 +1245,7 @@ class _BnReluFn(torch.autograd.Function):
             _call('mdmm_bn_relu_fwd', C.byref(a))
         ctx.sync = (group, gcount)
         ctx.save_for_backward(x, stats, g, b)
-        ctx.meta = (N, Cc, Ln, int(relu), a.splits, bn.eps)
+        ctx.meta = (N, Cc, Ln, int(relu), a.splits, bn.eps, G)
         ctx.shift_like = None if shift is None else shift.detach()
         return y
 
@@ -1253,16 +1257,16 @@ class _BnReluFn(torch.autograd.Function):
         if dy is None:
             return None, None, None, None, None, shift_grad
         x, stats, g, b = ctx.saved_tensors
-        N, Cc, Ln, relu, splits, eps = ctx.meta
+        N, Cc, Ln, relu, splits, eps, G = ctx.meta
         dy = _act(dy)
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         a = native.Bn()
-        a.N, a.C, a.L, a.relu, a.splits, a.eps = N, Cc, Ln, relu, splits, eps
+        a.N, a.C, a.L, a.relu, a.splits, a.eps, a.groups = N, Cc, Ln, relu, splits, eps, G
         a.bf16_io = int(x.dtype == torch.bfloat16)
         dx = torch.empty_like(x)
         dgb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
-        part = torch.empty(Cc * splits * 2, device=x.device, dtype=torch.float64)
+        part = torch.empty(G * Cc * splits * 2, device=x.device, dtype=torch.float64)
         a.x, a.gamma, a.beta, a.dy, a.dx = _ptr(x), _ptr(g), _ptr(b), _ptr(dy), _ptr(dx)
         a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
         a.dgamma, a.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
@@ -1394,7 +1398,41 @@ def batchnorm_relu(x, bn, relu=True, shift=None):
     """nn.Sequential(bn, nn.ReLU())(x) for a BatchNorm1d / BatchNorm2d holder in training mode.
     shift: the bias of the convolution that produced x when the caller left it out (it cancels in
     the normalisation; it still enters the running mean, and its gradient is exactly zero)."""
+    if BN_GROUPS > 1 and bn_groups_for(x.shape[0], bn) == 1:
+        # the batch holds several passes but the grouped launch does not apply (synchronised statistics,
+        # cumulative-average momentum): pass by pass, as the stock module would be called
+        return torch.cat([_BnReluFn.apply(c, bn.weight, bn.bias, bn, relu, shift) for c in x.chunk(BN_GROUPS)])
     return _BnReluFn.apply(x, bn.weight, bn.bias, bn, relu, shift)
+
+
+BN_GROUPS = 1           # > 1 while bn_groups() is active
+
+
+class bn_groups:
+    """Context: the batch handed to the plug-in holds `n` passes one after the other (equal sizes); training-mode
+    BatchNorm layers normalise each with its own statistics and update the running statistics pass by pass --
+    what n successive calls of the module do (dgts.py:132-145 decodes pass by pass), in one launch per layer
+    and direction (mdmm_bn_t.groups)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        global BN_GROUPS
+        self.prev, BN_GROUPS = BN_GROUPS, self.n
+
+    def __exit__(self, *exc):
+        global BN_GROUPS
+        BN_GROUPS = self.prev
+
+
+def bn_groups_for(n_rows, bn):
+    """Groups the fused BatchNorm launch takes for a batch of n_rows under the active bn_groups()."""
+    if BN_GROUPS <= 1 or n_rows % BN_GROUPS or bn_sync_group() is not None:
+        return 1
+    if bn.track_running_stats and bn.running_mean is not None and bn.momentum is None:
+        return 1
+    return BN_GROUPS
 
 
 # ------------------------------------------------------------------------------------

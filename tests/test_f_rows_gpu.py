@@ -172,3 +172,37 @@ def test_batchnorm_split_phases_equal_fused(dev, dtype, monkeypatch):
                     bn.running_var.clone()))
     for a_, b_ in zip(*res):
         assert torch.equal(a_, b_) or float((a_ - b_).abs().max() / (b_.abs().max() + 1e-30)) < 1e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('groups', [2, 3])
+def test_batchnorm_groups_equal_separate_calls(dev, dtype, groups):
+    """ops.bn_groups(G): one launch per direction over a batch that holds G passes must be G successive calls of
+    the layer on the passes -- outputs, input and affine gradients, the running statistics after all of them and
+    num_batches_tracked (what MultiDMM._decode_for_loss relies on when it decodes the passes of a modality as
+    one batch; the reference decodes pass by pass, dgts.py:132-145)."""
+    import copy
+    from mdmm import ops
+    torch.manual_seed(groups)
+    n = 24
+    x = (torch.randn(groups * n, 16, 8, 8, device=dev) * torch.arange(1, groups * n + 1, device=dev).view(-1, 1, 1, 1) / n).to(dtype)
+    gy = torch.randn(groups * n, 16, 8, 8, device=dev).to(dtype)
+    shift = torch.randn(16, device=dev)
+    bn_a = torch.nn.BatchNorm2d(16).to(dev).train()
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5); bn_a.bias.normal_()
+    bn_b = copy.deepcopy(bn_a)
+    xa = x.clone().requires_grad_()
+    with ops.bn_groups(groups):
+        ya = ops.batchnorm_relu(xa, bn_a, shift=shift)
+    ga = torch.autograd.grad(ya, [xa, bn_a.weight, bn_a.bias], gy)
+    xb = x.clone().requires_grad_()
+    yb = torch.cat([ops.batchnorm_relu(c, bn_b, shift=shift) for c in xb.chunk(groups)])
+    gb = torch.autograd.grad(yb, [xb, bn_b.weight, bn_b.bias], gy)
+    assert torch.equal(ya, yb)
+    assert torch.equal(ga[0], gb[0])
+    for a_, b_ in zip(ga[1:], gb[1:]):                      # (G partial sums added in another order)
+        assert helpers.rel_err(a_, b_) < 1e-6
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == groups
+    assert helpers.rel_err(bn_a.running_mean, bn_b.running_mean) < 1e-6
+    assert helpers.rel_err(bn_a.running_var, bn_b.running_var) < 1e-6
