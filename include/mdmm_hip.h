@@ -552,9 +552,13 @@ int mdmm_conv1d_wgrad(const mdmm_conv1d_t* args, void* ws, float* dw, void* stre
  *   mdmm_gemm_split: the number of slices the library wants for a call (its `split` field is ignored); the caller
  *   sets split to it.  The plug-in heads' shapes -- one 256-wide side, bf16 operands in memory, no transposition
  *   flags -- run on shape-specialised kernels (csrc/gemm_heads.hip) behind the same entry point.  */
+#define MDMM_GEMM_RELU 32
 typedef struct mdmm_gemm {
   int32_t I, J, L, ta, tb, split;
-  int32_t a_bf16, b_bf16, c_bf16, reserved;   /* 1: that matrix is bf16 in memory instead of fp32 */
+  int32_t a_bf16, b_bf16, c_bf16;   /* 1: that matrix is bf16 in memory instead of fp32 */
+  int32_t flags;         /* MDMM_GEMM_RELU: c = max(c, 0) (the nn.ReLU behind z_to_feat, common.py:141-148); bits 0-4 are
+                          * measurement switches of tools/ (converting operand path, staggered contraction start, generic
+                          * tile kernel for a head shape, kernel parts) and 0 in product calls */
   const void* a;
   int64_t lda;
   const void* b;

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(512) void expand_kernel(const mdmm_gemm_t g, int ro
     for (int s = 0; s < 16; ++s) wf[s] = gb[2 * s];
   }
   // the block's 256 bias values behind the images (read back per stage: sixteen registers less)
+  const bool relu = (g.flags & MDMM_GEMM_RELU) != 0;
   char* const epi = lds + 2 * X_STAGE;
   float* const bias_l = reinterpret_cast<float*>(lds + 3 * X_STAGE);
   if (tid < 256) bias_l[tid] = g.bias ? g.bias[col0 + tid] : 0.f;
@@ -142,7 +143,11 @@ __global__ __launch_bounds__(512) void expand_kernel(const mdmm_gemm_t g, int ro
         const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
         bf16x4 p;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) p[e] = (__bf16)(acc[t][4 * q + e] + bq[e]);
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[t][4 * q + e] + bq[e];
+          if (relu) v = fmaxf(v, 0.f);
+          p[e] = (__bf16)v;
+        }
         *reinterpret_cast<u32x2*>(epi + (32 * t + l32) * XRS + (32 * wave + 8 * q + 4 * h) * 2) = __builtin_bit_cast(u32x2, p);
       }
     __syncthreads();
@@ -285,7 +290,8 @@ __global__ __launch_bounds__(512) void contract_kernel(const mdmm_gemm_t g) {
       for (int r = 0; r < 16; ++r) {
         const int i = row0 + 64 * wm + 32 * x + 8 * (r >> 2) + (r & 3) + 4 * h;
         if (i >= g.I) continue;
-        const float v = acc[x][y][r] + bias;
+        float v = acc[x][y][r] + bias;
+        if (direct && (g.flags & MDMM_GEMM_RELU)) v = fmaxf(v, 0.f);
         if (!direct) cw[(int64_t)i * g.J + j] = v;
         else if (g.c_bf16) reinterpret_cast<__bf16*>(g.c)[(int64_t)i * g.ldc + j] = (__bf16)v;
         else reinterpret_cast<float*>(g.c)[(int64_t)i * g.ldc + j] = v;
@@ -443,6 +449,7 @@ __global__ __launch_bounds__(256) void contract_fold_kernel(const mdmm_gemm_t g)
     const float4 b = *reinterpret_cast<const float4*>(g.bias + j);
     s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
   }
+  if (g.flags & MDMM_GEMM_RELU) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
   if (g.c_bf16) {
     bf16x4 p;
     p[0] = (__bf16)s.x; p[1] = (__bf16)s.y; p[2] = (__bf16)s.z; p[3] = (__bf16)s.w;
@@ -457,14 +464,14 @@ __global__ __launch_bounds__(256) void contract_fold_kernel(const mdmm_gemm_t g)
 namespace heads {
 
 bool expand_ok(const mdmm_gemm_t* g) {
-  if (g->ta || g->tb || !g->a_bf16 || !g->b_bf16 || !g->c_bf16 || g->split != 1 || (g->reserved & 4)) return false;
+  if (g->ta || g->tb || !g->a_bf16 || !g->b_bf16 || !g->c_bf16 || g->split != 1 || (g->flags & 4)) return false;
   if (g->L != XK || g->J < 256 || (g->J & 255) || g->I < 1) return false;
   if ((g->lda & 7) || (g->ldb & 7) || (g->ldc & 7) || g->lda < XK || g->ldb < XK || g->ldc < g->J) return false;
   return !((((uintptr_t)g->a) | ((uintptr_t)g->b) | ((uintptr_t)g->c)) & 15);
 }
 
 int expand_launch(const mdmm_gemm_t* g, hipStream_t st) {
-  const int mode = (g->reserved >> 3) & 3;
+  const int mode = (g->flags >> 3) & 3;
   auto kern = mode == 1 ? expand_kernel<1> : mode == 2 ? expand_kernel<2> : mode == 3 ? expand_kernel<3> : expand_kernel<0>;
   if (int rc = mdmm_lds_attr_fn((const void*)kern, (size_t)X_LDS)) return rc;
   // one workgroup per CU: column blocks x row ranges ~ 256, ranges in whole stages
@@ -479,7 +486,7 @@ int expand_launch(const mdmm_gemm_t* g, hipStream_t st) {
 }
 
 bool contract_ok(const mdmm_gemm_t* g) {
-  if (g->ta || g->tb || !g->a_bf16 || !g->b_bf16 || (g->reserved & 4)) return false;
+  if (g->ta || g->tb || !g->a_bf16 || !g->b_bf16 || (g->flags & 4)) return false;
   if (g->J < CN || (g->J % CN) || g->L < 8 * CK || (g->L % CK) || g->I < 1 || g->split < 1) return false;
   if ((g->lda & 7) || (g->ldb & 7) || (g->ldc & 3) || g->lda < g->L || g->ldb < g->L || g->ldc < g->J) return false;
   return !((((uintptr_t)g->a) | ((uintptr_t)g->b) | ((uintptr_t)g->c)) & 15);
@@ -495,7 +502,7 @@ int contract_split(const mdmm_gemm_t* g) {
 }
 
 int contract_launch(const mdmm_gemm_t* g, hipStream_t st) {
-  const int mode = (g->reserved >> 3) & 3;
+  const int mode = (g->flags >> 3) & 3;
   auto kern = mode == 1 ? contract_kernel<1> : mode == 2 ? contract_kernel<2> : mode == 3 ? contract_kernel<3> : contract_kernel<0>;
   if (int rc = mdmm_lds_attr_fn((const void*)kern, (size_t)C_LDS)) return rc;
   const int tiles = ((g->I + CM - 1) / CM) * (g->J / CN);
@@ -508,7 +515,7 @@ int contract_launch(const mdmm_gemm_t* g, hipStream_t st) {
 }
 
 bool wgrad_ok(const mdmm_gemm_t* g) {
-  if (!g->ta || !g->tb || !g->a_bf16 || !g->b_bf16 || g->c_bf16 || g->bias || (g->reserved & 4)) return false;
+  if (!g->ta || !g->tb || !g->a_bf16 || !g->b_bf16 || g->c_bf16 || g->bias || (g->flags & (4 | MDMM_GEMM_RELU))) return false;
   const bool sa = g->I == 256 && g->J >= 128 && !(g->J & 127), sb = g->J == 256 && g->I >= 128 && !(g->I & 127);
   if (!(sa || sb) || g->L < 512 || g->split < 1) return false;
   if ((g->lda & 7) || (g->ldb & 7) || (g->ldc & 3) || g->lda < g->I || g->ldb < g->J || g->ldc < g->J) return false;

@@ -134,15 +134,15 @@ __device__ __forceinline__ void gemm_body(const mdmm_gemm_t& g, char (*lds)[2 * 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
   // raw: a bf16 operand read along the contraction whose rows are 16-byte aligned
-  const bool raw_a = !(g.reserved & 1) && !TA && g.a_bf16 && (g.lda & 7) == 0 && (g.L & 7) == 0 && (((uintptr_t)g.a) & 15) == 0;
-  const bool raw_b = !(g.reserved & 1) && !TB && g.b_bf16 && (g.ldb & 7) == 0 && (g.L & 7) == 0 && (((uintptr_t)g.b) & 15) == 0;
+  const bool raw_a = !(g.flags & 1) && !TA && g.a_bf16 && (g.lda & 7) == 0 && (g.L & 7) == 0 && (((uintptr_t)g.a) & 15) == 0;
+  const bool raw_b = !(g.flags & 1) && !TB && g.b_bf16 && (g.ldb & 7) == 0 && (g.L & 7) == 0 && (((uintptr_t)g.b) & 15) == 0;
   Regs ra, rb;
   // workgroups start their contraction range at different steps and wrap around: tiles of one launch do
   // not walk the same address bits (rows are a power of two apart) through the memory channels in step
   const int nst = s_hi - s_lo;
   int cur = 0;
   if (nst > 0) {
-    cur = (g.reserved & 2) ? (int)((blockIdx.y * 5u + blockIdx.x * 3u + blockIdx.z * 7u) % (unsigned)nst) : 0;
+    cur = (g.flags & 2) ? (int)((blockIdx.y * 5u + blockIdx.x * 3u + blockIdx.z * 7u) % (unsigned)nst) : 0;
     load_tile<TA, FULL>(g.a, g.a_bf16, raw_a, g.lda, g.I, g.L, i0, (s_lo + cur) * BL, tid, ra);
     load_tile<TB, FULL>(g.b, g.b_bf16, raw_b, g.ldb, g.J, g.L, j0, (s_lo + cur) * BL, tid, rb);
   }
@@ -185,8 +185,10 @@ __device__ __forceinline__ void gemm_body(const mdmm_gemm_t& g, char (*lds)[2 * 
       for (int r = 0; r < 16; ++r) {
         const int i = i0 + wi + 32 * x + acc_row(r) + 4 * h;
         if (i >= g.I) continue;
-        if (cbf) reinterpret_cast<__bf16*>(g.c)[(int64_t)i * ldc + j] = (__bf16)(acc[x][y][r] + bias);
-        else c[(int64_t)i * ldc + j] = acc[x][y][r] + bias;
+        float v = acc[x][y][r] + bias;
+        if ((g.flags & MDMM_GEMM_RELU) && g.split == 1) v = fmaxf(v, 0.f);
+        if (cbf) reinterpret_cast<__bf16*>(g.c)[(int64_t)i * ldc + j] = (__bf16)v;
+        else c[(int64_t)i * ldc + j] = v;
       }
     }
 }
@@ -206,7 +208,8 @@ __global__ void gemm_fold_kernel(const mdmm_gemm_t g) {
   float s = 0.f;
   for (int z = 0; z < g.split; ++z) s += g.ws[(size_t)z * n + e];
   const int64_t i = e / g.J, j = e % g.J;
-  const float v = s + (g.bias ? g.bias[j] : 0.f);
+  float v = s + (g.bias ? g.bias[j] : 0.f);
+  if (g.flags & MDMM_GEMM_RELU) v = fmaxf(v, 0.f);
   if (g.c_bf16) reinterpret_cast<__bf16*>(g.c)[i * g.ldc + j] = (__bf16)v;
   else reinterpret_cast<float*>(g.c)[i * g.ldc + j] = v;
 }

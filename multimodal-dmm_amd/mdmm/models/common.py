@@ -243,7 +243,10 @@ class _ProbDecoder(nn.Module):
         first = first[0] if isinstance(first, nn.Sequential) else first
         # bf16-stored activations only into a stack the tile kernels take (the audio stacks stay fp32)
         act = ops.conv_chain_takes(first, (z.shape[0],) + tuple(self.feat_shape)) if z.is_cuda else False
-        x = self.z_to_feat[1](ops.plug_linear(self.z_to_feat[0], z, act_out=act)).view(-1, *self.feat_shape)
+        if isinstance(self.z_to_feat[1], nn.ReLU):       # (the ReLU in the GEMM's epilogue on the own kernels)
+            x = ops.plug_linear(self.z_to_feat[0], z, act_out=act, relu=True).view(-1, *self.feat_shape)
+        else:
+            x = self.z_to_feat[1](ops.plug_linear(self.z_to_feat[0], z, act_out=act)).view(-1, *self.feat_shape)
         if logits:      # everything but the final nn.Sigmoid (for the fused sigmoid + BCE loss)
             for layer in list(self.deconv_stack)[:-1]:
                 x = layer(x)

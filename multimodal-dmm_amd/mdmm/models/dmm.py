@@ -321,7 +321,7 @@ class MultiDMM(MultiDGTS):
         return ops.kld_gauss(glb_mean, glb_std, nxt_mean, nxt_std)
 
     # ---- the ELBO step ----------------------------------------------------------------
-    def _decode_for_loss(self, m, z_list, **kw):
+    def _decode_for_loss(self, m, z_list, stacked=False, **kw):
         """Decode modality m for a list of (T,B,D) latents -> list of parameter tuples.
         One batched decoder call.  A decoder that holds BatchNorm in training mode keeps per-pass batch
         statistics, as in the reference (dgts.py:132-145 decodes pass by pass): the stock conv blocks of
@@ -333,11 +333,15 @@ class MultiDMM(MultiDGTS):
         bns = [x for x in dec.modules() if isinstance(x, nn.modules.batchnorm._BatchNorm)] if dec.training else []
         grouped = bool(bns) and self._bn_in_blocks(dec, bns) and os.environ.get('MDMM_BN_GROUPS') != '0'
         if (bns and not grouped) or len(z_list) == 1:
+            if stacked:
+                return None             # (the caller falls back to the per-pass form)
             outs = [self._plug(dec, z.reshape(-1, self.z_dim), **kw) for z in z_list]
             return [tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in o) for o in outs]
         n = len(z_list)
         with ops.bn_groups(n if grouped else 1):
             out = self._plug(dec, torch.stack(z_list).reshape(-1, self.z_dim), **kw)
+        if stacked:                     # the parameter tensors of all passes, pass-major, as they come
+            return out
         # unbind, not r[i]: its backward is ONE stack of the per-pass gradients, where every
         # integer index would zero-fill and add a full-size tensor
         out = [r.reshape(n, t_max, b_dim, *r.shape[1:]).unbind(0) for r in out]
@@ -388,6 +392,10 @@ class MultiDMM(MultiDGTS):
                                   weight=float(mult), into=total)
                 continue
             if self._logit_decoder(m):      # sigmoid + BCE + masks in one pass each way
+                stacked = self._decode_for_loss(m, [zs[p] for p in used], logits=True, stacked=True)
+                if stacked is not None:     # the passes as one batch: scored in place, one gradient buffer
+                    ops.nll_bernoulli_logits(stacked[0], targets[m], mask, 2, float(mult), total, passes=len(used))
+                    continue
                 for rec in self._decode_for_loss(m, [zs[p] for p in used], logits=True):
                     ops.nll_bernoulli_logits(rec[0], targets[m], mask, 2, float(mult), total)
                 continue

@@ -126,6 +126,7 @@ class Bn(C.Structure):
 
 
 BN_STATS, BN_APPLY = 1, 2
+GEMM_RELU = 32
 
 
 class Conv(C.Structure):
@@ -174,7 +175,7 @@ class VrnnLayout(C.Structure):
 
 class Gemm(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('I', 'J', 'L', 'ta', 'tb', 'split', 'a_bf16', 'b_bf16', 'c_bf16',
-                                          'reserved')] +
+                                          'flags')] +
                 [('a', _P), ('lda', C.c_int64), ('b', _P), ('ldb', C.c_int64), ('bias', _P), ('c', _P),
                  ('ldc', C.c_int64), ('ws', _P)])
 

@@ -877,16 +877,26 @@ def nll_bernoulli(theta, x, mask=None, lead_dims=2, weight=1.0, into=None):
 
 
 class _NllBernLogitsFn(torch.autograd.Function):
+    """passes > 1: `logits` holds that many passes one after the other, each scored against the same
+    observations x; the gradient is written pass by pass into one buffer of the batch's shape (decoded as one
+    batch, MultiDMM._decode_for_loss, the passes' gradients never exist as separate tensors that autograd would
+    have to stack)."""
+
     @staticmethod
-    def forward(ctx, logits, x, mask, rows, inner, weight, into):
+    def forward(ctx, logits, x, mask, rows, inner, weight, into, passes=1):
         _need_gpu(logits, x)
         lg, xv = _act(logits), _f32c(x)
+        if lg.numel() != passes * rows * inner:
+            raise ValueError('logits of %d elements for %d passes of %d x %d' % (lg.numel(), passes, rows, inner))
         acc = _term_acc(into, lg.device)
         ctx.bf = lg.dtype == torch.bfloat16
-        _call('mdmm_nll_bernoulli_logits_bf16_fwd' if ctx.bf else 'mdmm_nll_bernoulli_logits_fwd', _ptr(lg), _ptr(xv),
-              _ptr(mask), rows, inner, weight, _ptr(acc), tag='mdmm_nll_bernoulli_logits_fwd')
+        step = rows * inner * lg.element_size()
+        for p in range(passes):
+            _call('mdmm_nll_bernoulli_logits_bf16_fwd' if ctx.bf else 'mdmm_nll_bernoulli_logits_fwd',
+                  lg.data_ptr() + p * step, _ptr(xv), _ptr(mask), rows, inner, weight, _ptr(acc),
+                  tag='mdmm_nll_bernoulli_logits_fwd')
         ctx.save_for_backward(lg, xv)
-        ctx.mask, ctx.rows, ctx.inner, ctx.weight = mask, rows, inner, weight
+        ctx.mask, ctx.rows, ctx.inner, ctx.weight, ctx.passes = mask, rows, inner, weight, passes
         return _term_out(acc, into, lg.device)
 
     @staticmethod
@@ -894,18 +904,22 @@ class _NllBernLogitsFn(torch.autograd.Function):
         lg, xv = ctx.saved_tensors
         gl = torch.empty_like(lg)
         gd = _gdev(g)
-        _call('mdmm_nll_bernoulli_logits_bf16_bwd' if ctx.bf else 'mdmm_nll_bernoulli_logits_bwd', _ptr(lg), _ptr(xv),
-              _ptr(ctx.mask), ctx.rows, ctx.inner, ctx.weight, _ptr(gd), _ptr(gl), tag='mdmm_nll_bernoulli_logits_bwd')
-        return gl, None, None, None, None, None, None
+        step = ctx.rows * ctx.inner * lg.element_size()
+        for p in range(ctx.passes):
+            _call('mdmm_nll_bernoulli_logits_bf16_bwd' if ctx.bf else 'mdmm_nll_bernoulli_logits_bwd',
+                  lg.data_ptr() + p * step, _ptr(xv), _ptr(ctx.mask), ctx.rows, ctx.inner, ctx.weight, _ptr(gd),
+                  gl.data_ptr() + p * step, tag='mdmm_nll_bernoulli_logits_bwd')
+        return gl, None, None, None, None, None, None, None
 
 
-def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None):
+def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None, passes=1):
     """losses.py:23-42 on the pre-sigmoid activations of a decoder whose last module is nn.Sigmoid
-    (common.py:163-165): sigmoid + binary cross entropy + masks in one pass each way."""
+    (common.py:163-165): sigmoid + binary cross entropy + masks in one pass each way.  passes: logits =
+    that many stacked passes, each scored against x (the sum of their terms)."""
     rows = _lead_rows(x, lead_dims)
     inner = x.numel() // rows
     return _term_done(_NllBernLogitsFn.apply(logits, x, _row_mask(mask, rows, x), rows, inner,
-                                             float(weight), into), into)
+                                             float(weight), into, int(passes)), into)
 
 
 def nan_to_zero(x, lead_dims=2):
@@ -1027,15 +1041,16 @@ def _rows(t):
     return t
 
 
-def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.float32):
+def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.float32, relu=False):
     """c (I,J) = bias + A B^T on csrc/gemm_tiles.hip / gemm_heads.hip; a, b are _rows() matrices.  The library
     says into how many slices it cuts the contraction (mdmm_gemm_split; their slabs are summed through ws)."""
     g = native.Gemm()
     g.I, g.J, g.L, g.ta, g.tb, g.split = I, J, L, int(ta), int(tb), 1
     # A/B switches: bit 0 = bf16 operands through the converting path, bit 1 = staggered contraction start,
     # bit 2 = the generic tile kernel where a shape-specialised one (csrc/gemm_heads.hip) would be taken
-    g.reserved = (int(os.environ.get('MDMM_GEMM_NO_RAW') == '1') | (2 * int(os.environ.get('MDMM_GEMM_ROT', '0') == '1'))
-                  | (4 * int(os.environ.get('MDMM_GEMM_GENERIC', '0') == '1')) | (8 * int(os.environ.get('MDMM_GEMM_MODE', '0'))))
+    g.flags = (int(os.environ.get('MDMM_GEMM_NO_RAW') == '1') | (2 * int(os.environ.get('MDMM_GEMM_ROT', '0') == '1'))
+                  | (4 * int(os.environ.get('MDMM_GEMM_GENERIC', '0') == '1')) | (8 * int(os.environ.get('MDMM_GEMM_MODE', '0')))
+                  | (native.GEMM_RELU if relu else 0))
     g.a, g.lda, g.b, g.ldb = _ptr(a), a.stride(0), _ptr(b), b.stride(0)
     g.a_bf16, g.b_bf16 = int(a.dtype == torch.bfloat16), int(b.dtype == torch.bfloat16)
     c = torch.empty(I, J, device=a.device, dtype=out_dtype)
@@ -1116,7 +1131,7 @@ class _LinearTilesFn(torch.autograd.Function):
     generic kernel applies while staging, the weight and its transpose from _lin_pack)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, out_dtype=torch.float32):
+    def forward(ctx, x, weight, bias, out_dtype=torch.float32, relu=False):
         ctx.set_materialize_grads(False)
         x, w = _rows(x), _rows(weight.detach())
         m, k = x.shape
@@ -1135,16 +1150,20 @@ class _LinearTilesFn(torch.autograd.Function):
             # result is bit-identical; bf16 operands read along the contraction are moved as they are
             wf = w.to(torch.bfloat16) if k % 8 == 0 else w
         y = _gemm_bf16(x, False, _rows(wf), False, m, n, k, _f32c(bias.detach()) if bias is not None else None,
-                       tag='linear_fwd[%dx%d]' % (k, n), out_dtype=out_dtype)
-        ctx.save_for_backward(x, weight)
+                       tag='linear_fwd[%dx%d]' % (k, n), out_dtype=out_dtype, relu=relu)
+        # relu: max(., 0) in the kernel's epilogue (the nn.ReLU behind z_to_feat: one pass over the 4096-wide
+        # activation less); its adjoint masks the incoming gradient with y > 0 first
+        ctx.save_for_backward(x, weight, y if relu else None)
         ctx.has_bias, ctx.heads = bias is not None, heads
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors
         if g is None:
-            return None, None, None, None
+            return None, None, None, None, None
+        if y is not None:
+            g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0)
         g = _rows(g)
         w = _rows(weight.detach())
         m, k = x.shape
@@ -1163,24 +1182,27 @@ class _LinearTilesFn(torch.autograd.Function):
             gx = _gemm_bf16(g, False, w, True, m, k, n, tag='linear_dgrad[%dx%d]' % (k, n), out_dtype=gx_dtype)
         if ctx.needs_input_grad[1]:
             gw = _gemm_bf16(g, True, x, True, n, k, m, tag='linear_wgrad[%dx%d]' % (k, n))
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def linear_tiles(x, weight, bias):
     return _LinearTilesFn.apply(x, weight, bias)
 
 
-def plug_linear(layer, x, act_out=False):
+def plug_linear(layer, x, act_out=False, relu=False):
     """An nn.Linear of a stock plug-in: on the own bf16-operand GEMM while conv_operands(bfloat16)
     is active, else the module itself.  act_out: the output is an activation of the conv chain
-    (stored as ACT_STORAGE) rather than a latent-side quantity (always fp32)."""
+    (stored as ACT_STORAGE) rather than a latent-side quantity (always fp32).  relu: followed by nn.ReLU
+    (in the GEMM's epilogue on the own kernels)."""
     if CONV_OPERANDS is torch.bfloat16 and linear_tiles_supported(x, layer.weight):
-        return _LinearTilesFn.apply(x, layer.weight, layer.bias, ACT_STORAGE if act_out else torch.float32)
+        return _LinearTilesFn.apply(x, layer.weight, layer.bias, ACT_STORAGE if act_out else torch.float32, relu)
     if x.dtype != layer.weight.dtype:
         x = x.to(layer.weight.dtype)
     if x.is_cuda and x.dim() == 2 and not torch.is_autocast_enabled():
-        return tall_linear(x, layer)        # (bias gradient on the own column sum, see colsum)
-    return layer(x)
+        y = tall_linear(x, layer)           # (bias gradient on the own column sum, see colsum)
+    else:
+        y = layer(x)
+    return torch.relu(y) if relu else y
 
 
 def tall_projection(x, weight, bias, precision=None):

@@ -115,3 +115,32 @@ def test_heads_through_plug_linear(dev):
     assert rel(g_we, rb(ge).t() @ flat.detach().float()) < 2e-5
     assert rel(g_wd, gd.float().t() @ rb(z.detach())) < 2e-5
     assert rel(g_be, ge.sum(0)) < 1e-5 and rel(g_bd, gd.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('generic', ['0', '1'])
+def test_relu_epilogue(dev, monkeypatch, generic):
+    """ops.plug_linear(..., relu=True): nn.ReLU behind z_to_feat (common.py:141-148) in the GEMM's epilogue
+    (MDMM_GEMM_RELU), on the shape-specialised and on the generic kernel, bf16 and fp32 output, with a split
+    contraction too; the adjoint masks the gradient with y > 0."""
+    import torch.nn as nn
+    from mdmm import ops
+    monkeypatch.setenv('MDMM_GEMM_GENERIC', generic)
+    torch.manual_seed(1)
+    rb = lambda t: t.to(torch.bfloat16).float()      # noqa: E731
+    for (k, n, act) in ((256, 4096, True), (256, 512, False), (4096, 256, False)):
+        lin = nn.Linear(k, n).to(dev)
+        x = torch.randn(1500, k, device=dev)
+        if k > 256:
+            x = x.bfloat16()
+        x.requires_grad_()
+        with ops.conv_operands(torch.bfloat16, torch.bfloat16):
+            y = ops.plug_linear(lin, x, act_out=act, relu=True)
+        ref = torch.relu(rb(x.detach()) @ rb(lin.weight.detach()).t() + lin.bias.detach())
+        assert float(y.float().min()) >= 0.0
+        assert rel(y, ref) < (8e-3 if act else 2e-5)
+        gy = torch.randn_like(y)
+        gx, gw, gb = torch.autograd.grad(y, [x, lin.weight, lin.bias], gy)
+        gm = gy.float() * (y.float() > 0)
+        assert rel(gb, gm.sum(0)) < 1e-5
+        assert rel(gw, rb(gm).t() @ rb(x.detach())) < 2e-5
+        assert rel(gx, rb(gm) @ rb(lin.weight.detach())) < (8e-3 if gx.dtype == torch.bfloat16 else 2e-5)
