@@ -288,6 +288,15 @@ int mdmm_nll_bernoulli_logits_bf16_fwd(const void* logits, const float* x, const
 int mdmm_nll_bernoulli_logits_bf16_bwd(const void* logits, const float* x, const float* seq_mask,
                                        int64_t rows, int inner, float scale, const float* scale_dev,
                                        void* g_logits, void* stream);
+/* `passes` parameter tensors one after the other (logits: passes x rows x inner, fp32 or bf16), each scored against the
+ * same observations -- the passes of one ELBO step (dgts.py:119-129) decoded as one batch; x and the mask are read
+ * once for all of them; the result is the sum of the passes' terms, g_logits has the shape of logits.  */
+int mdmm_nll_bernoulli_logits_passes_fwd(const void* logits, int logits_bf16, int passes, const float* x,
+                                         const float* seq_mask, int64_t rows, int inner, float weight,
+                                         double* out, void* stream);
+int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logits_bf16, int passes, const float* x,
+                                         const float* seq_mask, int64_t rows, int inner, float scale,
+                                         const float* scale_dev, void* g_logits, void* stream);
 /* NaN -> 0 and the per-row "seen" flag of MultiDMM.encode (dmm.py:164-166) in one pass:
  * out[r][i] = isnan(x[r][i]) ? 0 : x[r][i];  seen[r] = no NaN in row r  (float 0 / 1).  */
 int mdmm_nan_to_zero(const float* x, int64_t rows, int inner, float* out, float* seen, void* stream);

@@ -167,9 +167,11 @@ struct RowWalk {
 
 // T = storage type of theta / g_theta (fp32, or bf16 for the logits of the bf16-activation plug-ins)
 template <bool LOGITS, typename T>
+// passes: theta holds that many parameter tensors one after the other (the passes of one ELBO step decoded as
+// one batch), each scored against the same n observations: x and the mask are read once for all of them
 __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
-    float weight, double* out) {
+    float weight, double* out, int passes) {
   float acc = 0.f;
   const bool vec = (inner & 3) == 0 && (n & 3) == 0;
   if (vec) {
@@ -180,20 +182,22 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ thet
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride, rw.next()) {
       if (mask && mask[rw.row] == 0.f) continue;
       const float4 xv = reinterpret_cast<const float4*>(x)[i];
-      const float4 th = ld4f(theta, i);
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-      float ts[4] = {th.x, th.y, th.z, th.w};
+      for (int ps = 0; ps < passes; ++ps) {
+        const float4 th = ld4f(theta, i + ps * n4);
+        float ts[4] = {th.x, th.y, th.z, th.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (xs[j] != xs[j]) continue;
-        if constexpr (LOGITS && sizeof(T) == 2) {
-          const float sp = softplus_fast(ts[j]);                // -log(1 - theta); -log(theta) = sp - l
-          acc += sp - xs[j] * ts[j];
-          continue;
+        for (int j = 0; j < 4; ++j) {
+          if (xs[j] != xs[j]) continue;
+          if constexpr (LOGITS && sizeof(T) == 2) {
+            const float sp = softplus_fast(ts[j]);              // -log(1 - theta); -log(theta) = sp - l
+            acc += sp - xs[j] * ts[j];
+            continue;
+          }
+          if (LOGITS) ts[j] = sigmoid_ref(ts[j]);
+          const float l1 = fmaxf(logf(ts[j]), -100.0f), l0 = fmaxf(log1pf(-ts[j]), -100.0f);
+          acc -= xs[j] * l1 + (1.0f - xs[j]) * l0;            // F.binary_cross_entropy
         }
-        if (LOGITS) ts[j] = sigmoid_ref(ts[j]);
-        const float l1 = fmaxf(logf(ts[j]), -100.0f), l0 = fmaxf(log1pf(-ts[j]), -100.0f);
-        acc -= xs[j] * l1 + (1.0f - xs[j]) * l0;              // F.binary_cross_entropy
       }
     }
   } else {
@@ -201,9 +205,11 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ thet
       const float xv = x[i];
       if (xv != xv) continue;
       if (mask && mask[i / inner] == 0.f) continue;
-      const float th = LOGITS ? sigmoid_ref((float)theta[i]) : (float)theta[i];
-      const float l1 = fmaxf(logf(th), -100.0f), l0 = fmaxf(log1pf(-th), -100.0f);
-      acc -= xv * l1 + (1.0f - xv) * l0;
+      for (int ps = 0; ps < passes; ++ps) {
+        const float th = LOGITS ? sigmoid_ref((float)theta[i + ps * n]) : (float)theta[i + ps * n];
+        const float l1 = fmaxf(logf(th), -100.0f), l0 = fmaxf(log1pf(-th), -100.0f);
+        acc -= xv * l1 + (1.0f - xv) * l0;
+      }
     }
   }
   block_add((double)weight * (double)acc, out);
@@ -234,7 +240,7 @@ __device__ __forceinline__ float nllb_grad(float t, float xv, bool on, float sca
 template <bool LOGITS, typename T>
 __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
-    float scale, const float* __restrict__ scale_dev, T* g_theta) {
+    float scale, const float* __restrict__ scale_dev, T* g_theta, int passes) {
   if (scale_dev) scale *= *scale_dev;
   if ((inner & 3) == 0 && (n & 3) == 0) {
     const int64_t n4 = n >> 2;
@@ -244,15 +250,20 @@ __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ thet
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride, rw.next()) {
       const bool on = !(mask && mask[rw.row] == 0.f);
       const float4 xv = reinterpret_cast<const float4*>(x)[i];
-      const float4 th = ld4f(theta, i);
-      const float g[4] = {nllb_grad<LOGITS, T>(th.x, xv.x, on, scale), nllb_grad<LOGITS, T>(th.y, xv.y, on, scale),
-                          nllb_grad<LOGITS, T>(th.z, xv.z, on, scale), nllb_grad<LOGITS, T>(th.w, xv.w, on, scale)};
-      st4g(g_theta, i, g);
+      for (int ps = 0; ps < passes; ++ps) {
+        const float4 th = ld4f(theta, i + ps * n4);
+        const float g[4] = {nllb_grad<LOGITS, T>(th.x, xv.x, on, scale), nllb_grad<LOGITS, T>(th.y, xv.y, on, scale),
+                            nllb_grad<LOGITS, T>(th.z, xv.z, on, scale), nllb_grad<LOGITS, T>(th.w, xv.w, on, scale)};
+        st4g(g_theta, i + ps * n4, g);
+      }
     }
     return;
   }
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
-    g_theta[i] = (T)nllb_grad<LOGITS, T>((float)theta[i], x[i], !(mask && mask[i / inner] == 0.f), scale);
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    const bool on = !(mask && mask[i / inner] == 0.f);
+    for (int ps = 0; ps < passes; ++ps)
+      g_theta[i + ps * n] = (T)nllb_grad<LOGITS, T>((float)theta[i + ps * n], x[i], on, scale);
+  }
 }
 
 // ---------------------------------------------------------------- nll_categorical --
@@ -469,7 +480,7 @@ extern "C" int mdmm_nll_bernoulli_fwd(const float* theta, const float* x, const 
   if (!theta || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_fwd_kernel<false, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, theta, x,
-                     seq_mask, n, inner, weight, out);
+                     seq_mask, n, inner, weight, out, 1);
   CHECK_LAUNCH();
 }
 
@@ -479,7 +490,7 @@ extern "C" int mdmm_nll_bernoulli_logits_fwd(const float* logits, const float* x
   if (!logits || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_fwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, logits, x,
-                     seq_mask, n, inner, weight, out);
+                     seq_mask, n, inner, weight, out, 1);
   CHECK_LAUNCH();
 }
 
@@ -489,7 +500,7 @@ extern "C" int mdmm_nll_bernoulli_logits_bwd(const float* logits, const float* x
   if (!logits || !x || !g_logits || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_bwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, logits, x, seq_mask,
-                     n, inner, scale, scale_dev, g_logits);
+                     n, inner, scale, scale_dev, g_logits, 1);
   CHECK_LAUNCH();
 }
 
@@ -499,7 +510,7 @@ extern "C" int mdmm_nll_bernoulli_logits_bf16_fwd(const void* logits, const floa
   if (!logits || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_fwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
-                     (const __bf16*)logits, x, seq_mask, n, inner, weight, out);
+                     (const __bf16*)logits, x, seq_mask, n, inner, weight, out, 1);
   CHECK_LAUNCH();
 }
 
@@ -509,7 +520,35 @@ extern "C" int mdmm_nll_bernoulli_logits_bf16_bwd(const void* logits, const floa
   if (!logits || !x || !g_logits || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_bwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, (const __bf16*)logits,
-                     x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits);
+                     x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits, 1);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_bernoulli_logits_passes_fwd(const void* logits, int logits_bf16, int passes, const float* x,
+                                                    const float* seq_mask, int64_t rows, int inner, float weight,
+                                                    double* out, void* stream) {
+  if (!logits || !x || !out || rows < 0 || inner < 1 || passes < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  if (logits_bf16)
+    hipLaunchKernelGGL((nllb_fwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
+                       (const __bf16*)logits, x, seq_mask, n, inner, weight, out, passes);
+  else
+    hipLaunchKernelGGL((nllb_fwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
+                       (const float*)logits, x, seq_mask, n, inner, weight, out, passes);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logits_bf16, int passes, const float* x,
+                                                    const float* seq_mask, int64_t rows, int inner, float scale,
+                                                    const float* scale_dev, void* g_logits, void* stream) {
+  if (!logits || !x || !g_logits || rows < 0 || inner < 1 || passes < 1) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  if (logits_bf16)
+    hipLaunchKernelGGL((nllb_bwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
+                       (const __bf16*)logits, x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits, passes);
+  else
+    hipLaunchKernelGGL((nllb_bwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
+                       (const float*)logits, x, seq_mask, n, inner, scale, scale_dev, (float*)g_logits, passes);
   CHECK_LAUNCH();
 }
 
@@ -519,7 +558,7 @@ extern "C" int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const 
   if (!theta || !x || !g_theta || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_bwd_kernel<false, float>), dim3(grid_for(n)), dim3(NT), 0, STREAM, theta, x, seq_mask,
-                     n, inner, scale, scale_dev, g_theta);
+                     n, inner, scale, scale_dev, g_theta, 1);
   CHECK_LAUNCH();
 }
 

@@ -890,11 +890,8 @@ class _NllBernLogitsFn(torch.autograd.Function):
             raise ValueError('logits of %d elements for %d passes of %d x %d' % (lg.numel(), passes, rows, inner))
         acc = _term_acc(into, lg.device)
         ctx.bf = lg.dtype == torch.bfloat16
-        step = rows * inner * lg.element_size()
-        for p in range(passes):
-            _call('mdmm_nll_bernoulli_logits_bf16_fwd' if ctx.bf else 'mdmm_nll_bernoulli_logits_fwd',
-                  lg.data_ptr() + p * step, _ptr(xv), _ptr(mask), rows, inner, weight, _ptr(acc),
-                  tag='mdmm_nll_bernoulli_logits_fwd')
+        _call('mdmm_nll_bernoulli_logits_passes_fwd', _ptr(lg), int(ctx.bf), passes, _ptr(xv), _ptr(mask), rows, inner,
+              weight, _ptr(acc), tag='mdmm_nll_bernoulli_logits_fwd')
         ctx.save_for_backward(lg, xv)
         ctx.mask, ctx.rows, ctx.inner, ctx.weight, ctx.passes = mask, rows, inner, weight, passes
         return _term_out(acc, into, lg.device)
@@ -904,11 +901,8 @@ class _NllBernLogitsFn(torch.autograd.Function):
         lg, xv = ctx.saved_tensors
         gl = torch.empty_like(lg)
         gd = _gdev(g)
-        step = ctx.rows * ctx.inner * lg.element_size()
-        for p in range(ctx.passes):
-            _call('mdmm_nll_bernoulli_logits_bf16_bwd' if ctx.bf else 'mdmm_nll_bernoulli_logits_bwd',
-                  lg.data_ptr() + p * step, _ptr(xv), _ptr(ctx.mask), ctx.rows, ctx.inner, ctx.weight, _ptr(gd),
-                  gl.data_ptr() + p * step, tag='mdmm_nll_bernoulli_logits_bwd')
+        _call('mdmm_nll_bernoulli_logits_passes_bwd', _ptr(lg), int(ctx.bf), ctx.passes, _ptr(xv), _ptr(ctx.mask),
+              ctx.rows, ctx.inner, ctx.weight, _ptr(gd), _ptr(gl), tag='mdmm_nll_bernoulli_logits_bwd')
         return gl, None, None, None, None, None, None, None
 
 

@@ -206,3 +206,29 @@ def test_batchnorm_groups_equal_separate_calls(dev, dtype, groups):
     assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == groups
     assert helpers.rel_err(bn_a.running_mean, bn_b.running_mean) < 1e-6
     assert helpers.rel_err(bn_a.running_var, bn_b.running_var) < 1e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('inner', [3 * 8 * 8, 7])
+def test_bernoulli_logits_stacked_passes(dev, dtype, inner):
+    """ops.nll_bernoulli_logits(..., passes=P) on P stacked parameter tensors = the sum of P calls on the passes
+    (losses.py:23-42 per pass, dgts.py:119-129): value and the gradient, written into one buffer of the
+    batch's shape; missing observations (NaN) and padded rows as in the per-pass form."""
+    from mdmm import ops
+    torch.manual_seed(inner)
+    T, B, P = 5, 6, 3
+    x = torch.rand(T, B, inner, device=dev)
+    x[1, 2] = float('nan')
+    x[3, :, 0] = float('nan')
+    mask = torch.ones(T, B, dtype=torch.bool, device=dev)
+    mask[4, 3:] = False
+    lg = (torch.randn(P * T * B, inner, device=dev) * 3).to(dtype)
+    a = lg.clone().requires_grad_()
+    la = ops.nll_bernoulli_logits(a, x, mask, 2, 0.7, None, passes=P)
+    ga, = torch.autograd.grad(la, a)
+    b = lg.clone().requires_grad_()
+    lb = sum(ops.nll_bernoulli_logits(c, x, mask, 2, 0.7, None) for c in b.chunk(P))
+    gb, = torch.autograd.grad(lb, b)
+    assert ga.dtype == dtype and ga.shape == a.shape
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
+    assert torch.equal(ga, gb)
