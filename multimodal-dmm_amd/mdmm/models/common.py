@@ -17,12 +17,17 @@ import torch.nn.functional as F
 
 def _lin(x, layer):
     """Linear holder applied through the split-K weight-gradient path on the GPU."""
+    if x.is_cuda and x.dim() > 2 and not torch.is_autocast_enabled() and x.dtype == layer.weight.dtype:
+        # leading dimensions (the (T*B, 1, h) output of the Categorical encoders' nn.Embedding): as rows
+        return _lin(x.reshape(-1, x.shape[-1]), layer).reshape(*x.shape[:-1], layer.weight.shape[0])
     if x.is_cuda and x.dim() == 2 and not torch.is_autocast_enabled() and x.dtype == layer.weight.dtype:
         from .. import ops
         # with the model's projections switched to bf16 operands (MultiDGTS.conv_dtype), the wide layers
         # of the stock MLP holders run on the own GEMM like the image plug-ins' heads
         if ops.CONV_OPERANDS is torch.bfloat16 and ops.linear_tiles_supported(x, layer.weight):
             return ops.linear_tiles(x, layer.weight, layer.bias)
+        if ops.CONV_OPERANDS is torch.bfloat16 and ops.linear_tiles_thin_supported(x, layer.weight):
+            return ops.linear_tiles_thin(x, layer.weight, layer.bias)       # (the 10-wide layers: zero-padded)
         return ops.tall_linear(x, layer)
     return layer(x)         # under autocast (plugin_dtype) the stock module casts for itself
 

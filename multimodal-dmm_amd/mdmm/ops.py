@@ -1016,6 +1016,10 @@ def tall_linear(x, layer):
     """Apply an nn.Linear holder to a (rows, in) activation through _TallLinearFn."""
     if x.dim() != 2 or not x.is_floating_point():
         return layer(x)
+    if os.environ.get('MDMM_TRACE_LIB') == '1':         # which layers still reach the library's GEMM
+        import sys
+        print('tall_linear (library GEMM): x %s %s -> %d, conv_operands %s' % (tuple(x.shape), x.dtype, layer.weight.shape[0],
+                                                                              CONV_OPERANDS), file=sys.stderr, flush=True)
     return _TallLinearFn.apply(x, layer.weight, layer.bias)
 
 
@@ -1095,6 +1099,37 @@ def linear_tiles_supported(x, weight):
     m, k = x.shape
     n = weight.shape[0]
     return m >= 512 and m % 4 == 0 and k % 4 == 0 and n % 4 == 0 and k >= 32 and n >= 32
+
+
+def linear_tiles_thin_supported(x, weight):
+    """A Linear with a thin side (the 10-wide layers of the Categorical modality's stock MLPs, common.py:9-41:
+    10 -> 256 and 256 -> 10) that the own GEMM takes once that side is zero-padded to 32."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32):
+        return False
+    if torch.is_autocast_enabled():
+        return False
+    m, k = x.shape
+    n = weight.shape[0]
+    thin_k, thin_n = (k < 32 or k % 4 != 0), (n < 32 or n % 4 != 0)
+    return m >= 512 and m % 4 == 0 and (thin_k or thin_n) and max(k, n) >= 32 and (thin_k or k % 4 == 0) and (thin_n or n % 4 == 0)
+
+
+def linear_tiles_thin(x, weight, bias):
+    """y = x W^T + b on csrc/gemm_tiles.hip with the thin side padded by zeros (plain differentiable pads and a
+    slice around _LinearTilesFn: the padded weight rows / columns meet zeros and receive zero gradients)."""
+    import torch.nn.functional as F
+    m, k = x.shape
+    n = weight.shape[0]
+    kp = k if (k >= 32 and k % 4 == 0) else max(32, (k + 3) // 4 * 4)
+    np_ = n if (n >= 32 and n % 4 == 0) else max(32, (n + 3) // 4 * 4)
+    if kp != k:
+        x = F.pad(x, (0, kp - k))
+        weight = F.pad(weight, (0, kp - k))
+    if np_ != n:
+        weight = F.pad(weight, (0, 0, 0, np_ - n))
+        bias = F.pad(bias, (0, np_ - n)) if bias is not None else None
+    y = _LinearTilesFn.apply(x, weight, bias)
+    return y[:, :n] if np_ != n else y
 
 
 def _heads_shape(k, n):

@@ -144,3 +144,26 @@ def test_relu_epilogue(dev, monkeypatch, generic):
         assert rel(gb, gm.sum(0)) < 1e-5
         assert rel(gw, rb(gm).t() @ rb(x.detach())) < 2e-5
         assert rel(gx, rb(gm) @ rb(lin.weight.detach())) < (8e-3 if gx.dtype == torch.bfloat16 else 2e-5)
+
+
+@pytest.mark.parametrize('k,n', [(256, 10), (10, 256), (256, 30), (37, 64)])
+def test_thin_linear_padded(dev, k, n):
+    """ops.linear_tiles_thin: the 10-wide layers of the Categorical modality's stock MLPs (common.py:9-41) on the
+    own GEMM with the thin side zero-padded -- values and all three gradients against torch on the bf16-rounded
+    operands; the padding rows / columns leave no trace."""
+    import torch.nn as nn
+    from mdmm import ops
+    torch.manual_seed(k + n)
+    rb = lambda t: t.to(torch.bfloat16).float()      # noqa: E731
+    lin = nn.Linear(k, n).to(dev)
+    x = torch.randn(2048, k, device=dev, requires_grad=True)
+    assert ops.linear_tiles_thin_supported(x, lin.weight) and not ops.linear_tiles_supported(x, lin.weight)
+    y = ops.linear_tiles_thin(x, lin.weight, lin.bias)
+    assert tuple(y.shape) == (2048, n)
+    assert rel(y, rb(x.detach()) @ rb(lin.weight.detach()).t() + lin.bias.detach()) < 2e-5
+    gy = torch.randn(2048, n, device=dev)
+    gx, gw, gb = torch.autograd.grad(y, [x, lin.weight, lin.bias], gy)
+    assert tuple(gw.shape) == (n, k) and tuple(gx.shape) == (2048, k)
+    assert rel(gx, rb(gy) @ rb(lin.weight.detach())) < 2e-5
+    assert rel(gw, rb(gy).t() @ rb(x.detach())) < 2e-5
+    assert rel(gb, gy.sum(0)) < 1e-5
