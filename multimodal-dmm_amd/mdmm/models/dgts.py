@@ -80,6 +80,27 @@ class MultiDGTS(nn.Module):
         return (self.dists[m] == 'Bernoulli' and isinstance(self.dec[m], common._ProbDecoder)
                 and self.plugin_dtype is None and not torch.is_autocast_enabled())
 
+    @staticmethod
+    def _bn_in_blocks(dec, bns):
+        """Every BatchNorm of the module sits inside a conv block of models.common (the ones that honour
+        ops.bn_groups)."""
+        from . import common
+        inside = set()
+        for blk in dec.modules():
+            if isinstance(blk, common._ConvBlock) and isinstance(blk.net, nn.Sequential):
+                inside.add(id(blk.net[1]))
+        return all(id(b) in inside for b in bns)
+
+    def _grouped_bn_decoder(self, dec):
+        """True when the decoder's training-mode BatchNorm layers all honour ops.bn_groups (or it has none): the
+        passes of a modality may then be decoded as ONE batch with per-pass statistics."""
+        import os
+        bns = [x for x in dec.modules() if isinstance(x, nn.modules.batchnorm._BatchNorm)] if dec.training else []
+        if not bns:
+            return True, False
+        ok = self._bn_in_blocks(dec, bns) and os.environ.get('MDMM_BN_GROUPS') != '0'
+        return ok, ok
+
     def _noise(self):
         if self.noise is None:
             self.noise = PhiloxNoise()

@@ -259,6 +259,15 @@ class MultiDKS(MultiDGTS):
             used = [p for p, mods in enumerate(loss_mods) if m in mods]
             if mult == 0 or not used:
                 continue
+            batched, groups = self._grouped_bn_decoder(self.dec[m])
+            if self._logit_decoder(m) and batched and len(used) > 1:
+                # the passes that score this modality as ONE decoder call (per-pass BatchNorm statistics:
+                # ops.bn_groups) and one loss launch each way, as MultiDMM._decode_for_loss
+                zs = torch.stack([z[:, p * b_dim:(p + 1) * b_dim] for p in used]).reshape(-1, self.z_dim)
+                with ops.bn_groups(len(used) if groups else 1):
+                    lg = self._plug(self.dec[m], zs, logits=True)[0]
+                ops.nll_bernoulli_logits(lg, targets[m], mask, 2, float(mult), total, passes=len(used))
+                continue
             for p in used:
                 zp = z[:, p * b_dim:(p + 1) * b_dim].reshape(-1, self.z_dim)
                 if self._logit_decoder(m):      # sigmoid + BCE + masks in one pass each way

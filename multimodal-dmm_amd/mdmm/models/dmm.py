@@ -347,16 +347,6 @@ class MultiDMM(MultiDGTS):
         out = [r.reshape(n, t_max, b_dim, *r.shape[1:]).unbind(0) for r in out]
         return [tuple(r[i] for r in out) for i in range(n)]
 
-    @staticmethod
-    def _bn_in_blocks(dec, bns):
-        """Every BatchNorm of the module sits inside a conv block of models.common (the ones that honour
-        ops.bn_groups)."""
-        inside = set()
-        for blk in dec.modules():
-            if isinstance(blk, common._ConvBlock) and isinstance(blk.net, nn.Sequential):
-                inside.add(id(blk.net[1]))
-        return all(id(b) in inside for b in bns)
-
     def _fused_nll(self, m, z):
         dec = self.dec[m]
         return (self.dists[m] == 'Normal' and type(dec) is common.GaussianMLP
