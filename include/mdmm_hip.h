@@ -489,16 +489,18 @@ typedef struct mdmm_bn {
    * pass then normalises with the global mean / variance (forward; running statistics from them too) or
    * forms dx with the global means of g and g xhat (backward; dgamma / dbeta stay this rank's own sums,
    * the gradient all-reduce adds them up).  phase = 0 and global_sums = NULL: one rank, both passes.  */
-  int32_t phase;
+  int32_t phase;         /* 0, MDMM_BN_STATS, MDMM_BN_APPLY, or MDMM_BN_FINALIZE: reduction pass + save_mean / save_invstd /
+                          * running statistics, no y (the consumer normalises on the fly: mdmm_conv_t.in_mean) */
   int32_t groups;        /* > 1: x holds `groups` batches of N images one after the other, each normalised with its own
                           * statistics (save_mean / save_invstd: [groups][C]; partial: groups x C x splits x 2), the running
                           * statistics updated group by group, dgamma / dbeta summed over them -- successive calls of the
-                          * stock module (one per pass, dgts.py:132-145) as one launch.  One rank, phase 0 only.  */
+                          * stock module (one per pass, dgts.py:132-145) as one launch.  One rank; phase 0 or MDMM_BN_FINALIZE.  */
   const double* global_sums;
   double global_count;
 } mdmm_bn_t;
 #define MDMM_BN_STATS 1
 #define MDMM_BN_APPLY 2
+#define MDMM_BN_FINALIZE 3
 int mdmm_bn_splits(int64_t N, int C, int64_t L);
 int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream);
 int mdmm_bn_relu_bwd(const mdmm_bn_t* a, void* stream);
@@ -524,6 +526,18 @@ typedef struct mdmm_conv {
   void* big;             /* (N, CB, 2S, 2S)  fp32 or bf16 */
   const void* wfrag;
   const float* bias;
+  /* Training-mode BatchNorm + ReLU of the block in front (common.py:70-112: Conv/Deconv -> BatchNorm -> ReLU)
+   * applied to the SMALL side while it is staged (mdmm_conv_up: the Deconv's input; mdmm_conv_wgrad with a small
+   * side that is the layer's input): small holds the block's PRE-normalisation output, the kernel forms
+   * max(0, x * gamma[c] * invstd[g][c] + (beta[c] - mean[g][c] * gamma[c] * invstd[g][c])) per element with the
+   * arithmetic of mdmm_bn_relu_fwd's apply pass and rounds it to the small side's storage type -- the normalised
+   * activation never travels through HBM.  in_mean / in_invstd: [groups][CS] (mdmm_bn_t.save_mean / save_invstd
+   * of a phase = MDMM_BN_FINALIZE call), image n belongs to group n / in_group_n; NULL in_mean: no transform.  */
+  const float* in_mean;
+  const float* in_invstd;
+  const float* in_gamma;  /* (CS) or NULL = 1 */
+  const float* in_beta;   /* (CS) or NULL = 0 */
+  int32_t in_group_n, in_relu;
 } mdmm_conv_t;
 int mdmm_conv_supported(const mdmm_conv_t* args);
 int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* args, int up);

@@ -184,8 +184,10 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
   }
   x += (size_t)grp * N * C * L;
   y += (size_t)grp * N * C * L;
+  if (!y) return;                                // MDMM_BN_FINALIZE: the consumer normalises (mdmm_conv_t.in_mean)
   const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
-  const float scale = g * invstd, shift = b - (float)mean * scale;
+  // (one rounding each, spelled out: csrc/conv_tiles.hip forms the same two numbers from save_mean / save_invstd)
+  const float scale = g * invstd, shift = fmaf(-(float)mean, scale, b);
   const Span sp = span_of(N);
   if (VEC) {
     constexpr int W = VecW<T>::W;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_stats_kernel(const T* __restrict__ 
   partial += (size_t)blockIdx.z * C * gridDim.y * 2;
   const float mean = save_mean[(size_t)blockIdx.z * C + c], invstd = save_invstd[(size_t)blockIdx.z * C + c];
   const float g_ = gamma ? gamma[c] : 1.0f, b_ = beta ? beta[c] : 0.0f;
-  const float scale = g_ * invstd, shift = b_ - mean * scale;     // as the forward pass forms them
+  const float scale = g_ * invstd, shift = fmaf(-mean, scale, b_);     // as the forward pass forms them
   const Span sp = span_of(N);
   float s1 = 0.f, s2 = 0.f;
   double d1 = 0, d2 = 0;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
   dy += goff; x += goff; dx += goff;
   const float mean = save_mean[(size_t)grp * C + c], invstd = save_invstd[(size_t)grp * C + c];
   const float g_ = gamma ? gamma[c] : 1.0f, b_ = beta ? beta[c] : 0.0f;
-  const float k = g_ * invstd, shift = b_ - mean * k;
+  const float k = g_ * invstd, shift = fmaf(-mean, k, b_);
   const Span sp = span_of(N);
   auto one = [&](float dyv, float xv) {
     const float xh = (xv - mean) * invstd;
@@ -363,9 +365,9 @@ int check(const mdmm_bn_t* a) {
   if (!a || a->N < 1 || a->C < 1 || a->L < 1 || !a->x || !a->partial || !a->save_mean || !a->save_invstd)
     return MDMM_E_ARG;
   if (a->splits < 1 || a->splits > 65535) return MDMM_E_ARG;
-  if (a->phase < 0 || a->phase > MDMM_BN_APPLY) return MDMM_E_ARG;
+  if (a->phase < 0 || a->phase > MDMM_BN_FINALIZE) return MDMM_E_ARG;
   if (a->global_sums && !(a->global_count >= 1.0)) return MDMM_E_ARG;
-  if (a->groups < 0 || a->groups > 65535 || (a->groups > 1 && (a->phase != 0 || a->global_sums))) return MDMM_E_ARG;
+  if (a->groups < 0 || a->groups > 65535 || (a->groups > 1 && ((a->phase != 0 && a->phase != MDMM_BN_FINALIZE) || a->global_sums))) return MDMM_E_ARG;
   return 0;
 }
 
@@ -390,7 +392,8 @@ void launch_fwd(const mdmm_bn_t* a, hipStream_t st) {
   if (a->phase != MDMM_BN_STATS)
     hipLaunchKernelGGL((bn_apply_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->x, a->N, a->C, a->L, a->partial,
                        a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
-                       a->mean_shift, (T*)a->y, a->save_mean, a->save_invstd, a->global_sums, a->global_count);
+                       a->mean_shift, a->phase == MDMM_BN_FINALIZE ? (T*)nullptr : (T*)a->y, a->save_mean, a->save_invstd,
+                       a->global_sums, a->global_count);
 }
 template <bool VEC, typename T>
 void launch_bwd(const mdmm_bn_t* a, hipStream_t st) {
@@ -409,7 +412,7 @@ void launch_bwd(const mdmm_bn_t* a, hipStream_t st) {
 extern "C" int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream) {
   int rc = check(a);
   if (rc) return rc;
-  if (!a->y && a->phase != MDMM_BN_STATS) return MDMM_E_ARG;
+  if (!a->y && a->phase != MDMM_BN_STATS && a->phase != MDMM_BN_FINALIZE) return MDMM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (a->bf16_io) { if (vec_ok(a)) launch_fwd<true, __bf16>(a, st); else launch_fwd<false, __bf16>(a, st); }
   else { if (vec_ok(a)) launch_fwd<true, float>(a, st); else launch_fwd<false, float>(a, st); }

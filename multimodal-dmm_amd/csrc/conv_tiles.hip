@@ -64,6 +64,27 @@ __device__ __forceinline__ void store1(void* base, size_t idx, float v) {
   else reinterpret_cast<float*>(base)[idx] = v;
 }
 
+// BatchNorm + ReLU of the block in front, applied while the layer's input is staged (mdmm_conv_t.in_mean): a table
+// [group][scale | shift][channel] in LDS behind the kernel's images, formed from the saved statistics exactly as
+// batchnorm.hip's apply pass forms them; norm1 = its per-element arithmetic and storage rounding.
+constexpr int NORM_GROUPS = 8;
+template <int C>
+__device__ __forceinline__ void norm_table(const mdmm_conv_t& a, float* tab, int nthreads) {
+  const int groups = (a.N + a.in_group_n - 1) / a.in_group_n;
+  for (int i = threadIdx.x; i < groups * C; i += nthreads) {
+    const int g = i / C, c = i % C;
+    const float gm = a.in_gamma ? a.in_gamma[c] : 1.0f, bt = a.in_beta ? a.in_beta[c] : 0.0f;
+    const float scale = gm * a.in_invstd[i];
+    tab[(2 * g) * C + c] = scale;
+    tab[(2 * g + 1) * C + c] = fmaf(-a.in_mean[i], scale, bt);
+  }
+}
+__device__ __forceinline__ __bf16 norm1(__bf16 v, float scale, float shift, bool relu) {
+  float f = fmaf((float)v, scale, shift);
+  if (relu) f = fmaxf(f, 0.f);
+  return (__bf16)f;
+}
+
 template <int S, int CS, int CB>
 struct Shape {
   static constexpr int CBP = CB;                          // big-side channels as staged (4 = padded 1..4)
@@ -153,8 +174,8 @@ __device__ __forceinline__ void up_fetch(const mdmm_conv_t& a, int n, UpStage<S,
     for (int j = 0; j < 8; ++j) st.u[q][j] = load4<SB>(a.small, src0 + (size_t)(cg * 8 + j) * U::NPIX + p);
   }
 }
-template <int S, int CS, int CB>
-__device__ __forceinline__ void up_commit(char* smem, const UpStage<S, CS>& st) {
+template <int S, int CS, int CB, bool NORM = false>
+__device__ __forceinline__ void up_commit(char* smem, const UpStage<S, CS>& st, const float* tab = nullptr, bool relu = false) {
   using U = UpStage<S, CS>;
   using G = Shape<S, CS, CB>;
 #pragma unroll
@@ -163,8 +184,17 @@ __device__ __forceinline__ void up_commit(char* smem, const UpStage<S, CS>& st) 
     if (U::ITEMS % 256 != 0 && it >= U::ITEMS) continue;
     const int p = 4 * (it % (U::NPIX / 4)), cg = it / (U::NPIX / 4), y = p / S, x = p % S;
     bf16x8 v0, v1, v2, v3;
+    if constexpr (NORM) {               // this image's group: tab = [scale | shift][CS]
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { v0[j] = st.u[q][j][0]; v1[j] = st.u[q][j][1]; v2[j] = st.u[q][j][2]; v3[j] = st.u[q][j][3]; }
+      for (int j = 0; j < 8; ++j) {
+        const float sc = tab[cg * 8 + j], sh = tab[CS + cg * 8 + j];
+        v0[j] = norm1(st.u[q][j][0], sc, sh, relu); v1[j] = norm1(st.u[q][j][1], sc, sh, relu);
+        v2[j] = norm1(st.u[q][j][2], sc, sh, relu); v3[j] = norm1(st.u[q][j][3], sc, sh, relu);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v0[j] = st.u[q][j][0]; v1[j] = st.u[q][j][1]; v2[j] = st.u[q][j][2]; v3[j] = st.u[q][j][3]; }
+    }
     char* at = smem + ((y + 1) * G::UP_PW + x + 1) * G::UP_PS + cg * 16;
     *reinterpret_cast<uint4*>(at) = __builtin_bit_cast(uint4, v0);
     *reinterpret_cast<uint4*>(at + G::UP_PS) = __builtin_bit_cast(uint4, v1);
@@ -173,10 +203,12 @@ __device__ __forceinline__ void up_commit(char* smem, const UpStage<S, CS>& st) 
   }
 }
 
-template <int S, int CS, int CB, bool SB, bool BB>
+template <int S, int CS, int CB, bool SB, bool BB, bool NORM = false>
 __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   using G = Shape<S, CS, CB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const ntab = reinterpret_cast<float*>(smem + G::UP_LDS);
+  if constexpr (NORM) norm_table<CS>(a, ntab, 256);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
   const int py = wave >> 1, px = wave & 1, cb = a.CB;
   // this class's weights stay in registers for the whole kernel
@@ -198,7 +230,8 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   UpStage<S, CS> stage;
   if ((int)blockIdx.x < a.N) up_fetch<S, CS, SB>(a, blockIdx.x, stage);
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
-    up_commit<S, CS, CB>(smem, stage);
+    if constexpr (NORM) up_commit<S, CS, CB, true>(smem, stage, ntab + (size_t)(n / a.in_group_n) * 2 * CS, a.in_relu != 0);
+    else up_commit<S, CS, CB>(smem, stage);
     __syncthreads();
     if (n + (int)gridDim.x < a.N) up_fetch<S, CS, SB>(a, n + gridDim.x, stage);
     const size_t dst0 = (size_t)n * cb * (4 * NPIX);
@@ -383,11 +416,12 @@ struct Wg {
 
 __device__ __forceinline__ uint32_t shift16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbyte(hi, lo, 2); }
 
-template <int S, int CS, int CB, int KS, bool SB, bool BB>
+template <int S, int CS, int CB, int KS, bool SB, bool BB, bool NORM = false>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, float* part, int NT) {
   using G = Shape<S, CS, CB>;
   using W = Wg<S, CS, CB, KS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const ntab = reinterpret_cast<float*>(smem + ((W::LDS + 15) & ~15));
   char* sm = smem;
   char* pl = smem + W::SM_LDS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, cb = a.CB;
@@ -404,6 +438,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   for (int i = threadIdx.x; i < W::LDS / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
+  if constexpr (NORM) norm_table<CS>(a, ntab, 512);
   // per job: this lane's column -> byte offset of its plane rows (or -1) and its shift (-1, 0, +1)
   int col_off[MAXJ], col_sh[MAXJ];
   bool mt_of[MAXJ];
@@ -455,12 +490,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
       }
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int n_img) {
 #pragma unroll
     for (int q = 0; q < SM_IT; ++q) {
       const int it = threadIdx.x + 512 * q;
-      if (it < CS * NPIX / 8)
-        *reinterpret_cast<uint4*>(sm + (it / (NPIX / 8)) * W::SM_RS + (it % (NPIX / 8)) * 16) = __builtin_bit_cast(uint4, rs[q]);
+      if (it < CS * NPIX / 8) {
+        bf16x8 v = rs[q];
+        if constexpr (NORM) {           // the small side is the layer's input: the block in front's BatchNorm + ReLU
+          const float* tab = ntab + (size_t)(n_img / a.in_group_n) * 2 * CS;
+          const int ch = it / (NPIX / 8);
+          const float sc = tab[ch], sh = tab[CS + ch];
+          const bool relu = a.in_relu != 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = norm1(v[j], sc, sh, relu);
+        }
+        *reinterpret_cast<uint4*>(sm + (it / (NPIX / 8)) * W::SM_RS + (it % (NPIX / 8)) * 16) = __builtin_bit_cast(uint4, v);
+      }
     }
 #pragma unroll
     for (int q = 0; q < BG_IT; ++q) {
@@ -478,7 +523,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   };
   if ((int)blockIdx.x < a.N) fetch(blockIdx.x);
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
-    commit();
+    commit(n);
     __syncthreads();
     if (n + (int)gridDim.x < a.N) fetch(n + gridDim.x);
     for (int c = idle ? W::KCH : my_ks; c < W::KCH; c += ksplit) {
@@ -597,6 +642,10 @@ int io_of(const mdmm_conv_t* a) {
   const bool sb = a->flags & MDMM_CONV_SMALL_BF16, bb = a->flags & MDMM_CONV_BIG_BF16;
   return sb ? (bb ? 1 : 2) : (bb ? -1 : 0);
 }
+constexpr int NORM_LDS(int channels) { return NORM_GROUPS * 2 * channels * 4; }
+bool norm_ok(const mdmm_conv_t* a) {
+  return a->in_invstd && a->in_group_n >= 1 && (a->N + a->in_group_n - 1) / a->in_group_n <= NORM_GROUPS;
+}
 template <int S, int CS, int CB, bool SB, bool BB>
 int run_up_io(const mdmm_conv_t* a, hipStream_t st) {
   using G = Shape<S, CS, CB>;
@@ -606,8 +655,21 @@ int run_up_io(const mdmm_conv_t* a, hipStream_t st) {
   hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2)), dim3(256), G::UP_LDS, st, *a);
   return (int)hipGetLastError();
 }
+// the small side normalised while it is staged (in_mean): bf16 activations on both sides only
+template <int S, int CS, int CB>
+int run_up_norm(const mdmm_conv_t* a, hipStream_t st) {
+  using G = Shape<S, CS, CB>;
+  if (io_of(a) != 1 || !norm_ok(a)) return MDMM_E_ARG;
+  auto k = conv_up_kernel<S, CS, CB, true, true, true>;
+  constexpr int lds = G::UP_LDS + NORM_LDS(CS);
+  int rc = set_lds(k, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2)), dim3(256), lds, st, *a);
+  return (int)hipGetLastError();
+}
 template <int S, int CS, int CB>
 int run_up(const mdmm_conv_t* a, hipStream_t st) {
+  if (a->in_mean) return run_up_norm<S, CS, CB>(a, st);
   switch (io_of(a)) {
     case 0: return run_up_io<S, CS, CB, false, false>(a, st);
     case 1: return run_up_io<S, CS, CB, true, true>(a, st);
@@ -649,7 +711,19 @@ int run_wgrad_io(const mdmm_conv_t* a, float* part, hipStream_t st) {
   return (int)hipGetLastError();
 }
 template <int S, int CS, int CB, int KS>
+int run_wgrad_norm(const mdmm_conv_t* a, float* part, hipStream_t st) {
+  using W = Wg<S, CS, CB, KS>;
+  if (io_of(a) != 1 || !norm_ok(a)) return MDMM_E_ARG;
+  auto k = conv_wgrad_kernel<S, CS, CB, KS, true, true, true>;
+  constexpr int lds = ((W::LDS + 15) & ~15) + NORM_LDS(CS);
+  int rc = set_lds(k, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k, dim3(wgrad_parts(a)), dim3(512), lds, st, *a, part, wgrad_nt(a));
+  return (int)hipGetLastError();
+}
+template <int S, int CS, int CB, int KS>
 int run_wgrad(const mdmm_conv_t* a, float* part, hipStream_t st) {
+  if (a->in_mean) return run_wgrad_norm<S, CS, CB, KS>(a, part, st);
   switch (io_of(a)) {
     case 0: return run_wgrad_io<S, CS, CB, KS, false, false>(a, part, st);
     case 1: return run_wgrad_io<S, CS, CB, KS, true, true>(a, part, st);
@@ -714,6 +788,7 @@ extern "C" int mdmm_conv_up(const mdmm_conv_t* a, void* stream) {
 extern "C" int mdmm_conv_down(const mdmm_conv_t* a, void* stream) {
   int rc = check_io(a);
   if (rc) return rc;
+  if (a->in_mean) return MDMM_E_ARG;            // (input normalisation: the small side of up / wgrad only)
   if (!a->wfrag) return MDMM_E_ARG;
   if (((uintptr_t)a->wfrag) & 15) return MDMM_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;

@@ -118,6 +118,21 @@ class _ConvBlock(nn.Module):
                   layer.groups, layer.dilation)
 
     def forward(self, x):
+        from .. import ops
+        pending = x if isinstance(x, ops.DeferredNorm) else None
+        if pending is not None:
+            # the block in front left its BatchNorm + ReLU to this one (ops.bn_defer): a Deconv on the tile kernels
+            # normalises while it stages its input, anything else takes the materialised activation
+            layer = self.net[0] if isinstance(self.net, nn.Sequential) else self.net
+            if ops.bn_deconv_supported(pending, layer):
+                if isinstance(self.net, nn.Sequential):
+                    bn = self.net[1]
+                    y_pre = ops.bn_deconv(pending, layer, bias=False)
+                    if ops.BN_DEFER and ops.batchnorm_relu_supported(y_pre, bn):
+                        return ops.DeferredNorm(y_pre, bn, layer.bias)
+                    return ops.batchnorm_relu(y_pre, bn, shift=layer.bias)
+                return ops.bn_deconv(pending, layer)
+            x = pending.tensor()
         if isinstance(self.net, nn.Sequential):
             layer, bn = self.net[0], self.net[1]
             # BatchNorm + ReLU in training mode: two fused streaming passes each way
@@ -125,9 +140,11 @@ class _ConvBlock(nn.Module):
             # convolution's bias cancels in the normalisation: it is not added (one pass over the
             # activations forward, one reduction backward less per layer) and only enters the
             # running mean, as in the stock modules.
-            from .. import ops
             if ops.batchnorm_relu_supported(x, bn) and x.is_cuda:
-                return ops.batchnorm_relu(self._conv_nobias(layer, x), bn, shift=layer.bias)
+                y_pre = self._conv_nobias(layer, x)
+                if ops.BN_DEFER and isinstance(layer, nn.ConvTranspose2d) and y_pre.dtype == torch.bfloat16:
+                    return ops.DeferredNorm(y_pre, bn, layer.bias)
+                return ops.batchnorm_relu(y_pre, bn, shift=layer.bias)
             # evaluation mode (running statistics) and CPU: the stock modules, in the weights' precision
             if x.dtype != layer.weight.dtype:
                 x = x.to(layer.weight.dtype)
@@ -252,11 +269,15 @@ class _ProbDecoder(nn.Module):
             x = ops.plug_linear(self.z_to_feat[0], z, act_out=act, relu=True).view(-1, *self.feat_shape)
         else:
             x = self.z_to_feat[1](ops.plug_linear(self.z_to_feat[0], z, act_out=act)).view(-1, *self.feat_shape)
-        if logits:      # everything but the final nn.Sigmoid (for the fused sigmoid + BCE loss)
+        # (conv blocks hand their BatchNorm + ReLU to the next Deconv where that one normalises on the fly)
+        with ops.bn_defer(z.is_cuda):
             for layer in list(self.deconv_stack)[:-1]:
                 x = layer(x)
+        if isinstance(x, ops.DeferredNorm):
+            x = x.tensor()
+        if logits:      # everything but the final nn.Sigmoid (for the fused sigmoid + BCE loss)
             return (x,)
-        return (self.deconv_stack(x),)
+        return (self.deconv_stack[-1](x),)
 
 
 class ImageDecoder(_ProbDecoder):

@@ -126,13 +126,14 @@ class Bn(C.Structure):
                 [('phase', C.c_int32), ('groups', C.c_int32), ('global_sums', _P), ('global_count', C.c_double)])
 
 
-BN_STATS, BN_APPLY = 1, 2
+BN_STATS, BN_APPLY, BN_FINALIZE = 1, 2, 3
 GEMM_RELU = 32
 
 
 class Conv(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB', 'KS', 'flags')] +
-                [(n, _P) for n in ('small', 'big', 'wfrag', 'bias')])
+                [(n, _P) for n in ('small', 'big', 'wfrag', 'bias', 'in_mean', 'in_invstd', 'in_gamma', 'in_beta')] +
+                [('in_group_n', C.c_int32), ('in_relu', C.c_int32)])
 
 
 class Conv1d(C.Structure):

@@ -1761,6 +1761,158 @@ class _ConvTilesFn(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _BnDeconvFn(torch.autograd.Function):
+    """relu(batchnorm(x_pre)) of one conv block followed by the next block's ConvTranspose2d(k4,s2,p1), without
+    the normalised activation ever travelling through HBM: the statistics pass of csrc/batchnorm.hip alone
+    (mdmm_bn_t.phase = MDMM_BN_FINALIZE: save_mean / save_invstd / running statistics), then the deconvolution
+    normalises its input while it stages it (mdmm_conv_t.in_mean) -- one read and one write of the activation
+    less per block than _BnReluFn + _ConvTilesFn, same values bit for bit.  Backward: the deconvolution's input
+    gradient (= the gradient of the normalised activation), its weight gradient with the same on-the-fly
+    normalisation of x_pre, then the BatchNorm adjoint kernels on (that gradient, x_pre)."""
+
+    @staticmethod
+    def forward(ctx, x_pre, gamma, beta, bn, shift, weight, bias):
+        ctx.set_materialize_grads(False)
+        _need_gpu(x_pre)
+        x = _act(x_pre)
+        N, Cc, s = x.shape[0], x.shape[1], x.shape[2]
+        Ln = s * s
+        G = bn_groups_for(N, bn)
+        a = native.Bn()
+        a.N, a.C, a.L, a.relu, a.groups, a.phase = N // G, Cc, Ln, 1, G, native.BN_FINALIZE
+        a.bf16_io = 1
+        lib = native.lib()
+        a.splits = max(1, lib.mdmm_bn_splits(N // G, Cc, Ln) // G) if G > 1 else lib.mdmm_bn_splits(N, Cc, Ln)
+        a.eps = bn.eps
+        stats = torch.empty(2, G, Cc, device=x.device, dtype=torch.float32)
+        part = torch.empty(G * Cc * a.splits * 2, device=x.device, dtype=torch.float64)
+        g = None if gamma is None else _f32c(gamma.detach())
+        b = None if beta is None else _f32c(beta.detach())
+        a.x, a.gamma, a.beta = _ptr(x), _ptr(g), _ptr(b)
+        a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
+        if bn.track_running_stats and bn.running_mean is not None:
+            bn.num_batches_tracked.add_(G)
+            a.momentum = bn.momentum
+            a.running_mean, a.running_var = _ptr(bn.running_mean), _ptr(bn.running_var)
+            sh = None if shift is None else _f32c(shift.detach())
+            a.mean_shift = _ptr(sh)
+        _call('mdmm_bn_relu_fwd', C.byref(a), nbytes=x.numel() * x.element_size(), tag='mdmm_bn_stats')
+        ks, cb = weight.shape[-1], weight.shape[1]
+        y = torch.empty(N, cb, 2 * s, 2 * s, device=x.device, dtype=torch.bfloat16)
+        c = _conv_desc(N, x.shape, y.shape, ks)
+        c.flags = _conv_flags(x, y)
+        c.small, c.big = _ptr(x), _ptr(y)
+        c.bias = _ptr(_f32c(bias.detach())) if bias is not None else None
+        keep = _conv_pack(weight, c, True)
+        c.wfrag = _ptr(keep)
+        c.in_mean, c.in_invstd, c.in_gamma, c.in_beta = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(g), _ptr(b)
+        c.in_group_n, c.in_relu = N // G, 1
+        _call('mdmm_conv_up', C.byref(c), tag='conv_up[S=%d]' % s)
+        ctx.save_for_backward(x, stats, g, b, weight)
+        ctx.meta = (N // G, Cc, Ln, a.splits, bn.eps, G)
+        ctx.has_bias = bias is not None
+        ctx.shift_like = None if shift is None else shift.detach()
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, g, b, weight = ctx.saved_tensors
+        shift_grad = None
+        if ctx.shift_like is not None and ctx.needs_input_grad[4]:
+            shift_grad = torch.zeros_like(ctx.shift_like)
+        if gy is None:
+            return None, None, None, None, shift_grad, None, None
+        gy = _act(gy)
+        if gy.dtype != torch.bfloat16:
+            gy = gy.to(torch.bfloat16)
+        Ng, Cc, Ln, splits, eps, G = ctx.meta
+        N, ks = x.shape[0], weight.shape[-1]
+        gw = gb = dx = None
+        dgb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
+        c = _conv_desc(N, x.shape, gy.shape, ks)
+        c.flags = _conv_flags(x, gy)
+        need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if need_x:
+            dyn = torch.empty_like(x)               # gradient of the normalised activation
+            c.small, c.big = _ptr(dyn), _ptr(gy)
+            keep = _conv_pack(weight, c, False)
+            c.wfrag = _ptr(keep)
+            _call('mdmm_conv_down', C.byref(c), tag='conv_down[S=%d]' % c.S)
+        if ctx.needs_input_grad[5]:
+            c.small, c.big, c.wfrag = _ptr(x), _ptr(gy), None
+            c.in_mean, c.in_invstd, c.in_gamma, c.in_beta = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(g), _ptr(b)
+            c.in_group_n, c.in_relu = Ng, 1
+            ws = torch.empty(native.lib().mdmm_conv_wgrad_ws_bytes(C.byref(c)), device=x.device, dtype=torch.uint8)
+            gw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
+            _call('mdmm_conv_wgrad', C.byref(c), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % c.S)
+        if ctx.has_bias and ctx.needs_input_grad[6]:
+            gb = colsum(gy.reshape(N, -1)).reshape(gy.shape[1], -1).sum(1)
+        if need_x:
+            a = native.Bn()
+            a.N, a.C, a.L, a.relu, a.splits, a.eps, a.groups = Ng, Cc, Ln, 1, splits, eps, G
+            a.bf16_io = 1
+            dx = torch.empty_like(x)
+            part = torch.empty(G * Cc * splits * 2, device=x.device, dtype=torch.float64)
+            a.x, a.gamma, a.beta, a.dy, a.dx = _ptr(x), _ptr(g), _ptr(b), _ptr(dyn), _ptr(dx)
+            a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
+            a.dgamma, a.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
+            _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=x.numel() * x.element_size() * 5)
+        return (dx, dgb[0] if (need_x and ctx.needs_input_grad[1]) else None,
+                dgb[1] if (need_x and ctx.needs_input_grad[2]) else None, None, shift_grad, gw, gb)
+
+
+class DeferredNorm:
+    """What a conv block hands to the next one under bn_defer(): its convolution's output BEFORE BatchNorm + ReLU,
+    with the norm layer (and the convolution's bias, which only enters the running mean).  The consumer either
+    fuses the normalisation into its own staging (bn_deconv) or calls tensor() for the materialised activation."""
+
+    def __init__(self, x_pre, bn, shift):
+        self.x_pre, self.bn, self.shift = x_pre, bn, shift
+
+    def tensor(self):
+        return batchnorm_relu(self.x_pre, self.bn, shift=self.shift)
+
+
+BN_DEFER = False
+
+
+class bn_defer:
+    """Context (ImageDecoder's stack): conv blocks return DeferredNorm instead of the normalised activation when
+    the next block can normalise on the fly."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global BN_DEFER
+        self.prev, BN_DEFER = BN_DEFER, self.on
+
+    def __exit__(self, *exc):
+        global BN_DEFER
+        BN_DEFER = self.prev
+
+
+def bn_deconv_supported(pending, layer):
+    """The next block's layer is a ConvTranspose2d the tile kernels take on bf16 activations, the pending norm is a
+    training-mode BatchNorm on its own rank's statistics with at most 8 groups."""
+    import torch.nn as nn
+    x, bn = pending.x_pre, pending.bn
+    if not (isinstance(layer, nn.ConvTranspose2d) and x.is_cuda and x.dtype == torch.bfloat16 and ACT_STORAGE is torch.bfloat16):
+        return False
+    if os.environ.get('MDMM_BN_DECONV') == '0' or not conv_tiles_supported(layer, x) or not bn.training:
+        return False
+    if bn_sync_group() is not None or (bn.track_running_stats and bn.running_mean is not None and bn.momentum is None):
+        return False
+    return BN_GROUPS <= 8
+
+
+def bn_deconv(pending, layer, bias=True):
+    """layer(relu(bn(x_pre))) for a DeferredNorm that bn_deconv_supported accepts."""
+    bn = pending.bn
+    return _BnDeconvFn.apply(pending.x_pre, bn.weight, bn.bias, bn, pending.shift, layer.weight,
+                             layer.bias if bias else None)
+
+
 def conv_tiles(layer, x, bias=True):
     """layer(x) for a Conv2d / ConvTranspose2d that conv_tiles_supported accepts (bias=False leaves
     the layer's bias out, as the blocks in front of a BatchNorm do)."""

@@ -232,3 +232,37 @@ def test_bernoulli_logits_stacked_passes(dev, dtype, inner):
     assert ga.dtype == dtype and ga.shape == a.shape
     assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
     assert torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize('groups', [1, 2])
+def test_deferred_batchnorm_in_deconv_equals_materialised(dev, groups, monkeypatch):
+    """ImageDecoder with its blocks' BatchNorm + ReLU applied by the NEXT deconvolution while it stages its input
+    (ops.bn_defer / _BnDeconvFn: mdmm_bn_t.phase = MDMM_BN_FINALIZE + mdmm_conv_t.in_mean) against the same
+    decoder with every normalised activation materialised (MDMM_BN_DECONV=0): logits, every parameter gradient,
+    the input gradient and the running statistics -- the same arithmetic, so equal to the last bit except where
+    partial sums are added in another order."""
+    import copy
+    from mdmm import ops
+    from mdmm.models import common as C
+    torch.manual_seed(3 + groups)
+    dec_a = C.ImageDecoder(256, n_channels=3).to(dev).train()
+    dec_b = copy.deepcopy(dec_a)
+    z = torch.randn(groups * 40, 256, device=dev)
+    res = []
+    for dec, flag in ((dec_a, '1'), (dec_b, '0')):
+        monkeypatch.setenv('MDMM_BN_DECONV', flag)
+        zi = z.clone().requires_grad_()
+        with ops.conv_operands(torch.bfloat16, torch.bfloat16), ops.bn_groups(groups):
+            out = dec(zi, logits=True)[0]
+        gy = torch.randn(out.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).to(out.dtype)
+        grads = torch.autograd.grad(out, [zi] + list(dec.parameters()), gy, allow_unused=True)
+        res.append((out, grads, {k: v.clone() for k, v in dec.state_dict().items() if 'running' in k or 'tracked' in k}))
+    (oa, ga, sa), (ob, gb, sb) = res
+    assert torch.equal(oa, ob)
+    names = ['z'] + [k for k, _ in dec_a.named_parameters()]
+    for k, a_, b_ in zip(names, ga, gb):
+        assert (a_ is None) == (b_ is None), k
+        if a_ is not None:
+            assert helpers.rel_err(a_.float(), b_.float()) < 1e-6, k
+    for k in sa:
+        assert helpers.rel_err(sa[k].float(), sb[k].float()) < 1e-6, k
