@@ -142,7 +142,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
                                                       float* running_var, const float* mean_shift,
                                                       T* __restrict__ y,
                                                       float* save_mean, float* save_invstd,
-                                                      const double* __restrict__ gsum, double gcount) {
+                                                      const double* __restrict__ gsum, double gcount, int nparts) {
   const int c = blockIdx.x;
   const int grp = blockIdx.z, n_grp = gridDim.z;       // groups: each N images with statistics of their own
   const double M = gsum ? gcount : (double)N * (double)L;
@@ -151,10 +151,10 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
     if (gsum) {                                  // statistics of the GLOBAL batch (all ranks), see mdmm_bn_t
       d1 = gsum[2 * c]; d2 = gsum[2 * c + 1];
     } else {
-      const double* p = partial + (size_t)gi * C * gridDim.y * 2;
-      for (int s = 0; s < (int)gridDim.y; ++s) {
-        d1 += p[((size_t)c * gridDim.y + s) * 2];
-        d2 += p[((size_t)c * gridDim.y + s) * 2 + 1];
+      const double* p = partial + (size_t)gi * C * nparts * 2;
+      for (int s = 0; s < nparts; ++s) {
+        d1 += p[((size_t)c * nparts + s) * 2];
+        d2 += p[((size_t)c * nparts + s) * 2 + 1];
       }
     }
     mean = d1 / M;
@@ -389,11 +389,15 @@ void launch_fwd(const mdmm_bn_t* a, hipStream_t st) {
   const dim3 grid(a->C, a->splits, a->groups > 1 ? a->groups : 1);
   if (a->phase != MDMM_BN_APPLY)
     hipLaunchKernelGGL((bn_stats_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->x, a->N, a->C, a->L, a->partial);
-  if (a->phase != MDMM_BN_STATS)
-    hipLaunchKernelGGL((bn_apply_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->x, a->N, a->C, a->L, a->partial,
+  if (a->phase != MDMM_BN_STATS) {
+    // (MDMM_BN_FINALIZE: one workgroup per channel and group folds the partial sums; nothing is normalised here)
+    const bool fin = a->phase == MDMM_BN_FINALIZE;
+    hipLaunchKernelGGL((bn_apply_kernel<VEC, T>), fin ? dim3(a->C, 1, grid.z) : grid, dim3(fin ? 64 : NT), 0, st,
+                       (const T*)a->x, a->N, a->C, a->L, a->partial,
                        a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
-                       a->mean_shift, a->phase == MDMM_BN_FINALIZE ? (T*)nullptr : (T*)a->y, a->save_mean, a->save_invstd,
-                       a->global_sums, a->global_count);
+                       a->mean_shift, fin ? (T*)nullptr : (T*)a->y, a->save_mean, a->save_invstd,
+                       a->global_sums, a->global_count, a->splits);
+  }
 }
 template <bool VEC, typename T>
 void launch_bwd(const mdmm_bn_t* a, hipStream_t st) {

@@ -247,7 +247,7 @@ def test_deferred_batchnorm_in_deconv_equals_materialised(dev, groups, monkeypat
     torch.manual_seed(3 + groups)
     dec_a = C.ImageDecoder(256, n_channels=3).to(dev).train()
     dec_b = copy.deepcopy(dec_a)
-    z = torch.randn(groups * 40, 256, device=dev)
+    z = torch.randn(groups * 520, 256, device=dev)         # (>= 512 rows: the heads' own GEMM and its ReLU epilogue)
     res = []
     for dec, flag in ((dec_a, '1'), (dec_b, '0')):
         monkeypatch.setenv('MDMM_BN_DECONV', flag)
