@@ -19,6 +19,7 @@
 // of the reference's image models (n_kernels = 64, n_layers = 3).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "sweep_internal.h"
 
 namespace {
@@ -698,7 +699,13 @@ int run_down(const mdmm_conv_t* a, hipStream_t st) {
 constexpr int WGRAD_GRID = 512, WGRAD_FOLD = 16;        // two workgroups per CU; second-stage groups
 int wgrad_nt(const mdmm_conv_t* a) { return (a->KS * a->KS * a->CB + 31) / 32; }
 int wgrad_parts(const mdmm_conv_t* a) {
-  const int g = a->S == 8 ? WGRAD_GRID * 3 / 2 : WGRAD_GRID;  // S = 8: 46 KB of LDS, three workgroups per CU
+  // two workgroups per CU for every shape (S = 8 used 768: its 59 KB of LDS fit two per CU, so the third half-round
+  // only added 33 MB of partial slabs: 0.375 -> 0.320 ms at 20,480 images, tools/ab_conv_wgrad_grid.sh)
+  int g = WGRAD_GRID;
+  if (const char* e = getenv(a->S == 8 ? "MDMM_CONV_WGRAD_GRID8" : "MDMM_CONV_WGRAD_GRID")) {     // (measurement switch)
+    const int v = atoi(e);
+    if (v >= 64 && v <= 4096) g = v;
+  }
   return a->N < g ? a->N : g;
 }
 template <int S, int CS, int CB, int KS, bool SB, bool BB>
