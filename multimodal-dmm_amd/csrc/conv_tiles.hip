@@ -635,7 +635,11 @@ int shape_id(const mdmm_conv_t* a) {
 template <typename Kern>
 int set_lds(Kern kern, int bytes) { return mdmm_lds_attr_fn((const void*)kern, (size_t)bytes); }
 
-int grid_for(int N, int per_cu) { const int g = 256 * per_cu; return N < g ? N : g; }
+int grid_for(int N, int per_cu, const char* env = nullptr) {
+  if (env) if (const char* e = getenv(env)) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }     // (measurement switch)
+  const int g = 256 * per_cu;
+  return N < g ? N : g;
+}
 
 // storage of the two sides (mdmm_conv_t.flags): fp32 / fp32, bf16 / bf16, or bf16 small side with an
 // fp32 big side (the first encoder layer reads the fp32 frames)
@@ -653,7 +657,7 @@ int run_up_io(const mdmm_conv_t* a, hipStream_t st) {
   auto k = conv_up_kernel<S, CS, CB, SB, BB>;
   int rc = set_lds(k, G::UP_LDS);
   if (rc) return rc;
-  hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2)), dim3(256), G::UP_LDS, st, *a);
+  hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2, "MDMM_CONV_UP_PER_CU")), dim3(256), G::UP_LDS, st, *a);
   return (int)hipGetLastError();
 }
 // the small side normalised while it is staged (in_mean): bf16 activations on both sides only
@@ -665,7 +669,7 @@ int run_up_norm(const mdmm_conv_t* a, hipStream_t st) {
   constexpr int lds = G::UP_LDS + NORM_LDS(CS);
   int rc = set_lds(k, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2)), dim3(256), lds, st, *a);
+  hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2, "MDMM_CONV_UP_PER_CU")), dim3(256), lds, st, *a);
   return (int)hipGetLastError();
 }
 template <int S, int CS, int CB>
@@ -684,7 +688,9 @@ int run_down_io(const mdmm_conv_t* a, hipStream_t st) {
   auto k = conv_down_kernel<S, CS, CB, KS, SB, BB>;
   int rc = set_lds(k, D::LDS);
   if (rc) return rc;
-  hipLaunchKernelGGL(k, dim3(grid_for(a->N, D::LDS <= 80 * 1024 ? 2 : 1)), dim3(256), D::LDS, st, *a);
+  // workgroups per CU by what their LDS lets run side by side (S = 32: 36 KB, four per CU: 0.259 -> 0.222 ms at 20,480
+  // images, tools/ab_conv_grid.sh; three at S = 16 and more than two of the up kernels measured no better)
+  hipLaunchKernelGGL(k, dim3(grid_for(a->N, D::LDS <= 40 * 1024 ? 4 : (D::LDS <= 80 * 1024 ? 2 : 1), "MDMM_CONV_DOWN_PER_CU")), dim3(256), D::LDS, st, *a);
   return (int)hipGetLastError();
 }
 template <int S, int CS, int CB, int KS>
