@@ -104,7 +104,10 @@ template <int S, int CS, int CB, int KS>
 struct Down {
   using G = Shape<S, CS, CB>;
   static constexpr int CH = G::THIN ? KS : KS * KS * CB / 16;    // chunks of the contraction
-  static constexpr int W_LDS = G::MT_S * CH * 1024;
+  // CS = 64 (S = 8): two pixel tiles x two channel tiles = one job per wave and image, so a wave's weight fragments
+  // stay in ITS registers (CH x 4) instead of 64 KB of LDS that kept a second workgroup off the CU
+  static constexpr bool WREG = G::MT_S > 1 && (S * S / 32) * G::MT_S == 4;
+  static constexpr int W_LDS = WREG ? 0 : G::MT_S * CH * 1024;
   static constexpr int LDS = W_LDS + G::DN_LDS_P;
 };
 
@@ -306,6 +309,12 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   char* wl = smem;
   char* patch = smem + D::W_LDS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, cb = a.CB;
+  uint4 wreg[D::WREG ? D::CH : 1];
+  if constexpr (D::WREG) {
+    const uint4* src = reinterpret_cast<const uint4*>(a.wfrag) + (size_t)(wave / (S * S / 32)) * D::CH * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < D::CH; ++c) wreg[c] = src[c * 64];
+  }
   for (int i = threadIdx.x; i < D::W_LDS / 16; i += 256)
     reinterpret_cast<uint4*>(wl)[i] = reinterpret_cast<const uint4*>(a.wfrag)[i];
   for (int i = threadIdx.x; i < G::DN_LDS_P / 16; i += 256) reinterpret_cast<uint4*>(patch)[i] = uint4{0, 0, 0, 0};
@@ -378,7 +387,8 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
           bv = *reinterpret_cast<const uint4*>(base + ((tap / KS) * G::DN_PW + tap % KS) * G::DN_PS + off * 2);
         }
         // (the chain starts from the constant zero; the bias joins the live rows at the store)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wrow[c * 64]), __builtin_bit_cast(bf16x8, bv),
+        const uint4 wv = D::WREG ? wreg[c] : wrow[c * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, bv),
                                                       c ? acc : f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                                                                        0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       }
