@@ -86,6 +86,19 @@ __device__ __forceinline__ __bf16 norm1(__bf16 v, float scale, float shift, bool
   return (__bf16)f;
 }
 
+// two consecutive elements (idx even)
+template <bool BF>
+__device__ __forceinline__ void store2(void* base, size_t idx, float v0, float v1) {
+  if constexpr (BF) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 p;
+    p[0] = (__bf16)v0; p[1] = (__bf16)v1;
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<__bf16*>(base) + idx) = __builtin_bit_cast(uint32_t, p);
+  } else {
+    *reinterpret_cast<float2*>(reinterpret_cast<float*>(base) + idx) = float2{v0, v1};
+  }
+}
+
 template <int S, int CS, int CB>
 struct Shape {
   static constexpr int CBP = CB;                          // big-side channels as staged (4 = padded 1..4)
@@ -215,12 +228,18 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   if constexpr (NORM) norm_table<CS>(a, ntab, 256);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
   const int py = wave >> 1, px = wave & 1, cb = a.CB;
-  // this class's weights stay in registers for the whole kernel
-  uint4 wf[G::UP_CH];
+  // this class's weights stay in registers for the whole kernel (CB <= 4: the wave takes BOTH column parities of its
+  // row parity, for every other pixel tile: wf = the even columns' class, wf1 = the odd columns')
+  uint4 wf[G::UP_CH], wf1[CB <= 4 ? G::UP_CH : 1];
   {
-    const uint4* src = reinterpret_cast<const uint4*>(a.wfrag) + (size_t)wave * G::UP_CH * 64 + lane;
+    const int cls = CB <= 4 ? 2 * py : wave;
+    const uint4* src = reinterpret_cast<const uint4*>(a.wfrag) + (size_t)cls * G::UP_CH * 64 + lane;
 #pragma unroll
     for (int c = 0; c < G::UP_CH; ++c) wf[c] = src[c * 64];
+    if constexpr (CB <= 4) {
+#pragma unroll
+      for (int c = 0; c < G::UP_CH; ++c) wf1[c] = src[(G::UP_CH + c) * 64];
+    }
   }
   for (int i = threadIdx.x; i < G::UP_LDS / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
   float bias[16];
@@ -246,11 +265,14 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
       // Two tiles at a time: a tile is a chain of UP_CH dependent MFMAs, two chains hide each other's
       // latency; every chain starts from the constant zero, the bias joins the rows that are stored.
       static_assert((NPIX / 32) % 2 == 0, "tile pairs");
-      for (int tile = 0; tile < NPIX / 32; tile += 2) {
+      // A lane ends up with the two horizontally adjacent output pixels (2x, 2x + 1) of its input pixel and
+      // stores them as one 4-byte (bf16) / 8-byte element: 32 lanes = one contiguous run of a row.  (With one
+      // parity class per wave every store filled every other 2-byte element of its lines: the kernel sat at a third
+      // of the HBM rate on its stores.)
+      for (int tile = px; tile < NPIX / 32; tile += 2) {
         const int p0 = tile * 32 + (lane & 31), y0 = p0 / S, x0 = p0 % S;
-        const int p1 = p0 + 32, y1 = p1 / S, x1 = p1 % S;
-        const char* base0 = smem + ((y0 + py) * G::UP_PW + x0 + px) * G::UP_PS + 16 * h;
-        const char* base1 = smem + ((y1 + py) * G::UP_PW + x1 + px) * G::UP_PS + 16 * h;
+        const char* base0 = smem + ((y0 + py) * G::UP_PW + x0) * G::UP_PS + 16 * h;
+        const char* base1 = base0 + G::UP_PS;
         f32x16 acc0, acc1;
 #pragma unroll
         for (int c = 0; c < G::UP_CH; ++c) {
@@ -259,18 +281,14 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
           const uint4 b0 = *reinterpret_cast<const uint4*>(base0 + at), b1 = *reinterpret_cast<const uint4*>(base1 + at);
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, b0),
                                                          c ? acc0 : ZERO, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, b1),
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf1[c]), __builtin_bit_cast(bf16x8, b1),
                                                          c ? acc1 : ZERO, 0, 0, 0);
         }
         if (h == 0) {
-          const size_t o0 = dst0 + (size_t)(2 * y0 + py) * G::B2 + 2 * x0 + px;
-          const size_t o1 = dst0 + (size_t)(2 * y1 + py) * G::B2 + 2 * x1 + px;
+          const size_t o0 = dst0 + (size_t)(2 * y0 + py) * G::B2 + 2 * x0;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (r < cb) {
-              store1<BB>(a.big, o0 + (size_t)r * (4 * NPIX), acc0[r] + bias[r]);
-              store1<BB>(a.big, o1 + (size_t)r * (4 * NPIX), acc1[r] + bias[r]);
-            }
+            if (r < cb) store2<BB>(a.big, o0 + (size_t)r * (4 * NPIX), acc0[r] + bias[r], acc1[r] + bias[r]);
         }
       }
     } else {
