@@ -501,6 +501,7 @@ typedef struct mdmm_bn {
 #define MDMM_BN_STATS 1
 #define MDMM_BN_APPLY 2
 #define MDMM_BN_FINALIZE 3
+#define MDMM_BN_FINALIZE_GIVEN 4   /* as MDMM_BN_FINALIZE with `partial` already filled (mdmm_conv_t.out_stats): no pass over x */
 int mdmm_bn_splits(int64_t N, int C, int64_t L);
 int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream);
 int mdmm_bn_relu_bwd(const mdmm_bn_t* a, void* stream);
@@ -538,11 +539,19 @@ typedef struct mdmm_conv {
   const float* in_gamma;  /* (CS) or NULL = 1 */
   const float* in_beta;   /* (CS) or NULL = 0 */
   int32_t in_group_n, in_relu;
+  /* mdmm_conv_up with 16 or 32 output channels and bf16 sides: the statistics pass of the BatchNorm BEHIND this layer
+   * for free -- every workgroup adds (sum, sum of squares) of the values it stores (after their rounding to the big
+   * side's storage type) into out_stats[((g * CB + c) * mdmm_conv_up_parts(args) + workgroup) * 2 + {0, 1}], g = n /
+   * out_group_n; the caller zeroes the buffer and hands it to mdmm_bn_relu_fwd as `partial` with phase =
+   * MDMM_BN_FINALIZE_GIVEN and splits = mdmm_conv_up_parts.  NULL: none.  */
+  double* out_stats;
+  int32_t out_group_n, reserved;
 } mdmm_conv_t;
 int mdmm_conv_supported(const mdmm_conv_t* args);
 int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* args, int up);
 int mdmm_conv_pack(const mdmm_conv_t* args, int up, const float* weight, void* out, void* stream);
 int mdmm_conv_up(const mdmm_conv_t* args, void* stream);
+int mdmm_conv_up_parts(const mdmm_conv_t* args);     /* workgroups of that launch = partial slabs of out_stats */
 int mdmm_conv_down(const mdmm_conv_t* args, void* stream);
 int64_t mdmm_conv_wgrad_ws_bytes(const mdmm_conv_t* args);
 int mdmm_conv_wgrad(const mdmm_conv_t* args, void* ws, float* dw, void* stream);

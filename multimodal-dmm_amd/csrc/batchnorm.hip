@@ -365,9 +365,9 @@ int check(const mdmm_bn_t* a) {
   if (!a || a->N < 1 || a->C < 1 || a->L < 1 || !a->x || !a->partial || !a->save_mean || !a->save_invstd)
     return MDMM_E_ARG;
   if (a->splits < 1 || a->splits > 65535) return MDMM_E_ARG;
-  if (a->phase < 0 || a->phase > MDMM_BN_FINALIZE) return MDMM_E_ARG;
+  if (a->phase < 0 || a->phase > MDMM_BN_FINALIZE_GIVEN) return MDMM_E_ARG;
   if (a->global_sums && !(a->global_count >= 1.0)) return MDMM_E_ARG;
-  if (a->groups < 0 || a->groups > 65535 || (a->groups > 1 && ((a->phase != 0 && a->phase != MDMM_BN_FINALIZE) || a->global_sums))) return MDMM_E_ARG;
+  if (a->groups < 0 || a->groups > 65535 || (a->groups > 1 && ((a->phase != 0 && a->phase < MDMM_BN_FINALIZE) || a->global_sums))) return MDMM_E_ARG;
   return 0;
 }
 
@@ -387,11 +387,11 @@ namespace {
 template <bool VEC, typename T>
 void launch_fwd(const mdmm_bn_t* a, hipStream_t st) {
   const dim3 grid(a->C, a->splits, a->groups > 1 ? a->groups : 1);
-  if (a->phase != MDMM_BN_APPLY)
+  if (a->phase != MDMM_BN_APPLY && a->phase != MDMM_BN_FINALIZE_GIVEN)
     hipLaunchKernelGGL((bn_stats_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->x, a->N, a->C, a->L, a->partial);
   if (a->phase != MDMM_BN_STATS) {
     // (MDMM_BN_FINALIZE: one workgroup per channel and group folds the partial sums; nothing is normalised here)
-    const bool fin = a->phase == MDMM_BN_FINALIZE;
+    const bool fin = a->phase == MDMM_BN_FINALIZE || a->phase == MDMM_BN_FINALIZE_GIVEN;
     hipLaunchKernelGGL((bn_apply_kernel<VEC, T>), fin ? dim3(a->C, 1, grid.z) : grid, dim3(fin ? 64 : NT), 0, st,
                        (const T*)a->x, a->N, a->C, a->L, a->partial,
                        a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
@@ -416,7 +416,7 @@ void launch_bwd(const mdmm_bn_t* a, hipStream_t st) {
 extern "C" int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream) {
   int rc = check(a);
   if (rc) return rc;
-  if (!a->y && a->phase != MDMM_BN_STATS && a->phase != MDMM_BN_FINALIZE) return MDMM_E_ARG;
+  if (!a->y && a->phase != MDMM_BN_STATS && a->phase < MDMM_BN_FINALIZE) return MDMM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (a->bf16_io) { if (vec_ok(a)) launch_fwd<true, __bf16>(a, st); else launch_fwd<false, __bf16>(a, st); }
   else { if (vec_ok(a)) launch_fwd<true, float>(a, st); else launch_fwd<false, float>(a, st); }

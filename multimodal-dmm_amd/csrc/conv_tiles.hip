@@ -220,11 +220,12 @@ __device__ __forceinline__ void up_commit(char* smem, const UpStage<S, CS>& st, 
   }
 }
 
-template <int S, int CS, int CB, bool SB, bool BB, bool NORM = false>
+template <int S, int CS, int CB, bool SB, bool BB, bool NORM = false, bool STATS = false>
 __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   using G = Shape<S, CS, CB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const ntab = reinterpret_cast<float*>(smem + G::UP_LDS);
+  float* const sred = ntab + NORM_GROUPS * 2 * CS;       // STATS: [wave][half][register][sum | sum of squares]
   if constexpr (NORM) norm_table<CS>(a, ntab, 256);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
   const int py = wave >> 1, px = wave & 1, cb = a.CB;
@@ -248,11 +249,49 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
     const int m = acc_row(r) + 4 * h;
     bias[r] = (a.bias && m < cb) ? a.bias[m] : 0.f;
   }
+  // STATS (mdmm_conv_t.out_stats): per-lane running sums of what this lane stores, per accumulator register
+  // (= channel acc_row(r) + 4 h); flushed per statistics group (the images of a workgroup come in rising order)
+  constexpr int SR = STATS ? CB / 2 : 1;
+  float s1[SR], s2[SR];
+  int cur_g = -1;
+  auto stats_flush = [&](int g) {
+    if constexpr (STATS) {
+#pragma unroll
+      for (int r = 0; r < SR; ++r) {
+        float u = s1[r], v = s2[r];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) { u += __shfl_xor(u, off, 64); v += __shfl_xor(v, off, 64); }
+        if ((lane & 31) == 0) { sred[((wave * 2 + h) * 16 + r) * 2] = u; sred[((wave * 2 + h) * 16 + r) * 2 + 1] = v; }
+        s1[r] = 0.f; s2[r] = 0.f;
+      }
+      __syncthreads();
+      if (threadIdx.x < CB) {
+        const int m = threadIdx.x, hh = (m >> 2) & 1, r = 4 * (m >> 3) + (m & 3);
+        double d1 = 0, d2 = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { d1 += sred[((w * 2 + hh) * 16 + r) * 2]; d2 += sred[((w * 2 + hh) * 16 + r) * 2 + 1]; }
+        double* o = a.out_stats + (((size_t)g * CB + m) * gridDim.x + blockIdx.x) * 2;
+        o[0] = d1; o[1] = d2;
+      }
+      __syncthreads();
+    }
+  };
+  if constexpr (STATS) {
+#pragma unroll
+    for (int r = 0; r < SR; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+  }
   __syncthreads();
   constexpr int NPIX = S * S;
   UpStage<S, CS> stage;
   if ((int)blockIdx.x < a.N) up_fetch<S, CS, SB>(a, blockIdx.x, stage);
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
+    if constexpr (STATS) {
+      const int g = n / a.out_group_n;
+      if (g != cur_g) {
+        if (cur_g >= 0) stats_flush(cur_g);
+        cur_g = g;
+      }
+    }
     if constexpr (NORM) up_commit<S, CS, CB, true>(smem, stage, ntab + (size_t)(n / a.in_group_n) * 2 * CS, a.in_relu != 0);
     else up_commit<S, CS, CB>(smem, stage);
     __syncthreads();
@@ -309,12 +348,18 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
 #pragma unroll
         for (int r = 0; r < CB / 2; ++r) {
           const int m = acc_row(r) + 4 * h;
-          store1<BB>(a.big, o + (size_t)m * (4 * NPIX), acc[r] + bias[r]);
+          const float v = acc[r] + bias[r];
+          store1<BB>(a.big, o + (size_t)m * (4 * NPIX), v);
+          if constexpr (STATS) {            // of the value as stored (what a pass over the tensor would read)
+            const float vr = BB ? (float)(__bf16)v : v;
+            s1[r] += vr; s2[r] = fmaf(vr, vr, s2[r]);
+          }
         }
       }
     }
     __syncthreads();
   }
+  if constexpr (STATS) { if (cur_g >= 0) stats_flush(cur_g); }
 }
 
 // ------------------------------------------------------------------------------- down ----
@@ -700,8 +745,24 @@ int run_up_norm(const mdmm_conv_t* a, hipStream_t st) {
   hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2, "MDMM_CONV_UP_PER_CU")), dim3(256), lds, st, *a);
   return (int)hipGetLastError();
 }
+// with the output's BatchNorm statistics (out_stats): 16 / 32 output channels, bf16 on both sides
+template <int S, int CS, int CB, bool NORM>
+int run_up_stats(const mdmm_conv_t* a, hipStream_t st) {
+  using G = Shape<S, CS, CB>;
+  if constexpr (CB <= 4) return MDMM_E_ARG;
+  else {
+    if (io_of(a) != 1 || a->out_group_n < 1 || a->CB != CB || (NORM && !norm_ok(a))) return MDMM_E_ARG;
+    auto k = conv_up_kernel<S, CS, CB, true, true, NORM, true>;
+    constexpr int lds = G::UP_LDS + NORM_LDS(CS) + 4 * 2 * 16 * 2 * 4;
+    int rc = set_lds(k, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2, "MDMM_CONV_UP_PER_CU")), dim3(256), lds, st, *a);
+    return (int)hipGetLastError();
+  }
+}
 template <int S, int CS, int CB>
 int run_up(const mdmm_conv_t* a, hipStream_t st) {
+  if (a->out_stats) return a->in_mean ? run_up_stats<S, CS, CB, true>(a, st) : run_up_stats<S, CS, CB, false>(a, st);
   if (a->in_mean) return run_up_norm<S, CS, CB>(a, st);
   switch (io_of(a)) {
     case 0: return run_up_io<S, CS, CB, false, false>(a, st);
@@ -776,6 +837,8 @@ int run_wgrad(const mdmm_conv_t* a, float* part, hipStream_t st) {
 }  // namespace
 
 extern "C" int mdmm_conv_supported(const mdmm_conv_t* a) { return shape_id(a) >= 0; }
+
+extern "C" int mdmm_conv_up_parts(const mdmm_conv_t* a) { return a ? grid_for(a->N, 2, "MDMM_CONV_UP_PER_CU") : 0; }
 
 extern "C" int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* a, int up) {
   const int id = shape_id(a);

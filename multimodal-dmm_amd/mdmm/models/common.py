@@ -127,9 +127,10 @@ class _ConvBlock(nn.Module):
             if ops.bn_deconv_supported(pending, layer):
                 if isinstance(self.net, nn.Sequential):
                     bn = self.net[1]
+                    if ops.BN_DEFER and bn.training:      # (this block's statistics out of the deconvolution's epilogue)
+                        y_pre, part = ops.bn_deconv(pending, layer, bias=False, stats_for=bn)
+                        return ops.DeferredNorm(y_pre, bn, layer.bias, part)
                     y_pre = ops.bn_deconv(pending, layer, bias=False)
-                    if ops.BN_DEFER and ops.batchnorm_relu_supported(y_pre, bn):
-                        return ops.DeferredNorm(y_pre, bn, layer.bias)
                     return ops.batchnorm_relu(y_pre, bn, shift=layer.bias)
                 return ops.bn_deconv(pending, layer)
             x = pending.tensor()
@@ -141,9 +142,11 @@ class _ConvBlock(nn.Module):
             # activations forward, one reduction backward less per layer) and only enters the
             # running mean, as in the stock modules.
             if ops.batchnorm_relu_supported(x, bn) and x.is_cuda:
+                if ops.BN_DEFER and isinstance(layer, nn.ConvTranspose2d) and ops.conv_tiles_supported(layer, x) \
+                        and ops.ACT_STORAGE is torch.bfloat16:
+                    y_pre, part = ops.conv_tiles(layer, x, bias=False, stats_for=bn)
+                    return ops.DeferredNorm(y_pre, bn, layer.bias, part)
                 y_pre = self._conv_nobias(layer, x)
-                if ops.BN_DEFER and isinstance(layer, nn.ConvTranspose2d) and y_pre.dtype == torch.bfloat16:
-                    return ops.DeferredNorm(y_pre, bn, layer.bias)
                 return ops.batchnorm_relu(y_pre, bn, shift=layer.bias)
             # evaluation mode (running statistics) and CPU: the stock modules, in the weights' precision
             if x.dtype != layer.weight.dtype:

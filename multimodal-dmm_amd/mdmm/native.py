@@ -33,7 +33,7 @@ SYMBOLS = [
     'mdmm_gauss_mlp_supported', 'mdmm_gauss_mlp_dw_width', 'mdmm_gauss_mlp_dw_rows',
     'mdmm_gauss_mlp_fwd', 'mdmm_gauss_mlp_bwd',
     'mdmm_bn_splits', 'mdmm_bn_relu_fwd', 'mdmm_bn_relu_bwd',
-    'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_up', 'mdmm_conv_down',
+    'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_up', 'mdmm_conv_up_parts', 'mdmm_conv_down',
     'mdmm_conv_wgrad_ws_bytes', 'mdmm_conv_wgrad',
     'mdmm_gemm_supported', 'mdmm_gemm_split', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
     'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
@@ -126,14 +126,15 @@ class Bn(C.Structure):
                 [('phase', C.c_int32), ('groups', C.c_int32), ('global_sums', _P), ('global_count', C.c_double)])
 
 
-BN_STATS, BN_APPLY, BN_FINALIZE = 1, 2, 3
+BN_STATS, BN_APPLY, BN_FINALIZE, BN_FINALIZE_GIVEN = 1, 2, 3, 4
 GEMM_RELU = 32
 
 
 class Conv(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB', 'KS', 'flags')] +
                 [(n, _P) for n in ('small', 'big', 'wfrag', 'bias', 'in_mean', 'in_invstd', 'in_gamma', 'in_beta')] +
-                [('in_group_n', C.c_int32), ('in_relu', C.c_int32)])
+                [('in_group_n', C.c_int32), ('in_relu', C.c_int32), ('out_stats', _P), ('out_group_n', C.c_int32),
+                 ('reserved', C.c_int32)])
 
 
 class Conv1d(C.Structure):
@@ -279,6 +280,7 @@ def lib():
         L.mdmm_conv_pack_bytes.restype = C.c_int64
         L.mdmm_conv_pack.argtypes = [C.POINTER(Conv), C.c_int, _P, _P, _P]
         L.mdmm_conv_up.argtypes = [C.POINTER(Conv), _P]
+        L.mdmm_conv_up_parts.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_down.argtypes = [C.POINTER(Conv), _P]
         L.mdmm_conv_wgrad_ws_bytes.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_wgrad_ws_bytes.restype = C.c_int64

@@ -1695,12 +1695,29 @@ def prepack_convs(modules):
             _conv_pack(layer.weight, a, False)
 
 
+def _conv_out_stats(a, groups, y):
+    """Zeroed partial-sum buffer of mdmm_conv_t.out_stats for `groups` statistics groups of the N images of y
+    (sets the descriptor's fields); [groups][CB][parts][2] doubles, parts = workgroups of the launch."""
+    parts = native.lib().mdmm_conv_up_parts(C.byref(a))
+    part = torch.zeros(groups * a.CB * parts * 2, device=y.device, dtype=torch.float64)
+    a.out_stats, a.out_group_n = _ptr(part), a.N // groups
+    return part
+
+
+def conv_out_stats_supported(layer, x):
+    """The deconvolution's epilogue can carry the BatchNorm statistics of its output: ConvTranspose2d on the tile
+    kernels, 16 or 32 output channels, bf16 activations on both sides."""
+    import torch.nn as nn
+    return (isinstance(layer, nn.ConvTranspose2d) and x.dtype == torch.bfloat16 and ACT_STORAGE is torch.bfloat16
+            and layer.weight.shape[1] in (16, 32) and os.environ.get('MDMM_BN_EPILOGUE') != '0')
+
+
 class _ConvTilesFn(torch.autograd.Function):
     """One stride-2 layer of the image pyramids: transposed = ConvTranspose2d(k4,s2,p1) (small ->
     big), else Conv2d(k3,s2,p1) (big -> small).  weight is torch's [CS][CB][KS][KS] either way."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, transposed):
+    def forward(ctx, x, weight, bias, transposed, stats_groups=0):
         ctx.set_materialize_grads(False)
         x = _act(x)
         n, ks = x.shape[0], weight.shape[-1]
@@ -1723,17 +1740,23 @@ class _ConvTilesFn(torch.autograd.Function):
         a.bias = _ptr(_f32c(bias.detach())) if bias is not None else None
         keep = _conv_pack(weight, a, transposed)
         a.wfrag = _ptr(keep)
+        part = None
+        if stats_groups:                # the statistics pass of the BatchNorm behind this layer, in the epilogue
+            part = _conv_out_stats(a, stats_groups, y)
         _call('mdmm_conv_up' if transposed else 'mdmm_conv_down', C.byref(a),
               tag='conv_%s[S=%d]' % ('up' if transposed else 'down', s))
         ctx.transposed, ctx.has_bias = transposed, bias is not None
         ctx.save_for_backward(x, weight)
+        if part is not None:
+            ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gpart=None):
         x, weight = ctx.saved_tensors
         if gy is None:                  # (set_materialize_grads(False): an output that reaches no loss term)
-            return None, None, None, None
+            return None, None, None, None, None
         gy = _act(gy)
         n, ks = x.shape[0], weight.shape[-1]
         transposed = ctx.transposed
@@ -1758,7 +1781,7 @@ class _ConvTilesFn(torch.autograd.Function):
             # kernel (the images are the strided dimension), then C short rows
             c = gy.shape[1]
             gb = colsum(gy.reshape(n, -1)).reshape(c, -1).sum(1)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 class _BnDeconvFn(torch.autograd.Function):
@@ -1771,7 +1794,7 @@ class _BnDeconvFn(torch.autograd.Function):
     normalisation of x_pre, then the BatchNorm adjoint kernels on (that gradient, x_pre)."""
 
     @staticmethod
-    def forward(ctx, x_pre, gamma, beta, bn, shift, weight, bias):
+    def forward(ctx, x_pre, gamma, beta, bn, shift, weight, bias, part_in=None, stats_groups=0):
         ctx.set_materialize_grads(False)
         _need_gpu(x_pre)
         x = _act(x_pre)
@@ -1785,7 +1808,11 @@ class _BnDeconvFn(torch.autograd.Function):
         a.splits = max(1, lib.mdmm_bn_splits(N // G, Cc, Ln) // G) if G > 1 else lib.mdmm_bn_splits(N, Cc, Ln)
         a.eps = bn.eps
         stats = torch.empty(2, G, Cc, device=x.device, dtype=torch.float32)
-        part = torch.empty(G * Cc * a.splits * 2, device=x.device, dtype=torch.float64)
+        if part_in is not None:         # (sum, sum of squares) per workgroup of the producing deconvolution's epilogue
+            part = part_in
+            a.phase, a.splits = native.BN_FINALIZE_GIVEN, part_in.numel() // (G * Cc * 2)
+        else:
+            part = torch.empty(G * Cc * a.splits * 2, device=x.device, dtype=torch.float64)
         g = None if gamma is None else _f32c(gamma.detach())
         b = None if beta is None else _f32c(beta.detach())
         a.x, a.gamma, a.beta = _ptr(x), _ptr(g), _ptr(b)
@@ -1807,21 +1834,25 @@ class _BnDeconvFn(torch.autograd.Function):
         c.wfrag = _ptr(keep)
         c.in_mean, c.in_invstd, c.in_gamma, c.in_beta = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(g), _ptr(b)
         c.in_group_n, c.in_relu = N // G, 1
+        part_out = _conv_out_stats(c, stats_groups, y) if stats_groups else None
         _call('mdmm_conv_up', C.byref(c), tag='conv_up[S=%d]' % s)
         ctx.save_for_backward(x, stats, g, b, weight)
-        ctx.meta = (N // G, Cc, Ln, a.splits, bn.eps, G)
+        ctx.meta = (N // G, Cc, Ln, lib.mdmm_bn_splits(N // G, Cc, Ln) if part_in is not None else a.splits, bn.eps, G)
         ctx.has_bias = bias is not None
         ctx.shift_like = None if shift is None else shift.detach()
+        if part_out is not None:
+            ctx.mark_non_differentiable(part_out)
+            return y, part_out
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gpart=None):
         x, stats, g, b, weight = ctx.saved_tensors
         shift_grad = None
         if ctx.shift_like is not None and ctx.needs_input_grad[4]:
             shift_grad = torch.zeros_like(ctx.shift_like)
         if gy is None:
-            return None, None, None, None, shift_grad, None, None
+            return None, None, None, None, shift_grad, None, None, None, None
         gy = _act(gy)
         if gy.dtype != torch.bfloat16:
             gy = gy.to(torch.bfloat16)
@@ -1858,7 +1889,7 @@ class _BnDeconvFn(torch.autograd.Function):
             a.dgamma, a.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
             _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=x.numel() * x.element_size() * 5)
         return (dx, dgb[0] if (need_x and ctx.needs_input_grad[1]) else None,
-                dgb[1] if (need_x and ctx.needs_input_grad[2]) else None, None, shift_grad, gw, gb)
+                dgb[1] if (need_x and ctx.needs_input_grad[2]) else None, None, shift_grad, gw, gb, None, None)
 
 
 class DeferredNorm:
@@ -1866,8 +1897,8 @@ class DeferredNorm:
     with the norm layer (and the convolution's bias, which only enters the running mean).  The consumer either
     fuses the normalisation into its own staging (bn_deconv) or calls tensor() for the materialised activation."""
 
-    def __init__(self, x_pre, bn, shift):
-        self.x_pre, self.bn, self.shift = x_pre, bn, shift
+    def __init__(self, x_pre, bn, shift, part=None):
+        self.x_pre, self.bn, self.shift, self.part = x_pre, bn, shift, part     # part: mdmm_conv_t.out_stats of x_pre
 
     def tensor(self):
         return batchnorm_relu(self.x_pre, self.bn, shift=self.shift)
@@ -1906,19 +1937,33 @@ def bn_deconv_supported(pending, layer):
     return BN_GROUPS <= 8
 
 
-def bn_deconv(pending, layer, bias=True):
-    """layer(relu(bn(x_pre))) for a DeferredNorm that bn_deconv_supported accepts."""
+def bn_deconv(pending, layer, bias=True, stats_for=None):
+    """layer(relu(bn(x_pre))) for a DeferredNorm that bn_deconv_supported accepts.  stats_for: the BatchNorm behind
+    `layer` when its statistics are to come out of this deconvolution's epilogue -> (output, partial sums)."""
     bn = pending.bn
-    return _BnDeconvFn.apply(pending.x_pre, bn.weight, bn.bias, bn, pending.shift, layer.weight,
-                             layer.bias if bias else None)
+    groups = 0
+    if stats_for is not None and conv_out_stats_supported(layer, pending.x_pre):
+        groups = bn_groups_for(pending.x_pre.shape[0], stats_for)
+    out = _BnDeconvFn.apply(pending.x_pre, bn.weight, bn.bias, bn, pending.shift, layer.weight,
+                            layer.bias if bias else None, pending.part, groups)
+    if stats_for is not None:
+        return out if groups else (out, None)
+    return out
 
 
-def conv_tiles(layer, x, bias=True):
+def conv_tiles(layer, x, bias=True, stats_for=None):
     """layer(x) for a Conv2d / ConvTranspose2d that conv_tiles_supported accepts (bias=False leaves
-    the layer's bias out, as the blocks in front of a BatchNorm do)."""
+    the layer's bias out, as the blocks in front of a BatchNorm do).  stats_for: the BatchNorm behind the layer
+    when its statistics are to come out of the deconvolution's epilogue -> (output, partial sums or None)."""
     import torch.nn as nn
-    return _ConvTilesFn.apply(x, layer.weight, layer.bias if bias else None,
-                              isinstance(layer, nn.ConvTranspose2d))
+    tr = isinstance(layer, nn.ConvTranspose2d)
+    if stats_for is not None:
+        xa = _act(x)
+        if conv_out_stats_supported(layer, xa):
+            return _ConvTilesFn.apply(x, layer.weight, layer.bias if bias else None, tr,
+                                      bn_groups_for(x.shape[0], stats_for))
+        return _ConvTilesFn.apply(x, layer.weight, layer.bias if bias else None, tr), None
+    return _ConvTilesFn.apply(x, layer.weight, layer.bias if bias else None, tr)
 
 
 class _GaussMlpFn(torch.autograd.Function):
