@@ -538,8 +538,12 @@ typedef struct mdmm_conv {
   const float* in_invstd;
   const float* in_gamma;  /* (CS) or NULL = 1 */
   const float* in_beta;   /* (CS) or NULL = 0 */
-  int32_t in_group_n, in_relu;
-  /* mdmm_conv_up with 16 or 32 output channels and bf16 sides: the statistics pass of the BatchNorm BEHIND this layer
+  int32_t in_group_n;
+  int32_t in_relu;        /* bit 0: ReLU behind the norm; bit 1 (mdmm_conv_wgrad): the normalised input is the BIG side (a Conv's
+                           * input; mdmm_conv_down always normalises its big side, mdmm_conv_up its small side; channel counts
+                           * and tables follow that side) */
+  /* mdmm_conv_up with 16 or 32 output channels and bf16 sides (mdmm_conv_down with 16 or 32 output channels, bf16 small
+   * side: parts = mdmm_conv_down_parts, CS channels): the statistics pass of the BatchNorm BEHIND this layer
    * for free -- every workgroup adds (sum, sum of squares) of the values it stores (after their rounding to the big
    * side's storage type) into out_stats[((g * CB + c) * mdmm_conv_up_parts(args) + workgroup) * 2 + {0, 1}], g = n /
    * out_group_n; the caller zeroes the buffer and hands it to mdmm_bn_relu_fwd as `partial` with phase =
@@ -552,6 +556,7 @@ int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* args, int up);
 int mdmm_conv_pack(const mdmm_conv_t* args, int up, const float* weight, void* out, void* stream);
 int mdmm_conv_up(const mdmm_conv_t* args, void* stream);
 int mdmm_conv_up_parts(const mdmm_conv_t* args);     /* workgroups of that launch = partial slabs of out_stats */
+int mdmm_conv_down_parts(const mdmm_conv_t* args);   /* the same for mdmm_conv_down with in_mean / out_stats */
 int mdmm_conv_down(const mdmm_conv_t* args, void* stream);
 int64_t mdmm_conv_wgrad_ws_bytes(const mdmm_conv_t* args);
 int mdmm_conv_wgrad(const mdmm_conv_t* args, void* ws, float* dw, void* stream);

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
         cur_g = g;
       }
     }
-    if constexpr (NORM) up_commit<S, CS, CB, true>(smem, stage, ntab + (size_t)(n / a.in_group_n) * 2 * CS, a.in_relu != 0);
+    if constexpr (NORM) up_commit<S, CS, CB, true>(smem, stage, ntab + (size_t)(n / a.in_group_n) * 2 * CS, (a.in_relu & 1) != 0);
     else up_commit<S, CS, CB>(smem, stage);
     __syncthreads();
     if (n + (int)gridDim.x < a.N) up_fetch<S, CS, SB>(a, n + gridDim.x, stage);
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
 
 // ------------------------------------------------------------------------------- down ----
 // small[n][m][y][x] = bias[m] + sum_{ch, ky, kx} big[n][ch][2y-1+ky][2x-1+kx] W[m][ch][ky][kx]
-template <int S, int CS, int CB, int KS, bool SB, bool BB>
+template <int S, int CS, int CB, int KS, bool SB, bool BB, bool NORM = false, bool STATS = false>
 __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   using G = Shape<S, CS, CB>;
   using D = Down<S, CS, CB, KS>;
@@ -372,6 +372,41 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   char* wl = smem;
   char* patch = smem + D::W_LDS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, cb = a.CB;
+  // NORM: the BIG side (this Conv's input) is the block in front's pre-normalisation output (mdmm_conv_t.in_mean);
+  // STATS: sums of the stored small side for the BatchNorm behind this layer (mdmm_conv_t.out_stats)
+  float* const ntab = reinterpret_cast<float*>(smem + ((D::LDS + 15) & ~15));
+  float* const sred = ntab + NORM_GROUPS * 2 * CB;
+  if constexpr (NORM) norm_table<CB>(a, ntab, 256);
+  static_assert(!STATS || G::MT_S == 1, "output statistics: one channel tile");
+  constexpr int SRD = STATS ? (CS >= 32 ? 16 : CS / 2) : 1;
+  float s1[SRD], s2[SRD];
+  int cur_g = -1;
+  auto stats_flush = [&](int g) {
+    if constexpr (STATS) {
+#pragma unroll
+      for (int r = 0; r < SRD; ++r) {
+        float u = s1[r], v = s2[r];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) { u += __shfl_xor(u, off, 64); v += __shfl_xor(v, off, 64); }
+        if ((lane & 31) == 0) { sred[((wave * 2 + h) * 16 + r) * 2] = u; sred[((wave * 2 + h) * 16 + r) * 2 + 1] = v; }
+        s1[r] = 0.f; s2[r] = 0.f;
+      }
+      __syncthreads();
+      if (threadIdx.x < CS) {
+        const int m = threadIdx.x, hh = (m >> 2) & 1, r = 4 * (m >> 3) + (m & 3);
+        double d1 = 0, d2 = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { d1 += sred[((w * 2 + hh) * 16 + r) * 2]; d2 += sred[((w * 2 + hh) * 16 + r) * 2 + 1]; }
+        double* o = a.out_stats + (((size_t)g * CS + m) * gridDim.x + blockIdx.x) * 2;
+        o[0] = d1; o[1] = d2;
+      }
+      __syncthreads();
+    }
+  };
+  if constexpr (STATS) {
+#pragma unroll
+    for (int r = 0; r < SRD; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+  }
   uint4 wreg[D::WREG ? D::CH : 1];
   if constexpr (D::WREG) {
     const uint4* src = reinterpret_cast<const uint4*>(a.wfrag) + (size_t)(wave / (S * S / 32)) * D::CH * 64 + lane;
@@ -395,6 +430,13 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   }
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
     const size_t src0 = (size_t)n * cb * BPIX;
+    if constexpr (STATS) {
+      const int g = n / a.out_group_n;
+      if (g != cur_g) {
+        if (cur_g >= 0) stats_flush(cur_g);
+        cur_g = g;
+      }
+    }
     if constexpr (G::THIN) {
       // four consecutive x per item: four elements per channel, 32 contiguous bytes of the patch
       for (int it = threadIdx.x; it < BPIX / 4; it += 256) {
@@ -422,8 +464,19 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) u[j] = load4<BB>(a.big, src0 + (size_t)(cg * 8 + j) * BPIX + p);
         bf16x8 v0, v1, v2, v3;
+        if constexpr (NORM) {
+          const float* tab = ntab + (size_t)(n / a.in_group_n) * 2 * CB;
+          const bool relu = (a.in_relu & 1) != 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { v0[j] = u[j][0]; v1[j] = u[j][1]; v2[j] = u[j][2]; v3[j] = u[j][3]; }
+          for (int j = 0; j < 8; ++j) {
+            const float sc = tab[cg * 8 + j], sh = tab[CB + cg * 8 + j];
+            v0[j] = norm1(u[j][0], sc, sh, relu); v1[j] = norm1(u[j][1], sc, sh, relu);
+            v2[j] = norm1(u[j][2], sc, sh, relu); v3[j] = norm1(u[j][3], sc, sh, relu);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { v0[j] = u[j][0]; v1[j] = u[j][1]; v2[j] = u[j][2]; v3[j] = u[j][3]; }
+        }
         char* at = patch + ((y + 1) * G::DN_PW + x + 1) * G::DN_PS + cg * 16;
         *reinterpret_cast<uint4*>(at) = __builtin_bit_cast(uint4, v0);
         *reinterpret_cast<uint4*>(at + G::DN_PS) = __builtin_bit_cast(uint4, v1);
@@ -458,11 +511,17 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
 #pragma unroll
       for (int r = 0; r < RV; ++r) {
         const int m = 32 * mt + acc_row(r) + 4 * h;
-        store1<SB>(a.small, dst0 + (size_t)m * NPIX + p, acc[r] + ((G::MT_S > 1 && mt) ? b1[r] : b0[r]));
+        const float v = acc[r] + ((G::MT_S > 1 && mt) ? b1[r] : b0[r]);
+        store1<SB>(a.small, dst0 + (size_t)m * NPIX + p, v);
+        if constexpr (STATS) {              // of the value as stored
+          const float vr = SB ? (float)(__bf16)v : v;
+          s1[r] += vr; s2[r] = fmaf(vr, vr, s2[r]);
+        }
       }
     }
     __syncthreads();
   }
+  if constexpr (STATS) { if (cur_g >= 0) stats_flush(cur_g); }
 }
 
 // ------------------------------------------------------------------------------ wgrad ----
@@ -490,7 +549,8 @@ struct Wg {
 
 __device__ __forceinline__ uint32_t shift16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbyte(hi, lo, 2); }
 
-template <int S, int CS, int CB, int KS, bool SB, bool BB, bool NORM = false>
+// NORM: 1 = the SMALL side is the layer's input in pre-normalisation form (Deconv), 2 = the BIG side is (Conv)
+template <int S, int CS, int CB, int KS, bool SB, bool BB, int NORM = 0>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, float* part, int NT) {
   using G = Shape<S, CS, CB>;
   using W = Wg<S, CS, CB, KS>;
@@ -512,7 +572,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   for (int i = threadIdx.x; i < W::LDS / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
-  if constexpr (NORM) norm_table<CS>(a, ntab, 512);
+  if constexpr (NORM == 1) norm_table<CS>(a, ntab, 512);
+  if constexpr (NORM == 2) norm_table<CB>(a, ntab, 512);
   // per job: this lane's column -> byte offset of its plane rows (or -1) and its shift (-1, 0, +1)
   int col_off[MAXJ], col_sh[MAXJ];
   bool mt_of[MAXJ];
@@ -570,11 +631,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
       const int it = threadIdx.x + 512 * q;
       if (it < CS * NPIX / 8) {
         bf16x8 v = rs[q];
-        if constexpr (NORM) {           // the small side is the layer's input: the block in front's BatchNorm + ReLU
+        if constexpr (NORM == 1) {      // the small side is the layer's input: the block in front's BatchNorm + ReLU
           const float* tab = ntab + (size_t)(n_img / a.in_group_n) * 2 * CS;
           const int ch = it / (NPIX / 8);
           const float sc = tab[ch], sh = tab[CS + ch];
-          const bool relu = a.in_relu != 0;
+          const bool relu = (a.in_relu & 1) != 0;
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = norm1(v[j], sc, sh, relu);
         }
@@ -586,9 +647,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
       const int it = threadIdx.x + 512 * q;
       if (it < cb * B2 * (B2 / 8)) {
         const int xg = it % (B2 / 8), Y = (it / (B2 / 8)) % B2, b = it / ((B2 / 8) * B2);
+        bf16x8 w8 = rb[q];
+        if constexpr (NORM == 2) {      // the big side is the layer's input (Conv): the block in front's BatchNorm + ReLU
+          const float* tab = ntab + (size_t)(n_img / a.in_group_n) * 2 * CB;
+          const float sc = tab[b], sh = tab[CB + b];
+          const bool relu = (a.in_relu & 1) != 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w8[j] = norm1(w8[j], sc, sh, relu);
+        }
         bf16x4 e, o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { e[j] = rb[q][2 * j]; o[j] = rb[q][2 * j + 1]; }
+        for (int j = 0; j < 4; ++j) { e[j] = w8[2 * j]; o[j] = w8[2 * j + 1]; }
         char* row = pl + (size_t)b * W::PL_CS + (Y + 1) * W::PL_RS + 16 + xg * 8;
         *reinterpret_cast<uint2*>(row) = __builtin_bit_cast(uint2, e);
         *reinterpret_cast<uint2*>(row + CB * W::PL_CS) = __builtin_bit_cast(uint2, o);
@@ -771,6 +840,7 @@ int run_up(const mdmm_conv_t* a, hipStream_t st) {
     default: return MDMM_E_ARG;
   }
 }
+constexpr int down_per_cu(int lds) { return lds <= 40 * 1024 ? 4 : (lds <= 80 * 1024 ? 2 : 1); }
 template <int S, int CS, int CB, int KS, bool SB, bool BB>
 int run_down_io(const mdmm_conv_t* a, hipStream_t st) {
   using D = Down<S, CS, CB, KS>;
@@ -779,11 +849,43 @@ int run_down_io(const mdmm_conv_t* a, hipStream_t st) {
   if (rc) return rc;
   // workgroups per CU by what their LDS lets run side by side (S = 32: 36 KB, four per CU: 0.259 -> 0.222 ms at 20,480
   // images, tools/ab_conv_grid.sh; three at S = 16 and more than two of the up kernels measured no better)
-  hipLaunchKernelGGL(k, dim3(grid_for(a->N, D::LDS <= 40 * 1024 ? 4 : (D::LDS <= 80 * 1024 ? 2 : 1), "MDMM_CONV_DOWN_PER_CU")), dim3(256), D::LDS, st, *a);
+  hipLaunchKernelGGL(k, dim3(grid_for(a->N, down_per_cu(D::LDS), "MDMM_CONV_DOWN_PER_CU")), dim3(256), D::LDS, st, *a);
   return (int)hipGetLastError();
+}
+// the big side normalised while it is staged (in_mean) and / or the small side's statistics (out_stats): bf16 small
+// side; bf16 big side, or the fp32 frames of the first encoder layer (statistics only)
+template <int S, int CS, int CB, int KS, bool BB, bool NORM, bool STATS>
+int run_down_fused(const mdmm_conv_t* a, hipStream_t st) {
+  using G = Shape<S, CS, CB>;
+  using D = Down<S, CS, CB, KS>;
+  if constexpr ((STATS && G::MT_S > 1) || (NORM && G::THIN)) return MDMM_E_ARG;
+  else {
+    if ((NORM && !norm_ok(a)) || (STATS && a->out_group_n < 1)) return MDMM_E_ARG;
+    auto k = conv_down_kernel<S, CS, CB, KS, true, BB, NORM, STATS>;
+    constexpr int lds = ((D::LDS + 15) & ~15) + NORM_LDS(CB) + 4 * 2 * 16 * 2 * 4;
+    int rc = set_lds(k, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k, dim3(grid_for(a->N, down_per_cu(lds), "MDMM_CONV_DOWN_PER_CU")), dim3(256), lds, st, *a);
+    return (int)hipGetLastError();
+  }
+}
+template <int S, int CS, int CB, int KS>
+int down_parts(const mdmm_conv_t* a) {
+  using D = Down<S, CS, CB, KS>;
+  constexpr int lds = ((D::LDS + 15) & ~15) + NORM_LDS(CB) + 4 * 2 * 16 * 2 * 4;
+  return grid_for(a->N, down_per_cu(lds), "MDMM_CONV_DOWN_PER_CU");
 }
 template <int S, int CS, int CB, int KS>
 int run_down(const mdmm_conv_t* a, hipStream_t st) {
+  if (a->in_mean || a->out_stats) {
+    const int io = io_of(a);
+    if (io != 1 && io != 2) return MDMM_E_ARG;
+    const bool nm = a->in_mean != nullptr, stt = a->out_stats != nullptr;
+    if (io == 2) return (!nm && stt) ? run_down_fused<S, CS, CB, KS, false, false, true>(a, st) : MDMM_E_ARG;
+    if (nm && stt) return run_down_fused<S, CS, CB, KS, true, true, true>(a, st);
+    if (nm) return run_down_fused<S, CS, CB, KS, true, true, false>(a, st);
+    return run_down_fused<S, CS, CB, KS, true, false, true>(a, st);
+  }
   switch (io_of(a)) {
     case 0: return run_down_io<S, CS, CB, KS, false, false>(a, st);
     case 1: return run_down_io<S, CS, CB, KS, true, true>(a, st);
@@ -816,8 +918,9 @@ template <int S, int CS, int CB, int KS>
 int run_wgrad_norm(const mdmm_conv_t* a, float* part, hipStream_t st) {
   using W = Wg<S, CS, CB, KS>;
   if (io_of(a) != 1 || !norm_ok(a)) return MDMM_E_ARG;
-  auto k = conv_wgrad_kernel<S, CS, CB, KS, true, true, true>;
-  constexpr int lds = ((W::LDS + 15) & ~15) + NORM_LDS(CS);
+  constexpr int lds = ((W::LDS + 15) & ~15) + NORM_LDS(CS > CB ? CS : CB);
+  const bool big = (a->in_relu & 2) != 0;        // which side is the layer's input
+  auto k = big ? conv_wgrad_kernel<S, CS, CB, KS, true, true, 2> : conv_wgrad_kernel<S, CS, CB, KS, true, true, 1>;
   int rc = set_lds(k, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(k, dim3(wgrad_parts(a)), dim3(512), lds, st, *a, part, wgrad_nt(a));
@@ -839,6 +942,13 @@ int run_wgrad(const mdmm_conv_t* a, float* part, hipStream_t st) {
 extern "C" int mdmm_conv_supported(const mdmm_conv_t* a) { return shape_id(a) >= 0; }
 
 extern "C" int mdmm_conv_up_parts(const mdmm_conv_t* a) { return a ? grid_for(a->N, 2, "MDMM_CONV_UP_PER_CU") : 0; }
+
+extern "C" int mdmm_conv_down_parts(const mdmm_conv_t* a) {
+  const int id = shape_id(a);
+  if (id < 0) return 0;
+  if (a->KS == 4) return id == 0 ? down_parts<8, 64, 32, 4>(a) : (id == 1 ? down_parts<16, 32, 16, 4>(a) : down_parts<32, 16, 4, 4>(a));
+  return id == 0 ? down_parts<8, 64, 32, 3>(a) : (id == 1 ? down_parts<16, 32, 16, 3>(a) : down_parts<32, 16, 4, 3>(a));
+}
 
 extern "C" int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* a, int up) {
   const int id = shape_id(a);
@@ -892,7 +1002,7 @@ extern "C" int mdmm_conv_up(const mdmm_conv_t* a, void* stream) {
 extern "C" int mdmm_conv_down(const mdmm_conv_t* a, void* stream) {
   int rc = check_io(a);
   if (rc) return rc;
-  if (a->in_mean) return MDMM_E_ARG;            // (input normalisation: the small side of up / wgrad only)
+
   if (!a->wfrag) return MDMM_E_ARG;
   if (((uintptr_t)a->wfrag) & 15) return MDMM_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;

@@ -142,7 +142,7 @@ class _ConvBlock(nn.Module):
             # activations forward, one reduction backward less per layer) and only enters the
             # running mean, as in the stock modules.
             if ops.batchnorm_relu_supported(x, bn) and x.is_cuda:
-                if ops.BN_DEFER and isinstance(layer, nn.ConvTranspose2d) and ops.conv_tiles_supported(layer, x) \
+                if ops.BN_DEFER and isinstance(layer, (nn.ConvTranspose2d, nn.Conv2d)) and ops.conv_tiles_supported(layer, x) \
                         and ops.ACT_STORAGE is torch.bfloat16:
                     y_pre, part = ops.conv_tiles(layer, x, bias=False, stats_for=bn)
                     return ops.DeferredNorm(y_pre, bn, layer.bias, part)
@@ -218,7 +218,12 @@ class _GaussHead(nn.Module):
         nn.init.xavier_uniform_(self.feat_to_z_std[0].weight)
 
     def forward(self, x):
-        feats = self.conv_stack(x)
+        from .. import ops
+        # (conv blocks hand their BatchNorm + ReLU to the next Conv where that one normalises on the fly)
+        with ops.bn_defer(x.is_cuda):
+            feats = self.conv_stack(x)
+        if isinstance(feats, ops.DeferredNorm):
+            feats = feats.tensor()
         if not self.gauss_out:
             return feats
         flat = feats.view(-1, self.feat_dim)

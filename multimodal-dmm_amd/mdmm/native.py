@@ -33,7 +33,7 @@ SYMBOLS = [
     'mdmm_gauss_mlp_supported', 'mdmm_gauss_mlp_dw_width', 'mdmm_gauss_mlp_dw_rows',
     'mdmm_gauss_mlp_fwd', 'mdmm_gauss_mlp_bwd',
     'mdmm_bn_splits', 'mdmm_bn_relu_fwd', 'mdmm_bn_relu_bwd',
-    'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_up', 'mdmm_conv_up_parts', 'mdmm_conv_down',
+    'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_up', 'mdmm_conv_up_parts', 'mdmm_conv_down_parts', 'mdmm_conv_down',
     'mdmm_conv_wgrad_ws_bytes', 'mdmm_conv_wgrad',
     'mdmm_gemm_supported', 'mdmm_gemm_split', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
     'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
@@ -281,6 +281,7 @@ def lib():
         L.mdmm_conv_pack.argtypes = [C.POINTER(Conv), C.c_int, _P, _P, _P]
         L.mdmm_conv_up.argtypes = [C.POINTER(Conv), _P]
         L.mdmm_conv_up_parts.argtypes = [C.POINTER(Conv)]
+        L.mdmm_conv_down_parts.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_down.argtypes = [C.POINTER(Conv), _P]
         L.mdmm_conv_wgrad_ws_bytes.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_wgrad_ws_bytes.restype = C.c_int64

@@ -1695,21 +1695,26 @@ def prepack_convs(modules):
             _conv_pack(layer.weight, a, False)
 
 
-def _conv_out_stats(a, groups, y):
+def _conv_out_stats(a, groups, y, up=True):
     """Zeroed partial-sum buffer of mdmm_conv_t.out_stats for `groups` statistics groups of the N images of y
-    (sets the descriptor's fields); [groups][CB][parts][2] doubles, parts = workgroups of the launch."""
-    parts = native.lib().mdmm_conv_up_parts(C.byref(a))
-    part = torch.zeros(groups * a.CB * parts * 2, device=y.device, dtype=torch.float64)
+    (sets the descriptor's fields); [groups][channels of y][parts][2] doubles, parts = workgroups of the launch."""
+    lib = native.lib()
+    parts = lib.mdmm_conv_up_parts(C.byref(a)) if up else lib.mdmm_conv_down_parts(C.byref(a))
+    part = torch.zeros(groups * (a.CB if up else a.CS) * parts * 2, device=y.device, dtype=torch.float64)
     a.out_stats, a.out_group_n = _ptr(part), a.N // groups
     return part
 
 
 def conv_out_stats_supported(layer, x):
-    """The deconvolution's epilogue can carry the BatchNorm statistics of its output: ConvTranspose2d on the tile
-    kernels, 16 or 32 output channels, bf16 activations on both sides."""
+    """The layer's epilogue can carry the BatchNorm statistics of its output: a ConvTranspose2d (bf16 on both
+    sides) or Conv2d (bf16 output; the first encoder layer reads fp32 frames) on the tile kernels with 16 or 32
+    output channels."""
     import torch.nn as nn
-    return (isinstance(layer, nn.ConvTranspose2d) and x.dtype == torch.bfloat16 and ACT_STORAGE is torch.bfloat16
-            and layer.weight.shape[1] in (16, 32) and os.environ.get('MDMM_BN_EPILOGUE') != '0')
+    if ACT_STORAGE is not torch.bfloat16 or os.environ.get('MDMM_BN_EPILOGUE') == '0':
+        return False
+    if isinstance(layer, nn.ConvTranspose2d):
+        return x.dtype == torch.bfloat16 and layer.weight.shape[1] in (16, 32)
+    return isinstance(layer, nn.Conv2d) and layer.weight.shape[0] in (16, 32)
 
 
 class _ConvTilesFn(torch.autograd.Function):
@@ -1742,7 +1747,7 @@ class _ConvTilesFn(torch.autograd.Function):
         a.wfrag = _ptr(keep)
         part = None
         if stats_groups:                # the statistics pass of the BatchNorm behind this layer, in the epilogue
-            part = _conv_out_stats(a, stats_groups, y)
+            part = _conv_out_stats(a, stats_groups, y, up=transposed)
         _call('mdmm_conv_up' if transposed else 'mdmm_conv_down', C.byref(a),
               tag='conv_%s[S=%d]' % ('up' if transposed else 'down', s))
         ctx.transposed, ctx.has_bias = transposed, bias is not None
@@ -1785,30 +1790,33 @@ class _ConvTilesFn(torch.autograd.Function):
 
 
 class _BnDeconvFn(torch.autograd.Function):
-    """relu(batchnorm(x_pre)) of one conv block followed by the next block's ConvTranspose2d(k4,s2,p1), without
-    the normalised activation ever travelling through HBM: the statistics pass of csrc/batchnorm.hip alone
-    (mdmm_bn_t.phase = MDMM_BN_FINALIZE: save_mean / save_invstd / running statistics), then the deconvolution
-    normalises its input while it stages it (mdmm_conv_t.in_mean) -- one read and one write of the activation
-    less per block than _BnReluFn + _ConvTilesFn, same values bit for bit.  Backward: the deconvolution's input
-    gradient (= the gradient of the normalised activation), its weight gradient with the same on-the-fly
-    normalisation of x_pre, then the BatchNorm adjoint kernels on (that gradient, x_pre)."""
+    """relu(batchnorm(x_pre)) of one conv block followed by the next block's ConvTranspose2d(k4,s2,p1) (transposed) or
+    Conv2d(k3,s2,p1), without the normalised activation ever travelling through HBM: the statistics of
+    csrc/batchnorm.hip alone (mdmm_bn_t.phase = MDMM_BN_FINALIZE: save_mean / save_invstd / running statistics; from
+    the producing layer's epilogue sums where it left them: part_in, MDMM_BN_FINALIZE_GIVEN), then the convolution
+    normalises its input while it stages it (mdmm_conv_t.in_mean) -- same values bit for bit as _BnReluFn +
+    _ConvTilesFn.  Backward: the convolution's input gradient (= the gradient of the normalised activation), its
+    weight gradient with the same on-the-fly normalisation of x_pre, then the BatchNorm adjoint kernels on (that
+    gradient, x_pre).  stats_groups: the output's (sum, sum of squares) out of this layer's epilogue for the
+    BatchNorm behind it -> (y, partial sums)."""
 
     @staticmethod
-    def forward(ctx, x_pre, gamma, beta, bn, shift, weight, bias, part_in=None, stats_groups=0):
+    def forward(ctx, x_pre, gamma, beta, bn, shift, weight, bias, part_in=None, stats_groups=0, transposed=True):
         ctx.set_materialize_grads(False)
         _need_gpu(x_pre)
         x = _act(x_pre)
-        N, Cc, s = x.shape[0], x.shape[1], x.shape[2]
-        Ln = s * s
+        N, Cc, side = x.shape[0], x.shape[1], x.shape[2]
+        Ln = side * side
         G = bn_groups_for(N, bn)
         a = native.Bn()
         a.N, a.C, a.L, a.relu, a.groups, a.phase = N // G, Cc, Ln, 1, G, native.BN_FINALIZE
         a.bf16_io = 1
         lib = native.lib()
         a.splits = max(1, lib.mdmm_bn_splits(N // G, Cc, Ln) // G) if G > 1 else lib.mdmm_bn_splits(N, Cc, Ln)
+        bwd_splits = a.splits
         a.eps = bn.eps
         stats = torch.empty(2, G, Cc, device=x.device, dtype=torch.float32)
-        if part_in is not None:         # (sum, sum of squares) per workgroup of the producing deconvolution's epilogue
+        if part_in is not None:         # (sum, sum of squares) per workgroup of the producing layer's epilogue
             part = part_in
             a.phase, a.splits = native.BN_FINALIZE_GIVEN, part_in.numel() // (G * Cc * 2)
         else:
@@ -1824,20 +1832,26 @@ class _BnDeconvFn(torch.autograd.Function):
             sh = None if shift is None else _f32c(shift.detach())
             a.mean_shift = _ptr(sh)
         _call('mdmm_bn_relu_fwd', C.byref(a), nbytes=x.numel() * x.element_size(), tag='mdmm_bn_stats')
-        ks, cb = weight.shape[-1], weight.shape[1]
-        y = torch.empty(N, cb, 2 * s, 2 * s, device=x.device, dtype=torch.bfloat16)
-        c = _conv_desc(N, x.shape, y.shape, ks)
-        c.flags = _conv_flags(x, y)
-        c.small, c.big = _ptr(x), _ptr(y)
+        ks, cs, cb = weight.shape[-1], weight.shape[0], weight.shape[1]
+        if transposed:                  # x = the small side
+            y = torch.empty(N, cb, 2 * side, 2 * side, device=x.device, dtype=torch.bfloat16)
+            small, big = x, y
+        else:                           # x = the big side
+            y = torch.empty(N, cs, side // 2, side // 2, device=x.device, dtype=torch.bfloat16)
+            small, big = y, x
+        c = _conv_desc(N, small.shape, big.shape, ks)
+        c.flags = _conv_flags(small, big)
+        c.small, c.big = _ptr(small), _ptr(big)
         c.bias = _ptr(_f32c(bias.detach())) if bias is not None else None
-        keep = _conv_pack(weight, c, True)
+        keep = _conv_pack(weight, c, transposed)
         c.wfrag = _ptr(keep)
         c.in_mean, c.in_invstd, c.in_gamma, c.in_beta = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(g), _ptr(b)
         c.in_group_n, c.in_relu = N // G, 1
-        part_out = _conv_out_stats(c, stats_groups, y) if stats_groups else None
-        _call('mdmm_conv_up', C.byref(c), tag='conv_up[S=%d]' % s)
+        part_out = _conv_out_stats(c, stats_groups, y, up=transposed) if stats_groups else None
+        _call('mdmm_conv_up' if transposed else 'mdmm_conv_down', C.byref(c),
+              tag='conv_%s[S=%d]' % ('up' if transposed else 'down', c.S))
         ctx.save_for_backward(x, stats, g, b, weight)
-        ctx.meta = (N // G, Cc, Ln, lib.mdmm_bn_splits(N // G, Cc, Ln) if part_in is not None else a.splits, bn.eps, G)
+        ctx.meta = (N // G, Cc, Ln, bwd_splits, bn.eps, G, transposed)
         ctx.has_bias = bias is not None
         ctx.shift_like = None if shift is None else shift.detach()
         if part_out is not None:
@@ -1852,27 +1866,29 @@ class _BnDeconvFn(torch.autograd.Function):
         if ctx.shift_like is not None and ctx.needs_input_grad[4]:
             shift_grad = torch.zeros_like(ctx.shift_like)
         if gy is None:
-            return None, None, None, None, shift_grad, None, None, None, None
+            return None, None, None, None, shift_grad, None, None, None, None, None
         gy = _act(gy)
         if gy.dtype != torch.bfloat16:
             gy = gy.to(torch.bfloat16)
-        Ng, Cc, Ln, splits, eps, G = ctx.meta
+        Ng, Cc, Ln, splits, eps, G, transposed = ctx.meta
         N, ks = x.shape[0], weight.shape[-1]
         gw = gb = dx = None
         dgb = torch.empty(2, Cc, device=x.device, dtype=torch.float32)
-        c = _conv_desc(N, x.shape, gy.shape, ks)
-        c.flags = _conv_flags(x, gy)
+        small, big = (x, gy) if transposed else (gy, x)
+        c = _conv_desc(N, small.shape, big.shape, ks)
+        c.flags = _conv_flags(small, big)
         need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         if need_x:
             dyn = torch.empty_like(x)               # gradient of the normalised activation
-            c.small, c.big = _ptr(dyn), _ptr(gy)
-            keep = _conv_pack(weight, c, False)
+            c.small, c.big = (_ptr(dyn), _ptr(gy)) if transposed else (_ptr(gy), _ptr(dyn))
+            keep = _conv_pack(weight, c, not transposed)
             c.wfrag = _ptr(keep)
-            _call('mdmm_conv_down', C.byref(c), tag='conv_down[S=%d]' % c.S)
+            _call('mdmm_conv_down' if transposed else 'mdmm_conv_up', C.byref(c),
+                  tag='conv_%s[S=%d]' % ('down' if transposed else 'up', c.S))
         if ctx.needs_input_grad[5]:
-            c.small, c.big, c.wfrag = _ptr(x), _ptr(gy), None
+            c.small, c.big, c.wfrag = _ptr(small), _ptr(big), None
             c.in_mean, c.in_invstd, c.in_gamma, c.in_beta = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(g), _ptr(b)
-            c.in_group_n, c.in_relu = Ng, 1
+            c.in_group_n, c.in_relu = Ng, (1 if transposed else 3)      # (bit 1: the input is the big side)
             ws = torch.empty(native.lib().mdmm_conv_wgrad_ws_bytes(C.byref(c)), device=x.device, dtype=torch.uint8)
             gw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
             _call('mdmm_conv_wgrad', C.byref(c), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % c.S)
@@ -1889,7 +1905,7 @@ class _BnDeconvFn(torch.autograd.Function):
             a.dgamma, a.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
             _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=x.numel() * x.element_size() * 5)
         return (dx, dgb[0] if (need_x and ctx.needs_input_grad[1]) else None,
-                dgb[1] if (need_x and ctx.needs_input_grad[2]) else None, None, shift_grad, gw, gb, None, None)
+                dgb[1] if (need_x and ctx.needs_input_grad[2]) else None, None, shift_grad, gw, gb, None, None, None)
 
 
 class DeferredNorm:
@@ -1928,7 +1944,8 @@ def bn_deconv_supported(pending, layer):
     training-mode BatchNorm on its own rank's statistics with at most 8 groups."""
     import torch.nn as nn
     x, bn = pending.x_pre, pending.bn
-    if not (isinstance(layer, nn.ConvTranspose2d) and x.is_cuda and x.dtype == torch.bfloat16 and ACT_STORAGE is torch.bfloat16):
+    if not (isinstance(layer, (nn.ConvTranspose2d, nn.Conv2d)) and x.is_cuda and x.dtype == torch.bfloat16
+            and ACT_STORAGE is torch.bfloat16):
         return False
     if os.environ.get('MDMM_BN_DECONV') == '0' or not conv_tiles_supported(layer, x) or not bn.training:
         return False
@@ -1940,12 +1957,13 @@ def bn_deconv_supported(pending, layer):
 def bn_deconv(pending, layer, bias=True, stats_for=None):
     """layer(relu(bn(x_pre))) for a DeferredNorm that bn_deconv_supported accepts.  stats_for: the BatchNorm behind
     `layer` when its statistics are to come out of this deconvolution's epilogue -> (output, partial sums)."""
+    import torch.nn as nn
     bn = pending.bn
     groups = 0
     if stats_for is not None and conv_out_stats_supported(layer, pending.x_pre):
         groups = bn_groups_for(pending.x_pre.shape[0], stats_for)
     out = _BnDeconvFn.apply(pending.x_pre, bn.weight, bn.bias, bn, pending.shift, layer.weight,
-                            layer.bias if bias else None, pending.part, groups)
+                            layer.bias if bias else None, pending.part, groups, isinstance(layer, nn.ConvTranspose2d))
     if stats_for is not None:
         return out if groups else (out, None)
     return out

@@ -278,3 +278,42 @@ def test_deferred_batchnorm_in_deconv_equals_materialised(dev, groups, monkeypat
             assert l2(a_, b_) < 2e-3, k
     for k in se:
         assert helpers.rel_err(se[k].float(), sb[k].float()) < 1e-5, k
+
+
+def test_deferred_batchnorm_in_encoder_convs(dev, monkeypatch):
+    """The same for ImageEncoder (Conv2d blocks: mdmm_conv_down normalises its big side while staging it, the
+    statistics come out of the producing convolution's epilogue -- the first layer's from fp32 frames): against the
+    materialised form, as test_deferred_batchnorm_in_deconv_equals_materialised."""
+    import copy
+    from mdmm import ops
+    from mdmm.models import common as C
+    torch.manual_seed(11)
+    ref = C.ImageEncoder(256, n_channels=3).to(dev).train()
+    x = torch.rand(600, 3, 64, 64, device=dev)
+    res = []
+    for deconv, epilogue in (('1', '1'), ('1', '0'), ('0', '0')):
+        enc = copy.deepcopy(ref)
+        monkeypatch.setenv('MDMM_BN_DECONV', deconv)
+        monkeypatch.setenv('MDMM_BN_EPILOGUE', epilogue)
+        with ops.conv_operands(torch.bfloat16, torch.bfloat16):
+            mean, std = enc(x)
+        gm = torch.randn(mean.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        grads = torch.autograd.grad((mean * gm).sum() + std.sum(), list(enc.parameters()), allow_unused=True)
+        res.append((torch.cat([mean, std], 1), grads,
+                    {k: v.clone() for k, v in enc.state_dict().items() if 'running' in k or 'tracked' in k}))
+    names = [k for k, _ in ref.named_parameters()]
+    (oe, ge, se), (oa, ga, sa), (ob, gb, sb) = res
+    l2 = lambda a_, b_: float((a_.float() - b_.float()).norm() / (b_.float().norm() + 1e-30))      # noqa: E731
+    assert torch.equal(oa, ob)
+    for k, a_, b_ in zip(names, ga, gb):
+        assert (a_ is None) == (b_ is None), k
+        if a_ is not None:
+            assert l2(a_, b_) < 1e-6, k
+    for k in sa:
+        assert l2(sa[k], sb[k]) < 1e-6, k
+    assert l2(oe, ob) < 2e-4
+    for k, a_, b_ in zip(names, ge, gb):
+        if a_ is not None:
+            assert l2(a_, b_) < 2e-3, k
+    for k in se:
+        assert l2(se[k], sb[k]) < 1e-5, k
