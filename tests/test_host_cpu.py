@@ -339,3 +339,31 @@ def test_colsum_launch_geometry():
     assert 1 <= L.mdmm_colsum_splits(10240, 4096) <= 64
     assert L.mdmm_colsum_splits(100, 64) == 1
     assert L.mdmm_colsum(None, 0, 8, 8, 8, None, None, None) < 0
+
+
+def test_gemm_split_and_conv_parts_planning():
+    """Host-side planning entry points (no GPU work): mdmm_gemm_split for the plug-in heads' shapes (csrc/gemm_heads.hip)
+    and for the generic tiles; the workgroup counts behind mdmm_conv_t.out_stats."""
+    import ctypes as C
+    from mdmm import native
+    L = native.lib()
+    g = native.Gemm()
+    # encoder head forward 10,240 x 4096 -> 256, bf16 operands: 80 row tiles -> 3 slices (240 workgroups)
+    g.I, g.J, g.L, g.a_bf16, g.b_bf16, g.lda, g.ldb, g.ldc = 10240, 256, 4096, 1, 1, 4096, 4096, 256
+    g.a = g.b = g.c = 1 << 20
+    assert L.mdmm_gemm_split(C.byref(g)) == 3
+    # decoder head 256 -> 4096, bf16 in and out: weight-stationary kernel, never split
+    g.I, g.J, g.L, g.lda, g.ldb, g.ldc, g.c_bf16 = 10240, 4096, 256, 256, 256, 4096, 1
+    assert L.mdmm_gemm_split(C.byref(g)) == 1
+    # weight gradient 4096 x 256 over 10,240 rows: 32 tiles x 8 slices
+    g.I, g.J, g.L, g.ta, g.tb, g.lda, g.ldb, g.ldc, g.c_bf16 = 4096, 256, 10240, 1, 1, 4096, 256, 256, 0
+    assert L.mdmm_gemm_split(C.byref(g)) == 8
+    # fp32 operands: the generic tiles' rule (fewer than two tiles per CU -> slices of at least eight steps)
+    g.a_bf16 = g.b_bf16 = 0
+    s = L.mdmm_gemm_split(C.byref(g))
+    assert 1 <= s <= 64 and s <= (10240 // 32) // 8
+    c = native.Conv()
+    c.N, c.S, c.CS, c.CB, c.KS = 20480, 16, 32, 16, 4
+    assert L.mdmm_conv_up_parts(C.byref(c)) == 512
+    c.N = 100
+    assert L.mdmm_conv_up_parts(C.byref(c)) == 100 and 1 <= L.mdmm_conv_down_parts(C.byref(c)) <= 100
