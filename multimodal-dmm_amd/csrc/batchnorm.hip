@@ -81,13 +81,9 @@ struct Rows {
 };
 
 struct Span { int64_t n_lo, n_hi; };
-// mirror: the apply pass of the backward walks the images in the opposite order of the statistics pass in front of
-// it -- what that one read last (and the Infinity Cache still holds) is read first
-__device__ __forceinline__ Span span_of(int64_t N, bool mirror = false) {
+__device__ __forceinline__ Span span_of(int64_t N) {
   const int64_t per = (N + gridDim.y - 1) / gridDim.y;
-  const int64_t by = mirror ? (int64_t)gridDim.y - 1 - blockIdx.y : blockIdx.y;
-  Span s; s.n_lo = by * per; s.n_hi = s.n_lo + per < N ? s.n_lo + per : N;
-  if (s.n_lo > N) s.n_lo = N;
+  Span s; s.n_lo = blockIdx.y * per; s.n_hi = s.n_lo + per < N ? s.n_lo + per : N;
   return s;
 }
 
@@ -296,7 +292,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
                                                           const double* __restrict__ partial,
                                                           T* __restrict__ dx, float* dgamma,
                                                           float* dbeta, const double* __restrict__ gsum,
-                                                          double gcount, int mirror) {
+                                                          double gcount) {
   const int c = blockIdx.x;
   const int grp = blockIdx.z, n_grp = gridDim.z;
   auto sums_of = [&](int gi, double& d1, double& d2) {
@@ -327,7 +323,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
   const float mean = save_mean[(size_t)grp * C + c], invstd = save_invstd[(size_t)grp * C + c];
   const float g_ = gamma ? gamma[c] : 1.0f, b_ = beta ? beta[c] : 0.0f;
   const float k = g_ * invstd, shift = fmaf(-mean, k, b_);
-  const Span sp = span_of(N, mirror != 0);
+  const Span sp = span_of(N);
   auto one = [&](float dyv, float xv) {
     const float xh = (xv - mean) * invstd;
     const float gv = (relu && fmaf(xv, k, shift) <= 0.f) ? 0.f : dyv;
@@ -412,7 +408,7 @@ void launch_bwd(const mdmm_bn_t* a, hipStream_t st) {
   if (a->phase != MDMM_BN_STATS)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->dy, (const T*)a->x, a->N, a->C,
                        a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial, (T*)a->dx,
-                       a->dgamma, a->dbeta, a->global_sums, a->global_count, getenv("MDMM_BN_MIRROR") ? atoi(getenv("MDMM_BN_MIRROR")) : 1);
+                       a->dgamma, a->dbeta, a->global_sums, a->global_count);
 }
 
 }  // namespace
