@@ -237,24 +237,49 @@ __device__ __forceinline__ float nllb_grad(float t, float xv, bool on, float sca
   }
 }
 
+// chan_part (optional; vector path, up to 4 channels of chan4 float4 each per row): per workgroup the sums of the
+// stored gradient per channel over its elements -- the bias gradient of a conv layer that produced theta (its
+// column sums over images and pixels) without another pass over g_theta; [gridDim.x][4] floats, folded by the caller
 template <bool LOGITS, typename T>
 __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
-    float scale, const float* __restrict__ scale_dev, T* g_theta, int passes) {
+    float scale, const float* __restrict__ scale_dev, T* g_theta, int passes, float* chan_part, int chan4) {
   if (scale_dev) scale *= *scale_dev;
   if ((inner & 3) == 0 && (n & 3) == 0) {
     const int64_t n4 = n >> 2;
     const int inner4 = inner >> 2;
     const int64_t stride = (int64_t)gridDim.x * NT;
     RowWalk rw((int64_t)blockIdx.x * NT + threadIdx.x, stride, inner4);
+    float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride, rw.next()) {
       const bool on = !(mask && mask[rw.row] == 0.f);
       const float4 xv = reinterpret_cast<const float4*>(x)[i];
+      float gs = 0.f;
       for (int ps = 0; ps < passes; ++ps) {
         const float4 th = ld4f(theta, i + ps * n4);
         const float g[4] = {nllb_grad<LOGITS, T>(th.x, xv.x, on, scale), nllb_grad<LOGITS, T>(th.y, xv.y, on, scale),
                             nllb_grad<LOGITS, T>(th.z, xv.z, on, scale), nllb_grad<LOGITS, T>(th.w, xv.w, on, scale)};
         st4g(g_theta, i + ps * n4, g);
+        if (chan_part) {                        // (of the values as stored)
+          if constexpr (sizeof(T) == 2) gs += ((float)(__bf16)g[0] + (float)(__bf16)g[1]) + ((float)(__bf16)g[2] + (float)(__bf16)g[3]);
+          else gs += (g[0] + g[1]) + (g[2] + g[3]);
+        }
+      }
+      if (chan_part) {
+        const int c = rw.rem / chan4;
+        cs0 += c == 0 ? gs : 0.f; cs1 += c == 1 ? gs : 0.f; cs2 += c == 2 ? gs : 0.f; cs3 += c == 3 ? gs : 0.f;
+      }
+    }
+    if (chan_part) {
+      __shared__ float red[NT / 64][4];
+      cs0 = wave_sum(cs0); cs1 = wave_sum(cs1); cs2 = wave_sum(cs2); cs3 = wave_sum(cs3);
+      const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+      if (lane == 0) { red[w][0] = cs0; red[w][1] = cs1; red[w][2] = cs2; red[w][3] = cs3; }
+      __syncthreads();
+      if (threadIdx.x < 4) {
+        float t = 0.f;
+        for (int k = 0; k < NT / 64; ++k) t += red[k][threadIdx.x];
+        chan_part[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
       }
     }
     return;
@@ -500,7 +525,7 @@ extern "C" int mdmm_nll_bernoulli_logits_bwd(const float* logits, const float* x
   if (!logits || !x || !g_logits || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_bwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, logits, x, seq_mask,
-                     n, inner, scale, scale_dev, g_logits, 1);
+                     n, inner, scale, scale_dev, g_logits, 1, nullptr, 0);
   CHECK_LAUNCH();
 }
 
@@ -520,7 +545,7 @@ extern "C" int mdmm_nll_bernoulli_logits_bf16_bwd(const void* logits, const floa
   if (!logits || !x || !g_logits || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_bwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, (const __bf16*)logits,
-                     x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits, 1);
+                     x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits, 1, nullptr, 0);
   CHECK_LAUNCH();
 }
 
@@ -538,17 +563,25 @@ extern "C" int mdmm_nll_bernoulli_logits_passes_fwd(const void* logits, int logi
   CHECK_LAUNCH();
 }
 
+extern "C" int mdmm_nll_chan_parts(void) { return 2048; }
+
 extern "C" int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logits_bf16, int passes, const float* x,
                                                     const float* seq_mask, int64_t rows, int inner, float scale,
-                                                    const float* scale_dev, void* g_logits, void* stream) {
+                                                    const float* scale_dev, void* g_logits, float* chan_part,
+                                                    int channels, void* stream) {
   if (!logits || !x || !g_logits || rows < 0 || inner < 1 || passes < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
+  int chan4 = 0;
+  if (chan_part) {        // per-channel sums: rows of `channels` equal pieces, whole float4s, the vector path
+    if (channels < 1 || channels > 4 || inner % (4 * channels) || (n & 3)) return MDMM_E_ARG;
+    chan4 = inner / (4 * channels);
+  }
   if (logits_bf16)
     hipLaunchKernelGGL((nllb_bwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
-                       (const __bf16*)logits, x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits, passes);
+                       (const __bf16*)logits, x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits, passes, chan_part, chan4);
   else
     hipLaunchKernelGGL((nllb_bwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
-                       (const float*)logits, x, seq_mask, n, inner, scale, scale_dev, (float*)g_logits, passes);
+                       (const float*)logits, x, seq_mask, n, inner, scale, scale_dev, (float*)g_logits, passes, chan_part, chan4);
   CHECK_LAUNCH();
 }
 
@@ -558,7 +591,7 @@ extern "C" int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const 
   if (!theta || !x || !g_theta || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_bwd_kernel<false, float>), dim3(grid_for(n)), dim3(NT), 0, STREAM, theta, x, seq_mask,
-                     n, inner, scale, scale_dev, g_theta, 1);
+                     n, inner, scale, scale_dev, g_theta, 1, nullptr, 0);
   CHECK_LAUNCH();
 }
 

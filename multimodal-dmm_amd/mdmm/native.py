@@ -37,7 +37,7 @@ SYMBOLS = [
     'mdmm_conv_wgrad_ws_bytes', 'mdmm_conv_wgrad',
     'mdmm_gemm_supported', 'mdmm_gemm_split', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
     'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
-    'mdmm_nll_bernoulli_logits_passes_fwd', 'mdmm_nll_bernoulli_logits_passes_bwd',
+    'mdmm_nll_bernoulli_logits_passes_fwd', 'mdmm_nll_bernoulli_logits_passes_bwd', 'mdmm_nll_chan_parts',
     'mdmm_conv1d_supported', 'mdmm_conv1d_up', 'mdmm_conv1d_down', 'mdmm_conv1d_wgrad_ws_bytes', 'mdmm_conv1d_wgrad',
     'mdmm_colsum_splits', 'mdmm_colsum',
     'mdmm_vrnn_layout', 'mdmm_vrnn_supported', 'mdmm_vrnn_fwd', 'mdmm_vrnn_bwd',
@@ -243,7 +243,8 @@ def lib():
         L.mdmm_nll_bernoulli_logits_bf16_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_bernoulli_logits_bf16_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
         L.mdmm_nll_bernoulli_logits_passes_fwd.argtypes = [_P, i32, i32, _P, _P, i64, i32, f32, _P, _P]
-        L.mdmm_nll_bernoulli_logits_passes_bwd.argtypes = [_P, i32, i32, _P, _P, i64, i32, f32, _P, _P, _P]
+        L.mdmm_nll_bernoulli_logits_passes_bwd.argtypes = [_P, i32, i32, _P, _P, i64, i32, f32, _P, _P, _P, i32, _P]
+        L.mdmm_nll_chan_parts.argtypes = []
         L.mdmm_nan_to_zero.argtypes = [_P, i64, i32, _P, _P, _P]
         L.mdmm_nll_categorical_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_categorical_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]

@@ -343,6 +343,7 @@ def wide_trans(cfg):
 
 def clear_caches(params=()):
     """Drop host-side caches (call before capturing a step into a HIP graph)."""
+    _GRAD_CHANSUM.clear()
     for p in params:
         if hasattr(p, '_mdmm_pack'):
             del p._mdmm_pack
@@ -883,7 +884,7 @@ class _NllBernLogitsFn(torch.autograd.Function):
     have to stack)."""
 
     @staticmethod
-    def forward(ctx, logits, x, mask, rows, inner, weight, into, passes=1):
+    def forward(ctx, logits, x, mask, rows, inner, weight, into, passes=1, channels=0):
         _need_gpu(logits, x)
         lg, xv = _act(logits), _f32c(x)
         if lg.numel() != passes * rows * inner:
@@ -894,6 +895,7 @@ class _NllBernLogitsFn(torch.autograd.Function):
               weight, _ptr(acc), tag='mdmm_nll_bernoulli_logits_fwd')
         ctx.save_for_backward(lg, xv)
         ctx.mask, ctx.rows, ctx.inner, ctx.weight, ctx.passes = mask, rows, inner, weight, passes
+        ctx.channels = channels if (0 < channels <= 4 and inner % (4 * channels) == 0 and (rows * inner) % 4 == 0) else 0
         return _term_out(acc, into, lg.device)
 
     @staticmethod
@@ -901,19 +903,47 @@ class _NllBernLogitsFn(torch.autograd.Function):
         lg, xv = ctx.saved_tensors
         gl = torch.empty_like(lg)
         gd = _gdev(g)
+        part = None
+        if ctx.channels:        # the per-channel sums of gl on the way (the producing conv layer's bias gradient)
+            part = torch.zeros(native.lib().mdmm_nll_chan_parts(), 4, device=lg.device, dtype=torch.float32)
         _call('mdmm_nll_bernoulli_logits_passes_bwd', _ptr(lg), int(ctx.bf), ctx.passes, _ptr(xv), _ptr(ctx.mask),
-              ctx.rows, ctx.inner, ctx.weight, _ptr(gd), _ptr(gl), tag='mdmm_nll_bernoulli_logits_bwd')
-        return gl, None, None, None, None, None, None, None
+              ctx.rows, ctx.inner, ctx.weight, _ptr(gd), _ptr(gl), _ptr(part), ctx.channels,
+              tag='mdmm_nll_bernoulli_logits_bwd')
+        if part is not None:
+            _stash_chansum(gl, colsum(part)[:ctx.channels])
+        return gl, None, None, None, None, None, None, None, None
 
 
-def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None, passes=1):
+# Per-channel sums of a gradient tensor that its producer had at hand, for the consumer that needs them as a bias
+# gradient (the last Deconv behind the Bernoulli loss): keyed by the tensor's address, the tensor itself kept alive
+# with the entry (so that address cannot be handed to another tensor); at most two entries wait, dropped by
+# clear_caches.  A miss (copied gradient, other consumer) is the consumer's own column sum.
+_GRAD_CHANSUM = {}
+
+
+def _stash_chansum(g, sums):
+    while len(_GRAD_CHANSUM) >= 2:
+        _GRAD_CHANSUM.pop(next(iter(_GRAD_CHANSUM)))
+    _GRAD_CHANSUM[g.data_ptr()] = (g, sums)
+
+
+def _take_chansum(g, channels):
+    hit = _GRAD_CHANSUM.pop(g.data_ptr(), None)
+    if hit is not None and hit[0].numel() == g.numel() and hit[0].dtype == g.dtype and hit[1].numel() == channels:
+        return hit[1]
+    return None
+
+
+def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None, passes=1, channels=0):
     """losses.py:23-42 on the pre-sigmoid activations of a decoder whose last module is nn.Sigmoid
     (common.py:163-165): sigmoid + binary cross entropy + masks in one pass each way.  passes: logits =
     that many stacked passes, each scored against x (the sum of their terms)."""
     rows = _lead_rows(x, lead_dims)
     inner = x.numel() // rows
+    if not channels and x.dim() == lead_dims + 3:       # (T, B, C, H, W) observations: C channels per row
+        channels = x.shape[lead_dims]
     return _term_done(_NllBernLogitsFn.apply(logits, x, _row_mask(mask, rows, x), rows, inner,
-                                             float(weight), into, int(passes)), into)
+                                             float(weight), into, int(passes), int(channels)), into)
 
 
 def nan_to_zero(x, lead_dims=2):
@@ -1785,7 +1815,9 @@ class _ConvTilesFn(torch.autograd.Function):
             # per-channel sums over images and pixels: column sums of the (N, C*H*W) matrix on the own
             # kernel (the images are the strided dimension), then C short rows
             c = gy.shape[1]
-            gb = colsum(gy.reshape(n, -1)).reshape(c, -1).sum(1)
+            gb = _take_chansum(gy, c)
+            if gb is None:
+                gb = colsum(gy.reshape(n, -1)).reshape(c, -1).sum(1)
         return gx, gw, gb, None, None
 
 
@@ -1893,7 +1925,9 @@ class _BnDeconvFn(torch.autograd.Function):
             gw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
             _call('mdmm_conv_wgrad', C.byref(c), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % c.S)
         if ctx.has_bias and ctx.needs_input_grad[6]:
-            gb = colsum(gy.reshape(N, -1)).reshape(gy.shape[1], -1).sum(1)
+            gb = _take_chansum(gy, gy.shape[1])
+            if gb is None:
+                gb = colsum(gy.reshape(N, -1)).reshape(gy.shape[1], -1).sum(1)
         if need_x:
             a = native.Bn()
             a.N, a.C, a.L, a.relu, a.splits, a.eps, a.groups = Ng, Cc, Ln, 1, splits, eps, G

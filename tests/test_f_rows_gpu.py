@@ -317,3 +317,39 @@ def test_deferred_batchnorm_in_encoder_convs(dev, monkeypatch):
             assert l2(a_, b_) < 2e-3, k
     for k in se:
         assert l2(se[k], sb[k]) < 1e-5, k
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('chans', [1, 3])
+def test_bernoulli_logits_backward_channel_sums(dev, dtype, chans):
+    """The Bernoulli loss's backward leaves the per-channel sums of the gradient it writes (the bias gradient of the
+    Deconv that produced the logits) for its consumer: equal to the sums of the stored gradient, and taken by
+    _ConvTilesFn.backward instead of a column sum over the whole tensor."""
+    import torch.nn as nn
+    from mdmm import ops
+    torch.manual_seed(chans)
+    T, B, P, H = 4, 5, 2, 64
+    x = torch.rand(T, B, chans, H, H, device=dev)
+    x[1, 2] = float('nan')
+    mask = torch.ones(T, B, dtype=torch.bool, device=dev)
+    mask[3, 3:] = False
+    lg = (torch.randn(P * T * B, chans, H, H, device=dev) * 2).to(dtype).requires_grad_()
+    ops._GRAD_CHANSUM.clear()
+    loss = ops.nll_bernoulli_logits(lg, x, mask, 2, 1.3, None, passes=P)
+    g, = torch.autograd.grad(loss, lg)
+    sums = ops._take_chansum(g, chans)
+    assert sums is not None and ops._take_chansum(g, chans) is None          # taken once
+    ref = g.float().sum((0, 2, 3))
+    assert helpers.rel_err(sums, ref) < 2e-6
+    # end to end: a Deconv in front of the loss gets its bias gradient from there
+    layer = nn.ConvTranspose2d(16, chans, 4, 2, 1).to(dev)
+    a = torch.randn(P * T * B, 16, H // 2, H // 2, device=dev).to(torch.bfloat16)
+    res = []
+    for use in (True, False):
+        with ops.conv_operands(torch.bfloat16, torch.bfloat16):
+            y = ops.conv_tiles(layer, a)
+        loss = ops.nll_bernoulli_logits(y, x, mask, 2, 1.3, None, passes=P)
+        if not use:
+            loss = loss + 0.0 * y.float().sum()          # a second consumer of y: its gradient is a new tensor
+        res.append(torch.autograd.grad(loss, layer.bias)[0])
+    assert helpers.rel_err(res[0], res[1]) < 1e-5
