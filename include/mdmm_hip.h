@@ -552,7 +552,8 @@ typedef struct mdmm_conv {
    * side: parts = mdmm_conv_down_parts, CS channels): the statistics pass of the BatchNorm BEHIND this layer
    * for free -- every workgroup adds (sum, sum of squares) of the values it stores (after their rounding to the big
    * side's storage type) into out_stats[((g * CB + c) * mdmm_conv_up_parts(args) + workgroup) * 2 + {0, 1}], g = n /
-   * out_group_n; the caller zeroes the buffer and hands it to mdmm_bn_relu_fwd as `partial` with phase =
+   * out_group_n (at most 32 groups; every workgroup writes its slab of every group); the caller hands the buffer to
+   * mdmm_bn_relu_fwd as `partial` with phase =
    * MDMM_BN_FINALIZE_GIVEN and splits = mdmm_conv_up_parts.  NULL: none.  */
   double* out_stats;
   int32_t out_group_n, reserved;

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   constexpr int SR = STATS ? CB / 2 : 1;
   float s1[SR], s2[SR];
   int cur_g = -1;
+  unsigned seen_groups = 0;
   auto stats_flush = [&](int g) {
     if constexpr (STATS) {
 #pragma unroll
@@ -273,7 +274,19 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
         double* o = a.out_stats + (((size_t)g * CB + m) * gridDim.x + blockIdx.x) * 2;
         o[0] = d1; o[1] = d2;
       }
+      seen_groups |= 1u << g;
       __syncthreads();
+    }
+  };
+  // every workgroup writes its slab of every group (zeros where it held no image): the caller need not clear the buffer
+  auto stats_rest = [&]() {
+    if constexpr (STATS) {
+      const int groups = (a.N + a.out_group_n - 1) / a.out_group_n;
+      for (int g = 0; g < groups; ++g)
+        if (!((seen_groups >> g) & 1u) && threadIdx.x < CB) {
+          double* o = a.out_stats + (((size_t)g * CB + threadIdx.x) * gridDim.x + blockIdx.x) * 2;
+          o[0] = 0.0; o[1] = 0.0;
+        }
     }
   };
   if constexpr (STATS) {
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
     }
     __syncthreads();
   }
-  if constexpr (STATS) { if (cur_g >= 0) stats_flush(cur_g); }
+  if constexpr (STATS) { if (cur_g >= 0) stats_flush(cur_g); stats_rest(); }
 }
 
 // ------------------------------------------------------------------------------- down ----
@@ -381,6 +394,7 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   constexpr int SRD = STATS ? (CS >= 32 ? 16 : CS / 2) : 1;
   float s1[SRD], s2[SRD];
   int cur_g = -1;
+  unsigned seen_groups = 0;
   auto stats_flush = [&](int g) {
     if constexpr (STATS) {
 #pragma unroll
@@ -400,7 +414,19 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
         double* o = a.out_stats + (((size_t)g * CS + m) * gridDim.x + blockIdx.x) * 2;
         o[0] = d1; o[1] = d2;
       }
+      seen_groups |= 1u << g;
       __syncthreads();
+    }
+  };
+  // every workgroup writes its slab of every group (zeros where it held no image): the caller need not clear the buffer
+  auto stats_rest = [&]() {
+    if constexpr (STATS) {
+      const int groups = (a.N + a.out_group_n - 1) / a.out_group_n;
+      for (int g = 0; g < groups; ++g)
+        if (!((seen_groups >> g) & 1u) && threadIdx.x < CS) {
+          double* o = a.out_stats + (((size_t)g * CS + threadIdx.x) * gridDim.x + blockIdx.x) * 2;
+          o[0] = 0.0; o[1] = 0.0;
+        }
     }
   };
   if constexpr (STATS) {
@@ -521,7 +547,7 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
     }
     __syncthreads();
   }
-  if constexpr (STATS) { if (cur_g >= 0) stats_flush(cur_g); }
+  if constexpr (STATS) { if (cur_g >= 0) stats_flush(cur_g); stats_rest(); }
 }
 
 // ------------------------------------------------------------------------------ wgrad ----

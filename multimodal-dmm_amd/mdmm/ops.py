@@ -1726,11 +1726,11 @@ def prepack_convs(modules):
 
 
 def _conv_out_stats(a, groups, y, up=True):
-    """Zeroed partial-sum buffer of mdmm_conv_t.out_stats for `groups` statistics groups of the N images of y
+    """Partial-sum buffer of mdmm_conv_t.out_stats for `groups` statistics groups of the N images of y
     (sets the descriptor's fields); [groups][channels of y][parts][2] doubles, parts = workgroups of the launch."""
     lib = native.lib()
     parts = lib.mdmm_conv_up_parts(C.byref(a)) if up else lib.mdmm_conv_down_parts(C.byref(a))
-    part = torch.zeros(groups * (a.CB if up else a.CS) * parts * 2, device=y.device, dtype=torch.float64)
+    part = torch.empty(groups * (a.CB if up else a.CS) * parts * 2, device=y.device, dtype=torch.float64)
     a.out_stats, a.out_group_n = _ptr(part), a.N // groups
     return part
 
