@@ -561,6 +561,18 @@ typedef struct mdmm_conv {
 int mdmm_conv_supported(const mdmm_conv_t* args);
 int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* args, int up);
 int mdmm_conv_pack(const mdmm_conv_t* args, int up, const float* weight, void* out, void* stream);
+/* the packs of several layers / directions in one launch (a step re-packs every layer after the optimizer's update) */
+#define MDMM_CONV_PACK_BATCH_MAX 32
+typedef struct mdmm_conv_pack_item {
+  const float* weight;   /* torch's [CS][CB][KS][KS] */
+  void* out;             /* mdmm_conv_pack_bytes(args, up) bytes, 16-byte aligned */
+  int32_t S, CS, CB, KS, up, reserved;
+} mdmm_conv_pack_item_t;
+typedef struct mdmm_conv_pack_batch {
+  int32_t n, reserved;
+  mdmm_conv_pack_item_t item[MDMM_CONV_PACK_BATCH_MAX];
+} mdmm_conv_pack_batch_t;
+int mdmm_conv_pack_batch(const mdmm_conv_pack_batch_t* batch, void* stream);
 int mdmm_conv_up(const mdmm_conv_t* args, void* stream);
 int mdmm_conv_up_parts(const mdmm_conv_t* args);     /* workgroups of that launch = partial slabs of out_stats */
 int mdmm_conv_down_parts(const mdmm_conv_t* args);   /* the same for mdmm_conv_down with in_mean / out_stats */
@@ -616,6 +628,21 @@ int mdmm_gemm_supported(const mdmm_gemm_t* args);
 int mdmm_gemm_split(const mdmm_gemm_t* args);
 int64_t mdmm_gemm_ws_bytes(const mdmm_gemm_t* args);
 int mdmm_gemm_bf16(const mdmm_gemm_t* args, void* stream);
+/* The heads' operand copies for a step in one launch: out = bf16(weight) (n x k), out_t = its transpose (k x n); n, k
+ * multiples of 64, weight fp32 with leading dimension ld (what mdmm_gemm_bf16's shape-specialised kernels take as B). */
+#define MDMM_LIN_PACK_BATCH_MAX 16
+typedef struct mdmm_lin_pack_item {
+  const float* weight;
+  void* out;
+  void* out_t;
+  int32_t n, k;
+  int64_t ld;
+} mdmm_lin_pack_item_t;
+typedef struct mdmm_lin_pack_batch {
+  int32_t n, reserved;
+  mdmm_lin_pack_item_t item[MDMM_LIN_PACK_BATCH_MAX];
+} mdmm_lin_pack_batch_t;
+int mdmm_lin_pack_batch(const mdmm_lin_pack_batch_t* batch, void* stream);
 /* Column sums out[j] = sum_i a[i*lda + j] of a (rows x cols) fp32 or bf16 matrix: the bias gradient of
  * those projections (autograd of nn.Linear's bias, common.py:114-175), which the row-major gradient
  * makes a strided reduction.  cols, lda multiples of 4; ws = mdmm_colsum_splits(rows, cols) * cols floats. */

@@ -128,7 +128,7 @@ struct Down {
 // A-operand fragments: entry [tile][chunk][lane] = 8 bf16, row m = 32 tile + lane % 32,
 // contraction index k = 16 chunk + 8 (lane / 32) + j.
 template <int S, int CS, int CB>
-__global__ void pack_up_kernel(const float* w, int cb, int KS, uint4* out) {
+__device__ __forceinline__ void pack_up_body(const float* w, int cb, int KS, uint4* out) {
   using G = Shape<S, CS, CB>;
   const int total = 4 * G::UP_CH * 64;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -147,8 +147,11 @@ __global__ void pack_up_kernel(const float* w, int cb, int KS, uint4* out) {
   }
 }
 
+template <int S, int CS, int CB>
+__global__ void pack_up_kernel(const float* w, int cb, int KS, uint4* out) { pack_up_body<S, CS, CB>(w, cb, KS, out); }
+
 template <int S, int CS, int CB, int KS>
-__global__ void pack_down_kernel(const float* w, int cb, uint4* out) {
+__device__ __forceinline__ void pack_down_body(const float* w, int cb, uint4* out) {
   using G = Shape<S, CS, CB>;
   using D = Down<S, CS, CB, KS>;
   const int total = G::MT_S * D::CH * 64;
@@ -166,6 +169,29 @@ __global__ void pack_down_kernel(const float* w, int cb, uint4* out) {
       v[j] = (__bf16)x;
     }
     out[idx] = __builtin_bit_cast(uint4, v);
+  }
+}
+
+template <int S, int CS, int CB, int KS>
+__global__ void pack_down_kernel(const float* w, int cb, uint4* out) { pack_down_body<S, CS, CB, KS>(w, cb, out); }
+
+// every pack of a step in ONE launch (mdmm_conv_pack_batch): blockIdx.y = item
+__global__ void pack_batch_kernel(const mdmm_conv_pack_batch_t b) {
+  const mdmm_conv_pack_item_t& it = b.item[blockIdx.y];
+  uint4* o = reinterpret_cast<uint4*>(it.out);
+  const int id = it.S == 8 ? 0 : (it.S == 16 ? 1 : 2);
+  if (it.up) {
+    if (id == 0) pack_up_body<8, 64, 32>(it.weight, it.CB, it.KS, o);
+    else if (id == 1) pack_up_body<16, 32, 16>(it.weight, it.CB, it.KS, o);
+    else pack_up_body<32, 16, 4>(it.weight, it.CB, it.KS, o);
+  } else if (it.KS == 4) {
+    if (id == 0) pack_down_body<8, 64, 32, 4>(it.weight, it.CB, o);
+    else if (id == 1) pack_down_body<16, 32, 16, 4>(it.weight, it.CB, o);
+    else pack_down_body<32, 16, 4, 4>(it.weight, it.CB, o);
+  } else {
+    if (id == 0) pack_down_body<8, 64, 32, 3>(it.weight, it.CB, o);
+    else if (id == 1) pack_down_body<16, 32, 16, 3>(it.weight, it.CB, o);
+    else pack_down_body<32, 16, 4, 3>(it.weight, it.CB, o);
   }
 }
 
@@ -1003,6 +1029,19 @@ extern "C" int mdmm_conv_pack(const mdmm_conv_t* a, int up, const float* w, void
     else if (id == 1) hipLaunchKernelGGL((pack_down_kernel<16, 32, 16, 3>), dim3(16), dim3(256), 0, st, w, a->CB, o);
     else hipLaunchKernelGGL((pack_down_kernel<32, 16, 4, 3>), dim3(16), dim3(256), 0, st, w, a->CB, o);
   }
+  return (int)hipGetLastError();
+}
+
+extern "C" int mdmm_conv_pack_batch(const mdmm_conv_pack_batch_t* b, void* stream) {
+  if (!b || b->n < 1 || b->n > MDMM_CONV_PACK_BATCH_MAX) return MDMM_E_ARG;
+  for (int i = 0; i < b->n; ++i) {
+    const mdmm_conv_pack_item_t& it = b->item[i];
+    mdmm_conv_t a = {};
+    a.N = 1; a.S = it.S; a.CS = it.CS; a.CB = it.CB; a.KS = it.KS;
+    if (shape_id(&a) < 0 || !it.weight || !it.out) return MDMM_E_ARG;
+    if (((uintptr_t)it.out) & 15) return MDMM_E_ALIGN;
+  }
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(16, b->n), dim3(256), 0, (hipStream_t)stream, *b);
   return (int)hipGetLastError();
 }
 

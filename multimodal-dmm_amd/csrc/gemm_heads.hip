@@ -459,6 +459,38 @@ __global__ __launch_bounds__(256) void contract_fold_kernel(const mdmm_gemm_t g)
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The heads' weights as bf16, plain and transposed, for every Linear of a step in one launch (mdmm_lin_pack_batch):
+// blockIdx.y = item, blockIdx.x = 64 x 64 tile of it (transposed through LDS, 8-byte stores both ways).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lin_pack_kernel(const mdmm_lin_pack_batch_t b) {
+  __shared__ __bf16 tile[64][64 + 4];
+  const mdmm_lin_pack_item_t& it = b.item[blockIdx.y];
+  const int tk = it.k / 64, tiles = (it.n / 64) * tk;
+  if ((int)blockIdx.x >= tiles) return;
+  const int r0 = ((int)blockIdx.x / tk) * 64, c0 = ((int)blockIdx.x % tk) * 64;
+  const int t = threadIdx.x, tr = t >> 4, tc = (t & 15) * 4;
+  __bf16* out = reinterpret_cast<__bf16*>(it.out);
+  __bf16* out_t = reinterpret_cast<__bf16*>(it.out_t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = tr + 16 * i;
+    const float4 v = *reinterpret_cast<const float4*>(it.weight + (int64_t)(r0 + r) * it.ld + c0 + tc);
+    bf16x4 p;
+    p[0] = (__bf16)v.x; p[1] = (__bf16)v.y; p[2] = (__bf16)v.z; p[3] = (__bf16)v.w;
+    *reinterpret_cast<u32x2*>(out + (int64_t)(r0 + r) * it.k + c0 + tc) = __builtin_bit_cast(u32x2, p);
+    tile[tc][r] = p[0]; tile[tc + 1][r] = p[1]; tile[tc + 2][r] = p[2]; tile[tc + 3][r] = p[3];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tr + 16 * i;           // column of the weight = row of the transpose
+    bf16x4 p;
+    p[0] = tile[c][tc]; p[1] = tile[c][tc + 1]; p[2] = tile[c][tc + 2]; p[3] = tile[c][tc + 3];
+    *reinterpret_cast<u32x2*>(out_t + (int64_t)(c0 + c) * it.n + r0 + tc) = __builtin_bit_cast(u32x2, p);
+  }
+}
+
 }  // namespace
 
 namespace heads {
@@ -547,3 +579,18 @@ int wgrad_launch(const mdmm_gemm_t* g, hipStream_t st) {
 }
 
 }  // namespace heads
+
+extern "C" int mdmm_lin_pack_batch(const mdmm_lin_pack_batch_t* b, void* stream) {
+  if (!b || b->n < 1 || b->n > MDMM_LIN_PACK_BATCH_MAX) return MDMM_E_ARG;
+  int tiles = 0;
+  for (int i = 0; i < b->n; ++i) {
+    const mdmm_lin_pack_item_t& it = b->item[i];
+    if (!it.weight || !it.out || !it.out_t || it.n < 64 || it.k < 64 || (it.n & 63) || (it.k & 63) || it.ld < it.k || (it.ld & 3))
+      return MDMM_E_ARG;
+    if ((((uintptr_t)it.weight) & 15) || (((uintptr_t)it.out) | ((uintptr_t)it.out_t)) & 7) return MDMM_E_ALIGN;
+    const int tl = (it.n / 64) * (it.k / 64);
+    if (tl > tiles) tiles = tl;
+  }
+  hipLaunchKernelGGL(lin_pack_kernel, dim3(tiles, b->n), dim3(256), 0, (hipStream_t)stream, *b);
+  return (int)hipGetLastError();
+}

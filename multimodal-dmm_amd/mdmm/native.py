@@ -33,7 +33,7 @@ SYMBOLS = [
     'mdmm_gauss_mlp_supported', 'mdmm_gauss_mlp_dw_width', 'mdmm_gauss_mlp_dw_rows',
     'mdmm_gauss_mlp_fwd', 'mdmm_gauss_mlp_bwd',
     'mdmm_bn_splits', 'mdmm_bn_relu_fwd', 'mdmm_bn_relu_bwd',
-    'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_up', 'mdmm_conv_up_parts', 'mdmm_conv_down_parts', 'mdmm_conv_down',
+    'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_pack_batch', 'mdmm_lin_pack_batch', 'mdmm_conv_up', 'mdmm_conv_up_parts', 'mdmm_conv_down_parts', 'mdmm_conv_down',
     'mdmm_conv_wgrad_ws_bytes', 'mdmm_conv_wgrad',
     'mdmm_gemm_supported', 'mdmm_gemm_split', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
     'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
@@ -127,6 +127,23 @@ class Bn(C.Structure):
 
 
 BN_STATS, BN_APPLY, BN_FINALIZE, BN_FINALIZE_GIVEN = 1, 2, 3, 4
+CONV_PACK_BATCH_MAX, LIN_PACK_BATCH_MAX = 32, 16
+
+
+class ConvPackItem(C.Structure):
+    _fields_ = [('weight', _P), ('out', _P)] + [(n, C.c_int32) for n in ('S', 'CS', 'CB', 'KS', 'up', 'reserved')]
+
+
+class ConvPackBatch(C.Structure):
+    _fields_ = [('n', C.c_int32), ('reserved', C.c_int32), ('item', ConvPackItem * CONV_PACK_BATCH_MAX)]
+
+
+class LinPackItem(C.Structure):
+    _fields_ = [('weight', _P), ('out', _P), ('out_t', _P), ('n', C.c_int32), ('k', C.c_int32), ('ld', C.c_int64)]
+
+
+class LinPackBatch(C.Structure):
+    _fields_ = [('n', C.c_int32), ('reserved', C.c_int32), ('item', LinPackItem * LIN_PACK_BATCH_MAX)]
 GEMM_RELU = 32
 
 
@@ -280,6 +297,8 @@ def lib():
         L.mdmm_conv_pack_bytes.argtypes = [C.POINTER(Conv), C.c_int]
         L.mdmm_conv_pack_bytes.restype = C.c_int64
         L.mdmm_conv_pack.argtypes = [C.POINTER(Conv), C.c_int, _P, _P, _P]
+        L.mdmm_conv_pack_batch.argtypes = [C.POINTER(ConvPackBatch), _P]
+        L.mdmm_lin_pack_batch.argtypes = [C.POINTER(LinPackBatch), _P]
         L.mdmm_conv_up.argtypes = [C.POINTER(Conv), _P]
         L.mdmm_conv_up_parts.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_down_parts.argtypes = [C.POINTER(Conv)]

@@ -1698,16 +1698,23 @@ def conv1d_tiles(layer, x, bias=True):
 
 
 def prepack_convs(modules):
-    """Build (or refresh) both fragment packs of every stride-2 layer of the given plug-in modules on the
-    current stream.  A step that forks streams calls this before the fork: the packs are cached on the
-    weights, and one built on a forked stream would be read by the others without a dependency."""
+    """Build (or refresh) both fragment packs of every stride-2 layer of the given plug-in modules -- and the bf16
+    operand copies of their Linear heads -- on the current stream.  A step that forks streams calls this before the
+    fork: the packs are cached on the weights, and one built on a forked stream would be read by the others without a
+    dependency.  Everything that is missing is packed by ONE launch per kind (mdmm_conv_pack_batch,
+    mdmm_lin_pack_batch): a training step re-packs every layer, at its head, where nothing else can run yet."""
     import torch.nn as nn
     table = {(64, 32): 8, (32, 16): 16}
+    conv_items, lin_items = [], []
     for mod in modules:
         for layer in mod.modules():
             if isinstance(layer, nn.Linear) and layer.weight.is_cuda and layer.weight.dtype == torch.float32 \
                     and _heads_shape(layer.in_features, layer.out_features):
-                _lin_pack(layer.weight)             # (the Linear heads' bf16 weight and its transpose)
+                w = layer.weight
+                key = (w.data_ptr(), w._version, tuple(w.shape))
+                hit = getattr(w, '_mdmm_conv_lin', None)
+                if hit is None or hit[0] != key:
+                    lin_items.append((w, key))
                 continue
             if not isinstance(layer, (nn.Conv2d, nn.ConvTranspose2d)) or not layer.weight.is_cuda:
                 continue
@@ -1721,8 +1728,49 @@ def prepack_convs(modules):
                 continue
             a = native.Conv()
             a.N, a.S, a.CS, a.CB, a.KS = 1, s, cs, cb, layer.weight.shape[-1]
-            _conv_pack(layer.weight, a, True)
-            _conv_pack(layer.weight, a, False)
+            for up in (True, False):
+                key = (layer.weight.data_ptr(), layer.weight._version, a.S, a.KS)
+                hit = getattr(layer.weight, '_mdmm_conv_up' if up else '_mdmm_conv_down', None)
+                if hit is None or hit[0] != key:
+                    conv_items.append((layer.weight, a, up, key))
+    if os.environ.get('MDMM_PACK_BATCH') == '0':        # A/B switch: one launch per pack, as before
+        for w, a, up, key in conv_items:
+            _conv_pack(w, a, up)
+        for w, key in lin_items:
+            _lin_pack(w)
+        return
+    lib = native.lib()
+    for lo in range(0, len(conv_items), native.CONV_PACK_BATCH_MAX):
+        chunk = conv_items[lo:lo + native.CONV_PACK_BATCH_MAX]
+        b = native.ConvPackBatch()
+        b.n = len(chunk)
+        keep = []
+        for i, (w, a, up, key) in enumerate(chunk):
+            buf = torch.empty(lib.mdmm_conv_pack_bytes(C.byref(a), int(up)), device=w.device, dtype=torch.uint8)
+            wc = _f32c(w.detach())
+            keep.append(wc)
+            it = b.item[i]
+            it.weight, it.out, it.S, it.CS, it.CB, it.KS, it.up = _ptr(wc), _ptr(buf), a.S, a.CS, a.CB, a.KS, int(up)
+            setattr(w, '_mdmm_conv_up' if up else '_mdmm_conv_down', (key, buf))
+        _call('mdmm_conv_pack_batch', C.byref(b), tag='conv_pack_batch')
+    ok = [(w, key) for w, key in lin_items if w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 and w.stride(1) == 1
+          and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0]
+    ok_ids = {id(w) for w, _ in ok}
+    for w, key in lin_items:
+        if id(w) not in ok_ids:
+            _lin_pack(w)
+    for lo in range(0, len(ok), native.LIN_PACK_BATCH_MAX):
+        chunk = ok[lo:lo + native.LIN_PACK_BATCH_MAX]
+        b = native.LinPackBatch()
+        b.n = len(chunk)
+        for i, (w, key) in enumerate(chunk):
+            n, k = w.shape
+            wb = torch.empty(n, k, device=w.device, dtype=torch.bfloat16)
+            wt = torch.empty(k, n, device=w.device, dtype=torch.bfloat16)
+            it = b.item[i]
+            it.weight, it.out, it.out_t, it.n, it.k, it.ld = _ptr(w.detach()), _ptr(wb), _ptr(wt), n, k, w.stride(0)
+            w._mdmm_conv_lin = (key, wb, wt)
+        _call('mdmm_lin_pack_batch', C.byref(b), tag='lin_pack_batch')
 
 
 def _conv_out_stats(a, groups, y, up=True):
