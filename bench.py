@@ -503,9 +503,14 @@ def run(cfg, args, world, rank, device, graph):
     if graph:       # same step, captured once into two HIP graphs (collective in between, eager)
         try:
             c0, warm = model.noise.counter, 3
-            step = GraphedElboStep(model, optimizer, bucket, inputs, mask, lengths, 1.0, cfg.rec, warmup=warm, **kw)
+            graphed = GraphedElboStep(model, optimizer, bucket, inputs, mask, lengths, 1.0, cfg.rec, warmup=warm, **kw)
+
+            def step():     # as a trainer drives it (trainer.py:226-244): this batch's KLD multiplier and number of
+                graphed.schedule(kld_mult=1.0, n_points=n_points_global)     # time-points go to the device, then the replay
+                return graphed()
+            step.g_step, step.loss = graphed.g_step, graphed.loss
             c_capture = model.noise.counter - (model.noise.counter - c0) // (warm + 1)   # host stream id the capture starts at
-            execution = 'hipgraph'
+            execution = 'hipgraph, schedule scalars on the device'
             if os.environ.get(GRAPH_QUEUES_ENV):
                 execution += ' (%s executor queues)' % os.environ[GRAPH_QUEUES_ENV]
         except Exception as exc:        # noqa: BLE001 -- never lose the run to a capture problem

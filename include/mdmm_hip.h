@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 20
+#define MDMM_ABI_VERSION 21
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -609,6 +609,7 @@ int mdmm_conv1d_wgrad(const mdmm_conv1d_t* args, void* ws, float* dw, void* stre
  *   sets split to it.  The plug-in heads' shapes -- one 256-wide side, bf16 operands in memory, no transposition
  *   flags -- run on shape-specialised kernels (csrc/gemm_heads.hip) behind the same entry point.  */
 #define MDMM_GEMM_RELU 32
+#define MDMM_GEMM_F32 64
 typedef struct mdmm_gemm {
   int32_t I, J, L, ta, tb, split;
   int32_t a_bf16, b_bf16, c_bf16;   /* 1: that matrix is bf16 in memory instead of fp32 */
@@ -628,6 +629,11 @@ int mdmm_gemm_supported(const mdmm_gemm_t* args);
 int mdmm_gemm_split(const mdmm_gemm_t* args);
 int64_t mdmm_gemm_ws_bytes(const mdmm_gemm_t* args);
 int mdmm_gemm_bf16(const mdmm_gemm_t* args, void* stream);
+/* The same products with fp32 operands on the fp32 matrix instruction (flags |= MDMM_GEMM_F32; a, b, c fp32 in
+ * memory): the Linear layers outside the sweeps of a model whose precision switches are fp32 -- the stock MLP
+ * holders common.py:9-41 and the DKS projections dks.py:219-231 in parity mode, where round 2 called the BLAS.
+ * Ask mdmm_gemm_split / mdmm_gemm_ws_bytes with the flag set.  */
+int mdmm_gemm_f32(const mdmm_gemm_t* args, void* stream);
 /* The heads' operand copies for a step in one launch: out = bf16(weight) (n x k), out_t = its transpose (k x n); n, k
  * multiples of 64, weight fp32 with leading dimension ld (what mdmm_gemm_bf16's shape-specialised kernels take as B). */
 #define MDMM_LIN_PACK_BATCH_MAX 16

@@ -117,6 +117,31 @@ __device__ __forceinline__ void store_tile(char* lds, int tid, const Regs& r, bo
   }
 }
 
+// C rows = A rows (registers), C columns = B rows (lanes)
+__device__ __forceinline__ void store_c(const mdmm_gemm_t& g, const f32x16 (&acc)[2][2], int i0, int j0, int wi, int wj,
+                                        int lane, int h) {
+  float* c = g.split > 1 ? g.ws + (size_t)blockIdx.z * g.I * g.J : reinterpret_cast<float*>(g.c);
+  const int64_t ldc = g.split > 1 ? g.J : g.ldc;
+  const bool cbf = g.c_bf16 && g.split == 1;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int j = j0 + wj + 32 * y + (lane & 31);
+      if (j >= g.J) continue;
+      const float bias = (g.bias && g.split == 1) ? g.bias[j] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi + 32 * x + acc_row(r) + 4 * h;
+        if (i >= g.I) continue;
+        float v = acc[x][y][r] + bias;
+        if ((g.flags & MDMM_GEMM_RELU) && g.split == 1) v = fmaxf(v, 0.f);
+        if (cbf) reinterpret_cast<__bf16*>(g.c)[(int64_t)i * ldc + j] = (__bf16)v;
+        else c[(int64_t)i * ldc + j] = v;
+      }
+    }
+}
+
 template <bool TA, bool TB, bool FULL>
 __device__ __forceinline__ void gemm_body(const mdmm_gemm_t& g, char (*lds)[2 * TILE_LDS]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
@@ -170,27 +195,7 @@ __device__ __forceinline__ void gemm_body(const mdmm_gemm_t& g, char (*lds)[2 * 
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[1][1], 0, 0, 0);
     }
   }
-  // C rows = A rows (registers), C columns = B rows (lanes)
-  float* c = g.split > 1 ? g.ws + (size_t)blockIdx.z * g.I * g.J : reinterpret_cast<float*>(g.c);
-  const int64_t ldc = g.split > 1 ? g.J : g.ldc;
-  const bool cbf = g.c_bf16 && g.split == 1;
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      const int j = j0 + wj + 32 * y + (lane & 31);
-      if (j >= g.J) continue;
-      const float bias = (g.bias && g.split == 1) ? g.bias[j] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = i0 + wi + 32 * x + acc_row(r) + 4 * h;
-        if (i >= g.I) continue;
-        float v = acc[x][y][r] + bias;
-        if ((g.flags & MDMM_GEMM_RELU) && g.split == 1) v = fmaxf(v, 0.f);
-        if (cbf) reinterpret_cast<__bf16*>(g.c)[(int64_t)i * ldc + j] = (__bf16)v;
-        else c[(int64_t)i * ldc + j] = v;
-      }
-    }
+  store_c(g, acc, i0, j0, wi, wj, lane, h);
 }
 
 template <bool TA, bool TB>
@@ -199,6 +204,111 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mdmm_gemm_t g) {
   const bool full = (int)(blockIdx.x + 1) * BT <= g.J && (int)(blockIdx.y + 1) * BT <= g.I && g.L % BL == 0;
   if (full) gemm_body<TA, TB, true>(g, lds);
   else gemm_body<TA, TB, false>(g, lds);
+}
+
+// ---- fp32 operands (MDMM_GEMM_F32): the same tile on v_mfma_f32_32x32x2_f32 ---------------------------
+// The Linear layers outside the sweeps of a model whose switches are fp32 (the parity mode, 1e-5 against the
+// oracle): products of fp32 operands, fp32 accumulation -- no rounding of an operand anywhere.  16 contraction
+// values per step ([row][16 l] fp32 = the same 80-byte LDS rows); lane half h reads l = 8h .. 8h+7 of its row
+// as two 16-byte pieces and MFMA i contracts l = i and l = 8 + i (any pairing works: both operands use it).
+constexpr int BLF = 16;
+
+template <bool T, bool FULL>
+__device__ __forceinline__ void load_tile_f32(const void* src, bool bf, int64_t ld, int rows, int L, int row0, int l0,
+                                              int tid, float4 (&r)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int it = tid + 256 * q;
+    float4 v = float4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!T) {
+      const int row = it >> 2, lg = it & 3;
+      if (FULL || (row0 + row < rows && l0 + 4 * lg < L)) v = ld4(src, (int64_t)(row0 + row) * ld + l0 + 4 * lg, bf);
+    } else {
+      const int l = it >> 5, rg = it & 31;
+      if (FULL || (l0 + l < L && row0 + 4 * rg < rows)) v = ld4(src, (int64_t)(l0 + l) * ld + row0 + 4 * rg, bf);
+    }
+    r[q] = v;
+  }
+}
+
+template <bool T>
+__device__ __forceinline__ void store_tile_f32(char* lds, int tid, const float4 (&r)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int it = tid + 256 * q;
+    if constexpr (!T) {
+      const int row = it >> 2, lg = it & 3;
+      *reinterpret_cast<float4*>(lds + row * RS + lg * 16) = r[q];
+    } else {
+      const int l = it >> 5, rg = it & 31;
+      char* at = lds + (4 * rg) * RS + l * 4;
+      *reinterpret_cast<float*>(at) = r[q].x;
+      *reinterpret_cast<float*>(at + RS) = r[q].y;
+      *reinterpret_cast<float*>(at + 2 * RS) = r[q].z;
+      *reinterpret_cast<float*>(at + 3 * RS) = r[q].w;
+    }
+  }
+}
+
+template <bool TA, bool TB, bool FULL>
+__device__ __forceinline__ void gemm_body_f32(const mdmm_gemm_t& g, char (*lds)[2 * TILE_LDS]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int j0 = blockIdx.x * BT, i0 = blockIdx.y * BT;
+  const int steps_all = (g.L + BLF - 1) / BLF;
+  const int per = (steps_all + g.split - 1) / g.split;
+  const int s_lo = blockIdx.z * per, s_hi = min(steps_all, s_lo + per);
+  const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  float4 ra[2], rb[2];
+  const int nst = s_hi - s_lo;
+  if (nst > 0) {
+    load_tile_f32<TA, FULL>(g.a, g.a_bf16, g.lda, g.I, g.L, i0, s_lo * BLF, tid, ra);
+    load_tile_f32<TB, FULL>(g.b, g.b_bf16, g.ldb, g.J, g.L, j0, s_lo * BLF, tid, rb);
+  }
+  for (int s = 0; s < nst; ++s) {
+    char* buf = lds[s & 1];
+    store_tile_f32<TA>(buf, tid, ra);
+    store_tile_f32<TB>(buf + TILE_LDS, tid, rb);
+    __syncthreads();
+    if (s + 1 < nst) {
+      load_tile_f32<TA, FULL>(g.a, g.a_bf16, g.lda, g.I, g.L, i0, (s_lo + s + 1) * BLF, tid, ra);
+      load_tile_f32<TB, FULL>(g.b, g.b_bf16, g.ldb, g.J, g.L, j0, (s_lo + s + 1) * BLF, tid, rb);
+    }
+    const char* pa = buf + (wi + (lane & 31)) * RS + 32 * h;
+    const char* pb = buf + TILE_LDS + (wj + (lane & 31)) * RS + 32 * h;
+    float a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float4 va0 = *reinterpret_cast<const float4*>(pa + 16 * c), va1 = *reinterpret_cast<const float4*>(pa + 32 * RS + 16 * c);
+      const float4 vb0 = *reinterpret_cast<const float4*>(pb + 16 * c), vb1 = *reinterpret_cast<const float4*>(pb + 32 * RS + 16 * c);
+      a0[4 * c] = va0.x; a0[4 * c + 1] = va0.y; a0[4 * c + 2] = va0.z; a0[4 * c + 3] = va0.w;
+      a1[4 * c] = va1.x; a1[4 * c + 1] = va1.y; a1[4 * c + 2] = va1.z; a1[4 * c + 3] = va1.w;
+      b0[4 * c] = vb0.x; b0[4 * c + 1] = vb0.y; b0[4 * c + 2] = vb0.z; b0[4 * c + 3] = vb0.w;
+      b1[4 * c] = vb1.x; b1[4 * c + 1] = vb1.y; b1[4 * c + 2] = vb1.z; b1[4 * c + 3] = vb1.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1[i], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0[i], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc[1][1], 0, 0, 0);
+    }
+  }
+  store_c(g, acc, i0, j0, wi, wj, lane, h);
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const mdmm_gemm_t g) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2 * TILE_LDS];
+  const bool full = (int)(blockIdx.x + 1) * BT <= g.J && (int)(blockIdx.y + 1) * BT <= g.I && g.L % BLF == 0;
+  if (full) gemm_body_f32<TA, TB, true>(g, lds);
+  else gemm_body_f32<TA, TB, false>(g, lds);
 }
 
 // c[i][j] = bias[j] + sum over the split slabs
@@ -317,11 +427,15 @@ extern "C" int mdmm_gemm_split(const mdmm_gemm_t* g) {
   if (!g || g->I < 1 || g->J < 1 || g->L < 1) return 1;
   mdmm_gemm_t t = *g;
   t.split = 1;
-  if (heads::expand_ok(&t)) return 1;
-  if (heads::contract_ok(&t)) return heads::contract_split(&t);
-  if (heads::wgrad_ok(&t)) return heads::wgrad_split(&t);
+  const bool f32 = (g->flags & MDMM_GEMM_F32) != 0;
+  if (!f32) {
+    if (heads::expand_ok(&t)) return 1;
+    if (heads::contract_ok(&t)) return heads::contract_split(&t);
+    if (heads::wgrad_ok(&t)) return heads::wgrad_split(&t);
+  }
   // generic tiles: with fewer than two 128 x 128 tiles per CU the contraction is cut, eight steps per slice at least
-  const int64_t tiles = (int64_t)((g->I + BT - 1) / BT) * ((g->J + BT - 1) / BT), steps = (g->L + BL - 1) / BL;
+  const int bl = f32 ? BLF : BL;
+  const int64_t tiles = (int64_t)((g->I + BT - 1) / BT) * ((g->J + BT - 1) / BT), steps = (g->L + bl - 1) / bl;
   if (tiles >= 512) return 1;
   int64_t s = steps / 8;
   const int64_t want = (512 + tiles - 1) / tiles;
@@ -340,11 +454,20 @@ extern "C" int mdmm_gemm_bf16(const mdmm_gemm_t* g, void* stream) {
   if ((((uintptr_t)g->a) & (g->a_bf16 ? 7 : 15)) || (((uintptr_t)g->b) & (g->b_bf16 ? 7 : 15))) return MDMM_E_ALIGN;
   if (g->split > 1 && !g->ws) return MDMM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (heads::expand_ok(g)) return heads::expand_launch(g, st);
-  if (heads::contract_ok(g)) return heads::contract_launch(g, st);
-  if (heads::wgrad_ok(g)) return heads::wgrad_launch(g, st);
+  const bool f32 = (g->flags & MDMM_GEMM_F32) != 0;
+  if (f32 && (g->a_bf16 || g->b_bf16 || g->c_bf16)) return MDMM_E_ARG;
+  if (!f32) {
+    if (heads::expand_ok(g)) return heads::expand_launch(g, st);
+    if (heads::contract_ok(g)) return heads::contract_launch(g, st);
+    if (heads::wgrad_ok(g)) return heads::wgrad_launch(g, st);
+  }
   const dim3 grid((g->J + BT - 1) / BT, (g->I + BT - 1) / BT, g->split);
-  if (!g->ta && !g->tb) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, st, *g);
+  if (f32) {
+    if (!g->ta && !g->tb) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, *g);
+    else if (!g->ta && g->tb) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, *g);
+    else if (g->ta && g->tb) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, *g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, *g);
+  } else if (!g->ta && !g->tb) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, st, *g);
   else if (!g->ta && g->tb) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, st, *g);
   else if (g->ta && g->tb) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, st, *g);
   else hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, st, *g);
@@ -353,4 +476,13 @@ extern "C" int mdmm_gemm_bf16(const mdmm_gemm_t* g, void* stream) {
   const int64_t n = (int64_t)g->I * g->J;
   hipLaunchKernelGGL(gemm_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *g);
   return (int)hipGetLastError();
+}
+
+// The same products with fp32 operands (v_mfma_f32_32x32x2_f32; every matrix fp32 in memory): sets MDMM_GEMM_F32.
+// mdmm_gemm_split / mdmm_gemm_ws_bytes are asked with the flag set.
+extern "C" int mdmm_gemm_f32(const mdmm_gemm_t* g, void* stream) {
+  if (!g) return MDMM_E_ARG;
+  mdmm_gemm_t t = *g;
+  t.flags |= MDMM_GEMM_F32;
+  return mdmm_gemm_bf16(&t, stream);
 }

@@ -7,6 +7,8 @@ shard, normalises by the GLOBAL number of time-points, and one all-reduce(SUM) o
 flat fp32 gradient bucket (RCCL over xGMI; gloo in the CPU tests) makes every rank's Adam
 step identical.  No collective touches the sweep itself.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -98,6 +100,22 @@ def shard_batch(inputs, mask, lengths, rank, world):
             list(lengths[lo:hi]))
 
 
+def clip_flat_(flat, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (trainer.py:240-241) on the flat gradient buffer, capturable: the global L2
+    norm from the own column-sum kernel (ATen's multi-block reduction does not survive graph replay)
+    plus single-block sums, no host read.  flat *= min(1, max_norm / (norm + 1e-6)); returns the norm."""
+    from . import ops
+    sq = flat * flat
+    k = sq.numel() // 256 * 256
+    if flat.is_cuda and k:
+        total = ops.colsum(sq[:k].view(-1, 256)).sum() + sq[k:].sum()
+    else:
+        total = sq.sum()
+    norm = total.sqrt()
+    flat.mul_((max_norm / (norm + 1e-6)).clamp(max=1.0))
+    return norm
+
+
 def elbo_step(model, optimizer, bucket, inputs, mask, lengths, kld_mult, rec_mults,
               targets=None, n_points_global=None, clip_grad=None, group=None, **train_args):
     """One ELBO step = trainer.py:237-252 on this rank's shard.
@@ -125,26 +143,37 @@ class GraphedElboStep:
     Shapes and tensors are static (the batch buffers are filled in place by the caller);
     fresh noise per replay comes from the Philox device counter (PhiloxNoise.advance).
 
-    For steady-state measurement and fixed-schedule training only: `kld_mult`, `rec_mults`, `lengths`
-    and the normalisation by the number of time-points are Python constants frozen into the captured
-    launches (a trainer that anneals the KLD weight, trainer.py:227-229, or changes the batch shape
-    re-captures, or uses `elbo_step`); gradient clipping is not part of the captured step; the
-    constructor's `warmup` eager steps are real optimizer steps on the given batch."""
+    What a trainer changes from batch to batch is read from the device, not frozen into the captured launches
+    (trainer.py:226-244): the annealed KLD multiplier and the number of time-points the loss is divided by live
+    in 0-dim device tensors (`schedule(kld_mult=..., n_points=...)` before a call), and gradient clipping
+    (`clip_grad`, trainer.py:240-241: one global L2 norm over all parameters, after the all-reduce) is part of
+    the optimizer graph.  `rec_mults` (fixed for a run in the reference, trainer.py:223) and the batch SHAPE are
+    constants of the capture; the constructor's `warmup` eager steps are real optimizer steps on the given batch."""
 
     def __init__(self, model, optimizer, bucket, inputs, mask, lengths, kld_mult, rec_mults,
-                 targets=None, n_points_global=None, group=None, warmup=3, **train_args):
+                 targets=None, n_points_global=None, group=None, warmup=3, clip_grad=None, **train_args):
         from . import ops
-        if train_args.pop('clip_grad', None):
-            raise ValueError('GraphedElboStep does not capture gradient clipping: use elbo_step')
         self.model, self.optimizer, self.bucket, self.group = model, optimizer, bucket, group
         n_points = sum(lengths) if n_points_global is None else n_points_global
         noise = model._noise()
+        dev = bucket.flat.device
+        self.kld_mult = torch.tensor(float(kld_mult), dtype=torch.float32, device=dev)
+        self.inv_points = torch.tensor(1.0 / float(n_points), dtype=torch.float32, device=dev)
+        self.clip_grad = float(clip_grad) if clip_grad is not None and clip_grad > 0 else None
 
         def fwd_bwd():
-            loss = model.step(inputs, mask, kld_mult, rec_mults, targets=targets,
-                              lengths=lengths, **train_args)
-            (loss / n_points).backward()
+            loss = model.step(inputs, mask, float(kld_mult) if os.environ.get('MDMM_FROZEN_SCHEDULE') == '1' else self.kld_mult,
+                              rec_mults, targets=targets, lengths=lengths, **train_args)
+            if os.environ.get('MDMM_FROZEN_SCHEDULE') == '1':      # A/B switch: round 2's Python constants
+                (loss / n_points).backward()
+            else:
+                loss.backward(gradient=self.inv_points)              # (no product node in front of the step's graph)
             return loss.detach()
+
+        def clip_and_step():
+            if self.clip_grad is not None:
+                clip_flat_(bucket.flat, self.clip_grad)
+            optimizer.step()
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -154,7 +183,7 @@ class GraphedElboStep:
                 fwd_bwd()
                 bucket.check_views()
                 bucket.allreduce(group)
-                optimizer.step()
+                clip_and_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops.clear_caches(model.parameters())
@@ -169,7 +198,15 @@ class GraphedElboStep:
                 noise.advance()
         with torch.cuda.graph(self.g_opt, pool=self.g_step.pool(),
                               capture_error_mode='thread_local'):
-            optimizer.step()
+            clip_and_step()
+
+    def schedule(self, kld_mult=None, n_points=None):
+        """Set the KLD multiplier / the normalisation of the next replays (in-place device writes on the current
+        stream, ordered in front of the replay)."""
+        if kld_mult is not None:
+            self.kld_mult.fill_(float(kld_mult))
+        if n_points is not None:
+            self.inv_points.fill_(1.0 / float(n_points))
 
     def __call__(self):
         self.g_step.replay()

@@ -253,7 +253,7 @@ class MultiDKS(MultiDGTS):
             ops.gtf_param_list(self.fwd))
         big_mask = mask.reshape(t_max, 1, b_dim).expand(t_max, n_pass, b_dim).reshape(t_max, rows, 1)
         total = ops.LossSum(im.device)              # all terms add into one device accumulator
-        ops.kld_gauss(im, is_, pm, ps_, big_mask, float(kld_mult), total)
+        ops.kld_gauss(im, is_, pm, ps_, big_mask, *ops.weighted_into(total, kld_mult))
         for m in self.modalities:
             mult = rec_mults.get(m, 1.0)
             used = [p for p, mods in enumerate(loss_mods) if m in mods]

@@ -363,7 +363,7 @@ class MultiDMM(MultiDGTS):
         mask, mask_kld = mask if isinstance(mask, tuple) else (mask, mask)
         # every term adds itself, weighted, to one device accumulator (ops.LossSum)
         total = ops.LossSum(infer[0].device)
-        ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld, float(kld_mult), total)
+        ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld, *ops.weighted_into(total, kld_mult))
         zs_all = zs
         zs = zs.unbind(0)               # per-pass views whose backward is one stack (see _decode_for_loss)
         for m in self.modalities:

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 20
+ABI_VERSION = 21
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -35,7 +35,7 @@ SYMBOLS = [
     'mdmm_bn_splits', 'mdmm_bn_relu_fwd', 'mdmm_bn_relu_bwd',
     'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_pack_batch', 'mdmm_lin_pack_batch', 'mdmm_conv_up', 'mdmm_conv_up_parts', 'mdmm_conv_down_parts', 'mdmm_conv_down',
     'mdmm_conv_wgrad_ws_bytes', 'mdmm_conv_wgrad',
-    'mdmm_gemm_supported', 'mdmm_gemm_split', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16',
+    'mdmm_gemm_supported', 'mdmm_gemm_split', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16', 'mdmm_gemm_f32',
     'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
     'mdmm_nll_bernoulli_logits_passes_fwd', 'mdmm_nll_bernoulli_logits_passes_bwd', 'mdmm_nll_chan_parts',
     'mdmm_conv1d_supported', 'mdmm_conv1d_up', 'mdmm_conv1d_down', 'mdmm_conv1d_wgrad_ws_bytes', 'mdmm_conv1d_wgrad',
@@ -145,6 +145,7 @@ class LinPackItem(C.Structure):
 class LinPackBatch(C.Structure):
     _fields_ = [('n', C.c_int32), ('reserved', C.c_int32), ('item', LinPackItem * LIN_PACK_BATCH_MAX)]
 GEMM_RELU = 32
+GEMM_F32 = 64
 
 
 class Conv(C.Structure):
@@ -317,6 +318,7 @@ def lib():
         L.mdmm_gemm_ws_bytes.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_ws_bytes.restype = C.c_int64
         L.mdmm_gemm_bf16.argtypes = [C.POINTER(Gemm), _P]
+        L.mdmm_gemm_f32.argtypes = [C.POINTER(Gemm), _P]
         L.mdmm_colsum_splits.argtypes = [C.c_int64, C.c_int]
         L.mdmm_colsum.argtypes = [_P, C.c_int, C.c_int64, C.c_int, C.c_int64, _P, _P, _P]
         L.mdmm_vrnn_layout.argtypes = [C.POINTER(Vrnn), C.POINTER(VrnnLayout)]

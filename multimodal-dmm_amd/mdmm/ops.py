@@ -741,10 +741,32 @@ class LossSum:
     def __init__(self, device):
         self.acc = torch.zeros(1, dtype=torch.float64, device=device)
         self.handles = []
+        self.children = []
+
+    def scaled(self, w):
+        """A sub-sum that enters this one times `w`, a 0-dim DEVICE tensor: for a weight that changes between
+        replays of a captured step (the annealed KLD multiplier, trainer.py:227-229) -- the kernels' float
+        weights are launch arguments and would be frozen into the graph.  Terms added `into=` the sub-sum carry
+        their constant weights as usual; its backward kernels read `w * upstream` from the device."""
+        c = LossSum(self.acc.device)
+        self.children.append((w, c))
+        return c
 
     def total(self):
         """0-dim fp32 loss; call once, after the last term."""
-        return _LossTotalFn.apply(self.acc, *self.handles)
+        if not self.children:
+            return _LossTotalFn.apply(self.acc, *self.handles)
+        assert all(not c.children for _, c in self.children)
+        return _LossTotalScaledFn.apply(self.acc, len(self.handles), [(w, c.acc, len(c.handles)) for w, c in self.children],
+                                        *self.handles, *[h for _, c in self.children for h in c.handles])
+
+
+def weighted_into(total, weight):
+    """(float weight, LossSum) for a term weight that is a Python number or a 0-dim device tensor (see
+    LossSum.scaled)."""
+    if torch.is_tensor(weight):
+        return 1.0, total.scaled(weight)
+    return float(weight), total
 
 
 class _LossTotalFn(torch.autograd.Function):
@@ -756,6 +778,27 @@ class _LossTotalFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return (None,) + (g,) * ctx.n
+
+
+class _LossTotalScaledFn(torch.autograd.Function):
+    """LossSum.total() with sub-sums scaled by device scalars (LossSum.scaled): value = acc + sum_c w_c acc_c, the
+    handles of sub-sum c receive w_c times the upstream gradient (one small product per sub-sum each way)."""
+
+    @staticmethod
+    def forward(ctx, acc, n_own, subs, *handles):
+        t = _scalar(acc)
+        for w, acc_c, _ in subs:
+            t = t + w.to(torch.float32) * _scalar(acc_c)
+        ctx.n_own, ctx.counts = n_own, [n for _, _, n in subs]
+        ctx.save_for_backward(*[w for w, _, _ in subs])
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        out = (g,) * ctx.n_own
+        for w, n in zip(ctx.saved_tensors, ctx.counts):
+            out += (g * w.to(g.dtype),) * n
+        return (None, None, None) + out
 
 
 def _term_out(acc, into, dev):
@@ -1042,10 +1085,65 @@ class _TallLinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _LinearF32Fn(torch.autograd.Function):
+    """y = x W^T + b with fp32 operands on csrc/gemm_tiles.hip's fp32 tiles (v_mfma_f32_32x32x2_f32; forward, input
+    gradient, split weight gradient, bias gradient on the column-sum kernel): the Linear layers outside the sweeps
+    of a model whose precision switches are fp32 -- nothing is rounded, so the parity tolerances of that mode
+    (1e-5 against the oracle) hold without the BLAS."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.set_materialize_grads(False)
+        x, w = _rows(x), _rows(weight.detach())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        m, k = x.shape
+        return _gemm_bf16(x, False, w, False, m, w.shape[0], k, _f32c(bias.detach()) if bias is not None else None,
+                          tag='linear_f32_fwd[%dx%d]' % (k, w.shape[0]), f32=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        x, weight = ctx.saved_tensors
+        g, w = _rows(g), _rows(weight.detach())
+        m, k = x.shape
+        n = w.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _gemm_bf16(g, False, w, True, m, k, n, tag='linear_f32_dgrad[%dx%d]' % (k, n), f32=True)
+        if ctx.needs_input_grad[1]:
+            gw = _gemm_bf16(g, True, x, True, n, k, m, tag='linear_f32_wgrad[%dx%d]' % (k, n), f32=True)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = colsum(g)
+        return gx, gw, gb
+
+
+def linear_f32_supported(x, weight):
+    """Shapes the fp32 tiles take (as linear_tiles_supported, fp32 in memory on both sides)."""
+    return (x.dtype == torch.float32 and linear_tiles_supported(x, weight)
+            and os.environ.get('MDMM_LIBRARY_GEMM') != '1')       # (A/B switch: the round-2 route through the BLAS)
+
+
+def linear_f32(x, weight, bias):
+    """fp32 Linear on the own tiles, a thin side (the 10-wide layers of the Categorical MLPs) zero-padded as in
+    linear_tiles_thin; None when the shape is not one the tiles take."""
+    if linear_f32_supported(x, weight):
+        return _LinearF32Fn.apply(x, weight, bias)
+    if linear_tiles_thin_supported(x, weight) and os.environ.get('MDMM_LIBRARY_GEMM') != '1':
+        return linear_tiles_thin(x, weight, bias, fn=_LinearF32Fn)
+    return None
+
+
 def tall_linear(x, layer):
-    """Apply an nn.Linear holder to a (rows, in) activation through _TallLinearFn."""
+    """Apply an nn.Linear holder to a (rows, in) fp32 activation: the own fp32 tiles where the shape allows, else
+    the library GEMM of _TallLinearFn (few rows, odd dimensions)."""
     if x.dim() != 2 or not x.is_floating_point():
         return layer(x)
+    if x.is_cuda and layer.weight.dtype == torch.float32:
+        y = linear_f32(x, layer.weight, layer.bias)
+        if y is not None:
+            return y
     if os.environ.get('MDMM_TRACE_LIB') == '1':         # which layers still reach the library's GEMM
         import sys
         print('tall_linear (library GEMM): x %s %s -> %d, conv_operands %s' % (tuple(x.shape), x.dtype, layer.weight.shape[0],
@@ -1069,16 +1167,17 @@ def _rows(t):
     return t
 
 
-def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.float32, relu=False):
+def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.float32, relu=False, f32=False):
     """c (I,J) = bias + A B^T on csrc/gemm_tiles.hip / gemm_heads.hip; a, b are _rows() matrices.  The library
-    says into how many slices it cuts the contraction (mdmm_gemm_split; their slabs are summed through ws)."""
+    says into how many slices it cuts the contraction (mdmm_gemm_split; their slabs are summed through ws).
+    f32: fp32 operands on the fp32 matrix instruction (mdmm_gemm_f32) instead of bf16-rounded ones."""
     g = native.Gemm()
     g.I, g.J, g.L, g.ta, g.tb, g.split = I, J, L, int(ta), int(tb), 1
     # A/B switches: bit 0 = bf16 operands through the converting path, bit 1 = staggered contraction start,
     # bit 2 = the generic tile kernel where a shape-specialised one (csrc/gemm_heads.hip) would be taken
     g.flags = (int(os.environ.get('MDMM_GEMM_NO_RAW') == '1') | (2 * int(os.environ.get('MDMM_GEMM_ROT', '0') == '1'))
                   | (4 * int(os.environ.get('MDMM_GEMM_GENERIC', '0') == '1')) | (8 * int(os.environ.get('MDMM_GEMM_MODE', '0')))
-                  | (native.GEMM_RELU if relu else 0))
+                  | (native.GEMM_RELU if relu else 0) | (native.GEMM_F32 if f32 else 0))
     g.a, g.lda, g.b, g.ldb = _ptr(a), a.stride(0), _ptr(b), b.stride(0)
     g.a_bf16, g.b_bf16 = int(a.dtype == torch.bfloat16), int(b.dtype == torch.bfloat16)
     c = torch.empty(I, J, device=a.device, dtype=out_dtype)
@@ -1088,7 +1187,7 @@ def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.flo
     if split > 1:
         ws = torch.empty(split * I * J, device=a.device, dtype=torch.float32)
         g.ws = _ptr(ws)
-    _call('mdmm_gemm_bf16', C.byref(g), tag=tag)
+    _call('mdmm_gemm_f32' if f32 else 'mdmm_gemm_bf16', C.byref(g), tag=tag)
     return c
 
 
@@ -1144,7 +1243,7 @@ def linear_tiles_thin_supported(x, weight):
     return m >= 512 and m % 4 == 0 and (thin_k or thin_n) and max(k, n) >= 32 and (thin_k or k % 4 == 0) and (thin_n or n % 4 == 0)
 
 
-def linear_tiles_thin(x, weight, bias):
+def linear_tiles_thin(x, weight, bias, fn=None):
     """y = x W^T + b on csrc/gemm_tiles.hip with the thin side padded by zeros (plain differentiable pads and a
     slice around _LinearTilesFn: the padded weight rows / columns meet zeros and receive zero gradients)."""
     import torch.nn.functional as F
@@ -1158,7 +1257,7 @@ def linear_tiles_thin(x, weight, bias):
     if np_ != n:
         weight = F.pad(weight, (0, 0, 0, np_ - n))
         bias = F.pad(bias, (0, np_ - n)) if bias is not None else None
-    y = _LinearTilesFn.apply(x, weight, bias)
+    y = (fn or _LinearTilesFn).apply(x, weight, bias)
     return y[:, :n] if np_ != n else y
 
 
@@ -1269,6 +1368,10 @@ def tall_projection(x, weight, bias, precision=None):
     when the model's contractions run in bf16, else the fp32 library GEMM of _TallLinearFn."""
     if PRECISIONS[precision] == native.PREC_BF16 and linear_tiles_supported(x, weight):
         return _LinearTilesFn.apply(x, weight, bias)
+    if x.is_cuda and weight.dtype == torch.float32 and x.dim() == 2:
+        y = linear_f32(x, weight, bias)
+        if y is not None:
+            return y
     return _TallLinearFn.apply(x, weight, bias)
 
 

@@ -1417,6 +1417,60 @@ def test_linear_tiles_match_torch(dev, m, k, n):
     close(gwb[:, :k], gyb.float().t() @ xr, 2e-5, 'linear wgrad, bf16 storage')
 
 
+@pytest.mark.parametrize('m,k,n', [(512, 32, 32), (1000, 36, 40), (2048, 256, 4096), (10240, 4096, 256), (640, 260, 132),
+                                   (9216, 10, 256), (9216, 256, 10)])
+def test_linear_f32_tiles_match_fp64(dev, m, k, n):
+    """csrc/gemm_tiles.hip's fp32-operand tiles (mdmm_gemm_f32: the Linear layers outside the sweeps when the
+    model's switches are fp32 -- stock MLP holders common.py:9-41, plug-in heads 114-175, DKS projections
+    dks.py:219-231) against the fp64 product of the SAME fp32 operands: forward, input gradient, split weight
+    gradient, bias gradient; thin (10-wide) sides through the zero pad; a column slice of a wider weight."""
+    from mdmm import ops
+    torch.manual_seed(m + k + n)
+    x = torch.randn(m, k, device=dev, requires_grad=True)
+    wide = (torch.randn(n, k + 8, device=dev) / k ** 0.5).requires_grad_()
+    bias = torch.randn(n, device=dev, requires_grad=True)
+    thin = k < 32 or n < 32
+    for w in ((wide[:, :k],) if thin else (wide[:, 8:], wide[:, :k])):
+        assert ops.linear_f32_supported(x, w) != thin
+        y = ops.linear_f32(x, w, bias)
+        assert y is not None and y.dtype == torch.float32 and y.shape == (m, n)
+        gy = torch.randn_like(y)
+        gx, gwide, gb = torch.autograd.grad(y, [x, wide, bias], gy)
+        x64, w64, g64 = x.detach().double(), w.detach().double(), gy.double()
+        # fp32 accumulation over up to 10,240 terms: a few 1e-7 of the result's scale, nothing like bf16's 4e-3
+        close(y, (x64 @ w64.t() + bias.detach().double()).float(), 2e-6, 'linear f32 fwd')
+        close(gx, (g64 @ w64).float(), 2e-6, 'linear f32 dgrad')
+        gw = gwide[:, 8:] if w.data_ptr() != wide.data_ptr() else gwide[:, :k]
+        close(gw, (g64.t() @ x64).float(), 2e-6, 'linear f32 wgrad')
+        close(gb, g64.sum(0).float(), 1e-5, 'linear f32 bias grad')
+
+
+def test_fp32_model_calls_no_library_gemm(dev):
+    """With fp32 switches the Linear layers outside the sweeps run on the own fp32 tiles: tall_linear /
+    tall_projection of a big-enough batch never reach _TallLinearFn (round 2: torch.addmm / bmm)."""
+    import torch.nn as nn
+    from mdmm import ops
+    calls = []
+    orig = ops._TallLinearFn.apply
+    ops._TallLinearFn.apply = lambda *a: calls.append(tuple(a[0].shape)) or orig(*a)
+    try:
+        torch.manual_seed(0)
+        lay = nn.Linear(256, 4096).to(dev)
+        x = torch.randn(2048, 256, device=dev, requires_grad=True)
+        y = ops.tall_linear(x, lay)
+        y2 = ops.tall_projection(x, lay.weight[:512], lay.bias[:512], None)
+        cat = nn.Linear(256, 10).to(dev)
+        y3 = ops.tall_linear(x, cat)
+        (y.sum() + y2.sum() + y3.sum()).backward()
+        close(y, lay(x), 1e-5, 'tall_linear on the fp32 tiles')
+        close(y3, cat(x), 1e-5, 'thin tall_linear on the fp32 tiles')
+        assert calls == []
+        ops.tall_linear(x[:100], lay)               # few rows: the library route is still there
+        assert calls == [(100, 256)]
+    finally:
+        ops._TallLinearFn.apply = orig
+
+
 @pytest.mark.parametrize('kind,c_in,c_out,length', [('conv', 10, 4, 1281), ('conv', 4, 8, 641), ('conv', 8, 16, 321),
                                                      ('deconv', 16, 8, 161), ('deconv', 8, 4, 321), ('deconv', 4, 10, 641),
                                                      ('conv', 3, 5, 17), ('deconv', 5, 3, 9)])

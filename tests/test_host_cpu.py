@@ -362,8 +362,32 @@ def test_gemm_split_and_conv_parts_planning():
     g.a_bf16 = g.b_bf16 = 0
     s = L.mdmm_gemm_split(C.byref(g))
     assert 1 <= s <= 64 and s <= (10240 // 32) // 8
+    # fp32 operands on the fp32 matrix instruction (MDMM_GEMM_F32): never a head kernel, 16-value steps
+    g.I, g.J, g.L, g.ta, g.tb, g.lda, g.ldb, g.ldc = 10240, 256, 4096, 0, 0, 4096, 4096, 256
+    g.flags = native.GEMM_F32
+    s = L.mdmm_gemm_split(C.byref(g))
+    assert 1 <= s <= 64 and s <= (4096 // 16) // 8
+    g.split = s
+    assert L.mdmm_gemm_ws_bytes(C.byref(g)) == (s * 10240 * 256 * 4 if s > 1 else 0)
+    g.flags, g.split = 0, 1
     c = native.Conv()
     c.N, c.S, c.CS, c.CB, c.KS = 20480, 16, 32, 16, 4
     assert L.mdmm_conv_up_parts(C.byref(c)) == 512
     c.N = 100
     assert L.mdmm_conv_up_parts(C.byref(c)) == 100 and 1 <= L.mdmm_conv_down_parts(C.byref(c)) <= 100
+
+
+def test_clip_flat_matches_clip_grad_norm():
+    """harness.clip_flat_ (the captured step's gradient clipping) = torch.nn.utils.clip_grad_norm_ on the same
+    gradients (trainer.py:240-241), clipping and not clipping."""
+    from mdmm.harness import clip_flat_
+    torch.manual_seed(0)
+    for scale, max_norm in ((1.0, 0.5), (1e-3, 5.0)):
+        ps = [torch.nn.Parameter(torch.zeros(n)) for n in (7, 300, 1025)]
+        for p in ps:
+            p.grad = torch.randn_like(p) * scale
+        flat = torch.cat([p.grad for p in ps]).clone()
+        norm = clip_flat_(flat, max_norm)
+        ref = torch.nn.utils.clip_grad_norm_(ps, max_norm)
+        assert abs(float(norm) - float(ref)) <= 1e-6 * float(ref)
+        assert torch.allclose(flat, torch.cat([p.grad for p in ps]), rtol=1e-6, atol=0)

@@ -11,6 +11,7 @@ graphs by mdmm.harness.GraphedElboStep -- with the allocator dirtied first -- an
 (Three bugs of this project were green eagerly and wrong under replay: a pack built on a forked
 stream, a per-type "LDS attribute set" flag, a BatchNorm fusion that gave NaNs.)  The batch is small
 so that the oracle finishes; trainer.py:237-252 is what the step restates."""
+import numpy as np
 import pytest
 import torch
 
@@ -263,3 +264,92 @@ def test_step_cfg5_plugins_matches_oracle(mode, dev):
             continue
         e = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30))
         assert e < (TOL_GRAD_BF16 if bf16 else 2e-3), 'cfg5 %s grad %s vs oracle: %.3e' % (mode, k, e)
+
+
+@pytest.mark.parametrize('kind', ['dmm', 'dks'])
+def test_graph_replay_follows_the_trainers_schedule(kind, dev):
+    """What the reference's training loop changes from batch to batch (trainer.py:226-244: the annealed KLD
+    multiplier, the division by the batch's number of time-points, gradient clipping) is read from the device by
+    the captured step: one capture, three schedule points, each compared with the eager step at that point."""
+    from mdmm import models
+    from mdmm.harness import GradBucket, GraphedElboStep, clip_flat_
+    from mdmm.noise import PhiloxNoise
+    T, B = 12, 16
+    g = torch.Generator().manual_seed(3)
+    x = {'x': torch.randn(T, B, 2, generator=g).to(dev), 'y': torch.randn(T, B, 3, generator=g).to(dev)}
+    lengths = [T] * (B - 3) + [9, 5, 2]
+    mask = orc.len_to_mask(lengths).to(dev)
+    torch.manual_seed(0)
+    if kind == 'dmm':
+        m = models.MultiDMM(['x', 'y'], [2, 3], h_dim=32, z_dim=32, device=dev)
+        kw = dict(train_particles=4)
+    else:
+        m = models.MultiDKS(['x', 'y'], [2, 3], h_dim=16, z_dim=8, device=dev)
+        kw = {}
+    m.noise = noise = PhiloxNoise(seed=11)
+    rec = {'x': .5, 'y': 2.0}
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+    bucket = GradBucket(m.parameters())
+    clip = 0.05                                                # small enough to bite
+    c0 = noise.counter
+    step = GraphedElboStep(m, opt, bucket, x, mask, lengths, 0.0, rec, warmup=1, clip_grad=clip, **kw)
+    per_step = (noise.counter - c0) // 2
+    c_capture = noise.counter - per_step
+    for kld, n_points in ((0.0, sum(lengths)), (0.37, 2 * sum(lengths)), (1.0, sum(lengths) - 7)):
+        step.schedule(kld_mult=kld, n_points=n_points)
+        d0 = noise.device_counter(dev).clone()
+        step.g_step.replay()
+        torch.cuda.synchronize()
+        loss_r, flat_r = float(step.loss), bucket.flat.clone()
+        # the optimizer graph's clipping, on a copy (the graph itself would also move the weights)
+        clipped = flat_r.clone()
+        norm = clip_flat_(clipped, clip)
+        # eager: Python-number schedule, the stock clip_grad_norm_
+        noise.counter = c_capture
+        noise.device_counter(dev).copy_(d0)
+        bucket.release()
+        loss = m.step(x, mask, kld, rec, lengths=lengths, **kw)
+        (loss / n_points).backward()
+        loss_e = float(loss)
+        assert abs(loss_r - loss_e) <= 2e-6 * abs(loss_e), (kind, kld, loss_r, loss_e)
+        ge = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in m.parameters()])
+        assert float((flat_r - ge).norm() / ge.norm()) < 1e-5, (kind, kld)
+        ref_norm = torch.nn.utils.clip_grad_norm_([p for p in m.parameters() if p.grad is not None], clip)
+        assert float(ref_norm) > clip                          # the clip is active
+        assert abs(float(norm) - float(ref_norm)) <= 1e-5 * float(ref_norm)
+        ge_c = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in m.parameters()])
+        assert float((clipped - ge_c).norm() / ge_c.norm()) < 1e-5
+        bucket.check_views()
+    # the whole pair of graphs, a few times over: finite, and the weights move
+    w0 = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+    for i in range(3):
+        step.schedule(kld_mult=0.1 * i)
+        assert np.isfinite(float(step()))
+    w1 = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    assert torch.isfinite(w1).all() and float((w1 - w0).abs().max()) > 0
+
+
+def test_clip_flat_under_replay(dev):
+    """clip_flat_ captured and replayed (its norm is a many-row reduction: the own column-sum kernel, not ATen's
+    multi-block sum which goes wrong from the second replay on) against clip_grad_norm_."""
+    from mdmm.harness import clip_flat_
+    n = 3_000_017
+    src = torch.randn(n, device=dev) * 0.3
+    flat = src.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        clip_flat_(flat.clone(), 5.0)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        norm = clip_flat_(flat, 5.0)
+    for _ in range(3):
+        flat.copy_(src)
+        graph.replay()
+    torch.cuda.synchronize()
+    ref = src.clone().requires_grad_()
+    ref.grad = src.clone()
+    ref_norm = torch.nn.utils.clip_grad_norm_([ref], 5.0)
+    assert abs(float(norm) - float(ref_norm)) <= 1e-5 * float(ref_norm)
+    assert float((flat - ref.grad).norm() / ref.grad.norm()) < 1e-6
