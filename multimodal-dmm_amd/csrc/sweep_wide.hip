@@ -39,7 +39,9 @@ struct FwdLds {
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <bool F32, int RT, bool K1>
+// LR (K = 1 only): the accumulator registers of a lane that can hold live rows (see wide_bwd_kernel); the
+// elementwise phases and the fusion skip the others.
+template <bool F32, int RT, bool K1, int LR = 16>
 __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, const WideGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = FwdLds<F32, RT>;
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          if (K1 && r >= LR) { x[rt][r] = 0.f; acc[rt][r] = 0.f; continue; }
           const float ex = fast::exp(__builtin_amdgcn_fmed3f(x[rt][r], -30.f, 30.f));
           x[rt][r] = fast::rcp(1.0f + ex);              // 1 - gate
           acc[rt][r] = fmaf(acc[rt][r], ex, bl);
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          if (K1 && r >= LR) { m_[rt][r] = 0.f; var_[rt][r] = 0.f; continue; }
           const float sq = softplus_w<F32>(acc[rt][r]) + a.min_std;               // common.py:66
           const float v = fmaf(sq, sq, MDMM_POE_EPS);
           const float u = fast::rcp(fmaf(t0, v, 1.0f));
@@ -176,6 +180,11 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          if (4 * q >= LR) {           // registers without live rows
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[rt][4 * q + j] = 0.f;
+            continue;
+          }
           float e[4] = {0.f, 0.f, 0.f, 0.f};
           const int r0 = 32 * rt + 8 * q + 4 * h;
           // (the draw of the last step only enters `samples`)
@@ -375,7 +384,11 @@ __device__ __forceinline__ float tile_sum(const f32x16 (&v)[RT]) {
   return s;
 }
 
-template <bool F32, int RT, bool K1>
+// LR (K = 1 only): accumulator registers of a lane that can hold live rows -- a tile's rows 0 .. NP-1 are pairs,
+// register r holds rows 8 (r / 4) + r % 4 + 4 h, so NP <= 8 -> registers 0..3, NP <= 16 -> 0..7.  The per-pair
+// state of a lane (adjoints, noise, fusion results: seven floats a slot) and the elementwise phases cover
+// those registers only: at cfg3 (NP = 8) a quarter of the slots, no register scratch (it was 288 B a lane).
+template <bool F32, int RT, bool K1, int LR = 16>
 __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, const WideGeo g,
                                                         const WideWs ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -409,7 +422,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
   const float t0 = fast::rcp(sg0 * sg0 + MDMM_POE_EPS), num0 = mu0 * t0;
 
   const float dt0 = -2.0f * sg0 * t0 * t0;       // d t0 / d sigma0
-  constexpr int NS = K1 ? 16 * RT : RT;          // pair slots held by a lane
+  static_assert(K1 || LR == 16, "LR is a K = 1 parameter");
+  constexpr int NS = K1 ? LR * RT : RT;          // pair slots held by a lane
   float adj_a[NS], adj_b[NS], se[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) { adj_a[s] = 0.f; adj_b[s] = 0.f; se[s] = 0.f; }
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const bool live = rowbase[r0 + j] != ~0ull;
-          if constexpr (K1) se[rt * 16 + 4 * q + j] = live ? e[j] : 0.f;
+          if constexpr (K1) { if (4 * q + j < LR) se[rt * LR + 4 * q + j] = live ? e[j] : 0.f; }
           else acc += live ? e[j] : 0.f;
         }
       }
@@ -474,8 +488,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int s = rt * 16 + reg;
+        for (int reg = 0; reg < LR; ++reg) {
+          const int s = rt * LR + reg;
           fa[s] = fuse_bwd(a, exs, tab[acc_row(rt, reg) + 4 * h], t, n, mu0, sg0, adj_a[s], adj_b[s], se[s],
                            sampled, inv_k, i == 0, true, g_mu0, g_sg0);
         }
@@ -530,7 +544,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
             const float ee = live ? e[j] : 0.f;
             acc[rt][reg] = live ? fmaf(ee, zs, zm) : 0.f;
             lb |= live ? (1u << reg) : 0u;
-            if constexpr (K1) se[rt * 16 + reg] = ee; else esum += ee;
+            if constexpr (K1) { if (reg < LR) se[rt * LR + reg] = ee; } else esum += ee;
           }
         }
         live_bits[rt] = lb;
@@ -591,6 +605,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        if (K1 && r >= LR) { omg[rt][r] = 0.f; muq[rt][r] = 0.f; continue; }
         const float ex = fast::exp(__builtin_amdgcn_fmed3f(omg[rt][r], -30.f, 30.f));
         omg[rt][r] = fast::rcp(1.0f + ex);
         muq[rt][r] = fmaf(nl[rt][r], ex, bl);
@@ -629,6 +644,10 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
 #pragma unroll
         for (int k = 0; k < CG; ++k) {
           const int r = c0 + k;
+          if (K1 && r >= LR) {         // a register without live rows: zeros, as its masked adjoints were
+            o_g3[k] = 0.f; o_gg[k] = 0.f; o_gl[k] = 0.f; nl[rt][r] = 0.f;
+            continue;
+          }
           const float pre = acc[rt][r];
           const float sq = softplus_w<F32>(pre) + a.min_std;
           const float v = fmaf(sq, sq, MDMM_POE_EPS);
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
           const float mraw = fmaf(muq[rt][r], u, num0 * rp), sd = fast::sqrt(rp);
           const float m = (mraw != mraw) ? 0.f : mraw;                            // dgts.py:49
           float g_m, g_sd;
-          if constexpr (K1) { g_m = fa[rt * 16 + r].gpm; g_sd = fa[rt * 16 + r].gps; }
+          if constexpr (K1) { g_m = fa[rt * LR + (r < LR ? r : 0)].gpm; g_sd = fa[rt * LR + (r < LR ? r : 0)].gps; }
           else { g_m = gpmk + gv2k * (m - mb); g_sd = gv2k * sd; }
           const bool live = (live_bits[rt] >> r) & 1u;
           if (!live || mraw != mraw) g_m = 0.f;                    // (the mean was overwritten by 0)
@@ -724,7 +743,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
             const int r = 4 * q + j;
             const bool live = (live_bits[rt] >> r) & 1u;
             const float gz = live ? acc[rt][r] : 0.f;
-            if constexpr (K1) { adj_a[rt * 16 + r] = gz; adj_b[rt * 16 + r] = gz * e[j]; }
+            if constexpr (K1) { if (r < LR) { adj_a[rt * LR + r] = gz; adj_b[rt * LR + r] = gz * e[j]; } }
             else { sa += gz; sb = fmaf(gz, e[j], sb); }
           }
         }
@@ -964,10 +983,10 @@ __global__ __launch_bounds__(256) void frag_pack_kernel(const mdmm_gtf_raw_t raw
 template <typename Kern>
 int set_lds(Kern kern, int bytes) { return mdmm_lds_attr_fn((const void*)kern, (size_t)bytes); }
 
-template <bool F32, int RT, bool K1>
+template <bool F32, int RT, bool K1, int LR = 16>
 int launch_fwd(const mdmm_sweep_t* a, const WideGeo& g, hipStream_t stream) {
   using L = FwdLds<F32, RT>;
-  auto kern = wide_fwd_kernel<F32, RT, K1>;
+  auto kern = wide_fwd_kernel<F32, RT, K1, LR>;
   int rc = set_lds(kern, L::BYTES);
   if (rc) return rc;
   const int grid = (g.n_pairs + g.NP - 1) / g.NP;
@@ -975,10 +994,10 @@ int launch_fwd(const mdmm_sweep_t* a, const WideGeo& g, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <bool F32, int RT, bool K1>
+template <bool F32, int RT, bool K1, int LR = 16>
 int launch_bwd(const mdmm_sweep_t* a, const WideGeo& g, const WideWs& ws, hipStream_t stream) {
   using L = BwdLds<F32, RT>;
-  auto kern = wide_bwd_kernel<F32, RT, K1>;
+  auto kern = wide_bwd_kernel<F32, RT, K1, LR>;
   int rc = set_lds(kern, L::BYTES);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)ws.n_wg), dim3(NTHR), L::BYTES, stream, *a, g, ws);
@@ -1051,7 +1070,13 @@ int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (!RT) return mdmm_wide_sweep_fwd_long(a, stream);      // more particles than the row tiles hold
   if (((uintptr_t)a->gtf_frag) & 15) return MDMM_E_ALIGN;
   const bool f32 = a->precision == MDMM_PREC_F32;
-  if (a->K == 1) return f32 ? launch_fwd<true, 1, true>(a, g, stream) : launch_fwd<false, 1, true>(a, g, stream);
+  if (a->K == 1) {
+    if (f32) return launch_fwd<true, 1, true>(a, g, stream);
+    const bool lr_off = getenv("MDMM_K1_LR16") != nullptr;                  // A/B switch: every register slot, as before
+    if (g.NP <= 8 && !lr_off) return launch_fwd<false, 1, true, 4>(a, g, stream);
+    if (g.NP <= 16 && !lr_off) return launch_fwd<false, 1, true, 8>(a, g, stream);
+    return launch_fwd<false, 1, true, 16>(a, g, stream);
+  }
   if (a->noise_park && (f32 || !mdmm_wide_bwd4_supported(a) || a->noise_park_bytes < mdmm_wide_noise_park_bytes(a) ||
                         (((uintptr_t)a->noise_park) & 15)))
     return MDMM_E_ARG;                      // (a park only where the one-round backward will read it)
@@ -1069,7 +1094,11 @@ int mdmm_wide_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->wide_ws_bytes < carve(a, g, RT, &ws)) return MDMM_E_ARG;
   const bool f32 = a->precision == MDMM_PREC_F32;
   int rc;
-  if (a->K == 1) rc = f32 ? launch_bwd<true, 1, true>(a, g, ws, stream) : launch_bwd<false, 1, true>(a, g, ws, stream);
+  const bool lr_off = getenv("MDMM_K1_LR16") != nullptr;                    // A/B switch: every register slot, as before
+  if (a->K == 1 && f32) rc = launch_bwd<true, 1, true>(a, g, ws, stream);
+  else if (a->K == 1) rc = (g.NP <= 8 && !lr_off) ? launch_bwd<false, 1, true, 4>(a, g, ws, stream)
+                         : ((g.NP <= 16 && !lr_off) ? launch_bwd<false, 1, true, 8>(a, g, ws, stream)
+                                                    : launch_bwd<false, 1, true, 16>(a, g, ws, stream));
   else rc = f32 ? launch_bwd<true, 1, false>(a, g, ws, stream) : launch_bwd<false, 2, false>(a, g, ws, stream);
   if (rc) return rc;
   return wide_wgrad_launch(ws, f32, spill_chunks(f32, RT, a->K == 1, g.NP), a->dw_partial, stream);
