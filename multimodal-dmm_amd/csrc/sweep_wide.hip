@@ -39,6 +39,18 @@ struct FwdLds {
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
+// the pair table in LDS (a struct cannot be copied out of another address space: read as a 2-vector)
+typedef int i32x2l __attribute__((ext_vector_type(2)));
+struct lds_tab_t {
+  const __attribute__((address_space(3))) i32x2l* p;
+  __device__ __forceinline__ PairRef operator[](int i) const {
+    const i32x2l v = p[i];
+    PairRef r; r.p = v.x; r.b = v.y;
+    return r;
+  }
+};
+typedef const __attribute__((address_space(3))) uint64_t* lds_row_t;
+
 // LR (K = 1 only): the accumulator registers of a lane that can hold live rows (see wide_bwd_kernel); the
 // elementwise phases and the fusion skip the others.
 template <bool F32, int RT, bool K1, int LR = 16>
@@ -56,12 +68,14 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
 
   build_tables<RT, K1>(a, g, reinterpret_cast<PairRef*>(smem + L::OFF_TAB),
                        reinterpret_cast<uint64_t*>(smem + L::OFF_ROW));
-  const PairRef* tab = reinterpret_cast<const PairRef*>(smem + L::OFF_TAB);
-  const uint64_t* rowbase = reinterpret_cast<const uint64_t*>(smem + L::OFF_ROW);
+  // (LDS-typed: through a generic pointer every table read would be a flat load, which counts on both memory
+  //  counters -- a wait for it drains the weight ring as well)
+  lds_tab_t tab; tab.p = (const __attribute__((address_space(3))) i32x2l*)(smem + L::OFF_TAB);
+  lds_row_t rowbase = (lds_row_t)reinterpret_cast<const uint64_t*>(smem + L::OFF_ROW);
 
   // this lane's fragment pointer of every layer, A-operand addresses, biases, global prior
-  const uint4* const frag0 = reinterpret_cast<const uint4*>(a.gtf_frag) + (size_t)wave * O::NCH * 64 + lane;
-  const uint4* frag = frag0;
+  const gw_ptr frag0 = (gw_ptr)a.gtf_frag + (size_t)wave * O::NCH * 64 + lane;       // (global-typed: wide_tiles.h)
+  gw_ptr frag = frag0;
   const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(a.gtf_frag) +
                                                      (size_t)N_LAYER * O::LAYER_U4);
   auto W = [&](int layer) { return frag + (size_t)layer * O::LAYER_U4; };
@@ -75,14 +89,14 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
   ring_fill(ring, W(L_W1G));
   __syncthreads();
 
-  const PairRef* const tab0 = tab;
-  const uint64_t* const rowbase0 = rowbase;
+  const lds_tab_t tab0 = tab;
+  const lds_row_t rowbase0 = rowbase;
   for (int i = 0; i < T; ++i) {
     // the tables never change, so the compiler would hoist every read of them out of the time
     // loop and keep ~100 registers of (pair, noise base) alive across it: re-derive the pointers
     // from an opaque zero every step
     tab = tab0; rowbase = rowbase0; frag = frag0;    // (the same for the per-layer weight pointers)
-    asm volatile("" : "+v"(tab), "+v"(rowbase), "+v"(frag));
+    asm volatile("" : "+v"(tab.p), "+v"(rowbase), "+v"(frag));
     // ... and for the launch arguments: inside the loop they are read through an opaque copy of
     // the kernarg pointer (the sweep descriptor is the first kernel argument), so that pointers,
     // expert descriptors and Philox keys are scalar loads at their use, not ~150 hoisted SGPRs
@@ -190,16 +204,28 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           // (the draw of the last step only enters `samples`)
           // (a register group none of whose rows carries a pair draws nothing: at 8 pairs per workgroup that is
           //  three of the four Philox calls of a step)
-          if (sampled && (!last || a.samples) && 32 * rt + 8 * q < g.NP) eps_group(a, noff, t_term, rowbase + r0, n, e);
-          // the four rows' expert loads as one batch, then the products (a dead group: nothing to load)
+          // the four rows' expert loads as one batch, then the products (a dead group: nothing to load); the
+          // draws are made while the loads are on their way
+          // (launch arguments as one batch of scalar loads, tables through LDS reads: see the backward kernel)
+          FuseArgs fz;
+          fuse_args(a, exs, fz);
+          float* const o_im = a.infer_mean; float* const o_is = a.infer_std;
+          float* const o_pm = a.prior_mean; float* const o_ps = a.prior_std;
+          float* const o_smp = a.samples;
+          const lds_tab_t tabl = tab;
           PairRef prs4[4];
           ExpertVals ev[4];
 #pragma unroll
+          for (int j = 0; j < 4; ++j) prs4[j] = tabl[r0 + j];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
           for (int j = 0; j < 4; ++j) {
-            prs4[j] = tab[r0 + j];
             ev[j].on = 0;
-            if (prs4[j].p >= 0) load_experts(a, exs, prs4[j], (size_t)t * B + prs4[j].b, n, ev[j]);
+            if (prs4[j].p >= 0) load_experts_d(fz.ed, prs4[j], (size_t)t * B + prs4[j].b, n, ev[j]);
           }
+          __builtin_amdgcn_sched_barrier(0);
+          if (sampled && (!last || o_smp) && 32 * rt + 8 * q < g.NP)
+            eps_group(a, noff, t_term, rowbase + r0, n, e);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int reg = 4 * q + j;
@@ -210,13 +236,13 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
               const size_t tb = (size_t)t * B + pr.b;
               fast::Poe pq; pq.init(); pq.add(pm, ps, 1.0f);
               poe_experts(a, exs, pr, tb, n, ev[j], pq);
-              if (a.use_inv_prior) pq.add(mu0, -sg0, 1.0f);
+              if (fz.inv_prior) pq.add(mu0, -sg0, 1.0f);
               float im, is; pq.finish(im, is);
               const size_t o = (((size_t)pr.p * T + t) * B + pr.b) * WD + n;
-              a.infer_mean[o] = im; a.infer_std[o] = is;
-              a.prior_mean[o] = pm; a.prior_std[o] = ps;
+              o_im[o] = im; o_is[o] = is;
+              o_pm[o] = pm; o_ps[o] = ps;
               zz = sampled ? fmaf(e[j], is, im) : im;
-              if (a.samples) a.samples[o] = zz;
+              if (o_smp) o_smp[o] = zz;
             }
             z[rt][reg] = zz;
           }
@@ -359,14 +385,14 @@ struct BwdLds {
 
 // `chs` = chunks per (array, wave) actually kept: all of them, or -- K = 1 with at most 16 (pass, sequence)
 // pairs per workgroup, bf16 -- only chunk 0 (rows 0..15; the rows of chunk 1 are all dead)
-template <bool F32, int RT>
-__device__ __forceinline__ void spill_tiles(uint4* dst, const f32x16 (&v)[RT], int chs) {
+template <bool F32, int RT, class SP>
+__device__ __forceinline__ void spill_tiles(SP dst, const f32x16 (&v)[RT], int chs) {
   constexpr int CT = Op<F32>::CH_TILE;
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int s = 0; s < CT; ++s)
-      if (rt * CT + s < chs) dst[(rt * CT + s) * 64] = acc_chunk<F32>(v[rt], s);
+      if (rt * CT + s < chs) st4(dst + (rt * CT + s) * 64, acc_chunk<F32>(v[rt], s));
 }
 
 // chunks per (array, wave) of one spilled item for this launch (see spill_tiles)
@@ -407,11 +433,13 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
 
   build_tables<RT, K1>(a, g, reinterpret_cast<PairRef*>(smem + L::OFF_TAB),
                        reinterpret_cast<uint64_t*>(smem + L::OFF_ROW));
-  const PairRef* tab = reinterpret_cast<const PairRef*>(smem + L::OFF_TAB);
-  const uint64_t* rowbase = reinterpret_cast<const uint64_t*>(smem + L::OFF_ROW);
+  // (LDS-typed: through a generic pointer every table read would be a flat load, which counts on both memory
+  //  counters -- a wait for it drains the weight ring as well)
+  lds_tab_t tab; tab.p = (const __attribute__((address_space(3))) i32x2l*)(smem + L::OFF_TAB);
+  lds_row_t rowbase = (lds_row_t)reinterpret_cast<const uint64_t*>(smem + L::OFF_ROW);
 
-  const uint4* const frag0 = reinterpret_cast<const uint4*>(a.gtf_frag) + (size_t)wave * O::NCH * 64 + lane;
-  const uint4* frag = frag0;
+  const gw_ptr frag0 = (gw_ptr)a.gtf_frag + (size_t)wave * O::NCH * 64 + lane;       // (global-typed: wide_tiles.h)
+  gw_ptr frag = frag0;
   const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(a.gtf_frag) +
                                                      (size_t)N_LAYER * O::LAYER_U4);
   auto W = [&](int layer) { return frag + (size_t)layer * O::LAYER_U4; };
@@ -462,19 +490,19 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
   }
 
   const int chs = (!F32 && K1 && g.NP <= 16) ? 1 : CH;
-  uint4* my_spill = ws.spill + ((size_t)blockIdx.x * ws.n_step * N_SPILL * NWAVE + wave) * chs * 64 + lane;
-  uint4* spill_it = my_spill;
+  const gs_ptr my_spill = (gs_ptr)ws.spill + ((size_t)blockIdx.x * ws.n_step * N_SPILL * NWAVE + wave) * chs * 64 + lane;
+  gs_ptr spill_it = my_spill;
   auto spill_at = [&](int step, int arr) {
     return spill_it + ((size_t)step * N_SPILL + arr) * NWAVE * chs * 64;
   };
 
-  const PairRef* const tab0 = tab;
-  const uint64_t* const rowbase0 = rowbase;
+  const lds_tab_t tab0 = tab;
+  const lds_row_t rowbase0 = rowbase;
   for (int i = T - 1; i >= 0; --i) {
     // see the forward kernel: keeps invariant reads and address arithmetic inside the loop
     tab = tab0; rowbase = rowbase0; frag = frag0;
     spill_it = my_spill;
-    asm volatile("" : "+v"(tab), "+v"(rowbase), "+v"(frag), "+v"(spill_it));
+    asm volatile("" : "+v"(tab.p), "+v"(rowbase), "+v"(frag), "+v"(spill_it));
     KArgs* kap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kap));
     KArgs& a = *kap;
@@ -484,7 +512,9 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     STAMP(0);
     // ---- (A) adjoint of sampling + fusion at step i
     FuseAdj fa[NS];
-    if constexpr (K1) {
+    constexpr bool BATCH = K1 && LR == 4 && RT == 1;   // (more slots in flight than four do not fit the registers)
+    [[maybe_unused]] float zm_pre[BATCH ? NS : 1], zs_pre[BATCH ? NS : 1];  // the particles' (mean, std) of R1
+    if constexpr (K1 && !BATCH) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -493,6 +523,40 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
           fa[s] = fuse_bwd(a, exs, tab[acc_row(rt, reg) + 4 * h], t, n, mu0, sg0, adj_a[s], adj_b[s], se[s],
                            sampled, inv_k, i == 0, true, g_mu0, g_sg0);
         }
+    } else if constexpr (K1) {
+      // the phase's launch arguments as one batch of scalar loads, the pair table through LDS reads (the
+      // laundered table pointer is generic: its loads count on both memory counters and drain the weight ring),
+      // then every pair's loads in flight before the first algebra, and with them the (mean, std) of the
+      // previous step's rows that R1 turns into particles
+      const int t_prev = a.reverse ? t + 1 : t - 1;
+      FuseArgs fz;
+      fuse_args(a, exs, fz);
+      const float* const p_im = a.infer_mean;
+      const float* const p_is = a.infer_std;
+      const lds_tab_t tabl = tab;
+      PairRef prl[NS];
+#pragma unroll
+      for (int reg = 0; reg < LR; ++reg) prl[reg] = tabl[acc_row(0, reg) + 4 * h];
+      __builtin_amdgcn_sched_barrier(0);
+      FuseIn fin[NS];
+#pragma unroll
+      for (int reg = 0; reg < LR; ++reg) fuse_bwd_load(fz, prl[reg], t, n, fin[reg]);
+      if (i > 0) {
+#pragma unroll
+        for (int reg = 0; reg < LR; ++reg) {
+          float zm = 0.f, zs = 0.f;
+          if (prl[reg].p >= 0) {
+            const size_t o = (((size_t)prl[reg].p * T + t_prev) * B + prl[reg].b) * WD + n;
+            zm = p_im[o]; zs = p_is[o];
+          }
+          zm_pre[reg] = zm; zs_pre[reg] = zs;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);       // (every request in front of the first algebra)
+#pragma unroll
+      for (int reg = 0; reg < LR; ++reg)
+        fa[reg] = fuse_bwd_math(fz, exs, prl[reg], t, n, mu0, sg0, adj_a[reg], adj_b[reg], se[reg],
+                                sampled, inv_k, i == 0, true, g_mu0, g_sg0, fin[reg]);
     } else {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -534,9 +598,11 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
             const int reg = 4 * q + j;
             const bool live = rowbase[r0 + j] != ~0ull;
             float zm = zm_t, zs = zs_t;
-            if constexpr (K1) {
+            if constexpr (BATCH) {
+              if (reg < LR) { zm = zm_pre[rt * LR + reg]; zs = zs_pre[rt * LR + reg]; }     // (requested in (A))
+            } else if constexpr (K1) {
               const PairRef pr = tab[r0 + j];
-              if (pr.p >= 0) {
+              if (pr.p >= 0 && reg < LR) {
                 const size_t o = (((size_t)pr.p * T + t_prev) * B + pr.b) * WD + n;
                 zm = a.infer_mean[o]; zs = a.infer_std[o];
               }
@@ -681,9 +747,9 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
         store_image_part<F32, CG>(img0, o_gl, rt, c0, wave, lane);
         const int ch = rt * O::CH_TILE + c0 / CG;
         if (ch < chs) {
-          spill_at(i - 1, S_G3)[ch * 64] = pack_chunk<F32, CG>(o_g3);
-          spill_at(i - 1, S_GG)[ch * 64] = pack_chunk<F32, CG>(o_gg);
-          spill_at(i - 1, S_GLIN)[ch * 64] = pack_chunk<F32, CG>(o_gl);
+          st4(spill_at(i - 1, S_G3) + ch * 64, pack_chunk<F32, CG>(o_g3));
+          st4(spill_at(i - 1, S_GG) + ch * 64, pack_chunk<F32, CG>(o_gg));
+          st4(spill_at(i - 1, S_GLIN) + ch * 64, pack_chunk<F32, CG>(o_gl));
         }
         __builtin_amdgcn_sched_barrier(0);     // one group at a time
       }

@@ -62,9 +62,9 @@ __device__ __forceinline__ void build_tables(const mdmm_sweep_t& a, const WideGe
 // N(0,1) draws of the four rows (registers 4q .. 4q+3) of one accumulator register group:
 // e[j] = eps(row j, feature n).  Philox yields four consecutive features per counter, so lane u
 // of a quad draws row u's four features and the quad transposes (wide_tiles.h).
-template <class A>
+template <class A, class RB>
 __device__ __forceinline__ void eps_group(const A& a, uint64_t noff, uint64_t t_term,
-                                          const uint64_t* rowbase_r0, int n, float (&e)[4]) {
+                                          RB rowbase_r0, int n, float (&e)[4]) {
   if (a.eps) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -163,49 +163,110 @@ __device__ __forceinline__ void poe_experts(const A& a, const E* exs, PairRef pr
   }
 }
 
+// The launch arguments the fusion phases read, fetched as ONE batch of scalar loads per step (fuse_args): read
+// where they are used, every pointer and every expert descriptor field is a scalar load + wait + branch of its
+// own in front of the vector load it feeds -- some twenty dependent scalar round trips per pair (measured with
+// the in-kernel stamps: 18 k of a K = 1 backward step's 62 k cycles, whatever the number of loads in flight).
+struct ExpDesc { const float *mean, *std, *mask; float *g_mean, *g_std; int64_t stride; unsigned bits; };
+struct FuseArgs {
+  const float *gsmp, *gim, *gis, *prm, *prs, *gpm, *gps;
+  int n_exp, T, B;
+  bool inv_prior;
+  ExpDesc ed[EXB];
+};
 template <class A, class E>
-__device__ __forceinline__ FuseAdj fuse_bwd(const A& a, const E* exs, PairRef pr, int t, int n, float mu0,
-                                            float sg0, float adj_a, float adj_b, float se,
-                                            bool sampled, float inv_k, bool first, bool owner,
-                                            float& g_mu0, float& g_sg0) {
+__device__ __forceinline__ void fuse_args(const A& a, const E* exs, FuseArgs& z) {
+  z.gsmp = a.g_samples; z.gim = a.g_infer_mean; z.gis = a.g_infer_std;
+  z.prm = a.prior_mean; z.prs = a.prior_std; z.gpm = a.g_prior_mean; z.gps = a.g_prior_std;
+  z.n_exp = a.E; z.T = a.T; z.B = a.B; z.inv_prior = a.use_inv_prior;
+#pragma unroll
+  for (int e = 0; e < EXB; ++e) {
+    const bool on = e < z.n_exp;
+    z.ed[e].mean = on ? exs[e].mean : nullptr; z.ed[e].std = on ? exs[e].std : nullptr;
+    z.ed[e].mask = on ? exs[e].mask : nullptr;
+    z.ed[e].g_mean = on ? exs[e].g_mean : nullptr; z.ed[e].g_std = on ? exs[e].g_std : nullptr;
+    z.ed[e].stride = on ? exs[e].pass_stride : 0; z.ed[e].bits = on ? exs[e].pass_bits : 0u;
+  }
+}
+// load_experts from the fetched descriptors
+__device__ __forceinline__ void load_experts_d(const ExpDesc (&ed)[EXB], PairRef pr, size_t tb, int n, ExpertVals& v) {
+  v.on = 0;
+#pragma unroll
+  for (int e = 0; e < EXB; ++e) {
+    v.mu[e] = 0.f; v.sd[e] = 1.f; v.c[e] = 0.f;
+    if ((ed[e].bits >> pr.p) & 1u) {
+      v.on |= 1u << e;
+      v.c[e] = ed[e].mask ? ed[e].mask[tb] : 1.0f;
+      const size_t off = (size_t)pr.p * ed[e].stride + tb * WD + n;
+      v.mu[e] = ed[e].mean[off]; v.sd[e] = ed[e].std[off];
+    }
+  }
+}
+
+// what fuse_bwd reads from memory for one pair, requested together (fuse_bwd_load) so that the loads of SEVERAL
+// pairs can be in flight before the first algebra (the K = 1 kernels hold a pair per accumulator register)
+struct FuseIn {
+  float gsmp, l_gim, l_gis, prm, prs, l_gpm, l_gps;
+  ExpertVals ev;
+};
+__device__ __forceinline__ void fuse_bwd_load(const FuseArgs& z, PairRef pr, int t, int n, FuseIn& f) {
+  f.gsmp = 0.f; f.l_gim = 0.f; f.l_gis = 0.f; f.prm = 0.f; f.prs = 1.f; f.l_gpm = 0.f; f.l_gps = 0.f;
+  f.ev.on = 0;
+  if (pr.p < 0) return;
+  const size_t tb = (size_t)t * z.B + pr.b;
+  const size_t o = (((size_t)pr.p * z.T + t) * z.B + pr.b) * WD + n;
+  if (z.gsmp) f.gsmp = z.gsmp[o];
+  if (z.gim) f.l_gim = z.gim[o];
+  if (z.gis) f.l_gis = z.gis[o];
+  f.prm = z.prm[o]; f.prs = z.prs[o];
+  if (z.gpm) f.l_gpm = z.gpm[o];
+  if (z.gps) f.l_gps = z.gps[o];
+  load_experts_d(z.ed, pr, tb, n, f.ev);
+}
+
+template <class E>
+__device__ __forceinline__ FuseAdj fuse_bwd_math(const FuseArgs& z, const E* exs, PairRef pr, int t, int n, float mu0,
+                                                 float sg0, float adj_a, float adj_b, float se,
+                                                 bool sampled, float inv_k, bool first, bool owner,
+                                                 float& g_mu0, float& g_sg0, const FuseIn& f) {
   FuseAdj r; r.gpm = 0.f; r.gps = 0.f; r.prm = 0.f; r.prs = 1.f;
   if (pr.p < 0) return r;
-  const size_t tb = (size_t)t * a.B + pr.b;
-  const size_t o = (((size_t)pr.p * a.T + t) * a.B + pr.b) * WD + n;
-  // every load of the pair first ...
-  const float gsmp = a.g_samples ? a.g_samples[o] : 0.f;
-  const float l_gim = a.g_infer_mean ? a.g_infer_mean[o] : 0.f;
-  const float l_gis = a.g_infer_std ? a.g_infer_std[o] : 0.f;
-  const float prm = a.prior_mean[o], prs = a.prior_std[o];
-  const float l_gpm = a.g_prior_mean ? a.g_prior_mean[o] : 0.f;
-  const float l_gps = a.g_prior_std ? a.g_prior_std[o] : 0.f;
-  ExpertVals ev;
-  load_experts(a, exs, pr, tb, n, ev);
-  // ... then the algebra
-  float g_im = l_gim + adj_a + gsmp;
-  float g_is = l_gis;
+  const size_t tb = (size_t)t * z.B + pr.b;
+  const size_t o = (((size_t)pr.p * z.T + t) * z.B + pr.b) * WD + n;
+  const float gsmp = f.gsmp, prm = f.prm, prs = f.prs;
+  const ExpertVals& ev = f.ev;
+  float g_im = f.l_gim + adj_a + gsmp;
+  float g_is = f.l_gis;
   if (sampled) g_is += adj_b + gsmp * se * inv_k;
   fast::Poe q; q.init(); q.add(prm, prs, 1.0f);
-  poe_experts(a, exs, pr, tb, n, ev, q);
-  if (a.use_inv_prior) q.add(mu0, -sg0, 1.0f);
+#pragma unroll
+  for (int e = 0; e < EXB; ++e)
+    if ((ev.on >> e) & 1u) q.add(ev.mu[e], ev.sd[e], ev.c[e]);
+  for (int e = EXB; e < z.n_exp; ++e) {
+    const auto& ex = exs[e];
+    if (!((ex.pass_bits >> pr.p) & 1u)) continue;
+    const float c = ex.mask ? ex.mask[tb] : 1.0f;
+    const size_t off = (size_t)pr.p * ex.pass_stride + tb * WD + n;
+    q.add(ex.mean[off], ex.std[off], c);
+  }
+  if (z.inv_prior) q.add(mu0, -sg0, 1.0f);
   const float rp = fast::rcp(q.prec), is = fast::sqrt(rp);
   float g_num, g_prec, gm, gs;
   poe_out_bwd_f(q.num, rp, is, g_im, g_is, g_num, g_prec);
   poe_expert_bwd_f(prm, prs, 1.0f, g_num, g_prec, gm, gs);
-  r.gpm = gm + l_gpm;
-  r.gps = gs + l_gps;
+  r.gpm = gm + f.l_gpm;
+  r.gps = gs + f.l_gps;
   r.prm = prm; r.prs = prs;
 #pragma unroll
   for (int e = 0; e < EXB; ++e)
     if ((ev.on >> e) & 1u) {
-      const auto& ex = exs[e];
       poe_expert_bwd_f(ev.mu[e], ev.sd[e], ev.c[e], g_num, g_prec, gm, gs);
       if (owner) {
-        if (ex.g_mean) ex.g_mean[o] = gm;       // one slab per pass, (P,T,B,D)
-        if (ex.g_std) ex.g_std[o] = gs;
+        if (z.ed[e].g_mean) z.ed[e].g_mean[o] = gm;       // one slab per pass, (P,T,B,D)
+        if (z.ed[e].g_std) z.ed[e].g_std[o] = gs;
       }
     }
-  for (int e = EXB; e < a.E; ++e) {
+  for (int e = EXB; e < z.n_exp; ++e) {
     const auto& ex = exs[e];
     if (!((ex.pass_bits >> pr.p) & 1u)) continue;
     const float c = ex.mask ? ex.mask[tb] : 1.0f;
@@ -217,13 +278,25 @@ __device__ __forceinline__ FuseAdj fuse_bwd(const A& a, const E* exs, PairRef pr
     }
   }
   if (owner) {
-    if (a.use_inv_prior) {
+    if (z.inv_prior) {
       poe_expert_bwd_f(mu0, -sg0, 1.0f, g_num, g_prec, gm, gs);
       g_mu0 += gm; g_sg0 -= gs;
     }
     if (first) { g_mu0 += r.gpm; g_sg0 += r.gps; }     // first step: prior = p(z)
   }
   return r;
+}
+
+template <class A, class E>
+__device__ __forceinline__ FuseAdj fuse_bwd(const A& a, const E* exs, PairRef pr, int t, int n, float mu0,
+                                            float sg0, float adj_a, float adj_b, float se,
+                                            bool sampled, float inv_k, bool first, bool owner,
+                                            float& g_mu0, float& g_sg0) {
+  FuseArgs z;
+  fuse_args(a, exs, z);
+  FuseIn f;
+  fuse_bwd_load(z, pr, t, n, f);
+  return fuse_bwd_math(z, exs, pr, t, n, mu0, sg0, adj_a, adj_b, se, sampled, inv_k, first, owner, g_mu0, g_sg0, f);
 }
 
 // weight-gradient contraction over the spilled operand chunks + fold into one dw_partial row

@@ -92,11 +92,25 @@ __device__ __forceinline__ void fill_acc(f32x16 (&acc)[RT], float b) {
 #endif
 template <int RT> struct Pf { static constexpr int N = RT == 1 ? WIDE_PF_RT1 : (RT == 2 ? WIDE_PF_RT2 : WIDE_PF_RT4); };
 
+// Weight fragments and spill chunks through GLOBAL-address-space pointers (gw_ptr / gs_ptr).  The kernels launder
+// their per-lane pointers once per time step (asm volatile "+v": keeps address arithmetic out of the loop's live
+// set); a laundered generic pointer makes every access a FLAT instruction, which counts on the vector-memory AND
+// the LDS counter and may complete out of order -- the compiler then waits with vmcnt(0) at every use: each trip
+// of the contraction loop drained the whole prefetch ring (an L2 round trip per PF chunks; it is why deeper rings
+// never changed the time).  (HIP's uint4 class has no assignment across address spaces: plain vectors.)
+typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4g* gw_ptr;
+typedef __attribute__((address_space(1))) u32x4g* gs_ptr;
+__device__ __forceinline__ uint4 ldw(const uint4* p) { return *p; }
+__device__ __forceinline__ uint4 ldw(gw_ptr p) { const u32x4g v = *p; return __builtin_bit_cast(uint4, v); }
+__device__ __forceinline__ void st4(uint4* p, const uint4& v) { *p = v; }
+__device__ __forceinline__ void st4(gs_ptr p, const uint4& v) { *p = __builtin_bit_cast(u32x4g, v); }
+
 // first PF chunks of a layer slice into the ring (w = this lane's fragment pointer of the layer)
-template <int PF>
-__device__ __forceinline__ void ring_fill(uint4 (&ring)[PF], const uint4* __restrict__ w) {
+template <int PF, class WP>
+__device__ __forceinline__ void ring_fill(uint4 (&ring)[PF], WP w) {
 #pragma unroll
-  for (int c = 0; c < PF; ++c) ring[c] = w[c * 64];
+  for (int c = 0; c < PF; ++c) ring[c] = ldw(w + c * 64);
 }
 
 // acc[rt] += X[32rt .. 32rt+32)[0..256) . W_slice^T.  `xrow` = this lane's A-operand address in
@@ -104,21 +118,19 @@ __device__ __forceinline__ void ring_fill(uint4 (&ring)[PF], const uint4* __rest
 // pointer into the layer (chunk c at w[64c]).  The ring holds chunks 0..PF-1 of `w` on entry and
 // chunks 0..PF-1 of `wnext` (the layer the wave contracts with next) on exit, so the weight
 // stream never drains at a phase boundary.
-template <bool F32, int RT, int PF>
-__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[RT], const char* xrow,
-                                          const uint4* __restrict__ w,
-                                          const uint4* __restrict__ wnext, uint4 (&ring)[PF]) {
+template <bool F32, int RT, int PF, class WP>
+__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[RT], const char* xrow, WP w, WP wnext, uint4 (&ring)[PF]) {
   constexpr int NCH = Op<F32>::NCH, RS = Op<F32>::RS;
   static_assert(NCH % PF == 0, "ring depth");
   // a real loop over groups of PF chunks: fully unrolled, the compiler hoists every weight load
   // of the phase to its top and spills
 #pragma unroll 1
   for (int c0 = 0; c0 < NCH; c0 += PF) {
-    const uint4* nxt = (c0 + PF < NCH) ? w + (c0 + PF) * 64 : wnext;
+    WP nxt = (c0 + PF < NCH) ? w + (c0 + PF) * 64 : wnext;
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const uint4 b = ring[u];
-      ring[u] = nxt[u * 64];
+      ring[u] = ldw(nxt + u * 64);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const uint4 av = *reinterpret_cast<const uint4*>(xrow + rt * 32 * RS + 32 * (c0 + u));
