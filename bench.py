@@ -476,6 +476,9 @@ def roofline_bytes(timer, spans):
 GRAPH_QUEUES_ENV, GRAPH_QUEUES = 'DEBUG_HIP_FORCE_GRAPH_QUEUES', '5'
 
 
+ANNEAL = False        # tools: a KLD multiplier that changes with every call of the replayed step
+
+
 def run(cfg, args, world, rank, device, graph):
     """Time args.steps steps of cfg on this rank; returns the result dict (rank 0) or None."""
     import torch
@@ -505,8 +508,12 @@ def run(cfg, args, world, rank, device, graph):
             c0, warm = model.noise.counter, 3
             graphed = GraphedElboStep(model, optimizer, bucket, inputs, mask, lengths, 1.0, cfg.rec, warmup=warm, **kw)
 
+            calls = [0]
+
             def step():     # as a trainer drives it (trainer.py:226-244): this batch's KLD multiplier and number of
-                graphed.schedule(kld_mult=1.0, n_points=n_points_global)     # time-points go to the device, then the replay
+                calls[0] += 1                                                # time-points go to the device, then the replay
+                kld = 1.0 - 1e-3 * (calls[0] % 7) if ANNEAL else 1.0         # (ANNEAL: tools/bench_one_extra.py)
+                graphed.schedule(kld_mult=kld, n_points=n_points_global)
                 return graphed()
             step.g_step, step.loss = graphed.g_step, graphed.loss
             c_capture = model.noise.counter - (model.noise.counter - c0) // (warm + 1)   # host stream id the capture starts at

@@ -32,8 +32,8 @@ __global__ __launch_bounds__(NTHR) void gru_wide_fwd_kernel(const mdmm_gru_t a, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, n = 32 * wave + (lane & 31);
   const int T = a.T, B = a.B, H = WD, b0 = blockIdx.x * NP;
-  const uint4* const frag0 = reinterpret_cast<const uint4*>(a.w_frag) + (size_t)wave * O::NCH * 64 + lane;
-  const uint4* frag = frag0;
+  const gw_ptr frag0 = (gw_ptr)a.w_frag + (size_t)wave * O::NCH * 64 + lane;       // (global-typed: wide_tiles.h)
+  gw_ptr frag = frag0;
   auto W = [&](int layer) { return frag + (size_t)layer * O::LAYER_U4; };
   const int arow = (lane & 31) * O::RS + 16 * h;
   const float br = a.b_hh[n], bu = a.b_hh[H + n], bn = a.b_hh[2 * H + n];
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(NTHR) void gru_wide_bwd_kernel(const mdmm_gru_t a, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, n = 32 * wave + (lane & 31);
   const int T = a.T, B = a.B, H = WD, b0 = blockIdx.x * NP;
-  const uint4* const frag0 = reinterpret_cast<const uint4*>(a.w_frag) + (size_t)wave * O::NCH * 64 + lane;
-  const uint4* frag = frag0;
+  const gw_ptr frag0 = (gw_ptr)a.w_frag + (size_t)wave * O::NCH * 64 + lane;       // (global-typed: wide_tiles.h)
+  gw_ptr frag = frag0;
   auto W = [&](int layer) { return frag + (size_t)layer * O::LAYER_U4; };
   const int arow = (lane & 31) * O::RS + 16 * h;
   const float br = a.b_hh[n], bu = a.b_hh[H + n], bn = a.b_hh[2 * H + n];
@@ -198,9 +198,9 @@ __global__ __launch_bounds__(NTHR) void comb_wide_fwd_kernel(const mdmm_dks_t a,
   const int h = lane >> 5, n = 32 * wave + (lane & 31);
   const int T = a.T, B = a.B, b0 = blockIdx.x * NP;
   const uint64_t noff = dks_noff(a);
-  const uint4* const gf0 = reinterpret_cast<const uint4*>(a.gtf_frag) + (size_t)wave * O::NCH * 64 + lane;
-  const uint4* const cf0 = reinterpret_cast<const uint4*>(a.comb_frag) + (size_t)wave * O::NCH * 64 + lane;
-  const uint4 *gf = gf0, *cf = cf0;
+  const gw_ptr gf0 = (gw_ptr)a.gtf_frag + (size_t)wave * O::NCH * 64 + lane;       // (global-typed: wide_tiles.h)
+  const gw_ptr cf0 = (gw_ptr)a.comb_frag + (size_t)wave * O::NCH * 64 + lane;
+  gw_ptr gf = gf0, cf = cf0;
   const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(a.gtf_frag) +
                                                      (size_t)N_LAYER * O::LAYER_U4);
   auto G = [&](int layer) { return gf + (size_t)layer * O::LAYER_U4; };
@@ -350,9 +350,9 @@ __global__ __launch_bounds__(NTHR) void comb_wide_bwd_kernel(const mdmm_dks_t a,
   const int h = lane >> 5, n = 32 * wave + (lane & 31);
   const int T = a.T, B = a.B, b0 = blockIdx.x * NP;
   const uint64_t noff = dks_noff(a);
-  const uint4* const gf0 = reinterpret_cast<const uint4*>(a.gtf_frag) + (size_t)wave * O::NCH * 64 + lane;
-  const uint4* const cf0 = reinterpret_cast<const uint4*>(a.comb_frag) + (size_t)wave * O::NCH * 64 + lane;
-  const uint4 *gf = gf0, *cf = cf0;
+  const gw_ptr gf0 = (gw_ptr)a.gtf_frag + (size_t)wave * O::NCH * 64 + lane;       // (global-typed: wide_tiles.h)
+  const gw_ptr cf0 = (gw_ptr)a.comb_frag + (size_t)wave * O::NCH * 64 + lane;
+  gw_ptr gf = gf0, cf = cf0;
   const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(a.gtf_frag) +
                                                      (size_t)N_LAYER * O::LAYER_U4);
   auto G = [&](int layer) { return gf + (size_t)layer * O::LAYER_U4; };

@@ -39,17 +39,6 @@ struct FwdLds {
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-// the pair table in LDS (a struct cannot be copied out of another address space: read as a 2-vector)
-typedef int i32x2l __attribute__((ext_vector_type(2)));
-struct lds_tab_t {
-  const __attribute__((address_space(3))) i32x2l* p;
-  __device__ __forceinline__ PairRef operator[](int i) const {
-    const i32x2l v = p[i];
-    PairRef r; r.p = v.x; r.b = v.y;
-    return r;
-  }
-};
-typedef const __attribute__((address_space(3))) uint64_t* lds_row_t;
 
 // LR (K = 1 only): the accumulator registers of a lane that can hold live rows (see wide_bwd_kernel); the
 // elementwise phases and the fusion skip the others.

@@ -224,8 +224,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
 
   build_tables<RT, false>(a, g, reinterpret_cast<PairRef*>(smem + 3 * img),
                           reinterpret_cast<uint64_t*>(smem + 3 * img + 64));
-  const PairRef* tab = reinterpret_cast<const PairRef*>(smem + 3 * img);
-  const uint64_t* rowbase = reinterpret_cast<const uint64_t*>(smem + 3 * img + 64);
+  lds_tab_t tab; tab.p = (const __attribute__((address_space(3))) i32x2l*)(smem + 3 * img);      // (LDS-typed: wide_sweep.h)
+  lds_row_t rowbase = (lds_row_t)reinterpret_cast<const uint64_t*>(smem + 3 * img + 64);
 
   // wave-uniform bases (scalar registers) + one per-lane index: fragments, biases, spill, park
   const gw_t frag0 = (gw_t)a.gtf_frag + (size_t)wave * NCH * 64;
@@ -301,12 +301,12 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     }
   };
   auto park_at = [&](int slot) { return park_w + slot * 64 + lane; };
-  const PairRef* const tab0 = tab;
-  const uint64_t* const rowbase0 = rowbase;
+  const lds_tab_t tab0 = tab;
+  const lds_row_t rowbase0 = rowbase;
   for (int i = T - 1; i >= 0; --i) {
     // keep invariant reads and address arithmetic inside the loop (see wide_fwd_kernel)
     tab = tab0; rowbase = rowbase0;
-    asm volatile("" : "+v"(tab), "+v"(rowbase));
+    asm volatile("" : "+v"(tab.p), "+v"(rowbase));
     frag = frag0; bias = bias0; spill_w = spill0; park_w = park0; fwd_noise = fwd_noise0;
     asm volatile("" : "+s"(frag), "+s"(bias), "+s"(spill_w), "+s"(park_w), "+s"(fwd_noise));
     KArgs* kap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();

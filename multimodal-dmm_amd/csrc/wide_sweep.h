@@ -33,6 +33,22 @@ struct WideGeo {
 struct PairRef { int p, b; };      // p < 0: slot unused
 typedef const __attribute__((address_space(4))) mdmm_sweep_t KArgs;   // the descriptor in kernarg memory
 
+// The tables of build_tables as the sweeps read them: LDS-typed.  Through a generic pointer (the kernels launder
+// their table pointers once per step) every read is a FLAT load, which counts on both memory counters and may
+// complete out of order: the wait behind it is vmcnt(0) lgkmcnt(0) -- it drains the weight ring and every store
+// on its way to HBM.
+// the pair table in LDS (a struct cannot be copied out of another address space: read as a 2-vector)
+typedef int i32x2l __attribute__((ext_vector_type(2)));
+struct lds_tab_t {
+  const __attribute__((address_space(3))) i32x2l* p;
+  __device__ __forceinline__ PairRef operator[](int i) const {
+    const i32x2l v = p[i];
+    PairRef r; r.p = v.x; r.b = v.y;
+    return r;
+  }
+};
+typedef const __attribute__((address_space(3))) uint64_t* lds_row_t;
+
 __device__ __forceinline__ uint64_t noise_off(const mdmm_sweep_t& a) {
   return a.offset + (a.offset_dev ? *a.offset_dev : 0);
 }

@@ -157,9 +157,12 @@ class GraphedElboStep:
         n_points = sum(lengths) if n_points_global is None else n_points_global
         noise = model._noise()
         dev = bucket.flat.device
-        self.kld_mult = torch.tensor(float(kld_mult), dtype=torch.float32, device=dev)
-        self.inv_points = torch.tensor(1.0 / float(n_points), dtype=torch.float32, device=dev)
+        self._sched = torch.tensor([float(kld_mult), 1.0 / float(n_points)], dtype=torch.float32, device=dev)
+        self.kld_mult, self.inv_points = self._sched[0], self._sched[1]        # 0-dim views
         self.clip_grad = float(clip_grad) if clip_grad is not None and clip_grad > 0 else None
+        self._host_buf = torch.tensor([float(kld_mult), 1.0 / float(n_points)], dtype=torch.float32).pin_memory()
+        self._host = {'kld_mult': self._host_buf[0], 'inv_points': self._host_buf[1]}
+        self._sched_ws = torch.empty(8, dtype=torch.float32, device=dev)
 
         def fwd_bwd():
             loss = model.step(inputs, mask, float(kld_mult) if os.environ.get('MDMM_FROZEN_SCHEDULE') == '1' else self.kld_mult,
@@ -192,6 +195,7 @@ class GraphedElboStep:
         # not invalidate the capture
         bucket.release()        # the captured backward writes autograd's own gradient buffers ...
         with torch.cuda.graph(self.g_step, capture_error_mode='thread_local'):
+            self._fetch_schedule()
             self.loss = fwd_bwd()
             bucket.check_views()                         # ... gathered into the flat buffer by one cat
             if hasattr(noise, 'advance'):
@@ -200,13 +204,32 @@ class GraphedElboStep:
                               capture_error_mode='thread_local'):
             clip_and_step()
 
+    def _fetch_schedule(self):
+        """First node(s) of the step graph: the two schedule scalars from pinned host memory into their device
+        tensor.  A kernel that reads the host buffer through its device address (the column-sum kernel over one
+        row = a copy), not a memcpy node: with two host-to-device copy nodes at its head the replayed cfg3 step
+        took 30.7 instead of 29.5 ms.  (A/B: MDMM_SCHEDULE_FETCH=memcpy | none)"""
+        how = os.environ.get('MDMM_SCHEDULE_FETCH', 'kernel')
+        if how == 'memcpy':
+            self._sched.copy_(self._host_buf, non_blocking=True)
+        elif how == 'kernel':
+            from . import ops
+            ops._call('mdmm_colsum', self._host_buf.data_ptr(), 0, 1, 2, 2, ops._ptr(self._sched_ws), ops._ptr(self._sched))
+
     def schedule(self, kld_mult=None, n_points=None):
-        """Set the KLD multiplier / the normalisation of the next replays (in-place device writes on the current
-        stream, ordered in front of the replay)."""
-        if kld_mult is not None:
-            self.kld_mult.fill_(float(kld_mult))
-        if n_points is not None:
-            self.inv_points.fill_(1.0 / float(n_points))
+        """Set the KLD multiplier / the normalisation of the next replays.  The step graph's first nodes copy both
+        scalars from pinned host memory, so nothing is launched between replays (measured on this ROCm: any stream
+        operation between two replays of the cfg4 step -- a fill kernel or a host-to-device copy alike -- ends in a
+        memory fault under the forced executor queues, DESIGN 5.2).  A value that did not change costs nothing;
+        one that did waits for the replays in flight (they read the host scalars when they start) and is written
+        by the CPU."""
+        new = {'kld_mult': kld_mult, 'inv_points': None if n_points is None else 1.0 / float(n_points)}
+        changed = {k: float(v) for k, v in new.items() if v is not None and float(v) != float(self._host[k])}
+        if not changed:
+            return
+        torch.cuda.current_stream().synchronize()
+        for k, v in changed.items():
+            self._host[k].fill_(v)
 
     def __call__(self):
         self.g_step.replay()

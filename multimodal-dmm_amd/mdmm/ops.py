@@ -54,11 +54,18 @@ class KernelTimer:
 
 
 TIMER = None    # assign a KernelTimer to switch per-launch timing on
+_SYNC_CALLS = os.environ.get('MDMM_SYNC_CALLS') == '1'
 
 
 def _call(name, *args, tag=None, nbytes=0):
     """nbytes: the call's ALGORITHMIC HBM bytes (tensors it has to read / write once), for the timer."""
     fn = getattr(native.lib(), name)
+    if _SYNC_CALLS:             # debugging: a faulting kernel aborts the process -- the last name printed is its call
+        import sys
+        print('mdmm call', name, tag or '', file=sys.stderr, flush=True)
+        native.check(fn(*args, _stream()), name)
+        torch.cuda.synchronize()
+        return
     if TIMER is None:
         native.check(fn(*args, _stream()), name)
         return
