@@ -279,6 +279,12 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       }
       STAMP(12);
       float zsum[RT];
+      // (the phase's launch arguments as one batch of scalar loads: wide_sweep.h, FuseArgs)
+      FuseArgs fz;
+      fuse_args(a, exs, fz);
+      float* const o_im = a.infer_mean; float* const o_is = a.infer_std;
+      float* const o_pm = a.prior_mean; float* const o_ps = a.prior_std;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         PairRef pr = tab[rt];          // a tile's pair is wave-uniform: scalar address math
@@ -287,15 +293,15 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
         if (pr.p >= 0) {
           const size_t tb = (size_t)t * B + pr.b;
           ExpertVals ev;
-          load_experts(a, exs, pr, tb, n, ev);          // (one batch of loads per tile)
+          load_experts_d(fz.ed, pr, tb, n, ev);         // (one batch of loads per tile)
           fast::Poe pq; pq.init(); pq.add(pm[rt], ps[rt], 1.0f);
           poe_experts(a, exs, pr, tb, n, ev, pq);
-          if (a.use_inv_prior) pq.add(mu0, -sg0, 1.0f);
+          if (fz.inv_prior) pq.add(mu0, -sg0, 1.0f);
           pq.finish(im, is);
           const size_t o = (((size_t)pr.p * T + t) * B + pr.b) * WD + n;
           if (h == 0 && (rt & (g.TPP - 1)) == 0) {
-            a.infer_mean[o] = im; a.infer_std[o] = is;
-            a.prior_mean[o] = pm[rt]; a.prior_std[o] = ps[rt];
+            o_im[o] = im; o_is[o] = is;
+            o_pm[o] = pm[rt]; o_ps[o] = ps[rt];
           }
         }
         const int kb = 32 * (rt & (g.TPP - 1));
