@@ -233,6 +233,13 @@ class GraphedElboStep:
 
     def __call__(self):
         self.g_step.replay()
-        self.bucket.allreduce(self.group)
+        if dist.is_available() and dist.is_initialized() and (self.group is not None or dist.get_world_size() > 1):
+            # The collective is a stream operation between two replays.  On this ROCm such an operation does not
+            # reliably wait for every queue of the replay in front of it (schedule()): the gradients
+            # must be complete before RCCL reads them, so the host waits for the step graph first.
+            # (A/B on a multi-GPU box: MDMM_NO_REPLAY_SYNC=1)
+            if os.environ.get('MDMM_NO_REPLAY_SYNC') != '1':
+                torch.cuda.current_stream().synchronize()
+            self.bucket.allreduce(self.group)
         self.g_opt.replay()
         return self.loss
