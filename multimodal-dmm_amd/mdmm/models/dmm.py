@@ -356,8 +356,13 @@ class MultiDMM(MultiDGTS):
     def _mode_loss(self, enc, targets, mask, kld_mult, rec_mults, pass_mods, loss_mods, t_max,
                    b_dim, mode, sample, sample_init, flt_particles, smt_particles):
         """sum over passes of [kld_mult*KLD + sum_m mult_m*NLL_m]  (dgts.py:119-129, 132-145)"""
-        infer, prior, zs = self._run_passes(enc, pass_mods, t_max, b_dim, mode, sample,
-                                            sample_init, flt_particles, smt_particles)
+        passes = self._run_passes(enc, pass_mods, t_max, b_dim, mode, sample,
+                                  sample_init, flt_particles, smt_particles)
+        return self._passes_loss(passes, targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim)
+
+    def _passes_loss(self, passes, targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim):
+        """The loss of one mode from its passes' (infer, prior, samples): see _mode_loss."""
+        infer, prior, zs = passes
         # mask: (T,B) fp32 row mask, or the pair (row mask, row mask tiled over the passes) that
         # `step` prepares once for all its loss terms
         mask, mask_kld = mask if isinstance(mask, tuple) else (mask, mask)
@@ -481,15 +486,57 @@ class MultiDMM(MultiDGTS):
             for x in (mu, sd, seen):
                 x.record_stream(side)
         mask_f.record_stream(side); mask_kld.record_stream(side)
-        side.wait_stream(main)
+        # Experiment: the smoothing-mode term's SWEEPS in front of the filtering-mode term, its
+        # decoders and loss behind it.  Autograd issues backward nodes newest first, and a replayed graph starts
+        # its nodes roughly in the order they were captured: with the two terms one after the other the
+        # filtering-mode backward is captured -- and started -- behind the other term's whole backward, 4 ms
+        # into the backward phase, and runs alone for 6 ms behind the K-particle backward sweep.  Split, the
+        # capture order is: smoothing decoders' backward, filtering-mode backward, smoothing sweeps' backward.
+        # The Philox stream ids are handed out as in the plain order (bit-identical results).
+        noise = self._noise()
+        split = (os.environ.get('MDMM_SPLIT_S') == '1' and not noise.replay and torch.is_grad_enabled()
+                 and side is not main)
+        if split:
+            fork = torch.cuda.Event()
+            fork.record(main)
+            c0, n_f = noise.counter, (2 if f_mode in SMOOTH_MODES else 1)
+            noise.counter = c0 + n_f
+            passes_s = self._run_passes(enc, pass_mods, t_max, b_dim, s_mode, sample, sample_init,
+                                        train_particles, smt_particles)
+            c_after_s = noise.counter
+            noise.counter = c0
+            side.wait_event(fork)
+        else:
+            side.wait_stream(main)
+        def filter_loss():
+            return f_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
+                                            loss_mods, t_max, b_dim, f_mode, sample,
+                                            sample_init, kwargs.get('flt_particles', 1),
+                                            smt_particles)
+
         with torch.cuda.stream(side):
-            loss_f = f_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
-                                              loss_mods, t_max, b_dim, f_mode, sample,
-                                              sample_init, kwargs.get('flt_particles', 1),
-                                              smt_particles)
-        loss_s = s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
-                                          loss_mods, t_max, b_dim, s_mode, sample,
-                                          sample_init, train_particles, smt_particles)
+            if os.environ.get('MDMM_EAGER_F') == '1' and torch.is_grad_enabled():
+                # Experiment: value AND gradients of the filtering-mode term right here, on the side
+                # stream -- with respect to the encoder outputs and the parameters behind them -- so that its
+                # decoder backward and K = 1 backward sweep are issued in front of the smoothing term's forward
+                # instead of behind its whole backward (a replayed graph starts its nodes roughly in the order
+                # they were captured: the term's backward used to start 4 ms into the backward phase and ran
+                # alone for 6 ms behind the K-particle backward sweep).
+                wrt = [x for mu, sd, _ in enc.values() for x in (mu, sd) if x.requires_grad]
+                wrt += [self.z0_mean, self.z0_log_std, *self._gtf('fwd'), *self._gtf('bwd')]
+                wrt += [p for m in self.modalities for p in self.dec[m].parameters()]
+                loss_f = _EagerGradFn.apply(filter_loss, *wrt)
+            else:
+                loss_f = filter_loss()
+        if split:
+            assert noise.counter == c0 + n_f, 'stream ids of the filtering-mode term'
+            noise.counter = c_after_s
+            loss_s = s_mult * self._passes_loss(passes_s, targets, (mask_f, mask_kld), kld_mult, rec_mults, loss_mods,
+                                                t_max, b_dim)
+        else:
+            loss_s = s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
+                                              loss_mods, t_max, b_dim, s_mode, sample,
+                                              sample_init, train_particles, smt_particles)
         main.wait_stream(side)
         if match_mult > 0:
             main.wait_stream(third)
