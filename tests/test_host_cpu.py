@@ -391,3 +391,36 @@ def test_clip_flat_matches_clip_grad_norm():
         ref = torch.nn.utils.clip_grad_norm_(ps, max_norm)
         assert abs(float(norm) - float(ref)) <= 1e-6 * float(ref)
         assert torch.allclose(flat, torch.cat([p.grad for p in ps]), rtol=1e-6, atol=0)
+
+
+def test_loss_sum_with_a_device_weight():
+    """ops.LossSum.scaled (the annealed KLD multiplier of a captured step, trainer.py:227-229): the total is
+    acc + w * acc_sub, the sub-sum's terms receive w times the upstream gradient, the others the gradient itself
+    (plain torch on the CPU: the terms' kernels only ever see those two device scalars)."""
+    from mdmm import ops
+    total = ops.LossSum(torch.device('cpu'))
+    w = torch.tensor(0.25)
+    sub = total.scaled(w)
+    assert ops.weighted_into(total, 0.5) == (0.5, total)
+    wt, into = ops.weighted_into(total, w)
+    assert wt == 1.0 and into is not total and into.acc.dtype == torch.float64
+
+    class Term(torch.autograd.Function):          # what a term's kernel pair does: adds into acc, scales by g
+        @staticmethod
+        def forward(ctx, x, acc, weight):
+            acc += weight * x.double().sum()
+            ctx.weight = weight
+            return torch.empty(())
+
+        @staticmethod
+        def backward(ctx, g):
+            return ctx.weight * g.expand(3), None, None
+
+    a, b = torch.tensor([1., 2., 3.], requires_grad=True), torch.tensor([4., 5., 6.], requires_grad=True)
+    total.handles.append(Term.apply(a, total.acc, 2.0))
+    sub.handles.append(Term.apply(b, sub.acc, 1.0))
+    loss = total.total()
+    assert abs(float(loss) - (2.0 * 6.0 + 0.25 * 15.0)) < 1e-6
+    loss.backward(gradient=torch.tensor(0.5))
+    assert torch.allclose(a.grad, torch.full((3,), 0.5 * 2.0))
+    assert torch.allclose(b.grad, torch.full((3,), 0.5 * 0.25))
