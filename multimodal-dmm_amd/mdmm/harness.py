@@ -162,6 +162,7 @@ class GraphedElboStep:
         self.clip_grad = float(clip_grad) if clip_grad is not None and clip_grad > 0 else None
         self._host_buf = torch.tensor([float(kld_mult), 1.0 / float(n_points)], dtype=torch.float32).pin_memory()
         self._host = {'kld_mult': self._host_buf[0], 'inv_points': self._host_buf[1]}
+        self._asked = {'kld_mult': float(kld_mult), 'inv_points': 1.0 / float(n_points)}
         self._sched_ws = torch.empty(8, dtype=torch.float32, device=dev)
 
         def fwd_bwd():
@@ -220,15 +221,17 @@ class GraphedElboStep:
         """Set the KLD multiplier / the normalisation of the next replays.  The step graph's first nodes copy both
         scalars from pinned host memory, so nothing is launched between replays (measured on this ROCm: any stream
         operation between two replays of the cfg4 step -- a fill kernel or a host-to-device copy alike -- ends in a
-        memory fault under the forced executor queues, DESIGN 5.2).  A value that did not change costs nothing;
+        memory fault under the forced executor queues, DESIGN 5.3).  A value that did not change costs nothing;
         one that did waits for the replays in flight (they read the host scalars when they start) and is written
         by the CPU."""
         new = {'kld_mult': kld_mult, 'inv_points': None if n_points is None else 1.0 / float(n_points)}
-        changed = {k: float(v) for k, v in new.items() if v is not None and float(v) != float(self._host[k])}
+        # (compared as requested, in double: the pinned copies are fp32 and would never equal 1 / n_points)
+        changed = {k: float(v) for k, v in new.items() if v is not None and float(v) != self._asked[k]}
         if not changed:
             return
         torch.cuda.current_stream().synchronize()
         for k, v in changed.items():
+            self._asked[k] = v
             self._host[k].fill_(v)
 
     def __call__(self):
