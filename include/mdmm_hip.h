@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 21
+#define MDMM_ABI_VERSION 22
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -746,6 +746,44 @@ int mdmm_vrnn_layout(const mdmm_vrnn_t* args, mdmm_vrnn_layout_t* out);
 int mdmm_vrnn_supported(const mdmm_vrnn_t* args, int backward);
 int mdmm_vrnn_fwd(const mdmm_vrnn_t* args, void* stream);
 int mdmm_vrnn_bwd(const mdmm_vrnn_t* args, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Batch preparation and evaluation metrics on the device: the callers either side of the
+ * ELBO step.  Integer / byte work is bit-exact against the reference's functions (tests/golden/g10_batch.npz).
+ * --------------------------------------------------------------------------------- */
+/* datasets/multiseq.py:341-353 pad_and_merge + the reordering of seq_collate_dict (372-386): the sequences of one
+ * modality lie packed in `flat` (sequence i from row seq_offset[i], rows of `row` floats, original order); batch
+ * column b of out (T, B, row) is sequence order[b], lengths[b] rows of it, NaN behind.  */
+int mdmm_collate_pad(const float* flat, const int64_t* seq_offset, const int32_t* order, const int32_t* lengths,
+                     int T, int B, int64_t row, float* out, void* stream);
+/* multiseq.py:405-420 func_delete (clone + NaN the chosen steps) in one pass: out[s] = del[s] ? NaN : x[s],
+ * s = t * B + b, del (T*B) bytes.  */
+int mdmm_delete_steps(const float* x, const uint8_t* del, int64_t steps, int64_t row, float* out, void* stream);
+/* multiseq.py:388-403 seq_decoll / seq_decoll_dict: de-pad and reorder.  parts[i] (T, B, row), i < n_parts (the
+ * entries of a reconstruction tuple, stacked on axis 1 as the reference's np.stack does; 1 for a plain tensor);
+ * output sequence j is batch column idx = order[j], stored as [lengths[idx]][n_parts][row] from row
+ * out_offset[j] of `out` (ONE device-to-host copy of `out` then replaces B of them).  */
+#define MDMM_DECOLL_MAX_PARTS 4
+int mdmm_decollate_pack(const float* const* parts, int n_parts, int T, int B, int64_t row, const int32_t* lengths,
+                        const int32_t* order, const int64_t* out_offset, float* out, void* stream);
+/* spirals.py:104-105, weizmann.py:129-130, 136-137: out[s] (+)= sum_i (rec[s][i] - tgt[s][i])^2 (each term divided
+ * by `div` first when div != 0, the reference's order of operations).  NaN targets (padding) give NaN, which
+ * mdmm_time_avg's mask removes -- as in the reference.  */
+int mdmm_sqerr_steps(const float* rec, const float* tgt, int64_t steps, int64_t row, float div, int accumulate,
+                     float* out, void* stream);
+/* time_avg (spirals.py:107-110, weizmann.py:143-150): out[j] = sum_t (mask[t][b] ? val[t][b] : 0) / lengths[b],
+ * b = order[j] (order NULL: b = j).  mask: bytes (T, B), lengths: float (B).  */
+int mdmm_time_avg(const float* val, const uint8_t* mask, int T, int B, const float* lengths, const int32_t* order,
+                  float* out, void* stream);
+/* time_acc (weizmann.py:152-162): out[j] = #{t : argmax_c probs[t][b][c] == (long) target[t][b]} / lengths[b].  */
+int mdmm_time_acc(const float* probs, const float* target, int T, int B, int n_cat, const float* lengths,
+                  const int32_t* order, float* out, void* stream);
+/* utils.py:110-212 eval_ssim(X, Y) for (N, C, H, W) fp32 images: the five maps blurred with the 1-D window
+ * (win taps, valid padding) along x, then along y; out (N) = mean over channels and pixels of the SSIM map.
+ * ws: mdmm_ssim_ws_floats(N, C) floats.  */
+int64_t mdmm_ssim_ws_floats(int64_t N, int C);
+int mdmm_ssim(const float* x, const float* y, int64_t N, int C, int H, int W, const float* window, int win,
+              float data_range, float* ws, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -182,9 +182,9 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
       running_mean[c] = rm; running_var[c] = rv;
     }
   }
-  x += (size_t)grp * N * C * L;
-  y += (size_t)grp * N * C * L;
   if (!y) return;                                // MDMM_BN_FINALIZE: the consumer normalises (mdmm_conv_t.in_mean)
+  x += (size_t)grp * N * C * L;                  // (tested BEFORE the group offset: null + offset is not null)
+  y += (size_t)grp * N * C * L;
   const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
   // (one rounding each, spelled out: csrc/conv_tiles.hip forms the same two numbers from save_mean / save_invstd)
   const float scale = g * invstd, shift = fmaf(-(float)mean, scale, b);

@@ -1,12 +1,25 @@
-"""On-device batch preparation: the reference builds masks and NaN deletions
-with Python loops over B x M sequences and numpy RNG on the host (datasets/multiseq.py:321-327,
-405-448, called per batch at trainer.py:235, 284-287).  These are the same operations as a few
-vectorised tensor ops on whatever device the batch lives on, so the ELBO step is not left waiting
-for the host at B = 4096.  Draw-for-draw equality with numpy's generator is not possible; the
-index sets follow the same distributions, and every function accepts the random part explicitly
-(`t_start`, `scores`) so that the deterministic part can be checked exactly.
+"""On-device batch preparation: collate, de-collate and the NaN deletions the reference does
+with Python loops over the B x M sequences of a batch on the host (datasets/multiseq.py:321-327 len_to_mask,
+341-353 pad_and_merge, 372-386 seq_collate_dict, 388-403 seq_decoll / seq_decoll_dict, 405-448 func_delete and
+its four users; called per batch at trainer.py:231-235, 284-287, 300-306).
+
+Split of the work:
+* HOST LOGIC (this file, plain Python / numpy on B-sized index arrays): sorting by length, offsets, which time steps
+  of which sequence are deleted.  `*_steps` return the (T, B) bool table of deleted steps.  With `rng='numpy'`
+  the random draws are numpy's legacy generator in the reference's own call order (modality-major,
+  sequence-minor: multiseq.py:411-419), so a run seeded with `np.random.seed(s)` deletes exactly the steps the
+  reference deletes -- pinned bit for bit by tests/golden/g10_batch.npz.  Without it the draws come from a torch
+  generator on the device (same distributions, no host round trip per sequence).
+* DEVICE WORK (csrc/batch_eval.hip through the C ABI): every pass over the (T, B, *dims) data -- NaN-padded
+  merge, clone + NaN rows, de-pad + reorder -- is one kernel launch per modality.  There is no CPU fallback for
+  those: the data functions raise on host tensors.
 """
+import ctypes as C
+
+import numpy as np
 import torch
+
+from . import native
 
 
 def len_to_mask(lengths, device=None, time_first=True):
@@ -17,75 +30,252 @@ def len_to_mask(lengths, device=None, time_first=True):
     return (mask if time_first else mask.t()).unsqueeze(-1)
 
 
-def _lens(batch, lengths):
-    first = batch[next(iter(batch))]
-    t_max, b_dim = first.shape[:2]
-    if lengths is None:
-        return torch.full((b_dim,), t_max, device=first.device, dtype=torch.long), t_max
-    return torch.as_tensor(lengths, device=first.device, dtype=torch.long), t_max
+# ------------------------------------------------------------------------------------------------ device calls --
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _apply(batch, delete, modalities):
-    """delete: {m: (T,B) bool} -> copy of the batch with those time-points set to NaN."""
-    out = {}
-    for m, x in batch.items():
-        if modalities is not None and m not in modalities:
-            out[m] = x.clone()
-            continue
-        d = delete[m].reshape(delete[m].shape + (1,) * (x.dim() - 2))
-        out[m] = torch.where(d, torch.full_like(x, float('nan')), x)
+def _need_gpu(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise native.MdmmError('mdmm.batch moves batch data on an MI355X only: got a %s tensor (no CPU fallback)'
+                                   % t.device)
+
+
+def _i32(values, device):
+    return torch.as_tensor(np.asarray(values, dtype=np.int32), device=device)
+
+
+def _i64(values, device):
+    return torch.as_tensor(np.asarray(values, dtype=np.int64), device=device)
+
+
+def delete_steps(x, steps):
+    """x (T, B, *dims) fp32 on the GPU, steps (T, B) bool: a copy of x with those time steps NaN (func_delete's
+    clone + assignment, multiseq.py:410-419, as one pass)."""
+    _need_gpu(x)
+    if x.dtype != torch.float32:
+        raise native.MdmmError('delete_steps takes fp32 batches (the collate produces fp32), got %s' % x.dtype)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    n = x.shape[0] * x.shape[1]
+    if n == 0 or x.numel() == 0:
+        return out
+    d = steps.to(device=x.device, dtype=torch.uint8).contiguous()
+    assert d.numel() == n
+    native.check(native.lib().mdmm_delete_steps(x.data_ptr(), d.data_ptr(), n, x.numel() // n, out.data_ptr(),
+                                                _stream()), 'mdmm_delete_steps')
     return out
 
 
-def burst_delete(batch, burst_frac, lengths=None, modalities=None, generator=None, t_start=None):
-    """One burst of int(burst_frac * len) missing steps per (modality, sequence), starting at a
-    uniform position (multiseq.py:428-434).  t_start: optional {m: (B,) long} to fix the draws."""
-    lens, t_max = _lens(batch, lengths)
+# -------------------------------------------------------------------------------------------------- host logic --
+def _host_lengths(batch, lengths):
+    first = batch[next(iter(batch))]
+    t_max, b_dim = first.shape[:2]
+    if lengths is None:                                    # multiseq.py:414-415
+        lengths = [t_max] * b_dim
+    if torch.is_tensor(lengths):
+        lengths = lengths.tolist()
+    return [int(n) for n in lengths], int(t_max), first.device
+
+
+def _numpy_rng(rng):
+    if rng is None:
+        return None
+    if isinstance(rng, str):
+        if rng != 'numpy':
+            raise ValueError("rng: None (torch generator on the device), 'numpy' or a numpy RandomState")
+        return np.random
+    return rng
+
+
+def _range_table(lo, hi, t_max, device):
+    t = torch.arange(t_max, device=device).unsqueeze(1)
+    return (t >= _i64(lo, device).unsqueeze(0)) & (t < _i64(hi, device).unsqueeze(0))
+
+
+def burst_steps(lengths, t_max, burst_frac, device=None, t_start=None, generator=None, rng=None):
+    """(T, B) bool: one burst of int(burst_frac * len) steps per sequence from a uniform start (multiseq.py:428-434).
+    t_start: the starts, given; rng: numpy draws in the reference's order; else torch draws on `device`."""
+    width = [int(burst_frac * n) for n in lengths]
+    rs = _numpy_rng(rng)
+    if t_start is not None:
+        start = [int(s) for s in (t_start.tolist() if torch.is_tensor(t_start) else t_start)]
+    elif rs is not None:
+        start = [int(rs.randint(n)) for n in lengths]
+    else:
+        lens = _i64(lengths, device)
+        u = torch.rand(lens.shape, generator=generator, device=lens.device)
+        s = torch.minimum((u * lens).long(), lens - 1)
+        stop = torch.minimum(s + _i64(width, device), lens)
+        t = torch.arange(t_max, device=lens.device).unsqueeze(1)
+        return (t >= s.unsqueeze(0)) & (t < stop.unsqueeze(0))
+    stop = [min(s + w, n) for s, w, n in zip(start, width, lengths)]
+    return _range_table(start, stop, t_max, device)
+
+
+def rand_steps(lengths, t_max, del_frac, device=None, indices=None, scores=None, generator=None, rng=None):
+    """(T, B) bool: int(del_frac * len) distinct steps per sequence (multiseq.py:422-426).  indices: the chosen steps
+    per sequence, given; rng: numpy's choice() in the reference's order; scores: (T, B) ranking noise (the k smallest
+    valid scores go); else torch draws on `device`."""
+    k = [int(del_frac * n) for n in lengths]
+    rs = _numpy_rng(rng)
+    if indices is None and rs is not None:
+        indices = [rs.choice(n, kk, False) for n, kk in zip(lengths, k)]
+    if indices is not None:
+        table = np.zeros((t_max, len(lengths)), dtype=bool)
+        for b, idx in enumerate(indices):
+            table[np.asarray(idx, dtype=np.int64), b] = True
+        return torch.as_tensor(table, device=device)
+    lens = _i64(lengths, device)
     t = torch.arange(t_max, device=lens.device).unsqueeze(1)
-    width = (burst_frac * lens.double()).long()
-    delete = {}
-    for m in batch:
-        if t_start is not None:
-            start = t_start[m].to(lens.device)
-        else:
-            u = torch.rand(lens.shape, generator=generator, device=lens.device)
-            start = torch.minimum((u * lens).long(), lens - 1)
-        stop = torch.minimum(start + width, lens)
-        delete[m] = (t >= start.unsqueeze(0)) & (t < stop.unsqueeze(0))
-    return _apply(batch, delete, modalities)
+    s = scores.to(lens.device) if scores is not None else \
+        torch.rand((t_max, len(lengths)), generator=generator, device=lens.device)
+    s = torch.where(t < lens.unsqueeze(0), s, torch.full_like(s, float('inf')))
+    rank = s.argsort(dim=0).argsort(dim=0)
+    return rank < _i64(k, device).unsqueeze(0)
 
 
-def rand_delete(batch, del_frac, lengths=None, modalities=None, generator=None, scores=None):
-    """int(del_frac * len) distinct random steps per (modality, sequence) (multiseq.py:422-426).
-    scores: optional {m: (T,B)} ranking noise; the k smallest valid scores are deleted."""
-    lens, t_max = _lens(batch, lengths)
-    t = torch.arange(t_max, device=lens.device).unsqueeze(1)
-    k = (del_frac * lens.double()).long()
-    delete = {}
-    for m in batch:
-        s = scores[m].to(lens.device) if scores is not None else \
-            torch.rand((t_max, lens.shape[0]), generator=generator, device=lens.device)
-        s = torch.where(t < lens.unsqueeze(0), s, torch.full_like(s, float('inf')))
-        rank = s.argsort(dim=0).argsort(dim=0)
-        delete[m] = rank < k.unsqueeze(0)
-    return _apply(batch, delete, modalities)
+def segment_steps(lengths, t_max, f_start, f_stop, keep, device=None):
+    """(T, B) bool: the steps keep_segment (multiseq.py:436-441) / del_segment (443-448) delete."""
+    lo = [int(f_start * n) for n in lengths]
+    hi = [int(f_stop * n) for n in lengths]
+    inside = _range_table(lo, hi, t_max, device)
+    if not keep:
+        return inside
+    return _range_table([0] * len(lengths), lengths, t_max, device) & ~inside
 
 
-def _segment(batch, f_start, f_stop, lengths, modalities, keep):
-    lens, t_max = _lens(batch, lengths)
-    t = torch.arange(t_max, device=lens.device).unsqueeze(1)
-    lo, hi = (f_start * lens.double()).long(), (f_stop * lens.double()).long()
-    inside = (t >= lo.unsqueeze(0)) & (t < hi.unsqueeze(0))
-    valid = t < lens.unsqueeze(0)
-    d = (valid & ~inside) if keep else inside
-    return _apply(batch, {m: d for m in batch}, modalities)
+def _func_delete(batch, steps_of, modalities):
+    """func_delete (multiseq.py:405-420): every modality cloned, the listed ones with their steps NaN; the step
+    tables are built in the reference's order (batch key order) so that numpy draws line up."""
+    if modalities is None:
+        modalities = list(batch.keys())
+    out = {}
+    for m, x in batch.items():
+        if m not in modalities:
+            _need_gpu(x)
+            out[m] = x.clone().detach()
+            continue
+        out[m] = delete_steps(x, steps_of(m))
+    return out
+
+
+def burst_delete(batch, burst_frac, lengths=None, modalities=None, generator=None, t_start=None, rng=None):
+    """multiseq.py:428-434 on the device.  t_start: optional {m: (B,)} to fix the draws."""
+    lens, t_max, dev = _host_lengths(batch, lengths)
+    return _func_delete(batch, lambda m: burst_steps(lens, t_max, burst_frac, dev, None if t_start is None else t_start[m],
+                                                     generator, rng), modalities)
+
+
+def rand_delete(batch, del_frac, lengths=None, modalities=None, generator=None, scores=None, indices=None, rng=None):
+    """multiseq.py:422-426 on the device.  scores / indices: optional {m: ...} to fix the draws."""
+    lens, t_max, dev = _host_lengths(batch, lengths)
+    return _func_delete(batch, lambda m: rand_steps(lens, t_max, del_frac, dev, None if indices is None else indices[m],
+                                                    None if scores is None else scores[m], generator, rng), modalities)
 
 
 def keep_segment(batch, f_start, f_stop, lengths=None, modalities=None):
     """Delete everything outside [f_start, f_stop) of each sequence (multiseq.py:436-441)."""
-    return _segment(batch, f_start, f_stop, lengths, modalities, True)
+    lens, t_max, dev = _host_lengths(batch, lengths)
+    table = segment_steps(lens, t_max, f_start, f_stop, True, dev)
+    return _func_delete(batch, lambda m: table, modalities)
 
 
 def del_segment(batch, f_start, f_stop, lengths=None, modalities=None):
     """Delete [f_start, f_stop) of each sequence (multiseq.py:443-448)."""
-    return _segment(batch, f_start, f_stop, lengths, modalities, False)
+    lens, t_max, dev = _host_lengths(batch, lengths)
+    table = segment_steps(lens, t_max, f_start, f_stop, False, dev)
+    return _func_delete(batch, lambda m: table, modalities)
+
+
+# ------------------------------------------------------------------------------------------------------ collate --
+def collate_plan(seq_lengths, item_lengths=None):
+    """Host logic of seq_collate_dict (multiseq.py:372-386): (order, lengths) -- sequences sorted by their item
+    length, longest first, ties in their original order (Python's stable sort, as the reference's `sorted`)."""
+    item_lengths = list(seq_lengths if item_lengths is None else item_lengths)
+    order = sorted(range(len(item_lengths)), key=lambda i: item_lengths[i], reverse=True)
+    return order, [int(item_lengths[i]) for i in order]
+
+
+def pad_and_merge(sequences, max_len=None, device='cuda', order=None):
+    """multiseq.py:341-353: unequal-length (len_i, *dims) arrays -> (max_len, n, *dims) fp32, NaN behind each
+    sequence's end.  The sequences go to the GPU as ONE packed buffer; `order` (optional) puts sequence order[b] into
+    batch column b without re-packing on the host."""
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        raise native.MdmmError('pad_and_merge builds the batch on an MI355X (no CPU fallback), got %s' % dev)
+    n = len(sequences)
+    dims = tuple(sequences[0].shape[1:])
+    seq_len = [len(s) for s in sequences]
+    order = list(range(n)) if order is None else list(order)
+    lengths = [seq_len[i] for i in order]
+    if max_len is None:
+        max_len = max(lengths)
+    if max(lengths) > max_len:
+        raise ValueError('a sequence of %d steps does not fit max_len = %d' % (max(lengths), max_len))
+    row = int(np.prod(dims)) if dims else 1
+    flat = np.concatenate([np.asarray(s, dtype=np.float32).reshape(len(s), row) for s in sequences], axis=0) \
+        if sum(seq_len) else np.zeros((0, row), np.float32)
+    offset = np.concatenate([[0], np.cumsum(seq_len)[:-1]]).astype(np.int64)
+    out = torch.empty((max_len, n) + dims, dtype=torch.float32, device=dev)
+    if out.numel() == 0:
+        return out
+    flat_d = torch.from_numpy(flat).to(dev, non_blocking=True)
+    with torch.cuda.device(dev):
+        native.check(native.lib().mdmm_collate_pad(flat_d.data_ptr(), _i64(offset, dev).data_ptr(),
+                                                   _i32(order, dev).data_ptr(), _i32(lengths, dev).data_ptr(),
+                                                   max_len, n, row, out.data_ptr(), _stream()), 'mdmm_collate_pad')
+    return out
+
+
+def seq_collate_dict(data, time_first=True, device='cuda'):
+    """multiseq.py:372-386 with the batch tensors built on the device: (batch, mask, lengths, order, seq_ids).
+    data: list of {modality: (len, *dims) array, 'length': int, 'id': ...} items (MultiseqDataset.__getitem__ with
+    item_as_dict=True).  The caller's list is left in its order (the reference sorts it in place)."""
+    modalities = [k for k in data[0] if k not in ['length', 'id']]
+    order, lengths = collate_plan([d['length'] for d in data])
+    seq_ids = [data[i]['id'] for i in order]
+    batch = {}
+    for m in modalities:
+        padded = pad_and_merge([d[m] for d in data], max(lengths), device, order)
+        batch[m] = padded if time_first else padded.transpose(0, 1)
+    mask = len_to_mask(lengths, device=device, time_first=time_first)
+    return batch, mask, lengths, order, seq_ids
+
+
+def seq_decoll(batch, lengths, order, time_first=True):
+    """multiseq.py:388-399: list of de-padded numpy arrays, entry j = batch column order[j] (the reference's own
+    indexing); a tuple of tensors is stacked on axis 1.  One kernel + ONE device-to-host copy instead of one per
+    sequence (and per tuple entry)."""
+    parts = list(batch) if type(batch) is tuple else [batch]
+    if not time_first:
+        parts = [p.transpose(0, 1) for p in parts]
+    parts = [p.contiguous().float() for p in parts]
+    _need_gpu(*parts)
+    if len(parts) > 4:
+        raise native.MdmmError('seq_decoll: at most 4 tensors per tuple (MDMM_DECOLL_MAX_PARTS)')
+    T, B = parts[0].shape[:2]
+    dims = tuple(parts[0].shape[2:])
+    row = int(np.prod(dims)) if dims else 1
+    dev = parts[0].device
+    lengths = [int(n) for n in (lengths.tolist() if torch.is_tensor(lengths) else lengths)]
+    order = [int(i) for i in order]
+    out_len = [min(lengths[i], T) for i in order]
+    offset = np.concatenate([[0], np.cumsum(out_len)]).astype(np.int64)
+    out = torch.empty((int(offset[-1]), len(parts), row), dtype=torch.float32, device=dev)
+    if out.numel():
+        ptrs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+        with torch.cuda.device(dev):
+            native.check(native.lib().mdmm_decollate_pack(ptrs, len(parts), T, B, row,
+                                                          _i32([min(n, T) for n in lengths], dev).data_ptr(),
+                                                          _i32(order, dev).data_ptr(), _i64(offset[:-1], dev).data_ptr(),
+                                                          out.data_ptr(), _stream()), 'mdmm_decollate_pack')
+    host = out.cpu().numpy()
+    shape = ((len(parts),) if type(batch) is tuple else ()) + dims
+    return [host[offset[j]:offset[j + 1]].reshape((out_len[j],) + shape) for j in range(len(order))]
+
+
+def seq_decoll_dict(batch_dict, lengths, order, time_first=True):
+    """multiseq.py:401-403."""
+    return {k: seq_decoll(b, lengths, order, time_first) for k, b in batch_dict.items()}

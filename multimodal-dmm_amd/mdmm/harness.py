@@ -154,6 +154,14 @@ class GraphedElboStep:
                  targets=None, n_points_global=None, group=None, warmup=3, clip_grad=None, **train_args):
         from . import ops
         self.model, self.optimizer, self.bucket, self.group = model, optimizer, bucket, group
+        if getattr(model, 'bn_sync', None) is not None:
+            with ops.bn_sync(model.bn_sync):
+                if ops.bn_sync_group() is not None:
+                    # (synchronised BatchNorm statistics are one collective + a host read per layer and direction:
+                    # neither can be captured, and the capture would die with an opaque error far from the cause)
+                    raise RuntimeError('GraphedElboStep cannot capture a step with synchronised BatchNorm statistics '
+                                       '(model.bn_sync): run harness.elbo_step eagerly, or leave bn_sync = None')
+        self._replayed = None                                # event behind the last replay, on the stream it ran on
         n_points = sum(lengths) if n_points_global is None else n_points_global
         noise = model._noise()
         dev = bucket.flat.device
@@ -229,7 +237,14 @@ class GraphedElboStep:
         changed = {k: float(v) for k, v in new.items() if v is not None and float(v) != self._asked[k]}
         if not changed:
             return
-        torch.cuda.current_stream().synchronize()
+        if os.environ.get('MDMM_SCHEDULE_FETCH', 'kernel') == 'none':
+            raise RuntimeError('schedule(): MDMM_SCHEDULE_FETCH=none freezes the captured values; nothing would change')
+        # the replays in flight read the host scalars when they start: wait for the stream they were launched on
+        # (not for whatever stream is current here)
+        if self._replayed is not None:
+            self._replayed.synchronize()
+        else:
+            torch.cuda.current_stream().synchronize()
         for k, v in changed.items():
             self._asked[k] = v
             self._host[k].fill_(v)
@@ -245,4 +260,7 @@ class GraphedElboStep:
                 torch.cuda.current_stream().synchronize()
             self.bucket.allreduce(self.group)
         self.g_opt.replay()
+        if self._replayed is None:
+            self._replayed = torch.cuda.Event()
+        self._replayed.record()                              # (behind both replays, on the replay stream)
         return self.loss

@@ -127,7 +127,11 @@ class _ConvBlock(nn.Module):
             if ops.bn_deconv_supported(pending, layer):
                 if isinstance(self.net, nn.Sequential):
                     bn = self.net[1]
-                    if ops.BN_DEFER and bn.training:      # (this block's statistics out of the deconvolution's epilogue)
+                    if not ops.batchnorm_relu_supported(pending.x_pre, bn):
+                        # this block's BatchNorm is frozen (eval mode) or under autocast: the stock modules on the
+                        # deconvolution's biased output -- running statistics used and left alone, as nn.BatchNorm does
+                        return self.net[2](bn(ops.bn_deconv(pending, layer)))
+                    if ops.BN_DEFER:                      # (this block's statistics out of the deconvolution's epilogue)
                         y_pre, part = ops.bn_deconv(pending, layer, bias=False, stats_for=bn)
                         return ops.DeferredNorm(y_pre, bn, layer.bias, part)
                     y_pre = ops.bn_deconv(pending, layer, bias=False)

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 21
+ABI_VERSION = 22
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -41,6 +41,8 @@ SYMBOLS = [
     'mdmm_conv1d_supported', 'mdmm_conv1d_up', 'mdmm_conv1d_down', 'mdmm_conv1d_wgrad_ws_bytes', 'mdmm_conv1d_wgrad',
     'mdmm_colsum_splits', 'mdmm_colsum',
     'mdmm_vrnn_layout', 'mdmm_vrnn_supported', 'mdmm_vrnn_fwd', 'mdmm_vrnn_bwd',
+    'mdmm_collate_pad', 'mdmm_delete_steps', 'mdmm_decollate_pack', 'mdmm_sqerr_steps', 'mdmm_time_avg', 'mdmm_time_acc',
+    'mdmm_ssim_ws_floats', 'mdmm_ssim',
 ]
 
 _P = C.c_void_p
@@ -325,6 +327,15 @@ def lib():
         L.mdmm_vrnn_supported.argtypes = [C.POINTER(Vrnn), C.c_int]
         L.mdmm_vrnn_fwd.argtypes = [C.POINTER(Vrnn), _P]
         L.mdmm_vrnn_bwd.argtypes = [C.POINTER(Vrnn), _P]
+        L.mdmm_collate_pad.argtypes = [_P, _P, _P, _P, i32, i32, i64, _P, _P]
+        L.mdmm_delete_steps.argtypes = [_P, _P, i64, i64, _P, _P]
+        L.mdmm_decollate_pack.argtypes = [C.POINTER(_P), i32, i32, i32, i64, _P, _P, _P, _P, _P]
+        L.mdmm_sqerr_steps.argtypes = [_P, _P, i64, i64, f32, i32, _P, _P]
+        L.mdmm_time_avg.argtypes = [_P, _P, i32, i32, _P, _P, _P, _P]
+        L.mdmm_time_acc.argtypes = [_P, _P, i32, i32, i32, _P, _P, _P, _P]
+        L.mdmm_ssim_ws_floats.argtypes = [i64, i32]
+        L.mdmm_ssim_ws_floats.restype = i64
+        L.mdmm_ssim.argtypes = [_P, _P, i64, i32, i32, i32, _P, i32, f32, _P, _P, _P]
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
         for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp), (7, Bn), (8, Conv),

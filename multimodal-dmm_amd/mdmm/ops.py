@@ -1183,7 +1183,7 @@ def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.flo
     # A/B switches: bit 0 = bf16 operands through the converting path, bit 1 = staggered contraction start,
     # bit 2 = the generic tile kernel where a shape-specialised one (csrc/gemm_heads.hip) would be taken
     g.flags = (int(os.environ.get('MDMM_GEMM_NO_RAW') == '1') | (2 * int(os.environ.get('MDMM_GEMM_ROT', '0') == '1'))
-                  | (4 * int(os.environ.get('MDMM_GEMM_GENERIC', '0') == '1')) | (8 * int(os.environ.get('MDMM_GEMM_MODE', '0')))
+                  | (4 * int(os.environ.get('MDMM_GEMM_GENERIC', '0') == '1')) | (8 * (int(os.environ.get('MDMM_GEMM_MODE', '0')) & 3))
                   | (native.GEMM_RELU if relu else 0) | (native.GEMM_F32 if f32 else 0))
     g.a, g.lda, g.b, g.ldb = _ptr(a), a.stride(0), _ptr(b), b.stride(0)
     g.a_bf16, g.b_bf16 = int(a.dtype == torch.bfloat16), int(b.dtype == torch.bfloat16)

@@ -682,14 +682,221 @@ def g9_plugins():
     save_npz(os.path.join(HERE, 'g9_plugins.npz'), out)
 
 
+# ------------------------------------------------------------- G10 batch preparation --
+def _g10_items():
+    """Seven ragged sequences with tied lengths (pins the stable sort), three modalities: a vector one, an
+    image-like one stored as float64 (the collate casts), and integer labels with a trailing unit dimension."""
+    rs = np.random.RandomState(5)
+    lens = [5, 9, 9, 3, 12, 1, 9]
+    items = []
+    for i, n in enumerate(lens):
+        items.append({'a': rs.randn(n, 3).astype(np.float32),
+                      'img': rs.rand(n, 2, 4, 4),                       # float64
+                      'lab': rs.randint(0, 10, (n, 1)).astype(np.int64),
+                      'length': n, 'id': 'seq%02d' % i})
+    return items
+
+
+def g10_batch():
+    """The reference's own collate / decollate / deletion functions (datasets/multiseq.py:341-448) on seeded
+    ragged sequences; numpy's legacy generator seeded before every deletion call.  Stored: the items, the collated
+    batch, mask, lengths, order, ids, every deleted batch, and the decollated arrays (tensor and tuple form)."""
+    import numpy.random as nrand
+    from datasets import multiseq as mseq
+    items = _g10_items()
+    out = {'items': {str(i): {k: (np.asarray(v) if k not in ('id',) else np.array(v)) for k, v in it.items()}
+                     for i, it in enumerate(items)}}
+    batch, mask, lengths, order, ids = mseq.seq_collate_dict([dict(it) for it in items])
+    out['collate'] = {'batch': batch, 'mask': mask, 'lengths': np.array(lengths), 'order': np.array(order),
+                      'ids': np.array(ids)}
+    single = mseq.seq_collate_dict([dict(items[4])])            # a batch of one (pad_and_merge's .float() branch)
+    out['collate_one'] = {'batch': single[0], 'lengths': np.array(single[2]), 'order': np.array(single[3])}
+    tf = mseq.seq_collate_dict([dict(it) for it in items], time_first=False)
+    out['collate_batch_first'] = {'batch': tf[0], 'mask': tf[1]}
+    dele = {}
+    nrand.seed(11)
+    dele['burst_0.3'] = mseq.burst_delete(batch, 0.3, lengths)
+    nrand.seed(12)
+    dele['burst_0.5_a_lab'] = mseq.burst_delete(batch, 0.5, lengths, modalities=['a', 'lab'])
+    nrand.seed(13)
+    dele['burst_0.2_nolen'] = mseq.burst_delete(batch, 0.2)
+    nrand.seed(14)
+    dele['rand_0.4'] = mseq.rand_delete(batch, 0.4, lengths)
+    nrand.seed(15)
+    dele['rand_0.9_img'] = mseq.rand_delete(batch, 0.9, lengths, modalities=['img'])
+    dele['keep_0.25_0.75'] = mseq.keep_segment(batch, 0.25, 0.75, lengths)
+    dele['del_0.2_0.6'] = mseq.del_segment(batch, 0.2, 0.6, lengths)
+    nrand.seed(16)                                              # the evaluation chain of spirals.py / trainer.py:284-287
+    chain = mseq.rand_delete(batch, 0.5, lengths)
+    dele['rand_then_keep'] = mseq.keep_segment(chain, 0.25, 0.75, lengths)
+    out['delete'] = dele
+    g = torch.Generator().manual_seed(3)
+    rec = {'a': (torch.randn(12, 7, 3, generator=g), torch.rand(12, 7, 3, generator=g)),      # (mean, std) tuple
+           'img': (torch.rand(12, 7, 2, 4, 4, generator=g),),                                # one-entry tuple
+           'z': torch.randn(12, 7, 5, generator=g)}                                          # plain tensor
+    dec = mseq.seq_decoll_dict(rec, lengths, order)
+    out['decoll'] = {'in': {k: (list(v) if type(v) is tuple else v) for k, v in rec.items()},
+                     'out': {k: [np.asarray(x) for x in v] for k, v in dec.items()}}
+    save_npz(os.path.join(HERE, 'g10_batch.npz'), out)
+    print('  order %s lengths %s' % (order, lengths))
+
+
+# --------------------------------------------------------------- G11 evaluation metrics --
+def g11_metrics():
+    """The reference's evaluation metrics as values: utils.eval_ssim (utils.py:162-212) on 64 x 64 frames, and
+    SpiralsTrainer.compute_metrics (spirals.py:93-111) / WeizmannTrainer.compute_metrics (weizmann.py:116-166)
+    called unbound on a seeded evaluation forward of the reference model.  weizmann.py imports cv2 (absent here,
+    used only by its video writers): the generator registers an EMPTY module under that name before importing it --
+    second harness-side shim, nothing of compute_metrics touches it."""
+    import types
+    import argparse
+    from utils import eval_ssim as ref_ssim
+    import spirals as ref_spirals_main
+    if 'cv2' not in sys.modules:
+        sys.modules['cv2'] = types.ModuleType('cv2')
+    import weizmann as ref_weizmann_main
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    X = torch.rand(6, 3, 64, 64, generator=g)
+    Y = (X + 0.2 * torch.randn(6, 3, 64, 64, generator=g)).clamp(0, 1)
+    Y[4] = X[4]                                                   # identical images: SSIM 1
+    X1, Y1 = torch.rand(5, 1, 64, 64, generator=g), torch.rand(5, 1, 64, 64, generator=g)
+    Y1[2, 0, 5, 7] = float('nan')                                 # NaN frames (padding) stay NaN
+    out['ssim'] = {'X': X, 'Y': Y, 'out': ref_ssim(X, Y), 'X1': X1, 'Y1': Y1, 'out1': ref_ssim(X1, Y1),
+                   'Xs': X[:, :, :20, :33], 'Ys': Y[:, :, :20, :33], 'outs': ref_ssim(X[:, :, :20, :33].contiguous(),
+                                                                                         Y[:, :, :20, :33].contiguous())}
+    # Spirals
+    mods = ['spiral-x', 'spiral-y']
+    torch.manual_seed(2)
+    ref = ref_models.MultiDMM(mods, dims=(1 for _ in mods), z_dim=5, h_dim=20, device=CPU).eval()
+    lengths = [9, 7, 7, 4]
+    order = [2, 0, 3, 1]
+    targets = make_inputs([(m, 1, 'Normal') for m in mods], 9, lengths, seed=4)
+    inputs = make_inputs([(m, 1, 'Normal') for m in mods], 9, lengths, seed=4, nan_spans=[('spiral-x', 2, 5, 1)])
+    mask = ref_len_to_mask(lengths)
+    args = argparse.Namespace(device=CPU, rec_mults={m: 0.5 for m in mods})
+    RECORD.clear()
+    with torch.no_grad():
+        infer, prior, recon = ref(inputs, lengths=lengths, sample=False)
+        met = ref_spirals_main.SpiralsTrainer.compute_metrics(None, ref, infer, prior, recon, targets, mask, lengths,
+                                                              order, args)
+    out['spirals'] = {'sd': ref.state_dict(), 'infer': list(infer), 'prior': list(prior),
+                      'recon': {m: list(recon[m]) for m in mods}, 'targets': targets, 'lengths': np.array(lengths),
+                      'order': np.array(order), 'metrics': {k: np.asarray(v, dtype=np.float64) for k, v in met.items()}}
+    print('  spirals metrics', {k: np.round(np.asarray(v), 4).tolist() for k, v in met.items()})
+    # Weizmann-shaped (24 x 24 frames so that the fixture stays small; the SSIM window is the reference's 11)
+    for tag, wmods in (('weizmann', ['video', 'mask', 'action']), ('weizmann_video_only', ['video'])):
+        dims = {'video': (3, 24, 24), 'mask': (1, 24, 24), 'action': 10}
+        dists = {'video': 'Bernoulli', 'mask': 'Bernoulli', 'action': 'Categorical'}
+        torch.manual_seed(3)
+        enc = {m: FlatGaussEnc(int(np.prod(dims[m])), 6, 12) for m in wmods if m != 'action'}
+        dec = {m: ShapedBernoulliDec(6, dims[m], 12) for m in wmods if m != 'action'}
+        ref = ref_models.MultiDMM(wmods, [dims[m] for m in wmods], [dists[m] for m in wmods], encoders=enc,
+                                  decoders=dec, z_dim=6, h_dim=12, device=CPU).eval()
+        lengths = [6, 6, 4, 2, 1]
+        order = [1, 4, 0, 2, 3]
+        spec = [(m, dims[m] if m != 'action' else 10, dists[m]) for m in wmods]
+        targets = make_inputs(spec, 6, lengths, seed=8)
+        g2 = torch.Generator().manual_seed(9)
+        for m in wmods:
+            if m != 'action':
+                targets[m] = torch.where(torch.isnan(targets[m]), targets[m], torch.rand(targets[m].shape, generator=g2))
+        mask = ref_len_to_mask(lengths)
+        args = argparse.Namespace(device=CPU, rec_mults={'video': 1.0, 'mask': 1.0, 'action': 10.0})
+        with torch.no_grad():
+            infer, prior, recon = ref(targets, lengths=lengths, sample=False)
+            if 'action' in recon:       # an untrained model is never right: make every other observed label the prediction
+                targets = dict(targets)
+                lab, best = targets['action'].clone(), recon['action'][0].argmax(dim=-1, keepdim=True).float()
+                pick = (torch.arange(6).view(6, 1, 1) + torch.arange(len(lengths)).view(1, -1, 1)) % 2 == 0
+                targets['action'] = torch.where(pick & ~torch.isnan(lab), best, lab)
+            met = ref_weizmann_main.WeizmannTrainer.compute_metrics(None, ref, infer, prior, recon, targets, mask,
+                                                                    lengths, order, args)
+        out[tag] = {'infer': list(infer), 'prior': list(prior), 'recon': {m: list(recon[m]) for m in wmods},
+                    'targets': targets, 'lengths': np.array(lengths), 'order': np.array(order),
+                    'metrics': {k: np.asarray(v, dtype=np.float64) for k, v in met.items()}}
+        print('  %s metrics' % tag, {k: np.round(np.asarray(v, dtype=np.float64), 4).tolist() for k, v in met.items()})
+    save_npz(os.path.join(HERE, 'g11_metrics.npz'), out)
+
+
+# ------------------------------------------------------- G12 sample() and checkpoints --
+def g12_sample():
+    """MultiDMM.sample (dmm.py:260-317, 414-418; both directions) and MultiDKS.sample (dks.py:299-342) of the
+    reference with every eps draw recorded, checked against the oracle while generating; and two checkpoints written
+    by the reference's Trainer.save_checkpoint (trainer.py:397-399) -- tests/golden/g12_spirals.pth (Spirals DMM)
+    and g12_conv.pth (image plug-ins: every conv registered under two state_dict keys, common.py:75-86) -- with the
+    evaluation forward of the models that were saved."""
+    import trainer as ref_trainer
+    C = ref_models.common
+    out = {}
+    mods, dims = ['a', 'b'], [3, 2]
+    for direction in ('fwd', 'bwd'):
+        torch.manual_seed(1)
+        ref = ref_models.MultiDMM(mods, dims, h_dim=12, z_dim=6, device=CPU).eval()
+        o = orc.OracleDMM(mods, dims, h_dim=12, z_dim=6).eval()
+        o.load_state_dict(ref.state_dict())
+        RECORD.clear()
+        with torch.no_grad():
+            recon = ref.sample(7, 4, direction)
+            eps = list(RECORD)
+            o.noise = orc.ReplayNoise(eps)
+            orecon = o.sample(7, 4, direction)
+        for m in mods:
+            for a_, b_ in zip(orecon[m], recon[m]):
+                check('sample %s %s' % (direction, m), a_, b_, 1e-6)
+        out['dmm_' + direction] = {'sd': ref.state_dict(), 'eps': eps, 'recon': {m: list(recon[m]) for m in mods}}
+    torch.manual_seed(2)
+    ref = ref_models.MultiDKS(mods, dims, h_dim=12, z_dim=6, device=CPU).eval()
+    o = orc.OracleDKS(mods, dims, h_dim=12, z_dim=6).eval()
+    o.load_state_dict(ref.state_dict())
+    RECORD.clear()
+    with torch.no_grad():
+        recon = ref.sample(7, 4)
+        eps = list(RECORD)
+        o.noise = orc.ReplayNoise(eps)
+        orecon = o.sample(7, 4)
+    for m in mods:
+        for a_, b_ in zip(orecon[m], recon[m]):
+            check('dks sample %s' % m, a_, b_, 1e-6)
+    out['dks'] = {'sd': ref.state_dict(), 'eps': eps, 'recon': {m: list(recon[m]) for m in mods}}
+    # checkpoints in the trainer's format
+    smods = ['spiral-x', 'spiral-y']
+    torch.manual_seed(4)
+    ref = ref_models.MultiDMM(smods, dims=(1 for _ in smods), z_dim=5, h_dim=20, device=CPU).eval()
+    ref_trainer.Trainer.save_checkpoint(None, smods, ref, os.path.join(HERE, 'g12_spirals.pth'))
+    lengths = [8, 6, 3]
+    inputs = make_inputs([(m, 1, 'Normal') for m in smods], 8, lengths, seed=6, nan_spans=[('spiral-y', 1, 4, 0)])
+    with torch.no_grad():
+        infer, prior, recon = ref(inputs, lengths=lengths, sample=False)
+    out['ckpt_spirals'] = {'inputs': inputs, 'lengths': np.array(lengths), 'infer': list(infer), 'prior': list(prior),
+                           'recon': {m: list(recon[m]) for m in smods}}
+    cmods, cdims, cdists = ['video', 'action'], [(3, 64, 64), 10], ['Bernoulli', 'Categorical']
+    torch.manual_seed(5)
+    ref = ref_models.MultiDMM(cmods, cdims, cdists, encoders={'video': C.ImageEncoder(8, n_channels=3)},
+                              decoders={'video': C.ImageDecoder(8, n_channels=3)}, z_dim=8, h_dim=8, device=CPU)
+    ref.train()
+    lengths = [3, 2]
+    inputs = make_inputs([('video', (3, 64, 64), 'Bernoulli'), ('action', 10, 'Categorical')], 3, lengths, seed=7)
+    with torch.no_grad():
+        ref(inputs, lengths=lengths)                            # one training-mode forward: running statistics move
+    ref.eval()
+    ref_trainer.Trainer.save_checkpoint(None, cmods, ref, os.path.join(HERE, 'g12_conv.pth'))
+    with torch.no_grad():
+        infer, prior, recon = ref(inputs, lengths=lengths, sample=False)
+    out['ckpt_conv'] = {'inputs': inputs, 'lengths': np.array(lengths), 'infer': list(infer), 'prior': list(prior),
+                        'recon': {m: list(recon[m]) for m in cmods},
+                        'keys': np.array(sorted(ref.state_dict().keys()))}
+    save_npz(os.path.join(HERE, 'g12_sample.npz'), out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     for fn in (g1_primitives, g2_zfilter, g3_forward, g4_step, g5_dks, g6_vrnn, g7_state_dicts,
-               g8_trajectory, g9_plugins):
+               g8_trajectory, g9_plugins, g10_batch, g11_metrics, g12_sample):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)
         fn()
     for f in sorted(os.listdir(HERE)):
-        if f.endswith('.npz'):
+        if f.endswith('.npz') or f.endswith('.pth'):
             print('%-24s %8.1f KB' % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

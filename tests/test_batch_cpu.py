@@ -1,84 +1,146 @@
-"""mdmm.batch (vectorised mask / deletion ops) against a loop restatement of
-datasets/multiseq.py:405-448 with the random part fixed."""
+"""Host logic of mdmm.batch against golden G10 -- outputs of the reference's own
+datasets/multiseq.py functions (seq_collate_dict, burst_delete, rand_delete, keep_segment, del_segment with numpy's
+legacy generator seeded; tests/golden/make_golden.py::g10_batch).  What runs here without a GPU: the sort order and
+lengths of the collate, and WHICH (t, b) steps every deletion removes -- bit for bit, with the numpy draws made in
+the reference's call order.  The data passes themselves are kernels (tests/test_f_rows_gpu.py); on host tensors they
+must refuse to run."""
 import numpy as np
+import pytest
 import torch
 
-import helpers  # noqa: F401
+import helpers
 from oracle import mdmm_oracle as orc
 
-
-def _loop_delete(batch, idx_of, lengths, modalities=None):
-    """func_delete, multiseq.py:405-420."""
-    out = {}
-    for m, x in batch.items():
-        out[m] = x.clone()
-        if modalities is not None and m not in modalities:
-            continue
-        for b in range(x.shape[1]):
-            idx = idx_of(m, b, lengths[b])
-            out[m][idx, b] = float('nan')
-    return out
+G = helpers.Golden('g10_batch.npz')
+MODS = ['a', 'img', 'lab']
 
 
-def _same(a, b):
-    for m in a:
-        assert torch.equal(torch.isnan(a[m]), torch.isnan(b[m])), m
-        ok = ~torch.isnan(a[m])
-        assert torch.equal(a[m][ok], b[m][ok]), m
+def golden_items():
+    items = []
+    i = 0
+    while G.has('items/%d/length' % i):
+        it = {m: G.z['items/%d/%s' % (i, m)] for m in MODS}
+        it['length'] = int(G.z['items/%d/length' % i])
+        it['id'] = str(G.z['items/%d/id' % i])
+        items.append(it)
+        i += 1
+    return items
 
 
-def _batch():
-    g = torch.Generator().manual_seed(0)
-    lengths = [12, 12, 9, 5, 1]
-    x = {'a': torch.randn(12, 5, 3, generator=g), 'b': torch.randn(12, 5, 2, 2, generator=g)}
-    for m in x:
-        for b, n in enumerate(lengths):
-            x[m][n:, b] = float('nan')
-    return x, lengths
+def collated():
+    return {m: G.t('collate/batch/' + m) for m in MODS}, G.t('collate/lengths').tolist(), G.t('collate/order').tolist()
+
+
+def same_bits(a, b):
+    """NaN pattern and every other value identical."""
+    a, b = a.cpu(), b.cpu()
+    return a.shape == b.shape and a.dtype == b.dtype and torch.equal(torch.isnan(a), torch.isnan(b)) \
+        and torch.equal(torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0))
+
+
+def apply_steps(x, steps):
+    """(test-local) what csrc/batch_eval.hip::delete_steps_kernel does, for checking the step tables on the CPU."""
+    d = steps.reshape(steps.shape + (1,) * (x.dim() - 2))
+    return torch.where(d, torch.full_like(x, float('nan')), x)
 
 
 def test_len_to_mask():
     from mdmm import batch
     for lengths in ([6, 5, 3], [4], [7, 7]):
         assert torch.equal(batch.len_to_mask(lengths), orc.len_to_mask(lengths))
+    _, lengths, _ = collated()
+    assert torch.equal(batch.len_to_mask(lengths), G.t('collate/mask'))
+    assert torch.equal(batch.len_to_mask(lengths, time_first=False), G.t('collate_batch_first/mask'))
 
 
-def test_burst_delete_matches_loop():
+def test_collate_plan_is_the_references_stable_sort():
     from mdmm import batch
-    x, lengths = _batch()
-    rng = np.random.RandomState(1)
-    starts = {m: torch.tensor([rng.randint(n) for n in lengths]) for m in x}
-    frac = 0.3
-    ref = _loop_delete(x, lambda m, b, n: list(range(int(starts[m][b]),
-                                                     min(int(starts[m][b]) + int(frac * n), n))), lengths)
-    _same(batch.burst_delete(x, frac, lengths, t_start=starts), ref)
-    out = batch.burst_delete(x, frac, lengths, generator=torch.Generator().manual_seed(3))
-    for m in x:                      # random starts: right number of deletions, inside the sequence
-        for b, n in enumerate(lengths):
-            new = torch.isnan(out[m][:n, b]).flatten(1).any(1).sum().item()
-            assert new <= int(frac * n) and (int(frac * n) == 0 or new >= 1)
-            assert torch.isnan(out[m][n:, b]).all()
-    only_a = batch.burst_delete(x, frac, lengths, modalities=['a'], t_start=starts)
-    _same({'b': only_a['b']}, {'b': x['b']})
+    items = golden_items()
+    order, lengths = batch.collate_plan([it['length'] for it in items])
+    assert order == G.t('collate/order').tolist() and lengths == G.t('collate/lengths').tolist()
+    assert [items[i]['id'] for i in order] == [str(s) for s in G.z['collate/ids']]
+    # the collated golden really is "sequence order[b] in column b, NaN behind its end"
+    x, _, _ = collated()
+    for b, i in enumerate(order):
+        n = items[i]['length']
+        for m in MODS:
+            assert torch.equal(x[m][:n, b], torch.from_numpy(items[i][m].astype(np.float32)))
+            assert torch.isnan(x[m][n:, b]).all()
 
 
-def test_rand_delete_matches_loop():
+CASES = [   # (golden key, seed, function, fraction(s), lengths given, modalities)
+    ('burst_0.3', 11, 'burst', (0.3,), True, None),
+    ('burst_0.5_a_lab', 12, 'burst', (0.5,), True, ['a', 'lab']),
+    ('burst_0.2_nolen', 13, 'burst', (0.2,), False, None),
+    ('rand_0.4', 14, 'rand', (0.4,), True, None),
+    ('rand_0.9_img', 15, 'rand', (0.9,), True, ['img']),
+    ('keep_0.25_0.75', None, 'keep', (0.25, 0.75), True, None),
+    ('del_0.2_0.6', None, 'del', (0.2, 0.6), True, None),
+]
+
+
+def steps_for(kind, fr, lens, t_max, rng):
     from mdmm import batch
-    x, lengths = _batch()
-    g = torch.Generator().manual_seed(5)
-    scores = {m: torch.rand(12, 5, generator=g) for m in x}
-    frac = 0.4
-
-    def idx_of(m, b, n):
-        return torch.argsort(scores[m][:n, b])[:int(frac * n)].tolist()
-
-    _same(batch.rand_delete(x, frac, lengths, scores=scores), _loop_delete(x, idx_of, lengths))
+    if kind == 'burst':
+        return batch.burst_steps(lens, t_max, fr[0], rng=rng)
+    if kind == 'rand':
+        return batch.rand_steps(lens, t_max, fr[0], rng=rng)
+    return batch.segment_steps(lens, t_max, fr[0], fr[1], kind == 'keep')
 
 
-def test_segments_match_loop():
+@pytest.mark.parametrize('key,seed,kind,fr,use_len,mods', CASES)
+def test_deleted_steps_match_the_reference_bit_for_bit(key, seed, kind, fr, use_len, mods):
+    x, lengths, _ = collated()
+    t_max = x['a'].shape[0]
+    lens = lengths if use_len else [t_max] * len(lengths)
+    if seed is not None:
+        np.random.seed(seed)
+    for m in MODS:                                     # the reference's loop order (multiseq.py:411-419)
+        want = G.t('delete/%s/%s' % (key, m))
+        if mods is not None and m not in mods:
+            assert same_bits(want, x[m])
+            continue
+        got = apply_steps(x[m], steps_for(kind, fr, lens, t_max, 'numpy'))
+        assert same_bits(got, want), (key, m)
+
+
+def test_evaluation_chain_rand_then_keep():
+    x, lengths, _ = collated()
+    t_max = x['a'].shape[0]
+    np.random.seed(16)
+    for m in MODS:
+        y = apply_steps(x[m], steps_for('rand', (0.5,), lengths, t_max, 'numpy'))
+        y = apply_steps(y, steps_for('keep', (0.25, 0.75), lengths, t_max, None))
+        assert same_bits(y, G.t('delete/rand_then_keep/' + m))
+
+
+def test_torch_generator_draws_have_the_references_distribution():
     from mdmm import batch
-    x, lengths = _batch()
-    keep = _loop_delete(x, lambda m, b, n: list(range(0, int(0.25 * n))) + list(range(int(0.75 * n), n)), lengths)
-    _same(batch.keep_segment(x, 0.25, 0.75, lengths), keep)
-    dele = _loop_delete(x, lambda m, b, n: list(range(int(0.25 * n), int(0.75 * n))), lengths)
-    _same(batch.del_segment(x, 0.25, 0.75, lengths), dele)
+    lengths, t_max = [12, 12, 9, 5, 1], 12
+    g = torch.Generator().manual_seed(3)
+    s = batch.burst_steps(lengths, t_max, 0.3, generator=g)
+    r = batch.rand_steps(lengths, t_max, 0.4, generator=g)
+    for b, n in enumerate(lengths):
+        assert not s[n:, b].any() and not r[n:, b].any()
+        k = int(s[:, b].sum())
+        assert k <= int(0.3 * n) and (int(0.3 * n) == 0 or k >= 1)
+        idx = torch.nonzero(s[:, b]).flatten()
+        assert k == 0 or int(idx[-1] - idx[0]) == k - 1            # one contiguous burst
+        assert int(r[:, b].sum()) == int(0.4 * n)
+    fixed = batch.burst_steps(lengths, t_max, 0.3, t_start=[11, 0, 4, 4, 0])
+    assert torch.nonzero(fixed[:, 0]).flatten().tolist() == [11] and torch.nonzero(fixed[:, 2]).flatten().tolist() == [4, 5]
+
+
+def test_data_passes_refuse_host_tensors():
+    from mdmm import batch, metrics, native
+    x, lengths, order = collated()
+    with pytest.raises(native.MdmmError):
+        batch.burst_delete(x, 0.3, lengths, rng='numpy')
+    with pytest.raises(native.MdmmError):
+        batch.seq_collate_dict(golden_items(), device='cpu')
+    with pytest.raises(native.MdmmError):
+        batch.seq_decoll_dict({'a': x['a']}, lengths, order)
+    with pytest.raises(native.MdmmError):
+        metrics.eval_ssim(torch.rand(2, 1, 16, 16), torch.rand(2, 1, 16, 16))
+    with pytest.raises(native.MdmmError):
+        metrics.time_avg(torch.rand(3, 2), torch.ones(3, 2, 1, dtype=torch.bool), [3, 2])

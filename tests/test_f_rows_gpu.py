@@ -1,14 +1,16 @@
-"""SURVEY 8(f) rows on the GPU: on-device batch preparation (f2) against the loop restatement of
-datasets/multiseq.py:405-448, the sampling API (f4: dmm.py:414-418, dks.py:299-342) against the
-oracle, and the data-parallel harness entered through RCCL (8e) with a one-rank group."""
+"""SURVEY 8(f) rows on the GPU: on-device batch preparation (f2) bit for bit against golden G10 (outputs of the
+reference's datasets/multiseq.py functions), evaluation metrics (f3) against golden G11 (utils.eval_ssim and the
+trainers' compute_metrics), the sampling API and checkpoints (f4) against golden G12 and the oracle, and the
+data-parallel harness entered through RCCL (8e) with a one-rank group."""
 import os
 
+import numpy as np
 import pytest
 import torch
 
 import helpers  # noqa: F401
 from oracle import mdmm_oracle as orc
-from test_batch_cpu import _batch, _loop_delete, _same
+from test_batch_cpu import CASES, G, MODS, collated, golden_items, same_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -23,39 +25,214 @@ def _cpu(d):
     return {k: v.cpu() for k, v in d.items()}
 
 
-def test_batch_ops_on_device_match_loop(dev):
+# ------------------------------------------------------------------------------------------- f2: golden G10 --
+def test_collate_on_device_is_the_references_batch(dev):
     from mdmm import batch
-    x, lengths = _batch()
-    xd = {k: v.to(dev) for k, v in x.items()}
-    assert torch.equal(batch.len_to_mask(lengths, device=dev).cpu(), orc.len_to_mask(lengths))
-    g = torch.Generator().manual_seed(1)
-    starts = {m: torch.stack([torch.randint(0, n, (1,), generator=g)[0] for n in lengths]) for m in x}
-    frac = 0.3
-    ref = _loop_delete(x, lambda m, b, n: list(range(int(starts[m][b]), min(int(starts[m][b]) + int(frac * n), n))), lengths)
-    out = batch.burst_delete(xd, frac, lengths, t_start=starts)
-    assert all(v.is_cuda for v in out.values())
-    _same(_cpu(out), ref)
-    scores = {m: torch.rand(12, 5, generator=g) for m in x}
-    ref = _loop_delete(x, lambda m, b, n: torch.argsort(scores[m][:n, b])[:int(0.4 * n)].tolist(), lengths)
-    _same(_cpu(batch.rand_delete(xd, 0.4, lengths, scores=scores)), ref)
-    keep = _loop_delete(x, lambda m, b, n: list(range(0, int(0.25 * n))) + list(range(int(0.75 * n), n)), lengths)
-    _same(_cpu(batch.keep_segment(xd, 0.25, 0.75, lengths)), keep)
-    dele = _loop_delete(x, lambda m, b, n: list(range(int(0.25 * n), int(0.75 * n))), lengths)
-    _same(_cpu(batch.del_segment(xd, 0.25, 0.75, lengths)), dele)
-    # random draws on the device generator: right number of deletions, padding untouched
-    out = batch.burst_delete(xd, frac, lengths, generator=torch.Generator(device=dev).manual_seed(3))
-    for m in x:
+    items = golden_items()
+    before = [it['id'] for it in items]
+    got, mask, lengths, order, ids = batch.seq_collate_dict(items, device=dev)
+    assert [it['id'] for it in items] == before                      # the caller's list is not reordered
+    assert lengths == G.t('collate/lengths').tolist() and order == G.t('collate/order').tolist()
+    assert ids == [str(s) for s in G.z['collate/ids']]
+    assert mask.is_cuda and torch.equal(mask.cpu(), G.t('collate/mask'))
+    for m in MODS:
+        assert got[m].is_cuda and same_bits(got[m], G.t('collate/batch/' + m)), m
+    one = batch.seq_collate_dict([items[4]], device=dev)
+    for m in MODS:
+        assert same_bits(one[0][m], G.t('collate_one/batch/' + m)), m
+    bf = batch.seq_collate_dict(items, time_first=False, device=dev)
+    for m in MODS:
+        assert same_bits(bf[0][m], G.t('collate_batch_first/batch/' + m)), m
+    assert torch.equal(bf[1].cpu(), G.t('collate_batch_first/mask'))
+    # pad_and_merge alone (multiseq.py:341-353): original order, longer max_len
+    pm = batch.pad_and_merge([it['a'] for it in items], max_len=14, device=dev)
+    assert pm.shape == (14, 7, 3) and torch.isnan(pm[12:]).all()
+    for i, it in enumerate(items):
+        assert torch.equal(pm[:it['length'], i].cpu(), torch.from_numpy(it['a'])) and torch.isnan(pm[it['length']:, i]).all()
+
+
+@pytest.mark.parametrize('key,seed,kind,fr,use_len,mods', CASES)
+def test_deletions_on_device_match_the_reference_bit_for_bit(dev, key, seed, kind, fr, use_len, mods):
+    from mdmm import batch
+    x, lengths, _ = collated()
+    xd = {m: v.to(dev) for m, v in x.items()}
+    lens = lengths if use_len else None
+    if seed is not None:
+        np.random.seed(seed)
+    if kind == 'burst':
+        out = batch.burst_delete(xd, fr[0], lens, modalities=mods, rng='numpy')
+    elif kind == 'rand':
+        out = batch.rand_delete(xd, fr[0], lens, modalities=mods, rng='numpy')
+    elif kind == 'keep':
+        out = batch.keep_segment(xd, fr[0], fr[1], lens, modalities=mods)
+    else:
+        out = batch.del_segment(xd, fr[0], fr[1], lens, modalities=mods)
+    for m in MODS:
+        assert out[m].is_cuda and out[m].data_ptr() != xd[m].data_ptr()
+        assert same_bits(out[m], G.t('delete/%s/%s' % (key, m))), (key, m)
+        assert same_bits(xd[m], x[m])                                    # inputs untouched
+
+
+def test_evaluation_deletion_chain_and_device_generator(dev):
+    from mdmm import batch, models
+    x, lengths, _ = collated()
+    xd = {m: v.to(dev) for m, v in x.items()}
+    np.random.seed(16)
+    out = batch.keep_segment(batch.rand_delete(xd, 0.5, lengths, rng='numpy'), 0.25, 0.75, lengths)
+    for m in MODS:
+        assert same_bits(out[m], G.t('delete/rand_then_keep/' + m)), m
+    # draws on the device generator: right number of deletions, padding untouched
+    out = batch.burst_delete(xd, 0.3, lengths, generator=torch.Generator(device=dev).manual_seed(3))
+    for m in MODS:
         for b, n in enumerate(lengths):
             new = torch.isnan(out[m][:n, b]).flatten(1).any(1).sum().item()
-            assert new <= int(frac * n) and (int(frac * n) == 0 or new >= 1)
+            assert new <= int(0.3 * n) and (int(0.3 * n) == 0 or new >= 1)
             assert torch.isnan(out[m][n:, b]).all()
     # feeds straight into a step: the deleted batch is what the model sees
-    from mdmm import models
-    m = models.MultiDMM(['a', 'b'], [3, 4], h_dim=8, z_dim=4, device=dev)
-    flat = lambda d: {k: v.flatten(2) for k, v in d.items()}      # noqa: E731
-    loss = m.step(flat(out), batch.len_to_mask(lengths, device=dev), 1.0, {}, targets=flat(xd),
-                  lengths=lengths)
+    m = models.MultiDMM(['a', 'img'], [3, 32], h_dim=8, z_dim=4, device=dev)
+    flat = lambda d: {k: d[k].flatten(2) for k in ('a', 'img')}      # noqa: E731
+    loss = m.step(flat(out), batch.len_to_mask(lengths, device=dev), 1.0, {}, targets=flat(xd), lengths=lengths)
     assert torch.isfinite(loss)
+
+
+def test_decollate_on_device_is_the_references_lists(dev):
+    from mdmm import batch
+    _, lengths, order = collated()
+    rec = {'a': tuple(t.to(dev) for t in G.seq('decoll/in/a')), 'img': tuple(t.to(dev) for t in G.seq('decoll/in/img')),
+           'z': G.t('decoll/in/z').to(dev)}
+    got = batch.seq_decoll_dict(rec, lengths, order)
+    for k in rec:
+        want = G.seq('decoll/out/' + k)
+        assert len(got[k]) == len(want) == len(order)
+        for a_, b_ in zip(got[k], want):
+            assert isinstance(a_, np.ndarray) and a_.shape == tuple(b_.shape) and np.array_equal(a_, b_.numpy()), k
+    # batch-first form
+    got_bf = batch.seq_decoll(rec['z'].transpose(0, 1).contiguous(), lengths, order, time_first=False)
+    for a_, b_ in zip(got_bf, G.seq('decoll/out/z')):
+        assert np.array_equal(a_, b_.numpy())
+
+
+# ------------------------------------------------------------------------------------------- f3: golden G11 --
+G11 = helpers.Golden('g11_metrics.npz')
+
+
+def test_ssim_matches_the_references_eval_ssim(dev):
+    from mdmm import metrics
+    for xk, yk, ok in (('X', 'Y', 'out'), ('X1', 'Y1', 'out1'), ('Xs', 'Ys', 'outs')):
+        X, Y, want = G11.t('ssim/' + xk), G11.t('ssim/' + yk), G11.t('ssim/' + ok)
+        got = metrics.eval_ssim(X.to(dev), Y.to(dev)).cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(want)), xk
+        ok_ = ~torch.isnan(want)
+        assert float((got[ok_] - want[ok_]).abs().max()) < 2e-6, (xk, got, want)
+    assert abs(float(metrics.eval_ssim(G11.t('ssim/X').to(dev), G11.t('ssim/X').to(dev))[0]) - 1.0) < 1e-6
+    w = metrics.fspecial_gauss_1d(11, 1.5)
+    assert abs(float(w.sum()) - 1) < 1e-6 and w.shape == (11,)
+
+
+def _metric_case(tag, dev):
+    mods = sorted({k.split('/')[2] for k in G11.keys if k.startswith(tag + '/recon/')})
+    recon = {m: tuple(t.to(dev) for t in G11.seq('%s/recon/%s' % (tag, m))) for m in mods}
+    targets = {m: G11.t('%s/targets/%s' % (tag, m)).to(dev) for m in mods}
+    infer = tuple(t.to(dev) for t in G11.seq(tag + '/infer'))
+    prior = tuple(t.to(dev) for t in G11.seq(tag + '/prior'))
+    lengths, order = G11.t(tag + '/lengths').tolist(), G11.t(tag + '/order').tolist()
+    want = {k[len(tag + '/metrics/'):]: G11.z[k] for k in G11.keys if k.startswith(tag + '/metrics/')}
+    return mods, recon, targets, infer, prior, lengths, order, want
+
+
+def _check_metrics(got, want, tol=2e-5):
+    assert list(got.keys()) == list(want.keys())
+    for k, w in want.items():
+        g = np.asarray(got[k], dtype=np.float64)
+        assert g.shape == w.shape, k
+        assert np.all(np.abs(g - w) <= tol * np.maximum(1.0, np.abs(w))), (k, g, w)
+
+
+def test_spirals_metrics_match_the_reference(dev):
+    from mdmm import batch, metrics, models
+    mods, recon, targets, infer, prior, lengths, order, want = _metric_case('spirals', dev)
+    mods = ['spiral-x', 'spiral-y']
+    m = models.MultiDMM(mods, [1, 1], z_dim=5, h_dim=20, device=dev).eval()
+    mask = batch.len_to_mask(lengths, device=dev)
+    got = metrics.compute_spirals_metrics(m, infer, prior, recon, targets, mask, lengths, order, {k: 0.5 for k in mods})
+    _check_metrics(got, want)
+    assert isinstance(got['mse'], list) and isinstance(got['kld_loss'], float)
+
+
+@pytest.mark.parametrize('tag', ['weizmann', 'weizmann_video_only'])
+def test_weizmann_metrics_match_the_reference(dev, tag):
+    from mdmm import batch, metrics, models
+    mods, recon, targets, infer, prior, lengths, order, want = _metric_case(tag, dev)
+    wm = [m for m in ['video', 'mask', 'action'] if m in mods]
+    dims = {'video': (3, 24, 24), 'mask': (1, 24, 24), 'action': 10}
+    dists = {'video': 'Bernoulli', 'mask': 'Bernoulli', 'action': 'Categorical'}
+    enc = {k: helpers.FlatGaussEnc(int(np.prod(dims[k])), 6, 12) for k in wm if k != 'action'}
+    dec = {k: helpers.ShapedBernoulliDec(6, dims[k], 12) for k in wm if k != 'action'}
+    m = models.MultiDMM(wm, [dims[k] for k in wm], [dists[k] for k in wm], encoders=enc, decoders=dec, z_dim=6, h_dim=12,
+                        device=dev).eval()
+    mask = batch.len_to_mask(lengths, device=dev)
+    got = metrics.compute_weizmann_metrics(m, infer, prior, recon, targets, mask, lengths, order,
+                                           {'video': 1.0, 'mask': 1.0, 'action': 10.0})
+    _check_metrics(got, want)
+    if tag == 'weizmann':
+        assert max(got['action']) == 1.0 and min(got['action']) == 0.5      # the fixture's accuracies are not trivial
+
+
+# ------------------------------------------------------------------------------------------- f4: golden G12 --
+G12 = helpers.Golden('g12_sample.npz')
+
+
+@pytest.mark.parametrize('case', ['dmm_fwd', 'dmm_bwd', 'dks'])
+def test_sample_matches_the_references_sample(dev, case):
+    """MultiDMM.sample (dmm.py:414-418, both directions) / MultiDKS.sample (dks.py:299-342) with the reference's
+    recorded eps replayed: the reference's own outputs."""
+    from mdmm import models
+    from mdmm.noise import ReplayNoise
+    names, dims = ['a', 'b'], [3, 2]
+    cls = models.MultiDKS if case == 'dks' else models.MultiDMM
+    m = cls(names, dims, h_dim=12, z_dim=6, device=dev).eval()
+    m.load_state_dict(G12.sub(case + '/sd'))
+    m.noise = ReplayNoise(G12.seq(case + '/eps'))
+    with torch.no_grad():
+        got = m.sample(7, 4) if case == 'dks' else m.sample(7, 4, case[4:])
+    assert m.noise.exhausted
+    for k in names:
+        want = G12.seq('%s/recon/%s' % (case, k))
+        assert isinstance(got[k], tuple) and len(got[k]) == len(want)
+        for a_, b_ in zip(got[k], want):
+            assert helpers.rel_err(a_, b_) < 2e-5
+
+
+@pytest.mark.parametrize('which', ['spirals', 'conv'])
+def test_reference_checkpoint_loads_and_reproduces_its_forward(dev, which):
+    """A .pth written by the reference's Trainer.save_checkpoint (trainer.py:397-399: {'modalities', 'model'}) is
+    loaded into the product's model with load_state_dict (strict; the conv plug-ins' doubly registered keys
+    included) and the evaluation forward equals the one the reference computed before saving."""
+    from mdmm import models
+    from mdmm.models import common as C
+    ck = torch.load(os.path.join(helpers.GOLDEN_DIR, 'g12_%s.pth' % which), map_location=dev)
+    assert set(ck) == {'modalities', 'model'}
+    tag = 'ckpt_' + which
+    if which == 'spirals':
+        assert ck['modalities'] == ['spiral-x', 'spiral-y']
+        m = models.MultiDMM(ck['modalities'], dims=(1 for _ in ck['modalities']), z_dim=5, h_dim=20, device=dev)
+    else:
+        assert ck['modalities'] == ['video', 'action']
+        m = models.MultiDMM(ck['modalities'], [(3, 64, 64), 10], ['Bernoulli', 'Categorical'],
+                            encoders={'video': C.ImageEncoder(8, n_channels=3)},
+                            decoders={'video': C.ImageDecoder(8, n_channels=3)}, z_dim=8, h_dim=8, device=dev)
+        assert sorted(m.state_dict().keys()) == [str(k) for k in G12.z[tag + '/keys']]
+    m.load_state_dict(ck['model'])
+    m.eval()
+    inputs = {k: v.to(dev) for k, v in G12.sub(tag + '/inputs').items()}
+    lengths = G12.t(tag + '/lengths').tolist()
+    with torch.no_grad():
+        infer, prior, recon = m(inputs, lengths=lengths, sample=False)
+    for a_, b_ in zip(infer + prior, G12.seq(tag + '/infer') + G12.seq(tag + '/prior')):
+        assert helpers.rel_err(a_, b_) < 2e-5
+    for k in ck['modalities']:
+        for a_, b_ in zip(recon[k], G12.seq('%s/recon/%s' % (tag, k))):
+            assert helpers.rel_err(a_, b_) < 5e-5
 
 
 @pytest.mark.parametrize('direction', ['fwd', 'bwd'])

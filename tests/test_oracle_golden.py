@@ -365,3 +365,42 @@ def test_golden_z5_knife_edge_relu():
     moves = [float((grad(seed)[0] - ref).norm() / ref.norm()) for seed in range(6)]
     assert all(e < 1e-6 or 5e-4 < e < 2e-3 for e in moves), moves
     assert any(e > 5e-4 for e in moves), moves
+
+
+# --------------------------------------------------------------------------- G12 --
+@pytest.mark.parametrize('case', ['dmm_fwd', 'dmm_bwd', 'dks'])
+def test_sample_is_the_references_sample(case):
+    """oracle sample() (dmm.py:260-317, 414-418; dks.py:299-342) pinned: the reference's outputs with its eps."""
+    g = Golden('g12_sample.npz')
+    cls = orc.OracleDKS if case == 'dks' else orc.OracleDMM
+    o = cls(['a', 'b'], [3, 2], h_dim=12, z_dim=6).eval()
+    o.load_state_dict(g.sub(case + '/sd'))
+    o.noise = orc.ReplayNoise(g.seq(case + '/eps'))
+    with torch.no_grad():
+        got = o.sample(7, 4) if case == 'dks' else o.sample(7, 4, case[4:])
+    for k in ('a', 'b'):
+        for a_, b_ in zip(got[k], g.seq('%s/recon/%s' % (case, k))):
+            close(a_, b_, 1e-6)
+
+
+def test_reference_checkpoint_format_and_keys():
+    """The .pth fixtures are what trainer.py:397-399 writes; the product's CPU-constructible holders take them
+    strictly (host logic: no kernel involved), the oracle reproduces the saved model's evaluation forward."""
+    import os
+    import helpers
+    from mdmm import models
+    g = Golden('g12_sample.npz')
+    ck = torch.load(os.path.join(helpers.GOLDEN_DIR, 'g12_spirals.pth'), map_location='cpu')
+    assert set(ck) == {'modalities', 'model'} and ck['modalities'] == ['spiral-x', 'spiral-y']
+    m = models.MultiDMM(ck['modalities'], dims=(1 for _ in ck['modalities']), z_dim=5, h_dim=20, device=torch.device('cpu'))
+    m.load_state_dict(ck['model'])
+    o = orc.OracleDMM(ck['modalities'], [1, 1], h_dim=20, z_dim=5).eval()
+    o.load_state_dict(ck['model'])
+    inputs = g.sub('ckpt_spirals/inputs')
+    with torch.no_grad():
+        infer, prior, recon = o(inputs, lengths=g.t('ckpt_spirals/lengths').tolist(), sample=False)
+    for a_, b_ in zip(infer + prior, g.seq('ckpt_spirals/infer') + g.seq('ckpt_spirals/prior')):
+        close(a_, b_)
+    ck = torch.load(os.path.join(helpers.GOLDEN_DIR, 'g12_conv.pth'), map_location='cpu')
+    assert sorted(ck['model'].keys()) == [str(k) for k in g.z['ckpt_conv/keys']]
+    assert any('.conv.' in k for k in ck['model']) and any('.net.0.' in k for k in ck['model'])   # both registrations
