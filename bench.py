@@ -330,20 +330,22 @@ def cpu_baseline(cfg, device=None, seconds_budget=45.0):
     best = min(trial, key=trial.get)
     torch.set_num_threads(best)
     t0, n = time.perf_counter(), 0
-    while n < 2 and (n < 1 or time.perf_counter() - t_start < seconds_budget):
+    while n < 3 or (n < 8 and time.perf_counter() - t_start < 0.5 * seconds_budget):      # >= 3 steps at the chosen count
         one()
         n += 1
-    dt = min((time.perf_counter() - t0) / n, trial[best])
+    dt = (time.perf_counter() - t0) / n
     torch.set_num_threads(all_cores)
     ratio = ORACLE_OVER_REFERENCE_TIME.get(cfg.name)
     out = {'value': round(b_dim / dt, 3), 'unit': 'sequences/s', 'cores': best, 'kind': 'port',
            'by_threads': {str(k): round(b_dim / v, 3) for k, v in sorted(trial.items())},
            'oracle_over_reference_step_time': ratio,
-           'sample': 'single steps of the same %s step at B=%d (sequences/s is flat in B on the CPU, BASELINE.md 2; the '
-                     'full batch would take minutes per step), torch-CPU oracle; s/step by threads: %s; host has %d '
-                     'cores; best %d threads, %.2f s/step.  The oracle takes %s x the unmodified reference\'s step time '
+           'steps_timed': n,
+           'sample': '%d consecutive steps of the same %s step at B=%d at the best thread count of one trial step each '
+                     '(sequences/s is flat in B on the CPU, BASELINE.md 2; the full batch would take minutes per step), '
+                     'torch-CPU oracle; trial s/step by threads: %s; host has %d cores; best %d threads, %.2f s/step over '
+                     'the timed steps.  The oracle takes %s x the unmodified reference\'s step time '
                      '(same shapes and weights, 8 cores of the build container, tools/oracle_vs_reference_time.py)'
-                     % (cfg.name, b_dim, {k: round(v, 2) for k, v in sorted(trial.items())}, all_cores, best, dt, ratio)}
+                     % (n, cfg.name, b_dim, {k: round(v, 2) for k, v in sorted(trial.items())}, all_cores, best, dt, ratio)}
     return out, delta
 
 
@@ -399,7 +401,7 @@ def sweep_bytes(cfg, tag, b_dim):
 def load_traffic(tag, cfg, b_dim):
     """HBM bytes per launch from the PMC passes kept under profiles/ (tools/pmc_traffic.sh; counters cannot be
     collected from inside the benchmark process) -- only when the record was taken at THIS shape."""
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         path = os.path.join(REPO, 'profiles', name)
         if not os.path.exists(path):
             continue
@@ -448,11 +450,18 @@ def roofline_of(cfg, spans, b_dim, want_k1=False):
     peak = BF16_PEAK_TFLOPS if wide else F32_PEAK_TFLOPS
     nbytes = sweep_bytes(cfg, tag, b_dim)
     traffic, source = load_traffic(tag, cfg, b_dim)
+    # T_roof = max(algorithmic bytes / HBM peak, algorithmic flops / matrix peak); `bound` names the
+    # larger term and `frac` = T_roof / T_measured.  The COUNTER view (measured HBM traffic instead of the
+    # algorithmic bytes) is reported beside it as `traffic_bound`; it never decides the headline fields.
     t_mfma = flops / (peak * 1e12)
-    t_hbm = (traffic or nbytes) / (HBM_PEAK_GBS * 1e9)
+    t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
     bound = 'mfma' if t_mfma >= t_hbm else 'hbm'
     tf, gbs = flops / avg_s / 1e12, nbytes / avg_s / 1e9
     rf = {'bound': bound, 'kernel': tag}
+    if traffic:
+        t_traffic = traffic / (HBM_PEAK_GBS * 1e9)
+        rf['traffic_bound'] = {'bound': 'mfma' if t_mfma >= t_traffic else 'hbm', 'hbm_time_ms': round(t_traffic * 1e3, 4),
+                               'frac_of_launch': round(t_traffic / avg_s, 4)}
     if bound == 'mfma':
         rf.update({'achieved': round(tf, 3), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(tf / peak, 4)})
     else:
@@ -484,6 +493,42 @@ def roofline_bytes(timer, spans):
     return {'bound': 'hbm', 'kernel': tag, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'launches': n_launch,
             'launch_ms': round(tot_ms / n_launch, 4), 'algorithmic_bytes_per_launch': nbytes // n_launch}
+
+
+# Whole-step algorithmic work (SURVEY 8d "whole-step context", counted for what the step's arithmetic NEEDS, not for
+# what the reference re-executes): forward FLOPs per frame of the plug-ins (torch flop counter on the reference's
+# modules) -- every modality encoded once, decoded once per pass that scores it (multimodal pass + its own
+# unimodal pass, in both modes: 4 decodes, dgts.py:119-129) --, the sweeps' 3.31 GFLOP per sequence; backward = 2 x.
+# Bytes: inputs and targets read once (fp32 frames), the sweeps' SURVEY figure; activations between fused kernels are
+# not algorithmic.
+PLUGIN_FWD_MFLOP = {'cfg3': {'enc': 9.80 + 9.21, 'dec': 12.06 + 11.01, 'decodes': 4}}
+
+
+def roofline_step(cfg, b_dim, ms_per_step):
+    if cfg.name not in ('cfg2', 'cfg3'):
+        return None
+    p_pass = 1 + cfg.M
+    sweep_fwd = p_pass * 27 * (cfg.T - 1) * gtf_flops(cfg.D, cfg.H) * b_dim                 # P * 27 * (T - 1) * F_GTF
+    m_p = [cfg.M] + [1] * cfg.M if cfg.M > 1 else [1]
+    sweep_bytes_fwd = sum(6 * m + 14 for m in m_p) * cfg.T * cfg.D * 4 * b_dim
+    flops, nbytes = 3 * sweep_fwd, 3 * sweep_bytes_fwd
+    parts = {'sweeps_tflop': round(3 * sweep_fwd / 1e12, 3)}
+    if cfg.name in PLUGIN_FWD_MFLOP:
+        pl = PLUGIN_FWD_MFLOP[cfg.name]
+        conv_fwd = (pl['enc'] + pl['decodes'] * pl['dec']) * 1e6 * cfg.T * b_dim
+        flops += 3 * conv_fwd
+        frame_bytes = sum(int(__import__('math').prod(d)) if isinstance(d, tuple) else 1 for d in cfg.dims) * 4
+        nbytes += 2 * frame_bytes * cfg.T * b_dim                                             # inputs + targets, read once
+        parts['plugins_tflop'] = round(3 * conv_fwd / 1e12, 3)
+    peak = cfg.peak
+    t_mfma, t_hbm = flops / (peak * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
+    t_roof = max(t_mfma, t_hbm)
+    return {'bound': 'mfma' if t_mfma >= t_hbm else 'hbm', 'algorithmic_flops': flops, 'algorithmic_bytes': nbytes,
+            'roof_times_ms': {'mfma': round(t_mfma * 1e3, 4), 'hbm': round(t_hbm * 1e3, 4)},
+            'achieved_tflops': round(flops / (ms_per_step * 1e-3) / 1e12, 2), 'peak_tflops': peak,
+            'frac': round(t_roof * 1e3 / ms_per_step, 4), 'parts': parts,
+            'note': 'whole step: algorithmic flops and bytes (sweeps + plug-in conv chain, backward = 2 x forward) '
+                    'over ms_per_step; frac = T_roof / T_step'}
 
 
 GRAPH_QUEUES_ENV, GRAPH_QUEUES = 'DEBUG_HIP_FORCE_GRAPH_QUEUES', '5'
@@ -630,6 +675,7 @@ def run(cfg, args, world, rank, device, graph):
         'config': out_cfg,
         'roofline': rf,
         'roofline_k1': rf_k1,
+        'roofline_step': roofline_step(cfg, b_dim, 1e3 * elapsed / args.steps),
         # library calls by device time per step: HIP-event spans minus the calibrated cost of an empty event pair
         # per call (eager probe steps; per-KERNEL device times: profiles/*_kernel_stats.md from rocprofv3)
         'calls_ms_per_step': {t_: round(max(v[1] - v[0] * pair_ms, 0.0) / n_probe, 4) for t_, v in
@@ -692,6 +738,27 @@ def main():
             cmd[cmd.index('--master-port') + 1] = env['MASTER_PORT']
             rc = launch(env, None)
         raise SystemExit(rc)
+    default_queues = None
+    if (env_world is None and args.gpus == 1 and cfg is Cfg3 and ours and not args.no_extra
+            and os.environ.get('MDMM_BENCH_NO_DEFAULT_QUEUES_RUN') != '1'):
+        # The headline is timed with five executor queues, a DEBUG_ variable of the runtime.  The same step with the
+        # runtime's default is measured beside it -- in a child process started BEFORE this one touches the GPU (the
+        # variable is read when the runtime loads; a process that has initialised the GPU must not start another).
+        env = dict(os.environ)
+        env.pop(GRAPH_QUEUES_ENV, None)
+        env['MDMM_BENCH_DEFAULT_QUEUES'] = '1'
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', 'cfg3', '--no-cpu-baseline', '--no-extra',
+               '--steps', str(args.steps), '--warmup', str(args.warmup)] + (['--batch', str(args.batch)] if args.batch else [])
+        try:
+            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
+            r = json.loads(line)
+            default_queues = {'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'],
+                              'execution': r['config']['execution'], 'replay_matches_eager': r['config'].get('replay_matches_eager'),
+                              'note': 'the same cfg3 step with the HIP graph executor\'s default stream count (no %s), '
+                                      'separate process, measured before the headline run' % GRAPH_QUEUES_ENV}
+        except Exception as exc:        # noqa: BLE001 -- a side measurement never costs the run
+            default_queues = {'error': repr(exc)[:200]}
     world = int(env_world or '1')
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks'
@@ -722,7 +789,9 @@ def main():
             a2.steps, a2.warmup, a2.batch = 10, 3, 0
             r2 = run(Cfg2, a2, 1, 0, device, graph=True)
             out['extra'] = {'cfg2': {k: r2[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline',
-                                                        'roofline_k1')}}
+                                                        'roofline_k1', 'roofline_step')}}
+            if default_queues is not None:
+                out['extra']['cfg3_default_queues'] = default_queues
             torch.cuda.empty_cache()
             a4 = argparse.Namespace(**vars(args))
             a4.steps, a4.warmup, a4.batch = 5, 2, 0

@@ -290,10 +290,12 @@ int mdmm_nll_bernoulli_logits_bf16_bwd(const void* logits, const float* x, const
                                        void* g_logits, void* stream);
 /* `passes` parameter tensors one after the other (logits: passes x rows x inner, fp32 or bf16), each scored against the
  * same observations -- the passes of one ELBO step (dgts.py:119-129) decoded as one batch; x and the mask are read
- * once for all of them; the result is the sum of the passes' terms, g_logits has the shape of logits.  */
+ * once for all of them; the result is the sum of the passes' terms, g_logits has the shape of logits.
+ * pass_weight (optional, HOST array of `passes` <= 8 floats): a multiplier per pass on top of weight / scale -- the
+ * passes of one decoder batch may belong to loss terms of different weight (dmm.py:547-553: f_mult, s_mult).  */
 int mdmm_nll_bernoulli_logits_passes_fwd(const void* logits, int logits_bf16, int passes, const float* x,
                                          const float* seq_mask, int64_t rows, int inner, float weight,
-                                         double* out, void* stream);
+                                         const float* pass_weight, double* out, void* stream);
 /* chan_part (optional): rows are `channels` (<= 4) equal pieces (a (C, H, W) observation); every workgroup leaves the
  * sums of the gradient it stored per channel in chan_part[workgroup][4] (mdmm_nll_chan_parts() x 4 floats, zeroed by
  * the caller): their column sums are the bias gradient of the conv layer that produced the logits (autograd of
@@ -301,8 +303,8 @@ int mdmm_nll_bernoulli_logits_passes_fwd(const void* logits, int logits_bf16, in
 int mdmm_nll_chan_parts(void);
 int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logits_bf16, int passes, const float* x,
                                          const float* seq_mask, int64_t rows, int inner, float scale,
-                                         const float* scale_dev, void* g_logits, float* chan_part, int channels,
-                                         void* stream);
+                                         const float* pass_weight, const float* scale_dev, void* g_logits,
+                                         float* chan_part, int channels, void* stream);
 /* NaN -> 0 and the per-row "seen" flag of MultiDMM.encode (dmm.py:164-166) in one pass:
  * out[r][i] = isnan(x[r][i]) ? 0 : x[r][i];  seen[r] = no NaN in row r  (float 0 / 1).  */
 int mdmm_nan_to_zero(const float* x, int64_t rows, int inner, float* out, float* seen, void* stream);

@@ -165,13 +165,25 @@ struct RowWalk {
   }
 };
 
+// per-pass multipliers of the stacked-pass launches (on top of the call's weight / scale): the passes of one
+// decoder batch may belong to loss terms with different weights (dmm.py:547-553: f_mult, s_mult)
+struct PassW { float w[8]; int uniform; };
+inline PassW pass_w(const float* host, int passes) {
+  PassW p; p.uniform = 1;
+  for (int i = 0; i < 8; ++i) p.w[i] = 1.0f;
+  if (host) {
+    for (int i = 0; i < passes && i < 8; ++i) { p.w[i] = host[i]; if (host[i] != 1.0f) p.uniform = 0; }
+  }
+  return p;
+}
+
 // T = storage type of theta / g_theta (fp32, or bf16 for the logits of the bf16-activation plug-ins)
 template <bool LOGITS, typename T>
 // passes: theta holds that many parameter tensors one after the other (the passes of one ELBO step decoded as
 // one batch), each scored against the same n observations: x and the mask are read once for all of them
 __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
-    float weight, double* out, int passes) {
+    float weight, double* out, int passes, PassW pw) {
   float acc = 0.f;
   const bool vec = (inner & 3) == 0 && (n & 3) == 0;
   if (vec) {
@@ -186,18 +198,20 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ thet
       for (int ps = 0; ps < passes; ++ps) {
         const float4 th = ld4f(theta, i + ps * n4);
         float ts[4] = {th.x, th.y, th.z, th.w};
+        float a = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (xs[j] != xs[j]) continue;
           if constexpr (LOGITS && sizeof(T) == 2) {
             const float sp = softplus_fast(ts[j]);              // -log(1 - theta); -log(theta) = sp - l
-            acc += sp - xs[j] * ts[j];
+            a += sp - xs[j] * ts[j];
             continue;
           }
           if (LOGITS) ts[j] = sigmoid_ref(ts[j]);
           const float l1 = fmaxf(logf(ts[j]), -100.0f), l0 = fmaxf(log1pf(-ts[j]), -100.0f);
-          acc -= xs[j] * l1 + (1.0f - xs[j]) * l0;            // F.binary_cross_entropy
+          a -= xs[j] * l1 + (1.0f - xs[j]) * l0;              // F.binary_cross_entropy
         }
+        acc += pw.uniform ? a : pw.w[ps & 7] * a;
       }
     }
   } else {
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ thet
       for (int ps = 0; ps < passes; ++ps) {
         const float th = LOGITS ? sigmoid_ref((float)theta[i + ps * n]) : (float)theta[i + ps * n];
         const float l1 = fmaxf(logf(th), -100.0f), l0 = fmaxf(log1pf(-th), -100.0f);
-        acc -= xv * l1 + (1.0f - xv) * l0;
+        acc -= (pw.uniform ? 1.0f : pw.w[ps & 7]) * (xv * l1 + (1.0f - xv) * l0);
       }
     }
   }
@@ -243,7 +257,7 @@ __device__ __forceinline__ float nllb_grad(float t, float xv, bool on, float sca
 template <bool LOGITS, typename T>
 __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
-    float scale, const float* __restrict__ scale_dev, T* g_theta, int passes, float* chan_part, int chan4) {
+    float scale, const float* __restrict__ scale_dev, T* g_theta, int passes, float* chan_part, int chan4, PassW pw) {
   if (scale_dev) scale *= *scale_dev;
   if ((inner & 3) == 0 && (n & 3) == 0) {
     const int64_t n4 = n >> 2;
@@ -257,8 +271,9 @@ __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ thet
       float gs = 0.f;
       for (int ps = 0; ps < passes; ++ps) {
         const float4 th = ld4f(theta, i + ps * n4);
-        const float g[4] = {nllb_grad<LOGITS, T>(th.x, xv.x, on, scale), nllb_grad<LOGITS, T>(th.y, xv.y, on, scale),
-                            nllb_grad<LOGITS, T>(th.z, xv.z, on, scale), nllb_grad<LOGITS, T>(th.w, xv.w, on, scale)};
+        const float sc = pw.uniform ? scale : scale * pw.w[ps & 7];
+        const float g[4] = {nllb_grad<LOGITS, T>(th.x, xv.x, on, sc), nllb_grad<LOGITS, T>(th.y, xv.y, on, sc),
+                            nllb_grad<LOGITS, T>(th.z, xv.z, on, sc), nllb_grad<LOGITS, T>(th.w, xv.w, on, sc)};
         st4g(g_theta, i + ps * n4, g);
         if (chan_part) {                        // (of the values as stored)
           if constexpr (sizeof(T) == 2) gs += ((float)(__bf16)g[0] + (float)(__bf16)g[1]) + ((float)(__bf16)g[2] + (float)(__bf16)g[3]);
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ thet
   for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
     const bool on = !(mask && mask[i / inner] == 0.f);
     for (int ps = 0; ps < passes; ++ps)
-      g_theta[i + ps * n] = (T)nllb_grad<LOGITS, T>((float)theta[i + ps * n], x[i], on, scale);
+      g_theta[i + ps * n] = (T)nllb_grad<LOGITS, T>((float)theta[i + ps * n], x[i], on, pw.uniform ? scale : scale * pw.w[ps & 7]);
   }
 }
 
@@ -505,7 +520,7 @@ extern "C" int mdmm_nll_bernoulli_fwd(const float* theta, const float* x, const 
   if (!theta || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_fwd_kernel<false, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, theta, x,
-                     seq_mask, n, inner, weight, out, 1);
+                     seq_mask, n, inner, weight, out, 1, pass_w(nullptr, 1));
   CHECK_LAUNCH();
 }
 
@@ -515,7 +530,7 @@ extern "C" int mdmm_nll_bernoulli_logits_fwd(const float* logits, const float* x
   if (!logits || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_fwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, logits, x,
-                     seq_mask, n, inner, weight, out, 1);
+                     seq_mask, n, inner, weight, out, 1, pass_w(nullptr, 1));
   CHECK_LAUNCH();
 }
 
@@ -525,7 +540,7 @@ extern "C" int mdmm_nll_bernoulli_logits_bwd(const float* logits, const float* x
   if (!logits || !x || !g_logits || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_bwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, logits, x, seq_mask,
-                     n, inner, scale, scale_dev, g_logits, 1, nullptr, 0);
+                     n, inner, scale, scale_dev, g_logits, 1, nullptr, 0, pass_w(nullptr, 1));
   CHECK_LAUNCH();
 }
 
@@ -535,7 +550,7 @@ extern "C" int mdmm_nll_bernoulli_logits_bf16_fwd(const void* logits, const floa
   if (!logits || !x || !out || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_fwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
-                     (const __bf16*)logits, x, seq_mask, n, inner, weight, out, 1);
+                     (const __bf16*)logits, x, seq_mask, n, inner, weight, out, 1, pass_w(nullptr, 1));
   CHECK_LAUNCH();
 }
 
@@ -545,21 +560,21 @@ extern "C" int mdmm_nll_bernoulli_logits_bf16_bwd(const void* logits, const floa
   if (!logits || !x || !g_logits || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_bwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, (const __bf16*)logits,
-                     x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits, 1, nullptr, 0);
+                     x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits, 1, nullptr, 0, pass_w(nullptr, 1));
   CHECK_LAUNCH();
 }
 
 extern "C" int mdmm_nll_bernoulli_logits_passes_fwd(const void* logits, int logits_bf16, int passes, const float* x,
                                                     const float* seq_mask, int64_t rows, int inner, float weight,
-                                                    double* out, void* stream) {
-  if (!logits || !x || !out || rows < 0 || inner < 1 || passes < 1) return MDMM_E_ARG;
+                                                    const float* pass_weight, double* out, void* stream) {
+  if (!logits || !x || !out || rows < 0 || inner < 1 || passes < 1 || (pass_weight && passes > 8)) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   if (logits_bf16)
     hipLaunchKernelGGL((nllb_fwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
-                       (const __bf16*)logits, x, seq_mask, n, inner, weight, out, passes);
+                       (const __bf16*)logits, x, seq_mask, n, inner, weight, out, passes, pass_w(pass_weight, passes));
   else
     hipLaunchKernelGGL((nllb_fwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
-                       (const float*)logits, x, seq_mask, n, inner, weight, out, passes);
+                       (const float*)logits, x, seq_mask, n, inner, weight, out, passes, pass_w(pass_weight, passes));
   CHECK_LAUNCH();
 }
 
@@ -567,9 +582,9 @@ extern "C" int mdmm_nll_chan_parts(void) { return 2048; }
 
 extern "C" int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logits_bf16, int passes, const float* x,
                                                     const float* seq_mask, int64_t rows, int inner, float scale,
-                                                    const float* scale_dev, void* g_logits, float* chan_part,
-                                                    int channels, void* stream) {
-  if (!logits || !x || !g_logits || rows < 0 || inner < 1 || passes < 1) return MDMM_E_ARG;
+                                                    const float* pass_weight, const float* scale_dev, void* g_logits,
+                                                    float* chan_part, int channels, void* stream) {
+  if (!logits || !x || !g_logits || rows < 0 || inner < 1 || passes < 1 || (pass_weight && passes > 8)) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   int chan4 = 0;
   if (chan_part) {        // per-channel sums: rows of `channels` equal pieces, whole float4s, the vector path
@@ -578,10 +593,10 @@ extern "C" int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logi
   }
   if (logits_bf16)
     hipLaunchKernelGGL((nllb_bwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
-                       (const __bf16*)logits, x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits, passes, chan_part, chan4);
+                       (const __bf16*)logits, x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits, passes, chan_part, chan4, pass_w(pass_weight, passes));
   else
     hipLaunchKernelGGL((nllb_bwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
-                       (const float*)logits, x, seq_mask, n, inner, scale, scale_dev, (float*)g_logits, passes, chan_part, chan4);
+                       (const float*)logits, x, seq_mask, n, inner, scale, scale_dev, (float*)g_logits, passes, chan_part, chan4, pass_w(pass_weight, passes));
   CHECK_LAUNCH();
 }
 
@@ -591,7 +606,7 @@ extern "C" int mdmm_nll_bernoulli_bwd(const float* theta, const float* x, const 
   if (!theta || !x || !g_theta || rows < 0 || inner < 1) return MDMM_E_ARG;
   const int64_t n = rows * inner;
   hipLaunchKernelGGL((nllb_bwd_kernel<false, float>), dim3(grid_for(n)), dim3(NT), 0, STREAM, theta, x, seq_mask,
-                     n, inner, scale, scale_dev, g_theta, 1, nullptr, 0);
+                     n, inner, scale, scale_dev, g_theta, 1, nullptr, 0, pass_w(nullptr, 1));
   CHECK_LAUNCH();
 }
 

@@ -222,10 +222,13 @@ def pad_and_merge(sequences, max_len=None, device='cuda', order=None):
     if out.numel() == 0:
         return out
     flat_d = torch.from_numpy(flat).to(dev, non_blocking=True)
+    # (the index tensors stay referenced until the launch is queued: a temporary's block goes back to the caching
+    # allocator the moment its data_ptr() has been taken, and the next temporary would be handed the same bytes)
+    off_d, ord_d, len_d = _i64(offset, dev), _i32(order, dev), _i32(lengths, dev)
     with torch.cuda.device(dev):
-        native.check(native.lib().mdmm_collate_pad(flat_d.data_ptr(), _i64(offset, dev).data_ptr(),
-                                                   _i32(order, dev).data_ptr(), _i32(lengths, dev).data_ptr(),
+        native.check(native.lib().mdmm_collate_pad(flat_d.data_ptr(), off_d.data_ptr(), ord_d.data_ptr(), len_d.data_ptr(),
                                                    max_len, n, row, out.data_ptr(), _stream()), 'mdmm_collate_pad')
+    del off_d, ord_d, len_d, flat_d                       # (stream-ordered allocator: safe behind the launch)
     return out
 
 
@@ -266,11 +269,11 @@ def seq_decoll(batch, lengths, order, time_first=True):
     out = torch.empty((int(offset[-1]), len(parts), row), dtype=torch.float32, device=dev)
     if out.numel():
         ptrs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+        len_d, ord_d, off_d = _i32([min(n, T) for n in lengths], dev), _i32(order, dev), _i64(offset[:-1], dev)
         with torch.cuda.device(dev):
-            native.check(native.lib().mdmm_decollate_pack(ptrs, len(parts), T, B, row,
-                                                          _i32([min(n, T) for n in lengths], dev).data_ptr(),
-                                                          _i32(order, dev).data_ptr(), _i64(offset[:-1], dev).data_ptr(),
-                                                          out.data_ptr(), _stream()), 'mdmm_decollate_pack')
+            native.check(native.lib().mdmm_decollate_pack(ptrs, len(parts), T, B, row, len_d.data_ptr(), ord_d.data_ptr(),
+                                                          off_d.data_ptr(), out.data_ptr(), _stream()), 'mdmm_decollate_pack')
+        del len_d, ord_d, off_d
     host = out.cpu().numpy()
     shape = ((len(parts),) if type(batch) is tuple else ()) + dims
     return [host[offset[j]:offset[j + 1]].reshape((out_len[j],) + shape) for j in range(len(order))]

@@ -92,9 +92,9 @@ def time_avg(val, mask, lengths, order=None):
     T, B = val.shape
     m = mask.reshape(T, B).to(device=val.device, dtype=torch.uint8).contiguous()
     out = torch.empty(B, dtype=torch.float32, device=val.device)
-    o = _order_i(order, val.device)
+    o, ln = _order_i(order, val.device), _lengths_f(lengths, val.device)        # (referenced until the launch is queued)
     with torch.cuda.device(val.device):
-        native.check(native.lib().mdmm_time_avg(val.data_ptr(), m.data_ptr(), T, B, _lengths_f(lengths, val.device).data_ptr(),
+        native.check(native.lib().mdmm_time_avg(val.data_ptr(), m.data_ptr(), T, B, ln.data_ptr(),
                                                 None if o is None else o.data_ptr(), out.data_ptr(), _stream()), 'mdmm_time_avg')
     return out
 
@@ -105,10 +105,9 @@ def time_acc(probs, targets, lengths, order=None):
     probs, targets = _f32(probs), _f32(targets)
     T, B, n_cat = probs.shape
     out = torch.empty(B, dtype=torch.float32, device=probs.device)
-    o = _order_i(order, probs.device)
+    o, ln = _order_i(order, probs.device), _lengths_f(lengths, probs.device)
     with torch.cuda.device(probs.device):
-        native.check(native.lib().mdmm_time_acc(probs.data_ptr(), targets.data_ptr(), T, B, n_cat,
-                                                _lengths_f(lengths, probs.device).data_ptr(),
+        native.check(native.lib().mdmm_time_acc(probs.data_ptr(), targets.data_ptr(), T, B, n_cat, ln.data_ptr(),
                                                 None if o is None else o.data_ptr(), out.data_ptr(), _stream()), 'mdmm_time_acc')
     return out
 

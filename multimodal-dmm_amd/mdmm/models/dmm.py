@@ -362,40 +362,55 @@ class MultiDMM(MultiDGTS):
 
     def _passes_loss(self, passes, targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim):
         """The loss of one mode from its passes' (infer, prior, samples): see _mode_loss."""
-        infer, prior, zs = passes
+        return self._joint_loss([(passes, 1.0)], targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim)
+
+    def _joint_loss(self, terms, targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim):
+        """sum over the terms (passes, mult) -- the modes of one step, dmm.py:547-553 -- of
+        mult * sum over passes of [kld_mult * KLD + sum_m mult_m * NLL_m]  (dgts.py:119-129, 132-145).
+        Every modality is decoded ONCE for all the terms: the passes that score it (two per mode: the multimodal
+        pass and its own unimodal one) are one decoder batch -- per-pass BatchNorm statistics through
+        ops.bn_groups, updated in the reference's call order --, scored by one loss launch each way with the
+        terms' weights as per-pass multipliers.  The two modes of a step used to decode separately: twice the
+        launches of the conv chain at half the size, every decoder parameter's gradient accumulated by autograd."""
         # mask: (T,B) fp32 row mask, or the pair (row mask, row mask tiled over the passes) that
         # `step` prepares once for all its loss terms
         mask, mask_kld = mask if isinstance(mask, tuple) else (mask, mask)
         # every term adds itself, weighted, to one device accumulator (ops.LossSum)
-        total = ops.LossSum(infer[0].device)
-        ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld, *ops.weighted_into(total, kld_mult))
-        zs_all = zs
-        zs = zs.unbind(0)               # per-pass views whose backward is one stack (see _decode_for_loss)
+        total = ops.LossSum(terms[0][0][0][0].device)
+        kw, kinto = ops.weighted_into(total, kld_mult)
+        for (infer, prior, _), mult in terms:
+            ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld, kw * float(mult), kinto)
+        zs_all = [t[0][2] for t in terms]
+        zs = [z.unbind(0) for z in zs_all]      # per-pass views whose backward is one stack (see _decode_for_loss)
         for m in self.modalities:
             mult = rec_mults.get(m, 1.0)
             used = [p for p, mods in enumerate(loss_mods) if m in mods]
             if mult == 0 or not used:
                 continue
-            if self._fused_nll(m, zs_all):
+            if self._fused_nll(m, zs_all[0]):
                 # stock GaussianMLP decoder scored by nll_gauss: one launch each way, the
                 # reconstruction itself is never written (csrc/mlp.hip, NLL head)
-                if used == list(range(used[0], used[-1] + 1)):
-                    z = zs_all[used[0]:used[-1] + 1]
-                else:
-                    z = torch.stack([zs[p] for p in used])
-                ops.gauss_mlp_nll(z.reshape(-1, self.z_dim), self.dec[m], targets[m], mask,
-                                  weight=float(mult), into=total)
+                for i, (_, tmult) in enumerate(terms):
+                    if used == list(range(used[0], used[-1] + 1)):
+                        z = zs_all[i][used[0]:used[-1] + 1]
+                    else:
+                        z = torch.stack([zs[i][p] for p in used])
+                    ops.gauss_mlp_nll(z.reshape(-1, self.z_dim), self.dec[m], targets[m], mask,
+                                      weight=float(mult) * float(tmult), into=total)
                 continue
+            z_list = [zs[i][p] for i in range(len(terms)) for p in used]
+            w_list = [float(tmult) for _, tmult in terms for _ in used]
             if self._logit_decoder(m):      # sigmoid + BCE + masks in one pass each way
-                stacked = self._decode_for_loss(m, [zs[p] for p in used], logits=True, stacked=True)
+                stacked = self._decode_for_loss(m, z_list, logits=True, stacked=True) if len(z_list) <= 8 else None
                 if stacked is not None:     # the passes as one batch: scored in place, one gradient buffer
-                    ops.nll_bernoulli_logits(stacked[0], targets[m], mask, 2, float(mult), total, passes=len(used))
+                    ops.nll_bernoulli_logits(stacked[0], targets[m], mask, 2, float(mult), total, passes=len(z_list),
+                                             pass_weight=w_list)
                     continue
-                for rec in self._decode_for_loss(m, [zs[p] for p in used], logits=True):
-                    ops.nll_bernoulli_logits(rec[0], targets[m], mask, 2, float(mult), total)
+                for rec, w in zip(self._decode_for_loss(m, z_list, logits=True), w_list):
+                    ops.nll_bernoulli_logits(rec[0], targets[m], mask, 2, float(mult) * w, total)
                 continue
-            for rec in self._decode_for_loss(m, [zs[p] for p in used]):
-                self._nll(m, rec, targets[m], mask, weight=float(mult), into=total)
+            for rec, w in zip(self._decode_for_loss(m, z_list), w_list):
+                self._nll(m, rec, targets[m], mask, weight=float(mult) * w, into=total)
         return total.total()
 
     def step(self, inputs, mask, kld_mult, rec_mults, targets=None, uni_loss=True, **kwargs):
@@ -486,57 +501,33 @@ class MultiDMM(MultiDGTS):
             for x in (mu, sd, seen):
                 x.record_stream(side)
         mask_f.record_stream(side); mask_kld.record_stream(side)
-        # Experiment: the smoothing-mode term's SWEEPS in front of the filtering-mode term, its
-        # decoders and loss behind it.  Autograd issues backward nodes newest first, and a replayed graph starts
-        # its nodes roughly in the order they were captured: with the two terms one after the other the
-        # filtering-mode backward is captured -- and started -- behind the other term's whole backward, 4 ms
-        # into the backward phase, and runs alone for 6 ms behind the K-particle backward sweep.  Split, the
-        # capture order is: smoothing decoders' backward, filtering-mode backward, smoothing sweeps' backward.
-        # The Philox stream ids are handed out as in the plain order (bit-identical results).
-        noise = self._noise()
-        split = (os.environ.get('MDMM_SPLIT_S') == '1' and not noise.replay and torch.is_grad_enabled()
-                 and side is not main)
-        if split:
-            fork = torch.cuda.Event()
-            fork.record(main)
-            c0, n_f = noise.counter, (2 if f_mode in SMOOTH_MODES else 1)
-            noise.counter = c0 + n_f
-            passes_s = self._run_passes(enc, pass_mods, t_max, b_dim, s_mode, sample, sample_init,
-                                        train_particles, smt_particles)
-            c_after_s = noise.counter
-            noise.counter = c0
-            side.wait_event(fork)
-        else:
-            side.wait_stream(main)
-        def filter_loss():
-            return f_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
-                                            loss_mods, t_max, b_dim, f_mode, sample,
-                                            sample_init, kwargs.get('flt_particles', 1),
-                                            smt_particles)
-
-        with torch.cuda.stream(side):
-            if os.environ.get('MDMM_EAGER_F') == '1' and torch.is_grad_enabled():
-                # Experiment: value AND gradients of the filtering-mode term right here, on the side
-                # stream -- with respect to the encoder outputs and the parameters behind them -- so that its
-                # decoder backward and K = 1 backward sweep are issued in front of the smoothing term's forward
-                # instead of behind its whole backward (a replayed graph starts its nodes roughly in the order
-                # they were captured: the term's backward used to start 4 ms into the backward phase and ran
-                # alone for 6 ms behind the K-particle backward sweep).
-                wrt = [x for mu, sd, _ in enc.values() for x in (mu, sd) if x.requires_grad]
-                wrt += [self.z0_mean, self.z0_log_std, *self._gtf('fwd'), *self._gtf('bwd')]
-                wrt += [p for m in self.modalities for p in self.dec[m].parameters()]
-                loss_f = _EagerGradFn.apply(filter_loss, *wrt)
-            else:
-                loss_f = filter_loss()
-        if split:
-            assert noise.counter == c0 + n_f, 'stream ids of the filtering-mode term'
-            noise.counter = c_after_s
-            loss_s = s_mult * self._passes_loss(passes_s, targets, (mask_f, mask_kld), kld_mult, rec_mults, loss_mods,
-                                                t_max, b_dim)
-        else:
+        side.wait_stream(main)
+        flt_particles = kwargs.get('flt_particles', 1)
+        if os.environ.get('MDMM_JOINT_DECODE') == '0':
+            # A/B switch: the two modes as two independent loss terms, each with its own decoder calls
+            with torch.cuda.stream(side):
+                loss_f = f_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
+                                                  loss_mods, t_max, b_dim, f_mode, sample, sample_init, flt_particles,
+                                                  smt_particles)
             loss_s = s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
                                               loss_mods, t_max, b_dim, s_mode, sample,
                                               sample_init, train_particles, smt_particles)
+        else:
+            # The sweeps of the two modes side by side (the filtering mode's on the side stream), then ONE loss over
+            # both: every decoder runs once per step (_joint_loss).  Draw order as the reference's: the filtering
+            # mode's passes first.
+            with torch.cuda.stream(side):
+                passes_f = self._run_passes(enc, pass_mods, t_max, b_dim, f_mode, sample, sample_init, flt_particles,
+                                            smt_particles)
+            passes_s = self._run_passes(enc, pass_mods, t_max, b_dim, s_mode, sample, sample_init, train_particles,
+                                        smt_particles)
+            main.wait_stream(side)
+            for grp in passes_f:
+                for x in (grp if isinstance(grp, tuple) else (grp,)):
+                    x.record_stream(main)
+            loss_f = 0
+            loss_s = self._joint_loss([(passes_f, f_mult), (passes_s, s_mult)], targets, (mask_f, mask_kld), kld_mult,
+                                      rec_mults, loss_mods, t_max, b_dim)
         main.wait_stream(side)
         if match_mult > 0:
             main.wait_stream(third)

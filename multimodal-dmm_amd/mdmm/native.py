@@ -262,8 +262,8 @@ def lib():
         L.mdmm_nll_bernoulli_logits_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
         L.mdmm_nll_bernoulli_logits_bf16_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_bernoulli_logits_bf16_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
-        L.mdmm_nll_bernoulli_logits_passes_fwd.argtypes = [_P, i32, i32, _P, _P, i64, i32, f32, _P, _P]
-        L.mdmm_nll_bernoulli_logits_passes_bwd.argtypes = [_P, i32, i32, _P, _P, i64, i32, f32, _P, _P, _P, i32, _P]
+        L.mdmm_nll_bernoulli_logits_passes_fwd.argtypes = [_P, i32, i32, _P, _P, i64, i32, f32, C.POINTER(C.c_float), _P, _P]
+        L.mdmm_nll_bernoulli_logits_passes_bwd.argtypes = [_P, i32, i32, _P, _P, i64, i32, f32, C.POINTER(C.c_float), _P, _P, _P, i32, _P]
         L.mdmm_nll_chan_parts.argtypes = []
         L.mdmm_nan_to_zero.argtypes = [_P, i64, i32, _P, _P, _P]
         L.mdmm_nll_categorical_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]

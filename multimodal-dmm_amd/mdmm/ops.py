@@ -934,15 +934,20 @@ class _NllBernLogitsFn(torch.autograd.Function):
     have to stack)."""
 
     @staticmethod
-    def forward(ctx, logits, x, mask, rows, inner, weight, into, passes=1, channels=0):
+    def forward(ctx, logits, x, mask, rows, inner, weight, into, passes=1, channels=0, pass_weight=None):
         _need_gpu(logits, x)
         lg, xv = _act(logits), _f32c(x)
         if lg.numel() != passes * rows * inner:
             raise ValueError('logits of %d elements for %d passes of %d x %d' % (lg.numel(), passes, rows, inner))
         acc = _term_acc(into, lg.device)
         ctx.bf = lg.dtype == torch.bfloat16
+        ctx.pw = None
+        if pass_weight is not None and any(float(w) != 1.0 for w in pass_weight):
+            if len(pass_weight) != passes or passes > 8:
+                raise ValueError('pass_weight: one multiplier per pass, at most 8 passes')
+            ctx.pw = (C.c_float * passes)(*[float(w) for w in pass_weight])      # (host array, read at launch)
         _call('mdmm_nll_bernoulli_logits_passes_fwd', _ptr(lg), int(ctx.bf), passes, _ptr(xv), _ptr(mask), rows, inner,
-              weight, _ptr(acc), tag='mdmm_nll_bernoulli_logits_fwd')
+              weight, ctx.pw, _ptr(acc), tag='mdmm_nll_bernoulli_logits_fwd')
         ctx.save_for_backward(lg, xv)
         ctx.mask, ctx.rows, ctx.inner, ctx.weight, ctx.passes = mask, rows, inner, weight, passes
         ctx.channels = channels if (0 < channels <= 4 and inner % (4 * channels) == 0 and (rows * inner) % 4 == 0) else 0
@@ -957,11 +962,11 @@ class _NllBernLogitsFn(torch.autograd.Function):
         if ctx.channels:        # the per-channel sums of gl on the way (the producing conv layer's bias gradient)
             part = torch.zeros(native.lib().mdmm_nll_chan_parts(), 4, device=lg.device, dtype=torch.float32)
         _call('mdmm_nll_bernoulli_logits_passes_bwd', _ptr(lg), int(ctx.bf), ctx.passes, _ptr(xv), _ptr(ctx.mask),
-              ctx.rows, ctx.inner, ctx.weight, _ptr(gd), _ptr(gl), _ptr(part), ctx.channels,
+              ctx.rows, ctx.inner, ctx.weight, ctx.pw, _ptr(gd), _ptr(gl), _ptr(part), ctx.channels,
               tag='mdmm_nll_bernoulli_logits_bwd')
         if part is not None:
             _stash_chansum(gl, colsum(part)[:ctx.channels])
-        return gl, None, None, None, None, None, None, None, None
+        return gl, None, None, None, None, None, None, None, None, None
 
 
 # Per-channel sums of a gradient tensor that its producer had at hand, for the consumer that needs them as a bias
@@ -984,7 +989,7 @@ def _take_chansum(g, channels):
     return None
 
 
-def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None, passes=1, channels=0):
+def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None, passes=1, channels=0, pass_weight=None):
     """losses.py:23-42 on the pre-sigmoid activations of a decoder whose last module is nn.Sigmoid
     (common.py:163-165): sigmoid + binary cross entropy + masks in one pass each way.  passes: logits =
     that many stacked passes, each scored against x (the sum of their terms)."""
@@ -993,7 +998,7 @@ def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=Non
     if not channels and x.dim() == lead_dims + 3:       # (T, B, C, H, W) observations: C channels per row
         channels = x.shape[lead_dims]
     return _term_done(_NllBernLogitsFn.apply(logits, x, _row_mask(mask, rows, x), rows, inner,
-                                             float(weight), into, int(passes), int(channels)), into)
+                                             float(weight), into, int(passes), int(channels), pass_weight), into)
 
 
 def nan_to_zero(x, lead_dims=2):

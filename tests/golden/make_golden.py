@@ -889,10 +889,60 @@ def g12_sample():
     save_npz(os.path.join(HERE, 'g12_sample.npz'), out)
 
 
+# ------------------------------------------------------- G13 cfg1 at the BASELINE batch --
+def g13_cfg1_b25():
+    """BASELINE configs[0] as stated -- Spirals, MultiDMM BFVI, z = 5, h = 20, T = 100, batch = 25 -- one training step of
+    the reference on 25 sequences of its own Spirals data (collate, burst deletion, epoch-1 KLD multiplier as in G8):
+    batch, every eps draw (stored as float16 pairs hi + lo would not be exact: kept fp32), loss, every gradient."""
+    import shutil
+    import numpy.random as nrand
+    from datasets import multiseq as mseq
+    from datasets import spirals as ref_spirals
+    tmp = os.path.join(HERE, '_spirals_tmp')
+    shutil.rmtree(tmp, ignore_errors=True)
+    ref_spirals.gen_dataset(data_dir=tmp)
+    mods = ['spiral-x', 'spiral-y']
+    data = ref_spirals.SpiralsDataset(mods, tmp, 'train', truncate=True, item_as_dict=True)
+    B = 25
+    torch.manual_seed(0)
+    ref = ref_models.MultiDMM(mods, dims=(1 for _ in mods), z_dim=5, h_dim=20, device=CPU)
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    o = orc.OracleDMM(mods, [1, 1], h_dim=20, z_dim=5)
+    o.load_state_dict(sd0)
+    rec_mults = {m: 0.5 for m in mods}
+    n_batches = len(data) // B
+    nrand.seed(7)
+    targets, mask, lengths, order, ids = mseq.seq_collate_dict([data[i] for i in range(B)])
+    targets = {m: targets[m] for m in mods}
+    kld_mult = 1.0 * n_batches / (100 * n_batches)
+    inputs = mseq.burst_delete(targets, 0.1, lengths)
+    inputs = {m: inputs[m] for m in mods}
+    ref.train()
+    RECORD.clear()
+    loss = ref.step(inputs, mask, kld_mult, rec_mults, targets=targets, lengths=lengths)
+    (loss / sum(lengths)).backward()
+    eps = list(RECORD)
+    o.noise = orc.ReplayNoise(eps)
+    oloss = o.step(inputs, mask, kld_mult, rec_mults, targets=targets, lengths=lengths)
+    (oloss / sum(lengths)).backward()
+    check('cfg1 B=25 loss', oloss, loss, 1e-5)
+    grads = grads_of(ref)
+    og = grads_of(o)
+    for k in grads:
+        check('cfg1 B=25 grad ' + k, og[k], grads[k], 2e-3)
+    print('  B=%d T=%d loss %.5f  (%d eps draws, %.1f M floats)' % (B, max(lengths), float(loss), len(eps),
+                                                                  sum(e.numel() for e in eps) / 1e6))
+    shutil.rmtree(tmp, ignore_errors=True)
+    save_npz(os.path.join(HERE, 'g13_cfg1_b25.npz'),
+             {'sd0': sd0, 'inputs': inputs, 'targets': targets, 'lengths': np.array(lengths), 'kld_mult': np.array(kld_mult),
+              'eps': eps, 'loss': loss.detach(), 'grads': grads})
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     for fn in (g1_primitives, g2_zfilter, g3_forward, g4_step, g5_dks, g6_vrnn, g7_state_dicts,
-               g8_trajectory, g9_plugins, g10_batch, g11_metrics, g12_sample):
+               g8_trajectory, g9_plugins, g10_batch, g11_metrics, g12_sample,
+               g13_cfg1_b25):
         if only and fn.__name__ not in only:
             continue
         print(fn.__name__)

@@ -160,3 +160,53 @@ def rel_err(a, b):
     if a.numel() == 0:
         return 0.0
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def note(tag, value):
+    """Append a measured parity margin to gpurun_out/parity_measured.jsonl (GPU runs; the stated tolerances of the
+    bf16 tests are set from these records).  Never fails a test."""
+    import json
+    try:
+        d = os.path.join(REPO, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'parity_measured.jsonl'), 'a') as f:
+            f.write(json.dumps({'tag': tag, 'value': value}) + '\n')
+    except OSError:
+        pass
+
+
+# ---- stated tolerances of the bf16-operand modes (DESIGN section 2) -------------------------------------------------
+# Loss: the north star's 1e-4 relative (measured on the GPU, gpurun_out/parity_measured.jsonl -> profiles/r04_parity_
+# measured.txt: 1.4e-6 ... 8.6e-6).  Gradients: L2 relative error per parameter tensor, bounded PER TENSOR CLASS at three
+# times the largest value measured for the class in that family of tests, never looser than round 3's blanket 1e-1
+# (1.5e-1 for BatchNorm affine parameters over a few hundred frames).  The first transition layers (a ReLU behind bf16
+# operands: rounding flips gates) and the conv stacks on a handful of frames are where bf16 operands show; everything
+# else sits one to two decades lower.
+TOL_LOSS_BF16 = 1e-4
+_BF16_GRAD_TOL = {
+    # family 'mlp': stock MLP encoders / decoders (z256 step and DKS cfg4-shape tests): measured maxima
+    #   gtf_first 5.4e-2, plug_other 3.1e-2, gtf_rest 4.0e-3, other 6.3e-3
+    'mlp': {'gtf_first': 1e-1, 'plug_other': 1e-1, 'gtf_rest': 1.2e-2, 'other': 2e-2, 'bn_affine': 1e-1, 'conv': 1e-1},
+    # family 'conv': conv plug-ins with bf16-stored activations on a few frames: measured maxima
+    #   bn_affine 8.9e-2, conv 7.4e-2, gtf_first 8.5e-2, gtf_rest 3.7e-2, plug_other 6.6e-2, other 1.2e-2
+    'conv': {'gtf_first': 1e-1, 'plug_other': 1e-1, 'gtf_rest': 1e-1, 'other': 3.6e-2, 'bn_affine': 1.5e-1, 'conv': 1e-1},
+}
+
+
+def grad_class(name):
+    import re
+    if re.search(r'(z_to_gate\.0|z_nonlin\.0)', name):
+        return 'gtf_first'
+    if '.net.1.' in name:
+        return 'bn_affine'
+    if 'conv_stack' in name or 'deconv' in name:
+        return 'conv'
+    if re.search(r'(z_to_gate\.2|z_nonlin\.2|z_lin|z_to_std)', name):
+        return 'gtf_rest'
+    if name.startswith('enc.') or name.startswith('dec.'):
+        return 'plug_other'
+    return 'other'
+
+
+def bf16_grad_tol(name, family):
+    return _BF16_GRAD_TOL[family][grad_class(name)]

@@ -17,6 +17,7 @@ import pytest
 import torch
 import torch.nn as nn
 
+import helpers
 from helpers import (FlatGaussEnc, Golden, ShapedBernoulliDec, make_inputs, rel_err)
 from oracle import mdmm_oracle as orc
 
@@ -442,6 +443,28 @@ def test_step_golden(case, dev):
             assert l2 < TOL_GRAD_TIGHT, '%s %s grad rel err L2 %.3e' % (case, k, l2)
 
 
+def test_step_cfg1_at_the_baseline_batch_golden(dev):
+    """BASELINE configs[0] as stated (Spirals, z = 5, h = 20, T = 100, batch = 25): one training step of the reference
+    on 25 sequences of its own data (golden G13) -- loss and every parameter gradient."""
+    from mdmm import models
+    from mdmm.noise import ReplayNoise
+    g = Golden('g13_cfg1_b25.npz')
+    mods = ['spiral-x', 'spiral-y']
+    m = models.MultiDMM(mods, dims=(1 for _ in mods), z_dim=5, h_dim=20, device=dev)
+    m.load_state_dict(g.sub('sd0'))
+    lengths = g.t('lengths').tolist()
+    assert len(lengths) == 25 and max(lengths) == 100
+    mask = orc.len_to_mask(lengths).to(dev)
+    m.noise = ReplayNoise(g.seq('eps'))
+    loss = m.step(cuda(g.sub('inputs'), dev), mask, float(g.scalar('kld_mult')), {k: 0.5 for k in mods},
+                  targets=cuda(g.sub('targets'), dev), lengths=lengths)
+    assert m.noise.exhausted
+    close(loss, g.t('loss'), TOL_LOSS, 'cfg1 B=25 loss')
+    (loss / sum(lengths)).backward()
+    for k, p in m.named_parameters():
+        grad_close(p.grad, g.t('grads/' + k), k)
+
+
 # ----------------------------------------------------------------- trainer trajectory --
 def test_trajectory_of_the_spirals_trainer_golden(dev):
     """harness.elbo_step (gradient bucket + Adam) over the three recorded batches of the
@@ -806,6 +829,7 @@ def test_dks_cfg4_shape_matches_oracle(dev, kernel_family, path, monkeypatch):
     oloss = o.step(inputs, mask, 0.9, rec, targets=targets, lengths=lengths)
     (oloss / sum(lengths)).backward()
     bf16 = path == 'wide_bf16'
+    helpers.note('dks_cfg4[%s].loss' % path, abs(float(loss) - float(oloss)) / abs(float(oloss)))
     close(loss, oloss, TOL_LOSS_BF16 if bf16 else TOL_LOSS, 'dks cfg4 loss')
     og = dict(o.named_parameters())
     for k, p in m.named_parameters():
@@ -814,17 +838,18 @@ def test_dks_cfg4_shape_matches_oracle(dev, kernel_family, path, monkeypatch):
             continue
         if bf16:
             e = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30))
-            assert e < TOL_GRAD_BF16, 'dks cfg4 bf16 grad %s: %.3e' % (k, e)
+            helpers.note('dks_cfg4[wide_bf16].grad.' + k, e)
+            assert e < helpers.bf16_grad_tol(k, 'mlp'), 'dks cfg4 bf16 grad %s: %.3e' % (k, e)
         else:
             grad_close(p.grad, ref, k)
 
 
 # Tolerances of the bf16-operand mode of the wide sweeps (MultiDGTS.sweep_dtype = torch.bfloat16):
 # every contraction rounds its operands to 8 significand bits (accumulation, latent state, products
-# of experts and reductions stay fp32), so outputs agree with the fp32 oracle to a few 1e-3 and
-# gradients to a few 1e-2 (relu gates flipped by the operand rounding dominate the first layers).
-TOL_LOSS_BF16 = 5e-3
-TOL_GRAD_BF16 = 1e-1
+# of experts and reductions stay fp32): the ELBO agrees with the fp32 oracle to ~1e-5 relative (bound: the north
+# star's 1e-4), gradients per tensor class as stated in tests/helpers.py (relu gates flipped by the operand
+# rounding dominate the first transition layers).
+TOL_LOSS_BF16 = helpers.TOL_LOSS_BF16        # 1e-4, the north star (round 3: 5e-3; measured 1.4e-6 ... 8.6e-6)
 
 
 def _z256_step_vs_oracle(dev, T, lengths, K, sweep_dtype, nan_prob=0.0, seed=5, mods=3):
@@ -871,6 +896,8 @@ def _z256_step_vs_oracle(dev, T, lengths, K, sweep_dtype, nan_prob=0.0, seed=5, 
     oloss = o.step(inputs, mask, 1.0, rec, targets=targets, lengths=lengths, **kw)
     (oloss / sum(lengths)).backward()
     bf16 = sweep_dtype is torch.bfloat16
+    tag = 'z256[T=%d,B=%d,K=%d,%s,nan=%g]' % (T, B, K, 'bf16' if bf16 else 'f32', nan_prob)
+    helpers.note(tag + '.loss', abs(float(loss) - float(oloss)) / abs(float(oloss)))
     close(loss, oloss, TOL_LOSS_BF16 if bf16 else TOL_LOSS, 'z256 step loss')
     og = dict(o.named_parameters())
     for k, p in m.named_parameters():
@@ -879,7 +906,8 @@ def _z256_step_vs_oracle(dev, T, lengths, K, sweep_dtype, nan_prob=0.0, seed=5, 
             continue
         if bf16:
             e = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30))
-            assert e < TOL_GRAD_BF16, 'z256 bf16 grad %s: %.3e' % (k, e)
+            helpers.note(tag + '.grad.' + k, e)
+            assert e < helpers.bf16_grad_tol(k, 'mlp'), 'z256 bf16 grad %s: %.3e' % (k, e)
         else:
             grad_close(p.grad, ref, k)
 
@@ -1369,6 +1397,7 @@ def test_step_weizmann_frames_conv_bf16_matches_oracle(dev, kernel_family, act):
     o.noise = orc.ReplayNoise(draws)
     oloss = o.step(inputs, mask, 1.0, rec, targets=targets, lengths=lengths, **kw)
     (oloss / sum(lengths)).backward()
+    helpers.note('conv_bf16.loss', abs(float(loss) - float(oloss)) / abs(float(oloss)))
     close(loss, oloss, TOL_LOSS_BF16, 'weizmann-frames conv bf16 step loss')
     og = dict(o.named_parameters())
     gmax = max(float(v.grad.abs().max()) for v in og.values() if v.grad is not None)
@@ -1377,7 +1406,8 @@ def test_step_weizmann_frames_conv_bf16_matches_oracle(dev, kernel_family, act):
         if float(ref.abs().max()) < 1e-4 * gmax:      # conv biases in front of a BatchNorm: exactly zero
             continue
         e = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30))
-        assert e < TOL_GRAD_BF16, 'conv bf16 grad %s: %.3e' % (k, e)
+        helpers.note('conv_bf16.grad.' + k, e)
+        assert e < helpers.bf16_grad_tol(k, 'conv'), 'conv bf16 grad %s: %.3e' % (k, e)
 
 
 @pytest.mark.parametrize('m,k,n', [(512, 32, 32), (1000, 36, 40), (2048, 256, 4096), (4096, 4096, 256), (640, 260, 132)])

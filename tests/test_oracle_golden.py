@@ -404,3 +404,20 @@ def test_reference_checkpoint_format_and_keys():
     ck = torch.load(os.path.join(helpers.GOLDEN_DIR, 'g12_conv.pth'), map_location='cpu')
     assert sorted(ck['model'].keys()) == [str(k) for k in g.z['ckpt_conv/keys']]
     assert any('.conv.' in k for k in ck['model']) and any('.net.0.' in k for k in ck['model'])   # both registrations
+
+
+def test_cfg1_step_at_the_baseline_batch():
+    """Golden G13: BASELINE configs[0] at its stated batch of 25 (one reference training step, T = 100)."""
+    g = Golden('g13_cfg1_b25.npz')
+    mods = ['spiral-x', 'spiral-y']
+    o = orc.OracleDMM(mods, [1, 1], h_dim=20, z_dim=5)
+    o.load_state_dict(g.sub('sd0'))
+    lengths = g.t('lengths').tolist()
+    o.noise = orc.ReplayNoise(g.seq('eps'))
+    loss = o.step(g.sub('inputs'), orc.len_to_mask(lengths), float(g.scalar('kld_mult')), {k: 0.5 for k in mods},
+                  targets=g.sub('targets'), lengths=lengths)
+    assert o.noise.pos == len(o.noise.tensors)
+    close(loss, g.t('loss'), 1e-5)
+    (loss / sum(lengths)).backward()
+    for k, p in o.named_parameters():
+        assert rel_err(p.grad, g.t('grads/' + k)) < 2e-3, k

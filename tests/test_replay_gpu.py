@@ -21,7 +21,7 @@ from oracle import mdmm_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-TOL_LOSS_BF16, TOL_GRAD_BF16 = 5e-3, 1e-1        # as tests/test_hip_parity.py (operand rounding only)
+TOL_LOSS_BF16 = helpers.TOL_LOSS_BF16              # 1e-4, as tests/test_hip_parity.py; gradients: helpers.bf16_grad_tol
 TOL_REPLAY_LOSS, TOL_REPLAY_GRAD = 1e-6, 1e-5    # replay vs eager: same kernels, same inputs
 
 
@@ -46,13 +46,13 @@ def _grads(model):
     return {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
 
 
-@pytest.mark.parametrize('name', ['cfg3', 'cfg4'])
-def test_graph_replay_matches_eager_and_oracle(name, dev):
-    from mdmm import models, ops
+def _replay_vs_eager(name, lengths, dev):
+    """Capture the step at this batch, replay it three times, run the same step eagerly on the same weights and the
+    same Philox stream; asserts loss and every gradient equal (TOL_REPLAY_*).  Returns what the oracle leg needs."""
+    from mdmm import models
     from mdmm.harness import GradBucket, GraphedElboStep
     from mdmm.noise import PhiloxNoise
     cfg = bench.CONFIGS[name]
-    lengths = [40, 40, 40, 31, 17, 6]
     K, warm = bench.TRAIN_PARTICLES, 1
     n_points = sum(lengths)
     x_cpu, tg_cpu, mask_cpu, x, tg, mask = _ragged_batch(cfg, lengths, dev)
@@ -97,13 +97,39 @@ def test_graph_replay_matches_eager_and_oracle(name, dev):
     loss_e, g_e = float(loss), _grads(model)
     assert abs(loss_r - loss_e) <= TOL_REPLAY_LOSS * abs(loss_e), (loss_r, loss_e)
     gmax = max(float(v.abs().max()) for v in g_e.values() if v is not None)
+    worst = 0.0
     for k, ge in g_e.items():
         gr = g_r[k]
         assert (ge is None) == (gr is None), k
         if ge is None or float(ge.abs().max()) < 1e-6 * gmax:
             continue
         e = float((gr - ge).norm() / (ge.norm() + 1e-30))
+        worst = max(worst, e)
         assert e < TOL_REPLAY_GRAD, 'replay vs eager grad %s: %.3e' % (k, e)
+    helpers.note('replay_vs_eager[%s,B=%d]' % (name, len(lengths)), {'loss': abs(loss_r - loss_e) / abs(loss_e), 'grad': worst})
+    return dict(cfg=cfg, K=K, n_points=n_points, x_cpu=x_cpu, tg_cpu=tg_cpu, mask_cpu=mask_cpu, sd=sd, c_capture=c_capture,
+                d0=d0, loss_r=loss_r, g_r=g_r)
+
+
+@pytest.mark.parametrize('name', ['cfg3', 'cfg4'])
+def test_graph_replay_matches_eager_full_size(name, dev):
+    """The size bench.py times (B = 256, T = 40, ragged tail): replay #3 against the eager step on the same
+    Philox stream.  No oracle at this size -- it needs none: replay adds no arithmetic.  (An ordering of this
+    step that is bit-identical at 6 sequences replayed to wrong gradients at 256, DESIGN 5.4: size-dependent
+    replay bugs are what the small test cannot see.)"""
+    lengths = sorted([40] * 200 + [int(n) for n in np.random.RandomState(3).randint(5, 40, 56)], reverse=True)
+    _replay_vs_eager(name, lengths, dev)
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('name', ['cfg3', 'cfg4'])
+def test_graph_replay_matches_eager_and_oracle(name, dev):
+    from mdmm import ops
+    from mdmm.noise import PhiloxNoise
+    lengths = [40, 40, 40, 31, 17, 6]
+    r = _replay_vs_eager(name, lengths, dev)
+    cfg, K, n_points, sd, c_capture, d0 = r['cfg'], r['K'], r['n_points'], r['sd'], r['c_capture'], r['d0']
+    x_cpu, tg_cpu, mask_cpu, loss_r, g_r = r['x_cpu'], r['tg_cpu'], r['mask_cpu'], r['loss_r'], r['g_r']
 
     # ---- the oracle, with the draws of that step replayed
     o = cfg.oracle(orc) if name == 'cfg3' else _oracle_dks(cfg)
@@ -135,6 +161,7 @@ def test_graph_replay_matches_eager_and_oracle(name, dev):
     (oloss / n_points).backward()
     assert o.noise.pos == len(draws)
     rel = abs(loss_r - float(oloss)) / abs(float(oloss))
+    helpers.note('replayed_vs_oracle[%s].loss' % name, rel)
     assert rel < TOL_LOSS_BF16, 'replayed %s loss vs oracle: %.3e' % (name, rel)
     og = dict(o.named_parameters())
     omax = max(float(v.grad.abs().max()) for v in og.values() if v.grad is not None)
@@ -144,7 +171,8 @@ def test_graph_replay_matches_eager_and_oracle(name, dev):
             continue
         e = float((gr.cpu() - ref).norm() / (ref.norm() + 1e-30))
         # (the affine parameters of a BatchNorm over 240 frames: operand rounding reaches 1.2e-1 on single draws)
-        tol = 1.5 * TOL_GRAD_BF16 if '.net.1.' in k else TOL_GRAD_BF16
+        tol = helpers.bf16_grad_tol(k, 'conv')
+        helpers.note('replayed_vs_oracle[%s].grad.%s' % (name, k), e)
         assert e < tol, 'replayed %s grad %s vs oracle: %.3e' % (name, k, e)
 
 
@@ -255,6 +283,7 @@ def test_step_cfg5_plugins_matches_oracle(mode, dev):
     (oloss / n_points).backward()
     bf16 = mode == 'bf16'
     rel = abs(float(loss) - float(oloss)) / abs(float(oloss))
+    helpers.note('cfg5_plugins[%s].loss' % mode, rel)
     assert rel < (TOL_LOSS_BF16 if bf16 else 1e-5), 'cfg5 %s loss vs oracle: %.3e' % (mode, rel)
     og = dict(o.named_parameters())
     omax = max(float(v.grad.abs().max()) for v in og.values() if v.grad is not None)
@@ -263,7 +292,8 @@ def test_step_cfg5_plugins_matches_oracle(mode, dev):
         if float(ref.abs().max()) < 1e-4 * omax:      # conv biases in front of a BatchNorm: exactly zero
             continue
         e = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30))
-        assert e < (TOL_GRAD_BF16 if bf16 else 2e-3), 'cfg5 %s grad %s vs oracle: %.3e' % (mode, k, e)
+        helpers.note('cfg5_plugins[%s].grad.%s' % (mode, k), e)
+        assert e < (helpers.bf16_grad_tol(k, 'conv') if bf16 else 2e-3), 'cfg5 %s grad %s vs oracle: %.3e' % (mode, k, e)
 
 
 @pytest.mark.parametrize('kind', ['dmm', 'dks'])
