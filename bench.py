@@ -62,6 +62,10 @@ for _k in ('MIOPEN_DEBUG_CONV_GEMM', 'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD',
            'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD', 'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW'):
     os.environ.setdefault(_k, '0')
 
+# Graph replay workaround of this ROCm (mdmm/__init__.py: the runtime's graph packet capture faults replayed steps);
+# read when the runtime initialises, so set before torch touches the GPU.  An exported value wins.
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 TRAIN_PARTICLES = 25
 F32_PEAK_TFLOPS = 157.3          # MI355X dense f32 (vector = f32-input MFMA), MI355X_MICROARCH.md
 BF16_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA
@@ -575,9 +579,11 @@ def run(cfg, args, world, rank, device, graph):
                 return graphed()
             step.g_step, step.loss = graphed.g_step, graphed.loss
             c_capture = model.noise.counter - (model.noise.counter - c0) // (warm + 1)   # host stream id the capture starts at
-            execution = 'hipgraph, schedule scalars on the device'
+            execution = 'hipgraph, schedule scalars on the device, executor default queues'
             if os.environ.get(GRAPH_QUEUES_ENV):
-                execution += ' (%s executor queues)' % os.environ[GRAPH_QUEUES_ENV]
+                execution = execution.replace('executor default queues', '%s executor queues' % os.environ[GRAPH_QUEUES_ENV])
+            execution += ', DEBUG_CLR_GRAPH_PACKET_CAPTURE=%s (runtime workaround, mdmm/__init__.py)' % os.environ.get(
+                'DEBUG_CLR_GRAPH_PACKET_CAPTURE')
         except Exception as exc:        # noqa: BLE001 -- never lose the run to a capture problem
             print('bench: HIP-graph capture failed (%r); running the step eagerly' % (exc,),
                   file=sys.stderr, flush=True)
@@ -701,15 +707,11 @@ def main():
     if args.warmup is None:
         args.warmup = 2 if cfg is Cfg3 else 3
 
-    # The HIP graph executor spreads independent branches of a replayed graph over its own streams
-    # (4 by default).  With 5 the cfg3 step's two loss terms land on different ones more often:
-    # 46.3 -> 44.3 ms per step, same kernels, same loss (7 and more crash the runtime).
-    # Read by the runtime when it loads, so it is set before torch is imported; an exported value wins.
-    ours = (not args.eager and GRAPH_QUEUES_ENV not in os.environ
-            and os.environ.get('MDMM_BENCH_DEFAULT_QUEUES') != '1')
-    if ours:
-        os.environ[GRAPH_QUEUES_ENV] = GRAPH_QUEUES
-
+    # Round 2-3 asked the HIP graph executor for five streams (DEBUG_HIP_FORCE_GRAPH_QUEUES=5: 46.3 -> 44.3 ms then).  With
+    # the runtime's graph packet capture switched off (the replay workaround above) the default is as fast
+    # (30.24 vs 30.25 ms, profiles/r04k_packet_capture.txt; 6 / 8 / 12 queues: 30.14 / 30.14 / 30.16 and no crash any more),
+    # so nothing is forced; an exported value is honoured and named in config.execution.
+    ours = False
     env_world = os.environ.get('WORLD_SIZE')
     if env_world is None and args.gpus > 1:
         # start the ranks ourselves, BEFORE anything in this process touches the GPU
@@ -738,27 +740,6 @@ def main():
             cmd[cmd.index('--master-port') + 1] = env['MASTER_PORT']
             rc = launch(env, None)
         raise SystemExit(rc)
-    default_queues = None
-    if (env_world is None and args.gpus == 1 and cfg is Cfg3 and ours and not args.no_extra
-            and os.environ.get('MDMM_BENCH_NO_DEFAULT_QUEUES_RUN') != '1'):
-        # The headline is timed with five executor queues, a DEBUG_ variable of the runtime.  The same step with the
-        # runtime's default is measured beside it -- in a child process started BEFORE this one touches the GPU (the
-        # variable is read when the runtime loads; a process that has initialised the GPU must not start another).
-        env = dict(os.environ)
-        env.pop(GRAPH_QUEUES_ENV, None)
-        env['MDMM_BENCH_DEFAULT_QUEUES'] = '1'
-        cmd = [sys.executable, os.path.abspath(__file__), '--config', 'cfg3', '--no-cpu-baseline', '--no-extra',
-               '--steps', str(args.steps), '--warmup', str(args.warmup)] + (['--batch', str(args.batch)] if args.batch else [])
-        try:
-            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-            line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
-            r = json.loads(line)
-            default_queues = {'value': r['value'], 'unit': r['unit'], 'ms_per_step': r['ms_per_step'],
-                              'execution': r['config']['execution'], 'replay_matches_eager': r['config'].get('replay_matches_eager'),
-                              'note': 'the same cfg3 step with the HIP graph executor\'s default stream count (no %s), '
-                                      'separate process, measured before the headline run' % GRAPH_QUEUES_ENV}
-        except Exception as exc:        # noqa: BLE001 -- a side measurement never costs the run
-            default_queues = {'error': repr(exc)[:200]}
     world = int(env_world or '1')
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks'
@@ -790,8 +771,6 @@ def main():
             r2 = run(Cfg2, a2, 1, 0, device, graph=True)
             out['extra'] = {'cfg2': {k: r2[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline',
                                                         'roofline_k1', 'roofline_step')}}
-            if default_queues is not None:
-                out['extra']['cfg3_default_queues'] = default_queues
             torch.cuda.empty_cache()
             a4 = argparse.Namespace(**vars(args))
             a4.steps, a4.warmup, a4.batch = 5, 2, 0

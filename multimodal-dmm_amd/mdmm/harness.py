@@ -162,6 +162,12 @@ class GraphedElboStep:
                     raise RuntimeError('GraphedElboStep cannot capture a step with synchronised BatchNorm statistics '
                                        '(model.bn_sync): run harness.elbo_step eagerly, or leave bn_sync = None')
         self._replayed = None                                # event behind the last replay, on the stream it ran on
+        import mdmm
+        if (os.environ.get(mdmm.PACKET_CAPTURE_ENV, '1') != '0' or mdmm.PACKET_CAPTURE_LATE) \
+                and os.environ.get('MDMM_ALLOW_PACKET_CAPTURE') != '1':
+            raise RuntimeError('GraphedElboStep: export %s=0 before the process touches the GPU (mdmm sets it at import when '
+                               'it is imported first): with the runtime\'s graph packet capture a replayed step faults as soon '
+                               'as a copy runs between replays (tools/repro_replay_op.py)' % mdmm.PACKET_CAPTURE_ENV)
         n_points = sum(lengths) if n_points_global is None else n_points_global
         noise = model._noise()
         dev = bucket.flat.device

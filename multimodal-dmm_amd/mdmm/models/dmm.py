@@ -25,6 +25,9 @@ from .. import ops
 from . import common
 from .dgts import MultiDGTS
 
+# order in which `step` issues its two loss terms: 'fs' = filtering-mode term first (the reference's program order),
+# 'sf' = smoothing-mode term first (see step); A/B: MDMM_TERM_ORDER
+TERM_ORDER = os.environ.get('MDMM_TERM_ORDER', 'fs')
 FILTER_MODES = ('ffilter', 'bfilter')
 SMOOTH_MODES = ('fsmooth', 'bsmooth')
 
@@ -503,15 +506,40 @@ class MultiDMM(MultiDGTS):
         mask_f.record_stream(side); mask_kld.record_stream(side)
         side.wait_stream(main)
         flt_particles = kwargs.get('flt_particles', 1)
-        if os.environ.get('MDMM_JOINT_DECODE') == '0':
-            # A/B switch: the two modes as two independent loss terms, each with its own decoder calls
-            with torch.cuda.stream(side):
-                loss_f = f_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
-                                                  loss_mods, t_max, b_dim, f_mode, sample, sample_init, flt_particles,
-                                                  smt_particles)
-            loss_s = s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
-                                              loss_mods, t_max, b_dim, s_mode, sample,
-                                              sample_init, train_particles, smt_particles)
+        if os.environ.get('MDMM_JOINT_DECODE') != '1':
+            # The two modes as two independent loss terms, each with its own decoder calls, on two streams.
+            # (MDMM_JOINT_DECODE=1: one decoder batch per modality for both modes, _joint_loss -- half the launches of
+            # the conv chain, measured SLOWER: 31.1 vs 30.1 ms per cfg3 step, profiles/r04_ab_joint_decode.txt -- the
+            # filtering-mode term's decoders then no longer run next to the other term's sweeps.)
+            def term_f():
+                with torch.cuda.stream(side):
+                    return f_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
+                                                    loss_mods, t_max, b_dim, f_mode, sample, sample_init, flt_particles,
+                                                    smt_particles)
+
+            def term_s():
+                return s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
+                                                loss_mods, t_max, b_dim, s_mode, sample,
+                                                sample_init, train_particles, smt_particles)
+
+            noise = self._noise()
+            if TERM_ORDER == 'sf' and not noise.replay and side is not main:
+                # The smoothing-mode term is ISSUED first: autograd runs the newest nodes first, so the filtering-mode
+                # term's backward (decoders, K = 1 sweep) is then captured -- and started -- in front of the other
+                # term's, next to it, instead of alone behind the K-particle backward sweep that owns the chip
+                # (profiles/r03o_timeline_replay.txt: 1.5 ms of tail).  Philox stream ids are handed out as in the
+                # plain order, so the results are bit-identical to it.
+                c0, n_f = noise.counter, (2 if f_mode in SMOOTH_MODES else 1)
+                noise.counter = c0 + n_f
+                loss_s = term_s()
+                c_after = noise.counter
+                noise.counter = c0
+                loss_f = term_f()
+                assert noise.counter == c0 + n_f, 'stream ids of the filtering-mode term'
+                noise.counter = c_after
+            else:
+                loss_f = term_f()
+                loss_s = term_s()
         else:
             # The sweeps of the two modes side by side (the filtering mode's on the side stream), then ONE loss over
             # both: every decoder runs once per step (_joint_loss).  Draw order as the reference's: the filtering

@@ -1,6 +1,9 @@
 import os
 import sys
 
+# (before anything initialises the GPU: see mdmm/__init__.py)
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))

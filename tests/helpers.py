@@ -187,9 +187,11 @@ _BF16_GRAD_TOL = {
     # family 'mlp': stock MLP encoders / decoders (z256 step and DKS cfg4-shape tests): measured maxima
     #   gtf_first 5.4e-2, plug_other 3.1e-2, gtf_rest 4.0e-3, other 6.3e-3
     'mlp': {'gtf_first': 1e-1, 'plug_other': 1e-1, 'gtf_rest': 1.2e-2, 'other': 2e-2, 'bn_affine': 1e-1, 'conv': 1e-1},
-    # family 'conv': conv plug-ins with bf16-stored activations on a few frames: measured maxima
-    #   bn_affine 8.9e-2, conv 7.4e-2, gtf_first 8.5e-2, gtf_rest 3.7e-2, plug_other 6.6e-2, other 1.2e-2
-    'conv': {'gtf_first': 1e-1, 'plug_other': 1e-1, 'gtf_rest': 1e-1, 'other': 3.6e-2, 'bn_affine': 1.5e-1, 'conv': 1e-1},
+    # family 'conv': conv plug-ins with bf16-stored activations on a few frames (6 sequences): measured maxima
+    #   bn_affine 1.2e-1, conv 9.1e-2, gtf_first 8.5e-2, gtf_rest 3.7e-2, plug_other 7.8e-2, other 6.0e-2 (the DKS
+    #   recurrences' input weights, which read the conv features) -- three times any of them is past round 3's bounds,
+    #   which therefore stay
+    'conv': {'gtf_first': 1e-1, 'plug_other': 1e-1, 'gtf_rest': 1e-1, 'other': 1e-1, 'bn_affine': 1.5e-1, 'conv': 1e-1},
 }
 
 
