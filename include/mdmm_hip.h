@@ -204,6 +204,18 @@ typedef struct mdmm_sweep {
    * not keep; backward: regenerate from seed / offset, as ever).  Same pointer for both calls of one sweep.  */
   void* noise_park;
   int64_t noise_park_bytes;
+  /* Optional: the masked KL term of the sweep's own (infer, prior) -- losses.py:14-21 through dgts.py:147-152,
+   * 1/2 sum_{p,t,b,d} mask[t][b] (2 ln s_pr - 2 ln s_inf + (s_inf^2 + (m_inf - m_pr)^2) / s_pr^2 - 1) -- inside
+   * the sweep that produces / consumes those four tensors, for the shapes mdmm_sweep_kld_fused() accepts (K = 1 on
+   * the wide family).  Forward: kld_out += kld_weight * KLD (one fp64 atomic per workgroup).  Backward: the term's
+   * adjoints (Appendix B of SURVEY.md) times kld_weight * *kld_scale_dev join the upstream gradients of
+   * (infer, prior) in the fusion adjoint, so neither four (P,T,B,D) gradient tensors nor the launches that wrote
+   * and read them exist.  kld_out == NULL (forward) / kld_scale_dev == NULL (backward) = not fused.  */
+  const float* kld_mask;        /* (T*B) 0 / 1, NULL = all ones */
+  double* kld_out;
+  const float* kld_scale_dev;
+  float kld_weight;
+  int32_t reserved2;
 } mdmm_sweep_t;
 
 int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream);
@@ -215,6 +227,8 @@ int mdmm_sweep_bwd_mode(const mdmm_sweep_t* args);
 int mdmm_sweep_dw_width(int D, int H);
 /* != 0 if this sweep (sizes, K, gtf_frag) runs on the wide family */
 int mdmm_sweep_wide(const mdmm_sweep_t* args);
+/* != 0 if the forward AND the backward sweep of this shape take the fused KL term (kld_* fields) */
+int mdmm_sweep_kld_fused(const mdmm_sweep_t* args);
 int64_t mdmm_sweep_wide_ws_bytes(const mdmm_sweep_t* args);
 int64_t mdmm_sweep_noise_park_bytes(const mdmm_sweep_t* args);
 int64_t mdmm_sweep_dw_rows(const mdmm_sweep_t* args);

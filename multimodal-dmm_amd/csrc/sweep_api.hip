@@ -12,9 +12,15 @@ static bool force_generic() {
   return v && v[0] == '1';
 }
 
+// the fused KL term exists in the wide K = 1 kernels only: any other route would drop it silently
+static bool kld_lost(const mdmm_sweep_t* a) {
+  return (a->kld_out || a->kld_scale_dev) && (force_generic() || !mdmm_sweep_kld_fused(a));
+}
+
 extern "C" int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream) {
   int rc = mdmm_sweep_check_args(args, 0);
   if (rc) return rc;
+  if (kld_lost(args)) return MDMM_E_ARG;
   if (!force_generic()) {
     if (args->trans_only && args->gtf_frag) {
       rc = mdmm_wide_trans(args, 0, (hipStream_t)stream);
@@ -31,6 +37,7 @@ extern "C" int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream) {
 extern "C" int mdmm_bfvi_sweep_bwd(const mdmm_sweep_t* args, void* stream) {
   int rc = mdmm_sweep_check_args(args, 1);
   if (rc) return rc;
+  if (kld_lost(args)) return MDMM_E_ARG;
   if (!force_generic()) {
     if (args->trans_only && args->gtf_frag) {
       rc = mdmm_wide_trans(args, 1, (hipStream_t)stream);

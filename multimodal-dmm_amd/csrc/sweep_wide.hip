@@ -78,6 +78,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
   ring_fill(ring, W(L_W1G));
   __syncthreads();
 
+  [[maybe_unused]] float kl_acc = 0.f;      // fused KL term (K = 1): this lane's sum over its (row, step) elements
   const lds_tab_t tab0 = tab;
   const lds_row_t rowbase0 = rowbase;
   for (int i = 0; i < T; ++i) {
@@ -201,6 +202,8 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           float* const o_im = a.infer_mean; float* const o_is = a.infer_std;
           float* const o_pm = a.prior_mean; float* const o_ps = a.prior_std;
           float* const o_smp = a.samples;
+          const float* const kl_mask = a.kld_mask;
+          const bool kl_on = a.kld_out != nullptr;
           const lds_tab_t tabl = tab;
           PairRef prs4[4];
           ExpertVals ev[4];
@@ -230,6 +233,11 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
               const size_t o = (((size_t)pr.p * T + t) * B + pr.b) * WD + n;
               o_im[o] = im; o_is[o] = is;
               o_pm[o] = pm; o_ps[o] = ps;
+              if (kl_on) {       // losses.py:14-21 on the values just stored
+                const float ip = fast::rcp(ps), d = (im - pm) * ip, r_ = is * ip;
+                const float term = 2.0f * (fast::log(ps) - fast::log(is)) + fmaf(r_, r_, d * d) - 1.0f;
+                kl_acc += (kl_mask ? kl_mask[tb] : 1.0f) * term;
+              }
               zz = sampled ? fmaf(e[j], is, im) : im;
               if (o_smp) o_smp[o] = zz;
             }
@@ -358,6 +366,20 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       store_image<F32, RT>(imgZ, z, wave, lane);
       __syncthreads();
       STAMP(15);
+    }
+  }
+  if constexpr (K1) {
+    if (a.kld_out) {                 // one fp64 atomic per workgroup (as csrc/reduce.hip's kld kernel)
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);
+      const float w = wave_sum(kl_acc);
+      if (lane == 0) red[wave] = w;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < NWAVE; ++k) t += (double)red[k];
+        atomicAdd(a.kld_out, 0.5 * (double)a.kld_weight * t);
+      }
     }
   }
 }
@@ -1128,6 +1150,7 @@ int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
 int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   WideGeo g;
   const int RT = plan(a, false, &g);
+  if (a && (a->kld_out || a->kld_scale_dev) && !mdmm_sweep_kld_fused(a)) return MDMM_E_ARG;   // (never dropped silently)
   if (!RT) return mdmm_wide_sweep_fwd_long(a, stream);      // more particles than the row tiles hold
   if (((uintptr_t)a->gtf_frag) & 15) return MDMM_E_ALIGN;
   const bool f32 = a->precision == MDMM_PREC_F32;
@@ -1145,6 +1168,7 @@ int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
 }
 
 int mdmm_wide_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
+  if (a && (a->kld_out || a->kld_scale_dev) && !mdmm_sweep_kld_fused(a)) return MDMM_E_ARG;
   if (mdmm_wide_bwd4_supported(a)) return mdmm_wide_sweep_bwd4(a, stream);     // K <= 25, bf16: one round
   WideGeo g;
   const int RT = plan(a, true, &g);
@@ -1188,6 +1212,11 @@ int wide::wide_wgrad_launch(const WideWs& ws, bool f32, int CH, float* dw_partia
 int mdmm_wide_bwd_supported(const mdmm_sweep_t* a) {
   WideGeo g;
   return plan(a, true, &g) != 0;
+}
+
+extern "C" int mdmm_sweep_kld_fused(const mdmm_sweep_t* a) {
+  WideGeo g;
+  return a && a->K == 1 && !a->trans_only && plan(a, false, &g) != 0 && plan(a, true, &g) != 0;
 }
 
 extern "C" int mdmm_sweep_wide(const mdmm_sweep_t* a) {

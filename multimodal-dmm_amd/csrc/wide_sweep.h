@@ -189,12 +189,16 @@ struct FuseArgs {
   int n_exp, T, B;
   bool inv_prior;
   ExpDesc ed[EXB];
+  const float* kld_mask;      // fused KL term (mdmm_sweep_t.kld_*): row mask and weight * upstream gradient (0 = off)
+  float kld_w;
 };
 template <class A, class E>
 __device__ __forceinline__ void fuse_args(const A& a, const E* exs, FuseArgs& z) {
   z.gsmp = a.g_samples; z.gim = a.g_infer_mean; z.gis = a.g_infer_std;
   z.prm = a.prior_mean; z.prs = a.prior_std; z.gpm = a.g_prior_mean; z.gps = a.g_prior_std;
   z.n_exp = a.E; z.T = a.T; z.B = a.B; z.inv_prior = a.use_inv_prior;
+  z.kld_mask = a.kld_mask;
+  z.kld_w = a.kld_scale_dev ? a.kld_weight * *a.kld_scale_dev : 0.f;
 #pragma unroll
   for (int e = 0; e < EXB; ++e) {
     const bool on = e < z.n_exp;
@@ -267,11 +271,22 @@ __device__ __forceinline__ FuseAdj fuse_bwd_math(const FuseArgs& z, const E* exs
   }
   if (z.inv_prior) q.add(mu0, -sg0, 1.0f);
   const float rp = fast::rcp(q.prec), is = fast::sqrt(rp);
+  float kl_pm = 0.f, kl_ps = 0.f;
+  if (z.kld_w != 0.f) {
+    // the fused KL term's adjoints join the upstream gradients of (infer, prior)
+    const float w = z.kld_w * (z.kld_mask ? z.kld_mask[tb] : 1.0f);
+    const float mraw = q.num * rp, im = (mraw != mraw) ? 0.f : mraw;
+    const float ip = fast::rcp(prs), ip2 = ip * ip, d = im - prm;
+    g_im = fmaf(w * d, ip2, g_im);
+    g_is = fmaf(w, is * ip2 - fast::rcp(is), g_is);
+    kl_pm = -w * d * ip2;
+    kl_ps = w * (ip - fmaf(is, is, d * d) * ip2 * ip);
+  }
   float g_num, g_prec, gm, gs;
   poe_out_bwd_f(q.num, rp, is, g_im, g_is, g_num, g_prec);
   poe_expert_bwd_f(prm, prs, 1.0f, g_num, g_prec, gm, gs);
-  r.gpm = gm + f.l_gpm;
-  r.gps = gs + f.l_gps;
+  r.gpm = gm + f.l_gpm + kl_pm;
+  r.gps = gs + f.l_gps + kl_ps;
   r.prm = prm; r.prs = prs;
 #pragma unroll
   for (int e = 0; e < EXB; ++e)

@@ -225,7 +225,7 @@ class MultiDMM(MultiDGTS):
         return eps.to(self.z0_mean.device)
 
     def _sweep(self, experts, t_max, b_dim, n_pass, direction, sample, n_particles,
-               sample_init, use_inv_prior, need_samples, draws=None):
+               sample_init, use_inv_prior, need_samples, draws=None, kld=None):
         reverse = direction == 'bwd'
         kw = dict(T=t_max, B=b_dim, D=self.z_dim, H=self.h_dim, P=n_pass, K=n_particles,
                   reverse=reverse, sample=sample, sample_init=sample_init,
@@ -234,8 +234,10 @@ class MultiDMM(MultiDGTS):
         eps = self._eps_or_stream(kw, t_max, b_dim, n_pass, n_particles, sample, sample_init,
                                   reverse, draws)
         cfg = ops.SweepCfg(**kw)
+        if kld is not None:         # (mask, weight, LossSum, [did the sweep take it?])
+            kld[3] = ops.sweep_kld_fused(cfg)
         return ops.bfvi_sweep(cfg, self._gtf(direction), self.z0_mean, self.z0_log_std, experts,
-                              eps)
+                              eps, kld=tuple(kld[:3]) if kld is not None and kld[3] else None)
 
     def z_filter(self, z_mean, z_std, z_masks, direction='fwd', sample=True, n_particles=1,
                  sample_init=False):
@@ -251,7 +253,7 @@ class MultiDMM(MultiDGTS):
         return (im[0], is_[0]), (pm[0], ps[0]), zs[0]
 
     def _run_passes(self, enc, pass_mods, t_max, b_dim, mode, sample, sample_init,
-                    flt_particles, smt_particles):
+                    flt_particles, smt_particles, kld=None):
         """All passes of one mode in one (filter) or two (filter + smoother) launches.
 
         enc: {m: (mean, std, seen)}; pass_mods: per pass, the modalities it conditions on.
@@ -277,8 +279,11 @@ class MultiDMM(MultiDGTS):
                 if smoothing:
                     s_draws.append(self.noise.take(
                         _n_draws(t_max, sample, smt_particles, sample_init)))
+        # kld: [row mask, weight, LossSum, taken?] -- the sweep whose (infer, prior) the mode returns may form the
+        # KL term itself (ops.sweep_kld_fused); kld[3] tells the caller whether it did
         im, is_, pm, ps, zs = self._sweep(obs, t_max, b_dim, n_pass, flt_dir, sample,
-                                          flt_particles, flt_init, False, not smoothing, f_draws)
+                                          flt_particles, flt_init, False, not smoothing, f_draws,
+                                          kld=None if smoothing else kld)
         if smoothing:
             smt_dir = 'fwd' if mode == 'fsmooth' else 'bwd'
             flt_mask = torch.ones(t_max, b_dim, device=pm.device, dtype=torch.float32)
@@ -286,7 +291,7 @@ class MultiDMM(MultiDGTS):
             all_bits = (1 << n_pass) - 1
             experts = obs + [ops.ExpertSpec(pm, ps, flt_mask, all_bits, True)]   # dmm.py:479-485
             im, is_, pm, ps, zs = self._sweep(experts, t_max, b_dim, n_pass, smt_dir, sample,
-                                              smt_particles, sample_init, True, True, s_draws)
+                                              smt_particles, sample_init, True, True, s_draws, kld=kld)
         return (im, is_), (pm, ps), zs
 
     @staticmethod
@@ -359,15 +364,21 @@ class MultiDMM(MultiDGTS):
     def _mode_loss(self, enc, targets, mask, kld_mult, rec_mults, pass_mods, loss_mods, t_max,
                    b_dim, mode, sample, sample_init, flt_particles, smt_particles):
         """sum over passes of [kld_mult*KLD + sum_m mult_m*NLL_m]  (dgts.py:119-129, 132-145)"""
+        total = ops.LossSum(self.z0_mean.device)
+        kw, kinto = ops.weighted_into(total, kld_mult)
+        row_mask = mask[0] if isinstance(mask, tuple) else mask
+        kld = [row_mask, kw, kinto, False]
         passes = self._run_passes(enc, pass_mods, t_max, b_dim, mode, sample,
-                                  sample_init, flt_particles, smt_particles)
-        return self._passes_loss(passes, targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim)
+                                  sample_init, flt_particles, smt_particles, kld=kld)
+        return self._joint_loss([(passes, 1.0)], targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim,
+                                total=total, kld_into=(kw, kinto), kld_done=kld[3])
 
     def _passes_loss(self, passes, targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim):
         """The loss of one mode from its passes' (infer, prior, samples): see _mode_loss."""
         return self._joint_loss([(passes, 1.0)], targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim)
 
-    def _joint_loss(self, terms, targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim):
+    def _joint_loss(self, terms, targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim, total=None,
+                    kld_into=None, kld_done=False):
         """sum over the terms (passes, mult) -- the modes of one step, dmm.py:547-553 -- of
         mult * sum over passes of [kld_mult * KLD + sum_m mult_m * NLL_m]  (dgts.py:119-129, 132-145).
         Every modality is decoded ONCE for all the terms: the passes that score it (two per mode: the multimodal
@@ -379,10 +390,14 @@ class MultiDMM(MultiDGTS):
         # `step` prepares once for all its loss terms
         mask, mask_kld = mask if isinstance(mask, tuple) else (mask, mask)
         # every term adds itself, weighted, to one device accumulator (ops.LossSum)
-        total = ops.LossSum(terms[0][0][0][0].device)
-        kw, kinto = ops.weighted_into(total, kld_mult)
-        for (infer, prior, _), mult in terms:
-            ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld, kw * float(mult), kinto)
+        # total / kld_into: the sum (and its KLD sub-sum) the caller made before the sweeps ran; kld_done: the sweeps
+        # have already added the KL terms to it (ops.sweep_kld_fused)
+        if total is None:
+            total = ops.LossSum(terms[0][0][0][0].device)
+        kw, kinto = kld_into if kld_into is not None else ops.weighted_into(total, kld_mult)
+        if not kld_done:
+            for (infer, prior, _), mult in terms:
+                ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld, kw * float(mult), kinto)
         zs_all = [t[0][2] for t in terms]
         zs = [z.unbind(0) for z in zs_all]      # per-pass views whose backward is one stack (see _decode_for_loss)
         for m in self.modalities:

@@ -378,6 +378,9 @@ class SweepCfg:
         if precision not in PRECISIONS:
             raise ValueError('sweep precision %r: use torch.float32 or torch.bfloat16' % (precision,))
         self.precision = precision          # operand type of the wide family's contractions
+        # fused KL term of the sweep's own (infer, prior) (mdmm_sweep_t.kld_*): (row mask (T*B) fp32 or None,
+        # weight, LossSum) set by bfvi_sweep(kld=...) where sweep_kld_fused(cfg) holds
+        self.kld = None
 
 
 def _sweep_tag(which, cfg):
@@ -461,6 +464,11 @@ class _SweepFn(torch.autograd.Function):
         s.infer_mean, s.infer_std, s.prior_mean, s.prior_std = [_ptr(o) for o in out]
         s.samples = _ptr(smp)
         ctx.noise_park = None
+        kh = None
+        if cfg.kld is not None:
+            k_mask, k_weight, k_into = cfg.kld
+            s.kld_mask, s.kld_weight, s.kld_out = _ptr(k_mask), float(k_weight), _ptr(k_into.acc)
+            kh = torch.empty((), dtype=torch.float32, device=dev)       # ties the term into LossSum.total()'s graph
         if wide:
             s.gtf_frag, s.precision = _ptr(frag.buf), frag.precision
             if not native.lib().mdmm_sweep_wide(C.byref(s)):
@@ -484,10 +492,13 @@ class _SweepFn(torch.autograd.Function):
         if smp is None:
             smp = out[0].new_empty(0)
             ctx.mark_non_differentiable(smp)
-        return out[0], out[1], out[2], out[3], smp
+        if kh is None:
+            kh = out[0].new_empty(0)
+            ctx.mark_non_differentiable(kh)
+        return out[0], out[1], out[2], out[3], smp, kh
 
     @staticmethod
-    def backward(ctx, g_im, g_is, g_pm, g_ps, g_smp):
+    def backward(ctx, g_im, g_is, g_pm, g_ps, g_smp, g_kh=None):
         cfg, n_exp, packed = ctx.cfg, ctx.n_exp, ctx.packed
         saved = ctx.saved_tensors
         z0m, z0s, im, is_, pm, ps = saved[:6]
@@ -521,6 +532,10 @@ class _SweepFn(torch.autograd.Function):
         L = native.lib()
         gz0 = torch.zeros(2, cfg.D, device=dev, dtype=torch.float32)
         s.g_z0_mean, s.g_z0_sigma = gz0[0].data_ptr(), gz0[1].data_ptr()
+        g_kd = None
+        if cfg.kld is not None and g_kh is not None:    # the fused KL term: its adjoints are formed inside the sweep
+            g_kd = _gdev(g_kh)
+            s.kld_mask, s.kld_weight, s.kld_scale_dev = _ptr(cfg.kld[0]), float(cfg.kld[1]), _ptr(g_kd)
         G = X = part = None
         if ctx.frag is not None:                        # wide family: spills + own contraction
             s.gtf_frag, s.precision = _ptr(ctx.frag.buf), ctx.frag.precision
@@ -562,17 +577,35 @@ class _SweepFn(torch.autograd.Function):
         return (None, None, None, None, None, g_z0_mean, g_z0_log, *g_gtf, *g_flat)
 
 
-def bfvi_sweep(cfg, gtf_params, z0_mean, z0_log_std, experts, eps=None):
+def sweep_kld_fused(cfg):
+    """True where the sweep kernels themselves form the masked KL term of their (infer, prior) and its adjoints
+    (mdmm_sweep_t.kld_*): K = 1 sweeps of the wide family, forward and backward.  (A/B: MDMM_KLD_FUSED=0)"""
+    if os.environ.get('MDMM_KLD_FUSED') == '0' or cfg.K != 1 or cfg.trans_only:
+        return False
+    return wide_shape(cfg) and wide_shape(cfg, bwd=True)
+
+
+def bfvi_sweep(cfg, gtf_params, z0_mean, z0_log_std, experts, eps=None, kld=None):
     """Run one filtering / smoothing sweep for cfg.P passes.
 
     experts: list of ExpertSpec.  Returns (infer_mean, infer_std, prior_mean, prior_std,
-    samples), each (P,T,B,D) (samples is empty when cfg.need_samples is False)."""
+    samples), each (P,T,B,D) (samples is empty when cfg.need_samples is False).
+    kld = (row mask (T*B) or None, weight, LossSum): where sweep_kld_fused(cfg), weight * KL(infer || prior) is added to
+    the sum by the sweep itself (the caller then does not call kld_gauss on the outputs)."""
     masks = [_f32c(e.mask) for e in experts]
     bits = [int(e.pass_bits) for e in experts]
     per_pass = [bool(e.per_pass) for e in experts]
     _need_gpu(eps, *masks)
     tensors = list(gtf_params) + [e.mean for e in experts] + [e.std for e in experts]
-    return _SweepFn.apply(cfg, _f32c(eps), masks, bits, per_pass, z0_mean, z0_log_std, *tensors)
+    if kld is not None:
+        if not sweep_kld_fused(cfg):
+            raise native.MdmmError('this sweep shape has no fused KL term: ask sweep_kld_fused(cfg) first')
+        k_mask, k_weight, k_into = kld
+        cfg.kld = (None if k_mask is None else _f32c(k_mask).reshape(-1), float(k_weight), k_into)
+    out = _SweepFn.apply(cfg, _f32c(eps), masks, bits, per_pass, z0_mean, z0_log_std, *tensors)
+    if kld is not None:
+        kld[2].handles.append(out[5])
+    return out[:5]
 
 
 class _TransFn(torch.autograd.Function):

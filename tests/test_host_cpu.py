@@ -40,6 +40,7 @@ def test_binding_struct_layout_matches_header():
     expect = n_int * 4 + 8 + 16 + 4 * 8 + 96 + 8 * 56 + 5 * 8 + 5 * 8 + 3 * 8 + 2 * 8 + 8 + 16 + 8
     expect += 8 + 4 + 4 + 8 + 8          # wide family: gtf_frag, precision, reserved1, wide_ws, wide_ws_bytes
     expect += 8 + 8                      # noise_park, noise_park_bytes
+    expect += 8 + 8 + 8 + 4 + 4          # fused KL term: kld_mask, kld_out, kld_scale_dev, kld_weight, reserved2
     assert ctypes.sizeof(native.Sweep) == expect
 
 
