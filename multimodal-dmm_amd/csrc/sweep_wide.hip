@@ -27,10 +27,11 @@ using namespace wide;
 
 
 
-template <bool F32, int RT>
+// NI images: two (Z / NL and one hidden layer at a time), or four for the three-phase K = 1 forward (Z, HG, HN, NL)
+template <bool F32, int RT, int NI = 2>
 struct FwdLds {
   static constexpr int IMG = 32 * RT * Op<F32>::RS;
-  static constexpr int OFF_Z = 0, OFF_H = IMG, OFF_TAB = 2 * IMG;
+  static constexpr int OFF_Z = 0, OFF_H = IMG, OFF_TAB = NI * IMG;
   static constexpr int OFF_ROW = OFF_TAB + 32 * RT * (int)sizeof(PairRef);
   static constexpr int BYTES = OFF_ROW + 32 * RT * 8;
 };
@@ -40,15 +41,26 @@ struct FwdLds {
 // forward
 // ---------------------------------------------------------------------------------------
 
+template <int N> struct PrefetchK1 { PairRef pr[N]; ExpertVals ev[N]; };
+
 // LR (K = 1 only): the accumulator registers of a lane that can hold live rows (see wide_bwd_kernel); the
 // elementwise phases and the fusion skip the others.
-template <bool F32, int RT, bool K1, int LR = 16>
+// P3 (K = 1 only): the transition as THREE contraction phases instead of six.  Its layers form three levels -- {W1g,
+// W1n, Wl} read z, {W2g, W2n} read the hidden layers, Ws reads nl -- and at one row tile the accumulators of a
+// level fit the registers (16 each), so the levels run back to back on four LDS images with three workgroup barriers
+// per step instead of eight; the weight stream (the K = 1 sweep's bound: every workgroup pulls all 768 KB of the
+// direction's fragments through its CU's L2 port per step) never pauses at a barrier.  The step's expert loads do
+// not depend on the chain either: they are requested at the head of the step and land under the contractions.
+template <bool F32, int RT, bool K1, int LR = 16, bool P3 = false>
 __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, const WideGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using L = FwdLds<F32, RT>;
+  static_assert(!P3 || (K1 && RT == 1), "the three-phase forward is a K = 1 shape");
+  using L = FwdLds<F32, RT, P3 ? 4 : 2>;
   using O = Op<F32>;
   char* imgZ = smem + L::OFF_Z;
   char* imgH = smem + L::OFF_H;
+  [[maybe_unused]] char* imgN = smem + 2 * L::IMG;       // P3: relu(W1n z)
+  [[maybe_unused]] char* imgL = smem + 3 * L::IMG;       // P3: nl
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, n = 32 * wave + (lane & 31);
   const int T = a.T, B = a.B, K = a.K;
@@ -96,6 +108,76 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
     const auto* exs = a.experts;
     const int t = a.reverse ? T - 1 - i : i;
     f32x16 m_[RT], var_[RT];       // per particle: p(z) * q'(z | z_prev)  (dmm.py:239-252)
+    // P3: this step's pairs and their expert values, requested before the contractions
+    constexpr bool PREF = P3 && LR <= 4;        // (eight pairs' values in flight are 96 registers: they spill)
+    [[maybe_unused]] PrefetchK1<PREF ? LR : 1> pf;
+    if constexpr (PREF) {
+      FuseArgs fz0;
+      fuse_args(a, exs, fz0);
+      const lds_tab_t tabl = tab;
+#pragma unroll
+      for (int r = 0; r < LR; ++r) pf.pr[r] = tabl[acc_row(0, r) + 4 * h];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < LR; ++r) {
+        pf.ev[r].on = 0;
+        if (pf.pr[r].p >= 0) load_experts_d(fz0.ed, pf.pr[r], (size_t)t * B + pf.pr[r].b, n, pf.ev[r]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (P3) {
+      if (i > 0) {
+        f32x16 acc[RT], x[RT], lin[RT];
+        STAMP(0);
+        // level 1: both hidden layers and z_lin from the Z image
+        fill_acc(acc, b1g);
+        gemm_tile<F32, RT, Pf<RT>::N>(acc, imgZ + arow, W(L_W1G), W(L_W1N), ring);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+        store_image<F32, RT>(imgH, acc, wave, lane);
+        fill_acc(acc, b1n);
+        gemm_tile<F32, RT, Pf<RT>::N>(acc, imgZ + arow, W(L_W1N), W(L_WL), ring);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
+        store_image<F32, RT>(imgN, acc, wave, lane);
+        fill_acc(lin, bl);
+        gemm_tile<F32, RT, Pf<RT>::N>(lin, imgZ + arow, W(L_WL), W(L_W2G), ring);
+        STAMP(2);
+        __syncthreads();
+        STAMP(3);
+        // level 2: gate pre-activation and the non-linear branch
+        fill_acc(x, b2g);
+        gemm_tile<F32, RT, Pf<RT>::N>(x, imgH + arow, W(L_W2G), W(L_W2N), ring);
+        fill_acc(acc, b2n);
+        gemm_tile<F32, RT, Pf<RT>::N>(acc, imgN + arow, W(L_W2N), W(L_WS), ring);
+        store_image<F32, RT>(imgL, acc, wave, lane);
+        // muq = (1 - g) (e^x nl + bl + Wl z) = (1 - g) lin + g nl
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (r >= LR) { m_[0][r] = 0.f; continue; }
+          const float ex = fast::exp(__builtin_amdgcn_fmed3f(x[0][r], -30.f, 30.f));
+          m_[0][r] = fast::rcp(1.0f + ex) * fmaf(acc[0][r], ex, lin[0][r]);
+        }
+        STAMP(6);
+        __syncthreads();
+        STAMP(7);
+        // level 3: std pre-activation, then p(z) * q'(z | z_prev) (see the six-phase form below)
+        fill_acc(acc, bs);
+        gemm_tile<F32, RT, Pf<RT>::N>(acc, imgL + arow, W(L_WS), W(L_W1G), ring);
+        STAMP(16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (r >= LR) { m_[0][r] = 0.f; var_[0][r] = 0.f; continue; }
+          const float sq = softplus_w<F32>(acc[0][r]) + a.min_std;               // common.py:66
+          const float v = fmaf(sq, sq, MDMM_POE_EPS);
+          const float u = fast::rcp(fmaf(t0, v, 1.0f));
+          const float var = v * u;
+          const float mm = fmaf(m_[0][r], u, num0 * var);
+          m_[0][r] = (mm != mm) ? 0.f : mm;                                      // dgts.py:49
+          var_[0][r] = var;
+        }
+      }
+    } else
     if (i > 0) {
       f32x16 acc[RT], x[RT];
       STAMP(0);
@@ -207,15 +289,20 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           const lds_tab_t tabl = tab;
           PairRef prs4[4];
           ExpertVals ev[4];
+          if constexpr (P3 && LR <= 4) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) prs4[j] = tabl[r0 + j];
-          __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 4; ++j) { prs4[j] = pf.pr[4 * q + j]; ev[j] = pf.ev[4 * q + j]; }
+          } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            ev[j].on = 0;
-            if (prs4[j].p >= 0) load_experts_d(fz.ed, prs4[j], (size_t)t * B + prs4[j].b, n, ev[j]);
+            for (int j = 0; j < 4; ++j) prs4[j] = tabl[r0 + j];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              ev[j].on = 0;
+              if (prs4[j].p >= 0) load_experts_d(fz.ed, prs4[j], (size_t)t * B + prs4[j].b, n, ev[j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
           if (sampled && (!last || o_smp) && 32 * rt + 8 * q < g.NP)
             eps_group(a, noff, t_term, rowbase + r0, n, e);
 #pragma unroll
@@ -361,7 +448,8 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
     }
     STAMP(13);
     if (!last) {
-      __syncthreads();               // every wave is done with the H image (5b) and Z (5a)
+      // (P3: the Z image was last read in level 1, two barriers ago)
+      if constexpr (!P3) __syncthreads();               // every wave is done with the H image (5b) and Z (5a)
       STAMP(14);
       store_image<F32, RT>(imgZ, z, wave, lane);
       __syncthreads();
@@ -1066,10 +1154,10 @@ __global__ __launch_bounds__(256) void frag_pack_kernel(const mdmm_gtf_raw_t raw
 template <typename Kern>
 int set_lds(Kern kern, int bytes) { return mdmm_lds_attr_fn((const void*)kern, (size_t)bytes); }
 
-template <bool F32, int RT, bool K1, int LR = 16>
+template <bool F32, int RT, bool K1, int LR = 16, bool P3 = false>
 int launch_fwd(const mdmm_sweep_t* a, const WideGeo& g, hipStream_t stream) {
-  using L = FwdLds<F32, RT>;
-  auto kern = wide_fwd_kernel<F32, RT, K1, LR>;
+  using L = FwdLds<F32, RT, P3 ? 4 : 2>;
+  auto kern = wide_fwd_kernel<F32, RT, K1, LR, P3>;
   int rc = set_lds(kern, L::BYTES);
   if (rc) return rc;
   const int grid = (g.n_pairs + g.NP - 1) / g.NP;
@@ -1157,8 +1245,10 @@ int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->K == 1) {
     if (f32) return launch_fwd<true, 1, true>(a, g, stream);
     const bool lr_off = getenv("MDMM_K1_LR16") != nullptr;                  // A/B switch: every register slot, as before
-    if (g.NP <= 8 && !lr_off) return launch_fwd<false, 1, true, 4>(a, g, stream);
-    if (g.NP <= 16 && !lr_off) return launch_fwd<false, 1, true, 8>(a, g, stream);
+    const char* p3e = getenv("MDMM_K1_3PHASE");                             // A/B switch: the six-phase form (0)
+    const bool p3 = !(p3e && p3e[0] == '0');
+    if (g.NP <= 8 && !lr_off) return p3 ? launch_fwd<false, 1, true, 4, true>(a, g, stream) : launch_fwd<false, 1, true, 4>(a, g, stream);
+    if (g.NP <= 16 && !lr_off) return p3 ? launch_fwd<false, 1, true, 8, true>(a, g, stream) : launch_fwd<false, 1, true, 8>(a, g, stream);
     return launch_fwd<false, 1, true, 16>(a, g, stream);
   }
   if (a->noise_park && (f32 || !mdmm_wide_bwd4_supported(a) || a->noise_park_bytes < mdmm_wide_noise_park_bytes(a) ||
