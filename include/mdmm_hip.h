@@ -216,6 +216,24 @@ typedef struct mdmm_sweep {
   const float* kld_scale_dev;
   float kld_weight;
   int32_t reserved2;
+  /* Optional RIDER (shapes mdmm_sweep_rider_supported() accepts: wide family, bf16 operands, K = 25): a second,
+   * single-particle chain of the same direction, experts and transition weights rides in the first dead row (row K)
+   * of every pair's 32-row tile -- the K = 1 filtering pass MultiDMM.step runs next to the K-particle filter pass of
+   * its smoothing mode (dmm.py:547-553 with 464-470: `bfilter` and the first sweep of `fsmooth`).  The rider has its
+   * own product of experts, its own noise stream (seed, rider_offset [+ *offset_dev], elements indexed as a
+   * (P,T,1,B,D) tensor, or rider_eps) and its own outputs, and stays out of the particles' moment matching; its KL
+   * term may be fused (kld_* fields then refer to the RIDER's (infer, prior): it is the K = 1 chain whose
+   * posterior the loss scores).  rider_infer_mean != NULL switches it on.  The backward of the rider chain is the
+   * K = 1 backward sweep on the rider's outputs (same stream id), a launch of its own.  */
+  float* rider_infer_mean;
+  float* rider_infer_std;
+  float* rider_prior_mean;
+  float* rider_prior_std;
+  float* rider_samples;         /* may be NULL */
+  const float* rider_eps;       /* (P,T,1,B,D) recorded draws, or NULL */
+  uint64_t rider_offset;
+  int32_t rider_sample;
+  int32_t rider_sample_init;
 } mdmm_sweep_t;
 
 int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream);
@@ -229,6 +247,8 @@ int mdmm_sweep_dw_width(int D, int H);
 int mdmm_sweep_wide(const mdmm_sweep_t* args);
 /* != 0 if the forward AND the backward sweep of this shape take the fused KL term (kld_* fields) */
 int mdmm_sweep_kld_fused(const mdmm_sweep_t* args);
+/* != 0 if the forward sweep of this shape carries a rider chain (rider_* fields) */
+int mdmm_sweep_rider_supported(const mdmm_sweep_t* args);
 int64_t mdmm_sweep_wide_ws_bytes(const mdmm_sweep_t* args);
 int64_t mdmm_sweep_noise_park_bytes(const mdmm_sweep_t* args);
 int64_t mdmm_sweep_dw_rows(const mdmm_sweep_t* args);

@@ -51,10 +51,17 @@ template <int N> struct PrefetchK1 { PairRef pr[N]; ExpertVals ev[N]; };
 // per step instead of eight; the weight stream (the K = 1 sweep's bound: every workgroup pulls all 768 KB of the
 // direction's fragments through its CU's L2 port per step) never pauses at a barrier.  The step's expert loads do
 // not depend on the chain either: they are requested at the head of the step and land under the contractions.
-template <bool F32, int RT, bool K1, int LR = 16, bool P3 = false>
+// RD (K = 25 particles, one row tile per pair): a RIDER chain in row RD_ROW of every tile -- mdmm_sweep_t.rider_*: the
+// single-particle filtering pass of the same direction, experts and weights.  Row 25 is accumulator register 13 of
+// the lower lane half; it takes part in every contraction like any row (the images hold all 32 rows of a tile), is
+// masked out of the particles' moments as a dead row always was, and gets its own product of experts, draw and
+// outputs in the fusion phase.
+constexpr int RD_ROW = 25, RD_REG = 13;       // row = 8 (reg / 4) + reg % 4 + 4 h  with h = 0
+template <bool F32, int RT, bool K1, int LR = 16, bool P3 = false, bool RD = false>
 __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, const WideGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(!P3 || (K1 && RT == 1), "the three-phase forward is a K = 1 shape");
+  static_assert(!RD || (!K1 && !F32 && RT == 4), "the rider rides the bf16 K-particle forward");
   using L = FwdLds<F32, RT, P3 ? 4 : 2>;
   using O = Op<F32>;
   char* imgZ = smem + L::OFF_Z;
@@ -335,6 +342,14 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
     } else {
       // per row tile: moments over the pair's particles (dgts.py:79-83), fusion, particles
       float pm[RT], ps[RT];
+      [[maybe_unused]] float rpm[RT], rps[RT];       // rider: its own transition prior (row RD_ROW, lower lane half)
+      if constexpr (RD) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          rpm[rt] = (i > 0) ? m_[rt][RD_REG] : mu0;
+          rps[rt] = (i > 0) ? fast::sqrt(var_[rt][RD_REG]) : sg0;
+        }
+      }
       if (i > 0) {
         float s1[RT], s2[RT], s3[RT];
 #pragma unroll
@@ -398,7 +413,33 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
             o_im[o] = im; o_is[o] = is;
             o_pm[o] = pm[rt]; o_ps[o] = ps[rt];
           }
-        }
+          if constexpr (RD) {
+            // the rider's own fusion (same experts, already in registers), draw and outputs
+            fast::Poe q2; q2.init(); q2.add(rpm[rt], rps[rt], 1.0f);
+            poe_experts(a, exs, pr, tb, n, ev, q2);
+            if (fz.inv_prior) q2.add(mu0, -sg0, 1.0f);
+            float im2, is2; q2.finish(im2, is2);
+            const bool smp2 = a.rider_sample || (i == 0 && a.rider_sample_init);
+            float e2 = 0.f;
+            if (smp2 && (!last || a.rider_samples)) {
+              const uint64_t idx = (((uint64_t)pr.p * T + t) * B + pr.b) * (uint64_t)WD + n;     // (P,T,1,B,D)
+              e2 = a.rider_eps ? a.rider_eps[idx]
+                               : philox_normal(a.seed, a.rider_offset + (a.offset_dev ? *a.offset_dev : 0), idx);
+            }
+            const float z2 = smp2 ? fmaf(e2, is2, im2) : im2;
+            if (h == 0) {
+              a.rider_infer_mean[o] = im2; a.rider_infer_std[o] = is2;
+              a.rider_prior_mean[o] = rpm[rt]; a.rider_prior_std[o] = rps[rt];
+              if (a.rider_samples) a.rider_samples[o] = z2;
+              if (a.kld_out) {       // the fused KL term is the rider's (see mdmm_sweep_t)
+                const float ip = fast::rcp(rps[rt]), d = (im2 - rpm[rt]) * ip, r_ = is2 * ip;
+                const float term = 2.0f * (fast::log(rps[rt]) - fast::log(is2)) + fmaf(r_, r_, d * d) - 1.0f;
+                kl_acc += (a.kld_mask ? a.kld_mask[tb] : 1.0f) * term;
+              }
+            }
+            rpm[rt] = z2; rps[rt] = e2;        // (handed to the particle loop below: the rider's next z and its draw)
+          }
+        } else if constexpr (RD) { rpm[rt] = 0.f; rps[rt] = 0.f; }
         const int kb = 32 * (rt & (g.TPP - 1));
         float zs = 0.f;
         const bool need = pr.p >= 0 && (!last || a.samples);
@@ -421,6 +462,12 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
               e[j] = live ? e[j] : 0.f;
               z[rt][4 * q + j] = zz;
               zs += zz;
+            }
+            if constexpr (RD) {
+              if (4 * q <= RD_REG && RD_REG < 4 * q + 4 && h == 0) {      // row RD_ROW: the rider (not in zs)
+                z[rt][RD_REG] = rpm[rt];
+                e[RD_REG - 4 * q] = rps[rt];
+              }
             }
           }
           if constexpr (RT == 4 && !F32) {
@@ -456,7 +503,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       STAMP(15);
     }
   }
-  if constexpr (K1) {
+  if constexpr (K1 || RD) {
     if (a.kld_out) {                 // one fp64 atomic per workgroup (as csrc/reduce.hip's kld kernel)
       __syncthreads();
       float* red = reinterpret_cast<float*>(smem);
@@ -1154,10 +1201,10 @@ __global__ __launch_bounds__(256) void frag_pack_kernel(const mdmm_gtf_raw_t raw
 template <typename Kern>
 int set_lds(Kern kern, int bytes) { return mdmm_lds_attr_fn((const void*)kern, (size_t)bytes); }
 
-template <bool F32, int RT, bool K1, int LR = 16, bool P3 = false>
+template <bool F32, int RT, bool K1, int LR = 16, bool P3 = false, bool RD = false>
 int launch_fwd(const mdmm_sweep_t* a, const WideGeo& g, hipStream_t stream) {
   using L = FwdLds<F32, RT, P3 ? 4 : 2>;
-  auto kern = wide_fwd_kernel<F32, RT, K1, LR, P3>;
+  auto kern = wide_fwd_kernel<F32, RT, K1, LR, P3, RD>;
   int rc = set_lds(kern, L::BYTES);
   if (rc) return rc;
   const int grid = (g.n_pairs + g.NP - 1) / g.NP;
@@ -1238,7 +1285,10 @@ int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
 int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   WideGeo g;
   const int RT = plan(a, false, &g);
-  if (a && (a->kld_out || a->kld_scale_dev) && !mdmm_sweep_kld_fused(a)) return MDMM_E_ARG;   // (never dropped silently)
+  const bool rider = a && a->rider_infer_mean;
+  if (rider && (!mdmm_sweep_rider_supported(a) || !a->rider_infer_std || !a->rider_prior_mean || !a->rider_prior_std))
+    return MDMM_E_ARG;
+  if (a && (a->kld_out || a->kld_scale_dev) && !(rider || mdmm_sweep_kld_fused(a))) return MDMM_E_ARG;   // (never dropped silently)
   if (!RT) return mdmm_wide_sweep_fwd_long(a, stream);      // more particles than the row tiles hold
   if (((uintptr_t)a->gtf_frag) & 15) return MDMM_E_ALIGN;
   const bool f32 = a->precision == MDMM_PREC_F32;
@@ -1254,6 +1304,7 @@ int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->noise_park && (f32 || !mdmm_wide_bwd4_supported(a) || a->noise_park_bytes < mdmm_wide_noise_park_bytes(a) ||
                         (((uintptr_t)a->noise_park) & 15)))
     return MDMM_E_ARG;                      // (a park only where the one-round backward will read it)
+  if (rider) return launch_fwd<false, 4, false, 16, false, true>(a, g, stream);
   return f32 ? launch_fwd<true, 1, false>(a, g, stream) : launch_fwd<false, 4, false>(a, g, stream);
 }
 
@@ -1302,6 +1353,12 @@ int wide::wide_wgrad_launch(const WideWs& ws, bool f32, int CH, float* dw_partia
 int mdmm_wide_bwd_supported(const mdmm_sweep_t* a) {
   WideGeo g;
   return plan(a, true, &g) != 0;
+}
+
+extern "C" int mdmm_sweep_rider_supported(const mdmm_sweep_t* a) {
+  WideGeo g;
+  if (!a || a->K != RD_ROW || a->precision != MDMM_PREC_BF16 || a->trans_only) return 0;
+  return plan(a, false, &g) == 4 && g.TPP == 1;
 }
 
 extern "C" int mdmm_sweep_kld_fused(const mdmm_sweep_t* a) {

@@ -225,19 +225,30 @@ class MultiDMM(MultiDGTS):
         return eps.to(self.z0_mean.device)
 
     def _sweep(self, experts, t_max, b_dim, n_pass, direction, sample, n_particles,
-               sample_init, use_inv_prior, need_samples, draws=None, kld=None):
+               sample_init, use_inv_prior, need_samples, draws=None, kld=None, rider=None):
         reverse = direction == 'bwd'
         kw = dict(T=t_max, B=b_dim, D=self.z_dim, H=self.h_dim, P=n_pass, K=n_particles,
                   reverse=reverse, sample=sample, sample_init=sample_init,
                   use_inv_prior=use_inv_prior, min_std=self.min_std, need_samples=need_samples,
                   precision=self.sweep_dtype)
+        rd = None
+        if rider is not None:
+            # the single-particle filtering pass of the same direction as a rider chain of this sweep: its stream id /
+            # recorded draws come FIRST (the reference runs that mode before this one, dmm.py:547-553)
+            rkw = {}
+            r_eps = self._eps_or_stream(rkw, t_max, b_dim, n_pass, 1, rider['sample'], rider['sample_init'], reverse,
+                                        rider.get('draws'))
+            rd = dict(sample=rider['sample'] or False, sample_init=rider['sample_init'], offset=rkw.get('offset', 0),
+                      eps=r_eps, kld=tuple(rider['kld'][:3]) if rider.get('kld') is not None else None)
+            if r_eps is None and self._noise().replay:      # (no draws recorded: a MAP chain)
+                rd['sample'] = False
         eps = self._eps_or_stream(kw, t_max, b_dim, n_pass, n_particles, sample, sample_init,
                                   reverse, draws)
         cfg = ops.SweepCfg(**kw)
         if kld is not None:         # (mask, weight, LossSum, [did the sweep take it?])
             kld[3] = ops.sweep_kld_fused(cfg)
         return ops.bfvi_sweep(cfg, self._gtf(direction), self.z0_mean, self.z0_log_std, experts,
-                              eps, kld=tuple(kld[:3]) if kld is not None and kld[3] else None)
+                              eps, kld=tuple(kld[:3]) if kld is not None and kld[3] else None, rider=rd)
 
     def z_filter(self, z_mean, z_std, z_masks, direction='fwd', sample=True, n_particles=1,
                  sample_init=False):
@@ -252,8 +263,19 @@ class MultiDMM(MultiDGTS):
                                           n_particles, sample_init, False, True, draws)
         return (im[0], is_[0]), (pm[0], ps[0]), zs[0]
 
+    def _rider_ok(self, t_max, b_dim, n_pass, f_mode, s_mode, flt_particles, train_particles):
+        """The filtering mode's K = 1 pass can ride the smoothing mode's K-particle filter pass (ops.sweep_rider_supported):
+        same sweep direction (bfilter + fsmooth, or ffilter + bsmooth), one particle, the wide bf16 tile shape."""
+        if f_mode not in FILTER_MODES or s_mode not in SMOOTH_MODES or flt_particles != 1:
+            return False
+        if ('fwd' if f_mode == 'ffilter' else 'bwd') != ('fwd' if s_mode == 'bsmooth' else 'bwd'):
+            return False
+        cfg = ops.SweepCfg(T=t_max, B=b_dim, D=self.z_dim, H=self.h_dim, P=n_pass, K=train_particles,
+                           precision=self.sweep_dtype)
+        return ops.sweep_rider_supported(cfg)
+
     def _run_passes(self, enc, pass_mods, t_max, b_dim, mode, sample, sample_init,
-                    flt_particles, smt_particles, kld=None):
+                    flt_particles, smt_particles, kld=None, rider=None, after_filter=None):
         """All passes of one mode in one (filter) or two (filter + smoother) launches.
 
         enc: {m: (mean, std, seen)}; pass_mods: per pass, the modalities it conditions on.
@@ -272,6 +294,9 @@ class MultiDMM(MultiDGTS):
         flt_init = sample_init if mode in FILTER_MODES else False
         replay = self._noise().replay
         f_draws = s_draws = None
+        if replay and rider is not None:      # the riding mode's passes come first in the reference's draw order
+            rider = dict(rider)
+            rider['draws'] = [self.noise.take(_n_draws(t_max, rider['sample'], 1, rider['sample_init'])) for _ in range(n_pass)]
         if replay:      # the reference runs the passes one after the other (dgts.py:119-129)
             f_draws, s_draws = [], []
             for _ in range(n_pass):
@@ -281,9 +306,16 @@ class MultiDMM(MultiDGTS):
                         _n_draws(t_max, sample, smt_particles, sample_init)))
         # kld: [row mask, weight, LossSum, taken?] -- the sweep whose (infer, prior) the mode returns may form the
         # KL term itself (ops.sweep_kld_fused); kld[3] tells the caller whether it did
-        im, is_, pm, ps, zs = self._sweep(obs, t_max, b_dim, n_pass, flt_dir, sample,
-                                          flt_particles, flt_init, False, not smoothing, f_draws,
-                                          kld=None if smoothing else kld)
+        res = self._sweep(obs, t_max, b_dim, n_pass, flt_dir, sample,
+                          flt_particles, flt_init, False, not smoothing, f_draws,
+                          kld=None if smoothing else kld, rider=rider)
+        rider_out = None
+        if rider is not None:
+            res, rider_out = res
+            rider_out = ((rider_out[0], rider_out[1]), (rider_out[2], rider_out[3]), rider_out[4])
+            if after_filter is not None:
+                after_filter(rider_out)         # (the riding mode's loss may start now, on its own stream)
+        im, is_, pm, ps, zs = res
         if smoothing:
             smt_dir = 'fwd' if mode == 'fsmooth' else 'bwd'
             flt_mask = torch.ones(t_max, b_dim, device=pm.device, dtype=torch.float32)
@@ -292,6 +324,8 @@ class MultiDMM(MultiDGTS):
             experts = obs + [ops.ExpertSpec(pm, ps, flt_mask, all_bits, True)]   # dmm.py:479-485
             im, is_, pm, ps, zs = self._sweep(experts, t_max, b_dim, n_pass, smt_dir, sample,
                                               smt_particles, sample_init, True, True, s_draws, kld=kld)
+        if rider is not None:
+            return ((im, is_), (pm, ps), zs), rider_out
         return (im, is_), (pm, ps), zs
 
     @staticmethod
@@ -519,9 +553,40 @@ class MultiDMM(MultiDGTS):
             for x in (mu, sd, seen):
                 x.record_stream(side)
         mask_f.record_stream(side); mask_kld.record_stream(side)
-        side.wait_stream(main)
         flt_particles = kwargs.get('flt_particles', 1)
-        if os.environ.get('MDMM_JOINT_DECODE') != '1':
+        if self._rider_ok(t_max, b_dim, len(pass_mods), f_mode, s_mode, flt_particles, train_particles) \
+                and os.environ.get('MDMM_JOINT_DECODE') != '1':
+            # The filtering mode's single-particle pass RIDES the smoothing mode's K-particle filter pass (same
+            # direction, experts and transition weights: dmm.py:547-553 with 464-470): one row of the latter's tiles,
+            # no forward sweep of its own.  Its loss (decoders, reconstruction terms) starts on the side stream as
+            # soon as that sweep is done, next to the smoother and the smoothing mode's loss.
+            total_f = ops.LossSum(self.z0_mean.device)
+            kw_f, kinto_f = ops.weighted_into(total_f, kld_mult)
+            box = {}
+
+            def filter_term(passes_f):
+                side.wait_stream(main)
+                for grp in passes_f:
+                    for x in (grp if isinstance(grp, tuple) else (grp,)):
+                        x.record_stream(side)
+                with torch.cuda.stream(side):
+                    box['loss'] = f_mult * self._joint_loss([(passes_f, 1.0)], targets, (mask_f, mask_kld), kld_mult,
+                                                            rec_mults, loss_mods, t_max, b_dim, total=total_f,
+                                                            kld_into=(kw_f, kinto_f), kld_done=True)
+
+            total_s = ops.LossSum(self.z0_mean.device)
+            kw_s, kinto_s = ops.weighted_into(total_s, kld_mult)
+            kld_s = [mask_f, kw_s, kinto_s, False]
+            passes_s, _ = self._run_passes(enc, pass_mods, t_max, b_dim, s_mode, sample, sample_init, train_particles,
+                                           smt_particles, kld=kld_s,
+                                           rider=dict(sample=sample, sample_init=sample_init, kld=[mask_f, kw_f, kinto_f]),
+                                           after_filter=filter_term)
+            loss_s = s_mult * self._joint_loss([(passes_s, 1.0)], targets, (mask_f, mask_kld), kld_mult, rec_mults,
+                                               loss_mods, t_max, b_dim, total=total_s, kld_into=(kw_s, kinto_s),
+                                               kld_done=kld_s[3])
+            loss_f = box['loss']
+        elif os.environ.get('MDMM_JOINT_DECODE') != '1':
+            side.wait_stream(main)
             # The two modes as two independent loss terms, each with its own decoder calls, on two streams.
             # (MDMM_JOINT_DECODE=1: one decoder batch per modality for both modes, _joint_loss -- half the launches of
             # the conv chain, measured SLOWER: 31.1 vs 30.1 ms per cfg3 step, profiles/r04_ab_joint_decode.txt -- the
@@ -556,6 +621,7 @@ class MultiDMM(MultiDGTS):
                 loss_f = term_f()
                 loss_s = term_s()
         else:
+            side.wait_stream(main)
             # The sweeps of the two modes side by side (the filtering mode's on the side stream), then ONE loss over
             # both: every decoder runs once per step (_joint_loss).  Draw order as the reference's: the filtering
             # mode's passes first.

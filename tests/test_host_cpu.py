@@ -41,6 +41,7 @@ def test_binding_struct_layout_matches_header():
     expect += 8 + 4 + 4 + 8 + 8          # wide family: gtf_frag, precision, reserved1, wide_ws, wide_ws_bytes
     expect += 8 + 8                      # noise_park, noise_park_bytes
     expect += 8 + 8 + 8 + 4 + 4          # fused KL term: kld_mask, kld_out, kld_scale_dev, kld_weight, reserved2
+    expect += 6 * 8 + 8 + 4 + 4          # rider: five outputs, eps, offset, sample, sample_init
     assert ctypes.sizeof(native.Sweep) == expect
 
 
