@@ -258,11 +258,12 @@ class GraphedElboStep:
     def __call__(self):
         self.g_step.replay()
         if dist.is_available() and dist.is_initialized() and (self.group is not None or dist.get_world_size() > 1):
-            # The collective is a stream operation between two replays.  On this ROCm such an operation does not
-            # reliably wait for every queue of the replay in front of it (schedule()): the gradients
-            # must be complete before RCCL reads them, so the host waits for the step graph first.
-            # (A/B on a multi-GPU box: MDMM_NO_REPLAY_SYNC=1)
-            if os.environ.get('MDMM_NO_REPLAY_SYNC') != '1':
+            # The collective is a stream operation between two replays.  Round 3 put a host wait in front of it
+            # because such operations faulted replayed steps on this ROCm; the cause was the runtime's graph packet
+            # capture (mdmm/__init__.py), with it off 200 replays of cfg3 / cfg4 through this branch (a one-rank RCCL
+            # group, tools/dryrun_allreduce.py, profiles/r04v_dryrun_allreduce.txt) keep bit-identical gradients with
+            # and without the wait, which costs 0.4 ms per step.  MDMM_REPLAY_SYNC=1 brings it back.
+            if os.environ.get('MDMM_REPLAY_SYNC') == '1':
                 torch.cuda.current_stream().synchronize()
             self.bucket.allreduce(self.group)
         self.g_opt.replay()
