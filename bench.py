@@ -414,6 +414,7 @@ def load_traffic(tag, cfg, b_dim):
         except ValueError:
             continue
         for key, rec in table.items():
+            key = rec.get('key', key)               # (r04: one file for several shapes, the call's tag under 'key')
             shape = rec.get('shape', {'B': 256, 'T': 40, 'P': 4} if name.startswith('r02') else None)
             if key in tag and shape == {'B': b_dim, 'T': cfg.T, 'P': 1 + cfg.M}:
                 return rec.get('bytes_per_launch'), rec.get('source')
