@@ -395,35 +395,19 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       float* const o_im = a.infer_mean; float* const o_is = a.infer_std;
       float* const o_pm = a.prior_mean; float* const o_ps = a.prior_std;
       __builtin_amdgcn_sched_barrier(0);
-      // (tile by tile each batch of expert loads sits behind the previous tile's output stores -- four memory round
-      // trips per step, profiles/r04x_stamps_k25.txt -- batching them was tried:)
-      // FWD_LB tiles' loads per batch.  Measured (tools/build_variant.sh, tools/bench_sweep.py K=25 at cfg3 size):
-      // 1 = tile by tile 2.16-2.19 ms, 2 -> 2.32-2.35, 4 -> 2.44-2.45: the values in flight cost more scratch
-      // (152 -> 452 B per lane) than the three memory round trips they hide.
-#ifndef FWD_LB
-#define FWD_LB 1
-#endif
-      constexpr int LB = (RT % FWD_LB == 0) ? FWD_LB : 1;
-      PairRef prs_[RT];
-      ExpertVals evs_[LB];
+      // (Tile by tile each batch of expert loads sits behind the previous tile's output stores: four memory round trips
+      // per step, profiles/r04x_stamps_k25.txt.  Requesting two / four tiles' loads together was measured -- tools/
+      // bench_sweep.py K=25 at cfg3 size: 2.16-2.19 ms as is, 2.32-2.35 with two, 2.44-2.45 with four: the values in
+      // flight cost more scratch (152 -> 452 B per lane) than the round trips they hide.)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        if (rt % LB == 0) {
-#pragma unroll
-          for (int u = 0; u < LB; ++u) {
-            PairRef pr = tab[rt + u];          // a tile's pair is wave-uniform: scalar address math
-            pr.p = __builtin_amdgcn_readfirstlane(pr.p); pr.b = __builtin_amdgcn_readfirstlane(pr.b);
-            prs_[rt + u] = pr;
-            evs_[u].on = 0;
-            if (pr.p >= 0) load_experts_d(fz.ed, pr, (size_t)t * B + pr.b, n, evs_[u]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        const PairRef pr = prs_[rt];
+        PairRef pr = tab[rt];          // a tile's pair is wave-uniform: scalar address math
+        pr.p = __builtin_amdgcn_readfirstlane(pr.p); pr.b = __builtin_amdgcn_readfirstlane(pr.b);
         float im = 0.f, is = 0.f;
         if (pr.p >= 0) {
           const size_t tb = (size_t)t * B + pr.b;
-          const ExpertVals& ev = evs_[rt % LB];
+          ExpertVals ev;
+          load_experts_d(fz.ed, pr, tb, n, ev);         // (one batch of loads per tile)
           fast::Poe pq; pq.init(); pq.add(pm[rt], ps[rt], 1.0f);
           poe_experts(a, exs, pr, tb, n, ev, pq);
           if (fz.inv_prior) pq.add(mu0, -sg0, 1.0f);
