@@ -416,6 +416,8 @@ def load_traffic(tag, cfg, b_dim):
         for key, rec in table.items():
             key = rec.get('key', key)               # (r04: one file for several shapes, the call's tag under 'key')
             shape = rec.get('shape', {'B': 256, 'T': 40, 'P': 4} if name.startswith('r02') else None)
+            if key.startswith('sweep_wide') and cfg.dtype != 'bf16':
+                continue                            # (the wide records were taken with bf16 operands)
             if key in tag and shape == {'B': b_dim, 'T': cfg.T, 'P': 1 + cfg.M}:
                 return rec.get('bytes_per_launch'), rec.get('source')
     return None, None

@@ -679,7 +679,9 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
             c.x = hl[0]; c.y = hl[1]; c.z = wl[0]; c.w = wl[1];
             SPILL_ST(spill_at(i - 1, S_GLIN, rt, q >> 1), c);
           }
-          __builtin_amdgcn_sched_barrier(0);     // one group at a time
+#ifndef B4_E_FREE
+          __builtin_amdgcn_sched_barrier(0);     // one group at a time (A/B -DB4_E_FREE, tools/build_variant.sh: 5.20 vs 5.18 ms per call -- no gain)
+#endif
         }
       }
     }
