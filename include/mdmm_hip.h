@@ -821,6 +821,23 @@ int64_t mdmm_ssim_ws_floats(int64_t N, int C);
 int mdmm_ssim(const float* x, const float* y, int64_t N, int C, int H, int W, const float* window, int win,
               float data_range, float* ws, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * The Categorical decoder's head scored in place: CategoricalMLP.h_to_out (common.py:9-23: Linear(h -> n_cat) + Softmax)
+ * + losses.nll_categorical (losses.py:44-66: minus the summed PROBABILITY of the label) as one kernel each way.
+ * hid (rows, H) fp32 = the trunk's ReLU output, rows = passes x label_rows; row n is scored against label[n mod
+ * label_rows] (float labels, NaN = missing) under seq_mask[n mod label_rows]; pass_weight as for the stacked Bernoulli
+ * loss.  forward: probs (rows, n_cat) are kept for the backward, *out += weight * sum.  backward: g_hid (rows, H) and
+ * mdmm_cat_head_slabs(rows) slab rows of [n_cat][H] dW | [n_cat] db partial sums (the caller adds the rows up).
+ * --------------------------------------------------------------------------------- */
+int mdmm_cat_head_supported(int H, int n_cat);
+int mdmm_cat_head_slabs(int64_t rows);
+int mdmm_cat_head_nll_fwd(const float* hid, const float* w, const float* bias, const float* label,
+                          const float* seq_mask, int64_t rows, int64_t label_rows, int H, int n_cat, float weight,
+                          int passes, const float* pass_weight, float* probs, double* out, void* stream);
+int mdmm_cat_head_nll_bwd(const float* hid, const float* w, const float* label, const float* seq_mask, int64_t rows,
+                          int64_t label_rows, int H, int n_cat, float scale, const float* scale_dev, int passes,
+                          const float* pass_weight, const float* probs, float* g_hid, float* slab, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,16 @@ def _mlp_trunk(in_dim, h_dim):
     return nn.Sequential(nn.Linear(in_dim, h_dim), nn.ReLU())
 
 
+def mlp_trunk_relu(x, layer):
+    """relu(layer(x)) of a stock MLP holder's trunk (common.py:13-14, 30-31) for (rows, in) activations: on the own
+    GEMM with the ReLU in its epilogue where the tiles take the shape, else Linear + F.relu."""
+    if x.is_cuda and x.dim() == 2 and not torch.is_autocast_enabled() and x.dtype == layer.weight.dtype:
+        from .. import ops
+        if ops.CONV_OPERANDS is torch.bfloat16 and ops.linear_tiles_supported(x, layer.weight):
+            return ops._LinearTilesFn.apply(x, layer.weight, layer.bias, torch.float32, True)
+    return F.relu(_lin(x, layer))
+
+
 class CategoricalMLP(nn.Module):
     """in -> h -> softmax probs; forward returns the 1-tuple (probs,).  common.py:9-23"""
 

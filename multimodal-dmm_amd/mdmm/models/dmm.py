@@ -389,6 +389,14 @@ class MultiDMM(MultiDGTS):
         out = [r.reshape(n, t_max, b_dim, *r.shape[1:]).unbind(0) for r in out]
         return [tuple(r[i] for r in out) for i in range(n)]
 
+    def _cat_head(self, m, z):
+        dec = self.dec[m]
+        if not (self.dists[m] == 'Categorical' and type(dec) is common.CategoricalMLP and self.plugin_dtype is None
+                and z.is_cuda and z.dtype == torch.float32 and not torch.is_autocast_enabled()):
+            return False
+        w = dec.h_to_out[0].weight
+        return w.dtype == torch.float32 and ops.cat_head_supported(w.shape[1], w.shape[0])
+
     def _fused_nll(self, m, z):
         dec = self.dec[m]
         return (self.dists[m] == 'Normal' and type(dec) is common.GaussianMLP
@@ -452,6 +460,15 @@ class MultiDMM(MultiDGTS):
                 continue
             z_list = [zs[i][p] for i in range(len(terms)) for p in used]
             w_list = [float(tmult) for _, tmult in terms for _ in used]
+            if self._cat_head(m, z_list[0]) and len(z_list) <= 8:
+                # stock CategoricalMLP scored by nll_categorical: the trunk on the GEMM (ReLU in its epilogue where the
+                # tiles take it), then head + softmax + loss as one kernel each way (csrc/cat_head.hip)
+                dec = self.dec[m]
+                z = torch.stack(z_list).reshape(-1, self.z_dim) if len(z_list) > 1 else z_list[0].reshape(-1, self.z_dim)
+                hid = self._plug(common.mlp_trunk_relu, z, layer=dec.in_to_h[0])
+                ops.cat_head_nll(hid, dec.h_to_out[0], targets[m], mask, weight=float(mult), into=total,
+                                 passes=len(z_list), pass_weight=w_list)
+                continue
             if self._logit_decoder(m):      # sigmoid + BCE + masks in one pass each way
                 stacked = self._decode_for_loss(m, z_list, logits=True, stacked=True) if len(z_list) <= 8 else None
                 if stacked is not None:     # the passes as one batch: scored in place, one gradient buffer

@@ -43,6 +43,7 @@ SYMBOLS = [
     'mdmm_vrnn_layout', 'mdmm_vrnn_supported', 'mdmm_vrnn_fwd', 'mdmm_vrnn_bwd',
     'mdmm_collate_pad', 'mdmm_delete_steps', 'mdmm_decollate_pack', 'mdmm_sqerr_steps', 'mdmm_time_avg', 'mdmm_time_acc',
     'mdmm_ssim_ws_floats', 'mdmm_ssim',
+    'mdmm_cat_head_supported', 'mdmm_cat_head_slabs', 'mdmm_cat_head_nll_fwd', 'mdmm_cat_head_nll_bwd',
 ]
 
 _P = C.c_void_p
@@ -342,6 +343,10 @@ def lib():
         L.mdmm_ssim_ws_floats.argtypes = [i64, i32]
         L.mdmm_ssim_ws_floats.restype = i64
         L.mdmm_ssim.argtypes = [_P, _P, i64, i32, i32, i32, _P, i32, f32, _P, _P, _P]
+        L.mdmm_cat_head_supported.argtypes = [i32, i32]
+        L.mdmm_cat_head_slabs.argtypes = [i64]
+        L.mdmm_cat_head_nll_fwd.argtypes = [_P, _P, _P, _P, _P, i64, i64, i32, i32, f32, i32, C.POINTER(C.c_float), _P, _P, _P]
+        L.mdmm_cat_head_nll_bwd.argtypes = [_P, _P, _P, _P, i64, i64, i32, i32, f32, _P, i32, C.POINTER(C.c_float), _P, _P, _P, _P]
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
         for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp), (7, Bn), (8, Conv),

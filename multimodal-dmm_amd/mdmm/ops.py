@@ -1172,6 +1172,58 @@ def nll_categorical(probs, x, mask=None, lead_dims=2, weight=1.0, into=None):
                                       float(weight), into), into)
 
 
+class _CatHeadNllFn(torch.autograd.Function):
+    """CategoricalMLP.h_to_out (Linear + Softmax, common.py:9-23) + losses.nll_categorical (losses.py:44-66) in one
+    kernel each way (csrc/cat_head.hip): hid (passes * R, H) -> weight * sum over rows of -probs[label]."""
+
+    @staticmethod
+    def forward(ctx, hid, weight, bias, label, mask, w_scalar, into, passes, pass_weight):
+        _need_gpu(hid, weight, label)
+        h, w, lb = _f32c(hid), _f32c(weight.detach()), _f32c(label).reshape(-1)
+        rows, H = h.shape
+        n_cat = w.shape[0]
+        acc = _term_acc(into, h.device)
+        probs = torch.empty(rows, n_cat, device=h.device, dtype=torch.float32)
+        ctx.pw = None
+        if pass_weight is not None and any(float(x) != 1.0 for x in pass_weight):
+            ctx.pw = (C.c_float * passes)(*[float(x) for x in pass_weight])
+        b = _f32c(bias.detach()) if bias is not None else None
+        _call('mdmm_cat_head_nll_fwd', _ptr(h), _ptr(w), _ptr(b), _ptr(lb), _ptr(mask), rows, lb.numel(), H, n_cat,
+              float(w_scalar), passes, ctx.pw, _ptr(probs), _ptr(acc), tag='cat_head_nll_fwd')
+        ctx.save_for_backward(h, w, lb, probs)
+        ctx.mask, ctx.w_scalar, ctx.passes, ctx.has_bias = mask, float(w_scalar), passes, bias is not None
+        return _term_out(acc, into, h.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w, lb, probs = ctx.saved_tensors
+        rows, H = h.shape
+        n_cat = w.shape[0]
+        gd = _gdev(g)
+        g_hid = torch.empty_like(h)
+        slabs = native.lib().mdmm_cat_head_slabs(rows)
+        slab = torch.empty(slabs, n_cat * H + n_cat, device=h.device, dtype=torch.float32)
+        _call('mdmm_cat_head_nll_bwd', _ptr(h), _ptr(w), _ptr(lb), _ptr(ctx.mask), rows, lb.numel(), H, n_cat,
+              ctx.w_scalar, _ptr(gd), ctx.passes, ctx.pw, _ptr(probs), _ptr(g_hid), _ptr(slab), tag='cat_head_nll_bwd')
+        tot = colsum(slab)
+        gw = tot[:n_cat * H].reshape(n_cat, H)
+        gb = tot[n_cat * H:] if ctx.has_bias else None
+        return g_hid, gw, gb, None, None, None, None, None, None
+
+
+def cat_head_supported(h_dim, n_cat):
+    """The fused head + softmax + loss kernels take this layer shape (A/B: MDMM_CAT_HEAD=0)."""
+    return os.environ.get('MDMM_CAT_HEAD') != '0' and bool(native.lib().mdmm_cat_head_supported(int(h_dim), int(n_cat)))
+
+
+def cat_head_nll(hid, layer, target, mask=None, weight=1.0, into=None, passes=1, pass_weight=None):
+    """nll_categorical(softmax(layer(hid)), target) for the stacked passes of one step: hid (passes * R, H), target
+    (R,) / (T, B, 1) float labels with NaN = missing, mask covers the R rows."""
+    tgt = target.reshape(-1)
+    return _term_done(_CatHeadNllFn.apply(hid, layer.weight, layer.bias, tgt, _row_mask(mask, tgt.numel(), tgt),
+                                          float(weight), into, int(passes), pass_weight), into)
+
+
 def philox_normal(seed, offset, shape, device, offset_dev=None):
     """The eps tensor a sweep with stream id (seed, offset [+ *offset_dev]) draws, materialised."""
     out = torch.empty(tuple(shape), device=device, dtype=torch.float32)

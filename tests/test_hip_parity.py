@@ -1681,3 +1681,34 @@ def test_packs_follow_fused_optimizer_updates(dev, kernel_family, which):
     for a_, b_ in zip(losses[True], losses[False]):
         assert abs(a_ - b_) <= 2e-4 * abs(b_), (losses[True], losses[False])
     assert abs(losses[True][2] - losses[True][0]) > 1e-3 * abs(losses[True][0])      # (the steps did move the loss)
+
+
+@pytest.mark.parametrize('passes,weights', [(1, None), (4, [0.5, 0.5, 0.25, 2.0])])
+def test_categorical_head_kernel_matches_torch(dev, passes, weights):
+    """csrc/cat_head.hip (CategoricalMLP.h_to_out + Softmax + nll_categorical, common.py:9-23, losses.py:44-66) against
+    the stock modules + the reference's loss arithmetic in torch: value, d hid, d W, d b; NaN labels, masked rows,
+    stacked passes with per-pass weights, a ragged last tile."""
+    from mdmm import ops
+    torch.manual_seed(3)
+    R, H, n_cat = 333, 256, 10
+    layer = nn.Linear(H, n_cat).to(dev)
+    hid = torch.relu(torch.randn(passes * R, H, device=dev)).requires_grad_()
+    label = torch.randint(0, n_cat, (R,), device=dev).float()
+    label[::7] = float('nan')
+    mask = (torch.rand(R, device=dev) > 0.2).float()
+    total = ops.LossSum(dev)
+    ops.cat_head_nll(hid, layer, label, mask, weight=10.0, into=total, passes=passes, pass_weight=weights)
+    loss = total.total()
+    (loss * 0.37).backward()
+    got = (float(loss), hid.grad.clone(), layer.weight.grad.clone(), layer.bias.grad.clone())
+    hid.grad = None; layer.zero_grad()
+    probs = torch.softmax(layer(hid), dim=1).reshape(passes, R, n_cat)
+    on = (~torch.isnan(label)) & (mask > 0)
+    idx = torch.nan_to_num(label, nan=0.0).long()
+    picked = probs.gather(2, idx.view(1, R, 1).expand(passes, R, 1)).squeeze(2) * on.float()
+    pw = torch.tensor(weights if weights else [1.0] * passes, device=dev).view(passes, 1)
+    ref = -10.0 * (picked * pw).sum()
+    (ref * 0.37).backward()
+    assert abs(got[0] - float(ref)) <= 1e-5 * abs(float(ref))
+    for a_, b_ in zip(got[1:], (hid.grad, layer.weight.grad, layer.bias.grad)):
+        assert rel_err(a_, b_) < 2e-5
