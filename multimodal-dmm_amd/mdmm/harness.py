@@ -259,11 +259,13 @@ class GraphedElboStep:
         self.g_step.replay()
         if dist.is_available() and dist.is_initialized() and (self.group is not None or dist.get_world_size() > 1):
             # The collective is a stream operation between two replays.  Round 3 put a host wait in front of it
-            # because such operations faulted replayed steps on this ROCm; the cause was the runtime's graph packet
-            # capture (mdmm/__init__.py), with it off 200 replays of cfg3 / cfg4 through this branch (a one-rank RCCL
+            # because such operations faulted replayed steps on this ROCm; the main cause was the runtime's graph packet
+            # capture (mdmm/__init__.py).  With it off, 200 replays of cfg3 / cfg4 through this branch (a one-rank RCCL
             # group, tools/dryrun_allreduce.py, profiles/r04v_dryrun_allreduce.txt) keep bit-identical gradients with
-            # and without the wait, which costs 0.4 ms per step.  MDMM_REPLAY_SYNC=1 brings it back.
-            if os.environ.get('MDMM_REPLAY_SYNC') == '1':
+            # and without the wait (0.4 ms per step) -- but the GPU suite run as ONE process (dozens of graphs captured
+            # and destroyed before this test) aborted in test_graphed_conv_step_through_rccl_world_one without it and
+            # passes with it, so the wait stays the default.  MDMM_REPLAY_SYNC=0 drops it.
+            if os.environ.get('MDMM_REPLAY_SYNC') != '0':
                 torch.cuda.current_stream().synchronize()
             self.bucket.allreduce(self.group)
         self.g_opt.replay()

@@ -1,6 +1,6 @@
 """the N > 1 step on ONE GPU -- a real RCCL group of one rank forces GraphedElboStep.__call__ through its
 all-reduce branch ([graph: step + backward] -> all_reduce of the flat gradient -> [graph: Adam]) for 200 replays of cfg4
-(and cfg3) at B = 256, with (MDMM_REPLAY_SYNC=1; in the r04v record: NO_REPLAY_SYNC=0) and without the host wait in front of the collective; every 50th
+(and cfg3) at B = 256, with (the default; in the r04v record: NO_REPLAY_SYNC=0) and without (MDMM_REPLAY_SYNC=0) the host wait in front of the collective; every 50th
 replay's gradients are compared with the same step run eagerly on the same weights and Philox stream.
 usage: python tools/dryrun_allreduce.py [cfg4|cfg3] [replays]"""
 import os, sys, time
@@ -57,6 +57,6 @@ for it in range(1, n_rep + 1):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print('%s NO_REPLAY_SYNC=%s: %d replays through the all-reduce branch, worst gradient diff %.2e, %.2f ms per step (checks included)'
-      % (name, "0" if os.environ.get("MDMM_REPLAY_SYNC") == "1" else "1", n_rep, worst, 1e3 * dt / n_rep), flush=True)
+      % (name, "1" if os.environ.get("MDMM_REPLAY_SYNC") == "0" else "0", n_rep, worst, 1e3 * dt / n_rep), flush=True)
 assert worst < 1e-5
 dist.destroy_process_group()
