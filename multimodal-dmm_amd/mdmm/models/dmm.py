@@ -15,6 +15,7 @@ state_dict layout and public methods.  What differs is how the work is executed:
 Noise: in-kernel Philox by default; assign `model.noise = ReplayNoise(draws)` to replay
 draws recorded from the reference's `_sample_gauss` in its own call order.
 """
+import contextlib
 import numpy as np
 import os
 
@@ -389,6 +390,30 @@ class MultiDMM(MultiDGTS):
         out = [r.reshape(n, t_max, b_dim, *r.shape[1:]).unbind(0) for r in out]
         return [tuple(r[i] for r in out) for i in range(n)]
 
+    _mod_streams = None
+
+    def _modality_streams(self, n, key='e'):
+        """n - 1 side streams for work that is independent per modality.  Used for the ENCODERS (key 'e': the video and
+        mask pyramids and the label embedding side by side at the head of the step, 29.70 -> 29.45 ms per cfg3 step).
+        The decoders + loss terms of a mode can go the same way (keys 's', 'f') and should not: three conv chains
+        next to each other are SLOWER (smoothing mode alone: 32.0 ms), and a fork from the filtering mode's side stream
+        (a fork inside a fork) ends the graph capture with a segmentation fault in the runtime
+        (profiles/r04ae_ab_mod_streams.txt).  MDMM_MOD_STREAMS = comma list of keys, 0 = none; default 'e'.
+        MDMM_ONE_STREAM=1 also keeps everything on the caller's stream."""
+        which = os.environ.get('MDMM_MOD_STREAMS', 'e')
+        if (which == '0' or os.environ.get('MDMM_ONE_STREAM') == '1' or not self.z0_mean.is_cuda or n < 2):
+            return []
+        if which not in ('1', 'all') and key not in which.split(','):      # (experiments: a subset of 'e', 'f', 's')
+            return []
+        if self._mod_streams is None:
+            self._mod_streams = {}
+        # key: who forks ('e' encoders, 'f' / 's' the two loss terms of a step) -- one set each, made on first use in
+        # the eager warm-up steps (creating a stream inside a graph capture ends it with a segmentation fault here)
+        mine = self._mod_streams.setdefault(key, [])
+        while len(mine) < n - 1:
+            mine.append(torch.cuda.Stream(device=self.z0_mean.device))
+        return mine[:n - 1]
+
     def _cat_head(self, m, z):
         dec = self.dec[m]
         if not (self.dists[m] == 'Categorical' and type(dec) is common.CategoricalMLP and self.plugin_dtype is None
@@ -413,14 +438,15 @@ class MultiDMM(MultiDGTS):
         passes = self._run_passes(enc, pass_mods, t_max, b_dim, mode, sample,
                                   sample_init, flt_particles, smt_particles, kld=kld)
         return self._joint_loss([(passes, 1.0)], targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim,
-                                total=total, kld_into=(kw, kinto), kld_done=kld[3])
+                                total=total, kld_into=(kw, kinto), kld_done=kld[3],
+                                stream_key='f' if mode in FILTER_MODES else 's')
 
     def _passes_loss(self, passes, targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim):
         """The loss of one mode from its passes' (infer, prior, samples): see _mode_loss."""
         return self._joint_loss([(passes, 1.0)], targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim)
 
     def _joint_loss(self, terms, targets, mask, kld_mult, rec_mults, loss_mods, t_max, b_dim, total=None,
-                    kld_into=None, kld_done=False):
+                    kld_into=None, kld_done=False, stream_key='s'):
         """sum over the terms (passes, mult) -- the modes of one step, dmm.py:547-553 -- of
         mult * sum over passes of [kld_mult * KLD + sum_m mult_m * NLL_m]  (dgts.py:119-129, 132-145).
         Every modality is decoded ONCE for all the terms: the passes that score it (two per mode: the multimodal
@@ -442,11 +468,32 @@ class MultiDMM(MultiDGTS):
                 ops.kld_gauss(infer[0], infer[1], prior[0], prior[1], mask_kld, kw * float(mult), kinto)
         zs_all = [t[0][2] for t in terms]
         zs = [z.unbind(0) for z in zs_all]      # per-pass views whose backward is one stack (see _decode_for_loss)
-        for m in self.modalities:
+        scored = [m for m in self.modalities
+                  if rec_mults.get(m, 1.0) != 0 and any(m in mods for mods in loss_mods)]
+        cur = torch.cuda.current_stream() if zs_all[0].is_cuda else None
+        sides = self._modality_streams(len(scored), stream_key) if cur is not None else []
+        used_streams = []
+        for k_m, m in enumerate(scored):
+            # modality k_m's decoder + loss on stream k_m (the first one stays on the caller's stream)
+            st = sides[k_m - 1] if (sides and k_m > 0) else None
+            if st is not None:
+                st.wait_stream(cur)
+                for z in zs_all:
+                    z.record_stream(st)
+                used_streams.append(st)
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                self._score_modality(m, terms, zs, zs_all, targets, mask, rec_mults, loss_mods, t_max, b_dim, total)
+        for st in used_streams:
+            cur.wait_stream(st)
+        return total.total()
+
+    def _score_modality(self, m, terms, zs, zs_all, targets, mask, rec_mults, loss_mods, t_max, b_dim, total):
+        """Decode modality m for every pass that scores it and add its weighted NLL terms to `total`."""
+        if True:
             mult = rec_mults.get(m, 1.0)
             used = [p for p, mods in enumerate(loss_mods) if m in mods]
             if mult == 0 or not used:
-                continue
+                return
             if self._fused_nll(m, zs_all[0]):
                 # stock GaussianMLP decoder scored by nll_gauss: one launch each way, the
                 # reconstruction itself is never written (csrc/mlp.hip, NLL head)
@@ -457,7 +504,7 @@ class MultiDMM(MultiDGTS):
                         z = torch.stack([zs[i][p] for p in used])
                     ops.gauss_mlp_nll(z.reshape(-1, self.z_dim), self.dec[m], targets[m], mask,
                                       weight=float(mult) * float(tmult), into=total)
-                continue
+                return
             z_list = [zs[i][p] for i in range(len(terms)) for p in used]
             w_list = [float(tmult) for _, tmult in terms for _ in used]
             if self._cat_head(m, z_list[0]) and len(z_list) <= 8:
@@ -468,19 +515,18 @@ class MultiDMM(MultiDGTS):
                 hid = self._plug(common.mlp_trunk_relu, z, layer=dec.in_to_h[0])
                 ops.cat_head_nll(hid, dec.h_to_out[0], targets[m], mask, weight=float(mult), into=total,
                                  passes=len(z_list), pass_weight=w_list)
-                continue
+                return
             if self._logit_decoder(m):      # sigmoid + BCE + masks in one pass each way
                 stacked = self._decode_for_loss(m, z_list, logits=True, stacked=True) if len(z_list) <= 8 else None
                 if stacked is not None:     # the passes as one batch: scored in place, one gradient buffer
                     ops.nll_bernoulli_logits(stacked[0], targets[m], mask, 2, float(mult), total, passes=len(z_list),
                                              pass_weight=w_list)
-                    continue
+                    return
                 for rec, w in zip(self._decode_for_loss(m, z_list, logits=True), w_list):
                     ops.nll_bernoulli_logits(rec[0], targets[m], mask, 2, float(mult) * w, total)
-                continue
+                return
             for rec, w in zip(self._decode_for_loss(m, z_list), w_list):
                 self._nll(m, rec, targets[m], mask, weight=float(mult) * w, into=total)
-        return total.total()
 
     def step(self, inputs, mask, kld_mult, rec_mults, targets=None, uni_loss=True, **kwargs):
         """Bidirectional training step, dmm.py:503-554 (see the module docstring for how the
@@ -550,7 +596,21 @@ class MultiDMM(MultiDGTS):
                 loss_m = _EagerGradFn.apply(match_loss, self.z0_mean, self.z0_log_std,
                                             *self._gtf('fwd'), *self._gtf('bwd'))
             loss_m.record_stream(torch.cuda.current_stream())
-        enc = {m: self._encode_one(m, inputs[m]) for m in self.modalities if m in inputs}
+        present = [m for m in self.modalities if m in inputs]
+        enc, e_cur = {}, torch.cuda.current_stream()
+        e_sides = self._modality_streams(len(present))
+        for k_m, m in enumerate(present):        # every modality's encoder on a stream of its own (_modality_streams)
+            st = e_sides[k_m - 1] if (e_sides and k_m > 0) else None
+            if st is not None:
+                st.wait_stream(e_cur)
+                inputs[m].record_stream(st)
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                enc[m] = self._encode_one(m, inputs[m])
+            if st is not None:
+                for x in enc[m]:
+                    x.record_stream(e_cur)
+        for st in e_sides[:max(0, len(present) - 1)]:
+            e_cur.wait_stream(st)
         # fp32 row masks for all the loss reductions of the step, made once (both streams read them)
         mask_f = mask.to(torch.float32).reshape(-1)
         mask_kld = mask_f.repeat(len(pass_mods)) if len(pass_mods) > 1 else mask_f
@@ -589,7 +649,7 @@ class MultiDMM(MultiDGTS):
                 with torch.cuda.stream(side):
                     box['loss'] = f_mult * self._joint_loss([(passes_f, 1.0)], targets, (mask_f, mask_kld), kld_mult,
                                                             rec_mults, loss_mods, t_max, b_dim, total=total_f,
-                                                            kld_into=(kw_f, kinto_f), kld_done=True)
+                                                            kld_into=(kw_f, kinto_f), kld_done=True, stream_key='f')
 
             total_s = ops.LossSum(self.z0_mean.device)
             kw_s, kinto_s = ops.weighted_into(total_s, kld_mult)

@@ -1097,13 +1097,13 @@ class _NllBernLogitsFn(torch.autograd.Function):
 
 # Per-channel sums of a gradient tensor that its producer had at hand, for the consumer that needs them as a bias
 # gradient (the last Deconv behind the Bernoulli loss): keyed by the tensor's address, the tensor itself kept alive
-# with the entry (so that address cannot be handed to another tensor); at most two entries wait, dropped by
+# with the entry (so that address cannot be handed to another tensor); at most eight entries wait, dropped by
 # clear_caches.  A miss (copied gradient, other consumer) is the consumer's own column sum.
 _GRAD_CHANSUM = {}
 
 
 def _stash_chansum(g, sums):
-    while len(_GRAD_CHANSUM) >= 2:
+    while len(_GRAD_CHANSUM) >= 8:        # (several decoders' backward passes may be in flight on their own streams)
         _GRAD_CHANSUM.pop(next(iter(_GRAD_CHANSUM)))
     _GRAD_CHANSUM[g.data_ptr()] = (g, sums)
 
