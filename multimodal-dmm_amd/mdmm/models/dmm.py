@@ -400,7 +400,9 @@ class MultiDMM(MultiDGTS):
         (a fork inside a fork) ends the graph capture with a segmentation fault in the runtime
         (profiles/r04ae_ab_mod_streams.txt).  MDMM_MOD_STREAMS = comma list of keys, 0 = none; default 'e'.
         MDMM_ONE_STREAM=1 also keeps everything on the caller's stream."""
-        which = os.environ.get('MDMM_MOD_STREAMS', 'e')
+        which = os.environ.get('MDMM_MOD_STREAMS', 'e' if self.conv_dtype is torch.bfloat16 else '0')
+        # (own conv kernels only: with the library's fp32 convolutions the encoders side by side are SLOWER, the
+        #  fp32-operand cfg3 step 139 -> 150 ms)
         if (which == '0' or os.environ.get('MDMM_ONE_STREAM') == '1' or not self.z0_mean.is_cuda or n < 2):
             return []
         if which not in ('1', 'all') and key not in which.split(','):      # (experiments: a subset of 'e', 'f', 's')
