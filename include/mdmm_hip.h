@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 22
+#define MDMM_ABI_VERSION 23
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -539,6 +539,9 @@ typedef struct mdmm_bn {
                           * stock module (one per pass, dgts.py:132-145) as one launch.  One rank; phase 0 or MDMM_BN_FINALIZE.  */
   const double* global_sums;
   double global_count;
+  int32_t partial_splits; /* mdmm_bn_relu_bwd, phase = MDMM_BN_APPLY without global_sums: `partial` holds this many slabs per
+                           * (group, channel) instead of `splits` (the producer's workgroups: mdmm_conv_t.bst_part); 0 = splits */
+  int32_t reserved;
 } mdmm_bn_t;
 #define MDMM_BN_STATS 1
 #define MDMM_BN_APPLY 2
@@ -593,6 +596,16 @@ typedef struct mdmm_conv {
    * MDMM_BN_FINALIZE_GIVEN and splits = mdmm_conv_up_parts.  NULL: none.  */
   double* out_stats;
   int32_t out_group_n, reserved;
+  /* mdmm_conv_wgrad with in_mean on the SMALL side (a Deconv's weight gradient, small = the pre-normalisation output x
+   * of the block in front, bf16 sides): the REDUCTION pass of that block's BatchNorm adjoint (mdmm_bn_relu_bwd, phase
+   * MDMM_BN_STATS) out of this launch, which stages every element of x anyway.  bst_dy = the gradient of the
+   * normalised activation (N, CS, S, S) bf16 (the Deconv's input gradient, mdmm_conv_down).  Every workgroup leaves
+   * (sum g, sum g xhat), g = dy [bn(x) > 0] (in_relu bit 0), xhat = (x - in_mean) in_invstd, of its images in
+   * bst_part[((grp * CS + c) * mdmm_conv_wgrad_parts(args) + workgroup) * 2 + {0, 1}] (zeros for groups it held no
+   * image of); the caller hands that buffer to mdmm_bn_relu_bwd as `partial` with phase = MDMM_BN_APPLY and
+   * partial_splits = mdmm_conv_wgrad_parts(args).  NULL bst_dy: none.  */
+  const void* bst_dy;
+  double* bst_part;
 } mdmm_conv_t;
 int mdmm_conv_supported(const mdmm_conv_t* args);
 int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* args, int up);
@@ -614,6 +627,7 @@ int mdmm_conv_up_parts(const mdmm_conv_t* args);     /* workgroups of that launc
 int mdmm_conv_down_parts(const mdmm_conv_t* args);   /* the same for mdmm_conv_down with in_mean / out_stats */
 int mdmm_conv_down(const mdmm_conv_t* args, void* stream);
 int64_t mdmm_conv_wgrad_ws_bytes(const mdmm_conv_t* args);
+int mdmm_conv_wgrad_parts(const mdmm_conv_t* args);  /* workgroups of mdmm_conv_wgrad = partial slabs of bst_part */
 int mdmm_conv_wgrad(const mdmm_conv_t* args, void* ws, float* dw, void* stream);
 
 /* Stride-2 1-D convolution pyramids of the audio plug-ins (common.py:177-219, 221-290): AudioConv =

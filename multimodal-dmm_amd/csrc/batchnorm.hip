@@ -292,28 +292,36 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
                                                           const double* __restrict__ partial,
                                                           T* __restrict__ dx, float* dgamma,
                                                           float* dbeta, const double* __restrict__ gsum,
-                                                          double gcount) {
+                                                          double gcount, int psplits) {
+  __shared__ double sh[2 * NT / 64];
   const int c = blockIdx.x;
   const int grp = blockIdx.z, n_grp = gridDim.z;
+  // psplits = 0: the slabs of this call's own reduction pass (one per workgroup row: a short loop in every thread);
+  // > 0: the slabs a producer's workgroups left (mdmm_conv_t.bst_part: up to a thousand): summed by the workgroup
+  const int ns = psplits > 0 ? psplits : (int)gridDim.y;
   auto sums_of = [&](int gi, double& d1, double& d2) {
-    const double* p = partial + (size_t)gi * C * gridDim.y * 2;
+    const double* p = partial + ((size_t)gi * C + c) * ns * 2;
     d1 = 0; d2 = 0;
-    for (int s = 0; s < (int)gridDim.y; ++s) {
-      d1 += p[((size_t)c * gridDim.y + s) * 2];
-      d2 += p[((size_t)c * gridDim.y + s) * 2 + 1];
+    if (psplits > 0) {
+      for (int s = threadIdx.x; s < ns; s += NT) { d1 += p[2 * s]; d2 += p[2 * s + 1]; }
+      block_sum2(d1, d2, sh);
+    } else {
+      for (int s = 0; s < ns; ++s) { d1 += p[2 * s]; d2 += p[2 * s + 1]; }
     }
   };
   double d1, d2;
   sums_of(grp, d1, d2);
-  if (blockIdx.y == 0 && threadIdx.x == 0 && grp == 0) {     // this rank's part of the parameter gradients
+  if (blockIdx.y == 0 && grp == 0 && (psplits > 0 || threadIdx.x == 0)) {     // this rank's part of the parameter gradients
     double t1 = d1, t2 = d2;                     // (the affine parameters are shared by the groups)
     for (int gi = 1; gi < n_grp; ++gi) {
       double e1, e2;
       sums_of(gi, e1, e2);
       t1 += e1; t2 += e2;
     }
-    if (dgamma) dgamma[c] = (float)t2;
-    if (dbeta) dbeta[c] = (float)t1;
+    if (threadIdx.x == 0) {
+      if (dgamma) dgamma[c] = (float)t2;
+      if (dbeta) dbeta[c] = (float)t1;
+    }
   }
   if (gsum) { d1 = gsum[2 * c]; d2 = gsum[2 * c + 1]; }      // means over the GLOBAL batch
   const double M = gsum ? gcount : (double)N * (double)L;
@@ -367,7 +375,9 @@ int check(const mdmm_bn_t* a) {
   if (a->splits < 1 || a->splits > 65535) return MDMM_E_ARG;
   if (a->phase < 0 || a->phase > MDMM_BN_FINALIZE_GIVEN) return MDMM_E_ARG;
   if (a->global_sums && !(a->global_count >= 1.0)) return MDMM_E_ARG;
-  if (a->groups < 0 || a->groups > 65535 || (a->groups > 1 && ((a->phase != 0 && a->phase < MDMM_BN_FINALIZE) || a->global_sums))) return MDMM_E_ARG;
+  if (a->partial_splits < 0 || a->partial_splits > (1 << 20)) return MDMM_E_ARG;
+  if (a->groups < 0 || a->groups > 65535 || (a->groups > 1 && ((a->phase != 0 && a->phase < MDMM_BN_FINALIZE &&
+                                                                  !(a->phase == MDMM_BN_APPLY && a->partial_splits > 0)) || a->global_sums))) return MDMM_E_ARG;
   return 0;
 }
 
@@ -408,7 +418,8 @@ void launch_bwd(const mdmm_bn_t* a, hipStream_t st) {
   if (a->phase != MDMM_BN_STATS)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->dy, (const T*)a->x, a->N, a->C,
                        a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial, (T*)a->dx,
-                       a->dgamma, a->dbeta, a->global_sums, a->global_count);
+                       a->dgamma, a->dbeta, a->global_sums, a->global_count,
+                       (a->phase == MDMM_BN_APPLY && !a->global_sums) ? a->partial_splits : 0);
 }
 
 }  // namespace

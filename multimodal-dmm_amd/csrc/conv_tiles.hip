@@ -602,12 +602,20 @@ struct Wg {
 __device__ __forceinline__ uint32_t shift16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbyte(hi, lo, 2); }
 
 // NORM: 1 = the SMALL side is the layer's input in pre-normalisation form (Deconv), 2 = the BIG side is (Conv)
-template <int S, int CS, int CB, int KS, bool SB, bool BB, int NORM = 0>
+// BST (with NORM = 1): the reduction pass of that normalisation's adjoint on the way -- the kernel stages every element
+// x of the small side anyway; with the gradient of the normalised activation (mdmm_conv_t.bst_dy) fetched beside it,
+// (sum g, sum g xhat), g = dy [bn(x) > 0], are per-thread sums over the elements a thread stages (always the same
+// channel), folded per workgroup in LDS (batchnorm.hip, bn_bwd_stats_kernel: the same arithmetic per element)
+template <int S, int CS, int CB, int KS, bool SB, bool BB, int NORM = 0, bool BST = false>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, float* part, int NT) {
   using G = Shape<S, CS, CB>;
   using W = Wg<S, CS, CB, KS>;
+  static_assert(!BST || (NORM == 1 && SB), "the adjoint's sums: bf16 small side in pre-normalisation form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const ntab = reinterpret_cast<float*>(smem + ((W::LDS + 15) & ~15));
+  // BST: [group][mean | invstd][channel] and the workgroup's sums [group][channel][2] behind the scale / shift table
+  float* const mtab = ntab + NORM_GROUPS * 2 * (CS > CB ? CS : CB);
+  double* const gacc = reinterpret_cast<double*>(mtab + NORM_GROUPS * 2 * CS);
   char* sm = smem;
   char* pl = smem + W::SM_LDS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, cb = a.CB;
@@ -626,6 +634,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   for (int i = threadIdx.x; i < W::LDS / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = uint4{0, 0, 0, 0};
   if constexpr (NORM == 1) norm_table<CS>(a, ntab, 512);
   if constexpr (NORM == 2) norm_table<CB>(a, ntab, 512);
+  if constexpr (BST) {
+    const int groups = (a.N + a.in_group_n - 1) / a.in_group_n;
+    for (int i = threadIdx.x; i < groups * CS; i += 512) {
+      const int g = i / CS, c = i % CS;
+      mtab[(2 * g) * CS + c] = a.in_mean[i];
+      mtab[(2 * g + 1) * CS + c] = a.in_invstd[i];
+    }
+    for (int i = threadIdx.x; i < NORM_GROUPS * CS * 2; i += 512) gacc[i] = 0.0;
+  }
   // per job: this lane's column -> byte offset of its plane rows (or -1) and its shift (-1, 0, +1)
   int col_off[MAXJ], col_sh[MAXJ];
   bool mt_of[MAXJ];
@@ -661,12 +678,37 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   // workgroup keeps one image in LDS; without this every image would pay the HBM latency in the open)
   constexpr int SM_IT = (CS * NPIX / 8 + 511) / 512, BG_IT = (CB * B2 * (B2 / 8) + 511) / 512;
   bf16x8 rs[SM_IT], rb[BG_IT];
+  bf16x8 rd[BST ? SM_IT : 1];
+  float bs1[BST ? SM_IT : 1], bs2[BST ? SM_IT : 1];
+  int bst_g = -1;
+  if constexpr (BST) {
+#pragma unroll
+    for (int q = 0; q < SM_IT; ++q) { bs1[q] = 0.f; bs2[q] = 0.f; }
+  }
+  // a thread's sums -> the workgroup's table of group g (a thread's elements are always one channel's)
+  auto bst_flush = [&](int g) {
+    if constexpr (BST) {
+#pragma unroll
+      for (int q = 0; q < SM_IT; ++q) {
+        const int it = threadIdx.x + 512 * q;
+        if (it < CS * NPIX / 8) {
+          const int ch = it / (NPIX / 8);
+          atomicAdd(&gacc[(g * CS + ch) * 2], (double)bs1[q]);
+          atomicAdd(&gacc[(g * CS + ch) * 2 + 1], (double)bs2[q]);
+        }
+        bs1[q] = 0.f; bs2[q] = 0.f;
+      }
+    }
+  };
   auto fetch = [&](int n) {
     const size_t ssrc = (size_t)n * CS * NPIX, bsrc = (size_t)n * cb * BPIX;
 #pragma unroll
     for (int q = 0; q < SM_IT; ++q) {
       const int it = threadIdx.x + 512 * q;
-      if (it < CS * NPIX / 8) rs[q] = load8<SB>(a.small, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
+      if (it < CS * NPIX / 8) {
+        rs[q] = load8<SB>(a.small, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
+        if constexpr (BST) rd[q] = load8<true>(a.bst_dy, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
+      }
     }
 #pragma unroll
     for (int q = 0; q < BG_IT; ++q) {
@@ -684,10 +726,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
       if (it < CS * NPIX / 8) {
         bf16x8 v = rs[q];
         if constexpr (NORM == 1) {      // the small side is the layer's input: the block in front's BatchNorm + ReLU
-          const float* tab = ntab + (size_t)(n_img / a.in_group_n) * 2 * CS;
+          const int grp = n_img / a.in_group_n;
+          const float* tab = ntab + (size_t)grp * 2 * CS;
           const int ch = it / (NPIX / 8);
           const float sc = tab[ch], sh = tab[CS + ch];
           const bool relu = (a.in_relu & 1) != 0;
+          if constexpr (BST) {
+            const float mean = mtab[(2 * grp) * CS + ch], invstd = mtab[(2 * grp + 1) * CS + ch];
+            const bf16x8 d = rd[q];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float xv = (float)v[j];
+              const float xh = (xv - mean) * invstd;
+              const float gv = (relu && fmaf(xv, sc, sh) <= 0.f) ? 0.f : (float)d[j];
+              bs1[q] += gv; bs2[q] = fmaf(gv, xh, bs2[q]);
+            }
+          }
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = norm1(v[j], sc, sh, relu);
         }
@@ -718,6 +772,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   };
   if ((int)blockIdx.x < a.N) fetch(blockIdx.x);
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
+    if constexpr (BST) {
+      const int g = n / a.in_group_n;
+      if (g != bst_g) {
+        if (bst_g >= 0) bst_flush(bst_g);
+        bst_g = g;
+      }
+    }
     commit(n);
     __syncthreads();
     if (n + (int)gridDim.x < a.N) fetch(n + gridDim.x);
@@ -768,6 +829,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
     }
     __syncthreads();
   }
+  if constexpr (BST) {
+    // this workgroup's slab of every group (zeros where it held no image: the caller need not clear the buffer)
+    if (bst_g >= 0) bst_flush(bst_g);
+    __syncthreads();
+    const int groups = (a.N + a.in_group_n - 1) / a.in_group_n;
+    for (int i = threadIdx.x; i < groups * CS; i += 512) {
+      double* o = a.bst_part + ((size_t)i * gridDim.x + blockIdx.x) * 2;
+      o[0] = gacc[2 * i]; o[1] = gacc[2 * i + 1];
+    }
+  }
   // fold the contraction splits of the workgroup through LDS, then one slab per workgroup
   if (ksplit > 1) {
     float* red = reinterpret_cast<float*>(smem);
@@ -783,7 +854,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
     }
   }
   if (idle || my_ks > 0) return;
-  // slab of this workgroup, already in dW's layout [cs][b][ky][kx]
+  // slab of this workgroup as [cs][tap][b]: a half-wave's 32 columns are 128 contiguous bytes (in dW's own layout
+  // [cs][b][ky][kx] every lane wrote four bytes of a different 64-byte line, sixteen times over: 33 k partial-line
+  // writes per workgroup at S = 8); the last fold pass moves the sums into dW's layout (conv_fold_kernel, perm_cb)
   float* out = part + (size_t)blockIdx.x * CS * NCOL;
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
@@ -791,17 +864,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
     if (job >= jobs) break;
     const int nt = job % NT, mt = job / NT, col = 32 * nt + (lane & 31);
     if (col >= NCOL) continue;
-    const int tap = col / cb, b = col % cb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = 32 * mt + acc_row(r) + 4 * h;
-      if (m < CS) out[(size_t)m * NCOL + b * (KS * KS) + tap] = acc[j][r];
+      if (m < CS) out[(size_t)m * NCOL + col] = acc[j][r];
     }
   }
 }
 
-// dst[g][e] = sum over p = g, g + groups, ... of src[p][e]
-__global__ void conv_fold_kernel(const float* src, int parts, int64_t elems, int groups, float* dst) {
+// dst[g][e] = sum over p = g, g + groups, ... of src[p][e]; perm_cb > 0 (last pass, groups = 1): element e of a slab is
+// (cs, tap, b) = (e / (kk perm_cb), ...) and lands at dW's [cs][b][tap]
+__global__ void conv_fold_kernel(const float* src, int parts, int64_t elems, int groups, float* dst, int perm_cb, int kk) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
   if (e >= elems) return;
@@ -815,7 +888,12 @@ __global__ void conv_fold_kernel(const float* src, int parts, int64_t elems, int
     s3 += src[(size_t)(p + 3 * groups) * elems + e];
   }
   for (; p < parts; p += groups) s0 += src[(size_t)p * elems + e];
-  dst[(size_t)g * elems + e] = (s0 + s1) + (s2 + s3);
+  int64_t at = e;
+  if (perm_cb > 0) {
+    const int ncol = kk * perm_cb, col = (int)(e % ncol);
+    at = (e / ncol) * ncol + (int64_t)(col % perm_cb) * kk + col / perm_cb;
+  }
+  dst[(size_t)g * elems + at] = (s0 + s1) + (s2 + s3);
 }
 
 int shape_id(const mdmm_conv_t* a) {
@@ -972,6 +1050,15 @@ int run_wgrad_norm(const mdmm_conv_t* a, float* part, hipStream_t st) {
   if (io_of(a) != 1 || !norm_ok(a)) return MDMM_E_ARG;
   constexpr int lds = ((W::LDS + 15) & ~15) + NORM_LDS(CS > CB ? CS : CB);
   const bool big = (a->in_relu & 2) != 0;        // which side is the layer's input
+  if (a->bst_dy) {                               // + the small side's BatchNorm adjoint sums (bst_part)
+    if (big || !a->bst_part || !a->in_mean) return MDMM_E_ARG;
+    constexpr int lds_b = lds + NORM_LDS(CS) + NORM_GROUPS * CS * 2 * 8;
+    auto kb = conv_wgrad_kernel<S, CS, CB, KS, true, true, 1, true>;
+    int rc = set_lds(kb, lds_b);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kb, dim3(wgrad_parts(a)), dim3(512), lds_b, st, *a, part, wgrad_nt(a));
+    return (int)hipGetLastError();
+  }
   auto k = big ? conv_wgrad_kernel<S, CS, CB, KS, true, true, 2> : conv_wgrad_kernel<S, CS, CB, KS, true, true, 1>;
   int rc = set_lds(k, lds);
   if (rc) return rc;
@@ -980,6 +1067,7 @@ int run_wgrad_norm(const mdmm_conv_t* a, float* part, hipStream_t st) {
 }
 template <int S, int CS, int CB, int KS>
 int run_wgrad(const mdmm_conv_t* a, float* part, hipStream_t st) {
+  if (a->bst_dy && !a->in_mean) return MDMM_E_ARG;
   if (a->in_mean) return run_wgrad_norm<S, CS, CB, KS>(a, part, st);
   switch (io_of(a)) {
     case 0: return run_wgrad_io<S, CS, CB, KS, false, false>(a, part, st);
@@ -1082,6 +1170,8 @@ extern "C" int mdmm_conv_down(const mdmm_conv_t* a, void* stream) {
   return run_down<32, 16, 4, 3>(a, st);
 }
 
+extern "C" int mdmm_conv_wgrad_parts(const mdmm_conv_t* a) { return shape_id(a) < 0 ? 0 : wgrad_parts(a); }
+
 extern "C" int64_t mdmm_conv_wgrad_ws_bytes(const mdmm_conv_t* a) {
   if (shape_id(a) < 0) return 0;
   return (int64_t)(wgrad_parts(a) + WGRAD_FOLD) * a->CS * a->CB * a->KS * a->KS * 4;
@@ -1109,10 +1199,10 @@ extern "C" int mdmm_conv_wgrad(const mdmm_conv_t* a, void* ws, float* dw, void* 
   const unsigned blocks = (unsigned)((elems + 255) / 256);
   if (parts > 4 * WGRAD_FOLD) {
     float* folded = part + (size_t)parts * elems;
-    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, WGRAD_FOLD), dim3(256), 0, st, part, parts, elems, WGRAD_FOLD, folded);
-    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, 1), dim3(256), 0, st, folded, WGRAD_FOLD, elems, 1, dw);
+    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, WGRAD_FOLD), dim3(256), 0, st, part, parts, elems, WGRAD_FOLD, folded, 0, 0);
+    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, 1), dim3(256), 0, st, folded, WGRAD_FOLD, elems, 1, dw, a->CB, a->KS * a->KS);
   } else {
-    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, 1), dim3(256), 0, st, part, parts, elems, 1, dw);
+    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, 1), dim3(256), 0, st, part, parts, elems, 1, dw, a->CB, a->KS * a->KS);
   }
   return (int)hipGetLastError();
 }

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 22
+ABI_VERSION = 23
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -33,7 +33,7 @@ SYMBOLS = [
     'mdmm_gauss_mlp_supported', 'mdmm_gauss_mlp_dw_width', 'mdmm_gauss_mlp_dw_rows',
     'mdmm_gauss_mlp_fwd', 'mdmm_gauss_mlp_bwd',
     'mdmm_bn_splits', 'mdmm_bn_relu_fwd', 'mdmm_bn_relu_bwd',
-    'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_pack_batch', 'mdmm_lin_pack_batch', 'mdmm_conv_up', 'mdmm_conv_up_parts', 'mdmm_conv_down_parts', 'mdmm_conv_down',
+    'mdmm_conv_supported', 'mdmm_conv_pack_bytes', 'mdmm_conv_pack', 'mdmm_conv_pack_batch', 'mdmm_lin_pack_batch', 'mdmm_conv_up', 'mdmm_conv_up_parts', 'mdmm_conv_down_parts', 'mdmm_conv_down', 'mdmm_conv_wgrad_parts',
     'mdmm_conv_wgrad_ws_bytes', 'mdmm_conv_wgrad',
     'mdmm_gemm_supported', 'mdmm_gemm_split', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16', 'mdmm_gemm_f32',
     'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
@@ -130,7 +130,8 @@ class Bn(C.Structure):
                 [('eps', C.c_float), ('momentum', C.c_float)] +
                 [(n, _P) for n in ('x', 'gamma', 'beta', 'running_mean', 'running_var', 'y', 'save_mean',
                                    'save_invstd', 'dy', 'dx', 'dgamma', 'dbeta', 'partial', 'mean_shift')] +
-                [('phase', C.c_int32), ('groups', C.c_int32), ('global_sums', _P), ('global_count', C.c_double)])
+                [('phase', C.c_int32), ('groups', C.c_int32), ('global_sums', _P), ('global_count', C.c_double),
+                 ('partial_splits', C.c_int32), ('reserved', C.c_int32)])
 
 
 BN_STATS, BN_APPLY, BN_FINALIZE, BN_FINALIZE_GIVEN = 1, 2, 3, 4
@@ -159,7 +160,8 @@ class Conv(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB', 'KS', 'flags')] +
                 [(n, _P) for n in ('small', 'big', 'wfrag', 'bias', 'in_mean', 'in_invstd', 'in_gamma', 'in_beta')] +
                 [('in_group_n', C.c_int32), ('in_relu', C.c_int32), ('out_stats', _P), ('out_group_n', C.c_int32),
-                 ('reserved', C.c_int32)])
+                 ('reserved', C.c_int32)] +
+                [('bst_dy', _P), ('bst_part', _P)])
 
 
 class Conv1d(C.Structure):
@@ -312,6 +314,7 @@ def lib():
         L.mdmm_conv_up.argtypes = [C.POINTER(Conv), _P]
         L.mdmm_conv_up_parts.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_down_parts.argtypes = [C.POINTER(Conv)]
+        L.mdmm_conv_wgrad_parts.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_down.argtypes = [C.POINTER(Conv), _P]
         L.mdmm_conv_wgrad_ws_bytes.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_wgrad_ws_bytes.restype = C.c_int64

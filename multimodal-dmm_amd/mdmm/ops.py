@@ -2251,6 +2251,7 @@ class _BnDeconvFn(torch.autograd.Function):
         c = _conv_desc(N, small.shape, big.shape, ks)
         c.flags = _conv_flags(small, big)
         need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        bst_part = None
         if need_x:
             dyn = torch.empty_like(x)               # gradient of the normalised activation
             c.small, c.big = (_ptr(dyn), _ptr(gy)) if transposed else (_ptr(gy), _ptr(dyn))
@@ -2262,6 +2263,14 @@ class _BnDeconvFn(torch.autograd.Function):
             c.small, c.big, c.wfrag = _ptr(small), _ptr(big), None
             c.in_mean, c.in_invstd, c.in_gamma, c.in_beta = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(g), _ptr(b)
             c.in_group_n, c.in_relu = Ng, (1 if transposed else 3)      # (bit 1: the input is the big side)
+            # (not at 8 x 8: ten more registers take that kernel from two workgroups per CU to one)
+            if need_x and transposed and G <= 8 and os.environ.get('MDMM_BN_BWD_STATS_FUSED', '1') != '0' \
+                    and (c.S >= 16 or os.environ.get('MDMM_BN_BWD_STATS_FUSED') == '2'):
+                # the reduction pass of the BatchNorm adjoint rides on the weight-gradient kernel, which stages every
+                # element of x anyway: dyn is read beside it once instead of (dyn, x) in a pass of their own
+                bst_splits = native.lib().mdmm_conv_wgrad_parts(C.byref(c))
+                bst_part = torch.empty(G * Cc * bst_splits * 2, device=x.device, dtype=torch.float64)
+                c.bst_dy, c.bst_part = _ptr(dyn), _ptr(bst_part)
             ws = torch.empty(native.lib().mdmm_conv_wgrad_ws_bytes(C.byref(c)), device=x.device, dtype=torch.uint8)
             gw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
             _call('mdmm_conv_wgrad', C.byref(c), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % c.S)
@@ -2274,11 +2283,15 @@ class _BnDeconvFn(torch.autograd.Function):
             a.N, a.C, a.L, a.relu, a.splits, a.eps, a.groups = Ng, Cc, Ln, 1, splits, eps, G
             a.bf16_io = 1
             dx = torch.empty_like(x)
-            part = torch.empty(G * Cc * splits * 2, device=x.device, dtype=torch.float64)
+            if bst_part is not None:
+                part = bst_part
+                a.phase, a.partial_splits = native.BN_APPLY, bst_splits
+            else:
+                part = torch.empty(G * Cc * splits * 2, device=x.device, dtype=torch.float64)
             a.x, a.gamma, a.beta, a.dy, a.dx = _ptr(x), _ptr(g), _ptr(b), _ptr(dyn), _ptr(dx)
             a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
             a.dgamma, a.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
-            _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=x.numel() * x.element_size() * 5)
+            _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=x.numel() * x.element_size() * (3 if bst_part is not None else 5))
         return (dx, dgb[0] if (need_x and ctx.needs_input_grad[1]) else None,
                 dgb[1] if (need_x and ctx.needs_input_grad[2]) else None, None, shift_grad, gw, gb, None, None, None)
 

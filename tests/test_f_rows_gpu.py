@@ -428,6 +428,9 @@ def test_deferred_batchnorm_in_deconv_equals_materialised(dev, groups, monkeypat
     ref = C.ImageDecoder(256, n_channels=3).to(dev).train()
     z = torch.randn(groups * 520, 256, device=dev)         # (>= 512 rows: the heads' own GEMM and its ReLU epilogue)
     res = []
+    # (the adjoint's sums by their own pass in every leg: out of the weight-gradient kernel they are added in another
+    #  order -- test_batchnorm_adjoint_sums_out_of_the_weight_gradient_kernel)
+    monkeypatch.setenv('MDMM_BN_BWD_STATS_FUSED', '0')
     for deconv, epilogue in (('1', '1'), ('1', '0'), ('0', '0')):
         dec = copy.deepcopy(ref)
         monkeypatch.setenv('MDMM_BN_DECONV', deconv)
@@ -455,6 +458,42 @@ def test_deferred_batchnorm_in_deconv_equals_materialised(dev, groups, monkeypat
             assert l2(a_, b_) < 2e-3, k
     for k in se:
         assert helpers.rel_err(se[k].float(), sb[k].float()) < 1e-5, k
+
+
+@pytest.mark.parametrize('groups', [1, 3])
+def test_batchnorm_adjoint_sums_out_of_the_weight_gradient_kernel(dev, groups, monkeypatch):
+    """_BnDeconvFn.backward: the reduction pass of the BatchNorm adjoint (sum g, sum g xhat) riding on the Deconv's
+    weight-gradient kernel, which stages every element of the BatchNorm's input anyway (mdmm_conv_t.bst_dy,
+    MDMM_BN_BWD_STATS_FUSED=1: the default; =2: at 8 x 8 too when that layer has a BatchNorm in front) against the
+    separate pass over (g, x) (=0): the same sums in another order -- every gradient to 1e-5 (L2), BatchNorm affine
+    gradients included."""
+    import copy
+    from mdmm import ops
+    from mdmm.models import common as C
+    torch.manual_seed(5 + groups)
+    ref = C.ImageDecoder(256, n_channels=3).to(dev).train()
+    z = torch.randn(groups * 530, 256, device=dev)
+    res = {}
+    for mode in ('0', '1', '2'):
+        dec = copy.deepcopy(ref)
+        monkeypatch.setenv('MDMM_BN_BWD_STATS_FUSED', mode)
+        zi = z.clone().requires_grad_()
+        with ops.conv_operands(torch.bfloat16, torch.bfloat16), ops.bn_groups(groups):
+            out = dec(zi, logits=True)[0]
+        gy = torch.randn(out.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).to(out.dtype)
+        res[mode] = (out, torch.autograd.grad(out, [zi] + list(dec.parameters()), gy, allow_unused=True))
+    names = ['z'] + [k for k, _ in ref.named_parameters()]
+    l2 = lambda a_, b_: float((a_.float() - b_.float()).norm() / (b_.float().norm() + 1e-30))      # noqa: E731
+    worst = 0.0
+    for mode in ('1', '2'):
+        assert torch.equal(res[mode][0], res['0'][0])
+        for k, a_, b_ in zip(names, res[mode][1], res['0'][1]):
+            assert (a_ is None) == (b_ is None), k
+            if a_ is not None:
+                e = l2(a_, b_)
+                worst = max(worst, e)
+                assert e < 1e-5, (mode, k, e)
+    helpers.note('bn_adjoint_sums_fused.l2[groups=%d]' % groups, worst)
 
 
 def test_deferred_batchnorm_in_encoder_convs(dev, monkeypatch):

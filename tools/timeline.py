@@ -41,6 +41,22 @@ def short(n):
     return n.split('(')[0][:46]
 
 
+# how much of the wall no kernel at all is on the device (launch gaps of the chain), and the chain's longest idle gaps
+cover, cur_s, cur_e, idle = 0, step[0][0], step[0][1], []
+for s, e, n, _ in step[1:]:
+    if s > cur_e:
+        cover += cur_e - cur_s
+        idle.append((s - cur_e, cur_e - t0, short(n)))
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+cover += cur_e - cur_s
+print('device busy (any kernel) %.2f ms of %.2f ms wall; %d idle gaps, total %.2f ms; gaps >= 20 us: %d (%.2f ms)' % (
+    cover / 1e6, (t1 - t0) / 1e6, len(idle), sum(g for g, _, _ in idle) / 1e6,
+    sum(1 for g, _, _ in idle if g >= 20000), sum(g for g, _, _ in idle if g >= 20000) / 1e6))
+for g, at, n in sorted(idle, reverse=True)[:12]:
+    print('   idle %.1f us at %.2f ms, before %s' % (g / 1e3, at / 1e6, n))
+
 nb = int((t1 - t0) / 1e6 / bin_ms) + 1
 for b in range(nb):
     a, z = t0 + b * bin_ms * 1e6, t0 + (b + 1) * bin_ms * 1e6
