@@ -614,8 +614,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const ntab = reinterpret_cast<float*>(smem + ((W::LDS + 15) & ~15));
   // BST: [group][mean | invstd][channel] and the workgroup's sums [group][channel][2] behind the scale / shift table
-  float* const mtab = ntab + NORM_GROUPS * 2 * (CS > CB ? CS : CB);
-  double* const gacc = reinterpret_cast<double*>(mtab + NORM_GROUPS * 2 * CS);
+  // (tables of the launch's own group count: with eight groups' worth S = 16 / 32 would not fit two workgroups per CU)
+  const int n_groups = NORM ? (a.N + a.in_group_n - 1) / a.in_group_n : 0;
+  float* const mtab = ntab + n_groups * 2 * (CS > CB ? CS : CB);
+  double* const gacc = reinterpret_cast<double*>(mtab + n_groups * 2 * CS);
   char* sm = smem;
   char* pl = smem + W::SM_LDS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, cb = a.CB;
@@ -625,7 +627,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   const int ksplit = jobs >= 8 ? 1 : 8 / jobs;
   const int my_ks = jobs >= 8 ? 0 : wave / jobs;
   const bool idle = my_ks >= ksplit;                              // 8 is not a multiple of `jobs`
-  constexpr int MAXJ = 4;
+  // jobs per wave: S = 8 has 2 x 16 (KS = 3: 2 x 9) tiles for eight waves; S = 16 at most eight, S = 32 at most two
+  // (as four everywhere, three accumulator tiles and their branches were dead weight: 136 -> ~90 registers at S = 16)
+  constexpr int MAXJ = S == 8 ? 4 : 1;
   f32x16 acc[MAXJ];
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j)
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
       mtab[(2 * g) * CS + c] = a.in_mean[i];
       mtab[(2 * g + 1) * CS + c] = a.in_invstd[i];
     }
-    for (int i = threadIdx.x; i < NORM_GROUPS * CS * 2; i += 512) gacc[i] = 0.0;
+    for (int i = threadIdx.x; i < groups * CS * 2; i += 512) gacc[i] = 0.0;
   }
   // per job: this lane's column -> byte offset of its plane rows (or -1) and its shift (-1, 0, +1)
   int col_off[MAXJ], col_sh[MAXJ];
@@ -732,21 +736,27 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
           const float sc = tab[ch], sh = tab[CS + ch];
           const bool relu = (a.in_relu & 1) != 0;
           if constexpr (BST) {
+            // one pass per element: the normalised value (norm1's arithmetic) decides the adjoint's ReLU mask too
             const float mean = mtab[(2 * grp) * CS + ch], invstd = mtab[(2 * grp + 1) * CS + ch];
             const bf16x8 d = rd[q];
+            float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const float xv = (float)v[j];
-              const float xh = (xv - mean) * invstd;
-              const float gv = (relu && fmaf(xv, sc, sh) <= 0.f) ? 0.f : (float)d[j];
-              bs1[q] += gv; bs2[q] = fmaf(gv, xh, bs2[q]);
+              const float f = fmaf(xv, sc, sh);
+              const float gv = (relu && f <= 0.f) ? 0.f : (float)d[j];
+              t1 += gv; t2 = fmaf(gv, (xv - mean) * invstd, t2);
+              v[j] = (__bf16)(relu ? fmaxf(f, 0.f) : f);
             }
-          }
+            bs1[q] += t1; bs2[q] += t2;
+          } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = norm1(v[j], sc, sh, relu);
+            for (int j = 0; j < 8; ++j) v[j] = norm1(v[j], sc, sh, relu);
+          }
         }
         *reinterpret_cast<uint4*>(sm + (it / (NPIX / 8)) * W::SM_RS + (it % (NPIX / 8)) * 16) = __builtin_bit_cast(uint4, v);
       }
+      if constexpr (BST) __builtin_amdgcn_sched_barrier(0);     // one vector at a time (interleaved, four vectors' temporaries cost 70 registers)
     }
 #pragma unroll
     for (int q = 0; q < BG_IT; ++q) {
@@ -1048,11 +1058,12 @@ template <int S, int CS, int CB, int KS>
 int run_wgrad_norm(const mdmm_conv_t* a, float* part, hipStream_t st) {
   using W = Wg<S, CS, CB, KS>;
   if (io_of(a) != 1 || !norm_ok(a)) return MDMM_E_ARG;
-  constexpr int lds = ((W::LDS + 15) & ~15) + NORM_LDS(CS > CB ? CS : CB);
+  const int groups = (a->N + a->in_group_n - 1) / a->in_group_n;
+  const int lds = ((W::LDS + 15) & ~15) + groups * 2 * (CS > CB ? CS : CB) * 4;
   const bool big = (a->in_relu & 2) != 0;        // which side is the layer's input
   if (a->bst_dy) {                               // + the small side's BatchNorm adjoint sums (bst_part)
     if (big || !a->bst_part || !a->in_mean) return MDMM_E_ARG;
-    constexpr int lds_b = lds + NORM_LDS(CS) + NORM_GROUPS * CS * 2 * 8;
+    const int lds_b = lds + groups * 2 * CS * 4 + groups * CS * 2 * 8;
     auto kb = conv_wgrad_kernel<S, CS, CB, KS, true, true, 1, true>;
     int rc = set_lds(kb, lds_b);
     if (rc) return rc;

@@ -2263,9 +2263,11 @@ class _BnDeconvFn(torch.autograd.Function):
             c.small, c.big, c.wfrag = _ptr(small), _ptr(big), None
             c.in_mean, c.in_invstd, c.in_gamma, c.in_beta = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(g), _ptr(b)
             c.in_group_n, c.in_relu = Ng, (1 if transposed else 3)      # (bit 1: the input is the big side)
-            # (not at 8 x 8: ten more registers take that kernel from two workgroups per CU to one)
-            if need_x and transposed and G <= 8 and os.environ.get('MDMM_BN_BWD_STATS_FUSED', '1') != '0' \
-                    and (c.S >= 16 or os.environ.get('MDMM_BN_BWD_STATS_FUSED') == '2'):
+            # (at 32 x 32 the gradient's prefetch registers take the kernel from two workgroups per CU to one: alone,
+            #  171 + 110 us apart and 291 us together -- inside the step, next to the other streams' kernels, together is
+            #  0.3 ms per step better; MDMM_BN_BWD_STATS_FUSED=3: at 16 x 16 only, =0: nowhere)
+            mode = os.environ.get('MDMM_BN_BWD_STATS_FUSED', '1')
+            if need_x and transposed and G <= 8 and mode != '0' and (c.S == 16 or mode != '3'):
                 # the reduction pass of the BatchNorm adjoint rides on the weight-gradient kernel, which stages every
                 # element of x anyway: dyn is read beside it once instead of (dyn, x) in a pass of their own
                 bst_splits = native.lib().mdmm_conv_wgrad_parts(C.byref(c))
