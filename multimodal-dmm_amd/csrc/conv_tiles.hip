@@ -682,6 +682,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   // workgroup keeps one image in LDS; without this every image would pay the HBM latency in the open)
   constexpr int SM_IT = (CS * NPIX / 8 + 511) / 512, BG_IT = (CB * B2 * (B2 / 8) + 511) / 512;
   bf16x8 rs[SM_IT], rb[BG_IT];
+  // S = 32: the gradient is fetched where it is used instead of travelling beside x through the contraction (its 16
+  // registers were the difference between one and two workgroups per CU; the other workgroup covers the round trip)
+  constexpr bool BST_LATE = BST && S == 32;
   bf16x8 rd[BST ? SM_IT : 1];
   float bs1[BST ? SM_IT : 1], bs2[BST ? SM_IT : 1];
   int bst_g = -1;
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
       const int it = threadIdx.x + 512 * q;
       if (it < CS * NPIX / 8) {
         rs[q] = load8<SB>(a.small, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
-        if constexpr (BST) rd[q] = load8<true>(a.bst_dy, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
+        if constexpr (BST && !BST_LATE) rd[q] = load8<true>(a.bst_dy, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
       }
     }
 #pragma unroll
@@ -724,6 +727,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
     }
   };
   auto commit = [&](int n_img) {
+    if constexpr (BST_LATE) {
+      const size_t ssrc = (size_t)n_img * CS * NPIX;
+#pragma unroll
+      for (int q = 0; q < SM_IT; ++q) {
+        const int it = threadIdx.x + 512 * q;
+        if (it < CS * NPIX / 8) rd[q] = load8<true>(a.bst_dy, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < SM_IT; ++q) {
       const int it = threadIdx.x + 512 * q;
@@ -747,6 +758,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
               const float gv = (relu && f <= 0.f) ? 0.f : (float)d[j];
               t1 += gv; t2 = fmaf(gv, (xv - mean) * invstd, t2);
               v[j] = (__bf16)(relu ? fmaxf(f, 0.f) : f);
+            }
+            {   // the vector's sums are complete before its LDS store is issued (left alone the scheduler sends all four
+                // vectors' stores first and keeps 64 intermediate values for the sums: 101 -> 196 registers at S = 32)
+              uint4 pk = __builtin_bit_cast(uint4, v);
+              asm volatile("" : "+v"(pk.x), "+v"(pk.y), "+v"(pk.z), "+v"(pk.w), "+v"(t1), "+v"(t2));
+              v = __builtin_bit_cast(bf16x8, pk);
             }
             bs1[q] += t1; bs2[q] += t2;
           } else {
