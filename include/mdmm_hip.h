@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 23
+#define MDMM_ABI_VERSION 24
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -542,6 +542,10 @@ typedef struct mdmm_bn {
   int32_t partial_splits; /* mdmm_bn_relu_bwd, phase = MDMM_BN_APPLY without global_sums: `partial` holds this many slabs per
                            * (group, channel) instead of `splits` (the producer's workgroups: mdmm_conv_t.bst_part); 0 = splits */
   int32_t reserved;
+  /* mdmm_bn_relu_bwd: non-NULL = stop behind the reduction -- fold the partial sums, write dgamma / dbeta and
+   * bwd_means[(grp * C + c) * 2 + {0, 1}] = (mean of g, mean of g xhat) over the group's N * L elements, no dx (NULL
+   * allowed): the consumer of dx applies them itself (mdmm_conv_t.lazy_dy).  One rank (no global_sums).  */
+  float* bwd_means;
 } mdmm_bn_t;
 #define MDMM_BN_STATS 1
 #define MDMM_BN_APPLY 2
@@ -606,6 +610,22 @@ typedef struct mdmm_conv {
    * partial_splits = mdmm_conv_wgrad_parts(args).  NULL bst_dy: none.  */
   const void* bst_dy;
   double* bst_part;
+  /* mdmm_conv_down as a Deconv's input gradient (KS = 4, bf16 sides, 16 or 32 big-side channels) whose BIG side -- the
+   * Deconv's output gradient -- is the input gradient dx of a training-mode BatchNorm + ReLU that has only been REDUCED
+   * so far: the apply pass of mdmm_bn_relu_bwd runs while the side is staged.  lazy_dy = the gradient of the
+   * normalised activation, lazy_x = the BatchNorm's input (both (N, CB, 2S, 2S) bf16), lazy_mean / lazy_invstd
+   * [groups][CB] its saved statistics (image n in group n / lazy_group_n, at most 8 groups), lazy_gamma / lazy_beta (CB)
+   * or NULL, lazy_means [groups][CB][2] = (mean of g, mean of g xhat) (mdmm_bn_t.bwd_means), lazy_relu bit 0 = ReLU
+   * behind the norm.  `big` is then an OUTPUT: dx is written there (for the weight-gradient launch behind this one), the
+   * same values bit for bit as the apply pass's.  NULL lazy_dy: `big` is read.  */
+  const void* lazy_dy;
+  const void* lazy_x;
+  const float* lazy_mean;
+  const float* lazy_invstd;
+  const float* lazy_gamma;
+  const float* lazy_beta;
+  const float* lazy_means;
+  int32_t lazy_group_n, lazy_relu;
 } mdmm_conv_t;
 int mdmm_conv_supported(const mdmm_conv_t* args);
 int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* args, int up);

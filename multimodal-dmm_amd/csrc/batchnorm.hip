@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
                                                           const double* __restrict__ partial,
                                                           T* __restrict__ dx, float* dgamma,
                                                           float* dbeta, const double* __restrict__ gsum,
-                                                          double gcount, int psplits) {
+                                                          double gcount, int psplits, float* means_out) {
   __shared__ double sh[2 * NT / 64];
   const int c = blockIdx.x;
   const int grp = blockIdx.z, n_grp = gridDim.z;
@@ -326,6 +326,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
   if (gsum) { d1 = gsum[2 * c]; d2 = gsum[2 * c + 1]; }      // means over the GLOBAL batch
   const double M = gsum ? gcount : (double)N * (double)L;
   const float mg = (float)(d1 / M), mgx = (float)(d2 / M);
+  if (means_out) {                                 // reduction only (mdmm_bn_t.bwd_means): the consumer applies
+    if (threadIdx.x == 0) { means_out[((size_t)grp * C + c) * 2] = mg; means_out[((size_t)grp * C + c) * 2 + 1] = mgx; }
+    return;
+  }
   const size_t goff = (size_t)grp * N * C * L;
   dy += goff; x += goff; dx += goff;
   const float mean = save_mean[(size_t)grp * C + c], invstd = save_invstd[(size_t)grp * C + c];
@@ -415,11 +419,14 @@ void launch_bwd(const mdmm_bn_t* a, hipStream_t st) {
   if (a->phase != MDMM_BN_APPLY)
     hipLaunchKernelGGL((bn_bwd_stats_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->dy, (const T*)a->x, a->N, a->C,
                        a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial);
-  if (a->phase != MDMM_BN_STATS)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<VEC, T>), grid, dim3(NT), 0, st, (const T*)a->dy, (const T*)a->x, a->N, a->C,
-                       a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu, a->partial, (T*)a->dx,
-                       a->dgamma, a->dbeta, a->global_sums, a->global_count,
-                       (a->phase == MDMM_BN_APPLY && !a->global_sums) ? a->partial_splits : 0);
+  if (a->phase != MDMM_BN_STATS) {
+    const bool fin = a->bwd_means != nullptr;      // fold + means only: one workgroup per (channel, group)
+    const int given = (a->phase == MDMM_BN_APPLY && !a->global_sums) ? a->partial_splits : 0;
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<VEC, T>), fin ? dim3(a->C, 1, grid.z) : grid, dim3(NT), 0, st, (const T*)a->dy,
+                       (const T*)a->x, a->N, a->C, a->L, a->gamma, a->beta, a->save_mean, a->save_invstd, a->relu,
+                       a->partial, fin ? (T*)nullptr : (T*)a->dx, a->dgamma, a->dbeta, a->global_sums, a->global_count,
+                       fin ? (given > 0 ? given : a->splits) : given, a->bwd_means);
+  }
 }
 
 }  // namespace
@@ -437,7 +444,8 @@ extern "C" int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream) {
 extern "C" int mdmm_bn_relu_bwd(const mdmm_bn_t* a, void* stream) {
   int rc = check(a);
   if (rc) return rc;
-  if (!a->dy || (!a->dx && a->phase != MDMM_BN_STATS)) return MDMM_E_ARG;
+  if (!a->dy || (!a->dx && a->phase != MDMM_BN_STATS && !a->bwd_means)) return MDMM_E_ARG;
+  if (a->bwd_means && a->global_sums) return MDMM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (a->bf16_io) { if (vec_ok(a)) launch_bwd<true, __bf16>(a, st); else launch_bwd<false, __bf16>(a, st); }
   else { if (vec_ok(a)) launch_bwd<true, float>(a, st); else launch_bwd<false, float>(a, st); }

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
 
 // ------------------------------------------------------------------------------- down ----
 // small[n][m][y][x] = bias[m] + sum_{ch, ky, kx} big[n][ch][2y-1+ky][2x-1+kx] W[m][ch][ky][kx]
-template <int S, int CS, int CB, int KS, bool SB, bool BB, bool NORM = false, bool STATS = false>
+template <int S, int CS, int CB, int KS, bool SB, bool BB, bool NORM = false, bool STATS = false, bool LAZY = false>
 __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   using G = Shape<S, CS, CB>;
   using D = Down<S, CS, CB, KS>;
@@ -412,10 +412,28 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   char* patch = smem + D::W_LDS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, cb = a.CB;
   // NORM: the BIG side (this Conv's input) is the block in front's pre-normalisation output (mdmm_conv_t.in_mean);
-  // STATS: sums of the stored small side for the BatchNorm behind this layer (mdmm_conv_t.out_stats)
+  // STATS: sums of the stored small side for the BatchNorm behind this layer (mdmm_conv_t.out_stats);
+  // LAZY: the BIG side (a Deconv's output gradient) is the input gradient of a BatchNorm + ReLU whose adjoint has only
+  //       been REDUCED so far (mdmm_conv_t.lazy_dy): the apply pass of batchnorm.hip (bn_bwd_apply_kernel, the same
+  //       arithmetic per element) runs while the side is staged, and the values are also written to `big` for the
+  //       weight-gradient kernel behind this launch -- the gradient is read once less
   float* const ntab = reinterpret_cast<float*>(smem + ((D::LDS + 15) & ~15));
   float* const sred = ntab + NORM_GROUPS * 2 * CB;
   if constexpr (NORM) norm_table<CB>(a, ntab, 256);
+  static_assert(!LAZY || (!NORM && !STATS && SB && BB && !G::THIN), "lazy adjoint: bf16 sides, 16 / 32 channels");
+  float4* const ltab = reinterpret_cast<float4*>(ntab);        // LAZY: [group][channel][2] = (mean, invstd, k, shift), (mg, mgx, -, -)
+  if constexpr (LAZY) {
+    const int groups = (a.N + a.lazy_group_n - 1) / a.lazy_group_n;
+    for (int i = threadIdx.x; i < groups * CB; i += 256) {
+      const int c = i % CB;
+      const float gm = a.lazy_gamma ? a.lazy_gamma[c] : 1.0f, bt = a.lazy_beta ? a.lazy_beta[c] : 0.0f;
+      const float mean = a.lazy_mean[i], invstd = a.lazy_invstd[i];
+      const float k = gm * invstd;
+      ltab[2 * i] = float4{mean, invstd, k, fmaf(-mean, k, bt)};
+      ltab[2 * i + 1] = float4{a.lazy_means[2 * i], a.lazy_means[2 * i + 1], 0.f, 0.f};
+    }
+    __syncthreads();
+  }
   static_assert(!STATS || G::MT_S == 1, "output statistics: one channel tile");
   constexpr int SRD = STATS ? (CS >= 32 ? 16 : CS / 2) : 1;
   float s1[SRD], s2[SRD];
@@ -513,8 +531,31 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
       for (int it = threadIdx.x; it < (BPIX / 4) * NCG; it += 256) {
         const int p = 4 * (it % (BPIX / 4)), cg = it / (BPIX / 4), y = p / B2, x = p % B2;
         bf16x4 u[8];
+        if constexpr (LAZY) {
+          bf16x4 xw[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) u[j] = load4<BB>(a.big, src0 + (size_t)(cg * 8 + j) * BPIX + p);
+          for (int j = 0; j < 8; ++j) {
+            u[j] = load4<true>(a.lazy_dy, src0 + (size_t)(cg * 8 + j) * BPIX + p);
+            xw[j] = load4<true>(a.lazy_x, src0 + (size_t)(cg * 8 + j) * BPIX + p);
+          }
+          const float4* tab = ltab + (size_t)(n / a.lazy_group_n) * 2 * CB;
+          const bool relu = (a.lazy_relu & 1) != 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float4 t0 = tab[2 * (cg * 8 + j)], t1 = tab[2 * (cg * 8 + j) + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float xv = (float)xw[j][e];
+              const float xh = (xv - t0.x) * t0.y;
+              const float gv = (relu && fmaf(xv, t0.z, t0.w) <= 0.f) ? 0.f : (float)u[j][e];
+              u[j][e] = (__bf16)(t0.z * (gv - t1.x - xh * t1.y));
+            }
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.big) + src0 + (size_t)(cg * 8 + j) * BPIX + p) = u[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) u[j] = load4<BB>(a.big, src0 + (size_t)(cg * 8 + j) * BPIX + p);
+        }
         bf16x8 v0, v1, v2, v3;
         if constexpr (NORM) {
           const float* tab = ntab + (size_t)(n / a.in_group_n) * 2 * CB;
@@ -1026,6 +1067,26 @@ int run_down_fused(const mdmm_conv_t* a, hipStream_t st) {
     return (int)hipGetLastError();
   }
 }
+// the big side's BatchNorm adjoint applied while it is staged (lazy_dy): Deconv input gradients at 16 / 32 channels
+template <int S, int CS, int CB, int KS>
+int run_down_lazy(const mdmm_conv_t* a, hipStream_t st) {
+  using G = Shape<S, CS, CB>;
+  using D = Down<S, CS, CB, KS>;
+  if constexpr (G::THIN || KS != 4) return MDMM_E_ARG;
+  else {
+    if (io_of(a) != 1 || a->in_mean || a->out_stats || !a->lazy_x || !a->lazy_mean || !a->lazy_invstd || !a->lazy_means ||
+        a->lazy_group_n < 1 || a->CB != CB)
+      return MDMM_E_ARG;
+    const int groups = (a->N + a->lazy_group_n - 1) / a->lazy_group_n;
+    if (groups > NORM_GROUPS) return MDMM_E_ARG;
+    auto k = conv_down_kernel<S, CS, CB, KS, true, true, false, false, true>;
+    const int lds = ((D::LDS + 15) & ~15) + groups * CB * 32;
+    int rc = set_lds(k, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k, dim3(grid_for(a->N, down_per_cu(lds), "MDMM_CONV_DOWN_PER_CU")), dim3(256), lds, st, *a);
+    return (int)hipGetLastError();
+  }
+}
 template <int S, int CS, int CB, int KS>
 int down_parts(const mdmm_conv_t* a) {
   using D = Down<S, CS, CB, KS>;
@@ -1034,6 +1095,7 @@ int down_parts(const mdmm_conv_t* a) {
 }
 template <int S, int CS, int CB, int KS>
 int run_down(const mdmm_conv_t* a, hipStream_t st) {
+  if (a->lazy_dy) return run_down_lazy<S, CS, CB, KS>(a, st);
   if (a->in_mean || a->out_stats) {
     const int io = io_of(a);
     if (io != 1 && io != 2) return MDMM_E_ARG;

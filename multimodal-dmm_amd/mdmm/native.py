@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 23
+ABI_VERSION = 24
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -131,7 +131,7 @@ class Bn(C.Structure):
                 [(n, _P) for n in ('x', 'gamma', 'beta', 'running_mean', 'running_var', 'y', 'save_mean',
                                    'save_invstd', 'dy', 'dx', 'dgamma', 'dbeta', 'partial', 'mean_shift')] +
                 [('phase', C.c_int32), ('groups', C.c_int32), ('global_sums', _P), ('global_count', C.c_double),
-                 ('partial_splits', C.c_int32), ('reserved', C.c_int32)])
+                 ('partial_splits', C.c_int32), ('reserved', C.c_int32), ('bwd_means', _P)])
 
 
 BN_STATS, BN_APPLY, BN_FINALIZE, BN_FINALIZE_GIVEN = 1, 2, 3, 4
@@ -161,7 +161,9 @@ class Conv(C.Structure):
                 [(n, _P) for n in ('small', 'big', 'wfrag', 'bias', 'in_mean', 'in_invstd', 'in_gamma', 'in_beta')] +
                 [('in_group_n', C.c_int32), ('in_relu', C.c_int32), ('out_stats', _P), ('out_group_n', C.c_int32),
                  ('reserved', C.c_int32)] +
-                [('bst_dy', _P), ('bst_part', _P)])
+                [('bst_dy', _P), ('bst_part', _P)] +
+                [(n, _P) for n in ('lazy_dy', 'lazy_x', 'lazy_mean', 'lazy_invstd', 'lazy_gamma', 'lazy_beta', 'lazy_means')] +
+                [('lazy_group_n', C.c_int32), ('lazy_relu', C.c_int32)])
 
 
 class Conv1d(C.Structure):

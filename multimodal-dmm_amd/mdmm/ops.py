@@ -351,6 +351,7 @@ def wide_trans(cfg):
 def clear_caches(params=()):
     """Drop host-side caches (call before capturing a step into a HIP graph)."""
     _GRAD_CHANSUM.clear()
+    _LAZY_BN.clear()
     for p in params:
         if hasattr(p, '_mdmm_pack'):
             del p._mdmm_pack
@@ -1113,6 +1114,53 @@ def _take_chansum(g, channels):
     if hit is not None and hit[0].numel() == g.numel() and hit[0].dtype == g.dtype and hit[1].numel() == channels:
         return hit[1]
     return None
+
+
+# A BatchNorm adjoint that has only been REDUCED (_BnDeconvFn.backward with lazy_dx): the tensor it returns as dx is
+# still unwritten; the deconvolution in front -- its only consumer, checked when the forward was built -- applies the
+# adjoint while it stages that tensor (mdmm_conv_t.lazy_dy) and writes it.  Keyed by the tensor's address, the tensor and
+# everything the apply pass needs kept alive with the entry; a consumer that cannot stage lazily calls _lazy_finish.
+_LAZY_BN = {}
+
+
+def _lazy_stash(dx, entry):
+    _LAZY_BN[dx.data_ptr()] = (dx, entry)
+
+
+def _lazy_take(g):
+    hit = _LAZY_BN.pop(g.data_ptr(), None)
+    if hit is not None and hit[0] is not g and not (hit[0].shape == g.shape and hit[0].dtype == g.dtype):
+        raise native.MdmmError('a lazily applied BatchNorm gradient reached a consumer in another form (%s %s for %s %s)'
+                               % (tuple(g.shape), g.dtype, tuple(hit[0].shape), hit[0].dtype))
+    return None if hit is None else hit[1]
+
+
+def _lazy_finish(entry, dx):
+    """The apply pass after all (batchnorm.hip): dx from (dyn, x, the partial sums)."""
+    a = native.Bn()
+    a.N, a.C, a.L, a.relu, a.splits, a.eps, a.groups = entry['Ng'], entry['C'], entry['L'], 1, entry['splits'], entry['eps'], entry['G']
+    a.bf16_io, a.phase, a.partial_splits = 1, native.BN_APPLY, entry['psplits'] or entry['splits']
+    a.x, a.gamma, a.beta, a.dy, a.dx = _ptr(entry['x']), _ptr(entry['g']), _ptr(entry['b']), _ptr(entry['dyn']), _ptr(dx)
+    a.save_mean, a.save_invstd, a.partial = entry['stats'][0].data_ptr(), entry['stats'][1].data_ptr(), _ptr(entry['part'])
+    _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=dx.numel() * dx.element_size() * 3)
+
+
+def _lazy_conv_args(c, entry):
+    c.lazy_dy, c.lazy_x = _ptr(entry['dyn']), _ptr(entry['x'])
+    c.lazy_mean, c.lazy_invstd = entry['stats'][0].data_ptr(), entry['stats'][1].data_ptr()
+    c.lazy_gamma, c.lazy_beta, c.lazy_means = _ptr(entry['g']), _ptr(entry['b']), _ptr(entry['means'])
+    c.lazy_group_n, c.lazy_relu = entry['Ng'], 1
+
+
+def lazy_bn_ok(x_pre):
+    """x_pre (the pre-normalisation output a DeferredNorm carries) comes straight out of a deconvolution whose backward
+    can apply this BatchNorm's adjoint while it stages its output gradient: a _BnDeconvFn on a ConvTranspose2d with 16 or
+    32 output channels (MDMM_BN_LAZY_DX=0: never)."""
+    fn = getattr(x_pre, 'grad_fn', None)
+    if fn is None or os.environ.get('MDMM_BN_LAZY_DX', '1') == '0':
+        return False
+    return (type(fn).__name__ == '_BnDeconvFnBackward' and getattr(fn, 'lazy_consumer', False)
+            and x_pre.dim() == 4 and x_pre.shape[1] == 16 and x_pre.dtype == torch.bfloat16 and x_pre.is_contiguous())
 
 
 def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None, passes=1, channels=0, pass_weight=None):
@@ -2225,6 +2273,10 @@ class _BnDeconvFn(torch.autograd.Function):
               tag='conv_%s[S=%d]' % ('up' if transposed else 'down', c.S))
         ctx.save_for_backward(x, stats, g, b, weight)
         ctx.meta = (N // G, Cc, Ln, bwd_splits, bn.eps, G, transposed)
+        # this BatchNorm's adjoint left to the deconvolution that produced x_pre (decided before the output exists);
+        # this deconvolution's own backward takes such a gradient for its output when its big side has 16 channels
+        ctx.lazy_dx = bool(transposed and G <= 8 and lazy_bn_ok(x_pre))
+        ctx.lazy_consumer = bool(transposed and ks == 4 and cb == 16 and side == 16)
         ctx.has_bias = bias is not None
         ctx.shift_like = None if shift is None else shift.detach()
         if part_out is not None:
@@ -2240,6 +2292,7 @@ class _BnDeconvFn(torch.autograd.Function):
             shift_grad = torch.zeros_like(ctx.shift_like)
         if gy is None:
             return None, None, None, None, shift_grad, None, None, None, None, None
+        lazy_in = _lazy_take(gy)             # gy still unwritten: the BatchNorm behind this layer left its apply pass to us
         gy = _act(gy)
         if gy.dtype != torch.bfloat16:
             gy = gy.to(torch.bfloat16)
@@ -2257,8 +2310,15 @@ class _BnDeconvFn(torch.autograd.Function):
             c.small, c.big = (_ptr(dyn), _ptr(gy)) if transposed else (_ptr(gy), _ptr(dyn))
             keep = _conv_pack(weight, c, not transposed)
             c.wfrag = _ptr(keep)
+            if lazy_in is not None and ctx.lazy_consumer:
+                _lazy_conv_args(c, lazy_in)             # ... applied while gy is staged, and written to gy
+            elif lazy_in is not None:
+                _lazy_finish(lazy_in, gy)
             _call('mdmm_conv_down' if transposed else 'mdmm_conv_up', C.byref(c),
                   tag='conv_%s[S=%d]' % ('down' if transposed else 'up', c.S))
+            c.lazy_dy = c.lazy_x = None
+        elif lazy_in is not None:
+            _lazy_finish(lazy_in, gy)
         if ctx.needs_input_grad[5]:
             c.small, c.big, c.wfrag = _ptr(small), _ptr(big), None
             c.in_mean, c.in_invstd, c.in_gamma, c.in_beta = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(g), _ptr(b)
@@ -2293,7 +2353,16 @@ class _BnDeconvFn(torch.autograd.Function):
             a.x, a.gamma, a.beta, a.dy, a.dx = _ptr(x), _ptr(g), _ptr(b), _ptr(dyn), _ptr(dx)
             a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
             a.dgamma, a.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
-            _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=x.numel() * x.element_size() * (3 if bst_part is not None else 5))
+            if ctx.lazy_dx:
+                # reduction only: the means of g and g xhat; dx is written by the deconvolution in front while it stages it
+                means = torch.empty(G, Cc, 2, device=x.device, dtype=torch.float32)
+                a.bwd_means, a.dx = _ptr(means), None
+                _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=0 if bst_part is not None else x.numel() * x.element_size() * 2,
+                      tag='mdmm_bn_bwd_reduce')
+                _lazy_stash(dx, dict(dyn=dyn, x=x, stats=stats, g=g, b=b, means=means, part=part, Ng=Ng, C=Cc, L=Ln, G=G,
+                                     eps=eps, splits=splits, psplits=bst_splits if bst_part is not None else 0))
+            else:
+                _call('mdmm_bn_relu_bwd', C.byref(a), nbytes=x.numel() * x.element_size() * (3 if bst_part is not None else 5))
         return (dx, dgb[0] if (need_x and ctx.needs_input_grad[1]) else None,
                 dgb[1] if (need_x and ctx.needs_input_grad[2]) else None, None, shift_grad, gw, gb, None, None, None)
 

@@ -471,7 +471,7 @@ def test_batchnorm_adjoint_sums_out_of_the_weight_gradient_kernel(dev, groups, m
     from mdmm.models import common as C
     torch.manual_seed(5 + groups)
     ref = C.ImageDecoder(256, n_channels=3).to(dev).train()
-    z = torch.randn(groups * 530, 256, device=dev)
+    z = torch.randn(groups * 528, 256, device=dev)         # (a multiple of 4, >= 512: the heads on the own GEMM -> bf16 activations)
     res = {}
     for mode in ('0', '1', '3'):
         dec = copy.deepcopy(ref)
@@ -493,6 +493,42 @@ def test_batchnorm_adjoint_sums_out_of_the_weight_gradient_kernel(dev, groups, m
                 worst = max(worst, e)
                 assert e < 1e-5, (mode, k, e)
     helpers.note('bn_adjoint_sums_fused.l2[groups=%d]' % groups, worst)
+
+
+@pytest.mark.parametrize('groups', [1, 2])
+def test_batchnorm_adjoint_applied_by_the_consuming_deconvolution(dev, groups, monkeypatch):
+    """The apply pass of a decoder block's BatchNorm adjoint left to the deconvolution in front (ops.lazy_bn_ok: the
+    block's _BnDeconvFn.backward stops behind the reduction, the producer's input-gradient kernel forms dx while it
+    stages it -- mdmm_conv_t.lazy_dy -- and writes it for its weight-gradient kernel) against the apply pass as a
+    kernel of its own (MDMM_BN_LAZY_DX=0): the same arithmetic per element on the same sums -- every gradient bit for
+    bit.  Both with the adjoint's sums from their own pass and from the weight-gradient kernel."""
+    import copy
+    from mdmm import ops
+    from mdmm.models import common as C
+    torch.manual_seed(9 + groups)
+    ref = C.ImageDecoder(256, n_channels=3).to(dev).train()
+    z = torch.randn(groups * 528, 256, device=dev)         # (a multiple of 4, >= 512: the heads on the own GEMM -> bf16 activations)
+    names = ['z'] + [k for k, _ in ref.named_parameters()]
+    for fused in ('0', '1'):
+        res = {}
+        for lazy in ('0', '1'):
+            dec = copy.deepcopy(ref)
+            monkeypatch.setenv('MDMM_BN_BWD_STATS_FUSED', fused)
+            monkeypatch.setenv('MDMM_BN_LAZY_DX', lazy)
+            zi = z.clone().requires_grad_()
+            with ops.conv_operands(torch.bfloat16, torch.bfloat16), ops.bn_groups(groups):
+                out = dec(zi, logits=True)[0]
+            gy = torch.randn(out.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).to(out.dtype)
+            monkeypatch.setattr(ops, 'TIMER', ops.KernelTimer())
+            res[lazy] = torch.autograd.grad(out, [zi] + list(dec.parameters()), gy, allow_unused=True)
+            calls = set(ops.TIMER.spans)
+            monkeypatch.setattr(ops, 'TIMER', None)
+            assert ('mdmm_bn_bwd_reduce' in calls) == (lazy == '1'), calls
+            assert not ops._LAZY_BN
+        for k, a_, b_ in zip(names, res['1'], res['0']):
+            assert (a_ is None) == (b_ is None), k
+            if a_ is not None:
+                assert torch.equal(a_, b_), (fused, k)
 
 
 def test_deferred_batchnorm_in_encoder_convs(dev, monkeypatch):
