@@ -1154,13 +1154,13 @@ def _lazy_conv_args(c, entry):
 
 def lazy_bn_ok(x_pre):
     """x_pre (the pre-normalisation output a DeferredNorm carries) comes straight out of a deconvolution whose backward
-    can apply this BatchNorm's adjoint while it stages its output gradient: a _BnDeconvFn on a ConvTranspose2d with 16 or
-    32 output channels (MDMM_BN_LAZY_DX=0: never)."""
+    can apply this BatchNorm's adjoint while it stages its output gradient: a ConvTranspose2d 32 -> 16 channels at 16 x 16
+    (_BnDeconvFn) or 64 -> 32 at 8 x 8 (_ConvTilesFn) on bf16 activations (MDMM_BN_LAZY_DX=0: never)."""
     fn = getattr(x_pre, 'grad_fn', None)
     if fn is None or os.environ.get('MDMM_BN_LAZY_DX', '1') == '0':
         return False
-    return (type(fn).__name__ == '_BnDeconvFnBackward' and getattr(fn, 'lazy_consumer', False)
-            and x_pre.dim() == 4 and x_pre.shape[1] == 16 and x_pre.dtype == torch.bfloat16 and x_pre.is_contiguous())
+    return (type(fn).__name__ in ('_BnDeconvFnBackward', '_ConvTilesFnBackward') and getattr(fn, 'lazy_consumer', False)
+            and x_pre.dim() == 4 and x_pre.shape[1] in (16, 32) and x_pre.dtype == torch.bfloat16 and x_pre.is_contiguous())
 
 
 def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None, passes=1, channels=0, pass_weight=None):
@@ -2170,6 +2170,9 @@ class _ConvTilesFn(torch.autograd.Function):
         _call('mdmm_conv_up' if transposed else 'mdmm_conv_down', C.byref(a),
               tag='conv_%s[S=%d]' % ('up' if transposed else 'down', s))
         ctx.transposed, ctx.has_bias = transposed, bias is not None
+        # (this layer's input-gradient kernel takes a lazily applied BatchNorm gradient for its output: lazy_bn_ok)
+        ctx.lazy_consumer = bool(transposed and ks == 4 and cb == 32 and s == 8 and x.dtype == torch.bfloat16
+                                 and y.dtype == torch.bfloat16)
         ctx.save_for_backward(x, weight)
         if part is not None:
             ctx.mark_non_differentiable(part)
@@ -2181,6 +2184,7 @@ class _ConvTilesFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         if gy is None:                  # (set_materialize_grads(False): an output that reaches no loss term)
             return None, None, None, None, None
+        lazy_in = _lazy_take(gy)
         gy = _act(gy)
         n, ks = x.shape[0], weight.shape[-1]
         transposed = ctx.transposed
@@ -2193,8 +2197,15 @@ class _ConvTilesFn(torch.autograd.Function):
             a.small, a.big = (_ptr(gx), _ptr(gy)) if transposed else (_ptr(gy), _ptr(gx))
             keep = _conv_pack(weight, a, not transposed)
             a.wfrag = _ptr(keep)
+            if lazy_in is not None and ctx.lazy_consumer:
+                _lazy_conv_args(a, lazy_in)             # the BatchNorm adjoint applied while gy is staged, and written to gy
+            elif lazy_in is not None:
+                _lazy_finish(lazy_in, gy)
             _call('mdmm_conv_down' if transposed else 'mdmm_conv_up', C.byref(a),
                   tag='conv_%s[S=%d]' % ('down' if transposed else 'up', a.S))
+            a.lazy_dy = a.lazy_x = None
+        elif lazy_in is not None:
+            _lazy_finish(lazy_in, gy)
         if ctx.needs_input_grad[1]:
             a.small, a.big, a.wfrag = _ptr(small), _ptr(big), None
             ws = torch.empty(native.lib().mdmm_conv_wgrad_ws_bytes(C.byref(a)), device=x.device, dtype=torch.uint8)
