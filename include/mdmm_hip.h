@@ -617,7 +617,10 @@ typedef struct mdmm_conv {
    * [groups][CB] its saved statistics (image n in group n / lazy_group_n, at most 8 groups), lazy_gamma / lazy_beta (CB)
    * or NULL, lazy_means [groups][CB][2] = (mean of g, mean of g xhat) (mdmm_bn_t.bwd_means), lazy_relu bit 0 = ReLU
    * behind the norm.  `big` is then an OUTPUT: dx is written there (for the weight-gradient launch behind this one), the
-   * same values bit for bit as the apply pass's.  NULL lazy_dy: `big` is read.  */
+   * same values bit for bit as the apply pass's.  NULL lazy_dy: `big` is read.
+   * mdmm_conv_wgrad with lazy_dy: the SMALL side (a Conv's output gradient, bf16; CS channels, tables [groups][CS]) is
+   * formed the same way while it is staged and is NOT written anywhere (`small` is ignored): for a layer whose input
+   * needs no gradient -- the first encoder layer on the frames -- dx never exists in HBM.  */
   const void* lazy_dy;
   const void* lazy_x;
   const float* lazy_mean;

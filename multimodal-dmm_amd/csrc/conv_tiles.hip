@@ -647,11 +647,15 @@ __device__ __forceinline__ uint32_t shift16(uint32_t hi, uint32_t lo) { return _
 // x of the small side anyway; with the gradient of the normalised activation (mdmm_conv_t.bst_dy) fetched beside it,
 // (sum g, sum g xhat), g = dy [bn(x) > 0], are per-thread sums over the elements a thread stages (always the same
 // channel), folded per workgroup in LDS (batchnorm.hip, bn_bwd_stats_kernel: the same arithmetic per element)
-template <int S, int CS, int CB, int KS, bool SB, bool BB, int NORM = 0, bool BST = false>
+// LZ: the SMALL side (a Conv's output gradient) is the input gradient dx of a BatchNorm + ReLU whose adjoint has only been
+// reduced (mdmm_conv_t.lazy_dy, as conv_down_kernel's LAZY): formed from (dy, x) while the side is staged -- for a layer
+// whose own input needs no gradient (the first encoder layer on the frames) dx never exists in HBM
+template <int S, int CS, int CB, int KS, bool SB, bool BB, int NORM = 0, bool BST = false, bool LZ = false>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, float* part, int NT) {
   using G = Shape<S, CS, CB>;
   using W = Wg<S, CS, CB, KS>;
   static_assert(!BST || (NORM == 1 && SB), "the adjoint's sums: bf16 small side in pre-normalisation form");
+  static_assert(!LZ || (NORM == 0 && !BST && SB), "lazy adjoint: bf16 small side, nothing else staged specially");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const ntab = reinterpret_cast<float*>(smem + ((W::LDS + 15) & ~15));
   // BST: [group][mean | invstd][channel] and the workgroup's sums [group][channel][2] behind the scale / shift table
@@ -659,6 +663,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   const int n_groups = NORM ? (a.N + a.in_group_n - 1) / a.in_group_n : 0;
   float* const mtab = ntab + n_groups * 2 * (CS > CB ? CS : CB);
   double* const gacc = reinterpret_cast<double*>(mtab + n_groups * 2 * CS);
+  float4* const ltab = reinterpret_cast<float4*>(ntab);        // LZ: [group][channel][2] (conv_down_kernel's table)
+  if constexpr (LZ) {
+    const int groups = (a.N + a.lazy_group_n - 1) / a.lazy_group_n;
+    for (int i = threadIdx.x; i < groups * CS; i += 512) {
+      const int c = i % CS;
+      const float gm = a.lazy_gamma ? a.lazy_gamma[c] : 1.0f, bt = a.lazy_beta ? a.lazy_beta[c] : 0.0f;
+      const float mean = a.lazy_mean[i], invstd = a.lazy_invstd[i];
+      const float k = gm * invstd;
+      ltab[2 * i] = float4{mean, invstd, k, fmaf(-mean, k, bt)};
+      ltab[2 * i + 1] = float4{a.lazy_means[2 * i], a.lazy_means[2 * i + 1], 0.f, 0.f};
+    }
+  }
   char* sm = smem;
   char* pl = smem + W::SM_LDS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, cb = a.CB;
@@ -726,7 +742,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   // S = 32: the gradient is fetched where it is used instead of travelling beside x through the contraction (its 16
   // registers were the difference between one and two workgroups per CU; the other workgroup covers the round trip)
   constexpr bool BST_LATE = BST && S == 32;
-  bf16x8 rd[BST ? SM_IT : 1];
+  bf16x8 rd[(BST || LZ) ? SM_IT : 1];                  // LZ: rs = dy, rd = x
   float bs1[BST ? SM_IT : 1], bs2[BST ? SM_IT : 1];
   int bst_g = -1;
   if constexpr (BST) {
@@ -754,7 +770,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
     for (int q = 0; q < SM_IT; ++q) {
       const int it = threadIdx.x + 512 * q;
       if (it < CS * NPIX / 8) {
-        rs[q] = load8<SB>(a.small, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
+        if constexpr (LZ) {
+          rs[q] = load8<true>(a.lazy_dy, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
+          rd[q] = load8<true>(a.lazy_x, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
+        } else {
+          rs[q] = load8<SB>(a.small, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
+        }
         if constexpr (BST && !BST_LATE) rd[q] = load8<true>(a.bst_dy, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
       }
     }
@@ -781,6 +802,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
       const int it = threadIdx.x + 512 * q;
       if (it < CS * NPIX / 8) {
         bf16x8 v = rs[q];
+        if constexpr (LZ) {             // batchnorm.hip, bn_bwd_apply_kernel: dx from (dy, x) and the group's means
+          const float4* tab = ltab + (size_t)(n_img / a.lazy_group_n) * 2 * CS;
+          const int ch = it / (NPIX / 8);
+          const float4 t0 = tab[2 * ch], t1 = tab[2 * ch + 1];
+          const bool relu = (a.lazy_relu & 1) != 0;
+          const bf16x8 xw = rd[q];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xv = (float)xw[j];
+            const float xh = (xv - t0.x) * t0.y;
+            const float gv = (relu && fmaf(xv, t0.z, t0.w) <= 0.f) ? 0.f : (float)v[j];
+            v[j] = (__bf16)(t0.z * (gv - t1.x - xh * t1.y));
+          }
+        }
         if constexpr (NORM == 1) {      // the small side is the layer's input: the block in front's BatchNorm + ReLU
           const int grp = n_img / a.in_group_n;
           const float* tab = ntab + (size_t)grp * 2 * CS;
@@ -1155,8 +1190,27 @@ int run_wgrad_norm(const mdmm_conv_t* a, float* part, hipStream_t st) {
   hipLaunchKernelGGL(k, dim3(wgrad_parts(a)), dim3(512), lds, st, *a, part, wgrad_nt(a));
   return (int)hipGetLastError();
 }
+// the small side formed from a reduced BatchNorm adjoint while it is staged (lazy_dy): bf16 small side
+template <int S, int CS, int CB, int KS>
+int run_wgrad_lazy(const mdmm_conv_t* a, float* part, hipStream_t st) {
+  using W = Wg<S, CS, CB, KS>;
+  const int io = io_of(a);
+  if ((io != 1 && io != 2) || a->in_mean || a->bst_dy || !a->lazy_x || !a->lazy_mean || !a->lazy_invstd || !a->lazy_means ||
+      a->lazy_group_n < 1)
+    return MDMM_E_ARG;
+  const int groups = (a->N + a->lazy_group_n - 1) / a->lazy_group_n;
+  if (groups > NORM_GROUPS) return MDMM_E_ARG;
+  const int lds = ((W::LDS + 15) & ~15) + groups * CS * 32;
+  auto k = io == 1 ? conv_wgrad_kernel<S, CS, CB, KS, true, true, 0, false, true>
+                   : conv_wgrad_kernel<S, CS, CB, KS, true, false, 0, false, true>;
+  int rc = set_lds(k, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k, dim3(wgrad_parts(a)), dim3(512), lds, st, *a, part, wgrad_nt(a));
+  return (int)hipGetLastError();
+}
 template <int S, int CS, int CB, int KS>
 int run_wgrad(const mdmm_conv_t* a, float* part, hipStream_t st) {
+  if (a->lazy_dy) return run_wgrad_lazy<S, CS, CB, KS>(a, part, st);
   if (a->bst_dy && !a->in_mean) return MDMM_E_ARG;
   if (a->in_mean) return run_wgrad_norm<S, CS, CB, KS>(a, part, st);
   switch (io_of(a)) {

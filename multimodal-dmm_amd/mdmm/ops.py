@@ -1155,7 +1155,8 @@ def _lazy_conv_args(c, entry):
 def lazy_bn_ok(x_pre):
     """x_pre (the pre-normalisation output a DeferredNorm carries) comes straight out of a deconvolution whose backward
     can apply this BatchNorm's adjoint while it stages its output gradient: a ConvTranspose2d 32 -> 16 channels at 16 x 16
-    (_BnDeconvFn) or 64 -> 32 at 8 x 8 (_ConvTilesFn) on bf16 activations (MDMM_BN_LAZY_DX=0: never)."""
+    (_BnDeconvFn) or 64 -> 32 at 8 x 8 (_ConvTilesFn) on bf16 activations, or the first encoder layer (Conv2d 3 -> 16 on
+    frames that need no gradient: its weight-gradient kernel) (MDMM_BN_LAZY_DX=0: never)."""
     fn = getattr(x_pre, 'grad_fn', None)
     if fn is None or os.environ.get('MDMM_BN_LAZY_DX', '1') == '0':
         return False
@@ -2143,6 +2144,7 @@ class _ConvTilesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, transposed, stats_groups=0):
         ctx.set_materialize_grads(False)
+        x_needs_grad = x.requires_grad
         x = _act(x)
         n, ks = x.shape[0], weight.shape[-1]
         cs, cb = weight.shape[0], weight.shape[1]
@@ -2173,6 +2175,11 @@ class _ConvTilesFn(torch.autograd.Function):
         # (this layer's input-gradient kernel takes a lazily applied BatchNorm gradient for its output: lazy_bn_ok)
         ctx.lazy_consumer = bool(transposed and ks == 4 and cb == 32 and s == 8 and x.dtype == torch.bfloat16
                                  and y.dtype == torch.bfloat16)
+        # ... and the first encoder layer (Conv 3 -> 16 on frames that need no gradient): its weight-gradient kernel
+        # forms the gradient of its output while it stages it; that gradient is never written
+        ctx.lazy_wgrad = bool(not transposed and ks == 3 and cs == 16 and s == 32 and not x_needs_grad
+                              and y.dtype == torch.bfloat16)
+        ctx.lazy_consumer = ctx.lazy_consumer or ctx.lazy_wgrad
         ctx.save_for_backward(x, weight)
         if part is not None:
             ctx.mark_non_differentiable(part)
@@ -2197,20 +2204,24 @@ class _ConvTilesFn(torch.autograd.Function):
             a.small, a.big = (_ptr(gx), _ptr(gy)) if transposed else (_ptr(gy), _ptr(gx))
             keep = _conv_pack(weight, a, not transposed)
             a.wfrag = _ptr(keep)
-            if lazy_in is not None and ctx.lazy_consumer:
+            if lazy_in is not None and ctx.lazy_consumer and transposed:
                 _lazy_conv_args(a, lazy_in)             # the BatchNorm adjoint applied while gy is staged, and written to gy
             elif lazy_in is not None:
                 _lazy_finish(lazy_in, gy)
             _call('mdmm_conv_down' if transposed else 'mdmm_conv_up', C.byref(a),
                   tag='conv_%s[S=%d]' % ('down' if transposed else 'up', a.S))
             a.lazy_dy = a.lazy_x = None
-        elif lazy_in is not None:
+        elif lazy_in is not None and not (ctx.lazy_wgrad and ctx.needs_input_grad[1] and not (ctx.has_bias and ctx.needs_input_grad[2])):
             _lazy_finish(lazy_in, gy)
+            lazy_in = None
         if ctx.needs_input_grad[1]:
             a.small, a.big, a.wfrag = _ptr(small), _ptr(big), None
+            if lazy_in is not None and not ctx.needs_input_grad[0]:
+                _lazy_conv_args(a, lazy_in)             # gy formed while the kernel stages it; never written
             ws = torch.empty(native.lib().mdmm_conv_wgrad_ws_bytes(C.byref(a)), device=x.device, dtype=torch.uint8)
             gw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
             _call('mdmm_conv_wgrad', C.byref(a), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % a.S)
+            a.lazy_dy = a.lazy_x = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             # per-channel sums over images and pixels: column sums of the (N, C*H*W) matrix on the own
             # kernel (the images are the strided dimension), then C short rows
@@ -2286,7 +2297,7 @@ class _BnDeconvFn(torch.autograd.Function):
         ctx.meta = (N // G, Cc, Ln, bwd_splits, bn.eps, G, transposed)
         # this BatchNorm's adjoint left to the deconvolution that produced x_pre (decided before the output exists);
         # this deconvolution's own backward takes such a gradient for its output when its big side has 16 channels
-        ctx.lazy_dx = bool(transposed and G <= 8 and lazy_bn_ok(x_pre))
+        ctx.lazy_dx = bool(G <= 8 and lazy_bn_ok(x_pre))
         ctx.lazy_consumer = bool(transposed and ks == 4 and cb == 16 and side == 16)
         ctx.has_bias = bias is not None
         ctx.shift_like = None if shift is None else shift.detach()

@@ -531,6 +531,37 @@ def test_batchnorm_adjoint_applied_by_the_consuming_deconvolution(dev, groups, m
                 assert torch.equal(a_, b_), (fused, k)
 
 
+def test_encoder_batchnorm_adjoint_applied_by_the_first_layers_weight_gradient(dev, monkeypatch):
+    """ImageEncoder: the adjoint of the first block's BatchNorm stops behind its reduction, and the first layer's
+    weight-gradient kernel (Conv2d 3 -> 16 on frames that need no gradient) forms the gradient of its output while it
+    stages it (mdmm_conv_wgrad with lazy_dy): that tensor is never written.  Against the apply pass as a kernel of its
+    own (MDMM_BN_LAZY_DX=0): every parameter gradient bit for bit."""
+    import copy
+    from mdmm import ops
+    from mdmm.models import common as C
+    torch.manual_seed(21)
+    ref = C.ImageEncoder(256, n_channels=3).to(dev).train()
+    x = torch.rand(600, 3, 64, 64, device=dev)
+    names = [k for k, _ in ref.named_parameters()]
+    res = {}
+    for lazy in ('0', '1'):
+        enc = copy.deepcopy(ref)
+        monkeypatch.setenv('MDMM_BN_LAZY_DX', lazy)
+        with ops.conv_operands(torch.bfloat16, torch.bfloat16):
+            mean, std = enc(x)
+        gm = torch.randn(mean.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        monkeypatch.setattr(ops, 'TIMER', ops.KernelTimer())
+        res[lazy] = torch.autograd.grad((mean * gm).sum() + std.sum(), list(enc.parameters()), allow_unused=True)
+        calls = set(ops.TIMER.spans)
+        monkeypatch.setattr(ops, 'TIMER', None)
+        assert ('mdmm_bn_bwd_reduce' in calls) == (lazy == '1'), calls
+        assert not ops._LAZY_BN
+    for k, a_, b_ in zip(names, res['1'], res['0']):
+        assert (a_ is None) == (b_ is None), k
+        if a_ is not None:
+            assert torch.equal(a_, b_), k
+
+
 def test_deferred_batchnorm_in_encoder_convs(dev, monkeypatch):
     """The same for ImageEncoder (Conv2d blocks: mdmm_conv_down normalises its big side while staging it, the
     statistics come out of the producing convolution's epilogue -- the first layer's from fp32 frames): against the
