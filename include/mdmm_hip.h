@@ -600,10 +600,11 @@ typedef struct mdmm_conv {
    * MDMM_BN_FINALIZE_GIVEN and splits = mdmm_conv_up_parts.  NULL: none.  */
   double* out_stats;
   int32_t out_group_n, reserved;
-  /* mdmm_conv_wgrad with in_mean on the SMALL side (a Deconv's weight gradient, small = the pre-normalisation output x
-   * of the block in front, bf16 sides): the REDUCTION pass of that block's BatchNorm adjoint (mdmm_bn_relu_bwd, phase
-   * MDMM_BN_STATS) out of this launch, which stages every element of x anyway.  bst_dy = the gradient of the
-   * normalised activation (N, CS, S, S) bf16 (the Deconv's input gradient, mdmm_conv_down).  Every workgroup leaves
+  /* mdmm_conv_wgrad with in_mean (a Deconv's weight gradient: the SMALL side, or with in_relu bit 1 a Conv's: the BIG
+   * side with 16 / 32 channels, = the pre-normalisation output x of the block in front, bf16 sides): the REDUCTION pass
+   * of that block's BatchNorm adjoint (mdmm_bn_relu_bwd, phase MDMM_BN_STATS) out of this launch, which stages every
+   * element of x anyway.  bst_dy = the gradient of the normalised activation, bf16, in x's shape (the layer's input
+   * gradient, mdmm_conv_down / mdmm_conv_up); CS below = that side's channel count.  Every workgroup leaves
    * (sum g, sum g xhat), g = dy [bn(x) > 0] (in_relu bit 0), xhat = (x - in_mean) in_invstd, of its images in
    * bst_part[((grp * CS + c) * mdmm_conv_wgrad_parts(args) + workgroup) * 2 + {0, 1}] (zeros for groups it held no
    * image of); the caller hands that buffer to mdmm_bn_relu_bwd as `partial` with phase = MDMM_BN_APPLY and

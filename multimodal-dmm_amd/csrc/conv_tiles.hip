@@ -654,15 +654,16 @@ template <int S, int CS, int CB, int KS, bool SB, bool BB, int NORM = 0, bool BS
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, float* part, int NT) {
   using G = Shape<S, CS, CB>;
   using W = Wg<S, CS, CB, KS>;
-  static_assert(!BST || (NORM == 1 && SB), "the adjoint's sums: bf16 small side in pre-normalisation form");
+  static_assert(!BST || (NORM == 1 && SB) || (NORM == 2 && BB), "the adjoint's sums: the bf16 side in pre-normalisation form");
   static_assert(!LZ || (NORM == 0 && !BST && SB), "lazy adjoint: bf16 small side, nothing else staged specially");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const ntab = reinterpret_cast<float*>(smem + ((W::LDS + 15) & ~15));
   // BST: [group][mean | invstd][channel] and the workgroup's sums [group][channel][2] behind the scale / shift table
   // (tables of the launch's own group count: with eight groups' worth S = 16 / 32 would not fit two workgroups per CU)
   const int n_groups = NORM ? (a.N + a.in_group_n - 1) / a.in_group_n : 0;
+  constexpr int CC = NORM == 2 ? CB : CS;                      // channels of the normalised side
   float* const mtab = ntab + n_groups * 2 * (CS > CB ? CS : CB);
-  double* const gacc = reinterpret_cast<double*>(mtab + n_groups * 2 * CS);
+  double* const gacc = reinterpret_cast<double*>(mtab + n_groups * 2 * CC);
   float4* const ltab = reinterpret_cast<float4*>(ntab);        // LZ: [group][channel][2] (conv_down_kernel's table)
   if constexpr (LZ) {
     const int groups = (a.N + a.lazy_group_n - 1) / a.lazy_group_n;
@@ -697,12 +698,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   if constexpr (NORM == 2) norm_table<CB>(a, ntab, 512);
   if constexpr (BST) {
     const int groups = (a.N + a.in_group_n - 1) / a.in_group_n;
-    for (int i = threadIdx.x; i < groups * CS; i += 512) {
-      const int g = i / CS, c = i % CS;
-      mtab[(2 * g) * CS + c] = a.in_mean[i];
-      mtab[(2 * g + 1) * CS + c] = a.in_invstd[i];
+    for (int i = threadIdx.x; i < groups * CC; i += 512) {
+      const int g = i / CC, c = i % CC;
+      mtab[(2 * g) * CC + c] = a.in_mean[i];
+      mtab[(2 * g + 1) * CC + c] = a.in_invstd[i];
     }
-    for (int i = threadIdx.x; i < groups * CS * 2; i += 512) gacc[i] = 0.0;
+    for (int i = threadIdx.x; i < groups * CC * 2; i += 512) gacc[i] = 0.0;
   }
   // per job: this lane's column -> byte offset of its plane rows (or -1) and its shift (-1, 0, +1)
   int col_off[MAXJ], col_sh[MAXJ];
@@ -742,23 +743,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
   // S = 32: the gradient is fetched where it is used instead of travelling beside x through the contraction (its 16
   // registers were the difference between one and two workgroups per CU; the other workgroup covers the round trip)
   constexpr bool BST_LATE = BST && S == 32;
-  bf16x8 rd[(BST || LZ) ? SM_IT : 1];                  // LZ: rs = dy, rd = x
-  float bs1[BST ? SM_IT : 1], bs2[BST ? SM_IT : 1];
+  constexpr int NQ = NORM == 2 ? BG_IT : SM_IT;       // vectors of the normalised side per thread
+  bf16x8 rd[(BST || LZ) ? NQ : 1];                     // LZ: rs = dy, rd = x
+  float bs1[BST ? NQ : 1], bs2[BST ? NQ : 1];
   int bst_g = -1;
   if constexpr (BST) {
 #pragma unroll
-    for (int q = 0; q < SM_IT; ++q) { bs1[q] = 0.f; bs2[q] = 0.f; }
+    for (int q = 0; q < NQ; ++q) { bs1[q] = 0.f; bs2[q] = 0.f; }
   }
   // a thread's sums -> the workgroup's table of group g (a thread's elements are always one channel's)
   auto bst_flush = [&](int g) {
     if constexpr (BST) {
 #pragma unroll
-      for (int q = 0; q < SM_IT; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         const int it = threadIdx.x + 512 * q;
-        if (it < CS * NPIX / 8) {
-          const int ch = it / (NPIX / 8);
-          atomicAdd(&gacc[(g * CS + ch) * 2], (double)bs1[q]);
-          atomicAdd(&gacc[(g * CS + ch) * 2 + 1], (double)bs2[q]);
+        const bool in = NORM == 2 ? it < cb * B2 * (B2 / 8) : it < CS * NPIX / 8;
+        if (in) {
+          const int ch = NORM == 2 ? it / ((B2 / 8) * B2) : it / (NPIX / 8);
+          atomicAdd(&gacc[(g * CC + ch) * 2], (double)bs1[q]);
+          atomicAdd(&gacc[(g * CC + ch) * 2 + 1], (double)bs2[q]);
         }
         bs1[q] = 0.f; bs2[q] = 0.f;
       }
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
         } else {
           rs[q] = load8<SB>(a.small, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
         }
-        if constexpr (BST && !BST_LATE) rd[q] = load8<true>(a.bst_dy, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
+        if constexpr (BST && NORM == 1 && !BST_LATE) rd[q] = load8<true>(a.bst_dy, ssrc + (size_t)(it / (NPIX / 8)) * NPIX + (it % (NPIX / 8)) * 8);
       }
     }
 #pragma unroll
@@ -785,6 +788,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
       if (it < cb * B2 * (B2 / 8)) {
         const int xg = it % (B2 / 8), Y = (it / (B2 / 8)) % B2, b = it / ((B2 / 8) * B2);
         rb[q] = load8<BB>(a.big, bsrc + ((size_t)b * B2 + Y) * B2 + 8 * xg);
+        if constexpr (BST && NORM == 2) rd[q] = load8<true>(a.bst_dy, bsrc + ((size_t)b * B2 + Y) * B2 + 8 * xg);
       }
     }
   };
@@ -858,11 +862,32 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
         const int xg = it % (B2 / 8), Y = (it / (B2 / 8)) % B2, b = it / ((B2 / 8) * B2);
         bf16x8 w8 = rb[q];
         if constexpr (NORM == 2) {      // the big side is the layer's input (Conv): the block in front's BatchNorm + ReLU
-          const float* tab = ntab + (size_t)(n_img / a.in_group_n) * 2 * CB;
+          const int grp = n_img / a.in_group_n;
+          const float* tab = ntab + (size_t)grp * 2 * CB;
           const float sc = tab[b], sh = tab[CB + b];
           const bool relu = (a.in_relu & 1) != 0;
+          if constexpr (BST) {          // + the adjoint's sums, as on the small side above
+            const float mean = mtab[(2 * grp) * CC + b], invstd = mtab[(2 * grp + 1) * CC + b];
+            const bf16x8 d = rd[q];
+            float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) w8[j] = norm1(w8[j], sc, sh, relu);
+            for (int j = 0; j < 8; ++j) {
+              const float xv = (float)w8[j];
+              const float f = fmaf(xv, sc, sh);
+              const float gv = (relu && f <= 0.f) ? 0.f : (float)d[j];
+              t1 += gv; t2 = fmaf(gv, (xv - mean) * invstd, t2);
+              w8[j] = (__bf16)(relu ? fmaxf(f, 0.f) : f);
+            }
+            {
+              uint4 pk = __builtin_bit_cast(uint4, w8);
+              asm volatile("" : "+v"(pk.x), "+v"(pk.y), "+v"(pk.z), "+v"(pk.w), "+v"(t1), "+v"(t2));
+              w8 = __builtin_bit_cast(bf16x8, pk);
+            }
+            bs1[q] += t1; bs2[q] += t2;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w8[j] = norm1(w8[j], sc, sh, relu);
+          }
         }
         bf16x4 e, o;
 #pragma unroll
@@ -937,7 +962,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
     if (bst_g >= 0) bst_flush(bst_g);
     __syncthreads();
     const int groups = (a.N + a.in_group_n - 1) / a.in_group_n;
-    for (int i = threadIdx.x; i < groups * CS; i += 512) {
+    for (int i = threadIdx.x; i < groups * CC; i += 512) {
       double* o = a.bst_part + ((size_t)i * gridDim.x + blockIdx.x) * 2;
       o[0] = gacc[2 * i]; o[1] = gacc[2 * i + 1];
     }
@@ -1175,10 +1200,12 @@ int run_wgrad_norm(const mdmm_conv_t* a, float* part, hipStream_t st) {
   const int groups = (a->N + a->in_group_n - 1) / a->in_group_n;
   const int lds = ((W::LDS + 15) & ~15) + groups * 2 * (CS > CB ? CS : CB) * 4;
   const bool big = (a->in_relu & 2) != 0;        // which side is the layer's input
-  if (a->bst_dy) {                               // + the small side's BatchNorm adjoint sums (bst_part)
-    if (big || !a->bst_part || !a->in_mean) return MDMM_E_ARG;
-    const int lds_b = lds + groups * 2 * CS * 4 + groups * CS * 2 * 8;
-    auto kb = conv_wgrad_kernel<S, CS, CB, KS, true, true, 1, true>;
+  if (a->bst_dy) {                               // + the normalised side's BatchNorm adjoint sums (bst_part)
+    if (!a->bst_part || !a->in_mean) return MDMM_E_ARG;
+    const int cc = big ? CB : CS;
+    if (big && CB <= 4) return MDMM_E_ARG;
+    const int lds_b = lds + groups * 2 * cc * 4 + groups * cc * 2 * 8;
+    auto kb = big ? conv_wgrad_kernel<S, CS, CB, KS, true, true, 2, true> : conv_wgrad_kernel<S, CS, CB, KS, true, true, 1, true>;
     int rc = set_lds(kb, lds_b);
     if (rc) return rc;
     hipLaunchKernelGGL(kb, dim3(wgrad_parts(a)), dim3(512), lds_b, st, *a, part, wgrad_nt(a));

@@ -2349,7 +2349,9 @@ class _BnDeconvFn(torch.autograd.Function):
             #  171 + 110 us apart and 291 us together -- inside the step, next to the other streams' kernels, together is
             #  0.3 ms per step better; MDMM_BN_BWD_STATS_FUSED=3: at 16 x 16 only, =0: nowhere)
             mode = os.environ.get('MDMM_BN_BWD_STATS_FUSED', '1')
-            if need_x and transposed and G <= 8 and mode != '0' and (c.S == 16 or mode != '3'):
+            # (a Conv's -- the encoders' -- at 16 x 16 only: at 8 x 8 the sums' registers cost that kernel its second
+            #  workgroup per CU)
+            if need_x and G <= 8 and mode != '0' and (c.S == 16 or (mode != '3' and transposed)):
                 # the reduction pass of the BatchNorm adjoint rides on the weight-gradient kernel, which stages every
                 # element of x anyway: dyn is read beside it once instead of (dyn, x) in a pass of their own
                 bst_splits = native.lib().mdmm_conv_wgrad_parts(C.byref(c))

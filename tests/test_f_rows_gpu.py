@@ -531,6 +531,36 @@ def test_batchnorm_adjoint_applied_by_the_consuming_deconvolution(dev, groups, m
                 assert torch.equal(a_, b_), (fused, k)
 
 
+def test_encoder_batchnorm_adjoint_sums_out_of_the_weight_gradient_kernel(dev, monkeypatch):
+    """The same as test_batchnorm_adjoint_sums_out_of_the_weight_gradient_kernel for the encoders' Conv2d blocks: the
+    weight-gradient kernel of Conv 16 -> 32 stages the first block's pre-normalisation output as its BIG side and leaves
+    that BatchNorm's adjoint sums (mdmm_conv_t.bst_dy with in_relu bit 1): every gradient to 1e-5 (L2)."""
+    import copy
+    from mdmm import ops
+    from mdmm.models import common as C
+    torch.manual_seed(23)
+    ref = C.ImageEncoder(256, n_channels=3).to(dev).train()
+    x = torch.rand(600, 3, 64, 64, device=dev)
+    names = [k for k, _ in ref.named_parameters()]
+    res = {}
+    for mode in ('0', '1'):
+        enc = copy.deepcopy(ref)
+        monkeypatch.setenv('MDMM_BN_BWD_STATS_FUSED', mode)
+        with ops.conv_operands(torch.bfloat16, torch.bfloat16):
+            mean, std = enc(x)
+        gm = torch.randn(mean.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        res[mode] = torch.autograd.grad((mean * gm).sum() + std.sum(), list(enc.parameters()), allow_unused=True)
+    l2 = lambda a_, b_: float((a_.float() - b_.float()).norm() / (b_.float().norm() + 1e-30))      # noqa: E731
+    worst = 0.0
+    for k, a_, b_ in zip(names, res['1'], res['0']):
+        assert (a_ is None) == (b_ is None), k
+        if a_ is not None:
+            worst = max(worst, l2(a_, b_))
+            assert l2(a_, b_) < 1e-5, (k, l2(a_, b_))
+    assert worst > 0.0          # (the fused path did run: another summation order)
+    helpers.note('bn_adjoint_sums_fused.encoder.l2', worst)
+
+
 def test_encoder_batchnorm_adjoint_applied_by_the_first_layers_weight_gradient(dev, monkeypatch):
     """ImageEncoder: the adjoint of the first block's BatchNorm stops behind its reduction, and the first layer's
     weight-gradient kernel (Conv2d 3 -> 16 on frames that need no gradient) forms the gradient of its output while it
@@ -573,6 +603,7 @@ def test_deferred_batchnorm_in_encoder_convs(dev, monkeypatch):
     ref = C.ImageEncoder(256, n_channels=3).to(dev).train()
     x = torch.rand(600, 3, 64, 64, device=dev)
     res = []
+    monkeypatch.setenv('MDMM_BN_BWD_STATS_FUSED', '0')      # (test_encoder_batchnorm_adjoint_sums_... covers the other order)
     for deconv, epilogue in (('1', '1'), ('1', '0'), ('0', '0')):
         enc = copy.deepcopy(ref)
         monkeypatch.setenv('MDMM_BN_DECONV', deconv)
