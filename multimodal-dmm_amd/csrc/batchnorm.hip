@@ -143,18 +143,35 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
                                                       T* __restrict__ y,
                                                       float* save_mean, float* save_invstd,
                                                       const double* __restrict__ gsum, double gcount, int nparts) {
+  __shared__ double sh[2 * NT / 64];
   const int c = blockIdx.x;
   const int grp = blockIdx.z, n_grp = gridDim.z;       // groups: each N images with statistics of their own
   const double M = gsum ? gcount : (double)N * (double)L;
+  // Many slabs (a producing convolution's workgroups left them: mdmm_conv_t.out_stats, 512 per channel): summed by the
+  // workgroup -- as a loop in every thread that fold was 74 us per launch of a kernel that does nothing else
+  // (MDMM_BN_FINALIZE_GIVEN), twelve launches on the forward chain of a cfg3 step.  Few slabs: every thread its own loop.
+  const bool coop = !gsum && nparts > 32;
   auto stats_of = [&](int gi, double& mean, double& var) {
     double d1 = 0, d2 = 0;
     if (gsum) {                                  // statistics of the GLOBAL batch (all ranks), see mdmm_bn_t
       d1 = gsum[2 * c]; d2 = gsum[2 * c + 1];
     } else {
-      const double* p = partial + (size_t)gi * C * nparts * 2;
-      for (int s = 0; s < nparts; ++s) {
-        d1 += p[((size_t)c * nparts + s) * 2];
-        d2 += p[((size_t)c * nparts + s) * 2 + 1];
+      const double* p = partial + ((size_t)gi * C + c) * nparts * 2;
+      if (coop) {
+        for (int s = threadIdx.x; s < nparts; s += blockDim.x) { d1 += p[2 * s]; d2 += p[2 * s + 1]; }
+        d1 = mdmm::wave_sum_d(d1); d2 = mdmm::wave_sum_d(d2);
+        const int nw = blockDim.x >> 6;
+        if (nw > 1) {
+          if ((threadIdx.x & 63) == 0) { sh[2 * (threadIdx.x >> 6)] = d1; sh[2 * (threadIdx.x >> 6) + 1] = d2; }
+          __syncthreads();
+          d1 = 0; d2 = 0;
+          for (int i = 0; i < nw; ++i) { d1 += sh[2 * i]; d2 += sh[2 * i + 1]; }
+          __syncthreads();
+        } else {
+          d1 = __shfl(d1, 0, 64); d2 = __shfl(d2, 0, 64);       // (the sum sits in lane 0)
+        }
+      } else {
+        for (int s = 0; s < nparts; ++s) { d1 += p[2 * s]; d2 += p[2 * s + 1]; }
       }
     }
     mean = d1 / M;
@@ -164,23 +181,21 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
   double mean, var;
   stats_of(grp, mean, var);
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  if (blockIdx.y == 0 && threadIdx.x == 0) {
-    save_mean[(size_t)grp * C + c] = (float)mean; save_invstd[(size_t)grp * C + c] = invstd;
-    if (running_mean && grp == 0) {              // torch: unbiased variance into the running stat
-      // the groups are successive calls of the stock module: their updates in that order
-      const float ms = mean_shift ? mean_shift[c] : 0.0f;
-      float rm = running_mean[c], rv = running_var[c];
-      for (int gi = 0; gi < n_grp; ++gi) {
-        double mg = mean, vg = var;
-        if (gi > 0) stats_of(gi, mg, vg);
-        const double unb = M > 1 ? vg * M / (M - 1) : vg;
-        // mean_shift: the bias of the convolution in front, left out of x (it cancels in the
-        // normalisation) but part of the statistic the stock modules track
-        rm = (1.0f - momentum) * rm + momentum * ((float)mg + ms);
-        rv = (1.0f - momentum) * rv + momentum * (float)unb;
-      }
-      running_mean[c] = rm; running_var[c] = rv;
+  if (blockIdx.y == 0 && threadIdx.x == 0) { save_mean[(size_t)grp * C + c] = (float)mean; save_invstd[(size_t)grp * C + c] = invstd; }
+  if (blockIdx.y == 0 && running_mean && grp == 0 && (coop || threadIdx.x == 0)) {     // torch: unbiased variance into the running stat
+    // the groups are successive calls of the stock module: their updates in that order
+    const float ms = mean_shift ? mean_shift[c] : 0.0f;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int gi = 0; gi < n_grp; ++gi) {
+      double mg = mean, vg = var;
+      if (gi > 0) stats_of(gi, mg, vg);
+      const double unb = M > 1 ? vg * M / (M - 1) : vg;
+      // mean_shift: the bias of the convolution in front, left out of x (it cancels in the
+      // normalisation) but part of the statistic the stock modules track
+      rm = (1.0f - momentum) * rm + momentum * ((float)mg + ms);
+      rv = (1.0f - momentum) * rv + momentum * (float)unb;
     }
+    if (threadIdx.x == 0) { running_mean[c] = rm; running_var[c] = rv; }
   }
   if (!y) return;                                // MDMM_BN_FINALIZE: the consumer normalises (mdmm_conv_t.in_mean)
   x += (size_t)grp * N * C * L;                  // (tested BEFORE the group offset: null + offset is not null)
