@@ -145,6 +145,29 @@ __device__ __forceinline__ void pack_up_body(const float* w, int cb, int KS, uin
     }
     out[idx] = __builtin_bit_cast(uint4, v);
   }
+  // 1 .. 4 output channels: a second set for ONE chain over the 3 x 3 neighbourhood of an input pixel (nine chunks of
+  // CS = 16 channels) whose rows are all four parity classes: row m = 8 py + 4 (ch / 2) + 2 (ch % 2) + px, so that a
+  // lane's registers 4 py + 2 (ch % 2) + {0, 1} are the two horizontally adjacent output pixels of channel
+  // 2 (lane / 32) + ch % 2.  Tap (dy, dx) in {-1, 0, 1}^2 feeds class (py, px) where dy in {py - 1, py}, dx in {px - 1, px}:
+  // kernel element (1 + py - 2 dy, 1 + px - 2 dx).
+  if constexpr (CB <= 4) {
+    static_assert(CS == 16, "one chunk per tap");
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 9 * 64; idx += gridDim.x * blockDim.x) {
+      const int lane = idx & 63, t = idx >> 6, m = lane & 31, h = lane >> 5;
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const int py = m >> 3, ch = 2 * ((m >> 2) & 1) + ((m >> 1) & 1), px = m & 1;
+      const int ky = 1 + py - 2 * dy, kx = 1 + px - 2 * dx;
+      const bool live = m < 16 && ch < cb && (dy == py - 1 || dy == py) && (dx == px - 1 || dx == px) && ky >= 0 &&
+                        kx >= 0 && ky < KS && kx < KS;
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ci = 8 * h + j;
+        v[j] = (__bf16)(live ? w[((size_t)(ci * cb + ch) * KS + ky) * KS + kx] : 0.f);
+      }
+      out[total + idx] = __builtin_bit_cast(uint4, v);
+    }
+  }
 }
 
 template <int S, int CS, int CB>
@@ -246,7 +269,7 @@ __device__ __forceinline__ void up_commit(char* smem, const UpStage<S, CS>& st, 
   }
 }
 
-template <int S, int CS, int CB, bool SB, bool BB, bool NORM = false, bool STATS = false>
+template <int S, int CS, int CB, bool SB, bool BB, bool NORM = false, bool STATS = false, bool T9 = false>
 __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   using G = Shape<S, CS, CB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -257,8 +280,13 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   const int py = wave >> 1, px = wave & 1, cb = a.CB;
   // this class's weights stay in registers for the whole kernel (CB <= 4: the wave takes BOTH column parities of its
   // row parity, for every other pixel tile: wf = the even columns' class, wf1 = the odd columns')
-  uint4 wf[G::UP_CH], wf1[CB <= 4 ? G::UP_CH : 1];
-  {
+  uint4 wf[T9 ? 9 : G::UP_CH], wf1[(CB <= 4 && !T9) ? G::UP_CH : 1];
+  if constexpr (T9) {
+    // one chain per pixel tile over the 3 x 3 neighbourhood, all four parity classes as its rows (pack_up_body)
+    const uint4* src = reinterpret_cast<const uint4*>(a.wfrag) + (size_t)4 * G::UP_CH * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) wf[c] = src[c * 64];
+  } else {
     const int cls = CB <= 4 ? 2 * py : wave;
     const uint4* src = reinterpret_cast<const uint4*>(a.wfrag) + (size_t)cls * G::UP_CH * 64 + lane;
 #pragma unroll
@@ -337,7 +365,45 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
     if (n + (int)gridDim.x < a.N) up_fetch<S, CS, SB>(a, n + gridDim.x, stage);
     const size_t dst0 = (size_t)n * cb * (4 * NPIX);
     constexpr f32x16 ZERO = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (CB <= 4) {
+    if constexpr (T9) {
+      // 1 .. 4 output channels, nine MFMAs per tile of 32 input pixels for all four classes (sixteen as four class
+      // chains; nine instead of sixteen operand reads too).  A lane holds channels 2 h, 2 h + 1: for each output row
+      // parity and channel the two horizontally adjacent pixels -- one 4-byte (bf16) element, 32 lanes one run of a row.
+      static_assert(CB <= 4 && CS == 16 && (NPIX / 32) % 8 == 0, "thin side, tile pairs per wave");
+      const float bs0 = (a.bias && 2 * h < cb) ? a.bias[2 * h] : 0.f, bs1 = (a.bias && 2 * h + 1 < cb) ? a.bias[2 * h + 1] : 0.f;
+      const bool live0 = 2 * h < cb, live1 = 2 * h + 1 < cb;
+      for (int tile = wave; tile < NPIX / 32; tile += 8) {
+        // two tiles per trip: two independent chains
+        const int p0 = tile * 32 + (lane & 31), y0 = p0 / S, x0 = p0 % S;
+        const int p1 = p0 + 4 * 32, y1 = p1 / S, x1 = p1 % S;
+        const char* base0 = smem + (y0 * G::UP_PW + x0) * G::UP_PS + 16 * h;
+        const char* base1 = smem + (y1 * G::UP_PW + x1) * G::UP_PS + 16 * h;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+          const int at = ((c / 3) * G::UP_PW + c % 3) * G::UP_PS;          // (dy + 1, dx + 1) in the haloed patch
+          const uint4 b0 = *reinterpret_cast<const uint4*>(base0 + at), b1 = *reinterpret_cast<const uint4*>(base1 + at);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, b0),
+                                                         c ? acc0 : ZERO, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, b1),
+                                                         c ? acc1 : ZERO, 0, 0, 0);
+        }
+        const size_t plane = (size_t)(4 * NPIX);
+        const size_t o0 = dst0 + (size_t)(2 * h) * plane + (size_t)(2 * y0) * G::B2 + 2 * x0;
+        const size_t o1 = dst0 + (size_t)(2 * h) * plane + (size_t)(2 * y1) * G::B2 + 2 * x1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {           // output row parity
+          if (live0) {
+            store2<BB>(a.big, o0 + q * G::B2, acc0[4 * q] + bs0, acc0[4 * q + 1] + bs0);
+            store2<BB>(a.big, o1 + q * G::B2, acc1[4 * q] + bs0, acc1[4 * q + 1] + bs0);
+          }
+          if (live1) {
+            store2<BB>(a.big, o0 + plane + q * G::B2, acc0[4 * q + 2] + bs1, acc0[4 * q + 3] + bs1);
+            store2<BB>(a.big, o1 + plane + q * G::B2, acc1[4 * q + 2] + bs1, acc1[4 * q + 3] + bs1);
+          }
+        }
+      }
+    } else if constexpr (CB <= 4) {
       // 1 .. 4 output channels: rows 0 .. 3 of a tile, all in the lower half-wave's registers 0 .. 3
       // (sixteen lane-dependent `m < cb` tests per tile were most of this kernel's instructions).
       // Two tiles at a time: a tile is a chain of UP_CH dependent MFMAs, two chains hide each other's
@@ -1051,10 +1117,16 @@ constexpr int NORM_LDS(int channels) { return NORM_GROUPS * 2 * channels * 4; }
 bool norm_ok(const mdmm_conv_t* a) {
   return a->in_invstd && a->in_group_n >= 1 && (a->N + a->in_group_n - 1) / a->in_group_n <= NORM_GROUPS;
 }
+// 1 .. 4 output channels: the nine-tap chain (A/B: MDMM_CONV_UP_T9=0, the four class chains)
+bool up_t9() {
+  static const bool on = [] { const char* e = getenv("MDMM_CONV_UP_T9"); return !e || atoi(e) != 0; }();
+  return on;
+}
 template <int S, int CS, int CB, bool SB, bool BB>
 int run_up_io(const mdmm_conv_t* a, hipStream_t st) {
   using G = Shape<S, CS, CB>;
   auto k = conv_up_kernel<S, CS, CB, SB, BB>;
+  if constexpr (CB <= 4) { if (up_t9()) k = conv_up_kernel<S, CS, CB, SB, BB, false, false, true>; }
   int rc = set_lds(k, G::UP_LDS);
   if (rc) return rc;
   hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2, "MDMM_CONV_UP_PER_CU")), dim3(256), G::UP_LDS, st, *a);
@@ -1066,6 +1138,7 @@ int run_up_norm(const mdmm_conv_t* a, hipStream_t st) {
   using G = Shape<S, CS, CB>;
   if (io_of(a) != 1 || !norm_ok(a)) return MDMM_E_ARG;
   auto k = conv_up_kernel<S, CS, CB, true, true, true>;
+  if constexpr (CB <= 4) { if (up_t9()) k = conv_up_kernel<S, CS, CB, true, true, true, false, true>; }
   constexpr int lds = G::UP_LDS + NORM_LDS(CS);
   int rc = set_lds(k, lds);
   if (rc) return rc;
@@ -1264,7 +1337,7 @@ extern "C" int mdmm_conv_down_parts(const mdmm_conv_t* a) {
 extern "C" int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* a, int up) {
   const int id = shape_id(a);
   if (id < 0) return 0;
-  if (up) return (int64_t)4 * (4 * a->CS / 16) * 1024;
+  if (up) return (int64_t)4 * (4 * a->CS / 16) * 1024 + (id == 2 ? 9 * 1024 : 0);      // (+ the thin side's nine-tap set)
   const int ch = id == 2 ? a->KS : a->KS * a->KS * a->CB / 16;
   return (int64_t)((a->CS + 31) / 32) * ch * 1024;
 }
