@@ -628,6 +628,11 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int r = 4 * q + k;
+#ifndef B4_E_ALL
+            // a register that is a dead row in BOTH half-waves (row 8 q + k >= K; at K = 25: registers 13 .. 15, a fifth of
+            // this phase's arithmetic): its outputs are the zeros the masks below would have made them
+            if (8 * q + k >= K) { o_g3[k] = 0.f; o_gg[k] = 0.f; o_gl[k] = 0.f; v1[rt][r] = 0.f; continue; }
+#endif
             const float pre = v1[rt][r] + bs;
             const float muq = v0[rt][r];
             // softplus and its derivative from one exponential: y = e^-|pre|
