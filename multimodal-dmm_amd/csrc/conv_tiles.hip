@@ -280,18 +280,27 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
   const int py = wave >> 1, px = wave & 1, cb = a.CB;
   // this class's weights stay in registers for the whole kernel (CB <= 4: the wave takes BOTH column parities of its
   // row parity, for every other pixel tile: wf = the even columns' class, wf1 = the odd columns')
-  uint4 wf[T9 ? 9 : G::UP_CH], wf1[(CB <= 4 && !T9) ? G::UP_CH : 1];
+  // P2 (16 output channels): a wave takes BOTH column parities of its row parity for every other pixel tile, as the thin
+  // side did before its nine-tap chain: a lane then holds the two horizontally adjacent output pixels of its input pixel
+  // and stores them as one 4-byte element (with one class per wave every store filled every other 2-byte element of its
+  // lines, twice over)
+#ifdef CONV_UP_NO_P2       // (A/B build, tools/build_variant.sh)
+  constexpr bool P2 = false;
+#else
+  constexpr bool P2 = CB == 16 && !T9;
+#endif
+  uint4 wf[T9 ? 9 : G::UP_CH], wf1[((CB <= 4 && !T9) || P2) ? G::UP_CH : 1];
   if constexpr (T9) {
     // one chain per pixel tile over the 3 x 3 neighbourhood, all four parity classes as its rows (pack_up_body)
     const uint4* src = reinterpret_cast<const uint4*>(a.wfrag) + (size_t)4 * G::UP_CH * 64 + lane;
 #pragma unroll
     for (int c = 0; c < 9; ++c) wf[c] = src[c * 64];
   } else {
-    const int cls = CB <= 4 ? 2 * py : wave;
+    const int cls = (CB <= 4 || P2) ? 2 * py : wave;
     const uint4* src = reinterpret_cast<const uint4*>(a.wfrag) + (size_t)cls * G::UP_CH * 64 + lane;
 #pragma unroll
     for (int c = 0; c < G::UP_CH; ++c) wf[c] = src[c * 64];
-    if constexpr (CB <= 4) {
+    if constexpr (CB <= 4 || P2) {
 #pragma unroll
       for (int c = 0; c < G::UP_CH; ++c) wf1[c] = src[(G::UP_CH + c) * 64];
     }
@@ -433,6 +442,35 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (r < cb) store2<BB>(a.big, o0 + (size_t)r * (4 * NPIX), acc0[r] + bias[r], acc1[r] + bias[r]);
+        }
+      }
+    } else if constexpr (P2) {
+      static_assert((NPIX / 32) % 2 == 0, "tile pairs");
+      for (int tile = px; tile < NPIX / 32; tile += 2) {
+        const int p0 = tile * 32 + (lane & 31), y0 = p0 / S, x0 = p0 % S;
+        const char* base0 = smem + ((y0 + py) * G::UP_PW + x0) * G::UP_PS + 16 * h;
+        const char* base1 = base0 + G::UP_PS;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int c = 0; c < G::UP_CH; ++c) {
+          const int tap = (16 * c) / CS, off = (16 * c) % CS;
+          const int at = ((tap >> 1) * G::UP_PW + (tap & 1)) * G::UP_PS + off * 2;
+          const uint4 b0 = *reinterpret_cast<const uint4*>(base0 + at), b1 = *reinterpret_cast<const uint4*>(base1 + at);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[c]), __builtin_bit_cast(bf16x8, b0),
+                                                         c ? acc0 : ZERO, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf1[c]), __builtin_bit_cast(bf16x8, b1),
+                                                         c ? acc1 : ZERO, 0, 0, 0);
+        }
+        const size_t o0 = dst0 + (size_t)(2 * y0 + py) * G::B2 + 2 * x0;
+#pragma unroll
+        for (int r = 0; r < CB / 2; ++r) {
+          const int m = acc_row(r) + 4 * h;
+          const float v0 = acc0[r] + bias[r], v1 = acc1[r] + bias[r];
+          store2<BB>(a.big, o0 + (size_t)m * (4 * NPIX), v0, v1);
+          if constexpr (STATS) {            // of the values as stored
+            const float r0 = BB ? (float)(__bf16)v0 : v0, r1 = BB ? (float)(__bf16)v1 : v1;
+            s1[r] += r0 + r1; s2[r] = fmaf(r0, r0, fmaf(r1, r1, s2[r]));
+          }
         }
       }
     } else {
