@@ -125,6 +125,14 @@ class MultiDMM(MultiDGTS):
         mask = torch.ones(shape[:-1], dtype=torch.uint8, device=mean.device)
         return mean, std, mask
 
+    def _prior_ms(self, shape):
+        """(mean, std) of prior(shape) as broadcast VIEWS (shape[-1] == 1): `repeat` is a copy kernel each way and the
+        mask a fill -- six launches per kld_prior call on the prior-matching term's chain of few-microsecond launches."""
+        if shape[-1] != 1:
+            return self.prior(shape)[:2]
+        lead = tuple(shape[:-1])
+        return (self.z0_mean.expand(*lead, self.z_dim), (self.z0_log_std.exp() + self.min_std).expand(*lead, self.z_dim))
+
     def _encode_one(self, m, x):
         """One modality -> ((T,B,D) mean, (T,B,D) std, (T,B) bool seen).  dmm.py:164-177"""
         t_max, b_dim = x.shape[:2]
@@ -181,7 +189,7 @@ class MultiDMM(MultiDGTS):
         (drawn by the caller at the reference's position in the draw order)."""
         if z_init is not None:
             raise NotImplementedError('z_init: see dmm.py:292 -- unusable in the reference')
-        glb_mean, glb_std, _ = self.prior((b_dim, 1))
+        glb_mean, glb_std = self._prior_ms((b_dim, 1))
         mean_t, std_t = glb_mean, glb_std
         means, stds = [], []
         if inclusive:
@@ -358,7 +366,7 @@ class MultiDMM(MultiDGTS):
 
     def kld_prior(self, n_particles, direction='fwd', eps=None):
         """dmm.py:496-501"""
-        glb_mean, glb_std, _ = self.prior((1, 1, 1))
+        glb_mean, glb_std = self._prior_ms((1, 1, 1))
         nxt_mean, nxt_std = self.z_sample(1, 1, direction, True, n_particles,
                                           eps=None if eps is None else [eps])
         return ops.kld_gauss(glb_mean, glb_std, nxt_mean, nxt_std)
