@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 24
+#define MDMM_ABI_VERSION 25
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -263,6 +263,20 @@ int mdmm_sweep_spill_width_x(int D, int H);
 int mdmm_spill_wgrad_splits(int64_t rows, int gcols, int xcols);
 int mdmm_spill_wgrad(const float* G, int ldg, int gcol0, int gcols, const float* X, int ldx,
                      int xcol0, int xcols, int64_t rows, int splits, float* out, void* stream);
+/* The same for up to four (G slice, X slice) pairs over the SAME rows in ONE launch (no row splits: short spills --
+ * the 50 rows of the prior-matching term, dmm.py:496-501): out = gcols x xcols floats per item. */
+#define MDMM_SPILL_WGRAD_BATCH_MAX 4
+typedef struct mdmm_spill_wgrad_item {
+  int32_t gcol0, gcols, xcol0, xcols;
+  float* out;
+  int32_t tiles, reserved;     /* (filled by the library) */
+} mdmm_spill_wgrad_item_t;
+typedef struct mdmm_spill_wgrad_batch {
+  int32_t n, reserved;
+  mdmm_spill_wgrad_item_t item[MDMM_SPILL_WGRAD_BATCH_MAX];
+} mdmm_spill_wgrad_batch_t;
+int mdmm_spill_wgrad_batch(const float* G, int ldg, const float* X, int ldx, int64_t rows,
+                           const mdmm_spill_wgrad_batch_t* batch, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Stand-alone product / mixture of experts: MultiDGTS.product_of_experts

@@ -48,7 +48,63 @@ __global__ __launch_bounds__(NT) void spill_wgrad_kernel(const float* __restrict
         slab[(size_t)(n0 + tn + i) * xcols + k0 + tk + j] = acc[i][j];
 }
 
+// up to four (G slice, X slice) products over the SAME rows in one launch (blockIdx.x walks the items' tiles): the
+// four weight blocks of one GaussianGTF from a short spill (the prior-matching term's 50 rows: four 12-us launches
+// one after the other on a chain of few-microsecond launches)
+__global__ __launch_bounds__(NT) void spill_wgrad_batch_kernel(const float* __restrict__ G, int ldg,
+                                                               const float* __restrict__ X, int ldx, int64_t rows,
+                                                               const mdmm_spill_wgrad_batch_t b) {
+  __shared__ float gs[RC][TS + 4], xs[RC][TS + 4];
+  int item = 0, t = blockIdx.x;
+  while (item + 1 < b.n && t >= b.item[item].tiles) { t -= b.item[item].tiles; ++item; }
+  const auto& it = b.item[item];
+  const int kt = (it.xcols + TS - 1) / TS;
+  const int n0 = (t / kt) * TS, k0 = (t % kt) * TS;
+  const int tn = (threadIdx.x >> 4) * 4, tk = (threadIdx.x & 15) * 4;
+  float acc[4][4] = {};
+  for (int64_t r0 = 0; r0 < rows; r0 += RC) {
+    for (int idx = threadIdx.x; idx < RC * TS; idx += NT) {
+      const int rr = idx / TS, c = idx - rr * TS;
+      const int64_t r = r0 + rr;
+      gs[rr][c] = (r < rows && n0 + c < it.gcols) ? G[r * ldg + it.gcol0 + n0 + c] : 0.f;
+      xs[rr][c] = (r < rows && k0 + c < it.xcols) ? X[r * ldx + it.xcol0 + k0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+      const float4 gv = *reinterpret_cast<const float4*>(&gs[rr][tn]);
+      const float4 xv = *reinterpret_cast<const float4*>(&xs[rr][tk]);
+      const float ga[4] = {gv.x, gv.y, gv.z, gv.w}, xa[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(ga[i], xa[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n0 + tn + i < it.gcols && k0 + tk + j < it.xcols)
+        it.out[(size_t)(n0 + tn + i) * it.xcols + k0 + tk + j] = acc[i][j];
+}
+
 }  // namespace
+
+extern "C" int mdmm_spill_wgrad_batch(const float* G, int ldg, const float* X, int ldx, int64_t rows,
+                                      const mdmm_spill_wgrad_batch_t* b, void* stream) {
+  if (!G || !X || !b || rows < 0 || b->n < 1 || b->n > MDMM_SPILL_WGRAD_BATCH_MAX) return MDMM_E_ARG;
+  mdmm_spill_wgrad_batch_t c = *b;
+  int total = 0;
+  for (int i = 0; i < c.n; ++i) {
+    if (!c.item[i].out || c.item[i].gcols < 1 || c.item[i].xcols < 1) return MDMM_E_ARG;
+    c.item[i].tiles = ((c.item[i].gcols + TS - 1) / TS) * ((c.item[i].xcols + TS - 1) / TS);
+    total += c.item[i].tiles;
+  }
+  hipLaunchKernelGGL(spill_wgrad_batch_kernel, dim3(total), dim3(NT), 0, (hipStream_t)stream, G, ldg, X, ldx, rows, c);
+  return (int)hipGetLastError();
+}
 
 extern "C" int mdmm_spill_wgrad_splits(int64_t rows, int gcols, int xcols) {
   const int tiles = ((gcols + TS - 1) / TS) * ((xcols + TS - 1) / TS);

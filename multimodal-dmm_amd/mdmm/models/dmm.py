@@ -183,13 +183,13 @@ class MultiDMM(MultiDGTS):
                                   self.h_dim, self.min_std, precision=self.sweep_dtype)
 
     def z_sample(self, t_max, b_dim, direction='fwd', sample=True, n_particles=1, z_init=None,
-                 inclusive=False, eps=None):
+                 inclusive=False, eps=None, _glb=None):
         """dmm.py:260-317 (z_init is not supported: the reference's own handling of it,
         line 292, cannot run).  eps: optional list of pre-drawn (K,B,D) noise, one per step
         (drawn by the caller at the reference's position in the draw order)."""
         if z_init is not None:
             raise NotImplementedError('z_init: see dmm.py:292 -- unusable in the reference')
-        glb_mean, glb_std = self._prior_ms((b_dim, 1))
+        glb_mean, glb_std = self._prior_ms((b_dim, 1)) if _glb is None else _glb      # (_glb: the caller's own prior((b_dim, 1)))
         mean_t, std_t = glb_mean, glb_std
         means, stds = [], []
         if inclusive:
@@ -206,6 +206,8 @@ class MultiDMM(MultiDGTS):
             means.append(mean_t); stds.append(std_t)
         if direction == 'bwd':
             means.reverse(); stds.reverse()
+        if len(means) == 1 and os.environ.get('MDMM_MATCH_TRIM') != '0':             # (a view: stack is a copy kernel each way)
+            return means[0].unsqueeze(0), stds[0].unsqueeze(0)
         return torch.stack(means), torch.stack(stds)
 
     def sample(self, t_max, b_dim, direction='fwd'):
@@ -368,7 +370,8 @@ class MultiDMM(MultiDGTS):
         """dmm.py:496-501"""
         glb_mean, glb_std = self._prior_ms((1, 1, 1))
         nxt_mean, nxt_std = self.z_sample(1, 1, direction, True, n_particles,
-                                          eps=None if eps is None else [eps])
+                                          eps=None if eps is None else [eps],
+                                          _glb=(glb_mean[0], glb_std[0]) if os.environ.get('MDMM_MATCH_TRIM') != '0' else None)
         return ops.kld_gauss(glb_mean, glb_std, nxt_mean, nxt_std)
 
     # ---- the ELBO step ----------------------------------------------------------------

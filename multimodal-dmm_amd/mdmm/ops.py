@@ -187,10 +187,21 @@ class PackedGtf:
         if G is None or G.shape[0] == 0:
             return [torch.zeros_like(p) for p in like]
         gb = colsum(G) if G.is_cuda else G.sum(0)       # (CPU: only the host-side layout test, with its own `contract`)
-        d_in = spill_wgrad(G, 0, F1, X, 0, Dp)
-        d_gate = spill_wgrad(G, F1, Dp, X, Dp, Hp)
-        d_nl = spill_wgrad(G, F1 + Dp, Dp, X, Dp + Hp, Hp)
-        d_std = spill_wgrad(G, F1 + 2 * Dp, Dp, X, Dp + 2 * Hp, Dp)
+        blocks = [(0, F1, 0, Dp), (F1, Dp, Dp, Hp), (F1 + Dp, Dp, Dp + Hp, Hp), (F1 + 2 * Dp, Dp, Dp + 2 * Hp, Dp)]
+        if contract is None and G.is_cuda and os.environ.get('MDMM_MATCH_TRIM') != '0' and all(native.lib().mdmm_spill_wgrad_splits(G.shape[0], gc, xc) == 1
+                                                  for _, gc, _, xc in blocks):
+            # a short spill (the prior-matching term's 50 rows): the four blocks in ONE launch
+            b = native.SpillWgradBatch()
+            b.n = 4
+            outs = []
+            for k, (g0, gc, x0, xc) in enumerate(blocks):
+                o = torch.empty(gc, xc, device=G.device, dtype=torch.float32)
+                outs.append(o)
+                b.item[k].gcol0, b.item[k].gcols, b.item[k].xcol0, b.item[k].xcols, b.item[k].out = g0, gc, x0, xc, _ptr(o)
+            _call('mdmm_spill_wgrad_batch', _ptr(G), G.stride(0), _ptr(X), X.stride(0), G.shape[0], C.byref(b))
+            d_in, d_gate, d_nl, d_std = outs
+        else:
+            d_in, d_gate, d_nl, d_std = [spill_wgrad(G, g0, gc, X, x0, xc) for g0, gc, x0, xc in blocks]
         return [d_in[0:H, :D], gb[0:H],                                   # z_to_gate.0
                 d_gate[:D, :H], gb[F1:F1 + D],                            # z_to_gate.2
                 d_in[2 * Hp:2 * Hp + D, :D], gb[2 * Hp:2 * Hp + D],       # z_lin
