@@ -606,14 +606,32 @@ class MultiDMM(MultiDGTS):
                 # pass, these ~60 launches are the last thing the autograd engine issues, their
                 # accumulation into the transition gradients waits for the long K-particle sweep,
                 # and they end up as a 0.4 ms tail behind it (tools/step_stamps.py)
-                loss_m = _EagerGradFn.apply(match_loss, self.z0_mean, self.z0_log_std,
-                                            *self._gtf('fwd'), *self._gtf('bwd'))
+                if os.environ.get('MDMM_MATCH_EAGER_GRAD', '1') == '0':      # A/B: the term's backward left to the step's
+                    loss_m = match_loss()
+                else:
+                    loss_m = _EagerGradFn.apply(match_loss, self.z0_mean, self.z0_log_std,
+                                                *self._gtf('fwd'), *self._gtf('bwd'))
             loss_m.record_stream(torch.cuda.current_stream())
         present = [m for m in self.modalities if m in inputs]
         enc, e_cur = {}, torch.cuda.current_stream()
-        e_sides = self._modality_streams(len(present))
+        # EVERY encoder on a side stream, none on the caller's (MDMM_ENC_ALL_SIDE=0: the first one there).  What the
+        # kernel traces of the replayed step show (profiles/r04al_ab_match_term.txt): the graph executor runs four queues
+        # and starts a forked branch only when the SEGMENT of the queue it forked from ends; the prior-matching term's
+        # chain of few-microsecond launches (forked off first) continues the forking queue, so every other branch waits
+        # for it -- 0.87 ms with the first encoder behind it on the caller's stream.  With all encoders forked they start
+        # together at its end (0.70 ms: the chain no longer shares its queue with anything) and run side by side:
+        # 25.96 / 26.04 -> 25.67 / 25.81 ms per cfg3 step.  (Forking the term behind the encoders, or a launch of the
+        # caller's own behind the forks, does not move it off that queue.)
+        all_side = os.environ.get('MDMM_ENC_ALL_SIDE', '1') == '1'
+        e_sides = self._modality_streams(len(present) + (1 if all_side else 0))
+        if all_side and len(e_sides) != len(present):
+            all_side = False
+            e_sides = self._modality_streams(len(present))
         for k_m, m in enumerate(present):        # every modality's encoder on a stream of its own (_modality_streams)
-            st = e_sides[k_m - 1] if (e_sides and k_m > 0) else None
+            if all_side:
+                st = e_sides[k_m]
+            else:
+                st = e_sides[k_m - 1] if (e_sides and k_m > 0) else None
             if st is not None:
                 st.wait_stream(e_cur)
                 inputs[m].record_stream(st)
@@ -622,7 +640,7 @@ class MultiDMM(MultiDGTS):
             if st is not None:
                 for x in enc[m]:
                     x.record_stream(e_cur)
-        for st in e_sides[:max(0, len(present) - 1)]:
+        for st in (e_sides if all_side else e_sides[:max(0, len(present) - 1)]):
             e_cur.wait_stream(st)
         # fp32 row masks for all the loss reductions of the step, made once (both streams read them)
         mask_f = mask.to(torch.float32).reshape(-1)
