@@ -608,6 +608,11 @@ class MultiDMM(MultiDGTS):
                 # and they end up as a 0.4 ms tail behind it (tools/step_stamps.py)
                 if os.environ.get('MDMM_MATCH_EAGER_GRAD', '1') == '0':      # A/B: the term's backward left to the step's
                     loss_m = match_loss()
+                elif os.environ.get('MDMM_MATCH_FUSED', '1') != '0':
+                    # value and gradients from direct kernel calls, no autograd graph inside (ops._PriorMatchFn)
+                    loss_m = ops.prior_match(match_mult * kld_mult * mask.sum().float(), match_eps, self.z0_mean,
+                                             self.z0_log_std, [self._gtf('fwd'), self._gtf('bwd')], match_particles,
+                                             self.z_dim, self.h_dim, self.min_std, precision=self.sweep_dtype)
                 else:
                     loss_m = _EagerGradFn.apply(match_loss, self.z0_mean, self.z0_log_std,
                                                 *self._gtf('fwd'), *self._gtf('bwd'))

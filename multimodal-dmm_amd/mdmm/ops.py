@@ -770,6 +770,101 @@ class _TransFn(torch.autograd.Function):
                 (gz0[1] * torch.exp(z0s)).reshape(ctx.z0_shapes[1]), *g_gtf)
 
 
+_ONES = {}
+
+
+def _one(device):
+    """A cached fp32 device scalar 1.0 (the upstream gradient of kernels that are run for their unscaled gradients)."""
+    k = str(device)
+    if k not in _ONES:
+        _ONES[k] = torch.ones(1, device=device, dtype=torch.float32)
+    return _ONES[k]
+
+
+class _PriorMatchFn(torch.autograd.Function):
+    """The prior-matching term of MultiDMM.step (dmm.py:540-545): scale * sum over the given directions of
+    kld_prior(K, direction) (dmm.py:496-501: K particles from the global prior, one transition step with moment matching,
+    KL divergence of the global prior from the result).  Value AND every gradient in the forward, from direct kernel
+    calls and a handful of elementwise launches -- no autograd graph inside: ~20 launches per direction where prior() /
+    z_sample() / z_next() / kld_gauss() under an inner torch.autograd.grad were ~45 (this chain of few-microsecond
+    launches holds back every other branch of the replayed step: models/dmm.py, the encoders' streams).  The backward
+    scales the kept gradients.  inputs: scale (0-dim tensor, no gradient), eps = one (K,1,D) draw per direction,
+    gtf = the directions' 12 parameters each."""
+
+    @staticmethod
+    def forward(ctx, scale, eps_list, cfg, n_dir, z0_mean, z0_log_std, *gtf_all):
+        ctx.set_materialize_grads(False)
+        _need_gpu(z0_mean, z0_log_std)
+        dev, D, K = z0_mean.device, cfg.D, cfg.K
+        z0m, zls = _f32c(z0_mean.detach().reshape(-1)), _f32c(z0_log_std.detach().reshape(-1))
+        sig = torch.exp(zls)
+        std = sig + cfg.min_std
+        one = _one(dev)
+        total = torch.zeros(1, device=dev, dtype=torch.float64)
+        g_mean = g_sig = None
+        g_params = []
+        L = native.lib()
+        for d in range(n_dir):
+            params = gtf_all[12 * d:12 * (d + 1)]
+            eps = _f32c(eps_list[d]).reshape(K, 1, D)
+            z = torch.addcmul(z0m, std, eps)                       # (K,1,D) particles from the global prior
+            packed = packed_gtf(params, D, cfg.H)
+            frag = packed_frag(params, D, cfg.H, PRECISIONS[cfg.precision]) if wide_trans(cfg) else None
+            pm = torch.empty(1, D, device=dev, dtype=torch.float32)
+            ps = torch.empty_like(pm)
+            s = native.Sweep()
+            _fill_common(s, cfg, z0m, zls, packed, None)
+            s.E = 0
+            s.z_rows = _ptr(z)
+            s.prior_mean, s.prior_std = _ptr(pm), _ptr(ps)
+            if frag is not None:
+                s.gtf_frag, s.precision = _ptr(frag.buf), frag.precision
+            _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('fwd', cfg))
+            # KL(global prior || moment-matched next prior), summed into `total`; its gradients at upstream 1
+            _call('mdmm_kld_gauss_fwd', _ptr(z0m), _ptr(std), _ptr(pm), _ptr(ps), None, 1, D, 1.0, _ptr(total))
+            gk = torch.empty(4, D, device=dev, dtype=torch.float32)
+            _call('mdmm_kld_gauss_bwd', _ptr(z0m), _ptr(std), _ptr(pm), _ptr(ps), None, 1, D, 1.0, _ptr(one),
+                  gk[0].data_ptr(), gk[1].data_ptr(), gk[2].data_ptr(), gk[3].data_ptr(), 0)
+            # the transition's adjoint (as _TransFn.backward)
+            s.g_prior_mean, s.g_prior_std = gk[2].data_ptr(), gk[3].data_ptr()
+            gz = torch.empty_like(z)
+            s.g_z_rows = _ptr(gz)
+            gz0 = torch.zeros(2, D, device=dev, dtype=torch.float32)
+            s.g_z0_mean, s.g_z0_sigma = gz0[0].data_ptr(), gz0[1].data_ptr()
+            G = torch.empty(K, L.mdmm_sweep_spill_width_g(D, cfg.H), device=dev)
+            X = torch.empty(K, L.mdmm_sweep_spill_width_x(D, cfg.H), device=dev)
+            s.spill_g, s.spill_x, s.spill_rows = _ptr(G), _ptr(X), K
+            _call('mdmm_bfvi_sweep_bwd', C.byref(s), tag=_sweep_tag('bwd', cfg))
+            g_params += packed.unpack_grads(G, X, [p.detach() for p in params])
+            # through the particles z = mean + std eps, the transition's own use of the global prior, and the KL term
+            gz2 = gz.reshape(K, D)
+            gm_d = gz2.sum(0).add_(gk[0]).add_(gz0[0])
+            gs_d = (gz2 * eps.reshape(K, D)).sum(0).add_(gk[1]).add_(gz0[1])
+            g_mean = gm_d if g_mean is None else g_mean.add_(gm_d)
+            g_sig = gs_d if g_sig is None else g_sig.add_(gs_d)
+        g_ls = g_sig * sig
+        kept = [g_mean.reshape(z0_mean.shape), g_ls.reshape(z0_log_std.shape)] + [g.contiguous() for g in g_params]
+        sc = scale.detach().to(torch.float32).reshape(())
+        ctx.save_for_backward(sc, *kept)
+        return (total.to(torch.float32) * sc).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        sc, *kept = ctx.saved_tensors
+        if g is None:
+            return (None,) * (6 + len(kept) - 2)
+        scaled = torch._foreach_mul(list(kept), g.to(torch.float32) * sc)
+        return (None, None, None, None) + tuple(scaled)
+
+
+def prior_match(scale, eps_list, z0_mean, z0_log_std, gtf_by_dir, K, D, H, min_std, precision=None):
+    """scale * sum_d kld_prior(K, d) with every gradient formed in the forward (see _PriorMatchFn); gtf_by_dir: the 12
+    GaussianGTF parameters of each direction, eps_list: the directions' (K,1,D) draws."""
+    cfg = SweepCfg(T=1, B=1, D=D, H=H, P=1, K=K, min_std=min_std, trans_only=True, precision=precision)
+    flat = [p for params in gtf_by_dir for p in params]
+    return _PriorMatchFn.apply(scale, list(eps_list), cfg, len(gtf_by_dir), z0_mean, z0_log_std, *flat)
+
+
 def gtf_transition(z_rows, gtf_params, z0_mean, z0_log_std, H, min_std, precision=None):
     K, B, D = z_rows.shape
     cfg = SweepCfg(T=1, B=B, D=D, H=H, P=1, K=K, min_std=min_std, trans_only=True,
