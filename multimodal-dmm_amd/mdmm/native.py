@@ -364,7 +364,7 @@ def lib():
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
         for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp), (7, Bn), (8, Conv),
-                          (9, FragLayers), (10, Gemm), (11, Conv1d), (12, Vrnn), (13, VrnnLayout)):
+                          (9, FragLayers), (10, Gemm), (11, Conv1d), (12, Vrnn), (13, VrnnLayout), (14, SpillWgradBatch)):
             if L.mdmm_sizeof(which) != C.sizeof(st):
                 raise MdmmError('struct %s: library %d bytes, binding %d bytes'
                                 % (st.__name__, L.mdmm_sizeof(which), C.sizeof(st)))
