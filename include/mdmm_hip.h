@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 25
+#define MDMM_ABI_VERSION 26
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -309,6 +309,14 @@ int mdmm_kld_gauss_bwd(const float* m1, const float* s1, const float* m2, const 
                        const float* seq_mask, int64_t rows, int inner, float scale,
                        const float* scale_dev, float* g_m1, float* g_s1, float* g_m2, float* g_s2,
                        int accumulate, void* stream);
+/* The particles of MultiDMM.kld_prior (dmm.py:496-501: K draws from the global prior) and the way back through them:
+ * z[k][d] = mean[d] + std[d] eps[k][d] (+ `zero[0 .. n_zero)` cleared: the transition adjoint's accumulators);
+ * g_mean[d] (+)= sum_k gz[k][d] + a_mean[d] + b_mean[d], g_sig[d] (+)= sum_k gz[k][d] eps[k][d] + a_sig[d] + b_sig[d]
+ * (a, b: the KL term's and the transition's own gradients with respect to the global prior). */
+int mdmm_prior_particles(const float* mean, const float* std, const float* eps, int K, int D, float* z, float* zero,
+                         int n_zero, void* stream);
+int mdmm_prior_grads(const float* gz, const float* eps, int K, int D, const float* a_mean, const float* a_sig,
+                     const float* b_mean, const float* b_sig, float* g_mean, float* g_sig, int accumulate, void* stream);
 /* losses.py:68-89 nll_gauss; x may hold NaN (= missing, excluded) */
 int mdmm_nll_gauss_fwd(const float* mean, const float* std, const float* x,
                        const float* seq_mask, int64_t rows, int inner, float weight, double* out,

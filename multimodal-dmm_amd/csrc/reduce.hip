@@ -493,6 +493,50 @@ extern "C" int mdmm_kld_gauss_bwd(const float* m1, const float* s1, const float*
   CHECK_LAUNCH();
 }
 
+// The prior-matching term's particles and the way back through them (dmm.py:496-501, 260-317 with t_max = 1): two
+// launches in place of nine elementwise / reduction launches of the framework per direction, on a chain of few-microsecond
+// launches that every other branch of the replayed step waits for (models/dmm.py, ops._PriorMatchFn).
+namespace {
+// z[k][d] = mean[d] + std[d] eps[k][d];  zero[0 .. n_zero) = 0 (the transition adjoint's d z0 accumulators)
+__global__ void prior_particles_kernel(const float* __restrict__ mean, const float* __restrict__ std,
+                                       const float* __restrict__ eps, int K, int D, float* __restrict__ z,
+                                       float* __restrict__ zero, int n_zero) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < K * D) { const int d = i % D; z[i] = fmaf(std[d], eps[i], mean[d]); }
+  if (zero && i < n_zero) zero[i] = 0.f;
+}
+// g_mean[d] (+)= sum_k gz[k][d] + a_mean[d] + b_mean[d];  g_sig[d] (+)= sum_k gz[k][d] eps[k][d] + a_sig[d] + b_sig[d]
+__global__ void prior_grads_kernel(const float* __restrict__ gz, const float* __restrict__ eps, int K, int D,
+                                   const float* __restrict__ a_mean, const float* __restrict__ a_sig,
+                                   const float* __restrict__ b_mean, const float* __restrict__ b_sig,
+                                   float* __restrict__ g_mean, float* __restrict__ g_sig, int accumulate) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < K; ++k) { const float g = gz[(size_t)k * D + d]; s1 += g; s2 = fmaf(g, eps[(size_t)k * D + d], s2); }
+  s1 += a_mean[d] + b_mean[d];
+  s2 += a_sig[d] + b_sig[d];
+  if (accumulate) { g_mean[d] += s1; g_sig[d] += s2; } else { g_mean[d] = s1; g_sig[d] = s2; }
+}
+}  // namespace
+
+extern "C" int mdmm_prior_particles(const float* mean, const float* std, const float* eps, int K, int D, float* z,
+                                    float* zero, int n_zero, void* stream) {
+  if (!mean || !std || !eps || !z || K < 1 || D < 1 || n_zero < 0) return MDMM_E_ARG;
+  const int n = K * D > n_zero ? K * D : n_zero;
+  hipLaunchKernelGGL(prior_particles_kernel, dim3((n + 255) / 256), dim3(256), 0, STREAM, mean, std, eps, K, D, z, zero, n_zero);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_prior_grads(const float* gz, const float* eps, int K, int D, const float* a_mean, const float* a_sig,
+                                const float* b_mean, const float* b_sig, float* g_mean, float* g_sig, int accumulate,
+                                void* stream) {
+  if (!gz || !eps || !a_mean || !a_sig || !b_mean || !b_sig || !g_mean || !g_sig || K < 1 || D < 1) return MDMM_E_ARG;
+  hipLaunchKernelGGL(prior_grads_kernel, dim3((D + 63) / 64), dim3(64), 0, STREAM, gz, eps, K, D, a_mean, a_sig, b_mean, b_sig,
+                     g_mean, g_sig, accumulate);
+  CHECK_LAUNCH();
+}
+
 extern "C" int mdmm_nll_gauss_fwd(const float* mean, const float* std, const float* x,
                                   const float* seq_mask, int64_t rows, int inner, float weight,
                                   double* out, void* stream) {

@@ -12,13 +12,13 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 25
+ABI_VERSION = 26
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
     'mdmm_version', 'mdmm_strerror', 'mdmm_pad', 'mdmm_sizeof',
     'mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd',
-    'mdmm_sweep_spill_width_g', 'mdmm_sweep_spill_width_x', 'mdmm_spill_wgrad', 'mdmm_spill_wgrad_batch', 'mdmm_spill_wgrad_splits',
+    'mdmm_sweep_spill_width_g', 'mdmm_sweep_spill_width_x', 'mdmm_spill_wgrad', 'mdmm_spill_wgrad_batch', 'mdmm_spill_wgrad_splits', 'mdmm_prior_particles', 'mdmm_prior_grads',
     'mdmm_sweep_bwd_mode', 'mdmm_sweep_dw_width', 'mdmm_sweep_dw_rows',
     'mdmm_sweep_wide', 'mdmm_sweep_kld_fused', 'mdmm_sweep_rider_supported', 'mdmm_sweep_wide_ws_bytes', 'mdmm_sweep_noise_park_bytes', 'mdmm_gtf_frag_bytes', 'mdmm_gtf_frag_pack',
     'mdmm_poe_fwd', 'mdmm_poe_bwd', 'mdmm_moe_fwd', 'mdmm_moe_bwd',
@@ -258,6 +258,8 @@ def lib():
         for name in ('mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd'):
             getattr(L, name).argtypes = [C.POINTER(Dks), _P]
         L.mdmm_spill_wgrad_splits.argtypes = [C.c_int64, C.c_int, C.c_int]
+        L.mdmm_prior_particles.argtypes = [_P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P]
+        L.mdmm_prior_grads.argtypes = [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P]
         L.mdmm_spill_wgrad_batch.argtypes = [_P, C.c_int, _P, C.c_int, C.c_int64, C.POINTER(SpillWgradBatch), _P]
         L.mdmm_spill_wgrad.argtypes = [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int64,
                                        C.c_int, _P, _P]

@@ -801,13 +801,16 @@ class _PriorMatchFn(torch.autograd.Function):
         std = sig + cfg.min_std
         one = _one(dev)
         total = torch.zeros(1, device=dev, dtype=torch.float64)
-        g_mean = g_sig = None
+        g_ms = torch.empty(2, D, device=dev, dtype=torch.float32)         # d / d (mean, std) of the global prior
         g_params = []
         L = native.lib()
         for d in range(n_dir):
             params = gtf_all[12 * d:12 * (d + 1)]
             eps = _f32c(eps_list[d]).reshape(K, 1, D)
-            z = torch.addcmul(z0m, std, eps)                       # (K,1,D) particles from the global prior
+            z = torch.empty(K, 1, D, device=dev, dtype=torch.float32)
+            gz0 = torch.empty(2, D, device=dev, dtype=torch.float32)
+            # (K,1,D) particles from the global prior; the transition adjoint's d z0 accumulators cleared on the way
+            _call('mdmm_prior_particles', _ptr(z0m), _ptr(std), _ptr(eps), K, D, _ptr(z), _ptr(gz0), 2 * D)
             packed = packed_gtf(params, D, cfg.H)
             frag = packed_frag(params, D, cfg.H, PRECISIONS[cfg.precision]) if wide_trans(cfg) else None
             pm = torch.empty(1, D, device=dev, dtype=torch.float32)
@@ -829,7 +832,6 @@ class _PriorMatchFn(torch.autograd.Function):
             s.g_prior_mean, s.g_prior_std = gk[2].data_ptr(), gk[3].data_ptr()
             gz = torch.empty_like(z)
             s.g_z_rows = _ptr(gz)
-            gz0 = torch.zeros(2, D, device=dev, dtype=torch.float32)
             s.g_z0_mean, s.g_z0_sigma = gz0[0].data_ptr(), gz0[1].data_ptr()
             G = torch.empty(K, L.mdmm_sweep_spill_width_g(D, cfg.H), device=dev)
             X = torch.empty(K, L.mdmm_sweep_spill_width_x(D, cfg.H), device=dev)
@@ -837,13 +839,10 @@ class _PriorMatchFn(torch.autograd.Function):
             _call('mdmm_bfvi_sweep_bwd', C.byref(s), tag=_sweep_tag('bwd', cfg))
             g_params += packed.unpack_grads(G, X, [p.detach() for p in params])
             # through the particles z = mean + std eps, the transition's own use of the global prior, and the KL term
-            gz2 = gz.reshape(K, D)
-            gm_d = gz2.sum(0).add_(gk[0]).add_(gz0[0])
-            gs_d = (gz2 * eps.reshape(K, D)).sum(0).add_(gk[1]).add_(gz0[1])
-            g_mean = gm_d if g_mean is None else g_mean.add_(gm_d)
-            g_sig = gs_d if g_sig is None else g_sig.add_(gs_d)
-        g_ls = g_sig * sig
-        kept = [g_mean.reshape(z0_mean.shape), g_ls.reshape(z0_log_std.shape)] + [g.contiguous() for g in g_params]
+            _call('mdmm_prior_grads', _ptr(gz), _ptr(eps), K, D, gk[0].data_ptr(), gk[1].data_ptr(), gz0[0].data_ptr(),
+                  gz0[1].data_ptr(), g_ms[0].data_ptr(), g_ms[1].data_ptr(), int(d > 0))
+        g_ls = g_ms[1] * sig
+        kept = [g_ms[0].reshape(z0_mean.shape), g_ls.reshape(z0_log_std.shape)] + [g.contiguous() for g in g_params]
         sc = scale.detach().to(torch.float32).reshape(())
         ctx.save_for_backward(sc, *kept)
         return (total.to(torch.float32) * sc).reshape(())
