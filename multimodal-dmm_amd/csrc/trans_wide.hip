@@ -210,9 +210,14 @@ __global__ __launch_bounds__(NTHR) void trans_wide_bwd_kernel(const mdmm_sweep_t
   const float gps = a.g_prior_std ? a.g_prior_std[(size_t)b * WD + n] : 0.f;
   const float gv2k = gps * fast::rcp(ps) * inv_k, gpmk = gpm * inv_k;
   float g_mu0 = 0.f, g_sg0 = 0.f;
-  f32x16 g3[RT], gg[RT], gl[RT], gn[RT];
+  // Tile by tile, each tile's three image-bound results handed over (LDS image + weight-gradient spill) as soon as they
+  // exist: with two tiles (the prior-matching term's 50 particles) four input and four output arrays of 32 registers
+  // each were live around this loop -- 908 bytes of scratch per lane, a scratch setup per launch, 135 us for one step
+  f32x16 gn[RT];
+  __syncthreads();                                      // every wave is past its reads of the images
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < RT; ++rt) {
+    float t3[16], tg[16], tl[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const bool live = acc_row(rt, r) + 4 * h < K;
@@ -235,21 +240,27 @@ __global__ __launch_bounds__(NTHR) void trans_wide_bwd_kernel(const mdmm_sweep_t
       const float g_muq = g_num * tq;
       const float g_sq = -fmaf(g_num, s.muq[rt][r], g_prec) * tq * tq * 2.0f * sq;
       const float gate = 1.0f - s.omg[rt][r];
-      g3[rt][r] = g_sq * fast::softplus_grad(pre);
-      gg[rt][r] = g_muq * gate * (s.nl[rt][r] - s.muq[rt][r]);
-      gl[rt][r] = g_muq * s.omg[rt][r];
+      t3[r] = g_sq * fast::softplus_grad(pre);
+      tg[r] = g_muq * gate * (s.nl[rt][r] - s.muq[rt][r]);
+      tl[r] = g_muq * s.omg[rt][r];
       gn[rt][r] = g_muq * gate;
     }
-  __syncthreads();                                      // every wave is past its reads of the images
-  store_image<F32, RT>(img1, g3, wave, lane);
-  store_image<F32, RT>(img2, gg, wave, lane);
-  store_image<F32, RT>(img0, gl, wave, lane);
-  if (a.spill_g) {
-    put_rows<RT>(a.spill_g, row0, WG, 2 * WD + n, K, h, gl);
-    put_rows<RT>(a.spill_g, row0, WG, 3 * WD + n, K, h, gg);
-    put_rows<RT>(a.spill_g, row0, WG, 5 * WD + n, K, h, g3);
+    store_image_part<F32, 16>(img1, t3, rt, 0, wave, lane);
+    store_image_part<F32, 16>(img2, tg, rt, 0, wave, lane);
+    store_image_part<F32, 16>(img0, tl, rt, 0, wave, lane);
+    if (a.spill_g) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = acc_row(rt, r) + 4 * h;
+        if (k < K) {
+          float* row = a.spill_g + (row0 + k) * WG + n;
+          row[2 * WD] = tl[r]; row[3 * WD] = tg[r]; row[5 * WD] = t3[r];
+        }
+      }
+    }
   }
   __syncthreads();
+  f32x16 g3[RT], gg[RT];
   gemm_tile<F32, RT, Pf<RT>::N>(gn, img1 + arow, W(T_WS), W(T_W2G), ring);
   store_image<F32, RT>(img3, gn, wave, lane);
   if (a.spill_g) put_rows<RT>(a.spill_g, row0, WG, 4 * WD + n, K, h, gn);
