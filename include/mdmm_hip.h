@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 26
+#define MDMM_ABI_VERSION 27
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -197,13 +197,20 @@ typedef struct mdmm_sweep {
   int32_t reserved1;
   void* wide_ws;
   int64_t wide_ws_bytes;
-  /* Optional, wide family with K particles: the forward sweep leaves the noise it drew here
-   * (mdmm_sweep_noise_park_bytes(args) bytes, 0 = this shape has no use for it; fp32, in the backward
-   * kernel's own row order) and the backward sweep reads it back instead of drawing it again -- Philox +
-   * Box-Muller for every particle row was a tenth of that kernel.  NULL on either side = draw (forward: do
-   * not keep; backward: regenerate from seed / offset, as ever).  Same pointer for both calls of one sweep.  */
-  void* noise_park;
-  int64_t noise_park_bytes;
+  /* Wide family with K particles (bf16 operands, 2 <= K <= 25): what the forward sweep keeps for the backward sweep
+   * of the same call, mdmm_sweep_fwd_park_bytes(args) bytes (0 = this shape has no use for it), in the backward
+   * kernel's own register order:
+   *   - the noise it drew (fp32),
+   *   - per transition row the X-side operands of the weight gradients -- z, relu(gate hidden), relu(nl hidden), nl --
+   *     as bf16 MFMA operand chunks (the weight-gradient contraction reads them where they lie),
+   *   - the gate (a bf16 code that keeps g and 1 - g), the mean before the product with the global prior and the
+   *     std head's pre-activation (fp32), the two relu masks.
+   * With it the backward sweep (sweep_wide_bwd4.hip) neither draws noise nor runs the transition forward again
+   * (three of its six contraction levels) and spills six operand arrays instead of ten.  NULL on the forward side =
+   * keep nothing; NULL on the backward side = the two-round backward kernel, which recomputes.  Same pointer for both
+   * calls of one sweep.  */
+  void* fwd_park;
+  int64_t fwd_park_bytes;
   /* Optional: the masked KL term of the sweep's own (infer, prior) -- losses.py:14-21 through dgts.py:147-152,
    * 1/2 sum_{p,t,b,d} mask[t][b] (2 ln s_pr - 2 ln s_inf + (s_inf^2 + (m_inf - m_pr)^2) / s_pr^2 - 1) -- inside
    * the sweep that produces / consumes those four tensors, for the shapes mdmm_sweep_kld_fused() accepts (K = 1 on
@@ -216,24 +223,6 @@ typedef struct mdmm_sweep {
   const float* kld_scale_dev;
   float kld_weight;
   int32_t reserved2;
-  /* Optional RIDER (shapes mdmm_sweep_rider_supported() accepts: wide family, bf16 operands, K = 25): a second,
-   * single-particle chain of the same direction, experts and transition weights rides in the first dead row (row K)
-   * of every pair's 32-row tile -- the K = 1 filtering pass MultiDMM.step runs next to the K-particle filter pass of
-   * its smoothing mode (dmm.py:547-553 with 464-470: `bfilter` and the first sweep of `fsmooth`).  The rider has its
-   * own product of experts, its own noise stream (seed, rider_offset [+ *offset_dev], elements indexed as a
-   * (P,T,1,B,D) tensor, or rider_eps) and its own outputs, and stays out of the particles' moment matching; its KL
-   * term may be fused (kld_* fields then refer to the RIDER's (infer, prior): it is the K = 1 chain whose
-   * posterior the loss scores).  rider_infer_mean != NULL switches it on.  The backward of the rider chain is the
-   * K = 1 backward sweep on the rider's outputs (same stream id), a launch of its own.  */
-  float* rider_infer_mean;
-  float* rider_infer_std;
-  float* rider_prior_mean;
-  float* rider_prior_std;
-  float* rider_samples;         /* may be NULL */
-  const float* rider_eps;       /* (P,T,1,B,D) recorded draws, or NULL */
-  uint64_t rider_offset;
-  int32_t rider_sample;
-  int32_t rider_sample_init;
 } mdmm_sweep_t;
 
 int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream);
@@ -247,10 +236,8 @@ int mdmm_sweep_dw_width(int D, int H);
 int mdmm_sweep_wide(const mdmm_sweep_t* args);
 /* != 0 if the forward AND the backward sweep of this shape take the fused KL term (kld_* fields) */
 int mdmm_sweep_kld_fused(const mdmm_sweep_t* args);
-/* != 0 if the forward sweep of this shape carries a rider chain (rider_* fields) */
-int mdmm_sweep_rider_supported(const mdmm_sweep_t* args);
 int64_t mdmm_sweep_wide_ws_bytes(const mdmm_sweep_t* args);
-int64_t mdmm_sweep_noise_park_bytes(const mdmm_sweep_t* args);
+int64_t mdmm_sweep_fwd_park_bytes(const mdmm_sweep_t* args);
 int64_t mdmm_sweep_dw_rows(const mdmm_sweep_t* args);
 /* widths of one spill_g / spill_x row for (D,H) */
 int mdmm_sweep_spill_width_g(int D, int H);

@@ -14,10 +14,9 @@ static bool force_generic() {
 
 // the fused KL term exists in the wide K = 1 kernels only: any other route would drop it silently
 static bool kld_lost(const mdmm_sweep_t* a) {
-  if (a->rider_infer_mean && (force_generic() || !mdmm_sweep_rider_supported(a))) return true;    // (a rider nobody carries)
   if (!(a->kld_out || a->kld_scale_dev)) return false;
   if (force_generic()) return true;
-  return !(mdmm_sweep_kld_fused(a) || (a->rider_infer_mean && mdmm_sweep_rider_supported(a)));
+  return !mdmm_sweep_kld_fused(a);
 }
 
 extern "C" int mdmm_bfvi_sweep_fwd(const mdmm_sweep_t* args, void* stream) {

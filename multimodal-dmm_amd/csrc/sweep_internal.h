@@ -19,7 +19,8 @@ int mdmm_wide_bwd_supported(const mdmm_sweep_t* a);
 int mdmm_wide_sweep_bwd4(const mdmm_sweep_t* a, hipStream_t stream);      /* sweep_wide_bwd4.hip */
 int mdmm_wide_bwd4_supported(const mdmm_sweep_t* a);
 int64_t mdmm_wide_bwd4_ws_bytes(const mdmm_sweep_t* a);
-int64_t mdmm_wide_noise_park_bytes(const mdmm_sweep_t* a);     /* 0: the shape is not the one-round backward's */
+int64_t mdmm_wide_fwd_park_bytes(const mdmm_sweep_t* a);       /* 0: the shape is not the one-round backward's */
+int mdmm_wide_bwd4_shape(const mdmm_sweep_t* a);                /* the shape alone (with or without a park) */
 int mdmm_wide_trans(const mdmm_sweep_t* a, int bwd, hipStream_t stream);   /* trans_wide.hip */
 int mdmm_gru_wide(const mdmm_gru_t* a, int bwd, hipStream_t stream);     /* dks_wide.hip */
 int mdmm_dks_wide(const mdmm_dks_t* a, int bwd, hipStream_t stream);

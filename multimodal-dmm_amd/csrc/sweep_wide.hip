@@ -27,6 +27,20 @@ using namespace wide;
 
 
 
+// bit r of word rt: accumulator register r of tile rt is positive (the relu passes it)
+__device__ __forceinline__ uint4 relu_bits(const f32x16 (&v)[4]) {
+  unsigned w[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    unsigned mb = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mb |= (v[rt][r] > 0.f) ? (1u << r) : 0u;
+    w[rt] = mb;
+  }
+  uint4 o; o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+  return o;
+}
+
 // NI images: two (Z / NL and one hidden layer at a time), or four for the three-phase K = 1 forward (Z, HG, HN, NL)
 template <bool F32, int RT, int NI = 2>
 struct FwdLds {
@@ -51,17 +65,10 @@ template <int N> struct PrefetchK1 { PairRef pr[N]; ExpertVals ev[N]; };
 // per step instead of eight; the weight stream (the K = 1 sweep's bound: every workgroup pulls all 768 KB of the
 // direction's fragments through its CU's L2 port per step) never pauses at a barrier.  The step's expert loads do
 // not depend on the chain either: they are requested at the head of the step and land under the contractions.
-// RD (K = 25 particles, one row tile per pair): a RIDER chain in row RD_ROW of every tile -- mdmm_sweep_t.rider_*: the
-// single-particle filtering pass of the same direction, experts and weights.  Row 25 is accumulator register 13 of
-// the lower lane half; it takes part in every contraction like any row (the images hold all 32 rows of a tile), is
-// masked out of the particles' moments as a dead row always was, and gets its own product of experts, draw and
-// outputs in the fusion phase.
-constexpr int RD_ROW = 25, RD_REG = 13;       // row = 8 (reg / 4) + reg % 4 + 4 h  with h = 0
-template <bool F32, int RT, bool K1, int LR = 16, bool P3 = false, bool RD = false>
+template <bool F32, int RT, bool K1, int LR = 16, bool P3 = false>
 __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, const WideGeo g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(!P3 || (K1 && RT == 1), "the three-phase forward is a K = 1 shape");
-  static_assert(!RD || (!K1 && !F32 && RT == 4), "the rider rides the bf16 K-particle forward");
   using L = FwdLds<F32, RT, P3 ? 4 : 2>;
   using O = Op<F32>;
   char* imgZ = smem + L::OFF_Z;
@@ -97,6 +104,21 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
   ring_fill(ring, W(L_W1G));
   __syncthreads();
 
+  // what this sweep keeps for the one-round backward (wide_sweep.h, FwdPark): this lane's slots of the workgroup
+  constexpr bool PK = !K1 && !F32 && RT == 4;
+  // (wave-uniform bases in scalar registers; the lane is added where a slot is written)
+  [[maybe_unused]] gs_ptr pk_noise0 = nullptr, pk_xop0 = nullptr, pk_eop0 = nullptr;
+  if constexpr (PK) {
+    if (a.fwd_park) {
+      FwdPark pk;
+      fwd_park_carve(&a, &pk);
+      const int ws_ = __builtin_amdgcn_readfirstlane(wave);
+      pk_noise0 = (gs_ptr)pk.noise + ((size_t)blockIdx.x * T * NWAVE + ws_) * (16 * 64);
+      pk_xop0 = (gs_ptr)pk.xop + ((size_t)blockIdx.x * (T - 1) * 2 * X_ARR * NWAVE + ws_) * 256;
+      pk_eop0 = (gs_ptr)pk.eop + ((size_t)blockIdx.x * (T - 1) * NWAVE + ws_) * (EP_SLOTS * 64);
+    }
+  }
+
   [[maybe_unused]] float kl_acc = 0.f;      // fused KL term (K = 1): this lane's sum over its (row, step) elements
   const lds_tab_t tab0 = tab;
   const lds_row_t rowbase0 = rowbase;
@@ -106,6 +128,13 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
     // from an opaque zero every step
     tab = tab0; rowbase = rowbase0; frag = frag0;    // (the same for the per-layer weight pointers)
     asm volatile("" : "+v"(tab.p), "+v"(rowbase), "+v"(frag));
+    // the park slots of the transition into this step (item i - 1) and of this step's particles (item i)
+    [[maybe_unused]] gs_ptr pk_x = pk_xop0, pk_e = pk_eop0, pk_n = pk_noise0;
+    if constexpr (PK) {
+      asm volatile("" : "+s"(pk_x), "+s"(pk_e), "+s"(pk_n));
+      pk_x += (ptrdiff_t)(i - 1) * (2 * X_ARR * XOP_ARR_U4);
+      pk_e += (ptrdiff_t)(i - 1) * (NWAVE * EP_SLOTS * 64);
+    }
     // ... and for the launch arguments: inside the loop they are read through an opaque copy of
     // the kernarg pointer (the sweep descriptor is the first kernel argument), so that pointers,
     // expert descriptors and Philox keys are scalar loads at their use, not ~150 hoisted SGPRs
@@ -114,6 +143,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
     KArgs& a = *kap;
     const auto* exs = a.experts;
     const int t = a.reverse ? T - 1 - i : i;
+    [[maybe_unused]] const bool parked = PK && a.fwd_park != nullptr;      // (wave-uniform: a launch argument)
     f32x16 m_[RT], var_[RT];       // per particle: p(z) * q'(z | z_prev)  (dmm.py:239-252)
     // P3: this step's pairs and their expert values, requested before the contractions
     constexpr bool PREF = P3 && LR <= 4;        // (eight pairs' values in flight are 96 registers: they spill)
@@ -191,12 +221,17 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       // 1: gate hidden
       fill_acc(acc, b1g);
       gemm_tile<F32, RT, Pf<RT>::N>(acc, imgZ + arow, W(L_W1G), W(L_W2G), ring);
+      [[maybe_unused]] uint4 mk_g, mk_n;          // relu masks of the two hidden layers, one word per tile (park)
+      if constexpr (PK) { if (parked) mk_g = relu_bits(acc); }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rt][r] = fmaxf(acc[rt][r], 0.f);
       STAMP(1);
-      store_image<F32, RT>(imgH, acc, wave, lane);
+      if constexpr (PK) {
+        if (parked) { park_st(pk_e + EP_MASK * 64 + lane, mk_g); store_image_park(imgH, acc, wave, lane, pk_x + lane, X_HG); }
+        else store_image<F32, RT>(imgH, acc, wave, lane);
+      } else store_image<F32, RT>(imgH, acc, wave, lane);
       STAMP(2);
       __syncthreads();
       STAMP(3);
@@ -209,11 +244,15 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       // 3: non-linear hidden
       fill_acc(acc, b1n);
       gemm_tile<F32, RT, Pf<RT>::N>(acc, imgZ + arow, W(L_W1N), W(L_W2N), ring);
+      if constexpr (PK) { if (parked) mk_n = relu_bits(acc); }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rt][r] = fmaxf(acc[rt][r], 0.f);
-      store_image<F32, RT>(imgH, acc, wave, lane);
+      if constexpr (PK) {
+        if (parked) { park_st(pk_e + (EP_MASK + 1) * 64 + lane, mk_n); store_image_park(imgH, acc, wave, lane, pk_x + lane, X_HN); }
+        else store_image<F32, RT>(imgH, acc, wave, lane);
+      } else store_image<F32, RT>(imgH, acc, wave, lane);
       STAMP(6);
       __syncthreads();
       STAMP(7);
@@ -221,7 +260,10 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       fill_acc(acc, b2n);
       gemm_tile<F32, RT, Pf<RT>::N>(acc, imgH + arow, W(L_W2N), W(L_WL), ring);
       __syncthreads();
-      store_image<F32, RT>(imgH, acc, wave, lane);
+      if constexpr (PK) {
+        if (parked) store_image_park(imgH, acc, wave, lane, pk_x + lane, X_NL);
+        else store_image<F32, RT>(imgH, acc, wave, lane);
+      } else store_image<F32, RT>(imgH, acc, wave, lane);
       STAMP(8);
       // 5a: acc = e^x nl + bl + Wl z;  muq = (1 - g) acc
 #pragma unroll
@@ -233,11 +275,26 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           x[rt][r] = fast::rcp(1.0f + ex);              // 1 - gate
           acc[rt][r] = fmaf(acc[rt][r], ex, bl);
         }
+      if constexpr (PK) {
+        if (parked) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              bf16x8 c;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { const float omg = x[rt][8 * s + j]; c[j] = (__bf16)gate_code(1.0f - omg, omg); }
+              park_st(pk_e + (EP_GATE + 2 * rt + s) * 64 + lane, __builtin_bit_cast(uint4, c));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+      }
       gemm_tile<F32, RT, Pf<RT>::N>(acc, imgZ + arow, W(L_WL), W(L_WS), ring);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) m_[rt][r] = x[rt][r] * acc[rt][r];          // muq
+      if constexpr (PK) { if (parked) park_f32(pk_e + EP_MUQ * 64 + lane, m_); }
       STAMP(9);
       __syncthreads();
       STAMP(10);
@@ -245,6 +302,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       //   v = sq^2 + eps, u = 1 / (t0 v + 1):  var = v u,  mean = muq u + num0 var
       fill_acc(acc, bs);
       gemm_tile<F32, RT, Pf<RT>::N>(acc, imgH + arow, W(L_WS), W(L_W1G), ring);
+      if constexpr (PK) { if (parked) park_f32(pk_e + EP_PRE * 64 + lane, acc); }
       STAMP(16);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -342,14 +400,6 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
     } else {
       // per row tile: moments over the pair's particles (dgts.py:79-83), fusion, particles
       float pm[RT], ps[RT];
-      [[maybe_unused]] float rpm[RT], rps[RT];       // rider: its own transition prior (row RD_ROW, lower lane half)
-      if constexpr (RD) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          rpm[rt] = (i > 0) ? m_[rt][RD_REG] : mu0;
-          rps[rt] = (i > 0) ? fast::sqrt(var_[rt][RD_REG]) : sg0;
-        }
-      }
       if (i > 0) {
         float s1[RT], s2[RT], s3[RT];
 #pragma unroll
@@ -417,33 +467,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
             o_im[o] = im; o_is[o] = is;
             o_pm[o] = pm[rt]; o_ps[o] = ps[rt];
           }
-          if constexpr (RD) {
-            // the rider's own fusion (same experts, already in registers), draw and outputs
-            fast::Poe q2; q2.init(); q2.add(rpm[rt], rps[rt], 1.0f);
-            poe_experts(a, exs, pr, tb, n, ev, q2);
-            if (fz.inv_prior) q2.add(mu0, -sg0, 1.0f);
-            float im2, is2; q2.finish(im2, is2);
-            const bool smp2 = a.rider_sample || (i == 0 && a.rider_sample_init);
-            float e2 = 0.f;
-            if (smp2 && (!last || a.rider_samples)) {
-              const uint64_t idx = (((uint64_t)pr.p * T + t) * B + pr.b) * (uint64_t)WD + n;     // (P,T,1,B,D)
-              e2 = a.rider_eps ? a.rider_eps[idx]
-                               : philox_normal(a.seed, a.rider_offset + (a.offset_dev ? *a.offset_dev : 0), idx);
-            }
-            const float z2 = smp2 ? fmaf(e2, is2, im2) : im2;
-            if (h == 0) {
-              a.rider_infer_mean[o] = im2; a.rider_infer_std[o] = is2;
-              a.rider_prior_mean[o] = rpm[rt]; a.rider_prior_std[o] = rps[rt];
-              if (a.rider_samples) a.rider_samples[o] = z2;
-              if (a.kld_out) {       // the fused KL term is the rider's (see mdmm_sweep_t)
-                const float ip = fast::rcp(rps[rt]), d = (im2 - rpm[rt]) * ip, r_ = is2 * ip;
-                const float term = 2.0f * (fast::log(rps[rt]) - fast::log(is2)) + fmaf(r_, r_, d * d) - 1.0f;
-                kl_acc += (a.kld_mask ? a.kld_mask[tb] : 1.0f) * term;
-              }
-            }
-            rpm[rt] = z2; rps[rt] = e2;        // (handed to the particle loop below: the rider's next z and its draw)
-          }
-        } else if constexpr (RD) { rpm[rt] = 0.f; rps[rt] = 0.f; }
+        }
         const int kb = 32 * (rt & (g.TPP - 1));
         float zs = 0.f;
         const bool need = pr.p >= 0 && (!last || a.samples);
@@ -467,21 +491,14 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
               z[rt][4 * q + j] = zz;
               zs += zz;
             }
-            if constexpr (RD) {
-              if (4 * q <= RD_REG && RD_REG < 4 * q + 4 && h == 0) {      // row RD_ROW: the rider (not in zs)
-                z[rt][RD_REG] = rpm[rt];
-                e[RD_REG - 4 * q] = rps[rt];
-              }
-            }
           }
-          if constexpr (RT == 4 && !F32) {
+          if constexpr (PK) {
             // the noise of this step for the one-round backward (sweep_wide_bwd4.hip): its park slot of
             // (workgroup, time, wave, tile, register group), dead rows as zeros
-            if (a.noise_park) {
-              typedef float f32x4 __attribute__((ext_vector_type(4)));
-              const f32x4 o = {e[0], e[1], e[2], e[3]};
-              __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(a.noise_park) +
-                                                 ((((size_t)blockIdx.x * T + t) * NWAVE + wave) * 16 + rt * 4 + q) * 64 + lane);
+            if (parked) {
+              uint4 o;
+              o.x = __float_as_uint(e[0]); o.y = __float_as_uint(e[1]); o.z = __float_as_uint(e[2]); o.w = __float_as_uint(e[3]);
+              park_st(pk_n + ((size_t)t * NWAVE * 16 + rt * 4 + q) * 64 + lane, o);
             }
           }
         }
@@ -502,12 +519,15 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       // (P3: the Z image was last read in level 1, two barriers ago)
       if constexpr (!P3) __syncthreads();               // every wave is done with the H image (5b) and Z (5a)
       STAMP(14);
-      store_image<F32, RT>(imgZ, z, wave, lane);
+      if constexpr (PK) {         // (item i: rows of the next transition)
+        if (parked) store_image_park(imgZ, z, wave, lane, pk_x + 2 * X_ARR * XOP_ARR_U4 + lane, X_Z);
+        else store_image<F32, RT>(imgZ, z, wave, lane);
+      } else store_image<F32, RT>(imgZ, z, wave, lane);
       __syncthreads();
       STAMP(15);
     }
   }
-  if constexpr (K1 || RD) {
+  if constexpr (K1) {
     if (a.kld_out) {                 // one fp64 atomic per workgroup (as csrc/reduce.hip's kld kernel)
       __syncthreads();
       float* red = reinterpret_cast<float*>(smem);
@@ -1013,8 +1033,12 @@ __global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int x
   if (xcd_turn) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);        // gridDim.x is a multiple of 8
   const int blk = id % 6, sp = id / 6;
   if (sp >= ws.split) return;
-  const int garr = S_GHG + blk;                           // Ghg, Ghn, Glin, GG, GN, G3
-  const int xarr = blk < 3 ? S_Z : (blk == 3 ? S_HG : (blk == 4 ? S_HN : S_NL));
+  // operand arrays of the block: Ghg, Ghn, Glin, GG, GN, G3 against Z, Z, Z, HG, HN, NL -- all ten in the backward's
+  // spill, or (xop) the six G arrays there and the four X arrays where the forward sweep kept them (wide_sweep.h)
+  const bool own_x = ws.xop != nullptr;
+  const int gstr = own_x ? (int)G_ARR : (int)N_SPILL, xstr = own_x ? (int)X_ARR : (int)N_SPILL;
+  const int garr = own_x ? blk : S_GHG + blk;
+  const int xarr = own_x ? (blk < 3 ? (int)X_Z : blk - 2) : (blk < 3 ? (int)S_Z : (blk == 3 ? (int)S_HG : (blk == 4 ? (int)S_HN : (int)S_NL)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wa = wave >> 1, wb = wave & 1;
   const int64_t items = ws.n_wg * ws.n_step;
@@ -1047,17 +1071,18 @@ __global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int x
 #endif
 #define WG_LOAD(u)                                                               \
   if constexpr (u < per_thr) {                                                   \
-    sg##u = WG_LD(src + ((size_t)(it + 1) * N_SPILL + garr) * arr_u4 + u * NTHR);    \
-    sx##u = WG_LD(src + ((size_t)(it + 1) * N_SPILL + xarr) * arr_u4 + u * NTHR);    \
+    sg##u = WG_LD(gsrc + ((size_t)(it + 1) * gstr + garr) * arr_u4 + u * NTHR);    \
+    sx##u = WG_LD(xsrc + ((size_t)(it + 1) * xstr + xarr) * arr_u4 + u * NTHR);    \
   }
 #define WG_STORE(u) \
   if constexpr (u < per_thr) { dst[u * NTHR] = sg##u; dst[arr_u4 + u * NTHR] = sx##u; }
-  const uint4* src = ws.spill + threadIdx.x;
+  const uint4* gsrc = ws.spill + threadIdx.x;
+  const uint4* xsrc = (own_x ? ws.xop : ws.spill) + threadIdx.x;
   if (lo < hi) {
 #pragma unroll
     for (int u = 0; u < per_thr; ++u) {
-      lds[threadIdx.x + u * NTHR] = src[((size_t)lo * N_SPILL + garr) * arr_u4 + u * NTHR];
-      lds[arr_u4 + threadIdx.x + u * NTHR] = src[((size_t)lo * N_SPILL + xarr) * arr_u4 + u * NTHR];
+      lds[threadIdx.x + u * NTHR] = gsrc[((size_t)lo * gstr + garr) * arr_u4 + u * NTHR];
+      lds[arr_u4 + threadIdx.x + u * NTHR] = xsrc[((size_t)lo * xstr + xarr) * arr_u4 + u * NTHR];
     }
   }
   __syncthreads();
@@ -1205,10 +1230,10 @@ __global__ __launch_bounds__(256) void frag_pack_kernel(const mdmm_gtf_raw_t raw
 template <typename Kern>
 int set_lds(Kern kern, int bytes) { return mdmm_lds_attr_fn((const void*)kern, (size_t)bytes); }
 
-template <bool F32, int RT, bool K1, int LR = 16, bool P3 = false, bool RD = false>
+template <bool F32, int RT, bool K1, int LR = 16, bool P3 = false>
 int launch_fwd(const mdmm_sweep_t* a, const WideGeo& g, hipStream_t stream) {
   using L = FwdLds<F32, RT, P3 ? 4 : 2>;
-  auto kern = wide_fwd_kernel<F32, RT, K1, LR, P3, RD>;
+  auto kern = wide_fwd_kernel<F32, RT, K1, LR, P3>;
   int rc = set_lds(kern, L::BYTES);
   if (rc) return rc;
   const int grid = (g.n_pairs + g.NP - 1) / g.NP;
@@ -1279,6 +1304,7 @@ int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
     ws->db = reinterpret_cast<float*>(p); p += b_db;
     ws->dz0 = reinterpret_cast<float*>(p); p += b_dz;
     ws->slab = reinterpret_cast<float*>(p);
+    ws->xop = nullptr;
     ws->n_wg = n_wg; ws->n_step = n_step; ws->split = split;
   }
   return b_spill + b_db + b_dz + b_slab;
@@ -1289,10 +1315,7 @@ int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
 int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   WideGeo g;
   const int RT = plan(a, false, &g);
-  const bool rider = a && a->rider_infer_mean;
-  if (rider && (!mdmm_sweep_rider_supported(a) || !a->rider_infer_std || !a->rider_prior_mean || !a->rider_prior_std))
-    return MDMM_E_ARG;
-  if (a && (a->kld_out || a->kld_scale_dev) && !(rider || mdmm_sweep_kld_fused(a))) return MDMM_E_ARG;   // (never dropped silently)
+  if (a && (a->kld_out || a->kld_scale_dev) && !mdmm_sweep_kld_fused(a)) return MDMM_E_ARG;   // (never dropped silently)
   if (!RT) return mdmm_wide_sweep_fwd_long(a, stream);      // more particles than the row tiles hold
   if (((uintptr_t)a->gtf_frag) & 15) return MDMM_E_ALIGN;
   const bool f32 = a->precision == MDMM_PREC_F32;
@@ -1305,10 +1328,9 @@ int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
     if (g.NP <= 16 && !lr_off) return p3 ? launch_fwd<false, 1, true, 8, true>(a, g, stream) : launch_fwd<false, 1, true, 8>(a, g, stream);
     return launch_fwd<false, 1, true, 16>(a, g, stream);
   }
-  if (a->noise_park && (f32 || !mdmm_wide_bwd4_supported(a) || a->noise_park_bytes < mdmm_wide_noise_park_bytes(a) ||
-                        (((uintptr_t)a->noise_park) & 15)))
+  if (a->fwd_park && (f32 || !mdmm_wide_bwd4_shape(a) || a->fwd_park_bytes < mdmm_wide_fwd_park_bytes(a) ||
+                      (((uintptr_t)a->fwd_park) & 15)))
     return MDMM_E_ARG;                      // (a park only where the one-round backward will read it)
-  if (rider) return launch_fwd<false, 4, false, 16, false, true>(a, g, stream);
   return f32 ? launch_fwd<true, 1, false>(a, g, stream) : launch_fwd<false, 4, false>(a, g, stream);
 }
 
@@ -1359,12 +1381,6 @@ int mdmm_wide_bwd_supported(const mdmm_sweep_t* a) {
   return plan(a, true, &g) != 0;
 }
 
-extern "C" int mdmm_sweep_rider_supported(const mdmm_sweep_t* a) {
-  WideGeo g;
-  if (!a || a->K != RD_ROW || a->precision != MDMM_PREC_BF16 || a->trans_only) return 0;
-  return plan(a, false, &g) == 4 && g.TPP == 1;
-}
-
 extern "C" int mdmm_sweep_kld_fused(const mdmm_sweep_t* a) {
   WideGeo g;
   return a && a->K == 1 && !a->trans_only && plan(a, false, &g) != 0 && plan(a, true, &g) != 0;
@@ -1378,7 +1394,7 @@ extern "C" int mdmm_sweep_wide(const mdmm_sweep_t* a) {
          (a->precision == MDMM_PREC_F32 || a->precision == MDMM_PREC_BF16);
 }
 
-extern "C" int64_t mdmm_sweep_noise_park_bytes(const mdmm_sweep_t* a) { return mdmm_wide_noise_park_bytes(a); }
+extern "C" int64_t mdmm_sweep_fwd_park_bytes(const mdmm_sweep_t* a) { return mdmm_wide_fwd_park_bytes(a); }
 
 extern "C" int64_t mdmm_sweep_wide_ws_bytes(const mdmm_sweep_t* a) {
   if (mdmm_wide_bwd4_supported(a)) return mdmm_wide_bwd4_ws_bytes(a);

@@ -108,13 +108,104 @@ enum Spill { S_Z = 0, S_HG, S_HN, S_NL, S_GHG, S_GHN, S_GLIN, S_GG, S_GN, S_G3, 
 
 // workspace of one backward sweep (device pointers into mdmm_sweep_t.wide_ws)
 struct WideWs {
-  uint4* spill;      // [workgroup][step][N_SPILL][wave][chunk][lane]
+  uint4* spill;      // [workgroup][step][N_SPILL][wave][chunk][lane]  (xop set: [..][G_ARR][..], the G side only)
+  const uint4* xop;  // the X-side operand chunks where the forward sweep kept them (FwdPark.xop), or null
   float* db;         // [split][6][256] bias-gradient partial sums (written by the wgrad kernel)
   float* dz0;        // [workgroup][2][256] d/d(mu0, sigma0) partial sums
   float* slab;       // [split][6][256][256] weight-gradient partial sums
   int64_t n_wg, n_step;
   int split;
 };
+
+// What the K-particle forward sweep keeps for the one-round backward (mdmm_sweep_t.fwd_park: sweep_wide_bwd4.hip reads
+// it, wide_wgrad_kernel contracts the X-side operands where they lie).  A workgroup = four (pass, sequence) pairs,
+// one 32-row tile each; one slot = 64 lanes x 16 B of one wave.  Three regions:
+//   noise [workgroup][time T][wave][16][lane]                 fp32 draws of step t: slot 4 rt + q = registers 4q .. 4q+3 of tile rt
+//   xop   [workgroup][step T-1][half 2][X_ARR][wave][4][lane]   bf16 operand chunks (acc_chunk) of the rows of the transition
+//                                                             into processed step s + 1: wide_wgrad_kernel<false, 4>'s half-items
+//   eop   [workgroup][step T-1][wave][EP_SLOTS][lane]           what the elementwise adjoint of that transition reads back
+enum XArr { X_Z = 0, X_HG, X_HN, X_NL, X_ARR };
+enum GArr { G_HG = 0, G_HN, G_LIN, G_G, G_N, G_3, G_ARR };       // the backward's own spill, in weight-gradient block order
+enum EopSlot {
+  EP_GATE = 0,       //  8: the gate as bf16 codes (gate_code), slot 2 rt + s = registers 8s .. 8s+7 of tile rt
+  EP_MUQ = 8,        // 16: fp32 mean of q'(z | z_prev) before the product with the global prior, slot 4 rt + q
+  EP_PRE = 24,       // 16: fp32 pre-activation of the std head (bias included)
+  EP_MASK = 40,      //  2: relu masks of the gate / nl hidden layer, one 16-bit word per tile
+  EP_SLOTS = 42
+};
+struct FwdPark { uint4 *noise, *xop, *eop; };
+constexpr int PARK_PAIRS = 4;                          // pairs per workgroup of the kernels that share the park
+constexpr int XOP_ARR_U4 = NWAVE * 4 * 64;             // uint4 per operand array of one half-item
+// carve mdmm_sweep_t.fwd_park; returns the bytes needed
+__host__ __device__ inline int64_t fwd_park_carve(const mdmm_sweep_t* a, FwdPark* pk) {
+  const int64_t n_wg = ((int64_t)a->P * a->B + PARK_PAIRS - 1) / PARK_PAIRS, n_step = a->T - 1;
+  const int64_t b_noise = n_wg * a->T * NWAVE * 16 * 64 * 16;
+  const int64_t b_xop = n_wg * n_step * 2 * X_ARR * XOP_ARR_U4 * 16;
+  const int64_t b_eop = n_wg * n_step * NWAVE * EP_SLOTS * 64 * 16;
+  if (pk) {
+    char* p = reinterpret_cast<char*>(a->fwd_park);
+    pk->noise = reinterpret_cast<uint4*>(p); p += b_noise;
+    pk->xop = reinterpret_cast<uint4*>(p); p += b_xop;
+    pk->eop = reinterpret_cast<uint4*>(p);
+  }
+  return b_noise + b_xop + b_eop;
+}
+
+// streaming stores into the park (written once, read by another kernel much later)
+__device__ __forceinline__ void park_st(gs_ptr p, const uint4& v) { __builtin_nontemporal_store(__builtin_bit_cast(u32x4g, v), p); }
+// one accumulator array of four row tiles -> its bf16 operand chunks of the two half-items (`it` = this lane's
+// pointer of the item's first half, array `arr`)
+__device__ __forceinline__ void park_x(gs_ptr it, int arr, const f32x16 (&v)[4]) {
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      park_st(it + (((rt >> 1) * X_ARR + arr) * XOP_ARR_U4 + ((rt & 1) * 2 + s) * 64), acc_chunk<false>(v[rt], s));
+}
+// ... together with the array's LDS image (store_image): every bf16 word is formed once and goes both ways, tile by
+// tile (as two passes the second one's conversions are all hoisted in front of its stores: 32 more live registers)
+__device__ __forceinline__ void store_image_park(char* img, const f32x16 (&v)[4], int wave, int lane, gs_ptr it, int arr) {
+  constexpr int RS = Op<false>::RS;
+  char* base = img + 4 * (lane >> 5) * RS + (32 * wave + (lane & 31)) * 2;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    unsigned w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      bf16x2 pk;
+      pk[0] = (__bf16)v[rt][2 * k]; pk[1] = (__bf16)v[rt][2 * k + 1];
+      char* p = base + acc_row(rt, 2 * k) * RS;       // rows of registers 2k and 2k + 1 are neighbours
+      *reinterpret_cast<__bf16*>(p) = pk[0];
+      *reinterpret_cast<__bf16*>(p + RS) = pk[1];
+      w[k] = __builtin_bit_cast(unsigned, pk);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 c; c.x = w[4 * s]; c.y = w[4 * s + 1]; c.z = w[4 * s + 2]; c.w = w[4 * s + 3];
+      park_st(it + (((rt >> 1) * X_ARR + arr) * XOP_ARR_U4 + ((rt & 1) * 2 + s) * 64), c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// ... as fp32, slot 4 rt + q = registers 4q .. 4q+3 (`it` = this lane's pointer of the first slot)
+__device__ __forceinline__ void park_f32(gs_ptr it, const f32x16 (&v)[4]) {
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint4 o;
+      o.x = __float_as_uint(v[rt][4 * q]); o.y = __float_as_uint(v[rt][4 * q + 1]);
+      o.z = __float_as_uint(v[rt][4 * q + 2]); o.w = __float_as_uint(v[rt][4 * q + 3]);
+      park_st(it + (4 * rt + q) * 64, o);
+    }
+}
+
+// gate g in (0, 1) as one bf16 that keeps BOTH g and 1 - g to bf16 relative accuracy: the smaller
+// of the two, negative when it is g itself
+__device__ __forceinline__ float gate_code(float gate, float omg) { return gate < omg ? -gate : omg; }
+__device__ __forceinline__ void gate_decode(float c, float& gate, float& omg) {
+  if (c < 0.f) { gate = -c; omg = 1.0f + c; } else { omg = c; gate = 1.0f - c; }
+}
 
 __device__ __forceinline__ void poe_out_bwd_f(float num, float rp, float sd, float g_mean, float g_std,
                                               float& g_num, float& g_prec) {

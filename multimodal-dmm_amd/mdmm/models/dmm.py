@@ -26,9 +26,6 @@ from .. import ops
 from . import common
 from .dgts import MultiDGTS
 
-# order in which `step` issues its two loss terms: 'fs' = filtering-mode term first (the reference's program order),
-# 'sf' = smoothing-mode term first (see step); A/B: MDMM_TERM_ORDER
-TERM_ORDER = os.environ.get('MDMM_TERM_ORDER', 'fs')
 FILTER_MODES = ('ffilter', 'bfilter')
 SMOOTH_MODES = ('fsmooth', 'bsmooth')
 
@@ -38,33 +35,6 @@ def _n_draws(t_max, sample, n_particles, sample_init):
     if sample or n_particles > 1:
         return t_max
     return 1 if sample_init else 0
-
-
-class _EagerGradFn(torch.autograd.Function):
-    """fn() -> scalar loss that depends only on `params`: the forward computes the value and,
-    right away, d loss / d params; the backward only scales them by the upstream gradient."""
-
-    @staticmethod
-    def forward(ctx, fn, *params):
-        with torch.enable_grad():
-            loss = fn()
-            need = [p for p in params if p.requires_grad]
-            grads = torch.autograd.grad(loss, need, allow_unused=True) if need else ()
-        ctx.slots, kept = [], []
-        it = iter(grads)
-        for p in params:
-            g = next(it) if p.requires_grad else None
-            ctx.slots.append(None if g is None else len(kept))
-            if g is not None:
-                kept.append(g)
-        ctx.save_for_backward(*kept)
-        return loss.detach()
-
-    @staticmethod
-    def backward(ctx, g):
-        kept = ctx.saved_tensors
-        scaled = torch._foreach_mul(list(kept), g) if kept else []
-        return (None,) + tuple(None if i is None else scaled[i] for i in ctx.slots)
 
 
 class MultiDMM(MultiDGTS):
@@ -236,30 +206,19 @@ class MultiDMM(MultiDGTS):
         return eps.to(self.z0_mean.device)
 
     def _sweep(self, experts, t_max, b_dim, n_pass, direction, sample, n_particles,
-               sample_init, use_inv_prior, need_samples, draws=None, kld=None, rider=None):
+               sample_init, use_inv_prior, need_samples, draws=None, kld=None):
         reverse = direction == 'bwd'
         kw = dict(T=t_max, B=b_dim, D=self.z_dim, H=self.h_dim, P=n_pass, K=n_particles,
                   reverse=reverse, sample=sample, sample_init=sample_init,
                   use_inv_prior=use_inv_prior, min_std=self.min_std, need_samples=need_samples,
                   precision=self.sweep_dtype)
-        rd = None
-        if rider is not None:
-            # the single-particle filtering pass of the same direction as a rider chain of this sweep: its stream id /
-            # recorded draws come FIRST (the reference runs that mode before this one, dmm.py:547-553)
-            rkw = {}
-            r_eps = self._eps_or_stream(rkw, t_max, b_dim, n_pass, 1, rider['sample'], rider['sample_init'], reverse,
-                                        rider.get('draws'))
-            rd = dict(sample=rider['sample'] or False, sample_init=rider['sample_init'], offset=rkw.get('offset', 0),
-                      eps=r_eps, kld=tuple(rider['kld'][:3]) if rider.get('kld') is not None else None)
-            if r_eps is None and self._noise().replay:      # (no draws recorded: a MAP chain)
-                rd['sample'] = False
         eps = self._eps_or_stream(kw, t_max, b_dim, n_pass, n_particles, sample, sample_init,
                                   reverse, draws)
         cfg = ops.SweepCfg(**kw)
         if kld is not None:         # (mask, weight, LossSum, [did the sweep take it?])
             kld[3] = ops.sweep_kld_fused(cfg)
         return ops.bfvi_sweep(cfg, self._gtf(direction), self.z0_mean, self.z0_log_std, experts,
-                              eps, kld=tuple(kld[:3]) if kld is not None and kld[3] else None, rider=rd)
+                              eps, kld=tuple(kld[:3]) if kld is not None and kld[3] else None)
 
     def z_filter(self, z_mean, z_std, z_masks, direction='fwd', sample=True, n_particles=1,
                  sample_init=False):
@@ -274,19 +233,8 @@ class MultiDMM(MultiDGTS):
                                           n_particles, sample_init, False, True, draws)
         return (im[0], is_[0]), (pm[0], ps[0]), zs[0]
 
-    def _rider_ok(self, t_max, b_dim, n_pass, f_mode, s_mode, flt_particles, train_particles):
-        """The filtering mode's K = 1 pass can ride the smoothing mode's K-particle filter pass (ops.sweep_rider_supported):
-        same sweep direction (bfilter + fsmooth, or ffilter + bsmooth), one particle, the wide bf16 tile shape."""
-        if f_mode not in FILTER_MODES or s_mode not in SMOOTH_MODES or flt_particles != 1:
-            return False
-        if ('fwd' if f_mode == 'ffilter' else 'bwd') != ('fwd' if s_mode == 'bsmooth' else 'bwd'):
-            return False
-        cfg = ops.SweepCfg(T=t_max, B=b_dim, D=self.z_dim, H=self.h_dim, P=n_pass, K=train_particles,
-                           precision=self.sweep_dtype)
-        return ops.sweep_rider_supported(cfg)
-
     def _run_passes(self, enc, pass_mods, t_max, b_dim, mode, sample, sample_init,
-                    flt_particles, smt_particles, kld=None, rider=None, after_filter=None):
+                    flt_particles, smt_particles, kld=None):
         """All passes of one mode in one (filter) or two (filter + smoother) launches.
 
         enc: {m: (mean, std, seen)}; pass_mods: per pass, the modalities it conditions on.
@@ -305,9 +253,6 @@ class MultiDMM(MultiDGTS):
         flt_init = sample_init if mode in FILTER_MODES else False
         replay = self._noise().replay
         f_draws = s_draws = None
-        if replay and rider is not None:      # the riding mode's passes come first in the reference's draw order
-            rider = dict(rider)
-            rider['draws'] = [self.noise.take(_n_draws(t_max, rider['sample'], 1, rider['sample_init'])) for _ in range(n_pass)]
         if replay:      # the reference runs the passes one after the other (dgts.py:119-129)
             f_draws, s_draws = [], []
             for _ in range(n_pass):
@@ -317,16 +262,9 @@ class MultiDMM(MultiDGTS):
                         _n_draws(t_max, sample, smt_particles, sample_init)))
         # kld: [row mask, weight, LossSum, taken?] -- the sweep whose (infer, prior) the mode returns may form the
         # KL term itself (ops.sweep_kld_fused); kld[3] tells the caller whether it did
-        res = self._sweep(obs, t_max, b_dim, n_pass, flt_dir, sample,
-                          flt_particles, flt_init, False, not smoothing, f_draws,
-                          kld=None if smoothing else kld, rider=rider)
-        rider_out = None
-        if rider is not None:
-            res, rider_out = res
-            rider_out = ((rider_out[0], rider_out[1]), (rider_out[2], rider_out[3]), rider_out[4])
-            if after_filter is not None:
-                after_filter(rider_out)         # (the riding mode's loss may start now, on its own stream)
-        im, is_, pm, ps, zs = res
+        im, is_, pm, ps, zs = self._sweep(obs, t_max, b_dim, n_pass, flt_dir, sample,
+                                          flt_particles, flt_init, False, not smoothing, f_draws,
+                                          kld=None if smoothing else kld)
         if smoothing:
             smt_dir = 'fwd' if mode == 'fsmooth' else 'bwd'
             flt_mask = torch.ones(t_max, b_dim, device=pm.device, dtype=torch.float32)
@@ -335,8 +273,6 @@ class MultiDMM(MultiDGTS):
             experts = obs + [ops.ExpertSpec(pm, ps, flt_mask, all_bits, True)]   # dmm.py:479-485
             im, is_, pm, ps, zs = self._sweep(experts, t_max, b_dim, n_pass, smt_dir, sample,
                                               smt_particles, sample_init, True, True, s_draws, kld=kld)
-        if rider is not None:
-            return ((im, is_), (pm, ps), zs), rider_out
         return (im, is_), (pm, ps), zs
 
     @staticmethod
@@ -409,14 +345,10 @@ class MultiDMM(MultiDGTS):
         The decoders + loss terms of a mode can go the same way (keys 's', 'f') and should not: three conv chains
         next to each other are SLOWER (smoothing mode alone: 32.0 ms), and a fork from the filtering mode's side stream
         (a fork inside a fork) ends the graph capture with a segmentation fault in the runtime
-        (profiles/r04ae_ab_mod_streams.txt).  MDMM_MOD_STREAMS = comma list of keys, 0 = none; default 'e'.
-        MDMM_ONE_STREAM=1 also keeps everything on the caller's stream."""
-        which = os.environ.get('MDMM_MOD_STREAMS', 'e' if self.conv_dtype is torch.bfloat16 else '0')
+        (profiles/r04ae_ab_mod_streams.txt): only key 'e' forks."""
         # (own conv kernels only: with the library's fp32 convolutions the encoders side by side are SLOWER, the
         #  fp32-operand cfg3 step 139 -> 150 ms)
-        if (which == '0' or os.environ.get('MDMM_ONE_STREAM') == '1' or not self.z0_mean.is_cuda or n < 2):
-            return []
-        if which not in ('1', 'all') and key not in which.split(','):      # (experiments: a subset of 'e', 'f', 's')
+        if key != 'e' or self.conv_dtype is not torch.bfloat16 or not self.z0_mean.is_cuda or n < 2:
             return []
         if self._mod_streams is None:
             self._mod_streams = {}
@@ -541,6 +473,50 @@ class MultiDMM(MultiDGTS):
             for rec, w in zip(self._decode_for_loss(m, z_list), w_list):
                 self._nll(m, rec, targets[m], mask, weight=float(mult) * w, into=total)
 
+    def _match_term(self, weight, match_eps, match_particles):
+        """The prior-matching term of `step` (dmm.py:540-545) on a stream of its own: ~40 tiny launches that depend
+        on nothing else in the step, so that they never land on the chain of the long sweeps (13.5 -> 12.9 ms per
+        cfg2 step).  Value AND parameter gradients are formed now, in the forward phase, by direct kernel calls
+        (ops.prior_match): left to the backward pass they are the last thing the autograd engine issues and end up
+        as a 0.4 ms tail behind the K-particle sweep (tools/step_stamps.py).  Returns (loss, stream)."""
+        if self._match_stream is None:
+            self._match_stream = torch.cuda.Stream(device=self.z0_mean.device)
+        third = self._match_stream
+        for x in match_eps:
+            x.record_stream(third)
+        third.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(third):
+            loss_m = ops.prior_match(weight, match_eps, self.z0_mean, self.z0_log_std,
+                                     [self._gtf('fwd'), self._gtf('bwd')], match_particles,
+                                     self.z_dim, self.h_dim, self.min_std, precision=self.sweep_dtype)
+        loss_m.record_stream(torch.cuda.current_stream())
+        return loss_m, third
+
+    def _encode_all(self, inputs):
+        """Every present modality's encoder on a side stream of its own, none on the caller's (dmm.py:160-177 once per
+        step instead of once per pass).  The graph executor starts a forked branch only when the SEGMENT of the queue it
+        forked from ends, and the prior-matching term's chain of few-microsecond launches (forked off first) continues
+        the forking queue: with all encoders forked they start together at its end and run side by side
+        (profiles/r04al_ab_match_term.txt: 25.96 / 26.04 -> 25.67 / 25.81 ms per cfg3 step)."""
+        present = [m for m in self.modalities if m in inputs]
+        enc, cur = {}, torch.cuda.current_stream()
+        sides = self._modality_streams(len(present) + 1)
+        if len(sides) != len(present):
+            sides = []
+        for k_m, m in enumerate(present):
+            st = sides[k_m] if sides else None
+            if st is not None:
+                st.wait_stream(cur)
+                inputs[m].record_stream(st)
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                enc[m] = self._encode_one(m, inputs[m])
+            if st is not None:
+                for x in enc[m]:
+                    x.record_stream(cur)
+        for st in sides:
+            cur.wait_stream(st)
+        return enc
+
     def step(self, inputs, mask, kld_mult, rec_mults, targets=None, uni_loss=True, **kwargs):
         """Bidirectional training step, dmm.py:503-554 (see the module docstring for how the
         passes are fused).  Returns the un-normalised loss (caller divides by sum(lengths))."""
@@ -554,6 +530,7 @@ class MultiDMM(MultiDGTS):
         sample = kwargs.get('sample', True)
         sample_init = kwargs.get('sample_init', False)
         smt_particles = kwargs.get('smt_particles', 1)
+        flt_particles = kwargs.get('flt_particles', 1)
 
         inputs = {m: inputs[m] for m in inputs if m in self.modalities}    # dgts.py:113
         if targets is None:
@@ -561,17 +538,10 @@ class MultiDMM(MultiDGTS):
         t_max, b_dim = mask.shape[:2]
         mask = mask.to(self.z0_mean.device)
 
-        loss = 0
         match_eps = None
         if match_mult > 0:      # dmm.py:540-545: its two draws come first in the draw order
             match_eps = [self._noise().normal((match_particles, 1, self.z_dim),
                                               self.z0_mean.device) for _ in range(2)]
-
-        def match_loss():
-            n_obs = mask.sum().float()
-            return sum(match_mult * kld_mult * n_obs * self.kld_prior(match_particles, d, e)
-                       for d, e in zip(('fwd', 'bwd'), match_eps))
-
         # pass list of MultiDGTS.step (dgts.py:119-129): the multimodal pass, then unimodal
         pass_mods, loss_mods = [], []
         if len(self.modalities) > 1:
@@ -580,11 +550,12 @@ class MultiDMM(MultiDGTS):
         if uni_loss:
             pass_mods += [[m] for m in self.modalities]
             loss_mods += [[m] for m in self.modalities]
-        if not pass_mods:
-            return loss + match_loss() if match_mult > 0 else loss
-        # The prior-matching term (dmm.py:540-545) is ~40 tiny launches forward and ~60 backward
-        # that depend on nothing else in the step: a stream of its own, so that neither lands on
-        # the chain of the long sweeps (measured: 13.5 -> 12.9 ms per cfg2 step).
+        if not pass_mods:       # (one modality, uni_loss = False: the prior-matching term is the whole loss)
+            if match_mult <= 0:
+                return 0
+            n_obs = mask.sum().float()
+            return sum(match_mult * kld_mult * n_obs * self.kld_prior(match_particles, d, e)
+                       for d, e in zip(('fwd', 'bwd'), match_eps))
         # Every stream reads the packed transition weights: pack both directions once, HERE, on
         # the main stream before any stream forks off (a pack built on a forked stream would be
         # cached and then read by the others without a dependency -- a race under graph replay).
@@ -592,61 +563,10 @@ class MultiDMM(MultiDGTS):
             ops.prepack_gtf(self._gtf(direction), self.z_dim, self.h_dim, self.sweep_dtype)
         if self.conv_dtype is torch.bfloat16:           # (the same for the conv plug-ins' weight packs)
             ops.prepack_convs(list(self.enc.values()) + list(self.dec.values()))
+        loss_m, third = None, None
         if match_mult > 0:
-            if self._match_stream is None:
-                self._match_stream = torch.cuda.Stream(device=self.z0_mean.device)
-            third = self._match_stream
-            if os.environ.get('MDMM_ONE_STREAM') == '1':        # A/B switch: everything on the caller's stream
-                third = torch.cuda.current_stream()
-            for x in match_eps:
-                x.record_stream(third)
-            third.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(third):
-                # value AND parameter gradients now, in the forward phase: left to the backward
-                # pass, these ~60 launches are the last thing the autograd engine issues, their
-                # accumulation into the transition gradients waits for the long K-particle sweep,
-                # and they end up as a 0.4 ms tail behind it (tools/step_stamps.py)
-                if os.environ.get('MDMM_MATCH_EAGER_GRAD', '1') == '0':      # A/B: the term's backward left to the step's
-                    loss_m = match_loss()
-                elif os.environ.get('MDMM_MATCH_FUSED', '1') != '0':
-                    # value and gradients from direct kernel calls, no autograd graph inside (ops._PriorMatchFn)
-                    loss_m = ops.prior_match(match_mult * kld_mult * mask.sum().float(), match_eps, self.z0_mean,
-                                             self.z0_log_std, [self._gtf('fwd'), self._gtf('bwd')], match_particles,
-                                             self.z_dim, self.h_dim, self.min_std, precision=self.sweep_dtype)
-                else:
-                    loss_m = _EagerGradFn.apply(match_loss, self.z0_mean, self.z0_log_std,
-                                                *self._gtf('fwd'), *self._gtf('bwd'))
-            loss_m.record_stream(torch.cuda.current_stream())
-        present = [m for m in self.modalities if m in inputs]
-        enc, e_cur = {}, torch.cuda.current_stream()
-        # EVERY encoder on a side stream, none on the caller's (MDMM_ENC_ALL_SIDE=0: the first one there).  What the
-        # kernel traces of the replayed step show (profiles/r04al_ab_match_term.txt): the graph executor runs four queues
-        # and starts a forked branch only when the SEGMENT of the queue it forked from ends; the prior-matching term's
-        # chain of few-microsecond launches (forked off first) continues the forking queue, so every other branch waits
-        # for it -- 0.87 ms with the first encoder behind it on the caller's stream.  With all encoders forked they start
-        # together at its end (0.70 ms: the chain no longer shares its queue with anything) and run side by side:
-        # 25.96 / 26.04 -> 25.67 / 25.81 ms per cfg3 step.  (Forking the term behind the encoders, or a launch of the
-        # caller's own behind the forks, does not move it off that queue.)
-        all_side = os.environ.get('MDMM_ENC_ALL_SIDE', '1') == '1'
-        e_sides = self._modality_streams(len(present) + (1 if all_side else 0))
-        if all_side and len(e_sides) != len(present):
-            all_side = False
-            e_sides = self._modality_streams(len(present))
-        for k_m, m in enumerate(present):        # every modality's encoder on a stream of its own (_modality_streams)
-            if all_side:
-                st = e_sides[k_m]
-            else:
-                st = e_sides[k_m - 1] if (e_sides and k_m > 0) else None
-            if st is not None:
-                st.wait_stream(e_cur)
-                inputs[m].record_stream(st)
-            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-                enc[m] = self._encode_one(m, inputs[m])
-            if st is not None:
-                for x in enc[m]:
-                    x.record_stream(e_cur)
-        for st in (e_sides if all_side else e_sides[:max(0, len(present) - 1)]):
-            e_cur.wait_stream(st)
+            loss_m, third = self._match_term(match_mult * kld_mult * mask.sum().float(), match_eps, match_particles)
+        enc = self._encode_all(inputs)
         # fp32 row masks for all the loss reductions of the step, made once (both streams read them)
         mask_f = mask.to(torch.float32).reshape(-1)
         mask_kld = mask_f.repeat(len(pass_mods)) if len(pass_mods) > 1 else mask_f
@@ -659,99 +579,23 @@ class MultiDMM(MultiDGTS):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.z0_mean.device)
         side = self._side_stream
-        if os.environ.get('MDMM_ONE_STREAM') == '1':
-            side = main
         # tell the allocator the encoder outputs are also read on the side stream
         for mu, sd, seen in enc.values():
             for x in (mu, sd, seen):
                 x.record_stream(side)
         mask_f.record_stream(side); mask_kld.record_stream(side)
-        flt_particles = kwargs.get('flt_particles', 1)
-        if self._rider_ok(t_max, b_dim, len(pass_mods), f_mode, s_mode, flt_particles, train_particles) \
-                and os.environ.get('MDMM_JOINT_DECODE') != '1':
-            # The filtering mode's single-particle pass RIDES the smoothing mode's K-particle filter pass (same
-            # direction, experts and transition weights: dmm.py:547-553 with 464-470): one row of the latter's tiles,
-            # no forward sweep of its own.  Its loss (decoders, reconstruction terms) starts on the side stream as
-            # soon as that sweep is done, next to the smoother and the smoothing mode's loss.
-            total_f = ops.LossSum(self.z0_mean.device)
-            kw_f, kinto_f = ops.weighted_into(total_f, kld_mult)
-            box = {}
-
-            def filter_term(passes_f):
-                side.wait_stream(main)
-                for grp in passes_f:
-                    for x in (grp if isinstance(grp, tuple) else (grp,)):
-                        x.record_stream(side)
-                with torch.cuda.stream(side):
-                    box['loss'] = f_mult * self._joint_loss([(passes_f, 1.0)], targets, (mask_f, mask_kld), kld_mult,
-                                                            rec_mults, loss_mods, t_max, b_dim, total=total_f,
-                                                            kld_into=(kw_f, kinto_f), kld_done=True, stream_key='f')
-
-            total_s = ops.LossSum(self.z0_mean.device)
-            kw_s, kinto_s = ops.weighted_into(total_s, kld_mult)
-            kld_s = [mask_f, kw_s, kinto_s, False]
-            passes_s, _ = self._run_passes(enc, pass_mods, t_max, b_dim, s_mode, sample, sample_init, train_particles,
-                                           smt_particles, kld=kld_s,
-                                           rider=dict(sample=sample, sample_init=sample_init, kld=[mask_f, kw_f, kinto_f]),
-                                           after_filter=filter_term)
-            loss_s = s_mult * self._joint_loss([(passes_s, 1.0)], targets, (mask_f, mask_kld), kld_mult, rec_mults,
-                                               loss_mods, t_max, b_dim, total=total_s, kld_into=(kw_s, kinto_s),
-                                               kld_done=kld_s[3])
-            loss_f = box['loss']
-        elif os.environ.get('MDMM_JOINT_DECODE') != '1':
-            side.wait_stream(main)
-            # The two modes as two independent loss terms, each with its own decoder calls, on two streams.
-            # (MDMM_JOINT_DECODE=1: one decoder batch per modality for both modes, _joint_loss -- half the launches of
-            # the conv chain, measured SLOWER: 31.1 vs 30.1 ms per cfg3 step, profiles/r04_ab_joint_decode.txt -- the
-            # filtering-mode term's decoders then no longer run next to the other term's sweeps.)
-            def term_f():
-                with torch.cuda.stream(side):
-                    return f_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
-                                                    loss_mods, t_max, b_dim, f_mode, sample, sample_init, flt_particles,
-                                                    smt_particles)
-
-            def term_s():
-                return s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
-                                                loss_mods, t_max, b_dim, s_mode, sample,
-                                                sample_init, train_particles, smt_particles)
-
-            noise = self._noise()
-            if TERM_ORDER == 'sf' and not noise.replay and side is not main:
-                # The smoothing-mode term is ISSUED first: autograd runs the newest nodes first, so the filtering-mode
-                # term's backward (decoders, K = 1 sweep) is then captured -- and started -- in front of the other
-                # term's, next to it, instead of alone behind the K-particle backward sweep that owns the chip
-                # (profiles/r03o_timeline_replay.txt: 1.5 ms of tail).  Philox stream ids are handed out as in the
-                # plain order, so the results are bit-identical to it.
-                c0, n_f = noise.counter, (2 if f_mode in SMOOTH_MODES else 1)
-                noise.counter = c0 + n_f
-                loss_s = term_s()
-                c_after = noise.counter
-                noise.counter = c0
-                loss_f = term_f()
-                assert noise.counter == c0 + n_f, 'stream ids of the filtering-mode term'
-                noise.counter = c_after
-            else:
-                loss_f = term_f()
-                loss_s = term_s()
-        else:
-            side.wait_stream(main)
-            # The sweeps of the two modes side by side (the filtering mode's on the side stream), then ONE loss over
-            # both: every decoder runs once per step (_joint_loss).  Draw order as the reference's: the filtering
-            # mode's passes first.
-            with torch.cuda.stream(side):
-                passes_f = self._run_passes(enc, pass_mods, t_max, b_dim, f_mode, sample, sample_init, flt_particles,
-                                            smt_particles)
-            passes_s = self._run_passes(enc, pass_mods, t_max, b_dim, s_mode, sample, sample_init, train_particles,
-                                        smt_particles)
-            main.wait_stream(side)
-            for grp in passes_f:
-                for x in (grp if isinstance(grp, tuple) else (grp,)):
-                    x.record_stream(main)
-            loss_f = 0
-            loss_s = self._joint_loss([(passes_f, f_mult), (passes_s, s_mult)], targets, (mask_f, mask_kld), kld_mult,
-                                      rec_mults, loss_mods, t_max, b_dim)
+        side.wait_stream(main)
+        # the two modes as two independent loss terms, each with its own decoder calls, on two streams
+        with torch.cuda.stream(side):
+            loss_f = f_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
+                                              loss_mods, t_max, b_dim, f_mode, sample, sample_init, flt_particles,
+                                              smt_particles)
+        loss_s = s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
+                                          loss_mods, t_max, b_dim, s_mode, sample, sample_init, train_particles,
+                                          smt_particles)
         main.wait_stream(side)
-        if match_mult > 0:
+        loss = loss_f + loss_s
+        if loss_m is not None:
             main.wait_stream(third)
             loss = loss + loss_m
-        return loss + loss_f + loss_s
+        return loss

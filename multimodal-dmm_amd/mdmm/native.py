@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 26
+ABI_VERSION = 27
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -20,7 +20,7 @@ SYMBOLS = [
     'mdmm_bfvi_sweep_fwd', 'mdmm_bfvi_sweep_bwd',
     'mdmm_sweep_spill_width_g', 'mdmm_sweep_spill_width_x', 'mdmm_spill_wgrad', 'mdmm_spill_wgrad_batch', 'mdmm_spill_wgrad_splits', 'mdmm_prior_particles', 'mdmm_prior_grads',
     'mdmm_sweep_bwd_mode', 'mdmm_sweep_dw_width', 'mdmm_sweep_dw_rows',
-    'mdmm_sweep_wide', 'mdmm_sweep_kld_fused', 'mdmm_sweep_rider_supported', 'mdmm_sweep_wide_ws_bytes', 'mdmm_sweep_noise_park_bytes', 'mdmm_gtf_frag_bytes', 'mdmm_gtf_frag_pack',
+    'mdmm_sweep_wide', 'mdmm_sweep_kld_fused', 'mdmm_sweep_wide_ws_bytes', 'mdmm_sweep_fwd_park_bytes', 'mdmm_gtf_frag_bytes', 'mdmm_gtf_frag_pack',
     'mdmm_poe_fwd', 'mdmm_poe_bwd', 'mdmm_moe_fwd', 'mdmm_moe_bwd',
     'mdmm_kld_gauss_fwd', 'mdmm_kld_gauss_bwd',
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
@@ -79,11 +79,8 @@ class Sweep(C.Structure):
                  ('spill_g', _P), ('spill_x', _P), ('spill_rows', C.c_int64),
                  ('dw_partial', _P), ('dw_partial_rows', C.c_int64), ('offset_dev', _P),
                  ('gtf_frag', _P), ('precision', C.c_int32), ('reserved1', C.c_int32),
-                 ('wide_ws', _P), ('wide_ws_bytes', C.c_int64), ('noise_park', _P), ('noise_park_bytes', C.c_int64),
-                 ('kld_mask', _P), ('kld_out', _P), ('kld_scale_dev', _P), ('kld_weight', C.c_float), ('reserved2', C.c_int32),
-                 ('rider_infer_mean', _P), ('rider_infer_std', _P), ('rider_prior_mean', _P), ('rider_prior_std', _P),
-                 ('rider_samples', _P), ('rider_eps', _P), ('rider_offset', C.c_uint64), ('rider_sample', C.c_int32),
-                 ('rider_sample_init', C.c_int32)])
+                 ('wide_ws', _P), ('wide_ws_bytes', C.c_int64), ('fwd_park', _P), ('fwd_park_bytes', C.c_int64),
+                 ('kld_mask', _P), ('kld_out', _P), ('kld_scale_dev', _P), ('kld_weight', C.c_float), ('reserved2', C.c_int32)])
 
 
 MAX_FRAG_LAYERS = 12
@@ -301,11 +298,10 @@ def lib():
         L.mdmm_layers_frag_pack.argtypes = [C.POINTER(FragLayers), C.c_int, _P, _P]
         L.mdmm_sweep_wide.argtypes = [C.POINTER(Sweep)]
         L.mdmm_sweep_kld_fused.argtypes = [C.POINTER(Sweep)]
-        L.mdmm_sweep_rider_supported.argtypes = [C.POINTER(Sweep)]
         L.mdmm_sweep_wide_ws_bytes.argtypes = [C.POINTER(Sweep)]
         L.mdmm_sweep_wide_ws_bytes.restype = C.c_int64
-        L.mdmm_sweep_noise_park_bytes.argtypes = [C.POINTER(Sweep)]
-        L.mdmm_sweep_noise_park_bytes.restype = C.c_int64
+        L.mdmm_sweep_fwd_park_bytes.argtypes = [C.POINTER(Sweep)]
+        L.mdmm_sweep_fwd_park_bytes.restype = C.c_int64
         if L.mdmm_version() != ABI_VERSION:
             raise MdmmError('libmdmm_hip.so ABI %d != binding ABI %d'
                             % (L.mdmm_version(), ABI_VERSION))

@@ -393,9 +393,6 @@ class SweepCfg:
         # fused KL term of the sweep's own (infer, prior) (mdmm_sweep_t.kld_*): (row mask (T*B) fp32 or None,
         # weight, LossSum) set by bfvi_sweep(kld=...) where sweep_kld_fused(cfg) holds
         self.kld = None
-        # rider chain of the forward sweep (mdmm_sweep_t.rider_*; set by bfvi_sweep(rider=...)): dict(sample, sample_init,
-        # seed, offset, eps, kld) -- the K = 1 filtering pass of the same direction, experts and weights
-        self.rider = None
 
 
 def _sweep_tag(which, cfg):
@@ -478,19 +475,8 @@ class _SweepFn(torch.autograd.Function):
             ex.pass_bits = bits[e]
         s.infer_mean, s.infer_std, s.prior_mean, s.prior_std = [_ptr(o) for o in out]
         s.samples = _ptr(smp)
-        ctx.noise_park = None
+        ctx.fwd_park = None
         kh = None
-        r_out, r_smp = None, None
-        if cfg.rider is not None:
-            rd = cfg.rider
-            r_out = [torch.empty(shape, device=dev, dtype=torch.float32) for _ in range(4)]
-            r_smp = torch.empty(shape, device=dev, dtype=torch.float32)
-            (s.rider_infer_mean, s.rider_infer_std, s.rider_prior_mean, s.rider_prior_std) = [_ptr(o) for o in r_out]
-            s.rider_samples, s.rider_eps = _ptr(r_smp), _ptr(rd['eps'])
-            s.rider_offset, s.rider_sample, s.rider_sample_init = int(rd['offset']), int(rd['sample']), int(rd['sample_init'])
-            if rd.get('kld') is not None:       # the fused KL term of a sweep with a rider is the RIDER's
-                k_mask, k_weight, k_into = rd['kld']
-                s.kld_mask, s.kld_weight, s.kld_out = _ptr(k_mask), float(k_weight), _ptr(k_into.acc)
         if cfg.kld is not None:
             k_mask, k_weight, k_into = cfg.kld
             s.kld_mask, s.kld_weight, s.kld_out = _ptr(k_mask), float(k_weight), _ptr(k_into.acc)
@@ -499,14 +485,15 @@ class _SweepFn(torch.autograd.Function):
             s.gtf_frag, s.precision = _ptr(frag.buf), frag.precision
             if not native.lib().mdmm_sweep_wide(C.byref(s)):
                 raise native.MdmmError('wide sweep refused a shape wide_shape() accepted')
-            if cfg.rider is not None and not native.lib().mdmm_sweep_rider_supported(C.byref(s)):
-                raise native.MdmmError('this sweep shape carries no rider: ask sweep_rider_supported(cfg) first')
-            if any(ctx.needs_input_grad) and os.environ.get('MDMM_NOISE_PARK') != '0':
-                # the backward sweep reads the noise this sweep draws instead of drawing it again
-                nb = native.lib().mdmm_sweep_noise_park_bytes(C.byref(s))
+            if any(ctx.needs_input_grad) and os.environ.get('MDMM_FWD_PARK') != '0':
+                # K particles, bf16 operands: the forward keeps its noise and the transition's activations for the
+                # backward sweep (mdmm_sweep_t.fwd_park), which then neither draws nor runs the transition again
+                # (MDMM_FWD_PARK=0: no park, the two-round backward that recomputes -- the cross-check of
+                #  tests/test_hip_parity.py::test_parked_backward_matches_recompute)
+                nb = native.lib().mdmm_sweep_fwd_park_bytes(C.byref(s))
                 if nb > 0:
-                    ctx.noise_park = torch.empty(nb, device=dev, dtype=torch.uint8)
-                    s.noise_park, s.noise_park_bytes = _ptr(ctx.noise_park), nb
+                    ctx.fwd_park = torch.empty(nb, device=dev, dtype=torch.uint8)
+                    s.fwd_park, s.fwd_park_bytes = _ptr(ctx.fwd_park), nb
             _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('wide_fwd', cfg))
         else:
             _call('mdmm_bfvi_sweep_fwd', C.byref(s), tag=_sweep_tag('fwd', cfg))
@@ -523,14 +510,10 @@ class _SweepFn(torch.autograd.Function):
         if kh is None:
             kh = out[0].new_empty(0)
             ctx.mark_non_differentiable(kh)
-        if r_out is None:
-            return out[0], out[1], out[2], out[3], smp, kh
-        # (the rider's outputs leave as plain values: its adjoint is a node of its own, _RiderFn)
-        ctx.mark_non_differentiable(*r_out, r_smp)
-        return out[0], out[1], out[2], out[3], smp, kh, r_out[0], r_out[1], r_out[2], r_out[3], r_smp
+        return out[0], out[1], out[2], out[3], smp, kh
 
     @staticmethod
-    def backward(ctx, g_im, g_is, g_pm, g_ps, g_smp, g_kh=None, *g_rider):
+    def backward(ctx, g_im, g_is, g_pm, g_ps, g_smp, g_kh=None):
         cfg, n_exp, packed = ctx.cfg, ctx.n_exp, ctx.packed
         saved = ctx.saved_tensors
         z0m, z0s, im, is_, pm, ps = saved[:6]
@@ -548,7 +531,7 @@ class _SweepFn(torch.autograd.Function):
             ex.mean, ex.std, ex.mask = _ptr(means[e]), _ptr(stds[e]), _ptr(ctx.masks[e])
             ex.pass_stride = tbd if ctx.per_pass[e] else 0
             ex.pass_bits = ctx.bits[e]
-            off = getattr(ctx, 'in_off', 7)         # position of the first GTF parameter among the Function's inputs
+            off = 7                                 # position of the first GTF parameter among the Function's inputs
             need = ctx.needs_input_grad[off + 12 + e] or ctx.needs_input_grad[off + 12 + n_exp + e]
             if need:    # one slab per pass, written only for the passes the expert is part of
                 # the kernels write the whole (T,B,D) slab of every pass the expert is part of
@@ -566,14 +549,14 @@ class _SweepFn(torch.autograd.Function):
         gz0 = torch.zeros(2, cfg.D, device=dev, dtype=torch.float32)
         s.g_z0_mean, s.g_z0_sigma = gz0[0].data_ptr(), gz0[1].data_ptr()
         g_kd = None
-        if cfg.kld is not None and cfg.rider is None and g_kh is not None:    # the fused KL term: its adjoints are formed inside the sweep
+        if cfg.kld is not None and g_kh is not None:    # the fused KL term: its adjoints are formed inside the sweep
             g_kd = _gdev(g_kh)
             s.kld_mask, s.kld_weight, s.kld_scale_dev = _ptr(cfg.kld[0]), float(cfg.kld[1]), _ptr(g_kd)
         G = X = part = None
         if ctx.frag is not None:                        # wide family: spills + own contraction
             s.gtf_frag, s.precision = _ptr(ctx.frag.buf), ctx.frag.precision
-            if ctx.noise_park is not None:
-                s.noise_park, s.noise_park_bytes = _ptr(ctx.noise_park), ctx.noise_park.numel()
+            if ctx.fwd_park is not None:
+                s.fwd_park, s.fwd_park_bytes = _ptr(ctx.fwd_park), ctx.fwd_park.numel()
             assert L.mdmm_sweep_bwd_mode(C.byref(s)) == 2
             ws = torch.empty(L.mdmm_sweep_wide_ws_bytes(C.byref(s)), device=dev, dtype=torch.uint8)
             part = torch.empty(1, L.mdmm_sweep_dw_width(cfg.D, cfg.H), device=dev)
@@ -611,43 +594,6 @@ class _SweepFn(torch.autograd.Function):
         return (None, None, None, None, None, g_z0_mean, g_z0_log, *g_gtf, *g_flat)
 
 
-class _RiderFn(torch.autograd.Function):
-    """The rider chain of a K-particle forward sweep (mdmm_sweep_t.rider_*) as an autograd node of its own: the forward
-    hands the rider's outputs through, the backward is the K = 1 backward sweep on them (same experts, weights and
-    Philox stream id) -- _SweepFn.backward with a K = 1 configuration.  Its own node, so that it runs as soon as the
-    riding mode's loss has been differentiated, next to the other mode's backward, and the K-particle backward does not
-    wait for it."""
-
-    @staticmethod
-    def forward(ctx, cfg1, eps, masks, bits, per_pass, r_tensors, z0_mean, z0_log_std, *tensors):
-        ctx.set_materialize_grads(False)
-        gtf_params, flat = tensors[:12], tensors[12:]
-        n_exp = len(flat) // 2
-        means = [_f32c(t) for t in flat[:n_exp]]
-        stds = [_f32c(t) for t in flat[n_exp:]]
-        z0m, z0s = _f32c(z0_mean.detach().reshape(-1)), _f32c(z0_log_std.detach().reshape(-1))
-        ctx.cfg, ctx.eps, ctx.masks, ctx.bits, ctx.per_pass = cfg1, eps, masks, bits, per_pass
-        ctx.packed, ctx.n_exp = packed_gtf(gtf_params, cfg1.D, cfg1.H), n_exp
-        ctx.frag = packed_frag(gtf_params, cfg1.D, cfg1.H, PRECISIONS[cfg1.precision])
-        ctx.noise_park = None
-        ctx.in_off = 8
-        ctx.gtf_like = [p.detach() for p in gtf_params]
-        ctx.save_for_backward(z0m, z0s, r_tensors[0], r_tensors[1], r_tensors[2], r_tensors[3], *means, *stds)
-        ctx.z0_shapes = (z0_mean.shape, z0_log_std.shape)
-        ctx.in_shapes = [t.shape for t in flat]
-        outs = [t.view_as(t) for t in r_tensors]
-        kh = torch.empty((), dtype=torch.float32, device=z0m.device) if cfg1.kld is not None else z0m.new_empty(0)
-        if cfg1.kld is None:
-            ctx.mark_non_differentiable(kh)
-        return (*outs, kh)
-
-    @staticmethod
-    def backward(ctx, g_im, g_is, g_pm, g_ps, g_smp, g_kh=None):
-        g = _SweepFn.backward(ctx, g_im, g_is, g_pm, g_ps, g_smp, g_kh)
-        #  _SweepFn's inputs: (cfg, eps, masks, bits, per_pass, z0_mean, z0_log_std, *tensors); ours has r_tensors in front of z0
-        return g[:5] + (None,) + g[5:]
-
-
 def sweep_kld_fused(cfg):
     """True where the sweep kernels themselves form the masked KL term of their (infer, prior) and its adjoints
     (mdmm_sweep_t.kld_*): K = 1 sweeps of the wide family, forward and backward.  (A/B: MDMM_KLD_FUSED=0)"""
@@ -656,20 +602,7 @@ def sweep_kld_fused(cfg):
     return wide_shape(cfg) and wide_shape(cfg, bwd=True)
 
 
-def sweep_rider_supported(cfg):
-    """True where the K-particle forward sweep can carry the single-particle filtering pass of the same direction as a
-    rider chain (mdmm_sweep_t.rider_*): the wide family's bf16 one-tile-per-pair shape with 25 particles.
-    OFF unless MDMM_RIDER=1: measured on the cfg3 step it removes the K = 1 forward launch (0.44 ms; with everything on
-    one stream the step gains 0.4 ms: 33.4 vs 33.8) but costs the multi-stream step 0.8 ms (30.8 vs 29.9 ms,
-    profiles/r04t_ab_rider.txt): the riding mode's decoders can then only start behind the K-particle forward, which
-    owns every CU for 2 ms, instead of running next to it."""
-    if os.environ.get('MDMM_RIDER') != '1' or cfg.K != 25 or cfg.trans_only:
-        return False
-    return (wide_shape(cfg) and wide_shape(cfg, bwd=True) and PRECISIONS[cfg.precision] == native.PREC_BF16
-            and os.environ.get('MDMM_WIDE_BWD4') != '0')
-
-
-def bfvi_sweep(cfg, gtf_params, z0_mean, z0_log_std, experts, eps=None, kld=None, rider=None):
+def bfvi_sweep(cfg, gtf_params, z0_mean, z0_log_std, experts, eps=None, kld=None):
     """Run one filtering / smoothing sweep for cfg.P passes.
 
     experts: list of ExpertSpec.  Returns (infer_mean, infer_std, prior_mean, prior_std,
@@ -686,30 +619,9 @@ def bfvi_sweep(cfg, gtf_params, z0_mean, z0_log_std, experts, eps=None, kld=None
             raise native.MdmmError('this sweep shape has no fused KL term: ask sweep_kld_fused(cfg) first')
         k_mask, k_weight, k_into = kld
         cfg.kld = (None if k_mask is None else _f32c(k_mask).reshape(-1), float(k_weight), k_into)
-    if rider is not None:
-        # rider = dict(sample, sample_init, offset, eps=None, kld=None): returns the rider's five outputs behind the sweep's
-        if not sweep_rider_supported(cfg) or kld is not None:
-            raise native.MdmmError('this sweep shape carries no rider (sweep_rider_supported), or kld= given for its own chain')
-        rd = dict(rider)
-        rd['eps'] = _f32c(rd.get('eps'))
-        if rd.get('kld') is not None:
-            k_mask, k_weight, k_into = rd['kld']
-            rd['kld'] = (None if k_mask is None else _f32c(k_mask).reshape(-1), float(k_weight), k_into)
-        cfg.rider = rd
     out = _SweepFn.apply(cfg, _f32c(eps), masks, bits, per_pass, z0_mean, z0_log_std, *tensors)
     if kld is not None:
         kld[2].handles.append(out[5])
-    if rider is not None:
-        rd = cfg.rider
-        cfg1 = SweepCfg(cfg.T, cfg.B, cfg.D, cfg.H, P=cfg.P, K=1, reverse=cfg.reverse, sample=rd['sample'],
-                        sample_init=rd['sample_init'], use_inv_prior=cfg.use_inv_prior, min_std=cfg.min_std,
-                        seed=cfg.seed, offset=rd['offset'], need_samples=True, offset_dev=cfg.offset_dev,
-                        precision=cfg.precision)
-        cfg1.kld = rd.get('kld')
-        r = _RiderFn.apply(cfg1, rd['eps'], masks, bits, per_pass, tuple(out[6:11]), z0_mean, z0_log_std, *tensors)
-        if cfg1.kld is not None:
-            cfg1.kld[2].handles.append(r[5])
-        return out[:5], r[:5]
     return out[:5]
 
 

@@ -965,21 +965,6 @@ def test_step_z256_matches_oracle(dev, kernel_family, path, monkeypatch):
     _z256_step_vs_oracle(dev, 5, [5, 4, 2], 25, torch.float32)
 
 
-def test_step_cfg3_shape_with_rider_matches_oracle(dev, kernel_family, monkeypatch):
-    """The opt-in rider (mdmm_sweep_t.rider_*, MDMM_RIDER=1): the filtering mode's K = 1 pass computed inside the
-    smoothing mode's 25-particle forward sweep (row 25 of every pair's tile), its adjoint by the K = 1 backward sweep on
-    the rider's outputs -- same oracle comparison as the plain step, and the same loss as the plain step to 1e-6."""
-    if kernel_family == 'generic':
-        pytest.skip('the rider lives in the wide kernels')
-    from mdmm import ops
-    monkeypatch.setenv('MDMM_RIDER', '1')
-    calls = []
-    orig = ops._RiderFn.apply
-    monkeypatch.setattr(ops._RiderFn, 'apply', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
-    _z256_step_vs_oracle(dev, 40, [40, 40, 37, 30, 22, 9], 25, torch.bfloat16)
-    assert calls, 'the rider path was not taken'
-
-
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_step_cfg3_shape_matches_oracle(dev, kernel_family, dtype):
     """BASELINE cfg3 shape on a batch the oracle can do: T = 40, 32 sequences, three modalities

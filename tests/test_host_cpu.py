@@ -39,9 +39,8 @@ def test_binding_struct_layout_matches_header():
     n_int = 12
     expect = n_int * 4 + 8 + 16 + 4 * 8 + 96 + 8 * 56 + 5 * 8 + 5 * 8 + 3 * 8 + 2 * 8 + 8 + 16 + 8
     expect += 8 + 4 + 4 + 8 + 8          # wide family: gtf_frag, precision, reserved1, wide_ws, wide_ws_bytes
-    expect += 8 + 8                      # noise_park, noise_park_bytes
+    expect += 8 + 8                      # fwd_park, fwd_park_bytes
     expect += 8 + 8 + 8 + 4 + 4          # fused KL term: kld_mask, kld_out, kld_scale_dev, kld_weight, reserved2
-    expect += 6 * 8 + 8 + 4 + 4          # rider: five outputs, eps, offset, sample, sample_init
     assert ctypes.sizeof(native.Sweep) == expect
 
 
@@ -241,30 +240,6 @@ def test_harness_anneal_and_bucket():
     x = {'a': torch.arange(24.).reshape(3, 8, 1)}
     xs, ms, ls = harness.shard_batch(x, torch.ones(3, 8, 1), [3] * 8, 1, 4)
     assert xs['a'].shape == (3, 2, 1) and ls == [3, 3] and torch.equal(xs['a'], x['a'][:, 2:4])
-
-
-def test_eager_grad_function_matches_plain_autograd():
-    """models/dmm.py::_EagerGradFn (value and parameter gradients computed in the forward phase,
-    scaled in the backward) is the same function of its parameters as running fn() directly."""
-    from mdmm.models.dmm import _EagerGradFn
-    torch.manual_seed(0)
-    a = torch.randn(3, 4, requires_grad=True)
-    b = torch.randn(4, requires_grad=True)
-    c = torch.randn(2, requires_grad=True)           # not used by fn: gradient stays None
-    frozen = torch.randn(4)                          # requires_grad False
-
-    def fn():
-        return ((a * frozen).sum(0) * b).pow(2).sum()
-
-    scale = torch.tensor(0.37, requires_grad=True)
-    out = _EagerGradFn.apply(fn, a, b, c, frozen) * scale
-    out.backward()
-    got = (a.grad.clone(), b.grad.clone(), c.grad, scale.grad.clone())
-    for t in (a, b, scale):
-        t.grad = None
-    (fn() * scale).backward()
-    assert torch.allclose(got[0], a.grad) and torch.allclose(got[1], b.grad)
-    assert got[2] is None and torch.allclose(got[3], scale.grad)
 
 
 def test_vrnn_scan_layout_and_limits():

@@ -77,9 +77,9 @@ for ci, (T, B, P, K, inv, rev, smp, sinit) in enumerate(cases):
         got, ggot = run(ops.SweepCfg(precision=prec, **base), gtf, z0m, z0s, experts, kw['bwd'])
         if prec is torch.bfloat16 and kw['bwd'] and 1 < K <= 25:
             # the one-round backward (sweep_wide_bwd4.hip) against the two-round one, same operands
-            os.environ['MDMM_WIDE_BWD4'] = '0'
+            os.environ['MDMM_FWD_PARK'] = '0'
             _, gold = run(ops.SweepCfg(precision=prec, **base), gtf, z0m, z0s, experts, 1)
-            os.environ['MDMM_WIDE_BWD4'] = '1'
+            os.environ['MDMM_FWD_PARK'] = '1'
             l2 = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
             print('      bwd4 vs two-round bf16 backward: max-rel %.3e, L2 %.3e; two-round vs fp32 generic: L2 %.3e, bwd4 vs generic L2 %.3e'
                   % (max(err(a, b) for a, b in zip(ggot, gold)), max(l2(a, b) for a, b in zip(ggot, gold)),

@@ -49,16 +49,12 @@ else:
              11: 'barrier', 12: 'D1 gemm+store+spill', 13: 'barrier', 14: 'D2 2 gemms+store+spills', 15: 'barrier+store+barrier',
              16: 'D3 3 gemms+adj', 17: 'barrier'}
     order = list(range(18))
-    if os.environ.get('MDMM_WIDE_BWD4', '1') != '0' and 1 < K <= 25 and kw['bf16']:
-        names = {0: 'step start', 1: '(A) fuse adjoint -> park', 2: 'R1 particles (Philox), eps -> park', 3: 'barrier, Z store+spill, barrier',
-                 4: 'R2 2 gemms+relu+stores+spills', 5: 'barrier', 6: 'R3 gate gemm+code, nl gemm+spill', 7: 'barrier, nl store, lin gemm, muq -> park',
-                 8: 'barrier', 9: 'R4 gemm', 10: 'barrier', 11: 'E elementwise+stores+spills', 12: 'barrier',
-                 13: 'D1 2 gemms+masks+spills', 14: 'barrier, GHG store, GN from spill, barrier', 15: 'D2 2 gemms+mask+spill',
-                 16: 'barrier, GHN from spill, barrier', 17: 'D3 2 gemms + sums',
-                 18: '  (A) tile 0 loads issued', 19: '  tile 0 Philox + z', 20: '  tile 0 fuse algebra + stores',
-                 21: '  tiles 1-2 done', 22: '  tile 3 loads issued', 23: '  tile 3 Philox + z', 24: '  tile 3 fuse algebra'}
-        names.update({25: '  R4: fa loads issued, acc zeroed', 26: '  R4 gemm: prologue reads', 27: '  trip 0', 28: '  trip 1', 29: '  trip 2'})
-        order = [0, 18, 19, 20, 21, 22, 23, 24] + list(range(1, 9)) + [25, 26, 27, 28, 29] + list(range(9, 18))
+    if os.environ.get('MDMM_FWD_PARK', '1') != '0' and 1 < K <= 25 and kw['bf16']:
+        # sweep_wide_bwd4.hip (the forward kept its park)
+        names = {0: 'step start', 1: 'pair 0: fuse adjoint, barrier, E', 2: 'pair 1: fuse adjoint, E', 3: 'pair 2', 4: 'pair 3',
+                 5: 'mask loads, barrier', 6: 'D1 2 gemms + masks', 7: 'barrier, GN / GHG stores+spills, barrier',
+                 8: 'D2 2 gemms + mask', 9: 'barrier, GHN store+spill, barrier', 10: 'D3 2 gemms + sums'}
+        order = list(range(11))
 for w in (0, 7):
     print('wave %d (cycles since step start; delta)' % w)
     prev = int(s[w, 0])
