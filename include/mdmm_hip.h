@@ -844,11 +844,13 @@ int mdmm_collate_pad(const float* flat, const int64_t* seq_offset, const int32_t
 int mdmm_delete_steps(const float* x, const uint8_t* del, int64_t steps, int64_t row, float* out, void* stream);
 /* multiseq.py:388-403 seq_decoll / seq_decoll_dict: de-pad and reorder.  parts[i] (T, B, row), i < n_parts (the
  * entries of a reconstruction tuple, stacked on axis 1 as the reference's np.stack does; 1 for a plain tensor);
- * output sequence j is batch column idx = order[j], stored as [lengths[idx]][n_parts][row] from row
- * out_offset[j] of `out` (ONE device-to-host copy of `out` then replaces B of them).  */
+ * output sequence j < n_out is batch column idx = order[j] (any list of columns, as the reference's `for idx in
+ * order`: a subset, repeats; every entry in [0, B)), stored as [lengths[idx]][n_parts][row] from row out_offset[j]
+ * of `out` (ONE device-to-host copy of `out` then replaces n_out of them).  lengths has B entries, order and
+ * out_offset n_out.  */
 #define MDMM_DECOLL_MAX_PARTS 4
 int mdmm_decollate_pack(const float* const* parts, int n_parts, int T, int B, int64_t row, const int32_t* lengths,
-                        const int32_t* order, const int64_t* out_offset, float* out, void* stream);
+                        const int32_t* order, int n_out, const int64_t* out_offset, float* out, void* stream);
 /* spirals.py:104-105, weizmann.py:129-130, 136-137: out[s] (+)= sum_i (rec[s][i] - tgt[s][i])^2 (each term divided
  * by `div` first when div != 0, the reference's order of operations).  NaN targets (padding) give NaN, which
  * mdmm_time_avg's mask removes -- as in the reference.  */

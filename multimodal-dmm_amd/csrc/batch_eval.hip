@@ -60,14 +60,14 @@ struct Parts { const float* p[MDMM_DECOLL_MAX_PARTS]; };
 // sequence j of the output = batch column idx = order[j]: [lengths[idx]][n_parts][row] from row out_offset[j]
 __global__ __launch_bounds__(NT) void decollate_kernel(Parts parts, int n_parts, int T, int B, int64_t row,
                                                        const int32_t* __restrict__ lengths,
-                                                       const int32_t* __restrict__ order,
+                                                       const int32_t* __restrict__ order, int n_out,
                                                        const int64_t* __restrict__ out_offset,
                                                        float* __restrict__ out) {
-  const int64_t jobs = (int64_t)T * B;
+  const int64_t jobs = (int64_t)T * n_out;
   for (int64_t s = blockIdx.x; s < jobs; s += gridDim.x) {
-    const int t = (int)(s / B), j = (int)(s % B);
+    const int t = (int)(s / n_out), j = (int)(s % n_out);
     const int idx = order[j];
-    if (t >= lengths[idx]) continue;
+    if (idx < 0 || idx >= B || t >= lengths[idx]) continue;
     for (int i = 0; i < n_parts; ++i)
       put_row(out + ((out_offset[j] + t) * n_parts + i) * row, parts.p[i] + ((int64_t)t * B + idx) * row, row);
   }
@@ -228,19 +228,19 @@ extern "C" int mdmm_delete_steps(const float* x, const uint8_t* del, int64_t ste
 }
 
 extern "C" int mdmm_decollate_pack(const float* const* parts, int n_parts, int T, int B, int64_t row,
-                                   const int32_t* lengths, const int32_t* order, const int64_t* out_offset,
-                                   float* out, void* stream) {
+                                   const int32_t* lengths, const int32_t* order, int n_out,
+                                   const int64_t* out_offset, float* out, void* stream) {
   if (!parts || n_parts < 1 || n_parts > MDMM_DECOLL_MAX_PARTS || !lengths || !order || !out_offset || !out ||
-      T < 0 || B < 0 || row < 1)
+      T < 0 || B < 0 || n_out < 0 || row < 1)
     return n_parts > MDMM_DECOLL_MAX_PARTS ? MDMM_E_LIMIT : MDMM_E_ARG;
-  if ((int64_t)T * B == 0) return 0;
+  if ((int64_t)T * n_out == 0 || B == 0) return 0;
   Parts p{};
   for (int i = 0; i < n_parts; ++i) {
     if (!parts[i]) return MDMM_E_ARG;
     p.p[i] = parts[i];
   }
-  hipLaunchKernelGGL(decollate_kernel, dim3(grid_of((int64_t)T * B)), dim3(NT), 0, STREAM, p, n_parts, T, B, row,
-                     lengths, order, out_offset, out);
+  hipLaunchKernelGGL(decollate_kernel, dim3(grid_of((int64_t)T * n_out)), dim3(NT), 0, STREAM, p, n_parts, T, B, row,
+                     lengths, order, n_out, out_offset, out);
   CHECK_LAUNCH();
 }
 

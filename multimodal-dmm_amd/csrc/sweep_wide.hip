@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) m_[rt][r] = x[rt][r] * acc[rt][r];          // muq
-      if constexpr (PK) { if (parked) park_f32(pk_e + EP_MUQ * 64 + lane, m_); }
+      if constexpr (PK) { if (parked) park_e(pk_e + EP_MUQ * 64 + lane, m_); }
       STAMP(9);
       __syncthreads();
       STAMP(10);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       //   v = sq^2 + eps, u = 1 / (t0 v + 1):  var = v u,  mean = muq u + num0 var
       fill_acc(acc, bs);
       gemm_tile<F32, RT, Pf<RT>::N>(acc, imgH + arow, W(L_WS), W(L_W1G), ring);
-      if constexpr (PK) { if (parked) park_f32(pk_e + EP_PRE * 64 + lane, acc); }
+      if constexpr (PK) { if (parked) park_e(pk_e + EP_PRE * 64 + lane, acc); }
       STAMP(16);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -388,7 +388,8 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
               if (kl_on) {       // losses.py:14-21 on the values just stored
                 const float ip = fast::rcp(ps), d = (im - pm) * ip, r_ = is * ip;
                 const float term = 2.0f * (fast::log(ps) - fast::log(is)) + fmaf(r_, r_, d * d) - 1.0f;
-                kl_acc += (kl_mask ? kl_mask[tb] : 1.0f) * term;
+                if (!kl_mask || kl_mask[tb] != 0.f) kl_acc += term;       // (selected, not multiplied: a masked row's
+                                                                          //  inf / NaN stays out, as losses.py:19 masked_select)
               }
               zz = sampled ? fmaf(e[j], is, im) : im;
               if (o_smp) o_smp[o] = zz;

@@ -122,10 +122,13 @@ struct AIn {
   float e_mu[EB], e_sd[EB], e_c[EB];
 };
 // what the elementwise adjoint reads from the park for one operand chunk (registers 8s .. 8s+7 of one pair's tile)
-struct EIn { u32x4 nl, gt, mq[2], pr[2]; };
+struct EIn { u32x4 nl, gt, mq, pr; };
 struct PairAdj { float gpm, gps, prm, prs; bool valid; };
 struct ExpD { const float *mean, *std, *mask; float *g_mean, *g_std; int64_t stride; unsigned bits; };
 
+// KC: the particle count as a compile-time constant (25: the reference's train_particles, dmm.py:534), or 0 = read
+// from the launch arguments -- with it the live-row tests of every image store and elementwise group fold away
+template <int KC>
 __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, const WideGeo g,
                                                          const WideWs ws, const FwdPark park) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
   // and a reload from scratch is a vector-memory load -- it waits for every older store of the wave.
   int lane, h, n, odd, kh, kh2, arow, srow;
   unsigned sel;
-  const int T = a.T, B = a.B, K = a.K;
+  const int T = a.T, B = a.B, K = KC ? KC : a.K;
   const int ts = K * RS, img = RT * ts;
   auto regeo = [&]() {
     int l;
@@ -226,15 +229,22 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     const int n_exp = a.E;
     const bool inv_prior = a.use_inv_prior;
     const float min_std = a.min_std;
-    ExpD ed[EB];
+    // The expert descriptors are fetched where a pair's loads / stores are issued, one batch of scalar loads each time
+    // (through a fresh opaque copy of the kernarg pointer): kept for the whole step they are ~60 scalar registers that
+    // the allocator parks in vector lanes -- 600 v_readlane per step.
+    auto fetch_ed = [&](ExpD (&ed)[EB]) __attribute__((always_inline)) {
+      KArgs* k2 = kap;
+      asm volatile("" : "+s"(k2));
+      const auto* ex2 = k2->experts;
 #pragma unroll
-    for (int e = 0; e < EB; ++e) {
-      const bool on = e < n_exp;
-      ed[e].mean = on ? exs[e].mean : nullptr; ed[e].std = on ? exs[e].std : nullptr;
-      ed[e].mask = on ? exs[e].mask : nullptr;
-      ed[e].g_mean = on ? exs[e].g_mean : nullptr; ed[e].g_std = on ? exs[e].g_std : nullptr;
-      ed[e].stride = on ? exs[e].pass_stride : 0; ed[e].bits = on ? exs[e].pass_bits : 0u;
-    }
+      for (int e = 0; e < EB; ++e) {
+        const bool on = e < n_exp;
+        ed[e].mean = on ? ex2[e].mean : nullptr; ed[e].std = on ? ex2[e].std : nullptr;
+        ed[e].mask = on ? ex2[e].mask : nullptr;
+        ed[e].g_mean = on ? ex2[e].g_mean : nullptr; ed[e].g_std = on ? ex2[e].g_std : nullptr;
+        ed[e].stride = on ? ex2[e].pass_stride : 0; ed[e].bits = on ? ex2[e].pass_bits : 0u;
+      }
+    };
     // pair of tile rt (wave-uniform: scalar address math)
     auto pair_of = [&](int rt, int& pp, int& pb) __attribute__((always_inline)) {
       const int pair = pair0 + rt;
@@ -249,6 +259,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
 #pragma unroll
       for (int e = 0; e < EB; ++e) { x.e_mu[e] = 0.f; x.e_sd[e] = 1.f; x.e_c[e] = 0.f; }
       if (!pair_of(rt, pp, pb)) return;
+      ExpD ed[EB];
+      fetch_ed(ed);
       const size_t tb = (size_t)t * B + pb;
       const size_t o = (((size_t)pp * T + t) * B + pb) * WD + n;
       if (p_gsmp) x.gsmp = p_gsmp[o];
@@ -271,11 +283,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       x.nl = park_ld((gw_t)park.xop + ((((size_t)blockIdx.x * (T - 1) + (i - 1)) * 2 + (rt >> 1)) * X_ARR + X_NL) * ARR_U4 +
                      (wave * 4 + (rt & 1) * 2 + s) * 64 + lane);
       x.gt = park_ld(eop_i + (EP_GATE + 2 * rt + s) * 64);
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        x.mq[d] = park_ld(eop_i + (EP_MUQ + 4 * rt + 2 * s + d) * 64);
-        x.pr[d] = park_ld(eop_i + (EP_PRE + 4 * rt + 2 * s + d) * 64);
-      }
+      x.mq = park_ld(eop_i + (EP_MUQ + 2 * rt + s) * 64);
+      x.pr = park_ld(eop_i + (EP_PRE + 2 * rt + s) * 64);
     };
     unsigned pv = 0;                                  // bit rt: tile rt carries a pair
     f32x16 v1[RT];
@@ -287,6 +296,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       r.gpm = 0.f; r.gps = 0.f; r.prm = x.prm; r.prs = x.prs;
       pv |= r.valid ? (1u << rt) : 0u;
       if (r.valid) {
+        ExpD ed[EB];
+        fetch_ed(ed);
         const size_t tb = (size_t)t * B + pb;
         const size_t o = (((size_t)pp * T + t) * B + pb) * WD + n;
         const float gi_m = x.g_im + adj_a[rt] + x.gsmp;
@@ -353,8 +364,11 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       for (int d = 0; d < 2; ++d) {
         const int q = 2 * s + d;
         const unsigned wn0 = y.nl[2 * d], wn1 = y.nl[2 * d + 1], wg0 = y.gt[2 * d], wg1 = y.gt[2 * d + 1];
+        const unsigned wm0 = y.mq[2 * d], wm1 = y.mq[2 * d + 1], wp0 = y.pr[2 * d], wp1 = y.pr[2 * d + 1];
         const float nlv[4] = {bf16_lo(wn0), bf16_hi(wn0), bf16_lo(wn1), bf16_hi(wn1)};
         const float gtv[4] = {bf16_lo(wg0), bf16_hi(wg0), bf16_lo(wg1), bf16_hi(wg1)};
+        const float mqv[4] = {bf16_lo(wm0), bf16_hi(wm0), bf16_lo(wm1), bf16_hi(wm1)};
+        const float prv[4] = {bf16_lo(wp0), bf16_hi(wp0), bf16_lo(wp1), bf16_hi(wp1)};
         float o_g3[4], o_gg[4], o_gl[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -362,8 +376,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
           // a register that is a dead row in BOTH half-waves (row 8 q + k >= K; at K = 25: registers 13 .. 15, a fifth of
           // this phase's arithmetic): its outputs are the zeros the masks below would have made them
           if (8 * q + k >= K) { o_g3[k] = 0.f; o_gg[k] = 0.f; o_gl[k] = 0.f; v1[rt][r] = 0.f; continue; }
-          const float pre = __uint_as_float(y.pr[d][k]);
-          const float muq = __uint_as_float(y.mq[d][k]);
+          const float pre = prv[k];
+          const float muq = mqv[k];
           // softplus and its derivative from one exponential: y = e^-|pre|
           const float ey = fast::exp(-fabsf(pre));
           const float r1 = fast::rcp(1.0f + ey);
@@ -627,8 +641,9 @@ int mdmm_wide_sweep_bwd4(const mdmm_sweep_t* a, hipStream_t stream) {
   fwd_park_carve(a, &park);
   ws.xop = park.xop;
   const int lds = 3 * RT * a->K * RS;
-  if (int rc = mdmm_lds_attr_fn((const void*)wide_bwd4_kernel, (size_t)lds)) return rc;
-  hipLaunchKernelGGL(wide_bwd4_kernel, dim3((unsigned)ws.n_wg), dim3(NTHR), lds, stream, *a, g, ws, park);
+  auto kern = a->K == 25 ? wide_bwd4_kernel<25> : wide_bwd4_kernel<0>;
+  if (int rc = mdmm_lds_attr_fn((const void*)kern, (size_t)lds)) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)ws.n_wg), dim3(NTHR), lds, stream, *a, g, ws, park);
   if (int rc = (int)hipGetLastError()) return rc;
   WideWs w2 = ws;
   w2.n_step = ws.n_step * 2;                // the contraction walks half-items

@@ -128,10 +128,10 @@ enum XArr { X_Z = 0, X_HG, X_HN, X_NL, X_ARR };
 enum GArr { G_HG = 0, G_HN, G_LIN, G_G, G_N, G_3, G_ARR };       // the backward's own spill, in weight-gradient block order
 enum EopSlot {
   EP_GATE = 0,       //  8: the gate as bf16 codes (gate_code), slot 2 rt + s = registers 8s .. 8s+7 of tile rt
-  EP_MUQ = 8,        // 16: fp32 mean of q'(z | z_prev) before the product with the global prior, slot 4 rt + q
-  EP_PRE = 24,       // 16: fp32 pre-activation of the std head (bias included)
-  EP_MASK = 40,      //  2: relu masks of the gate / nl hidden layer, one 16-bit word per tile
-  EP_SLOTS = 42
+  EP_MUQ = 8,        //  8: mean of q'(z | z_prev) before the product with the global prior (bf16, as the gate)
+  EP_PRE = 16,       //  8: pre-activation of the std head, bias included (bf16)
+  EP_MASK = 24,      //  2: relu masks of the gate / nl hidden layer, one 16-bit word per tile
+  EP_SLOTS = 26
 };
 struct FwdPark { uint4 *noise, *xop, *eop; };
 constexpr int PARK_PAIRS = 4;                          // pairs per workgroup of the kernels that share the park
@@ -187,17 +187,14 @@ __device__ __forceinline__ void store_image_park(char* img, const f32x16 (&v)[4]
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-// ... as fp32, slot 4 rt + q = registers 4q .. 4q+3 (`it` = this lane's pointer of the first slot)
-__device__ __forceinline__ void park_f32(gs_ptr it, const f32x16 (&v)[4]) {
+// ... as bf16 chunks in slots 2 rt + s (`it` = this lane's pointer of the first slot)
+__device__ __forceinline__ void park_e(gs_ptr it, const f32x16 (&v)[4]) {
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
+  for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uint4 o;
-      o.x = __float_as_uint(v[rt][4 * q]); o.y = __float_as_uint(v[rt][4 * q + 1]);
-      o.z = __float_as_uint(v[rt][4 * q + 2]); o.w = __float_as_uint(v[rt][4 * q + 3]);
-      park_st(it + (4 * rt + q) * 64, o);
-    }
+    for (int s = 0; s < 2; ++s) park_st(it + (2 * rt + s) * 64, acc_chunk<false>(v[rt], s));
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // gate g in (0, 1) as one bf16 that keeps BOTH g and 1 - g to bf16 relative accuracy: the smaller

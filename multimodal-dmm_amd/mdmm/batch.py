@@ -63,8 +63,9 @@ def delete_steps(x, steps):
         return out
     d = steps.to(device=x.device, dtype=torch.uint8).contiguous()
     assert d.numel() == n
-    native.check(native.lib().mdmm_delete_steps(x.data_ptr(), d.data_ptr(), n, x.numel() // n, out.data_ptr(),
-                                                _stream()), 'mdmm_delete_steps')
+    with torch.cuda.device(x.device):                      # (the stream of the batch's device, not of the current one)
+        native.check(native.lib().mdmm_delete_steps(x.data_ptr(), d.data_ptr(), n, x.numel() // n, out.data_ptr(),
+                                                    _stream()), 'mdmm_delete_steps')
     return out
 
 
@@ -264,15 +265,22 @@ def seq_decoll(batch, lengths, order, time_first=True):
     dev = parts[0].device
     lengths = [int(n) for n in (lengths.tolist() if torch.is_tensor(lengths) else lengths)]
     order = [int(i) for i in order]
+    # `order` is any list of batch columns (the reference: `for idx in order`) -- a subset, repeats: every entry has to
+    # name a column of the batch and an entry of `lengths`
+    if len(lengths) < B:
+        raise ValueError('seq_decoll: %d lengths for a batch of %d sequences' % (len(lengths), B))
+    if any(i < 0 or i >= B for i in order):
+        raise IndexError('seq_decoll: order entries must lie in [0, %d)' % B)
     out_len = [min(lengths[i], T) for i in order]
     offset = np.concatenate([[0], np.cumsum(out_len)]).astype(np.int64)
     out = torch.empty((int(offset[-1]), len(parts), row), dtype=torch.float32, device=dev)
     if out.numel():
         ptrs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
-        len_d, ord_d, off_d = _i32([min(n, T) for n in lengths], dev), _i32(order, dev), _i64(offset[:-1], dev)
+        len_d, ord_d, off_d = _i32([min(n, T) for n in lengths[:B]], dev), _i32(order, dev), _i64(offset[:-1], dev)
         with torch.cuda.device(dev):
             native.check(native.lib().mdmm_decollate_pack(ptrs, len(parts), T, B, row, len_d.data_ptr(), ord_d.data_ptr(),
-                                                          off_d.data_ptr(), out.data_ptr(), _stream()), 'mdmm_decollate_pack')
+                                                          len(order), off_d.data_ptr(), out.data_ptr(), _stream()),
+                         'mdmm_decollate_pack')
         del len_d, ord_d, off_d
     host = out.cpu().numpy()
     shape = ((len(parts),) if type(batch) is tuple else ()) + dims

@@ -348,7 +348,7 @@ def lib():
         L.mdmm_vrnn_bwd.argtypes = [C.POINTER(Vrnn), _P]
         L.mdmm_collate_pad.argtypes = [_P, _P, _P, _P, i32, i32, i64, _P, _P]
         L.mdmm_delete_steps.argtypes = [_P, _P, i64, i64, _P, _P]
-        L.mdmm_decollate_pack.argtypes = [C.POINTER(_P), i32, i32, i32, i64, _P, _P, _P, _P, _P]
+        L.mdmm_decollate_pack.argtypes = [C.POINTER(_P), i32, i32, i32, i64, _P, _P, i32, _P, _P, _P]
         L.mdmm_sqerr_steps.argtypes = [_P, _P, i64, i64, f32, i32, _P, _P]
         L.mdmm_time_avg.argtypes = [_P, _P, i32, i32, _P, _P, _P, _P]
         L.mdmm_time_acc.argtypes = [_P, _P, i32, i32, i32, _P, _P, _P, _P]

@@ -112,6 +112,27 @@ def test_decollate_on_device_is_the_references_lists(dev):
         assert np.array_equal(a_, b_.numpy())
 
 
+def test_decollate_takes_any_list_of_columns(dev):
+    """multiseq.py:388-399 `for idx in order`: `order` may be a subset of the batch's columns, repeat some, be longer
+    or shorter than the batch (the kernel used to index order[] / out_offset[] with the batch size)."""
+    from mdmm import batch
+    _, lengths, order = collated()
+    z = G.t('decoll/in/z').to(dev)
+    B = z.shape[1]
+    full = batch.seq_decoll(z, lengths, list(range(B)))
+    for sub in ([order[0]], order[:2], [order[-1], order[0], order[-1]], list(order) + [order[0]] * 3, []):
+        got = batch.seq_decoll(z, lengths, sub)
+        assert len(got) == len(sub)
+        for a_, idx in zip(got, sub):
+            assert np.array_equal(a_, full[idx]), (sub, idx)
+    tup = batch.seq_decoll((z, z * 2), lengths, order[:1])
+    assert tup[0].shape[1] == 2 and np.array_equal(tup[0][:, 1], 2 * full[order[0]])
+    with pytest.raises(IndexError):
+        batch.seq_decoll(z, lengths, [B])
+    with pytest.raises(ValueError):
+        batch.seq_decoll(z, lengths[:B - 1], [0])
+
+
 # ------------------------------------------------------------------------------------------- f3: golden G11 --
 G11 = helpers.Golden('g11_metrics.npz')
 

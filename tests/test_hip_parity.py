@@ -955,6 +955,54 @@ def test_fused_kld_equals_separate_kernels(dev, kernel_family, dtype, monkeypatc
             assert d < (2e-3 if dtype is torch.bfloat16 else 2e-5), (k, d)
 
 
+@pytest.mark.parametrize('particles', [25, 7])
+def test_parked_backward_matches_recompute(dev, kernel_family, particles, monkeypatch):
+    """K-particle sweeps at z = 256 with bf16 operands: the one-round backward that reads what the forward sweep kept
+    (mdmm_sweep_t.fwd_park: noise, gate, non-linear branch, mean, std pre-activation, relu masks, X-side weight-gradient
+    operands; csrc/sweep_wide_bwd4.hip) against the two-round backward that runs the transition forward again
+    (MDMM_FWD_PARK=0) -- the same step (dmm.py:503-554), the same Philox stream, ragged lengths and NaN spans.  The loss
+    is the same forward; the gradients differ by the bf16 rounding of the parked mean / pre-activation / gate
+    (measured 2.5e-3 L2 on tools/check_wide.py's cases)."""
+    if kernel_family == 'generic':
+        pytest.skip('wide family only')
+    from mdmm import models, ops
+    from mdmm.noise import PhiloxNoise
+    spec = [('v', 6, 'Normal'), ('m', 3, 'Normal'), ('a', 10, 'Categorical')]
+    names, dims, dists = [s_[0] for s_ in spec], [s_[1] for s_ in spec], [s_[2] for s_ in spec]
+    T, lengths = 9, [9, 9, 8, 6, 5, 3, 1]          # 4 passes x 7 sequences = 28 pairs = 7 workgroups of four
+    targets = make_inputs(spec, T, lengths, seed=4)
+    inputs = {k: v.clone() for k, v in targets.items()}
+    inputs['v'][2:4, 1] = float('nan'); inputs['m'][5:, 0] = float('nan')
+    mask = orc.len_to_mask(lengths)
+    res = []
+    for park in ('1', '0'):
+        monkeypatch.setenv('MDMM_FWD_PARK', park)
+        torch.manual_seed(3)
+        m = models.MultiDMM(names, dims, dists, h_dim=256, z_dim=256, device=dev)
+        m.sweep_dtype = torch.bfloat16
+        m.noise = PhiloxNoise(seed=17)
+        parks = []
+        orig = ops._SweepFn.backward
+
+        def spy(ctx, *g, _orig=orig):
+            parks.append(ctx.fwd_park is not None)
+            return _orig(ctx, *g)
+        monkeypatch.setattr(ops._SweepFn, 'backward', staticmethod(spy))
+        loss = m.step(cuda(inputs, dev), mask.to(dev), 0.7, {'v': 1.0, 'm': 1.0, 'a': 10.0}, targets=cuda(targets, dev),
+                      lengths=lengths, train_particles=particles, match_mult=0.0)
+        (loss / sum(lengths)).backward()
+        monkeypatch.setattr(ops._SweepFn, 'backward', staticmethod(orig))
+        assert any(parks) == (park == '1'), (park, parks)          # the route under test is the one that ran
+        res.append((float(loss), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0]), (res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys()
+    for k in res[1][1]:
+        a_, b_ = res[0][1][k], res[1][1][k]
+        assert torch.isfinite(a_).all(), k
+        d = float((a_ - b_).norm() / (b_.norm() + 1e-30))
+        assert d < 1e-2, (k, d)
+
+
 @pytest.mark.parametrize('path', ['wide', 'generic'])
 def test_step_z256_matches_oracle(dev, kernel_family, path, monkeypatch):
     """Small batch, fp32: 'wide' = the MFMA kernels of csrc/sweep_wide.hip (fp32 operands),
