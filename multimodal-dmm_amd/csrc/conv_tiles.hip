@@ -1139,8 +1139,7 @@ int shape_id(const mdmm_conv_t* a) {
 template <typename Kern>
 int set_lds(Kern kern, int bytes) { return mdmm_lds_attr_fn((const void*)kern, (size_t)bytes); }
 
-int grid_for(int N, int per_cu, const char* env = nullptr) {
-  if (env) if (const char* e = getenv(env)) { const int v = atoi(e); if (v >= 1 && v <= 16) per_cu = v; }     // (measurement switch)
+int grid_for(int N, int per_cu) {
   const int g = 256 * per_cu;
   return N < g ? N : g;
 }
@@ -1155,19 +1154,14 @@ constexpr int NORM_LDS(int channels) { return NORM_GROUPS * 2 * channels * 4; }
 bool norm_ok(const mdmm_conv_t* a) {
   return a->in_invstd && a->in_group_n >= 1 && (a->N + a->in_group_n - 1) / a->in_group_n <= NORM_GROUPS;
 }
-// 1 .. 4 output channels: the nine-tap chain (A/B: MDMM_CONV_UP_T9=0, the four class chains)
-bool up_t9() {
-  static const bool on = [] { const char* e = getenv("MDMM_CONV_UP_T9"); return !e || atoi(e) != 0; }();
-  return on;
-}
 template <int S, int CS, int CB, bool SB, bool BB>
 int run_up_io(const mdmm_conv_t* a, hipStream_t st) {
   using G = Shape<S, CS, CB>;
   auto k = conv_up_kernel<S, CS, CB, SB, BB>;
-  if constexpr (CB <= 4) { if (up_t9()) k = conv_up_kernel<S, CS, CB, SB, BB, false, false, true>; }
+  if constexpr (CB <= 4) k = conv_up_kernel<S, CS, CB, SB, BB, false, false, true>;       // 1 .. 4 output channels: the nine-tap chain
   int rc = set_lds(k, G::UP_LDS);
   if (rc) return rc;
-  hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2, "MDMM_CONV_UP_PER_CU")), dim3(256), G::UP_LDS, st, *a);
+  hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2)), dim3(256), G::UP_LDS, st, *a);
   return (int)hipGetLastError();
 }
 // the small side normalised while it is staged (in_mean): bf16 activations on both sides only
@@ -1176,11 +1170,11 @@ int run_up_norm(const mdmm_conv_t* a, hipStream_t st) {
   using G = Shape<S, CS, CB>;
   if (io_of(a) != 1 || !norm_ok(a)) return MDMM_E_ARG;
   auto k = conv_up_kernel<S, CS, CB, true, true, true>;
-  if constexpr (CB <= 4) { if (up_t9()) k = conv_up_kernel<S, CS, CB, true, true, true, false, true>; }
+  if constexpr (CB <= 4) k = conv_up_kernel<S, CS, CB, true, true, true, false, true>;
   constexpr int lds = G::UP_LDS + NORM_LDS(CS);
   int rc = set_lds(k, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2, "MDMM_CONV_UP_PER_CU")), dim3(256), lds, st, *a);
+  hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2)), dim3(256), lds, st, *a);
   return (int)hipGetLastError();
 }
 // with the output's BatchNorm statistics (out_stats): 16 / 32 output channels, bf16 on both sides
@@ -1194,7 +1188,7 @@ int run_up_stats(const mdmm_conv_t* a, hipStream_t st) {
     constexpr int lds = G::UP_LDS + NORM_LDS(CS) + 4 * 2 * 16 * 2 * 4;
     int rc = set_lds(k, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2, "MDMM_CONV_UP_PER_CU")), dim3(256), lds, st, *a);
+    hipLaunchKernelGGL(k, dim3(grid_for(a->N, 2)), dim3(256), lds, st, *a);
     return (int)hipGetLastError();
   }
 }
@@ -1218,7 +1212,7 @@ int run_down_io(const mdmm_conv_t* a, hipStream_t st) {
   if (rc) return rc;
   // workgroups per CU by what their LDS lets run side by side (S = 32: 36 KB, four per CU: 0.259 -> 0.222 ms at 20,480
   // images, tools/ab_conv_grid.sh; three at S = 16 and more than two of the up kernels measured no better)
-  hipLaunchKernelGGL(k, dim3(grid_for(a->N, down_per_cu(D::LDS), "MDMM_CONV_DOWN_PER_CU")), dim3(256), D::LDS, st, *a);
+  hipLaunchKernelGGL(k, dim3(grid_for(a->N, down_per_cu(D::LDS))), dim3(256), D::LDS, st, *a);
   return (int)hipGetLastError();
 }
 // the big side normalised while it is staged (in_mean) and / or the small side's statistics (out_stats): bf16 small
@@ -1234,7 +1228,7 @@ int run_down_fused(const mdmm_conv_t* a, hipStream_t st) {
     constexpr int lds = ((D::LDS + 15) & ~15) + NORM_LDS(CB) + 4 * 2 * 16 * 2 * 4;
     int rc = set_lds(k, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k, dim3(grid_for(a->N, down_per_cu(lds), "MDMM_CONV_DOWN_PER_CU")), dim3(256), lds, st, *a);
+    hipLaunchKernelGGL(k, dim3(grid_for(a->N, down_per_cu(lds))), dim3(256), lds, st, *a);
     return (int)hipGetLastError();
   }
 }
@@ -1254,7 +1248,7 @@ int run_down_lazy(const mdmm_conv_t* a, hipStream_t st) {
     const int lds = ((D::LDS + 15) & ~15) + groups * CB * 32;
     int rc = set_lds(k, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k, dim3(grid_for(a->N, down_per_cu(lds), "MDMM_CONV_DOWN_PER_CU")), dim3(256), lds, st, *a);
+    hipLaunchKernelGGL(k, dim3(grid_for(a->N, down_per_cu(lds))), dim3(256), lds, st, *a);
     return (int)hipGetLastError();
   }
 }
@@ -1262,7 +1256,7 @@ template <int S, int CS, int CB, int KS>
 int down_parts(const mdmm_conv_t* a) {
   using D = Down<S, CS, CB, KS>;
   constexpr int lds = ((D::LDS + 15) & ~15) + NORM_LDS(CB) + 4 * 2 * 16 * 2 * 4;
-  return grid_for(a->N, down_per_cu(lds), "MDMM_CONV_DOWN_PER_CU");
+  return grid_for(a->N, down_per_cu(lds));
 }
 template <int S, int CS, int CB, int KS>
 int run_down(const mdmm_conv_t* a, hipStream_t st) {
@@ -1288,11 +1282,7 @@ int wgrad_nt(const mdmm_conv_t* a) { return (a->KS * a->KS * a->CB + 31) / 32; }
 int wgrad_parts(const mdmm_conv_t* a) {
   // two workgroups per CU for every shape (S = 8 used 768: its 59 KB of LDS fit two per CU, so the third half-round
   // only added 33 MB of partial slabs: 0.375 -> 0.320 ms at 20,480 images, tools/ab_conv_wgrad_grid.sh)
-  int g = WGRAD_GRID;
-  if (const char* e = getenv(a->S == 8 ? "MDMM_CONV_WGRAD_GRID8" : "MDMM_CONV_WGRAD_GRID")) {     // (measurement switch)
-    const int v = atoi(e);
-    if (v >= 64 && v <= 4096) g = v;
-  }
+  const int g = WGRAD_GRID;
   return a->N < g ? a->N : g;
 }
 template <int S, int CS, int CB, int KS, bool SB, bool BB>
@@ -1363,7 +1353,7 @@ int run_wgrad(const mdmm_conv_t* a, float* part, hipStream_t st) {
 
 extern "C" int mdmm_conv_supported(const mdmm_conv_t* a) { return shape_id(a) >= 0; }
 
-extern "C" int mdmm_conv_up_parts(const mdmm_conv_t* a) { return a ? grid_for(a->N, 2, "MDMM_CONV_UP_PER_CU") : 0; }
+extern "C" int mdmm_conv_up_parts(const mdmm_conv_t* a) { return a ? grid_for(a->N, 2) : 0; }
 
 extern "C" int mdmm_conv_down_parts(const mdmm_conv_t* a) {
   const int id = shape_id(a);

@@ -1275,7 +1275,6 @@ int plan(const mdmm_sweep_t* a, bool bwd, WideGeo* g) {
     // CUs (rows >= NP of the tile are dead; the matrix work they waste is idle anyway)
     g->TPP = 1; g->ntab = 32;
     g->NP = g->n_pairs <= 8 * 256 ? 8 : (g->n_pairs <= 16 * 256 ? 16 : 32);
-    if (const char* e = getenv("MDMM_K1_NP")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32) g->NP = v; }   // A/B switch
     return 1;
   }
   const int RT = f32 ? 1 : (bwd ? 2 : 4);
@@ -1293,7 +1292,6 @@ int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
   const int64_t n_wg = (g.n_pairs + g.NP - 1) / g.NP, n_step = a->T - 1;
   const int64_t items = n_wg * n_step;
   int split = 42;                                   // 6 * 42 = 252 workgroups: one round of the 256 CUs
-  if (const char* e = getenv("MDMM_WGRAD_SPLIT")) split = atoi(e) > 0 ? atoi(e) : split;     // A/B switch
   if (split > items) split = items > 0 ? (int)items : 1;
   auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
   const int64_t b_spill = up(items * N_SPILL * NWAVE * CH * 64 * 16);
@@ -1322,11 +1320,8 @@ int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   const bool f32 = a->precision == MDMM_PREC_F32;
   if (a->K == 1) {
     if (f32) return launch_fwd<true, 1, true>(a, g, stream);
-    const bool lr_off = getenv("MDMM_K1_LR16") != nullptr;                  // A/B switch: every register slot, as before
-    const char* p3e = getenv("MDMM_K1_3PHASE");                             // A/B switch: the six-phase form (0)
-    const bool p3 = !(p3e && p3e[0] == '0');
-    if (g.NP <= 8 && !lr_off) return p3 ? launch_fwd<false, 1, true, 4, true>(a, g, stream) : launch_fwd<false, 1, true, 4>(a, g, stream);
-    if (g.NP <= 16 && !lr_off) return p3 ? launch_fwd<false, 1, true, 8, true>(a, g, stream) : launch_fwd<false, 1, true, 8>(a, g, stream);
+    if (g.NP <= 8) return launch_fwd<false, 1, true, 4, true>(a, g, stream);         // (three contraction phases: DESIGN 4.2e)
+    if (g.NP <= 16) return launch_fwd<false, 1, true, 8, true>(a, g, stream);
     return launch_fwd<false, 1, true, 16>(a, g, stream);
   }
   if (a->fwd_park && (f32 || !mdmm_wide_bwd4_shape(a) || a->fwd_park_bytes < mdmm_wide_fwd_park_bytes(a) ||
@@ -1347,19 +1342,17 @@ int mdmm_wide_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->wide_ws_bytes < carve(a, g, RT, &ws)) return MDMM_E_ARG;
   const bool f32 = a->precision == MDMM_PREC_F32;
   int rc;
-  const bool lr_off = getenv("MDMM_K1_LR16") != nullptr;                    // A/B switch: every register slot, as before
   if (a->K == 1 && f32) rc = launch_bwd<true, 1, true>(a, g, ws, stream);
-  else if (a->K == 1) rc = (g.NP <= 8 && !lr_off) ? launch_bwd<false, 1, true, 4>(a, g, ws, stream)
-                         : ((g.NP <= 16 && !lr_off) ? launch_bwd<false, 1, true, 8>(a, g, ws, stream)
-                                                    : launch_bwd<false, 1, true, 16>(a, g, ws, stream));
+  else if (a->K == 1) rc = g.NP <= 8 ? launch_bwd<false, 1, true, 4>(a, g, ws, stream)
+                         : (g.NP <= 16 ? launch_bwd<false, 1, true, 8>(a, g, ws, stream)
+                                       : launch_bwd<false, 1, true, 16>(a, g, ws, stream));
   else rc = f32 ? launch_bwd<true, 1, false>(a, g, ws, stream) : launch_bwd<false, 2, false>(a, g, ws, stream);
   if (rc) return rc;
   return wide_wgrad_launch(ws, f32, spill_chunks(f32, RT, a->K == 1, g.NP), a->dw_partial, stream);
 }
 
 int wide::wide_wgrad_launch(const WideWs& ws, bool f32, int CH, float* dw_partial, hipStream_t stream) {
-  const char* turn_env = getenv("MDMM_WGRAD_XCD");                  // A/B switch, default on
-  const int turn = turn_env ? atoi(turn_env) : 1;
+  const int turn = 1;                                               // (workgroup ids dealt so that a slice's six blocks share an XCD)
   const int n_wgrad = (6 * ws.split + 7) & ~7;
   const int wg_lds = 2 * 2 * NWAVE * CH * 64 * 16;                  // two buffers of (G, X)
   auto wgrad = [&](auto kern) -> int {

@@ -151,9 +151,10 @@ class GraphedElboStep:
     constants of the capture; the constructor's `warmup` eager steps are real optimizer steps on the given batch."""
 
     def __init__(self, model, optimizer, bucket, inputs, mask, lengths, kld_mult, rec_mults,
-                 targets=None, n_points_global=None, group=None, warmup=3, clip_grad=None, **train_args):
+                 targets=None, n_points_global=None, group=None, warmup=3, clip_grad=None, host_wait=True, **train_args):
         from . import ops
         self.model, self.optimizer, self.bucket, self.group = model, optimizer, bucket, group
+        self.host_wait = bool(host_wait)      # N > 1: wait on the host between the step graph and the all-reduce (__call__)
         if getattr(model, 'bn_sync', None) is not None:
             with ops.bn_sync(model.bn_sync):
                 if ops.bn_sync_group() is not None:
@@ -180,12 +181,8 @@ class GraphedElboStep:
         self._sched_ws = torch.empty(8, dtype=torch.float32, device=dev)
 
         def fwd_bwd():
-            loss = model.step(inputs, mask, float(kld_mult) if os.environ.get('MDMM_FROZEN_SCHEDULE') == '1' else self.kld_mult,
-                              rec_mults, targets=targets, lengths=lengths, **train_args)
-            if os.environ.get('MDMM_FROZEN_SCHEDULE') == '1':      # A/B switch: round 2's Python constants
-                (loss / n_points).backward()
-            else:
-                loss.backward(gradient=self.inv_points)              # (no product node in front of the step's graph)
+            loss = model.step(inputs, mask, self.kld_mult, rec_mults, targets=targets, lengths=lengths, **train_args)
+            loss.backward(gradient=self.inv_points)              # (no product node in front of the step's graph)
             return loss.detach()
 
         def clip_and_step():
@@ -223,13 +220,9 @@ class GraphedElboStep:
         """First node(s) of the step graph: the two schedule scalars from pinned host memory into their device
         tensor.  A kernel that reads the host buffer through its device address (the column-sum kernel over one
         row = a copy), not a memcpy node: with two host-to-device copy nodes at its head the replayed cfg3 step
-        took 30.7 instead of 29.5 ms.  (A/B: MDMM_SCHEDULE_FETCH=memcpy | none)"""
-        how = os.environ.get('MDMM_SCHEDULE_FETCH', 'kernel')
-        if how == 'memcpy':
-            self._sched.copy_(self._host_buf, non_blocking=True)
-        elif how == 'kernel':
-            from . import ops
-            ops._call('mdmm_colsum', self._host_buf.data_ptr(), 0, 1, 2, 2, ops._ptr(self._sched_ws), ops._ptr(self._sched))
+        took 30.7 instead of 29.5 ms."""
+        from . import ops
+        ops._call('mdmm_colsum', self._host_buf.data_ptr(), 0, 1, 2, 2, ops._ptr(self._sched_ws), ops._ptr(self._sched))
 
     def schedule(self, kld_mult=None, n_points=None):
         """Set the KLD multiplier / the normalisation of the next replays.  The step graph's first nodes copy both
@@ -243,8 +236,6 @@ class GraphedElboStep:
         changed = {k: float(v) for k, v in new.items() if v is not None and float(v) != self._asked[k]}
         if not changed:
             return
-        if os.environ.get('MDMM_SCHEDULE_FETCH', 'kernel') == 'none':
-            raise RuntimeError('schedule(): MDMM_SCHEDULE_FETCH=none freezes the captured values; nothing would change')
         # the replays in flight read the host scalars when they start: wait for the stream they were launched on
         # (not for whatever stream is current here)
         if self._replayed is not None:
@@ -264,8 +255,8 @@ class GraphedElboStep:
             # group, tools/dryrun_allreduce.py, profiles/r04v_dryrun_allreduce.txt) keep bit-identical gradients with
             # and without the wait (0.4 ms per step) -- but the GPU suite run as ONE process (dozens of graphs captured
             # and destroyed before this test) aborted in test_graphed_conv_step_through_rccl_world_one without it and
-            # passes with it, so the wait stays the default.  MDMM_REPLAY_SYNC=0 drops it.
-            if os.environ.get('MDMM_REPLAY_SYNC') != '0':
+            # passes with it, so the wait stays the default (constructor argument host_wait=False drops it).
+            if self.host_wait:
                 torch.cuda.current_stream().synchronize()
             self.bucket.allreduce(self.group)
         self.g_opt.replay()

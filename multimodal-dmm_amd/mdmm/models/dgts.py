@@ -98,7 +98,7 @@ class MultiDGTS(nn.Module):
         bns = [x for x in dec.modules() if isinstance(x, nn.modules.batchnorm._BatchNorm)] if dec.training else []
         if not bns:
             return True, False
-        ok = self._bn_in_blocks(dec, bns) and os.environ.get('MDMM_BN_GROUPS') != '0'
+        ok = self._bn_in_blocks(dec, bns)
         return ok, ok
 
     def _noise(self):

@@ -176,7 +176,7 @@ class MultiDMM(MultiDGTS):
             means.append(mean_t); stds.append(std_t)
         if direction == 'bwd':
             means.reverse(); stds.reverse()
-        if len(means) == 1 and os.environ.get('MDMM_MATCH_TRIM') != '0':             # (a view: stack is a copy kernel each way)
+        if len(means) == 1:             # (a view: stack is a copy kernel each way)
             return means[0].unsqueeze(0), stds[0].unsqueeze(0)
         return torch.stack(means), torch.stack(stds)
 
@@ -307,7 +307,7 @@ class MultiDMM(MultiDGTS):
         glb_mean, glb_std = self._prior_ms((1, 1, 1))
         nxt_mean, nxt_std = self.z_sample(1, 1, direction, True, n_particles,
                                           eps=None if eps is None else [eps],
-                                          _glb=(glb_mean[0], glb_std[0]) if os.environ.get('MDMM_MATCH_TRIM') != '0' else None)
+                                          _glb=(glb_mean[0], glb_std[0]))
         return ops.kld_gauss(glb_mean, glb_std, nxt_mean, nxt_std)
 
     # ---- the ELBO step ----------------------------------------------------------------
@@ -321,7 +321,7 @@ class MultiDMM(MultiDGTS):
         dec = self.dec[m]
         t_max, b_dim = z_list[0].shape[:2]
         bns = [x for x in dec.modules() if isinstance(x, nn.modules.batchnorm._BatchNorm)] if dec.training else []
-        grouped = bool(bns) and self._bn_in_blocks(dec, bns) and os.environ.get('MDMM_BN_GROUPS') != '0'
+        grouped = bool(bns) and self._bn_in_blocks(dec, bns)
         if (bns and not grouped) or len(z_list) == 1:
             if stacked:
                 return None             # (the caller falls back to the per-pass form)

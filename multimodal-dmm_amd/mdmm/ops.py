@@ -54,18 +54,11 @@ class KernelTimer:
 
 
 TIMER = None    # assign a KernelTimer to switch per-launch timing on
-_SYNC_CALLS = os.environ.get('MDMM_SYNC_CALLS') == '1'
 
 
 def _call(name, *args, tag=None, nbytes=0):
     """nbytes: the call's ALGORITHMIC HBM bytes (tensors it has to read / write once), for the timer."""
     fn = getattr(native.lib(), name)
-    if _SYNC_CALLS:             # debugging: a faulting kernel aborts the process -- the last name printed is its call
-        import sys
-        print('mdmm call', name, tag or '', file=sys.stderr, flush=True)
-        native.check(fn(*args, _stream()), name)
-        torch.cuda.synchronize()
-        return
     if TIMER is None:
         native.check(fn(*args, _stream()), name)
         return
@@ -188,7 +181,7 @@ class PackedGtf:
             return [torch.zeros_like(p) for p in like]
         gb = colsum(G) if G.is_cuda else G.sum(0)       # (CPU: only the host-side layout test, with its own `contract`)
         blocks = [(0, F1, 0, Dp), (F1, Dp, Dp, Hp), (F1 + Dp, Dp, Dp + Hp, Hp), (F1 + 2 * Dp, Dp, Dp + 2 * Hp, Dp)]
-        if contract is None and G.is_cuda and os.environ.get('MDMM_MATCH_TRIM') != '0' and all(native.lib().mdmm_spill_wgrad_splits(G.shape[0], gc, xc) == 1
+        if contract is None and G.is_cuda and all(native.lib().mdmm_spill_wgrad_splits(G.shape[0], gc, xc) == 1
                                                   for _, gc, _, xc in blocks):
             # a short spill (the prior-matching term's 50 rows): the four blocks in ONE launch
             b = native.SpillWgradBatch()
@@ -337,6 +330,23 @@ def wide_shape(cfg, bwd=False):
     return cfg.K <= 64
 
 
+_WARNED_GENERIC_BWD = set()
+
+
+def _warn_generic_backward(cfg):
+    """Once per (K, precision): a training sweep at z = h = 256 with more particles than the wide backward kernels take
+    (64 with bf16 operands, 32 with fp32; `train_particles` is a caller kwarg, dmm.py:531-536) runs its backward -- and
+    with bf16 operands its forward too -- on the generic fp32 kernels, roughly ten times slower."""
+    key = (cfg.K, PRECISIONS[cfg.precision])
+    if key in _WARNED_GENERIC_BWD:
+        return
+    _WARNED_GENERIC_BWD.add(key)
+    import warnings
+    warnings.warn('mdmm: %d particles at z = h = 256 are more than the wide backward sweep takes (64 with bf16 operands, '
+                  '32 with fp32): this sweep trains on the generic fp32 kernels, about 10x slower.  The reference trains '
+                  'with train_particles=25.' % cfg.K, RuntimeWarning, stacklevel=3)
+
+
 def prepack_gtf(params, D, H, precision):
     """Build (or refresh) every cached operand pack of one GaussianGTF on the current stream.  A
     step that forks streams calls this before the fork: a pack built on a forked stream would be
@@ -454,6 +464,8 @@ class _SweepFn(torch.autograd.Function):
         wide = wide_shape(cfg)
         packed = packed_gtf(gtf_params, cfg.D, cfg.H)
         prec = PRECISIONS[cfg.precision]
+        if wide and not wide_shape(cfg, bwd=True) and any(ctx.needs_input_grad):
+            _warn_generic_backward(cfg)
         if wide and prec == native.PREC_BF16 and not wide_shape(cfg, bwd=True) and any(ctx.needs_input_grad):
             # more particles than the wide backward takes (K > 64): the backward runs on the generic fp32
             # kernels, which recompute the forward transition in fp32 -- so the forward must be the fp32
@@ -1278,8 +1290,8 @@ class _CatHeadNllFn(torch.autograd.Function):
 
 
 def cat_head_supported(h_dim, n_cat):
-    """The fused head + softmax + loss kernels take this layer shape (A/B: MDMM_CAT_HEAD=0)."""
-    return os.environ.get('MDMM_CAT_HEAD') != '0' and bool(native.lib().mdmm_cat_head_supported(int(h_dim), int(n_cat)))
+    """The fused head + softmax + loss kernels take this layer shape."""
+    return bool(native.lib().mdmm_cat_head_supported(int(h_dim), int(n_cat)))
 
 
 def cat_head_nll(hid, layer, target, mask=None, weight=1.0, into=None, passes=1, pass_weight=None):
@@ -1377,8 +1389,7 @@ class _LinearF32Fn(torch.autograd.Function):
 
 def linear_f32_supported(x, weight):
     """Shapes the fp32 tiles take (as linear_tiles_supported, fp32 in memory on both sides)."""
-    return (x.dtype == torch.float32 and linear_tiles_supported(x, weight)
-            and os.environ.get('MDMM_LIBRARY_GEMM') != '1')       # (A/B switch: the round-2 route through the BLAS)
+    return x.dtype == torch.float32 and linear_tiles_supported(x, weight)
 
 
 def linear_f32(x, weight, bias):
@@ -1386,7 +1397,7 @@ def linear_f32(x, weight, bias):
     linear_tiles_thin; None when the shape is not one the tiles take."""
     if linear_f32_supported(x, weight):
         return _LinearF32Fn.apply(x, weight, bias)
-    if linear_tiles_thin_supported(x, weight) and os.environ.get('MDMM_LIBRARY_GEMM') != '1':
+    if linear_tiles_thin_supported(x, weight):
         return linear_tiles_thin(x, weight, bias, fn=_LinearF32Fn)
     return None
 
@@ -1400,10 +1411,6 @@ def tall_linear(x, layer):
         y = linear_f32(x, layer.weight, layer.bias)
         if y is not None:
             return y
-    if os.environ.get('MDMM_TRACE_LIB') == '1':         # which layers still reach the library's GEMM
-        import sys
-        print('tall_linear (library GEMM): x %s %s -> %d, conv_operands %s' % (tuple(x.shape), x.dtype, layer.weight.shape[0],
-                                                                              CONV_OPERANDS), file=sys.stderr, flush=True)
     return _TallLinearFn.apply(x, layer.weight, layer.bias)
 
 
@@ -1429,11 +1436,10 @@ def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.flo
     f32: fp32 operands on the fp32 matrix instruction (mdmm_gemm_f32) instead of bf16-rounded ones."""
     g = native.Gemm()
     g.I, g.J, g.L, g.ta, g.tb, g.split = I, J, L, int(ta), int(tb), 1
-    # A/B switches: bit 0 = bf16 operands through the converting path, bit 1 = staggered contraction start,
-    # bit 2 = the generic tile kernel where a shape-specialised one (csrc/gemm_heads.hip) would be taken
-    g.flags = (int(os.environ.get('MDMM_GEMM_NO_RAW') == '1') | (2 * int(os.environ.get('MDMM_GEMM_ROT', '0') == '1'))
-                  | (4 * int(os.environ.get('MDMM_GEMM_GENERIC', '0') == '1')) | (8 * (int(os.environ.get('MDMM_GEMM_MODE', '0')) & 3))
-                  | (native.GEMM_RELU if relu else 0) | (native.GEMM_F32 if f32 else 0))
+    # MDMM_GEMM_GENERIC=1 (flag bit 2): the generic tile kernel where a shape-specialised one (csrc/gemm_heads.hip) would
+    # be taken -- the cross-check of tests/test_gemm_heads_gpu.py
+    g.flags = ((4 * int(os.environ.get('MDMM_GEMM_GENERIC', '0') == '1'))
+               | (native.GEMM_RELU if relu else 0) | (native.GEMM_F32 if f32 else 0))
     g.a, g.lda, g.b, g.ldb = _ptr(a), a.stride(0), _ptr(b), b.stride(0)
     g.a_bf16, g.b_bf16 = int(a.dtype == torch.bfloat16), int(b.dtype == torch.bfloat16)
     c = torch.empty(I, J, device=a.device, dtype=out_dtype)
@@ -2092,12 +2098,6 @@ def prepack_convs(modules):
                 hit = getattr(layer.weight, '_mdmm_conv_up' if up else '_mdmm_conv_down', None)
                 if hit is None or hit[0] != key:
                     conv_items.append((layer.weight, a, up, key))
-    if os.environ.get('MDMM_PACK_BATCH') == '0':        # A/B switch: one launch per pack, as before
-        for w, a, up, key in conv_items:
-            _conv_pack(w, a, up)
-        for w, key in lin_items:
-            _lin_pack(w)
-        return
     lib = native.lib()
     for lo in range(0, len(conv_items), native.CONV_PACK_BATCH_MAX):
         chunk = conv_items[lo:lo + native.CONV_PACK_BATCH_MAX]

@@ -1674,6 +1674,33 @@ def test_wide_forward_many_particles_matches_generic(dev, kernel_family, K, prec
         close(a_, b_, tol, 'many-particle forward ' + name)
 
 
+def test_training_sweep_beyond_the_wide_backward_warns_once(dev, kernel_family):
+    """`train_particles` is a caller kwarg (dmm.py:531-536): above 64 particles at z = h = 256 the training sweep leaves
+    the wide family for the generic fp32 kernels -- it must say so (once per shape), and still be right."""
+    if kernel_family == 'generic':
+        pytest.skip('wide family only')
+    import warnings
+    from mdmm import ops
+    torch.manual_seed(1)
+    T, B, D, K = 3, 2, 256, 70
+    gd = lambda *s: torch.randn(*s, device=dev)     # noqa: E731
+    shapes = [(D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,)]
+    gtf = [(0.06 * gd(*s)).requires_grad_() for s in shapes]
+    z0m, z0s = (gd(D) * 0.1).requires_grad_(), (gd(D) * 0.1).requires_grad_()
+    experts = [ops.ExpertSpec(gd(T, B, D).requires_grad_(), (gd(T, B, D).abs() + 0.3).requires_grad_(), None, 1, False)]
+    ops._WARNED_GENERIC_BWD.clear()
+    seen = []
+    for _ in range(2):
+        cfg = ops.SweepCfg(T, B, D, D, P=1, K=K, reverse=True, sample=True, seed=3, precision=torch.bfloat16)
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            outs = ops.bfvi_sweep(cfg, gtf, z0m, z0s, experts)
+            sum((o * o).sum() for o in outs if o.numel()).backward()
+        seen.append([w for w in rec if issubclass(w.category, RuntimeWarning) and 'generic fp32 kernels' in str(w.message)])
+    assert len(seen[0]) == 1 and len(seen[1]) == 0, seen
+    assert all(torch.isfinite(p.grad).all() for p in gtf)
+
+
 @pytest.mark.parametrize('which', ['dmm_z32', 'dmm_z256_conv'])
 def test_packs_follow_fused_optimizer_updates(dev, kernel_family, which):
     """Fused optimizers update parameters without moving their version counters: the cached operand

@@ -46,16 +46,23 @@ def _grads(model):
     return {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
 
 
-def _replay_vs_eager(name, lengths, dev):
+def _replay_vs_eager(name, lengths, dev, device_batch=False):
     """Capture the step at this batch, replay it three times, run the same step eagerly on the same weights and the
-    same Philox stream; asserts loss and every gradient equal (TOL_REPLAY_*).  Returns what the oracle leg needs."""
+    same Philox stream; asserts loss and every gradient equal (TOL_REPLAY_*).  Returns what the oracle leg needs.
+    device_batch: the configuration's own batch, made on the device (cfg5: ragged lengths and missingness are part of
+    its batch; 13 GB of host copies for an oracle leg that does not exist at that size are not made)."""
     from mdmm import models
     from mdmm.harness import GradBucket, GraphedElboStep
     from mdmm.noise import PhiloxNoise
     cfg = bench.CONFIGS[name]
     K, warm = bench.TRAIN_PARTICLES, 1
     n_points = sum(lengths)
-    x_cpu, tg_cpu, mask_cpu, x, tg, mask = _ragged_batch(cfg, lengths, dev)
+    if device_batch:
+        x, tg, mask, lengths2 = cfg.batch(cfg.T, len(lengths), 77, dev, lengths=lengths)
+        assert lengths2 == lengths
+        x_cpu = tg_cpu = mask_cpu = None
+    else:
+        x_cpu, tg_cpu, mask_cpu, x, tg, mask = _ragged_batch(cfg, lengths, dev)
     # recycled allocator blocks full of garbage: an unwritten output or a missing cross-stream
     # dependency in the captured step then shows up as a difference
     junk = [torch.randn(1 << 24, device=dev) * 1e3 for _ in range(8)]
@@ -65,7 +72,7 @@ def _replay_vs_eager(name, lengths, dev):
     model.noise = noise = PhiloxNoise(seed=4321)
     opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, capturable=True, fused=True)
     bucket = GradBucket(model.parameters())
-    kw = dict(targets=tg, train_particles=K) if name == 'cfg3' else dict(targets=tg)
+    kw = dict(targets=tg, train_particles=K) if name in ('cfg3', 'cfg5') else dict(targets=tg)
     c_before = noise.counter
     step = GraphedElboStep(model, opt, bucket, x, mask, lengths, 1.0, cfg.rec, n_points_global=n_points,
                            warmup=warm, **kw)
@@ -119,6 +126,17 @@ def test_graph_replay_matches_eager_full_size(name, dev):
     replay bugs are what the small test cannot see.)"""
     lengths = sorted([40] * 200 + [int(n) for n in np.random.RandomState(3).randint(5, 40, 56)], reverse=True)
     _replay_vs_eager(name, lengths, dev)
+    torch.cuda.empty_cache()
+
+
+def test_graph_replay_matches_eager_cfg5_per_gpu_size(dev):
+    """BASELINE cfg5 at its per-GPU size: 512 sequences, T = 128, ragged lengths 64..128, half of every modality's
+    steps missing.  3 passes x 512 = 1,536 (pass, sequence) pairs are 384 workgroups of the K-particle sweeps -- one and
+    a half rounds of the chip, a tail no smaller test takes -- and 127 steps of park per workgroup."""
+    g = torch.Generator().manual_seed(5)
+    lengths = sorted(torch.randint(64, 129, (512,), generator=g).tolist(), reverse=True)
+    lengths[0] = 128
+    _replay_vs_eager('cfg5', lengths, dev, device_batch=True)
     torch.cuda.empty_cache()
 
 

@@ -1,8 +1,8 @@
 """the N > 1 step on ONE GPU -- a real RCCL group of one rank forces GraphedElboStep.__call__ through its
 all-reduce branch ([graph: step + backward] -> all_reduce of the flat gradient -> [graph: Adam]) for 200 replays of cfg4
-(and cfg3) at B = 256, with (the default; in the r04v record: NO_REPLAY_SYNC=0) and without (MDMM_REPLAY_SYNC=0) the host wait in front of the collective; every 50th
+(and cfg3) at B = 256, with (the default) and without (third argument 0: GraphedElboStep(host_wait=False)) the host wait in front of the collective; every 50th
 replay's gradients are compared with the same step run eagerly on the same weights and Philox stream.
-usage: python tools/dryrun_allreduce.py [cfg4|cfg3] [replays]"""
+usage: python tools/dryrun_allreduce.py [cfg4|cfg3] [replays] [host_wait=1]"""
 import os, sys, time
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'multimodal-dmm_amd'))
@@ -16,6 +16,7 @@ from mdmm.noise import PhiloxNoise
 
 name = sys.argv[1] if len(sys.argv) > 1 else 'cfg4'
 n_rep = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+host_wait = (sys.argv[3] != '0') if len(sys.argv) > 3 else True
 dev = torch.device('cuda:0')
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 cfg = bench.CONFIGS[name]
@@ -28,7 +29,7 @@ x, tg, mask, lengths = cfg.batch(cfg.T, cfg.B, 1234, dev)
 kw = dict(targets=tg, train_particles=25) if name == 'cfg3' else dict(targets=tg)
 c0, warm = noise.counter, 1
 step = GraphedElboStep(model, opt, bucket, x, mask, lengths, 1.0, cfg.rec, n_points_global=sum(lengths), warmup=warm,
-                       group=dist.group.WORLD, **kw)
+                       group=dist.group.WORLD, host_wait=host_wait, **kw)
 per = (noise.counter - c0) // (warm + 1)
 c_cap = noise.counter - per
 worst, t0 = 0.0, time.perf_counter()
@@ -56,7 +57,7 @@ for it in range(1, n_rep + 1):
         bucket.release()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print('%s NO_REPLAY_SYNC=%s: %d replays through the all-reduce branch, worst gradient diff %.2e, %.2f ms per step (checks included)'
-      % (name, "1" if os.environ.get("MDMM_REPLAY_SYNC") == "0" else "0", n_rep, worst, 1e3 * dt / n_rep), flush=True)
+print('%s host_wait=%s: %d replays through the all-reduce branch, worst gradient diff %.2e, %.2f ms per step (checks included)'
+      % (name, int(host_wait), n_rep, worst, 1e3 * dt / n_rep), flush=True)
 assert worst < 1e-5
 dist.destroy_process_group()
