@@ -94,16 +94,20 @@ def test_bf16_gradient_error_shrinks_with_the_batch(dev):
 
 
 def test_bf16_adam_trajectory_follows_the_fp32_one(dev):
-    """Fifty Adam steps (trainer.py:237-252 through harness.elbo_step) of the cfg3 model on a B = 32 batch, once with
-    bf16 operands and once with fp32 operands: same initial weights, same batch, same Philox streams.  The ELBO curves
-    stay within 1 % of each other at EVERY step; the final parameters' relative L2 distance is recorded."""
+    """Fifty Adam steps (trainer.py:237-252 through harness.elbo_step) of the cfg3 model on a B = 32 batch at the
+    configuration's learning rate, once with bf16 operands and once with fp32 operands: same initial weights, same
+    batch, same Philox streams.  The ELBO curves stay within 1 % of each other at EVERY step (measured: 2e-5); the final
+    parameters' distance relative to the distance travelled is recorded.  (At 3x / 10x that learning rate BOTH modes show
+    the same one-step loss spikes -- step 25 / step 10, loss x1.4 / x2.6 -- where a pointwise comparison is
+    ill-conditioned (5 % / 17 % apart on that one step) and after which they are within 2e-4 again:
+    tools/train_traj_bf16.py, profiles/r05_bf16_trajectory.txt.)"""
     from mdmm.harness import GradBucket, elbo_step
     cfg = bench.Cfg3
     state = {k: v.detach().clone() for k, v in _cfg3_model(torch.float32, dev).state_dict().items()}
     curves, finals = {}, {}
     for dtype in (torch.float32, torch.bfloat16):
         m = _cfg3_model(dtype, dev, state)
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        opt = torch.optim.Adam(m.parameters(), lr=cfg.lr)
         bucket = GradBucket(m.parameters())
         x, tg, mask, lengths = cfg.batch(cfg.T, 32, 32, dev)
         losses = []
@@ -117,7 +121,7 @@ def test_bf16_adam_trajectory_follows_the_fp32_one(dev):
         torch.cuda.empty_cache()
     hi, lo = curves[torch.float32], curves[torch.bfloat16]
     assert np.isfinite(hi).all() and np.isfinite(lo).all()
-    assert hi[-1] < 0.98 * hi[0], 'the trajectory does not train (%.4e -> %.4e)' % (hi[0], hi[-1])
+    assert hi[-1] < 0.98 * hi[0] and (np.diff(hi) < 0).all(), 'the trajectory does not train (%.4e -> %.4e)' % (hi[0], hi[-1])
     rel = np.abs(lo - hi) / np.abs(hi)
     num = sum(float((finals[torch.bfloat16][k] - v).pow(2).sum()) for k, v in finals[torch.float32].items())
     den = sum(float((v - state[k].float()).pow(2).sum()) for k, v in finals[torch.float32].items())
