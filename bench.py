@@ -38,7 +38,9 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   its step-time ratio to the unmodified reference as measured in the build container;
   elbo_delta   -- |loss_hip - loss_oracle| / |loss_oracle| of one step on that sample, the kernels' noise
                   replayed into the oracle, for the timed precision mode and for fp32 operands;
-  extra        -- cfg2, cfg4 and cfg3 with fp32 operands ride along at N = 1.
+  extra        -- cfg2, cfg4 and cfg3 with fp32 operands ride along at N = 1, and the callers either side of the step
+                  (batch_prep: collate + burst deletion on the device; eval: 200-particle evaluation forward + metrics
+                  + decollate; tools/bench_callers.py).
 """
 import argparse
 import json
@@ -651,7 +653,20 @@ def run(cfg, args, world, rank, device, graph):
         timer, ops.TIMER = ops.TIMER, None
         timing_note = ('HIP events around every library call of %d eager re-runs of the same step, '
                        'right after the graph-replayed timed region' % n_probe)
+    # N > 1: what the one collective of a step costs by itself -- HIP events around all_reduce(flat gradient) behind a
+    # barrier, outside the timed region (in the timed step it sits between the two graphs, after a host wait)
+    allreduce_ms = None
     if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for e0, e1 in ev:
+            e0.record()
+            dist.all_reduce(bucket.flat)
+            e1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = round(sorted(e0.elapsed_time(e1) for e0, e1 in ev)[2], 4)
+        bucket.release()
         dist.barrier()
     loss_val = float(loss)
     if rank != 0:
@@ -673,7 +688,13 @@ def run(cfg, args, world, rank, device, graph):
             r['timing'] = timing_note
     out_cfg = {'workload': cfg.workload % b_dim, 'global_batch': world * b_dim, 'seq_len': cfg.T,
                'parallelism': 'dp%d' % world, 'loss': round(loss_val, 3), 'execution': execution,
-               'rccl_ranks': dist.get_world_size() if world > 1 and dist.is_initialized() else 1}
+               'rccl_ranks': dist.get_world_size() if world > 1 and dist.is_initialized() else 1,
+               # BatchNorm statistics of the conv plug-ins (common.py:80-84): over this rank's frames only -- the graph-
+               # replayed step cannot hold the synchronising collective (harness.GraphedElboStep); 10,240 frames per rank
+               'bn': 'per-rank' if any('net.1' in k for k, _ in model.named_parameters()) else 'none',
+               'allreduce': None if allreduce_ms is None else
+               {'ms': allreduce_ms, 'bytes': int(bucket.flat.numel() * 4), 'timing': 'HIP events, median of 5, outside the timed region',
+                'host_wait_before': True}}
     if replay_check is not None:
         out_cfg['replay_matches_eager'] = replay_check
     return {
@@ -787,6 +808,13 @@ def main():
             af.steps, af.warmup, af.batch = 3, 2, 0
             rf32 = run(Cfg3F32, af, 1, 0, device, graph=False)
             out['extra']['cfg3_f32'] = {k: rf32[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline')}
+            # the callers either side of the step: on-device batch preparation and the evaluation body
+            del rf32, r4, r2
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+            import bench_callers
+            out['extra']['batch_prep'] = bench_callers.measure_batch_prep(device)
+            out['extra']['eval'] = bench_callers.measure_eval(device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -11,8 +11,8 @@
 // three of the six contraction levels and ~100 k of a step's ~222 k cycles) and four of the ten operand arrays
 // are not spilled a second time:
 //   * 1,024 pairs are 256 workgroups: one round, every weight fragment feeds four MFMAs;
-//   * the LDS images hold LIVE rows only (row K*rt + k; dead MFMA rows re-read row K-1 of their tile and their
-//     results are never stored or summed): THREE 100-row images fit one CU's 160 KB;
+//   * the LDS images hold LIVE rows only (row K*rt + k; what the dead MFMA rows of a tile read is never stored or
+//     summed): THREE 100-row images fit one CU's 160 KB;
 //   * at most TWO accumulator arrays (2 x 64 registers) are live at any point.
 // Step (i = T-1 .. 1), images A / B / C, six workgroup barriers:
 //   A+E per pair: adjoint of sampling + fusion at step i (global loads, per-pair algebra), then the elementwise
@@ -60,6 +60,11 @@ __device__ __forceinline__ void mma16(f32x16& acc, const u32x4& a, const u32x4& 
 
 // acc[rt] += X[tile rt][0..256) . W_slice^T for the four row tiles; `x0` = this lane's A-operand
 // address of tile 0 in the image, `ts` = bytes between tiles (K rows).  Ring contract as gemm_tile.
+// The images hold K live rows per tile: MFMA rows >= K of a tile read on into the NEXT tile's first rows (behind the
+// last image: past the launch's LDS allocation, which reads as zero) -- whatever they hold, their products land in
+// accumulator rows that are never stored or summed.  (Re-reading row K - 1 instead, as this kernel did, put eight
+// lanes on one 16-byte address in every operand read: SQ_LDS_BANK_CONFLICT = 35 % of the LDS cycles,
+// profiles/r05_pmc_bwd4_before.txt; the forward kernels, whose 32 rows are 32 addresses, count none.)
 // The A operands of chunk c + 1 are read while chunk c's MFMAs issue (the read behind the last
 // chunk lands in the row pad and is dropped).
 template <bool NEXT = true>
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     lane = l; h = l >> 5; n = 32 * wave + (l & 31); odd = l & 1;
     kh = K - 4 * h; kh2 = kh - odd;
-    arow = min(l & 31, K - 1) * RS + 16 * h;          // A operand: tile 0 (dead MFMA rows re-read row K - 1)
+    arow = (l & 31) * RS + 16 * h;                    // A operand: tile 0 (dead MFMA rows: see gemm4)
     srow = (4 * h + odd) * RS + (n & ~1) * 2;         // image stores: see pair_word
     sel = odd ? 0x03020706u : 0x05040100u;
   };
@@ -204,6 +209,13 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
   };
   const int n_pairs = g.n_pairs;
   const int pair0 = blockIdx.x * RT;
+  // The relu masks of a step's hidden layers are requested a step ahead, in front of D3's contractions of the step
+  // before: requested in their own step they sat behind the E phase's spill stores on their way to HBM (the vector-memory
+  // counter is in order) and D1's mask epilogue waited ~8 k cycles for them.  (The first pair's fusion inputs and first
+  // operand chunk a step ahead as well: measured SLOWER, 4.07 vs 3.88 ms per call -- 35 more live registers through D3
+  // are 144 B more scratch per lane.)
+  u32x4 mkg = {0, 0, 0, 0}, mkn = {0, 0, 0, 0};
+  bool masks_ahead = false;
   for (int i = T - 1; i >= 0; --i) {
     // keep invariant reads and address arithmetic inside the loop (see wide_fwd_kernel)
     frag = frag0; spill_w = spill0; noise = noise0; eop = eop0;
@@ -252,8 +264,9 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       pp = valid ? pair / B : -1; pb = valid ? pair - pp * B : 0;
       return valid;
     };
-    const gw_t eop_i = eop + (size_t)(trans ? i - 1 : 0) * (NWAVE * EP_SLOTS * 64) + lane;
-    auto load_a = [&](int rt, AIn& x) __attribute__((always_inline)) {
+    auto eop_of = [&](int ii) __attribute__((always_inline)) { return eop + (size_t)(ii > 0 ? ii - 1 : 0) * (NWAVE * EP_SLOTS * 64) + lane; };
+    // (tt / ii: time index / loop index of the step the loads belong to -- this one, or the next one from D3)
+    auto load_a = [&](int rt, AIn& x, int tt) __attribute__((always_inline)) {
       int pp, pb;
       x.gsmp = 0.f; x.g_im = 0.f; x.g_is = 0.f; x.prm = 0.f; x.prs = 1.f; x.g_pm = 0.f; x.g_ps = 0.f;
 #pragma unroll
@@ -261,8 +274,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       if (!pair_of(rt, pp, pb)) return;
       ExpD ed[EB];
       fetch_ed(ed);
-      const size_t tb = (size_t)t * B + pb;
-      const size_t o = (((size_t)pp * T + t) * B + pb) * WD + n;
+      const size_t tb = (size_t)tt * B + pb;
+      const size_t o = (((size_t)pp * T + tt) * B + pb) * WD + n;
       if (p_gsmp) x.gsmp = p_gsmp[o];
       if (p_gim) x.g_im = p_gim[o];
       if (p_gis) x.g_is = p_gis[o];
@@ -278,13 +291,19 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
         }
       }
     };
-    auto load_e = [&](int rt, int s, EIn& x) __attribute__((always_inline)) {
+    auto load_e = [&](int rt, int s, EIn& x, int ii) __attribute__((always_inline)) {
       // (the non-linear branch is the X-side operand of the std head's weight gradient: the forward's chunks)
-      x.nl = park_ld((gw_t)park.xop + ((((size_t)blockIdx.x * (T - 1) + (i - 1)) * 2 + (rt >> 1)) * X_ARR + X_NL) * ARR_U4 +
+      const gw_t ep_ = eop_of(ii);
+      x.nl = park_ld((gw_t)park.xop + ((((size_t)blockIdx.x * (T - 1) + (ii - 1)) * 2 + (rt >> 1)) * X_ARR + X_NL) * ARR_U4 +
                      (wave * 4 + (rt & 1) * 2 + s) * 64 + lane);
-      x.gt = park_ld(eop_i + (EP_GATE + 2 * rt + s) * 64);
-      x.mq = park_ld(eop_i + (EP_MUQ + 2 * rt + s) * 64);
-      x.pr = park_ld(eop_i + (EP_PRE + 2 * rt + s) * 64);
+      x.gt = park_ld(ep_ + (EP_GATE + 2 * rt + s) * 64);
+      x.mq = park_ld(ep_ + (EP_MUQ + 2 * rt + s) * 64);
+      x.pr = park_ld(ep_ + (EP_PRE + 2 * rt + s) * 64);
+    };
+    auto load_masks = [&](int ii) __attribute__((always_inline)) {
+      const gw_t ep_ = eop_of(ii);
+      mkg = park_ld(ep_ + EP_MASK * 64);
+      mkn = park_ld(ep_ + (EP_MASK + 1) * 64);
     };
     unsigned pv = 0;                                  // bit rt: tile rt carries a pair
     f32x16 v1[RT];
@@ -433,32 +452,35 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       AIn xa, xb;
       EIn ya, yb;
       PairAdj f;
-      load_a(0, xa);
-      if (trans) load_e(0, 0, ya);
-      load_a(1, xb);
+      load_a(0, xa, t);
+      if (trans) {
+        load_e(0, 0, ya, i);
+        if (!masks_ahead) load_masks(i);              // (the first processed step)
+      }
+      load_a(1, xb, t);
       __builtin_amdgcn_sched_barrier(0);
       f = fuse(0, xa);
       __builtin_amdgcn_sched_barrier(0);
-      load_a(2, xa);
+      load_a(2, xa, t);
       if (trans) {
         __syncthreads();                              // images: every wave is past D3 of the step before
         regeo();
-        load_e(0, 1, yb);
+        load_e(0, 1, yb, i);
         __builtin_amdgcn_sched_barrier(0);
         eadj(0, 0, f, ya);
-        load_e(1, 0, ya);
+        load_e(1, 0, ya, i);
         __builtin_amdgcn_sched_barrier(0);
         eadj(0, 1, f, yb);
       }
       STAMP(1);
       f = fuse(1, xb);
       __builtin_amdgcn_sched_barrier(0);
-      load_a(3, xb);
+      load_a(3, xb, t);
       if (trans) {
-        load_e(1, 1, yb);
+        load_e(1, 1, yb, i);
         __builtin_amdgcn_sched_barrier(0);
         eadj(1, 0, f, ya);
-        load_e(2, 0, ya);
+        load_e(2, 0, ya, i);
         __builtin_amdgcn_sched_barrier(0);
         eadj(1, 1, f, yb);
       }
@@ -466,10 +488,10 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       f = fuse(2, xa);
       __builtin_amdgcn_sched_barrier(0);
       if (trans) {
-        load_e(2, 1, yb);
+        load_e(2, 1, yb, i);
         __builtin_amdgcn_sched_barrier(0);
         eadj(2, 0, f, ya);
-        load_e(3, 0, ya);
+        load_e(3, 0, ya, i);
         __builtin_amdgcn_sched_barrier(0);
         eadj(2, 1, f, yb);
       }
@@ -477,7 +499,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       f = fuse(3, xb);
       __builtin_amdgcn_sched_barrier(0);
       if (trans) {
-        load_e(3, 1, yb);
+        load_e(3, 1, yb, i);
         __builtin_amdgcn_sched_barrier(0);
         eadj(3, 0, f, ya);
         __builtin_amdgcn_sched_barrier(0);
@@ -486,9 +508,6 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     }
     STAMP(4);
     if (i == 0) break;
-    // the relu masks of the two hidden layers and the step's noise come back from the park meanwhile
-    const u32x4 mkg = park_ld(eop_i + EP_MASK * 64);
-    const u32x4 mkn = park_ld(eop_i + (EP_MASK + 1) * 64);
     u32x4 ring[PF];
     {
       const gw_t w = W(T_WS);
@@ -501,8 +520,10 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     // D1: d/d nl = direct + W_std^T d/d std-pre (v1); gate-hidden adjoint (v0)
     f32x16 v0[RT];
     gemm4(v1, smem + img + arow, ts, W(T_WS), W(T_W2G), ring);
+    STAMP(11);
     zero_acc(v0);
     gemm4(v0, smem + 2 * img + arow, ts, W(T_W2G), W(T_W2N), ring);
+    STAMP(12);
     {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
@@ -546,12 +567,19 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     __syncthreads();
     STAMP(9);
     regeo();
-    // D3: d/dz of the previous particles; their noise comes back from the forward's park meanwhile
+    // D3: d/dz of the previous particles; their noise comes back from the forward's park meanwhile -- and, first, the
+    // NEXT step's relu masks (see masks_ahead)
+    if (i > 1) load_masks(i - 1);
+    masks_ahead = true;
+    __builtin_amdgcn_sched_barrier(0);
     u32x4 ep[RT * 4];
 #pragma unroll
     for (int u = 0; u < RT * 4; ++u) ep[u] = park_ld(noise + (((size_t)t_prev * NWAVE) * 16 + u) * 64 + lane);
+    STAMP(13);
     gemm4(v0, smem + img + arow, ts, W(T_W1N), W(T_WL), ring);
+    STAMP(14);
     gemm4<false>(v0, smem + arow, ts, W(T_WL), W(T_WL), ring);
+    STAMP(15);
     // sums over the particles of d/dz, d/dz * eps and eps
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {

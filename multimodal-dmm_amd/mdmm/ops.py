@@ -464,9 +464,12 @@ class _SweepFn(torch.autograd.Function):
         wide = wide_shape(cfg)
         packed = packed_gtf(gtf_params, cfg.D, cfg.H)
         prec = PRECISIONS[cfg.precision]
-        if wide and not wide_shape(cfg, bwd=True) and any(ctx.needs_input_grad):
+        # will this sweep be differentiated?  (needs_input_grad alone says yes under torch.no_grad() too: the evaluation
+        # forward with 200 filter particles, trainer.py:358-361, would take the training route below)
+        need_bwd = getattr(cfg, 'grad_mode', True) and any(ctx.needs_input_grad)
+        if wide and not wide_shape(cfg, bwd=True) and need_bwd:
             _warn_generic_backward(cfg)
-        if wide and prec == native.PREC_BF16 and not wide_shape(cfg, bwd=True) and any(ctx.needs_input_grad):
+        if wide and prec == native.PREC_BF16 and not wide_shape(cfg, bwd=True) and need_bwd:
             # more particles than the wide backward takes (K > 64): the backward runs on the generic fp32
             # kernels, which recompute the forward transition in fp32 -- so the forward must be the fp32
             # one too, or the gradients would belong to a slightly different forward
@@ -497,7 +500,7 @@ class _SweepFn(torch.autograd.Function):
             s.gtf_frag, s.precision = _ptr(frag.buf), frag.precision
             if not native.lib().mdmm_sweep_wide(C.byref(s)):
                 raise native.MdmmError('wide sweep refused a shape wide_shape() accepted')
-            if any(ctx.needs_input_grad) and os.environ.get('MDMM_FWD_PARK') != '0':
+            if need_bwd and os.environ.get('MDMM_FWD_PARK') != '0':
                 # K particles, bf16 operands: the forward keeps its noise and the transition's activations for the
                 # backward sweep (mdmm_sweep_t.fwd_park), which then neither draws nor runs the transition again
                 # (MDMM_FWD_PARK=0: no park, the two-round backward that recomputes -- the cross-check of
@@ -631,6 +634,7 @@ def bfvi_sweep(cfg, gtf_params, z0_mean, z0_log_std, experts, eps=None, kld=None
             raise native.MdmmError('this sweep shape has no fused KL term: ask sweep_kld_fused(cfg) first')
         k_mask, k_weight, k_into = kld
         cfg.kld = (None if k_mask is None else _f32c(k_mask).reshape(-1), float(k_weight), k_into)
+    cfg.grad_mode = torch.is_grad_enabled()      # (inside Function.forward grad mode is always off)
     out = _SweepFn.apply(cfg, _f32c(eps), masks, bits, per_pass, z0_mean, z0_log_std, *tensors)
     if kld is not None:
         kld[2].handles.append(out[5])

@@ -53,8 +53,10 @@ else:
         # sweep_wide_bwd4.hip (the forward kept its park)
         names = {0: 'step start', 1: 'pair 0: fuse adjoint, barrier, E', 2: 'pair 1: fuse adjoint, E', 3: 'pair 2', 4: 'pair 3',
                  5: 'mask loads, barrier', 6: 'D1 2 gemms + masks', 7: 'barrier, GN / GHG stores+spills, barrier',
-                 8: 'D2 2 gemms + mask', 9: 'barrier, GHN store+spill, barrier', 10: 'D3 2 gemms + sums'}
-        order = list(range(11))
+                 8: 'D2 2 gemms + mask', 9: 'barrier, GHN store+spill, barrier', 10: 'D3 sums over the particles',
+                 11: '  D1 gemm 1 (Ws^T G3)', 12: '  D1 gemm 2 (W2g^T GG)', 13: '  D3 noise loads issued', 14: '  D3 gemm 1 (W1n^T GHN)',
+                 15: '  D3 gemm 2 (Wl^T Glin)'}
+        order = [0, 1, 2, 3, 4, 5, 11, 12, 6, 7, 8, 9, 13, 14, 15, 10]
 for w in (0, 7):
     print('wave %d (cycles since step start; delta)' % w)
     prev = int(s[w, 0])
