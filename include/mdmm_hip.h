@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 27
+#define MDMM_ABI_VERSION 28
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -351,6 +351,18 @@ int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logits_bf16, in
 /* NaN -> 0 and the per-row "seen" flag of MultiDMM.encode (dmm.py:164-166) in one pass:
  * out[r][i] = isnan(x[r][i]) ? 0 : x[r][i];  seen[r] = no NaN in row r  (float 0 / 1).  */
 int mdmm_nan_to_zero(const float* x, int64_t rows, int inner, float* out, float* seen, void* stream);
+
+/* Input gradients of the experts a sweep shares between passes (dgts.py:119-129: the multimodal pass and a modality's own
+ * unimodal pass read the same encoder output): mdmm_bfvi_sweep_bwd leaves one (T,B,D) slab per pass in a (P,T,B,D) buffer
+ * (mdmm_expert_t.g_mean / g_std); dst = sum over the passes of `bits` of src's slabs, for up to MDMM_FOLD_SLABS_MAX
+ * tensors in one launch (elems = T*B*D, a multiple of 4; 16-byte aligned pointers).  */
+#define MDMM_FOLD_SLABS_MAX 8
+typedef struct mdmm_fold_slabs {
+  int32_t n, P;
+  int64_t elems;
+  struct { const float* src; float* dst; uint32_t bits; uint32_t reserved; } item[MDMM_FOLD_SLABS_MAX];
+} mdmm_fold_slabs_t;
+int mdmm_fold_slabs(const mdmm_fold_slabs_t* f, void* stream);
 /* losses.py:44-66 nll_categorical: reference behaviour = minus the summed PROBABILITY of
  * the observed class (F.nll_loss on probs).  probs (rows, n_cat), x (rows) labels as
  * float (NaN = missing).  */
@@ -878,6 +890,15 @@ int mdmm_ssim(const float* x, const float* y, int64_t N, int C, int H, int W, co
  * loss.  forward: probs (rows, n_cat) are kept for the backward, *out += weight * sum.  backward: g_hid (rows, H) and
  * mdmm_cat_head_slabs(rows) slab rows of [n_cat][H] dW | [n_cat] db partial sums (the caller adds the rows up).
  * --------------------------------------------------------------------------------- */
+/* nn.Embedding(n_cat, H) -> nn.ReLU of the Categorical modality's stock encoder (dmm.py:78-85, dks.py:87-95) as one kernel
+ * each way: out[r] = max(W[label_r], 0) for fp32 labels (NaN or out-of-range label: a zero row); the backward writes
+ * mdmm_embed_relu_slabs(rows) slabs of [n_cat][H] partial sums of dW[c] = sum over rows with label c of g[r] * [W[c] > 0]
+ * (one per workgroup, no atomics; the caller adds the slabs up, e.g. with mdmm_colsum).  */
+int mdmm_embed_relu_supported(int H, int n_cat);
+int64_t mdmm_embed_relu_slabs(int64_t rows);
+int mdmm_embed_relu_fwd(const float* w, const float* label, int64_t rows, int n_cat, int H, float* out, void* stream);
+int mdmm_embed_relu_bwd(const float* w, const float* label, const float* g, int64_t rows, int n_cat, int H, float* slabs,
+                        void* stream);
 int mdmm_cat_head_supported(int H, int n_cat);
 int mdmm_cat_head_slabs(int64_t rows);
 int mdmm_cat_head_nll_fwd(const float* hid, const float* w, const float* bias, const float* label,

@@ -147,6 +147,47 @@ inline PassW pass_w(const float* host, int passes, int64_t rows) {
   return p;
 }
 inline size_t lds_bytes(int H, int n_cat) { return ((size_t)RB * (H + 1) + (size_t)n_cat * H + (size_t)RB * MAXC) * sizeof(float); }
+
+// ---------------------------------------------------------------------------------------
+// The Categorical ENCODER's first two modules, nn.Embedding(n_cat, h) -> nn.ReLU (dmm.py:78-85, dks.py:87-95), as one
+// kernel each way.  As stock modules the backward alone was fifteen launches (ATen's sort-based embedding_dense_backward)
+// for ten classes.  out[r][j] = max(W[label_r][j], 0); dW[c][j] = sum over rows r with label_r = c and W[c][j] > 0 of
+// g[r][j]: thread j owns column j of a workgroup's [n_cat][h] table in LDS (no atomics), one slab per workgroup (the
+// caller adds them up: mdmm_colsum over mdmm_embed_relu_slabs(rows) rows of n_cat * h) -- deterministic.
+// ---------------------------------------------------------------------------------------
+constexpr int EMB_ROWS = 256;            // rows per workgroup
+
+__global__ __launch_bounds__(NT) void embed_relu_fwd_kernel(const float* __restrict__ w, const float* __restrict__ label,
+                                                            int64_t rows, int n_cat, int H, float* __restrict__ out) {
+  const int64_t total = rows * H;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+    const int64_t r = i / H;
+    const int j = (int)(i - r * H);
+    const float lf = label[r];
+    const int c = (int)lf;
+    out[i] = (lf == lf && c >= 0 && c < n_cat) ? fmaxf(w[(size_t)c * H + j], 0.f) : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(NT) void embed_relu_bwd_kernel(const float* __restrict__ w, const float* __restrict__ label,
+                                                            const float* __restrict__ g, int64_t rows, int n_cat, int H,
+                                                            float* __restrict__ slab) {
+  extern __shared__ float lds[];          // [n_cat][H]
+  for (int i = threadIdx.x; i < n_cat * H; i += NT) lds[i] = 0.f;
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * EMB_ROWS, r1 = r0 + EMB_ROWS < rows ? r0 + EMB_ROWS : rows;
+  for (int j = threadIdx.x; j < H; j += NT) {
+    for (int64_t r = r0; r < r1; ++r) {
+      const float lf = label[r];
+      const int c = (int)lf;
+      if (!(lf == lf) || c < 0 || c >= n_cat) continue;
+      if (w[(size_t)c * H + j] > 0.f) lds[c * H + j] += g[r * H + j];
+    }
+  }
+  __syncthreads();
+  float* mine = slab + (size_t)blockIdx.x * n_cat * H;
+  for (int i = threadIdx.x; i < n_cat * H; i += NT) mine[i] = lds[i];
+}
 }  // namespace
 
 #include "sweep_internal.h"
@@ -187,5 +228,29 @@ extern "C" int mdmm_cat_head_nll_bwd(const float* hid, const float* w, const flo
   hipLaunchKernelGGL(cat_head_kernel<true>, dim3(grid_of(rows)), dim3(NT), lds, (hipStream_t)stream, hid, w, nullptr, label,
                      seq_mask, rows, label_rows, H, n_cat, scale, scale_dev, pass_w(pass_weight, passes, rows),
                      const_cast<float*>(probs), nullptr, g_hid, slab);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mdmm_embed_relu_supported(int H, int n_cat) { return H >= 1 && n_cat >= 1 && (int64_t)n_cat * H * 4 <= 64 * 1024; }
+
+extern "C" int64_t mdmm_embed_relu_slabs(int64_t rows) { return (rows + EMB_ROWS - 1) / EMB_ROWS; }
+
+extern "C" int mdmm_embed_relu_fwd(const float* w, const float* label, int64_t rows, int n_cat, int H, float* out, void* stream) {
+  if (!w || !label || !out || rows < 0) return MDMM_E_ARG;
+  if (!mdmm_embed_relu_supported(H, n_cat)) return MDMM_E_LIMIT;
+  if (rows == 0) return 0;
+  const int64_t total = rows * H;
+  const unsigned grid = (unsigned)((total + NT - 1) / NT < 4096 ? (total + NT - 1) / NT : 4096);
+  hipLaunchKernelGGL(embed_relu_fwd_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, w, label, rows, n_cat, H, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int mdmm_embed_relu_bwd(const float* w, const float* label, const float* g, int64_t rows, int n_cat, int H,
+                                   float* slabs, void* stream) {
+  if (!w || !label || !g || !slabs || rows < 1) return MDMM_E_ARG;
+  if (!mdmm_embed_relu_supported(H, n_cat)) return MDMM_E_LIMIT;
+  const unsigned wgs = (unsigned)mdmm_embed_relu_slabs(rows);
+  hipLaunchKernelGGL(embed_relu_bwd_kernel, dim3(wgs), dim3(NT), (size_t)n_cat * H * 4, (hipStream_t)stream, w, label, g, rows,
+                     n_cat, H, slabs);
   return (int)hipGetLastError();
 }

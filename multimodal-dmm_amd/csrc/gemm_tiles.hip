@@ -331,7 +331,7 @@ __global__ void gemm_fold_kernel(const mdmm_gemm_t g) {
 constexpr int CS_COLS = 64, CS_SPLIT_MAX = 64;
 
 __global__ __launch_bounds__(256) void colsum_kernel(const void* a, int bf, int64_t rows, int cols, int64_t lda,
-                                                     float* part) {
+                                                     float* part, float* out) {
   __shared__ float red[16][CS_COLS + 4];
   const int tid = threadIdx.x, rl = tid >> 4, cg = tid & 15;
   const int j = blockIdx.x * CS_COLS + 4 * cg;
@@ -350,13 +350,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* a, int bf, int6
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += red[r][tid];
-    part[(size_t)blockIdx.y * cols + blockIdx.x * CS_COLS + tid] = s;
+    if (gridDim.y > 1) part[(size_t)blockIdx.y * cols + blockIdx.x * CS_COLS + tid] = s;
+    else out[blockIdx.x * CS_COLS + tid] = s;           // (one slab: it is the result, no fold launch)
   }
 }
 
 // the same for any column count / leading dimension / alignment (one column per thread, four row lanes)
 __global__ __launch_bounds__(256) void colsum_any_kernel(const void* a, int bf, int64_t rows, int cols, int64_t lda,
-                                                         float* part) {
+                                                         float* part, float* out) {
   __shared__ float red[4][CS_COLS];
   const int tid = threadIdx.x, rl = tid >> 6, c = tid & 63;
   const int j = blockIdx.x * CS_COLS + c;
@@ -374,7 +375,11 @@ __global__ __launch_bounds__(256) void colsum_any_kernel(const void* a, int bf, 
   }
   red[rl][c] = s;
   __syncthreads();
-  if (rl == 0 && j < cols) part[(size_t)blockIdx.y * cols + j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  if (rl == 0 && j < cols) {
+    const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (gridDim.y > 1) part[(size_t)blockIdx.y * cols + j] = v;
+    else out[j] = v;
+  }
 }
 
 __global__ void colsum_fold_kernel(const float* part, int splits, int cols, float* out) {
@@ -396,6 +401,9 @@ extern "C" int mdmm_colsum_splits(int64_t rows, int cols) {
   return s < 1 ? 1 : (int)s;
 }
 
+// (A one-launch form -- the last workgroup of a column tile to arrive folds its slabs -- was built and measured 7x
+//  SLOWER, 0.32 vs 0.045 ms at 20,480 x 4096: the device-scope fence in front of the arrival counter writes back and
+//  invalidates the XCD's L2 in every one of the 2,048 workgroups.  Two launches it stays.)
 extern "C" int mdmm_colsum(const void* a, int a_bf16, int64_t rows, int cols, int64_t lda, float* ws, float* out,
                            void* stream) {
   if (!a || !ws || !out || rows < 1 || cols < 1 || lda < cols) return MDMM_E_ARG;
@@ -404,11 +412,11 @@ extern "C" int mdmm_colsum(const void* a, int a_bf16, int64_t rows, int cols, in
   const dim3 grid((cols + CS_COLS - 1) / CS_COLS, splits);
   // 16-byte row pieces where the shape allows them, one element per thread otherwise
   if ((cols & 3) || (lda & 3) || (((uintptr_t)a) & (a_bf16 ? 7 : 15)))
-    hipLaunchKernelGGL(colsum_any_kernel, grid, dim3(256), 0, st, a, a_bf16, rows, cols, lda, ws);
+    hipLaunchKernelGGL(colsum_any_kernel, grid, dim3(256), 0, st, a, a_bf16, rows, cols, lda, ws, out);
   else
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, a, a_bf16, rows, cols, lda, ws);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, a, a_bf16, rows, cols, lda, ws, out);
   int rc = (int)hipGetLastError();
-  if (rc) return rc;
+  if (rc || splits == 1) return rc;
   hipLaunchKernelGGL(colsum_fold_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, (const float*)ws, splits, cols, out);
   return (int)hipGetLastError();
 }

@@ -777,6 +777,37 @@ extern "C" int mdmm_gtf_pack(const mdmm_gtf_raw_t* raw, int D, int H, float* out
   CHECK_LAUNCH();
 }
 
+// ---------------------------------------------------------------------------------------
+// fold of per-pass gradient slabs (the sweeps' backward writes one (T,B,D) slab per pass an expert took part in; a
+// shared expert's input gradient is their sum, dgts.py:119-129): every expert of a sweep in ONE launch
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_slabs_kernel(const mdmm_fold_slabs_t f) {
+  const int64_t n4 = f.elems >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    for (int k = 0; k < f.n; ++k) {
+      const float4* src = reinterpret_cast<const float4*>(f.item[k].src);
+      float4 acc = {0.f, 0.f, 0.f, 0.f};
+      bool first = true;
+      for (int p = 0; p < f.P; ++p) {
+        if (!((f.item[k].bits >> p) & 1u)) continue;
+        const float4 v = src[(size_t)p * n4 + i];
+        if (first) { acc = v; first = false; }                    // (in pass order: the sums of the torch adds it replaces)
+        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+      }
+      reinterpret_cast<float4*>(f.item[k].dst)[i] = acc;
+    }
+  }
+}
+
+extern "C" int mdmm_fold_slabs(const mdmm_fold_slabs_t* f, void* stream) {
+  if (!f || f->n < 1 || f->n > MDMM_FOLD_SLABS_MAX || f->P < 1 || f->P > 32 || f->elems < 0 || (f->elems & 3)) return MDMM_E_ARG;
+  for (int k = 0; k < f->n; ++k)
+    if (!f->item[k].src || !f->item[k].dst || ((((uintptr_t)f->item[k].src) | ((uintptr_t)f->item[k].dst)) & 15)) return MDMM_E_ARG;
+  if (f->elems == 0) return 0;
+  hipLaunchKernelGGL(fold_slabs_kernel, dim3(grid_for(f->elems / 4)), dim3(256), 0, STREAM, *f);
+  CHECK_LAUNCH();
+}
+
 __global__ void clock_kernel(unsigned long long* out) { *out = wall_clock64(); }
 
 extern "C" int mdmm_debug_clock(unsigned long long* out, void* stream) {

@@ -41,6 +41,18 @@ __device__ __forceinline__ uint4 relu_bits(const f32x16 (&v)[4]) {
   return o;
 }
 
+// registers 0 .. LR-1 of one accumulator tile as fp32, LR / 4 slots (`it` = this lane's pointer of the first slot)
+template <int LR>
+__device__ __forceinline__ void k1_park_f32(gs_ptr it, const f32x16& v) {
+#pragma unroll
+  for (int q = 0; q < LR / 4; ++q) {
+    uint4 o;
+    o.x = __float_as_uint(v[4 * q]); o.y = __float_as_uint(v[4 * q + 1]);
+    o.z = __float_as_uint(v[4 * q + 2]); o.w = __float_as_uint(v[4 * q + 3]);
+    park_st(it + q * 64, o);
+  }
+}
+
 // NI images: two (Z / NL and one hidden layer at a time), or four for the three-phase K = 1 forward (Z, HG, HN, NL)
 template <bool F32, int RT, int NI = 2>
 struct FwdLds {
@@ -119,6 +131,19 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
     }
   }
 
+  // K = 1, three-phase form: the park of the K = 1 backward (wide_sweep.h, FwdParkK1)
+  constexpr bool PK1 = K1 && P3 && !F32;
+  [[maybe_unused]] gs_ptr k1_xop0 = nullptr, k1_eop0 = nullptr;
+  if constexpr (PK1) {
+    if (a.fwd_park) {
+      FwdParkK1 pk;
+      fwd_park_k1_carve(&a, g.NP, &pk);
+      const int ws_ = __builtin_amdgcn_readfirstlane(wave);
+      k1_xop0 = (gs_ptr)pk.xop + ((size_t)blockIdx.x * (T - 1) * X_ARR * NWAVE + ws_) * 64;
+      k1_eop0 = (gs_ptr)pk.eop + ((size_t)blockIdx.x * (T - 1) * NWAVE + ws_) * (k1_slots(LR) * 64);
+    }
+  }
+
   [[maybe_unused]] float kl_acc = 0.f;      // fused KL term (K = 1): this lane's sum over its (row, step) elements
   const lds_tab_t tab0 = tab;
   const lds_row_t rowbase0 = rowbase;
@@ -143,7 +168,13 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
     KArgs& a = *kap;
     const auto* exs = a.experts;
     const int t = a.reverse ? T - 1 - i : i;
-    [[maybe_unused]] const bool parked = PK && a.fwd_park != nullptr;      // (wave-uniform: a launch argument)
+    [[maybe_unused]] const bool parked = (PK || PK1) && a.fwd_park != nullptr;      // (wave-uniform: a launch argument)
+    [[maybe_unused]] gs_ptr k1_x = k1_xop0, k1_e = k1_eop0;
+    if constexpr (PK1) {
+      asm volatile("" : "+s"(k1_x), "+s"(k1_e));
+      k1_x += (ptrdiff_t)(i - 1) * (X_ARR * NWAVE * 64);
+      k1_e += (ptrdiff_t)(i - 1) * (NWAVE * k1_slots(LR) * 64);
+    }
     f32x16 m_[RT], var_[RT];       // per particle: p(z) * q'(z | z_prev)  (dmm.py:239-252)
     // P3: this step's pairs and their expert values, requested before the contractions
     constexpr bool PREF = P3 && LR <= 4;        // (eight pairs' values in flight are 96 registers: they spill)
@@ -172,11 +203,29 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
         store_image<F32, RT>(imgH, acc, wave, lane);
+        [[maybe_unused]] unsigned k1_mg = 0;
+        if constexpr (PK1) {
+          if (parked) {
+#pragma unroll
+            for (int r = 0; r < LR; ++r) k1_mg |= (acc[0][r] > 0.f) ? (1u << r) : 0u;
+            park_st(k1_x + X_HG * NWAVE * 64 + lane, acc_chunk<false>(acc[0], 0));
+          }
+        }
         fill_acc(acc, b1n);
         gemm_tile<F32, RT, Pf<RT>::N>(acc, imgZ + arow, W(L_W1N), W(L_WL), ring);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = fmaxf(acc[0][r], 0.f);
         store_image<F32, RT>(imgN, acc, wave, lane);
+        if constexpr (PK1) {
+          if (parked) {
+            unsigned mn = 0;
+#pragma unroll
+            for (int r = 0; r < LR; ++r) mn |= (acc[0][r] > 0.f) ? (1u << r) : 0u;
+            uint4 mk; mk.x = k1_mg; mk.y = mn; mk.z = 0u; mk.w = 0u;
+            park_st(k1_e + (K1_ARRS * (LR / 4)) * 64 + lane, mk);
+            park_st(k1_x + X_HN * NWAVE * 64 + lane, acc_chunk<false>(acc[0], 0));
+          }
+        }
         fill_acc(lin, bl);
         gemm_tile<F32, RT, Pf<RT>::N>(lin, imgZ + arow, W(L_WL), W(L_W2G), ring);
         STAMP(2);
@@ -188,12 +237,25 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
         fill_acc(acc, b2n);
         gemm_tile<F32, RT, Pf<RT>::N>(acc, imgN + arow, W(L_W2N), W(L_WS), ring);
         store_image<F32, RT>(imgL, acc, wave, lane);
+        if constexpr (PK1) {
+          if (parked) {
+            park_st(k1_x + X_NL * NWAVE * 64 + lane, acc_chunk<false>(acc[0], 0));
+            k1_park_f32<LR>(k1_e + (K1_NL * (LR / 4)) * 64 + lane, acc[0]);
+          }
+        }
         // muq = (1 - g) (e^x nl + bl + Wl z) = (1 - g) lin + g nl
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          if (r >= LR) { m_[0][r] = 0.f; continue; }
+          if (r >= LR) { m_[0][r] = 0.f; x[0][r] = 0.f; continue; }
           const float ex = fast::exp(__builtin_amdgcn_fmed3f(x[0][r], -30.f, 30.f));
-          m_[0][r] = fast::rcp(1.0f + ex) * fmaf(acc[0][r], ex, lin[0][r]);
+          x[0][r] = fast::rcp(1.0f + ex);                 // 1 - gate
+          m_[0][r] = x[0][r] * fmaf(acc[0][r], ex, lin[0][r]);
+        }
+        if constexpr (PK1) {
+          if (parked) {
+            k1_park_f32<LR>(k1_e + (K1_OMG * (LR / 4)) * 64 + lane, x[0]);
+            k1_park_f32<LR>(k1_e + (K1_MUQ * (LR / 4)) * 64 + lane, m_[0]);
+          }
         }
         STAMP(6);
         __syncthreads();
@@ -201,6 +263,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
         // level 3: std pre-activation, then p(z) * q'(z | z_prev) (see the six-phase form below)
         fill_acc(acc, bs);
         gemm_tile<F32, RT, Pf<RT>::N>(acc, imgL + arow, W(L_WS), W(L_W1G), ring);
+        if constexpr (PK1) { if (parked) k1_park_f32<LR>(k1_e + (K1_PRE * (LR / 4)) * 64 + lane, acc[0]); }
         STAMP(16);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -523,7 +586,10 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       if constexpr (PK) {         // (item i: rows of the next transition)
         if (parked) store_image_park(imgZ, z, wave, lane, pk_x + 2 * X_ARR * XOP_ARR_U4 + lane, X_Z);
         else store_image<F32, RT>(imgZ, z, wave, lane);
-      } else store_image<F32, RT>(imgZ, z, wave, lane);
+      } else {
+        store_image<F32, RT>(imgZ, z, wave, lane);
+        if constexpr (PK1) { if (parked) park_st(k1_x + (X_ARR + X_Z) * NWAVE * 64 + lane, acc_chunk<false>(z[0], 0)); }
+      }
       __syncthreads();
       STAMP(15);
     }
@@ -591,10 +657,14 @@ __device__ __forceinline__ float tile_sum(const f32x16 (&v)[RT]) {
 // register r holds rows 8 (r / 4) + r % 4 + 4 h, so NP <= 8 -> registers 0..3, NP <= 16 -> 0..7.  The per-pair
 // state of a lane (adjoints, noise, fusion results: seven floats a slot) and the elementwise phases cover
 // those registers only: at cfg3 (NP = 8) a quarter of the slots, no register scratch (it was 288 B a lane).
-template <bool F32, int RT, bool K1, int LR = 16>
+// PKB (K = 1, bf16 operands, LR <= 8): the forward sweep of the same call kept what the elementwise adjoint reads
+// (mdmm_sweep_t.fwd_park, wide_sweep.h FwdParkK1) -- R1 .. R4 (six of the twelve contractions, three barriers) are not run,
+// the four X-side weight-gradient operands are not spilled again (wide_wgrad_kernel reads the forward's chunks).
+template <bool F32, int RT, bool K1, int LR = 16, bool PKB = false>
 __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, const WideGeo g,
                                                         const WideWs ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(!PKB || (K1 && !F32 && RT == 1 && LR <= 8), "the parked backward is a K = 1 bf16 shape");
   using L = BwdLds<F32, RT>;
   using O = Op<F32>;
   constexpr int CH = RT * O::CH_TILE;            // chunks of one spilled array slice
@@ -635,7 +705,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
   float g_mu0 = 0.f, g_sg0 = 0.f;
 
   uint4 ring[Pf<RT>::N];
-  ring_fill(ring, W(L_W1G));
+  ring_fill(ring, W(PKB ? T_WS : L_W1G));
   __syncthreads();
 
   // sum over the particles of the noise of the LAST processed step (enters through `samples`)
@@ -667,11 +737,18 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
   }
 
   const int chs = (!F32 && K1 && g.NP <= 16) ? 1 : CH;
-  const gs_ptr my_spill = (gs_ptr)ws.spill + ((size_t)blockIdx.x * ws.n_step * N_SPILL * NWAVE + wave) * chs * 64 + lane;
+  constexpr int NSP = PKB ? (int)G_ARR : (int)N_SPILL, SP0 = PKB ? (int)S_GHG : 0;      // (PKB: the G side only)
+  const gs_ptr my_spill = (gs_ptr)ws.spill + ((size_t)blockIdx.x * ws.n_step * NSP * NWAVE + wave) * chs * 64 + lane;
   gs_ptr spill_it = my_spill;
   auto spill_at = [&](int step, int arr) {
-    return spill_it + ((size_t)step * N_SPILL + arr) * NWAVE * chs * 64;
+    return spill_it + ((size_t)step * NSP + (arr - SP0)) * NWAVE * chs * 64;
   };
+  [[maybe_unused]] gw_ptr k1_eop0 = nullptr;
+  if constexpr (PKB) {
+    FwdParkK1 pk;
+    fwd_park_k1_carve(&a, g.NP, &pk);
+    k1_eop0 = (gw_ptr)pk.eop + ((size_t)blockIdx.x * (T - 1) * NWAVE + wave) * (k1_slots(LR) * 64) + lane;
+  }
 
   const lds_tab_t tab0 = tab;
   const lds_row_t rowbase0 = rowbase;
@@ -749,6 +826,34 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     const uint64_t t_term = (uint64_t)t_prev * K * B * WD;
     unsigned live_bits[RT];
     f32x16 acc[RT], nl[RT], omg[RT], muq[RT];
+    [[maybe_unused]] unsigned mask_g[RT], mask_n[RT];
+    if constexpr (PKB) {
+      // what R1 .. R4 would compute again comes back from the forward's park: std pre-activation -> acc, the mean before
+      // the product with the global prior -> muq, nl, 1 - gate -> omg (registers 0 .. LR-1; the rest are dead rows)
+      gw_ptr e_it = k1_eop0;
+      asm volatile("" : "+v"(e_it));
+      e_it += (size_t)(i - 1) * (NWAVE * k1_slots(LR) * 64);
+      zero_acc(acc); zero_acc(nl); zero_acc(omg); zero_acc(muq);
+#pragma unroll
+      for (int q = 0; q < LR / 4; ++q) {
+        const uint4 vp = ldw(e_it + (K1_PRE * (LR / 4) + q) * 64), vm = ldw(e_it + (K1_MUQ * (LR / 4) + q) * 64);
+        const uint4 vn = ldw(e_it + (K1_NL * (LR / 4) + q) * 64), vo = ldw(e_it + (K1_OMG * (LR / 4) + q) * 64);
+        acc[0][4 * q] = __uint_as_float(vp.x); acc[0][4 * q + 1] = __uint_as_float(vp.y);
+        acc[0][4 * q + 2] = __uint_as_float(vp.z); acc[0][4 * q + 3] = __uint_as_float(vp.w);
+        muq[0][4 * q] = __uint_as_float(vm.x); muq[0][4 * q + 1] = __uint_as_float(vm.y);
+        muq[0][4 * q + 2] = __uint_as_float(vm.z); muq[0][4 * q + 3] = __uint_as_float(vm.w);
+        nl[0][4 * q] = __uint_as_float(vn.x); nl[0][4 * q + 1] = __uint_as_float(vn.y);
+        nl[0][4 * q + 2] = __uint_as_float(vn.z); nl[0][4 * q + 3] = __uint_as_float(vn.w);
+        omg[0][4 * q] = __uint_as_float(vo.x); omg[0][4 * q + 1] = __uint_as_float(vo.y);
+        omg[0][4 * q + 2] = __uint_as_float(vo.z); omg[0][4 * q + 3] = __uint_as_float(vo.w);
+      }
+      const uint4 mk = ldw(e_it + (K1_ARRS * (LR / 4)) * 64);
+      mask_g[0] = mk.x; mask_n[0] = mk.y;
+      unsigned lb = 0;
+#pragma unroll
+      for (int reg = 0; reg < LR; ++reg) lb |= (rowbase[acc_row(0, reg) + 4 * h] != ~0ull) ? (1u << reg) : 0u;
+      live_bits[0] = lb;
+    } else {
     // R1: particles
     {
 #pragma unroll
@@ -807,7 +912,6 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     __syncthreads();
     STAMP(3);
     // R2: hidden layers
-    unsigned mask_g[RT], mask_n[RT];
     fill_acc(acc, b1g);
     gemm_tile<F32, RT, Pf<RT>::N>(acc, img0 + arow, W(L_W1G), W(L_W1N), ring);
 #pragma unroll
@@ -866,6 +970,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     // R4: std pre-activation
     fill_acc(acc, bs);
     gemm_tile<F32, RT, Pf<RT>::N>(acc, img3 + arow, W(L_WS), W(T_WS), ring);
+    }
     STAMP(8);
     // E: elementwise adjoint; acc: pre -> G3, omg -> Glin, nl -> direct part of GN, muq -> GG.
     // Product with the global prior as in the forward kernel (v = sq^2 + eps, u = 1/(t0 v + 1)):
@@ -966,7 +1071,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
     zero_acc(acc);
     gemm_tile<F32, RT, Pf<RT>::N>(acc, img1 + arow, W(T_W1G), W(T_W1N), ring);
     gemm_tile<F32, RT, Pf<RT>::N>(acc, img2 + arow, W(T_W1N), W(T_WL), ring);
-    gemm_tile<F32, RT, Pf<RT>::N>(acc, img0 + arow, W(T_WL), W(L_W1G), ring);
+    gemm_tile<F32, RT, Pf<RT>::N>(acc, img0 + arow, W(T_WL), W(PKB ? T_WS : L_W1G), ring);
     // sums over the particles of d/dz and d/dz * eps; the noise is drawn again here instead of
     // being kept alive across the step (32 registers that spilled)
     {
@@ -986,7 +1091,12 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
             const int r = 4 * q + j;
             const bool live = (live_bits[rt] >> r) & 1u;
             const float gz = live ? acc[rt][r] : 0.f;
-            if constexpr (K1) { if (r < LR) { adj_a[rt * LR + r] = gz; adj_b[rt * LR + r] = gz * e[j]; } }
+            if constexpr (K1) {
+              if (r < LR) {
+                adj_a[rt * LR + r] = gz; adj_b[rt * LR + r] = gz * e[j];
+                if constexpr (PKB) se[rt * LR + r] = live ? e[j] : 0.f;        // (R1 set it where it drew the particles)
+              }
+            }
             else { sa += gz; sb = fmaf(gz, e[j], sb); }
           }
         }
@@ -1242,10 +1352,10 @@ int launch_fwd(const mdmm_sweep_t* a, const WideGeo& g, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <bool F32, int RT, bool K1, int LR = 16>
+template <bool F32, int RT, bool K1, int LR = 16, bool PKB = false>
 int launch_bwd(const mdmm_sweep_t* a, const WideGeo& g, const WideWs& ws, hipStream_t stream) {
   using L = BwdLds<F32, RT>;
-  auto kern = wide_bwd_kernel<F32, RT, K1, LR>;
+  auto kern = wide_bwd_kernel<F32, RT, K1, LR, PKB>;
   int rc = set_lds(kern, L::BYTES);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)ws.n_wg), dim3(NTHR), L::BYTES, stream, *a, g, ws);
@@ -1286,15 +1396,21 @@ int plan(const mdmm_sweep_t* a, bool bwd, WideGeo* g) {
 }
 
 // carve the backward workspace; returns the bytes needed
+// the K = 1 sweeps whose forward keeps a park for the backward (FwdParkK1): bf16 operands, the three-phase forward
+bool k1_park_shape(const mdmm_sweep_t* a, const WideGeo& g) {
+  return a->K == 1 && a->precision == MDMM_PREC_BF16 && g.NP <= 16 && a->T >= 1;
+}
+
 int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
   const bool f32 = a->precision == MDMM_PREC_F32;
   const int CH = spill_chunks(f32, RT, a->K == 1, g.NP);
+  const int n_arr = (a->fwd_park && k1_park_shape(a, g)) ? (int)G_ARR : (int)N_SPILL;     // (parked: the G side only)
   const int64_t n_wg = (g.n_pairs + g.NP - 1) / g.NP, n_step = a->T - 1;
   const int64_t items = n_wg * n_step;
   int split = 42;                                   // 6 * 42 = 252 workgroups: one round of the 256 CUs
   if (split > items) split = items > 0 ? (int)items : 1;
   auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
-  const int64_t b_spill = up(items * N_SPILL * NWAVE * CH * 64 * 16);
+  const int64_t b_spill = up(items * n_arr * NWAVE * CH * 64 * 16);
   const int64_t b_db = up((int64_t)split * 6 * WD * 4), b_dz = up(n_wg * 2 * WD * 4);
   const int64_t b_slab = up((int64_t)split * 6 * WD * WD * 4);
   if (ws) {
@@ -1319,6 +1435,9 @@ int mdmm_wide_sweep_fwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (((uintptr_t)a->gtf_frag) & 15) return MDMM_E_ALIGN;
   const bool f32 = a->precision == MDMM_PREC_F32;
   if (a->K == 1) {
+    if (a->fwd_park && (!k1_park_shape(a, g) || a->fwd_park_bytes < fwd_park_k1_carve(a, g.NP, nullptr) ||
+                        (((uintptr_t)a->fwd_park) & 15)))
+      return MDMM_E_ARG;                    // (a park only where the K = 1 backward will read it)
     if (f32) return launch_fwd<true, 1, true>(a, g, stream);
     if (g.NP <= 8) return launch_fwd<false, 1, true, 4, true>(a, g, stream);         // (three contraction phases: DESIGN 4.2e)
     if (g.NP <= 16) return launch_fwd<false, 1, true, 8, true>(a, g, stream);
@@ -1342,7 +1461,16 @@ int mdmm_wide_sweep_bwd(const mdmm_sweep_t* a, hipStream_t stream) {
   if (a->wide_ws_bytes < carve(a, g, RT, &ws)) return MDMM_E_ARG;
   const bool f32 = a->precision == MDMM_PREC_F32;
   int rc;
+  const bool parked = a->fwd_park && k1_park_shape(a, g);
+  if (parked) {
+    if (a->fwd_park_bytes < fwd_park_k1_carve(a, g.NP, nullptr) || (((uintptr_t)a->fwd_park) & 15)) return MDMM_E_ARG;
+    FwdParkK1 pk;
+    fwd_park_k1_carve(a, g.NP, &pk);
+    ws.xop = pk.xop;
+  }
   if (a->K == 1 && f32) rc = launch_bwd<true, 1, true>(a, g, ws, stream);
+  else if (a->K == 1 && parked) rc = g.NP <= 8 ? launch_bwd<false, 1, true, 4, true>(a, g, ws, stream)
+                                               : launch_bwd<false, 1, true, 8, true>(a, g, ws, stream);
   else if (a->K == 1) rc = g.NP <= 8 ? launch_bwd<false, 1, true, 4>(a, g, ws, stream)
                          : (g.NP <= 16 ? launch_bwd<false, 1, true, 8>(a, g, ws, stream)
                                        : launch_bwd<false, 1, true, 16>(a, g, ws, stream));
@@ -1388,7 +1516,11 @@ extern "C" int mdmm_sweep_wide(const mdmm_sweep_t* a) {
          (a->precision == MDMM_PREC_F32 || a->precision == MDMM_PREC_BF16);
 }
 
-extern "C" int64_t mdmm_sweep_fwd_park_bytes(const mdmm_sweep_t* a) { return mdmm_wide_fwd_park_bytes(a); }
+extern "C" int64_t mdmm_sweep_fwd_park_bytes(const mdmm_sweep_t* a) {
+  WideGeo g;
+  if (a && a->K == 1 && plan(a, true, &g) != 0 && k1_park_shape(a, g)) return fwd_park_k1_carve(a, g.NP, nullptr);
+  return mdmm_wide_fwd_park_bytes(a);
+}
 
 extern "C" int64_t mdmm_sweep_wide_ws_bytes(const mdmm_sweep_t* a) {
   if (mdmm_wide_bwd4_supported(a)) return mdmm_wide_bwd4_ws_bytes(a);

@@ -197,6 +197,28 @@ __device__ __forceinline__ void park_e(gs_ptr it, const f32x16 (&v)[4]) {
   }
 }
 
+// The same idea for the K = 1 sweeps (one (pass, sequence) pair per row, NP = 8 or 16 pairs per workgroup: the
+// three-phase forward, wide_fwd_kernel<false, 1, true, LR, true>): a workgroup-step is a few KB, so everything the
+// elementwise adjoint reads is kept as fp32 -- the backward that reads it is the backward that recomputed, to the bit:
+//   xop [workgroup][step T-1][X_ARR][wave][1][lane]      bf16 operand chunk 0 (rows 0 .. 15) of z, relu hidden layers, nl
+//   eop [workgroup][step T-1][wave][K1_SLOTS(LR)][lane]  fp32, LR / 4 slots each: std pre-activation, mean before the
+//                                                      product with the global prior, nl, 1 - gate; one slot of relu masks
+struct FwdParkK1 { uint4 *xop, *eop; };
+enum K1Arr { K1_PRE = 0, K1_MUQ, K1_NL, K1_OMG, K1_ARRS };
+__host__ __device__ constexpr int k1_slots(int LR) { return K1_ARRS * (LR / 4) + 1; }
+__host__ __device__ inline int64_t fwd_park_k1_carve(const mdmm_sweep_t* a, int NP, FwdParkK1* pk) {
+  const int LR = NP <= 8 ? 4 : 8;
+  const int64_t n_wg = ((int64_t)a->P * a->B + NP - 1) / NP, n_step = a->T - 1;
+  const int64_t b_xop = n_wg * n_step * X_ARR * NWAVE * 64 * 16;
+  const int64_t b_eop = n_wg * n_step * NWAVE * k1_slots(LR) * 64 * 16;
+  if (pk) {
+    char* p = reinterpret_cast<char*>(a->fwd_park);
+    pk->xop = reinterpret_cast<uint4*>(p); p += b_xop;
+    pk->eop = reinterpret_cast<uint4*>(p);
+  }
+  return b_xop + b_eop;
+}
+
 // gate g in (0, 1) as one bf16 that keeps BOTH g and 1 - g to bf16 relative accuracy: the smaller
 // of the two, negative when it is g itself
 __device__ __forceinline__ float gate_code(float gate, float omg) { return gate < omg ? -gate : omg; }

@@ -115,6 +115,11 @@ class MultiDMM(MultiDGTS):
                     seen.reshape(t_max, b_dim))
         x, seen = self._clean(x)
         if self.dists[m] == 'Categorical':
+            stack = ops.embed_relu_stack(enc) if (x.is_cuda and x.shape[2:].numel() == 1 and self.plugin_dtype is None
+                                                  and not torch.is_autocast_enabled()) else None
+            if stack is not None:       # Embedding + ReLU as one kernel each way, then the stack's tail on the rows
+                mean, std = self._plug(stack[1], ops.embed_relu(x, stack[0].weight))
+                return mean.reshape(t_max, b_dim, -1), std.reshape(t_max, b_dim, -1), seen
             x = x.long()
         mean, std = self._plug(self.enc[m], x.flatten(0, 1))
         return mean.reshape(t_max, b_dim, -1), std.reshape(t_max, b_dim, -1), seen

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 27
+ABI_VERSION = 28
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -25,7 +25,8 @@ SYMBOLS = [
     'mdmm_kld_gauss_fwd', 'mdmm_kld_gauss_bwd',
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
     'mdmm_nll_bernoulli_fwd', 'mdmm_nll_bernoulli_bwd',
-    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero',
+    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero', 'mdmm_fold_slabs', 'mdmm_embed_relu_supported', 'mdmm_embed_relu_slabs', 'mdmm_embed_relu_fwd',
+    'mdmm_embed_relu_bwd',
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
     'mdmm_philox_normal', 'mdmm_debug_clock', 'mdmm_gtf_pack_size', 'mdmm_gtf_pack',
     'mdmm_gru_skip_fwd', 'mdmm_gru_skip_bwd', 'mdmm_dks_combiner_fwd', 'mdmm_dks_combiner_bwd',
@@ -81,6 +82,17 @@ class Sweep(C.Structure):
                  ('gtf_frag', _P), ('precision', C.c_int32), ('reserved1', C.c_int32),
                  ('wide_ws', _P), ('wide_ws_bytes', C.c_int64), ('fwd_park', _P), ('fwd_park_bytes', C.c_int64),
                  ('kld_mask', _P), ('kld_out', _P), ('kld_scale_dev', _P), ('kld_weight', C.c_float), ('reserved2', C.c_int32)])
+
+
+FOLD_SLABS_MAX = 8
+
+
+class FoldSlabItem(C.Structure):
+    _fields_ = [('src', _P), ('dst', _P), ('bits', C.c_uint32), ('reserved', C.c_uint32)]
+
+
+class FoldSlabs(C.Structure):
+    _fields_ = [('n', C.c_int32), ('P', C.c_int32), ('elems', C.c_int64), ('item', FoldSlabItem * FOLD_SLABS_MAX)]
 
 
 MAX_FRAG_LAYERS = 12
@@ -283,6 +295,12 @@ def lib():
         L.mdmm_nll_bernoulli_logits_passes_bwd.argtypes = [_P, i32, i32, _P, _P, i64, i32, f32, C.POINTER(C.c_float), _P, _P, _P, i32, _P]
         L.mdmm_nll_chan_parts.argtypes = []
         L.mdmm_nan_to_zero.argtypes = [_P, i64, i32, _P, _P, _P]
+        L.mdmm_fold_slabs.argtypes = [C.POINTER(FoldSlabs), _P]
+        L.mdmm_embed_relu_supported.argtypes = [i32, i32]
+        L.mdmm_embed_relu_slabs.argtypes = [i64]
+        L.mdmm_embed_relu_slabs.restype = C.c_int64
+        L.mdmm_embed_relu_fwd.argtypes = [_P, _P, i64, i32, i32, _P, _P]
+        L.mdmm_embed_relu_bwd.argtypes = [_P, _P, _P, i64, i32, i32, _P, _P]
         L.mdmm_nll_categorical_fwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P]
         L.mdmm_nll_categorical_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
         L.mdmm_philox_normal.argtypes = [C.c_uint64, C.c_uint64, _P, i64, _P, _P]

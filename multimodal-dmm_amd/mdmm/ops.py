@@ -447,6 +447,28 @@ def _fold_passes(g, bits, per_pass, n_pass):
     return out
 
 
+def _fold_all(g_means, g_stds, bits, per_pass, n_pass):
+    """_fold_passes for every expert of a sweep: the shared experts that took part in two or more passes are summed by ONE
+    launch (mdmm_fold_slabs) instead of one torch add per tensor and extra pass."""
+    out_m, out_s = [None] * len(g_means), [None] * len(g_stds)
+    batch = []
+    for e, (gm, gs, b, pp) in enumerate(zip(g_means, g_stds, bits, per_pass)):
+        n_act = bin(b & ((1 << n_pass) - 1)).count('1')
+        for out, g in ((out_m, gm), (out_s, gs)):
+            if g is not None and not pp and n_act >= 2 and g.is_cuda and g[0].numel() % 4 == 0 and len(batch) < native.FOLD_SLABS_MAX:
+                out[e] = torch.empty_like(g[0])
+                batch.append((g, out[e], b))
+            else:
+                out[e] = _fold_passes(g, b, pp, n_pass)
+    if batch:
+        f = native.FoldSlabs()
+        f.n, f.P, f.elems = len(batch), n_pass, batch[0][0][0].numel()
+        for k, (g, dst, b) in enumerate(batch):
+            f.item[k].src, f.item[k].dst, f.item[k].bits = _ptr(g), _ptr(dst), b
+        _call('mdmm_fold_slabs', C.byref(f), tag='fold_slabs[%d]' % len(batch))
+    return out_m, out_s
+
+
 class _SweepFn(torch.autograd.Function):
     """MultiDMM.z_filter (dmm.py:319-412) for P passes at once -> mdmm_bfvi_sweep_fwd/_bwd."""
 
@@ -599,8 +621,7 @@ class _SweepFn(torch.autograd.Function):
                 g_gtf = packed.unpack_grads(G, X, ctx.gtf_like)
         g_z0_mean = gz0[0].reshape(ctx.z0_shapes[0])
         g_z0_log = (gz0[1] * torch.exp(z0s)).reshape(ctx.z0_shapes[1])
-        g_means = [_fold_passes(g, b, pp, cfg.P) for g, b, pp in zip(g_means, ctx.bits, ctx.per_pass)]
-        g_stds = [_fold_passes(g, b, pp, cfg.P) for g, b, pp in zip(g_stds, ctx.bits, ctx.per_pass)]
+        g_means, g_stds = _fold_all(g_means, g_stds, ctx.bits, ctx.per_pass, cfg.P)
 
         g_flat = ([g.reshape(sh) if g is not None else None
                    for g, sh in zip(g_means, ctx.in_shapes[:n_exp])] +
@@ -1291,6 +1312,48 @@ class _CatHeadNllFn(torch.autograd.Function):
         gw = tot[:n_cat * H].reshape(n_cat, H)
         gb = tot[n_cat * H:] if ctx.has_bias else None
         return g_hid, gw, gb, None, None, None, None, None, None
+
+
+class _EmbedReluFn(torch.autograd.Function):
+    """relu(nn.Embedding(label)) of the Categorical modality's stock encoder (dmm.py:78-85) -> mdmm_embed_relu_fwd/_bwd."""
+
+    @staticmethod
+    def forward(ctx, label, weight):
+        rows, (n_cat, h) = label.numel(), weight.shape
+        out = torch.empty(rows, h, device=weight.device, dtype=torch.float32)
+        w = _f32c(weight.detach())
+        _call('mdmm_embed_relu_fwd', _ptr(w), _ptr(label), rows, n_cat, h, _ptr(out), tag='embed_relu_fwd')
+        ctx.save_for_backward(label, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        label, w = ctx.saved_tensors
+        rows, (n_cat, h) = label.numel(), w.shape
+        g = _f32c(g)
+        slabs = torch.empty(native.lib().mdmm_embed_relu_slabs(rows), n_cat * h, dtype=torch.float32, device=w.device)
+        _call('mdmm_embed_relu_bwd', _ptr(w), _ptr(label), _ptr(g), rows, n_cat, h, _ptr(slabs), tag='embed_relu_bwd')
+        dw = colsum(slabs).reshape(n_cat, h)
+        return None, dw
+
+
+def embed_relu_stack(enc):
+    """The stock Categorical encoder nn.Sequential(nn.Embedding, nn.ReLU, tail) whose first two modules the fused kernels
+    take (plain fp32 embedding: no padding index, no max-norm, dense gradients), or None."""
+    import torch.nn as nn
+    if not (isinstance(enc, nn.Sequential) and len(enc) == 3 and type(enc[0]) is nn.Embedding and type(enc[1]) is nn.ReLU):
+        return None
+    e = enc[0]
+    if e.padding_idx is not None or e.max_norm is not None or e.sparse or e.scale_grad_by_freq or e.weight.dtype != torch.float32:
+        return None
+    if not e.weight.is_cuda or not native.lib().mdmm_embed_relu_supported(e.weight.shape[1], e.weight.shape[0]):
+        return None
+    return e, enc[2]
+
+
+def embed_relu(label, weight):
+    """label: fp32 class ids (rows,), NaN-free; -> relu(weight[label]) (rows, h)."""
+    return _EmbedReluFn.apply(_f32c(label.reshape(-1)), weight)
 
 
 def cat_head_supported(h_dim, n_cat):

@@ -94,6 +94,13 @@ def _replay_vs_eager(name, lengths, dev, device_batch=False):
     g_r = _grads(model)
     assert torch.isfinite(bucket.flat).all()
 
+    if device_batch:
+        # the per-GPU-size step: its graph's memory pool goes before the eager step takes as much again (inside the whole
+        # suite, with what earlier tests left cached, both together did not fit 288 GB)
+        import gc
+        del step
+        gc.collect()
+        torch.cuda.empty_cache()
     # ---- the same step eagerly: same weights, same stream ids, same device counter
     noise.counter = c_capture
     noise.device_counter(dev).copy_(d0)
@@ -133,6 +140,9 @@ def test_graph_replay_matches_eager_cfg5_per_gpu_size(dev):
     """BASELINE cfg5 at its per-GPU size: 512 sequences, T = 128, ragged lengths 64..128, half of every modality's
     steps missing.  3 passes x 512 = 1,536 (pass, sequence) pairs are 384 workgroups of the K-particle sweeps -- one and
     a half rounds of the chip, a tail no smaller test takes -- and 127 steps of park per workgroup."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     g = torch.Generator().manual_seed(5)
     lengths = sorted(torch.randint(64, 129, (512,), generator=g).tolist(), reverse=True)
     lengths[0] = 128
