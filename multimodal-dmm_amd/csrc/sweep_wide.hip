@@ -660,6 +660,9 @@ __device__ __forceinline__ float tile_sum(const f32x16 (&v)[RT]) {
 // PKB (K = 1, bf16 operands, LR <= 8): the forward sweep of the same call kept what the elementwise adjoint reads
 // (mdmm_sweep_t.fwd_park, wide_sweep.h FwdParkK1) -- R1 .. R4 (six of the twelve contractions, three barriers) are not run,
 // the four X-side weight-gradient operands are not spilled again (wide_wgrad_kernel reads the forward's chunks).
+// cfg3 launch 1.11 -> 0.81 ms; in-kernel stamps of a parked step (profiles/r05_stamps_k1_parked.txt): 36.5 k cycles, of
+// which the fusion adjoint (A) 14 k, park loads + E 2-3 k, the six contractions 14.5 k, barriers 4 k.  (Requesting the
+// next step's (A) loads in front of D3 -- 80 registers carried across the step boundary -- measured 0.83 ms: not kept.)
 template <bool F32, int RT, bool K1, int LR = 16, bool PKB = false>
 __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, const WideGeo g,
                                                         const WideWs ws) {
