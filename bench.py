@@ -683,7 +683,12 @@ def run(cfg, args, world, rank, device, graph):
     rf_k1 = roofline_of(cfg, spans, b_dim, want_k1=True)
     if rf is None or cfg is Cfg4:   # (cfg4: the sweeps' model does not apply -- its recurrences are latency chains;
         rf = roofline_bytes(timer, spans) or rf      #  what fills its step is the streaming BatchNorm / conv chain)
-    for r in (rf, rf_k1):
+    # the conv family (the largest of the cfg3 step): its weight-gradient call with the most device time, algorithmic bytes
+    # (both activation sides read once, + the BatchNorm adjoint's gradient where the kernel carries its sums) over its
+    # HIP-event time against the HBM peak
+    conv_spans = {t: v for t, v in spans.items() if t.startswith('conv_wgrad')}
+    rf_conv = roofline_bytes(timer, conv_spans) if conv_spans else None
+    for r in (rf, rf_k1, rf_conv):
         if r is not None:
             r['timing'] = timing_note
     out_cfg = {'workload': cfg.workload % b_dim, 'global_batch': world * b_dim, 'seq_len': cfg.T,
@@ -705,6 +710,7 @@ def run(cfg, args, world, rank, device, graph):
         'config': out_cfg,
         'roofline': rf,
         'roofline_k1': rf_k1,
+        'roofline_conv': rf_conv,
         'roofline_step': roofline_step(cfg, b_dim, 1e3 * elapsed / args.steps),
         # library calls by device time per step: HIP-event spans minus the calibrated cost of an empty event pair
         # per call (eager probe steps; per-KERNEL device times: profiles/*_kernel_stats.md from rocprofv3)

@@ -155,7 +155,7 @@ inline size_t lds_bytes(int H, int n_cat) { return ((size_t)RB * (H + 1) + (size
 // g[r][j]: thread j owns column j of a workgroup's [n_cat][h] table in LDS (no atomics), one slab per workgroup (the
 // caller adds them up: mdmm_colsum over mdmm_embed_relu_slabs(rows) rows of n_cat * h) -- deterministic.
 // ---------------------------------------------------------------------------------------
-constexpr int EMB_ROWS = 256;            // rows per workgroup
+constexpr int EMB_ROWS = 32;             // rows per workgroup (a row's update is a dependent LDS read-modify-write: short chains, many workgroups)
 
 __global__ __launch_bounds__(NT) void embed_relu_fwd_kernel(const float* __restrict__ w, const float* __restrict__ label,
                                                             int64_t rows, int n_cat, int H, float* __restrict__ out) {
@@ -177,11 +177,20 @@ __global__ __launch_bounds__(NT) void embed_relu_bwd_kernel(const float* __restr
   __syncthreads();
   const int64_t r0 = (int64_t)blockIdx.x * EMB_ROWS, r1 = r0 + EMB_ROWS < rows ? r0 + EMB_ROWS : rows;
   for (int j = threadIdx.x; j < H; j += NT) {
-    for (int64_t r = r0; r < r1; ++r) {
-      const float lf = label[r];
-      const int c = (int)lf;
-      if (!(lf == lf) || c < 0 || c >= n_cat) continue;
-      if (w[(size_t)c * H + j] > 0.f) lds[c * H + j] += g[r * H + j];
+    for (int64_t r = r0; r < r1; r += 8) {
+      // eight rows' loads in flight, then their updates
+      float gv[8]; int cv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t rr = r + u;
+        const float lf = rr < r1 ? label[rr] : -1.f;
+        const int c = (int)lf;
+        cv[u] = (lf == lf && c >= 0 && c < n_cat) ? c : -1;
+        gv[u] = (rr < r1 && cv[u] >= 0) ? g[rr * H + j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (cv[u] >= 0 && w[(size_t)cv[u] * H + j] > 0.f) lds[cv[u] * H + j] += gv[u];
     }
   }
   __syncthreads();

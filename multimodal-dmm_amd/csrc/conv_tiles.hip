@@ -746,6 +746,18 @@ struct Wg {
 
 __device__ __forceinline__ uint32_t shift16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbyte(hi, lo, 2); }
 
+// Column order of a weight-gradient slab: col = ptap * cb + b with the taps CLASS-MAJOR by the shift their operand runs
+// need -- first the taps whose eight pixels are an aligned 16-byte run of a plane (kx = 1, 2), then those moved one element
+// back (kx = 0), then one element on (kx = 3).  A 32-column tile is then one class wherever cb >= 16 (every tile of the
+// 16 x 16 and 8 x 8 layers): its lanes share one shift, built without per-lane selects.  ptap -> tap = ky * KS + kx:
+__host__ __device__ inline int wg_tap(int ptap, int KS) {
+  if (KS == 4) {
+    if (ptap < 8) return (ptap >> 1) * 4 + 1 + (ptap & 1);
+    return ptap < 12 ? (ptap - 8) * 4 : (ptap - 12) * 4 + 3;
+  }
+  return ptap < 6 ? (ptap >> 1) * 3 + 1 + (ptap & 1) : (ptap - 6) * 3;
+}
+
 // NORM: 1 = the SMALL side is the layer's input in pre-normalisation form (Deconv), 2 = the BIG side is (Conv)
 // BST (with NORM = 1): the reduction pass of that normalisation's adjoint on the way -- the kernel stages every element
 // x of the small side anyway; with the gradient of the normalised activation (mdmm_conv_t.bst_dy) fetched beside it,
@@ -822,7 +834,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
       mt_of[j] = (job / NT) != 0;
       const int nt = job % NT, col = 32 * nt + (lane & 31);
       if (col < NCOL) {
-        const int tap = col / cb, b = col % cb, ky = tap / KS, kx = tap % KS;
+        const int tap = wg_tap(col / cb, KS), b = col % cb, ky = tap / KS, kx = tap % KS;
         const int plane = (kx & 1) ? 0 : 1;                        // E holds the even columns
         col_off[j] = (plane * CB + b) * W::PL_CS + ky * W::PL_RS + 16;
         col_sh[j] = kx == 0 ? -1 : (kx == 3 ? 1 : 0);
@@ -830,13 +842,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
     }
   }
   nj = __builtin_amdgcn_readfirstlane(nj);
-  // a tile whose 32 columns are one tap (CB = 32) needs the same shift in every lane: -1 / 0 / +1; 2 = mixed
+  // a tile whose valid columns all need the same shift: -1 / 0 / +1 (wave-uniform branches, no per-lane selects);
+  // 2 = mixed classes (cb <= 4: the 32 x 32 layers).  inval: the tile has columns past NCOL (their operand is zero).
+  constexpr bool UNI = CB >= 16;                   // every tile is one class (compile time: no mixed path, no selector)
+  constexpr bool INVAL = !UNI || (CB == 16 && KS == 3);      // tiles with columns past NCOL exist
   int ush[MAXJ];
+  [[maybe_unused]] bool inval[MAXJ];
+  [[maybe_unused]] uint32_t psel[MAXJ];            // mixed tiles: byte selector of a lane's shift (see the contraction loop)
 #pragma unroll
   for (int j = 0; j < MAXJ; ++j) {
-    const int first = __builtin_amdgcn_readfirstlane(col_sh[j]);
-    const bool same = CB == 32 && __all((col_sh[j] == first && col_off[j] >= 0) ? 1 : 0);
+    const int first = __builtin_amdgcn_readfirstlane(col_sh[j]);       // (lane 0's column is valid in every tile that exists)
+    const bool same = UNI || __all((col_off[j] < 0 || col_sh[j] == first) ? 1 : 0);
     ush[j] = same ? first : 2;
+    inval[j] = INVAL && !__all(col_off[j] >= 0 ? 1 : 0);
+    psel[j] = col_sh[j] != 0 ? 0x05040302u : 0x07060504u;
   }
   __syncthreads();
   constexpr int NPIX = W::NPIX, BPIX = 4 * NPIX, B2 = 2 * S;
@@ -1030,31 +1049,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
           const char* at = pl + (valid ? col_off[j] : 16) + rowoff;
           const uint4 m = *reinterpret_cast<const uint4*>(at);
           uint4 bv = m;
-          if (CB != 32) {                         // (compile time) tiles mix taps: per-lane selects
-            const uint32_t prev = *reinterpret_cast<const uint32_t*>(at - 4);
-            const uint32_t next = *reinterpret_cast<const uint32_t*>(at + 16);
-            const int sh = col_sh[j];
-            bv.x = sh < 0 ? shift16(m.x, prev) : (sh > 0 ? shift16(m.y, m.x) : m.x);
-            bv.y = sh < 0 ? shift16(m.y, m.x) : (sh > 0 ? shift16(m.z, m.y) : m.y);
-            bv.z = sh < 0 ? shift16(m.z, m.y) : (sh > 0 ? shift16(m.w, m.z) : m.z);
-            bv.w = sh < 0 ? shift16(m.w, m.z) : (sh > 0 ? shift16(next, m.w) : m.w);
-            if (!valid) bv = uint4{0, 0, 0, 0};
-          } else if (ush[j] == -1) {              // wave-uniform branches: no per-lane selects, one extra read
+          if (ush[j] == -1) {                     // wave-uniform branches: no per-lane selects, one extra read
             const uint32_t prev = *reinterpret_cast<const uint32_t*>(at - 4);
             bv = uint4{shift16(m.x, prev), shift16(m.y, m.x), shift16(m.z, m.y), shift16(m.w, m.z)};
           } else if (ush[j] == 1) {
             const uint32_t next = *reinterpret_cast<const uint32_t*>(at + 16);
             bv = uint4{shift16(m.y, m.x), shift16(m.z, m.y), shift16(m.w, m.z), shift16(next, m.w)};
-          } else if (ush[j] == 2) {
+          } else if (!UNI && ush[j] == 2) {
+            // mixed classes: a five-dword window (the run and the dword before or behind it, by the lane's shift), then one
+            // byte permute per dword -- alignbyte by 2 for a shifted lane, the upper dword for an aligned one
+            // (9 instructions; as three-way selects of both shifted forms it was 16)
             const uint32_t prev = *reinterpret_cast<const uint32_t*>(at - 4);
             const uint32_t next = *reinterpret_cast<const uint32_t*>(at + 16);
-            const int sh = col_sh[j];
-            bv.x = sh < 0 ? shift16(m.x, prev) : (sh > 0 ? shift16(m.y, m.x) : m.x);
-            bv.y = sh < 0 ? shift16(m.y, m.x) : (sh > 0 ? shift16(m.z, m.y) : m.y);
-            bv.z = sh < 0 ? shift16(m.z, m.y) : (sh > 0 ? shift16(m.w, m.z) : m.z);
-            bv.w = sh < 0 ? shift16(m.w, m.z) : (sh > 0 ? shift16(next, m.w) : m.w);
-            if (!valid) bv = uint4{0, 0, 0, 0};
+            const bool up = col_sh[j] > 0;
+            const uint32_t w0 = up ? m.x : prev, w1 = up ? m.y : m.x, w2 = up ? m.z : m.y, w3 = up ? m.w : m.z,
+                           w4 = up ? next : m.w;
+            bv = uint4{__builtin_amdgcn_perm(w1, w0, psel[j]), __builtin_amdgcn_perm(w2, w1, psel[j]),
+                       __builtin_amdgcn_perm(w3, w2, psel[j]), __builtin_amdgcn_perm(w4, w3, psel[j])};
           }
+          if constexpr (INVAL) { if (inval[j] && !valid) bv = uint4{0, 0, 0, 0}; }
           mma(acc[j], mt_of[j] ? a1 : a0, bv);
         }
       }
@@ -1105,7 +1118,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
 }
 
 // dst[g][e] = sum over p = g, g + groups, ... of src[p][e]; perm_cb > 0 (last pass, groups = 1): element e of a slab is
-// (cs, tap, b) = (e / (kk perm_cb), ...) and lands at dW's [cs][b][tap]
+// (cs, ptap, b) = (e / (kk perm_cb), ...) -- taps in the slabs' class-major order, wg_tap -- and lands at dW's [cs][b][tap]
 __global__ void conv_fold_kernel(const float* src, int parts, int64_t elems, int groups, float* dst, int perm_cb, int kk) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
@@ -1123,7 +1136,7 @@ __global__ void conv_fold_kernel(const float* src, int parts, int64_t elems, int
   int64_t at = e;
   if (perm_cb > 0) {
     const int ncol = kk * perm_cb, col = (int)(e % ncol);
-    at = (e / ncol) * ncol + (int64_t)(col % perm_cb) * kk + col / perm_cb;
+    at = (e / ncol) * ncol + (int64_t)(col % perm_cb) * kk + wg_tap(col / perm_cb, kk == 16 ? 4 : 3);
   }
   dst[(size_t)g * elems + at] = (s0 + s1) + (s2 + s3);
 }

@@ -2304,7 +2304,8 @@ class _ConvTilesFn(torch.autograd.Function):
                 _lazy_conv_args(a, lazy_in)             # gy formed while the kernel stages it; never written
             ws = torch.empty(native.lib().mdmm_conv_wgrad_ws_bytes(C.byref(a)), device=x.device, dtype=torch.uint8)
             gw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
-            _call('mdmm_conv_wgrad', C.byref(a), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % a.S)
+            _call('mdmm_conv_wgrad', C.byref(a), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % a.S,
+                  nbytes=small.numel() * small.element_size() + big.numel() * big.element_size())     # (each side read once)
             a.lazy_dy = a.lazy_x = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             # per-channel sums over images and pixels: column sums of the (N, C*H*W) matrix on the own
@@ -2443,7 +2444,9 @@ class _BnDeconvFn(torch.autograd.Function):
                 c.bst_dy, c.bst_part = _ptr(dyn), _ptr(bst_part)
             ws = torch.empty(native.lib().mdmm_conv_wgrad_ws_bytes(C.byref(c)), device=x.device, dtype=torch.uint8)
             gw = torch.empty_like(weight, dtype=torch.float32, memory_format=torch.contiguous_format)
-            _call('mdmm_conv_wgrad', C.byref(c), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % c.S)
+            _call('mdmm_conv_wgrad', C.byref(c), _ptr(ws), _ptr(gw), tag='conv_wgrad[S=%d]' % c.S,
+                  nbytes=(small.numel() * small.element_size() + big.numel() * big.element_size()
+                          + (dyn.numel() * dyn.element_size() if bst_part is not None else 0)))     # (+ the adjoint's gradient)
         if ctx.has_bias and ctx.needs_input_grad[6]:
             gb = _take_chansum(gy, gy.shape[1])
             if gb is None:
