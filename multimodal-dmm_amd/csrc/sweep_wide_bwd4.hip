@@ -572,22 +572,24 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     if (i > 1) load_masks(i - 1);
     masks_ahead = true;
     __builtin_amdgcn_sched_barrier(0);
-    u32x4 ep[RT * 4];
+    // (the 64 noise registers of the four tiles beside v0, the ring and the A operands were 30 registers too many: the
+    //  allocator parked that much of the step's state in scratch around D3 -- 1.8 GB of scratch traffic per call.  Two
+    //  tiles' noise is requested in front of the contractions, the other two's behind them, under the first two's sums.)
+    u32x4 ep[8];
 #pragma unroll
-    for (int u = 0; u < RT * 4; ++u) ep[u] = park_ld(noise + (((size_t)t_prev * NWAVE) * 16 + u) * 64 + lane);
+    for (int u = 0; u < 8; ++u) ep[u] = park_ld(noise + (((size_t)t_prev * NWAVE) * 16 + u) * 64 + lane);
     STAMP(13);
     gemm4(v0, smem + img + arow, ts, W(T_W1N), W(T_WL), ring);
     STAMP(14);
     gemm4<false>(v0, smem + arow, ts, W(T_WL), W(T_WL), ring);
     STAMP(15);
     // sums over the particles of d/dz, d/dz * eps and eps
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
+    auto sums = [&](int rt, const u32x4 (&e4s)[8], int base) __attribute__((always_inline)) {
       const bool valid = (pv >> rt) & 1u;
       float sa = 0.f, sb = 0.f, sc = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const u32x4 e4 = ep[rt * 4 + q];
+        const u32x4 e4 = e4s[base + q];
         const float e[4] = {__uint_as_float(e4.x), __uint_as_float(e4.y), __uint_as_float(e4.z), __uint_as_float(e4.w)};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -597,7 +599,14 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
         }
       }
       adj_a[rt] = half_sum(sa); adj_b[rt] = half_sum(sb); se[rt] = half_sum(sc);
-    }
+    };
+    u32x4 ep2[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ep2[u] = park_ld(noise + (((size_t)t_prev * NWAVE) * 16 + 8 + u) * 64 + lane);
+    __builtin_amdgcn_sched_barrier(0);
+    sums(0, ep, 0); sums(1, ep, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    sums(2, ep2, 0); sums(3, ep2, 4);
     STAMP(10);
   }
 
