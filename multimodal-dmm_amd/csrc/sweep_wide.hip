@@ -87,8 +87,19 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
   char* imgH = smem + L::OFF_H;
   [[maybe_unused]] char* imgN = smem + 2 * L::IMG;       // P3: relu(W1n z)
   [[maybe_unused]] char* imgL = smem + 3 * L::IMG;       // P3: nl
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int h = lane >> 5, n = 32 * wave + (lane & 31);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: scalar address math
+  // What derives from the lane id is RE-derived at the head of every step and of every tile of the fusion phase (regeo)
+  // from an opaque read of the id: kept across the step these values are what the allocator parks in scratch, and a reload
+  // from scratch is a vector-memory load -- it waits for every older store of the wave, here the streaming park stores on
+  // their way to HBM (the K-particle fusion phase reloaded `n` behind each of its sixteen noise stores).
+  int lane, h, n, arow;
+  auto regeo = [&]() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    lane = l; h = l >> 5; n = 32 * wave + (l & 31);
+    arow = (l & 31) * Op<F32>::RS + 16 * h;
+  };
+  regeo();
   const int T = a.T, B = a.B, K = a.K;
   const uint64_t noff = noise_off(a);
   const float inv_k = 1.0f / (float)K;
@@ -106,7 +117,6 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
   const float* bias = reinterpret_cast<const float*>(reinterpret_cast<const uint4*>(a.gtf_frag) +
                                                      (size_t)N_LAYER * O::LAYER_U4);
   auto W = [&](int layer) { return frag + (size_t)layer * O::LAYER_U4; };
-  const int arow = (lane & 31) * O::RS + 16 * h;
   const float b1g = bias[B_1G * WD + n], b1n = bias[B_1N * WD + n], bl = bias[B_L * WD + n];
   const float b2g = bias[B_2G * WD + n], b2n = bias[B_2N * WD + n], bs = bias[B_S * WD + n];
   const float mu0 = a.z0_mean[n], sg0 = fast::exp(a.z0_log_std[n]) + a.min_std;
@@ -168,6 +178,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
     KArgs& a = *kap;
     const auto* exs = a.experts;
     const int t = a.reverse ? T - 1 - i : i;
+    regeo();
     [[maybe_unused]] const bool parked = (PK || PK1) && a.fwd_park != nullptr;      // (wave-uniform: a launch argument)
     [[maybe_unused]] gs_ptr k1_x = k1_xop0, k1_e = k1_eop0;
     if constexpr (PK1) {
@@ -515,6 +526,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       // flight cost more scratch (152 -> 452 B per lane) than the round trips they hide.)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
+        regeo();
         PairRef pr = tab[rt];          // a tile's pair is wave-uniform: scalar address math
         pr.p = __builtin_amdgcn_readfirstlane(pr.p); pr.b = __builtin_amdgcn_readfirstlane(pr.b);
         float im = 0.f, is = 0.f;
