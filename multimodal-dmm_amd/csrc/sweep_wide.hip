@@ -129,15 +129,13 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
   // what this sweep keeps for the one-round backward (wide_sweep.h, FwdPark): this lane's slots of the workgroup
   constexpr bool PK = !K1 && !F32 && RT == 4;
   // (wave-uniform bases in scalar registers; the lane is added where a slot is written)
-  [[maybe_unused]] gs_ptr pk_noise0 = nullptr, pk_xop0 = nullptr, pk_eop0 = nullptr;
+  [[maybe_unused]] gs_ptr pk_noise0 = nullptr, pk_item0 = nullptr;
   if constexpr (PK) {
     if (a.fwd_park) {
       FwdPark pk;
       fwd_park_carve(&a, &pk);
-      const int ws_ = __builtin_amdgcn_readfirstlane(wave);
-      pk_noise0 = (gs_ptr)pk.noise + ((size_t)blockIdx.x * T * NWAVE + ws_) * (16 * 64);
-      pk_xop0 = (gs_ptr)pk.xop + ((size_t)blockIdx.x * (T - 1) * 2 * X_ARR * NWAVE + ws_) * 256;
-      pk_eop0 = (gs_ptr)pk.eop + ((size_t)blockIdx.x * (T - 1) * NWAVE + ws_) * (EP_SLOTS * 64);
+      pk_noise0 = (gs_ptr)pk.noise + ((size_t)blockIdx.x * T * NWAVE + wave) * (NOISE_SLOTS * 64);
+      pk_item0 = (gs_ptr)pk.item + (size_t)blockIdx.x * (T - 1) * PK_ITEM_U4;
     }
   }
 
@@ -164,11 +162,10 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
     tab = tab0; rowbase = rowbase0; frag = frag0;    // (the same for the per-layer weight pointers)
     asm volatile("" : "+v"(tab.p), "+v"(rowbase), "+v"(frag));
     // the park slots of the transition into this step (item i - 1) and of this step's particles (item i)
-    [[maybe_unused]] gs_ptr pk_x = pk_xop0, pk_e = pk_eop0, pk_n = pk_noise0;
+    [[maybe_unused]] gs_ptr pk_x = pk_item0, pk_n = pk_noise0;       // (pk_x: item i - 1; + lane where a slot is written)
     if constexpr (PK) {
-      asm volatile("" : "+s"(pk_x), "+s"(pk_e), "+s"(pk_n));
-      pk_x += (ptrdiff_t)(i - 1) * (2 * X_ARR * XOP_ARR_U4);
-      pk_e += (ptrdiff_t)(i - 1) * (NWAVE * EP_SLOTS * 64);
+      asm volatile("" : "+s"(pk_x), "+s"(pk_n));
+      pk_x += (ptrdiff_t)(i - 1) * PK_ITEM_U4;
     }
     // ... and for the launch arguments: inside the loop they are read through an opaque copy of
     // the kernarg pointer (the sweep descriptor is the first kernel argument), so that pointers,
@@ -303,7 +300,10 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
         for (int r = 0; r < 16; ++r) acc[rt][r] = fmaxf(acc[rt][r], 0.f);
       STAMP(1);
       if constexpr (PK) {
-        if (parked) { park_st(pk_e + EP_MASK * 64 + lane, mk_g); store_image_park(imgH, acc, wave, lane, pk_x + lane, X_HG); }
+        if (parked) {
+          park_st(pk_x + PK_MASK_U4 + (wave * 2) * 64 + lane, mk_g);
+          store_image_park(imgH, acc, wave, lane, pk_x + X_HG * P7_U4 + lane);
+        }
         else store_image<F32, RT>(imgH, acc, wave, lane);
       } else store_image<F32, RT>(imgH, acc, wave, lane);
       STAMP(2);
@@ -324,7 +324,10 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rt][r] = fmaxf(acc[rt][r], 0.f);
       if constexpr (PK) {
-        if (parked) { park_st(pk_e + (EP_MASK + 1) * 64 + lane, mk_n); store_image_park(imgH, acc, wave, lane, pk_x + lane, X_HN); }
+        if (parked) {
+          park_st(pk_x + PK_MASK_U4 + (wave * 2 + 1) * 64 + lane, mk_n);
+          store_image_park(imgH, acc, wave, lane, pk_x + X_HN * P7_U4 + lane);
+        }
         else store_image<F32, RT>(imgH, acc, wave, lane);
       } else store_image<F32, RT>(imgH, acc, wave, lane);
       STAMP(6);
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       gemm_tile<F32, RT, Pf<RT>::N>(acc, imgH + arow, W(L_W2N), W(L_WL), ring);
       __syncthreads();
       if constexpr (PK) {
-        if (parked) store_image_park(imgH, acc, wave, lane, pk_x + lane, X_NL);
+        if (parked) store_image_park(imgH, acc, wave, lane, pk_x + X_NL * P7_U4 + lane);
         else store_image<F32, RT>(imgH, acc, wave, lane);
       } else store_image<F32, RT>(imgH, acc, wave, lane);
       STAMP(8);
@@ -350,25 +353,15 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           acc[rt][r] = fmaf(acc[rt][r], ex, bl);
         }
       if constexpr (PK) {
-        if (parked) {
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              bf16x8 c;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) { const float omg = x[rt][8 * s + j]; c[j] = (__bf16)gate_code(1.0f - omg, omg); }
-              park_st(pk_e + (EP_GATE + 2 * rt + s) * 64 + lane, __builtin_bit_cast(uint4, c));
-              __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        if (parked)
+          park_p7(pk_x + PK_GATE * P7_U4 + lane, wave, [&](int rt, int r) { const float omg = x[rt][r]; return gate_code(1.0f - omg, omg); });
       }
       gemm_tile<F32, RT, Pf<RT>::N>(acc, imgZ + arow, W(L_WL), W(L_WS), ring);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) m_[rt][r] = x[rt][r] * acc[rt][r];          // muq
-      if constexpr (PK) { if (parked) park_e(pk_e + EP_MUQ * 64 + lane, m_); }
+      if constexpr (PK) { if (parked) park_p7(pk_x + PK_MUQ * P7_U4 + lane, wave, [&](int rt, int r) { return m_[rt][r]; }); }
       STAMP(9);
       __syncthreads();
       STAMP(10);
@@ -376,7 +369,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       //   v = sq^2 + eps, u = 1 / (t0 v + 1):  var = v u,  mean = muq u + num0 var
       fill_acc(acc, bs);
       gemm_tile<F32, RT, Pf<RT>::N>(acc, imgH + arow, W(L_WS), W(L_W1G), ring);
-      if constexpr (PK) { if (parked) park_e(pk_e + EP_PRE * 64 + lane, acc); }
+      if constexpr (PK) { if (parked) park_p7(pk_x + PK_PRE * P7_U4 + lane, wave, [&](int rt, int r) { return acc[rt][r]; }); }
       STAMP(16);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -524,6 +517,9 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       // per step, profiles/r04x_stamps_k25.txt.  Requesting two / four tiles' loads together was measured -- tools/
       // bench_sweep.py K=25 at cfg3 size: 2.16-2.19 ms as is, 2.32-2.35 with two, 2.44-2.45 with four: the values in
       // flight cost more scratch (152 -> 452 B per lane) than the round trips they hide.)
+      [[maybe_unused]] float e12[RT];       // (park: the draws of register 12 of the tiles)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) e12[rt] = 0.f;
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         regeo();
@@ -570,15 +566,26 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           }
           if constexpr (PK) {
             // the noise of this step for the one-round backward (sweep_wide_bwd4.hip): its park slot of
-            // (workgroup, time, wave, tile, register group), dead rows as zeros
+            // (workgroup, time, wave, tile, register group), dead rows as zeros; register 12 of the four tiles shares a slot
             if (parked) {
-              uint4 o;
-              o.x = __float_as_uint(e[0]); o.y = __float_as_uint(e[1]); o.z = __float_as_uint(e[2]); o.w = __float_as_uint(e[3]);
-              park_st(pk_n + ((size_t)t * NWAVE * 16 + rt * 4 + q) * 64 + lane, o);
+              if (q < 3) {
+                uint4 o;
+                o.x = __float_as_uint(e[0]); o.y = __float_as_uint(e[1]); o.z = __float_as_uint(e[2]); o.w = __float_as_uint(e[3]);
+                park_st(pk_n + ((size_t)t * NWAVE * NOISE_SLOTS + rt * 3 + q) * 64 + lane, o);
+              } else {
+                e12[rt] = e[0];
+              }
             }
           }
         }
         zsum[rt] = half_sum(zs);
+      }
+      if constexpr (PK) {
+        if (parked) {
+          uint4 o;
+          o.x = __float_as_uint(e12[0]); o.y = __float_as_uint(e12[1]); o.z = __float_as_uint(e12[2]); o.w = __float_as_uint(e12[3]);
+          park_st(pk_n + ((size_t)t * NWAVE * NOISE_SLOTS + 12) * 64 + lane, o);
+        }
       }
       if (a.samples) {
 #pragma unroll
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       if constexpr (!P3) __syncthreads();               // every wave is done with the H image (5b) and Z (5a)
       STAMP(14);
       if constexpr (PK) {         // (item i: rows of the next transition)
-        if (parked) store_image_park(imgZ, z, wave, lane, pk_x + 2 * X_ARR * XOP_ARR_U4 + lane, X_Z);
+        if (parked) store_image_park(imgZ, z, wave, lane, pk_x + PK_ITEM_U4 + X_Z * P7_U4 + lane);
         else store_image<F32, RT>(imgZ, z, wave, lane);
       } else {
         store_image<F32, RT>(imgZ, z, wave, lane);
@@ -1263,6 +1270,114 @@ __global__ __launch_bounds__(NTHR) void wide_wgrad_kernel(const WideWs ws, int x
       }
 }
 
+// The same contraction over P7 arrays (wide_sweep.h: the K-particle park and the one-round backward's spill, seven
+// chunks per lane and array for the four tiles of an item).  An item is staged as its two sub-blocks in turn -- four
+// chunks, then three -- through the same two LDS buffers of four chunks: a UNIT is (item, sub), units are dealt to the
+// row splits, the next unit travels through registers while the current one is multiplied.  G arrays: ws.spill
+// [item][G_ARR][P7_U4]; X arrays: ws.xop [item][PK_ITEM_U4] (the forward's park: the four X arrays come first).
+__global__ __launch_bounds__(NTHR) void wide_wgrad7_kernel(const WideWs ws, int xcd_turn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int id = blockIdx.x;
+  if (xcd_turn) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);        // gridDim.x is a multiple of 8
+  const int blk = id % 6, sp = id / 6;
+  if (sp >= ws.split) return;
+  const int garr = blk, xarr = blk < 3 ? (int)X_Z : blk - 2;         // Ghg, Ghn, Glin, GG, GN, G3 against Z, Z, Z, HG, HN, NL
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wa = wave >> 1, wb = wave & 1;
+  const int64_t units = ws.n_wg * ws.n_step * 2;
+  const int64_t per = (units + ws.split - 1) / ws.split;
+  const int64_t lo = sp * per, hi = (lo + per < units) ? lo + per : units;
+  f32x16 acc[2][4], accb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  uint4 ones;
+  ones.x = ones.y = ones.z = ones.w = 0x3F803F80u;
+  constexpr int buf_u4 = NWAVE * 4 * 64;                  // uint4 per operand of one buffer (a four-chunk sub-block)
+  uint4* lds = reinterpret_cast<uint4*>(smem);            // [2 buffers][G | X][buf_u4]
+  uint4 sg0, sg1, sg2, sg3, sx0, sx1, sx2, sx3;
+  // sub-block `sub` of unit u: 4 or 3 chunks per wave, contiguous -- thread t stages elements t, t + 512, ...
+  auto gptr = [&](int64_t u) { return ws.spill + ((u >> 1) * G_ARR + garr) * (size_t)P7_U4 + (u & 1) * P7_SUB1 + threadIdx.x; };
+  auto xptr = [&](int64_t u) { return ws.xop + (u >> 1) * (size_t)PK_ITEM_U4 + (size_t)xarr * P7_U4 + (u & 1) * P7_SUB1 + threadIdx.x; };
+#define W7_LOAD(k)                                                          \
+  if (k < nch) { sg##k = nt_load_u4(gp + k * NTHR); sx##k = nt_load_u4(xp + k * NTHR); }
+#define W7_STORE(k) \
+  if (k < nch) { dst[k * NTHR] = sg##k; dst[buf_u4 + k * NTHR] = sx##k; }
+  if (lo < hi) {
+    const int nch = (lo & 1) ? 3 : 4;
+    const uint4* gp = gptr(lo);
+    const uint4* xp = xptr(lo);
+    W7_LOAD(0) W7_LOAD(1) W7_LOAD(2) W7_LOAD(3)
+    uint4* dst = lds + threadIdx.x;
+    W7_STORE(0) W7_STORE(1) W7_STORE(2) W7_STORE(3)
+  }
+  __syncthreads();
+  for (int64_t it = lo; it < hi; ++it) {
+    const int buf = (int)((it - lo) & 1);
+    const bool more = it + 1 < hi;
+    const int chs = (it & 1) ? 3 : 4;                      // chunks per wave of this unit
+    if (more) {
+      const int nch = ((it + 1) & 1) ? 3 : 4;
+      const uint4* gp = gptr(it + 1);
+      const uint4* xp = xptr(it + 1);
+      W7_LOAD(0) W7_LOAD(1) W7_LOAD(2) W7_LOAD(3)
+    }
+    // (a sub-block lies as [wave][chs][lane])
+    const uint4* gpl = lds + (size_t)buf * 2 * buf_u4 + (size_t)(2 * wa) * chs * 64 + lane;
+    const uint4* xpl = lds + (size_t)buf * 2 * buf_u4 + buf_u4 + (size_t)(4 * wb) * chs * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < chs) {
+        uint4 ga[2], xb[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ga[i] = gpl[(i * chs + c) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xb[j] = xpl[(j * chs + c) * 64];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mma<false>(acc[i][j], ga[i], xb[j]);
+        if (wb == 0) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) mma<false>(accb[i], ga[i], ones);
+        }
+      }
+    }
+    if (more) {                   // the other buffer's readers passed the barrier of the previous trip
+      const int nch = ((it + 1) & 1) ? 3 : 4;
+      uint4* dst = lds + (size_t)(buf ^ 1) * 2 * buf_u4 + threadIdx.x;
+      W7_STORE(0) W7_STORE(1) W7_STORE(2) W7_STORE(3)
+    }
+    __syncthreads();
+  }
+#undef W7_LOAD
+#undef W7_STORE
+  if (wb == 0 && (lane & 31) == 0) {            // every column of accb holds the row sums
+    float* db = ws.db + ((size_t)sp * 6 + blk) * WD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) db[32 * (2 * wa + i) + acc_row(0, r) + 4 * (lane >> 5)] = accb[i][r];
+  }
+  float* slab = ws.slab + ((size_t)sp * 6 + blk) * WD * WD;
+  const int hh = lane >> 5, col = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * (2 * wa + i) + acc_row(0, r) + 4 * hh;
+        slab[(size_t)row * WD + 32 * (4 * wb + j) + col] = acc[i][j][r];
+      }
+}
+
 // slabs / per-workgroup partials -> one row in the dw_partial layout (include/mdmm_hip.h):
 //   dW_in [768][256] (z_to_gate.0 | z_nonlin.0 | z_lin) | dW_gate | dW_nl | dW_std | db_in [768] |
 //   db_gate | db_nl | db_std | d z0_mean | d sigma0
@@ -1434,7 +1549,7 @@ int64_t carve(const mdmm_sweep_t* a, const WideGeo& g, int RT, WideWs* ws) {
     ws->db = reinterpret_cast<float*>(p); p += b_db;
     ws->dz0 = reinterpret_cast<float*>(p); p += b_dz;
     ws->slab = reinterpret_cast<float*>(p);
-    ws->xop = nullptr;
+    ws->xop = nullptr; ws->p7 = 0;
     ws->n_wg = n_wg; ws->n_step = n_step; ws->split = split;
   }
   return b_spill + b_db + b_dz + b_slab;
@@ -1504,7 +1619,8 @@ int wide::wide_wgrad_launch(const WideWs& ws, bool f32, int CH, float* dw_partia
     return 0;
   };
   int rc;
-  if (f32) rc = CH == 4 ? wgrad(wide_wgrad_kernel<true, 4>) : wgrad(wide_wgrad_kernel<true, 8>);
+  if (ws.p7) rc = wgrad(wide_wgrad7_kernel);
+  else if (f32) rc = CH == 4 ? wgrad(wide_wgrad_kernel<true, 4>) : wgrad(wide_wgrad_kernel<true, 8>);
   else rc = CH == 1 ? wgrad(wide_wgrad_kernel<false, 1>) : (CH == 2 ? wgrad(wide_wgrad_kernel<false, 2>) : wgrad(wide_wgrad_kernel<false, 4>));
   if (rc) return rc;
   rc = (int)hipGetLastError();

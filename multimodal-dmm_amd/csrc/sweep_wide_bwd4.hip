@@ -39,7 +39,6 @@ constexpr int LAYER_U4 = Op<false>::LAYER_U4;
 constexpr int PF = B4_PF;                  // weight chunks in flight per wave
 constexpr int RT = PARK_PAIRS;             // row tiles = pairs per workgroup
 constexpr int KMAX = 25;                   // 3 images x 4 K rows x 528 B <= 160 KB
-constexpr int ARR_U4 = XOP_ARR_U4;         // uint4 per spilled array of one half-item
 
 // global-memory views of the packed weights, the spill and the park: as members of the argument
 // structs the pointers are generic, and generic (flat) loads count on the LDS counter too -- every
@@ -159,11 +158,11 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
 
   // wave-uniform bases (scalar registers) + one per-lane index: fragments, biases, spill, park
   const gw_t frag0 = (gw_t)a.gtf_frag + (size_t)wave * NCH * 64;
-  const gs_t spill0 = (gs_t)ws.spill + ((size_t)blockIdx.x * ws.n_step * 2 * G_ARR * NWAVE + wave) * 256;
-  // the forward sweep's park of this (workgroup, wave): noise [time][wave][16][lane], eop [step][wave][EP_SLOTS][lane]
-  const gw_t noise0 = (gw_t)park.noise + ((size_t)blockIdx.x * T * NWAVE + wave) * (16 * 64);
-  const gw_t eop0 = (gw_t)park.eop + ((size_t)blockIdx.x * (T - 1) * NWAVE + wave) * (EP_SLOTS * 64);
-  gw_t noise = noise0, eop = eop0;
+  const gs_t spill0 = (gs_t)ws.spill + (size_t)blockIdx.x * ws.n_step * (G_ARR * P7_U4);      // [workgroup][step][G_ARR] P7 arrays
+  // the forward sweep's park of this workgroup (wide_sweep.h, FwdPark): noise [time][wave][NOISE_SLOTS][lane], items [step]
+  const gw_t noise0 = (gw_t)park.noise + ((size_t)blockIdx.x * T * NWAVE + wave) * (NOISE_SLOTS * 64);
+  const gw_t item0 = (gw_t)park.item + (size_t)blockIdx.x * (T - 1) * PK_ITEM_U4;
+  gw_t noise = noise0, item = item0;
   gw_t frag = frag0;
   gs_t spill_w = spill0;
   auto W = [&](int layer) { return frag + (size_t)layer * LAYER_U4 + lane; };
@@ -181,30 +180,38 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     for (int rt = 0; rt < RT; ++rt) {
       float acc = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const u32x4 e4 = noise[(((size_t)t * NWAVE) * 16 + rt * 4 + q) * 64 + lane];
+      for (int q = 0; q < 3; ++q) {
+        const u32x4 e4 = noise[(((size_t)t * NWAVE) * NOISE_SLOTS + rt * 3 + q) * 64 + lane];
         acc += (__uint_as_float(e4.x) + __uint_as_float(e4.y)) + (__uint_as_float(e4.z) + __uint_as_float(e4.w));
       }
+      acc += __uint_as_float(noise[(((size_t)t * NWAVE) * NOISE_SLOTS + 12) * 64 + lane][rt]);       // register 12
       se[rt] = half_sum(acc);
     }
   }
 
-  // chunk (rt, s) of array `arr` at step `step`: [workgroup][step][half][array][wave][chunk][lane]
-  auto spill_at = [&](int step, int arr, int rt, int s) {
-    return spill_w + (((size_t)step * 2 + (rt >> 1)) * G_ARR + arr) * ARR_U4 + ((rt & 1) * 2 + s) * 64 + lane;
+  // chunk c (P7 order, wide_sweep.h) of array `arr` at step `step`
+  auto spill_at = [&](int step, int arr, int c) {
+    return spill_w + ((size_t)step * G_ARR + arr) * P7_U4 + p7_off(wave, c) + lane;
   };
   // an accumulator array -> its spill chunks and the live rows of an image (p0 = image + srow)
   auto put_arr = [&](const f32x16 (&v)[RT], int step, int arr, char* p0) {
+    unsigned hw[12];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       unsigned w[8];
       tile_words(v[rt], w);
-      u32x4 c0, c1;
-      c0.x = w[0]; c0.y = w[1]; c0.z = w[2]; c0.w = w[3]; c1.x = w[4]; c1.y = w[5]; c1.z = w[6]; c1.w = w[7];
-      SPILL_ST(spill_at(step, arr, rt, 0), c0);
-      SPILL_ST(spill_at(step, arr, rt, 1), c1);
+      u32x4 c0;
+      c0.x = w[0]; c0.y = w[1]; c0.z = w[2]; c0.w = w[3];
+      SPILL_ST(spill_at(step, arr, rt), c0);
+      hw[3 * rt] = w[4]; hw[3 * rt + 1] = w[5]; hw[3 * rt + 2] = w[6];
 #pragma unroll
       for (int k = 0; k < 8; ++k) store_word(p0 + rt * ts, w[k], sel, k, K, kh2);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      u32x4 c;
+      c.x = hw[4 * j]; c.y = hw[4 * j + 1]; c.z = hw[4 * j + 2]; c.w = hw[4 * j + 3];
+      SPILL_ST(spill_at(step, arr, 4 + j), c);
     }
   };
   const int n_pairs = g.n_pairs;
@@ -218,8 +225,8 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
   bool masks_ahead = false;
   for (int i = T - 1; i >= 0; --i) {
     // keep invariant reads and address arithmetic inside the loop (see wide_fwd_kernel)
-    frag = frag0; spill_w = spill0; noise = noise0; eop = eop0;
-    asm volatile("" : "+s"(frag), "+s"(spill_w), "+s"(noise), "+s"(eop));
+    frag = frag0; spill_w = spill0; noise = noise0; item = item0;
+    asm volatile("" : "+s"(frag), "+s"(spill_w), "+s"(noise), "+s"(item));
     KArgs* kap = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kap));
     KArgs& a = *kap;
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       pp = valid ? pair / B : -1; pb = valid ? pair - pp * B : 0;
       return valid;
     };
-    auto eop_of = [&](int ii) __attribute__((always_inline)) { return eop + (size_t)(ii > 0 ? ii - 1 : 0) * (NWAVE * EP_SLOTS * 64) + lane; };
+    auto item_of = [&](int ii) __attribute__((always_inline)) { return item + (size_t)(ii > 0 ? ii - 1 : 0) * PK_ITEM_U4 + lane; };
     // (tt / ii: time index / loop index of the step the loads belong to -- this one, or the next one from D3)
     auto load_a = [&](int rt, AIn& x, int tt) __attribute__((always_inline)) {
       int pp, pb;
@@ -291,19 +298,18 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
         }
       }
     };
-    auto load_e = [&](int rt, int s, EIn& x, int ii) __attribute__((always_inline)) {
-      // (the non-linear branch is the X-side operand of the std head's weight gradient: the forward's chunks)
-      const gw_t ep_ = eop_of(ii);
-      x.nl = park_ld((gw_t)park.xop + ((((size_t)blockIdx.x * (T - 1) + (ii - 1)) * 2 + (rt >> 1)) * X_ARR + X_NL) * ARR_U4 +
-                     (wave * 4 + (rt & 1) * 2 + s) * 64 + lane);
-      x.gt = park_ld(ep_ + (EP_GATE + 2 * rt + s) * 64);
-      x.mq = park_ld(ep_ + (EP_MUQ + 2 * rt + s) * 64);
-      x.pr = park_ld(ep_ + (EP_PRE + 2 * rt + s) * 64);
+    // chunk c (P7 order) of the four parked arrays the elementwise adjoint reads
+    auto load_e = [&](int c, EIn& x, int ii) __attribute__((always_inline)) {
+      const gw_t it = item_of(ii) + p7_off(wave, c);
+      x.nl = park_ld(it + X_NL * P7_U4);       // (the non-linear branch: also the X-side operand of the std head's weight gradient)
+      x.gt = park_ld(it + PK_GATE * P7_U4);
+      x.mq = park_ld(it + PK_MUQ * P7_U4);
+      x.pr = park_ld(it + PK_PRE * P7_U4);
     };
     auto load_masks = [&](int ii) __attribute__((always_inline)) {
-      const gw_t ep_ = eop_of(ii);
-      mkg = park_ld(ep_ + EP_MASK * 64);
-      mkn = park_ld(ep_ + (EP_MASK + 1) * 64);
+      const gw_t it = item_of(ii) + PK_MASK_U4 + (wave * 2) * 64;
+      mkg = park_ld(it);
+      mkn = park_ld(it + 64);
     };
     unsigned pv = 0;                                  // bit rt: tile rt carries a pair
     f32x16 v1[RT];
@@ -368,142 +374,138 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       }
       return r;
     };
-    // ---- elementwise adjoint of one operand chunk (registers 8s .. 8s+7 of pair rt's tile) of the transition into step i
-    // (common.py:62-68, dmm.py:239-258, dgts.py:39-51, 79-83 backwards) on the parked values.  Product with the global
-    // prior as in the forward kernel (v = sq^2 + eps, u = 1/(t0 v + 1)): var = v u, mean = muq u + num0 var;
-    // d mean/d muq = u,  d/d sq via tq = 1/v.
-    auto eadj = [&](int rt, int s, const PairAdj& f, const EIn& y) __attribute__((always_inline)) {
+    // ---- elementwise adjoint of the transition into step i (common.py:62-68, dmm.py:239-258, dgts.py:39-51, 79-83 backwards)
+    // on the parked values, one bf16 WORD = registers (r, r + 1) of one tile at a time.  Product with the global prior as in
+    // the forward kernel (v = sq^2 + eps, u = 1/(t0 v + 1)): var = v u, mean = muq u + num0 var; d mean/d muq = u,
+    // d/d sq via tq = 1/v.  `wi` = the word's position in its chunk; returns the three output words.
+    struct Words { unsigned g3, gg, gl; };
+    auto eword = [&](int rt, int r, const PairAdj& f, const EIn& y, int wi) __attribute__((always_inline)) {
       const float t0 = fast::rcp(sg0 * sg0 + MDMM_POE_EPS), num0 = mu0 * t0;
       const float dt0 = -2.0f * sg0 * t0 * t0;       // d t0 / d sigma0
       const float gv2k = f.gps * fast::rcp(f.prs) * inv_k;      // 2 g_v / K  (dgts.py:79-83)
       const float gpmk = f.gpm * inv_k, mb = f.prm;
-      char* const pa = smem + srow + rt * ts;
-      unsigned w3[4], wg[4], wl[4];
+      const unsigned wn = y.nl[wi], wg = y.gt[wi], wm = y.mq[wi], wp = y.pr[wi];
+      const float nlv[2] = {bf16_lo(wn), bf16_hi(wn)}, gtv[2] = {bf16_lo(wg), bf16_hi(wg)};
+      const float mqv[2] = {bf16_lo(wm), bf16_hi(wm)}, prv[2] = {bf16_lo(wp), bf16_hi(wp)};
+      float o_g3[2], o_gg[2], o_gl[2];
 #pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const int q = 2 * s + d;
-        const unsigned wn0 = y.nl[2 * d], wn1 = y.nl[2 * d + 1], wg0 = y.gt[2 * d], wg1 = y.gt[2 * d + 1];
-        const unsigned wm0 = y.mq[2 * d], wm1 = y.mq[2 * d + 1], wp0 = y.pr[2 * d], wp1 = y.pr[2 * d + 1];
-        const float nlv[4] = {bf16_lo(wn0), bf16_hi(wn0), bf16_lo(wn1), bf16_hi(wn1)};
-        const float gtv[4] = {bf16_lo(wg0), bf16_hi(wg0), bf16_lo(wg1), bf16_hi(wg1)};
-        const float mqv[4] = {bf16_lo(wm0), bf16_hi(wm0), bf16_lo(wm1), bf16_hi(wm1)};
-        const float prv[4] = {bf16_lo(wp0), bf16_hi(wp0), bf16_lo(wp1), bf16_hi(wp1)};
-        float o_g3[4], o_gg[4], o_gl[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int r = 4 * q + k;
-          // a register that is a dead row in BOTH half-waves (row 8 q + k >= K; at K = 25: registers 13 .. 15, a fifth of
-          // this phase's arithmetic): its outputs are the zeros the masks below would have made them
-          if (8 * q + k >= K) { o_g3[k] = 0.f; o_gg[k] = 0.f; o_gl[k] = 0.f; v1[rt][r] = 0.f; continue; }
-          const float pre = prv[k];
-          const float muq = mqv[k];
-          // softplus and its derivative from one exponential: y = e^-|pre|
-          const float ey = fast::exp(-fabsf(pre));
-          const float r1 = fast::rcp(1.0f + ey);
-          const float sq = fmaxf(pre, 0.f) + fast::log(1.0f + ey) + min_std;       // common.py:66
-          const float dsp = pre >= 0.f ? r1 : ey * r1;                              // sigmoid(pre)
-          const float v = fmaf(sq, sq, MDMM_POE_EPS);
-          const float u = fast::rcp(fmaf(t0, v, 1.0f));
-          const float rp = v * u;                                  // variance of the product
-          const float mraw = fmaf(muq, u, num0 * rp);
-          const bool live = f.valid && (8 * q + k < kh);
-          const bool good = live && mraw == mraw;                  // (a NaN mean was overwritten by 0, dgts.py:49)
-          const float m = (mraw != mraw) ? 0.f : mraw;
-          const float g_m = good ? gpmk + gv2k * (m - mb) : 0.f;
-          const float gvl = live ? gv2k : 0.f;                     // g_sd * sd = gv2k * rp: no square root
-          const float g_num = g_m * rp;
-          const float g_prec = -fmaf(g_m, m, 0.5f * gvl * rp) * rp;
-          const float g_t0 = fmaf(g_num, mu0, g_prec);             // d/d prec of the global prior
-          g_mu0 = fmaf(g_num, t0, g_mu0);
-          g_sg0 = fmaf(g_t0, dt0, g_sg0);
-          const float tq = fast::rcp(v);
-          const float g_muq = g_num * tq;
-          const float g_sq = -fmaf(g_num, muq, g_prec) * tq * tq * 2.0f * sq;
-          float gate, omg;
-          gate_decode(gtv[k], gate, omg);
-          o_g3[k] = g_sq * dsp;                                                 // d/d std pre-act
-          o_gg[k] = g_muq * gate * (nlv[k] - muq);                            // d/d gate pre-act
-          o_gl[k] = g_muq * omg;                                              // d/d z_lin
-          v1[rt][r] = g_muq * gate;                                           // direct part of d/d nl
-        }
-        w3[2 * d] = pack2(o_g3[0], o_g3[1]); w3[2 * d + 1] = pack2(o_g3[2], o_g3[3]);
-        wg[2 * d] = pack2(o_gg[0], o_gg[1]); wg[2 * d + 1] = pack2(o_gg[2], o_gg[3]);
-        wl[2 * d] = pack2(o_gl[0], o_gl[1]); wl[2 * d + 1] = pack2(o_gl[2], o_gl[3]);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          store_word(pa + img, w3[2 * d + c], sel, 2 * q + c, K, kh2);
-          store_word(pa + 2 * img, wg[2 * d + c], sel, 2 * q + c, K, kh2);
-          store_word(pa, wl[2 * d + c], sel, 2 * q + c, K, kh2);
-        }
-        __builtin_amdgcn_sched_barrier(0);     // one group at a time
+      for (int k = 0; k < 2; ++k) {
+        const int rr = r + k, row = 8 * (rr >> 2) + (rr & 3);       // (+ 4 h)
+        // a register that is a dead row in BOTH half-waves (row >= K; at K = 25: register 13): its outputs are the zeros
+        // the masks below would have made them
+        if (row >= K) { o_g3[k] = 0.f; o_gg[k] = 0.f; o_gl[k] = 0.f; v1[rt][rr] = 0.f; continue; }
+        const float pre = prv[k];
+        const float muq = mqv[k];
+        // softplus and its derivative from one exponential: y = e^-|pre|
+        const float ey = fast::exp(-fabsf(pre));
+        const float r1 = fast::rcp(1.0f + ey);
+        const float sq = fmaxf(pre, 0.f) + fast::log(1.0f + ey) + min_std;       // common.py:66
+        const float dsp = pre >= 0.f ? r1 : ey * r1;                              // sigmoid(pre)
+        const float v = fmaf(sq, sq, MDMM_POE_EPS);
+        const float u = fast::rcp(fmaf(t0, v, 1.0f));
+        const float rp = v * u;                                  // variance of the product
+        const float mraw = fmaf(muq, u, num0 * rp);
+        const bool live = f.valid && (row < kh);
+        const bool good = live && mraw == mraw;                  // (a NaN mean was overwritten by 0, dgts.py:49)
+        const float m = (mraw != mraw) ? 0.f : mraw;
+        const float g_m = good ? gpmk + gv2k * (m - mb) : 0.f;
+        const float gvl = live ? gv2k : 0.f;                     // g_sd * sd = gv2k * rp: no square root
+        const float g_num = g_m * rp;
+        const float g_prec = -fmaf(g_m, m, 0.5f * gvl * rp) * rp;
+        const float g_t0 = fmaf(g_num, mu0, g_prec);             // d/d prec of the global prior
+        g_mu0 = fmaf(g_num, t0, g_mu0);
+        g_sg0 = fmaf(g_t0, dt0, g_sg0);
+        const float tq = fast::rcp(v);
+        const float g_muq = g_num * tq;
+        const float g_sq = -fmaf(g_num, muq, g_prec) * tq * tq * 2.0f * sq;
+        float gate, omg;
+        gate_decode(gtv[k], gate, omg);
+        o_g3[k] = g_sq * dsp;                                                 // d/d std pre-act
+        o_gg[k] = g_muq * gate * (nlv[k] - muq);                            // d/d gate pre-act
+        o_gl[k] = g_muq * omg;                                              // d/d z_lin
+        v1[rt][rr] = g_muq * gate;                                          // direct part of d/d nl
       }
-      u32x4 c;
-      c.x = w3[0]; c.y = w3[1]; c.z = w3[2]; c.w = w3[3];
-      SPILL_ST(spill_at(i - 1, G_3, rt, s), c);
-      c.x = wg[0]; c.y = wg[1]; c.z = wg[2]; c.w = wg[3];
-      SPILL_ST(spill_at(i - 1, G_G, rt, s), c);
-      c.x = wl[0]; c.y = wl[1]; c.z = wl[2]; c.w = wl[3];
-      SPILL_ST(spill_at(i - 1, G_LIN, rt, s), c);
+      Words o;
+      o.g3 = pack2(o_g3[0], o_g3[1]); o.gg = pack2(o_gg[0], o_gg[1]); o.gl = pack2(o_gl[0], o_gl[1]);
+      // G3 -> B, GG -> C, Glin -> A (live rows of the images)
+      char* const pa = smem + srow + rt * ts;
+      store_word(pa + img, o.g3, sel, r >> 1, K, kh2);
+      store_word(pa + 2 * img, o.gg, sel, r >> 1, K, kh2);
+      store_word(pa, o.gl, sel, r >> 1, K, kh2);
+      return o;
+    };
+    // one P7 chunk c of the three arrays E produces (wide_sweep.h): chunk rt = words 0 .. 3 of tile rt, chunk 4 + j = words
+    // 4j .. 4j+3 of the flat list (tile, word 4 + k)
+    auto echunk = [&](int c, const PairAdj (&f)[RT], const EIn& y) __attribute__((always_inline)) {
+      u32x4 c3, cg, cl;
+#pragma unroll
+      for (int wi = 0; wi < 4; ++wi) {
+        const int rt = c < 4 ? c : (4 * (c - 4) + wi) / 3, r = c < 4 ? 2 * wi : 8 + 2 * ((4 * (c - 4) + wi) % 3);
+        const Words o = eword(rt, r, f[rt], y, wi);
+        c3[wi] = o.g3; cg[wi] = o.gg; cl[wi] = o.gl;
+        if (wi & 1) __builtin_amdgcn_sched_barrier(0);     // two words at a time
+      }
+      SPILL_ST(spill_at(i - 1, G_3, c), c3);
+      SPILL_ST(spill_at(i - 1, G_G, c), cg);
+      SPILL_ST(spill_at(i - 1, G_LIN, c), cl);
       __builtin_amdgcn_sched_barrier(0);
     };
-    // The loads of the next pair's fusion adjoint and of the next operand chunk are in flight while the current ones are
-    // worked on (the weight ring is empty meanwhile: it is refilled in front of the barrier that ends the phase).
+    // The loads of the next pair's fusion adjoint and of the next chunk are in flight while the current ones are worked on
+    // (the weight ring is empty meanwhile: it is refilled in front of the barrier that ends the phase).  The four lower
+    // chunks (registers 0 .. 7 of a tile) follow their pair's fusion adjoint, the three packed upper ones come last.
     {
       AIn xa, xb;
       EIn ya, yb;
-      PairAdj f;
+      PairAdj f[RT];
       load_a(0, xa, t);
       if (trans) {
-        load_e(0, 0, ya, i);
+        load_e(0, ya, i);
         if (!masks_ahead) load_masks(i);              // (the first processed step)
       }
       load_a(1, xb, t);
       __builtin_amdgcn_sched_barrier(0);
-      f = fuse(0, xa);
+      f[0] = fuse(0, xa);
       __builtin_amdgcn_sched_barrier(0);
       load_a(2, xa, t);
       if (trans) {
         __syncthreads();                              // images: every wave is past D3 of the step before
         regeo();
-        load_e(0, 1, yb, i);
+        load_e(1, yb, i);
         __builtin_amdgcn_sched_barrier(0);
-        eadj(0, 0, f, ya);
-        load_e(1, 0, ya, i);
-        __builtin_amdgcn_sched_barrier(0);
-        eadj(0, 1, f, yb);
+        echunk(0, f, ya);
       }
       STAMP(1);
-      f = fuse(1, xb);
+      f[1] = fuse(1, xb);
       __builtin_amdgcn_sched_barrier(0);
       load_a(3, xb, t);
       if (trans) {
-        load_e(1, 1, yb, i);
+        load_e(2, ya, i);
         __builtin_amdgcn_sched_barrier(0);
-        eadj(1, 0, f, ya);
-        load_e(2, 0, ya, i);
-        __builtin_amdgcn_sched_barrier(0);
-        eadj(1, 1, f, yb);
+        echunk(1, f, yb);
       }
       STAMP(2);
-      f = fuse(2, xa);
+      f[2] = fuse(2, xa);
       __builtin_amdgcn_sched_barrier(0);
       if (trans) {
-        load_e(2, 1, yb, i);
+        load_e(3, yb, i);
         __builtin_amdgcn_sched_barrier(0);
-        eadj(2, 0, f, ya);
-        load_e(3, 0, ya, i);
-        __builtin_amdgcn_sched_barrier(0);
-        eadj(2, 1, f, yb);
+        echunk(2, f, ya);
       }
       STAMP(3);
-      f = fuse(3, xb);
+      f[3] = fuse(3, xb);
       __builtin_amdgcn_sched_barrier(0);
       if (trans) {
-        load_e(3, 1, yb, i);
+        load_e(4, ya, i);
         __builtin_amdgcn_sched_barrier(0);
-        eadj(3, 0, f, ya);
+        echunk(3, f, yb);
+        load_e(5, yb, i);
         __builtin_amdgcn_sched_barrier(0);
-        eadj(3, 1, f, yb);
+        echunk(4, f, ya);
+        load_e(6, ya, i);
+        __builtin_amdgcn_sched_barrier(0);
+        echunk(5, f, yb);
+        __builtin_amdgcn_sched_barrier(0);
+        echunk(6, f, ya);
       }
     }
     STAMP(4);
@@ -575,22 +577,27 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     // (the 64 noise registers of the four tiles beside v0, the ring and the A operands were 30 registers too many: the
     //  allocator parked that much of the step's state in scratch around D3 -- 1.8 GB of scratch traffic per call.  Two
     //  tiles' noise is requested in front of the contractions, the other two's behind them, under the first two's sums.)
-    u32x4 ep[8];
+    const gw_t nz = noise + ((size_t)t_prev * NWAVE) * NOISE_SLOTS * 64 + lane;
+    u32x4 ep[7];                                       // tiles 0, 1 (slots 3 rt + q) and the shared slot of register 12
 #pragma unroll
-    for (int u = 0; u < 8; ++u) ep[u] = park_ld(noise + (((size_t)t_prev * NWAVE) * 16 + u) * 64 + lane);
+    for (int u = 0; u < 6; ++u) ep[u] = park_ld(nz + u * 64);
+    ep[6] = park_ld(nz + 12 * 64);
     STAMP(13);
     gemm4(v0, smem + img + arow, ts, W(T_W1N), W(T_WL), ring);
     STAMP(14);
     gemm4<false>(v0, smem + arow, ts, W(T_WL), W(T_WL), ring);
     STAMP(15);
     // sums over the particles of d/dz, d/dz * eps and eps
-    auto sums = [&](int rt, const u32x4 (&e4s)[8], int base) __attribute__((always_inline)) {
+    auto sums = [&](int rt, const u32x4* e4s, float e12) __attribute__((always_inline)) {
       const bool valid = (pv >> rt) & 1u;
       float sa = 0.f, sb = 0.f, sc = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const u32x4 e4 = e4s[base + q];
-        const float e[4] = {__uint_as_float(e4.x), __uint_as_float(e4.y), __uint_as_float(e4.z), __uint_as_float(e4.w)};
+        float e[4] = {e12, 0.f, 0.f, 0.f};
+        if (q < 3) {
+          const u32x4 e4 = e4s[q];
+          e[0] = __uint_as_float(e4.x); e[1] = __uint_as_float(e4.y); e[2] = __uint_as_float(e4.z); e[3] = __uint_as_float(e4.w);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const bool live = valid && 8 * q + j < kh;
@@ -600,13 +607,13 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       }
       adj_a[rt] = half_sum(sa); adj_b[rt] = half_sum(sb); se[rt] = half_sum(sc);
     };
-    u32x4 ep2[8];
+    u32x4 ep2[6];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) ep2[u] = park_ld(noise + (((size_t)t_prev * NWAVE) * 16 + 8 + u) * 64 + lane);
+    for (int u = 0; u < 6; ++u) ep2[u] = park_ld(nz + (6 + u) * 64);
     __builtin_amdgcn_sched_barrier(0);
-    sums(0, ep, 0); sums(1, ep, 4);
+    sums(0, ep, __uint_as_float(ep[6].x)); sums(1, ep + 3, __uint_as_float(ep[6].y));
     __builtin_amdgcn_sched_barrier(0);
-    sums(2, ep2, 0); sums(3, ep2, 4);
+    sums(2, ep2, __uint_as_float(ep[6].z)); sums(3, ep2 + 3, __uint_as_float(ep[6].w));
     STAMP(10);
   }
 
@@ -631,10 +638,10 @@ bool b4_shape(const mdmm_sweep_t* a) {
 int64_t b4_carve(const mdmm_sweep_t* a, WideGeo* g, WideWs* ws) {
   const int64_t n_pairs = (int64_t)a->P * a->B;
   const int64_t n_wg = (n_pairs + RT - 1) / RT, n_step = a->T - 1;
-  const int64_t items = n_wg * n_step * 2;                  // half-items of 64 rows
+  const int64_t items = n_wg * n_step;                      // 128-row items of P7 arrays
   int split = 42;                                   // 6 * 42 = 252 workgroups: one round of the 256 CUs
-  if (split > items) split = items > 0 ? (int)items : 1;
-  const int64_t b_spill = up256(items * G_ARR * ARR_U4 * 16);
+  if (split > 2 * items) split = items > 0 ? (int)(2 * items) : 1;
+  const int64_t b_spill = up256(items * G_ARR * P7_U4 * 16);
   const int64_t b_db = up256((int64_t)split * 6 * WD * 4), b_dz = up256(n_wg * 2 * WD * 4);
   const int64_t b_slab = up256((int64_t)split * 6 * WD * WD * 4);
   if (g) {
@@ -649,7 +656,7 @@ int64_t b4_carve(const mdmm_sweep_t* a, WideGeo* g, WideWs* ws) {
     ws->db = reinterpret_cast<float*>(p); p += b_db;
     ws->dz0 = reinterpret_cast<float*>(p); p += b_dz;
     ws->slab = reinterpret_cast<float*>(p);
-    ws->xop = nullptr;
+    ws->xop = nullptr; ws->p7 = 0;
     ws->n_wg = n_wg; ws->n_step = n_step; ws->split = split;
   }
   return b_spill + b_db + b_dz + b_slab;
@@ -676,13 +683,13 @@ int mdmm_wide_sweep_bwd4(const mdmm_sweep_t* a, hipStream_t stream) {
   WideGeo g; WideWs ws; FwdPark park;
   if (a->wide_ws_bytes < b4_carve(a, &g, &ws)) return MDMM_E_ARG;
   fwd_park_carve(a, &park);
-  ws.xop = park.xop;
+  ws.xop = park.item;
+  ws.p7 = 1;
   const int lds = 3 * RT * a->K * RS;
   auto kern = a->K == 25 ? wide_bwd4_kernel<25> : wide_bwd4_kernel<0>;
   if (int rc = mdmm_lds_attr_fn((const void*)kern, (size_t)lds)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)ws.n_wg), dim3(NTHR), lds, stream, *a, g, ws, park);
   if (int rc = (int)hipGetLastError()) return rc;
   WideWs w2 = ws;
-  w2.n_step = ws.n_step * 2;                // the contraction walks half-items
   return wide_wgrad_launch(w2, false, 4, a->dw_partial, stream);
 }

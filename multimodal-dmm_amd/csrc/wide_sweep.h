@@ -108,8 +108,9 @@ enum Spill { S_Z = 0, S_HG, S_HN, S_NL, S_GHG, S_GHN, S_GLIN, S_GG, S_GN, S_G3, 
 
 // workspace of one backward sweep (device pointers into mdmm_sweep_t.wide_ws)
 struct WideWs {
-  uint4* spill;      // [workgroup][step][N_SPILL][wave][chunk][lane]  (xop set: [..][G_ARR][..], the G side only)
-  const uint4* xop;  // the X-side operand chunks where the forward sweep kept them (FwdPark.xop), or null
+  uint4* spill;      // [workgroup][step][N_SPILL][wave][chunk][lane]  (xop set: the G side only, [..][G_ARR][..] or P7 arrays)
+  const uint4* xop;  // the X-side operand chunks where the forward sweep kept them (FwdPark.item / FwdParkK1.xop), or null
+  int p7;            // xop and spill hold P7 arrays (K-particle park): wide_wgrad7_kernel
   float* db;         // [split][6][256] bias-gradient partial sums (written by the wgrad kernel)
   float* dz0;        // [workgroup][2][256] d/d(mu0, sigma0) partial sums
   float* slab;       // [split][6][256][256] weight-gradient partial sums
@@ -118,55 +119,81 @@ struct WideWs {
 };
 
 // What the K-particle forward sweep keeps for the one-round backward (mdmm_sweep_t.fwd_park: sweep_wide_bwd4.hip reads
-// it, wide_wgrad_kernel contracts the X-side operands where they lie).  A workgroup = four (pass, sequence) pairs,
-// one 32-row tile each; one slot = 64 lanes x 16 B of one wave.  Three regions:
-//   noise [workgroup][time T][wave][16][lane]                 fp32 draws of step t: slot 4 rt + q = registers 4q .. 4q+3 of tile rt
-//   xop   [workgroup][step T-1][half 2][X_ARR][wave][4][lane]   bf16 operand chunks (acc_chunk) of the rows of the transition
-//                                                             into processed step s + 1: wide_wgrad_kernel<false, 4>'s half-items
-//   eop   [workgroup][step T-1][wave][EP_SLOTS][lane]           what the elementwise adjoint of that transition reads back
+// it, wide_wgrad7_kernel contracts the X-side operands where they lie).  A workgroup = four (pass, sequence) pairs,
+// one 32-row tile each, K <= 25 particles a pair: of a lane's sixteen accumulator registers per tile only 0 .. 12 can
+// hold live rows (row = 8 (reg / 4) + reg % 4 + 4 h < 25), so a bf16 array of the four tiles is kept as SEVEN 16-byte
+// chunks per lane instead of eight ("P7"):
+//   chunk rt (0 .. 3)   registers 0 .. 7 of tile rt        = words 0 .. 3 (word k = registers 2k, 2k+1)
+//   chunk 4 + j (j < 3) words 4j .. 4j+3 of the flat list (tile, word 4 + k), k < 3: registers 8 .. 13 of the four tiles
+// Both operands of the weight-gradient contraction use the same order, so lane half h, element e of a chunk is the same
+// row on both sides (register 13 and, in the upper half-wave, register 12 are dead rows: zero on the G side).  Per
+// wave the chunks lie as [sub 0: 4 chunks][sub 1: 3 chunks] with the waves of a sub-block together (p7_off): the two
+// sub-items wide_wgrad7_kernel stages in turn.  One slot = 64 lanes x 16 B of one wave.  Regions:
+//   noise [workgroup][time T][wave][NOISE_SLOTS][lane]   fp32 draws of step t: slot 3 rt + q (q < 3) = registers 4q .. 4q+3
+//                                                       of tile rt, slot 12 = register 12 of the four tiles
+//   item  [workgroup][step T-1]: PK_ARR P7 arrays (the X-side operands z, relu hidden layers, nl of the rows of the
+//                                transition into processed step s + 1; the gate as gate_code, the mean before the product
+//                                with the global prior, the std head's pre-activation), then [wave][2][lane] relu masks
 enum XArr { X_Z = 0, X_HG, X_HN, X_NL, X_ARR };
+enum PkArr { PK_GATE = X_ARR, PK_MUQ, PK_PRE, PK_ARR };         // arrays of one parked item: the four X arrays first
 enum GArr { G_HG = 0, G_HN, G_LIN, G_G, G_N, G_3, G_ARR };       // the backward's own spill, in weight-gradient block order
-enum EopSlot {
-  EP_GATE = 0,       //  8: the gate as bf16 codes (gate_code), slot 2 rt + s = registers 8s .. 8s+7 of tile rt
-  EP_MUQ = 8,        //  8: mean of q'(z | z_prev) before the product with the global prior (bf16, as the gate)
-  EP_PRE = 16,       //  8: pre-activation of the std head, bias included (bf16)
-  EP_MASK = 24,      //  2: relu masks of the gate / nl hidden layer, one 16-bit word per tile
-  EP_SLOTS = 26
-};
-struct FwdPark { uint4 *noise, *xop, *eop; };
+struct FwdPark { uint4 *noise, *item; };
 constexpr int PARK_PAIRS = 4;                          // pairs per workgroup of the kernels that share the park
-constexpr int XOP_ARR_U4 = NWAVE * 4 * 64;             // uint4 per operand array of one half-item
+constexpr int NOISE_SLOTS = 13;
+constexpr int P7_SUB1 = NWAVE * 4 * 64;                // uint4 in front of an array's second sub-block
+constexpr int P7_U4 = NWAVE * 7 * 64;                  // uint4 per P7 array
+constexpr int PK_MASK_U4 = PK_ARR * P7_U4;             // the masks' offset inside an item
+constexpr int PK_ITEM_U4 = PK_MASK_U4 + NWAVE * 2 * 64;
+__host__ __device__ constexpr int p7_off(int wave, int c) {
+  return c < 4 ? (wave * 4 + c) * 64 : P7_SUB1 + (wave * 3 + (c - 4)) * 64;
+}
 // carve mdmm_sweep_t.fwd_park; returns the bytes needed
 __host__ __device__ inline int64_t fwd_park_carve(const mdmm_sweep_t* a, FwdPark* pk) {
   const int64_t n_wg = ((int64_t)a->P * a->B + PARK_PAIRS - 1) / PARK_PAIRS, n_step = a->T - 1;
-  const int64_t b_noise = n_wg * a->T * NWAVE * 16 * 64 * 16;
-  const int64_t b_xop = n_wg * n_step * 2 * X_ARR * XOP_ARR_U4 * 16;
-  const int64_t b_eop = n_wg * n_step * NWAVE * EP_SLOTS * 64 * 16;
+  const int64_t b_noise = n_wg * a->T * NWAVE * NOISE_SLOTS * 64 * 16;
+  const int64_t b_item = n_wg * n_step * PK_ITEM_U4 * 16;
   if (pk) {
     char* p = reinterpret_cast<char*>(a->fwd_park);
     pk->noise = reinterpret_cast<uint4*>(p); p += b_noise;
-    pk->xop = reinterpret_cast<uint4*>(p); p += b_xop;
-    pk->eop = reinterpret_cast<uint4*>(p);
+    pk->item = reinterpret_cast<uint4*>(p);
   }
-  return b_noise + b_xop + b_eop;
+  return b_noise + b_item;
 }
 
 // streaming stores into the park (written once, read by another kernel much later)
 __device__ __forceinline__ void park_st(gs_ptr p, const uint4& v) { __builtin_nontemporal_store(__builtin_bit_cast(u32x4g, v), p); }
-// one accumulator array of four row tiles -> its bf16 operand chunks of the two half-items (`it` = this lane's
-// pointer of the item's first half, array `arr`)
-__device__ __forceinline__ void park_x(gs_ptr it, int arr, const f32x16 (&v)[4]) {
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-      park_st(it + (((rt >> 1) * X_ARR + arr) * XOP_ARR_U4 + ((rt & 1) * 2 + s) * 64), acc_chunk<false>(v[rt], s));
+__device__ __forceinline__ unsigned bf16_pair(float a, float b) {
+  bf16x2 pk; pk[0] = (__bf16)a; pk[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, pk);
 }
-// ... together with the array's LDS image (store_image): every bf16 word is formed once and goes both ways, tile by
-// tile (as two passes the second one's conversions are all hoisted in front of its stores: 32 more live registers)
-__device__ __forceinline__ void store_image_park(char* img, const f32x16 (&v)[4], int wave, int lane, gs_ptr it, int arr) {
+// One array of four row tiles -> its P7 chunks.  `arr` = the array's base + this lane (wave-uniform base); f(rt, r) =
+// element of register r of tile rt.  Tile by tile (the lower chunk leaves at once, the three upper words wait in 12
+// registers for the packed chunks): as one pass per chunk the conversions are all hoisted in front of the stores.
+template <class F>
+__device__ __forceinline__ void park_p7(gs_ptr arr, int wave, F f) {
+  unsigned hw[12];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    uint4 c;
+    c.x = bf16_pair(f(rt, 0), f(rt, 1)); c.y = bf16_pair(f(rt, 2), f(rt, 3));
+    c.z = bf16_pair(f(rt, 4), f(rt, 5)); c.w = bf16_pair(f(rt, 6), f(rt, 7));
+    park_st(arr + p7_off(wave, rt), c);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) hw[3 * rt + k] = bf16_pair(f(rt, 8 + 2 * k), f(rt, 9 + 2 * k));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    uint4 c; c.x = hw[4 * j]; c.y = hw[4 * j + 1]; c.z = hw[4 * j + 2]; c.w = hw[4 * j + 3];
+    park_st(arr + p7_off(wave, 4 + j), c);
+  }
+}
+// ... together with the array's LDS image (store_image: all 32 rows of every tile): every bf16 word is formed once and
+// goes both ways
+__device__ __forceinline__ void store_image_park(char* img, const f32x16 (&v)[4], int wave, int lane, gs_ptr arr) {
   constexpr int RS = Op<false>::RS;
   char* base = img + 4 * (lane >> 5) * RS + (32 * wave + (lane & 31)) * 2;
+  unsigned hw[12];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
     unsigned w[8];
@@ -179,21 +206,15 @@ __device__ __forceinline__ void store_image_park(char* img, const f32x16 (&v)[4]
       *reinterpret_cast<__bf16*>(p + RS) = pk[1];
       w[k] = __builtin_bit_cast(unsigned, pk);
     }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      uint4 c; c.x = w[4 * s]; c.y = w[4 * s + 1]; c.z = w[4 * s + 2]; c.w = w[4 * s + 3];
-      park_st(it + (((rt >> 1) * X_ARR + arr) * XOP_ARR_U4 + ((rt & 1) * 2 + s) * 64), c);
-    }
+    uint4 c; c.x = w[0]; c.y = w[1]; c.z = w[2]; c.w = w[3];
+    park_st(arr + p7_off(wave, rt), c);
+    hw[3 * rt] = w[4]; hw[3 * rt + 1] = w[5]; hw[3 * rt + 2] = w[6];
     __builtin_amdgcn_sched_barrier(0);
   }
-}
-// ... as bf16 chunks in slots 2 rt + s (`it` = this lane's pointer of the first slot)
-__device__ __forceinline__ void park_e(gs_ptr it, const f32x16 (&v)[4]) {
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) park_st(it + (2 * rt + s) * 64, acc_chunk<false>(v[rt], s));
-    __builtin_amdgcn_sched_barrier(0);
+  for (int j = 0; j < 3; ++j) {
+    uint4 c; c.x = hw[4 * j]; c.y = hw[4 * j + 1]; c.z = hw[4 * j + 2]; c.w = hw[4 * j + 3];
+    park_st(arr + p7_off(wave, 4 + j), c);
   }
 }
 
