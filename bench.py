@@ -640,6 +640,14 @@ def run(cfg, args, world, rank, device, graph):
         del flat_r
     n_probe = args.steps
     timing_note = 'HIP events on the launch stream around every library call of the timed steps'
+    loss_val = float(loss)
+    if timer is None and graph:
+        # the eager probe steps below allocate a step's worth of memory of their own: the graphs' private pool goes first
+        # (cfg5 at its per-GPU batch: 133 GB of pool + as much again did not fit the 288 GB)
+        import gc
+        graphed = step = loss = None
+        gc.collect()
+        torch.cuda.empty_cache()
     if timer is None:
         # Graph replay leaves no place for events between nodes: re-run the same step eagerly
         # (not part of `value`) with HIP events around every library call.  Every rank takes the
@@ -668,7 +676,6 @@ def run(cfg, args, world, rank, device, graph):
         allreduce_ms = round(sorted(e0.elapsed_time(e1) for e0, e1 in ev)[2], 4)
         bucket.release()
         dist.barrier()
-    loss_val = float(loss)
     if rank != 0:
         return None
     spans = timer.summary()
