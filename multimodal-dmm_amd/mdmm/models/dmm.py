@@ -591,13 +591,15 @@ class MultiDMM(MultiDGTS):
         mask_f.record_stream(side); mask_kld.record_stream(side)
         side.wait_stream(main)
         # the two modes as two independent loss terms, each with its own decoder calls, on two streams
-        with torch.cuda.stream(side):
+        swap = os.environ.get('MDMM_TMP_SWAP', '0') == '1'
+        with (contextlib.nullcontext() if swap else torch.cuda.stream(side)):
             loss_f = f_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
                                               loss_mods, t_max, b_dim, f_mode, sample, sample_init, flt_particles,
                                               smt_particles)
-        loss_s = s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
-                                          loss_mods, t_max, b_dim, s_mode, sample, sample_init, train_particles,
-                                          smt_particles)
+        with (torch.cuda.stream(side) if swap else contextlib.nullcontext()):
+            loss_s = s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
+                                              loss_mods, t_max, b_dim, s_mode, sample, sample_init, train_particles,
+                                              smt_particles)
         main.wait_stream(side)
         loss = loss_f + loss_s
         if loss_m is not None:
