@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 28
+#define MDMM_ABI_VERSION 29
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -651,6 +651,11 @@ typedef struct mdmm_conv {
   const float* lazy_beta;
   const float* lazy_means;
   int32_t lazy_group_n, lazy_relu;
+  /* mdmm_conv_down with a bf16 small side: the small side written is the gradient that reaches a ReLU's OUTPUT
+   * (common.py:158-175: nn.Sequential(nn.Linear(z_dim, feat_dim), nn.ReLU()) in front of the first Deconv); small_relu_of =
+   * that output, (N, CS, S, S) bf16 -- the ReLU's adjoint is applied as the values are stored (0 where small_relu_of <= 0,
+   * aten::threshold_backward's test), one pass over the 4096-wide gradient less.  NULL: none.  */
+  const void* small_relu_of;
 } mdmm_conv_t;
 int mdmm_conv_supported(const mdmm_conv_t* args);
 int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* args, int up);

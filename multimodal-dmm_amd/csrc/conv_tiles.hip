@@ -602,8 +602,20 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
     b0[r] = a.bias ? a.bias[m] : 0.f;
     b1[r] = (a.bias && G::MT_S > 1) ? a.bias[32 + m] : 0.f;
   }
+  // small_relu_of: the ReLU adjoint of the layer in front on the values as they are stored.  The signs this wave's FIRST
+  // job needs are requested here, at the head of the image's iteration -- in front of the staging loads and (LAZY) stores,
+  // which a request in the epilogue would queue behind (memory operations retire in order) -- and kept as one bit each
+  constexpr int NT = NPIX / 32;
+  const __bf16* const relu_of = SB ? reinterpret_cast<const __bf16*>(a.small_relu_of) : nullptr;
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
     const size_t src0 = (size_t)n * cb * BPIX;
+    const size_t dst0 = (size_t)n * CS * NPIX;
+    __bf16 rv[RV];
+    if (relu_of && wave < NT * G::MT_S) {
+      const int tile = wave % NT, mt = wave / NT, p = tile * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < RV; ++r) rv[r] = relu_of[dst0 + (size_t)(32 * mt + acc_row(r) + 4 * h) * NPIX + p];
+    }
     if constexpr (STATS) {
       const int g = n / a.out_group_n;
       if (g != cur_g) {
@@ -681,9 +693,12 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
         *reinterpret_cast<uint4*>(at + 3 * G::DN_PS) = __builtin_bit_cast(uint4, v3);
       }
     }
+    unsigned dead0 = 0;                   // bit r: the first job's register r lands on a ReLU output <= 0
+    if (relu_of && wave < NT * G::MT_S) {
+#pragma unroll
+      for (int r = 0; r < RV; ++r) dead0 |= ((float)rv[r] <= 0.f) ? (1u << r) : 0u;
+    }
     __syncthreads();
-    const size_t dst0 = (size_t)n * CS * NPIX;
-    constexpr int NT = NPIX / 32;
     for (int job = wave; job < NT * G::MT_S; job += 4) {
       const int tile = job % NT, mt = job / NT;
       const int p = tile * 32 + (lane & 31), y = p / S, x = p % S;
@@ -708,7 +723,11 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
 #pragma unroll
       for (int r = 0; r < RV; ++r) {
         const int m = 32 * mt + acc_row(r) + 4 * h;
-        const float v = acc[r] + ((G::MT_S > 1 && mt) ? b1[r] : b0[r]);
+        float v = acc[r] + ((G::MT_S > 1 && mt) ? b1[r] : b0[r]);
+        if (relu_of) {                      // (later jobs of a wave, the 16 x 16 and 32 x 32 layers: fetched here)
+          const bool dead = job == wave ? ((dead0 >> r) & 1u) != 0 : (float)relu_of[dst0 + (size_t)m * NPIX + p] <= 0.f;
+          if (dead) v = 0.f;
+        }
         store1<SB>(a.small, dst0 + (size_t)m * NPIX + p, v);
         if constexpr (STATS) {              // of the value as stored
           const float vr = SB ? (float)(__bf16)v : v;
@@ -1273,6 +1292,7 @@ int down_parts(const mdmm_conv_t* a) {
 }
 template <int S, int CS, int CB, int KS>
 int run_down(const mdmm_conv_t* a, hipStream_t st) {
+  if (a->small_relu_of && io_of(a) == 0) return MDMM_E_ARG;       // (a bf16 small side)
   if (a->lazy_dy) return run_down_lazy<S, CS, CB, KS>(a, st);
   if (a->in_mean || a->out_stats) {
     const int io = io_of(a);

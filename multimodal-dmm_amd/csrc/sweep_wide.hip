@@ -520,6 +520,10 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
       [[maybe_unused]] float e12[RT];       // (park: the draws of register 12 of the tiles)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) e12[rt] = 0.f;
+      // K = 25: row 24 is the one live row of a tile's last register group -- the four tiles' draws of it as one call
+      const bool one12 = RT == 4 && g.TPP == 1 && K == 25;
+      float e24[4] = {0.f, 0.f, 0.f, 0.f};
+      if (one12 && (!last || a.samples)) eps_rows(a, noff, t_term, rowbase + 24, 32, n, e24);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         regeo();
@@ -546,7 +550,8 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float e[4] = {0.f, 0.f, 0.f, 0.f};
-          if (need && kb + 8 * q < K) eps_group(a, noff, t_term, rowbase + 32 * rt + 8 * q + 4 * h, n, e);
+          if (q == 3 && one12) e[0] = need ? e24[rt & 3] : 0.f;       // (rows 25 .. 31 and the upper half: masked below)
+          else if (need && kb + 8 * q < K) eps_group(a, noff, t_term, rowbase + 32 * rt + 8 * q + 4 * h, n, e);
           if (pr.p >= 0 && kb + 8 * q + 8 <= K) {          // whole register group live (uniform)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

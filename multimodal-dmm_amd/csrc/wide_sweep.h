@@ -95,6 +95,27 @@ __device__ __forceinline__ void eps_group(const A& a, uint64_t noff, uint64_t t_
   quad_transpose(e, u);
 }
 
+// The same draw for four rows a stride apart: e[j] = eps(row of rowbase[j * stride], feature n).  K = 25 leaves one live
+// row (24) in the last register group of a 32-row tile: its draw for the FOUR tiles of a wave is one Philox call here
+// instead of one per tile with seven of eight values dead (same counters, same values: a counter holds four features of
+// one row).
+template <class A, class RB>
+__device__ __forceinline__ void eps_rows(const A& a, uint64_t noff, uint64_t t_term, RB rowbase_0, int stride, int n,
+                                         float (&e)[4]) {
+  if (a.eps) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t rb = rowbase_0[j * stride];
+      e[j] = (rb != ~0ull) ? a.eps[rb + t_term + n] : 0.f;
+    }
+    return;
+  }
+  const int u = n & 3;
+  const uint64_t rb = rowbase_0[u * stride];
+  philox_normal4(a.seed, noff, (rb + t_term + (uint64_t)(n & ~3)) >> 2, e);
+  quad_transpose(e, u);
+}
+
 // per-tile sums -> total of the pair the tile belongs to (TPP = 1, 2 or 4 tiles per pair)
 template <int RT>
 __device__ __forceinline__ float pair_total(const float (&s)[RT], int rt, int tpp) {

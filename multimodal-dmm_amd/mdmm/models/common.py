@@ -113,10 +113,10 @@ class _ConvBlock(nn.Module):
         nn.init.xavier_uniform_(layer.weight)
 
     @staticmethod
-    def _conv_nobias(layer, x):
+    def _conv_nobias(layer, x, owed=None):
         from .. import ops
         if ops.conv_tiles_supported(layer, x):          # own bf16-operand kernels (csrc/conv_tiles.hip)
-            return ops.conv_tiles(layer, x, bias=False)
+            return ops.conv_tiles(layer, x, bias=False, owed=owed)
         if ops.conv1d_tiles_supported(layer, x):        # the audio pyramids (csrc/conv1d.hip, fp32)
             return ops.conv1d_tiles(layer, x, bias=False)
         if x.dtype != layer.weight.dtype:                # (a bf16-stored activation reaching a library layer)
@@ -127,7 +127,9 @@ class _ConvBlock(nn.Module):
         return fn(x, layer.weight, None, layer.stride, layer.padding, layer.output_padding,
                   layer.groups, layer.dilation)
 
-    def forward(self, x):
+    def forward(self, x, owed=None):
+        """owed: the ReLU-epilogue linear output x is a view of, whose adjoint a Deconv on the tile kernels applies in its
+        input-gradient kernel (ops.take_owed_relu); ignored on every other route."""
         from .. import ops
         pending = x if isinstance(x, ops.DeferredNorm) else None
         if pending is not None:
@@ -158,9 +160,9 @@ class _ConvBlock(nn.Module):
             if ops.batchnorm_relu_supported(x, bn) and x.is_cuda:
                 if ops.BN_DEFER and isinstance(layer, (nn.ConvTranspose2d, nn.Conv2d)) and ops.conv_tiles_supported(layer, x) \
                         and ops.ACT_STORAGE is torch.bfloat16:
-                    y_pre, part = ops.conv_tiles(layer, x, bias=False, stats_for=bn)
+                    y_pre, part = ops.conv_tiles(layer, x, bias=False, stats_for=bn, owed=owed)
                     return ops.DeferredNorm(y_pre, bn, layer.bias, part)
-                y_pre = self._conv_nobias(layer, x)
+                y_pre = self._conv_nobias(layer, x, owed)
                 return ops.batchnorm_relu(y_pre, bn, shift=layer.bias)
             # evaluation mode (running statistics) and CPU: the stock modules, in the weights' precision
             if x.dtype != layer.weight.dtype:
@@ -175,7 +177,7 @@ class _ConvBlock(nn.Module):
             return self.net[2](bn(layer(x)))
         from .. import ops
         if ops.conv_tiles_supported(self.net, x):
-            return ops.conv_tiles(self.net, x)
+            return ops.conv_tiles(self.net, x, owed=owed)
         if ops.conv1d_tiles_supported(self.net, x):
             return ops.conv1d_tiles(self.net, x)
         if x.dtype != self.net.weight.dtype:
@@ -287,14 +289,17 @@ class _ProbDecoder(nn.Module):
         first = first[0] if isinstance(first, nn.Sequential) else first
         # bf16-stored activations only into a stack the tile kernels take (the audio stacks stay fp32)
         act = ops.conv_chain_takes(first, (z.shape[0],) + tuple(self.feat_shape)) if z.is_cuda else False
+        owed = None
         if isinstance(self.z_to_feat[1], nn.ReLU):       # (the ReLU in the GEMM's epilogue on the own kernels)
-            x = ops.plug_linear(self.z_to_feat[0], z, act_out=act, relu=True).view(-1, *self.feat_shape)
+            owed = ops.plug_linear(self.z_to_feat[0], z, act_out=act, relu=True)
+            x = owed.view(-1, *self.feat_shape)
         else:
             x = self.z_to_feat[1](ops.plug_linear(self.z_to_feat[0], z, act_out=act)).view(-1, *self.feat_shape)
-        # (conv blocks hand their BatchNorm + ReLU to the next Deconv where that one normalises on the fly)
+        # (conv blocks hand their BatchNorm + ReLU to the next Deconv where that one normalises on the fly; the first one
+        # applies the adjoint of z_to_feat's ReLU in its input-gradient kernel where it runs on the tile kernels)
         with ops.bn_defer(z.is_cuda):
-            for layer in list(self.deconv_stack)[:-1]:
-                x = layer(x)
+            for k, layer in enumerate(list(self.deconv_stack)[:-1]):
+                x = layer(x, owed) if (k == 0 and owed is not None and isinstance(layer, _ConvBlock)) else layer(x)
         if isinstance(x, ops.DeferredNorm):
             x = x.tensor()
         if logits:      # everything but the final nn.Sigmoid (for the fused sigmoid + BCE loss)

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 28
+ABI_VERSION = 29
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -180,7 +180,7 @@ class Conv(C.Structure):
                  ('reserved', C.c_int32)] +
                 [('bst_dy', _P), ('bst_part', _P)] +
                 [(n, _P) for n in ('lazy_dy', 'lazy_x', 'lazy_mean', 'lazy_invstd', 'lazy_gamma', 'lazy_beta', 'lazy_means')] +
-                [('lazy_group_n', C.c_int32), ('lazy_relu', C.c_int32)])
+                [('lazy_group_n', C.c_int32), ('lazy_relu', C.c_int32), ('small_relu_of', _P)])
 
 
 class Conv1d(C.Structure):

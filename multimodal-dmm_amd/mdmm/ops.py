@@ -1641,6 +1641,7 @@ class _LinearTilesFn(torch.autograd.Function):
         # relu: max(., 0) in the kernel's epilogue (the nn.ReLU behind z_to_feat: one pass over the 4096-wide
         # activation less); its adjoint masks the incoming gradient with y > 0 first
         ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.relu_owed, ctx.relu_taken = bool(relu), False        # (take_owed_relu)
         ctx.has_bias, ctx.heads = bias is not None, heads
         return y
 
@@ -1649,7 +1650,7 @@ class _LinearTilesFn(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         if g is None:
             return None, None, None, None, None
-        if y is not None:
+        if y is not None and not ctx.relu_taken:      # (taken: the producer of g applied it, take_owed_relu)
             g = torch.ops.aten.threshold_backward(g.contiguous(), y, 0)
         g = _rows(g)
         w = _rows(weight.detach())
@@ -1674,6 +1675,24 @@ class _LinearTilesFn(torch.autograd.Function):
 
 def linear_tiles(x, weight, bias):
     return _LinearTilesFn.apply(x, weight, bias)
+
+
+# The ReLU in a linear layer's epilogue owes its adjoint -- a pass over the gradient of its output.  When that output goes
+# straight into a Deconv on the tile kernels (the decoders' z_to_feat -> deconv_stack[0], common.py:147-175), the Deconv's
+# input-gradient kernel applies it while it stores that gradient (mdmm_conv_t.small_relu_of): the caller names the debtor
+# (conv_tiles(..., owed=y)), the Deconv TAKES the debt and the linear's backward skips its threshold pass.  A tensor that is
+# not a view of that output, or a layer that does not run on the tile kernels, leaves everything as it was.
+def take_owed_relu(x, y):
+    """y = the output of plug_linear(..., relu=True), x = the tensor a Deconv is about to consume: if x is y (or a view of
+    all of it) and the ReLU's adjoint is still owed, mark it taken -> True (the caller masks the gradient of x with x > 0)."""
+    node = y.grad_fn if y is not None else None
+    if node is None or not getattr(node, 'relu_owed', False) or getattr(node, 'relu_taken', False):
+        return False
+    if x.dtype != torch.bfloat16 or y.dtype != x.dtype or x.numel() != y.numel() or x.data_ptr() != y.data_ptr() \
+            or not x.is_contiguous():
+        return False
+    node.relu_taken = True
+    return True
 
 
 def plug_linear(layer, x, act_out=False, relu=False):
@@ -2226,8 +2245,9 @@ class _ConvTilesFn(torch.autograd.Function):
     big), else Conv2d(k3,s2,p1) (big -> small).  weight is torch's [CS][CB][KS][KS] either way."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, transposed, stats_groups=0):
+    def forward(ctx, x, weight, bias, transposed, stats_groups=0, relu_in=False):
         ctx.set_materialize_grads(False)
+        ctx.relu_in = bool(relu_in)       # x = a ReLU's output whose adjoint this layer's input gradient applies (take_owed_relu)
         x_needs_grad = x.requires_grad
         x = _act(x)
         n, ks = x.shape[0], weight.shape[-1]
@@ -2274,7 +2294,7 @@ class _ConvTilesFn(torch.autograd.Function):
     def backward(ctx, gy, _gpart=None):
         x, weight = ctx.saved_tensors
         if gy is None:                  # (set_materialize_grads(False): an output that reaches no loss term)
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         lazy_in = _lazy_take(gy)
         gy = _act(gy)
         n, ks = x.shape[0], weight.shape[-1]
@@ -2292,9 +2312,11 @@ class _ConvTilesFn(torch.autograd.Function):
                 _lazy_conv_args(a, lazy_in)             # the BatchNorm adjoint applied while gy is staged, and written to gy
             elif lazy_in is not None:
                 _lazy_finish(lazy_in, gy)
+            if ctx.relu_in:
+                a.small_relu_of = _ptr(x)
             _call('mdmm_conv_down' if transposed else 'mdmm_conv_up', C.byref(a),
                   tag='conv_%s[S=%d]' % ('down' if transposed else 'up', a.S))
-            a.lazy_dy = a.lazy_x = None
+            a.lazy_dy = a.lazy_x = a.small_relu_of = None
         elif lazy_in is not None and not (ctx.lazy_wgrad and ctx.needs_input_grad[1] and not (ctx.has_bias and ctx.needs_input_grad[2])):
             _lazy_finish(lazy_in, gy)
             lazy_in = None
@@ -2314,7 +2336,7 @@ class _ConvTilesFn(torch.autograd.Function):
             gb = _take_chansum(gy, c)
             if gb is None:
                 gb = colsum(gy.reshape(n, -1)).reshape(c, -1).sum(1)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 class _BnDeconvFn(torch.autograd.Function):
@@ -2539,19 +2561,22 @@ def bn_deconv(pending, layer, bias=True, stats_for=None):
     return out
 
 
-def conv_tiles(layer, x, bias=True, stats_for=None):
+def conv_tiles(layer, x, bias=True, stats_for=None, owed=None):
     """layer(x) for a Conv2d / ConvTranspose2d that conv_tiles_supported accepts (bias=False leaves
     the layer's bias out, as the blocks in front of a BatchNorm do).  stats_for: the BatchNorm behind the layer
-    when its statistics are to come out of the deconvolution's epilogue -> (output, partial sums or None)."""
+    when its statistics are to come out of the deconvolution's epilogue -> (output, partial sums or None).
+    owed: the ReLU-epilogue linear output x is a view of (take_owed_relu)."""
     import torch.nn as nn
     tr = isinstance(layer, nn.ConvTranspose2d)
+    # (a Deconv on a ReLU-epilogue output: its input-gradient kernel applies that ReLU's adjoint, owed_relu)
+    relu_in = bool(tr and owed is not None and x.requires_grad and take_owed_relu(x, owed))
     if stats_for is not None:
         xa = _act(x)
         if conv_out_stats_supported(layer, xa):
             return _ConvTilesFn.apply(x, layer.weight, layer.bias if bias else None, tr,
-                                      bn_groups_for(x.shape[0], stats_for))
-        return _ConvTilesFn.apply(x, layer.weight, layer.bias if bias else None, tr), None
-    return _ConvTilesFn.apply(x, layer.weight, layer.bias if bias else None, tr)
+                                      bn_groups_for(x.shape[0], stats_for), relu_in)
+        return _ConvTilesFn.apply(x, layer.weight, layer.bias if bias else None, tr, 0, relu_in), None
+    return _ConvTilesFn.apply(x, layer.weight, layer.bias if bias else None, tr, 0, relu_in)
 
 
 class _GaussMlpFn(torch.autograd.Function):

@@ -1422,6 +1422,50 @@ def test_conv_tiles_match_torch(dev, kind, c_in, c_out, size):
         close(gwb, gwr, 1e-5, 'conv wgrad, bf16 storage')
 
 
+def test_first_deconv_takes_the_relu_adjoint(dev, monkeypatch):
+    """The decoders' z_to_feat = Linear + ReLU (common.py:158-175) in front of the first Deconv: with bf16-stored activations
+    the Deconv's input-gradient kernel applies the ReLU's adjoint as it stores that gradient (mdmm_conv_t.small_relu_of,
+    ops.take_owed_relu) and the linear's backward skips aten::threshold_backward.  Same values masked at a different
+    place: every gradient bit-identical to the route where nobody takes the debt; and the route really is taken."""
+    from mdmm import ops
+    from mdmm.models import common as C
+    torch.manual_seed(5)
+    dec = C.ImageDecoder(256, n_channels=1).to(dev).train()      # (z = 256: the linear runs on the tile kernels)
+    z0 = torch.randn(520, 256, device=dev)                            # (>= 512 rows: ops.linear_tiles_supported)
+    gy = None
+    res = {}
+    for taken in (True, False):
+        if not taken:
+            monkeypatch.setattr(ops, 'take_owed_relu', lambda x, y: False)
+        for bn in dec.modules():
+            if isinstance(bn, torch.nn.BatchNorm2d):
+                bn.reset_running_stats()
+        z = z0.clone().requires_grad_()
+        ops.TIMER = timer = ops.KernelTimer()
+        try:
+            with ops.conv_operands(torch.bfloat16, act=torch.bfloat16):
+                (y,) = dec(z, logits=True)
+            gy = torch.randn(y.shape, device=dev).to(y.dtype) if gy is None else gy
+            grads = torch.autograd.grad(y, [z] + list(dec.parameters()), gy, allow_unused=True)
+            torch.cuda.synchronize()
+        finally:
+            ops.TIMER = None
+        assert any(t.startswith('conv_down[S=8]') for t in timer.spans), set(timer.spans)
+        res[taken] = [g.clone() if g is not None else None for g in grads]
+    for a, b in zip(res[True], res[False]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    # the debt is taken on this route: a spy on the unpatched function
+    monkeypatch.undo()
+    calls = []
+    real = ops.take_owed_relu
+    monkeypatch.setattr(ops, 'take_owed_relu', lambda x, y: calls.append(real(x, y)) or calls[-1])
+    with ops.conv_operands(torch.bfloat16, act=torch.bfloat16):
+        (y,) = dec(z0.clone().requires_grad_(), logits=True)
+    assert calls == [True]
+
+
 @pytest.mark.parametrize('act', ['act_fp32', 'act_bf16'])
 def test_step_weizmann_frames_conv_bf16_matches_oracle(dev, kernel_family, act):
     """Full-size Weizmann plug-ins (64 x 64 frames, the stock ImageEncoder / ImageDecoder pyramids)
