@@ -190,6 +190,17 @@ class Cfg3F32(Cfg3):
         return m
 
 
+class Cfg3F32Own(Cfg3F32):
+    """... and its convolutions on the own fp32-operand path (MultiDGTS.conv_f32_own, csrc/conv_f32.hip)"""
+    workload = Cfg3F32.workload.replace('convolutions in the library', 'convolutions on the own fp32-operand products')
+
+    @classmethod
+    def model(cls, models, device):
+        m = super().model(models, device)
+        m.conv_f32_own = True
+        return m
+
+
 class Cfg4(Cfg3):
     """BASELINE configs[3] at its per-GPU size (2048 sequences on 8 GPUs): the same Weizmann-shaped batch and
     plug-ins under MultiDKS, backward-RNN with skip updates (B-Skip), feat_to_z, uni_loss."""
@@ -821,6 +832,11 @@ def main():
             af.steps, af.warmup, af.batch = 3, 2, 0
             rf32 = run(Cfg3F32, af, 1, 0, device, graph=False)
             out['extra']['cfg3_f32'] = {k: rf32[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline')}
+            # ... and with the convolutions on the own fp32-operand path too (no library kernel in the step)
+            rown = run(Cfg3F32Own, af, 1, 0, device, graph=False)
+            out['extra']['cfg3_f32']['own_convolutions'] = {k: rown[k] for k in ('value', 'ms_per_step')}
+            out['extra']['cfg3_f32']['own_convolutions']['loss'] = rown['config'].get('loss')
+            del rown
             # the callers either side of the step: on-device batch preparation and the evaluation body
             del rf32, r4, r2
             torch.cuda.empty_cache()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 29
+#define MDMM_ABI_VERSION 30
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -36,7 +36,7 @@ extern "C" {
 int mdmm_version(void);
 const char* mdmm_strerror(int code);
 /* sizeof() of an argument struct as the library was compiled, for a binding to check its own
- * declaration against at load time: 0 gtf, 1 expert, 2 sweep, 4 gru, 5 dks, 6 mlp, 7 bn; 0 if unknown */
+ * declaration against at load time: 0 gtf, 1 expert, 2 sweep, 4 gru, 5 dks, 6 mlp, 7 bn, ... 15 convf; 0 if unknown */
 size_t mdmm_sizeof(int which);
 /* round n up to the padded width the packed weights use (multiple of 4) */
 int mdmm_pad(int n);
@@ -679,6 +679,37 @@ int mdmm_conv_down(const mdmm_conv_t* args, void* stream);
 int64_t mdmm_conv_wgrad_ws_bytes(const mdmm_conv_t* args);
 int mdmm_conv_wgrad_parts(const mdmm_conv_t* args);  /* workgroups of mdmm_conv_wgrad = partial slabs of bst_part */
 int mdmm_conv_wgrad(const mdmm_conv_t* args, void* ws, float* dw, void* stream);
+
+/* The same image pyramids (common.py:70-112, 114-175) with fp32 OPERANDS -- the reference's arithmetic -- as explicit
+ * products on the fp32 matrix instruction: mdmm_gemm_f32 between the BIG side unfolded into its KS x KS neighbourhoods,
+ * the SMALL side as pixel-major rows, and torch's weight [CS][CB][KS][KS] read as the (CS x CB KS KS) matrix it is
+ * (csrc/conv_f32.hip; any S, CS, CB, KS = 3 (Conv2d k3 s2 p1) or 4 (ConvTranspose2d k4 s2 p1)):
+ *   Conv forward / Deconv input gradient:   rows(small) = unfold(big) W^T
+ *   Deconv forward / Conv input gradient:   big = fold(rows(small) W)
+ *   weight gradient of both:                dW = rows(small)^T unfold(big)
+ * Lp = mdmm_convf_cols(CB, KS) = CB KS KS rounded up to a multiple of 4 (the padding columns are zeros; W is handed to
+ * the products as a (CS x Lp) copy).  Every tensor fp32, NCHW, contiguous.
+ *   mdmm_convf_unfold: src = big (N, CB, 2S, 2S) -> dst = U (N S S, Lp),
+ *                      U[(n, y, x)][(cb, ky, kx)] = big[n][cb][2y - 1 + ky][2x - 1 + kx], 0 outside the image
+ *   mdmm_convf_fold:   src = Ucol (N S S, Lp) -> dst = big, big[n][cb][Y][X] = bias[cb] + the sum of the entries whose
+ *                      tap reaches (Y, X) (a gather: no atomics, any summation order question is four terms)
+ *   mdmm_convf_rows:   to_rows: src = small (N, CS, S, S) -> dst (N S S, CS); else src rows -> dst small, + bias[c]  */
+typedef struct mdmm_convf {
+  int32_t N, S, CS, CB, KS, Lp;
+  const void* src;
+  void* dst;
+  const float* bias;     /* fold: (CB), rows -> NCHW: (CS); or NULL */
+} mdmm_convf_t;
+int mdmm_convf_cols(int CB, int KS);
+int mdmm_convf_unfold(const mdmm_convf_t* args, void* stream);
+int mdmm_convf_fold(const mdmm_convf_t* args, void* stream);
+int mdmm_convf_rows(const mdmm_convf_t* args, int to_rows, void* stream);
+/* dw (CS x Lp) = rows^T U for rows (n_rows x CS, CS <= 64) and U (n_rows x Lp): the weight gradient's product, a few
+ * thousand outputs against millions of contracted rows, on v_mfma_f32_32x32x2_f32 straight from memory with per-slice
+ * partial sums folded in a fixed order; ws = mdmm_convf_wgrad_parts(n_rows, Lp) * CS * Lp floats.  (Wider small sides:
+ * mdmm_gemm_f32 with ta = tb = 1.)  */
+int mdmm_convf_wgrad_parts(int64_t n_rows, int Lp);
+int mdmm_convf_wgrad(const float* rows, const float* u, int64_t n_rows, int CS, int Lp, float* ws, float* dw, void* stream);
 
 /* Stride-2 1-D convolution pyramids of the audio plug-ins (common.py:177-219, 221-290): AudioConv =
  * nn.Conv1d(k3,s2,p1), AudioDeconv = nn.ConvTranspose1d(k3,s2,p1).  SMALL side (N, CS, S), BIG side

@@ -140,6 +140,7 @@ extern "C" size_t mdmm_sizeof(int which) {
     case 12: return sizeof(mdmm_vrnn_t);
     case 13: return sizeof(mdmm_vrnn_layout_t);
     case 14: return sizeof(mdmm_spill_wgrad_batch_t);
+    case 15: return sizeof(mdmm_convf_t);
     default: return 0;
   }
 }

@@ -819,6 +819,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
 #pragma unroll
       for (int reg = 0; reg < LR; ++reg) prl[reg] = tabl[acc_row(0, reg) + 4 * h];
       __builtin_amdgcn_sched_barrier(0);
+      STAMP(18);
       FuseIn fin[NS];
 #pragma unroll
       for (int reg = 0; reg < LR; ++reg) fuse_bwd_load(fz, prl[reg], t, n, fin[reg]);
@@ -834,6 +835,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd_kernel(const mdmm_sweep_t a, co
         }
       }
       __builtin_amdgcn_sched_barrier(0);       // (every request in front of the first algebra)
+      STAMP(19);
 #pragma unroll
       for (int reg = 0; reg < LR; ++reg)
         fa[reg] = fuse_bwd_math(fz, exs, prl[reg], t, n, mu0, sg0, adj_a[reg], adj_b[reg], se[reg],

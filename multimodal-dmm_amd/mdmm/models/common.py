@@ -119,6 +119,8 @@ class _ConvBlock(nn.Module):
             return ops.conv_tiles(layer, x, bias=False, owed=owed)
         if ops.conv1d_tiles_supported(layer, x):        # the audio pyramids (csrc/conv1d.hip, fp32)
             return ops.conv1d_tiles(layer, x, bias=False)
+        if ops.conv_f32_supported(layer, x):            # fp32 operands: own products (csrc/conv_f32.hip)
+            return ops.conv_f32(layer, x, bias=False)
         if x.dtype != layer.weight.dtype:                # (a bf16-stored activation reaching a library layer)
             x = x.to(layer.weight.dtype)
         if isinstance(layer, (nn.Conv1d, nn.Conv2d)):
@@ -167,19 +169,23 @@ class _ConvBlock(nn.Module):
             # evaluation mode (running statistics) and CPU: the stock modules, in the weights' precision
             if x.dtype != layer.weight.dtype:
                 x = x.to(layer.weight.dtype)
+            # (the convolution itself on the own fp32-operand products where they apply: evaluation on the GPU)
+            conv = (lambda t: ops.conv_f32(layer, t)) if ops.conv_f32_supported(layer, x) else layer
             if bn.training and ops.BN_GROUPS > 1:         # the batch holds several passes (ops.bn_groups): one by one
-                chunks = layer(x).chunk(ops.BN_GROUPS)
+                chunks = conv(x).chunk(ops.BN_GROUPS)
                 if ops.bn_sync_group() is not None:
                     return torch.cat([ops.sync_batchnorm_relu_torch(c, bn) for c in chunks])
                 return torch.cat([self.net[2](bn(c)) for c in chunks])
             if bn.training and ops.bn_sync_group() is not None:      # statistics of every rank's batch (ops.bn_sync)
-                return ops.sync_batchnorm_relu_torch(layer(x), bn)
-            return self.net[2](bn(layer(x)))
+                return ops.sync_batchnorm_relu_torch(conv(x), bn)
+            return self.net[2](bn(conv(x)))
         from .. import ops
         if ops.conv_tiles_supported(self.net, x):
             return ops.conv_tiles(self.net, x, owed=owed)
         if ops.conv1d_tiles_supported(self.net, x):
             return ops.conv1d_tiles(self.net, x)
+        if ops.conv_f32_supported(self.net, x):
+            return ops.conv_f32(self.net, x)
         if x.dtype != self.net.weight.dtype:
             x = x.to(self.net.weight.dtype)
         return self.net(x)

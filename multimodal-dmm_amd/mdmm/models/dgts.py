@@ -27,6 +27,10 @@ class MultiDGTS(nn.Module):
     # torch.bfloat16 (csrc/conv_tiles.hip: bf16 operands on the matrix cores, fp32 activations and
     # accumulation -- the same contract as sweep_dtype).
     conv_dtype = torch.float32
+    # With conv_dtype = float32: False (default) = the library's fp32 convolutions; True = the own fp32-operand path
+    # (csrc/conv_f32.hip: unfold / fold around mdmm_gemm_f32, any layer shape, 2e-6 against fp64) -- no library kernel
+    # in the step, at 1.75x the library's time (cfg3 with fp32 operands: 247 against 141 ms per step).
+    conv_f32_own = False
     # Storage type of the activations inside those plug-ins when conv_dtype is bfloat16: fp32 (default)
     # or bfloat16 (what autocast would store; halves the HBM traffic that bounds the conv / BatchNorm /
     # BCE chain).  Frames, latents, weights, statistics and every reduction stay fp32.
@@ -55,6 +59,9 @@ class MultiDGTS(nn.Module):
             if kw.get('logits'):        # pre-sigmoid activations for the fused BCE: kept as stored
                 return out
             return tuple(o.float() for o in out) if isinstance(out, tuple) else out.float()
+        if self.plugin_dtype is None and self.conv_dtype is torch.float32 and self.conv_f32_own and x.is_cuda:
+            with ops.conv_operands(torch.float32):
+                return module(x, **kw)
         if self.plugin_dtype is None or not x.is_cuda:
             return module(x, **kw)
         with torch.autocast('cuda', dtype=self.plugin_dtype):

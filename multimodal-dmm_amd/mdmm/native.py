@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 29
+ABI_VERSION = 30
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -39,6 +39,7 @@ SYMBOLS = [
     'mdmm_gemm_supported', 'mdmm_gemm_split', 'mdmm_gemm_ws_bytes', 'mdmm_gemm_bf16', 'mdmm_gemm_f32',
     'mdmm_nll_bernoulli_logits_bf16_fwd', 'mdmm_nll_bernoulli_logits_bf16_bwd',
     'mdmm_nll_bernoulli_logits_passes_fwd', 'mdmm_nll_bernoulli_logits_passes_bwd', 'mdmm_nll_chan_parts',
+    'mdmm_convf_cols', 'mdmm_convf_unfold', 'mdmm_convf_fold', 'mdmm_convf_rows', 'mdmm_convf_wgrad_parts', 'mdmm_convf_wgrad',
     'mdmm_conv1d_supported', 'mdmm_conv1d_up', 'mdmm_conv1d_down', 'mdmm_conv1d_wgrad_ws_bytes', 'mdmm_conv1d_wgrad',
     'mdmm_colsum_splits', 'mdmm_colsum',
     'mdmm_vrnn_layout', 'mdmm_vrnn_supported', 'mdmm_vrnn_fwd', 'mdmm_vrnn_bwd',
@@ -181,6 +182,10 @@ class Conv(C.Structure):
                 [('bst_dy', _P), ('bst_part', _P)] +
                 [(n, _P) for n in ('lazy_dy', 'lazy_x', 'lazy_mean', 'lazy_invstd', 'lazy_gamma', 'lazy_beta', 'lazy_means')] +
                 [('lazy_group_n', C.c_int32), ('lazy_relu', C.c_int32), ('small_relu_of', _P)])
+
+
+class ConvF(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB', 'KS', 'Lp')] + [(n, _P) for n in ('src', 'dst', 'bias')])
 
 
 class Conv1d(C.Structure):
@@ -346,6 +351,12 @@ def lib():
         L.mdmm_conv_wgrad_ws_bytes.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_wgrad_ws_bytes.restype = C.c_int64
         L.mdmm_conv_wgrad.argtypes = [C.POINTER(Conv), _P, _P, _P]
+        L.mdmm_convf_cols.argtypes = [C.c_int, C.c_int]
+        L.mdmm_convf_unfold.argtypes = [C.POINTER(ConvF), _P]
+        L.mdmm_convf_fold.argtypes = [C.POINTER(ConvF), _P]
+        L.mdmm_convf_rows.argtypes = [C.POINTER(ConvF), C.c_int, _P]
+        L.mdmm_convf_wgrad_parts.argtypes = [C.c_int64, C.c_int]
+        L.mdmm_convf_wgrad.argtypes = [_P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P]
         L.mdmm_conv1d_supported.argtypes = [C.POINTER(Conv1d)]
         L.mdmm_conv1d_up.argtypes = [C.POINTER(Conv1d), _P]
         L.mdmm_conv1d_down.argtypes = [C.POINTER(Conv1d), _P]
@@ -380,7 +391,7 @@ def lib():
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
         for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp), (7, Bn), (8, Conv),
-                          (9, FragLayers), (10, Gemm), (11, Conv1d), (12, Vrnn), (13, VrnnLayout), (14, SpillWgradBatch)):
+                          (9, FragLayers), (10, Gemm), (11, Conv1d), (12, Vrnn), (13, VrnnLayout), (14, SpillWgradBatch), (15, ConvF)):
             if L.mdmm_sizeof(which) != C.sizeof(st):
                 raise MdmmError('struct %s: library %d bytes, binding %d bytes'
                                 % (st.__name__, L.mdmm_sizeof(which), C.sizeof(st)))

@@ -2062,6 +2062,184 @@ def _conv_pack(weight, a, up):
     return hit[1]
 
 
+# ---- the image pyramids with fp32 operands (csrc/conv_f32.hip + mdmm_gemm_f32) ------------------------
+def _convf_kind(layer):
+    """(transposed, CS, CB, KS) of a Conv2d(k3,s2,p1) / ConvTranspose2d(k4,s2,p1), else None"""
+    import torch.nn as nn
+    if isinstance(layer, nn.ConvTranspose2d):
+        ok = (layer.kernel_size == (4, 4) and layer.stride == (2, 2) and layer.padding == (1, 1)
+              and layer.output_padding == (0, 0))
+        tr = True
+    elif type(layer) is nn.Conv2d:
+        ok = (layer.kernel_size == (3, 3) and layer.stride == (2, 2) and layer.padding == (1, 1)
+              and layer.padding_mode == 'zeros')
+        tr = False
+    else:
+        return None
+    if not ok or layer.dilation != (1, 1) or layer.groups != 1 or layer.weight.dtype != torch.float32:
+        return None
+    cs, cb, ks = layer.weight.shape[0], layer.weight.shape[1], layer.weight.shape[-1]
+    return tr, cs, cb, ks
+
+
+def conv_f32_supported(layer, x):
+    """fp32 activations on the GPU into a Conv2d(k3,s2,p1) / ConvTranspose2d(k4,s2,p1) while conv_operands(torch.float32)
+    is active (MultiDGTS.conv_f32_own): the own fp32-operand path instead of the library's kernels.  Any square size
+    (even on the big side) and channel counts with a small side that is a multiple of 4."""
+    if CONV_OPERANDS is not torch.float32 or not x.is_cuda or x.dim() != 4 or x.dtype != torch.float32:
+        return False
+    if torch.is_autocast_enabled() or x.shape[0] < 1 or x.shape[2] != x.shape[3]:
+        return False
+    kind = _convf_kind(layer)
+    if kind is None:
+        return False
+    tr, cs, cb, _ = kind
+    if cs % 4 or x.shape[1] != (cs if tr else cb):
+        return False
+    return tr or x.shape[2] % 2 == 0
+
+
+def _convf_desc(n, s, cs, cb, ks):
+    a = native.ConvF()
+    a.N, a.S, a.CS, a.CB, a.KS = n, s, cs, cb, ks
+    a.Lp = native.lib().mdmm_convf_cols(cb, ks)
+    return a
+
+
+def _convf_weight(weight):
+    """torch's [CS][CB][KS][KS] as the (CS, Lp) matrix the products take: itself where CB KS KS is a multiple of 4, else a
+    zero-padded copy (cached on the parameter)"""
+    cs = weight.shape[0]
+    w = _f32c(weight.detach()).reshape(cs, -1)
+    cols = w.shape[1]
+    lp = (cols + 3) & ~3
+    if lp == cols:
+        return w
+    key = (weight.data_ptr(), weight._version)
+    hit = getattr(weight, '_mdmm_convf_w', None)
+    if hit is None or hit[0] != key:
+        wp = torch.zeros(cs, lp, device=w.device, dtype=torch.float32)
+        wp[:, :cols] = w
+        hit = (key, wp)
+        weight._mdmm_convf_w = hit
+    return hit[1]
+
+
+def _convf_unfold(big, a):
+    u = torch.empty(a.N * a.S * a.S, a.Lp, device=big.device, dtype=torch.float32)
+    a.src, a.dst, a.bias = _ptr(big), _ptr(u), None
+    _call('mdmm_convf_unfold', C.byref(a), tag='convf_unfold[S=%d]' % a.S, nbytes=4 * (big.numel() + u.numel()))
+    return u
+
+
+def _convf_fold(ucol, a, bias):
+    big = torch.empty(a.N, a.CB, 2 * a.S, 2 * a.S, device=ucol.device, dtype=torch.float32)
+    a.src, a.dst, a.bias = _ptr(ucol), _ptr(big), _ptr(bias)
+    _call('mdmm_convf_fold', C.byref(a), tag='convf_fold[S=%d]' % a.S, nbytes=4 * (big.numel() + ucol.numel()))
+    return big
+
+
+def _convf_rows(small, a):
+    rows = torch.empty(a.N * a.S * a.S, a.CS, device=small.device, dtype=torch.float32)
+    a.src, a.dst, a.bias = _ptr(small), _ptr(rows), None
+    _call('mdmm_convf_rows', C.byref(a), 1, tag='convf_rows[S=%d]' % a.S, nbytes=8 * rows.numel())
+    return rows
+
+
+def _convf_from_rows(rows, a, bias):
+    small = torch.empty(a.N, a.CS, a.S, a.S, device=rows.device, dtype=torch.float32)
+    a.src, a.dst, a.bias = _ptr(rows), _ptr(small), _ptr(bias)
+    _call('mdmm_convf_rows', C.byref(a), 0, tag='convf_rows[S=%d]' % a.S, nbytes=8 * rows.numel())
+    return small
+
+
+def _convf_wgrad(sm, u, cs, lp, s):
+    """dW (CS, Lp) = sm^T u over the rows"""
+    rows = sm.shape[0]
+    if cs > 64:
+        return _gemm_bf16(sm, True, u, True, cs, lp, rows, f32=True, tag='convf_wgrad[S=%d]' % s)
+    ws = torch.empty(native.lib().mdmm_convf_wgrad_parts(rows, lp) * cs * lp, device=sm.device, dtype=torch.float32)
+    dw = torch.empty(cs, lp, device=sm.device, dtype=torch.float32)
+    _call('mdmm_convf_wgrad', _ptr(sm), _ptr(u), rows, cs, lp, _ptr(ws), _ptr(dw), tag='convf_wgrad[S=%d]' % s,
+          nbytes=4 * (sm.numel() + u.numel()))
+    return dw
+
+
+class _ConvF32Fn(torch.autograd.Function):
+    """One stride-2 layer of the image pyramids with fp32 operands (csrc/conv_f32.hip): transposed =
+    ConvTranspose2d(k4,s2,p1) (small -> big), else Conv2d(k3,s2,p1) (big -> small); weight is torch's [CS][CB][KS][KS]
+    either way.  Three products on mdmm_gemm_f32 between the unfolded big side and the small side's pixel rows; the
+    backward unfolds / transposes again instead of keeping those copies (KS^2 / 4 times the big side) alive."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, transposed):
+        ctx.set_materialize_grads(False)
+        _need_gpu(x, weight)
+        x = _f32c(x.detach())
+        cs, cb, ks = weight.shape[0], weight.shape[1], weight.shape[-1]
+        n = x.shape[0]
+        s = x.shape[2] if transposed else x.shape[2] // 2
+        a = _convf_desc(n, s, cs, cb, ks)
+        wp = _convf_weight(weight)
+        b = _f32c(bias.detach()) if bias is not None else None
+        rows = n * s * s
+        if transposed:      # big = fold(rows(small) W)
+            sm = _convf_rows(x, a)
+            ucol = _gemm_bf16(sm, False, wp, True, rows, a.Lp, cs, f32=True, tag='convf_up[S=%d]' % s)
+            y = _convf_fold(ucol, a, b)
+        else:               # rows(small) = unfold(big) W^T
+            u = _convf_unfold(x, a)
+            sm = _gemm_bf16(u, False, wp, False, rows, cs, a.Lp, f32=True, tag='convf_down[S=%d]' % s)
+            y = _convf_from_rows(sm, a, b)
+        ctx.geo = (n, s, cs, cb, ks, transposed, bias is not None)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        if gy is None:
+            return None, None, None, None
+        n, s, cs, cb, ks, transposed, has_bias = ctx.geo
+        gy = _f32c(gy)
+        a = _convf_desc(n, s, cs, cb, ks)
+        wp = _convf_weight(weight)
+        rows = n * s * s
+        gx = gw = gb = None
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if transposed:      # gy = the big side
+            u = _convf_unfold(gy, a) if (need_x or need_w) else None
+            if need_x:
+                gsm = _gemm_bf16(u, False, wp, False, rows, cs, a.Lp, f32=True, tag='convf_down[S=%d]' % s)
+                gx = _convf_from_rows(gsm, a, None)
+            if need_w:
+                sm = _convf_rows(x, a)
+                dwp = _convf_wgrad(sm, u, cs, a.Lp, s)
+        else:               # gy = the small side
+            gsm = _convf_rows(gy, a) if (need_x or need_w) else None
+            if need_x:
+                ucol = _gemm_bf16(gsm, False, wp, True, rows, a.Lp, cs, f32=True, tag='convf_up[S=%d]' % s)
+                gx = _convf_fold(ucol, a, None)
+            if need_w:
+                u = _convf_unfold(x, a)
+                dwp = _convf_wgrad(gsm, u, cs, a.Lp, s)
+        if need_w:
+            gw = dwp[:, :cb * ks * ks].reshape(weight.shape)
+            if not gw.is_contiguous():
+                gw = gw.contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            c = gy.shape[1]
+            gb = colsum(gy.reshape(n, -1)).reshape(c, -1).sum(1)
+        return gx, gw, gb, None
+
+
+def conv_f32(layer, x, bias=True):
+    """layer(x) for a Conv2d / ConvTranspose2d that conv_f32_supported accepts (bias=False leaves the layer's bias out,
+    as the blocks in front of a BatchNorm do)."""
+    tr = _convf_kind(layer)[0]
+    return _ConvF32Fn.apply(x, layer.weight, layer.bias if bias else None, tr)
+
+
 # ---- stride-2 1-D pyramids of the audio plug-ins (csrc/conv1d.hip, fp32) -----------------------------
 def _conv1d_desc(layer, shape):
     """native.Conv1d of a Conv1d(k3,s2,p1) / ConvTranspose1d(k3,s2,p1) applied to (N, C, L), or None."""

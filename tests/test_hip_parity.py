@@ -1254,7 +1254,7 @@ def test_batchnorm_relu_matches_torch(dev, kernel_family, shape):
     close(got.bias.grad, ref.bias.grad, 1e-3, 'bn dbeta, bf16 storage')
 
 
-@pytest.mark.parametrize('switches', ['fp32', 'bf16_switches'])
+@pytest.mark.parametrize('switches', ['fp32', 'bf16_switches', 'f32_own_convs'])
 def test_step_conv_plugins_matches_oracle(dev, kernel_family, switches):
     """(bf16_switches: conv_dtype = act_dtype = bfloat16 on plug-ins the tile kernels do NOT take --
     16 x 16 frames -- must fall back to the library's fp32 layers without handing them bf16 tensors.)
@@ -1282,6 +1282,8 @@ def test_step_conv_plugins_matches_oracle(dev, kernel_family, switches):
     m = models.MultiDMM(mods, dims, dists, encoders=enc, decoders=dec, h_dim=H, z_dim=D, device=dev)
     if switches == 'bf16_switches':
         m.conv_dtype = m.act_dtype = m.sweep_dtype = torch.bfloat16
+    if switches == 'f32_own_convs':         # fp32 operands, convolutions on csrc/conv_f32.hip instead of the library
+        m.conv_f32_own = True
     enc, dec = plugins()
     o = orc.OracleDMM(mods, dims, dists, encoders=enc, decoders=dec, h_dim=H, z_dim=D)
     o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
@@ -1420,6 +1422,77 @@ def test_conv_tiles_match_torch(dev, kind, c_in, c_out, size):
         close(yb.float(), fn(xr, wr, layer.bias.detach(), 2, 1), 8e-3, 'conv fwd, bf16 storage')
         close(gxb.float(), gxr, 8e-3, 'conv dgrad, bf16 storage')
         close(gwb, gwr, 1e-5, 'conv wgrad, bf16 storage')
+
+
+CONVF_LAYERS = CONV_LAYERS + [('deconv', 8, 5, 6), ('conv', 5, 12, 10), ('conv', 2, 4, 2)]
+
+
+@pytest.mark.parametrize('kind,c_in,c_out,size', CONVF_LAYERS)
+def test_conv_f32_matches_fp64(dev, kind, c_in, c_out, size):
+    """csrc/conv_f32.hip + mdmm_gemm_f32 (Conv2d k3 s2 p1 / ConvTranspose2d k4 s2 p1 with fp32 OPERANDS, common.py:70-112:
+    the reference's arithmetic) against the same layer in fp64: forward, input gradient, weight gradient and bias gradient
+    to fp32 summation order (2e-6 measured), for the six shapes of the 64 x 64 pyramids and three odd ones (channel counts
+    that pad the unfolded side, a 2 x 2 image)."""
+    import torch.nn as nn
+    from mdmm import ops
+    torch.manual_seed(c_in * 100 + c_out)
+    tr = kind == 'deconv'
+    for n in (1, 7, 130):
+        layer = (nn.ConvTranspose2d(c_in, c_out, 4, 2, 1) if tr else nn.Conv2d(c_in, c_out, 3, 2, 1)).to(dev)
+        x = torch.randn(n, c_in, size, size, device=dev, requires_grad=True)
+        assert not ops.conv_f32_supported(layer, x)          # (the default fp32 route is the library's)
+        with ops.conv_operands(torch.float32):
+            assert ops.conv_f32_supported(layer, x)
+        ops.TIMER = timer = ops.KernelTimer()
+        try:
+            y = ops.conv_f32(layer, x)
+            gy = torch.randn_like(y)
+            gx, gw, gb = torch.autograd.grad(y, [x, layer.weight, layer.bias], gy)
+            torch.cuda.synchronize()
+        finally:
+            ops.TIMER = None
+        assert {t.split('[')[0] for t in timer.spans} >= {'convf_up', 'convf_down', 'convf_wgrad'}, set(timer.spans)
+        fn = torch.nn.functional.conv_transpose2d if tr else torch.nn.functional.conv2d
+        xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, layer.weight, layer.bias))
+        yd = fn(xd, wd, bd, 2, 1)
+        gxd, gwd, gbd = torch.autograd.grad(yd, [xd, wd, bd], gy.double())
+        close(y, yd.float(), 1e-5, 'conv f32 fwd')
+        close(gx, gxd.float(), 1e-5, 'conv f32 dgrad')
+        close(gw, gwd.float(), 1e-5, 'conv f32 wgrad')
+        close(gb, gbd.float(), 1e-5, 'conv f32 bias grad')
+        # without a bias, and as the blocks call it
+        y0 = ops.conv_f32(layer, x, bias=False)
+        close(y0, fn(xd, wd, None, 2, 1).float(), 1e-5, 'conv f32 fwd, no bias')
+
+
+def test_fp32_conv_model_calls_no_library_convolution(dev):
+    """A training step of the stock image plug-ins (ImageEncoder / ImageDecoder,
+    common.py:114-175) with fp32 switches: every kernel the process launches is named -- none of them is one of the
+    library's convolution kernels (MIOpen: igemm / naive_conv / Conv_Winograd / gfx9 assembly kernels / im2col / transposes)
+    nor a library GEMM (Cijk_*)."""
+    from torch.profiler import profile, ProfilerActivity
+    from mdmm import ops
+    from mdmm.models import common as C
+    torch.manual_seed(2)
+    enc = C.ImageEncoder(32, n_channels=1).to(dev)
+    dec = C.ImageDecoder(32, n_channels=1).to(dev)
+    x = torch.rand(512, 1, 64, 64, device=dev)        # (>= 512 rows: the Linear heads run on the own fp32 tiles too)
+
+    def step():
+        with ops.conv_operands(torch.float32):      # (what MultiDGTS._plug does with conv_f32_own = True)
+            mean, std = enc(x)
+            (y,) = dec(mean + std, logits=True)
+        y.square().mean().backward()
+    step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    names = {e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA}
+    assert any('gemm_f32_kernel' in k for k in names) and any('unfold_kernel' in k for k in names), sorted(names)[:40]
+    bad = [k for k in names if any(w in k.lower() for w in ('miopen', 'igemm', 'naive_conv', 'winograd', 'im2col', 'col2im',
+                                                             'conv_', 'batched_transpose', 'sp3asm', 'cijk'))]
+    assert not bad, bad
 
 
 def test_first_deconv_takes_the_relu_adjoint(dev, monkeypatch):

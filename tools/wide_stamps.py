@@ -49,6 +49,9 @@ else:
              11: 'barrier', 12: 'D1 gemm+store+spill', 13: 'barrier', 14: 'D2 2 gemms+store+spills', 15: 'barrier+store+barrier',
              16: 'D3 3 gemms+adj', 17: 'barrier'}
     order = list(range(18))
+    if K == 1:
+        names.update({18: '  (A) arguments + pair table', 19: '  (A) requests issued'})
+        order = [0, 18, 19] + list(range(1, 18))
     if os.environ.get('MDMM_FWD_PARK', '1') != '0' and 1 < K <= 25 and kw['bf16']:
         # sweep_wide_bwd4.hip (the forward kept its park)
         names = {0: 'step start', 1: 'pair 0: fuse adjoint, barrier, E', 2: 'pair 1: fuse adjoint, E', 3: 'pair 2', 4: 'pair 3',
