@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 30
+#define MDMM_ABI_VERSION 31
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -351,6 +351,11 @@ int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logits_bf16, in
 /* NaN -> 0 and the per-row "seen" flag of MultiDMM.encode (dmm.py:164-166) in one pass:
  * out[r][i] = isnan(x[r][i]) ? 0 : x[r][i];  seen[r] = no NaN in row r  (float 0 / 1).  */
 int mdmm_nan_to_zero(const float* x, int64_t rows, int inner, float* out, float* seen, void* stream);
+/* The same with the cleaned rows written as bf16 (round to nearest even -- the conversion the conv kernels apply when
+ * they stage an fp32 side, so a first encoder layer fed these rows forms bit-identical operands): for frames whose only
+ * readers are mdmm_conv_down / mdmm_conv_wgrad with bf16 activations (2 instead of 4 bytes per element written here and
+ * read by each of them).  out: rows * inner bf16.  */
+int mdmm_nan_to_zero_bf16(const float* x, int64_t rows, int inner, void* out, float* seen, void* stream);
 
 /* Input gradients of the experts a sweep shares between passes (dgts.py:119-129: the multimodal pass and a modality's own
  * unimodal pass read the same encoder output): mdmm_bfvi_sweep_bwd leaves one (T,B,D) slab per pass in a (P,T,B,D) buffer

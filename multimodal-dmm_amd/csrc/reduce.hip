@@ -2,6 +2,7 @@
 // (dgts.py:15-83).  All HBM-bound streaming kernels: one pass over the operands,
 // float4 loads where the trailing extent allows, per-wave shuffle reduction, one fp64
 // atomic per workgroup.
+#include <type_traits>
 #include "mdmm_device.h"
 #include "../../include/mdmm_hip.h"
 
@@ -426,16 +427,22 @@ __global__ __launch_bounds__(NT) void philox_kernel(uint64_t seed, uint64_t offs
 }
 
 // ---------------------------------------------------------------- NaN -> 0 + seen ----
-// one workgroup per row (t, b): inputs of the image / audio encoders (dmm.py:164-166)
+// one workgroup per row (t, b): inputs of the image / audio encoders (dmm.py:164-166).  BF: the cleaned row is written
+// as bf16 (round to nearest even, the conversion the conv kernels apply when they stage an fp32 side): for frames whose
+// only readers are those kernels -- the first encoder layer and its weight gradient then read 2 bytes per element
+template <bool BF>
 __global__ __launch_bounds__(NT) void nan_to_zero_kernel(const float* __restrict__ x, int64_t rows,
-                                                         int inner, float* __restrict__ out,
+                                                         int inner, void* __restrict__ out_,
                                                          float* __restrict__ seen) {
+  using OutT = typename std::conditional<BF, __bf16, float>::type;
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  OutT* out = reinterpret_cast<OutT*>(out_);
   __shared__ int any_nan;
   for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
     if (threadIdx.x == 0) any_nan = 0;
     __syncthreads();
     const float* xr = x + r * inner;
-    float* orow = out + r * inner;
+    OutT* orow = out + r * inner;
     bool bad = false;
     if ((inner & 3) == 0 && !(((uintptr_t)xr | (uintptr_t)orow) & 15)) {
       for (int i = threadIdx.x; i < inner / 4; i += NT) {
@@ -444,13 +451,19 @@ __global__ __launch_bounds__(NT) void nan_to_zero_kernel(const float* __restrict
         if (v.y != v.y) { v.y = 0.f; bad = true; }
         if (v.z != v.z) { v.z = 0.f; bad = true; }
         if (v.w != v.w) { v.w = 0.f; bad = true; }
-        reinterpret_cast<float4*>(orow)[i] = v;
+        if constexpr (BF) {
+          bf16x4_t o;
+          o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+          reinterpret_cast<bf16x4_t*>(orow)[i] = o;
+        } else {
+          reinterpret_cast<float4*>(orow)[i] = v;
+        }
       }
     } else {
       for (int i = threadIdx.x; i < inner; i += NT) {
         float v = xr[i];
         if (v != v) { v = 0.f; bad = true; }
-        orow[i] = v;
+        orow[i] = (OutT)v;
       }
     }
     if (bad) any_nan = 1;
@@ -832,6 +845,15 @@ extern "C" int mdmm_nan_to_zero(const float* x, int64_t rows, int inner, float* 
   if (!x || !out || !seen || rows < 0 || inner < 1) return MDMM_E_ARG;
   if (rows == 0) return 0;
   const int64_t g = rows < 65536 ? rows : 65536;
-  hipLaunchKernelGGL(nan_to_zero_kernel, dim3((unsigned)g), dim3(NT), 0, STREAM, x, rows, inner, out, seen);
+  hipLaunchKernelGGL(nan_to_zero_kernel<false>, dim3((unsigned)g), dim3(NT), 0, STREAM, x, rows, inner, (void*)out, seen);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nan_to_zero_bf16(const float* x, int64_t rows, int inner, void* out, float* seen,
+                                     void* stream) {
+  if (!x || !out || !seen || rows < 0 || inner < 1) return MDMM_E_ARG;
+  if (rows == 0) return 0;
+  const int64_t g = rows < 65536 ? rows : 65536;
+  hipLaunchKernelGGL(nan_to_zero_kernel<true>, dim3((unsigned)g), dim3(NT), 0, STREAM, x, rows, inner, out, seen);
   CHECK_LAUNCH();
 }

@@ -71,14 +71,34 @@ class MultiDGTS(nn.Module):
         return out.float()
 
     @staticmethod
-    def _clean(x):
+    def _clean(x, store=torch.float32):
         """dmm.py:164-166 / dks.py:202-204: NaN -> 0 and the per-(t,b) "seen" flag -- one fused pass
-        over the (T,B,...) tensor on the GPU (csrc/reduce.hip, mdmm_nan_to_zero)."""
+        over the (T,B,...) tensor on the GPU (csrc/reduce.hip, mdmm_nan_to_zero).  store: see _frames_store."""
         if x.is_cuda and x.dtype == torch.float32:
-            x0, seen = ops.nan_to_zero(x)
+            x0, seen = ops.nan_to_zero(x, store=store)
             return x0, seen > 0
         nan = torch.isnan(x)
         return torch.where(nan, torch.zeros_like(x), x), ~nan.flatten(2, -1).any(dim=-1)
+
+    def _frames_store(self, enc, x):
+        """Storage type of the cleaned (T,B,C,H,W) frames handed to encoder `enc`: bf16 when their only reader is a
+        first layer on the tile convolutions with bf16 activations in training mode (conv_dtype = act_dtype = bf16:
+        that kernel and its weight gradient round every element to bf16 while staging it -- same operands bit for
+        bit, 2 instead of 4 bytes per element written once and read twice), else fp32."""
+        from . import common
+        if (self.plugin_dtype is not None or self.conv_dtype is not torch.bfloat16 or self.act_dtype is not torch.bfloat16
+                or not x.is_cuda or x.dim() != 5 or not enc.training or torch.is_autocast_enabled()):
+            return torch.float32
+        stack = getattr(enc, 'conv_stack', None) if isinstance(enc, common._GaussHead) else None
+        first = stack[0] if isinstance(stack, nn.Sequential) and len(stack) else None
+        if not isinstance(first, common.Conv) or not isinstance(first.net, nn.Sequential):
+            return torch.float32
+        layer, bn = first.net[0], first.net[1]
+        if not bn.training:
+            return torch.float32
+        with ops.conv_operands(torch.bfloat16, act=torch.bfloat16):
+            ok = ops.conv_chain_takes(layer, (x.shape[0] * x.shape[1],) + tuple(x.shape[2:]))
+        return torch.bfloat16 if ok else torch.float32
 
     def _logit_decoder(self, m):
         """Bernoulli decoders of the stock conv family end in nn.Sigmoid (common.py:163-165): the

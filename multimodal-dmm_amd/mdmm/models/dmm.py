@@ -113,7 +113,7 @@ class MultiDMM(MultiDGTS):
             mean, std, seen = ops.gauss_mlp(x.flatten(0, 1), enc, nan_to_zero=True)
             return (mean.reshape(t_max, b_dim, -1), std.reshape(t_max, b_dim, -1),
                     seen.reshape(t_max, b_dim))
-        x, seen = self._clean(x)
+        x, seen = self._clean(x, self._frames_store(enc, x))
         if self.dists[m] == 'Categorical':
             stack = ops.embed_relu_stack(enc) if (x.is_cuda and x.shape[2:].numel() == 1 and self.plugin_dtype is None
                                                   and not torch.is_autocast_enabled()) else None
@@ -591,15 +591,13 @@ class MultiDMM(MultiDGTS):
         mask_f.record_stream(side); mask_kld.record_stream(side)
         side.wait_stream(main)
         # the two modes as two independent loss terms, each with its own decoder calls, on two streams
-        swap = os.environ.get('MDMM_TMP_SWAP', '0') == '1'
-        with (contextlib.nullcontext() if swap else torch.cuda.stream(side)):
+        with torch.cuda.stream(side):
             loss_f = f_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
                                               loss_mods, t_max, b_dim, f_mode, sample, sample_init, flt_particles,
                                               smt_particles)
-        with (torch.cuda.stream(side) if swap else contextlib.nullcontext()):
-            loss_s = s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
-                                              loss_mods, t_max, b_dim, s_mode, sample, sample_init, train_particles,
-                                              smt_particles)
+        loss_s = s_mult * self._mode_loss(enc, targets, (mask_f, mask_kld), kld_mult, rec_mults, pass_mods,
+                                          loss_mods, t_max, b_dim, s_mode, sample, sample_init, train_particles,
+                                          smt_particles)
         main.wait_stream(side)
         loss = loss_f + loss_s
         if loss_m is not None:

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 30
+ABI_VERSION = 31
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -25,7 +25,7 @@ SYMBOLS = [
     'mdmm_kld_gauss_fwd', 'mdmm_kld_gauss_bwd',
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
     'mdmm_nll_bernoulli_fwd', 'mdmm_nll_bernoulli_bwd',
-    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero', 'mdmm_fold_slabs', 'mdmm_embed_relu_supported', 'mdmm_embed_relu_slabs', 'mdmm_embed_relu_fwd',
+    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero', 'mdmm_nan_to_zero_bf16', 'mdmm_fold_slabs', 'mdmm_embed_relu_supported', 'mdmm_embed_relu_slabs', 'mdmm_embed_relu_fwd',
     'mdmm_embed_relu_bwd',
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
     'mdmm_philox_normal', 'mdmm_debug_clock', 'mdmm_gtf_pack_size', 'mdmm_gtf_pack',
@@ -300,6 +300,7 @@ def lib():
         L.mdmm_nll_bernoulli_logits_passes_bwd.argtypes = [_P, i32, i32, _P, _P, i64, i32, f32, C.POINTER(C.c_float), _P, _P, _P, i32, _P]
         L.mdmm_nll_chan_parts.argtypes = []
         L.mdmm_nan_to_zero.argtypes = [_P, i64, i32, _P, _P, _P]
+        L.mdmm_nan_to_zero_bf16.argtypes = [_P, i64, i32, _P, _P, _P]
         L.mdmm_fold_slabs.argtypes = [C.POINTER(FoldSlabs), _P]
         L.mdmm_embed_relu_supported.argtypes = [i32, i32]
         L.mdmm_embed_relu_slabs.argtypes = [i64]

@@ -1230,15 +1230,17 @@ def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=Non
                                              float(weight), into, int(passes), int(channels), pass_weight), into)
 
 
-def nan_to_zero(x, lead_dims=2):
-    """dmm.py:164-166 on the GPU in one pass: (x with NaN -> 0, per-row seen flag (fp32 0/1))."""
+def nan_to_zero(x, lead_dims=2, store=torch.float32):
+    """dmm.py:164-166 on the GPU in one pass: (x with NaN -> 0, per-row seen flag (fp32 0/1)).
+    store = torch.bfloat16: the cleaned tensor as bf16 (round to nearest even) -- for frames that only the tile
+    convolutions with bf16 activations read (they would round each element the same way while staging it)."""
     _need_gpu(x)
     xv = _f32c(x)
     rows = _lead_rows(x, lead_dims)
     inner = xv.numel() // rows
-    out = torch.empty_like(xv)
+    out = torch.empty_like(xv, dtype=store)
     seen = torch.empty(xv.shape[:lead_dims], device=xv.device, dtype=torch.float32)
-    _call('mdmm_nan_to_zero', _ptr(xv), rows, inner, _ptr(out), _ptr(seen))
+    _call('mdmm_nan_to_zero_bf16' if store is torch.bfloat16 else 'mdmm_nan_to_zero', _ptr(xv), rows, inner, _ptr(out), _ptr(seen))
     return out, seen
 
 

@@ -687,3 +687,46 @@ def test_bernoulli_logits_backward_channel_sums(dev, dtype, chans):
             loss = loss + 0.0 * y.float().sum()          # a second consumer of y: its gradient is a new tensor
         res.append(torch.autograd.grad(loss, layer.bias)[0])
     assert helpers.rel_err(res[0], res[1]) < 1e-5
+
+
+def test_cleaned_frames_stored_as_bf16_equal_fp32_frames(dev, monkeypatch):
+    """MultiDMM._encode_one on the tile convolutions with bf16 activations: the NaN -> 0 pass writes the frames as bf16
+    (mdmm_nan_to_zero_bf16) because the first Conv2d and its weight-gradient kernel round every element to bf16 while
+    they stage it anyway.  Against the fp32 frames (MultiDGTS._frames_store forced to fp32): seen flags, (mean, std)
+    and every encoder parameter's gradient bit for bit; in evaluation mode the frames stay fp32."""
+    import bench
+    from mdmm import models, ops
+    torch.manual_seed(5)
+    m = bench.Cfg3.model(models, dev)
+    T, B = 6, 10
+    x, _, _, _ = bench.Cfg3.batch(T, B, 77, dev)
+    assert torch.isnan(x['video']).any()
+    for mod in ('video', 'mask'):
+        enc = m.enc[mod]
+        assert m._frames_store(enc, x[mod]) is torch.bfloat16
+        enc.eval()
+        assert m._frames_store(enc, x[mod]) is torch.float32
+        enc.train()
+        res = {}
+        for store in ('bf16', 'f32'):
+            if store == 'f32':
+                m._frames_store = lambda e, t: torch.float32
+            monkeypatch.setattr(ops, 'TIMER', ops.KernelTimer())
+            ops.clear_caches(m.parameters())
+            mean, std, seen = m._encode_one(mod, x[mod])
+            calls = set(ops.TIMER.spans)
+            monkeypatch.setattr(ops, 'TIMER', None)
+            assert ('mdmm_nan_to_zero_bf16' in calls) == (store == 'bf16'), calls
+            assert ('mdmm_nan_to_zero' in calls) == (store == 'f32'), calls
+            gm = torch.randn(mean.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+            grads = torch.autograd.grad((mean * gm).sum() + (std * std).sum(), list(enc.parameters()), allow_unused=True)
+            res[store] = (mean, std, seen, grads)
+            if store == 'f32':
+                del m._frames_store
+        a, b = res['bf16'], res['f32']
+        assert torch.equal(a[2], b[2]) and not a[2].all() and a[2].any()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for (k, _), ga, gb in zip(enc.named_parameters(), a[3], b[3]):
+            assert (ga is None) == (gb is None), k
+            if ga is not None:
+                assert torch.equal(ga, gb), k
