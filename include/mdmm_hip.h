@@ -348,6 +348,15 @@ int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logits_bf16, in
                                          const float* seq_mask, int64_t rows, int inner, float scale,
                                          const float* pass_weight, const float* scale_dev, void* g_logits,
                                          float* chan_part, int channels, void* stream);
+/* Forward AND gradient of the stacked-passes Bernoulli loss in one pass over bf16 logits (the decoders' last Deconv
+ * output, common.py:163-165, scored by losses.py:45-58): out += weight * sum_ps pass_weight[ps] * BCE as
+ * mdmm_nll_bernoulli_logits_passes_fwd, and logits[ps][i] is OVERWRITTEN by e = weight * pass_weight[ps] * (sigmoid(l) - x)
+ * (0 where x is NaN or the row is masked), rounded to bf16: the gradient of the loss with respect to the logits up to
+ * the upstream scalar, which the consumers apply to their own outputs (mdmm_conv_t.out_scale) -- the backward pass over
+ * (logits, x) of mdmm_nll_bernoulli_logits_passes_bwd does not run at all.  chan_part / channels as there (sums of e).  */
+int mdmm_nll_bernoulli_logits_passes_fwd_grad(void* logits, int passes, const float* x, const float* seq_mask,
+                                              int64_t rows, int inner, float weight, const float* pass_weight,
+                                              double* out, float* chan_part, int channels, void* stream);
 /* NaN -> 0 and the per-row "seen" flag of MultiDMM.encode (dmm.py:164-166) in one pass:
  * out[r][i] = isnan(x[r][i]) ? 0 : x[r][i];  seen[r] = no NaN in row r  (float 0 / 1).  */
 int mdmm_nan_to_zero(const float* x, int64_t rows, int inner, float* out, float* seen, void* stream);
@@ -661,6 +670,12 @@ typedef struct mdmm_conv {
    * that output, (N, CS, S, S) bf16 -- the ReLU's adjoint is applied as the values are stored (0 where small_relu_of <= 0,
    * aten::threshold_backward's test), one pass over the 4096-wide gradient less.  NULL: none.  */
   const void* small_relu_of;
+  /* mdmm_conv_down / mdmm_conv_wgrad with a BIG side that is a gradient still to be multiplied by a device scalar
+   * (mdmm_nll_bernoulli_logits_passes_fwd_grad leaves the loss's gradient without the upstream factor): *out_scale
+   * multiplies what the launch writes instead -- every small-side value of mdmm_conv_down before it is rounded and stored,
+   * dW of mdmm_conv_wgrad in its last fold pass (both are linear in that side; bst_dy, already a product of
+   * mdmm_conv_down, is taken as it is).  NULL: 1.  */
+  const float* out_scale;
 } mdmm_conv_t;
 int mdmm_conv_supported(const mdmm_conv_t* args);
 int64_t mdmm_conv_pack_bytes(const mdmm_conv_t* args, int up);

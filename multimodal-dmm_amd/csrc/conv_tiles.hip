@@ -607,6 +607,7 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
   // which a request in the epilogue would queue behind (memory operations retire in order) -- and kept as one bit each
   constexpr int NT = NPIX / 32;
   const __bf16* const relu_of = SB ? reinterpret_cast<const __bf16*>(a.small_relu_of) : nullptr;
+  const float osc = a.out_scale ? *a.out_scale : 1.0f;       // (a big side that still lacks its upstream scalar: mdmm_conv_t.out_scale)
   for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
     const size_t src0 = (size_t)n * cb * BPIX;
     const size_t dst0 = (size_t)n * CS * NPIX;
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
 #pragma unroll
       for (int r = 0; r < RV; ++r) {
         const int m = 32 * mt + acc_row(r) + 4 * h;
-        float v = acc[r] + ((G::MT_S > 1 && mt) ? b1[r] : b0[r]);
+        float v = (acc[r] + ((G::MT_S > 1 && mt) ? b1[r] : b0[r])) * osc;
         if (relu_of) {                      // (later jobs of a wave, the 16 x 16 and 32 x 32 layers: fetched here)
           const bool dead = job == wave ? ((dead0 >> r) & 1u) != 0 : (float)relu_of[dst0 + (size_t)m * NPIX + p] <= 0.f;
           if (dead) v = 0.f;
@@ -1138,7 +1139,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, fl
 
 // dst[g][e] = sum over p = g, g + groups, ... of src[p][e]; perm_cb > 0 (last pass, groups = 1): element e of a slab is
 // (cs, ptap, b) = (e / (kk perm_cb), ...) -- taps in the slabs' class-major order, wg_tap -- and lands at dW's [cs][b][tap]
-__global__ void conv_fold_kernel(const float* src, int parts, int64_t elems, int groups, float* dst, int perm_cb, int kk) {
+__global__ void conv_fold_kernel(const float* src, int parts, int64_t elems, int groups, float* dst, int perm_cb, int kk,
+                                 const float* scale) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
   if (e >= elems) return;
@@ -1157,7 +1159,8 @@ __global__ void conv_fold_kernel(const float* src, int parts, int64_t elems, int
     const int ncol = kk * perm_cb, col = (int)(e % ncol);
     at = (e / ncol) * ncol + (int64_t)(col % perm_cb) * kk + wg_tap(col / perm_cb, kk == 16 ? 4 : 3);
   }
-  dst[(size_t)g * elems + at] = (s0 + s1) + (s2 + s3);
+  const float sum = (s0 + s1) + (s2 + s3);
+  dst[(size_t)g * elems + at] = scale ? sum * *scale : sum;       // (mdmm_conv_t.out_scale, last pass)
 }
 
 int shape_id(const mdmm_conv_t* a) {
@@ -1504,10 +1507,13 @@ extern "C" int mdmm_conv_wgrad(const mdmm_conv_t* a, void* ws, float* dw, void* 
   const unsigned blocks = (unsigned)((elems + 255) / 256);
   if (parts > 4 * WGRAD_FOLD) {
     float* folded = part + (size_t)parts * elems;
-    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, WGRAD_FOLD), dim3(256), 0, st, part, parts, elems, WGRAD_FOLD, folded, 0, 0);
-    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, 1), dim3(256), 0, st, folded, WGRAD_FOLD, elems, 1, dw, a->CB, a->KS * a->KS);
+    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, WGRAD_FOLD), dim3(256), 0, st, part, parts, elems, WGRAD_FOLD, folded, 0, 0,
+                       (const float*)nullptr);
+    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, 1), dim3(256), 0, st, folded, WGRAD_FOLD, elems, 1, dw, a->CB, a->KS * a->KS,
+                       a->out_scale);
   } else {
-    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, 1), dim3(256), 0, st, part, parts, elems, 1, dw, a->CB, a->KS * a->KS);
+    hipLaunchKernelGGL(conv_fold_kernel, dim3(blocks, 1), dim3(256), 0, st, part, parts, elems, 1, dw, a->CB, a->KS * a->KS,
+                       a->out_scale);
   }
   return (int)hipGetLastError();
 }

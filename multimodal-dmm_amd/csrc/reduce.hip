@@ -307,6 +307,66 @@ __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ thet
   }
 }
 
+// Forward and gradient of the stacked passes in one pass over bf16 logits (mdmm_nll_bernoulli_logits_passes_fwd_grad):
+// the loss as nllb_fwd_kernel<true, __bf16>, and every logit overwritten by weight * w_ps * (sigmoid(l) - x) -- the
+// arithmetic of nllb_grad<true, __bf16> with the upstream scalar left to the consumers (mdmm_conv_t.out_scale).
+// Masked rows and NaN observations get zeros (nllb_bwd_kernel writes them too).  chan_part as in nllb_bwd_kernel.
+__global__ __launch_bounds__(NT) void nllb_fwd_grad_kernel(__bf16* __restrict__ theta,
+    const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
+    float weight, double* out, int passes, float* chan_part, int chan4, PassW pw) {
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  const int inner4 = inner >> 2;
+  const int64_t stride = (int64_t)gridDim.x * NT;
+  RowWalk rw((int64_t)blockIdx.x * NT + threadIdx.x, stride, inner4);
+  float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride, rw.next()) {
+    const bool on = !(mask && mask[rw.row] == 0.f);
+    if (!on) {
+      const float z[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int ps = 0; ps < passes; ++ps) st4g(theta, i + ps * n4, z);
+      continue;
+    }
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float gs = 0.f;
+    for (int ps = 0; ps < passes; ++ps) {
+      const float4 th = ld4f(theta, i + ps * n4);
+      const float ts[4] = {th.x, th.y, th.z, th.w};
+      const float sc = pw.uniform ? weight : weight * pw.w[ps & 7];
+      float a = 0.f, g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        g[j] = 0.f;
+        if (xs[j] != xs[j]) continue;
+        a += softplus_fast(ts[j]) - xs[j] * ts[j];
+        g[j] = sc * (mdmm::fast::sigmoid(ts[j]) - xs[j]);
+      }
+      acc += pw.uniform ? a : pw.w[ps & 7] * a;
+      st4g(theta, i + ps * n4, g);
+      if (chan_part) gs += ((float)(__bf16)g[0] + (float)(__bf16)g[1]) + ((float)(__bf16)g[2] + (float)(__bf16)g[3]);
+    }
+    if (chan_part) {
+      const int c = rw.rem / chan4;
+      cs0 += c == 0 ? gs : 0.f; cs1 += c == 1 ? gs : 0.f; cs2 += c == 2 ? gs : 0.f; cs3 += c == 3 ? gs : 0.f;
+    }
+  }
+  if (chan_part) {
+    __shared__ float red[NT / 64][4];
+    cs0 = wave_sum(cs0); cs1 = wave_sum(cs1); cs2 = wave_sum(cs2); cs3 = wave_sum(cs3);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[w][0] = cs0; red[w][1] = cs1; red[w][2] = cs2; red[w][3] = cs3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      float t = 0.f;
+      for (int k = 0; k < NT / 64; ++k) t += red[k][threadIdx.x];
+      chan_part[(size_t)blockIdx.x * 4 + threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+  block_add((double)weight * (double)acc, out);
+}
+
 // ---------------------------------------------------------------- nll_categorical --
 __global__ __launch_bounds__(NT) void nllc_fwd_kernel(const float* __restrict__ probs,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t rows, int n_cat,
@@ -654,6 +714,23 @@ extern "C" int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logi
   else
     hipLaunchKernelGGL((nllb_bwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
                        (const float*)logits, x, seq_mask, n, inner, scale, scale_dev, (float*)g_logits, passes, chan_part, chan4, pass_w(pass_weight, passes));
+  CHECK_LAUNCH();
+}
+
+extern "C" int mdmm_nll_bernoulli_logits_passes_fwd_grad(void* logits, int passes, const float* x, const float* seq_mask,
+                                                         int64_t rows, int inner, float weight, const float* pass_weight,
+                                                         double* out, float* chan_part, int channels, void* stream) {
+  if (!logits || !x || !out || rows < 0 || inner < 1 || passes < 1 || (pass_weight && passes > 8)) return MDMM_E_ARG;
+  const int64_t n = rows * inner;
+  if ((inner & 3) || (n & 3)) return MDMM_E_ARG;        // (whole float4s per row: the image decoders' logits)
+  if (((uintptr_t)logits & 7) || ((uintptr_t)x & 15)) return MDMM_E_ALIGN;
+  int chan4 = 0;
+  if (chan_part) {
+    if (channels < 1 || channels > 4 || inner % (4 * channels)) return MDMM_E_ARG;
+    chan4 = inner / (4 * channels);
+  }
+  hipLaunchKernelGGL(nllb_fwd_grad_kernel, dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM, (__bf16*)logits, x, seq_mask,
+                     n, inner, weight, out, passes, chan_part, chan4, pass_w(pass_weight, passes));
   CHECK_LAUNCH();
 }
 

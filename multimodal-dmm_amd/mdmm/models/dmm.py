@@ -470,7 +470,7 @@ class MultiDMM(MultiDGTS):
                 stacked = self._decode_for_loss(m, z_list, logits=True, stacked=True) if len(z_list) <= 8 else None
                 if stacked is not None:     # the passes as one batch: scored in place, one gradient buffer
                     ops.nll_bernoulli_logits(stacked[0], targets[m], mask, 2, float(mult), total, passes=len(z_list),
-                                             pass_weight=w_list)
+                                             pass_weight=w_list, consume=True)
                     return
                 for rec, w in zip(self._decode_for_loss(m, z_list, logits=True), w_list):
                     ops.nll_bernoulli_logits(rec[0], targets[m], mask, 2, float(mult) * w, total)

@@ -25,7 +25,7 @@ SYMBOLS = [
     'mdmm_kld_gauss_fwd', 'mdmm_kld_gauss_bwd',
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
     'mdmm_nll_bernoulli_fwd', 'mdmm_nll_bernoulli_bwd',
-    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero', 'mdmm_nan_to_zero_bf16', 'mdmm_fold_slabs', 'mdmm_embed_relu_supported', 'mdmm_embed_relu_slabs', 'mdmm_embed_relu_fwd',
+    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero', 'mdmm_nan_to_zero_bf16', 'mdmm_nll_bernoulli_logits_passes_fwd_grad', 'mdmm_fold_slabs', 'mdmm_embed_relu_supported', 'mdmm_embed_relu_slabs', 'mdmm_embed_relu_fwd',
     'mdmm_embed_relu_bwd',
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
     'mdmm_philox_normal', 'mdmm_debug_clock', 'mdmm_gtf_pack_size', 'mdmm_gtf_pack',
@@ -181,7 +181,7 @@ class Conv(C.Structure):
                  ('reserved', C.c_int32)] +
                 [('bst_dy', _P), ('bst_part', _P)] +
                 [(n, _P) for n in ('lazy_dy', 'lazy_x', 'lazy_mean', 'lazy_invstd', 'lazy_gamma', 'lazy_beta', 'lazy_means')] +
-                [('lazy_group_n', C.c_int32), ('lazy_relu', C.c_int32), ('small_relu_of', _P)])
+                [('lazy_group_n', C.c_int32), ('lazy_relu', C.c_int32), ('small_relu_of', _P), ('out_scale', _P)])
 
 
 class ConvF(C.Structure):
@@ -298,6 +298,7 @@ def lib():
         L.mdmm_nll_bernoulli_logits_bf16_bwd.argtypes = [_P, _P, _P, i64, i32, f32, _P, _P, _P]
         L.mdmm_nll_bernoulli_logits_passes_fwd.argtypes = [_P, i32, i32, _P, _P, i64, i32, f32, C.POINTER(C.c_float), _P, _P]
         L.mdmm_nll_bernoulli_logits_passes_bwd.argtypes = [_P, i32, i32, _P, _P, i64, i32, f32, C.POINTER(C.c_float), _P, _P, _P, i32, _P]
+        L.mdmm_nll_bernoulli_logits_passes_fwd_grad.argtypes = [_P, i32, _P, _P, i64, i32, f32, C.POINTER(C.c_float), _P, _P, i32, _P]
         L.mdmm_nll_chan_parts.argtypes = []
         L.mdmm_nan_to_zero.argtypes = [_P, i64, i32, _P, _P, _P]
         L.mdmm_nan_to_zero_bf16.argtypes = [_P, i64, i32, _P, _P, _P]

@@ -373,6 +373,10 @@ def clear_caches(params=()):
     """Drop host-side caches (call before capturing a step into a HIP graph)."""
     _GRAD_CHANSUM.clear()
     _LAZY_BN.clear()
+    if _GRAD_SCALE:
+        _GRAD_SCALE.clear()
+        raise native.MdmmError('a Bernoulli-loss gradient left without its upstream scalar was never taken by the layer that '
+                               'produced the logits (ops._GRAD_SCALE): the last backward pass used an unscaled gradient')
     for p in params:
         if hasattr(p, '_mdmm_pack'):
             del p._mdmm_pack
@@ -1115,7 +1119,7 @@ class _NllBernLogitsFn(torch.autograd.Function):
     have to stack)."""
 
     @staticmethod
-    def forward(ctx, logits, x, mask, rows, inner, weight, into, passes=1, channels=0, pass_weight=None):
+    def forward(ctx, logits, x, mask, rows, inner, weight, into, passes=1, channels=0, pass_weight=None, consume=False):
         _need_gpu(logits, x)
         lg, xv = _act(logits), _f32c(x)
         if lg.numel() != passes * rows * inner:
@@ -1127,15 +1131,34 @@ class _NllBernLogitsFn(torch.autograd.Function):
             if len(pass_weight) != passes or passes > 8:
                 raise ValueError('pass_weight: one multiplier per pass, at most 8 passes')
             ctx.pw = (C.c_float * passes)(*[float(w) for w in pass_weight])      # (host array, read at launch)
+        ctx.mask, ctx.rows, ctx.inner, ctx.weight, ctx.passes = mask, rows, inner, weight, passes
+        ctx.channels = channels if (0 < channels <= 4 and inner % (4 * channels) == 0 and (rows * inner) % 4 == 0) else 0
+        # consume: the caller gives the logits up (nll_bernoulli_logits checked who made them): one pass forms the loss AND
+        # overwrites them with their gradient up to the upstream scalar, which the producing layer's backward applies to
+        # its own outputs (mdmm_conv_t.out_scale) -- the backward pass over (logits, x) does not run
+        ctx.fused = bool(consume and ctx.bf and lg is logits and inner % 4 == 0 and (rows * inner) % 4 == 0)
+        if ctx.fused:
+            part = None
+            if ctx.channels:
+                part = torch.zeros(native.lib().mdmm_nll_chan_parts(), 4, device=lg.device, dtype=torch.float32)
+            _call('mdmm_nll_bernoulli_logits_passes_fwd_grad', _ptr(lg), passes, _ptr(xv), _ptr(mask), rows, inner,
+                  weight, ctx.pw, _ptr(acc), _ptr(part), ctx.channels, tag='mdmm_nll_bernoulli_logits_fwd')
+            ctx.save_for_backward(lg, part)
+            return _term_out(acc, into, lg.device)
         _call('mdmm_nll_bernoulli_logits_passes_fwd', _ptr(lg), int(ctx.bf), passes, _ptr(xv), _ptr(mask), rows, inner,
               weight, ctx.pw, _ptr(acc), tag='mdmm_nll_bernoulli_logits_fwd')
         ctx.save_for_backward(lg, xv)
-        ctx.mask, ctx.rows, ctx.inner, ctx.weight, ctx.passes = mask, rows, inner, weight, passes
-        ctx.channels = channels if (0 < channels <= 4 and inner % (4 * channels) == 0 and (rows * inner) % 4 == 0) else 0
         return _term_out(acc, into, lg.device)
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.fused:
+            e, part = ctx.saved_tensors
+            gd = _gdev(g)
+            if part is not None:
+                _stash_chansum(e, colsum(part)[:ctx.channels] * gd)
+            _stash_scale(e, gd)
+            return e, None, None, None, None, None, None, None, None, None, None
         lg, xv = ctx.saved_tensors
         gl = torch.empty_like(lg)
         gd = _gdev(g)
@@ -1147,7 +1170,7 @@ class _NllBernLogitsFn(torch.autograd.Function):
               tag='mdmm_nll_bernoulli_logits_bwd')
         if part is not None:
             _stash_chansum(gl, colsum(part)[:ctx.channels])
-        return gl, None, None, None, None, None, None, None, None, None
+        return gl, None, None, None, None, None, None, None, None, None, None
 
 
 # Per-channel sums of a gradient tensor that its producer had at hand, for the consumer that needs them as a bias
@@ -1168,6 +1191,36 @@ def _take_chansum(g, channels):
     if hit is not None and hit[0].numel() == g.numel() and hit[0].dtype == g.dtype and hit[1].numel() == channels:
         return hit[1]
     return None
+
+
+# A gradient tensor that still lacks its upstream scalar (_NllBernLogitsFn with consume: the loss's forward kernel wrote
+# it, the scalar exists only now, in the backward pass): the producing layer's backward -- checked when the forward was
+# built, scaled_grad_ok -- multiplies its own outputs by it instead (mdmm_conv_t.out_scale).  Keyed by the tensor's address,
+# the tensor kept alive with the entry.  An entry nobody took is a gradient that went on unscaled: clear_caches raises.
+_GRAD_SCALE = {}
+
+
+def _stash_scale(g, gd):
+    _GRAD_SCALE[g.data_ptr()] = (g, gd)
+
+
+def _take_scale(g):
+    hit = _GRAD_SCALE.pop(g.data_ptr(), None)
+    if hit is None:
+        return None
+    if hit[0] is not g and not (hit[0].shape == g.shape and hit[0].dtype == g.dtype):
+        raise native.MdmmError('a gradient that lacks its upstream scalar reached a consumer in another form (%s %s for %s %s)'
+                               % (tuple(g.shape), g.dtype, tuple(hit[0].shape), hit[0].dtype))
+    return hit[1]
+
+
+def scaled_grad_ok(logits):
+    """`logits` comes straight out of a layer whose backward multiplies its outputs by a pending upstream scalar
+    (_BnDeconvFn as a ConvTranspose2d on bf16 activations) and is contiguous bf16: the Bernoulli loss may overwrite it
+    with its gradient in the forward pass."""
+    fn = getattr(logits, 'grad_fn', None)
+    return (fn is not None and type(fn).__name__ == '_BnDeconvFnBackward' and getattr(fn, 'takes_scale', False)
+            and logits.dtype == torch.bfloat16 and logits.is_contiguous() and torch.is_grad_enabled())
 
 
 # A BatchNorm adjoint that has only been REDUCED (_BnDeconvFn.backward with lazy_dx): the tensor it returns as dx is
@@ -1218,7 +1271,8 @@ def lazy_bn_ok(x_pre):
             and x_pre.dim() == 4 and x_pre.shape[1] in (16, 32) and x_pre.dtype == torch.bfloat16 and x_pre.is_contiguous())
 
 
-def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None, passes=1, channels=0, pass_weight=None):
+def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None, passes=1, channels=0, pass_weight=None,
+                         consume=False):
     """losses.py:23-42 on the pre-sigmoid activations of a decoder whose last module is nn.Sigmoid
     (common.py:163-165): sigmoid + binary cross entropy + masks in one pass each way.  passes: logits =
     that many stacked passes, each scored against x (the sum of their terms)."""
@@ -1226,8 +1280,11 @@ def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=Non
     inner = x.numel() // rows
     if not channels and x.dim() == lead_dims + 3:       # (T, B, C, H, W) observations: C channels per row
         channels = x.shape[lead_dims]
+    # consume: the caller has no further use for `logits` (MultiDMM._score_modality: the decoder output exists for this
+    # loss only) -- see _NllBernLogitsFn.forward
+    consume = bool(consume) and scaled_grad_ok(logits) and logits.requires_grad
     return _term_done(_NllBernLogitsFn.apply(logits, x, _row_mask(mask, rows, x), rows, inner,
-                                             float(weight), into, int(passes), int(channels), pass_weight), into)
+                                             float(weight), into, int(passes), int(channels), pass_weight, consume), into)
 
 
 def nan_to_zero(x, lead_dims=2, store=torch.float32):
@@ -2586,6 +2643,9 @@ class _BnDeconvFn(torch.autograd.Function):
         # this deconvolution's own backward takes such a gradient for its output when its big side has 16 channels
         ctx.lazy_dx = bool(G <= 8 and lazy_bn_ok(x_pre))
         ctx.lazy_consumer = bool(transposed and ks == 4 and cb == 16 and side == 16)
+        # (an output gradient that still lacks its upstream scalar is taken as it is: backward multiplies this layer's own
+        #  outputs by it, scaled_grad_ok)
+        ctx.takes_scale = bool(transposed)
         ctx.has_bias = bias is not None
         ctx.shift_like = None if shift is None else shift.detach()
         if part_out is not None:
@@ -2602,7 +2662,10 @@ class _BnDeconvFn(torch.autograd.Function):
         if gy is None:
             return None, None, None, None, shift_grad, None, None, None, None, None
         lazy_in = _lazy_take(gy)             # gy still unwritten: the BatchNorm behind this layer left its apply pass to us
+        osc = _take_scale(gy)                # gy lacks its upstream scalar (the Bernoulli loss's forward kernel wrote it)
         gy = _act(gy)
+        if osc is not None and not (ctx.takes_scale and gy.dtype == torch.bfloat16):
+            gy, osc = (gy.float() * osc).to(gy.dtype), None
         if gy.dtype != torch.bfloat16:
             gy = gy.to(torch.bfloat16)
         Ng, Cc, Ln, splits, eps, G, transposed = ctx.meta
@@ -2612,6 +2675,7 @@ class _BnDeconvFn(torch.autograd.Function):
         small, big = (x, gy) if transposed else (gy, x)
         c = _conv_desc(N, small.shape, big.shape, ks)
         c.flags = _conv_flags(small, big)
+        c.out_scale = _ptr(osc)              # (mdmm_conv_down's small side and mdmm_conv_wgrad's dW, both linear in gy)
         need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         bst_part = None
         if need_x:
@@ -2653,6 +2717,8 @@ class _BnDeconvFn(torch.autograd.Function):
             gb = _take_chansum(gy, gy.shape[1])
             if gb is None:
                 gb = colsum(gy.reshape(N, -1)).reshape(gy.shape[1], -1).sum(1)
+                if osc is not None:
+                    gb = gb * osc
         if need_x:
             a = native.Bn()
             a.N, a.C, a.L, a.relu, a.splits, a.eps, a.groups = Ng, Cc, Ln, 1, splits, eps, G

@@ -730,3 +730,61 @@ def test_cleaned_frames_stored_as_bf16_equal_fp32_frames(dev, monkeypatch):
             assert (ga is None) == (gb is None), k
             if ga is not None:
                 assert torch.equal(ga, gb), k
+
+
+@pytest.mark.parametrize('chans', [1, 3])
+def test_bernoulli_loss_writes_its_gradient_in_the_forward_pass(dev, chans, monkeypatch):
+    """nll_bernoulli_logits(consume=True) behind an ImageDecoder on bf16 activations: one launch forms the loss and
+    overwrites the logits with weight * w_pass * (sigmoid(l) - x); the upstream scalar, known only in the backward pass,
+    multiplies the last Deconv's own outputs (mdmm_conv_t.out_scale: the input gradient in mdmm_conv_down's epilogue, dW
+    in the last fold pass, the bias gradient from the loss kernel's channel sums) -- mdmm_nll_bernoulli_logits_passes_bwd
+    does not run.  Against the separate backward kernel: loss bit for bit, every gradient to the rounding of a bf16 value
+    before instead of after one multiplication (the scalar is not a power of two here)."""
+    import copy
+    from mdmm import ops
+    from mdmm.models import common as C
+    torch.manual_seed(40 + chans)
+    T, B, P = 8, 32, 2          # (512 frames: the z_to_feat projection takes the tile GEMM from 512 rows on)
+    ref = C.ImageDecoder(256, n_channels=chans).to(dev).train()
+    z0 = torch.randn(P * T * B, 256, device=dev)
+    x = torch.rand(T, B, chans, 64, 64, device=dev)
+    x[1, 2] = float('nan')
+    x[2, 5, 0, 3:9] = float('nan')
+    mask = torch.ones(T, B, dtype=torch.bool, device=dev)
+    mask[6, 20:] = False
+    up = torch.tensor(0.37 / 1234.0, device=dev)          # the upstream factor, a device scalar at backward time only
+    res = {}
+    for consume in (True, False):
+        dec = copy.deepcopy(ref)
+        z = z0.clone().requires_grad_()
+        monkeypatch.setattr(ops, 'TIMER', ops.KernelTimer())
+        with ops.conv_operands(torch.bfloat16, torch.bfloat16), ops.bn_groups(P):
+            lg = dec(z, logits=True)[0]
+        assert lg.dtype == torch.bfloat16 and ops.scaled_grad_ok(lg)
+        keep = lg.detach().clone()
+        loss = ops.nll_bernoulli_logits(lg, x, mask, 2, 1.7, None, passes=P, pass_weight=[0.5, 0.25], consume=consume)
+        assert torch.equal(lg.detach(), keep) != consume          # (consumed: the logits are gone)
+        grads = torch.autograd.grad(loss * up, [z] + list(dec.parameters()), allow_unused=True)
+        calls = set(ops.TIMER.spans)
+        monkeypatch.setattr(ops, 'TIMER', None)
+        assert ('mdmm_nll_bernoulli_logits_bwd' in calls) != consume, calls
+        assert not ops._GRAD_SCALE and not ops._LAZY_BN
+        res[consume] = (loss.detach(), grads)
+    assert torch.equal(res[True][0], res[False][0])
+    names = ['z'] + [k for k, _ in ref.named_parameters()]
+    worst = 0.0
+    for k, a_, b_ in zip(names, res[True][1], res[False][1]):
+        assert (a_ is None) == (b_ is None), k
+        if a_ is not None:
+            # (every activation gradient down the chain is stored as bf16 -- another rounding of slightly other values at
+            #  each of its five stores, 2^-9 relative per element, carried through sums of terms of either sign)
+            e = float((a_.float() - b_.float()).norm() / (b_.float().norm() + 1e-30))
+            worst = max(worst, e)
+            assert e < 1e-2 and helpers.rel_err(a_, b_) < 3e-2, (k, e, helpers.rel_err(a_, b_))
+    assert worst > 0.0
+    helpers.note('bernoulli_grad_in_forward[c=%d].l2' % chans, worst)
+    # logits that no tile deconvolution produced: `consume` is not taken, they are left alone
+    free = (torch.randn(P * T * B, chans, 64, 64, device=dev) * 2).to(torch.bfloat16).requires_grad_()
+    keep = free.detach().clone()
+    g, = torch.autograd.grad(ops.nll_bernoulli_logits(free, x, mask, 2, 1.7, None, passes=P, consume=True), free)
+    assert torch.equal(free.detach(), keep) and g.data_ptr() != free.data_ptr() and not ops._GRAD_SCALE
