@@ -568,8 +568,12 @@ def run(cfg, args, world, rank, device, graph):
     torch.manual_seed(0)                    # identical weights on every rank
     model = cfg.model(models, device)
     model.noise = PhiloxNoise(seed=1000 + rank)
-    optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr, capturable=graph, fused=True)
     bucket = GradBucket(model.parameters())
+    if getattr(args, 'torch_adam', False):      # (A/B: the framework's fused multi-tensor Adam, three launches)
+        optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr, capturable=graph, fused=True)
+    else:                                       # torch.optim.Adam's update as one launch over the flat bucket
+        from mdmm.harness import FlatAdam
+        optimizer = FlatAdam(bucket, lr=cfg.lr)
     b_dim = args.batch or cfg.B
     inputs, targets, mask, lengths = cfg.batch(cfg.T, b_dim, 1234 + rank, device)
     n_points_global = sum(lengths) * world
@@ -748,6 +752,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the cfg2 / cfg4 lines that ride along')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay of the step')
+    ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam(fused=True) instead of harness.FlatAdam')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.steps is None:

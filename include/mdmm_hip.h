@@ -357,6 +357,16 @@ int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logits_bf16, in
 int mdmm_nll_bernoulli_logits_passes_fwd_grad(void* logits, int passes, const float* x, const float* seq_mask,
                                               int64_t rows, int inner, float weight, const float* pass_weight,
                                               double* out, float* chan_part, int channels, void* stream);
+/* torch.optim.Adam's update (the optimizer trainer.py:212 builds; no amsgrad, L2 weight decay added to the gradient) in
+ * one streaming launch: gradients and both moments as flat fp32 buffers of n elements in which parameter k owns
+ * [offs[k], offs[k + 1]) (offs: n_params + 1 entries, offs[0] = 0, offs[n_params] = n; harness.GradBucket's packing), the
+ * parameters where they live (p_ptrs[k] = parameter k's fp32 storage, contiguous) -- both tables in device memory.
+ *   gr = g + weight_decay p;  m += (1 - beta1)(gr - m);  v = beta2 v + (1 - beta2) gr^2;
+ *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps),  t = *step
+ * (a device scalar holding the count of this update, 1 for the first).  lr_dev (optional device scalar) overrides lr.  */
+int mdmm_adam_flat(float* const* p_ptrs, const int64_t* offs, int n_params, const float* g, float* m, float* v, int64_t n,
+                   const float* step, const float* lr_dev, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, void* stream);
 /* NaN -> 0 and the per-row "seen" flag of MultiDMM.encode (dmm.py:164-166) in one pass:
  * out[r][i] = isnan(x[r][i]) ? 0 : x[r][i];  seen[r] = no NaN in row r  (float 0 / 1).  */
 int mdmm_nan_to_zero(const float* x, int64_t rows, int inner, float* out, float* seen, void* stream);

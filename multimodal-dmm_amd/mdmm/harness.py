@@ -90,6 +90,95 @@ class GradBucket:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
 
 
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay) -- the optimizer the reference trainer builds
+    (trainer.py:212-213) -- for the parameters of a GradBucket, as ONE launch per step (csrc/reduce.hip,
+    mdmm_adam_flat): the gradients are the bucket's flat buffer, both moments are flat buffers in the same packing,
+    the parameters stay where they are (a device table of their addresses).  The framework's fused multi-tensor
+    kernel spends 0.25 ms in three launches of ~90 workgroups on the Weizmann model's 7.5 M parameters, at the tail
+    of a step where nothing runs beside it.  Capturable: the step count is a device scalar.  `step()` needs every
+    gradient to be the bucket's view (GradBucket.check_views(), which elbo_step / GraphedElboStep call).
+    state_dict(): per parameter {'step', 'exp_avg', 'exp_avg_sq'} as torch.optim.Adam keeps them."""
+
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if not bucket.flat.is_cuda:
+            raise RuntimeError('FlatAdam runs on the GPU (mdmm_adam_flat); use torch.optim.Adam on the CPU')
+        super().__init__(bucket.params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError('FlatAdam: one parameter group (the bucket)')
+        self.bucket = bucket
+        dev, n = bucket.flat.device, bucket.flat.numel()
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        offs = [0]
+        for p in bucket.params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError('FlatAdam: contiguous fp32 parameters')
+            offs.append(offs[-1] + p.numel())
+        self._offs = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self._ptrs, self._ptr_key = None, None
+        for p, lo, hi in zip(bucket.params, offs, offs[1:]):
+            self.state[p] = {'step': self.step_dev.reshape(()), 'exp_avg': self.exp_avg[lo:hi].view_as(p),
+                             'exp_avg_sq': self.exp_avg_sq[lo:hi].view_as(p)}
+
+    def _table(self):
+        key = tuple(p.data_ptr() for p in self.bucket.params)
+        if key != self._ptr_key:          # (a parameter's storage moved: model.to(), load with assign=True)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('FlatAdam: a parameter\'s storage changed; run one eager step before capturing')
+            self._ptrs = torch.tensor(key, dtype=torch.int64, device=self.bucket.flat.device)
+            self._ptr_key = key
+        return self._ptrs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import native, ops
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        b, grp = self.bucket, self.param_groups[0]
+        off = 0
+        for p in b.params:                 # (host check, no launch: the kernel reads the flat buffer)
+            if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + 4 * off:
+                raise RuntimeError('FlatAdam.step: gradients must be the bucket\'s views (GradBucket.check_views())')
+            off += p.numel()
+        ptrs = self._table()
+        self.step_dev.add_(1.0)
+        lr = grp['lr']
+        lr_dev = lr if isinstance(lr, torch.Tensor) else None
+        with torch.cuda.device(b.flat.device):
+            ops._call('mdmm_adam_flat', ptrs.data_ptr(), self._offs.data_ptr(), len(b.params), b.flat.data_ptr(),
+                      self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), b.flat.numel(), self.step_dev.data_ptr(),
+                      None if lr_dev is None else lr_dev.to(torch.float32).data_ptr(), 0.0 if lr_dev is not None else float(lr),
+                      float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']))
+        return loss
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam's (or this class's) state: copied INTO the flat buffers (the views stay views)."""
+        sd = state_dict['state']
+        ids = state_dict['param_groups'][0]['params']
+        if len(ids) != len(self.bucket.params):
+            raise ValueError('optimizer state for %d parameters, bucket holds %d' % (len(ids), len(self.bucket.params)))
+        steps = set()
+        with torch.no_grad():
+            for p, i in zip(self.bucket.params, ids):
+                st = sd.get(i)
+                if st is None:
+                    continue
+                self.state[p]['exp_avg'].copy_(st['exp_avg'])
+                self.state[p]['exp_avg_sq'].copy_(st['exp_avg_sq'])
+                steps.add(float(st['step']))
+            if len(steps) > 1:
+                raise ValueError('FlatAdam keeps one step count; the loaded state holds %s' % sorted(steps))
+            if steps:
+                self.step_dev.fill_(steps.pop())
+        for k, val in state_dict['param_groups'][0].items():
+            if k != 'params' and k in self.param_groups[0]:
+                self.param_groups[0][k] = val
+
+
 def shard_batch(inputs, mask, lengths, rank, world):
     """Contiguous split of the batch dimension (dim 1 of the time-first tensors)."""
     b_dim = len(lengths)

@@ -25,7 +25,7 @@ SYMBOLS = [
     'mdmm_kld_gauss_fwd', 'mdmm_kld_gauss_bwd',
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
     'mdmm_nll_bernoulli_fwd', 'mdmm_nll_bernoulli_bwd',
-    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero', 'mdmm_nan_to_zero_bf16', 'mdmm_nll_bernoulli_logits_passes_fwd_grad', 'mdmm_fold_slabs', 'mdmm_embed_relu_supported', 'mdmm_embed_relu_slabs', 'mdmm_embed_relu_fwd',
+    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero', 'mdmm_nan_to_zero_bf16', 'mdmm_adam_flat', 'mdmm_nll_bernoulli_logits_passes_fwd_grad', 'mdmm_fold_slabs', 'mdmm_embed_relu_supported', 'mdmm_embed_relu_slabs', 'mdmm_embed_relu_fwd',
     'mdmm_embed_relu_bwd',
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
     'mdmm_philox_normal', 'mdmm_debug_clock', 'mdmm_gtf_pack_size', 'mdmm_gtf_pack',
@@ -302,6 +302,7 @@ def lib():
         L.mdmm_nll_chan_parts.argtypes = []
         L.mdmm_nan_to_zero.argtypes = [_P, i64, i32, _P, _P, _P]
         L.mdmm_nan_to_zero_bf16.argtypes = [_P, i64, i32, _P, _P, _P]
+        L.mdmm_adam_flat.argtypes = [_P, _P, i32, _P, _P, _P, i64, _P, _P, f32, f32, f32, f32, f32, _P]
         L.mdmm_fold_slabs.argtypes = [C.POINTER(FoldSlabs), _P]
         L.mdmm_embed_relu_supported.argtypes = [i32, i32]
         L.mdmm_embed_relu_slabs.argtypes = [i64]

@@ -411,3 +411,58 @@ def test_clip_flat_under_replay(dev):
     ref_norm = torch.nn.utils.clip_grad_norm_([ref], 5.0)
     assert abs(float(norm) - float(ref_norm)) <= 1e-5 * float(ref_norm)
     assert float((flat - ref.grad).norm() / ref.grad.norm()) < 1e-6
+
+
+def test_flat_adam_follows_torch_adam(dev):
+    """harness.FlatAdam (mdmm_adam_flat: one launch over the GradBucket's flat gradient, flat moments, a table of
+    parameter addresses) against torch.optim.Adam on the same gradients: 25 updates of parameters of awkward sizes
+    (1, 3, 1000 x 7, ...: workgroup chunks that span several parameters), with and without weight decay; parameters and
+    both moments to 2e-6 of their scale, the state dict in torch.optim.Adam's form and loadable both ways."""
+    from mdmm.harness import FlatAdam, GradBucket
+    torch.manual_seed(3)
+    shapes = [(1,), (3,), (1000, 7), (5000,), (17, 33), (2,), (4096 + 5,), (64, 64)]
+    for wd in (0.0, 1e-2):
+        pa = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
+        pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+        bucket = GradBucket(pa)
+        opt_a = FlatAdam(bucket, lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=wd)
+        opt_b = torch.optim.Adam(pb, lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=wd)
+        for it in range(25):
+            gs = [torch.randn(*s, device=dev) * (0.1 + it % 3) for s in shapes]
+            for p, g in zip(pa, gs):
+                p.grad = g.clone()
+            bucket.check_views()
+            for p, g in zip(pb, gs):
+                p.grad = g.clone()
+            opt_a.step(); opt_b.step()
+            bucket.release()
+        for a, b in zip(pa, pb):
+            assert float((a - b).abs().max()) < 2e-6 * max(1.0, float(b.abs().max()))
+        sa, sb = opt_a.state_dict(), opt_b.state_dict()
+        for i in range(len(shapes)):
+            assert float(sa['state'][i]['step']) == float(sb['state'][i]['step']) == 25.0
+            for k in ('exp_avg', 'exp_avg_sq'):
+                x, y = sa['state'][i][k], sb['state'][i][k]
+                assert x.shape == y.shape and float((x - y).abs().max()) < 2e-6 * max(1e-3, float(y.abs().max())), (i, k)
+        # torch.optim.Adam's state into a fresh FlatAdam (copied into the flat buffers), and the other way round
+        pc = [torch.nn.Parameter(p.detach().clone()) for p in pb]
+        bc = GradBucket(pc)
+        opt_c = FlatAdam(bc, lr=1.0)
+        opt_c.load_state_dict(sb)
+        assert opt_c.param_groups[0]['lr'] == 3e-3 and float(opt_c.step_dev) == 25.0
+        assert torch.equal(opt_c.exp_avg[:1], sb['state'][0]['exp_avg'].reshape(-1))
+        assert opt_c.state[pc[2]]['exp_avg'].data_ptr() == opt_c.exp_avg.data_ptr() + 4 * 4      # still a view (1 + 3 before it)
+        opt_d = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in pa], lr=1.0)
+        opt_d.load_state_dict(sa)
+        g = torch.randn(*shapes[2], device=dev)
+        for params in (pc, pb):
+            for i, q in enumerate(params):
+                q.grad = g.clone() if i == 2 else torch.zeros_like(q)
+        bc.check_views()
+        opt_c.step()
+        opt_b.step()
+        for a, b in zip(pc, pb):
+            assert float((a - b).abs().max()) < 2e-6 * max(1.0, float(b.abs().max()))
+    with pytest.raises(RuntimeError):           # a gradient that is not the bucket's view
+        pa[0].grad = torch.zeros_like(pa[0])
+        opt_a.step()
