@@ -34,6 +34,14 @@ __device__ __forceinline__ void mma(f32x16& acc, const uint4& a, const uint4& b)
 }
 __device__ __forceinline__ constexpr int acc_row(int reg) { return 8 * (reg >> 2) + (reg & 3); }   // + 4 h
 
+// minimum waves per SIMD asked of the register allocator where a kernel sits a few registers above an occupancy step
+// (A/B build -DCONV_NO_OCC: none)
+#ifdef CONV_NO_OCC
+#define OCC_HINT(n) 1
+#else
+#define OCC_HINT(n) (n)
+#endif
+
 // Activations live in HBM as fp32 or as bf16 (mdmm_conv_t.flags): BF selects the element type of one
 // side.  load4 / load8: consecutive elements starting at element index idx (a multiple of 4 / 8).
 template <bool BF>
@@ -507,8 +515,10 @@ __global__ __launch_bounds__(256) void conv_up_kernel(const mdmm_conv_t a) {
 
 // ------------------------------------------------------------------------------- down ----
 // small[n][m][y][x] = bias[m] + sum_{ch, ky, kx} big[n][ch][2y-1+ky][2x-1+kx] W[m][ch][ky][kx]
+// (the 8 x 8 Deconv's input gradient keeps its 32 weight fragments in registers: left alone the allocator takes 256 + a
+//  few AGPRs and ONE workgroup fits a CU; two waves per SIMD asked for = at most 256 registers, two workgroups per CU)
 template <int S, int CS, int CB, int KS, bool SB, bool BB, bool NORM = false, bool STATS = false, bool LAZY = false>
-__global__ __launch_bounds__(256) void conv_down_kernel(const mdmm_conv_t a) {
+__global__ __launch_bounds__(256, (S == 8 && KS == 4 && SB) ? OCC_HINT(2) : 1) void conv_down_kernel(const mdmm_conv_t a) {
   using G = Shape<S, CS, CB>;
   using D = Down<S, CS, CB, KS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -787,7 +797,9 @@ __host__ __device__ inline int wg_tap(int ptap, int KS) {
 // reduced (mdmm_conv_t.lazy_dy, as conv_down_kernel's LAZY): formed from (dy, x) while the side is staged -- for a layer
 // whose own input needs no gradient (the first encoder layer on the frames) dx never exists in HBM
 template <int S, int CS, int CB, int KS, bool SB, bool BB, int NORM = 0, bool BST = false, bool LZ = false>
-__global__ __launch_bounds__(512) void conv_wgrad_kernel(const mdmm_conv_t a, float* part, int NT) {
+// (four waves per SIMD asked for = at most 128 registers = TWO of these 512-thread workgroups per CU, one staging its
+//  images while the other multiplies: the variants that carry the BatchNorm adjoint sums came out at 129-137)
+__global__ __launch_bounds__(512, OCC_HINT(4)) void conv_wgrad_kernel(const mdmm_conv_t a, float* part, int NT) {
   using G = Shape<S, CS, CB>;
   using W = Wg<S, CS, CB, KS>;
   static_assert(!BST || (NORM == 1 && SB) || (NORM == 2 && BB), "the adjoint's sums: the bf16 side in pre-normalisation form");

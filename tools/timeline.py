@@ -24,7 +24,7 @@ for r in rows:
     ev.append((s, e, name, wg))
 ev.sort()
 # a step ends with the fused Adam launch; take the last complete step
-ends = [i for i, x in enumerate(ev) if 'FusedOptimizer' in x[2]]        # (the fused Adam launches only: _foreach_mul is a multi_tensor_apply too)
+ends = [i for i, x in enumerate(ev) if 'FusedOptimizer' in x[2] or 'adam_flat_kernel' in x[2]]        # (the fused Adam launches only: _foreach_mul is a multi_tensor_apply too)
 gaps = [(a, b) for a, b in zip(ends, ends[1:]) if b - a > 100]        # (an optimizer step is a few launches)
 if not gaps:
     sys.exit('no full step between two optimizer launches in the trace')

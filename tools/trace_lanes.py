@@ -9,7 +9,7 @@ for r in rows:
         1, int(r['Workgroup_Size_X']) * int(r['Workgroup_Size_Y']) * int(r['Workgroup_Size_Z']))
     ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], wg, r['Queue_Id']))
 ev.sort()
-ends = [i for i, x in enumerate(ev) if 'FusedOptimizer' in x[2]]
+ends = [i for i, x in enumerate(ev) if 'FusedOptimizer' in x[2] or 'adam_flat_kernel' in x[2]]
 gaps = [(a, b) for a, b in zip(ends, ends[1:]) if b - a > 100]
 pick = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 min_us = float(sys.argv[3]) if len(sys.argv) > 3 else 30.0
