@@ -719,6 +719,8 @@ def run(cfg, args, world, rank, device, graph):
                # BatchNorm statistics of the conv plug-ins (common.py:80-84): over this rank's frames only -- the graph-
                # replayed step cannot hold the synchronising collective (harness.GraphedElboStep); 10,240 frames per rank
                'bn': 'per-rank' if any('net.1' in k for k, _ in model.named_parameters()) else 'none',
+               'optimizer': type(optimizer).__name__ + (' (torch.optim.Adam\'s update as one launch over the flat gradient bucket, mdmm_adam_flat)'
+                                                         if type(optimizer).__name__ == 'FlatAdam' else ' (fused, capturable)'),
                'allreduce': None if allreduce_ms is None else
                {'ms': allreduce_ms, 'bytes': int(bucket.flat.numel() * 4), 'timing': 'HIP events, median of 5, outside the timed region',
                 'host_wait_before': True}}
