@@ -87,7 +87,7 @@ class MultiDKS(MultiDGTS):
                 x = torch.zeros(shape, device=dev)
                 masks[m] = torch.zeros(t_max, b_dim, device=dev, dtype=torch.bool)
             else:
-                x, masks[m] = self._clean(inputs[m])
+                x, masks[m] = self._clean(inputs[m], self._frames_store(self.enc[m], inputs[m]))
             if self.dists[m] == 'Categorical':
                 x = x.long()
             feats[m] = self._plug(self.enc[m], x.flatten(0, 1)).reshape(t_max, b_dim, -1)
@@ -201,7 +201,7 @@ class MultiDKS(MultiDGTS):
         real, left = dict(), dict()
         for m in self.modalities:
             if any(m in ps for ps in passes):
-                x, seen = self._clean(inputs[m])
+                x, seen = self._clean(inputs[m], self._frames_store(self.enc[m], inputs[m]))
                 if self.dists[m] == 'Categorical':
                     x = x.long()
                 feat = self._plug(self.enc[m], x.flatten(0, 1)).reshape(t_max, b_dim, -1)
