@@ -543,12 +543,35 @@ def roofline_step(cfg, b_dim, ms_per_step):
     peak = cfg.peak
     t_mfma, t_hbm = flops / (peak * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
     t_roof = max(t_mfma, t_hbm)
-    return {'bound': 'mfma' if t_mfma >= t_hbm else 'hbm', 'algorithmic_flops': flops, 'algorithmic_bytes': nbytes,
-            'roof_times_ms': {'mfma': round(t_mfma * 1e3, 4), 'hbm': round(t_hbm * 1e3, 4)},
-            'achieved_tflops': round(flops / (ms_per_step * 1e-3) / 1e12, 2), 'peak_tflops': peak,
-            'frac': round(t_roof * 1e3 / ms_per_step, 4), 'parts': parts,
-            'note': 'whole step: algorithmic flops and bytes (sweeps + plug-in conv chain, backward = 2 x forward) '
-                    'over ms_per_step; frac = T_roof / T_step'}
+    out = {'bound': 'mfma' if t_mfma >= t_hbm else 'hbm', 'algorithmic_flops': flops, 'algorithmic_bytes': nbytes,
+           'roof_times_ms': {'mfma': round(t_mfma * 1e3, 4), 'hbm': round(t_hbm * 1e3, 4)},
+           'achieved_tflops': round(flops / (ms_per_step * 1e-3) / 1e12, 2), 'peak_tflops': peak,
+           'frac': round(t_roof * 1e3 / ms_per_step, 4), 'parts': parts,
+           'note': 'whole step: algorithmic flops and bytes (sweeps + plug-in conv chain, backward = 2 x forward) '
+                   'over ms_per_step; frac = T_roof / T_step'}
+    # what the step MOVES, measured (every kernel's FETCH_SIZE / WRITE_SIZE: tools/pmc_step_traffic.sh): the step as a whole
+    # against the HBM peak -- its kernels are the conv chain's activations and the K-particle sweeps' parks, not its flops
+    tr = step_traffic(cfg, b_dim)
+    if tr is not None:
+        gbs = tr['bytes_per_step'] / (ms_per_step * 1e-3) / 1e9
+        out['traffic'] = tr['bytes_per_step']
+        out['traffic_gbs'] = round(gbs, 1)
+        out['traffic_frac_of_hbm_peak'] = round(gbs / HBM_PEAK_GBS, 4)
+        out['traffic_over_algorithmic'] = round(tr['bytes_per_step'] / nbytes, 2)
+        out['traffic_source'] = tr['source']
+    return out
+
+
+def step_traffic(cfg, b_dim):
+    """Measured HBM-side bytes of one step (profiles/r05t_step_traffic.json), for the shape they were measured at."""
+    if cfg.name != 'cfg3' or b_dim != cfg.B:
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r05t_step_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 GRAPH_QUEUES_ENV, GRAPH_QUEUES = 'DEBUG_HIP_FORCE_GRAPH_QUEUES', '5'
