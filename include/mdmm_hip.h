@@ -586,11 +586,15 @@ typedef struct mdmm_bn {
   double global_count;
   int32_t partial_splits; /* mdmm_bn_relu_bwd, phase = MDMM_BN_APPLY without global_sums: `partial` holds this many slabs per
                            * (group, channel) instead of `splits` (the producer's workgroups: mdmm_conv_t.bst_part); 0 = splits */
-  int32_t reserved;
+  int32_t batches_add;    /* mdmm_bn_relu_fwd with num_batches: what is added to it (the number of stock-module calls this launch
+                           * stands for: `groups`) */
   /* mdmm_bn_relu_bwd: non-NULL = stop behind the reduction -- fold the partial sums, write dgamma / dbeta and
    * bwd_means[(grp * C + c) * 2 + {0, 1}] = (mean of g, mean of g xhat) over the group's N * L elements, no dx (NULL
    * allowed): the consumer of dx applies them itself (mdmm_conv_t.lazy_dy).  One rank (no global_sums).  */
   float* bwd_means;
+  /* mdmm_bn_relu_fwd: nn.BatchNorm's num_batches_tracked (one int64 in device memory), counted by the launch that updates
+   * the running statistics instead of by a launch of its own on the forward chain.  NULL: not counted here.  */
+  int64_t* num_batches;
 } mdmm_bn_t;
 #define MDMM_BN_STATS 1
 #define MDMM_BN_APPLY 2

@@ -142,9 +142,12 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
                                                       float* running_var, const float* mean_shift,
                                                       T* __restrict__ y,
                                                       float* save_mean, float* save_invstd,
-                                                      const double* __restrict__ gsum, double gcount, int nparts) {
+                                                      const double* __restrict__ gsum, double gcount, int nparts,
+                                                      int64_t* num_batches, int batches_add) {
   __shared__ double sh[2 * NT / 64];
   const int c = blockIdx.x;
+  // nn.BatchNorm's num_batches_tracked, counted here (mdmm_bn_t.num_batches) instead of by a launch of its own
+  if (num_batches && c == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *num_batches += batches_add;
   const int grp = blockIdx.z, n_grp = gridDim.z;       // groups: each N images with statistics of their own
   const double M = gsum ? gcount : (double)N * (double)L;
   // Many slabs (a producing convolution's workgroups left them: mdmm_conv_t.out_stats, 512 per channel): summed by the
@@ -425,7 +428,7 @@ void launch_fwd(const mdmm_bn_t* a, hipStream_t st) {
                        (const T*)a->x, a->N, a->C, a->L, a->partial,
                        a->gamma, a->beta, a->eps, a->relu, a->momentum, a->running_mean, a->running_var,
                        a->mean_shift, fin ? (T*)nullptr : (T*)a->y, a->save_mean, a->save_invstd,
-                       a->global_sums, a->global_count, a->splits);
+                       a->global_sums, a->global_count, a->splits, a->num_batches, a->batches_add);
   }
 }
 template <bool VEC, typename T>

@@ -141,7 +141,7 @@ class Bn(C.Structure):
                 [(n, _P) for n in ('x', 'gamma', 'beta', 'running_mean', 'running_var', 'y', 'save_mean',
                                    'save_invstd', 'dy', 'dx', 'dgamma', 'dbeta', 'partial', 'mean_shift')] +
                 [('phase', C.c_int32), ('groups', C.c_int32), ('global_sums', _P), ('global_count', C.c_double),
-                 ('partial_splits', C.c_int32), ('reserved', C.c_int32), ('bwd_means', _P)])
+                 ('partial_splits', C.c_int32), ('batches_add', C.c_int32), ('bwd_means', _P), ('num_batches', _P)])
 
 
 BN_STATS, BN_APPLY, BN_FINALIZE, BN_FINALIZE_GIVEN = 1, 2, 3, 4

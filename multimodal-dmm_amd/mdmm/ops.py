@@ -1816,7 +1816,10 @@ class _BnReluFn(torch.autograd.Function):
         a.x, a.gamma, a.beta, a.y = _ptr(x), _ptr(g), _ptr(b), _ptr(y)
         a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
         if bn.track_running_stats and bn.running_mean is not None:
-            bn.num_batches_tracked.add_(G)
+            if bn.momentum is not None and _counts_here(bn):
+                a.num_batches, a.batches_add = _ptr(bn.num_batches_tracked), G      # (counted by the launch itself)
+            else:
+                bn.num_batches_tracked.add_(G)
             # momentum None = cumulative average (torch: 1 / num_batches_tracked)
             a.momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             a.running_mean, a.running_var = _ptr(bn.running_mean), _ptr(bn.running_var)
@@ -1976,6 +1979,13 @@ class _SyncBnReluTorch(torch.autograd.Function):
 def sync_batchnorm_relu_torch(x, bn, relu=True):
     """nn.Sequential(bn, nn.ReLU())(x) in training mode with the statistics of the global batch (plain torch)."""
     return _SyncBnReluTorch.apply(x, bn.weight, bn.bias, bn, relu, bn_sync_group())
+
+
+def _counts_here(bn):
+    """nn.BatchNorm's num_batches_tracked can be counted by the statistics launch (mdmm_bn_t.num_batches): one int64 on
+    the GPU (the stock buffer)."""
+    nbt = bn.num_batches_tracked
+    return nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64 and nbt.numel() == 1
 
 
 def batchnorm_relu_supported(x, bn):
@@ -2613,7 +2623,10 @@ class _BnDeconvFn(torch.autograd.Function):
         a.x, a.gamma, a.beta = _ptr(x), _ptr(g), _ptr(b)
         a.save_mean, a.save_invstd, a.partial = stats[0].data_ptr(), stats[1].data_ptr(), _ptr(part)
         if bn.track_running_stats and bn.running_mean is not None:
-            bn.num_batches_tracked.add_(G)
+            if _counts_here(bn):
+                a.num_batches, a.batches_add = _ptr(bn.num_batches_tracked), G      # (counted by the launch itself)
+            else:
+                bn.num_batches_tracked.add_(G)
             a.momentum = bn.momentum
             a.running_mean, a.running_var = _ptr(bn.running_mean), _ptr(bn.running_var)
             sh = None if shift is None else _f32c(shift.detach())
