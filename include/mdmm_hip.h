@@ -788,9 +788,16 @@ typedef struct mdmm_gemm {
   const float* bias;     /* (J) or NULL */
   void* c;
   int64_t ldc;
-  float* ws;             /* split > 1: split * I * J floats */
+  float* ws;             /* split > 1: split * I * J floats (+ split * I with colsum_a) */
+  /* Optional output (I floats), weight-gradient calls of the shape-specialised kernels only (mdmm_gemm_colsum_a(args) = 1:
+   * ta = tb = 1, bf16 operands, one of I, J = 256): colsum_a[i] = sum over the L contracted rows of A[l][i] -- the bias
+   * gradient of the same nn.Linear (its weight gradient is G^T X, its bias gradient G^T 1), summed from the A tiles the
+   * launch stages anyway instead of by a pass of its own over G (mdmm_colsum).  ws: split * I floats behind the product's
+   * slabs.  NULL: not formed.  */
+  float* colsum_a;
 } mdmm_gemm_t;
 int mdmm_gemm_supported(const mdmm_gemm_t* args);
+int mdmm_gemm_colsum_a(const mdmm_gemm_t* args);   /* 1: this call (split set) forms colsum_a when asked */
 int mdmm_gemm_split(const mdmm_gemm_t* args);
 int64_t mdmm_gemm_ws_bytes(const mdmm_gemm_t* args);
 int mdmm_gemm_bf16(const mdmm_gemm_t* args, void* stream);

@@ -361,6 +361,22 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const mdmm_gemm_t g, int row
       *reinterpret_cast<u32x4*>(buf + (isa ? row * RSA : WK * RSA + row * RSB) + ch * 16) = r.v[q];
     }
   };
+  // mdmm_gemm_t.colsum_a: the sums over the rows of this workgroup's A columns, from the chunks it stages anyway -- a
+  // thread's A chunks are always the same eight columns (chunk tid % CHA of rows tid / CHA + 512 / CHA * q); the
+  // workgroups of column tile 0 only
+  constexpr int NQA = WK * CHA / 512;
+  const bool csum_on = g.colsum_a != nullptr && tb == 0;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto add_cols = [&](const WRegs& r) {
+#pragma unroll
+    for (int q = 0; q < NQA; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned u = r.v[q][e];
+        cs[2 * e] += __uint_as_float(u << 16);
+        cs[2 * e + 1] += __uint_as_float(u & 0xffff0000u);
+      }
+  };
   f32x16 acc[2][2];
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -373,6 +389,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const mdmm_gemm_t g, int row
     load_step(0, r0);
     load_step(min(1, nst - 1), r1);
     write_step(lds, r0);
+    if (csum_on) add_cols(r0);
     load_step(min(2, nst - 1), r0);
     __syncthreads();
     // transposed fragment reads: lane = (16-lane group gq, lane i of it); the group reads rows 8 h + 4 r2 + (i >> 2),
@@ -394,6 +411,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const mdmm_gemm_t g, int row
       a[0][0] = frag(fa, RSA, 0, 0); a[0][1] = frag(fa, RSA, 0, 1);
       b[0][0] = frag(fb, RSB, 0, 0); b[0][1] = frag(fb, RSB, 0, 1);
       write_step(lds + ((st + 1) & 1) * W_STAGE, rn);
+      if (csum_on && st + 1 < nst) add_cols(rn);          // (rn = step st + 1; past the end it is a clamped reload)
       load_step(min(st + 3, nst - 1), rn);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -431,6 +449,19 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const mdmm_gemm_t g, int row
         cw[(int64_t)i * ldc + j] = acc[x][y][r];
       }
     }
+  if (csum_on) {            // (uniform over the workgroup; the stage buffers are free behind the last step's barrier)
+    float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = cs[e];
+    __syncthreads();
+    if (tid < TA) {
+      const int ch = tid >> 3, e = tid & 7;
+      float t = 0.f;
+      for (int k = 0; k < 512 / CHA; ++k) t += red[(ch + CHA * k) * 8 + e];
+      float* const out = direct ? g.colsum_a : g.ws + (size_t)g.split * g.I * g.J + (size_t)z * g.I;
+      out[i0 + tid] = t;
+    }
+  }
 }
 
 // c[i][j] = bias[j] + sum over the slabs, four columns per thread
@@ -456,6 +487,16 @@ __global__ __launch_bounds__(256) void contract_fold_kernel(const mdmm_gemm_t g)
     *reinterpret_cast<u32x2*>(reinterpret_cast<__bf16*>(g.c) + i * g.ldc + j) = __builtin_bit_cast(u32x2, p);
   } else {
     *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.c) + i * g.ldc + j) = s;
+  }
+  // the column sums of A that a weight-gradient launch left per row slice (mdmm_gemm_t.colsum_a), behind the product's slabs
+  if (g.colsum_a && 4 * e4 < g.I) {
+    const float4* cp = reinterpret_cast<const float4*>(g.ws + (size_t)g.split * n) + e4;
+    float4 t = cp[0];
+    for (int z = 1; z < g.split; ++z) {
+      const float4 v = cp[(size_t)z * (g.I >> 2)];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(g.colsum_a + 4 * e4) = t;
   }
 }
 

@@ -454,13 +454,20 @@ extern "C" int mdmm_gemm_split(const mdmm_gemm_t* g) {
 
 extern "C" int64_t mdmm_gemm_ws_bytes(const mdmm_gemm_t* g) {
   if (!g || g->split <= 1) return 0;
-  return (int64_t)g->split * g->I * g->J * 4;
+  return (int64_t)g->split * g->I * g->J * 4 + (g->colsum_a ? (int64_t)g->split * g->I * 4 : 0);
+}
+
+// the call takes a weight-gradient kernel of gemm_heads.hip, which can sum A's columns on the way (mdmm_gemm_t.colsum_a)
+extern "C" int mdmm_gemm_colsum_a(const mdmm_gemm_t* g) {
+  if (!mdmm_gemm_supported(g) || (g->flags & MDMM_GEMM_F32)) return 0;
+  return (!heads::expand_ok(g) && !heads::contract_ok(g) && heads::wgrad_ok(g)) ? 1 : 0;
 }
 
 extern "C" int mdmm_gemm_bf16(const mdmm_gemm_t* g, void* stream) {
   if (!mdmm_gemm_supported(g) || !g->a || !g->b || !g->c) return MDMM_E_ARG;
   if ((((uintptr_t)g->a) & (g->a_bf16 ? 7 : 15)) || (((uintptr_t)g->b) & (g->b_bf16 ? 7 : 15))) return MDMM_E_ALIGN;
   if (g->split > 1 && !g->ws) return MDMM_E_ARG;
+  if (g->colsum_a && !mdmm_gemm_colsum_a(g)) return MDMM_E_ARG;       // (only where a kernel forms it)
   hipStream_t st = (hipStream_t)stream;
   const bool f32 = (g->flags & MDMM_GEMM_F32) != 0;
   if (f32 && (g->a_bf16 || g->b_bf16 || g->c_bf16)) return MDMM_E_ARG;

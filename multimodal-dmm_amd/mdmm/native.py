@@ -25,7 +25,7 @@ SYMBOLS = [
     'mdmm_kld_gauss_fwd', 'mdmm_kld_gauss_bwd',
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
     'mdmm_nll_bernoulli_fwd', 'mdmm_nll_bernoulli_bwd',
-    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero', 'mdmm_nan_to_zero_bf16', 'mdmm_adam_flat', 'mdmm_nll_bernoulli_logits_passes_fwd_grad', 'mdmm_fold_slabs', 'mdmm_embed_relu_supported', 'mdmm_embed_relu_slabs', 'mdmm_embed_relu_fwd',
+    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero', 'mdmm_nan_to_zero_bf16', 'mdmm_adam_flat', 'mdmm_gemm_colsum_a', 'mdmm_nll_bernoulli_logits_passes_fwd_grad', 'mdmm_fold_slabs', 'mdmm_embed_relu_supported', 'mdmm_embed_relu_slabs', 'mdmm_embed_relu_fwd',
     'mdmm_embed_relu_bwd',
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
     'mdmm_philox_normal', 'mdmm_debug_clock', 'mdmm_gtf_pack_size', 'mdmm_gtf_pack',
@@ -231,7 +231,7 @@ class Gemm(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('I', 'J', 'L', 'ta', 'tb', 'split', 'a_bf16', 'b_bf16', 'c_bf16',
                                           'flags')] +
                 [('a', _P), ('lda', C.c_int64), ('b', _P), ('ldb', C.c_int64), ('bias', _P), ('c', _P),
-                 ('ldc', C.c_int64), ('ws', _P)])
+                 ('ldc', C.c_int64), ('ws', _P), ('colsum_a', _P)])
 
 
 class MdmmError(RuntimeError):
@@ -368,6 +368,7 @@ def lib():
         L.mdmm_conv1d_wgrad.argtypes = [C.POINTER(Conv1d), _P, _P, _P]
         L.mdmm_gemm_supported.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_split.argtypes = [C.POINTER(Gemm)]
+        L.mdmm_gemm_colsum_a.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_ws_bytes.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_ws_bytes.restype = C.c_int64
         L.mdmm_gemm_bf16.argtypes = [C.POINTER(Gemm), _P]

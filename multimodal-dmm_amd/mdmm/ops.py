@@ -1556,10 +1556,12 @@ def _rows(t):
     return t
 
 
-def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.float32, relu=False, f32=False):
+def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.float32, relu=False, f32=False, colsum_a=False):
     """c (I,J) = bias + A B^T on csrc/gemm_tiles.hip / gemm_heads.hip; a, b are _rows() matrices.  The library
     says into how many slices it cuts the contraction (mdmm_gemm_split; their slabs are summed through ws).
-    f32: fp32 operands on the fp32 matrix instruction (mdmm_gemm_f32) instead of bf16-rounded ones."""
+    f32: fp32 operands on the fp32 matrix instruction (mdmm_gemm_f32) instead of bf16-rounded ones.
+    colsum_a: -> (c, sums over the contraction of A's columns, or None where the call's kernel does not form them:
+    mdmm_gemm_t.colsum_a -- a weight gradient G^T X also leaves the bias gradient G^T 1)."""
     g = native.Gemm()
     g.I, g.J, g.L, g.ta, g.tb, g.split = I, J, L, int(ta), int(tb), 1
     # MDMM_GEMM_GENERIC=1 (flag bit 2): the generic tile kernel where a shape-specialised one (csrc/gemm_heads.hip) would
@@ -1571,12 +1573,16 @@ def _gemm_bf16(a, ta, b, tb, I, J, L, bias=None, tag='gemm', out_dtype=torch.flo
     c = torch.empty(I, J, device=a.device, dtype=out_dtype)
     g.c, g.ldc, g.bias, g.c_bf16 = _ptr(c), J, _ptr(bias), int(out_dtype == torch.bfloat16)
     g.split = split = native.lib().mdmm_gemm_split(C.byref(g))
+    cs = None
+    if colsum_a and not f32 and native.lib().mdmm_gemm_colsum_a(C.byref(g)):
+        cs = torch.empty(I, device=a.device, dtype=torch.float32)
+        g.colsum_a = _ptr(cs)
     ws = None
     if split > 1:
-        ws = torch.empty(split * I * J, device=a.device, dtype=torch.float32)
+        ws = torch.empty(split * I * (J + (1 if cs is not None else 0)), device=a.device, dtype=torch.float32)
         g.ws = _ptr(ws)
     _call('mdmm_gemm_f32' if f32 else 'mdmm_gemm_bf16', C.byref(g), tag=tag)
-    return c
+    return (c, cs) if colsum_a else c
 
 
 def colsum(g):
@@ -1716,7 +1722,11 @@ class _LinearTilesFn(torch.autograd.Function):
         m, k = x.shape
         n = w.shape[0]
         gx = gw = gb = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        # a bf16 gradient (the decoders' 4096-wide one) whose weight-gradient launch stages every element anyway: the bias
+        # gradient comes out of that launch (mdmm_gemm_t.colsum_a) instead of a pass of its own over the gradient
+        gb_rides = want_gb and ctx.heads and ctx.needs_input_grad[1] and g.dtype == torch.bfloat16
+        if want_gb and not gb_rides:
             gb = colsum(g)                          # (of the gradient as it came, before any rounding)
         gx_dtype = ctx.gx_dtype
         if ctx.heads:
@@ -1728,7 +1738,12 @@ class _LinearTilesFn(torch.autograd.Function):
         elif ctx.needs_input_grad[0]:
             gx = _gemm_bf16(g, False, w, True, m, k, n, tag='linear_dgrad[%dx%d]' % (k, n), out_dtype=gx_dtype)
         if ctx.needs_input_grad[1]:
-            gw = _gemm_bf16(g, True, x, True, n, k, m, tag='linear_wgrad[%dx%d]' % (k, n))
+            if gb_rides:
+                gw, gb = _gemm_bf16(g, True, x, True, n, k, m, tag='linear_wgrad[%dx%d]' % (k, n), colsum_a=True)
+                if gb is None:
+                    gb = colsum(g)
+            else:
+                gw = _gemm_bf16(g, True, x, True, n, k, m, tag='linear_wgrad[%dx%d]' % (k, n))
         return gx, gw, gb, None, None
 
 

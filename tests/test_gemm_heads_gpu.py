@@ -88,6 +88,27 @@ def test_wgrad_matches_torch(dev, monkeypatch, m, i, j):
     assert rel(own, gen) < 5e-6
 
 
+@pytest.mark.parametrize('m,i,j', [(20480, 4096, 256), (10240, 256, 4096), (4099, 512, 256), (513, 256, 128), (1000, 256, 512)])
+def test_wgrad_leaves_the_bias_gradient(dev, monkeypatch, m, i, j):
+    """mdmm_gemm_t.colsum_a: the weight-gradient launch G^T X of an nn.Linear also leaves G^T 1 -- the sums over the rows of
+    the A tiles it stages anyway (row slices folded with the product's slabs) -- equal to the column-sum kernel's on the
+    same bf16 matrix; the product itself is unchanged bit for bit; the generic tile kernel declines (None)."""
+    from mdmm import ops
+    torch.manual_seed(m + i + j)
+    g_ = (torch.randn(m, i, device=dev) * 3).bfloat16()
+    x = torch.randn(m, j, device=dev).bfloat16()
+    plain = ops._gemm_bf16(g_, True, x, True, i, j, m)
+    own, cs = ops._gemm_bf16(g_, True, x, True, i, j, m, colsum_a=True)
+    assert torch.equal(own, plain)
+    assert cs is not None and cs.dtype == torch.float32 and tuple(cs.shape) == (i,)
+    ref = g_.double().sum(0)
+    assert float((cs.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max() + g_.float().abs().sum(0).max())
+    assert rel(cs, ops.colsum(g_)) < 2e-6
+    monkeypatch.setenv('MDMM_GEMM_GENERIC', '1')
+    gen, none = ops._gemm_bf16(g_, True, x, True, i, j, m, colsum_a=True)
+    assert none is None and rel(gen, own) < 5e-6
+
+
 def test_heads_through_plug_linear(dev):
     """ops.plug_linear on a stock nn.Linear head under conv_operands(bfloat16, act = bfloat16): the autograd
     function hands the kernels bf16 operands (the 256-wide side rounded on the way, the weight and its transpose
