@@ -372,6 +372,13 @@ def wide_trans(cfg):
 def clear_caches(params=()):
     """Drop host-side caches (call before capturing a step into a HIP graph)."""
     _GRAD_CHANSUM.clear()
+    if _LAZY_BN:
+        # a BatchNorm adjoint that was only reduced and whose consumer never came for it (lazy_bn_ok checks the producer of
+        # x_pre when the forward is built; a hook or a second consumer of that gradient is not seen there): the tensor it
+        # returned as dx was never written
+        import warnings
+        warnings.warn('mdmm: %d lazily applied BatchNorm gradient(s) were never taken by the layer in front (ops._LAZY_BN); '
+                      'the last backward pass used an unwritten gradient -- set MDMM_BN_LAZY_DX=0' % len(_LAZY_BN), RuntimeWarning)
     _LAZY_BN.clear()
     if _GRAD_SCALE:
         _GRAD_SCALE.clear()
