@@ -788,3 +788,49 @@ def test_bernoulli_loss_writes_its_gradient_in_the_forward_pass(dev, chans, monk
     keep = free.detach().clone()
     g, = torch.autograd.grad(ops.nll_bernoulli_logits(free, x, mask, 2, 1.7, None, passes=P, consume=True), free)
     assert torch.equal(free.detach(), keep) and g.data_ptr() != free.data_ptr() and not ops._GRAD_SCALE
+
+
+@pytest.mark.parametrize('cs,cb,s', [(64, 32, 8), (32, 16, 16), (16, 3, 32), (16, 1, 32)])
+@pytest.mark.parametrize('bf', [False, True])
+def test_conv_out_scale_is_a_multiplication_of_the_outputs(dev, cs, cb, s, bf):
+    """mdmm_conv_t.out_scale through the C ABI, every Deconv shape: mdmm_conv_down's small side and mdmm_conv_wgrad's dW
+    with *out_scale = 0.37 equal 0.37 x the plain launch -- bit for bit where the output is fp32 (one multiplication of
+    the same accumulator), to one bf16 rounding where the small side is stored as bf16; NULL leaves every bit alone."""
+    import ctypes as C
+    from mdmm import native, ops
+    torch.manual_seed(cs + cb + s)
+    n = 37
+    dt = torch.bfloat16 if bf else torch.float32
+    big = torch.randn(n, cb, 2 * s, 2 * s, device=dev).to(dt)
+    small_in = torch.randn(n, cs, s, s, device=dev).to(dt)
+    w = torch.randn(cs, cb, 4, 4, device=dev) * 0.1
+    sc = torch.tensor([0.37], device=dev)
+    lib = native.lib()
+
+    def desc(small, bigt):
+        a = ops._conv_desc(n, small.shape, bigt.shape, 4)
+        a.flags = ops._conv_flags(small, bigt)
+        a.small, a.big = small.data_ptr(), bigt.data_ptr()
+        return a
+
+    res = {}
+    for scaled in (False, True):
+        out = torch.empty(n, cs, s, s, device=dev, dtype=dt)
+        a = desc(out, big)
+        pack = torch.empty(lib.mdmm_conv_pack_bytes(C.byref(a), 0), device=dev, dtype=torch.uint8)
+        ops._call('mdmm_conv_pack', C.byref(a), 0, w.data_ptr(), pack.data_ptr())
+        a.wfrag = pack.data_ptr()
+        a.out_scale = sc.data_ptr() if scaled else None
+        ops._call('mdmm_conv_down', C.byref(a))
+        b = desc(small_in, big)
+        b.out_scale = sc.data_ptr() if scaled else None
+        ws = torch.empty(lib.mdmm_conv_wgrad_ws_bytes(C.byref(b)), device=dev, dtype=torch.uint8)
+        gw = torch.empty(cs, cb, 4, 4, device=dev)
+        ops._call('mdmm_conv_wgrad', C.byref(b), ws.data_ptr(), gw.data_ptr())
+        res[scaled] = (out, gw)
+    torch.cuda.synchronize()
+    assert torch.equal(res[True][1], res[False][1] * 0.37)
+    if bf:
+        assert helpers.rel_err(res[True][0].float(), res[False][0].float() * 0.37) < 8e-3
+    else:
+        assert torch.equal(res[True][0], res[False][0] * 0.37)
