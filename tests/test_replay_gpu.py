@@ -204,11 +204,13 @@ def test_graph_replay_matches_eager_and_oracle(name, dev):
         assert e < tol, 'replayed %s grad %s vs oracle: %.3e' % (name, k, e)
 
 
-def test_graphed_conv_step_through_rccl_world_one(dev, monkeypatch):
+@pytest.mark.parametrize('flat_adam', [True, False])
+def test_graphed_conv_step_through_rccl_world_one(dev, monkeypatch, flat_adam):
     """bench.py --gpus N per rank, on hardware with a real NCCL (= RCCL) group of one rank and the conv model of
     cfg3: [graph: step + backward] -> all_reduce of the flat gradient (eager, between the graphs) -> [graph: Adam].
     The collective really runs once per step, on the buffer the captured backward filled and the captured Adam
-    reads; losses and weights equal those of the group-less replayed step."""
+    reads; losses and weights equal those of the group-less replayed step.  flat_adam: harness.FlatAdam (what bench.py
+    runs: one launch over that same flat buffer) or torch.optim.Adam(fused, capturable)."""
     import os
     import torch.distributed as dist
     from mdmm import models
@@ -237,8 +239,12 @@ def test_graphed_conv_step_through_rccl_world_one(dev, monkeypatch):
             model = cfg.model(models, dev)
             model.bn_sync = True                     # one rank: the fused BatchNorm path (ops.bn_sync_group)
             model.noise = PhiloxNoise(seed=99)
-            opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, capturable=True, fused=True)
             bucket = GradBucket(model.parameters())
+            if flat_adam:
+                from mdmm.harness import FlatAdam
+                opt = FlatAdam(bucket, lr=cfg.lr)
+            else:
+                opt = torch.optim.Adam(model.parameters(), lr=cfg.lr, capturable=True, fused=True)
             n0 = len(calls)
             step = GraphedElboStep(model, opt, bucket, x, mask, lengths, 1.0, cfg.rec, targets=tg, group=group,
                                    warmup=1, train_particles=bench.TRAIN_PARTICLES)
