@@ -335,7 +335,10 @@ int mdmm_nll_bernoulli_logits_bf16_bwd(const void* logits, const float* x, const
  * same observations -- the passes of one ELBO step (dgts.py:119-129) decoded as one batch; x and the mask are read
  * once for all of them; the result is the sum of the passes' terms, g_logits has the shape of logits.
  * pass_weight (optional, HOST array of `passes` <= 8 floats): a multiplier per pass on top of weight / scale -- the
- * passes of one decoder batch may belong to loss terms of different weight (dmm.py:547-553: f_mult, s_mult).  */
+ * passes of one decoder batch may belong to loss terms of different weight (dmm.py:547-553: f_mult, s_mult).
+ * logits_bf16: 0 = fp32 logits scored with F.binary_cross_entropy's arithmetic on sigmoid(l) (the parity mode: saturation
+ * of the fp32 sigmoid at |l| > 17 and the -100 clamp included); 1 = bf16 logits, softplus(l) - x l (one exp, one log);
+ * 2 = fp32 logits with the arithmetic of 1 (the audio plug-ins' logits in a model whose contractions run in bf16).  */
 int mdmm_nll_bernoulli_logits_passes_fwd(const void* logits, int logits_bf16, int passes, const float* x,
                                          const float* seq_mask, int64_t rows, int inner, float weight,
                                          const float* pass_weight, double* out, void* stream);

@@ -179,7 +179,10 @@ inline PassW pass_w(const float* host, int passes) {
 }
 
 // T = storage type of theta / g_theta (fp32, or bf16 for the logits of the bf16-activation plug-ins)
-template <bool LOGITS, typename T>
+// FAST (fp32 logits): the one-exp-one-log form the bf16 logits take, instead of F.binary_cross_entropy's arithmetic on
+// sigmoid(l) (which the fp32 parity mode reproduces, saturation at |l| > 17 and -100 clamp included: three precise
+// transcendentals per element, ALU-bound -- 4.1 ms against 1.2 for the audio plug-ins' 65,536 x 12,810 logits at cfg5 size)
+template <bool LOGITS, typename T, bool FAST = false>
 // passes: theta holds that many parameter tensors one after the other (the passes of one ELBO step decoded as
 // one batch), each scored against the same n observations: x and the mask are read once for all of them
 __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ theta,
@@ -187,7 +190,39 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ thet
     float weight, double* out, int passes, PassW pw) {
   float acc = 0.f;
   const bool vec = (inner & 3) == 0 && (n & 3) == 0;
-  if (vec) {
+  if (!vec && (n & 3) == 0 && inner >= 4) {
+    // rows that are no whole float4s (the audio plug-ins' 10 x 1281 frames) in float4 pieces all the same: the tensors start
+    // 16-byte aligned and n is a multiple of 4, a piece may straddle two rows -- its elements look their own row's mask up
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    RowWalk rw(4 * ((int64_t)blockIdx.x * NT + threadIdx.x), 4 * stride, inner);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride, rw.next()) {
+      bool on[4];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { on[j] = !(mask && mask[rw.row + (rw.rem + j >= inner ? 1 : 0)] == 0.f); any |= on[j]; }
+      if (!any) continue;
+      const float4 xv = reinterpret_cast<const float4*>(x)[i];
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      for (int ps = 0; ps < passes; ++ps) {
+        const float4 th = ld4f(theta, i + ps * n4);
+        float ts[4] = {th.x, th.y, th.z, th.w};
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (xs[j] != xs[j] || !on[j]) continue;
+          if constexpr (LOGITS && (sizeof(T) == 2 || FAST)) {
+            a += softplus_fast(ts[j]) - xs[j] * ts[j];
+            continue;
+          }
+          if (LOGITS) ts[j] = sigmoid_ref(ts[j]);
+          const float l1 = fmaxf(logf(ts[j]), -100.0f), l0 = fmaxf(log1pf(-ts[j]), -100.0f);
+          a -= xs[j] * l1 + (1.0f - xs[j]) * l0;
+        }
+        acc += pw.uniform ? a : pw.w[ps & 7] * a;
+      }
+    }
+  } else if (vec) {
     const int64_t n4 = n >> 2;
     const int inner4 = inner >> 2;
     const int64_t stride = (int64_t)gridDim.x * NT;
@@ -203,7 +238,7 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ thet
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (xs[j] != xs[j]) continue;
-          if constexpr (LOGITS && sizeof(T) == 2) {
+          if constexpr (LOGITS && (sizeof(T) == 2 || FAST)) {
             const float sp = softplus_fast(ts[j]);              // -log(1 - theta); -log(theta) = sp - l
             a += sp - xs[j] * ts[j];
             continue;
@@ -216,11 +251,20 @@ __global__ __launch_bounds__(NT) void nllb_fwd_kernel(const T* __restrict__ thet
       }
     }
   } else {
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+    // (rows that are no whole float4s -- the audio plug-ins' 10 x 1281 frames: one element per thread and trip; the row of
+    //  an element walks with the stride as above instead of a 64-bit division per element)
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    RowWalk rw((int64_t)blockIdx.x * NT + threadIdx.x, stride, inner);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride, rw.next()) {
+      if (mask && mask[rw.row] == 0.f) continue;
       const float xv = x[i];
       if (xv != xv) continue;
-      if (mask && mask[i / inner] == 0.f) continue;
       for (int ps = 0; ps < passes; ++ps) {
+        if constexpr (LOGITS && (sizeof(T) == 2 || FAST)) {
+          const float l = (float)theta[i + ps * n];
+          acc += (pw.uniform ? 1.0f : pw.w[ps & 7]) * (softplus_fast(l) - xv * l);
+          continue;
+        }
         const float th = LOGITS ? sigmoid_ref((float)theta[i + ps * n]) : (float)theta[i + ps * n];
         const float l1 = fmaxf(logf(th), -100.0f), l0 = fmaxf(log1pf(-th), -100.0f);
         acc -= (pw.uniform ? 1.0f : pw.w[ps & 7]) * (xv * l1 + (1.0f - xv) * l0);
@@ -239,10 +283,10 @@ __device__ __forceinline__ void st4g(__bf16* p, int64_t i, const float (&g)[4]) 
   reinterpret_cast<bf16x4_t*>(p)[i] = v;
 }
 
-template <bool LOGITS, typename T>
+template <bool LOGITS, typename T, bool FAST = false>
 __device__ __forceinline__ float nllb_grad(float t, float xv, bool on, float scale) {
   if (!(xv == xv) || !on) return 0.f;
-  if constexpr (LOGITS && sizeof(T) == 2) {
+  if constexpr (LOGITS && (sizeof(T) == 2 || FAST)) {
     return scale * (mdmm::fast::sigmoid(t) - xv);                  // d/dl of softplus(l) - x l
   } else {
     const float th = LOGITS ? sigmoid_ref(t) : t;
@@ -255,11 +299,30 @@ __device__ __forceinline__ float nllb_grad(float t, float xv, bool on, float sca
 // chan_part (optional; vector path, up to 4 channels of chan4 float4 each per row): per workgroup the sums of the
 // stored gradient per channel over its elements -- the bias gradient of a conv layer that produced theta (its
 // column sums over images and pixels) without another pass over g_theta; [gridDim.x][4] floats, folded by the caller
-template <bool LOGITS, typename T>
+template <bool LOGITS, typename T, bool FAST = false>
 __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ theta,
     const float* __restrict__ x, const float* __restrict__ mask, int64_t n, int inner,
     float scale, const float* __restrict__ scale_dev, T* g_theta, int passes, float* chan_part, int chan4, PassW pw) {
   if (scale_dev) scale *= *scale_dev;
+  if ((inner & 3) != 0 && (n & 3) == 0 && inner >= 4 && !chan_part) {        // (float4 pieces across row ends: nllb_fwd_kernel)
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    RowWalk rw(4 * ((int64_t)blockIdx.x * NT + threadIdx.x), 4 * stride, inner);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride, rw.next()) {
+      bool on[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) on[j] = !(mask && mask[rw.row + (rw.rem + j >= inner ? 1 : 0)] == 0.f);
+      const float4 xv = reinterpret_cast<const float4*>(x)[i];
+      for (int ps = 0; ps < passes; ++ps) {
+        const float4 th = ld4f(theta, i + ps * n4);
+        const float sc = pw.uniform ? scale : scale * pw.w[ps & 7];
+        const float g[4] = {nllb_grad<LOGITS, T, FAST>(th.x, xv.x, on[0], sc), nllb_grad<LOGITS, T, FAST>(th.y, xv.y, on[1], sc),
+                            nllb_grad<LOGITS, T, FAST>(th.z, xv.z, on[2], sc), nllb_grad<LOGITS, T, FAST>(th.w, xv.w, on[3], sc)};
+        st4g(g_theta, i + ps * n4, g);
+      }
+    }
+    return;
+  }
   if ((inner & 3) == 0 && (n & 3) == 0) {
     const int64_t n4 = n >> 2;
     const int inner4 = inner >> 2;
@@ -273,8 +336,8 @@ __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ thet
       for (int ps = 0; ps < passes; ++ps) {
         const float4 th = ld4f(theta, i + ps * n4);
         const float sc = pw.uniform ? scale : scale * pw.w[ps & 7];
-        const float g[4] = {nllb_grad<LOGITS, T>(th.x, xv.x, on, sc), nllb_grad<LOGITS, T>(th.y, xv.y, on, sc),
-                            nllb_grad<LOGITS, T>(th.z, xv.z, on, sc), nllb_grad<LOGITS, T>(th.w, xv.w, on, sc)};
+        const float g[4] = {nllb_grad<LOGITS, T, FAST>(th.x, xv.x, on, sc), nllb_grad<LOGITS, T, FAST>(th.y, xv.y, on, sc),
+                            nllb_grad<LOGITS, T, FAST>(th.z, xv.z, on, sc), nllb_grad<LOGITS, T, FAST>(th.w, xv.w, on, sc)};
         st4g(g_theta, i + ps * n4, g);
         if (chan_part) {                        // (of the values as stored)
           if constexpr (sizeof(T) == 2) gs += ((float)(__bf16)g[0] + (float)(__bf16)g[1]) + ((float)(__bf16)g[2] + (float)(__bf16)g[3]);
@@ -300,10 +363,12 @@ __global__ __launch_bounds__(NT) void nllb_bwd_kernel(const T* __restrict__ thet
     }
     return;
   }
-  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-    const bool on = !(mask && mask[i / inner] == 0.f);
+  const int64_t stride = (int64_t)gridDim.x * NT;
+  RowWalk rw((int64_t)blockIdx.x * NT + threadIdx.x, stride, inner);
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride, rw.next()) {
+    const bool on = !(mask && mask[rw.row] == 0.f);
     for (int ps = 0; ps < passes; ++ps)
-      g_theta[i + ps * n] = (T)nllb_grad<LOGITS, T>((float)theta[i + ps * n], x[i], on, pw.uniform ? scale : scale * pw.w[ps & 7]);
+      g_theta[i + ps * n] = (T)nllb_grad<LOGITS, T, FAST>((float)theta[i + ps * n], x[i], on, pw.uniform ? scale : scale * pw.w[ps & 7]);
   }
 }
 
@@ -723,11 +788,15 @@ extern "C" int mdmm_nll_bernoulli_logits_bf16_bwd(const void* logits, const floa
 extern "C" int mdmm_nll_bernoulli_logits_passes_fwd(const void* logits, int logits_bf16, int passes, const float* x,
                                                     const float* seq_mask, int64_t rows, int inner, float weight,
                                                     const float* pass_weight, double* out, void* stream) {
-  if (!logits || !x || !out || rows < 0 || inner < 1 || passes < 1 || (pass_weight && passes > 8)) return MDMM_E_ARG;
+  if (!logits || !x || !out || rows < 0 || inner < 1 || passes < 1 || (pass_weight && passes > 8) || logits_bf16 < 0 || logits_bf16 > 2)
+    return MDMM_E_ARG;
   const int64_t n = rows * inner;
-  if (logits_bf16)
+  if (logits_bf16 == 1)
     hipLaunchKernelGGL((nllb_fwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
                        (const __bf16*)logits, x, seq_mask, n, inner, weight, out, passes, pass_w(pass_weight, passes));
+  else if (logits_bf16 == 2)        // fp32 logits, the bf16 path's arithmetic
+    hipLaunchKernelGGL((nllb_fwd_kernel<true, float, true>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
+                       (const float*)logits, x, seq_mask, n, inner, weight, out, passes, pass_w(pass_weight, passes));
   else
     hipLaunchKernelGGL((nllb_fwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
                        (const float*)logits, x, seq_mask, n, inner, weight, out, passes, pass_w(pass_weight, passes));
@@ -747,9 +816,12 @@ extern "C" int mdmm_nll_bernoulli_logits_passes_bwd(const void* logits, int logi
     if (channels < 1 || channels > 4 || inner % (4 * channels) || (n & 3)) return MDMM_E_ARG;
     chan4 = inner / (4 * channels);
   }
-  if (logits_bf16)
+  if (logits_bf16 == 1)
     hipLaunchKernelGGL((nllb_bwd_kernel<true, __bf16>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
                        (const __bf16*)logits, x, seq_mask, n, inner, scale, scale_dev, (__bf16*)g_logits, passes, chan_part, chan4, pass_w(pass_weight, passes));
+  else if (logits_bf16 == 2)
+    hipLaunchKernelGGL((nllb_bwd_kernel<true, float, true>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
+                       (const float*)logits, x, seq_mask, n, inner, scale, scale_dev, (float*)g_logits, passes, chan_part, chan4, pass_w(pass_weight, passes));
   else
     hipLaunchKernelGGL((nllb_bwd_kernel<true, float>), dim3(grid_for(n / 4 + 1)), dim3(NT), 0, STREAM,
                        (const float*)logits, x, seq_mask, n, inner, scale, scale_dev, (float*)g_logits, passes, chan_part, chan4, pass_w(pass_weight, passes));

@@ -468,12 +468,13 @@ class MultiDMM(MultiDGTS):
                 return
             if self._logit_decoder(m):      # sigmoid + BCE + masks in one pass each way
                 stacked = self._decode_for_loss(m, z_list, logits=True, stacked=True) if len(z_list) <= 8 else None
+                fast = self.conv_dtype is torch.bfloat16       # (fp32 logits -- the audio stacks' -- with the bf16 ones' arithmetic)
                 if stacked is not None:     # the passes as one batch: scored in place, one gradient buffer
                     ops.nll_bernoulli_logits(stacked[0], targets[m], mask, 2, float(mult), total, passes=len(z_list),
-                                             pass_weight=w_list, consume=True)
+                                             pass_weight=w_list, consume=True, fast=fast)
                     return
                 for rec, w in zip(self._decode_for_loss(m, z_list, logits=True), w_list):
-                    ops.nll_bernoulli_logits(rec[0], targets[m], mask, 2, float(mult) * w, total)
+                    ops.nll_bernoulli_logits(rec[0], targets[m], mask, 2, float(mult) * w, total, fast=fast)
                 return
             for rec, w in zip(self._decode_for_loss(m, z_list), w_list):
                 self._nll(m, rec, targets[m], mask, weight=float(mult) * w, into=total)

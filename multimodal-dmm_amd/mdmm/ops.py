@@ -1126,13 +1126,15 @@ class _NllBernLogitsFn(torch.autograd.Function):
     have to stack)."""
 
     @staticmethod
-    def forward(ctx, logits, x, mask, rows, inner, weight, into, passes=1, channels=0, pass_weight=None, consume=False):
+    def forward(ctx, logits, x, mask, rows, inner, weight, into, passes=1, channels=0, pass_weight=None, consume=False,
+                fast=False):
         _need_gpu(logits, x)
         lg, xv = _act(logits), _f32c(x)
         if lg.numel() != passes * rows * inner:
             raise ValueError('logits of %d elements for %d passes of %d x %d' % (lg.numel(), passes, rows, inner))
         acc = _term_acc(into, lg.device)
-        ctx.bf = lg.dtype == torch.bfloat16
+        # (mdmm_nll_bernoulli_logits_passes_*'s logits_bf16: 1 = bf16 logits, 2 = fp32 logits with their arithmetic)
+        ctx.bf = 1 if lg.dtype == torch.bfloat16 else (2 if fast else 0)
         ctx.pw = None
         if pass_weight is not None and any(float(w) != 1.0 for w in pass_weight):
             if len(pass_weight) != passes or passes > 8:
@@ -1143,7 +1145,7 @@ class _NllBernLogitsFn(torch.autograd.Function):
         # consume: the caller gives the logits up (nll_bernoulli_logits checked who made them): one pass forms the loss AND
         # overwrites them with their gradient up to the upstream scalar, which the producing layer's backward applies to
         # its own outputs (mdmm_conv_t.out_scale) -- the backward pass over (logits, x) does not run
-        ctx.fused = bool(consume and ctx.bf and lg is logits and inner % 4 == 0 and (rows * inner) % 4 == 0)
+        ctx.fused = bool(consume and ctx.bf == 1 and lg is logits and inner % 4 == 0 and (rows * inner) % 4 == 0)
         if ctx.fused:
             part = None
             if ctx.channels:
@@ -1165,7 +1167,7 @@ class _NllBernLogitsFn(torch.autograd.Function):
             if part is not None:
                 _stash_chansum(e, colsum(part)[:ctx.channels] * gd)
             _stash_scale(e, gd)
-            return e, None, None, None, None, None, None, None, None, None, None
+            return e, None, None, None, None, None, None, None, None, None, None, None
         lg, xv = ctx.saved_tensors
         gl = torch.empty_like(lg)
         gd = _gdev(g)
@@ -1177,7 +1179,7 @@ class _NllBernLogitsFn(torch.autograd.Function):
               tag='mdmm_nll_bernoulli_logits_bwd')
         if part is not None:
             _stash_chansum(gl, colsum(part)[:ctx.channels])
-        return gl, None, None, None, None, None, None, None, None, None, None
+        return gl, None, None, None, None, None, None, None, None, None, None, None
 
 
 # Per-channel sums of a gradient tensor that its producer had at hand, for the consumer that needs them as a bias
@@ -1279,10 +1281,12 @@ def lazy_bn_ok(x_pre):
 
 
 def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=None, passes=1, channels=0, pass_weight=None,
-                         consume=False):
+                         consume=False, fast=False):
     """losses.py:23-42 on the pre-sigmoid activations of a decoder whose last module is nn.Sigmoid
     (common.py:163-165): sigmoid + binary cross entropy + masks in one pass each way.  passes: logits =
-    that many stacked passes, each scored against x (the sum of their terms)."""
+    that many stacked passes, each scored against x (the sum of their terms).  fast: fp32 logits scored with the bf16 logits'
+    arithmetic (softplus(l) - x l) instead of F.binary_cross_entropy's on sigmoid(l) -- for a model whose contractions run
+    in bf16 (the fp32 parity mode keeps the reference's arithmetic, clamp and sigmoid saturation included)."""
     rows = _lead_rows(x, lead_dims)
     inner = x.numel() // rows
     if not channels and x.dim() == lead_dims + 3:       # (T, B, C, H, W) observations: C channels per row
@@ -1291,7 +1295,7 @@ def nll_bernoulli_logits(logits, x, mask=None, lead_dims=2, weight=1.0, into=Non
     # loss only) -- see _NllBernLogitsFn.forward
     consume = bool(consume) and scaled_grad_ok(logits) and logits.requires_grad
     return _term_done(_NllBernLogitsFn.apply(logits, x, _row_mask(mask, rows, x), rows, inner,
-                                             float(weight), into, int(passes), int(channels), pass_weight, consume), into)
+                                             float(weight), into, int(passes), int(channels), pass_weight, consume, bool(fast)), into)
 
 
 def nan_to_zero(x, lead_dims=2, store=torch.float32):

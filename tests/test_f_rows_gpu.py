@@ -407,7 +407,7 @@ def test_batchnorm_groups_equal_separate_calls(dev, dtype, groups):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('inner', [3 * 8 * 8, 7])
+@pytest.mark.parametrize('inner', [3 * 8 * 8, 7, 130])       # (130: float4 pieces that straddle row ends, n a multiple of 4)
 def test_bernoulli_logits_stacked_passes(dev, dtype, inner):
     """ops.nll_bernoulli_logits(..., passes=P) on P stacked parameter tensors = the sum of P calls on the passes
     (losses.py:23-42 per pass, dgts.py:119-129): value and the gradient, written into one buffer of the
@@ -430,6 +430,20 @@ def test_bernoulli_logits_stacked_passes(dev, dtype, inner):
     assert ga.dtype == dtype and ga.shape == a.shape
     assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
     assert torch.equal(ga, gb)
+    # against torch on the same logits (masked rows and NaN observations contribute nothing)
+    ref_l = lg.float().reshape(P, T, B, inner).detach().requires_grad_()
+    live = (mask.reshape(1, T, B, 1) & ~torch.isnan(x).reshape(1, T, B, inner)).expand(P, T, B, inner)
+    xt = torch.nan_to_num(x).reshape(1, T, B, inner).expand(P, T, B, inner)
+    ref = 0.7 * (torch.nn.functional.binary_cross_entropy_with_logits(ref_l, xt, reduction='none') * live).sum()
+    gr, = torch.autograd.grad(ref, ref_l)
+    assert abs(float(la) - float(ref)) <= (2e-5 if dtype is torch.float32 else 1e-4) * abs(float(ref))
+    assert helpers.rel_err(ga.float().reshape(P, T, B, inner), gr) < (2e-5 if dtype is torch.float32 else 8e-3)
+    if dtype is torch.float32:      # fp32 logits scored with the bf16 logits' arithmetic (fast): the same numbers to rounding
+        c = lg.clone().requires_grad_()
+        lc = ops.nll_bernoulli_logits(c, x, mask, 2, 0.7, None, passes=P, fast=True)
+        gc, = torch.autograd.grad(lc, c)
+        assert abs(float(lc) - float(la)) <= 2e-5 * abs(float(la))          # (hardware exp / log: ~1e-6 each)
+        assert helpers.rel_err(gc, ga) < 1e-4
 
 
 @pytest.mark.parametrize('groups', [1, 2])
