@@ -215,20 +215,54 @@ class MultiDKS(MultiDGTS):
                 else:                   # zero-masked inputs: every sequence sees the same features
                     h = self._rnn(m, feat[:, :1].contiguous(), gone[:, :1]).expand(-1, b_dim, -1)
                 left[m] = (feat, h, gone)
-        rest, stops = [], []
+        # The time-parallel part of the combiner's first layer, u = in_to_h[0]([., h_out_t, feat_t]) without its z columns
+        # (dks.py:246-280), is linear in the column blocks: a pass's u is the sum of one product per block, and a block --
+        # a modality's observed (or left-out) RNN states / features -- is the same tensor in every pass that picks it.  So each
+        # distinct block is projected ONCE with its own columns of the weight (the left-out ones are one row per step or one
+        # row in all: broadcast behind the product) and a pass adds its picks: the reference's (T, P*B, blocks) concatenation
+        # of every pass's picks (25 cat launches, 0.6 TB/s on 256-element pieces: 3.7 of the 26 ms of a cfg4 step) and three
+        # quarters of the projection's flops are not there; same products, another summation order (fp32 sums of partial
+        # products).
+        w_in = self.combiner.in_to_h[0].weight
+        bias = self.combiner.in_to_h[0].bias
+        col0, blocks = self.z_dim, {}
+        for k in ((1, 0) if self.feat_to_z else (1,)):             # column order of the reference: all h blocks, then all feats
+            for m in self.modalities:
+                width = (real[m] if m in real else left[m])[k].shape[-1]
+                blocks[(m, k)] = (col0, col0 + width)
+                col0 += width
+        proj = {}
+
+        def block(m, which, k):
+            key = (m, which, k)
+            if key not in proj:
+                t = (real[m] if which else left[m])[k]
+                if not which and k == 1:                           # (the left-out states are expanded views: project the rows that exist)
+                    t = t[:1, :1] if self.rnn_skip else t[:, :1]
+                c0, c1 = blocks[(m, k)]
+                y = ops.tall_projection(t.reshape(-1, t.shape[-1]), w_in[:, c0:c1], None, self.sweep_dtype)
+                proj[key] = y.reshape(t.shape[0], t.shape[1], self.h_dim)
+            return proj[key]
+
+        u_list, stops = [], []
         for ps in passes:
             pick = [real[m] if m in ps else left[m] for m in self.modalities]
-            cols = [v[1] for v in pick] + ([v[0] for v in pick] if self.feat_to_z else [])
-            rest.append(torch.cat(cols, dim=-1))
+            terms = [block(m, m in ps, k) for k in ((1, 0) if self.feat_to_z else (1,)) for m in self.modalities]
+            full = [t for t in terms if t.shape[1] == b_dim and t.shape[0] == t_max]
+            rest_ = [t for t in terms if not (t.shape[1] == b_dim and t.shape[0] == t_max)]
+            acc = bias
+            for t in rest_:                                        # the broadcast rows first (a handful of elements)
+                acc = acc + t
+            u_p = acc.expand(t_max, b_dim, self.h_dim) if not full else None
+            for t in full:
+                u_p = (t + acc) if u_p is None else (u_p + t)
+            u_list.append(u_p)
             both = torch.stack([v[2] for v in pick]).all(dim=0)
             steps = torch.arange(t_max, device=dev).unsqueeze(1)
             stops.append((both.long() * steps).max(dim=0).values)
-        rest = torch.cat(rest, dim=1)                              # (T, P*B, .)
+        u = torch.cat(u_list, dim=1).contiguous()                  # (T, P*B, H)
         t_stop = torch.cat(stops).to(torch.int32).contiguous()     # (P*B)
         rows = n_pass * b_dim
-        w_in = self.combiner.in_to_h[0].weight
-        u = ops.tall_projection(rest.reshape(t_max * rows, -1), w_in[:, self.z_dim:],
-                                self.combiner.in_to_h[0].bias, self.sweep_dtype).reshape(t_max, rows, self.h_dim)
         noise = self._noise()
         cfg = dict(T=t_max, B=rows, D=self.z_dim, H=self.h_dim, sample=sample,
                    sample_init=sample_init, min_std_gtf=float(self.fwd.min_std),
