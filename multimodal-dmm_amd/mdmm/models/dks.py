@@ -170,8 +170,12 @@ class MultiDKS(MultiDGTS):
             shape = (t_max, b_dim) + tuple(self.dims[m])
         else:
             shape = (t_max, b_dim, self.dims[m])
-        x = torch.zeros(shape, device=dev)
-        return x.long() if self.dists[m] == 'Categorical' else x
+        if self.dists[m] == 'Categorical':
+            return torch.zeros(shape, device=dev, dtype=torch.long)
+        probe = torch.empty((1,) * 5, device=dev).expand(shape) if len(shape) == 5 else None
+        # (frames for an encoder on the tile convolutions: zeros in the type the cleaned frames have, _frames_store)
+        store = self._frames_store(self.enc[m], probe) if probe is not None else torch.float32
+        return torch.zeros(shape, device=dev, dtype=store)
 
     def step(self, inputs, mask, kld_mult, rec_mults, targets=None, uni_loss=True, **kwargs):
         """MultiDGTS.step (dgts.py:85-130) for the DKS with the passes fused: the multimodal pass
