@@ -40,11 +40,15 @@ constexpr int XR = 64;               // rows per stage
 constexpr int XRS = XK * 2 + 16;     // LDS row stride (bytes): 16-byte fragment reads of 32 rows are conflict-free
 constexpr int X_STAGE = XR * XRS;
 constexpr int X_LDS = 3 * X_STAGE + 1024;   // two A stages + the output image + the bias
+// fp32 output (F32: the GRU input projections and the combiner's column blocks of MultiDKS, dks.py:219-231, 246-280, and
+// every other 256-deep Linear whose result is a latent-side quantity): the output image holds fp32 rows
+constexpr int XRS_F = 256 * 4 + 16;
+constexpr int X_LDS_F = 2 * X_STAGE + XR * XRS_F + 1024;
 
 struct XRegs { u32x4 v[4]; };
 
 // MODE (measurement only): 1 = no stores to memory, 2 = a quarter of the products, 3 = no loads after the first stages
-template <int MODE>
+template <int MODE, bool F32 = false>
 __global__ __launch_bounds__(512) void expand_kernel(const mdmm_gemm_t g, int rows_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(512) void expand_kernel(const mdmm_gemm_t g, int ro
   if (row_lo >= row_hi) return;
   const int nst = (row_hi - row_lo + XR - 1) / XR;
   const gld4 ga = (gld4)g.a;
-  const int64_t lda = g.lda >> 3, ldb = g.ldb >> 3, ldc = g.ldc >> 3;      // in 16-byte units
+  const int64_t lda = g.lda >> 3, ldb = g.ldb >> 3, ldc = F32 ? g.ldc >> 2 : g.ldc >> 3;      // in 16-byte units
 
   // stage loads: 2048 16-byte pieces, thread t takes pieces t + 512 q: piece c = (row c / 32, chunk c % 32);
   // rows past the end are read from the last row (no branch around a load) and never stored
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(512) void expand_kernel(const mdmm_gemm_t g, int ro
   // the block's 256 bias values behind the images (read back per stage: sixteen registers less)
   const bool relu = (g.flags & MDMM_GEMM_RELU) != 0;
   char* const epi = lds + 2 * X_STAGE;
-  float* const bias_l = reinterpret_cast<float*>(lds + 3 * X_STAGE);
+  float* const bias_l = reinterpret_cast<float*>(lds + (F32 ? 2 * X_STAGE + XR * XRS_F : 3 * X_STAGE));
   if (tid < 256) bias_l[tid] = g.bias ? g.bias[col0 + tid] : 0.f;
   write_stage(lds, r0);
   load_stage(min(2, nst - 1), r0);
@@ -141,24 +145,42 @@ __global__ __launch_bounds__(512) void expand_kernel(const mdmm_gemm_t g, int ro
       for (int q = 0; q < 4; ++q) {
         const float4 b4 = *reinterpret_cast<const float4*>(bias_l + 32 * wave + 8 * q + 4 * h);
         const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
-        bf16x4 p;
+        float vq[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = acc[t][4 * q + e] + bq[e];
           if (relu) v = fmaxf(v, 0.f);
-          p[e] = (__bf16)v;
+          vq[e] = v;
         }
-        *reinterpret_cast<u32x2*>(epi + (32 * t + l32) * XRS + (32 * wave + 8 * q + 4 * h) * 2) = __builtin_bit_cast(u32x2, p);
+        if constexpr (F32) {
+          *reinterpret_cast<float4*>(epi + (32 * t + l32) * XRS_F + (32 * wave + 8 * q + 4 * h) * 4) = float4{vq[0], vq[1], vq[2], vq[3]};
+        } else {
+          bf16x4 p;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p[e] = (__bf16)vq[e];
+          *reinterpret_cast<u32x2*>(epi + (32 * t + l32) * XRS + (32 * wave + 8 * q + 4 * h) * 2) = __builtin_bit_cast(u32x2, p);
+        }
       }
     __syncthreads();
     const gst4 gc = (gst4)g.c;
+    if constexpr (F32) {      // 64 rows x 64 16-byte pieces
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = tid + 512 * q;
-      const int row = row_lo + st * XR + (c >> 5);
-      const u32x4 v = *reinterpret_cast<const u32x4*>(epi + (c >> 5) * XRS + (c & 31) * 16);
-      if (MODE == 1 && v[0] != 0x12345678u) continue;
-      if (!TAIL || row < row_hi) gc[(int64_t)row * ldc + (col0 >> 3) + (c & 31)] = v;
+      for (int q = 0; q < 8; ++q) {
+        const int c = tid + 512 * q;
+        const int row = row_lo + st * XR + (c >> 6);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(epi + (c >> 6) * XRS_F + (c & 63) * 16);
+        if (MODE == 1 && v[0] != 0x12345678u) continue;
+        if (!TAIL || row < row_hi) gc[(int64_t)row * ldc + (col0 >> 2) + (c & 63)] = v;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = tid + 512 * q;
+        const int row = row_lo + st * XR + (c >> 5);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(epi + (c >> 5) * XRS + (c & 31) * 16);
+        if (MODE == 1 && v[0] != 0x12345678u) continue;
+        if (!TAIL || row < row_hi) gc[(int64_t)row * ldc + (col0 >> 3) + (c & 31)] = v;
+      }
     }
   };
   const std::integral_constant<bool, false> full;
@@ -537,16 +559,18 @@ __global__ __launch_bounds__(256) void lin_pack_kernel(const mdmm_lin_pack_batch
 namespace heads {
 
 bool expand_ok(const mdmm_gemm_t* g) {
-  if (g->ta || g->tb || !g->a_bf16 || !g->b_bf16 || !g->c_bf16 || g->split != 1 || (g->flags & 4)) return false;
+  if (g->ta || g->tb || !g->a_bf16 || !g->b_bf16 || g->split != 1 || (g->flags & 4)) return false;
   if (g->L != XK || g->J < 256 || (g->J & 255) || g->I < 1) return false;
-  if ((g->lda & 7) || (g->ldb & 7) || (g->ldc & 7) || g->lda < XK || g->ldb < XK || g->ldc < g->J) return false;
+  if ((g->lda & 7) || (g->ldb & 7) || (g->ldc & (g->c_bf16 ? 7 : 3)) || g->lda < XK || g->ldb < XK || g->ldc < g->J) return false;
   return !((((uintptr_t)g->a) | ((uintptr_t)g->b) | ((uintptr_t)g->c)) & 15);
 }
 
 int expand_launch(const mdmm_gemm_t* g, hipStream_t st) {
   const int mode = (g->flags >> 3) & 3;
   auto kern = mode == 1 ? expand_kernel<1> : mode == 2 ? expand_kernel<2> : mode == 3 ? expand_kernel<3> : expand_kernel<0>;
-  if (int rc = mdmm_lds_attr_fn((const void*)kern, (size_t)X_LDS)) return rc;
+  const int x_lds = g->c_bf16 ? X_LDS : X_LDS_F;
+  if (!g->c_bf16) kern = expand_kernel<0, true>;
+  if (int rc = mdmm_lds_attr_fn((const void*)kern, (size_t)x_lds)) return rc;
   // one workgroup per CU: column blocks x row ranges ~ 256, ranges in whole stages
   const int n_cb = g->J / 256;
   int ranges = 256 / n_cb;
@@ -554,7 +578,7 @@ int expand_launch(const mdmm_gemm_t* g, hipStream_t st) {
   int per = (g->I + ranges - 1) / ranges;
   per = (per + XR - 1) / XR * XR;
   ranges = (g->I + per - 1) / per;
-  hipLaunchKernelGGL(kern, dim3(n_cb * ranges), dim3(512), X_LDS, st, *g, per);
+  hipLaunchKernelGGL(kern, dim3(n_cb * ranges), dim3(512), x_lds, st, *g, per);
   return (int)hipGetLastError();
 }
 

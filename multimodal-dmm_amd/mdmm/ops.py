@@ -1702,8 +1702,10 @@ class _LinearTilesFn(torch.autograd.Function):
         ctx.gx_dtype = x.dtype
         # (the 4096-wide side must be bf16 already -- activations stored as bf16, ACT_STORAGE: rounding 84 MB here
         # would cost more than the kernels save)
+        # (a 256-deep product writes either output type -- expand_kernel<., F32>: the GRU input projections and the
+        #  combiner's column blocks of MultiDKS, the Categorical decoder's trunk)
         heads = (_heads_shape(k, n) and os.environ.get('MDMM_GEMM_GENERIC') != '1'
-                 and (k == 256 or x.dtype == torch.bfloat16) and (n == 256 or out_dtype == torch.bfloat16))
+                 and (k == 256 or x.dtype == torch.bfloat16) and (n == 256 or out_dtype == torch.bfloat16 or k == 256))
         if heads:
             wf = _lin_pack(weight)[0]
             if x.dtype != torch.bfloat16:

@@ -34,7 +34,8 @@ def _both(monkeypatch, fn):
 
 
 @pytest.mark.parametrize('m,n,odt', [(10240, 4096, torch.bfloat16), (1000, 512, torch.bfloat16), (37, 256, torch.bfloat16),
-                                     (243, 4096, torch.bfloat16), (64, 256, torch.bfloat16), (65, 768, torch.bfloat16)])
+                                     (243, 4096, torch.bfloat16), (64, 256, torch.bfloat16), (65, 768, torch.bfloat16),
+                                     (10240, 768, torch.float32), (1000, 256, torch.float32), (65, 512, torch.float32)])
 def test_expand_matches_torch(dev, monkeypatch, m, n, odt):
     from mdmm import ops
     torch.manual_seed(m + n)
