@@ -190,8 +190,12 @@ _BF16_GRAD_TOL = {
     # family 'conv': conv plug-ins with bf16-stored activations on a few frames (6 sequences): measured maxima
     #   bn_affine 1.2e-1, conv 9.1e-2, gtf_first 8.5e-2, gtf_rest 3.7e-2, plug_other 7.8e-2, other 6.0e-2 (the DKS
     #   recurrences' input weights, which read the conv features) -- three times any of them is past round 3's bounds,
-    #   which therefore stay
-    'conv': {'gtf_first': 1e-1, 'plug_other': 1e-1, 'gtf_rest': 1e-1, 'other': 1e-1, 'bn_affine': 1.5e-1, 'conv': 1e-1},
+    #   which therefore stay.  Round 5: the first encoder layers' weight gradients of the cfg4 replay test moved from
+    #   8.5e-2 / 9.1e-2 to 9.4e-2 / 1.03e-1 when MultiDKS.step began to sum the combiner's column-block products in another
+    #   fp32 ORDER (same bf16 operands, same products: models/dks.py) -- at four sequences this figure is a draw from the
+    #   rounding noise (which gates flip), +-1e-2 from one summation order to the next; tests/test_bf16_claim_gpu.py is
+    #   what tells noise from bias (the error halves from B = 6 to B = 256).  'conv': 1e-1 -> 1.2e-1.
+    'conv': {'gtf_first': 1e-1, 'plug_other': 1e-1, 'gtf_rest': 1e-1, 'other': 1e-1, 'bn_affine': 1.5e-1, 'conv': 1.2e-1},
 }
 
 
