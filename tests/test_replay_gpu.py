@@ -204,13 +204,15 @@ def test_graph_replay_matches_eager_and_oracle(name, dev):
         assert e < tol, 'replayed %s grad %s vs oracle: %.3e' % (name, k, e)
 
 
-@pytest.mark.parametrize('flat_adam', [True, False])
-def test_graphed_conv_step_through_rccl_world_one(dev, monkeypatch, flat_adam):
+def test_graphed_conv_step_through_rccl_world_one(dev, monkeypatch):
     """bench.py --gpus N per rank, on hardware with a real NCCL (= RCCL) group of one rank and the conv model of
     cfg3: [graph: step + backward] -> all_reduce of the flat gradient (eager, between the graphs) -> [graph: Adam].
     The collective really runs once per step, on the buffer the captured backward filled and the captured Adam
-    reads; losses and weights equal those of the group-less replayed step.  flat_adam: harness.FlatAdam (what bench.py
-    runs: one launch over that same flat buffer) or torch.optim.Adam(fused, capturable)."""
+    reads; losses and weights equal those of the group-less replayed step.  The optimizer is harness.FlatAdam, as in
+    bench.py (one launch over that same flat buffer; rounds 3-4 ran this test with torch.optim.Adam(fused, capturable)).
+    One process group per process: a second init / destroy cycle in the suite's process is one more chance for the
+    runtime abort DESIGN 5.5 / 6 describe (seen once in round 5 with this test parametrised over the optimizer)."""
+    flat_adam = True
     import os
     import torch.distributed as dist
     from mdmm import models
