@@ -73,8 +73,10 @@ def measure_batch_prep(device):
         out[name] = {
             'items': n, 'T': int(max(lengths)), 'item_bytes': in_bytes, 'batch_bytes': out_bytes,
             'seq_collate_dict': {'wall_ms': round(w_col, 3), 'stream_ms': round(d_col, 3),
-                                 'note': 'host packing + one host-to-device copy per modality + mdmm_collate_pad; the copy '
-                                         '(pageable host memory) is the time, not the kernel'},
+                                 'host_gbs': round(in_bytes / w_col / 1e6, 1),
+                                 'note': 'host threads pack the items into a pinned staging buffer piece by piece, every piece '
+                                         'copied to the device as it is packed (batch._to_device_packed), then mdmm_collate_pad; '
+                                         'host_gbs = item bytes over the wall time'},
             'burst_delete[device generator]': {'wall_ms': round(w_del, 3), 'stream_ms': round(d_del, 3),
                                                'hbm_gbs': round(2 * out_bytes / d_del / 1e6, 1),
                                                'hbm_frac': round(2 * out_bytes / d_del / 1e6 / HBM_PEAK_GBS, 4)},
