@@ -606,6 +606,10 @@ typedef struct mdmm_bn {
 int mdmm_bn_splits(int64_t N, int C, int64_t L);
 int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream);
 int mdmm_bn_relu_bwd(const mdmm_bn_t* a, void* stream);
+/* nn.BatchNorm in EVALUATION mode + nn.ReLU (common.py:80-84 under Trainer.evaluate, trainer.py:278-312) as one streaming
+ * pass: y = [relu] (x - running_mean[c]) gamma[c] / sqrt(running_var[c] + eps) + beta[c].  Fields read: N, L, C, relu,
+ * splits (mdmm_bn_splits), bf16_io, eps, x, y, gamma, beta, running_mean, running_var (nothing is updated).  */
+int mdmm_bn_relu_eval(const mdmm_bn_t* a, void* stream);
 
 /* Stride-2 convolution pyramids of the image plug-ins (common.py:70-112, 114-175): Conv =
  * nn.Conv2d(k3, s2, p1), Deconv = nn.ConvTranspose2d(k4, s2, p1) on 64 x 64 frames.  A layer

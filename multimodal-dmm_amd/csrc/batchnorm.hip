@@ -238,6 +238,52 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, i
   }
 }
 
+// ---- evaluation mode ------------------------------------------------------------------------
+// y = [relu] (x - running_mean) gamma / sqrt(running_var + eps) + beta: nn.BatchNorm in eval mode followed by nn.ReLU
+// (common.py:80-84 under Trainer.evaluate) as one streaming pass.  (The library's inference kernel took 4.7 ms per layer
+// on 10,240 x 16 x 32 x 32 fp32 -- 0.14 TB/s --, 38 of the 53 ms of the evaluation forward at cfg3 size.)
+template <bool VEC, typename T>
+__global__ __launch_bounds__(NT) void bn_eval_kernel(const T* __restrict__ x, int64_t N, int C, int64_t L,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ running_mean,
+                                                     const float* __restrict__ running_var, float eps, int relu,
+                                                     T* __restrict__ y) {
+  const int c = blockIdx.x;
+  const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+  const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+  const float scale = g * invstd, shift = fmaf(-running_mean[c], scale, b);
+  const Span sp = span_of(N);
+  if (VEC) {
+    constexpr int W = VecW<T>::W;
+    const int64_t LW = L / W, tot = (sp.n_hi - sp.n_lo) * LW;
+    const Rows rows(LW, tot);
+    for (int64_t i = threadIdx.x; i < tot; i += NT) {
+      int64_t n, l;
+      rows.split(i, n, l);
+      n += sp.n_lo;
+      float v[W];
+      ldv(x + (n * C + c) * L + W * l, v);
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        v[j] = fmaf(v[j], scale, shift);
+        if (relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      stv(y + (n * C + c) * L + W * l, v);
+    }
+  } else {
+    const int64_t tot = (sp.n_hi - sp.n_lo) * L;
+    const Rows rows(L, tot);
+    for (int64_t i = threadIdx.x; i < tot; i += NT) {
+      int64_t n, l;
+      rows.split(i, n, l);
+      n += sp.n_lo;
+      float o = fmaf((float)x[(n * C + c) * L + l], scale, shift);
+      if (relu) o = fmaxf(o, 0.f);
+      y[(n * C + c) * L + l] = (T)o;
+    }
+  }
+}
+
 // ---- backward -----------------------------------------------------------------------------
 // g = dy * [bn(x) > 0] (with ReLU);  partial = (sum g, sum g * xhat)
 template <bool VEC, typename T>
@@ -456,6 +502,27 @@ extern "C" int mdmm_bn_relu_fwd(const mdmm_bn_t* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->bf16_io) { if (vec_ok(a)) launch_fwd<true, __bf16>(a, st); else launch_fwd<false, __bf16>(a, st); }
   else { if (vec_ok(a)) launch_fwd<true, float>(a, st); else launch_fwd<false, float>(a, st); }
+  return (int)hipGetLastError();
+}
+
+extern "C" int mdmm_bn_relu_eval(const mdmm_bn_t* a, void* stream) {
+  if (!a || a->N < 1 || a->C < 1 || a->L < 1 || !a->x || !a->y || !a->running_mean || !a->running_var) return MDMM_E_ARG;
+  if (a->splits < 1 || a->splits > 65535) return MDMM_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(a->C, a->splits, 1);
+  const int w = a->bf16_io ? 8 : 4;
+  const bool vec = a->L % w == 0 && !(((uintptr_t)a->x | (uintptr_t)a->y) & 15);
+  if (a->bf16_io) {
+    if (vec) hipLaunchKernelGGL((bn_eval_kernel<true, __bf16>), grid, dim3(NT), 0, st, (const __bf16*)a->x, a->N, a->C, a->L, a->gamma,
+                                a->beta, a->running_mean, a->running_var, a->eps, a->relu, (__bf16*)a->y);
+    else hipLaunchKernelGGL((bn_eval_kernel<false, __bf16>), grid, dim3(NT), 0, st, (const __bf16*)a->x, a->N, a->C, a->L, a->gamma,
+                            a->beta, a->running_mean, a->running_var, a->eps, a->relu, (__bf16*)a->y);
+  } else {
+    if (vec) hipLaunchKernelGGL((bn_eval_kernel<true, float>), grid, dim3(NT), 0, st, (const float*)a->x, a->N, a->C, a->L, a->gamma,
+                                a->beta, a->running_mean, a->running_var, a->eps, a->relu, (float*)a->y);
+    else hipLaunchKernelGGL((bn_eval_kernel<false, float>), grid, dim3(NT), 0, st, (const float*)a->x, a->N, a->C, a->L, a->gamma,
+                            a->beta, a->running_mean, a->running_var, a->eps, a->relu, (float*)a->y);
+  }
   return (int)hipGetLastError();
 }
 

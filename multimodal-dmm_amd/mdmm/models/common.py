@@ -178,7 +178,10 @@ class _ConvBlock(nn.Module):
                 return torch.cat([self.net[2](bn(c)) for c in chunks])
             if bn.training and ops.bn_sync_group() is not None:      # statistics of every rank's batch (ops.bn_sync)
                 return ops.sync_batchnorm_relu_torch(conv(x), bn)
-            return self.net[2](bn(conv(x)))
+            y_pre = conv(x)
+            if isinstance(self.net[2], nn.ReLU) and ops.batchnorm_relu_eval_supported(y_pre, bn):
+                return ops.batchnorm_relu_eval(y_pre, bn)             # (evaluation: running statistics, one pass)
+            return self.net[2](bn(y_pre))
         from .. import ops
         if ops.conv_tiles_supported(self.net, x):
             return ops.conv_tiles(self.net, x, owed=owed)

@@ -25,7 +25,7 @@ SYMBOLS = [
     'mdmm_kld_gauss_fwd', 'mdmm_kld_gauss_bwd',
     'mdmm_nll_gauss_fwd', 'mdmm_nll_gauss_bwd',
     'mdmm_nll_bernoulli_fwd', 'mdmm_nll_bernoulli_bwd',
-    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero', 'mdmm_nan_to_zero_bf16', 'mdmm_adam_flat', 'mdmm_gemm_colsum_a', 'mdmm_nll_bernoulli_logits_passes_fwd_grad', 'mdmm_fold_slabs', 'mdmm_embed_relu_supported', 'mdmm_embed_relu_slabs', 'mdmm_embed_relu_fwd',
+    'mdmm_nll_bernoulli_logits_fwd', 'mdmm_nll_bernoulli_logits_bwd', 'mdmm_nan_to_zero', 'mdmm_nan_to_zero_bf16', 'mdmm_adam_flat', 'mdmm_gemm_colsum_a', 'mdmm_bn_relu_eval', 'mdmm_nll_bernoulli_logits_passes_fwd_grad', 'mdmm_fold_slabs', 'mdmm_embed_relu_supported', 'mdmm_embed_relu_slabs', 'mdmm_embed_relu_fwd',
     'mdmm_embed_relu_bwd',
     'mdmm_nll_categorical_fwd', 'mdmm_nll_categorical_bwd',
     'mdmm_philox_normal', 'mdmm_debug_clock', 'mdmm_gtf_pack_size', 'mdmm_gtf_pack',
@@ -340,6 +340,7 @@ def lib():
         L.mdmm_bn_splits.argtypes = [C.c_int64, C.c_int, C.c_int64]
         L.mdmm_bn_relu_fwd.argtypes = [C.POINTER(Bn), _P]
         L.mdmm_bn_relu_bwd.argtypes = [C.POINTER(Bn), _P]
+        L.mdmm_bn_relu_eval.argtypes = [C.POINTER(Bn), _P]
         L.mdmm_conv_supported.argtypes = [C.POINTER(Conv)]
         L.mdmm_conv_pack_bytes.argtypes = [C.POINTER(Conv), C.c_int]
         L.mdmm_conv_pack_bytes.restype = C.c_int64

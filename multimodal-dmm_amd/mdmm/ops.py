@@ -2023,6 +2023,32 @@ def batchnorm_relu_supported(x, bn):
             and not torch.is_autocast_enabled())
 
 
+def batchnorm_relu_eval_supported(x, bn):
+    """nn.BatchNorm{1,2}d in evaluation mode (running statistics) on the GPU, nothing to differentiate: the own one-pass
+    kernel (mdmm_bn_relu_eval) instead of the library's inference kernel."""
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and not bn.training and x.dim() >= 3
+            and bn.running_mean is not None and bn.running_var is not None and not torch.is_grad_enabled()
+            and not torch.is_autocast_enabled())
+
+
+def batchnorm_relu_eval(x, bn, relu=True):
+    """relu(bn(x)) for a BatchNorm holder in evaluation mode (batchnorm_relu_eval_supported)."""
+    xv = _act(x)
+    N, Cc = xv.shape[0], xv.shape[1]
+    Ln = xv[0, 0].numel()
+    a = native.Bn()
+    a.N, a.C, a.L, a.relu, a.eps = N, Cc, Ln, int(relu), bn.eps
+    a.bf16_io = int(xv.dtype == torch.bfloat16)
+    a.splits = native.lib().mdmm_bn_splits(N, Cc, Ln)
+    y = torch.empty_like(xv)
+    g = None if bn.weight is None else _f32c(bn.weight.detach())
+    b = None if bn.bias is None else _f32c(bn.bias.detach())
+    rm, rv = _f32c(bn.running_mean), _f32c(bn.running_var)
+    a.x, a.y, a.gamma, a.beta, a.running_mean, a.running_var = _ptr(xv), _ptr(y), _ptr(g), _ptr(b), _ptr(rm), _ptr(rv)
+    _call('mdmm_bn_relu_eval', C.byref(a), nbytes=2 * xv.numel() * xv.element_size())
+    return y
+
+
 def batchnorm_relu(x, bn, relu=True, shift=None):
     """nn.Sequential(bn, nn.ReLU())(x) for a BatchNorm1d / BatchNorm2d holder in training mode.
     shift: the bias of the convolution that produced x when the caller left it out (it cancels in

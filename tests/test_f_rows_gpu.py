@@ -848,3 +848,31 @@ def test_conv_out_scale_is_a_multiplication_of_the_outputs(dev, cs, cb, s, bf):
         assert helpers.rel_err(res[True][0].float(), res[False][0].float() * 0.37) < 8e-3
     else:
         assert torch.equal(res[True][0], res[False][0] * 0.37)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(130, 16, 32, 32), (7, 32, 16, 16), (33, 8, 641), (5, 3, 7, 9)])
+def test_batchnorm_eval_one_pass(dev, dtype, shape):
+    """mdmm_bn_relu_eval: nn.BatchNorm in evaluation mode + nn.ReLU (common.py:80-84 under Trainer.evaluate) as one
+    pass, against the stock modules on the same input (fp32: to rounding; bf16 storage: one rounding of the output);
+    the conv blocks of models.common take it under torch.no_grad() only, running statistics untouched."""
+    import torch.nn as nn
+    from mdmm import ops
+    torch.manual_seed(sum(shape))
+    bn = (nn.BatchNorm2d if len(shape) == 4 else nn.BatchNorm1d)(shape[1]).to(dev)
+    with torch.no_grad():
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.3, 2.0); bn.weight.normal_(); bn.bias.normal_()
+    bn.eval()
+    x = (torch.randn(*shape, device=dev) * 2).to(dtype)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    assert not ops.batchnorm_relu_eval_supported(x, bn)           # (grad mode on: the stock modules)
+    with torch.no_grad():
+        assert ops.batchnorm_relu_eval_supported(x, bn)
+        y = ops.batchnorm_relu_eval(x, bn)
+        ref = torch.relu(bn(x.float()))
+    assert y.dtype == dtype and y.shape == x.shape
+    assert helpers.rel_err(y.float(), ref) < (2e-6 if dtype is torch.float32 else 8e-3)
+    assert torch.equal(bn.running_mean, rm) and torch.equal(bn.running_var, rv)
+    bn.train()
+    with torch.no_grad():
+        assert not ops.batchnorm_relu_eval_supported(x, bn)
