@@ -166,6 +166,11 @@ class _ConvBlock(nn.Module):
                     return ops.DeferredNorm(y_pre, bn, layer.bias, part)
                 y_pre = self._conv_nobias(layer, x, owed)
                 return ops.batchnorm_relu(y_pre, bn, shift=layer.bias)
+            # evaluation of a model whose convolutions run with bf16 operands (conv_operands): the same tile kernels as in
+            # training (with the bias: it is part of what the running mean tracked) and the one-pass norm behind them
+            if (not bn.training and isinstance(self.net[2], nn.ReLU) and ops.conv_tiles_supported(layer, x)
+                    and ops.batchnorm_relu_eval_supported(x, bn)):
+                return ops.batchnorm_relu_eval(ops.conv_tiles(layer, x), bn)
             # evaluation mode (running statistics) and CPU: the stock modules, in the weights' precision
             if x.dtype != layer.weight.dtype:
                 x = x.to(layer.weight.dtype)
