@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 31
+#define MDMM_ABI_VERSION 32
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -768,6 +768,69 @@ int mdmm_conv1d_up(const mdmm_conv1d_t* args, void* stream);
 int mdmm_conv1d_down(const mdmm_conv1d_t* args, void* stream);
 int64_t mdmm_conv1d_wgrad_ws_bytes(const mdmm_conv1d_t* args);
 int mdmm_conv1d_wgrad(const mdmm_conv1d_t* args, void* ws, float* dw, void* stream);
+
+/* The audio plug-ins' stacks IN TRAINING, one launch per layer and direction (common.py:177-290: AudioConv /
+ * AudioDeconv -> BatchNorm1d -> ReLU blocks, AudioDecoder's last block scored by losses.py:23-42; csrc/audio_chain.hip).
+ * The stock shapes only: (CS, CB, S) in {(4, 10, 641), (8, 4, 321), (16, 8, 161)} -- both stacks use the same three.
+ * What sits between two convolutions never travels as a tensor of its own:
+ *   - the BatchNorm + ReLU BEHIND a layer: the layer leaves its PRE-normalisation output (bias left out: it cancels) and
+ *     per-workgroup (sum, sum of squares) slabs of what it stored (out_stats -> mdmm_bn_relu_fwd, MDMM_BN_FINALIZE_GIVEN);
+ *     the NEXT layer normalises while it stages that tensor (in_norm);
+ *   - the last AudioDeconv + nn.Sigmoid + F.binary_cross_entropy: the logits exist in registers only -- the forward
+ *     launch adds the loss, the backward launch forms them again and turns them into their gradient on the spot
+ *     (target / row_mask / loss ...: per frame 51 KB of observations are read, nothing 12,810 wide is written);
+ *   - backward: one launch per layer gives the input gradient AND the weight gradient from one staging of both sides;
+ *     a BatchNorm's adjoint is only REDUCED by the launch that produces the gradient of its output (in_adj ->
+ *     mdmm_bn_relu_bwd with bwd_means) and APPLIED by the launch of the layer in front while it stages that gradient
+ *     (out_norm / out_bwd_means); the first encoder layer cleans the NaN-marked frames while it stages them (in_frames).
+ * Activations and their gradients between the layers are fp32 or bf16 in memory (act_bf16), arithmetic fp32 FMA.  */
+typedef struct mdmm_audio_norm {   /* training-mode BatchNorm (+ ReLU) with saved statistics, applied on the fly */
+  const float* mean;     /* [groups][C] (mdmm_bn_t.save_mean); NULL = no norm on this side */
+  const float* invstd;   /* [groups][C] */
+  const float* gamma;    /* [C] or NULL = 1 */
+  const float* beta;     /* [C] or NULL = 0 */
+  int32_t group_n;       /* frame n belongs to group n / group_n; at most 8 groups; N % group_n == 0 */
+  int32_t relu;
+} mdmm_audio_norm_t;
+typedef struct mdmm_audio {
+  int32_t N, S, CS, CB;
+  int32_t up;            /* 1: ConvTranspose1d(k3,s2,p1), input = SMALL side (N, CS, S), output = BIG side (N, CB, 2S-1);
+                          * 0: Conv1d(k3,s2,p1), input = big side, output = small side */
+  int32_t act_bf16;      /* in / out / gout / gin are bf16 (1) or fp32 (0) in memory */
+  const float* weight;   /* torch's [CS][CB][3] for both layer kinds */
+  const float* bias;     /* per output channel, or NULL (a layer with BatchNorm behind it) */
+  const void* in;        /* the layer's input: the block in front's pre-normalisation output with in_norm, else as it is */
+  mdmm_audio_norm_t in_norm;
+  int32_t in_frames;     /* up = 0: `in` is fp32 whatever act_bf16 says, NaN = missing (dmm.py:164-166): zeros are staged */
+  int32_t in_relu_plain; /* backward, up = 1: `in` is a ReLU's output (z_to_feat, common.py:270-273): gin gets its adjoint */
+  float* seen;           /* in_frames, forward: [N] 1.0 where the frame holds no NaN, else 0.0; or NULL */
+  void* out;             /* forward: written (not with `target`); backward with out_norm: read (the saved pre-norm output) */
+  double* out_stats;     /* forward: [groups][C_out][mdmm_audio_parts][2] or NULL */
+  int32_t out_group_n;
+  /* the Bernoulli loss on an up layer's output (losses.py:23-42 on sigmoid(out)); N = passes * rows, frame p * rows + r
+   * is scored against target row r with pass_w[p]; in_norm.group_n must equal rows */
+  int32_t passes;
+  const float* target;   /* (rows, CB, 2S-1) fp32, NaN = unobserved; NULL = no loss */
+  const float* row_mask; /* (rows) fp32 0 / 1, or NULL */
+  int32_t fast;          /* 1: softplus(l) - x l on the hardware exp / log; 0: F.binary_cross_entropy's arithmetic on sigmoid(l) */
+  float loss_weight;
+  float pass_w[8];
+  double* loss;          /* forward: += loss_weight * sum */
+  const float* gscale;   /* backward: the loss's upstream gradient, one device float */
+  /* backward */
+  const void* gout;      /* gradient of the layer's output as its consumer left it (with out_norm: of the normalised one) */
+  mdmm_audio_norm_t out_norm;
+  const float* out_bwd_means;   /* with out_norm: [groups][C_out][2] (mdmm_bn_t.bwd_means) */
+  void* gin;             /* gradient of the (normalised) input, or NULL (frames) */
+  double* in_adj;        /* with in_norm and gin: [groups][C_in][mdmm_audio_parts][2] = (sum g r, sum g r xhat) of gin as stored */
+  float* ws;             /* mdmm_audio_parts * (CS*CB*3 + C_out) floats */
+  float* dw;             /* [CS][CB][3] */
+  float* dbias;          /* [C_out] or NULL */
+} mdmm_audio_t;
+int mdmm_audio_supported(const mdmm_audio_t* args);
+int mdmm_audio_parts(const mdmm_audio_t* args);      /* workgroups of both launches = slabs of out_stats / in_adj / ws */
+int mdmm_audio_fwd(const mdmm_audio_t* args, void* stream);
+int mdmm_audio_bwd(const mdmm_audio_t* args, void* stream);
 
 /* Time-parallel projections (every nn.Linear applied to all T*B rows at once: dks.py:219-231,
  * 246-280 GRU input projections / combiner feature columns; the Linear heads of the image

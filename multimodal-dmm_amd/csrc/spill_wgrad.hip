@@ -141,6 +141,7 @@ extern "C" size_t mdmm_sizeof(int which) {
     case 13: return sizeof(mdmm_vrnn_layout_t);
     case 14: return sizeof(mdmm_spill_wgrad_batch_t);
     case 15: return sizeof(mdmm_convf_t);
+    case 16: return sizeof(mdmm_audio_t);
     default: return 0;
   }
 }

@@ -289,6 +289,17 @@ class AudioEncoder(_GaussHead):
         if gauss_out:
             self._make_heads(z_dim)
 
+    def encode_frames(self, x, blocks):
+        """forward() on (N, 10, 1281) frames whose NaN still mark missing values (dmm.py:164-177 does the cleaning in front
+        of the encoder): the whole conv_stack as one autograd node on csrc/audio_chain.hip (mdmm.audio; `blocks` =
+        audio.encoder_plan(self)), the first layer cleans the frames while it stages them -> (mean, std, seen (N,) 0 / 1)."""
+        from .. import ops, audio
+        act = ops.ACT_STORAGE if ops.CONV_OPERANDS is torch.bfloat16 else torch.float32
+        feats, seen = audio.encode_frames(blocks, x, act)
+        flat = feats.view(-1, self.feat_dim)
+        return (ops.plug_linear(self.feat_to_z_mean, flat),
+                self.feat_to_z_std[1](ops.plug_linear(self.feat_to_z_std[0], flat)), seen)
+
 
 class _ProbDecoder(nn.Module):
     def _make(self, z_dim, block, n_out, n_kernels, n_layers):
@@ -341,3 +352,21 @@ class AudioDecoder(_ProbDecoder):
         self.feat_dim = self.feat_size * n_kernels
         self.feat_shape = (n_kernels, self.feat_size)
         self._make(z_dim, AudioDeconv, n_frames * 2, n_kernels, n_layers)
+
+    def nll(self, z, blocks, target, mask, weight, into, passes, pass_weight, fast):
+        """losses.py:23-42 of forward(z) against `target`, added to the ops.LossSum `into`: z_to_feat on the own GEMM, then
+        the deconv_stack and the Bernoulli loss as one autograd node on csrc/audio_chain.hip (mdmm.audio; `blocks` =
+        audio.decoder_plan(self)) -- the (N, 10, 1281) reconstruction is never written.  z holds `passes` stacked passes
+        of the target's rows, each with its own BatchNorm statistics (the stock module called pass by pass)."""
+        from .. import ops, audio
+        relu_plain = False
+        if isinstance(self.z_to_feat[1], nn.ReLU):
+            feat = ops.plug_linear(self.z_to_feat[0], z, act_out=True, relu=True)
+            x = feat.view(-1, *self.feat_shape)
+            # (the ReLU in the GEMM's epilogue owes its adjoint: the first layer's backward launch applies it)
+            relu_plain = bool(feat.requires_grad and ops.take_owed_relu(x, feat))
+        else:
+            x = self.z_to_feat[1](ops.plug_linear(self.z_to_feat[0], z, act_out=True)).view(-1, *self.feat_shape)
+        if ops.CONV_OPERANDS is torch.bfloat16 and x.dtype != ops.ACT_STORAGE:
+            x = x.to(ops.ACT_STORAGE)       # (a batch too small for the own GEMM: the library's fp32 output)
+        return audio.decoder_nll(blocks, x, target, mask, weight, into, passes, pass_weight, fast, relu_plain)

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .. import audio
 from . import common
 from .dgts import MultiDGTS
 
@@ -103,6 +104,16 @@ class MultiDMM(MultiDGTS):
         lead = tuple(shape[:-1])
         return (self.z0_mean.expand(*lead, self.z_dim), (self.z0_log_std.exp() + self.min_std).expand(*lead, self.z_dim))
 
+    def _audio_plan(self, module, x, plan):
+        """audio.encoder_plan / decoder_plan of a stock audio plug-in under the contexts _plug will run it in, or None."""
+        if self.plugin_dtype is not None or not x.is_cuda or not torch.is_grad_enabled() \
+                or os.environ.get('MDMM_AUDIO_FUSED', '1') == '0':
+            return None
+        if self.bn_sync is not None and ops.BN_SYNC is None:
+            with ops.bn_sync(self.bn_sync):
+                return plan(module)
+        return plan(module)
+
     def _encode_one(self, m, x):
         """One modality -> ((T,B,D) mean, (T,B,D) std, (T,B) bool seen).  dmm.py:164-177"""
         t_max, b_dim = x.shape[:2]
@@ -113,6 +124,12 @@ class MultiDMM(MultiDGTS):
             mean, std, seen = ops.gauss_mlp(x.flatten(0, 1), enc, nan_to_zero=True)
             return (mean.reshape(t_max, b_dim, -1), std.reshape(t_max, b_dim, -1),
                     seen.reshape(t_max, b_dim))
+        blocks = self._audio_plan(enc, x, audio.encoder_plan)
+        if blocks is not None and enc.gauss_out and x.dtype == torch.float32 and tuple(x.shape[2:]) == (10, 1281):
+            # the stock AudioEncoder in training: one autograd node for the conv stack, NaN -> 0 and the "seen" flag in
+            # its first layer's staging (mdmm.audio)
+            mean, std, seen = self._plug(enc.encode_frames, x.flatten(0, 1), blocks=blocks)
+            return mean.reshape(t_max, b_dim, -1), std.reshape(t_max, b_dim, -1), seen.reshape(t_max, b_dim) > 0
         x, seen = self._clean(x, self._frames_store(enc, x))
         if self.dists[m] == 'Categorical':
             stack = ops.embed_relu_stack(enc) if (x.is_cuda and x.shape[2:].numel() == 1 and self.plugin_dtype is None
@@ -467,8 +484,15 @@ class MultiDMM(MultiDGTS):
                                  passes=len(z_list), pass_weight=w_list)
                 return
             if self._logit_decoder(m):      # sigmoid + BCE + masks in one pass each way
+                fast = self.conv_dtype is torch.bfloat16       # (fp32 logits with the bf16 ones' arithmetic)
+                blocks = self._audio_plan(self.dec[m], z_list[0], audio.decoder_plan) if len(z_list) <= 8 else None
+                if blocks is not None and targets[m].dtype == torch.float32 and tuple(targets[m].shape[2:]) == (10, 1281):
+                    # the stock AudioDecoder in training: deconv_stack + loss as one autograd node, no reconstruction
+                    z = torch.stack(z_list).reshape(-1, self.z_dim) if len(z_list) > 1 else z_list[0].reshape(-1, self.z_dim)
+                    self._plug(self.dec[m].nll, z, blocks=blocks, target=targets[m], mask=mask, weight=float(mult), into=total,
+                               passes=len(z_list), pass_weight=w_list, fast=fast)
+                    return
                 stacked = self._decode_for_loss(m, z_list, logits=True, stacked=True) if len(z_list) <= 8 else None
-                fast = self.conv_dtype is torch.bfloat16       # (fp32 logits -- the audio stacks' -- with the bf16 ones' arithmetic)
                 if stacked is not None:     # the passes as one batch: scored in place, one gradient buffer
                     ops.nll_bernoulli_logits(stacked[0], targets[m], mask, 2, float(mult), total, passes=len(z_list),
                                              pass_weight=w_list, consume=True, fast=fast)

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 31
+ABI_VERSION = 32
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -41,6 +41,7 @@ SYMBOLS = [
     'mdmm_nll_bernoulli_logits_passes_fwd', 'mdmm_nll_bernoulli_logits_passes_bwd', 'mdmm_nll_chan_parts',
     'mdmm_convf_cols', 'mdmm_convf_unfold', 'mdmm_convf_fold', 'mdmm_convf_rows', 'mdmm_convf_wgrad_parts', 'mdmm_convf_wgrad',
     'mdmm_conv1d_supported', 'mdmm_conv1d_up', 'mdmm_conv1d_down', 'mdmm_conv1d_wgrad_ws_bytes', 'mdmm_conv1d_wgrad',
+    'mdmm_audio_supported', 'mdmm_audio_parts', 'mdmm_audio_fwd', 'mdmm_audio_bwd',
     'mdmm_colsum_splits', 'mdmm_colsum',
     'mdmm_vrnn_layout', 'mdmm_vrnn_supported', 'mdmm_vrnn_fwd', 'mdmm_vrnn_bwd',
     'mdmm_collate_pad', 'mdmm_delete_steps', 'mdmm_decollate_pack', 'mdmm_sqerr_steps', 'mdmm_time_avg', 'mdmm_time_acc',
@@ -190,6 +191,21 @@ class ConvF(C.Structure):
 
 class Conv1d(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB')] + [(n, _P) for n in ('small', 'big', 'weight', 'bias')])
+
+
+class AudioNorm(C.Structure):
+    _fields_ = [(n, _P) for n in ('mean', 'invstd', 'gamma', 'beta')] + [('group_n', C.c_int32), ('relu', C.c_int32)]
+
+
+class Audio(C.Structure):
+    """mdmm_audio_t: one layer of the audio plug-ins' stacks in training (csrc/audio_chain.hip)."""
+    _fields_ = ([(n, C.c_int32) for n in ('N', 'S', 'CS', 'CB', 'up', 'act_bf16')] +
+                [('weight', _P), ('bias', _P), ('in_', _P), ('in_norm', AudioNorm),
+                 ('in_frames', C.c_int32), ('in_relu_plain', C.c_int32), ('seen', _P), ('out', _P), ('out_stats', _P),
+                 ('out_group_n', C.c_int32), ('passes', C.c_int32), ('target', _P), ('row_mask', _P),
+                 ('fast', C.c_int32), ('loss_weight', C.c_float), ('pass_w', C.c_float * 8), ('loss', _P), ('gscale', _P),
+                 ('gout', _P), ('out_norm', AudioNorm), ('out_bwd_means', _P), ('gin', _P), ('in_adj', _P), ('ws', _P),
+                 ('dw', _P), ('dbias', _P)])
 
 
 VRNN_MAX_MODS = 4
@@ -367,6 +383,10 @@ def lib():
         L.mdmm_conv1d_wgrad_ws_bytes.argtypes = [C.POINTER(Conv1d)]
         L.mdmm_conv1d_wgrad_ws_bytes.restype = C.c_int64
         L.mdmm_conv1d_wgrad.argtypes = [C.POINTER(Conv1d), _P, _P, _P]
+        L.mdmm_audio_supported.argtypes = [C.POINTER(Audio)]
+        L.mdmm_audio_parts.argtypes = [C.POINTER(Audio)]
+        L.mdmm_audio_fwd.argtypes = [C.POINTER(Audio), _P]
+        L.mdmm_audio_bwd.argtypes = [C.POINTER(Audio), _P]
         L.mdmm_gemm_supported.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_split.argtypes = [C.POINTER(Gemm)]
         L.mdmm_gemm_colsum_a.argtypes = [C.POINTER(Gemm)]
@@ -396,7 +416,7 @@ def lib():
         L.mdmm_sizeof.argtypes = [C.c_int]
         L.mdmm_sizeof.restype = C.c_size_t
         for which, st in ((0, Gtf), (1, Expert), (2, Sweep), (4, Gru), (5, Dks), (6, Mlp), (7, Bn), (8, Conv),
-                          (9, FragLayers), (10, Gemm), (11, Conv1d), (12, Vrnn), (13, VrnnLayout), (14, SpillWgradBatch), (15, ConvF)):
+                          (9, FragLayers), (10, Gemm), (11, Conv1d), (12, Vrnn), (13, VrnnLayout), (14, SpillWgradBatch), (15, ConvF), (16, Audio)):
             if L.mdmm_sizeof(which) != C.sizeof(st):
                 raise MdmmError('struct %s: library %d bytes, binding %d bytes'
                                 % (st.__name__, L.mdmm_sizeof(which), C.sizeof(st)))

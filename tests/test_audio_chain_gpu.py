@@ -1,0 +1,194 @@
+"""-m gpu: the audio plug-ins' stacks as one autograd node each (mdmm.audio on csrc/audio_chain.hip, through the C ABI
+mdmm_audio_fwd / mdmm_audio_bwd) against the stock modules of the reference's plug-in classes run by plain PyTorch on
+the CPU in fp64 -- the same arithmetic the oracle's cfg5 model runs (bench.Cfg5.oracle builds it from these classes;
+reference: common.py:177-290, losses.py:23-42, dmm.py:164-177).  Values, every parameter gradient, the input gradient,
+the BatchNorm running statistics and the `seen` flags; fp32 activations tight, bf16 activations at bf16 bounds."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import helpers  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    return torch.device('cuda:0')
+
+
+def _models():
+    from mdmm.models import common
+    return common
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _decoder_reference(dec64, z, target, mask, passes, pass_w, weight):
+    """sum_p w_p * BCE(sum) of the stock module called pass by pass (dgts.py:132-145), fp64 on the CPU."""
+    rows = target.shape[0] * target.shape[1]
+    total = 0
+    zs = z.reshape(passes, rows, -1)
+    tg = target.reshape(rows, 10, 1281)
+    for p in range(passes):
+        probs = dec64(zs[p])[0]
+        on = mask.reshape(rows, 1, 1).bool() & ~torch.isnan(tg)
+        t0 = torch.where(on, tg, torch.zeros_like(tg))
+        term = F.binary_cross_entropy(probs, t0, reduction='none')
+        total = total + pass_w[p] * (term * on).sum()
+    return weight * total
+
+
+@pytest.mark.parametrize('act', ['fp32', 'bf16'])
+@pytest.mark.parametrize('passes', [1, 2])
+def test_audio_decoder_nll_node(act, passes, dev):
+    from mdmm import ops, audio
+    C = _models()
+    torch.manual_seed(3)
+    dec = C.AudioDecoder(32).to(dev).train()
+    with torch.no_grad():                       # (non-trivial affine parameters and running statistics)
+        for m in dec.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    ref = copy.deepcopy(dec).double().cpu().train()
+    t_max, b_dim = 5, 3
+    rows = t_max * b_dim
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(passes * rows, 32, generator=g)
+    target = torch.rand(t_max, b_dim, 10, 1281, generator=g)
+    target[3:, 1] = float('nan')                 # padding
+    target[1, 0, 2, 100:140] = float('nan')      # interior NaN: that element alone is unobserved
+    mask = torch.ones(t_max, b_dim)
+    mask[3:, 1] = 0
+    mask[4, 2] = 0                               # masked row with finite observations
+    pass_w = [0.5, 1.0][:passes]
+    weight = 0.7
+    bf16 = act == 'bf16'
+
+    zr = z.double().requires_grad_(True)
+    loss_ref = _decoder_reference(ref, zr, target.double(), mask.double(), passes, pass_w, weight)
+    up = 1.3
+    (up * loss_ref).backward()
+
+    zd = z.to(dev).requires_grad_(True)
+    total = ops.LossSum(dev)
+    with ops.conv_operands(torch.bfloat16 if bf16 else None, act=torch.bfloat16 if bf16 else torch.float32):
+        blocks = audio.decoder_plan(dec)
+        assert blocks is not None
+        dec.nll(zd, blocks, target.to(dev), mask.to(dev), weight, total, passes, pass_w, bf16)
+    loss = total.total()
+    (up * loss).backward()
+    torch.cuda.synchronize()
+
+    tol_v, tol_g = (3e-3, 6e-2) if bf16 else (2e-6, 3e-5)
+    assert abs(float(loss) - float(loss_ref)) < tol_v * abs(float(loss_ref)), (float(loss), float(loss_ref))
+    worst = {}
+    for (k, p), (_, q) in zip(dec.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        if 'deconv.bias' in k and 'deconv_stack.2' not in k:      # a bias in front of a BatchNorm: exactly zero
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        worst[k] = _rel(p.grad, q.grad)
+    worst['z'] = _rel(zd.grad, zr.grad)
+    for k, e in worst.items():
+        helpers.note('audio_dec[%s,%d].grad.%s' % (act, passes, k), e)
+    bad = {k: e for k, e in worst.items() if e > tol_g}
+    assert not bad, bad
+    # running statistics: updated pass by pass, as the stock module's calls would
+    for (k, b), (_, r) in zip(dec.named_buffers(), ref.named_buffers()):
+        if 'num_batches' in k:
+            assert int(b) == int(r) == passes, k
+        else:
+            assert _rel(b, r) < (2e-3 if bf16 else 1e-5), (k, _rel(b, r))
+
+
+@pytest.mark.parametrize('act', ['fp32', 'bf16'])
+def test_audio_encoder_node(act, dev):
+    from mdmm import ops, audio
+    C = _models()
+    torch.manual_seed(4)
+    enc = C.AudioEncoder(24).to(dev).train()
+    with torch.no_grad():
+        for m in enc.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    ref = copy.deepcopy(enc).double().cpu().train()
+    n = 11
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(n, 10, 1281, generator=g)
+    x[2] = float('nan')
+    x[5, 3, 7] = float('nan')
+    x[9, :, 1200:] = float('nan')
+    bf16 = act == 'bf16'
+    cm = torch.randn(n, 24, generator=g).double()
+    cs = torch.randn(n, 24, generator=g).double()
+
+    x0 = torch.where(torch.isnan(x), torch.zeros_like(x), x).double()
+    mean_r, std_r = ref(x0)
+    ((mean_r * cm).sum() + (std_r * cs).sum()).backward()
+    seen_r = ~torch.isnan(x).flatten(1).any(1)
+
+    with ops.conv_operands(torch.bfloat16 if bf16 else None, act=torch.bfloat16 if bf16 else torch.float32):
+        blocks = audio.encoder_plan(enc)
+        assert blocks is not None
+        mean, std, seen = enc.encode_frames(x.to(dev), blocks)
+    ((mean.double() * cm.to(dev)).sum() + (std.double() * cs.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(seen.cpu() > 0, seen_r)
+    tol_v, tol_g = (2e-2, 6e-2) if bf16 else (1e-5, 5e-5)
+    assert _rel(mean, mean_r) < tol_v and _rel(std, std_r) < tol_v, (_rel(mean, mean_r), _rel(std, std_r))
+    worst = {}
+    for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        if 'conv.bias' in k and 'conv_stack.2' not in k:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        worst[k] = _rel(p.grad, q.grad)
+    for k, e in worst.items():
+        helpers.note('audio_enc[%s].grad.%s' % (act, k), e)
+    bad = {k: e for k, e in worst.items() if e > tol_g}
+    assert not bad, bad
+    for (k, b), (_, r) in zip(enc.named_buffers(), ref.named_buffers()):
+        if 'num_batches' in k:
+            assert int(b) == int(r) == 1, k
+        else:
+            assert _rel(b, r) < (2e-3 if bf16 else 1e-5), (k, _rel(b, r))
+
+
+def test_audio_nodes_match_the_layer_by_layer_route(dev, monkeypatch):
+    """MDMM_AUDIO_FUSED=0 selects the route of models.common (csrc/conv1d.hip + batchnorm.hip + reduce.hip): the same
+    MultiDMM.step on a small vidTIMIT-shaped batch either way (fp32 operands: the two routes differ by summation order)."""
+    import bench
+    from mdmm import models
+    cfg = bench.CONFIGS['cfg5']
+    torch.manual_seed(0)
+    model = cfg.model(models, dev)
+    model.sweep_dtype = model.conv_dtype = model.act_dtype = torch.float32
+    x, tg, mask, lengths = cfg.batch(6, 3, 77, dev)
+    out = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('MDMM_AUDIO_FUSED', fused)
+        m2 = copy.deepcopy(model)
+        from mdmm.noise import PhiloxNoise
+        m2.noise = PhiloxNoise(seed=11)
+        loss = m2.step(x, mask, 1.0, cfg.rec, targets=tg, lengths=lengths, train_particles=3)
+        loss.backward()
+        torch.cuda.synchronize()
+        out[fused] = (float(loss), {k: p.grad.detach().clone() for k, p in m2.named_parameters() if p.grad is not None})
+    la, lb = out['1'][0], out['0'][0]
+    assert abs(la - lb) < 2e-6 * abs(lb), (la, lb)
+    for k, gb in out['0'][1].items():
+        ga = out['1'][1][k]
+        if float(gb.abs().max()) == 0.0:
+            assert float(ga.abs().max()) == 0.0, k
+            continue
+        assert _rel(ga, gb) < 2e-4, (k, _rel(ga, gb))
