@@ -933,10 +933,11 @@ int parts_for(const mdmm_audio_t* a, size_t lds) {
   if (per_cu < 1) per_cu = 1;
   // a workgroup strides the frames of ONE group at a time (the rows of the loss form): no more workgroups than a group has
   int groups = 1;
-  if (a->out_stats && a->out_group_n > 0 && a->N / a->out_group_n > groups) groups = a->N / a->out_group_n;
-  if (a->in_norm.mean && a->in_norm.group_n > 0 && a->N / a->in_norm.group_n > groups) groups = a->N / a->in_norm.group_n;
-  if (a->out_norm.mean && a->out_norm.group_n > 0 && a->N / a->out_norm.group_n > groups) groups = a->N / a->out_norm.group_n;
-  if (a->target && a->passes > groups) groups = a->passes;
+  // (from the integer fields alone: the caller sizes its slab buffers with mdmm_audio_parts before it has them to point at)
+  if (a->out_group_n > 0 && a->N / a->out_group_n > groups) groups = a->N / a->out_group_n;
+  if (a->in_norm.group_n > 0 && a->N / a->in_norm.group_n > groups) groups = a->N / a->in_norm.group_n;
+  if (a->out_norm.group_n > 0 && a->N / a->out_norm.group_n > groups) groups = a->N / a->out_norm.group_n;
+  if (a->passes > groups) groups = a->passes;
   const int units = a->N / groups > 0 ? a->N / groups : 1;
   const int g = 256 * per_cu;
   return units < g ? units : g;
