@@ -10,11 +10,14 @@
 //   up    big[cb][j]   = sum_{cs,k: j = 2l-1+k} small[cs][l] W[cs][cb][k]
 //   down  small[cs][l] = sum_{cb,k} big[cb][2l-1+k] W[cs][cb][k]
 //   wgrad dW[cs][cb][k] = sum_l small[cs][l] big[cb][2l-1+k]
-// One workgroup per frame at a time.  LDS images: the small side as rows of S + 1 floats (a zero behind each row), the
-// big side split into its odd and even positions (O[m] = big[2m+1] with a zero in front and behind, E[m] = big[2m]): every
-// read of the three products is unit-stride across the lanes.  Thread l owns small position l (up: outputs 2l, 2l + 1);
-// the weight gradient is dealt to tiles of 4 x (4|5) x 3 accumulators, the threads of a tile striding the positions.
-// Weights come through the scalar cache (uniform addresses, compile-time offsets): they cost no LDS bandwidth.
+// One workgroup per frame at a time, several workgroups per CU.  A frame's pieces (8 bytes per lane) are loaded into
+// REGISTERS one frame ahead: while frame n is computed from LDS, frame n + 1 is on its way (the first version staged,
+// waited and computed in turn and ran at a latency-bound 1-2 TB/s of its bytes).  LDS images: the small side as rows of
+// S + 1 floats (a zero behind each row), the big side split into odd and even positions (O[m] = big[2m+1] with a zero in
+// front and behind, E[m] = big[2m]): every read of the three products is unit-stride across the lanes.  Thread l owns small
+// position l (up: outputs 2l, 2l + 1); the weight gradient is dealt to tiles of 4 x (4|5) x 3 accumulators whose threads
+// stride PAIRS of positions (8-byte LDS reads).  The layer's weights sit in LDS in the order each product walks them
+// (16-byte broadcast reads, fully unrolled products).
 #include "mdmm_device.h"
 #include "../../include/mdmm_hip.h"
 #include "sweep_internal.h"
@@ -25,70 +28,83 @@ constexpr int NT = 256;
 constexpr int NWAVE = NT / 64;
 constexpr int MAXG = 8;
 
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float float2u_t __attribute__((ext_vector_type(2), aligned(4)));    // (a row of 1281 floats starts 4-byte aligned)
-// The layer's weights are read-only for the launch and every thread reads the same ones at compile-time offsets: through
-// the constant address space they come in by scalar loads (SGPRs as FMA operands), not as 120..384 vector registers.
-typedef const __attribute__((address_space(4))) float* wptr_t;
-__device__ __forceinline__ wptr_t as_const(const float* p) { return (wptr_t)(uintptr_t)p; }
 
 template <int CS_, int CB_, int S_> struct Shape {
   static constexpr int CS = CS_, CB = CB_, S = S_, LB = 2 * S_ - 1;
   static constexpr int NW = CS_ * CB_ * 3;
-  static constexpr int SP = S_ + 1;          // small-side LDS row
-  static constexpr int RB = 2 * (S_ + 1);    // big-side LDS row: O at [0, S] (O[m] at m + 1), E at [SP, SP + S)
+  static constexpr int SP = S_ + 1;          // small-side LDS row (even: pairs of positions are 8-byte aligned)
+  static constexpr int RB = 2 * (S_ + 1);    // big-side LDS row: O at [0, S] (O[m] at m + 1), E at [SP, SP + S), [RB - 1] = 0
+  static constexpr int WU = (3 * CB_ + 3) / 4 * 4;       // up product: per small channel its 3 CB weights, 16-byte rows
+  static constexpr int WD = 3 * CS_;                     // down product: per big channel its 3 CS weights
+  static constexpr int ITER = (S_ + NT - 1) / NT;        // positions per thread
   static constexpr int CBT = (CB_ % 4 == 0) ? 4 : 5;     // weight-gradient tile: 4 cs x CBT cb x 3 taps
   static constexpr int NTILE = (CS_ / 4) * (CB_ / CBT);
   static constexpr int TPT = NT / NTILE;     // threads per tile
   static constexpr int NA = 4 * CBT * 3;
   static_assert(CS_ % 4 == 0 && CB_ % CBT == 0 && NT % NTILE == 0, "tile split");
-  static_assert((CS_ * S_) % 4 == 0 && (CB_ * LB) % 2 == 0, "8-byte pieces");
+  static_assert((CS_ * S_) % 4 == 0 && (CB_ * LB) % 2 == 0 && SP % 2 == 0 && WD % 4 == 0, "8-byte pieces");
 };
 
-// ---- 8-byte pieces of a frame: four bf16 or two fp32 ---------------------------------------------------------------
-template <typename T> struct V8;
-template <> struct V8<float> {
-  static constexpr int N = 2;
-  static __device__ __forceinline__ void ld(const float* p, float (&v)[2]) {
-    const float2 u = *reinterpret_cast<const float2*>(p);
-    v[0] = u.x; v[1] = u.y;
-  }
-  static __device__ __forceinline__ void st(float* p, const float (&v)[2]) { *reinterpret_cast<float2*>(p) = float2{v[0], v[1]}; }
-};
-template <> struct V8<__bf16> {
-  static constexpr int N = 4;
-  static __device__ __forceinline__ void ld(const __bf16* p, float (&v)[4]) {
-    const bf16x4_t u = *reinterpret_cast<const bf16x4_t*>(p);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (float)u[j];
-  }
-  static __device__ __forceinline__ void st(__bf16* p, const float (&v)[4]) {
-    bf16x4_t u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) u[j] = (__bf16)v[j];
-    *reinterpret_cast<bf16x4_t*>(p) = u;
-  }
-};
 template <typename T> __device__ __forceinline__ float rnd(float v) { return (float)(T)v; }
+__host__ __device__ constexpr size_t align16(size_t b) { return (b + 15) & ~(size_t)15; }
+
+// ---- a frame's flat elements as 8-byte pieces (four bf16 or two fp32), piece q = k * NT + thread -------------------------
+template <typename T> struct V8 { static constexpr int N = sizeof(T) == 2 ? 4 : 2; };
+template <typename T> __device__ __forceinline__ void unpack(const uint2& u, float (&v)[V8<T>::N]) {
+  if constexpr (sizeof(T) == 2) {
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  } else {
+    v[0] = __uint_as_float(u.x); v[1] = __uint_as_float(u.y);
+  }
+}
+template <int NEL, typename T> struct Pieces {
+  static constexpr int VN = V8<T>::N, NP = NEL / VN, K = (NP + NT - 1) / NT;
+  static_assert(NEL % VN == 0, "whole pieces");
+  uint2 r[K];
+  template <int K0, int K1> __device__ __forceinline__ void load_part(const T* __restrict__ src) {
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+      const int q = k * NT + threadIdx.x;
+      if (k < K - 1 || q < NP) r[k] = *reinterpret_cast<const uint2*>(src + (size_t)q * VN);
+    }
+  }
+  __device__ __forceinline__ void load(const T* __restrict__ src) { load_part<0, K>(src); }
+};
+// (row, position) of a flat element: one division per walk, then steps by compile-time strides
+template <int ROW> struct Walk {
+  int c, p;
+  __device__ __forceinline__ explicit Walk(int e) { c = e / ROW; p = e - c * ROW; }
+  template <int STEP> __device__ __forceinline__ Walk stepped() const {
+    Walk w = *this;
+    w.c += STEP / ROW; w.p += STEP % ROW;
+    if (w.p >= ROW) { w.p -= ROW; ++w.c; }
+    return w;
+  }
+  __device__ __forceinline__ void inc() { if (++p == ROW) { p = 0; ++c; } }
+};
 
 // ---- per-(group, channel) tables in LDS ------------------------------------------------------------------------------
 // in-norm: y = max(0, fma(x, sc, sh)) with the two numbers formed as mdmm_bn_relu_fwd's apply pass forms them
 struct NormTab {
-  float sc[MAXG * 16], sh[MAXG * 16], mean[MAXG * 16], inv[MAXG * 16];
+  float2 ss[MAXG * 16];       // (sc, sh)
+  float2 mi[MAXG * 16];       // (mean, invstd)
 };
 // lazily applied BatchNorm adjoint: dx = k (g [fma(x, k, sh) > 0] - mg - xhat mgx)   (bn_bwd_apply_kernel)
 struct LazyTab {
-  float k[MAXG * 16], sh[MAXG * 16], mean[MAXG * 16], inv[MAXG * 16], mg[MAXG * 16], mgx[MAXG * 16];
+  float4 a[MAXG * 16];        // (k, sh, mean, invstd)
+  float2 m[MAXG * 16];        // (mg, mgx)
 };
-
 __device__ __forceinline__ void fill_norm(NormTab& t, const mdmm_audio_norm_t& nm, int C, int groups) {
   for (int i = threadIdx.x; i < groups * C; i += NT) {
     const int c = i % C;
     const float g = nm.gamma ? nm.gamma[c] : 1.0f, b = nm.beta ? nm.beta[c] : 0.0f;
     const float mean = nm.mean[i], inv = nm.invstd[i];
     const float sc = g * inv;
-    t.sc[i] = sc; t.sh[i] = fmaf(-mean, sc, b); t.mean[i] = mean; t.inv[i] = inv;
+    t.ss[i] = float2{sc, fmaf(-mean, sc, b)};
+    t.mi[i] = float2{mean, inv};
   }
 }
 __device__ __forceinline__ void fill_lazy(LazyTab& t, const mdmm_audio_norm_t& nm, const float* means, int C, int groups) {
@@ -97,163 +113,226 @@ __device__ __forceinline__ void fill_lazy(LazyTab& t, const mdmm_audio_norm_t& n
     const float g = nm.gamma ? nm.gamma[c] : 1.0f, b = nm.beta ? nm.beta[c] : 0.0f;
     const float mean = nm.mean[i], inv = nm.invstd[i];
     const float k = g * inv;
-    t.k[i] = k; t.sh[i] = fmaf(-mean, k, b); t.mean[i] = mean; t.inv[i] = inv;
-    t.mg[i] = means[2 * i]; t.mgx[i] = means[2 * i + 1];
+    t.a[i] = float4{k, fmaf(-mean, k, b), mean, inv};
+    t.m[i] = float2{means[2 * i], means[2 * i + 1]};
   }
 }
-
-// ---- staging ---------------------------------------------------------------------------------------------------------
-// small side (CS x S, flat in memory) -> rows of SP floats; NORM: normalised + ReLU, `raw` keeps what was read
-template <typename SH, typename T, bool NORM, bool RAW>
-__device__ __forceinline__ void stage_small(const T* __restrict__ src, float* dst, T* raw, const NormTab* t, int g, int relu) {
-  constexpr int VN = V8<T>::N;
-  for (int i = threadIdx.x * VN; i < SH::CS * SH::S; i += NT * VN) {
-    float v[VN];
-    V8<T>::ld(src + i, v);
-#pragma unroll
-    for (int j = 0; j < VN; ++j) {
-      const int e = i + j, c = e / SH::S, l = e - c * SH::S;
-      float x = v[j];
-      if (RAW) raw[e] = (T)x;
-      if (NORM) {
-        x = fmaf(x, t->sc[g * SH::CS + c], t->sh[g * SH::CS + c]);
-        if (relu) x = fmaxf(x, 0.f);
-      }
-      dst[c * SH::SP + l] = x;
-    }
-  }
+__device__ __forceinline__ float lazy_apply(const LazyTab* t, int q, float g, float y, int relu) {
+  const float4 a = t->a[q];
+  const float2 m = t->m[q];
+  const float xh = (y - a.z) * a.w;
+  const float gm = (relu && fmaf(y, a.x, a.y) <= 0.f) ? 0.f : g;
+  return a.x * (gm - m.x - xh * m.y);
 }
-// small-side GRADIENT with a BatchNorm adjoint still to apply: g = gradient of the normalised output, y = the pre-norm output
-template <typename SH, typename T, bool LAZY>
-__device__ __forceinline__ void stage_small_grad(const T* __restrict__ g, const T* __restrict__ y, float* dst, const LazyTab* t,
-                                                 int grp, int relu) {
-  constexpr int VN = V8<T>::N;
-  for (int i = threadIdx.x * VN; i < SH::CS * SH::S; i += NT * VN) {
-    float gv[VN], yv[VN];
-    V8<T>::ld(g + i, gv);
-    if (LAZY) V8<T>::ld(y + i, yv);
-#pragma unroll
-    for (int j = 0; j < VN; ++j) {
-      const int e = i + j, c = e / SH::S, l = e - c * SH::S;
-      float d = gv[j];
-      if (LAZY) {
-        const int q = grp * SH::CS + c;
-        const float xh = (yv[j] - t->mean[q]) * t->inv[q];
-        const float gm = (relu && fmaf(yv[j], t->k[q], t->sh[q]) <= 0.f) ? 0.f : d;
-        d = t->k[q] * (gm - t->mg[q] - xh * t->mgx[q]);
-      }
-      dst[c * SH::SP + l] = d;
-    }
+// the layer's weights into LDS: wu[cs][WU] = W[cs][.][.] as it is, wd[cb][cs][k] = W[cs][cb][k]
+template <typename SH>
+__device__ __forceinline__ void fill_weights(const float* __restrict__ w, float* wu, float* wd) {
+  for (int i = threadIdx.x; i < SH::NW; i += NT) {
+    const int cs = i / (SH::CB * 3), rest = i - cs * SH::CB * 3, cb = rest / 3, k = rest - cb * 3;
+    const float v = w[i];
+    if (wu) wu[cs * SH::WU + rest] = v;
+    if (wd) wd[cb * SH::WD + cs * 3 + k] = v;
   }
 }
 __device__ __forceinline__ int big_slot(int p, int SP) { return (p & 1) ? (p >> 1) + 1 : SP + (p >> 1); }
 
-// big side (CB x LB, flat) -> O / E rows.  FRAMES: fp32 frames with NaN = missing (zeros staged; returns "a NaN was seen")
-template <typename SH, typename T, bool NORM, bool RAW, bool FRAMES>
-__device__ __forceinline__ bool stage_big(const void* __restrict__ src_, float* dst, T* raw, const NormTab* t, int g, int relu) {
-  using TI = typename std::conditional<FRAMES, float, T>::type;
-  const TI* __restrict__ src = (const TI*)src_;
-  constexpr int VN = V8<TI>::N;
-  bool nan = false;
-  for (int i = threadIdx.x * VN; i < SH::CB * SH::LB; i += NT * VN) {
-    float v[VN];
-    V8<TI>::ld(src + i, v);
+// The (row, position) walks below are the same for every frame: left to itself the optimiser hoists them out of the
+// frame loop and they sit in registers (two per element, ~100 for the 26 pieces per thread of a 51 KB frame, ~70 in a
+// backward launch's three small images) at the price of a wave per SIMD or of scratch.  An opaque copy of the thread
+// index keeps them inside the loop: a few dozen integer operations per frame.
+__device__ __forceinline__ int opaque_tid() {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  return tid;
+}
+
+// ---- registers -> LDS images -----------------------------------------------------------------------------------------
+// small side (CS x S): rows of SP floats; NORM: normalised + ReLU; RAW: the pieces as they came, flat, beside it
+template <typename SH, typename T, bool NORM, bool RAW>
+__device__ __forceinline__ void put_small(const Pieces<SH::CS * SH::S, T>& f, float* dst, T* raw, const NormTab* t, int g, int relu) {
+  using P = Pieces<SH::CS * SH::S, T>;
+  Walk<SH::S> w0(opaque_tid() * P::VN);
 #pragma unroll
-    for (int j = 0; j < VN; ++j) {
-      const int e = i + j, c = e / SH::LB, p = e - c * SH::LB;
-      float x = v[j];
-      if (FRAMES) { if (x != x) { nan = true; x = 0.f; } }
-      if (RAW) raw[e] = (T)x;
-      if (NORM) {
-        x = fmaf(x, t->sc[g * SH::CB + c], t->sh[g * SH::CB + c]);
-        if (relu) x = fmaxf(x, 0.f);
+  for (int k = 0; k < P::K; ++k) {
+    const int q = k * NT + threadIdx.x;
+    if (k < P::K - 1 || q < P::NP) {
+      float v[P::VN];
+      unpack<T>(f.r[k], v);
+      if (RAW) *reinterpret_cast<uint2*>(raw + q * P::VN) = f.r[k];
+      Walk<SH::S> w = w0;
+#pragma unroll
+      for (int j = 0; j < P::VN; ++j) {
+        float x = v[j];
+        if (NORM) {
+          const float2 s = t->ss[g * SH::CS + w.c];
+          x = fmaf(x, s.x, s.y);
+          if (relu) x = fmaxf(x, 0.f);
+        }
+        dst[w.c * SH::SP + w.p] = x;
+        w.inc();
       }
-      dst[c * SH::RB + big_slot(p, SH::SP)] = x;
     }
+    w0 = w0.template stepped<NT * P::VN>();
+  }
+}
+// small-side GRADIENT; LAZY: a BatchNorm adjoint still to apply (fg = gradient of the normalised output, fy = the pre-norm output)
+template <typename SH, typename T, bool LAZY>
+__device__ __forceinline__ void put_small_grad(const Pieces<SH::CS * SH::S, T>& fg, const Pieces<SH::CS * SH::S, T>& fy, float* dst,
+                                               const LazyTab* t, int grp, int relu) {
+  using P = Pieces<SH::CS * SH::S, T>;
+  Walk<SH::S> w0(opaque_tid() * P::VN);
+#pragma unroll
+  for (int k = 0; k < P::K; ++k) {
+    const int q = k * NT + threadIdx.x;
+    if (k < P::K - 1 || q < P::NP) {
+      float gv[P::VN], yv[P::VN];
+      unpack<T>(fg.r[k], gv);
+      if (LAZY) unpack<T>(fy.r[k], yv);
+      Walk<SH::S> w = w0;
+#pragma unroll
+      for (int j = 0; j < P::VN; ++j) {
+        dst[w.c * SH::SP + w.p] = LAZY ? lazy_apply(t, grp * SH::CS + w.c, gv[j], yv[j], relu) : gv[j];
+        w.inc();
+      }
+    }
+    w0 = w0.template stepped<NT * P::VN>();
+  }
+}
+// big side (CB x LB) -> O / E rows.  FRAMES: fp32 frames with NaN = missing (zeros staged; returns "a NaN was seen")
+template <typename SH, typename TI, typename T, bool NORM, bool RAW, bool FRAMES, int K0 = 0, int K1 = Pieces<SH::CB * SH::LB, TI>::K>
+__device__ __forceinline__ bool put_big(const Pieces<SH::CB * SH::LB, TI>& f, float* dst, T* raw, const NormTab* t, int g, int relu) {
+  using P = Pieces<SH::CB * SH::LB, TI>;
+  bool nan = false;
+  Walk<SH::LB> w0((K0 * NT + opaque_tid()) * P::VN);
+#pragma unroll
+  for (int k = K0; k < K1; ++k) {
+    const int q = k * NT + threadIdx.x;
+    if (k < P::K - 1 || q < P::NP) {
+      float v[P::VN];
+      unpack<TI>(f.r[k], v);
+      if (RAW) *reinterpret_cast<uint2*>(raw + q * P::VN) = f.r[k];
+      Walk<SH::LB> w = w0;
+#pragma unroll
+      for (int j = 0; j < P::VN; ++j) {
+        float x = v[j];
+        if (FRAMES) { if (x != x) { nan = true; x = 0.f; } }
+        if (NORM) {
+          const float2 s = t->ss[g * SH::CB + w.c];
+          x = fmaf(x, s.x, s.y);
+          if (relu) x = fmaxf(x, 0.f);
+        }
+        dst[w.c * SH::RB + big_slot(w.p, SH::SP)] = x;
+        w.inc();
+      }
+    }
+    w0 = w0.template stepped<NT * P::VN>();
   }
   return nan;
 }
 template <typename SH, typename T, bool LAZY>
-__device__ __forceinline__ void stage_big_grad(const T* __restrict__ g, const T* __restrict__ y, float* dst, const LazyTab* t,
-                                               int grp, int relu) {
-  constexpr int VN = V8<T>::N;
-  for (int i = threadIdx.x * VN; i < SH::CB * SH::LB; i += NT * VN) {
-    float gv[VN], yv[VN];
-    V8<T>::ld(g + i, gv);
-    if (LAZY) V8<T>::ld(y + i, yv);
+__device__ __forceinline__ void put_big_grad(const Pieces<SH::CB * SH::LB, T>& fg, const Pieces<SH::CB * SH::LB, T>& fy, float* dst,
+                                             const LazyTab* t, int grp, int relu) {
+  using P = Pieces<SH::CB * SH::LB, T>;
+  Walk<SH::LB> w0(opaque_tid() * P::VN);
 #pragma unroll
-    for (int j = 0; j < VN; ++j) {
-      const int e = i + j, c = e / SH::LB, p = e - c * SH::LB;
-      float d = gv[j];
-      if (LAZY) {
-        const int q = grp * SH::CB + c;
-        const float xh = (yv[j] - t->mean[q]) * t->inv[q];
-        const float gm = (relu && fmaf(yv[j], t->k[q], t->sh[q]) <= 0.f) ? 0.f : d;
-        d = t->k[q] * (gm - t->mg[q] - xh * t->mgx[q]);
+  for (int k = 0; k < P::K; ++k) {
+    const int q = k * NT + threadIdx.x;
+    if (k < P::K - 1 || q < P::NP) {
+      float gv[P::VN], yv[P::VN];
+      unpack<T>(fg.r[k], gv);
+      if (LAZY) unpack<T>(fy.r[k], yv);
+      Walk<SH::LB> w = w0;
+#pragma unroll
+      for (int j = 0; j < P::VN; ++j) {
+        dst[w.c * SH::RB + big_slot(w.p, SH::SP)] = LAZY ? lazy_apply(t, grp * SH::CB + w.c, gv[j], yv[j], relu) : gv[j];
+        w.inc();
       }
-      dst[c * SH::RB + big_slot(p, SH::SP)] = d;
     }
+    w0 = w0.template stepped<NT * P::VN>();
+  }
+}
+// a frame's own layout in LDS (what a launch stores: rounded, flat) -> memory, piece by piece
+template <int NEL, typename T>
+__device__ __forceinline__ void copy_out(const T* ob, T* __restrict__ dst) {
+  using P = Pieces<NEL, T>;
+#pragma unroll
+  for (int k = 0; k < P::K; ++k) {
+    const int q = k * NT + threadIdx.x;
+    if (k < P::K - 1 || q < P::NP) *reinterpret_cast<uint2*>(dst + (size_t)q * P::VN) = *reinterpret_cast<const uint2*>(ob + q * P::VN);
+  }
+}
+template <int NEL, typename T> __device__ __forceinline__ void zero_frame(T* __restrict__ dst) {
+  using P = Pieces<NEL, T>;
+#pragma unroll
+  for (int k = 0; k < P::K; ++k) {
+    const int q = k * NT + threadIdx.x;
+    if (k < P::K - 1 || q < P::NP) *reinterpret_cast<uint2*>(dst + (size_t)q * P::VN) = uint2{0u, 0u};
   }
 }
 
 // ---- the three products ----------------------------------------------------------------------------------------------
-// ev[cb] = big[cb][2l], od[cb] = big[cb][2l + 1] from small rows sm (zero at [S])
+// ev[cb] += big[cb][2l], od[cb] += big[cb][2l + 1] from small rows sm (zero at [S]); wu: LDS, [cs][WU]
 template <typename SH>
-__device__ __forceinline__ void up_core(const float* sm, wptr_t w, int l, float (&ev)[SH::CB], float (&od)[SH::CB]) {
-  // (a real loop over the input channels: one channel's 3 CB weights are live at a time)
-#pragma nounroll
+__device__ __forceinline__ void up_core(const float* sm, const float* wu, int l, float (&ev)[SH::CB], float (&od)[SH::CB]) {
+  // (a real loop over the input channels, two per trip: unrolled whole, the scheduler hoists every weight read of the
+  //  product to its top and spills the registers they land in)
+#pragma unroll 2
   for (int cs = 0; cs < SH::CS; ++cs) {
     const float x0 = sm[cs * SH::SP + l], x1 = sm[cs * SH::SP + l + 1];
-    wptr_t wc = w + cs * SH::CB * 3;
 #pragma unroll
     for (int cb = 0; cb < SH::CB; ++cb) {
-      wptr_t wq = wc + cb * 3;
+      const float* wq = wu + cs * SH::WU + cb * 3;
       ev[cb] = fmaf(x0, wq[1], ev[cb]);
       od[cb] = fmaf(x1, wq[0], fmaf(x0, wq[2], od[cb]));
     }
   }
 }
-// out[cs] = small[cs][l] from the O / E rows
+// out[cs] += small[cs][l] from the O / E rows; wd: LDS, [cb][cs][3]
 template <typename SH>
-__device__ __forceinline__ void down_core(const float* bg, wptr_t w, int l, float (&out)[SH::CS]) {
-#pragma nounroll
+__device__ __forceinline__ void down_core(const float* bg, const float* wd, int l, float (&out)[SH::CS]) {
+#pragma unroll 2
   for (int cb = 0; cb < SH::CB; ++cb) {
-    const float v0 = bg[cb * SH::RB + l], v1 = bg[cb * SH::RB + SH::SP + l], v2 = bg[cb * SH::RB + l + 1];
-    wptr_t wc = w + cb * 3;
+    const float v0 = bg[cb * SH::RB + l], v2 = bg[cb * SH::RB + l + 1], v1 = bg[cb * SH::RB + SH::SP + l];
 #pragma unroll
     for (int cs = 0; cs < SH::CS; ++cs) {
-      wptr_t wq = wc + cs * SH::CB * 3;
+      const float* wq = wd + cb * SH::WD + cs * 3;
       out[cs] = fmaf(v0, wq[0], fmaf(v1, wq[1], fmaf(v2, wq[2], out[cs])));
     }
   }
 }
-// weight-gradient tile of this thread over the frame in LDS; accb (BIAS_S): sums of the small side's rows of the tile
+// weight-gradient tile of this thread over the frame in LDS, two positions per step (the odd S's last pair ends in the
+// small rows' zero); accb (BIAS_S): sums of the small side's rows of the tile
 template <typename SH, bool BIAS_S>
 __device__ __forceinline__ void wgrad_tile(const float* sm, const float* bg, float (&acc)[SH::NA], float (&accb)[4]) {
   const int q = threadIdx.x / SH::TPT, u = threadIdx.x - q * SH::TPT;
   const int cs0 = (q / (SH::CB / SH::CBT)) * 4, cb0 = (q % (SH::CB / SH::CBT)) * SH::CBT;
-  for (int l = u; l < SH::S; l += SH::TPT) {
-    float x[4];
+  constexpr int NPAIR = (SH::S + 1) / 2;
+  for (int m = u; m < NPAIR; m += SH::TPT) {
+    const int l = 2 * m;
+    float2 x[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = sm[(cs0 + i) * SH::SP + l];
+    for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const float2*>(sm + (cs0 + i) * SH::SP + l);
     if (BIAS_S && cb0 == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) accb[i] += x[i];
+      for (int i = 0; i < 4; ++i) accb[i] += x[i].x + x[i].y;
     }
 #pragma unroll
     for (int j = 0; j < SH::CBT; ++j) {
       const float* row = bg + (cb0 + j) * SH::RB;
-      const float v0 = row[l], v1 = row[SH::SP + l], v2 = row[l + 1];
+      const float2 o01 = *reinterpret_cast<const float2*>(row + l);          // O[l-1], O[l]
+      const float o2 = row[l + 2];                                           // O[l+1]
+      const float2 e01 = *reinterpret_cast<const float2*>(row + SH::SP + l); // E[l], E[l+1]
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        acc[(i * SH::CBT + j) * 3 + 0] = fmaf(x[i], v0, acc[(i * SH::CBT + j) * 3 + 0]);
-        acc[(i * SH::CBT + j) * 3 + 1] = fmaf(x[i], v1, acc[(i * SH::CBT + j) * 3 + 1]);
-        acc[(i * SH::CBT + j) * 3 + 2] = fmaf(x[i], v2, acc[(i * SH::CBT + j) * 3 + 2]);
+        float* a3 = acc + (i * SH::CBT + j) * 3;
+        a3[0] = fmaf(x[i].x, o01.x, fmaf(x[i].y, o01.y, a3[0]));
+        a3[1] = fmaf(x[i].x, e01.x, fmaf(x[i].y, e01.y, a3[1]));
+        a3[2] = fmaf(x[i].x, o01.y, fmaf(x[i].y, o2, a3[2]));
       }
     }
   }
 }
-// the tiles' sums over their threads -> this workgroup's slab ws[NW (+ bias...)]; red: NWAVE * (NA + 4) floats of LDS
+// the tiles' sums over their threads -> this workgroup's slab ws[NW | bias]; red: NWAVE * (NA + 4) floats of LDS
 template <typename SH, bool BIAS_S>
 __device__ __forceinline__ void wgrad_flush(float (&acc)[SH::NA], float (&accb)[4], float* red, float* slab) {
   constexpr int SPAN = SH::TPT < 64 ? SH::TPT : 64;      // lanes of one wave that share a tile
@@ -309,7 +388,7 @@ __device__ __forceinline__ void wgrad_flush(float (&acc)[SH::NA], float (&accb)[
   }
 }
 
-// per-channel pairs of fp32 partial sums of every thread -> one double pair per channel in `dst[c * stride * 2 + {0,1}]`
+// per-channel pairs of fp32 partial sums of every thread -> one double pair per channel in dst[c * stride * 2 + {0,1}]
 template <int C>
 __device__ __forceinline__ void block_pairs(const float (&s1)[C], const float (&s2)[C], double* red, double* dst, size_t stride) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -327,7 +406,6 @@ __device__ __forceinline__ void block_pairs(const float (&s1)[C], const float (&
     dst[(size_t)c * stride * 2 + h] = s;
   }
 }
-
 __device__ __forceinline__ void block_add_d(double v, double* red, double* out) {
   v = mdmm::wave_sum_d(v);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -340,7 +418,6 @@ __device__ __forceinline__ void block_add_d(double v, double* red, double* out) 
     atomicAdd(out, s);
   }
 }
-
 // per-channel fp32 sums of every thread -> dst[c] (one workgroup's slab entry)
 template <int C>
 __device__ __forceinline__ void block_sums(const float (&v)[C], float* red, float* dst) {
@@ -372,156 +449,180 @@ template <bool FAST> __device__ __forceinline__ float bce_grad(float l, float x,
   float g = scale * (th - x) / fmaxf((1.0f - th) * th, 1e-12f);
   return g * ((1.0f - th) * th);
 }
-
-// the observations of outputs 2l and 2l + 1 of every channel (the last position has no odd output: NaN = not scored)
+// the observations of outputs 2l and 2l + 1 of every channel for the thread's positions, kept in registers over the passes
+// that score the same row (the last position has no odd output: NaN = not scored; a position past the row: both NaN)
 template <typename SH>
-__device__ __forceinline__ void load_targets(const float* __restrict__ xr, int l, bool last, float (&x0)[SH::CB], float (&x1)[SH::CB]) {
-  if (!last) {
+__device__ __forceinline__ void load_targets(const float* __restrict__ xr, float (&x0)[SH::ITER][SH::CB], float (&x1)[SH::ITER][SH::CB]) {
 #pragma unroll
-    for (int cb = 0; cb < SH::CB; ++cb) {
-      const float2u_t v = *reinterpret_cast<const float2u_t*>(xr + cb * SH::LB + 2 * l);
-      x0[cb] = v[0]; x1[cb] = v[1];
+  for (int it = 0; it < SH::ITER; ++it) {
+    const int l = it * NT + threadIdx.x;
+    if (l < SH::S - 1) {
+#pragma unroll
+      for (int cb = 0; cb < SH::CB; ++cb) {
+        const float2u_t v = *reinterpret_cast<const float2u_t*>(xr + cb * SH::LB + 2 * l);
+        x0[it][cb] = v[0]; x1[it][cb] = v[1];
+      }
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < SH::CB; ++cb) {
+        x0[it][cb] = (l == SH::S - 1) ? xr[cb * SH::LB + 2 * l] : __builtin_nanf("");
+        x1[it][cb] = __builtin_nanf("");
+      }
     }
-  } else {
-#pragma unroll
-    for (int cb = 0; cb < SH::CB; ++cb) { x0[cb] = xr[cb * SH::LB + 2 * l]; x1[cb] = __builtin_nanf(""); }
   }
 }
-
-// ---- copies between LDS staging and the frames in memory -------------------------------------------------------------
-// ob: [CS * S] of T, the frame's own layout
-template <typename SH, typename T>
-__device__ __forceinline__ void copy_out_small(const T* ob, T* __restrict__ dst) {
-  constexpr int VN = V8<T>::N;
-  for (int i = threadIdx.x * VN; i < SH::CS * SH::S; i += NT * VN) {
-    if (sizeof(T) == 2) *reinterpret_cast<uint2*>(dst + i) = *reinterpret_cast<const uint2*>(ob + i);
-    else *reinterpret_cast<float2*>(dst + i) = *reinterpret_cast<const float2*>(ob + i);
+__device__ __forceinline__ int next_unmasked(int r, int step, int rows, const float* __restrict__ mask) {
+  if (mask) {
+    while (r < rows && mask[r] == 0.f) r += step;
   }
+  return r;
 }
-// ob: [CB][2 S] of T (rows padded by one so that the pairs (2l, 2l + 1) are aligned)
-template <typename SH, typename T>
-__device__ __forceinline__ void copy_out_big(const T* ob, T* __restrict__ dst) {
-  constexpr int VN = V8<T>::N;
-  for (int i = threadIdx.x * VN; i < SH::CB * SH::LB; i += NT * VN) {
-    float v[VN];
-#pragma unroll
-    for (int j = 0; j < VN; ++j) {
-      const int e = i + j, c = e / SH::LB, p = e - c * SH::LB;
-      v[j] = (float)ob[c * 2 * SH::S + p];
-    }
-    V8<T>::st(dst + i, v);
-  }
-}
-template <typename T> __device__ __forceinline__ void put_pair(T* ob, int at, float a, float b);
-template <> __device__ __forceinline__ void put_pair<float>(float* ob, int at, float a, float b) {
-  *reinterpret_cast<float2*>(ob + at) = float2{a, b};
-}
-template <> __device__ __forceinline__ void put_pair<__bf16>(__bf16* ob, int at, float a, float b) {
-  bf16x2_t u; u[0] = (__bf16)a; u[1] = (__bf16)b;
-  *reinterpret_cast<bf16x2_t*>(ob + at) = u;
-}
-template <typename T> __device__ __forceinline__ void zero_frame(T* __restrict__ dst, int n_el) {
-  constexpr int VN = V8<T>::N;
-  float z[VN];
-#pragma unroll
-  for (int j = 0; j < VN; ++j) z[j] = 0.f;
-  for (int i = threadIdx.x * VN; i < n_el; i += NT * VN) V8<T>::st(dst + i, z);
-}
-
-__host__ __device__ constexpr size_t align16(size_t b) { return (b + 15) & ~(size_t)15; }
 
 // =====================================================================================================================
-// up, forward: small -> big (+ statistics of what is stored), or small -> logits -> loss
+// up, forward: small -> big (+ statistics of what is stored)
 // =====================================================================================================================
 template <typename SH, typename T> struct UpFwdLds {
   static constexpr size_t a_off = 0;
-  static constexpr size_t tab_off = align16(a_off + sizeof(float) * SH::CS * SH::SP);
+  static constexpr size_t wu_off = align16(a_off + sizeof(float) * SH::CS * SH::SP);
+  static constexpr size_t tab_off = align16(wu_off + sizeof(float) * SH::CS * SH::WU);
   static constexpr size_t ob_off = align16(tab_off + sizeof(NormTab));
-  static constexpr size_t red_off = align16(ob_off + sizeof(T) * SH::CB * 2 * SH::S);
+  static constexpr size_t red_off = align16(ob_off + sizeof(T) * SH::CB * SH::LB);
   static constexpr size_t bytes = red_off + sizeof(double) * NWAVE * SH::CB * 2;
 };
 
-template <typename SH, typename T, bool LOSS, bool FAST>
-__global__ __launch_bounds__(NT) void audio_up_fwd_kernel(const mdmm_audio_t a) {
+template <typename SH, typename T>
+__global__ __launch_bounds__(NT, 4) void audio_up_fwd_kernel(const mdmm_audio_t a) {
   extern __shared__ float4 lds4[];
   char* lds = (char*)lds4;
   using L = UpFwdLds<SH, T>;
   float* as = (float*)(lds + L::a_off);
+  float* wu = (float*)(lds + L::wu_off);
   NormTab* tab = (NormTab*)(lds + L::tab_off);
   T* ob = (T*)(lds + L::ob_off);
   double* red = (double*)(lds + L::red_off);
   const bool norm = a.in_norm.mean != nullptr;
   const int relu = a.in_norm.relu;
   if (norm) fill_norm(*tab, a.in_norm, SH::CS, a.N / a.in_norm.group_n);
+  fill_weights<SH>(a.weight, wu, nullptr);
   for (int c = threadIdx.x; c < SH::CS; c += NT) as[c * SH::SP + SH::S] = 0.f;
   __syncthreads();
-  wptr_t w = as_const(a.weight);
   const T* __restrict__ in = (const T*)a.in;
-
-  if constexpr (LOSS) {
-    const int rows = a.N / a.passes;
-    float acc = 0.f;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-      if (a.row_mask && a.row_mask[r] == 0.f) continue;
-      const float* __restrict__ xr = a.target + (size_t)r * SH::CB * SH::LB;
-      for (int p = 0; p < a.passes; ++p) {
-        const int n = p * rows + r;
-        if (norm) stage_small<SH, T, true, false>(in + (size_t)n * SH::CS * SH::S, as, nullptr, tab, n / a.in_norm.group_n, relu);
-        else stage_small<SH, T, false, false>(in + (size_t)n * SH::CS * SH::S, as, nullptr, tab, 0, 0);
-        __syncthreads();
-        float t = 0.f;
-        for (int l = threadIdx.x; l < SH::S; l += NT) {
-          float x0[SH::CB], x1[SH::CB];
-          const bool last = l == SH::S - 1;
-          load_targets<SH>(xr, l, last, x0, x1);
+  T* __restrict__ out = (T*)a.out;
+  constexpr int IN_EL = SH::CS * SH::S, OUT_EL = SH::CB * SH::LB;
+  float bias[SH::CB];
+#pragma unroll
+  for (int cb = 0; cb < SH::CB; ++cb) bias[cb] = a.bias ? a.bias[cb] : 0.f;
+  const int out_gn = a.out_stats ? a.out_group_n : a.N;
+  const int groups = a.N / out_gn;
+  Pieces<IN_EL, T> fa;
+  for (int g = 0; g < groups; ++g) {
+    float s1[SH::CB], s2[SH::CB];
+#pragma unroll
+    for (int cb = 0; cb < SH::CB; ++cb) { s1[cb] = 0.f; s2[cb] = 0.f; }
+    const int end = (g + 1) * out_gn;
+    int n = g * out_gn + blockIdx.x;
+    if (n < end) fa.load(in + (size_t)n * IN_EL);
+    while (n < end) {
+      const int nn = n + gridDim.x;
+      if (norm) put_small<SH, T, true, false>(fa, as, nullptr, tab, n / a.in_norm.group_n, relu);
+      else put_small<SH, T, false, false>(fa, as, nullptr, tab, 0, 0);
+      if (nn < end) fa.load(in + (size_t)nn * IN_EL);
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < SH::ITER; ++it) {
+        const int l = it * NT + threadIdx.x;
+        if (l < SH::S) {
           float ev[SH::CB], od[SH::CB];
 #pragma unroll
-          for (int cb = 0; cb < SH::CB; ++cb) { ev[cb] = a.bias ? a.bias[cb] : 0.f; od[cb] = ev[cb]; }
-          up_core<SH>(as, w, l, ev, od);
-#pragma unroll
-          for (int cb = 0; cb < SH::CB; ++cb) {
-            if (x0[cb] == x0[cb]) t += bce_loss<FAST>(ev[cb], x0[cb]);
-            if (x1[cb] == x1[cb]) t += bce_loss<FAST>(od[cb], x1[cb]);
-          }
-        }
-        acc += a.pass_w[p & 7] * t;
-        __syncthreads();
-      }
-    }
-    block_add_d((double)a.loss_weight * (double)acc, red, a.loss);
-  } else {
-    T* __restrict__ out = (T*)a.out;
-    const int out_gn = a.out_stats ? a.out_group_n : a.N;
-    const int groups = a.N / out_gn;
-    for (int g = 0; g < groups; ++g) {
-      float s1[SH::CB], s2[SH::CB];
-#pragma unroll
-      for (int cb = 0; cb < SH::CB; ++cb) { s1[cb] = 0.f; s2[cb] = 0.f; }
-      for (int n = g * out_gn + blockIdx.x; n < (g + 1) * out_gn; n += gridDim.x) {
-        if (norm) stage_small<SH, T, true, false>(in + (size_t)n * SH::CS * SH::S, as, nullptr, tab, n / a.in_norm.group_n, relu);
-        else stage_small<SH, T, false, false>(in + (size_t)n * SH::CS * SH::S, as, nullptr, tab, 0, 0);
-        __syncthreads();
-        for (int l = threadIdx.x; l < SH::S; l += NT) {
-          float ev[SH::CB], od[SH::CB];
-#pragma unroll
-          for (int cb = 0; cb < SH::CB; ++cb) { ev[cb] = a.bias ? a.bias[cb] : 0.f; od[cb] = ev[cb]; }
-          up_core<SH>(as, w, l, ev, od);
+          for (int cb = 0; cb < SH::CB; ++cb) { ev[cb] = bias[cb]; od[cb] = bias[cb]; }
+          up_core<SH>(as, wu, l, ev, od);
           const bool last = l == SH::S - 1;
 #pragma unroll
           for (int cb = 0; cb < SH::CB; ++cb) {
             const float e = rnd<T>(ev[cb]), o = last ? 0.f : rnd<T>(od[cb]);
             s1[cb] += e + o;
             s2[cb] = fmaf(e, e, fmaf(o, o, s2[cb]));
-            put_pair<T>(ob, cb * 2 * SH::S + 2 * l, e, o);
+            ob[cb * SH::LB + 2 * l] = (T)e;
+            if (!last) ob[cb * SH::LB + 2 * l + 1] = (T)o;
           }
         }
-        __syncthreads();
-        copy_out_big<SH, T>(ob, out + (size_t)n * SH::CB * SH::LB);
       }
-      if (a.out_stats)
-        block_pairs<SH::CB>(s1, s2, red, a.out_stats + ((size_t)g * SH::CB * gridDim.x + blockIdx.x) * 2, gridDim.x);
+      __syncthreads();
+      copy_out<OUT_EL, T>(ob, out + (size_t)n * OUT_EL);
+      n = nn;
     }
+    if (a.out_stats)
+      block_pairs<SH::CB>(s1, s2, red, a.out_stats + ((size_t)g * SH::CB * gridDim.x + blockIdx.x) * 2, gridDim.x);
   }
+}
+
+// =====================================================================================================================
+// up + Bernoulli loss, forward: small -> logits (registers) -> loss
+// =====================================================================================================================
+template <typename SH, typename T> struct LossFwdLds {
+  static constexpr size_t a_off = 0;
+  static constexpr size_t wu_off = align16(a_off + sizeof(float) * SH::CS * SH::SP);
+  static constexpr size_t tab_off = align16(wu_off + sizeof(float) * SH::CS * SH::WU);
+  static constexpr size_t red_off = align16(tab_off + sizeof(NormTab));
+  static constexpr size_t bytes = red_off + sizeof(double) * NWAVE * 2;
+};
+
+template <typename SH, typename T, bool FAST>
+__global__ __launch_bounds__(NT, 3) void audio_loss_fwd_kernel(const mdmm_audio_t a) {
+  extern __shared__ float4 lds4[];
+  char* lds = (char*)lds4;
+  using L = LossFwdLds<SH, T>;
+  float* as = (float*)(lds + L::a_off);
+  float* wu = (float*)(lds + L::wu_off);
+  NormTab* tab = (NormTab*)(lds + L::tab_off);
+  double* red = (double*)(lds + L::red_off);
+  const bool norm = a.in_norm.mean != nullptr;
+  const int relu = a.in_norm.relu;
+  if (norm) fill_norm(*tab, a.in_norm, SH::CS, a.passes);
+  fill_weights<SH>(a.weight, wu, nullptr);
+  for (int c = threadIdx.x; c < SH::CS; c += NT) as[c * SH::SP + SH::S] = 0.f;
+  __syncthreads();
+  const T* __restrict__ in = (const T*)a.in;
+  constexpr int IN_EL = SH::CS * SH::S, TG_EL = SH::CB * SH::LB;
+  float bias[SH::CB];
+#pragma unroll
+  for (int cb = 0; cb < SH::CB; ++cb) bias[cb] = a.bias ? a.bias[cb] : 0.f;
+  const int rows = a.N / a.passes, step = gridDim.x;
+  float x0[SH::ITER][SH::CB], x1[SH::ITER][SH::CB];
+  Pieces<IN_EL, T> fa;
+  float acc = 0.f;
+  int r = next_unmasked(blockIdx.x, step, rows, a.row_mask), p = 0;
+  if (r < rows) fa.load(in + (size_t)r * IN_EL);
+  while (r < rows) {
+    int pn = p + 1, rn = r;
+    if (pn == a.passes) { pn = 0; rn = next_unmasked(r + step, step, rows, a.row_mask); }
+    if (p == 0) load_targets<SH>(a.target + (size_t)r * TG_EL, x0, x1);
+    if (norm) put_small<SH, T, true, false>(fa, as, nullptr, tab, p, relu);
+    else put_small<SH, T, false, false>(fa, as, nullptr, tab, 0, 0);
+    if (rn < rows) fa.load(in + ((size_t)pn * rows + rn) * IN_EL);
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int it = 0; it < SH::ITER; ++it) {
+      const int l = it * NT + threadIdx.x;
+      if (l < SH::S) {
+        float ev[SH::CB], od[SH::CB];
+#pragma unroll
+        for (int cb = 0; cb < SH::CB; ++cb) { ev[cb] = bias[cb]; od[cb] = bias[cb]; }
+        up_core<SH>(as, wu, l, ev, od);
+#pragma unroll
+        for (int cb = 0; cb < SH::CB; ++cb) {
+          const float xe = x0[it][cb], xo = x1[it][cb];
+          if (xe == xe) t += bce_loss<FAST>(ev[cb], xe);
+          if (xo == xo) t += bce_loss<FAST>(od[cb], xo);
+        }
+      }
+    }
+    acc += a.pass_w[p & 7] * t;
+    __syncthreads();
+    r = rn; p = pn;
+  }
+  block_add_d((double)a.loss_weight * (double)acc, red, a.loss);
 }
 
 // =====================================================================================================================
@@ -532,7 +633,9 @@ template <typename SH, typename T> struct UpBwdLds {
   static constexpr size_t big_off = align16(a_off + sizeof(float) * SH::CS * SH::SP);
   static constexpr size_t raw_off = align16(big_off + sizeof(float) * SH::CB * SH::RB);
   static constexpr size_t gb_off = align16(raw_off + sizeof(T) * SH::CS * SH::S);
-  static constexpr size_t tab_off = align16(gb_off + sizeof(T) * SH::CS * SH::S);
+  static constexpr size_t wu_off = align16(gb_off + sizeof(T) * SH::CS * SH::S);
+  static constexpr size_t wd_off = align16(wu_off + sizeof(float) * SH::CS * SH::WU);
+  static constexpr size_t tab_off = align16(wd_off + sizeof(float) * SH::CB * SH::WD);
   static constexpr size_t lazy_off = align16(tab_off + sizeof(NormTab));
   static constexpr size_t adj_off = align16(lazy_off + sizeof(LazyTab));
   static constexpr size_t red_off = align16(adj_off + sizeof(float) * NWAVE * MAXG * 2 * SH::CS);
@@ -541,7 +644,8 @@ template <typename SH, typename T> struct UpBwdLds {
   static constexpr size_t bytes = red_off + (red_bytes_a > red_bytes_b ? red_bytes_a : red_bytes_b);
 };
 
-// the small-side gradient of position l from the O / E rows + what the epilogue needs: gs rounded as stored
+// one position's small-side gradient as the launch stores it, and -- NORM -- its part of the adjoint sums of the BatchNorm
+// in front of the layer (of the values as stored)
 template <typename SH, typename T, bool NORM>
 __device__ __forceinline__ void small_grad_epilogue(const float (&gs)[SH::CS], const float* as, const T* raw, const NormTab* tab,
                                                     int gi, int l, int relu_in, int relu_plain, T* gb,
@@ -553,9 +657,9 @@ __device__ __forceinline__ void small_grad_epilogue(const float (&gs)[SH::CS], c
     if (relu_plain && !(av > 0.f)) g = 0.f;
     const float gr = rnd<T>(g);
     if (NORM) {
-      const int q = gi * SH::CS + cs;
+      const float2 mi = tab->mi[gi * SH::CS + cs];
       const float gm = (relu_in && !(av > 0.f)) ? 0.f : gr;
-      const float xh = ((float)raw[cs * SH::S + l] - tab->mean[q]) * tab->inv[q];
+      const float xh = ((float)raw[cs * SH::S + l] - mi.x) * mi.y;
       s1[cs] += gm;
       s2[cs] = fmaf(gm, xh, s2[cs]);
     }
@@ -563,8 +667,8 @@ __device__ __forceinline__ void small_grad_epilogue(const float (&gs)[SH::CS], c
   }
 }
 
-template <typename SH, typename T, bool LOSS, bool FAST>
-__global__ __launch_bounds__(NT) void audio_up_bwd_kernel(const mdmm_audio_t a) {
+template <typename SH, typename T>
+__global__ __launch_bounds__(NT, 3) void audio_up_bwd_kernel(const mdmm_audio_t a) {
   extern __shared__ float4 lds4[];
   char* lds = (char*)lds4;
   using L = UpBwdLds<SH, T>;
@@ -572,9 +676,9 @@ __global__ __launch_bounds__(NT) void audio_up_bwd_kernel(const mdmm_audio_t a) 
   float* big = (float*)(lds + L::big_off);
   T* raw = (T*)(lds + L::raw_off);
   T* gb = (T*)(lds + L::gb_off);
+  float* wd = (float*)(lds + L::wd_off);
   NormTab* tab = (NormTab*)(lds + L::tab_off);
   LazyTab* lazy = (LazyTab*)(lds + L::lazy_off);
-  float* adjw = (float*)(lds + L::adj_off);
   double* redd = (double*)(lds + L::red_off);
   float* redf = (float*)(lds + L::red_off);
   const bool norm = a.in_norm.mean != nullptr;
@@ -582,190 +686,273 @@ __global__ __launch_bounds__(NT) void audio_up_bwd_kernel(const mdmm_audio_t a) 
   const int relu_in = a.in_norm.relu;
   if (norm) fill_norm(*tab, a.in_norm, SH::CS, a.N / a.in_norm.group_n);
   if (lz) fill_lazy(*lazy, a.out_norm, a.out_bwd_means, SH::CB, a.N / a.out_norm.group_n);
+  fill_weights<SH>(a.weight, nullptr, wd);
   for (int c = threadIdx.x; c < SH::CS; c += NT) as[c * SH::SP + SH::S] = 0.f;
-  for (int c = threadIdx.x; c < SH::CB; c += NT) { big[c * SH::RB] = 0.f; big[c * SH::RB + SH::S] = 0.f; }
-  for (int i = threadIdx.x; i < NWAVE * MAXG * 2 * SH::CS; i += NT) adjw[i] = 0.f;
+  for (int c = threadIdx.x; c < SH::CB; c += NT) { big[c * SH::RB] = 0.f; big[c * SH::RB + SH::S] = 0.f; big[c * SH::RB + SH::RB - 1] = 0.f; }
   __syncthreads();
-  wptr_t w = as_const(a.weight);
   const T* __restrict__ in = (const T*)a.in;
+  const T* __restrict__ gout = (const T*)a.gout;
+  const T* __restrict__ ypre = (const T*)a.out;
   T* __restrict__ gin = (T*)a.gin;
+  constexpr int IN_EL = SH::CS * SH::S, OUT_EL = SH::CB * SH::LB;
   float acc[SH::NA], accb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < SH::NA; ++i) acc[i] = 0.f;
   float* slab = a.ws + (size_t)blockIdx.x * (SH::NW + 16);
-  float db[SH::CB];                      // (the loss layer's bias gradient: sums of the logits' gradient per channel)
+  const int in_gn = (norm && a.in_adj) ? a.in_norm.group_n : a.N;
+  const int groups = a.N / in_gn;
+  Pieces<IN_EL, T> fa;
+  Pieces<OUT_EL, T> fg, fy;
+  for (int g = 0; g < groups; ++g) {
+    float s1[SH::CS], s2[SH::CS];
 #pragma unroll
-  for (int cb = 0; cb < SH::CB; ++cb) db[cb] = 0.f;
-
-  if constexpr (LOSS) {
-    const int rows = a.N / a.passes;
-    const float gsc = a.gscale ? *a.gscale : 1.0f;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-      const bool masked = a.row_mask && a.row_mask[r] == 0.f;
-      const float* __restrict__ xr = a.target + (size_t)r * SH::CB * SH::LB;
-      for (int p = 0; p < a.passes; ++p) {
-        const int n = p * rows + r;
-        if (masked) { zero_frame<T>(gin + (size_t)n * SH::CS * SH::S, SH::CS * SH::S); continue; }
-        const int gi = norm ? n / a.in_norm.group_n : 0;
-        if (norm) stage_small<SH, T, true, true>(in + (size_t)n * SH::CS * SH::S, as, raw, tab, gi, relu_in);
-        else stage_small<SH, T, false, false>(in + (size_t)n * SH::CS * SH::S, as, raw, tab, 0, 0);
-        __syncthreads();
-        const float sc = gsc * a.loss_weight * a.pass_w[p & 7];
-        for (int l = threadIdx.x; l < SH::S; l += NT) {
-          float x0[SH::CB], x1[SH::CB];
-          const bool last = l == SH::S - 1;
-          load_targets<SH>(xr, l, last, x0, x1);
-          float ev[SH::CB], od[SH::CB];
-#pragma unroll
-          for (int cb = 0; cb < SH::CB; ++cb) { ev[cb] = a.bias ? a.bias[cb] : 0.f; od[cb] = ev[cb]; }
-          up_core<SH>(as, w, l, ev, od);
-#pragma unroll
-          for (int cb = 0; cb < SH::CB; ++cb) {
-            const float de = (x0[cb] == x0[cb]) ? bce_grad<FAST>(ev[cb], x0[cb], sc) : 0.f;
-            const float dd = (x1[cb] == x1[cb]) ? bce_grad<FAST>(od[cb], x1[cb], sc) : 0.f;
-            db[cb] += de + dd;
-            big[cb * SH::RB + SH::SP + l] = de;
-            if (!last) big[cb * SH::RB + l + 1] = dd;
-          }
-        }
-        __syncthreads();
-        wgrad_tile<SH, false>(as, big, acc, accb);
-        float s1[SH::CS], s2[SH::CS];
-#pragma unroll
-        for (int cs = 0; cs < SH::CS; ++cs) { s1[cs] = 0.f; s2[cs] = 0.f; }
-        for (int l = threadIdx.x; l < SH::S; l += NT) {
-          float gs[SH::CS];
-#pragma unroll
-          for (int cs = 0; cs < SH::CS; ++cs) gs[cs] = 0.f;
-          down_core<SH>(big, w, l, gs);
-          if (norm) small_grad_epilogue<SH, T, true>(gs, as, raw, tab, gi, l, relu_in, a.in_relu_plain, gb, s1, s2);
-          else small_grad_epilogue<SH, T, false>(gs, as, raw, tab, gi, l, relu_in, a.in_relu_plain, gb, s1, s2);
-        }
-        if (norm && a.in_adj) {           // this frame's adjoint sums into the wave's own slots of its group (one writer each)
-          const int wv = threadIdx.x >> 6;
-#pragma unroll
-          for (int cs = 0; cs < SH::CS; ++cs) {
-            const float t1 = mdmm::wave_sum(s1[cs]), t2 = mdmm::wave_sum(s2[cs]);
-            if ((threadIdx.x & 63) == 0) {
-              adjw[((wv * MAXG + gi) * SH::CS + cs) * 2] += t1;
-              adjw[((wv * MAXG + gi) * SH::CS + cs) * 2 + 1] += t2;
-            }
-          }
-        }
-        __syncthreads();
-        copy_out_small<SH, T>(gb, gin + (size_t)n * SH::CS * SH::S);
-      }
+    for (int cs = 0; cs < SH::CS; ++cs) { s1[cs] = 0.f; s2[cs] = 0.f; }
+    const int end = (g + 1) * in_gn;
+    int n = g * in_gn + blockIdx.x;
+    if (n < end) {
+      fa.load(in + (size_t)n * IN_EL);
+      fg.load(gout + (size_t)n * OUT_EL);
+      if (lz) fy.load(ypre + (size_t)n * OUT_EL);
     }
-    __syncthreads();
-    if (norm && a.in_adj) {
-      const int groups = a.N / a.in_norm.group_n;
-      for (int o = threadIdx.x; o < groups * SH::CS * 2; o += NT) {
-        const int h = o & 1, c = (o >> 1) % SH::CS, g = (o >> 1) / SH::CS;
-        double s = 0;
-        for (int k = 0; k < NWAVE; ++k) s += (double)adjw[((k * MAXG + g) * SH::CS + c) * 2 + h];
-        a.in_adj[(((size_t)g * SH::CS + c) * gridDim.x + blockIdx.x) * 2 + h] = s;
+    while (n < end) {
+      const int nn = n + gridDim.x;
+      const int gi = norm ? n / a.in_norm.group_n : 0;
+      if (norm) put_small<SH, T, true, true>(fa, as, raw, tab, gi, relu_in);
+      else put_small<SH, T, false, false>(fa, as, raw, tab, 0, 0);
+      if (lz) put_big_grad<SH, T, true>(fg, fy, big, lazy, n / a.out_norm.group_n, a.out_norm.relu);
+      else put_big_grad<SH, T, false>(fg, fy, big, lazy, 0, 0);
+      if (nn < end) {
+        fa.load(in + (size_t)nn * IN_EL);
+        fg.load(gout + (size_t)nn * OUT_EL);
+        if (lz) fy.load(ypre + (size_t)nn * OUT_EL);
       }
-    }
-  } else {
-    const T* __restrict__ gout = (const T*)a.gout;
-    const T* __restrict__ ypre = (const T*)a.out;
-    const int in_gn = (norm && a.in_adj) ? a.in_norm.group_n : a.N;
-    const int groups = a.N / in_gn;
-    for (int g = 0; g < groups; ++g) {
-      float s1[SH::CS], s2[SH::CS];
+      __syncthreads();
+      wgrad_tile<SH, false>(as, big, acc, accb);
+      if (gin) {
 #pragma unroll
-      for (int cs = 0; cs < SH::CS; ++cs) { s1[cs] = 0.f; s2[cs] = 0.f; }
-      for (int n = g * in_gn + blockIdx.x; n < (g + 1) * in_gn; n += gridDim.x) {
-        const int gi = norm ? n / a.in_norm.group_n : 0;
-        if (norm) stage_small<SH, T, true, true>(in + (size_t)n * SH::CS * SH::S, as, raw, tab, gi, relu_in);
-        else stage_small<SH, T, false, false>(in + (size_t)n * SH::CS * SH::S, as, raw, tab, 0, 0);
-        if (lz) stage_big_grad<SH, T, true>(gout + (size_t)n * SH::CB * SH::LB, ypre + (size_t)n * SH::CB * SH::LB, big, lazy,
-                                            n / a.out_norm.group_n, a.out_norm.relu);
-        else stage_big_grad<SH, T, false>(gout + (size_t)n * SH::CB * SH::LB, nullptr, big, lazy, 0, 0);
-        __syncthreads();
-        wgrad_tile<SH, false>(as, big, acc, accb);
-        if (gin) {
-          for (int l = threadIdx.x; l < SH::S; l += NT) {
+        for (int it = 0; it < SH::ITER; ++it) {
+          const int l = it * NT + threadIdx.x;
+          if (l < SH::S) {
             float gs[SH::CS];
 #pragma unroll
             for (int cs = 0; cs < SH::CS; ++cs) gs[cs] = 0.f;
-            down_core<SH>(big, w, l, gs);
+            down_core<SH>(big, wd, l, gs);
             if (norm) small_grad_epilogue<SH, T, true>(gs, as, raw, tab, gi, l, relu_in, a.in_relu_plain, gb, s1, s2);
             else small_grad_epilogue<SH, T, false>(gs, as, raw, tab, gi, l, relu_in, a.in_relu_plain, gb, s1, s2);
           }
         }
-        __syncthreads();
-        if (gin) copy_out_small<SH, T>(gb, gin + (size_t)n * SH::CS * SH::S);
       }
-      if (norm && a.in_adj)
-        block_pairs<SH::CS>(s1, s2, redd, a.in_adj + ((size_t)g * SH::CS * gridDim.x + blockIdx.x) * 2, gridDim.x);
+      __syncthreads();
+      if (gin) copy_out<IN_EL, T>(gb, gin + (size_t)n * IN_EL);
+      n = nn;
     }
+    if (norm && a.in_adj)
+      block_pairs<SH::CS>(s1, s2, redd, a.in_adj + ((size_t)g * SH::CS * gridDim.x + blockIdx.x) * 2, gridDim.x);
   }
   __syncthreads();
   wgrad_flush<SH, false>(acc, accb, redf, slab);
-  if constexpr (LOSS) block_sums<SH::CB>(db, redf, slab + SH::NW);
 }
 
+template <typename SH, typename T, bool FAST>
+__global__ __launch_bounds__(NT, 2) void audio_loss_bwd_kernel(const mdmm_audio_t a) {
+  extern __shared__ float4 lds4[];
+  char* lds = (char*)lds4;
+  using L = UpBwdLds<SH, T>;
+  float* as = (float*)(lds + L::a_off);
+  float* big = (float*)(lds + L::big_off);
+  T* raw = (T*)(lds + L::raw_off);
+  T* gb = (T*)(lds + L::gb_off);
+  float* wu = (float*)(lds + L::wu_off);
+  float* wd = (float*)(lds + L::wd_off);
+  NormTab* tab = (NormTab*)(lds + L::tab_off);
+  float* adjw = (float*)(lds + L::adj_off);
+  float* redf = (float*)(lds + L::red_off);
+  const bool norm = a.in_norm.mean != nullptr;
+  const int relu_in = a.in_norm.relu;
+  if (norm) fill_norm(*tab, a.in_norm, SH::CS, a.passes);
+  fill_weights<SH>(a.weight, wu, wd);
+  for (int c = threadIdx.x; c < SH::CS; c += NT) as[c * SH::SP + SH::S] = 0.f;
+  for (int c = threadIdx.x; c < SH::CB; c += NT) { big[c * SH::RB] = 0.f; big[c * SH::RB + SH::S] = 0.f; big[c * SH::RB + SH::RB - 1] = 0.f; }
+  for (int i = threadIdx.x; i < NWAVE * MAXG * 2 * SH::CS; i += NT) adjw[i] = 0.f;
+  __syncthreads();
+  const T* __restrict__ in = (const T*)a.in;
+  T* __restrict__ gin = (T*)a.gin;
+  constexpr int IN_EL = SH::CS * SH::S, TG_EL = SH::CB * SH::LB;
+  float bias[SH::CB], db[SH::CB];
+#pragma unroll
+  for (int cb = 0; cb < SH::CB; ++cb) { bias[cb] = a.bias ? a.bias[cb] : 0.f; db[cb] = 0.f; }
+  float acc[SH::NA], accb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < SH::NA; ++i) acc[i] = 0.f;
+  float* slab = a.ws + (size_t)blockIdx.x * (SH::NW + 16);
+  const int rows = a.N / a.passes, step = gridDim.x;
+  const float gsc = (a.gscale ? *a.gscale : 1.0f) * a.loss_weight;
+  float x0[SH::ITER][SH::CB], x1[SH::ITER][SH::CB];
+  Pieces<IN_EL, T> fa;
+  // rows nobody scores: their frames' gradient is zero (written on the way to the next scored row)
+  auto skip_masked = [&](int r0) {
+    while (r0 < rows && a.row_mask && a.row_mask[r0] == 0.f) {
+      for (int p2 = 0; p2 < a.passes; ++p2) zero_frame<IN_EL, T>(gin + ((size_t)p2 * rows + r0) * IN_EL);
+      r0 += step;
+    }
+    return r0;
+  };
+  int r = skip_masked(blockIdx.x), p = 0;
+  if (r < rows) fa.load(in + (size_t)r * IN_EL);
+  while (r < rows) {
+    int pn = p + 1, rn = r;
+    if (pn == a.passes) { pn = 0; rn = skip_masked(r + step); }
+    const int n = p * rows + r;
+    if (p == 0) load_targets<SH>(a.target + (size_t)r * TG_EL, x0, x1);
+    if (norm) put_small<SH, T, true, true>(fa, as, raw, tab, p, relu_in);
+    else put_small<SH, T, false, false>(fa, as, raw, tab, 0, 0);
+    if (rn < rows) fa.load(in + ((size_t)pn * rows + rn) * IN_EL);
+    __syncthreads();
+    // the logits again, turned into their gradient on the spot -> the O / E rows
+    const float sc = gsc * a.pass_w[p & 7];
+#pragma unroll
+    for (int it = 0; it < SH::ITER; ++it) {
+      const int l = it * NT + threadIdx.x;
+      if (l < SH::S) {
+        float ev[SH::CB], od[SH::CB];
+#pragma unroll
+        for (int cb = 0; cb < SH::CB; ++cb) { ev[cb] = bias[cb]; od[cb] = bias[cb]; }
+        up_core<SH>(as, wu, l, ev, od);
+        const bool last = l == SH::S - 1;
+#pragma unroll
+        for (int cb = 0; cb < SH::CB; ++cb) {
+          const float xe = x0[it][cb], xo = x1[it][cb];
+          const float de = (xe == xe) ? bce_grad<FAST>(ev[cb], xe, sc) : 0.f;
+          const float dd = (xo == xo) ? bce_grad<FAST>(od[cb], xo, sc) : 0.f;
+          db[cb] += de + dd;
+          big[cb * SH::RB + SH::SP + l] = de;
+          if (!last) big[cb * SH::RB + l + 1] = dd;
+        }
+      }
+    }
+    __syncthreads();
+    wgrad_tile<SH, false>(as, big, acc, accb);
+    float s1[SH::CS], s2[SH::CS];
+#pragma unroll
+    for (int cs = 0; cs < SH::CS; ++cs) { s1[cs] = 0.f; s2[cs] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < SH::ITER; ++it) {
+      const int l = it * NT + threadIdx.x;
+      if (l < SH::S) {
+        float gs[SH::CS];
+#pragma unroll
+        for (int cs = 0; cs < SH::CS; ++cs) gs[cs] = 0.f;
+        down_core<SH>(big, wd, l, gs);
+        if (norm) small_grad_epilogue<SH, T, true>(gs, as, raw, tab, p, l, relu_in, a.in_relu_plain, gb, s1, s2);
+        else small_grad_epilogue<SH, T, false>(gs, as, raw, tab, p, l, relu_in, a.in_relu_plain, gb, s1, s2);
+      }
+    }
+    if (norm && a.in_adj) {           // this frame's adjoint sums into the wave's own slots of its group (one writer each)
+      const int wv = threadIdx.x >> 6;
+#pragma unroll
+      for (int cs = 0; cs < SH::CS; ++cs) {
+        const float t1 = mdmm::wave_sum(s1[cs]), t2 = mdmm::wave_sum(s2[cs]);
+        if ((threadIdx.x & 63) == 0) {
+          adjw[((wv * MAXG + p) * SH::CS + cs) * 2] += t1;
+          adjw[((wv * MAXG + p) * SH::CS + cs) * 2 + 1] += t2;
+        }
+      }
+    }
+    __syncthreads();
+    copy_out<IN_EL, T>(gb, gin + (size_t)n * IN_EL);
+    r = rn; p = pn;
+  }
+  __syncthreads();
+  if (norm && a.in_adj) {
+    for (int o = threadIdx.x; o < a.passes * SH::CS * 2; o += NT) {
+      const int h = o & 1, c = (o >> 1) % SH::CS, g = (o >> 1) / SH::CS;
+      double s = 0;
+      for (int k = 0; k < NWAVE; ++k) s += (double)adjw[((k * MAXG + g) * SH::CS + c) * 2 + h];
+      a.in_adj[(((size_t)g * SH::CS + c) * gridDim.x + blockIdx.x) * 2 + h] = s;
+    }
+  }
+  wgrad_flush<SH, false>(acc, accb, redf, slab);
+  block_sums<SH::CB>(db, redf, slab + SH::NW);
+}
 
 // =====================================================================================================================
 // down, forward: big -> small (+ statistics of what is stored); the first encoder layer cleans the frames it stages
 // =====================================================================================================================
 template <typename SH, typename T> struct DownFwdLds {
   static constexpr size_t big_off = 0;
-  static constexpr size_t tab_off = align16(big_off + sizeof(float) * SH::CB * SH::RB);
+  static constexpr size_t wd_off = align16(big_off + sizeof(float) * SH::CB * SH::RB);
+  static constexpr size_t tab_off = align16(wd_off + sizeof(float) * SH::CB * SH::WD);
   static constexpr size_t ob_off = align16(tab_off + sizeof(NormTab));
   static constexpr size_t red_off = align16(ob_off + sizeof(T) * SH::CS * SH::S);
   static constexpr size_t bytes = red_off + sizeof(double) * NWAVE * SH::CS * 2;
 };
 
 template <typename SH, typename T, bool FRAMES>
-__global__ __launch_bounds__(NT) void audio_down_fwd_kernel(const mdmm_audio_t a) {
+__global__ __launch_bounds__(NT, 3) void audio_down_fwd_kernel(const mdmm_audio_t a) {
   extern __shared__ float4 lds4[];
   char* lds = (char*)lds4;
   using L = DownFwdLds<SH, T>;
+  using TI = typename std::conditional<FRAMES, float, T>::type;
   float* big = (float*)(lds + L::big_off);
+  float* wd = (float*)(lds + L::wd_off);
   NormTab* tab = (NormTab*)(lds + L::tab_off);
   T* ob = (T*)(lds + L::ob_off);
   double* red = (double*)(lds + L::red_off);
   const bool norm = !FRAMES && a.in_norm.mean != nullptr;
   const int relu = a.in_norm.relu;
   if (norm) fill_norm(*tab, a.in_norm, SH::CB, a.N / a.in_norm.group_n);
-  for (int c = threadIdx.x; c < SH::CB; c += NT) { big[c * SH::RB] = 0.f; big[c * SH::RB + SH::S] = 0.f; }
+  fill_weights<SH>(a.weight, nullptr, wd);
+  for (int c = threadIdx.x; c < SH::CB; c += NT) { big[c * SH::RB] = 0.f; big[c * SH::RB + SH::S] = 0.f; big[c * SH::RB + SH::RB - 1] = 0.f; }
   __syncthreads();
-  wptr_t w = as_const(a.weight);
+  const TI* __restrict__ in = (const TI*)a.in;
   T* __restrict__ out = (T*)a.out;
-  const size_t in_el = (size_t)SH::CB * SH::LB;
+  constexpr int IN_EL = SH::CB * SH::LB, OUT_EL = SH::CS * SH::S;
+  float bias[SH::CS];
+#pragma unroll
+  for (int cs = 0; cs < SH::CS; ++cs) bias[cs] = a.bias ? a.bias[cs] : 0.f;
   const int out_gn = a.out_stats ? a.out_group_n : a.N;
   const int groups = a.N / out_gn;
+  Pieces<IN_EL, TI> fa;
   for (int g = 0; g < groups; ++g) {
     float s1[SH::CS], s2[SH::CS];
 #pragma unroll
     for (int cs = 0; cs < SH::CS; ++cs) { s1[cs] = 0.f; s2[cs] = 0.f; }
-    for (int n = g * out_gn + blockIdx.x; n < (g + 1) * out_gn; n += gridDim.x) {
+    const int end = (g + 1) * out_gn;
+    int n = g * out_gn + blockIdx.x;
+    if (n < end) fa.load(in + (size_t)n * IN_EL);
+    while (n < end) {
+      const int nn = n + gridDim.x;
       if constexpr (FRAMES) {
-        const bool nan = stage_big<SH, T, false, false, true>((const float*)a.in + n * in_el, big, nullptr, tab, 0, 0);
+        const bool nan = put_big<SH, TI, T, false, false, true>(fa, big, nullptr, tab, 0, 0);
+        if (nn < end) fa.load(in + (size_t)nn * IN_EL);
         const int any = __syncthreads_or(nan ? 1 : 0);
         if (a.seen && threadIdx.x == 0) a.seen[n] = any ? 0.f : 1.f;
       } else {
-        if (norm) stage_big<SH, T, true, false, false>((const T*)a.in + n * in_el, big, nullptr, tab, n / a.in_norm.group_n, relu);
-        else stage_big<SH, T, false, false, false>((const T*)a.in + n * in_el, big, nullptr, tab, 0, 0);
+        if (norm) put_big<SH, TI, T, true, false, false>(fa, big, nullptr, tab, n / a.in_norm.group_n, relu);
+        else put_big<SH, TI, T, false, false, false>(fa, big, nullptr, tab, 0, 0);
+        if (nn < end) fa.load(in + (size_t)nn * IN_EL);
         __syncthreads();
       }
-      for (int l = threadIdx.x; l < SH::S; l += NT) {
-        float o[SH::CS];
 #pragma unroll
-        for (int cs = 0; cs < SH::CS; ++cs) o[cs] = a.bias ? a.bias[cs] : 0.f;
-        down_core<SH>(big, w, l, o);
+      for (int it = 0; it < SH::ITER; ++it) {
+        const int l = it * NT + threadIdx.x;
+        if (l < SH::S) {
+          float o[SH::CS];
 #pragma unroll
-        for (int cs = 0; cs < SH::CS; ++cs) {
-          const float v = rnd<T>(o[cs]);
-          s1[cs] += v;
-          s2[cs] = fmaf(v, v, s2[cs]);
-          ob[cs * SH::S + l] = (T)v;
+          for (int cs = 0; cs < SH::CS; ++cs) o[cs] = bias[cs];
+          down_core<SH>(big, wd, l, o);
+#pragma unroll
+          for (int cs = 0; cs < SH::CS; ++cs) {
+            const float v = rnd<T>(o[cs]);
+            s1[cs] += v;
+            s2[cs] = fmaf(v, v, s2[cs]);
+            ob[cs * SH::S + l] = (T)v;
+          }
         }
       }
       __syncthreads();
-      copy_out_small<SH, T>(ob, out + (size_t)n * SH::CS * SH::S);
+      copy_out<OUT_EL, T>(ob, out + (size_t)n * OUT_EL);
+      n = nn;
     }
     if (a.out_stats)
       block_pairs<SH::CS>(s1, s2, red, a.out_stats + ((size_t)g * SH::CS * gridDim.x + blockIdx.x) * 2, gridDim.x);
@@ -780,7 +967,8 @@ template <typename SH, typename T, bool FRAMES> struct DownBwdLds {
   static constexpr size_t ds_off = align16(big_off + sizeof(float) * SH::CB * SH::RB);
   static constexpr size_t raw_off = align16(ds_off + sizeof(float) * SH::CS * SH::SP);
   static constexpr size_t gb_off = align16(raw_off + (FRAMES ? 0 : sizeof(T) * SH::CB * SH::LB));
-  static constexpr size_t tab_off = align16(gb_off + (FRAMES ? 0 : sizeof(T) * SH::CB * 2 * SH::S));
+  static constexpr size_t wu_off = align16(gb_off + (FRAMES ? 0 : sizeof(T) * SH::CB * SH::LB));
+  static constexpr size_t tab_off = align16(wu_off + (FRAMES ? 0 : sizeof(float) * SH::CS * SH::WU));
   static constexpr size_t lazy_off = align16(tab_off + sizeof(NormTab));
   static constexpr size_t red_off = align16(lazy_off + sizeof(LazyTab));
   static constexpr size_t red_bytes_a = sizeof(double) * NWAVE * 16 * 2;
@@ -789,14 +977,16 @@ template <typename SH, typename T, bool FRAMES> struct DownBwdLds {
 };
 
 template <typename SH, typename T, bool FRAMES>
-__global__ __launch_bounds__(NT) void audio_down_bwd_kernel(const mdmm_audio_t a) {
+__global__ __launch_bounds__(NT, 2) void audio_down_bwd_kernel(const mdmm_audio_t a) {
   extern __shared__ float4 lds4[];
   char* lds = (char*)lds4;
   using L = DownBwdLds<SH, T, FRAMES>;
+  using TI = typename std::conditional<FRAMES, float, T>::type;
   float* big = (float*)(lds + L::big_off);
   float* ds = (float*)(lds + L::ds_off);
   T* rawb = (T*)(lds + L::raw_off);
   T* gbig = (T*)(lds + L::gb_off);
+  float* wu = (float*)(lds + L::wu_off);
   NormTab* tab = (NormTab*)(lds + L::tab_off);
   LazyTab* lazy = (LazyTab*)(lds + L::lazy_off);
   double* redd = (double*)(lds + L::red_off);
@@ -806,14 +996,15 @@ __global__ __launch_bounds__(NT) void audio_down_bwd_kernel(const mdmm_audio_t a
   const int relu_in = a.in_norm.relu;
   if (norm) fill_norm(*tab, a.in_norm, SH::CB, a.N / a.in_norm.group_n);
   if (lz) fill_lazy(*lazy, a.out_norm, a.out_bwd_means, SH::CS, a.N / a.out_norm.group_n);
+  if (!FRAMES) fill_weights<SH>(a.weight, wu, nullptr);
   for (int c = threadIdx.x; c < SH::CS; c += NT) ds[c * SH::SP + SH::S] = 0.f;
-  for (int c = threadIdx.x; c < SH::CB; c += NT) { big[c * SH::RB] = 0.f; big[c * SH::RB + SH::S] = 0.f; }
+  for (int c = threadIdx.x; c < SH::CB; c += NT) { big[c * SH::RB] = 0.f; big[c * SH::RB + SH::S] = 0.f; big[c * SH::RB + SH::RB - 1] = 0.f; }
   __syncthreads();
-  wptr_t w = as_const(a.weight);
+  const TI* __restrict__ in = (const TI*)a.in;
   const T* __restrict__ gout = (const T*)a.gout;
   const T* __restrict__ ypre = (const T*)a.out;
   T* __restrict__ gin = FRAMES ? nullptr : (T*)a.gin;
-  const size_t in_el = (size_t)SH::CB * SH::LB;
+  constexpr int IN_EL = SH::CB * SH::LB, OUT_EL = SH::CS * SH::S;
   float acc[SH::NA], accb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < SH::NA; ++i) acc[i] = 0.f;
@@ -821,53 +1012,87 @@ __global__ __launch_bounds__(NT) void audio_down_bwd_kernel(const mdmm_audio_t a
   const bool want_bias = a.dbias != nullptr;
   const int in_gn = (norm && a.in_adj && gin) ? a.in_norm.group_n : a.N;
   const int groups = a.N / in_gn;
+  Pieces<IN_EL, TI> fa;
+  Pieces<OUT_EL, T> fg, fy;
+  // (the 51 KB frames: only the first quarter of a frame's pieces waits in registers while the frame before it is computed;
+  //  the other quarters are asked for one step ahead of being spread into LDS, two quarters live at a time -- the whole
+  //  frame ahead took this kernel's registers over the limit, 336 bytes of scratch per lane)
+  constexpr int KA = Pieces<IN_EL, TI>::K, KH = FRAMES ? (KA + 3) / 4 : KA;      // (quarters, see below)
+  constexpr int KQ1 = KH, KQ2 = 2 * KH < KA ? 2 * KH : KA, KQ3 = 3 * KH < KA ? 3 * KH : KA;
   for (int g = 0; g < groups; ++g) {
     float s1[SH::CB], s2[SH::CB];
 #pragma unroll
     for (int cb = 0; cb < SH::CB; ++cb) { s1[cb] = 0.f; s2[cb] = 0.f; }
-    for (int n = g * in_gn + blockIdx.x; n < (g + 1) * in_gn; n += gridDim.x) {
+    const int end = (g + 1) * in_gn;
+    int n = g * in_gn + blockIdx.x;
+    if (n < end) {
+      fa.template load_part<0, KH>(in + (size_t)n * IN_EL);
+      fg.load(gout + (size_t)n * OUT_EL);
+      if (lz) fy.load(ypre + (size_t)n * OUT_EL);
+    }
+    while (n < end) {
+      const int nn = n + gridDim.x;
       const int gi = norm ? n / a.in_norm.group_n : 0;
       if constexpr (FRAMES) {
-        stage_big<SH, T, false, false, true>((const float*)a.in + n * in_el, big, nullptr, tab, 0, 0);
+        fa.template load_part<KQ1, KQ2>(in + (size_t)n * IN_EL);
+        __builtin_amdgcn_sched_barrier(0);
+        put_big<SH, TI, T, false, false, true, 0, KQ1>(fa, big, nullptr, tab, 0, 0);
+        fa.template load_part<KQ2, KQ3>(in + (size_t)n * IN_EL);
+        __builtin_amdgcn_sched_barrier(0);
+        put_big<SH, TI, T, false, false, true, KQ1, KQ2>(fa, big, nullptr, tab, 0, 0);
+        fa.template load_part<KQ3, KA>(in + (size_t)n * IN_EL);
+        __builtin_amdgcn_sched_barrier(0);
+        put_big<SH, TI, T, false, false, true, KQ2, KQ3>(fa, big, nullptr, tab, 0, 0);
+        put_big<SH, TI, T, false, false, true, KQ3, KA>(fa, big, nullptr, tab, 0, 0);
       } else {
-        if (norm) stage_big<SH, T, true, true, false>((const T*)a.in + n * in_el, big, rawb, tab, gi, relu_in);
-        else stage_big<SH, T, false, false, false>((const T*)a.in + n * in_el, big, rawb, tab, 0, 0);
+        if (norm) put_big<SH, TI, T, true, true, false>(fa, big, rawb, tab, gi, relu_in);
+        else put_big<SH, TI, T, false, false, false>(fa, big, rawb, tab, 0, 0);
       }
-      if (lz) stage_small_grad<SH, T, true>(gout + (size_t)n * SH::CS * SH::S, ypre + (size_t)n * SH::CS * SH::S, ds, lazy,
-                                            n / a.out_norm.group_n, a.out_norm.relu);
-      else stage_small_grad<SH, T, false>(gout + (size_t)n * SH::CS * SH::S, nullptr, ds, lazy, 0, 0);
+      if (lz) put_small_grad<SH, T, true>(fg, fy, ds, lazy, n / a.out_norm.group_n, a.out_norm.relu);
+      else put_small_grad<SH, T, false>(fg, fy, ds, lazy, 0, 0);
+      if (nn < end) {
+        fa.template load_part<0, KH>(in + (size_t)nn * IN_EL);
+        fg.load(gout + (size_t)nn * OUT_EL);
+        if (lz) fy.load(ypre + (size_t)nn * OUT_EL);
+      }
       __syncthreads();
       if (want_bias) wgrad_tile<SH, true>(ds, big, acc, accb);
       else wgrad_tile<SH, false>(ds, big, acc, accb);
       if constexpr (!FRAMES) {
         if (gin) {
-          for (int l = threadIdx.x; l < SH::S; l += NT) {
-            float ev[SH::CB], od[SH::CB];
 #pragma unroll
-            for (int cb = 0; cb < SH::CB; ++cb) { ev[cb] = 0.f; od[cb] = 0.f; }
-            up_core<SH>(ds, w, l, ev, od);
-            const bool last = l == SH::S - 1;
+          for (int it = 0; it < SH::ITER; ++it) {
+            const int l = it * NT + threadIdx.x;
+            if (l < SH::S) {
+              float ev[SH::CB], od[SH::CB];
 #pragma unroll
-            for (int cb = 0; cb < SH::CB; ++cb) {
-              const float ge = rnd<T>(ev[cb]), go = last ? 0.f : rnd<T>(od[cb]);
-              if (norm) {
-                const int q = gi * SH::CB + cb;
-                const float ae = big[cb * SH::RB + SH::SP + l], ao = big[cb * SH::RB + l + 1];
-                const float me = (relu_in && !(ae > 0.f)) ? 0.f : ge, mo = (last || (relu_in && !(ao > 0.f))) ? 0.f : go;
-                const float xe = ((float)rawb[cb * SH::LB + 2 * l] - tab->mean[q]) * tab->inv[q];
-                const float xo = last ? 0.f : ((float)rawb[cb * SH::LB + 2 * l + 1] - tab->mean[q]) * tab->inv[q];
-                s1[cb] += me + mo;
-                s2[cb] = fmaf(me, xe, fmaf(mo, xo, s2[cb]));
+              for (int cb = 0; cb < SH::CB; ++cb) { ev[cb] = 0.f; od[cb] = 0.f; }
+              up_core<SH>(ds, wu, l, ev, od);
+              const bool last = l == SH::S - 1;
+#pragma unroll
+              for (int cb = 0; cb < SH::CB; ++cb) {
+                const float ge = rnd<T>(ev[cb]), go = last ? 0.f : rnd<T>(od[cb]);
+                if (norm) {
+                  const float2 mi = tab->mi[gi * SH::CB + cb];
+                  const float ae = big[cb * SH::RB + SH::SP + l], ao = big[cb * SH::RB + l + 1];
+                  const float me = (relu_in && !(ae > 0.f)) ? 0.f : ge, mo = (last || (relu_in && !(ao > 0.f))) ? 0.f : go;
+                  const float xe = ((float)rawb[cb * SH::LB + 2 * l] - mi.x) * mi.y;
+                  const float xo = last ? 0.f : ((float)rawb[cb * SH::LB + 2 * l + 1] - mi.x) * mi.y;
+                  s1[cb] += me + mo;
+                  s2[cb] = fmaf(me, xe, fmaf(mo, xo, s2[cb]));
+                }
+                gbig[cb * SH::LB + 2 * l] = (T)ge;
+                if (!last) gbig[cb * SH::LB + 2 * l + 1] = (T)go;
               }
-              put_pair<T>(gbig, cb * 2 * SH::S + 2 * l, ge, go);
             }
           }
         }
       }
       __syncthreads();
       if constexpr (!FRAMES) {
-        if (gin) copy_out_big<SH, T>(gbig, gin + n * in_el);
+        if (gin) copy_out<IN_EL, T>(gbig, gin + (size_t)n * IN_EL);
       }
+      n = nn;
     }
     if constexpr (!FRAMES) {
       if (norm && a.in_adj && gin)
@@ -879,14 +1104,25 @@ __global__ __launch_bounds__(NT) void audio_down_bwd_kernel(const mdmm_audio_t a
   else wgrad_flush<SH, false>(acc, accb, redf, slab);
 }
 
-// dw[o] = sum over the workgroups' slabs (fixed order); the slab's tail holds the bias gradient
-__global__ void audio_fold_kernel(const float* __restrict__ ws, int parts, int stride, int nw, int nb, float* dw, float* dbias) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nw + nb) return;
+// dw[e] = sum over the workgroups' slabs (fixed order); the slab's tail holds the bias gradient.  64 outputs per workgroup,
+// 16 strided partial sums each, folded through LDS.
+__global__ __launch_bounds__(1024) void audio_fold_kernel(const float* __restrict__ ws, int parts, int stride, int nw, int nb, float* dw, float* dbias) {
+  __shared__ float red[16][64];
+  const int el = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
   float s = 0.f;
-  for (int p = 0; p < parts; ++p) s += ws[(size_t)p * stride + e];
-  if (e < nw) dw[e] = s;
-  else if (dbias) dbias[e - nw] = s;
+  if (e < nw + nb) {
+    for (int p = pg; p < parts; p += 16) s += ws[(size_t)p * stride + e];
+  }
+  red[pg][el] = s;
+  __syncthreads();
+  if (pg == 0 && e < nw + nb) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][el];
+    if (e < nw) dw[e] = t;
+    else if (dbias) dbias[e - nw] = t;
+  }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
@@ -945,6 +1181,7 @@ int parts_for(const mdmm_audio_t* a, size_t lds) {
 
 template <typename SH, typename T>
 size_t lds_bytes(const mdmm_audio_t* a, bool bwd) {
+  if (a->up && !bwd && a->target) return LossFwdLds<SH, T>::bytes;
   if (a->up) return bwd ? UpBwdLds<SH, T>::bytes : UpFwdLds<SH, T>::bytes;
   if (!bwd) return DownFwdLds<SH, T>::bytes;
   return a->in_frames ? DownBwdLds<SH, T, true>::bytes : DownBwdLds<SH, T, false>::bytes;
@@ -965,6 +1202,8 @@ template <typename F> int launch(F kern, const mdmm_audio_t* a, int grid, size_t
 
 template <typename SH, typename T>
 int run_st(const mdmm_audio_t* a, bool bwd, hipStream_t st) {
+  // (a 10 x 1281 big side stored as bf16 has no whole 8-byte pieces: only the loss forms and the fp32 frames exist there)
+  constexpr bool BIG_OK = (SH::CB * SH::LB) % V8<T>::N == 0;
   const int grid = parts_st<SH, T>(a);
   const size_t lds = lds_bytes<SH, T>(a, bwd);
   int rc;
@@ -972,30 +1211,34 @@ int run_st(const mdmm_audio_t* a, bool bwd, hipStream_t st) {
     if (a->up) {
       if (a->target) {
         if constexpr (SH::CB == 10) {
-          rc = a->fast ? launch(audio_up_fwd_kernel<SH, T, true, true>, a, grid, lds, st)
-                       : launch(audio_up_fwd_kernel<SH, T, true, false>, a, grid, lds, st);
+          rc = a->fast ? launch(audio_loss_fwd_kernel<SH, T, true>, a, grid, lds, st)
+                       : launch(audio_loss_fwd_kernel<SH, T, false>, a, grid, lds, st);
         } else rc = MDMM_E_ARG;
-      } else rc = launch(audio_up_fwd_kernel<SH, T, false, false>, a, grid, lds, st);
+      } else if constexpr (BIG_OK) rc = launch(audio_up_fwd_kernel<SH, T>, a, grid, lds, st);
+      else rc = MDMM_E_ARG;
     } else {
-      rc = a->in_frames ? launch(audio_down_fwd_kernel<SH, T, true>, a, grid, lds, st)
-                        : launch(audio_down_fwd_kernel<SH, T, false>, a, grid, lds, st);
+      if (a->in_frames) rc = launch(audio_down_fwd_kernel<SH, T, true>, a, grid, lds, st);
+      else if constexpr (BIG_OK) rc = launch(audio_down_fwd_kernel<SH, T, false>, a, grid, lds, st);
+      else rc = MDMM_E_ARG;
     }
     return rc;
   }
   if (a->up) {
     if (a->target) {
       if constexpr (SH::CB == 10) {
-        rc = a->fast ? launch(audio_up_bwd_kernel<SH, T, true, true>, a, grid, lds, st)
-                     : launch(audio_up_bwd_kernel<SH, T, true, false>, a, grid, lds, st);
+        rc = a->fast ? launch(audio_loss_bwd_kernel<SH, T, true>, a, grid, lds, st)
+                     : launch(audio_loss_bwd_kernel<SH, T, false>, a, grid, lds, st);
       } else rc = MDMM_E_ARG;
-    } else rc = launch(audio_up_bwd_kernel<SH, T, false, false>, a, grid, lds, st);
+    } else if constexpr (BIG_OK) rc = launch(audio_up_bwd_kernel<SH, T>, a, grid, lds, st);
+    else rc = MDMM_E_ARG;
   } else {
-    rc = a->in_frames ? launch(audio_down_bwd_kernel<SH, T, true>, a, grid, lds, st)
-                      : launch(audio_down_bwd_kernel<SH, T, false>, a, grid, lds, st);
+    if (a->in_frames) rc = launch(audio_down_bwd_kernel<SH, T, true>, a, grid, lds, st);
+    else if constexpr (BIG_OK) rc = launch(audio_down_bwd_kernel<SH, T, false>, a, grid, lds, st);
+    else rc = MDMM_E_ARG;
   }
   if (rc) return rc;
   const int nb = a->dbias ? (a->up ? SH::CB : SH::CS) : 0;
-  hipLaunchKernelGGL(audio_fold_kernel, dim3((SH::NW + nb + 127) / 128), dim3(128), 0, st, (const float*)a->ws, grid, SH::NW + 16,
+  hipLaunchKernelGGL(audio_fold_kernel, dim3((SH::NW + nb + 63) / 64), dim3(1024), 0, st, (const float*)a->ws, grid, SH::NW + 16,
                      SH::NW, nb, a->dw, a->dbias);
   return (int)hipGetLastError();
 }
