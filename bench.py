@@ -38,7 +38,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   its step-time ratio to the unmodified reference as measured in the build container;
   elbo_delta   -- |loss_hip - loss_oracle| / |loss_oracle| of one step on that sample, the kernels' noise
                   replayed into the oracle, for the timed precision mode and for fp32 operands;
-  extra        -- cfg2, cfg4 and cfg3 with fp32 operands ride along at N = 1, and the callers either side of the step
+  extra        -- cfg2, cfg4, cfg5 (at its per-GPU size) and cfg3 with fp32 operands ride along at N = 1, and the callers either side of the step
                   (batch_prep: collate + burst deletion on the device; eval: 200-particle evaluation forward + metrics
                   + decollate; tools/bench_callers.py).
 """
@@ -775,7 +775,7 @@ def main():
     ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg3')
     ap.add_argument('--batch', type=int, default=0, help='sequences per GPU (default: the config\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extra', action='store_true', help='skip the cfg2 / cfg4 lines that ride along')
+    ap.add_argument('--no-extra', action='store_true', help='skip the cfg2 / cfg4 / cfg5 / cfg3_f32 lines that ride along')
     ap.add_argument('--eager', action='store_true', help='no HIP-graph replay of the step')
     ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam(fused=True) instead of harness.FlatAdam')
     args = ap.parse_args()
@@ -855,6 +855,14 @@ def main():
             r4 = run(Cfg4, a4, 1, 0, device, graph=not args.eager)
             out['extra']['cfg4'] = {k: r4[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline',
                                                        'calls_ms_per_step')}
+            torch.cuda.empty_cache()
+            # BASELINE configs[4] at its per-GPU size (512 sequences, T = 128; video + audio plug-ins)
+            a5 = argparse.Namespace(**vars(args))
+            a5.steps, a5.warmup, a5.batch = 5, 2, 0
+            r5 = run(Cfg5, a5, 1, 0, device, graph=not args.eager)
+            out['extra']['cfg5'] = {k: r5[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline', 'roofline_k1',
+                                                       'calls_ms_per_step')}
+            del r5
             torch.cuda.empty_cache()
             # the same cfg3 step with fp32 operands everywhere (the mode whose parity tests hold 1e-5): library
             # convolutions, own fp32-operand sweeps; eager (the library's convolutions are not captured)

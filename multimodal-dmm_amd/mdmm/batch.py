@@ -16,6 +16,8 @@ Split of the work:
 """
 import ctypes as C
 
+import threading
+
 import numpy as np
 import torch
 
@@ -196,19 +198,44 @@ def del_segment(batch, f_start, f_stop, lengths=None, modalities=None):
 # to the device by an asynchronous copy as soon as it is packed, so the packing of piece i + 1 runs under the copy of
 # piece i.  (np.concatenate into pageable memory + one pageable copy moved the vidTIMIT-shaped per-GPU batch at 7.4 GB/s,
 # 673 ms for 5 GB; SURVEY 8 f2 exists because that host side is the bottleneck at B = 4096.)
-_STAGING = {}            # device index -> [pinned uint8 tensor, event behind the last copy out of it]
+_STAGING = {}            # device index -> [pinned uint8 tensor, event behind the last copy out of it, lock]
+_STAGING_GUARD = threading.Lock()
 _PACK_PIECE = 256 << 20  # bytes per piece
 _PACK_THREADS = 8
 
 
 def _staging(dev, nbytes):
-    ent = _STAGING.get(dev.index)
-    if ent is not None and ent[1] is not None:
-        ent[1].synchronize()             # the last batch's copies have left the buffer
-    if ent is None or ent[0].numel() < nbytes:
-        ent = [torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8).pin_memory(), None]
-        _STAGING[dev.index] = ent
+    """The device's staging entry, LOCKED (the caller releases ent[2] when its copies are queued): one batch at a time
+    packs into the buffer, a second thread's pad_and_merge for the same device waits."""
+    with _STAGING_GUARD:
+        ent = _STAGING.get(dev.index)
+        if ent is None:
+            ent = _STAGING[dev.index] = [None, None, threading.Lock()]
+    ent[2].acquire()
+    try:
+        if ent[1] is not None:
+            ent[1].synchronize()             # the last batch's copies have left the buffer
+            ent[1] = None
+        if ent[0] is None or ent[0].numel() < nbytes:
+            ent[0] = None                    # (the old block goes back to the caching host allocator first)
+            ent[0] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, pin_memory=True)   # pinned at once, no pageable twin
+    except BaseException:
+        ent[2].release()
+        raise
     return ent
+
+
+def drop_staging(device=None):
+    """Release the pinned staging buffer(s) of pad_and_merge (all devices, or one): after the copies out of them."""
+    with _STAGING_GUARD:
+        keys = list(_STAGING) if device is None else [torch.device(device).index]
+        for k in keys:
+            ent = _STAGING.pop(k, None)
+            if ent is not None:
+                with ent[2]:
+                    if ent[1] is not None:
+                        ent[1].synchronize()
+                    ent[0] = None
 
 
 def _to_device_packed(sequences, seq_len, offset, row, dev):
@@ -218,7 +245,22 @@ def _to_device_packed(sequences, seq_len, offset, row, dev):
     flat_d = torch.empty((total, row), dtype=torch.float32, device=dev)
     if total == 0:
         return flat_d
-    ent = _staging(dev, total * row * 4)
+    ent = _staging(dev, total * row * 4)          # (locked until the copies below are queued and their event recorded)
+    try:
+        _pack_and_copy(ent, sequences, seq_len, offset, row, total, flat_d, dev)
+    finally:
+        # whatever happened (a sequence of the wrong shape raises inside the pool), the copies already queued read the
+        # buffer: the next call must wait for them
+        with torch.cuda.device(dev):
+            ev = torch.cuda.Event()
+            ev.record()
+        ent[1] = ev
+        ent[2].release()
+    return flat_d
+
+
+def _pack_and_copy(ent, sequences, seq_len, offset, row, total, flat_d, dev):
+    from concurrent.futures import ThreadPoolExecutor
     host = ent[0][:total * row * 4].view(torch.float32).view(total, row)
     host_np = host.numpy()
 
@@ -252,10 +294,6 @@ def _to_device_packed(sequences, seq_len, offset, row, dev):
             r0, r1 = int(offset[a]), int(offset[b - 1] + seq_len[b - 1])
             if r1 > r0:
                 flat_d[r0:r1].copy_(host[r0:r1], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-    ent[1] = ev
-    return flat_d
 
 
 

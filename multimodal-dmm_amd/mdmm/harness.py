@@ -118,6 +118,8 @@ class FlatAdam(torch.optim.Optimizer):
             offs.append(offs[-1] + p.numel())
         self._offs = torch.tensor(offs, dtype=torch.int64, device=dev)
         self._ptrs, self._ptr_key = None, None
+        self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)     # a tensor lr as fp32, refreshed by copy_
+        self._captured_lr = None
         for p, lo, hi in zip(bucket.params, offs, offs[1:]):
             self.state[p] = {'step': self.step_dev.reshape(()), 'exp_avg': self.exp_avg[lo:hi].view_as(p),
                              'exp_avg_sq': self.exp_avg_sq[lo:hi].view_as(p)}
@@ -147,13 +149,36 @@ class FlatAdam(torch.optim.Optimizer):
         ptrs = self._table()
         self.step_dev.add_(1.0)
         lr = grp['lr']
-        lr_dev = lr if isinstance(lr, torch.Tensor) else None
+        lr_dev = None
+        if isinstance(lr, torch.Tensor):
+            if not lr.is_cuda or lr.numel() != 1:
+                raise RuntimeError('FlatAdam: a tensor learning rate must be one element on the GPU (the kernel reads it there)')
+            self._lr_dev.copy_(lr.detach().reshape(1))      # (persistent fp32 scalar: any dtype, capturable)
+            lr_dev = self._lr_dev
+        elif torch.cuda.is_current_stream_capturing():
+            self._captured_lr = float(lr)                   # (a launch argument of the captured node from here on)
         with torch.cuda.device(b.flat.device):
             ops._call('mdmm_adam_flat', ptrs.data_ptr(), self._offs.data_ptr(), len(b.params), b.flat.data_ptr(),
                       self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), b.flat.numel(), self.step_dev.data_ptr(),
-                      None if lr_dev is None else lr_dev.to(torch.float32).data_ptr(), 0.0 if lr_dev is not None else float(lr),
+                      None if lr_dev is None else lr_dev.data_ptr(), 0.0 if lr_dev is not None else float(lr),
                       float(grp['betas'][0]), float(grp['betas'][1]), float(grp['eps']), float(grp['weight_decay']))
         return loss
+
+    def check_replay(self):
+        """Called by GraphedElboStep before every replay: a float learning rate was frozen into the captured launch."""
+        lr = self.param_groups[0]['lr']
+        if self._captured_lr is not None and not isinstance(lr, torch.Tensor) and float(lr) != self._captured_lr:
+            raise RuntimeError('FlatAdam: lr changed from %g to %g after the step was captured -- a float lr is a constant of '
+                               'the graph; pass a one-element CUDA tensor as lr to change it between replays'
+                               % (self._captured_lr, float(lr)))
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for st in sd['state'].values():
+            st['step'] = self.step_dev.detach().clone().reshape(())
+            st['exp_avg'] = st['exp_avg'].detach().clone()
+            st['exp_avg_sq'] = st['exp_avg_sq'].detach().clone()
+        return sd
 
     def load_state_dict(self, state_dict):
         """torch.optim.Adam's (or this class's) state: copied INTO the flat buffers (the views stay views)."""
@@ -336,6 +361,9 @@ class GraphedElboStep:
             self._host[k].fill_(v)
 
     def __call__(self):
+        check = getattr(self.optimizer, 'check_replay', None)
+        if check is not None:
+            check()
         self.g_step.replay()
         if dist.is_available() and dist.is_initialized() and (self.group is not None or dist.get_world_size() > 1):
             # The collective is a stream operation between two replays.  Round 3 put a host wait in front of it

@@ -243,6 +243,8 @@ class MultiDKS(MultiDGTS):
                 t = (real[m] if which else left[m])[k]
                 if not which and k == 1:                           # (the left-out states are expanded views: project the rows that exist)
                     t = t[:1, :1] if self.rnn_skip else t[:, :1]
+                elif not which:                                    # (left-out features: every sequence's zero input gives the same row,
+                    t = t[:, :1]                                   #  as the left-out RNN above already takes it: one column, broadcast)
                 c0, c1 = blocks[(m, k)]
                 y = ops.tall_projection(t.reshape(-1, t.shape[-1]), w_in[:, c0:c1], None, self.sweep_dtype)
                 proj[key] = y.reshape(t.shape[0], t.shape[1], self.h_dim)
@@ -254,12 +256,17 @@ class MultiDKS(MultiDGTS):
             terms = [block(m, m in ps, k) for k in ((1, 0) if self.feat_to_z else (1,)) for m in self.modalities]
             full = [t for t in terms if t.shape[1] == b_dim and t.shape[0] == t_max]
             rest_ = [t for t in terms if not (t.shape[1] == b_dim and t.shape[0] == t_max)]
-            acc = bias
+            acc = bias                                             # (None for a bias-free first layer)
             for t in rest_:                                        # the broadcast rows first (a handful of elements)
-                acc = acc + t
-            u_p = acc.expand(t_max, b_dim, self.h_dim) if not full else None
+                acc = t if acc is None else acc + t
+            u_p = None
+            if not full:
+                u_p = (torch.zeros(self.h_dim, device=dev) if acc is None else acc).expand(t_max, b_dim, self.h_dim)
             for t in full:
-                u_p = (t + acc) if u_p is None else (u_p + t)
+                if u_p is None:
+                    u_p = t if acc is None else t + acc
+                else:
+                    u_p = u_p + t
             u_list.append(u_p)
             both = torch.stack([v[2] for v in pick]).all(dim=0)
             steps = torch.arange(t_max, device=dev).unsqueeze(1)

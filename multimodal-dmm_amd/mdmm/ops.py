@@ -1152,6 +1152,8 @@ class _NllBernLogitsFn(torch.autograd.Function):
                 part = torch.zeros(native.lib().mdmm_nll_chan_parts(), 4, device=lg.device, dtype=torch.float32)
             _call('mdmm_nll_bernoulli_logits_passes_fwd_grad', _ptr(lg), passes, _ptr(xv), _ptr(mask), rows, inner,
                   weight, ctx.pw, _ptr(acc), _ptr(part), ctx.channels, tag='mdmm_nll_bernoulli_logits_fwd')
+            # the logits are gone (they hold their gradient now): anyone who saved them for a backward of their own is told
+            torch.autograd.graph.increment_version(lg)
             ctx.save_for_backward(lg, part)
             return _term_out(acc, into, lg.device)
         _call('mdmm_nll_bernoulli_logits_passes_fwd', _ptr(lg), int(ctx.bf), passes, _ptr(xv), _ptr(mask), rows, inner,
@@ -1180,6 +1182,36 @@ class _NllBernLogitsFn(torch.autograd.Function):
         if part is not None:
             _stash_chansum(gl, colsum(part)[:ctx.channels])
         return gl, None, None, None, None, None, None, None, None, None, None, None
+
+
+# The two hand-offs below (_GRAD_SCALE, _LAZY_BN) leave a gradient INCOMPLETE when its backward node returns it and rely
+# on exactly one known consumer -- checked when the forward was built -- to finish it.  Whoever stashes one also asks the
+# autograd engine for a callback at the end of THIS backward pass: an entry still there means the gradient went somewhere
+# else (a hook's copy, a second consumer, an accumulation) unfinished, and the pass fails with that message instead of
+# training on it.  (The audio plug-ins need none of this: their stacks are one autograd node each, mdmm/audio.py.)
+_END_CHECK_QUEUED = False
+
+
+def _check_at_end_of_backward():
+    global _END_CHECK_QUEUED
+    if not _END_CHECK_QUEUED:
+        _END_CHECK_QUEUED = True
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_check)
+
+
+def _end_of_backward_check():
+    global _END_CHECK_QUEUED
+    _END_CHECK_QUEUED = False
+    n_scale, n_lazy = len(_GRAD_SCALE), len(_LAZY_BN)
+    _GRAD_SCALE.clear()
+    _LAZY_BN.clear()
+    _GRAD_CHANSUM.clear()
+    if n_scale or n_lazy:
+        raise native.MdmmError(
+            'this backward pass used %d Bernoulli-loss gradient(s) without their upstream scalar and %d BatchNorm input '
+            'gradient(s) that were never written: the layer that was to finish them (checked when the forward was built) did '
+            'not receive them -- a hook, a second consumer or an accumulation took its place.  MDMM_BN_LAZY_DX=0 and '
+            'nll_bernoulli_logits(consume=False) give every node a complete gradient.' % (n_scale, n_lazy))
 
 
 # Per-channel sums of a gradient tensor that its producer had at hand, for the consumer that needs them as a bias
@@ -1211,6 +1243,7 @@ _GRAD_SCALE = {}
 
 def _stash_scale(g, gd):
     _GRAD_SCALE[g.data_ptr()] = (g, gd)
+    _check_at_end_of_backward()
 
 
 def _take_scale(g):
@@ -1228,8 +1261,12 @@ def scaled_grad_ok(logits):
     (_BnDeconvFn as a ConvTranspose2d on bf16 activations) and is contiguous bf16: the Bernoulli loss may overwrite it
     with its gradient in the forward pass."""
     fn = getattr(logits, 'grad_fn', None)
-    return (fn is not None and type(fn).__name__ == '_BnDeconvFnBackward' and getattr(fn, 'takes_scale', False)
-            and logits.dtype == torch.bfloat16 and logits.is_contiguous() and torch.is_grad_enabled())
+    if fn is None or not isinstance(fn, _BnDeconvFn._backward_cls) or not getattr(fn, 'takes_scale', False):
+        return False
+    # (a hook on the logits, or a kept .grad, would be handed the gradient before its scalar)
+    if getattr(logits, '_backward_hooks', None) or logits.retains_grad:
+        return False
+    return logits.dtype == torch.bfloat16 and logits.is_contiguous() and torch.is_grad_enabled()
 
 
 # A BatchNorm adjoint that has only been REDUCED (_BnDeconvFn.backward with lazy_dx): the tensor it returns as dx is
@@ -1241,6 +1278,7 @@ _LAZY_BN = {}
 
 def _lazy_stash(dx, entry):
     _LAZY_BN[dx.data_ptr()] = (dx, entry)
+    _check_at_end_of_backward()
 
 
 def _lazy_take(g):
@@ -1276,7 +1314,9 @@ def lazy_bn_ok(x_pre):
     fn = getattr(x_pre, 'grad_fn', None)
     if fn is None or os.environ.get('MDMM_BN_LAZY_DX', '1') == '0':
         return False
-    return (type(fn).__name__ in ('_BnDeconvFnBackward', '_ConvTilesFnBackward') and getattr(fn, 'lazy_consumer', False)
+    if getattr(x_pre, '_backward_hooks', None) or x_pre.retains_grad:
+        return False
+    return (isinstance(fn, (_BnDeconvFn._backward_cls, _ConvTilesFn._backward_cls)) and getattr(fn, 'lazy_consumer', False)
             and x_pre.dim() == 4 and x_pre.shape[1] in (16, 32) and x_pre.dtype == torch.bfloat16 and x_pre.is_contiguous())
 
 

@@ -278,6 +278,79 @@ def _oracle_dks(cfg):
                          feat_to_z=True, rnn_dir='bwd', rnn_skip=True)
 
 
+# Per-class bounds of the bf16-operand gradients where they MEAN something: 32 sequences of the BASELINE shapes (1,200
+# frames per pass through every BatchNorm, 32 x 40 rows through every transition) -- rounding noise of single gates and
+# single frames averages out there, what is left is what bf16 operands cost.  The 4..6-sequence comparisons of this file
+# and of tests/test_hip_parity.py keep their (loose, round-3) bounds as a guard against outright breakage and record their
+# figures; THESE are the stated tolerances (profiles/r06_parity_measured.txt).
+BF16_GRAD_TOL_B32 = {'gtf_first': 3e-2, 'conv': 3e-2, 'plug_other': 3e-2, 'bn_affine': 5e-2, 'gtf_rest': 1.5e-2, 'other': 3e-2}
+
+
+@pytest.mark.parametrize('name', ['cfg3', 'cfg4'])
+def test_bf16_gradients_vs_oracle_at_32_sequences(name, dev):
+    """The timed precision mode (bf16 operands, bf16-stored conv activations) against the fp32 CPU oracle with the
+    kernels' noise replayed, at 32 sequences of the BASELINE shape (cfg3: MultiDMM.step, dmm.py:503-554; cfg4:
+    MultiDKS under MultiDGTS.step, dgts.py:85-130), ragged lengths: loss to 1e-4, every parameter gradient to its class's
+    bound in BF16_GRAD_TOL_B32."""
+    from mdmm import models, ops
+    from mdmm.noise import PhiloxNoise
+    cfg = bench.CONFIGS[name]
+    g = torch.Generator().manual_seed(9)
+    lengths = sorted([cfg.T] * 20 + torch.randint(5, cfg.T, (12,), generator=g).tolist(), reverse=True)
+    K, T, B, D = bench.TRAIN_PARTICLES, cfg.T, len(lengths), cfg.D
+    x_cpu, tg_cpu, mask_cpu, x, tg, mask = _ragged_batch(cfg, lengths, dev)
+    torch.manual_seed(1)
+    m = cfg.model(models, dev)
+    o = cfg.oracle(orc) if name == 'cfg3' else _oracle_dks(cfg)
+    o.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    o.train()
+    n_points = sum(lengths)
+    m.noise = PhiloxNoise(seed=66)
+    kw = dict(train_particles=K) if name == 'cfg3' else {}
+    loss = m.step(x, mask, 1.0, cfg.rec, targets=tg, lengths=lengths, **kw)
+    (loss / n_points).backward()
+    torch.cuda.synchronize()
+    noise = PhiloxNoise(seed=66)
+    P = 1 + cfg.M
+    if name == 'cfg3':
+        draws = [noise.normal((50, 1, D), dev).cpu(), noise.normal((50, 1, D), dev).cpu()]
+        sweeps = []
+        for k in (1, K, 1):
+            s_, off = noise.stream()
+            sweeps.append(ops.philox_normal(s_, off, (P, T, k, B, D), dev).cpu())
+        for p in range(P):
+            draws += [sweeps[0][p, t] for t in reversed(range(T))]
+        for p in range(P):
+            draws += [sweeps[1][p, t] for t in reversed(range(T))]
+            draws += [sweeps[2][p, t] for t in range(T)]
+    else:
+        s_, off = noise.stream()
+        eps = ops.philox_normal(s_, off, (T, P, B, D), dev).cpu()
+        draws = [eps[t, p] for p in range(P) for t in range(T)]
+    o.noise = orc.ReplayNoise(draws)
+    oloss = o.step(x_cpu, mask_cpu, 1.0, cfg.rec, targets=tg_cpu, lengths=lengths, **kw)
+    (oloss / n_points).backward()
+    assert o.noise.pos == len(draws)
+    rel = abs(float(loss) - float(oloss)) / abs(float(oloss))
+    helpers.note('b32_vs_oracle[%s].loss' % name, rel)
+    assert rel < TOL_LOSS_BF16, '%s B = 32 loss vs oracle: %.3e' % (name, rel)
+    og = dict(o.named_parameters())
+    omax = max(float(v.grad.abs().max()) for v in og.values() if v.grad is not None)
+    worst, bad = {}, {}
+    for k, p in m.named_parameters():
+        ref = og[k].grad if og[k].grad is not None else torch.zeros_like(og[k])
+        if float(ref.abs().max()) < 1e-4 * omax:      # conv biases in front of a BatchNorm: exactly zero
+            continue
+        e = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-30))
+        c = helpers.grad_class(k)
+        helpers.note('b32_vs_oracle[%s].grad.%s' % (name, k), e)
+        worst[c] = max(worst.get(c, 0.0), e)
+        if e >= BF16_GRAD_TOL_B32[c]:
+            bad[k] = e
+    helpers.note('b32_vs_oracle[%s].class_max' % name, worst)
+    assert not bad, (bad, worst)
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
 def test_step_cfg5_plugins_matches_oracle(mode, dev):
     """BASELINE cfg5 end to end with its real plug-ins (vidTIMIT.py:50-69; common.py:114-175, 221-290):
@@ -460,17 +533,35 @@ def test_flat_adam_follows_torch_adam(dev):
         assert opt_c.param_groups[0]['lr'] == 3e-3 and float(opt_c.step_dev) == 25.0
         assert torch.equal(opt_c.exp_avg[:1], sb['state'][0]['exp_avg'].reshape(-1))
         assert opt_c.state[pc[2]]['exp_avg'].data_ptr() == opt_c.exp_avg.data_ptr() + 4 * 4      # still a view (1 + 3 before it)
-        opt_d = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in pa], lr=1.0)
+        pd = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+        opt_d = torch.optim.Adam(pd, lr=1.0)
         opt_d.load_state_dict(sa)
+        # the loaded state is a copy: no tensor of it aliases the FlatAdam's live buffers or another parameter's step
+        steps_d = [opt_d.state[q]['step'] for q in pd]
+        assert len({t.data_ptr() for t in steps_d}) == len(pd) and opt_a.step_dev.data_ptr() not in {t.data_ptr() for t in steps_d}
+        assert all(opt_d.state[q]['exp_avg'].data_ptr() != opt_a.state[a]['exp_avg'].data_ptr() for q, a in zip(pd, pa))
         g = torch.randn(*shapes[2], device=dev)
-        for params in (pc, pb):
+        for params in (pc, pb, pd):
             for i, q in enumerate(params):
                 q.grad = g.clone() if i == 2 else torch.zeros_like(q)
         bc.check_views()
+        before = (opt_a.exp_avg.clone(), float(opt_a.step_dev))
         opt_c.step()
         opt_b.step()
-        for a, b in zip(pc, pb):
+        opt_d.step()
+        assert all(float(t) == 26.0 for t in steps_d)            # (one step, not one per parameter)
+        assert torch.equal(opt_a.exp_avg, before[0]) and float(opt_a.step_dev) == before[1]     # opt_a untouched by opt_d
+        for a, b, d in zip(pc, pb, pd):
             assert float((a - b).abs().max()) < 2e-6 * max(1.0, float(b.abs().max()))
+            assert float((d - b).abs().max()) < 2e-6 * max(1.0, float(b.abs().max()))
+    # a tensor learning rate: one element on the GPU, any dtype; a CPU tensor is refused
+    opt_a.param_groups[0]['lr'] = torch.tensor(3e-3, dtype=torch.float64, device=dev)
+    bucket.check_views()
+    opt_a.step()
+    opt_a.param_groups[0]['lr'] = torch.tensor(3e-3)
+    with pytest.raises(RuntimeError):
+        opt_a.step()
+    opt_a.param_groups[0]['lr'] = 3e-3
     with pytest.raises(RuntimeError):           # a gradient that is not the bucket's view
         pa[0].grad = torch.zeros_like(pa[0])
         opt_a.step()
