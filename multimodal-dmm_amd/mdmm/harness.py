@@ -174,10 +174,9 @@ class FlatAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         sd = super().state_dict()
-        for st in sd['state'].values():
-            st['step'] = self.step_dev.detach().clone().reshape(())
-            st['exp_avg'] = st['exp_avg'].detach().clone()
-            st['exp_avg_sq'] = st['exp_avg_sq'].detach().clone()
+        # (the packed dict's per-parameter entries ARE self.state's: new dicts with copies, the live views stay where they are)
+        sd['state'] = {i: {'step': self.step_dev.detach().clone().reshape(()), 'exp_avg': st['exp_avg'].detach().clone(),
+                           'exp_avg_sq': st['exp_avg_sq'].detach().clone()} for i, st in sd['state'].items()}
         return sd
 
     def load_state_dict(self, state_dict):

@@ -124,7 +124,7 @@ def test_saved_logits_are_marked_overwritten(dev):
     from mdmm import ops
     with ops.conv_operands(torch.bfloat16, act=torch.bfloat16):
         logits = dec(z, logits=True)[0]
-        other = (logits.float() ** 2).sum()          # (pow saves its input)
+        other = (logits * logits).sum().float()      # (the product saves `logits` itself)
         assert ops.scaled_grad_ok(logits)
         loss = ops.nll_bernoulli_logits(logits, x, mask, 2, 0.7, consume=True)
     with pytest.raises(RuntimeError, match='modified by an inplace operation'):
