@@ -245,8 +245,8 @@ class MultiDKS(MultiDGTS):
                 t = (real[m] if which else left[m])[k]
                 if not which and k == 1:                           # (the left-out states are expanded views: project the rows that exist)
                     t = t[:1, :1] if self.rnn_skip else t[:, :1]
-                elif not which and os.environ.get('MDMM_DKS_LEFT_COL', '1') != '0':
-                    t = t[:, :1]                                   # (left-out features: every sequence's zero input gives the same row)
+                elif not which:                                    # (left-out features: every sequence's zero input gives the same row,
+                    t = t[:, :1]                                   #  as the left-out RNN above takes it: one column, broadcast)
                 c0, c1 = blocks[(m, k)]
                 y = ops.tall_projection(t.reshape(-1, t.shape[-1]), w_in[:, c0:c1], None, self.sweep_dtype)
                 proj[key] = y.reshape(t.shape[0], t.shape[1], self.h_dim)
