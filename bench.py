@@ -278,6 +278,37 @@ class Cfg5:
         return orc.OracleDMM(cls.mods, cls.dims, cls.dists, encoders=enc, decoders=dec, h_dim=256, z_dim=256)
 
 
+class Cfg4F32(Cfg4):
+    """cfg4 with every contraction on fp32 operands (BASELINE configs[3] states no dtype)."""
+    name, dtype, peak = 'cfg4', 'f32', F32_PEAK_TFLOPS
+    workload = ('cfg4 (fp32 operands): Weizmann-shaped synthetic, MultiDKS backward RNN (B-Skip), feat_to_z, conv encoders/decoders, '
+                'z=h=256, T=40, B=%d per GPU, 20%% burst NaN; every contraction with fp32 operands (recurrences and projections on '
+                'the f32-input MFMA, convolutions in the library), activations fp32')
+
+    @classmethod
+    def model(cls, models, device):
+        import torch
+        m = super().model(models, device)
+        m.sweep_dtype = m.conv_dtype = m.act_dtype = torch.float32
+        return m
+
+
+class Cfg5F32(Cfg5):
+    """cfg5 with every contraction on fp32 operands (BASELINE configs[4] states no dtype)."""
+    name, dtype, peak = 'cfg5', 'f32', F32_PEAK_TFLOPS
+    workload = ('cfg5 (fp32 operands): vidTIMIT-shaped synthetic (video 3x64x64 + audio 10x1281, Bernoulli), MultiDMM BFVI, conv '
+                'encoders/decoders, z=h=256, T=128, B=%d per GPU, ragged lengths 64..128, 50%% independent missingness, '
+                'train_particles=25; every contraction with fp32 operands (sweeps on the f32-input MFMA, image convolutions in the '
+                'library, audio stacks on csrc/audio_chain.hip with fp32 activations)')
+
+    @classmethod
+    def model(cls, models, device):
+        import torch
+        m = super().model(models, device)
+        m.sweep_dtype = m.conv_dtype = m.act_dtype = torch.float32
+        return m
+
+
 CONFIGS = {'cfg2': Cfg2, 'cfg3': Cfg3, 'cfg4': Cfg4, 'cfg5': Cfg5}
 
 
@@ -733,7 +764,11 @@ def run(cfg, args, world, rank, device, graph):
     # HIP-event time against the HBM peak
     conv_spans = {t: v for t, v in spans.items() if t.startswith('conv_wgrad')}
     rf_conv = roofline_bytes(timer, conv_spans) if conv_spans else None
-    for r in (rf, rf_k1, rf_conv):
+    # the audio plug-ins' launches (cfg5; csrc/audio_chain.hip): the one with the most device time, its algorithmic bytes
+    # (frames, activations and gradients it has to read / write once; target rows nobody scores are not read) over its time
+    audio_spans = {t: v for t, v in spans.items() if t.startswith('audio_')}
+    rf_audio = roofline_bytes(timer, audio_spans) if audio_spans else None
+    for r in (rf, rf_k1, rf_conv, rf_audio):
         if r is not None:
             r['timing'] = timing_note
     out_cfg = {'workload': cfg.workload % b_dim, 'global_batch': world * b_dim, 'seq_len': cfg.T,
@@ -758,6 +793,7 @@ def run(cfg, args, world, rank, device, graph):
         'roofline': rf,
         'roofline_k1': rf_k1,
         'roofline_conv': rf_conv,
+        'roofline_audio': rf_audio,
         'roofline_step': roofline_step(cfg, b_dim, 1e3 * elapsed / args.steps),
         # library calls by device time per step: HIP-event spans minus the calibrated cost of an empty event pair
         # per call (eager probe steps; per-KERNEL device times: profiles/*_kernel_stats.md from rocprofv3)
@@ -861,7 +897,7 @@ def main():
             a5.steps, a5.warmup, a5.batch = 5, 2, 0
             r5 = run(Cfg5, a5, 1, 0, device, graph=not args.eager)
             out['extra']['cfg5'] = {k: r5[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline', 'roofline_k1',
-                                                       'calls_ms_per_step')}
+                                                       'roofline_conv', 'roofline_audio', 'calls_ms_per_step')}
             del r5
             torch.cuda.empty_cache()
             # the same cfg3 step with fp32 operands everywhere (the mode whose parity tests hold 1e-5): library
@@ -875,6 +911,14 @@ def main():
             out['extra']['cfg3_f32']['own_convolutions'] = {k: rown[k] for k in ('value', 'ms_per_step')}
             out['extra']['cfg3_f32']['own_convolutions']['loss'] = rown['config'].get('loss')
             del rown
+            # cfg4 / cfg5 with fp32 operands too (their BASELINE strings state no dtype): eager, two timed steps each
+            a45 = argparse.Namespace(**vars(args))
+            a45.steps, a45.warmup, a45.batch = 2, 1, 0
+            for key, c45 in (('cfg4_f32', Cfg4F32), ('cfg5_f32', Cfg5F32)):
+                torch.cuda.empty_cache()
+                r45 = run(c45, a45, 1, 0, device, graph=False)
+                out['extra'][key] = {k: r45[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config')}
+                del r45
             # the callers either side of the step: on-device batch preparation and the evaluation body
             del rf32, r4, r2
             torch.cuda.empty_cache()

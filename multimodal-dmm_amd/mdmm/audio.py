@@ -150,6 +150,21 @@ def _bn_adjoint(bn, y, stats, part, parts, group_n, groups, channels, length, ga
     return means, dgb[0], dgb[1]
 
 
+def _nb(*tensors):
+    """Algorithmic bytes of a launch = the tensors it has to read or write once (for ops.KernelTimer; 0 when nobody times)."""
+    if ops.TIMER is None:
+        return 0
+    return sum(t.numel() * t.element_size() for t in tensors if t is not None)
+
+
+def _scored_bytes(tg, mask):
+    """Bytes of the target rows a loss launch reads (rows nobody scores are skipped); a host read, timing runs only."""
+    if ops.TIMER is None:
+        return 0
+    per_row = tg[0].numel() * 4 if mask is None else tg.numel() * 4 // mask.numel()
+    return int(per_row * (tg.shape[0] if mask is None else float((mask != 0).sum())))
+
+
 def _ws(a, parts, dev):
     nw = a.CS * a.CB * 3
     return torch.empty(parts * (nw + 16), device=dev, dtype=torch.float32)
@@ -187,7 +202,7 @@ class _AudioDecNllFn(torch.autograd.Function):
             parts = _parts(a)
             part = torch.empty(passes * cb * parts * 2, device=dev, dtype=torch.float64)
             a.out_stats = _ptr(part)
-            _call('mdmm_audio_fwd', C.byref(a), tag='audio_up[S=%d]' % s)
+            _call('mdmm_audio_fwd', C.byref(a), tag='audio_up[S=%d]' % s, nbytes=_nb(cur, y))
             stats.append(_bn_finalize(blocks[k][1], y, part, parts, rows, passes, cb, 2 * s - 1, gam[k], bet[k], bias[k]))
             ys.append(y)
             cur = y
@@ -201,7 +216,7 @@ class _AudioDecNllFn(torch.autograd.Function):
             for i, v in enumerate(pass_weight):
                 pw[i] = float(v)
         a.pass_w = (C.c_float * 8)(*pw)
-        _call('mdmm_audio_fwd', C.byref(a), tag='audio_up_loss')
+        _call('mdmm_audio_fwd', C.byref(a), tag='audio_up_loss', nbytes=_nb(cur) + _scored_bytes(tg, mask))
         ctx.save_for_backward(x, ys[0], ys[1], stats[0], stats[1], tg, mask, *w, *[t for t in gam[:2]], *[t for t in bet[:2]],
                               bias[2])
         ctx.meta = (n, rows, passes, float(weight), pw, int(fast), int(bool(relu_plain)), act)
@@ -233,7 +248,7 @@ class _AudioDecNllFn(torch.autograd.Function):
         dw2 = torch.empty_like(w2)
         db2 = torch.empty(10, device=dev, dtype=torch.float32)
         a.gin, a.in_adj, a.ws, a.dw, a.dbias = _ptr(gin2), _ptr(adj), _ptr(ws), _ptr(dw2), _ptr(db2)
-        _call('mdmm_audio_bwd', C.byref(a), tag='audio_up_loss_bwd')
+        _call('mdmm_audio_bwd', C.byref(a), tag='audio_up_loss_bwd', nbytes=_nb(y1, gin2) + _scored_bytes(tg, mask))
         means1, dg1, dbt1 = _bn_adjoint(blocks[1][1], y1, st1, adj, parts, rows, passes, 4, 641, g1, b1)
         # middle layer (8 -> 4): its output gradient gets BatchNorm 1's adjoint while it is staged
         a = _layer(n, shapes[1], True, act, w1, None)
@@ -247,7 +262,7 @@ class _AudioDecNllFn(torch.autograd.Function):
         ws = _ws(a, parts, dev)
         dw1 = torch.empty_like(w1)
         a.gin, a.in_adj, a.ws, a.dw = _ptr(gin1), _ptr(adj), _ptr(ws), _ptr(dw1)
-        _call('mdmm_audio_bwd', C.byref(a), tag='audio_up_bwd[S=321]')
+        _call('mdmm_audio_bwd', C.byref(a), tag='audio_up_bwd[S=321]', nbytes=_nb(y0, y1, gin2, gin1))
         means0, dg0, dbt0 = _bn_adjoint(blocks[0][1], y0, st0, adj, parts, rows, passes, 8, 321, g0, b0)
         # first layer (16 -> 8) on the ReLU'd features
         a = _layer(n, shapes[0], True, act, w0, None)
@@ -262,7 +277,7 @@ class _AudioDecNllFn(torch.autograd.Function):
             gx = torch.empty_like(x)
             a.gin = _ptr(gx)
         a.ws, a.dw = _ptr(ws), _ptr(dw0)
-        _call('mdmm_audio_bwd', C.byref(a), tag='audio_up_bwd[S=161]')
+        _call('mdmm_audio_bwd', C.byref(a), tag='audio_up_bwd[S=161]', nbytes=_nb(x, y0, gin1, gx))
         z = lambda t: None if t is None else torch.zeros_like(t)
         # params order: (conv.weight, conv.bias, bn.weight, bn.bias) x 2, conv.weight, conv.bias
         grads = (dw0, z(blocks[0][0].bias), dg0, dbt0, dw1, z(blocks[1][0].bias), dg1, dbt1, dw2, db2)
@@ -318,7 +333,7 @@ class _AudioEncFn(torch.autograd.Function):
                 parts = _parts(a)
                 part = torch.empty(cs * parts * 2, device=dev, dtype=torch.float64)
                 a.out_stats = _ptr(part)
-            _call('mdmm_audio_fwd', C.byref(a), tag='audio_down[S=%d]' % s)
+            _call('mdmm_audio_fwd', C.byref(a), tag='audio_down[S=%d]' % s, nbytes=_nb(cur, y))
             if not last:
                 stats.append(_bn_finalize(blocks[k][1], y, part, parts, n, 1, cs, s, gam[k], bet[k], bias[k]))
             ys.append(y)
@@ -350,7 +365,7 @@ class _AudioEncFn(torch.autograd.Function):
         dw2 = torch.empty_like(w2)
         db2 = torch.empty(16, device=dev, dtype=torch.float32)
         a.gin, a.in_adj, a.ws, a.dw, a.dbias = _ptr(gin1), _ptr(adj), _ptr(ws), _ptr(dw2), _ptr(db2)
-        _call('mdmm_audio_bwd', C.byref(a), tag='audio_down_bwd[S=161]')
+        _call('mdmm_audio_bwd', C.byref(a), tag='audio_down_bwd[S=161]', nbytes=_nb(y1, gf, gin1))
         means1, dg1, dbt1 = _bn_adjoint(blocks[1][1], y1, st1, adj, parts, n, 1, 8, 321, g1, b1)
         # middle layer (4 -> 8)
         a = _layer(n, STACK[1], False, act, w1, None)
@@ -364,7 +379,7 @@ class _AudioEncFn(torch.autograd.Function):
         ws = _ws(a, parts, dev)
         dw1 = torch.empty_like(w1)
         a.gin, a.in_adj, a.ws, a.dw = _ptr(gin0), _ptr(adj), _ptr(ws), _ptr(dw1)
-        _call('mdmm_audio_bwd', C.byref(a), tag='audio_down_bwd[S=321]')
+        _call('mdmm_audio_bwd', C.byref(a), tag='audio_down_bwd[S=321]', nbytes=_nb(y0, y1, gin1, gin0))
         means0, dg0, dbt0 = _bn_adjoint(blocks[0][1], y0, st0, adj, parts, n, 1, 4, 641, g0, b0)
         # first layer (10 -> 4) on the frames: weight gradient only
         a = _layer(n, STACK[0], False, act, w0, None)
@@ -375,7 +390,7 @@ class _AudioEncFn(torch.autograd.Function):
         ws = _ws(a, parts, dev)
         dw0 = torch.empty_like(w0)
         a.ws, a.dw = _ptr(ws), _ptr(dw0)
-        _call('mdmm_audio_bwd', C.byref(a), tag='audio_down_bwd[S=641]')
+        _call('mdmm_audio_bwd', C.byref(a), tag='audio_down_bwd[S=641]', nbytes=_nb(x, y0, gin0))
         z = lambda t: None if t is None else torch.zeros_like(t)
         grads = (dw0, z(blocks[0][0].bias), dg0, dbt0, dw1, z(blocks[1][0].bias), dg1, dbt1, dw2, db2)
         return (None, None, None) + grads
