@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MDMM_ABI_VERSION 32
+#define MDMM_ABI_VERSION 33
 #define MDMM_MAX_EXPERTS 8 /* observation / filter experts fused per step (dmm.py:387-395) */
 #define MDMM_MAX_PASSES 8  /* ELBO passes swept together: 1 multimodal + M unimodal (dgts.py:119-129) */
 
@@ -826,6 +826,13 @@ typedef struct mdmm_audio {
   float* ws;             /* mdmm_audio_parts * (CS*CB*3 + C_out) floats */
   float* dw;             /* [CS][CB][3] */
   float* dbias;          /* [C_out] or NULL */
+  /* Frames of `in` / `gin` (in_stride) and of `out` / `gout` (out_stride) that lie further apart than their own length, in
+   * elements; 0 = dense.  The 2576-wide side of the plug-ins' Linear layers (z_to_feat 256 -> 2576, the encoder heads 2576 ->
+   * 256: common.py:232-236, 270-273) is handed around as rows of 2816 = 11 x 256 so that those layers run on the
+   * shape-specialised head kernels (csrc/gemm_heads.hip: expand / contract / wgrad want whole 256- or 128-column blocks):
+   * a launch that WRITES such rows (forward `out`, backward `gin`) also writes zeros behind each frame.  Not with the loss
+   * form or in_frames.  */
+  int32_t in_stride, out_stride;
 } mdmm_audio_t;
 int mdmm_audio_supported(const mdmm_audio_t* args);
 int mdmm_audio_parts(const mdmm_audio_t* args);      /* workgroups of both launches = slabs of out_stats / in_adj / ws */

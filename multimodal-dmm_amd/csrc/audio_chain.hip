@@ -261,6 +261,11 @@ __device__ __forceinline__ void copy_out(const T* ob, T* __restrict__ dst) {
     if (k < P::K - 1 || q < P::NP) *reinterpret_cast<uint2*>(dst + (size_t)q * P::VN) = *reinterpret_cast<const uint2*>(ob + q * P::VN);
   }
 }
+// zeros behind a frame whose row is longer than the frame (mdmm_audio_t.in_stride / out_stride): `n_el` elements, 8-byte pieces
+template <typename T> __device__ __forceinline__ void zero_tail(T* __restrict__ dst, int n_el) {
+  constexpr int VN = V8<T>::N;
+  for (int i = threadIdx.x * VN; i < n_el; i += NT * VN) *reinterpret_cast<uint2*>(dst + i) = uint2{0u, 0u};
+}
 template <int NEL, typename T> __device__ __forceinline__ void zero_frame(T* __restrict__ dst) {
   using P = Pieces<NEL, T>;
 #pragma unroll
@@ -509,6 +514,7 @@ __global__ __launch_bounds__(NT, 4) void audio_up_fwd_kernel(const mdmm_audio_t 
   const T* __restrict__ in = (const T*)a.in;
   T* __restrict__ out = (T*)a.out;
   constexpr int IN_EL = SH::CS * SH::S, OUT_EL = SH::CB * SH::LB;
+  const size_t in_st = a.in_stride ? (size_t)a.in_stride : (size_t)IN_EL;
   float bias[SH::CB];
 #pragma unroll
   for (int cb = 0; cb < SH::CB; ++cb) bias[cb] = a.bias ? a.bias[cb] : 0.f;
@@ -521,12 +527,12 @@ __global__ __launch_bounds__(NT, 4) void audio_up_fwd_kernel(const mdmm_audio_t 
     for (int cb = 0; cb < SH::CB; ++cb) { s1[cb] = 0.f; s2[cb] = 0.f; }
     const int end = (g + 1) * out_gn;
     int n = g * out_gn + blockIdx.x;
-    if (n < end) fa.load(in + (size_t)n * IN_EL);
+    if (n < end) fa.load(in + (size_t)n * in_st);
     while (n < end) {
       const int nn = n + gridDim.x;
       if (norm) put_small<SH, T, true, false>(fa, as, nullptr, tab, n / a.in_norm.group_n, relu);
       else put_small<SH, T, false, false>(fa, as, nullptr, tab, 0, 0);
-      if (nn < end) fa.load(in + (size_t)nn * IN_EL);
+      if (nn < end) fa.load(in + (size_t)nn * in_st);
       __syncthreads();
 #pragma unroll
       for (int it = 0; it < SH::ITER; ++it) {
@@ -695,6 +701,7 @@ __global__ __launch_bounds__(NT, 3) void audio_up_bwd_kernel(const mdmm_audio_t 
   const T* __restrict__ ypre = (const T*)a.out;
   T* __restrict__ gin = (T*)a.gin;
   constexpr int IN_EL = SH::CS * SH::S, OUT_EL = SH::CB * SH::LB;
+  const size_t in_st = a.in_stride ? (size_t)a.in_stride : (size_t)IN_EL;
   float acc[SH::NA], accb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < SH::NA; ++i) acc[i] = 0.f;
@@ -710,7 +717,7 @@ __global__ __launch_bounds__(NT, 3) void audio_up_bwd_kernel(const mdmm_audio_t 
     const int end = (g + 1) * in_gn;
     int n = g * in_gn + blockIdx.x;
     if (n < end) {
-      fa.load(in + (size_t)n * IN_EL);
+      fa.load(in + (size_t)n * in_st);
       fg.load(gout + (size_t)n * OUT_EL);
       if (lz) fy.load(ypre + (size_t)n * OUT_EL);
     }
@@ -722,7 +729,7 @@ __global__ __launch_bounds__(NT, 3) void audio_up_bwd_kernel(const mdmm_audio_t 
       if (lz) put_big_grad<SH, T, true>(fg, fy, big, lazy, n / a.out_norm.group_n, a.out_norm.relu);
       else put_big_grad<SH, T, false>(fg, fy, big, lazy, 0, 0);
       if (nn < end) {
-        fa.load(in + (size_t)nn * IN_EL);
+        fa.load(in + (size_t)nn * in_st);
         fg.load(gout + (size_t)nn * OUT_EL);
         if (lz) fy.load(ypre + (size_t)nn * OUT_EL);
       }
@@ -743,7 +750,10 @@ __global__ __launch_bounds__(NT, 3) void audio_up_bwd_kernel(const mdmm_audio_t 
         }
       }
       __syncthreads();
-      if (gin) copy_out<IN_EL, T>(gb, gin + (size_t)n * IN_EL);
+      if (gin) {
+        copy_out<IN_EL, T>(gb, gin + (size_t)n * in_st);
+        if (in_st > (size_t)IN_EL) zero_tail<T>(gin + (size_t)n * in_st + IN_EL, (int)(in_st - IN_EL));
+      }
       n = nn;
     }
     if (norm && a.in_adj)
@@ -907,6 +917,7 @@ __global__ __launch_bounds__(NT, 3) void audio_down_fwd_kernel(const mdmm_audio_
   const TI* __restrict__ in = (const TI*)a.in;
   T* __restrict__ out = (T*)a.out;
   constexpr int IN_EL = SH::CB * SH::LB, OUT_EL = SH::CS * SH::S;
+  const size_t out_st = a.out_stride ? (size_t)a.out_stride : (size_t)OUT_EL;
   float bias[SH::CS];
 #pragma unroll
   for (int cs = 0; cs < SH::CS; ++cs) bias[cs] = a.bias ? a.bias[cs] : 0.f;
@@ -951,7 +962,8 @@ __global__ __launch_bounds__(NT, 3) void audio_down_fwd_kernel(const mdmm_audio_
         }
       }
       __syncthreads();
-      copy_out<OUT_EL, T>(ob, out + (size_t)n * OUT_EL);
+      copy_out<OUT_EL, T>(ob, out + (size_t)n * out_st);
+      if (out_st > (size_t)OUT_EL) zero_tail<T>(out + (size_t)n * out_st + OUT_EL, (int)(out_st - OUT_EL));
       n = nn;
     }
     if (a.out_stats)
@@ -1005,6 +1017,7 @@ __global__ __launch_bounds__(NT, 2) void audio_down_bwd_kernel(const mdmm_audio_
   const T* __restrict__ ypre = (const T*)a.out;
   T* __restrict__ gin = FRAMES ? nullptr : (T*)a.gin;
   constexpr int IN_EL = SH::CB * SH::LB, OUT_EL = SH::CS * SH::S;
+  const size_t out_st = a.out_stride ? (size_t)a.out_stride : (size_t)OUT_EL;      // (gout lies as `out` of the forward does)
   float acc[SH::NA], accb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < SH::NA; ++i) acc[i] = 0.f;
@@ -1027,7 +1040,7 @@ __global__ __launch_bounds__(NT, 2) void audio_down_bwd_kernel(const mdmm_audio_
     int n = g * in_gn + blockIdx.x;
     if (n < end) {
       fa.template load_part<0, KH>(in + (size_t)n * IN_EL);
-      fg.load(gout + (size_t)n * OUT_EL);
+      fg.load(gout + (size_t)n * out_st);
       if (lz) fy.load(ypre + (size_t)n * OUT_EL);
     }
     while (n < end) {
@@ -1052,7 +1065,7 @@ __global__ __launch_bounds__(NT, 2) void audio_down_bwd_kernel(const mdmm_audio_
       else put_small_grad<SH, T, false>(fg, fy, ds, lazy, 0, 0);
       if (nn < end) {
         fa.template load_part<0, KH>(in + (size_t)nn * IN_EL);
-        fg.load(gout + (size_t)nn * OUT_EL);
+        fg.load(gout + (size_t)nn * out_st);
         if (lz) fy.load(ypre + (size_t)nn * OUT_EL);
       }
       __syncthreads();
@@ -1142,6 +1155,12 @@ int check(const mdmm_audio_t* a, bool bwd) {
   if (!a || a->N < 1 || shape_id(a) < 0 || !a->weight || !a->in) return MDMM_E_ARG;
   if (!norm_ok(a->in_norm, a->N) || !norm_ok(a->out_norm, a->N)) return MDMM_E_ARG;
   if (a->in_frames && (a->up || a->in_norm.mean)) return MDMM_E_ARG;
+  {
+    const int in_el = a->up ? a->CS * a->S : a->CB * (2 * a->S - 1), out_el = a->up ? a->CB * (2 * a->S - 1) : a->CS * a->S;
+    const int vn = a->act_bf16 ? 4 : 2;
+    if (a->in_stride && (a->in_stride < in_el || (a->in_stride % vn) || a->target || a->in_frames || !a->up)) return MDMM_E_ARG;
+    if (a->out_stride && (a->out_stride < out_el || (a->out_stride % vn) || a->target || a->up || a->out_norm.mean)) return MDMM_E_ARG;
+  }
   if (a->target) {
     if (!a->up || a->passes < 1 || a->passes > 8 || a->N % a->passes) return MDMM_E_ARG;
     if (a->in_norm.mean && a->in_norm.group_n != a->N / a->passes) return MDMM_E_ARG;

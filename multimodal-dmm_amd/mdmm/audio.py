@@ -21,6 +21,30 @@ from . import ops
 from .ops import _call, _ptr, _f32c, _gdev, _need_gpu, _term_acc, _term_out, _term_done, _row_mask, _lead_rows
 
 STACK = ((4, 10, 641), (8, 4, 321), (16, 8, 161))      # (CS, CB, S) of the three layers, big end first
+FEAT = 16 * 161          # the stacks' feature side, (N, 16, 161) flattened
+# ... handed to / taken from the Linear layers as rows of 2816 = 11 x 256 (zeros behind each frame) where those layers run
+# on the shape-specialised head kernels (csrc/gemm_heads.hip want whole 256- / 128-column blocks on their long side; on the
+# generic 128 x 128 tiles the 256 <-> 2576 products ran at 0.5-1.0 TB/s of their bytes, tools/time_audio_gemms.py)
+FEAT_PAD = (FEAT + 255) // 256 * 256
+
+
+def padded_rows(n_rows):
+    """True where the feature side travels as FEAT_PAD-wide rows: bf16 operands and activations, enough rows for the own GEMMs."""
+    return (ops.CONV_OPERANDS is torch.bfloat16 and ops.ACT_STORAGE is torch.bfloat16 and n_rows >= 512 and n_rows % 4 == 0)
+
+
+def pad_linear_out(layer):
+    """(weight, bias) of a Linear whose OUTPUT side is the feature side (z_to_feat), zero rows up to FEAT_PAD."""
+    import torch.nn.functional as F
+    w = F.pad(layer.weight, (0, 0, 0, FEAT_PAD - layer.weight.shape[0]))
+    b = None if layer.bias is None else F.pad(layer.bias, (0, FEAT_PAD - layer.bias.shape[0]))
+    return w, b
+
+
+def pad_linear_in(layer):
+    """weight of a Linear whose INPUT side is the feature side (the encoder heads), zero columns up to FEAT_PAD."""
+    import torch.nn.functional as F
+    return F.pad(layer.weight, (0, FEAT_PAD - layer.weight.shape[1]))
 
 
 def _blocks(stack, kind, last_has_norm=False):
@@ -177,8 +201,11 @@ class _AudioDecNllFn(torch.autograd.Function):
     def forward(ctx, feat, target, mask, rows, weight, into, passes, pass_weight, fast, relu_plain, blocks, *params):
         _need_gpu(feat, target)
         ctx.set_materialize_grads(False)
-        x = ops._act(feat).reshape(-1, 16, 161)
-        n = x.shape[0]
+        x = ops._act(feat)
+        if x.dim() != 2 or x.shape[1] not in (FEAT, FEAT_PAD):
+            x = x.reshape(-1, FEAT)
+        n, stride = x.shape[0], x.shape[1]           # (rows of FEAT_PAD: the frames lie `stride` elements apart)
+        ctx.feat_shape = tuple(feat.shape)
         if n != passes * rows:
             raise ValueError('%d frames for %d passes of %d rows' % (n, passes, rows))
         tg = _f32c(target)
@@ -197,6 +224,8 @@ class _AudioDecNllFn(torch.autograd.Function):
             a.in_ = _ptr(cur)
             if k > 0:
                 _set_norm(a.in_norm, stats[k - 1], gam[k - 1], bet[k - 1], rows)
+            elif stride != FEAT:
+                a.in_stride = stride
             y = torch.empty(n, cb, 2 * s - 1, device=dev, dtype=dt)
             a.out, a.out_group_n = _ptr(y), rows
             parts = _parts(a)
@@ -267,6 +296,8 @@ class _AudioDecNllFn(torch.autograd.Function):
         # first layer (16 -> 8) on the ReLU'd features
         a = _layer(n, shapes[0], True, act, w0, None)
         a.in_, a.out, a.gout = _ptr(x), _ptr(y0), _ptr(gin1)
+        if x.shape[1] != FEAT:
+            a.in_stride = x.shape[1]
         _set_norm(a.out_norm, st0, g0, b0, rows)
         a.out_bwd_means, a.in_relu_plain = _ptr(means0), relu_plain
         gx = None
@@ -281,6 +312,8 @@ class _AudioDecNllFn(torch.autograd.Function):
         z = lambda t: None if t is None else torch.zeros_like(t)
         # params order: (conv.weight, conv.bias, bn.weight, bn.bias) x 2, conv.weight, conv.bias
         grads = (dw0, z(blocks[0][0].bias), dg0, dbt0, dw1, z(blocks[1][0].bias), dg1, dbt1, dw2, db2)
+        if gx is not None:
+            gx = gx.reshape(ctx.feat_shape)
         return (gx, None, None, None, None, None, None, None, None, None, None) + grads
 
 
@@ -309,6 +342,7 @@ class _AudioEncFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         x = _f32c(frames).reshape(-1, 10, 1281)
         n, dev = x.shape[0], x.device
+        width = FEAT_PAD if (act_dtype == torch.bfloat16 and padded_rows(n)) else FEAT
         dt = act_dtype
         act = 1 if dt == torch.bfloat16 else 0
         w = [_f32c(blocks[k][0].weight.detach()) for k in range(3)]
@@ -327,8 +361,11 @@ class _AudioEncFn(torch.autograd.Function):
                 a.in_frames, a.seen = 1, _ptr(seen)
             else:
                 _set_norm(a.in_norm, stats[k - 1], gam[k - 1], bet[k - 1], n)
-            y = torch.empty(n, cs, s, device=dev, dtype=dt)
+            y = torch.empty(n, cs, s, device=dev, dtype=dt) if (not last or width == FEAT) else \
+                torch.empty(n, width, device=dev, dtype=dt)
             a.out, a.out_group_n = _ptr(y), n
+            if last and width != FEAT:
+                a.out_stride = width
             if not last:
                 parts = _parts(a)
                 part = torch.empty(cs * parts * 2, device=dev, dtype=torch.float64)
@@ -353,10 +390,12 @@ class _AudioEncFn(torch.autograd.Function):
         gf = ops._act(gf)
         if gf.dtype != dt:
             gf = gf.to(dt)
-        gf = gf.reshape(n, 16, 161)
+        gf = gf.reshape(n, -1)
         # last layer (8 -> 16, no norm behind it)
         a = _layer(n, STACK[2], False, act, w2, None)
         a.in_, a.gout = _ptr(y1), _ptr(gf)
+        if gf.shape[1] != FEAT:
+            a.out_stride = gf.shape[1]
         _set_norm(a.in_norm, st1, g1, b1, n)
         gin1 = torch.empty_like(y1)
         parts = _parts(a)
@@ -397,5 +436,6 @@ class _AudioEncFn(torch.autograd.Function):
 
 
 def encode_frames(blocks, frames, act_dtype):
-    """(features (N, 16, 161) in act_dtype, seen (N,) fp32) of (N, 10, 1281) fp32 frames whose NaN mark missing values."""
+    """(features (N, 16 * 161) -- or (N, FEAT_PAD) with zeros behind each frame, padded_rows -- in act_dtype, seen (N,) fp32)
+    of (N, 10, 1281) fp32 frames whose NaN mark missing values."""
     return _AudioEncFn.apply(frames, act_dtype, blocks, *decoder_params(blocks))

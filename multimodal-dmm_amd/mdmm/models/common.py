@@ -296,7 +296,13 @@ class AudioEncoder(_GaussHead):
         from .. import ops, audio
         act = ops.ACT_STORAGE if ops.CONV_OPERANDS is torch.bfloat16 else torch.float32
         feats, seen = audio.encode_frames(blocks, x, act)
-        flat = feats.view(-1, self.feat_dim)
+        flat = feats.view(feats.shape[0], -1)
+        if flat.shape[1] != self.feat_dim:
+            # rows of audio.FEAT_PAD (zeros behind each frame): the heads on the shape-specialised kernels, their weights
+            # with zero columns there
+            lm, ls = self.feat_to_z_mean, self.feat_to_z_std[0]
+            return (ops.linear_tiles(flat, audio.pad_linear_in(lm), lm.bias),
+                    self.feat_to_z_std[1](ops.linear_tiles(flat, audio.pad_linear_in(ls), ls.bias)), seen)
         return (ops.plug_linear(self.feat_to_z_mean, flat),
                 self.feat_to_z_std[1](ops.plug_linear(self.feat_to_z_std[0], flat)), seen)
 
@@ -360,7 +366,12 @@ class AudioDecoder(_ProbDecoder):
         of the target's rows, each with its own BatchNorm statistics (the stock module called pass by pass)."""
         from .. import ops, audio
         relu_plain = False
-        if isinstance(self.z_to_feat[1], nn.ReLU):
+        if isinstance(self.z_to_feat[1], nn.ReLU) and audio.padded_rows(z.shape[0]) and tuple(self.feat_shape) == (16, 161):
+            # rows of audio.FEAT_PAD (the product on the weight-stationary head kernel, zero weight rows behind the 2576)
+            w, b = audio.pad_linear_out(self.z_to_feat[0])
+            x = ops._LinearTilesFn.apply(z, w, b, torch.bfloat16, True)
+            relu_plain = bool(x.requires_grad and ops.take_owed_relu(x, x))
+        elif isinstance(self.z_to_feat[1], nn.ReLU):
             feat = ops.plug_linear(self.z_to_feat[0], z, act_out=True, relu=True)
             x = feat.view(-1, *self.feat_shape)
             # (the ReLU in the GEMM's epilogue owes its adjoint: the first layer's backward launch applies it)

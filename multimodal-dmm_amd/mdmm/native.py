@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('MDMM_LIB') or os.path.join(_HERE, 'lib', 'libmdmm_hip
 
 MAX_EXPERTS = 8
 MAX_PASSES = 8
-ABI_VERSION = 32
+ABI_VERSION = 33
 PREC_F32, PREC_BF16 = 0, 1
 
 SYMBOLS = [
@@ -205,7 +205,7 @@ class Audio(C.Structure):
                  ('out_group_n', C.c_int32), ('passes', C.c_int32), ('target', _P), ('row_mask', _P),
                  ('fast', C.c_int32), ('loss_weight', C.c_float), ('pass_w', C.c_float * 8), ('loss', _P), ('gscale', _P),
                  ('gout', _P), ('out_norm', AudioNorm), ('out_bwd_means', _P), ('gin', _P), ('in_adj', _P), ('ws', _P),
-                 ('dw', _P), ('dbias', _P)])
+                 ('dw', _P), ('dbias', _P), ('in_stride', C.c_int32), ('out_stride', C.c_int32)])
 
 
 VRNN_MAX_MODS = 4

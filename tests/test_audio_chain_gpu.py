@@ -164,6 +164,121 @@ def test_audio_encoder_node(act, dev):
             assert _rel(b, r) < (2e-3 if bf16 else 1e-5), (k, _rel(b, r))
 
 
+
+def _run_512(dev, act, padded, monkeypatch):
+    """Decoder node (512 frames, one pass) and encoder node (512 frames) on the chip; every gradient by name, and the
+    launches' tags."""
+    from mdmm import ops, audio
+    if not padded:
+        monkeypatch.setattr(audio, 'padded_rows', lambda n: False)
+    C = _models()
+    torch.manual_seed(5)
+    dec = C.AudioDecoder(256).to(dev).train()
+    enc = C.AudioEncoder(256).to(dev).train()
+    with torch.no_grad():
+        for m in list(dec.modules()) + list(enc.modules()):
+            if isinstance(m, nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    t_max, b_dim = 8, 64
+    rows = t_max * b_dim
+    g = torch.Generator().manual_seed(7)
+    z = torch.randn(rows, 256, generator=g) * 0.5
+    target = torch.rand(t_max, b_dim, 10, 1281, generator=g)
+    target[6:, 3] = float('nan')
+    mask = torch.ones(t_max, b_dim)
+    mask[6:, 3] = 0
+    x = torch.rand(rows, 10, 1281, generator=g)
+    x[5] = float('nan')
+    cm = torch.randn(rows, 256, generator=g).double()
+    bf16 = act == 'bf16'
+    zd = z.to(dev).requires_grad_(True)
+    total = ops.LossSum(dev)
+    ops.TIMER = timer = ops.KernelTimer()
+    try:
+        with ops.conv_operands(torch.bfloat16 if bf16 else None, act=torch.bfloat16 if bf16 else torch.float32):
+            assert audio.padded_rows(rows) == padded
+            dec.nll(zd, audio.decoder_plan(dec), target.to(dev), mask.to(dev), 1.0, total, 1, [1.0], bf16)
+            loss = total.total()
+            loss.backward()
+            mean, std, seen = enc.encode_frames(x.to(dev), audio.encoder_plan(enc))
+            ((mean.double() * cm.to(dev)).sum() + std.double().sum()).backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.TIMER = None
+    out = {'loss': loss.detach(), 'mean': mean.detach(), 'std': std.detach(), 'seen': seen.detach(), 'dec.z': zd.grad}
+    out.update({'dec.' + k: p.grad for k, p in dec.named_parameters()})
+    out.update({'enc.' + k: p.grad for k, p in enc.named_parameters()})
+    data = dict(z=z, target=target, mask=mask, x=x, cm=cm)
+    return out, set(timer.spans), (dec, enc), data
+
+
+_WIDE = {'linear_fwd[256x2816]', 'linear_fwd[2816x256]', 'linear_wgrad[256x2816]'}
+_BEHIND_A_NORM = ('dec.deconv_stack.0.deconv.bias', 'dec.deconv_stack.1.deconv.bias',
+                  'enc.conv_stack.0.conv.bias', 'enc.conv_stack.1.conv.bias')
+
+
+def test_audio_padded_feature_rows_are_a_layout(dev, monkeypatch):
+    """512 frames and bf16 activations: the 2576-wide feature side travels as rows of 2816 (zeros behind each frame) so that
+    z_to_feat and the encoder heads run on the shape-specialised head kernels (audio.padded_rows; mdmm_audio_t.in_stride /
+    out_stride).  The stacks' own results are THE SAME BITS either way (the stride is an address, not arithmetic); the
+    Linear layers around them differ by their kernels' summation order alone."""
+    a, tags_a, _, _ = _run_512(dev, 'bf16', True, monkeypatch)
+    b, tags_b, _, _ = _run_512(dev, 'bf16', False, monkeypatch)
+    assert _WIDE <= tags_a and not (_WIDE & tags_b), (sorted(tags_a), sorted(tags_b))
+    assert torch.equal(a['seen'], b['seen']) and torch.equal(a['loss'], b['loss'])
+    for k in a:
+        if k in _BEHIND_A_NORM or k in ('seen', 'loss'):
+            continue
+        assert a[k].shape == b[k].shape, k
+        if 'stack' in k:
+            assert torch.equal(a[k], b[k]), k
+        else:
+            e = _rel(a[k], b[k])
+            helpers.note('audio_512[padded vs generic].%s' % k, e)
+            assert e < 1e-5, (k, e)
+
+
+@pytest.mark.parametrize('act', ['fp32', 'bf16'])
+def test_audio_nodes_at_512_frames(act, dev, monkeypatch):
+    """The same two nodes at 512 frames against the fp64 modules.  The gradients in front of the FIRST BatchNorm's adjoint
+    are sums of 164,352 terms per channel that cancel (the adjoint removes the mean, so the terms of the next sum add to
+    about zero): every fp32 rounding of a per-channel mean is repeated in all of them and grows with sqrt(n) against the
+    sum -- 3.6e-4 with fp32 activations where 15 frames give 3e-5 (PyTorch's CPU kernels accumulate these in fp64 and
+    show 1e-6; the fp32 arithmetic of a GPU BatchNorm is ours).  Bounds: 2-3x the measured margins
+    (profiles/r06_parity_measured.txt, audio_512[...])."""
+    out, tags, (dec, enc), d = _run_512(dev, act, act == 'bf16', monkeypatch)
+    bf16 = act == 'bf16'
+    dref, eref = copy.deepcopy(dec).double().cpu().train(), copy.deepcopy(enc).double().cpu().train()
+    for m in (dref, eref):
+        m.zero_grad()
+    # (the running statistics were updated by the run above; train-mode arithmetic does not read them)
+    zr = d['z'].double().requires_grad_(True)
+    loss_ref = _decoder_reference(dref, zr, d['target'].double(), d['mask'].double(), 1, [1.0], 1.0)
+    loss_ref.backward()
+    x = d['x']
+    x0 = torch.where(torch.isnan(x), torch.zeros_like(x), x).double()
+    mr, sr = eref(x0)
+    ((mr * d['cm']).sum() + sr.sum()).backward()
+    ref = {'dec.z': zr.grad}
+    ref.update({'dec.' + k: p.grad for k, p in dref.named_parameters()})
+    ref.update({'enc.' + k: p.grad for k, p in eref.named_parameters()})
+    assert abs(float(out['loss']) - float(loss_ref)) < (3e-3 if bf16 else 2e-6) * abs(float(loss_ref))
+    assert torch.equal(out['seen'].cpu() > 0, ~torch.isnan(x).flatten(1).any(1))
+    tol_v = 2e-2 if bf16 else 1e-5
+    assert _rel(out['mean'], mr) < tol_v and _rel(out['std'], sr) < tol_v
+    first = ('dec.z', 'dec.z_to_feat', 'enc.conv_stack.0')          # in front of the first BatchNorm's adjoint
+    bad = {}
+    for k, r in ref.items():
+        if k in _BEHIND_A_NORM:
+            continue
+        e = _rel(out[k], r)
+        helpers.note('audio_512[%s].grad.%s' % (act, k), e)
+        tol = (2e-1 if bf16 else 1.6e-3) if k.startswith(first) else (7e-2 if bf16 else 1e-4)
+        if e > tol:
+            bad[k] = e
+    assert not bad, bad
+
+
 def test_audio_nodes_match_the_layer_by_layer_route(dev, monkeypatch):
     """MDMM_AUDIO_FUSED=0 selects the route of models.common (csrc/conv1d.hip + batchnorm.hip + reduce.hip): the same
     MultiDMM.step on a small vidTIMIT-shaped batch either way (fp32 operands: the two routes differ by summation order)."""
