@@ -378,7 +378,7 @@ class MultiDMM(MultiDGTS):
         # the eager warm-up steps (creating a stream inside a graph capture ends it with a segmentation fault here)
         mine = self._mod_streams.setdefault(key, [])
         while len(mine) < n - 1:
-            mine.append(torch.cuda.Stream(device=self.z0_mean.device))
+            mine.append(ops.branch_stream(self.z0_mean.device))
         return mine[:n - 1]
 
     def _cat_head(self, m, z):
@@ -510,7 +510,7 @@ class MultiDMM(MultiDGTS):
         (ops.prior_match): left to the backward pass they are the last thing the autograd engine issues and end up
         as a 0.4 ms tail behind the K-particle sweep (tools/step_stamps.py).  Returns (loss, stream)."""
         if self._match_stream is None:
-            self._match_stream = torch.cuda.Stream(device=self.z0_mean.device)
+            self._match_stream = ops.branch_stream(self.z0_mean.device)
         third = self._match_stream
         for x in match_eps:
             x.record_stream(third)
@@ -607,7 +607,7 @@ class MultiDMM(MultiDGTS):
         # of its forward, so the overlap holds for the backward sweeps too.
         main = torch.cuda.current_stream()
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.z0_mean.device)
+            self._side_stream = ops.branch_stream(self.z0_mean.device)
         side = self._side_stream
         # tell the allocator the encoder outputs are also read on the side stream
         for mu, sd, seen in enc.values():

@@ -330,6 +330,25 @@ def wide_shape(cfg, bwd=False):
     return cfg.K <= 64
 
 
+_BRANCH_STREAMS_ANNOUNCED = False
+
+
+def branch_stream(device):
+    """A stream for one branch of a step (models/dmm.py: the two loss terms, the encoders, the prior-matching term run side
+    by side).  A parameter shared by two branches (a transition, a decoder used by both loss terms) then receives
+    gradients produced on a stream other than the one its AccumulateGrad node was made on; autograd orders the two
+    itself (torch/csrc/autograd/input_buffer.cpp) and warns once per process that the node "was kept alive from an
+    earlier iteration" -- it was not: tools/accgrad_probe.py finds no node of a finished step alive, here or in stock
+    modules.  The mismatch is this design, so the warning is switched off when the first branch stream is made."""
+    global _BRANCH_STREAMS_ANNOUNCED
+    if not _BRANCH_STREAMS_ANNOUNCED:
+        _BRANCH_STREAMS_ANNOUNCED = True
+        quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if quiet is not None:
+            quiet(False)
+    return torch.cuda.Stream(device=device)
+
+
 _WARNED_GENERIC_BWD = set()
 
 
