@@ -472,11 +472,11 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
         float s1[RT], s2[RT], s3[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          const int kb = 32 * (rt & (g.TPP - 1));
+          const int kl = live_rows(g, K, rt);
           float a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            if (kb + 8 * q + 8 <= K) {           // whole register group live (uniform)
+            if (8 * q + 8 <= kl) {               // whole register group live (uniform)
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 const float mm = m_[rt][4 * q + j];
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
             } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const bool live = kb + 8 * q + 4 * h + j < K;
+                const bool live = 8 * q + 4 * h + j < kl;
                 const float mm = live ? m_[rt][4 * q + j] : 0.f;
                 a1 += mm; a2 += live ? var_[rt][4 * q + j] : 0.f; a3 = fmaf(mm, mm, a3);
               }
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) e12[rt] = 0.f;
       // K = 25: row 24 is the one live row of a tile's last register group -- the four tiles' draws of it as one call
-      const bool one12 = RT == 4 && g.TPP == 1 && K == 25;
+      const bool one12 = RT == 4 && ((g.TPP == 1 && K == 25) || (g.ks == 25 && g.kt == 25));
       float e24[4] = {0.f, 0.f, 0.f, 0.f};
       if (one12 && (!last || a.samples)) eps_rows(a, noff, t_term, rowbase + 24, 32, n, e24);
 #pragma unroll
@@ -544,15 +544,15 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
             o_pm[o] = pm[rt]; o_ps[o] = ps[rt];
           }
         }
-        const int kb = 32 * (rt & (g.TPP - 1));
+        const int kl = live_rows(g, K, rt);
         float zs = 0.f;
         const bool need = pr.p >= 0 && (!last || a.samples);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float e[4] = {0.f, 0.f, 0.f, 0.f};
           if (q == 3 && one12) e[0] = need ? e24[rt & 3] : 0.f;       // (rows 25 .. 31 and the upper half: masked below)
-          else if (need && kb + 8 * q < K) eps_group(a, noff, t_term, rowbase + 32 * rt + 8 * q + 4 * h, n, e);
-          if (pr.p >= 0 && kb + 8 * q + 8 <= K) {          // whole register group live (uniform)
+          else if (need && 8 * q < kl) eps_group(a, noff, t_term, rowbase + 32 * rt + 8 * q + 4 * h, n, e);
+          if (pr.p >= 0 && 8 * q + 8 <= kl) {              // whole register group live (uniform)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float zz = fmaf(e[j], is, im);
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(NTHR) void wide_fwd_kernel(const mdmm_sweep_t a, co
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const bool live = pr.p >= 0 && kb + 8 * q + 4 * h + j < K;
+              const bool live = pr.p >= 0 && 8 * q + 4 * h + j < kl;
               const float zz = live ? fmaf(e[j], is, im) : 0.f;
               e[j] = live ? e[j] : 0.f;
               z[rt][4 * q + j] = zz;
@@ -1513,6 +1513,7 @@ int plan(const mdmm_sweep_t* a, bool bwd, WideGeo* g) {
   if ((int64_t)a->P * a->T * a->B * WD >= (1ll << 40)) return 0;
   const bool f32 = a->precision == MDMM_PREC_F32;
   g->n_pairs = a->P * a->B;
+  g->ks = 32; g->kt = 32;
   g->stamps = nullptr;
 #ifdef WIDE_STAMPS
   if (const char* e = getenv("MDMM_STAMP_PTR")) g->stamps = (unsigned long long*)strtoull(e, nullptr, 16);
@@ -1529,6 +1530,8 @@ int plan(const mdmm_sweep_t* a, bool bwd, WideGeo* g) {
   if (tpp == 3) tpp = 4;
   if (tpp > RT) return 0;
   g->TPP = tpp; g->NP = RT / tpp; g->ntab = RT;
+  // the parked forward of more particles than a tile of the one-round backward holds: that kernel's geometry
+  if (!bwd && !f32 && a->fwd_park && quad_shape(a)) { g->ks = a->K / 4; g->kt = a->K / 4; }
   return RT;
 }
 
@@ -1638,7 +1641,7 @@ int wide::wide_wgrad_launch(const WideWs& ws, bool f32, int CH, float* dw_partia
 
 int mdmm_wide_bwd_supported(const mdmm_sweep_t* a) {
   WideGeo g;
-  return plan(a, true, &g) != 0;
+  return mdmm_wide_bwd4_supported(a) || plan(a, true, &g) != 0;      // (the one-round backward takes shapes of its own)
 }
 
 extern "C" int mdmm_sweep_kld_fused(const mdmm_sweep_t* a) {

@@ -1,7 +1,8 @@
 // K-particle backward sweep of the wide family (z = h = 256, bf16 operands) in ONE round of the chip:
 // the reverse scan of MultiDMM.z_filter (dmm.py:319-412; adjoints of z_next 214-258, the gated
 // transition common.py:62-68, product_of_experts dgts.py:15-51, mean_of_experts 53-83 and
-// _sample_gauss 177-180) for FOUR (pass, sequence) pairs per workgroup, 4 K <= 100 live rows.
+// _sample_gauss 177-180) for FOUR (pass, sequence) pairs per workgroup, 4 K <= 100 live rows -- or (QUAD geometry,
+// wide_sweep.h quad_shape: 25 < K <= 100 particles, K % 4 == 0) for ONE pair whose particles are the four tiles' rows.
 //
 // The forward sweep of the same call (sweep_wide.hip, wide_fwd_kernel<false, 4, false>: the same four pairs per
 // workgroup, the same lanes) has kept what this kernel needs of the transition in mdmm_sweep_t.fwd_park
@@ -38,7 +39,7 @@ constexpr int LAYER_U4 = Op<false>::LAYER_U4;
 #endif
 constexpr int PF = B4_PF;                  // weight chunks in flight per wave
 constexpr int RT = PARK_PAIRS;             // row tiles = pairs per workgroup
-constexpr int KMAX = 25;                   // 3 images x 4 K rows x 528 B <= 160 KB
+constexpr int KMAX = PARK_KT;              // 3 images x 4 K rows x 528 B <= 160 KB
 
 // global-memory views of the packed weights, the spill and the park: as members of the argument
 // structs the pointers are generic, and generic (flat) loads count on the LDS counter too -- every
@@ -132,7 +133,9 @@ struct ExpD { const float *mean, *std, *mask; float *g_mean, *g_std; int64_t str
 
 // KC: the particle count as a compile-time constant (25: the reference's train_particles, dmm.py:534), or 0 = read
 // from the launch arguments -- with it the live-row tests of every image store and elementwise group fold away
-template <int KC>
+// QUAD: the four tiles are one pair's particles (K = a.K / 4 rows each): sums over the particles span the tiles, what a
+// pair reads or writes once is read by every tile and written by the first
+template <int KC, bool QUAD = false>
 __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, const WideGeo g,
                                                          const WideWs ws, const FwdPark park) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
   // and a reload from scratch is a vector-memory load -- it waits for every older store of the wave.
   int lane, h, n, odd, kh, kh2, arow, srow;
   unsigned sel;
-  const int T = a.T, B = a.B, K = KC ? KC : a.K;
+  const int T = a.T, B = a.B, K = KC ? KC : (QUAD ? a.K / 4 : a.K);      // live rows of a tile
   const int ts = K * RS, img = RT * ts;
   auto regeo = [&]() {
     int l;
@@ -154,7 +157,15 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     sel = odd ? 0x03020706u : 0x05040100u;
   };
   regeo();
-  const float inv_k = 1.0f / (float)K;
+  const float inv_k = 1.0f / (float)(QUAD ? 4 * K : K);
+  // sums over a pair's particles from the sums over its tiles' rows
+  auto over_tiles = [&](float (&v)[RT]) __attribute__((always_inline)) {
+    if constexpr (QUAD) {
+      const float tot = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) v[rt] = tot;
+    }
+  };
 
   // wave-uniform bases (scalar registers) + one per-lane index: fragments, biases, spill, park
   const gw_t frag0 = (gw_t)a.gtf_frag + (size_t)wave * NCH * 64;
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       acc += __uint_as_float(noise[(((size_t)t * NWAVE) * NOISE_SLOTS + 12) * 64 + lane][rt]);       // register 12
       se[rt] = half_sum(acc);
     }
+    over_tiles(se);
   }
 
   // chunk c (P7 order, wide_sweep.h) of array `arr` at step `step`
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     }
   };
   const int n_pairs = g.n_pairs;
-  const int pair0 = blockIdx.x * RT;
+  const int pair0 = QUAD ? blockIdx.x : blockIdx.x * RT;
   // The relu masks of a step's hidden layers are requested a step ahead, in front of D3's contractions of the step
   // before: requested in their own step they sat behind the E phase's spill stores on their way to HBM (the vector-memory
   // counter is in order) and D1's mask epilogue waited ~8 k cycles for them.  (The first pair's fusion inputs and first
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     };
     // pair of tile rt (wave-uniform: scalar address math)
     auto pair_of = [&](int rt, int& pp, int& pb) __attribute__((always_inline)) {
-      const int pair = pair0 + rt;
+      const int pair = QUAD ? pair0 : pair0 + rt;
       const bool valid = pair < n_pairs;
       pp = valid ? pair / B : -1; pb = valid ? pair - pp * B : 0;
       return valid;
@@ -323,6 +335,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       if (r.valid) {
         ExpD ed[EB];
         fetch_ed(ed);
+        const bool wr = h == 0 && (!QUAD || rt == 0);      // the lanes that write what a pair writes once
         const size_t tb = (size_t)t * B + pb;
         const size_t o = (((size_t)pp * T + t) * B + pb) * WD + n;
         const float gi_m = x.g_im + adj_a[rt] + x.gsmp;
@@ -348,7 +361,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
         for (int e = 0; e < EB; ++e)
           if ((ed[e].bits >> pp) & 1u) {
             poe_expert_bwd_f(x.e_mu[e], x.e_sd[e], x.e_c[e], g_num, g_prec, gm, gs);
-            if (h == 0) {
+            if (wr) {
               if (ed[e].g_mean) ed[e].g_mean[o] = gm;       // one slab per pass, (P,T,B,D)
               if (ed[e].g_std) ed[e].g_std[o] = gs;
             }
@@ -359,12 +372,12 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
           const float c = ex.mask ? ex.mask[tb] : 1.0f;
           const size_t off = (size_t)pp * ex.pass_stride + tb * WD + n;
           poe_expert_bwd_f(ex.mean[off], ex.std[off], c, g_num, g_prec, gm, gs);
-          if (h == 0) {
+          if (wr) {
             if (ex.g_mean) ex.g_mean[o] = gm;
             if (ex.g_std) ex.g_std[o] = gs;
           }
         }
-        if (h == 0) {
+        if (wr) {
           if (inv_prior) {
             poe_expert_bwd_f(mu0, -sg0, 1.0f, g_num, g_prec, gm, gs);
             g_mu0 += gm; g_sg0 -= gs;
@@ -614,6 +627,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     sums(0, ep, __uint_as_float(ep[6].x)); sums(1, ep + 3, __uint_as_float(ep[6].y));
     __builtin_amdgcn_sched_barrier(0);
     sums(2, ep2, __uint_as_float(ep[6].z)); sums(3, ep2 + 3, __uint_as_float(ep[6].w));
+    over_tiles(adj_a); over_tiles(adj_b); over_tiles(se);
     STAMP(10);
   }
 
@@ -629,7 +643,7 @@ int64_t up256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 bool b4_shape(const mdmm_sweep_t* a) {
   if (!a || a->D != WD || a->H != WD || !a->gtf_frag || a->trans_only) return false;
-  if (a->precision != MDMM_PREC_BF16 || a->K < 2 || a->K > KMAX || a->T < 1) return false;
+  if (a->precision != MDMM_PREC_BF16 || a->K < 2 || (a->K > KMAX && !quad_shape(a)) || a->T < 1) return false;
   if ((int64_t)a->P * a->T * a->B * WD >= (1ll << 40)) return false;
   return true;
 }
@@ -637,7 +651,8 @@ bool b4_shape(const mdmm_sweep_t* a) {
 // carve the workspace; returns the bytes needed
 int64_t b4_carve(const mdmm_sweep_t* a, WideGeo* g, WideWs* ws) {
   const int64_t n_pairs = (int64_t)a->P * a->B;
-  const int64_t n_wg = (n_pairs + RT - 1) / RT, n_step = a->T - 1;
+  const bool quad = quad_shape(a);
+  const int64_t n_wg = quad ? n_pairs : (n_pairs + RT - 1) / RT, n_step = a->T - 1;
   const int64_t items = n_wg * n_step;                      // 128-row items of P7 arrays
   int split = 42;                                   // 6 * 42 = 252 workgroups: one round of the 256 CUs
   if (split > 2 * items) split = items > 0 ? (int)(2 * items) : 1;
@@ -645,7 +660,8 @@ int64_t b4_carve(const mdmm_sweep_t* a, WideGeo* g, WideWs* ws) {
   const int64_t b_db = up256((int64_t)split * 6 * WD * 4), b_dz = up256(n_wg * 2 * WD * 4);
   const int64_t b_slab = up256((int64_t)split * 6 * WD * WD * 4);
   if (g) {
-    g->n_pairs = (int)n_pairs; g->NP = RT; g->TPP = 1; g->ntab = RT; g->stamps = nullptr;
+    g->n_pairs = (int)n_pairs; g->NP = quad ? 1 : RT; g->TPP = quad ? RT : 1; g->ntab = RT; g->stamps = nullptr;
+    g->ks = quad ? a->K / 4 : 32; g->kt = g->ks;
 #ifdef WIDE_STAMPS
     if (const char* e = getenv("MDMM_STAMP_PTR")) g->stamps = (unsigned long long*)strtoull(e, nullptr, 16);
 #endif
@@ -685,8 +701,10 @@ int mdmm_wide_sweep_bwd4(const mdmm_sweep_t* a, hipStream_t stream) {
   fwd_park_carve(a, &park);
   ws.xop = park.item;
   ws.p7 = 1;
-  const int lds = 3 * RT * a->K * RS;
-  auto kern = a->K == 25 ? wide_bwd4_kernel<25> : wide_bwd4_kernel<0>;
+  const bool quad = quad_shape(a);
+  const int lds = 3 * RT * (quad ? a->K / 4 : a->K) * RS;
+  auto kern = a->K == 25 ? wide_bwd4_kernel<25> : (a->K == 100 ? wide_bwd4_kernel<25, true>
+                                                    : (quad ? wide_bwd4_kernel<0, true> : wide_bwd4_kernel<0>));
   if (int rc = mdmm_lds_attr_fn((const void*)kern, (size_t)lds)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)ws.n_wg), dim3(NTHR), lds, stream, *a, g, ws, park);
   if (int rc = (int)hipGetLastError()) return rc;

@@ -15,6 +15,8 @@ struct WideGeo {
   int NP;          // (pass, sequence) pairs per workgroup
   int TPP;         // row tiles per pair (K > 1), 1 for K = 1
   int ntab;        // slots in the pair table
+  int ks, kt;      // K > 1: particle k of a pair is row k % ks of its tile k / ks; a tile holds at most kt live rows.
+                   // 32 / 32 = whole tiles; K / 4 twice = the QUAD geometry of the parked K-particle sweeps (quad_shape)
   unsigned long long* stamps;   // diagnostic builds (-DWIDE_STAMPS): cycle stamps of one step
 };
 
@@ -61,9 +63,9 @@ __device__ __forceinline__ void build_tables(const mdmm_sweep_t& a, const WideGe
   const int R = 32 * RT;
   for (int r = threadIdx.x; r < R; r += NTHR) {
     const int slot = K1 ? r : (r >> 5) / g.TPP;
-    const int k = K1 ? 0 : (r - 32 * g.TPP * slot);
+    const int k = K1 ? 0 : g.ks * ((r >> 5) - g.TPP * slot) + (r & 31);
     const int64_t pair = (int64_t)blockIdx.x * g.NP + slot;
-    const bool live = slot < g.NP && pair < g.n_pairs && k < a.K;
+    const bool live = slot < g.NP && pair < g.n_pairs && k < a.K && (K1 || (r & 31) < g.kt);
     int p = -1, b = 0;
     if (slot < g.NP && pair < g.n_pairs) { p = (int)(pair / a.B); b = (int)(pair - (int64_t)p * a.B); }
     if (K1 || (r & 31) == 0) {
@@ -116,6 +118,12 @@ __device__ __forceinline__ void eps_rows(const A& a, uint64_t noff, uint64_t t_t
   quad_transpose(e, u);
 }
 
+// live rows of row tile rt (K > 1): the particles ks * (tile of the pair) + row < K, at most kt of them
+__device__ __forceinline__ int live_rows(const WideGeo& g, int K, int rt) {
+  const int left = K - g.ks * (rt & (g.TPP - 1));
+  return left < g.kt ? (left > 0 ? left : 0) : g.kt;
+}
+
 // per-tile sums -> total of the pair the tile belongs to (TPP = 1, 2 or 4 tiles per pair)
 template <int RT>
 __device__ __forceinline__ float pair_total(const float (&s)[RT], int rt, int tpp) {
@@ -160,6 +168,14 @@ enum PkArr { PK_GATE = X_ARR, PK_MUQ, PK_PRE, PK_ARR };         // arrays of one
 enum GArr { G_HG = 0, G_HN, G_LIN, G_G, G_N, G_3, G_ARR };       // the backward's own spill, in weight-gradient block order
 struct FwdPark { uint4 *noise, *item; };
 constexpr int PARK_PAIRS = 4;                          // pairs per workgroup of the kernels that share the park
+constexpr int PARK_KT = 25;                            // live rows of a tile the one-round backward's three images hold
+// QUAD geometry: more particles than one tile of the one-round backward takes (dmm.py:531-536, `train_particles` is the
+// caller's) -- ONE pair per workgroup, its K = 4 kt particles as four tiles of kt live rows each: the same images, park
+// slots and weight-gradient chunks as four pairs of kt particles; only the sums over the particles span the tiles.
+__host__ __device__ inline bool quad_shape(const mdmm_sweep_t* a) {
+  return a->K > PARK_KT && a->K <= 4 * PARK_KT && a->K % 4 == 0;
+}
+__host__ __device__ inline int park_pairs(const mdmm_sweep_t* a) { return quad_shape(a) ? 1 : PARK_PAIRS; }
 constexpr int NOISE_SLOTS = 13;
 constexpr int P7_SUB1 = NWAVE * 4 * 64;                // uint4 in front of an array's second sub-block
 constexpr int P7_U4 = NWAVE * 7 * 64;                  // uint4 per P7 array
@@ -170,7 +186,7 @@ __host__ __device__ constexpr int p7_off(int wave, int c) {
 }
 // carve mdmm_sweep_t.fwd_park; returns the bytes needed
 __host__ __device__ inline int64_t fwd_park_carve(const mdmm_sweep_t* a, FwdPark* pk) {
-  const int64_t n_wg = ((int64_t)a->P * a->B + PARK_PAIRS - 1) / PARK_PAIRS, n_step = a->T - 1;
+  const int64_t n_wg = ((int64_t)a->P * a->B + park_pairs(a) - 1) / park_pairs(a), n_step = a->T - 1;
   const int64_t b_noise = n_wg * a->T * NWAVE * NOISE_SLOTS * 64 * 16;
   const int64_t b_item = n_wg * n_step * PK_ITEM_U4 * 16;
   if (pk) {

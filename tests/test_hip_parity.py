@@ -1023,6 +1023,30 @@ def test_step_cfg3_shape_matches_oracle(dev, kernel_family, dtype):
     _z256_step_vs_oracle(dev, 40, lengths, 25, dtype)
 
 
+def test_step_100_particles_matches_oracle(dev, kernel_family, monkeypatch):
+    """`train_particles=100` (a caller kwarg, dmm.py:531-536) at z = h = 256 with bf16 operands: the whole training step on
+    the quad geometry of the parked sweeps (one pair's particles in the four tiles of a workgroup) against the oracle
+    with the kernels' Philox noise replayed -- loss at the bf16 bound, gradients at the per-class bf16 bounds of the
+    25-particle tests; the sweep that ran is checked to be the parked one (no generic-kernel warning)."""
+    if kernel_family == 'generic':
+        pytest.skip('wide family only')
+    import warnings
+    from mdmm import ops
+    ops._WARNED_GENERIC_BWD.clear()
+    parks = []
+    orig = ops._SweepFn.backward
+
+    def spy(ctx, *g, _orig=orig):
+        parks.append((ctx.cfg.K, ctx.fwd_park is not None))
+        return _orig(ctx, *g)
+    monkeypatch.setattr(ops._SweepFn, 'backward', staticmethod(spy))
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        _z256_step_vs_oracle(dev, 12, [12, 12, 11, 9, 7, 4, 2], 100, torch.bfloat16)
+    assert (100, True) in parks, parks
+    assert not [w for w in rec if 'generic fp32 kernels' in str(w.message)]
+
+
 def test_step_cfg5_shape_matches_oracle(dev, kernel_family):
     """BASELINE cfg5 shape: T = 128, ragged lengths 64..128, two modalities, every (t, b, modality)
     missing independently with probability 0.5, z = h = 256, 25 particles."""
@@ -1789,6 +1813,68 @@ def test_wide_forward_many_particles_matches_generic(dev, kernel_family, K, prec
     tol = 2e-5 if prec == 'f32' else 8e-3
     for name, a_, b_ in zip(('infer_mean', 'infer_std', 'prior_mean', 'prior_std', 'samples'), outs['wide'], outs['generic']):
         close(a_, b_, tol, 'many-particle forward ' + name)
+
+
+@pytest.mark.parametrize('K', [100, 68])
+def test_quad_training_sweep_matches_generic(dev, kernel_family, K, monkeypatch):
+    """`train_particles` above 64 at z = h = 256 (dmm.py:531-536) with bf16 operands: ONE pair per workgroup, its
+    particles as the four tiles of the parked forward / one-round backward (csrc/wide_sweep.h quad_shape,
+    sweep_wide_bwd4.hip QUAD) -- outputs and every gradient against the generic fp32 kernels on the same inputs and the
+    same Philox stream (two passes, masked and pass-selected experts, `samples` differentiated, reverse time).  What
+    differs is the rounding of bf16 operands (the same comparison at K = 25, the geometry the kernels were written for,
+    is recorded beside it); a lost 1/K, a sum over one tile instead of four or a pair written four times is O(1)."""
+    if kernel_family == 'generic':
+        pytest.skip('compares the two families itself')
+    import warnings
+    from mdmm import ops
+    T, B, D, P = 6, 3, 256, 2
+    shapes = [(D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,)]
+
+    def run(fam, k):
+        torch.manual_seed(7)
+        gd = lambda *s: torch.randn(*s, device=dev)     # noqa: E731
+        gtf = [(0.06 * gd(*s)).requires_grad_() for s in shapes]
+        z0m, z0s = (gd(D) * 0.1).requires_grad_(), (gd(D) * 0.1).requires_grad_()
+        e1 = ops.ExpertSpec(gd(T, B, D).requires_grad_(), (gd(T, B, D).abs() + 0.3).requires_grad_(),
+                            (torch.rand(T, B, device=dev) > 0.2).float(), 1, False)
+        e2 = ops.ExpertSpec(gd(T, B, D).requires_grad_(), (gd(T, B, D).abs() + 0.3).requires_grad_(), None, 3, False)
+        wts = [gd(P, T, B, D) for _ in range(5)]
+        monkeypatch.setenv('MDMM_NO_WIDE', '1' if fam == 'generic' else '0')
+        cfg = ops.SweepCfg(T, B, D, D, P=P, K=k, reverse=True, sample=True, seed=11, precision=torch.bfloat16,
+                           need_samples=True)
+        assert ops.wide_shape(cfg, bwd=True) == (fam == 'wide')
+        parks = []
+        orig = ops._SweepFn.backward
+
+        def spy(ctx, *g, _orig=orig):
+            parks.append(ctx.fwd_park is not None)
+            return _orig(ctx, *g)
+        monkeypatch.setattr(ops._SweepFn, 'backward', staticmethod(spy))
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            outs = ops.bfvi_sweep(cfg, gtf, z0m, z0s, [e1, e2])
+            sum((o * w).sum() for o, w in zip(outs, wts)).backward()
+        monkeypatch.setattr(ops._SweepFn, 'backward', staticmethod(orig))
+        assert parks == [fam == 'wide']                    # the route under test is the one that ran
+        assert not [w for w in rec if 'generic fp32 kernels' in str(w.message)] or fam == 'generic'
+        leaves = gtf + [z0m, z0s, e1.mean, e1.std, e2.mean, e2.std]
+        names = ['gtf%d' % i for i in range(12)] + ['z0_mean', 'z0_log_std', 'e1.mean', 'e1.std', 'e2.mean', 'e2.std']
+        return [o.detach().clone() for o in outs], dict(zip(names, [t.grad.clone() for t in leaves]))
+
+    ops._WARNED_GENERIC_BWD.clear()
+    worst = {}
+    for k in (K, 25):
+        ow, gw = run('wide', k)
+        og, gg = run('generic', k)
+        for name, a_, b_ in zip(('infer_mean', 'infer_std', 'prior_mean', 'prior_std', 'samples'), ow, og):
+            close(a_, b_, 8e-3, 'K = %d training forward %s' % (k, name))
+        worst[k] = {n: float((gw[n] - gg[n]).norm() / (gg[n].norm() + 1e-30)) for n in gg}
+        for n, e in worst[k].items():
+            helpers.note('quad_sweep[K=%d].grad.%s' % (k, n), e)
+        assert all(torch.isfinite(v).all() for v in gw.values())
+    # bf16 operands against fp32 ones: within twice what the 25-particle geometry shows on the same problem, and 5e-2
+    for n, e in worst[K].items():
+        assert e < max(2.0 * worst[25][n], 2e-2) and e < 5e-2, (n, e, worst[25][n])
 
 
 def test_training_sweep_beyond_the_wide_backward_warns_once(dev, kernel_family):
