@@ -1531,7 +1531,7 @@ int plan(const mdmm_sweep_t* a, bool bwd, WideGeo* g) {
   if (tpp > RT) return 0;
   g->TPP = tpp; g->NP = RT / tpp; g->ntab = RT;
   // the parked forward of more particles than a tile of the one-round backward holds: that kernel's geometry
-  if (!bwd && !f32 && a->fwd_park && quad_shape(a)) { g->ks = a->K / 4; g->kt = a->K / 4; }
+  if (!bwd && !f32 && a->fwd_park && quad_shape(a)) { g->ks = (a->K + 3) / 4; g->kt = g->ks; }
   return RT;
 }
 

@@ -145,7 +145,11 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
   // and a reload from scratch is a vector-memory load -- it waits for every older store of the wave.
   int lane, h, n, odd, kh, kh2, arow, srow;
   unsigned sel;
-  const int T = a.T, B = a.B, K = KC ? KC : (QUAD ? a.K / 4 : a.K);      // live rows of a tile
+  const int T = a.T, B = a.B, K = KC ? KC : (QUAD ? (a.K + 3) / 4 : a.K);      // live rows of a tile
+  // QUAD with a particle count that is no multiple of four: the LAST tile holds dk rows less (the forward filled the
+  // tiles in order, wide_sweep.h live_rows); everything that asks "is this row live" asks with its tile
+  const int dk = (QUAD && !KC) ? 4 * K - a.K : 0;
+  auto less = [&](int rt) __attribute__((always_inline)) { return (QUAD && !KC && rt == RT - 1) ? dk : 0; };
   const int ts = K * RS, img = RT * ts;
   auto regeo = [&]() {
     int l;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
     sel = odd ? 0x03020706u : 0x05040100u;
   };
   regeo();
-  const float inv_k = 1.0f / (float)(QUAD ? 4 * K : K);
+  const float inv_k = 1.0f / (float)(QUAD ? 4 * K - dk : K);
   // sums over a pair's particles from the sums over its tiles' rows
   auto over_tiles = [&](float (&v)[RT]) __attribute__((always_inline)) {
     if constexpr (QUAD) {
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       SPILL_ST(spill_at(step, arr, rt), c0);
       hw[3 * rt] = w[4]; hw[3 * rt + 1] = w[5]; hw[3 * rt + 2] = w[6];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) store_word(p0 + rt * ts, w[k], sel, k, K, kh2);
+      for (int k = 0; k < 8; ++k) store_word(p0 + rt * ts, w[k], sel, k, K - less(rt), kh2 - less(rt));
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
         const int rr = r + k, row = 8 * (rr >> 2) + (rr & 3);       // (+ 4 h)
         // a register that is a dead row in BOTH half-waves (row >= K; at K = 25: register 13): its outputs are the zeros
         // the masks below would have made them
-        if (row >= K) { o_g3[k] = 0.f; o_gg[k] = 0.f; o_gl[k] = 0.f; v1[rt][rr] = 0.f; continue; }
+        if (row >= K - less(rt)) { o_g3[k] = 0.f; o_gg[k] = 0.f; o_gl[k] = 0.f; v1[rt][rr] = 0.f; continue; }
         const float pre = prv[k];
         const float muq = mqv[k];
         // softplus and its derivative from one exponential: y = e^-|pre|
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
         const float u = fast::rcp(fmaf(t0, v, 1.0f));
         const float rp = v * u;                                  // variance of the product
         const float mraw = fmaf(muq, u, num0 * rp);
-        const bool live = f.valid && (row < kh);
+        const bool live = f.valid && (row < kh - less(rt));
         const bool good = live && mraw == mraw;                  // (a NaN mean was overwritten by 0, dgts.py:49)
         const float m = (mraw != mraw) ? 0.f : mraw;
         const float g_m = good ? gpmk + gv2k * (m - mb) : 0.f;
@@ -442,9 +446,9 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
       o.g3 = pack2(o_g3[0], o_g3[1]); o.gg = pack2(o_gg[0], o_gg[1]); o.gl = pack2(o_gl[0], o_gl[1]);
       // G3 -> B, GG -> C, Glin -> A (live rows of the images)
       char* const pa = smem + srow + rt * ts;
-      store_word(pa + img, o.g3, sel, r >> 1, K, kh2);
-      store_word(pa + 2 * img, o.gg, sel, r >> 1, K, kh2);
-      store_word(pa, o.gl, sel, r >> 1, K, kh2);
+      store_word(pa + img, o.g3, sel, r >> 1, K - less(rt), kh2 - less(rt));
+      store_word(pa + 2 * img, o.gg, sel, r >> 1, K - less(rt), kh2 - less(rt));
+      store_word(pa, o.gl, sel, r >> 1, K - less(rt), kh2 - less(rt));
       return o;
     };
     // one P7 chunk c of the three arrays E produces (wide_sweep.h): chunk rt = words 0 .. 3 of tile rt, chunk 4 + j = words
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
         const unsigned mb = mkg[rt];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const bool live = valid && (8 * (r >> 2) + (r & 3) < kh);
+          const bool live = valid && (8 * (r >> 2) + (r & 3) < kh - less(rt));
           if (!live) v1[rt][r] = 0.f;                                 // dead rows hold row K - 1's values
           if (!live || !((mb >> r) & 1u)) v0[rt][r] = 0.f;
         }
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
         const unsigned mb = mkn[rt];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (!(valid && (8 * (r >> 2) + (r & 3) < kh)) || !((mb >> r) & 1u)) v1[rt][r] = 0.f;
+          if (!(valid && (8 * (r >> 2) + (r & 3) < kh - less(rt))) || !((mb >> r) & 1u)) v1[rt][r] = 0.f;
       }
     }
     STAMP(8);
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(NTHR) void wide_bwd4_kernel(const mdmm_sweep_t a, c
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const bool live = valid && 8 * q + j < kh;
+          const bool live = valid && 8 * q + j < kh - less(rt);
           const float gz = live ? v0[rt][4 * q + j] : 0.f;
           sa += gz; sb = fmaf(gz, e[j], sb); sc += e[j];
         }
@@ -661,7 +665,7 @@ int64_t b4_carve(const mdmm_sweep_t* a, WideGeo* g, WideWs* ws) {
   const int64_t b_slab = up256((int64_t)split * 6 * WD * WD * 4);
   if (g) {
     g->n_pairs = (int)n_pairs; g->NP = quad ? 1 : RT; g->TPP = quad ? RT : 1; g->ntab = RT; g->stamps = nullptr;
-    g->ks = quad ? a->K / 4 : 32; g->kt = g->ks;
+    g->ks = quad ? (a->K + 3) / 4 : 32; g->kt = g->ks;
 #ifdef WIDE_STAMPS
     if (const char* e = getenv("MDMM_STAMP_PTR")) g->stamps = (unsigned long long*)strtoull(e, nullptr, 16);
 #endif
@@ -702,7 +706,7 @@ int mdmm_wide_sweep_bwd4(const mdmm_sweep_t* a, hipStream_t stream) {
   ws.xop = park.item;
   ws.p7 = 1;
   const bool quad = quad_shape(a);
-  const int lds = 3 * RT * (quad ? a->K / 4 : a->K) * RS;
+  const int lds = 3 * RT * (quad ? (a->K + 3) / 4 : a->K) * RS;
   auto kern = a->K == 25 ? wide_bwd4_kernel<25> : (a->K == 100 ? wide_bwd4_kernel<25, true>
                                                     : (quad ? wide_bwd4_kernel<0, true> : wide_bwd4_kernel<0>));
   if (int rc = mdmm_lds_attr_fn((const void*)kern, (size_t)lds)) return rc;

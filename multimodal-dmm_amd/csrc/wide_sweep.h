@@ -170,10 +170,11 @@ struct FwdPark { uint4 *noise, *item; };
 constexpr int PARK_PAIRS = 4;                          // pairs per workgroup of the kernels that share the park
 constexpr int PARK_KT = 25;                            // live rows of a tile the one-round backward's three images hold
 // QUAD geometry: more particles than one tile of the one-round backward takes (dmm.py:531-536, `train_particles` is the
-// caller's) -- ONE pair per workgroup, its K = 4 kt particles as four tiles of kt live rows each: the same images, park
-// slots and weight-gradient chunks as four pairs of kt particles; only the sums over the particles span the tiles.
+// caller's) -- ONE pair per workgroup, its K particles as four tiles of kt = ceil(K / 4) live rows each (the last one
+// 4 kt - K less): the same images, park slots and weight-gradient chunks as four pairs of kt particles; only the sums
+// over the particles span the tiles.
 __host__ __device__ inline bool quad_shape(const mdmm_sweep_t* a) {
-  return a->K > PARK_KT && a->K <= 4 * PARK_KT && a->K % 4 == 0;
+  return a->K > PARK_KT && a->K <= 4 * PARK_KT;
 }
 __host__ __device__ inline int park_pairs(const mdmm_sweep_t* a) { return quad_shape(a) ? 1 : PARK_PAIRS; }
 constexpr int NOISE_SLOTS = 13;

@@ -330,7 +330,7 @@ def wide_shape(cfg, bwd=False):
     if cfg.K <= 64:
         return True
     # above: the parked one-round backward with one pair's particles in its four tiles (csrc/wide_sweep.h, quad_shape)
-    return cfg.K <= 100 and cfg.K % 4 == 0 and os.environ.get('MDMM_FWD_PARK') != '0'
+    return cfg.K <= 100 and os.environ.get('MDMM_FWD_PARK') != '0'
 
 
 _BRANCH_STREAMS_ANNOUNCED = False
@@ -357,16 +357,15 @@ _WARNED_GENERIC_BWD = set()
 
 def _warn_generic_backward(cfg):
     """Once per (K, precision): a training sweep at z = h = 256 with more particles than the wide backward kernels take
-    (bf16 operands: 64, and the multiples of four up to 100; fp32: 32; `train_particles` is a caller kwarg,
-    dmm.py:531-536) runs its backward -- and with bf16 operands its forward too -- on the generic fp32 kernels, roughly
+    (bf16 operands: 100; fp32: 32; `train_particles` is a caller kwarg, dmm.py:531-536) runs its backward -- and with bf16 operands its forward too -- on the generic fp32 kernels, roughly
     ten times slower."""
     key = (cfg.K, PRECISIONS[cfg.precision])
     if key in _WARNED_GENERIC_BWD:
         return
     _WARNED_GENERIC_BWD.add(key)
     import warnings
-    warnings.warn('mdmm: %d particles at z = h = 256 are more than the wide backward sweep takes (bf16 operands: up to 64, '
-                  'and 68, 72, ... 100; fp32: 32): this sweep trains on the generic fp32 kernels, about 10x slower.  The '
+    warnings.warn('mdmm: %d particles at z = h = 256 are more than the wide backward sweep takes (bf16 operands: 100; '
+                  'fp32: 32): this sweep trains on the generic fp32 kernels, about 10x slower.  The '
                   'reference trains with train_particles=25.' % cfg.K, RuntimeWarning, stacklevel=3)
 
 

@@ -1815,11 +1815,11 @@ def test_wide_forward_many_particles_matches_generic(dev, kernel_family, K, prec
         close(a_, b_, tol, 'many-particle forward ' + name)
 
 
-@pytest.mark.parametrize('K', [100, 68])
+@pytest.mark.parametrize('K', [100, 68, 70, 97])
 def test_quad_training_sweep_matches_generic(dev, kernel_family, K, monkeypatch):
     """`train_particles` above 64 at z = h = 256 (dmm.py:531-536) with bf16 operands: ONE pair per workgroup, its
     particles as the four tiles of the parked forward / one-round backward (csrc/wide_sweep.h quad_shape,
-    sweep_wide_bwd4.hip QUAD) -- outputs and every gradient against the generic fp32 kernels on the same inputs and the
+    sweep_wide_bwd4.hip QUAD; 70 and 97: a last tile with fewer rows than the others) -- outputs and every gradient against the generic fp32 kernels on the same inputs and the
     same Philox stream (two passes, masked and pass-selected experts, `samples` differentiated, reverse time).  What
     differs is the rounding of bf16 operands (the same comparison at K = 25, the geometry the kernels were written for,
     is recorded beside it); a lost 1/K, a sum over one tile instead of four or a pair written four times is O(1)."""
@@ -1878,14 +1878,14 @@ def test_quad_training_sweep_matches_generic(dev, kernel_family, K, monkeypatch)
 
 
 def test_training_sweep_beyond_the_wide_backward_warns_once(dev, kernel_family):
-    """`train_particles` is a caller kwarg (dmm.py:531-536): above 64 particles at z = h = 256 the training sweep leaves
+    """`train_particles` is a caller kwarg (dmm.py:531-536): above 100 particles at z = h = 256 the training sweep leaves
     the wide family for the generic fp32 kernels -- it must say so (once per shape), and still be right."""
     if kernel_family == 'generic':
         pytest.skip('wide family only')
     import warnings
     from mdmm import ops
     torch.manual_seed(1)
-    T, B, D, K = 3, 2, 256, 70
+    T, B, D, K = 3, 2, 256, 104
     gd = lambda *s: torch.randn(*s, device=dev)     # noqa: E731
     shapes = [(D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,), (D, D), (D,)]
     gtf = [(0.06 * gd(*s)).requires_grad_() for s in shapes]
