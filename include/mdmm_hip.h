@@ -197,7 +197,8 @@ typedef struct mdmm_sweep {
   int32_t reserved1;
   void* wide_ws;
   int64_t wide_ws_bytes;
-  /* Wide family with K particles (bf16 operands, 2 <= K <= 25): what the forward sweep keeps for the backward sweep
+  /* Wide family with K particles (bf16 operands; 2 <= K <= 25: four (pass, sequence) pairs per workgroup; 65 <= K <= 100:
+   * one pair whose particles are the workgroup's four row tiles): what the forward sweep keeps for the backward sweep
    * of the same call, mdmm_sweep_fwd_park_bytes(args) bytes (0 = this shape has no use for it), in the backward
    * kernel's own register order:
    *   - the noise it drew (fp32),
