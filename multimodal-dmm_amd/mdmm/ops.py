@@ -1211,19 +1211,27 @@ class _NllBernLogitsFn(torch.autograd.Function):
 # autograd engine for a callback at the end of THIS backward pass: an entry still there means the gradient went somewhere
 # else (a hook's copy, a second consumer, an accumulation) unfinished, and the pass fails with that message instead of
 # training on it.  (The audio plug-ins need none of this: their stacks are one autograd node each, mdmm/audio.py.)
-_END_CHECK_QUEUED = False
+_END_CHECK_QUEUED = None        # the backward pass (autograd's graph-task id) the check is queued for
 
 
 def _check_at_end_of_backward():
+    """Queue the check once per backward PASS.  Keyed by the pass, not by a flag the check clears: a pass that dies half
+    way (somebody's saved tensor was overwritten, an out-of-memory) never runs its callbacks, and a flag left set would
+    switch the check off for every pass after it."""
     global _END_CHECK_QUEUED
-    if not _END_CHECK_QUEUED:
-        _END_CHECK_QUEUED = True
+    task = torch._C._current_graph_task_id()
+    if task != _END_CHECK_QUEUED:
+        if _END_CHECK_QUEUED is not None:          # the pass that queued before this one never reached its end
+            _GRAD_SCALE.clear()
+            _LAZY_BN.clear()
+            _GRAD_CHANSUM.clear()
+        _END_CHECK_QUEUED = task
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_check)
 
 
 def _end_of_backward_check():
     global _END_CHECK_QUEUED
-    _END_CHECK_QUEUED = False
+    _END_CHECK_QUEUED = None
     n_scale, n_lazy = len(_GRAD_SCALE), len(_LAZY_BN)
     _GRAD_SCALE.clear()
     _LAZY_BN.clear()
@@ -1264,8 +1272,8 @@ _GRAD_SCALE = {}
 
 
 def _stash_scale(g, gd):
-    _GRAD_SCALE[g.data_ptr()] = (g, gd)
     _check_at_end_of_backward()
+    _GRAD_SCALE[g.data_ptr()] = (g, gd)
 
 
 def _take_scale(g):
@@ -1299,8 +1307,8 @@ _LAZY_BN = {}
 
 
 def _lazy_stash(dx, entry):
-    _LAZY_BN[dx.data_ptr()] = (dx, entry)
     _check_at_end_of_backward()
+    _LAZY_BN[dx.data_ptr()] = (dx, entry)
 
 
 def _lazy_take(g):

@@ -363,7 +363,7 @@ def test_bf16_gradients_vs_oracle_at_32_sequences(name, dev):
         c = helpers.grad_class(k)
         helpers.note('b32_vs_oracle[%s].grad.%s' % (name, k), e)
         worst[c] = max(worst.get(c, 0.0), e)
-        if e >= BF16_GRAD_TOL_B32[c]:
+        if e >= BF16_GRAD_TOL_B32[name][c]:
             bad[k] = e
     helpers.note('b32_vs_oracle[%s].class_max' % name, worst)
     assert not bad, (bad, worst)
