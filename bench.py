@@ -911,9 +911,11 @@ def main():
             out['extra']['cfg3_f32']['own_convolutions'] = {k: rown[k] for k in ('value', 'ms_per_step')}
             out['extra']['cfg3_f32']['own_convolutions']['loss'] = rown['config'].get('loss')
             del rown
-            # cfg4 / cfg5 with fp32 operands too (their BASELINE strings state no dtype): eager, two timed steps each
+            # cfg4 / cfg5 with fp32 operands too (their BASELINE strings state no dtype): eager, two timed steps each behind
+            # TWO warm-up steps (with one, the library's search for the cfg5 image convolutions' backward kernels was still
+            # running in the timed steps: 3,951 ms per step recorded where the steady state is 632, profiles/r06n_cfg5_f32_spans.txt)
             a45 = argparse.Namespace(**vars(args))
-            a45.steps, a45.warmup, a45.batch = 2, 1, 0
+            a45.steps, a45.warmup, a45.batch = 2, 2, 0
             for key, c45 in (('cfg4_f32', Cfg4F32), ('cfg5_f32', Cfg5F32)):
                 torch.cuda.empty_cache()
                 r45 = run(c45, a45, 1, 0, device, graph=False)
