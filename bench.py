@@ -449,7 +449,7 @@ def sweep_bytes(cfg, tag, b_dim):
 def load_traffic(tag, cfg, b_dim):
     """HBM bytes per launch from the PMC passes kept under profiles/ (tools/pmc_traffic.sh; counters cannot be
     collected from inside the benchmark process) -- only when the record was taken at THIS shape."""
-    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+    for name in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
         path = os.path.join(REPO, 'profiles', name)
         if not os.path.exists(path):
             continue

@@ -1,10 +1,11 @@
 #!/bin/bash
 # GPU box: HBM traffic (FETCH_SIZE / WRITE_SIZE in separate --pmc passes, kernel-trace only: the guide's HBM recipe) of
-# the sweep calls at the BASELINE shapes -> OUTDIR/r05_pmc_traffic.json + r05_pmc_traffic_summary.txt (bench.py reads the
-# profiles/ copy; one record per (call, K, shape)).   usage: tools/pmc_traffic5.sh OUTDIR      (OUTDIR under gpurun_out/)
+# the sweep calls at the BASELINE shapes -> OUTDIR/${ROUND}_pmc_traffic.json + ${ROUND}_pmc_traffic_summary.txt (bench.py reads
+# the profiles/ copy; one record per (call, K, shape)).   usage: [ROUND=r06] tools/pmc_traffic5.sh OUTDIR      (OUTDIR under gpurun_out/)
 set -u
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$ROOT/$1"; mkdir -p "$OUT"
+export ROUND="${ROUND:-r06}"
 cd /tmp && export TMPDIR=/tmp
 # shape name : bench_sweep arguments
 SHAPES=("cfg3:P=4 B=256 T=40 D=256 H=256 bf16=1" "cfg5:P=3 B=512 T=128 D=256 H=256 bf16=1" "cfg2:P=3 B=1024 T=100 D=32 H=32 bf16=0")
@@ -18,8 +19,9 @@ for sh in "${SHAPES[@]}"; do
   done
 done
 python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections, json, re
+import csv, glob, sys, collections, json, re, os
 out = sys.argv[1]
+rnd = os.environ.get('ROUND', 'r06')
 shapes = {'cfg3': dict(B=256, T=40, P=4), 'cfg5': dict(B=512, T=128, P=3), 'cfg2': dict(B=1024, T=100, P=3)}
 tab, lines = {}, []
 for sname, shp in shapes.items():
@@ -47,9 +49,9 @@ for sname, shp in shapes.items():
                 'key': '%s[P=%d,%s' % (call, shp['P'], ktag), 'bytes_per_launch': rd + wr, 'read_bytes': rd, 'write_bytes': wr,
                 'kernels': sorted(ks), 'shape': shp,
                 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic5.sh: tools/bench_sweep.py at the %s '
-                          'shape, FETCH_SIZE x2 per the gfx950 correction), profiles/r05_pmc_traffic_summary.txt' % sname}
-open(out + '/r05_pmc_traffic_summary.txt', 'w').write('\n'.join(lines) + '\n')
-json.dump(tab, open(out + '/r05_pmc_traffic.json', 'w'), indent=1)
+                          'shape, FETCH_SIZE x2 per the gfx950 correction), profiles/%s_pmc_traffic_summary.txt' % (sname, rnd)}
+open(out + '/%s_pmc_traffic_summary.txt' % rnd, 'w').write('\n'.join(lines) + '\n')
+json.dump(tab, open(out + '/%s_pmc_traffic.json' % rnd, 'w'), indent=1)
 print('\n'.join(lines)); print(json.dumps({k: round(v['bytes_per_launch'] / 1e9, 3) for k, v in tab.items()}, indent=1))
 PY
 for sh in cfg3 cfg5 cfg2; do rm -rf "$OUT/$sh"; done
