@@ -2,6 +2,7 @@
 
 Same constructor, attributes and state_dict layout as the reference's MultiDKS.
 """
+import contextlib
 import numpy as np
 import os
 
@@ -114,6 +115,19 @@ class MultiDKS(MultiDGTS):
             x = h_new.reshape(t_max * b_dim, -1)
         return h_seq
 
+    _chains = None
+
+    def _chain_streams(self, n, dev):
+        """n side streams for the modalities' encoder + inference-GRU chains of `step` (made on first use, in the eager
+        warm-up steps: a stream made inside a graph capture ends it).  MDMM_DKS_STREAMS=0: everything on the caller's."""
+        if n < 1 or os.environ.get('MDMM_DKS_STREAMS', '1') == '0':
+            return []
+        if self._chains is None:
+            self._chains = []
+        while len(self._chains) < n:
+            self._chains.append(ops.branch_stream(dev))
+        return self._chains[:n]
+
     def forward(self, inputs, **kwargs):
         """dks.py:157-297.  Returns (infer, prior, recon)."""
         self._fresh_packs()
@@ -205,22 +219,40 @@ class MultiDKS(MultiDGTS):
         n_pass = len(passes)
         # features / inference-RNN states: observed version and left-out version per modality
         real, left = dict(), dict()
-        for m in self.modalities:
-            if any(m in ps for ps in passes):
-                x, seen = self._clean(inputs[m], self._frames_store(self.enc[m], inputs[m]))
-                if self.dists[m] == 'Categorical':
-                    x = x.long()
-                feat = self._plug(self.enc[m], x.flatten(0, 1)).reshape(t_max, b_dim, -1)
-                real[m] = (feat, self._rnn(m, feat, seen), seen)
-            if any(m not in ps for ps in passes):
-                feat = self._plug(self.enc[m], self._zero_input(m, t_max, b_dim, dev).flatten(0, 1))
-                feat = feat.reshape(t_max, b_dim, -1)
-                gone = torch.zeros(t_max, b_dim, device=dev, dtype=torch.bool)
-                if self.rnn_skip:       # never updated: stays at the initial state of the top layer
-                    h = self.h0[m][-1].reshape(1, 1, -1).expand(t_max, b_dim, -1)
-                else:                   # zero-masked inputs: every sequence sees the same features
-                    h = self._rnn(m, feat[:, :1].contiguous(), gone[:, :1]).expand(-1, b_dim, -1)
-                left[m] = (feat, h, gone)
+        # A modality's encoder -> input projection -> inference GRU is a chain of its own, and its T-step recurrence a
+        # latency chain on a few CUs: the modalities' chains run on a stream each (autograd replays every backward on its
+        # forward's stream, so the backward recurrences overlap as well) and join in front of the combiner.
+        cur = torch.cuda.current_stream() if dev.type == 'cuda' else None
+        sides = self._chain_streams(len(self.modalities) - 1, dev) if cur is not None else []
+        for k_m, m in enumerate(self.modalities):
+            st = sides[k_m - 1] if (sides and k_m > 0) else None
+            if st is not None:
+                st.wait_stream(cur)
+                if m in inputs and inputs[m].is_cuda:
+                    inputs[m].record_stream(st)
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                if any(m in ps for ps in passes):
+                    x, seen = self._clean(inputs[m], self._frames_store(self.enc[m], inputs[m]))
+                    if self.dists[m] == 'Categorical':
+                        x = x.long()
+                    feat = self._plug(self.enc[m], x.flatten(0, 1)).reshape(t_max, b_dim, -1)
+                    real[m] = (feat, self._rnn(m, feat, seen), seen)
+                if any(m not in ps for ps in passes):
+                    feat = self._plug(self.enc[m], self._zero_input(m, t_max, b_dim, dev).flatten(0, 1))
+                    feat = feat.reshape(t_max, b_dim, -1)
+                    gone = torch.zeros(t_max, b_dim, device=dev, dtype=torch.bool)
+                    if self.rnn_skip:       # never updated: stays at the initial state of the top layer
+                        h = self.h0[m][-1].reshape(1, 1, -1).expand(t_max, b_dim, -1)
+                    else:                   # zero-masked inputs: every sequence sees the same features
+                        h = self._rnn(m, feat[:, :1].contiguous(), gone[:, :1]).expand(-1, b_dim, -1)
+                    left[m] = (feat, h, gone)
+            if st is not None:              # (read by the combiner's projections on the caller's stream)
+                for grp in (real.get(m), left.get(m)):
+                    for x_ in (grp or ()):
+                        if torch.is_tensor(x_) and x_.is_cuda:
+                            x_.record_stream(cur)
+        for st in sides:
+            cur.wait_stream(st)
         # The time-parallel part of the combiner's first layer, u = in_to_h[0]([., h_out_t, feat_t]) without its z columns
         # (dks.py:246-280), is linear in the column blocks: a pass's u is the sum of one product per block, and a block --
         # a modality's observed (or left-out) RNN states / features -- is the same tensor in every pass that picks it.  So each
@@ -301,7 +333,15 @@ class MultiDKS(MultiDGTS):
         big_mask = mask.reshape(t_max, 1, b_dim).expand(t_max, n_pass, b_dim).reshape(t_max, rows, 1)
         total = ops.LossSum(im.device)              # all terms add into one device accumulator
         ops.kld_gauss(im, is_, pm, ps_, big_mask, *ops.weighted_into(total, kld_mult))
+        # (the decoders + loss terms stay on the caller's stream: on the modalities' streams as well the cfg4 step measured
+        #  21.05-21.12 ms against 20.91-20.94 -- two conv chains side by side share one HBM, as in MultiDMM)
         for m in self.modalities:
+            self._score(m, z, targets, mask, rec_mults, loss_mods, t_max, b_dim, total)
+        return total.total()
+
+    def _score(self, m, z, targets, mask, rec_mults, loss_mods, t_max, b_dim, total):
+        """Decode modality m for every pass that scores it and add its weighted NLL terms to `total` (dgts.py:119-129)."""
+        for _ in (0,):
             mult = rec_mults.get(m, 1.0)
             used = [p for p, mods in enumerate(loss_mods) if m in mods]
             if mult == 0 or not used:
@@ -325,7 +365,6 @@ class MultiDKS(MultiDGTS):
                 out = self._plug(self.dec[m], zp)
                 rec = tuple(r.reshape(t_max, b_dim, *r.shape[1:]) for r in out)
                 self._nll(m, rec, targets[m], mask, weight=float(mult), into=total)
-        return total.total()
 
     def sample(self, t_max, b_dim):
         """dks.py:299-342: ancestral sampling from the transition prior (not a hot path: the

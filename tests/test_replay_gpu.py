@@ -294,6 +294,33 @@ BF16_GRAD_TOL_B32 = {
 }
 
 
+def test_dks_modality_chains_on_streams_change_nothing(dev, monkeypatch):
+    """MultiDKS.step runs every modality's encoder -> input projection -> inference GRU on a stream of its own
+    (models/dks.py `_chain_streams`; MDMM_DKS_STREAMS=0: all on the caller's stream).  Same kernels on the same data
+    either way: loss and every gradient bit for bit, on cfg4's model (conv plug-ins + a holder; dgts.py:85-130,
+    dks.py:157-297)."""
+    from mdmm import models
+    from mdmm.noise import PhiloxNoise
+    cfg = bench.CONFIGS['cfg4']
+    lengths = [cfg.T] * 5 + [31, 17, 4]
+    _, _, _, x, tg, mask = _ragged_batch(cfg, lengths, dev)
+    res = []
+    for streams in ('1', '0'):
+        monkeypatch.setenv('MDMM_DKS_STREAMS', streams)
+        torch.manual_seed(6)
+        m = cfg.model(models, dev)
+        m.noise = PhiloxNoise(seed=5)
+        loss = m.step(x, mask, 0.8, cfg.rec, targets=tg, lengths=lengths)
+        (loss / sum(lengths)).backward()
+        torch.cuda.synchronize()
+        assert (m._chains is not None and len(m._chains) == 2) == (streams == '1')
+        res.append((loss.detach().clone(), _grads(m)))
+    assert torch.equal(res[0][0], res[1][0]), (float(res[0][0]), float(res[1][0]))
+    assert res[0][1].keys() == res[1][1].keys()
+    for k, g in res[0][1].items():
+        assert (g is None) == (res[1][1][k] is None) and (g is None or torch.equal(g, res[1][1][k])), k
+
+
 @pytest.mark.parametrize('name', ['cfg3', 'cfg4'])
 def test_bf16_gradients_vs_oracle_at_32_sequences(name, dev):
     """The timed precision mode (bf16 operands, bf16-stored conv activations) against the fp32 CPU oracle with the
