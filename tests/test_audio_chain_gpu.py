@@ -279,6 +279,30 @@ def test_audio_nodes_at_512_frames(act, dev, monkeypatch):
     assert not bad, bad
 
 
+def test_audio_plan_is_for_the_reference_stacks_only(dev):
+    """mdmm.audio.decoder_plan / encoder_plan: the reference's own stacks (common.py:177-290: three stride-2 k3 layers on
+    10 x 1281 frames, BatchNorm with momentum and running statistics) in training mode get the one-node route; anything
+    else -- evaluation mode, a cumulative-average BatchNorm, another kernel size, another width -- goes layer by layer."""
+    from mdmm import audio, ops
+    C = _models()
+    with ops.conv_operands(torch.bfloat16, act=torch.bfloat16):
+        dec, enc = C.AudioDecoder(32).to(dev), C.AudioEncoder(32).to(dev)
+        assert audio.decoder_plan(dec) is not None and audio.encoder_plan(enc) is not None
+        dec.eval(); enc.eval()
+        assert audio.decoder_plan(dec) is None and audio.encoder_plan(enc) is None
+        odd = C.AudioDecoder(32).to(dev)
+        odd.deconv_stack[0].net[1] = nn.BatchNorm1d(8, momentum=None).to(dev)       # cumulative average
+        assert audio.decoder_plan(odd) is None
+        odd = C.AudioEncoder(32).to(dev)
+        odd.conv_stack[1].net[0] = nn.Conv1d(4, 8, 5, 2, 2).to(dev)                # another kernel size
+        assert audio.encoder_plan(odd) is None
+        odd = C.AudioEncoder(32).to(dev)
+        odd.conv_stack[0].net[1] = nn.BatchNorm1d(4, affine=False).to(dev)
+        assert audio.encoder_plan(odd) is None
+    with ops.conv_operands(None, act=torch.float32):
+        assert audio.decoder_plan(C.AudioDecoder(32).to(dev)) is not None      # fp32 activations: the same nodes
+
+
 def test_audio_nodes_match_the_layer_by_layer_route(dev, monkeypatch):
     """MDMM_AUDIO_FUSED=0 selects the route of models.common (csrc/conv1d.hip + batchnorm.hip + reduce.hip): the same
     MultiDMM.step on a small vidTIMIT-shaped batch either way (fp32 operands: the two routes differ by summation order)."""

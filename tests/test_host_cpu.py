@@ -401,3 +401,65 @@ def test_loss_sum_with_a_device_weight():
     loss.backward(gradient=torch.tensor(0.5))
     assert torch.allclose(a.grad, torch.full((3,), 0.5 * 2.0))
     assert torch.allclose(b.grad, torch.full((3,), 0.5 * 0.25))
+
+
+def test_sweep_routing_by_shape_precision_and_switches(monkeypatch):
+    """Which kernel family a sweep is sent to (ops.wide_shape; csrc/sweep_wide.hip `plan`, wide_sweep.h `quad_shape`):
+    z = h = 256 only; any particle count forward; backward up to 32 rows with fp32 operands, up to 100 particles with
+    bf16 ones -- above 64 only while the forward keeps its park; the two switches that pin the generic kernels."""
+    import torch
+    from mdmm import ops
+    for k in ('MDMM_FORCE_GENERIC', 'MDMM_NO_WIDE', 'MDMM_FWD_PARK'):
+        monkeypatch.delenv(k, raising=False)
+    mk = lambda K, prec, D=256, **kw: ops.SweepCfg(8, 4, D, D, P=2, K=K, precision=prec, **kw)     # noqa: E731
+    bf, f32 = torch.bfloat16, torch.float32
+    assert not ops.wide_shape(mk(25, bf, D=32)) and not ops.wide_shape(mk(25, bf, trans_only=True))
+    assert all(ops.wide_shape(mk(K, p)) for K in (1, 25, 64, 100, 200) for p in (bf, f32))          # forward: any K
+    assert [ops.wide_shape(mk(K, f32), bwd=True) for K in (1, 25, 32, 33)] == [True, True, True, False]
+    assert [ops.wide_shape(mk(K, bf), bwd=True) for K in (1, 25, 64, 65, 70, 100, 101)] == [True] * 6 + [False]
+    monkeypatch.setenv('MDMM_FWD_PARK', '0')            # no park: the one-round backward (and its quad geometry) is off
+    assert [ops.wide_shape(mk(K, bf), bwd=True) for K in (25, 64, 65, 100)] == [True, True, False, False]
+    monkeypatch.delenv('MDMM_FWD_PARK')
+    for sw in ('MDMM_FORCE_GENERIC', 'MDMM_NO_WIDE'):
+        monkeypatch.setenv(sw, '1')
+        assert not ops.wide_shape(mk(25, bf)) and not ops.wide_shape(mk(25, bf), bwd=True)
+        monkeypatch.delenv(sw)
+    with pytest.raises(ValueError):
+        mk(25, torch.float16)
+
+
+def test_audio_plans_and_padded_rows_are_decided_on_the_host():
+    """mdmm.audio: no plan for a stack that is not on the GPU (there is no CPU path), and the 2,816-wide feature rows only
+    with bf16 operands AND bf16 activations at 512 frames or more (a multiple of four).  (Which GPU stacks get a plan:
+    tests/test_audio_chain_gpu.py::test_audio_plan_is_for_the_reference_stacks_only.)"""
+    import torch
+    from mdmm import audio, ops
+    from mdmm.models import common as C
+    dec, enc = C.AudioDecoder(32), C.AudioEncoder(32)
+    with ops.conv_operands(torch.bfloat16, act=torch.bfloat16):
+        assert audio.decoder_plan(dec) is None and audio.encoder_plan(enc) is None
+        assert [audio.padded_rows(n) for n in (508, 512, 514, 516, 65536)] == [False, True, False, True, True]
+    with ops.conv_operands(torch.bfloat16, act=torch.float32):
+        assert not audio.padded_rows(512)
+    with ops.conv_operands(None, act=torch.float32):
+        assert not audio.padded_rows(512)
+    assert audio.FEAT == 16 * 161 and audio.FEAT_PAD % 256 == 0 and audio.FEAT_PAD >= audio.FEAT
+    w, b = audio.pad_linear_out(dec.z_to_feat[0])
+    assert w.shape == (audio.FEAT_PAD, 32) and b.shape == (audio.FEAT_PAD,)
+    assert torch.equal(w[:audio.FEAT], dec.z_to_feat[0].weight) and float(w[audio.FEAT:].abs().max()) == 0.0
+    assert float(b[audio.FEAT:].abs().max()) == 0.0
+    wi = audio.pad_linear_in(enc.feat_to_z_mean)
+    assert wi.shape == (32, audio.FEAT_PAD) and torch.equal(wi[:, :audio.FEAT], enc.feat_to_z_mean.weight)
+    assert float(wi[:, audio.FEAT:].abs().max()) == 0.0
+
+
+def test_batchnorm_group_routing():
+    """ops.bn_groups_for: a batch of n passes is normalised as n groups by ONE launch only when the rows divide, no
+    statistics are synchronised and the running statistics use a momentum (not the cumulative average)."""
+    import torch.nn as nn
+    from mdmm import ops
+    bn, cum = nn.BatchNorm2d(4), nn.BatchNorm2d(4, momentum=None)
+    assert ops.bn_groups_for(12, bn) == 1
+    with ops.bn_groups(3):
+        assert ops.bn_groups_for(12, bn) == 3 and ops.bn_groups_for(13, bn) == 1 and ops.bn_groups_for(12, cum) == 1
+    assert ops.BN_GROUPS == 1
