@@ -529,7 +529,32 @@ def roofline_of(cfg, spans, b_dim, want_k1=False):
         rf['traffic_source'] = source
     if note:
         rf['choice'] = note
+    if want_k1 and wide and cfg.D == 256:
+        rf['design_bound'] = k1_design_bound(cfg, tag, b_dim, nbytes)
     return rf
+
+
+# The ceiling of the K = 1 wide sweeps AS DESIGNED: a workgroup re-streams its direction's weight fragments
+# from L2 once per time step -- 768 KB forward, 1.5 MB backward (bf16) -- through a CU port that delivers 61 B per clock
+# (tools/mb/l2_stream.hip, profiles/r04z_l2_stream.txt: 5.4 us per 768 KB pass, the same with 1 ... 128 workgroups), and
+# a launch is T - 1 dependent steps: no batch size makes a launch shorter than (T - 1) x 5.4 us (10.8 us backward); the
+# weight-gradient contraction and the reduction behind a backward sweep are HBM streams of the spilled operands.
+K1_STREAM_US = {'fwd': 5.4, 'bwd': 10.8}
+
+
+def k1_design_bound(cfg, tag, b_dim, nbytes):
+    which = 'bwd' if 'bwd' in tag else 'fwd'
+    pairs = (1 + cfg.M) * b_dim
+    n_wg = (pairs + 7) // 8 if pairs <= 8 * 256 else ((pairs + 15) // 16 if pairs <= 16 * 256 else (pairs + 31) // 32)
+    rounds = (n_wg + 255) // 256                       # workgroups hold a CU's LDS: one per CU at a time
+    t_stream = rounds * (cfg.T - 1) * K1_STREAM_US[which] * 1e-6
+    frac = nbytes / t_stream / 1e9 / HBM_PEAK_GBS
+    return {'frac': round(frac, 4), 'launch_ms_floor': round(t_stream * 1e3, 4), 'workgroups': n_wg, 'rounds': rounds,
+            'basis': 'T - 1 = %d dependent steps x %.1f us (one pass of the %s weight fragments through a CU\'s 61 B/clk L2 '
+                     'port, DESIGN 4.2e) per round of workgroups; algorithmic bytes of the launch over that time against the '
+                     'HBM peak.  The weight-gradient contraction and reduction that the measured call also contains are not '
+                     'in the floor.  North-star target 0.40: needs >= 2 x these bytes per step at the same step time '
+                     '(32-pair tiles, a batch of >= 8192 pairs).' % (cfg.T - 1, K1_STREAM_US[which], 'backward' if which == 'bwd' else 'forward')}
 
 
 def roofline_bytes(timer, spans):
