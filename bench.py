@@ -902,57 +902,74 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
-            out['cpu_baseline'], out['elbo_delta'] = cpu_baseline(cfg, device)
+            try:
+                out['cpu_baseline'], out['elbo_delta'] = cpu_baseline(cfg, device)
+            except Exception as exc:            # noqa: BLE001 -- the timed line is printed whatever the host leg does
+                out['cpu_baseline'] = {'value': None, 'unit': 'sequences/s', 'cores': 0, 'kind': 'port', 'sample': 'failed',
+                                       'error': '%s: %s' % (type(exc).__name__, str(exc)[:300])}
+                print('bench: cpu_baseline failed: %r' % (exc,), file=sys.stderr, flush=True)
         if world == 1 and cfg is Cfg3 and not args.no_extra:
-            torch.cuda.empty_cache()
-            a2 = argparse.Namespace(**vars(args))
-            a2.steps, a2.warmup, a2.batch = 10, 3, 0
-            r2 = run(Cfg2, a2, 1, 0, device, graph=True)
-            out['extra'] = {'cfg2': {k: r2[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline',
-                                                        'roofline_k1', 'roofline_step')}}
-            torch.cuda.empty_cache()
-            a4 = argparse.Namespace(**vars(args))
-            a4.steps, a4.warmup, a4.batch = 5, 2, 0
-            r4 = run(Cfg4, a4, 1, 0, device, graph=not args.eager)
-            out['extra']['cfg4'] = {k: r4[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline',
-                                                       'calls_ms_per_step')}
-            torch.cuda.empty_cache()
+            out['extra'] = {}
+
+            def ride_along(key, make):
+                """One ride-along measurement.  Whatever goes wrong in it (an out-of-memory in an fp32 sibling, a library
+                search that fails) is recorded under its key: the line of the timed configuration is printed regardless."""
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                try:
+                    out['extra'][key] = make()
+                except Exception as exc:        # noqa: BLE001
+                    torch.cuda.synchronize()
+                    out['extra'][key] = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:400])}
+                    print('bench: extra %r failed: %r' % (key, exc), file=sys.stderr, flush=True)
+                gc.collect()
+                torch.cuda.empty_cache()
+
+            def timed(c, steps, warmup, graph, keys, batch=0):
+                a_ = argparse.Namespace(**vars(args))
+                a_.steps, a_.warmup, a_.batch = steps, warmup, batch
+                r_ = run(c, a_, 1, 0, device, graph=graph)
+                return {k: r_[k] for k in keys if k in r_}
+
+            ride_along('cfg2', lambda: timed(Cfg2, 10, 3, True, ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline',
+                                                                 'roofline_k1', 'roofline_step')))
+            ride_along('cfg4', lambda: timed(Cfg4, 5, 2, not args.eager, ('value', 'unit', 'ms_per_step', 'dtype', 'config',
+                                                                          'roofline', 'calls_ms_per_step')))
             # BASELINE configs[4] at its per-GPU size (512 sequences, T = 128; video + audio plug-ins)
-            a5 = argparse.Namespace(**vars(args))
-            a5.steps, a5.warmup, a5.batch = 5, 2, 0
-            r5 = run(Cfg5, a5, 1, 0, device, graph=not args.eager)
-            out['extra']['cfg5'] = {k: r5[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline', 'roofline_k1',
-                                                       'roofline_conv', 'roofline_audio', 'calls_ms_per_step')}
-            del r5
-            torch.cuda.empty_cache()
+            ride_along('cfg5', lambda: timed(Cfg5, 5, 2, not args.eager, ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline',
+                                                                          'roofline_k1', 'roofline_conv', 'roofline_audio',
+                                                                          'calls_ms_per_step')))
+
             # the same cfg3 step with fp32 operands everywhere (the mode whose parity tests hold 1e-5): library
             # convolutions, own fp32-operand sweeps; eager (the library's convolutions are not captured)
-            af = argparse.Namespace(**vars(args))
-            af.steps, af.warmup, af.batch = 3, 2, 0
-            rf32 = run(Cfg3F32, af, 1, 0, device, graph=False)
-            out['extra']['cfg3_f32'] = {k: rf32[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline')}
-            # ... and with the convolutions on the own fp32-operand path too (no library kernel in the step)
-            rown = run(Cfg3F32Own, af, 1, 0, device, graph=False)
-            out['extra']['cfg3_f32']['own_convolutions'] = {k: rown[k] for k in ('value', 'ms_per_step')}
-            out['extra']['cfg3_f32']['own_convolutions']['loss'] = rown['config'].get('loss')
-            del rown
+            def cfg3_f32():
+                r = timed(Cfg3F32, 3, 3, False, ('value', 'unit', 'ms_per_step', 'dtype', 'config', 'roofline'))
+                # ... and with the convolutions on the own fp32-operand path too (no library kernel in the step)
+                a_ = argparse.Namespace(**vars(args))
+                a_.steps, a_.warmup, a_.batch = 3, 2, 0
+                rown = run(Cfg3F32Own, a_, 1, 0, device, graph=False)
+                r['own_convolutions'] = {'value': rown['value'], 'ms_per_step': rown['ms_per_step'],
+                                         'loss': rown['config'].get('loss')}
+                return r
+            ride_along('cfg3_f32', cfg3_f32)
             # cfg4 / cfg5 with fp32 operands too (their BASELINE strings state no dtype): eager, two timed steps each behind
             # TWO warm-up steps (with one, the library's search for the cfg5 image convolutions' backward kernels was still
-            # running in the timed steps: 3,951 ms per step recorded where the steady state is 632, profiles/r06n_cfg5_f32_spans.txt)
-            a45 = argparse.Namespace(**vars(args))
-            a45.steps, a45.warmup, a45.batch = 2, 2, 0
-            for key, c45 in (('cfg4_f32', Cfg4F32), ('cfg5_f32', Cfg5F32)):
-                torch.cuda.empty_cache()
-                r45 = run(c45, a45, 1, 0, device, graph=False)
-                out['extra'][key] = {k: r45[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'config')}
-                del r45
+            # running in the timed steps: 3,951 ms per step recorded where the steady state is 632, profiles/r06n_cfg5_f32_spans.txt).
+            # cfg5 at HALF its per-GPU batch: fp32 activations of 512 sequences x 128 steps are 211 GB of live tensors in an
+            # eager step, and a third step on the allocator's fragments did not fit the 288 GB (profiles/r06v: out of memory);
+            # sequences/s is what the line reports, the batch is in its config.
+            ride_along('cfg4_f32', lambda: timed(Cfg4F32, 2, 2, False, ('value', 'unit', 'ms_per_step', 'dtype', 'config')))
+            ride_along('cfg5_f32', lambda: timed(Cfg5F32, 2, 2, False, ('value', 'unit', 'ms_per_step', 'dtype', 'config'),
+                                                 batch=Cfg5.B // 2))
+
             # the callers either side of the step (SURVEY 8 f2 / f3): on-device batch preparation and the evaluation body
-            del rf32, r4, r2
-            torch.cuda.empty_cache()
-            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
-            import bench_callers
-            out['extra']['batch_prep'] = bench_callers.measure_batch_prep(device)
-            out['extra']['eval'] = bench_callers.measure_eval(device)
+            def callers(which):
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+                import bench_callers
+                return getattr(bench_callers, which)(device)
+            ride_along('batch_prep', lambda: callers('measure_batch_prep'))
+            ride_along('eval', lambda: callers('measure_eval'))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
