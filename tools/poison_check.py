@@ -1,7 +1,7 @@
 """GPU box: run one eager ELBO step with every torch.empty() on the GPU pre-filled with NaN (float types): any
 output or workspace element a kernel reads without having written it shows up as a non-finite loss / gradient.
 (Graph replay recycles allocator blocks; eager steps on a fresh process mostly see zeros and hide such reads.)
-usage: python tools/poison_check.py cfg3|cfg4|cfg5|cfg2 [lengths comma-separated]"""
+usage: [PARTICLES=100] python tools/poison_check.py cfg3|cfg4|cfg5|cfg2 [lengths comma-separated]"""
 import os, sys
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'multimodal-dmm_amd')); sys.path.insert(0, os.path.join(R, 'tests'))
@@ -44,7 +44,7 @@ def poisoned_like(t0, **k):
         t.fill_(float('nan'))
     return t
 torch.empty, torch.empty_like = poisoned, poisoned_like
-kw = dict(targets=tg, train_particles=bench.TRAIN_PARTICLES)
+kw = dict(targets=tg, train_particles=int(os.environ.get('PARTICLES', bench.TRAIN_PARTICLES)))        # PARTICLES=100: the quad geometry
 loss = model.step(x, mask, 1.0, cfg.rec, lengths=lengths, **kw)
 (loss / sum(lengths)).backward()
 torch.cuda.synchronize()
