@@ -124,14 +124,18 @@ __device__ __forceinline__ float lazy_apply(const LazyTab* t, int q, float g, fl
   const float gm = (relu && fmaf(y, a.x, a.y) <= 0.f) ? 0.f : g;
   return a.x * (gm - m.x - xh * m.y);
 }
-// the layer's weights into LDS: wu[cs][WU] = W[cs][.][.] as it is, wd[cb][cs][k] = W[cs][cb][k]
+// the layer's weights into LDS in the order the two products' PACKED multiply-adds take them (v_pk_fma_f32: two
+// neighbouring output channels per instruction, their weights one aligned 8-byte operand):
+//   wu[cs][cb / 2][slot][cb % 2], slot 0 = tap 1 (even outputs), 1 = tap 0, 2 = tap 2 (odd outputs)      (up_core)
+//   wd[cb][cs / 2][tap][cs % 2]                                                                        (down_core)
 template <typename SH>
 __device__ __forceinline__ void fill_weights(const float* __restrict__ w, float* wu, float* wd) {
+  static_assert(SH::CB % 2 == 0 && SH::CS % 2 == 0, "channel pairs");
   for (int i = threadIdx.x; i < SH::NW; i += NT) {
     const int cs = i / (SH::CB * 3), rest = i - cs * SH::CB * 3, cb = rest / 3, k = rest - cb * 3;
     const float v = w[i];
-    if (wu) wu[cs * SH::WU + rest] = v;
-    if (wd) wd[cb * SH::WD + cs * 3 + k] = v;
+    if (wu) wu[cs * SH::WU + (cb >> 1) * 6 + (k == 1 ? 0 : (k == 0 ? 2 : 4)) + (cb & 1)] = v;
+    if (wd) wd[cb * SH::WD + (cs >> 1) * 6 + 2 * k + (cs & 1)] = v;
   }
 }
 __device__ __forceinline__ int big_slot(int p, int SP) { return (p & 1) ? (p >> 1) + 1 : SP + (p >> 1); }
@@ -277,33 +281,104 @@ template <int NEL, typename T> __device__ __forceinline__ void zero_frame(T* __r
 
 // ---- the three products ----------------------------------------------------------------------------------------------
 // ev[cb] += big[cb][2l], od[cb] += big[cb][2l + 1] from small rows sm (zero at [S]); wu: LDS, [cs][WU]
-template <typename SH>
-__device__ __forceinline__ void up_core(const float* sm, const float* wu, int l, float (&ev)[SH::CB], float (&od)[SH::CB]) {
-  // (a real loop over the input channels, two per trip: unrolled whole, the scheduler hoists every weight read of the
-  //  product to its top and spills the registers they land in)
-#pragma unroll 2
-  for (int cs = 0; cs < SH::CS; ++cs) {
-    const float x0 = sm[cs * SH::SP + l], x1 = sm[cs * SH::SP + l + 1];
+typedef float v2f __attribute__((ext_vector_type(2)));
+// acc2[j] (+)= the packed products of output-channel pairs [J0, J0 + NJ) with one input channel's weights: the pairs'
+// 6 NJ floats are read as 16-byte pieces off ONE address, all issued before the first product (left to the scheduler the
+// reads were interleaved with the products, each behind an address move and a full wait: the loops ran at LDS latency --
+// the recomputed logits alone were a third of the loss backward's time, tools/time_audio.py ablations).  At most four
+// pairs (24 registers of weights) at a time.
+constexpr int PAIR_CHUNK = 4;
+template <int NP, class F>
+__device__ __forceinline__ void pair_chunks(const float* wrow, F f) {
 #pragma unroll
-    for (int cb = 0; cb < SH::CB; ++cb) {
-      const float* wq = wu + cs * SH::WU + cb * 3;
-      ev[cb] = fmaf(x0, wq[1], ev[cb]);
-      od[cb] = fmaf(x1, wq[0], fmaf(x0, wq[2], od[cb]));
-    }
+  for (int j0 = 0; j0 < NP; j0 += PAIR_CHUNK) {
+    constexpr int dummy = 0; (void)dummy;
+    const int nj = NP - j0 < PAIR_CHUNK ? NP - j0 : PAIR_CHUNK;
+    float4 q[(6 * PAIR_CHUNK) / 4];
+    const float4* w4 = reinterpret_cast<const float4*>(wrow + 6 * j0);       // (6 j0 floats: 16-byte aligned for even j0)
+#pragma unroll
+    for (int k = 0; k < (6 * PAIR_CHUNK) / 4; ++k)
+      if (4 * k < 6 * nj) q[k] = w4[k];
+    __builtin_amdgcn_sched_barrier(0);
+    const v2f* wp = reinterpret_cast<const v2f*>(q);
+#pragma unroll
+    for (int j = 0; j < PAIR_CHUNK; ++j)
+      if (j < nj) f(j0 + j, wp[3 * j], wp[3 * j + 1], wp[3 * j + 2]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
-// out[cs] += small[cs][l] from the O / E rows; wd: LDS, [cb][cs][3]
+// ev[cb] += big[cb][2l], od[cb] += big[cb][2l + 1] from small rows sm (zero at [S]); wu: LDS, fill_weights' order
+template <typename SH>
+__device__ __forceinline__ void up_core(const float* sm, const float* wu, int l, float (&ev)[SH::CB], float (&od)[SH::CB]) {
+  constexpr int NP = SH::CB / 2;
+  static_assert(PAIR_CHUNK % 2 == 0, "chunks start on 16-byte boundaries");
+  v2f e2[NP], o2[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) { e2[j] = v2f{ev[2 * j], ev[2 * j + 1]}; o2[j] = v2f{od[2 * j], od[2 * j + 1]}; }
+#pragma unroll 1
+  for (int cs = 0; cs < SH::CS; ++cs) {
+    const float x0 = sm[cs * SH::SP + l], x1 = sm[cs * SH::SP + l + 1];
+    const v2f a0 = v2f{x0, x0}, a1 = v2f{x1, x1};
+    pair_chunks<NP>(wu + cs * SH::WU, [&](int j, v2f w1, v2f w0, v2f w2) {
+      e2[j] = __builtin_elementwise_fma(a0, w1, e2[j]);
+      o2[j] = __builtin_elementwise_fma(a1, w0, __builtin_elementwise_fma(a0, w2, o2[j]));
+    });
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) { ev[2 * j] = e2[j].x; ev[2 * j + 1] = e2[j].y; od[2 * j] = o2[j].x; od[2 * j + 1] = o2[j].y; }
+}
+// out[cs] += small[cs][l] from the O / E rows; wd: LDS, fill_weights' order
 template <typename SH>
 __device__ __forceinline__ void down_core(const float* bg, const float* wd, int l, float (&out)[SH::CS]) {
-#pragma unroll 2
+  constexpr int NP = SH::CS / 2;
+  v2f r2[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) r2[j] = v2f{out[2 * j], out[2 * j + 1]};
+#pragma unroll 1
   for (int cb = 0; cb < SH::CB; ++cb) {
     const float v0 = bg[cb * SH::RB + l], v2 = bg[cb * SH::RB + l + 1], v1 = bg[cb * SH::RB + SH::SP + l];
-#pragma unroll
-    for (int cs = 0; cs < SH::CS; ++cs) {
-      const float* wq = wd + cb * SH::WD + cs * 3;
-      out[cs] = fmaf(v0, wq[0], fmaf(v1, wq[1], fmaf(v2, wq[2], out[cs])));
-    }
+    const v2f a0 = v2f{v0, v0}, a1 = v2f{v1, v1}, a2 = v2f{v2, v2};
+    pair_chunks<NP>(wd + cb * SH::WD, [&](int j, v2f w0, v2f w1, v2f w2) {
+      r2[j] = __builtin_elementwise_fma(a0, w0, __builtin_elementwise_fma(a1, w1, __builtin_elementwise_fma(a2, w2, r2[j])));
+    });
   }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) { out[2 * j] = r2[j].x; out[2 * j + 1] = r2[j].y; }
+}
+// the same for ALL of a thread's positions (l = it NT + thread) with one pass over the weights: a channel's weights are read
+// once for ITER positions instead of once per position (the down product was LDS-instruction-bound: five reads per six
+// packed products).  Positions past the row read inside LDS and are never stored.
+template <typename SH>
+__device__ __forceinline__ void down_core_all(const float* bg, const float* wd, float (&out)[SH::ITER][SH::CS]) {
+  constexpr int NP = SH::CS / 2, NI = SH::ITER;
+  v2f r2[NI][NP];
+  int lc[NI];
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int l = it * NT + threadIdx.x;
+    lc[it] = l < SH::S ? l : SH::S - 1;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) r2[it][j] = v2f{out[it][2 * j], out[it][2 * j + 1]};
+  }
+#pragma unroll 1
+  for (int cb = 0; cb < SH::CB; ++cb) {
+    v2f a0[NI], a1[NI], a2[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const float v0 = bg[cb * SH::RB + lc[it]], v2 = bg[cb * SH::RB + lc[it] + 1], v1 = bg[cb * SH::RB + SH::SP + lc[it]];
+      a0[it] = v2f{v0, v0}; a1[it] = v2f{v1, v1}; a2[it] = v2f{v2, v2};
+    }
+    pair_chunks<NP>(wd + cb * SH::WD, [&](int j, v2f w0, v2f w1, v2f w2) {
+#pragma unroll
+      for (int it = 0; it < NI; ++it)
+        r2[it][j] = __builtin_elementwise_fma(a0[it], w0, __builtin_elementwise_fma(a1[it], w1,
+                                              __builtin_elementwise_fma(a2[it], w2, r2[it][j])));
+    });
+  }
+#pragma unroll
+  for (int it = 0; it < NI; ++it)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { out[it][2 * j] = r2[it][j].x; out[it][2 * j + 1] = r2[it][j].y; }
 }
 // weight-gradient tile of this thread over the frame in LDS, two positions per step (the odd S's last pair ends in the
 // small rows' zero); accb (BIAS_S): sums of the small side's rows of the tile
@@ -453,6 +528,23 @@ template <bool FAST> __device__ __forceinline__ float bce_grad(float l, float x,
   const float th = 1.0f / (1.0f + expf(-l));
   float g = scale * (th - x) / fmaxf((1.0f - th) * th, 1e-12f);
   return g * ((1.0f - th) * th);
+}
+// ... of an observation that may be NaN (= not observed: no term).  FAST: the transcendental part does not touch the
+// observation, so it is computed unconditionally and the NaN test is a select on its result -- written as `x == x ? term : 0`
+// around the whole term the test became a branch around every one of a frame's 12,810 logits.
+template <bool FAST> __device__ __forceinline__ float bce_loss_seen(float l, float x) {
+  if (FAST) {
+    const float sp = fmaxf(l, 0.f) + mdmm::fast::log(1.0f + mdmm::fast::exp(-fabsf(l)));
+    return (x == x) ? sp - x * l : 0.f;
+  }
+  return (x == x) ? bce_loss<false>(l, x) : 0.f;
+}
+template <bool FAST> __device__ __forceinline__ float bce_grad_seen(float l, float x, float scale) {
+  if (FAST) {
+    const float sg = mdmm::fast::sigmoid(l);
+    return (x == x) ? scale * (sg - x) : 0.f;
+  }
+  return (x == x) ? bce_grad<false>(l, x, scale) : 0.f;
 }
 // the observations of outputs 2l and 2l + 1 of every channel for the thread's positions, kept in registers over the passes
 // that score the same row (the last position has no odd output: NaN = not scored; a position past the row: both NaN)
@@ -619,8 +711,7 @@ __global__ __launch_bounds__(NT, 3) void audio_loss_fwd_kernel(const mdmm_audio_
 #pragma unroll
         for (int cb = 0; cb < SH::CB; ++cb) {
           const float xe = x0[it][cb], xo = x1[it][cb];
-          if (xe == xe) t += bce_loss<FAST>(ev[cb], xe);
-          if (xo == xo) t += bce_loss<FAST>(od[cb], xo);
+          t += bce_loss_seen<FAST>(ev[cb], xe) + bce_loss_seen<FAST>(od[cb], xo);
         }
       }
     }
@@ -736,16 +827,18 @@ __global__ __launch_bounds__(NT, 3) void audio_up_bwd_kernel(const mdmm_audio_t 
       __syncthreads();
       wgrad_tile<SH, false>(as, big, acc, accb);
       if (gin) {
+        float gs[SH::ITER][SH::CS];
+#pragma unroll
+        for (int it = 0; it < SH::ITER; ++it)
+#pragma unroll
+          for (int cs = 0; cs < SH::CS; ++cs) gs[it][cs] = 0.f;
+        down_core_all<SH>(big, wd, gs);
 #pragma unroll
         for (int it = 0; it < SH::ITER; ++it) {
           const int l = it * NT + threadIdx.x;
           if (l < SH::S) {
-            float gs[SH::CS];
-#pragma unroll
-            for (int cs = 0; cs < SH::CS; ++cs) gs[cs] = 0.f;
-            down_core<SH>(big, wd, l, gs);
-            if (norm) small_grad_epilogue<SH, T, true>(gs, as, raw, tab, gi, l, relu_in, a.in_relu_plain, gb, s1, s2);
-            else small_grad_epilogue<SH, T, false>(gs, as, raw, tab, gi, l, relu_in, a.in_relu_plain, gb, s1, s2);
+            if (norm) small_grad_epilogue<SH, T, true>(gs[it], as, raw, tab, gi, l, relu_in, a.in_relu_plain, gb, s1, s2);
+            else small_grad_epilogue<SH, T, false>(gs[it], as, raw, tab, gi, l, relu_in, a.in_relu_plain, gb, s1, s2);
           }
         }
       }
@@ -832,8 +925,7 @@ __global__ __launch_bounds__(NT, 2) void audio_loss_bwd_kernel(const mdmm_audio_
 #pragma unroll
         for (int cb = 0; cb < SH::CB; ++cb) {
           const float xe = x0[it][cb], xo = x1[it][cb];
-          const float de = (xe == xe) ? bce_grad<FAST>(ev[cb], xe, sc) : 0.f;
-          const float dd = (xo == xo) ? bce_grad<FAST>(od[cb], xo, sc) : 0.f;
+          const float de = bce_grad_seen<FAST>(ev[cb], xe, sc), dd = bce_grad_seen<FAST>(od[cb], xo, sc);
           db[cb] += de + dd;
           big[cb * SH::RB + SH::SP + l] = de;
           if (!last) big[cb * SH::RB + l + 1] = dd;
@@ -845,16 +937,20 @@ __global__ __launch_bounds__(NT, 2) void audio_loss_bwd_kernel(const mdmm_audio_
     float s1[SH::CS], s2[SH::CS];
 #pragma unroll
     for (int cs = 0; cs < SH::CS; ++cs) { s1[cs] = 0.f; s2[cs] = 0.f; }
+    {
+      float gs[SH::ITER][SH::CS];
 #pragma unroll
-    for (int it = 0; it < SH::ITER; ++it) {
-      const int l = it * NT + threadIdx.x;
-      if (l < SH::S) {
-        float gs[SH::CS];
+      for (int it = 0; it < SH::ITER; ++it)
 #pragma unroll
-        for (int cs = 0; cs < SH::CS; ++cs) gs[cs] = 0.f;
-        down_core<SH>(big, wd, l, gs);
-        if (norm) small_grad_epilogue<SH, T, true>(gs, as, raw, tab, p, l, relu_in, a.in_relu_plain, gb, s1, s2);
-        else small_grad_epilogue<SH, T, false>(gs, as, raw, tab, p, l, relu_in, a.in_relu_plain, gb, s1, s2);
+        for (int cs = 0; cs < SH::CS; ++cs) gs[it][cs] = 0.f;
+      down_core_all<SH>(big, wd, gs);
+#pragma unroll
+      for (int it = 0; it < SH::ITER; ++it) {
+        const int l = it * NT + threadIdx.x;
+        if (l < SH::S) {
+          if (norm) small_grad_epilogue<SH, T, true>(gs[it], as, raw, tab, p, l, relu_in, a.in_relu_plain, gb, s1, s2);
+          else small_grad_epilogue<SH, T, false>(gs[it], as, raw, tab, p, l, relu_in, a.in_relu_plain, gb, s1, s2);
+        }
       }
     }
     if (norm && a.in_adj) {           // this frame's adjoint sums into the wave's own slots of its group (one writer each)
@@ -944,17 +1040,19 @@ __global__ __launch_bounds__(NT, 3) void audio_down_fwd_kernel(const mdmm_audio_
         if (nn < end) fa.load(in + (size_t)nn * IN_EL);
         __syncthreads();
       }
+      float o[SH::ITER][SH::CS];
+#pragma unroll
+      for (int it = 0; it < SH::ITER; ++it)
+#pragma unroll
+        for (int cs = 0; cs < SH::CS; ++cs) o[it][cs] = bias[cs];
+      down_core_all<SH>(big, wd, o);
 #pragma unroll
       for (int it = 0; it < SH::ITER; ++it) {
         const int l = it * NT + threadIdx.x;
         if (l < SH::S) {
-          float o[SH::CS];
-#pragma unroll
-          for (int cs = 0; cs < SH::CS; ++cs) o[cs] = bias[cs];
-          down_core<SH>(big, wd, l, o);
 #pragma unroll
           for (int cs = 0; cs < SH::CS; ++cs) {
-            const float v = rnd<T>(o[cs]);
+            const float v = rnd<T>(o[it][cs]);
             s1[cs] += v;
             s2[cs] = fmaf(v, v, s2[cs]);
             ob[cs * SH::S + l] = (T)v;

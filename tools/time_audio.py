@@ -70,3 +70,12 @@ print('decoder nll forward %.3f ms (%.2f TB/s of %.2f GB), forward + backward %.
 t_f, t_fb = timed(lambda: enc_fwd(False)), timed(lambda: enc_fwd(True))
 enc_bytes_f = rows * (12810 * 4 + (2564 + 2568 + 2576) * 2 * 2)
 print('encoder forward %.3f ms (%.2f TB/s of %.2f GB), forward + backward %.3f ms' % (t_f, enc_bytes_f / t_f / 1e9, enc_bytes_f / 1e9, t_fb))
+if os.environ.get('SPANS') == '1':       # per library call, HIP events (kernels alone on the chip)
+    ops.TIMER = timer = ops.KernelTimer()
+    for _ in range(3):
+        dec_fwd(True); enc_fwd(True)
+    torch.cuda.synchronize()
+    ops.TIMER = None
+    for k, (n, ms) in sorted(timer.summary().items(), key=lambda kv: -kv[1][1]):
+        if k.startswith('audio'):
+            print('%-28s %3d calls %8.3f ms each' % (k, n, ms / n))

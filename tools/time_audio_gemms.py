@@ -61,3 +61,32 @@ with ops.conv_operands(torch.bfloat16, act=torch.bfloat16):
 torch.cuda.synchronize()
 for k, (n, ms) in sorted(timer.summary().items(), key=lambda kv: -kv[1][1]):
     print('%-36s %3d calls %8.3f ms' % (k, n, ms))
+
+# ---- the same layers as they run since the feature rows are padded to audio.FEAT_PAD = 2816 (head GEMM kernels)
+from mdmm import audio
+print('padded rows (2816): the head kernels')
+ops.TIMER = None
+with ops.conv_operands(torch.bfloat16, act=torch.bfloat16):
+    def fbp():
+        w, b = audio.pad_linear_out(lin)
+        yy = ops._LinearTilesFn.apply(z, w, b, torch.bfloat16, True)
+        yy.backward(gyp)
+        z.grad = None; lin.weight.grad = None; lin.bias.grad = None
+    gyp = torch.randn(M, audio.FEAT_PAD, device=dev).to(torch.bfloat16)
+    report('z_to_feat forward + backward (padded)', timed(fbp), M * (256 * 4 + 2816 * 2) * 2 + M * 2816 * 2 * 2 + M * 256 * 4)
+    fpad = torch.randn(M2, audio.FEAT_PAD, device=dev).to(torch.bfloat16).requires_grad_(True)
+
+    def fb2p():
+        a = ops.linear_tiles(fpad, audio.pad_linear_in(h1), h1.bias)
+        b = ops.linear_tiles(fpad, audio.pad_linear_in(h2), h2.bias)
+        torch.autograd.backward([a, b], [g1, g2])
+        fpad.grad = None
+        for p in list(h1.parameters()) + list(h2.parameters()):
+            p.grad = None
+    report('two heads forward + backward (padded)', timed(fb2p), M2 * 2816 * 2 * 3 + 4 * M2 * 256 * 4)
+ops.TIMER = timer = ops.KernelTimer()
+with ops.conv_operands(torch.bfloat16, act=torch.bfloat16):
+    fbp(); fb2p()
+torch.cuda.synchronize()
+for k, (n, ms) in sorted(timer.summary().items(), key=lambda kv: -kv[1][1]):
+    print('%-36s %3d calls %8.3f ms' % (k, n, ms))
