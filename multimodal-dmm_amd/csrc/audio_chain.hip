@@ -351,6 +351,10 @@ __device__ __forceinline__ void down_core(const float* bg, const float* wd, int 
 template <typename SH>
 __device__ __forceinline__ void down_core_all(const float* bg, const float* wd, float (&out)[SH::ITER][SH::CS]) {
   constexpr int NP = SH::CS / 2, NI = SH::ITER;
+  if constexpr (NI == 1) {          // (one position: nothing to share)
+    down_core<SH>(bg, wd, (int)threadIdx.x < SH::S ? (int)threadIdx.x : SH::S - 1, out[0]);
+    return;
+  }
   v2f r2[NI][NP];
   int lc[NI];
 #pragma unroll
