@@ -14,6 +14,29 @@ from . import common
 from .dgts import MultiDGTS
 
 
+class _no_lazy_wgrad:
+    """While the modalities' chains of MultiDKS.step run on streams of their own, the first encoder layer's weight gradient
+    goes the plain way (the BatchNorm adjoint applied by a pass of its own, then mdmm_conv_wgrad on a finished gradient).
+    With the lazily formed gradient (ops._ConvTilesFn.lazy_wgrad) that ONE tensor -- enc.*.conv_stack.0.conv.weight's
+    gradient -- came out different from run to run at 1e-5 relative (tools/determinism_cfg4.py: 134 of 144 elements, a dozen
+    of the kernel's 256 workgroup slabs; every input of the launch bit-identical across the runs, the kernel bit-reproducible
+    when launched again on the same inputs, everything else in the step bit-identical; a device or stream wait on either
+    side of the launch removes it, as do MDMM_BN_LAZY_DX=0, MDMM_DKS_STREAMS=0 and AMD_SERIALIZE_KERNEL=3).  The cause was
+    not found in this round; MultiDMM's encoder streams, which take the lazy route, have never shown it
+    (replay == eager to the bit at every size tested)."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = ops.LAZY_WGRAD
+        if self.on:
+            ops.LAZY_WGRAD = False
+
+    def __exit__(self, *exc):
+        ops.LAZY_WGRAD = self.prev
+
+
 class MultiDKS(MultiDGTS):
     def __init__(self, modalities, dims, dists=None, encoders=None, decoders=None,
                  h_dim=32, z_dim=32, z0_mean=0.0, z0_std=1.0, min_std=1e-3, feat_to_z=True,
@@ -230,7 +253,7 @@ class MultiDKS(MultiDGTS):
                 st.wait_stream(cur)
                 if m in inputs and inputs[m].is_cuda:
                     inputs[m].record_stream(st)
-            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()), _no_lazy_wgrad(bool(sides)):
                 if any(m in ps for ps in passes):
                     x, seen = self._clean(inputs[m], self._frames_store(self.enc[m], inputs[m]))
                     if self.dists[m] == 'Categorical':

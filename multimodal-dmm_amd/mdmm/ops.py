@@ -2652,7 +2652,7 @@ class _ConvTilesFn(torch.autograd.Function):
                                  and y.dtype == torch.bfloat16)
         # ... and the first encoder layer (Conv 3 -> 16 on frames that need no gradient): its weight-gradient kernel
         # forms the gradient of its output while it stages it; that gradient is never written
-        ctx.lazy_wgrad = bool(not transposed and ks == 3 and cs == 16 and s == 32 and not x_needs_grad
+        ctx.lazy_wgrad = bool(LAZY_WGRAD and not transposed and ks == 3 and cs == 16 and s == 32 and not x_needs_grad
                               and y.dtype == torch.bfloat16)
         ctx.lazy_consumer = ctx.lazy_consumer or ctx.lazy_wgrad
         ctx.save_for_backward(x, weight)
@@ -2896,6 +2896,9 @@ class DeferredNorm:
 
 
 BN_DEFER = False
+# The first encoder layer's weight-gradient kernel may form its output gradient from a reduced BatchNorm adjoint while it
+# stages it (_ConvTilesFn.lazy_wgrad).  models/dks.py switches this off for its modality chains: see there.
+LAZY_WGRAD = True
 
 
 class bn_defer:

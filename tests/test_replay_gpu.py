@@ -294,6 +294,45 @@ BF16_GRAD_TOL_B32 = {
 }
 
 
+def test_cfg4_step_is_the_same_function_every_time(dev):
+    """The eager cfg4 step at the size bench.py times (MultiDKS with its modality chains on streams of their own), three
+    times on the same weights, batch and Philox stream, with another allocator state each time: every gradient within 1e-6
+    of the first run's (what is not bit-equal are the GRU initial states' gradients, ~1e-7: their sums use atomics).  With
+    the first encoder layer's LAZILY formed output gradient on those streams this was 1e-5 on that layer's weight gradient
+    (models/dks.py _no_lazy_wgrad, tools/determinism_cfg4.py)."""
+    from mdmm import models
+    from mdmm.noise import PhiloxNoise
+    cfg = bench.CONFIGS['cfg4']
+    lengths = sorted([40] * 200 + [int(n) for n in np.random.RandomState(3).randint(5, 40, 56)], reverse=True)
+    _, _, _, x, tg, mask = _ragged_batch(cfg, lengths, dev)
+    torch.manual_seed(0)
+    m = cfg.model(models, dev)
+    runs = []
+    for r in range(3):
+        m.noise = PhiloxNoise(seed=4321)
+        for p in m.parameters():
+            p.grad = None
+        junk = [torch.randn(1 << 22, device=dev) for _ in range(r)]
+        loss = m.step(x, mask, 1.0, cfg.rec, targets=tg, lengths=lengths)
+        (loss / sum(lengths)).backward()
+        torch.cuda.synchronize()
+        del junk
+        runs.append((loss.detach().clone(), _grads(m)))
+    worst = {}
+    for r in (1, 2):
+        assert torch.equal(runs[r][0], runs[0][0])
+        for k, g in runs[0][1].items():
+            if g is None:
+                continue
+            e = float((runs[r][1][k] - g).norm() / (g.norm() + 1e-30))
+            worst[k] = max(worst.get(k, 0.0), e)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    helpers.note('cfg4_rerun.worst', {k: v for k, v in top})
+    assert all(e < 1e-6 for e in worst.values()), top
+    assert all(e == 0.0 for k, e in worst.items() if not k.startswith('h0.')), [kv for kv in top if not kv[0].startswith('h0.')]
+    torch.cuda.empty_cache()
+
+
 def test_dks_modality_chains_on_streams_change_nothing(dev, monkeypatch):
     """MultiDKS.step runs every modality's encoder -> input projection -> inference GRU on a stream of its own
     (models/dks.py `_chain_streams`; MDMM_DKS_STREAMS=0: all on the caller's stream).  Same kernels on the same data
